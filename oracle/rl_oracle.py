@@ -1,0 +1,331 @@
+"""CPU ORACLE (test infrastructure, NOT product code) for the Richardson-Lucy path.
+
+numpy/scipy restatement of the reference's LsDeconvolveMultiGPU hot path.  Only
+``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
+import this module; the shipped path (``ipp_amd``) never does.
+
+PARITY UNPINNED for this half of the oracle: the reference's arithmetic lives in
+closed MATLAB builtins (convn / fftn / imfilter / imgaussfilt3) and in CUDA MEX
+files that cannot be built here (no MATLAB, no nvcc), and the
+reference holds no stored golden vectors.  The restatement therefore follows the
+reference *text* line by line (citations below, relative to /root/reference) and is
+pinned only by the known-answer / property checks taken from the reference's own
+test scripts (tests/test_oracle_rl.py).
+
+Array convention: numpy C-order ``(Z, Y, X)`` == MATLAB ``[X, Y, Z]`` column-major
+(conv3d_gpu.cu:93,98; gauss3d_gpu.cu:123).  All PSF extents are odd
+(LsMakePSF.m:32-38), so the centre is ``(k-1)/2 == k//2``.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+from scipy import ndimage, signal
+
+EPS_SINGLE = np.float32(2.0 ** -23)  # eps('single'), decon.m:62,154
+
+
+# --------------------------------------------------------------------------- convolutions
+def convn_same(a: np.ndarray, h: np.ndarray) -> np.ndarray:
+    """MATLAB ``convn(a, h, 'same')``: true convolution, zero outside, central part
+    (decon.m:61,64,70).  Computed in float64 and rounded once to float32."""
+    out = ndimage.convolve(a.astype(np.float64), h.astype(np.float64), mode="constant", cval=0.0)
+    return out.astype(np.float32)
+
+
+def conv3d_replicate(a: np.ndarray, h: np.ndarray) -> np.ndarray:
+    """``conv3d_gpu(a, h)``: same-size true convolution with the input index clamped
+    to the array (conv3d_gpu.cu:77-98: centre k/2, clamp, flipped kernel index)."""
+    out = ndimage.convolve(a.astype(np.float64), h.astype(np.float64), mode="nearest")
+    return out.astype(np.float32)
+
+
+def conv3d_replicate_loops(a: np.ndarray, h: np.ndarray) -> np.ndarray:
+    """Literal loop restatement of conv3d_gpu.cu:77-98 (small cases only); used by the
+    tests to pin :func:`conv3d_replicate` independently of scipy's boundary code."""
+    nz, ny, nx = a.shape
+    kz, ky, kx = h.shape
+    out = np.zeros(a.shape, np.float64)
+    for dz in range(kz):
+        iz = np.clip(np.arange(nz) + dz - kz // 2, 0, nz - 1)
+        for dy in range(ky):
+            iy = np.clip(np.arange(ny) + dy - ky // 2, 0, ny - 1)
+            for dx in range(kx):
+                ix = np.clip(np.arange(nx) + dx - kx // 2, 0, nx - 1)
+                w = float(h[kz - 1 - dz, ky - 1 - dy, kx - 1 - dx])
+                out += w * a[np.ix_(iz, iy, ix)].astype(np.float64)
+    return out.astype(np.float32)
+
+
+def flip3(psf: np.ndarray) -> np.ndarray:
+    """``psf.inv = psf(end:-1:1,end:-1:1,end:-1:1)`` (LsDeconv.m:163)."""
+    return np.ascontiguousarray(psf[::-1, ::-1, ::-1])
+
+
+# --------------------------------------------------------------------------- Gaussian
+def gaussian_taps(sigma: float, ksize: int) -> np.ndarray:
+    """``make_gaussian_kernel`` (gauss3d_gpu.cu:81-90): sigma is a float, sigma*sigma is
+    rounded in float, exp in double, stored as float, normalised by a double sum."""
+    s = np.float32(sigma)
+    s2 = float(np.float32(s * s))
+    r = ksize // 2
+    k = np.empty(ksize, np.float32)
+    for i in range(-r, r + 1):
+        k[i + r] = np.float32(math.exp(-0.5 * (i * i) / s2))
+    total = float(np.sum(k.astype(np.float64)))
+    return (k.astype(np.float64) / total).astype(np.float32)
+
+
+def default_ksize(sigma) -> list[int]:
+    """``ksize = 2*ceil(3*sigma)+1`` (gauss3d_gpu.cu:244-261)."""
+    return [2 * int(math.ceil(3.0 * float(s))) + 1 for s in sigma]
+
+
+def gauss3d(vol: np.ndarray, sigma, ksize=None) -> np.ndarray:
+    """``gauss3d_gpu(x, sigma[, ksize])``: three 1-D passes X, Y, Z with replicate
+    boundary (gauss3d_gpu.cu:93-138,163-192).  ``sigma``/``ksize`` are in reference
+    order ``[x, y, z]``.  Each pass accumulates in float32 like the kernel does
+    (we accumulate in float64 and round per pass: difference << 5e-5 test bound)."""
+    sigma = [float(sigma)] * 3 if np.isscalar(sigma) else [float(s) for s in sigma]
+    if ksize is None:
+        ksize = default_ksize(sigma)
+    elif np.isscalar(ksize):
+        ksize = [int(ksize)] * 3
+    out = vol.astype(np.float32)
+    for ref_axis in range(3):  # 0 = x, 1 = y, 2 = z
+        np_axis = 2 - ref_axis
+        taps = gaussian_taps(sigma[ref_axis], int(ksize[ref_axis]))
+        # symmetric taps: correlation == convolution
+        out = ndimage.correlate1d(out.astype(np.float64), taps.astype(np.float64), axis=np_axis,
+                                  mode="nearest").astype(np.float32)
+    return out
+
+
+# --------------------------------------------------------------------------- edge taper
+def matlab_round(x: float) -> int:
+    """MATLAB ``round``: half away from zero."""
+    return int(math.floor(abs(x) + 0.5)) * (1 if x >= 0 else -1)
+
+
+def make_taper(dimsz: int, taper_width: int) -> np.ndarray:
+    """make_taper.m:13-35 (ramp of w+1 samples, plateau, mirrored ramp without its
+    last sample, then cut/padded to ``dimsz``)."""
+    w = min(int(taper_width), dimsz // 2)
+    if w <= 0:
+        return np.ones(dimsz, np.float32)
+    ramp = np.linspace(0.0, 1.0, w + 1)
+    down = ramp[:-1][::-1]
+    if 2 * w < dimsz:
+        t = np.concatenate([ramp, np.ones(dimsz - 2 * w), down])
+    else:
+        t = np.concatenate([ramp, down])
+    t = t.astype(np.float32)
+    if t.size > dimsz:
+        t = t[:dimsz]
+    elif t.size < dimsz:
+        t = np.concatenate([t, np.ones(dimsz - t.size, np.float32)])
+    return t
+
+
+def taper_widths(psf_shape_zyx) -> list[int]:
+    """``max(8, round(size(psf,d)/2))`` per axis (edgetaper_3d.m:32), numpy order."""
+    return [max(8, matlab_round(k / 2.0)) for k in psf_shape_zyx]
+
+
+def edgetaper_mask_vectors(shape_zyx, psf_shape_zyx):
+    return [make_taper(n, w) for n, w in zip(shape_zyx, taper_widths(psf_shape_zyx))]
+
+
+def edgetaper_3d(bl: np.ndarray, psf: np.ndarray) -> np.ndarray:
+    """edgetaper_3d.m:13-44, GPU flavour (blur = conv3d_gpu with the sum-normalised PSF)."""
+    psf = psf.astype(np.float32)
+    assert np.all(np.isfinite(psf)) and np.all(psf >= 0)
+    psfn = (psf / np.float32(psf.sum(dtype=np.float32))).astype(np.float32)
+    blur = conv3d_replicate(bl, psfn)
+    tz, ty, tx = edgetaper_mask_vectors(bl.shape, psf.shape)
+    # mask = ((1 .* tx) .* ty) .* tz in single (edgetaper_3d.m:30-39, d = 1..3 -> x, y, z)
+    mask = (tx[None, None, :] * ty[None, :, None]).astype(np.float32) * tz[:, None, None]
+    one = np.float32(1.0)
+    return (mask * bl.astype(np.float32) + (one - mask) * blur).astype(np.float32)
+
+
+# --------------------------------------------------------------------------- RL loops
+def is_regularization_time(i: int, niter: int, regularize_interval: int) -> bool:
+    """decon.m:54-55 (i is 1-based)."""
+    apply = (regularize_interval > 0) and (regularize_interval < niter)
+    return bool(apply and (i > 1) and (i < niter) and (i % regularize_interval == 0))
+
+
+def _reg_kernel() -> np.ndarray:
+    r = np.full((3, 3, 3), np.float32(1.0 / 26.0), np.float32)  # decon.m:42
+    r[1, 1, 1] = 0
+    return r
+
+
+def _norm2(a: np.ndarray) -> float:
+    return float(np.sqrt(np.sum(a.astype(np.float64) ** 2)))
+
+
+def decon_spatial(bl, psf, niter, lam=0.0, stop_criterion=0.0, regularize_interval=0,
+                  psf_inv=None, gauss_flavour="gpu", return_iters=False):
+    """``deconSpatial`` (decon.m:26-124).  ``gauss_flavour``: "gpu" = gauss3d_gpu(bl,0.5)
+    (5 taps), "cpu" = imgaussfilt3(bl,0.5) (3 taps, replicate) -- decon.m:58."""
+    bl = bl.astype(np.float32)
+    psf = psf.astype(np.float32)
+    psf_inv = flip3(psf) if psf_inv is None else psf_inv.astype(np.float32)
+    lam = np.float32(lam)
+    R = _reg_kernel()
+    delta_prev = _norm2(bl) if stop_criterion > 0 else 0.0
+    bl = edgetaper_3d(bl, psf)
+    done = 0
+    for i in range(1, niter + 1):
+        reg = is_regularization_time(i, niter, regularize_interval)
+        if reg:
+            bl = gauss3d(bl, 0.5) if gauss_flavour == "gpu" else gauss3d(bl, 0.5, 3)
+        buf = convn_same(bl, psf)
+        buf = np.maximum(buf, EPS_SINGLE)
+        buf = (bl / buf).astype(np.float32)
+        buf = convn_same(buf, psf_inv)
+        if reg and lam > 0:
+            regv = convn_same(bl, R)
+            buf = (bl * buf * (np.float32(1) - lam) + regv * lam).astype(np.float32)
+        else:
+            buf = (bl * buf).astype(np.float32)
+        bl = np.abs(buf)
+        done = i
+        if stop_criterion > 0:
+            cur = _norm2(bl)
+            rel = abs(delta_prev - cur) / delta_prev * 100.0
+            delta_prev = cur
+            if i > 1 and rel <= stop_criterion:
+                break
+    return (bl, done) if return_iters else bl
+
+
+def pad_block_to_fft_shape(bl, fft_shape_zyx):
+    """decon.m:323-344 with mode 0 (zeros): pre = floor(missing/2), post = ceil."""
+    missing = [f - s for f, s in zip(fft_shape_zyx, bl.shape)]
+    assert all(m >= 0 for m in missing)
+    pre = [m // 2 for m in missing]
+    post = [m - p for m, p in zip(missing, pre)]
+    return np.pad(bl, list(zip(pre, post))), pre, post
+
+
+def unpad_block(bl, pre, post):
+    """decon.m:346-374."""
+    sl = tuple(slice(p, s - q) for p, q, s in zip(pre, post, bl.shape))
+    return np.ascontiguousarray(bl[sl])
+
+
+def otf_from_psf(psf, fft_shape_zyx):
+    """``fftn(ifftshift(zero-pad-centre(psf)))`` (decon.m:131-133; otf_gpu.cu:36-67)."""
+    p, _, _ = pad_block_to_fft_shape(psf.astype(np.float32), fft_shape_zyx)
+    return np.fft.fftn(np.fft.ifftshift(p).astype(np.float64))
+
+
+def decon_fft(bl, psf, fft_shape_zyx, niter, lam=0.0, stop_criterion=0.0, regularize_interval=0,
+              gauss_flavour="gpu", return_iters=False):
+    """``deconFFT`` (decon.m:127-204): circular convolution on ``fft_shape``; float64
+    transforms rounded to float32 at each ``real(ifftn(..))`` like the single-precision
+    reference buffers."""
+    bl = bl.astype(np.float32)
+    psf = psf.astype(np.float32)
+    lam = np.float32(lam)
+    otf = otf_from_psf(psf, fft_shape_zyx)
+    R = _reg_kernel()
+    bl = edgetaper_3d(bl, psf)
+    bl, pre, post = pad_block_to_fft_shape(bl, fft_shape_zyx)
+    delta_prev = _norm2(bl) if stop_criterion > 0 else 0.0
+    done = 0
+    for i in range(1, niter + 1):
+        reg = is_regularization_time(i, niter, regularize_interval)
+        if reg:
+            bl = gauss3d(bl, 0.5) if gauss_flavour == "gpu" else gauss3d(bl, 0.5, 3)
+        buf = np.real(np.fft.ifftn(np.fft.fftn(bl.astype(np.float64)) * otf)).astype(np.float32)
+        buf = np.maximum(buf, EPS_SINGLE)
+        buf = (bl / buf).astype(np.float32)
+        buf = np.real(np.fft.ifftn(np.fft.fftn(buf.astype(np.float64)) * np.conj(otf))).astype(np.float32)
+        if reg and lam > 0:
+            regv = convn_same(bl, R)
+            bl = (bl * buf * (np.float32(1) - lam) + regv * lam).astype(np.float32)
+        else:
+            bl = (bl * buf).astype(np.float32)
+        bl = np.abs(bl)
+        done = i
+        if stop_criterion > 0:
+            cur = _norm2(bl)
+            rel = abs(delta_prev - cur) / delta_prev * 100.0
+            delta_prev = cur
+            if i > 1 and rel <= stop_criterion:
+                break
+    out = unpad_block(bl, pre, post)
+    return (out, done) if return_iters else out
+
+
+def decon(bl, psf, niter, lam, stop_criterion, regularize_interval, use_fft=False, fft_shape_zyx=None, **kw):
+    """``decon`` dispatcher (decon.m:1-23), non-adaptive variants."""
+    if use_fft:
+        return decon_fft(bl, psf, fft_shape_zyx or bl.shape, niter, lam, stop_criterion, regularize_interval, **kw)
+    return decon_spatial(bl, psf, niter, lam, stop_criterion, regularize_interval, **kw)
+
+
+# --------------------------------------------------------------------------- block geometry
+def split_stack(stack_xyz, block_xyz, nblocks_xyz):
+    """split_stack.m:9-26: 1-based inclusive boxes, x fastest then y then z."""
+    sx, sy, sz = stack_xyz
+    bx, by, bz = block_xyz
+    nx, ny, nz = nblocks_xyz
+    p1, p2 = [], []
+    for iz in range(nz):
+        zs = iz * bz + 1
+        for iy in range(ny):
+            ys = iy * by + 1
+            for ix in range(nx):
+                xs = ix * bx + 1
+                p1.append((xs, ys, zs))
+                p2.append((min(xs + bx - 1, sx), min(ys + by - 1, sy), min(zs + bz - 1, sz)))
+    return np.array(p1, np.int64), np.array(p2, np.int64)
+
+
+def next_fast_len(n: int) -> int:
+    """7-smooth size >= n (LsDeconv.m:405-419)."""
+    while True:
+        m = n
+        for p in (2, 3, 5, 7):
+            while m % p == 0:
+                m //= p
+        if m == 1:
+            return n
+        n += 1
+
+
+def u16_to_f32(vol_u16: np.ndarray) -> np.ndarray:
+    """``im2single`` of uint16 data (LsDeconv.m:860,873): x / 65535 in single."""
+    return (vol_u16.astype(np.float32) / np.float32(65535.0)).astype(np.float32)
+
+
+# --------------------------------------------------------------------------- synthetic inputs
+def gaussian_psf(shape_zyx, sigma_zyx) -> np.ndarray:
+    """Separable Gaussian PSF normalised to sum 1 (BASELINE config 1 input)."""
+    axes = []
+    for n, s in zip(shape_zyx, sigma_zyx):
+        r = np.arange(n) - (n - 1) / 2.0
+        axes.append(np.exp(-0.5 * (r / s) ** 2))
+    p = axes[0][:, None, None] * axes[1][None, :, None] * axes[2][None, None, :]
+    return (p / p.sum()).astype(np.float32)
+
+
+def bead_volume(shape_zyx, seed=1234, psf=None) -> np.ndarray:
+    """SURVEY.md section 8d synthetic volume: background U(0.01,0.02), N/4096 beads with
+    amplitude U(0.2,1), blurred by the PSF, times (1 + N(0,0.01)) clipped >= 0."""
+    rng = np.random.default_rng(seed)
+    n = int(np.prod(shape_zyx))
+    vol = rng.uniform(0.01, 0.02, size=shape_zyx).astype(np.float32)
+    nb = max(1, n // 4096)
+    idx = rng.integers(0, n, size=nb)
+    vol.reshape(-1)[idx] += rng.uniform(0.2, 1.0, size=nb).astype(np.float32) * 20.0
+    if psf is not None:
+        vol = signal.fftconvolve(vol.astype(np.float64), psf.astype(np.float64), mode="same").astype(np.float32)
+    vol *= (1.0 + rng.normal(0.0, 0.01, size=shape_zyx)).astype(np.float32)
+    return np.clip(vol, 0.0, None).astype(np.float32)
