@@ -1,0 +1,271 @@
+// Error sink, device queries and the element-wise / data-movement kernels of the RL path.
+// All of these are pure HBM streaming kernels: 16 B per lane, grid-stride, >= 4 waves per SIMD.
+#include "mi_internal.h"
+#include "mi_lsdeconv.h"
+
+namespace mi {
+std::string& last_error_ref() {
+    thread_local std::string err;
+    return err;
+}
+}  // namespace mi
+
+using namespace mi;
+
+extern "C" const char* mi_last_error(void) { return last_error_ref().c_str(); }
+
+extern "C" int mi_abi_version(void) { return 1; }
+
+extern "C" int mi_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return fail(MI_ERR_HIP, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    return n;
+}
+
+extern "C" int mi_stream_synchronize(int dev, void* stream) {
+    MI_TRY(use_device(dev));
+    MI_HIP(hipStreamSynchronize(as_stream(stream)));
+    return MI_OK;
+}
+
+extern "C" int mi_next_fast_len(int n) {
+    if (n < 1) n = 1;
+    for (;; ++n) {
+        int m = n;
+        for (int p : {2, 3, 5, 7})
+            while (m % p == 0) m /= p;
+        if (m == 1) return n;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int kThreads = 256;
+inline unsigned stream_grid(size_t n_items) {
+    size_t b = (n_items + kThreads - 1) / kThreads;
+    const size_t cap = 256 * 16;  // 16 work-groups per CU, grid-stride beyond that
+    return static_cast<unsigned>(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+// uint16 -> float * scale (im2single). 8 elements (16 B in, 32 B out) per lane per step.
+__global__ __launch_bounds__(kThreads) void k_u16_to_f32(const uint16_t* __restrict__ src, float* __restrict__ dst,
+                                                          size_t n, float scale) {
+    size_t n8 = n / 8;
+    size_t tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    const uint4* s4 = reinterpret_cast<const uint4*>(src);
+    float4* d4 = reinterpret_cast<float4*>(dst);
+    for (size_t i = tid; i < n8; i += stride) {
+        uint4 v = s4[i];
+        float4 a, b;
+        a.x = (float)(v.x & 0xffffu) * scale; a.y = (float)(v.x >> 16) * scale;
+        a.z = (float)(v.y & 0xffffu) * scale; a.w = (float)(v.y >> 16) * scale;
+        b.x = (float)(v.z & 0xffffu) * scale; b.y = (float)(v.z >> 16) * scale;
+        b.z = (float)(v.w & 0xffffu) * scale; b.w = (float)(v.w >> 16) * scale;
+        d4[2 * i] = a;
+        d4[2 * i + 1] = b;
+    }
+    for (size_t i = n8 * 8 + tid; i < n; i += stride) dst[i] = (float)src[i] * scale;
+}
+
+__global__ __launch_bounds__(kThreads) void k_sub_dark(const float* __restrict__ src, float* __restrict__ dst, size_t n,
+                                                        float dark) {
+    size_t tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = tid; i < n; i += stride) dst[i] = fmaxf(src[i] - dark, 0.0f);
+}
+
+// sum of squares in double: per-thread double accumulators, wave shuffle tree, one atomicAdd(double)
+// per work-group.  (fp64 atomics on distinct groups commute up to rounding; the stop test compares
+// against a percentage threshold, decon.m:110-115.)
+__global__ __launch_bounds__(kThreads) void k_sumsq(const float* __restrict__ x, size_t n, double* __restrict__ out) {
+    size_t tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    double acc = 0.0;
+    size_t n4 = n / 4;
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    for (size_t i = tid; i < n4; i += stride) {
+        float4 v = x4[i];
+        acc += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+    }
+    for (size_t i = n4 * 4 + tid; i < n; i += stride) acc += (double)x[i] * x[i];
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    __shared__ double part[kThreads / 64];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int w = 0; w < kThreads / 64; ++w) s += part[w];
+        atomicAdd(out, s);
+    }
+}
+
+// dst (fx,fy,fz) = zero-pad-centre(src (nx,ny,nz)) or the crop back; one thread per 1 dst element
+__global__ __launch_bounds__(kThreads) void k_pad_center(const float* __restrict__ src, int nx, int ny, int nz,
+                                                          float* __restrict__ dst, int fx, int fy, int fz, int px, int py,
+                                                          int pz) {
+    size_t total = (size_t)fx * fy * fz;
+    size_t tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = tid; i < total; i += stride) {
+        int x = (int)(i % fx);
+        size_t r = i / fx;
+        int y = (int)(r % fy), z = (int)(r / fy);
+        int sx = x - px, sy = y - py, sz = z - pz;
+        float v = 0.0f;
+        if (sx >= 0 && sx < nx && sy >= 0 && sy < ny && sz >= 0 && sz < nz) v = src[((size_t)sz * ny + sy) * nx + sx];
+        dst[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void k_crop_center(const float* __restrict__ src, int fx, int fy, int fz,
+                                                           float* __restrict__ dst, int nx, int ny, int nz, int px, int py,
+                                                           int pz) {
+    size_t total = (size_t)nx * ny * nz;
+    size_t tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = tid; i < total; i += stride) {
+        int x = (int)(i % nx);
+        size_t r = i / nx;
+        int y = (int)(r % ny), z = (int)(r / ny);
+        dst[i] = src[((size_t)(z + pz) * fy + (y + py)) * fx + (x + px)];
+    }
+}
+
+// rows [y0, y0+rows) of every plane <-> packed (nz, rows, nx)
+template <bool PACK>
+__global__ __launch_bounds__(kThreads) void k_rows(float* __restrict__ vol, int nx, int ny, int nz, int y0, int rows,
+                                                    float* __restrict__ packed) {
+    size_t total = (size_t)nx * rows * nz;
+    size_t tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = tid; i < total; i += stride) {
+        int x = (int)(i % nx);
+        size_t r = i / nx;
+        int y = (int)(r % rows), z = (int)(r / rows);
+        size_t v = ((size_t)z * ny + (y0 + y)) * nx + x;
+        if (PACK) packed[i] = vol[v];
+        else vol[v] = packed[i];
+    }
+}
+
+// reg = convn(bl, R, 'same'), R = 1/26 on the 26 neighbours, 0 at the centre (decon.m:42,70).
+// Accumulation order follows the kernel index order of a true convolution; zero boundary.
+__global__ __launch_bounds__(kThreads) void k_reg_term(const float* __restrict__ bl, float* __restrict__ reg, int nx, int ny,
+                                                        int nz) {
+    size_t total = (size_t)nx * ny * nz;
+    size_t tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    const float w = 1.0f / 26.0f;
+    for (size_t i = tid; i < total; i += stride) {
+        int x = (int)(i % nx);
+        size_t r = i / nx;
+        int y = (int)(r % ny), z = (int)(r / ny);
+        float acc = 0.0f;
+        for (int dz = -1; dz <= 1; ++dz) {
+            int zz = z + dz;
+            if (zz < 0 || zz >= nz) continue;
+            for (int dy = -1; dy <= 1; ++dy) {
+                int yy = y + dy;
+                if (yy < 0 || yy >= ny) continue;
+                for (int dx = -1; dx <= 1; ++dx) {
+                    int xx = x + dx;
+                    if (xx < 0 || xx >= nx || (dx == 0 && dy == 0 && dz == 0)) continue;
+                    acc += w * bl[((size_t)zz * ny + yy) * nx + xx];
+                }
+            }
+        }
+        reg[i] = acc;
+    }
+}
+
+}  // namespace
+
+extern "C" int mi_u16_to_f32(int dev, void* stream, const uint16_t* src, float* dst, size_t n, float scale) {
+    MI_TRY(use_device(dev));
+    MI_REQUIRE(src && dst, "mi_u16_to_f32: null pointer");
+    MI_REQUIRE(((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0, "mi_u16_to_f32: pointers must be 16-byte aligned");
+    if (n == 0) return MI_OK;
+    hipLaunchKernelGGL(k_u16_to_f32, dim3(stream_grid(n / 8 + 1)), dim3(kThreads), 0, as_stream(stream), src, dst, n, scale);
+    return launch_check("k_u16_to_f32");
+}
+
+extern "C" int mi_subtract_dark(int dev, void* stream, const float* src, float* dst, size_t n, float dark) {
+    MI_TRY(use_device(dev));
+    MI_REQUIRE(src && dst, "mi_subtract_dark: null pointer");
+    if (n == 0) return MI_OK;
+    hipLaunchKernelGGL(k_sub_dark, dim3(stream_grid(n)), dim3(kThreads), 0, as_stream(stream), src, dst, n, dark);
+    return launch_check("k_sub_dark");
+}
+
+namespace mi {
+// enqueue sum(x^2) into *d_out (device double, zeroed here)
+int sumsq_async(hipStream_t s, const float* x, size_t n, double* d_out) {
+    MI_HIP(hipMemsetAsync(d_out, 0, sizeof(double), s));
+    if (n) {
+        hipLaunchKernelGGL(k_sumsq, dim3(stream_grid(n / 4 + 1)), dim3(kThreads), 0, s, x, n, d_out);
+        MI_TRY(launch_check("k_sumsq"));
+    }
+    return MI_OK;
+}
+}  // namespace mi
+
+extern "C" int mi_norm2(int dev, void* stream, const float* x, size_t n, double* norm2) {
+    MI_TRY(use_device(dev));
+    MI_REQUIRE(x && norm2, "mi_norm2: null pointer");
+    MI_REQUIRE(((uintptr_t)x % 16) == 0, "mi_norm2: pointer must be 16-byte aligned");
+    DevBuf d;
+    MI_TRY(d.alloc(sizeof(double)));
+    MI_TRY(sumsq_async(as_stream(stream), x, n, d.as<double>()));
+    double h = 0.0;
+    MI_HIP(hipMemcpyAsync(&h, d.p, sizeof(double), hipMemcpyDeviceToHost, as_stream(stream)));
+    MI_HIP(hipStreamSynchronize(as_stream(stream)));
+    *norm2 = sqrt(h);
+    return MI_OK;
+}
+
+extern "C" int mi_pad_center(int dev, void* stream, const float* src, int nx, int ny, int nz, float* dst, int fx, int fy,
+                             int fz) {
+    MI_TRY(use_device(dev));
+    MI_REQUIRE(src && dst, "mi_pad_center: null pointer");
+    MI_REQUIRE(nx > 0 && ny > 0 && nz > 0 && fx >= nx && fy >= ny && fz >= nz,
+               "pad_block_to_fft_shape: bl [%d %d %d] is larger than FFT shape [%d %d %d], cannot pad", nx, ny, nz, fx, fy, fz);
+    hipLaunchKernelGGL(k_pad_center, dim3(stream_grid((size_t)fx * fy * fz)), dim3(kThreads), 0, as_stream(stream), src, nx, ny,
+                       nz, dst, fx, fy, fz, (fx - nx) / 2, (fy - ny) / 2, (fz - nz) / 2);
+    return launch_check("k_pad_center");
+}
+
+extern "C" int mi_crop_center(int dev, void* stream, const float* src, int fx, int fy, int fz, float* dst, int nx, int ny,
+                              int nz) {
+    MI_TRY(use_device(dev));
+    MI_REQUIRE(src && dst, "mi_crop_center: null pointer");
+    MI_REQUIRE(nx > 0 && ny > 0 && nz > 0 && fx >= nx && fy >= ny && fz >= nz, "unpad_block: invalid sizes");
+    hipLaunchKernelGGL(k_crop_center, dim3(stream_grid((size_t)nx * ny * nz)), dim3(kThreads), 0, as_stream(stream), src, fx, fy,
+                       fz, dst, nx, ny, nz, (fx - nx) / 2, (fy - ny) / 2, (fz - nz) / 2);
+    return launch_check("k_crop_center");
+}
+
+extern "C" int mi_pack_rows(int dev, void* stream, const float* vol, int nx, int ny, int nz, int y0, int rows, float* packed) {
+    MI_TRY(use_device(dev));
+    MI_REQUIRE(vol && packed, "mi_pack_rows: null pointer");
+    MI_REQUIRE(nx > 0 && ny > 0 && nz > 0 && rows >= 0 && y0 >= 0 && y0 + rows <= ny, "mi_pack_rows: rows [%d,%d) outside [0,%d)", y0,
+               y0 + rows, ny);
+    if (rows == 0) return MI_OK;
+    hipLaunchKernelGGL(k_rows<true>, dim3(stream_grid((size_t)nx * rows * nz)), dim3(kThreads), 0, as_stream(stream),
+                       const_cast<float*>(vol), nx, ny, nz, y0, rows, packed);
+    return launch_check("k_rows<pack>");
+}
+
+extern "C" int mi_unpack_rows(int dev, void* stream, const float* packed, int nx, int ny, int nz, int y0, int rows, float* vol) {
+    MI_TRY(use_device(dev));
+    MI_REQUIRE(vol && packed, "mi_unpack_rows: null pointer");
+    MI_REQUIRE(nx > 0 && ny > 0 && nz > 0 && rows >= 0 && y0 >= 0 && y0 + rows <= ny, "mi_unpack_rows: rows [%d,%d) outside [0,%d)",
+               y0, y0 + rows, ny);
+    if (rows == 0) return MI_OK;
+    hipLaunchKernelGGL(k_rows<false>, dim3(stream_grid((size_t)nx * rows * nz)), dim3(kThreads), 0, as_stream(stream), vol, nx, ny, nz,
+                       y0, rows, const_cast<float*>(packed));
+    return launch_check("k_rows<unpack>");
+}
+
+extern "C" int mi_rl_reg_term(int dev, void* stream, const float* bl, float* reg, int nx, int ny, int nz) {
+    MI_TRY(use_device(dev));
+    MI_REQUIRE(bl && reg && bl != reg, "mi_rl_reg_term: null or aliased pointers");
+    MI_REQUIRE(nx > 0 && ny > 0 && nz > 0, "mi_rl_reg_term: empty volume");
+    hipLaunchKernelGGL(k_reg_term, dim3(stream_grid((size_t)nx * ny * nz)), dim3(kThreads), 0, as_stream(stream), bl, reg, nx, ny, nz);
+    return launch_check("k_reg_term");
+}

@@ -1,0 +1,39 @@
+// Internal interface of the direct convolution engine (conv3d_direct.hip).
+#pragma once
+#include "mi_internal.h"
+#include "mi_lsdeconv.h"
+
+namespace mi {
+
+enum ConvEpi {
+    EPI_NONE = 0,        // out = c
+    EPI_RATIO = 1,       // out = a ./ max(c, eps)                      (decon.m:62-63)
+    EPI_UPDATE = 2,      // out = abs(a .* c)                           (decon.m:76,79)
+    EPI_UPDATE_REG = 3,  // out = abs(a .* c .* (1-lambda) + b .* lambda) (decon.m:71,79)
+    EPI_TAPER_SHELL = 4  // out = c, tiles on the taper plateau skipped (edgetaper_3d.m:44)
+};
+
+struct ConvEpilogue {
+    const float* a = nullptr;
+    const float* b = nullptr;
+    float lambda = 0.0f;
+    int plat_lo[3] = {0, 0, 0};  // [lo, hi) per axis (x, y, z) where the taper is exactly 1
+    int plat_hi[3] = {0, 0, 0};
+};
+
+// offset of the kernel window start relative to the output sample, per boundary rule
+int conv_kernel_offset(int k, int boundary);
+// builds the x-padded tap table of the direct engine on the device: flip=true turns a convolution
+// kernel into the correlation taps the engine consumes (optionally sum-normalised)
+int direct_prepare_psf(hipStream_t s, const float* ker, int kx, int ky, int kz, bool normalise, bool flip, DevBuf& kf,
+                       int* kxp_out);
+// offs (optional) = window start offsets {cx, cy, cz}; default conv_kernel_offset(k, boundary)
+int direct_conv_launch(hipStream_t s, const float* img, const float* kf, float* out, int nx, int ny, int nz, int kx, int ky,
+                       int kz, int kxp, int boundary, int epi_kind, const ConvEpilogue& epi, const int* offs = nullptr);
+int gauss3d_async(hipStream_t s, float* vol, float* work, int nx, int ny, int nz, const float* sigma, const int* ksize);
+int edgetaper_async(hipStream_t s, float* bl, float* work, const float* psf, int nx, int ny, int nz, int kx, int ky, int kz);
+
+// common.hip
+int sumsq_async(hipStream_t s, const float* x, size_t n, double* d_out);
+
+}  // namespace mi

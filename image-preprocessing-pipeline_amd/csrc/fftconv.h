@@ -1,0 +1,43 @@
+// Internal interface of the rocFFT convolution engine (fftconv.hip).
+#pragma once
+#include <rocfft/rocfft.h>
+
+#include "conv3d_direct.h"
+
+namespace mi {
+
+// Where the PSF sample j of an axis lands in the length-F circular kernel: index (j - shift) mod F.
+//   exact "same" convolution (zero / replicate rules): shift = k - 1 - window_offset
+//   deconFFT flavour (decon.m:131-133): centred zero-pad then ifftshift -> shift = floor(F/2) - floor((F-k)/2)
+struct AxisPlan {
+    int n = 0;      // data extent
+    int k = 0;      // PSF extent
+    int F = 0;      // transform length
+    int o = 0;      // offset of the data inside the padded array (replicate: window offset)
+    int shift = 0;  // PSF placement shift
+};
+
+struct FftEngine {
+    int boundary = MI_BOUNDARY_ZERO;
+    AxisPlan ax[3];  // x, y, z
+    bool padded = false;  // F != n or o != 0: inputs are staged through `real`
+    rocfft_plan fwd = nullptr, inv = nullptr;
+    rocfft_execution_info info = nullptr;
+    DevBuf work, spec, real, otf, otf_adj;
+    size_t n_real = 0, n_spec = 0;  // element counts (floats / complex)
+    bool have_adj = false;
+
+    ~FftEngine();
+    int init(hipStream_t s, const int n[3], const int k[3], const int F[3], int boundary, bool deconfft_flavour,
+             const float* psf, const float* psf_inv, bool need_adjoint);
+    // c = conv(in, psf or its adjoint), then the epilogue of `epi_kind` into out (shape n)
+    int conv(hipStream_t s, const float* in, bool adjoint, float* out, int epi_kind, const ConvEpilogue& epi);
+    size_t device_bytes() const { return work.bytes + spec.bytes + real.bytes + otf.bytes + otf_adj.bytes; }
+};
+
+// writes the half-spectrum OTF of `psf` placed per `ax` (scaled) into `otf` using plan `fwd`
+int build_otf(hipStream_t s, rocfft_plan fwd, rocfft_execution_info info, const float* psf, const AxisPlan ax[3], float* real_scratch,
+              float* otf, float scale);
+int rocfft_global_setup();
+
+}  // namespace mi

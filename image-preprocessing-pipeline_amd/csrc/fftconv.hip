@@ -1,0 +1,310 @@
+// rocFFT convolution engine (MI_ENGINE_FFT): c = IFFT3(FFT3(x) .* OTF) on R2C half spectra.
+//
+// Replaces the reference's full complex fftn / .* / ifftn / real chain (decon.m:162-172: four C2C
+// transforms per iteration on complex single buffers plus ~8 element-wise passes and two conj(otf)
+// materialisations, :168,174) with: R2C -> one fused multiply (conj folded in as a flag, 1/N folded
+// into the OTF) -> C2R -> one fused epilogue (RL ratio or RL update).  The same engine serves
+//   * deconFFT semantics: circular on fft_shape, PSF placed as ifftshift(zero-pad-centre(psf))
+//     (decon.m:131-133, supplements/otf_gpu.cu:36-67) -- including the one-voxel offset that
+//     placement has for even fft_shape;
+//   * convn(...,'same') / conv3d_gpu semantics for large PSFs: the volume is staged into a padded
+//     buffer (zeros or clamped samples) large enough that circular wrap never reaches the output.
+#include <mutex>
+
+#include "fftconv.h"
+
+namespace mi {
+
+#define MI_FFT(call)                                                                                     \
+    do {                                                                                                 \
+        rocfft_status st_ = (call);                                                                      \
+        if (st_ != rocfft_status_success)                                                                \
+            return ::mi::fail(MI_ERR_FFT, "%s:%d: %s failed with rocfft_status %d", __FILE__, __LINE__,  \
+                              #call, (int)st_);                                                          \
+    } while (0)
+
+int rocfft_global_setup() {
+    static std::once_flag once;
+    static rocfft_status st = rocfft_status_success;
+    std::call_once(once, [] { st = rocfft_setup(); });
+    if (st != rocfft_status_success) return fail(MI_ERR_FFT, "rocfft_setup failed with status %d", (int)st);
+    return MI_OK;
+}
+
+namespace {
+
+constexpr int kThreads = 256;
+inline unsigned stream_grid(size_t n_items) {
+    size_t b = (n_items + kThreads - 1) / kThreads;
+    const size_t cap = 256 * 16;
+    return static_cast<unsigned>(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+// circular kernel image: dst[p] = psf[j] where p == (j - shift) mod F per axis, else 0
+__global__ __launch_bounds__(kThreads) void k_place_psf(const float* __restrict__ psf, float* __restrict__ dst, int kx, int ky, int kz,
+                                                         int Fx, int Fy, int Fz, int sx, int sy, int sz) {
+    const size_t total = (size_t)Fx * Fy * Fz;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % Fx);
+        const size_t r = i / Fx;
+        const int y = (int)(r % Fy), z = (int)(r / Fy);
+        const int jx = (x + sx) % Fx, jy = (y + sy) % Fy, jz = (z + sz) % Fz;
+        dst[i] = (jx < kx && jy < ky && jz < kz) ? psf[((size_t)jz * ky + jy) * kx + jx] : 0.0f;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void k_scale_c(float2* __restrict__ a, size_t n, float scale) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float2 v = a[i];
+        a[i] = make_float2(v.x * scale, v.y * scale);
+    }
+}
+
+// spec .*= otf  or  spec .*= conj(otf)
+template <bool CONJ>
+__global__ __launch_bounds__(kThreads) void k_mul_otf(float2* __restrict__ spec, const float2* __restrict__ otf, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float2 a = spec[i], b = otf[i];
+        const float bi = CONJ ? -b.y : b.y;
+        spec[i] = make_float2(a.x * b.x - a.y * bi, a.x * bi + a.y * b.x);
+    }
+}
+
+// padded staging: dst (F) <- src (n) at offset o; zero rule: zeros elsewhere; replicate rule: the
+// window [0, n + k - 1) holds clamped samples, zeros beyond
+__global__ __launch_bounds__(kThreads) void k_stage(const float* __restrict__ src, float* __restrict__ dst, int nx, int ny, int nz,
+                                                     int Fx, int Fy, int Fz, int ox, int oy, int oz, int kx, int ky, int kz,
+                                                     int replicate) {
+    const size_t total = (size_t)Fx * Fy * Fz;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % Fx);
+        const size_t r = i / Fx;
+        const int y = (int)(r % Fy), z = (int)(r / Fy);
+        int sx = x - ox, sy = y - oy, sz = z - oz;
+        float v = 0.0f;
+        if (replicate) {
+            if (x < nx + kx - 1 && y < ny + ky - 1 && z < nz + kz - 1) {
+                sx = min(max(sx, 0), nx - 1); sy = min(max(sy, 0), ny - 1); sz = min(max(sz, 0), nz - 1);
+                v = src[((size_t)sz * ny + sy) * nx + sx];
+            }
+        } else if (sx >= 0 && sx < nx && sy >= 0 && sy < ny && sz >= 0 && sz < nz) {
+            v = src[((size_t)sz * ny + sy) * nx + sx];
+        }
+        dst[i] = v;
+    }
+}
+
+template <int EPI>
+__device__ __forceinline__ float fft_epi(float c, size_t idx, const ConvEpilogue& e) {
+    if (EPI == EPI_RATIO) return e.a[idx] / fmaxf(c, kEpsSingle);
+    if (EPI == EPI_UPDATE) return fabsf(e.a[idx] * c);
+    if (EPI == EPI_UPDATE_REG) return fabsf(e.a[idx] * c * (1.0f - e.lambda) + e.b[idx] * e.lambda);
+    return c;
+}
+
+// out (n) = epilogue(c (F) cropped at o)
+template <int EPI>
+__global__ __launch_bounds__(kThreads) void k_fft_epilogue(const float* __restrict__ c, float* __restrict__ out, ConvEpilogue e, int nx,
+                                                            int ny, int nz, int Fx, int Fy, int ox, int oy, int oz) {
+    const size_t total = (size_t)nx * ny * nz;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % nx);
+        const size_t r = i / nx;
+        const int y = (int)(r % ny), z = (int)(r / ny);
+        out[i] = fft_epi<EPI>(c[((size_t)(z + oz) * Fy + (y + oy)) * Fx + (x + ox)], i, e);
+    }
+}
+
+// same-shape fast path: 16 B per lane
+template <int EPI>
+__global__ __launch_bounds__(kThreads) void k_fft_epilogue_flat(const float* __restrict__ c, float* __restrict__ out, ConvEpilogue e,
+                                                                 size_t n) {
+    const size_t n4 = n / 4;
+    const float4* c4 = reinterpret_cast<const float4*>(c);
+    const float4* a4 = reinterpret_cast<const float4*>(e.a);
+    const float4* b4 = reinterpret_cast<const float4*>(e.b);
+    float4* o4 = reinterpret_cast<float4*>(out);
+    const size_t tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = tid; i < n4; i += stride) {
+        const float4 cv = c4[i];
+        float4 r;
+        if (EPI == EPI_NONE) {
+            r = cv;
+        } else {
+            const float4 av = a4[i];
+            if (EPI == EPI_RATIO) {
+                r = make_float4(av.x / fmaxf(cv.x, kEpsSingle), av.y / fmaxf(cv.y, kEpsSingle), av.z / fmaxf(cv.z, kEpsSingle),
+                                av.w / fmaxf(cv.w, kEpsSingle));
+            } else if (EPI == EPI_UPDATE) {
+                r = make_float4(fabsf(av.x * cv.x), fabsf(av.y * cv.y), fabsf(av.z * cv.z), fabsf(av.w * cv.w));
+            } else {
+                const float4 bv = b4[i];
+                const float l = e.lambda, m = 1.0f - e.lambda;
+                r = make_float4(fabsf(av.x * cv.x * m + bv.x * l), fabsf(av.y * cv.y * m + bv.y * l), fabsf(av.z * cv.z * m + bv.z * l),
+                                fabsf(av.w * cv.w * m + bv.w * l));
+            }
+        }
+        o4[i] = r;
+    }
+    for (size_t i = n4 * 4 + tid; i < n; i += stride) out[i] = fft_epi<EPI>(c[i], i, e);
+}
+
+}  // namespace
+
+int build_otf(hipStream_t s, rocfft_plan fwd, rocfft_execution_info info, const float* psf, const AxisPlan ax[3], float* real_scratch,
+              float* otf, float scale) {
+    const size_t n_real = (size_t)ax[0].F * ax[1].F * ax[2].F;
+    const size_t n_spec = (size_t)(ax[0].F / 2 + 1) * ax[1].F * ax[2].F;
+    hipLaunchKernelGGL(k_place_psf, dim3(stream_grid(n_real)), dim3(kThreads), 0, s, psf, real_scratch, ax[0].k, ax[1].k, ax[2].k,
+                       ax[0].F, ax[1].F, ax[2].F, ax[0].shift, ax[1].shift, ax[2].shift);
+    MI_TRY(launch_check("k_place_psf"));
+    void* in[1] = {real_scratch};
+    void* out[1] = {otf};
+    MI_FFT(rocfft_execute(fwd, in, out, info));
+    if (scale != 1.0f) {
+        hipLaunchKernelGGL(k_scale_c, dim3(stream_grid(n_spec)), dim3(kThreads), 0, s, reinterpret_cast<float2*>(otf), n_spec, scale);
+        MI_TRY(launch_check("k_scale_c"));
+    }
+    return MI_OK;
+}
+
+FftEngine::~FftEngine() {
+    if (info) rocfft_execution_info_destroy(info);
+    if (fwd) rocfft_plan_destroy(fwd);
+    if (inv) rocfft_plan_destroy(inv);
+}
+
+static int make_plans(hipStream_t s, const size_t lengths[3], rocfft_plan* fwd, rocfft_plan* inv, rocfft_execution_info* info,
+                      DevBuf& work) {
+    MI_TRY(rocfft_global_setup());
+    MI_FFT(rocfft_plan_create(fwd, rocfft_placement_notinplace, rocfft_transform_type_real_forward, rocfft_precision_single, 3,
+                              lengths, 1, nullptr));
+    size_t wf = 0, wi = 0;
+    MI_FFT(rocfft_plan_get_work_buffer_size(*fwd, &wf));
+    if (inv) {
+        MI_FFT(rocfft_plan_create(inv, rocfft_placement_notinplace, rocfft_transform_type_real_inverse, rocfft_precision_single, 3,
+                                  lengths, 1, nullptr));
+        MI_FFT(rocfft_plan_get_work_buffer_size(*inv, &wi));
+    }
+    MI_FFT(rocfft_execution_info_create(info));
+    const size_t w = wf > wi ? wf : wi;
+    if (w) {
+        MI_TRY(work.alloc(w));
+        MI_FFT(rocfft_execution_info_set_work_buffer(*info, work.p, w));
+    }
+    MI_FFT(rocfft_execution_info_set_stream(*info, s));
+    return MI_OK;
+}
+
+int FftEngine::init(hipStream_t s, const int n[3], const int k[3], const int F[3], int boundary_, bool deconfft_flavour, const float* psf,
+                    const float* psf_inv, bool need_adjoint) {
+    boundary = boundary_;
+    padded = false;
+    for (int d = 0; d < 3; ++d) {
+        AxisPlan& a = ax[d];
+        a.n = n[d];
+        a.k = k[d];
+        a.F = F[d];
+        const int off = conv_kernel_offset(k[d], boundary);
+        a.o = boundary == MI_BOUNDARY_REPLICATE ? off : 0;
+        a.shift = deconfft_flavour ? (F[d] / 2 - (F[d] - k[d]) / 2) : (k[d] - 1 - off);
+        MI_REQUIRE(F[d] >= n[d] && F[d] >= k[d], "FFT shape %d smaller than data %d / PSF %d on axis %d", F[d], n[d], k[d], d);
+        if (a.F != a.n || a.o != 0) padded = true;
+    }
+    n_real = (size_t)F[0] * F[1] * F[2];
+    n_spec = (size_t)(F[0] / 2 + 1) * F[1] * F[2];
+    const size_t lengths[3] = {(size_t)F[0], (size_t)F[1], (size_t)F[2]};  // rocFFT: fastest dimension first
+    MI_TRY(make_plans(s, lengths, &fwd, &inv, &info, work));
+    MI_TRY(real.alloc(sizeof(float) * n_real));
+    MI_TRY(spec.alloc(sizeof(float) * 2 * n_spec));
+    MI_TRY(otf.alloc(sizeof(float) * 2 * n_spec));
+    const float scale = 1.0f / (float)((double)F[0] * F[1] * F[2]);
+    MI_TRY(build_otf(s, fwd, info, psf, ax, real.as<float>(), otf.as<float>(), scale));
+    // deconFFT never sees psf_inv (decon.m:18): its adjoint is conj(otf).  For 'same'-convolution
+    // semantics an explicit psf_inv is just another kernel with the same placement rule.
+    have_adj = need_adjoint && psf_inv != nullptr && !deconfft_flavour;
+    if (have_adj) {
+        MI_TRY(otf_adj.alloc(sizeof(float) * 2 * n_spec));
+        MI_TRY(build_otf(s, fwd, info, psf_inv, ax, real.as<float>(), otf_adj.as<float>(), scale));
+    } else if (need_adjoint && !deconfft_flavour) {
+        // conj(OTF) equals the OTF of the flipped PSF only when the placement is symmetric (odd extents)
+        for (int d = 0; d < 3; ++d)
+            MI_REQUIRE(k[d] % 2 == 1, "FFT engine: PSF extent %d on axis %d must be odd when psf_inv is implied", k[d], d);
+    }
+    return MI_OK;
+}
+
+int FftEngine::conv(hipStream_t s, const float* in, bool adjoint, float* out, int epi_kind, const ConvEpilogue& epi) {
+    MI_FFT(rocfft_execution_info_set_stream(info, s));
+    const float* src = in;
+    if (padded) {
+        hipLaunchKernelGGL(k_stage, dim3(stream_grid(n_real)), dim3(kThreads), 0, s, in, real.as<float>(), ax[0].n, ax[1].n, ax[2].n,
+                           ax[0].F, ax[1].F, ax[2].F, ax[0].o, ax[1].o, ax[2].o, ax[0].k, ax[1].k, ax[2].k,
+                           boundary == MI_BOUNDARY_REPLICATE ? 1 : 0);
+        MI_TRY(launch_check("k_stage"));
+        src = real.as<float>();
+    }
+    void* fin[1] = {const_cast<float*>(src)};
+    void* fout[1] = {spec.p};
+    MI_FFT(rocfft_execute(fwd, fin, fout, info));
+    const float2* o = reinterpret_cast<const float2*>(adjoint && have_adj ? otf_adj.p : otf.p);
+    if (adjoint && !have_adj)
+        hipLaunchKernelGGL(k_mul_otf<true>, dim3(stream_grid(n_spec)), dim3(kThreads), 0, s, spec.as<float2>(), o, n_spec);
+    else
+        hipLaunchKernelGGL(k_mul_otf<false>, dim3(stream_grid(n_spec)), dim3(kThreads), 0, s, spec.as<float2>(), o, n_spec);
+    MI_TRY(launch_check("k_mul_otf"));
+    void* iin[1] = {spec.p};
+    void* iout[1] = {real.p};
+    MI_FFT(rocfft_execute(inv, iin, iout, info));
+    const size_t n_out = (size_t)ax[0].n * ax[1].n * ax[2].n;
+    const bool flat = !padded && ((uintptr_t)out % 16) == 0 && (!epi.a || ((uintptr_t)epi.a % 16) == 0) &&
+                      (!epi.b || ((uintptr_t)epi.b % 16) == 0);
+#define MI_EPI(E)                                                                                                                  \
+    do {                                                                                                                           \
+        if (flat)                                                                                                                  \
+            hipLaunchKernelGGL(k_fft_epilogue_flat<E>, dim3(stream_grid(n_out / 4 + 1)), dim3(kThreads), 0, s, real.as<float>(), out, \
+                               epi, n_out);                                                                                        \
+        else                                                                                                                       \
+            hipLaunchKernelGGL(k_fft_epilogue<E>, dim3(stream_grid(n_out)), dim3(kThreads), 0, s, real.as<float>(), out, epi,      \
+                               ax[0].n, ax[1].n, ax[2].n, ax[0].F, ax[1].F, ax[0].o, ax[1].o, ax[2].o);                           \
+    } while (0)
+    switch (epi_kind) {
+        case EPI_NONE: case EPI_TAPER_SHELL: MI_EPI(EPI_NONE); break;
+        case EPI_RATIO: MI_EPI(EPI_RATIO); break;
+        case EPI_UPDATE: MI_EPI(EPI_UPDATE); break;
+        case EPI_UPDATE_REG: MI_EPI(EPI_UPDATE_REG); break;
+        default: return fail(MI_ERR_INVALID, "fft conv: unknown epilogue %d", epi_kind);
+    }
+#undef MI_EPI
+    return launch_check("k_fft_epilogue");
+}
+
+}  // namespace mi
+
+using namespace mi;
+
+extern "C" int mi_otf(int dev, void* stream, const float* psf, int kx, int ky, int kz, float* otf, int fx, int fy, int fz, float scale) {
+    MI_TRY(use_device(dev));
+    MI_REQUIRE(psf && otf, "otf_gpu: null pointer");
+    MI_REQUIRE(kx > 0 && ky > 0 && kz > 0 && fx >= kx && fy >= ky && fz >= kz, "otf_gpu: fft_shape must be >= psf size in every dimension");
+    hipStream_t s = as_stream(stream);
+    AxisPlan ax[3];
+    const int k[3] = {kx, ky, kz}, F[3] = {fx, fy, fz};
+    for (int d = 0; d < 3; ++d) {
+        ax[d].n = ax[d].F = F[d];
+        ax[d].k = k[d];
+        ax[d].shift = F[d] / 2 - (F[d] - k[d]) / 2;  // otf_gpu.cu:121-123 pre-pad + ifftshift (:36-67)
+    }
+    rocfft_plan fwd = nullptr;
+    rocfft_execution_info info = nullptr;
+    DevBuf work, real;
+    const size_t lengths[3] = {(size_t)fx, (size_t)fy, (size_t)fz};
+    int rc = make_plans(s, lengths, &fwd, nullptr, &info, work);
+    if (rc == MI_OK) rc = real.alloc(sizeof(float) * (size_t)fx * fy * fz);
+    if (rc == MI_OK) rc = build_otf(s, fwd, info, psf, ax, real.as<float>(), otf, scale);
+    hipError_t e = hipStreamSynchronize(s);
+    if (info) rocfft_execution_info_destroy(info);
+    if (fwd) rocfft_plan_destroy(fwd);
+    if (rc == MI_OK && e != hipSuccess) rc = fail(MI_ERR_HIP, "mi_otf: %s", hipGetErrorString(e));
+    return rc;
+}

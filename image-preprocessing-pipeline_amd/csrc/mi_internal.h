@@ -1,0 +1,95 @@
+// Internal helpers shared by the libmi_ipp.so translation units (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+
+#include "mi_common.h"
+
+namespace mi {
+
+inline int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+
+// thread-local error sink lives in common.hip
+std::string& last_error_ref();
+
+inline int fail(int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    last_error_ref() = buf;
+    return code;
+}
+
+#define MI_HIP(call)                                                                                     \
+    do {                                                                                                 \
+        hipError_t e_ = (call);                                                                          \
+        if (e_ != hipSuccess)                                                                            \
+            return ::mi::fail(MI_ERR_HIP, "%s:%d: %s failed: %s", __FILE__, __LINE__, #call,             \
+                              hipGetErrorString(e_));                                                    \
+    } while (0)
+
+#define MI_TRY(call)              \
+    do {                          \
+        int rc_ = (call);         \
+        if (rc_ != MI_OK) return rc_; \
+    } while (0)
+
+#define MI_REQUIRE(cond, ...)                                          \
+    do {                                                               \
+        if (!(cond)) return ::mi::fail(MI_ERR_INVALID, __VA_ARGS__);   \
+    } while (0)
+
+// selects the device for the calling thread; every entry point starts with this
+inline int use_device(int dev) {
+    int n = 0;
+    MI_HIP(hipGetDeviceCount(&n));
+    MI_REQUIRE(dev >= 0 && dev < n, "device %d out of range (have %d)", dev, n);
+    MI_HIP(hipSetDevice(dev));
+    return MI_OK;
+}
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline int launch_check(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(MI_ERR_HIP, "launch of %s failed: %s", what, hipGetErrorString(e));
+    return MI_OK;
+}
+
+constexpr float kEpsSingle = 1.1920928955078125e-07f;  // eps('single') = 2^-23 (decon.m:62)
+
+inline unsigned cdiv(size_t a, size_t b) { return static_cast<unsigned>((a + b - 1) / b); }
+
+// RAII device buffer for library-owned scratch
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
+    int alloc(size_t n) {
+        release();
+        if (n == 0) return MI_OK;
+        hipError_t e = hipMalloc(&p, n);
+        if (e != hipSuccess) {
+            p = nullptr;
+            return fail(MI_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", n, hipGetErrorString(e));
+        }
+        bytes = n;
+        return MI_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+}  // namespace mi

@@ -1,0 +1,548 @@
+// MIP-NCC pairwise tile registration on the device (replaces TeraStitcher/src/crossmips:
+// libcrossmips.cpp:101-515 norm_cross_corr_mips and the CPU/CUDA branches of compute_funcs.cu).
+//
+// Device side
+//   k_mips        one streaming pass over both overlap views -> 6 MIPs (compute_3_MIPs, :502-521).
+//                 A lane owns one column j of a 16-row band and keeps the xy maxima in registers; the
+//                 xz row maxima are reduced per wave with DPP shuffles, xz/yz partials are merged with
+//                 integer atomicMax on the float bit pattern (all values >= 0 as the MIPs start at 0).
+//   k_tile_sums   32x32 tile sums with the reference's FLOAT running sum in row/column order
+//                 (seq_cpu_compute_partial_sums, :474-500) -- bit-identical, one lane per tile.
+//   k_ncc         one work-group per shift (u,v): window means from tile sums + border pixels in fp64,
+//                 then num / F1 / F2 in fp64 with a fixed reduction tree (compute_NCC, :1163-1292;
+//                 replaces gpu_NCC_map/gpu_NCC_miss :730-935).  Serves full maps and "missing entry"
+//                 lists of the neighbourhood refinement alike.
+// Host side (this file, plain C++): argmax, neighbourhood refinement, peak widths and the final
+// alignment rules, kept bit-identical in float/int arithmetic to compute_funcs.cu:160-342,1294-1609.
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "mi_crossmips.h"
+#include "mi_internal.h"
+
+using namespace mi;
+
+namespace {
+
+constexpr int TILE = 32;  // TILE_SIDE, compute_funcs.h:66
+constexpr int MIP_ROWS = 16;
+constexpr int NCC_THREADS = 256;
+
+__device__ __forceinline__ void atomic_max_nonneg(float* addr, float v) {
+    atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
+}
+
+// view(k,i,j) = vol[k*slice + (i+i0)*pitch + (j+j0)], z = 0: A, z = 1: B
+__global__ __launch_bounds__(256) void k_mips(const float* __restrict__ A, const float* __restrict__ B, int dimk, int dimi_v, int dimj_v,
+                                               size_t slice, int pitch, int ai0, int aj0, float* __restrict__ xy1, float* __restrict__ xz1,
+                                               float* __restrict__ yz1, float* __restrict__ xy2, float* __restrict__ xz2,
+                                               float* __restrict__ yz2) {
+    const bool second = blockIdx.z == 1;
+    const float* vol = second ? B : A + (size_t)ai0 * pitch + aj0;
+    float* xy = second ? xy2 : xy1;
+    float* xz = second ? xz2 : xz1;
+    float* yz = second ? yz2 : yz1;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int i0 = blockIdx.y * MIP_ROWS;
+    const int rows = min(MIP_ROWS, dimi_v - i0);
+    const bool live = j < dimj_v;
+    float best[MIP_ROWS];
+#pragma unroll
+    for (int r = 0; r < MIP_ROWS; ++r) best[r] = 0.0f;
+    for (int k = 0; k < dimk; ++k) {
+        const float* p = vol + (size_t)k * slice + (size_t)i0 * pitch + j;
+        float colmax = 0.0f;
+#pragma unroll
+        for (int r = 0; r < MIP_ROWS; ++r) {
+            float v = 0.0f;
+            if (live && r < rows) v = p[(size_t)r * pitch];
+            best[r] = fmaxf(best[r], v);
+            colmax = fmaxf(colmax, v);
+            float rowmax = v;  // max over the 64 columns of this wave
+            for (int off = 32; off > 0; off >>= 1) rowmax = fmaxf(rowmax, __shfl_xor(rowmax, off, 64));
+            if ((threadIdx.x & 63) == 0 && r < rows) atomic_max_nonneg(&xz[(size_t)(i0 + r) * dimk + k], rowmax);
+        }
+        if (live) atomic_max_nonneg(&yz[(size_t)j * dimk + k], colmax);
+    }
+    if (live) {
+#pragma unroll
+        for (int r = 0; r < MIP_ROWS; ++r)
+            if (r < rows) xy[(size_t)(i0 + r) * dimj_v + j] = best[r];
+    }
+}
+
+__global__ void k_tile_sums(const float* __restrict__ img, int height, int width, float* __restrict__ ps) {
+    const int ph = height / TILE, pw = width / TILE;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ph * pw) return;
+    const int ti = t / pw, tj = t % pw;
+    const float* p = img + (size_t)ti * TILE * width + tj * TILE;
+    float s = 0.0f;
+    for (int l = 0; l < TILE; ++l)
+        for (int k = 0; k < TILE; ++k) s += p[(size_t)l * width + k];
+    ps[t] = s;
+}
+
+__device__ __forceinline__ double block_sum(double v, double* sh) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double r = 0.0;
+    for (int w = 0; w < NCC_THREADS / 64; ++w) r += sh[w];
+    return r;
+}
+
+// sum of mip over rows [r0,r0+nr) x cols [c0,c0+nc) (per-lane partial): interior tiles from ps, border
+// pixels directly (compute_funcs.cu:1186-1262); falls back to all pixels when ps == nullptr
+__device__ double window_partial(const float* __restrict__ mip, const float* __restrict__ ps, int dimv, int r0, int c0, int nr, int nc) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = NCC_THREADS / 64;
+    double acc = 0.0;
+    int su = r0, eu = r0, sv = c0, ev = c0;  // empty tiled region by default
+    if (ps) {
+        su = (r0 + TILE - 1) / TILE * TILE;
+        sv = (c0 + TILE - 1) / TILE * TILE;
+        eu = (r0 + nr) / TILE * TILE;
+        ev = (c0 + nc) / TILE * TILE;
+        if (su >= eu || sv >= ev) { su = eu = r0; sv = ev = c0; }
+        const int pw = dimv / TILE, tu = (eu - su) / TILE, tv = (ev - sv) / TILE;
+        for (int t = threadIdx.x; t < tu * tv; t += NCC_THREADS) acc += (double)ps[(su / TILE + t / tv) * pw + sv / TILE + t % tv];
+    }
+    for (int i = r0 + wave; i < r0 + nr; i += nw) {
+        const float* row = mip + (size_t)i * dimv;
+        if (i < su || i >= eu) {
+            for (int j = c0 + lane; j < c0 + nc; j += 64) acc += (double)row[j];
+        } else {
+            for (int j = c0 + lane; j < sv; j += 64) acc += (double)row[j];
+            for (int j = ev + lane; j < c0 + nc; j += 64) acc += (double)row[j];
+        }
+    }
+    return acc;
+}
+
+// NCC for shift (u,v).  Full map: blockIdx.x -> (u,v) row-major over [-du,du] x [-dv,dv].  List mode
+// (list != nullptr): entry q = blockIdx.x has u = list[3q], v = list[3q+1], output slot list[3q+2].
+__global__ __launch_bounds__(NCC_THREADS) void k_ncc(const float* __restrict__ m1, const float* __restrict__ m2, int dimu, int dimv,
+                                                      int du, int dv, const float* __restrict__ ps1, const float* __restrict__ ps2,
+                                                      const int* __restrict__ list, float* __restrict__ out) {
+    __shared__ double sh[NCC_THREADS / 64];
+    int u, v, slot;
+    if (list) {
+        u = list[3 * blockIdx.x];
+        v = list[3 * blockIdx.x + 1];
+        slot = list[3 * blockIdx.x + 2];
+    } else {
+        u = (int)(blockIdx.x / (2 * dv + 1)) - du;
+        v = (int)(blockIdx.x % (2 * dv + 1)) - dv;
+        slot = blockIdx.x;
+    }
+    const int nr = dimu - abs(u), nc = dimv - abs(v);
+    if (nr <= 0 || nc <= 0) {  // reference: empty loops, 0/0 (compute_funcs.cu:1277-1290)
+        if (threadIdx.x == 0) out[slot] = __int_as_float(0x7fc00000);
+        return;
+    }
+    const int a_u = max(u, 0), a_v = max(v, 0), b_u = max(-u, 0), b_v = max(-v, 0);
+    const bool tiled = ps1 && ps2 && dimu >= TILE && dimv >= TILE;
+    double fm = block_sum(window_partial(m1, tiled ? ps1 : nullptr, dimv, a_u, a_v, nr, nc), sh);
+    double tm = block_sum(window_partial(m2, tiled ? ps2 : nullptr, dimv, b_u, b_v, nr, nc), sh);
+    fm /= (double)(nr * nc);
+    tm /= (double)(nr * nc);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = NCC_THREADS / 64;
+    double num = 0.0, f1 = 0.0, f2 = 0.0;
+    for (int i = wave; i < nr; i += nw) {
+        const float* p = m1 + (size_t)(a_u + i) * dimv + a_v;
+        const float* q = m2 + (size_t)(b_u + i) * dimv + b_v;
+        for (int j = lane; j < nc; j += 64) {
+            const double f = (double)p[j], t = (double)q[j];
+            const double fp = f - fm, tp = t - tm;
+            num += f * tp;
+            f1 += fp * fp;
+            f2 += tp * tp;
+        }
+    }
+    num = block_sum(num, sh);
+    f1 = block_sum(f1, sh);
+    f2 = block_sum(f2, sh);
+    if (threadIdx.x == 0) out[slot] = (float)(num / sqrt(f1 * f2));
+}
+
+// ------------------------------------------------------------------------------------------------ host logic
+inline int imin(int a, int b) { return a < b ? a : b; }
+inline int imax(int a, int b) { return a > b ? a : b; }
+
+// compute_MAX_ind (compute_funcs.cu:1294-1305)
+int argmax_first(const float* v, int len) {
+    float best = v[0];
+    int ind = 0;
+    for (int i = 0; i < len; ++i)
+        if (v[i] > best) { best = v[i]; ind = i; }
+    return ind;
+}
+
+// half width of the peak at `ind` along one direction of the (2*wR1+1) x (2*wR2+1) window
+// (compute_NCC_width, compute_funcs.cu:160-282).  `second_bound` is the limit of the slope-projection
+// loops, which the reference takes from the horizontal range for both directions (:252,267); where it
+// exceeds this direction's own range the reference indexes outside the window, so it is clamped.
+int peak_half_width(const mi_ncc_params& P, const float* M, int ind, int step, int range, int second_bound) {
+#pragma clang fp contract(off)  // the float expression order below is part of the specification
+    if (range < P.minDim_NCCmap) return P.INF_W;
+    second_bound = imin(second_bound, range);
+    const float thr = P.widthThr * M[ind];
+    bool found = false;
+    int w = 1;
+    while (w <= range && !found) {
+        if (M[ind - w * step] <= thr) found = true; else ++w;
+    }
+    found = false;
+    while (w <= range && !found) {
+        if (M[ind + w * step] <= thr) found = true; else ++w;
+    }
+    if (found) return w;
+    float prec = M[ind - P.minPoints * step];
+    int dist = P.minPoints + 1;
+    while (dist <= second_bound && !found) {
+        if (M[ind - dist * step] >= prec) found = true;
+        else { prec = M[ind - dist * step]; ++dist; }
+    }
+    if (dist < 2 * P.minPoints) w = P.INF_W;
+    else w = (int)std::floor((float)((dist - 1) * (M[ind] - thr) / (M[ind] - prec)));
+    found = false;
+    prec = M[ind + P.minPoints * step];
+    dist = P.minPoints + 1;
+    while (dist <= second_bound && !found) {
+        if (M[ind + dist * step] >= prec) found = true;
+        else { prec = M[ind + dist * step]; ++dist; }
+    }
+    if (dist < 2 * P.minPoints) w = P.INF_W;
+    else w = imin(imax(w, (int)std::floor((float)((dist - 1) * (M[ind] - thr) / (M[ind] - prec)))), P.INF_W - 1);
+    return w;
+}
+
+// compute_NCC_alignment (compute_funcs.cu:297-342)
+void combine_axis(const mi_ncc_params& P, mi_ncc_descr* R, int ax, int d1, float p1, int w1, int d2, float p2, int w2) {
+#pragma clang fp contract(off)
+    if (w1 == 1) w1 = P.INF_W;
+    if (w2 == 1) w2 = P.INF_W;
+    const bool ok1 = p1 >= P.maxThr && w1 < P.INF_W, ok2 = p2 >= P.maxThr && w2 < P.INF_W;
+    int d;
+    float p;
+    int w;
+    if (ok1 && ok2) {
+        if (std::abs(d1 - d2) < imin(w1, w2)) {
+            const float mean = (p1 * d1 + p2 * d2) / (p1 + p2);
+            d = (int)std::floor((double)mean + 0.5);
+            p = (p1 * p1 + p2 * p2) / (p1 + p2);
+            w = imax(w1, w2);
+        } else if (p1 / w1 > p2 / w2) { d = d1; p = p1; w = w1; }
+        else { d = d2; p = p2; w = w2; }
+    } else if (ok1) { d = d1; p = p1; w = w1; }
+    else if (ok2) { d = d2; p = p2; w = w2; }
+    else { d = P.INV_COORD; p = P.UNR_NCC; w = P.INF_W; }
+    R->coord[ax] = d;
+    R->NCC_maxs[ax] = p;
+    R->NCC_widths[ax] = w;
+}
+
+struct PlaneGeom {  // one of the three MIP planes
+    int dimu, dimv;     // MIP extents
+    int delayu, delayv; // search half ranges
+    int wu, wv;         // window half extents (wRangeThr)
+    size_t mip1, mip2, ps1, ps2, map;  // float offsets inside the workspace
+    bool tiled;
+};
+
+struct Workspace {
+    DevBuf buf;       // floats: MIPs | tile sums | maps | miss results
+    DevBuf list;      // ints: (u, v, slot) triples of missing entries
+    size_t floats = 0;
+    int list_cap = 0;
+};
+
+int ncc_list(hipStream_t s, const float* base, const PlaneGeom& g, const int* d_list, int n, float* d_out) {
+    hipLaunchKernelGGL(k_ncc, dim3(n), dim3(NCC_THREADS), 0, s, base + g.mip1, base + g.mip2, g.dimu, g.dimv, g.delayu, g.delayv,
+                       g.tiled ? base + g.ps1 : nullptr, g.tiled ? base + g.ps2 : nullptr, d_list, d_out);
+    return launch_check("k_ncc(list)");
+}
+
+// compute_Neighborhood (compute_funcs.cu:1324-1592): win = (2wu+1)x(2wv+1) window around the peak,
+// re-centred up to maxIter times; entries exposed by a move are computed on the device.
+int refine_neighbourhood(hipStream_t s, const mi_ncc_params& P, const float* map, const PlaneGeom& g, const float* d_base, Workspace& ws,
+                         std::vector<float>& win, int* du, int* dv, bool* failed) {
+    const int H = 2 * g.wu + 1, W = 2 * g.wv + 1, Wm = 2 * g.delayv + 1;
+    int ind_max = argmax_first(map, (2 * g.delayu + 1) * Wm);
+    const int initu = imin(imax(0, ind_max / Wm - g.wu), 2 * (g.delayu - g.wu));
+    const int initv = imin(imax(0, ind_max % Wm - g.wv), 2 * (g.delayv - g.wv));
+    MI_REQUIRE(initu >= 0 && initv >= 0, "CrossMIPs: negative index detected (initi)");
+    win.assign((size_t)H * W, 0.0f);
+    for (int r = 0; r < H; ++r) std::memcpy(&win[(size_t)r * W], &map[(size_t)(initu + r) * Wm + initv], sizeof(float) * W);
+    *du = initu - g.delayu + g.wu;
+    *dv = initv - g.delayv + g.wv;
+    ind_max = W * (ind_max / Wm - initu) + (ind_max % Wm - initv);
+    const int ind_ref = W * g.wu + g.wv;
+    std::vector<float> old;
+    std::vector<int> miss;
+    for (int it = 0; it < P.maxIter && ind_max != ind_ref; ++it) {
+        const int deltau = ind_max / W - g.wu, deltav = ind_max % W - g.wv;
+        old = win;
+        *du += deltau;
+        *dv += deltav;
+        miss.clear();
+        for (int r = 0; r < H; ++r)
+            for (int c = 0; c < W; ++c) {
+                const int sr = r + deltau, sc = c + deltav;
+                if (sr >= 0 && sr < H && sc >= 0 && sc < W) win[(size_t)r * W + c] = old[(size_t)sr * W + sc];
+                else { miss.push_back(r - g.wu + *du); miss.push_back(c - g.wv + *dv); miss.push_back(r * W + c); }
+            }
+        const int n_miss = (int)miss.size() / 3;
+        MI_REQUIRE(n_miss == H * W - (H - std::abs(deltau)) * (W - std::abs(deltav)), "CrossMIPs: incomplete NCC map in compute_Neighborhood");
+        if (n_miss > 0) {
+            if (ws.list_cap < n_miss) {
+                MI_TRY(ws.list.alloc(sizeof(int) * 3 * (size_t)n_miss));
+                ws.list_cap = n_miss;
+            }
+            float* d_res = ws.buf.as<float>() + ws.floats;  // H*W result slots reserved behind the maps
+            MI_HIP(hipMemcpyAsync(ws.list.p, miss.data(), sizeof(int) * miss.size(), hipMemcpyHostToDevice, s));
+            MI_TRY(ncc_list(s, d_base, g, ws.list.as<int>(), n_miss, d_res));
+            std::vector<float> res((size_t)H * W);
+            MI_HIP(hipMemcpyAsync(res.data(), d_res, sizeof(float) * H * W, hipMemcpyDeviceToHost, s));
+            MI_HIP(hipStreamSynchronize(s));
+            for (int q = 0; q < n_miss; ++q) win[miss[3 * q + 2]] = res[miss[3 * q + 2]];
+        }
+        ind_max = argmax_first(win.data(), H * W);
+    }
+    if (ind_ref != ind_max) {
+        *du += ind_max / W - g.wu;
+        *dv += ind_max % W - g.wv;
+        *failed = true;
+    }
+    return MI_OK;
+}
+
+struct PairPlan {
+    int dimk, dimi_v, dimj_v;
+    int delayi, delayj, delayk;
+    int ai0, aj0;
+    PlaneGeom g[3];
+    size_t total_floats, map_floats, map_begin, res_floats;
+};
+
+int plan_pair(int dimk, int dimi, int dimj, int nk, int ni, int nj, int delayk, int delayi, int delayj, int side, mi_ncc_params* p,
+              PairPlan& pl) {
+    MI_REQUIRE(p, "CrossMIPs: missing configuration parameters");
+    if (p->enhance) return fail(MI_ERR_UNSUPPORTED, "CrossMIPs: enhance is not built (PDAlgoMIPNCC.cpp:81 never enables it)");
+    MI_REQUIRE(dimk > 0 && dimi > 0 && dimj > 0, "CrossMIPs: empty stack");
+    MI_REQUIRE(nk == 0, "CrossMIPs: nk must be 0 (CrossMIPs.h: assumed 0 by the current implementation)");
+    MI_REQUIRE(side == MI_NORTH_SOUTH || side == MI_WEST_EAST, "CrossMIPs: unexpected alignment configuration");
+    MI_REQUIRE(ni >= 0 && nj >= 0 && ni < dimi && nj < dimj, "CrossMIPs: initial offsets outside the stack");
+    MI_REQUIRE(delayi >= 0 && delayj >= 0 && delayk >= 0, "CrossMIPs: negative search range");
+    MI_REQUIRE(!(p->wRangeThr_i > delayi || p->wRangeThr_j > delayj || p->wRangeThr_k > delayk),
+               "CrossMIPs: one or more parameters: wRangeThr_i[=%d], wRangeThr_j[=%d], wRangeThr_k[=%d] are too large with respect to: "
+               "delayi[=%d], delayj[=%d], delayik[=%d]",
+               p->wRangeThr_i, p->wRangeThr_j, p->wRangeThr_k, delayi, delayj, delayk);
+    MI_REQUIRE(p->wRangeThr_i >= 0 && p->wRangeThr_j >= 0 && p->wRangeThr_k >= 0 && p->minPoints >= 1 && p->maxIter >= 0,
+               "CrossMIPs: invalid parameters");
+    // libcrossmips.cpp:260-262,275-277
+    delayi = imin(delayi, imax(0, dimi - ni - p->minDim_NCCsrc));
+    delayj = imin(delayj, imax(0, dimj - nj - p->minDim_NCCsrc));
+    delayk = imin(delayk, imax(0, dimk - nk - p->minDim_NCCsrc));
+    p->wRangeThr_i = imin(p->wRangeThr_i, delayi);
+    p->wRangeThr_j = imin(p->wRangeThr_j, delayj);
+    p->wRangeThr_k = imin(p->wRangeThr_k, delayk);
+    pl.dimk = dimk;
+    pl.dimi_v = side == MI_NORTH_SOUTH ? dimi - ni : dimi;
+    pl.dimj_v = side == MI_WEST_EAST ? dimj - nj : dimj;
+    pl.ai0 = side == MI_NORTH_SOUTH ? ni : 0;
+    pl.aj0 = side == MI_WEST_EAST ? nj : 0;
+    pl.delayi = delayi; pl.delayj = delayj; pl.delayk = delayk;
+    const int mu[3] = {pl.dimi_v, pl.dimi_v, pl.dimj_v}, mv[3] = {pl.dimj_v, dimk, dimk};
+    const int du[3] = {delayi, delayi, delayj}, dv[3] = {delayj, delayk, delayk};
+    const int wu[3] = {p->wRangeThr_i, p->wRangeThr_i, p->wRangeThr_j}, wv[3] = {p->wRangeThr_j, p->wRangeThr_k, p->wRangeThr_k};
+    size_t off = 0;
+    auto take = [&off](size_t n) { size_t o = off; off += (n + 3) / 4 * 4; return o; };
+    for (int m = 0; m < 3; ++m) {
+        PlaneGeom& g = pl.g[m];
+        g.dimu = mu[m]; g.dimv = mv[m]; g.delayu = du[m]; g.delayv = dv[m]; g.wu = wu[m]; g.wv = wv[m];
+        g.tiled = (g.dimu / TILE) * (g.dimv / TILE) > 0;
+    }
+    // MIPs first (one memset covers them), then tile sums, then maps (one D2H covers them)
+    for (int m = 0; m < 3; ++m) pl.g[m].mip1 = take((size_t)pl.g[m].dimu * pl.g[m].dimv);
+    for (int m = 0; m < 3; ++m) pl.g[m].mip2 = take((size_t)pl.g[m].dimu * pl.g[m].dimv);
+    const size_t mip_end = off;
+    for (int m = 0; m < 3; ++m) {
+        const size_t nt = (size_t)(pl.g[m].dimu / TILE) * (pl.g[m].dimv / TILE);
+        pl.g[m].ps1 = take(nt);
+        pl.g[m].ps2 = take(nt);
+    }
+    pl.map_begin = off;
+    size_t res = 0;
+    for (int m = 0; m < 3; ++m) {
+        pl.g[m].map = take((size_t)(2 * du[m] + 1) * (2 * dv[m] + 1));
+        res = std::max(res, (size_t)(2 * wu[m] + 1) * (2 * wv[m] + 1));
+    }
+    pl.map_floats = off - pl.map_begin;
+    pl.res_floats = res;
+    pl.total_floats = off;  // miss results live behind this
+    (void)mip_end;
+    return MI_OK;
+}
+
+int run_pair(hipStream_t s, const float* A, const float* B, int dimi, int dimj, int ni, int nj, int side, mi_ncc_params* p,
+             const PairPlan& pl, Workspace& ws, mi_ncc_descr* out, std::vector<float>& host_maps) {
+    const size_t need = pl.total_floats + pl.res_floats;
+    if (ws.buf.bytes < sizeof(float) * need) MI_TRY(ws.buf.alloc(sizeof(float) * need));
+    ws.floats = pl.total_floats;
+    float* base = ws.buf.as<float>();
+    // six MIPs start at 0 (libcrossmips.cpp:319-337)
+    MI_HIP(hipMemsetAsync(base, 0, sizeof(float) * pl.g[0].ps1, s));
+    dim3 grid((pl.dimj_v + 255) / 256, (pl.dimi_v + MIP_ROWS - 1) / MIP_ROWS, 2);
+    hipLaunchKernelGGL(k_mips, grid, dim3(256), 0, s, A, B, pl.dimk, pl.dimi_v, pl.dimj_v, (size_t)dimi * dimj, dimj, pl.ai0, pl.aj0,
+                       base + pl.g[0].mip1, base + pl.g[1].mip1, base + pl.g[2].mip1, base + pl.g[0].mip2, base + pl.g[1].mip2,
+                       base + pl.g[2].mip2);
+    MI_TRY(launch_check("k_mips"));
+    for (int m = 0; m < 3; ++m) {
+        const PlaneGeom& g = pl.g[m];
+        if (g.tiled) {
+            const int nt = (g.dimu / TILE) * (g.dimv / TILE);
+            hipLaunchKernelGGL(k_tile_sums, dim3((nt + 63) / 64), dim3(64), 0, s, base + g.mip1, g.dimu, g.dimv, base + g.ps1);
+            hipLaunchKernelGGL(k_tile_sums, dim3((nt + 63) / 64), dim3(64), 0, s, base + g.mip2, g.dimu, g.dimv, base + g.ps2);
+            MI_TRY(launch_check("k_tile_sums"));
+        }
+        hipLaunchKernelGGL(k_ncc, dim3((2 * g.delayu + 1) * (2 * g.delayv + 1)), dim3(NCC_THREADS), 0, s, base + g.mip1, base + g.mip2,
+                           g.dimu, g.dimv, g.delayu, g.delayv, g.tiled ? base + g.ps1 : nullptr, g.tiled ? base + g.ps2 : nullptr,
+                           (const int*)nullptr, base + g.map);
+        MI_TRY(launch_check("k_ncc(map)"));
+    }
+    host_maps.resize(pl.map_floats);
+    MI_HIP(hipMemcpyAsync(host_maps.data(), base + pl.map_begin, sizeof(float) * pl.map_floats, hipMemcpyDeviceToHost, s));
+    MI_HIP(hipStreamSynchronize(s));
+
+    std::vector<float> win[3];
+    int du[3], dv[3];
+    bool failed[3] = {false, false, false};
+    for (int m = 0; m < 3; ++m)
+        MI_TRY(refine_neighbourhood(s, *p, host_maps.data() + (pl.g[m].map - pl.map_begin), pl.g[m], base, ws, win[m], &du[m], &dv[m],
+                                    &failed[m]));
+    // compute_Alignment (compute_funcs.cu:1597-1609)
+    int w1[3], w2[3];
+    float peak[3];
+    for (int m = 0; m < 3; ++m) {
+        const PlaneGeom& g = pl.g[m];
+        const int rowlen = 2 * g.wv + 1, c = g.wu * rowlen + g.wv;
+        peak[m] = win[m][c];
+        if (failed[m]) { w1[m] = w2[m] = p->INF_W; continue; }
+        w2[m] = peak_half_width(*p, win[m].data(), c, 1, g.wv, g.wv);
+        w1[m] = peak_half_width(*p, win[m].data(), c, rowlen, g.wu, g.wv);
+    }
+    combine_axis(*p, out, 0, du[0], peak[0], w1[0], du[1], peak[1], w1[1]);  // V: xy rows, xz rows
+    combine_axis(*p, out, 1, dv[0], peak[0], w2[0], du[2], peak[2], w1[2]);  // H: xy cols, yz rows
+    combine_axis(*p, out, 2, dv[1], peak[1], w2[1], dv[2], peak[2], w2[2]);  // D: xz cols, yz cols
+    if (side == MI_NORTH_SOUTH) out->coord[0] += ni; else out->coord[1] += nj;  // libcrossmips.cpp:483-486
+    return MI_OK;
+}
+
+}  // namespace
+
+extern "C" void mi_ncc_default_params(int displ_max_V, int displ_max_H, int displ_max_D, mi_ncc_params* p) {
+    if (!p) return;
+    const int width_max = 30;  // S_NCC_WIDTH_MAX, stitcher/S_config.h:86
+    p->enhance = 0;
+    p->maxIter = 2;
+    p->maxThr = 0.10f;
+    p->UNR_NCC = 0.0f;  // S_NCC_PEAK_MIN, S_config.h:83
+    p->minPoints = 3;
+    p->wRangeThr_i = imin(displ_max_V, width_max - 1);
+    p->wRangeThr_j = imin(displ_max_H, width_max - 1);
+    p->wRangeThr_k = imin(displ_max_D, width_max - 1);
+    p->minDim_NCCsrc = 25;
+    p->minDim_NCCmap = 3;
+    p->INF_W = imax(p->wRangeThr_i, imax(p->wRangeThr_j, p->wRangeThr_k)) + 1;
+    p->widthThr = 0.80f;
+    p->INV_COORD = 0;
+}
+
+extern "C" int mi_ncc_mips(int dev, void* stream, const float* A, const float* B, int dimk, int dimi, int dimj, int nk, int ni, int nj,
+                           int delayk, int delayi, int delayj, int side, mi_ncc_params* p, mi_ncc_descr* out) {
+    MI_TRY(use_device(dev));
+    MI_REQUIRE(A && B && out, "CrossMIPs: null pointer");
+    PairPlan pl;
+    MI_TRY(plan_pair(dimk, dimi, dimj, nk, ni, nj, delayk, delayi, delayj, side, p, pl));
+    Workspace ws;
+    std::vector<float> maps;
+    return run_pair(as_stream(stream), A, B, dimi, dimj, ni, nj, side, p, pl, ws, out, maps);
+}
+
+extern "C" int mi_ncc_mips_host(int dev, void* stream, const float* A, const float* B, int dimk, int dimi, int dimj, int nk, int ni,
+                                int nj, int delayk, int delayi, int delayj, int side, mi_ncc_params* p, mi_ncc_descr* out) {
+    MI_TRY(use_device(dev));
+    MI_REQUIRE(A && B && out, "CrossMIPs: null pointer");
+    MI_REQUIRE(dimk > 0 && dimi > 0 && dimj > 0, "CrossMIPs: empty stack");
+    hipStream_t s = as_stream(stream);
+    const size_t n = (size_t)dimk * dimi * dimj;
+    DevBuf dA, dB;
+    MI_TRY(dA.alloc(sizeof(float) * n));
+    MI_TRY(dB.alloc(sizeof(float) * n));
+    MI_HIP(hipMemcpyAsync(dA.p, A, sizeof(float) * n, hipMemcpyHostToDevice, s));
+    MI_HIP(hipMemcpyAsync(dB.p, B, sizeof(float) * n, hipMemcpyHostToDevice, s));
+    int rc = mi_ncc_mips(dev, stream, dA.as<float>(), dB.as<float>(), dimk, dimi, dimj, nk, ni, nj, delayk, delayi, delayj, side, p, out);
+    hipError_t e = hipStreamSynchronize(s);
+    if (rc == MI_OK && e != hipSuccess) rc = fail(MI_ERR_HIP, "mi_ncc_mips_host: %s", hipGetErrorString(e));
+    return rc;
+}
+
+extern "C" int mi_ncc_mips_batch(int dev, void* stream, int n_pairs, const float* const* tiles, const int* a_idx, const int* b_idx,
+                                 int dimk, int dimi, int dimj, const int* ni, const int* nj, int delayk, int delayi, int delayj,
+                                 const int* side, mi_ncc_params* params, mi_ncc_descr* out) {
+    MI_TRY(use_device(dev));
+    MI_REQUIRE(n_pairs >= 0, "mi_ncc_mips_batch: negative pair count");
+    if (n_pairs == 0) return MI_OK;
+    MI_REQUIRE(tiles && a_idx && b_idx && ni && nj && side && params && out, "mi_ncc_mips_batch: null pointer");
+    Workspace ws;  // shared by all pairs: one allocation for the whole batch
+    std::vector<float> maps;
+    for (int q = 0; q < n_pairs; ++q) {
+        PairPlan pl;
+        MI_TRY(plan_pair(dimk, dimi, dimj, 0, ni[q], nj[q], delayk, delayi, delayj, side[q], &params[q], pl));
+        MI_REQUIRE(tiles[a_idx[q]] && tiles[b_idx[q]], "mi_ncc_mips_batch: null tile for pair %d", q);
+        MI_TRY(run_pair(as_stream(stream), tiles[a_idx[q]], tiles[b_idx[q]], dimi, dimj, ni[q], nj[q], side[q], &params[q], pl, ws, &out[q],
+                        maps));
+    }
+    return MI_OK;
+}
+
+extern "C" int mi_ncc_compute_mips(int dev, void* stream, const float* A, const float* B, int dimk, int dimi, int dimj, int ni, int nj,
+                                   int side, float* xy1, float* xz1, float* yz1, float* xy2, float* xz2, float* yz2) {
+    MI_TRY(use_device(dev));
+    MI_REQUIRE(A && B && xy1 && xz1 && yz1 && xy2 && xz2 && yz2, "compute_3_MIPs: null pointer");
+    MI_REQUIRE(side == MI_NORTH_SOUTH || side == MI_WEST_EAST, "CrossMIPs: unexpected alignment configuration");
+    MI_REQUIRE(dimk > 0 && ni >= 0 && nj >= 0 && ni < dimi && nj < dimj, "compute_3_MIPs: invalid extents");
+    hipStream_t s = as_stream(stream);
+    const int dimi_v = side == MI_NORTH_SOUTH ? dimi - ni : dimi, dimj_v = side == MI_WEST_EAST ? dimj - nj : dimj;
+    float* outs[6] = {xy1, xz1, yz1, xy2, xz2, yz2};
+    const size_t sz[3] = {(size_t)dimi_v * dimj_v, (size_t)dimi_v * dimk, (size_t)dimj_v * dimk};
+    for (int m = 0; m < 6; ++m) MI_HIP(hipMemsetAsync(outs[m], 0, sizeof(float) * sz[m % 3], s));
+    dim3 grid((dimj_v + 255) / 256, (dimi_v + MIP_ROWS - 1) / MIP_ROWS, 2);
+    hipLaunchKernelGGL(k_mips, grid, dim3(256), 0, s, A, B, dimk, dimi_v, dimj_v, (size_t)dimi * dimj, dimj, side == MI_NORTH_SOUTH ? ni : 0,
+                       side == MI_WEST_EAST ? nj : 0, xy1, xz1, yz1, xy2, xz2, yz2);
+    return launch_check("k_mips");
+}
+
+extern "C" int mi_ncc_compute_map(int dev, void* stream, const float* mip1, const float* mip2, int dimu, int dimv, int delayu, int delayv,
+                                  float* map) {
+    MI_TRY(use_device(dev));
+    MI_REQUIRE(mip1 && mip2 && map, "compute_NCC_map: null pointer");
+    MI_REQUIRE(dimu > 0 && dimv > 0 && delayu >= 0 && delayv >= 0, "compute_NCC_map: invalid extents");
+    hipStream_t s = as_stream(stream);
+    const int nt = (dimu / TILE) * (dimv / TILE);
+    DevBuf ps;
+    if (nt > 0) {
+        MI_TRY(ps.alloc(sizeof(float) * 2 * (size_t)nt));
+        hipLaunchKernelGGL(k_tile_sums, dim3((nt + 63) / 64), dim3(64), 0, s, mip1, dimu, dimv, ps.as<float>());
+        hipLaunchKernelGGL(k_tile_sums, dim3((nt + 63) / 64), dim3(64), 0, s, mip2, dimu, dimv, ps.as<float>() + nt);
+        MI_TRY(launch_check("k_tile_sums"));
+    }
+    hipLaunchKernelGGL(k_ncc, dim3((2 * delayu + 1) * (2 * delayv + 1)), dim3(NCC_THREADS), 0, s, mip1, mip2, dimu, dimv, delayu, delayv,
+                       nt > 0 ? ps.as<float>() : nullptr, nt > 0 ? ps.as<float>() + nt : nullptr, (const int*)nullptr, map);
+    MI_TRY(launch_check("k_ncc(map)"));
+    MI_HIP(hipStreamSynchronize(s));  // ps dies at scope exit
+    return MI_OK;
+}

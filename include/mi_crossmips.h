@@ -1,0 +1,87 @@
+/* mi_crossmips.h -- C ABI of TeraStitcher's MIP-NCC pairwise tile registration (crossmips).
+ *
+ * Replaces  NCC_descr_t* norm_cross_corr_mips(real_t* A, real_t* B, int dimk, int dimi, int dimj,
+ *           int nk, int ni, int nj, int delayk, int delayi, int delayj, int side, NCC_parms_t* p)
+ * (TeraStitcher/src/crossmips/CrossMIPs.h:89-91, libcrossmips.cpp:101-515) as called by
+ * PDAlgoMIPNCC::execute (stitcher/PDAlgoMIPNCC.cpp:96-97).  Differences from the reference ABI:
+ * an error code instead of iom::exception / exit(); the result is written into a caller-owned
+ * struct instead of a new-allocated one; no static device buffers (re-entrant per stream).
+ * Conventions: include/mi_common.h.
+ */
+#ifndef MI_CROSSMIPS_H
+#define MI_CROSSMIPS_H
+
+#include "mi_common.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI_NORTH_SOUTH 0 /* CrossMIPs.h:51 (== dir_vertical, Displacement.h:44) */
+#define MI_WEST_EAST 1   /* CrossMIPs.h:52 (== dir_horizontal) */
+
+/* NCC_descr_t (CrossMIPs.h:58-62): offset of B relative to A as (V, H, D), peak values, half widths */
+typedef struct {
+    int coord[3];
+    float NCC_maxs[3];
+    int NCC_widths[3];
+} mi_ncc_descr;
+
+/* NCC_parms_t (CrossMIPs.h:65-86) without the `enhance` transform tables (enhance must be 0:
+ * PDAlgoMIPNCC.cpp:81 always passes false).  wRangeThr_* are IN-OUT: clamped to the clamped search
+ * ranges exactly like libcrossmips.cpp:275-277, and read back by the caller (PDAlgoMIPNCC.cpp:104-106). */
+typedef struct {
+    int enhance;
+    int maxIter;
+    float maxThr;
+    float widthThr;
+    int wRangeThr_i, wRangeThr_j, wRangeThr_k;
+    int minPoints;
+    int minDim_NCCsrc;
+    int minDim_NCCmap;
+    float UNR_NCC;
+    int INF_W;
+    int INV_COORD;
+} mi_ncc_params;
+
+/* the fixed parameter set of PDAlgoMIPNCC::execute (PDAlgoMIPNCC.cpp:80-94) for search ranges
+ * displ_max_{V,H,D} */
+void mi_ncc_default_params(int displ_max_V, int displ_max_H, int displ_max_D, mi_ncc_params* p);
+
+/* One pair; A and B are DEVICE pointers to dimk*dimi*dimj floats in [0,1] (read-only).
+ * Semantics: Appendix B of SURVEY.md / libcrossmips.cpp:101-515.  Returns MI_ERR_INVALID where the
+ * reference throws (wRangeThr > delay :212-219, bad side :316, nk != 0).  Synchronises `stream`. */
+int mi_ncc_mips(int dev, void* stream, const float* A, const float* B, int dimk, int dimi, int dimj,
+                int nk, int ni, int nj, int delayk, int delayi, int delayj, int side,
+                mi_ncc_params* p, mi_ncc_descr* out);
+
+/* Same with HOST pointers (drop-in for the reference signature: uploads both tiles first). */
+int mi_ncc_mips_host(int dev, void* stream, const float* A, const float* B, int dimk, int dimi, int dimj,
+                     int nk, int ni, int nj, int delayk, int delayi, int delayj, int side,
+                     mi_ncc_params* p, mi_ncc_descr* out);
+
+/* n_pairs independent pairs with device-resident tiles: pair q aligns tiles[a_idx[q]] and
+ * tiles[b_idx[q]] (all tiles dimk*dimi*dimj) with side[q], nominal offsets ni[q]/nj[q] and its own
+ * in-out params[q]; results in out[q].  All index/param arrays are [host].  Synchronises. */
+int mi_ncc_mips_batch(int dev, void* stream, int n_pairs, const float* const* tiles,
+                      const int* a_idx, const int* b_idx, int dimk, int dimi, int dimj,
+                      const int* ni, const int* nj, int delayk, int delayi, int delayj, const int* side,
+                      mi_ncc_params* params, mi_ncc_descr* out);
+
+/* ---- building blocks (exposed for parity tests against the reference's exported helpers) ------ */
+
+/* compute_3_MIPs (compute_funcs.cu:502-521) on the overlap views selected by (side, ni, nj):
+ * writes xy[dimi_v*dimj_v], xz[dimi_v*dimk], yz[dimj_v*dimk] for A then B (6 device arrays). */
+int mi_ncc_compute_mips(int dev, void* stream, const float* A, const float* B, int dimk, int dimi, int dimj,
+                        int ni, int nj, int side, float* xy1, float* xz1, float* yz1,
+                        float* xy2, float* xz2, float* yz2);
+
+/* compute_NCC_map (compute_funcs.cu:939-1160): map[(2*delayu+1)*(2*delayv+1)] (device) from two
+ * dimu x dimv MIPs (device); fp64 accumulation, one work-group per (u, v). */
+int mi_ncc_compute_map(int dev, void* stream, const float* mip1, const float* mip2, int dimu, int dimv,
+                       int delayu, int delayv, float* map);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI_CROSSMIPS_H */

@@ -1,0 +1,141 @@
+/* mi_lsdeconv.h -- C ABI of the Richardson-Lucy deconvolution hot path (LsDeconvolveMultiGPU).
+ *
+ * Each entry point names the reference interface it replaces (paths relative to the reference
+ * repository).  Conventions: include/mi_common.h.  The reference-side binding a maintainer would
+ * add is shown in INTEGRATION.md.
+ */
+#ifndef MI_LSDECONV_H
+#define MI_LSDECONV_H
+
+#include "mi_common.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* boundary rule of a "same"-size 3-D convolution */
+typedef enum {
+    MI_BOUNDARY_ZERO = 0,      /* MATLAB convn(a,h,'same'): decon.m:61,64,70 */
+    MI_BOUNDARY_REPLICATE = 1, /* conv3d_gpu clamp: conv3d_gpu.cu:82-91 */
+    MI_BOUNDARY_CIRCULAR = 2   /* fftn/ifftn wrap on the given shape: decon.m:162-172 */
+} mi_boundary;
+
+/* convolution engine */
+typedef enum {
+    MI_ENGINE_AUTO = 0,   /* cost model on PSF taps / volume size (mi_engine_select) */
+    MI_ENGINE_DIRECT = 1, /* LDS-tiled direct convolution (fp32 FMA) */
+    MI_ENGINE_FFT = 2,    /* rocFFT R2C/C2R convolution, padded as the boundary rule requires */
+    MI_ENGINE_MFMA = 3    /* direct convolution as a banded implicit GEMM on fp32 MFMA */
+} mi_engine;
+
+/* ---- single kernels -------------------------------------------------------------------------- */
+
+/* out = conv3d_gpu(img, kernel)   [LsDeconvolveMultiGPU/conv3d_gpu.cu:101-148, kernel :68-99]
+ * img/out: nx*ny*nz floats, ker: kx*ky*kz floats (device), all extents >= 1; out must not alias img. */
+int mi_conv3d_replicate(int dev, void* stream, const float* img, const float* ker, float* out,
+                        int nx, int ny, int nz, int kx, int ky, int kz);
+
+/* out = convn(img, ker, 'same') with the chosen boundary rule and engine   [decon.m:61,64,70]
+ * ker extents must be odd for MI_ENGINE_FFT (always true for LsMakePSF PSFs: LsMakePSF.m:32-38). */
+int mi_conv3d(int dev, void* stream, const float* img, const float* ker, float* out,
+              int nx, int ny, int nz, int kx, int ky, int kz, int boundary, int engine);
+
+/* x = gauss3d_gpu(x, sigma[, ksize])   [LsDeconvolveMultiGPU/gauss3d_gpu.cu:209-311, :81-204]
+ * Overwrites vol (destructive, like the reference); work = nx*ny*nz floats of scratch.
+ * sigma [host] = {sx, sy, sz}; ksize [host] = {kx, ky, kz} or NULL for 2*ceil(3*sigma)+1 (:244-261);
+ * ksize <= 51 (MAX_KERNEL_SIZE, :77).  Axes are filtered X, Y, Z with replicate boundary. */
+int mi_gauss3d_inplace(int dev, void* stream, float* vol, float* work, int nx, int ny, int nz,
+                       const float* sigma, const int* ksize);
+
+/* bl = edgetaper_3d(bl, psf)   [LsDeconvolveMultiGPU/edgetaper_3d.m:13-44, make_taper.m:13-35]
+ * In place. work = nx*ny*nz floats.  psf need not be normalised (it is divided by its sum, :14).
+ * Only the border shell where the taper mask is < 1 is convolved. */
+int mi_edgetaper3d(int dev, void* stream, float* bl, float* work, const float* psf,
+                   int nx, int ny, int nz, int kx, int ky, int kz);
+
+/* otf = fftn(ifftshift(zero-pad-centre(psf)))   [supplements/otf_gpu.cu:36-67,125-144; decon.m:131-133]
+ * Written as the R2C half spectrum: complex interleaved float2 [fz][fy][fx/2+1], scaled by `scale`
+ * (pass 1.0f for the plain OTF). work: mi_otf_workspace_bytes(). */
+int mi_otf(int dev, void* stream, const float* psf, int kx, int ky, int kz, float* otf, int fx, int fy, int fz,
+           float scale);
+
+/* dst = single(src) * scale : im2single of uint16 blocks (LsDeconv.m:860,873; scale = 1/65535) */
+int mi_u16_to_f32(int dev, void* stream, const uint16_t* src, float* dst, size_t n, float scale);
+
+/* dst = max(src - dark, 0)   [LsDeconv.m:924-927], in place allowed */
+int mi_subtract_dark(int dev, void* stream, const float* src, float* dst, size_t n, float dark);
+
+/* *norm2 [host] = sqrt(sum(x.^2)) accumulated in double (norm(bl(:)), decon.m:47,109). Synchronises. */
+int mi_norm2(int dev, void* stream, const float* x, size_t n, double* norm2);
+
+/* zero-pad-centre / crop   [decon.m:323-374: pre = floor(missing/2), post = ceil] */
+int mi_pad_center(int dev, void* stream, const float* src, int nx, int ny, int nz, float* dst, int fx, int fy, int fz);
+int mi_crop_center(int dev, void* stream, const float* src, int fx, int fy, int fz, float* dst, int nx, int ny, int nz);
+
+/* ---- RL context: the two half-steps of one iteration (what the slab driver calls between halo
+ *      exchanges) ------------------------------------------------------------------------------ */
+
+typedef struct mi_rl_ctx mi_rl_ctx;
+
+/* Prepares PSF-derived constants for arrays of shape (nz, ny, nx): flipped/padded PSF for the direct
+ * engines, OTF + rocFFT plans + padded work buffers for the FFT engine (all owned by the context).
+ * psf_inv may be NULL (= psf flipped in all axes, LsDeconv.m:163).  Synchronises. */
+int mi_rl_create(int dev, void* stream, int nx, int ny, int nz, const float* psf, const float* psf_inv,
+                 int kx, int ky, int kz, int boundary, int engine, mi_rl_ctx** ctx);
+int mi_rl_destroy(mi_rl_ctx* ctx);
+/* engine actually chosen (mi_engine) and device bytes held by the context */
+int mi_rl_engine(const mi_rl_ctx* ctx);
+size_t mi_rl_device_bytes(const mi_rl_ctx* ctx);
+
+/* ratio = bl ./ max(conv(bl, psf), eps('single'))          [decon.m:61-63 / :162-167] */
+int mi_rl_forward_ratio(mi_rl_ctx* ctx, void* stream, const float* bl, float* ratio);
+/* bl = abs(bl .* conv(ratio, psf_inv))                      [decon.m:64,76,79 / :169-186]
+ * or, with lambda > 0 and reg != NULL, abs(bl.*conv.*(1-lambda) + reg.*lambda)   [decon.m:69-71] */
+int mi_rl_adjoint_update(mi_rl_ctx* ctx, void* stream, const float* ratio, float* bl, float lambda, const float* reg);
+/* reg = convn(bl, R, 'same'), R = ones(3,3,3)/26 with centre 0   [decon.m:42,70] */
+int mi_rl_reg_term(int dev, void* stream, const float* bl, float* reg, int nx, int ny, int nz);
+
+/* ---- whole loops ------------------------------------------------------------------------------ */
+
+typedef struct {
+    int niter;               /* decon.m: niter */
+    float lambda;            /* Tikhonov weight (decon.m:41,69) */
+    float stop_criterion;    /* % change of ||bl||_2, 0 disables (decon.m:108-118) */
+    int regularize_interval; /* decon.m:54-55 */
+    int engine;              /* mi_engine */
+    int skip_edgetaper;      /* 0: like decon.m:50/143; 1: caller tapered already (bench times the loop only) */
+    int gauss_taps;          /* 0: gauss3d_gpu(bl,0.5) default 5 taps (GPU path); 3: imgaussfilt3 CPU flavour */
+} mi_rl_options;
+
+/* bl = deconSpatial(bl, psf, psf_inv, ...)   [decon.m:26-124]  in place; iters_done [host] may be NULL.
+ * Allocates its scratch (2-3 volumes) with hipMalloc and frees it before returning.  Synchronises. */
+int mi_rl_spatial(int dev, void* stream, float* bl, const float* psf, const float* psf_inv,
+                  int nx, int ny, int nz, int kx, int ky, int kz, const mi_rl_options* opt, int* iters_done);
+
+/* bl = deconFFT(bl, psf, fft_shape, ...)   [decon.m:127-204]  in place; (fx,fy,fz) >= (nx,ny,nz).
+ * Synchronises. */
+int mi_rl_fft(int dev, void* stream, float* bl, const float* psf, int nx, int ny, int nz, int kx, int ky, int kz,
+              int fx, int fy, int fz, const mi_rl_options* opt, int* iters_done);
+
+/* bl = decon(bl, psf, niter, lambda, stop_criterion, regularize_interval, device_id, use_fft, fft_shape,
+ *            adaptive_psf)   [decon.m:1-23]; adaptive_psf != 0 returns MI_ERR_UNSUPPORTED. */
+int mi_decon(int dev, void* stream, float* bl, const float* psf, const float* psf_inv,
+             int nx, int ny, int nz, int kx, int ky, int kz, const mi_rl_options* opt,
+             int use_fft, const int* fft_shape_xyz, int adaptive_psf, int* iters_done);
+
+/* cost model used by MI_ENGINE_AUTO: returns MI_ENGINE_DIRECT or MI_ENGINE_FFT */
+int mi_engine_select(int nx, int ny, int nz, int kx, int ky, int kz, int boundary);
+
+/* next 7-smooth length >= n   [LsDeconv.m:405-419] */
+int mi_next_fast_len(int n);
+
+/* ---- slab halo helpers (multi-GPU sharding along Y) ------------------------------------------- */
+/* copy rows [y0, y0+rows) of every z-plane of a (nz, ny, nx) volume into/out of a packed
+ * (nz, rows, nx) buffer -- the send/recv staging of the RCCL halo exchange */
+int mi_pack_rows(int dev, void* stream, const float* vol, int nx, int ny, int nz, int y0, int rows, float* packed);
+int mi_unpack_rows(int dev, void* stream, const float* packed, int nx, int ny, int nz, int y0, int rows, float* vol);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI_LSDECONV_H */

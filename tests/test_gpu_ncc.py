@@ -1,0 +1,113 @@
+"""GPU parity: MIP-NCC registration (through the C ABI) against the golden vectors of the compiled reference
+and against the C oracle.  Integer outputs (offsets, widths, mutated wRangeThr) must be bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ncc_oracle as N
+from tests.golden_util import case_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+def _names(g):
+    return [str(n) for n in g["names"]]
+
+
+@pytest.mark.parametrize("idx", range(13))
+def test_golden_cases(dev, ncc_golden, idx):
+    from ipp_amd import crossmips
+    g = ncc_golden
+    name = _names(g)[idx]
+    A, B, overlap, side, dmax = case_inputs(g, name)
+    a, b = torch.from_numpy(A).to(dev), torch.from_numpy(B).to(dev)
+    d = crossmips.PDAlgoMIPNCC.execute(a, b, dmax[0], dmax[1], dmax[2], side, overlap)
+    assert d.VHD_coords == list(g[f"{name}/coord"])
+    assert d.NCC_widths == list(g[f"{name}/NCC_widths"])
+    assert d.wRangeThrs == list(g[f"{name}/wRangeThr"])
+    assert d.invWidths == [int(g[f"{name}/INF_W"])] * 3
+    assert d.delays == list(dmax)
+    want = g[f"{name}/NCC_maxs"]
+    assert np.allclose(np.array(d.NCC_maxs, np.float32), want, rtol=0, atol=2e-6, equal_nan=True)
+    # building blocks: MIPs exact, NCC maps to float rounding of an fp64 sum in a different order
+    dimk, dimi, dimj = A.shape
+    ni = dimi - overlap if side == 0 else 0
+    nj = dimj - overlap if side == 1 else 0
+    mips = crossmips.compute_mips(a, b, ni, nj, side)
+    for m, nm in enumerate(["xy1", "xz1", "yz1", "xy2", "xz2", "yz2"]):
+        assert np.array_equal(mips[m].cpu().numpy(), g[f"{name}/mip_{nm}"]), nm
+    di, dj, dk = (int(v) for v in g[f"{name}/delays_ijk"])
+    for m, (nm, du, dv) in enumerate([("xy", di, dj), ("xz", di, dk), ("yz", dj, dk)]):
+        got = crossmips.compute_NCC_map(mips[m], mips[m + 3], du, dv).cpu().numpy()
+        want_map = g[f"{name}/map_{nm}"]
+        assert np.array_equal(np.isnan(got), np.isnan(want_map))
+        assert np.allclose(got, want_map, rtol=0, atol=2e-6, equal_nan=True), nm
+
+
+def test_random_pairs_vs_oracle(dev):
+    from ipp_amd import crossmips
+    rng = np.random.default_rng(2024)
+    for trial in range(6):
+        side = trial % 2
+        shift = tuple(int(v) for v in rng.integers(-5, 6, size=3))
+        A, B = N.tile_pair((30, 120, 136), 40, side, shift, seed=300 + trial)
+        want = N.pdalgo_execute(A, B, 9, 9, 4, side, 40, kind="oracle")
+        got = crossmips.PDAlgoMIPNCC.execute(torch.from_numpy(A).to(dev), torch.from_numpy(B).to(dev), 9, 9, 4, side, 40)
+        assert got.VHD_coords == want["coord"] and got.NCC_widths == want["NCC_widths"]
+        assert got.wRangeThrs == want["wRangeThr"]
+        assert np.allclose(np.array(got.NCC_maxs, np.float32), want["NCC_maxs"], atol=2e-6, equal_nan=True)
+
+
+def test_host_pointer_entry_and_errors(dev):
+    import ctypes as C
+    from ipp_amd import capi, crossmips
+    A, B = N.tile_pair((26, 64, 64), 30, 1, (1, 0, 0), seed=1)
+    p = crossmips.NCC_parms_t(6, 6, 1)
+    out = capi.NccDescr()
+    rc = capi.lib().mi_ncc_mips_host(0, None, A.ctypes.data, B.ctypes.data, 26, 64, 64, 0, 0, 34, 1, 6, 6, 1, C.byref(p),
+                                     C.byref(out))
+    assert rc == 0
+    want = N.pdalgo_execute(A, B, 6, 6, 1, 1, 30, kind="oracle")
+    assert list(out.coord) == want["coord"] and list(out.NCC_widths) == want["NCC_widths"]
+    # wRangeThr larger than the search range: the reference throws (libcrossmips.cpp:212-219)
+    p = crossmips.NCC_parms_t(10, 10, 10)
+    with pytest.raises(capi.MiError, match="too large"):
+        crossmips.norm_cross_corr_mips(A, B, ni=0, nj=34, delayk=2, delayi=10, delayj=10, side=1, NCC_params=p)
+    with pytest.raises(ValueError, match="missing configuration"):
+        crossmips.norm_cross_corr_mips(A, B, nj=34, side=1)
+    with pytest.raises(capi.MiError, match="unexpected alignment"):
+        crossmips.norm_cross_corr_mips(A, B, nj=34, delayk=1, delayi=6, delayj=6, side=3, NCC_params=crossmips.NCC_parms_t(6, 6, 1))
+    with pytest.raises(ValueError, match="same dimensions"):
+        crossmips.PDAlgoMIPNCC.execute(torch.zeros((4, 8, 8)), torch.zeros((4, 8, 9)), 1, 1, 1, 0, 4)
+
+
+def test_grid_batch_recovers_jitter(dev):
+    """3x3 grid cut from one bead field with per-tile integer jitter (config 5 in miniature): every reliable
+    pair must return nominal + jitter difference, and the batch entry must equal pair-by-pair calls."""
+    from ipp_amd import crossmips
+    rng = np.random.default_rng(77)
+    tile, ov, R_, C_ = (30, 128, 128), 40, 3, 3
+    step = tile[1] - ov
+    field = N.bead_field((tile[0] + 8, R_ * step + ov + 16, C_ * step + ov + 16), seed=9, density=1 / 300)
+    jit = rng.integers(-3, 4, size=(R_, C_, 3))
+    jit[..., 2] = rng.integers(-1, 2, size=(R_, C_))
+    tiles = [[None] * C_ for _ in range(R_)]
+    for r in range(R_):
+        for c in range(C_):
+            v, h, d = jit[r, c]
+            z0, y0, x0 = 4 + d, 8 + r * step + v, 8 + c * step + h
+            tiles[r][c] = torch.from_numpy(np.ascontiguousarray(field[z0:z0 + tile[0], y0:y0 + tile[1], x0:x0 + tile[2]])).to(dev)
+    res = crossmips.compute_displacements(tiles, ov, ov, 8, 8, 3)
+    assert len(res) == 2 * R_ * C_ - R_ - C_
+    for (r, c, rb, cb, direction), d in res.items():
+        dj = jit[rb, cb] - jit[r, c]
+        nominal = [step if direction == 0 else 0, step if direction == 1 else 0, 0]
+        for ax in range(2):
+            assert d.NCC_widths[ax] < d.invWidths[ax], (r, c, direction)
+            assert d.VHD_coords[ax] == nominal[ax] + int(dj[ax])
+        single = crossmips.PDAlgoMIPNCC.execute(tiles[r][c], tiles[rb][cb], 8, 8, 3, direction, ov)
+        assert single.VHD_coords == d.VHD_coords and single.NCC_widths == d.NCC_widths
+    # pair sharding across ranks: the union of the shards is the whole set, no overlap
+    shards = [crossmips.compute_displacements(tiles, ov, ov, 8, 8, 3, rank=k, world_size=2) for k in range(2)]
+    assert set(shards[0]) | set(shards[1]) == set(res) and not (set(shards[0]) & set(shards[1]))
+    assert 0.0 <= next(iter(res.values())).evalReliability(0) <= 1.0

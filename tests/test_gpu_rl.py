@@ -1,0 +1,232 @@
+"""GPU parity: the HIP Richardson-Lucy path (through the C ABI) against the CPU oracle on the same seeded inputs.
+Tolerance for floating point: 1e-4 relative to the array maximum (BASELINE.json north_star), tighter where
+the reference's own scripts use a tighter bound."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import rl_oracle as R
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-4
+
+
+def _rel(got, want):
+    return float(np.abs(got.astype(np.float64) - want.astype(np.float64)).max() / max(float(np.abs(want).max()), 1e-30))
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+# ------------------------------------------------------------------ conv3d_gpu (R7)
+@pytest.mark.parametrize("shape,kshape", [((22, 25, 24), (3, 5, 7)), ((5, 6, 7), (3, 3, 3)), ((3, 3, 3), (3, 3, 3)),
+                                          ((16, 40, 150), (15, 9, 9)), ((9, 17, 130), (1, 1, 5)), ((12, 20, 33), (4, 2, 6)),
+                                          ((6, 7, 5), (9, 11, 13))])
+def test_conv3d_gpu_matches_oracle(dev, shape, kshape):
+    from ipp_amd import decon
+    rng = np.random.default_rng(42)
+    img = rng.random(shape, dtype=np.float32)
+    ker = rng.random(kshape, dtype=np.float32)
+    got = decon.conv3d_gpu(_t(img, dev), _t(ker, dev)).cpu().numpy()
+    want = R.conv3d_replicate_loops(img, ker) if any(k % 2 == 0 for k in kshape) else R.conv3d_replicate(img, ker)
+    assert got.shape == img.shape
+    assert np.abs(got - want).max() < 5e-4 * max(1.0, np.abs(want).max() / 50) and _rel(got, want) < 1e-5
+
+
+def test_conv3d_all_ones_centre_27(dev):
+    from ipp_amd import decon
+    out = decon.conv3d_gpu(torch.ones((5, 5, 5), device=dev), torch.ones((3, 3, 3), device=dev)).cpu().numpy()
+    assert abs(out[2, 2, 2] - 27.0) < 1e-4 and np.allclose(out, 27.0, atol=1e-4)  # edgetaper_3d_test.m:142-164
+
+
+@pytest.mark.parametrize("boundary", [0, 1, 2])
+@pytest.mark.parametrize("engine", [1, 2])
+def test_convn_same_boundaries_and_engines(dev, boundary, engine):
+    from ipp_amd import decon
+    rng = np.random.default_rng(7)
+    img = rng.random((14, 30, 41), dtype=np.float32)
+    ker = rng.random((5, 7, 9), dtype=np.float32)
+    got = decon.convn_same(_t(img, dev), _t(ker, dev), boundary=boundary, engine=engine).cpu().numpy()
+    if boundary == 0:
+        want = R.convn_same(img, ker)
+    elif boundary == 1:
+        want = R.conv3d_replicate(img, ker)
+    else:
+        from scipy import ndimage
+        want = ndimage.convolve(img.astype(np.float64), ker.astype(np.float64), mode="wrap").astype(np.float32)
+    assert _rel(got, want) < 2e-6 if engine == 1 else _rel(got, want) < 2e-5
+
+
+def test_conv3d_errors(dev):
+    from ipp_amd import capi, decon
+    with pytest.raises(ValueError):
+        decon.conv3d_gpu(torch.ones((5, 5), device=dev), torch.ones((3, 3, 3), device=dev))
+    with pytest.raises(TypeError):
+        decon.conv3d_gpu(torch.ones((5, 5, 5), device=dev, dtype=torch.float64), torch.ones((3, 3, 3), device=dev))
+    a = torch.ones((4, 4, 4), device=dev)
+    rc = capi.lib().mi_conv3d(0, None, a.data_ptr(), a.data_ptr(), a.data_ptr(), 4, 4, 4, 4, 4, 4, 0, 1)
+    assert rc == -1 and "aliased" in capi.last_error()
+
+
+# ------------------------------------------------------------------ gauss3d_gpu (R8)
+@pytest.mark.parametrize("shape", [(32, 64, 32), (20, 33, 47)])
+@pytest.mark.parametrize("sigma,ksize", [(2.5, None), ([1.5, 1.5, 2.5], [9, 11, 15]), ([0.5, 0.5, 2.5], None),
+                                         (0.25, 3), (8, 51), ([0.5, 0.5, 2.5], [13, 13, 25])])
+def test_gauss3d_gpu_matches_oracle(dev, shape, sigma, ksize):
+    from ipp_amd import decon
+    rng = np.random.default_rng(0)
+    x = rng.random(shape, dtype=np.float32)
+    t = _t(x, dev)
+    out = decon.gauss3d_gpu(t, sigma, ksize)
+    assert out.data_ptr() == t.data_ptr()  # destructive in place like the MEX (gauss3d_gpu.cu:289-293)
+    assert np.abs(out.cpu().numpy() - R.gauss3d(x, sigma, ksize)).max() < 5e-5  # gauss3d_gpu_test.m:16
+
+
+def test_gauss3d_errors(dev):
+    from ipp_amd import capi, decon
+    with pytest.raises(capi.MiError, match="MAX_KERNEL_SIZE"):
+        decon.gauss3d_gpu(torch.ones((8, 8, 8), device=dev), 1.0, 53)
+    with pytest.raises(ValueError):
+        decon.gauss3d_gpu(torch.ones((8, 8, 8), device=dev), [1.0, 2.0])
+
+
+# ------------------------------------------------------------------ edgetaper_3d (R6)
+@pytest.mark.parametrize("shape,kshape", [((32, 64, 64), (7, 15, 15)), ((5, 6, 7), (3, 3, 3)), ((3, 3, 3), (3, 3, 3)),
+                                          ((40, 50, 140), (21, 9, 9))])
+def test_edgetaper_matches_oracle(dev, shape, kshape):
+    from ipp_amd import decon
+    rng = np.random.default_rng(42)
+    bl = rng.random(shape, dtype=np.float32)
+    psf = R.gaussian_psf(kshape, [k / 5.0 for k in kshape]) * 3.0  # un-normalised on purpose (edgetaper_3d.m:14)
+    got = decon.edgetaper_3d(_t(bl, dev), _t(psf, dev)).cpu().numpy()
+    want = R.edgetaper_3d(bl, psf)
+    assert got.shape == bl.shape and np.abs(got - want).max() < 1e-5  # edgetaper_3d_test.m:4,40
+    assert got.min() >= 0.0 and got.max() <= 1.0 + 1e-6               # :77-83
+
+
+def test_edgetaper_rejects_negative_psf(dev):
+    from ipp_amd import decon
+    psf = -torch.ones((3, 3, 3), device=dev)
+    with pytest.raises(AssertionError):
+        decon.edgetaper_3d(torch.ones((8, 8, 8), device=dev), psf)
+
+
+# ------------------------------------------------------------------ otf_gpu (K3) / ingest / pad
+@pytest.mark.parametrize("F_xyz", [(25, 24, 20), (32, 32, 16), (21, 15, 9)])
+def test_otf_gpu_matches_definition(dev, F_xyz):
+    from ipp_amd import decon
+    psf = R.gaussian_psf((9, 15, 15), (2, 3, 3))
+    otf = decon.otf_gpu(_t(psf, dev), F_xyz).cpu().numpy()
+    ref = R.otf_from_psf(psf, (F_xyz[2], F_xyz[1], F_xyz[0]))[:, :, : F_xyz[0] // 2 + 1]
+    assert otf.shape == ref.shape
+    assert np.abs(otf - ref).max() / np.abs(ref).max() < 2e-6  # otf_gpu_test.m:82
+
+
+def test_u16_ingest_pad_crop_norm(dev):
+    from ipp_amd import decon
+    rng = np.random.default_rng(3)
+    u = rng.integers(0, 65536, size=(7, 9, 13), dtype=np.uint16)
+    got = decon.im2single(u).cpu().numpy()
+    assert np.array_equal(got, R.u16_to_f32(u)) or np.abs(got - R.u16_to_f32(u)).max() < 1e-7
+    a = _t(rng.random((6, 7, 9), dtype=np.float32), dev)
+    p, pre, post = decon.pad_block_to_fft_shape(a, (12, 10, 9))
+    want, wpre, wpost = R.pad_block_to_fft_shape(a.cpu().numpy(), (9, 10, 12))
+    assert np.array_equal(p.cpu().numpy(), want) and pre == wpre[::-1] and post == wpost[::-1]
+    assert torch.equal(decon.unpad_block(p, pre, post), a)
+    assert decon.norm2(a) == pytest.approx(float(np.linalg.norm(a.cpu().numpy().astype(np.float64))), rel=1e-12)
+    with pytest.raises(AssertionError):
+        decon.pad_block_to_fft_shape(a, (4, 4, 4))
+    assert [decon.next_fast_len(n) for n in (11, 2078, 512)] == [12, 2100, 512]
+
+
+# ------------------------------------------------------------------ decon (R1-R5)
+def _case(shape, kshape, sig, seed):
+    psf = R.gaussian_psf(kshape, sig)
+    return R.bead_volume(shape, seed=seed, psf=psf), psf
+
+
+@pytest.mark.parametrize("engine", [1, 2])
+@pytest.mark.parametrize("niter,lam,interval", [(5, 0.0, 0), (7, 0.0, 3), (7, 0.05, 2)])
+def test_decon_spatial_matches_oracle(dev, engine, niter, lam, interval):
+    from ipp_amd import decon
+    vol, psf = _case((20, 36, 44), (7, 5, 5), (1.5, 1.0, 1.0), 11)
+    want = R.decon_spatial(vol, psf, niter, lam, 0.0, interval)
+    got = decon.decon(_t(vol, dev), decon.make_psf_struct(psf), niter, lam, 0.0, interval, 1, False, None, False,
+                      engine=engine).cpu().numpy()
+    assert _rel(got, want) < REL
+
+
+@pytest.mark.parametrize("F_xyz", [None, (48, 40, 24)])
+@pytest.mark.parametrize("niter,lam,interval", [(5, 0.0, 0), (7, 0.05, 2)])
+def test_decon_fft_matches_oracle(dev, F_xyz, niter, lam, interval):
+    from ipp_amd import decon
+    vol, psf = _case((20, 36, 44), (7, 5, 5), (1.5, 1.0, 1.0), 12)
+    Fz = vol.shape if F_xyz is None else (F_xyz[2], F_xyz[1], F_xyz[0])
+    want = R.decon_fft(vol, psf, Fz, niter, lam, 0.0, interval)
+    got = decon.decon(_t(vol, dev), psf, niter, lam, 0.0, interval, 1, True,
+                      F_xyz if F_xyz is not None else (vol.shape[2], vol.shape[1], vol.shape[0]), False).cpu().numpy()
+    assert got.shape == vol.shape and _rel(got, want) < REL
+
+
+def test_decon_fft_semantics_on_direct_engine(dev):
+    # the deconFFT placement quirk (even fft_shape -> one-voxel offset) reproduced by both engines
+    from ipp_amd import decon
+    vol, psf = _case((16, 24, 32), (5, 5, 7), (1.0, 1.0, 1.5), 13)
+    F = (vol.shape[2], vol.shape[1], vol.shape[0])
+    a = decon.decon(_t(vol, dev), psf, 4, 0.0, 0.0, 0, 1, True, F, False, engine=1).cpu().numpy()
+    b = decon.decon(_t(vol, dev), psf, 4, 0.0, 0.0, 0, 1, True, F, False, engine=2).cpu().numpy()
+    assert _rel(a, b) < REL and _rel(a, R.decon_fft(vol, psf, vol.shape, 4)) < REL
+
+
+def test_decon_stop_criterion_and_numpy_roundtrip(dev):
+    from ipp_amd import decon
+    vol, psf = _case((12, 16, 16), (5, 5, 5), (1, 1, 1), 4)
+    want, it_want = R.decon_spatial(vol, psf, 50, stop_criterion=5.0, return_iters=True)
+    got, it = decon.decon(vol, psf, 50, 0.0, 5.0, 0, 1, False, None, False, return_iters=True)
+    assert isinstance(got, np.ndarray) and it == it_want and _rel(got, want) < REL
+
+
+def test_decon_config1_shape_parity(dev):
+    # BASELINE config 1 (256x256x64, 9x9x15 Gaussian PSF, 10 iterations) on a 1/8 crop for the oracle's sake
+    from ipp_amd import decon
+    psf = R.gaussian_psf((15, 9, 9), (2.5, 1.5, 1.5))
+    vol = R.bead_volume((32, 128, 128), seed=1234, psf=psf)
+    want = R.decon_spatial(vol, psf, 10, 0.0, 0.0, 3)
+    for engine in (1, 2):
+        got = decon.decon(_t(vol, dev), psf, 10, 0.0, 0.0, 3, 1, False, None, False, engine=engine).cpu().numpy()
+        assert _rel(got, want) < REL
+
+
+def test_decon_errors(dev):
+    from ipp_amd import capi, decon
+    vol = torch.ones((8, 8, 8), device=dev)
+    psf = np.ones((3, 3, 3), np.float32)
+    with pytest.raises(ValueError):
+        decon.decon(vol, psf, 1, 0, 0, 0, 1, False, None, True)  # adaptive needs use_fft (decwrap.py:216-217)
+    with pytest.raises(NotImplementedError):
+        decon.decon(vol, psf, 1, 0, 0, 0, 1, True, (8, 8, 8), True)
+    with pytest.raises(capi.MiError, match="cannot pad"):
+        decon.decon(vol, psf, 1, 0, 0, 0, 1, True, (4, 8, 8), False)
+    with pytest.raises(ValueError):
+        decon.decon(vol, psf, 1, 0, 0, 0, 0, False, None, False)  # device 0 = the MATLAB CPU path
+
+
+# ------------------------------------------------------------------ size-independent properties at scale
+def test_properties_at_scale(dev):
+    """256x256x64 (config 1 full size): linearity of the convolution, engines agree, RL keeps the volume
+    non-negative and (for a normalised PSF with circular boundary) conserves the total flux."""
+    from ipp_amd import decon
+    g = torch.Generator(device="cpu").manual_seed(5)
+    a = torch.rand((64, 256, 256), generator=g).to(dev)
+    b = torch.rand((64, 256, 256), generator=g).to(dev)
+    psf = _t(R.gaussian_psf((15, 9, 9), (2.5, 1.5, 1.5)), dev)
+    ca, cb = decon.convn_same(a, psf, engine=1), decon.convn_same(b, psf, engine=1)
+    cab = decon.convn_same(a + 2 * b, psf, engine=1)
+    assert float((cab - (ca + 2 * cb)).abs().max()) < 2e-5
+    assert float((decon.convn_same(a, psf, engine=2) - ca).abs().max()) < 2e-5
+    x = a.clone()
+    s0 = float(x.double().sum())
+    out = decon.decon(x, psf, 5, 0.0, 0.0, 0, 1, True, (256, 256, 64), False, skip_edgetaper=True)
+    assert float(out.min()) >= 0.0 and abs(float(out.double().sum()) - s0) / s0 < 1e-4
