@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""Headline benchmark: RL-deconvolution throughput (Gvoxel*iterations/s) of the MI355X hot path.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step is one Richardson-Lucy iteration (forward blur + ratio, adjoint blur + update; decon.m:162-186) over
+the whole resident volume.  Workload at N = 1: BASELINE.json config C3 -- 2048 x 2048 x 512 fp32 volume,
+31 x 31 x 61 light-sheet PSF, deconFFT semantics (circular on fft_shape = volume shape), lambda = 0,
+regularize_interval = 0, stop_criterion = 0; synthetic seeded data already resident in HBM when the timed
+region starts.  At N > 1 the same volume is cut into N slabs along Y (one rank per GPU, RCCL halo exchange
+over xGMI twice per iteration) => strong scaling.  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+WORKLOADS = {  # name: (volume (z,y,x), psf (z,y,x))
+    "c1": ((64, 256, 256), (15, 9, 9)),
+    "c2": ((256, 1024, 1024), (31, 15, 15)),
+    "c3": ((512, 2048, 2048), (61, 31, 31)),
+}
+HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec (MI355X_MICROARCH.md, chip-level parameters)
+ALGO_BYTES_PER_VOXEL_ITER = 48  # RL FFT path, SURVEY.md section 8d / DESIGN.md
+
+
+def make_psf(kshape):
+    from ipp_amd import psf as P
+    base, _ = P.generate_psf(lambda_em=525.0, lambda_ex=488.0, numerical_aperture=0.4, dxy=100.0, dz=250.0,
+                             refractive_index=1.42, f_cylinder_lens=240.0, slit_width=12.0)
+    return P.resample_psf(base, kshape)
+
+
+def make_volume(shape, device, seed=1234):
+    """Seeded synthetic volume generated on the device: background U(0.01,0.02) + sparse bright beads
+    (SURVEY.md 8d recipe without the host-side PSF blur, which would take minutes at this size)."""
+    import torch
+    g = torch.Generator(device=device).manual_seed(seed)
+    vol = torch.empty(shape, dtype=torch.float32, device=device).uniform_(0.01, 0.02, generator=g)
+    n = vol.numel()
+    nb = max(1, n // 4096)
+    idx = torch.randint(0, n, (nb,), generator=g, device=device)
+    amp = torch.empty(nb, dtype=torch.float32, device=device).uniform_(0.2, 1.0, generator=g)
+    vol.view(-1).index_put_((idx,), amp, accumulate=True)
+    return vol
+
+
+def cpu_baseline(kshape, seconds_budget=20.0):
+    """The oracle (numpy restatement of deconFFT, 1 host thread) on a bounded sub-volume of the same workload."""
+    import numpy as np
+    from oracle import rl_oracle
+    shape = (max(64, kshape[0] + 3), 192, 192)
+    rng = np.random.default_rng(1234)
+    vol = rng.uniform(0.01, 0.02, size=shape).astype(np.float32)
+    psf = make_psf(kshape)
+    otf = rl_oracle.otf_from_psf(psf, shape)
+    iters, t0 = 0, time.perf_counter()
+    bl = vol
+    while True:
+        buf = np.real(np.fft.ifftn(np.fft.fftn(bl.astype(np.float64)) * otf)).astype(np.float32)
+        buf = (bl / np.maximum(buf, rl_oracle.EPS_SINGLE)).astype(np.float32)
+        buf = np.real(np.fft.ifftn(np.fft.fftn(buf.astype(np.float64)) * np.conj(otf))).astype(np.float32)
+        bl = np.abs(bl * buf)
+        iters += 1
+        dt = time.perf_counter() - t0
+        if dt > seconds_budget * 0.5 or iters >= 8:
+            break
+    return {"value": float(np.prod(shape)) * iters / dt / 1e9, "unit": "Gvoxel*iter/s", "cores": 1, "kind": "port",
+            "sample": f"{iters} deconFFT iterations (oracle/rl_oracle.py loop body) on a {shape[2]}x{shape[1]}x{shape[0]} "
+                      f"sub-volume with the {kshape[2]}x{kshape[1]}x{kshape[0]} PSF, numpy pocketfft, 1 thread"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--engine", default="auto", choices=["auto", "direct", "fft"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ncc", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from ipp_amd import capi, decon
+    capi.require_gpu()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+
+    vshape, kshape = WORKLOADS[args.workload]
+    psf_np = make_psf(kshape)
+    engine = {"auto": capi.ENGINE_AUTO, "direct": capi.ENGINE_DIRECT, "fft": capi.ENGINE_FFT}[args.engine]
+    n_vox_global = vshape[0] * vshape[1] * vshape[2]
+
+    if world == 1:
+        bl = make_volume(vshape, dev)
+        ratio = torch.empty_like(bl)
+        ctx = decon.RLContext(vshape, psf_np, None, boundary=capi.BOUNDARY_CIRCULAR, engine=engine, device=dev)
+
+        def step():
+            ctx.forward_ratio(bl, ratio)
+            ctx.adjoint_update(ratio, bl)
+        parallelism = "single"
+        engine_used = ctx.engine
+    else:
+        from ipp_amd import slab
+        drv = slab.SlabRL(vshape, psf_np, rank=rank, world_size=world, device=dev, flavour="fft", engine=engine,
+                          seed=1234)
+        step = drv.iterate
+        parallelism = f"y-slabs x{world}, RCCL halo exchange"
+        engine_used = drv.ctx.engine
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    # HIP events on the stream the kernels are launched on (torch's current stream of this device)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    sync()
+    elapsed = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms_per_step = elapsed * 1e3 / args.steps
+        value = n_vox_global * args.steps / elapsed / 1e9
+        local_vox = n_vox_global / world
+        # dominant "kernel": one RL iteration of the FFT pipeline on this rank's slab
+        achieved = ALGO_BYTES_PER_VOXEL_ITER * local_vox / (dev_ms / args.steps * 1e-3) / 1e9
+        out = {
+            "metric": "RL-deconv Gvoxels/sec", "value": round(value, 4), "unit": "Gvoxel*iter/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "iterations_per_s": round(args.steps / elapsed, 4),
+            "config": {"workload": f"{args.workload}: {vshape[2]}x{vshape[1]}x{vshape[0]} fp32 volume, "
+                                   f"{kshape[2]}x{kshape[1]}x{kshape[0]} PSF, deconFFT semantics, lambda=0, reg_interval=0",
+                       "engine": {1: "direct", 2: "fft"}.get(engine_used, str(engine_used)), "parallelism": parallelism},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "kernel": "rl_iteration (R2C, OTF multiply, C2R, epilogue x2)",
+                         "algorithmic_bytes_per_voxel_iter": ALGO_BYTES_PER_VOXEL_ITER,
+                         "device_ms_per_iteration": round(dev_ms / args.steps, 4)},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(kshape)
+        if not args.no_ncc and world == 1:
+            try:
+                import bench_ncc
+                out["ncc"] = bench_ncc.run(dev)
+            except Exception as e:  # the NCC leg must not hide the headline number
+                out["ncc"] = {"error": repr(e)}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
