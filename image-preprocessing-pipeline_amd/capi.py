@@ -68,6 +68,7 @@ SIGNATURES = {
     "mi_pad_center": (_i, [_i, _vp, _vp, _i, _i, _i, _vp, _i, _i, _i]),
     "mi_crop_center": (_i, [_i, _vp, _vp, _i, _i, _i, _vp, _i, _i, _i]),
     "mi_rl_create": (_i, [_i, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, C.POINTER(_vp)]),
+    "mi_rl_create_ex": (_i, [_i, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _ip, _ip, _i, C.POINTER(_vp)]),
     "mi_rl_destroy": (_i, [_vp]),
     "mi_rl_engine": (_i, [_vp]),
     "mi_rl_device_bytes": (_sz, [_vp]),

@@ -28,8 +28,10 @@ int conv_kernel_offset(int k, int boundary);
 int direct_prepare_psf(hipStream_t s, const float* ker, int kx, int ky, int kz, bool normalise, bool flip, DevBuf& kf,
                        int* kxp_out);
 // offs (optional) = window start offsets {cx, cy, cz}; default conv_kernel_offset(k, boundary)
+// bnd3 (optional) = per-axis boundary rules {x, y, z}; default `boundary` on every axis
 int direct_conv_launch(hipStream_t s, const float* img, const float* kf, float* out, int nx, int ny, int nz, int kx, int ky,
-                       int kz, int kxp, int boundary, int epi_kind, const ConvEpilogue& epi, const int* offs = nullptr);
+                       int kz, int kxp, int boundary, int epi_kind, const ConvEpilogue& epi, const int* offs = nullptr,
+                       const int* bnd3 = nullptr);
 int gauss3d_async(hipStream_t s, float* vol, float* work, int nx, int ny, int nz, const float* sigma, const int* ksize);
 int edgetaper_async(hipStream_t s, float* bl, float* work, const float* psf, int nx, int ny, int nz, int kx, int ky, int kz);
 

@@ -74,8 +74,8 @@ __device__ __forceinline__ float epilogue(float c, size_t idx, int x, int y, int
 template <int EPI>
 __global__ __launch_bounds__(TX* TY) void k_conv3d_direct(const float* __restrict__ img, const float* __restrict__ kf,
                                                            float* __restrict__ out, ConvEpilogue epi, int nx, int ny, int nz,
-                                                           int kx, int ky, int kz, int kxp, int cx, int cy, int cz, int boundary,
-                                                           int gx, int gy, int gz) {
+                                                           int kx, int ky, int kz, int kxp, int cx, int cy, int cz, int bnd_x,
+                                                           int bnd_y, int bnd_z, int gx, int gy, int gz) {
     extern __shared__ __attribute__((aligned(16))) float tile[];
     // XCD-aware renumbering: ids b, b+8, b+16.. share an XCD; give each XCD one contiguous range of
     // tiles and walk z fastest inside it.
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(TX* TY) void k_conv3d_direct(const float* __restric
     float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
 
     for (int dz = 0; dz < kz; ++dz) {
-        const int gzi = wrap_index(bz + dz - cz, nz, boundary);
+        const int gzi = wrap_index(bz + dz - cz, nz, bnd_z);
         if (gzi < 0) continue;  // zero boundary: whole plane is zero (uniform branch)
         const float* plane = img + (size_t)gzi * ny * nx;
         __syncthreads();
@@ -112,8 +112,8 @@ __global__ __launch_bounds__(TX* TY) void k_conv3d_direct(const float* __restric
             int r = i / pitch, c = i - r * pitch;
             float v = 0.0f;
             if (c < TILE_X + kx - 1) {
-                int gyi = wrap_index(y0 + r, ny, boundary);
-                int gxi = wrap_index(x0 + c, nx, boundary);
+                int gyi = wrap_index(y0 + r, ny, bnd_y);
+                int gxi = wrap_index(x0 + c, nx, bnd_x);
                 if (gyi >= 0 && gxi >= 0) v = plane[(size_t)gyi * nx + gxi];
             }
             tile[i] = v;
@@ -172,7 +172,7 @@ int direct_prepare_psf(hipStream_t s, const float* ker, int kx, int ky, int kz, 
 }
 
 int direct_conv_launch(hipStream_t s, const float* img, const float* kf, float* out, int nx, int ny, int nz, int kx, int ky,
-                       int kz, int kxp, int boundary, int epi_kind, const ConvEpilogue& epi, const int* offs) {
+                       int kz, int kxp, int boundary, int epi_kind, const ConvEpilogue& epi, const int* offs, const int* bnd3) {
     const int gx = (nx + TILE_X - 1) / TILE_X, gy = (ny + TY - 1) / TY, gz = nz;
     const size_t total = (size_t)gx * gy * gz;
     MI_REQUIRE(total < (1ull << 31) - 8, "conv3d: volume too large for one launch");
@@ -182,6 +182,7 @@ int direct_conv_launch(hipStream_t s, const float* img, const float* kf, float* 
     const int cx = offs ? offs[0] : conv_kernel_offset(kx, boundary);
     const int cy = offs ? offs[1] : conv_kernel_offset(ky, boundary);
     const int cz = offs ? offs[2] : conv_kernel_offset(kz, boundary);
+    const int bnd_x = bnd3 ? bnd3[0] : boundary, bnd_y = bnd3 ? bnd3[1] : boundary, bnd_z = bnd3 ? bnd3[2] : boundary;
     dim3 grid(chunk * 8), block(TX, TY);
 #define MI_LAUNCH_CONV(E)                                                                                                    \
     do {                                                                                                                     \
@@ -189,7 +190,7 @@ int direct_conv_launch(hipStream_t s, const float* img, const float* kf, float* 
             MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3d_direct<E>),                                   \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                               \
         hipLaunchKernelGGL(k_conv3d_direct<E>, grid, block, lds, s, img, kf, out, epi, nx, ny, nz, kx, ky, kz, kxp, cx, cy, \
-                           cz, boundary, gx, gy, gz);                                                                        \
+                           cz, bnd_x, bnd_y, bnd_z, gx, gy, gz);                                                                        \
     } while (0)
     switch (epi_kind) {
         case EPI_NONE: MI_LAUNCH_CONV(EPI_NONE); break;

@@ -15,10 +15,10 @@ struct AxisPlan {
     int F = 0;      // transform length
     int o = 0;      // offset of the data inside the padded array (replicate: window offset)
     int shift = 0;  // PSF placement shift
+    int boundary = MI_BOUNDARY_ZERO;
 };
 
 struct FftEngine {
-    int boundary = MI_BOUNDARY_ZERO;
     AxisPlan ax[3];  // x, y, z
     bool padded = false;  // F != n or o != 0: inputs are staged through `real`
     rocfft_plan fwd = nullptr, inv = nullptr;
@@ -28,8 +28,9 @@ struct FftEngine {
     bool have_adj = false;
 
     ~FftEngine();
-    int init(hipStream_t s, const int n[3], const int k[3], const int F[3], int boundary, bool deconfft_flavour,
-             const float* psf, const float* psf_inv, bool need_adjoint);
+    // bnd/shift per axis (x, y, z): boundary rule and PSF placement shift (see AxisPlan)
+    int init(hipStream_t s, const int n[3], const int k[3], const int bnd[3], const int shift[3], const float* psf,
+             const float* psf_inv, bool need_adjoint);
     // c = conv(in, psf or its adjoint), then the epilogue of `epi_kind` into out (shape n)
     int conv(hipStream_t s, const float* in, bool adjoint, float* out, int epi_kind, const ConvEpilogue& epi);
     size_t device_bytes() const { return work.bytes + spec.bytes + real.bytes + otf.bytes + otf_adj.bytes; }

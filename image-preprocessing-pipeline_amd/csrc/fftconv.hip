@@ -74,22 +74,19 @@ __global__ __launch_bounds__(kThreads) void k_mul_otf(float2* __restrict__ spec,
 // window [0, n + k - 1) holds clamped samples, zeros beyond
 __global__ __launch_bounds__(kThreads) void k_stage(const float* __restrict__ src, float* __restrict__ dst, int nx, int ny, int nz,
                                                      int Fx, int Fy, int Fz, int ox, int oy, int oz, int kx, int ky, int kz,
-                                                     int replicate) {
+                                                     int rep_x, int rep_y, int rep_z) {
     const size_t total = (size_t)Fx * Fy * Fz;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int x = (int)(i % Fx);
         const size_t r = i / Fx;
         const int y = (int)(r % Fy), z = (int)(r / Fy);
         int sx = x - ox, sy = y - oy, sz = z - oz;
-        float v = 0.0f;
-        if (replicate) {
-            if (x < nx + kx - 1 && y < ny + ky - 1 && z < nz + kz - 1) {
-                sx = min(max(sx, 0), nx - 1); sy = min(max(sy, 0), ny - 1); sz = min(max(sz, 0), nz - 1);
-                v = src[((size_t)sz * ny + sy) * nx + sx];
-            }
-        } else if (sx >= 0 && sx < nx && sy >= 0 && sy < ny && sz >= 0 && sz < nz) {
-            v = src[((size_t)sz * ny + sy) * nx + sx];
-        }
+        // per axis: replicate rule = clamped samples inside [0, n + k - 1), zero rule = zeros outside [0, n)
+        bool ok = true;
+        if (rep_x) { ok = ok && x < nx + kx - 1; sx = min(max(sx, 0), nx - 1); } else ok = ok && sx >= 0 && sx < nx;
+        if (rep_y) { ok = ok && y < ny + ky - 1; sy = min(max(sy, 0), ny - 1); } else ok = ok && sy >= 0 && sy < ny;
+        if (rep_z) { ok = ok && z < nz + kz - 1; sz = min(max(sz, 0), nz - 1); } else ok = ok && sz >= 0 && sz < nz;
+        const float v = ok ? src[((size_t)sz * ny + sy) * nx + sx] : 0.0f;
         dst[i] = v;
     }
 }
@@ -196,20 +193,34 @@ static int make_plans(hipStream_t s, const size_t lengths[3], rocfft_plan* fwd, 
     return MI_OK;
 }
 
-int FftEngine::init(hipStream_t s, const int n[3], const int k[3], const int F[3], int boundary_, bool deconfft_flavour, const float* psf,
+int FftEngine::init(hipStream_t s, const int n[3], const int k[3], const int bnd[3], const int shift[3], const float* psf,
                     const float* psf_inv, bool need_adjoint) {
-    boundary = boundary_;
     padded = false;
+    bool conj_ok = true;
+    int F[3];
     for (int d = 0; d < 3; ++d) {
         AxisPlan& a = ax[d];
         a.n = n[d];
         a.k = k[d];
+        a.boundary = bnd[d];
+        a.shift = shift[d];
+        const int off = k[d] - 1 - shift[d];  // window start offset of the forward convolution
+        MI_REQUIRE(shift[d] >= 0 && off >= 0, "FFT engine: PSF placement shift %d outside [0, %d) on axis %d", shift[d], k[d], d);
+        a.o = 0;
+        if (bnd[d] == MI_BOUNDARY_CIRCULAR) {
+            F[d] = n[d];
+        } else if (bnd[d] == MI_BOUNDARY_REPLICATE) {
+            F[d] = mi_next_fast_len(n[d] + k[d] - 1);
+            a.o = off;
+        } else {
+            F[d] = mi_next_fast_len(n[d] + std::max(off, shift[d]));
+        }
         a.F = F[d];
-        const int off = conv_kernel_offset(k[d], boundary);
-        a.o = boundary == MI_BOUNDARY_REPLICATE ? off : 0;
-        a.shift = deconfft_flavour ? (F[d] / 2 - (F[d] - k[d]) / 2) : (k[d] - 1 - off);
-        MI_REQUIRE(F[d] >= n[d] && F[d] >= k[d], "FFT shape %d smaller than data %d / PSF %d on axis %d", F[d], n[d], k[d], d);
+        MI_REQUIRE(F[d] >= k[d], "FFT shape %d smaller than the PSF extent %d on axis %d", F[d], k[d], d);
         if (a.F != a.n || a.o != 0) padded = true;
+        // conj(OTF) is the adjoint the caller wants when the axis is circular (deconFFT: decon.m:168) or the
+        // placement is symmetric (odd extent, centred)
+        if (bnd[d] != MI_BOUNDARY_CIRCULAR && 2 * shift[d] != k[d] - 1) conj_ok = false;
     }
     n_real = (size_t)F[0] * F[1] * F[2];
     n_spec = (size_t)(F[0] / 2 + 1) * F[1] * F[2];
@@ -220,16 +231,14 @@ int FftEngine::init(hipStream_t s, const int n[3], const int k[3], const int F[3
     MI_TRY(otf.alloc(sizeof(float) * 2 * n_spec));
     const float scale = 1.0f / (float)((double)F[0] * F[1] * F[2]);
     MI_TRY(build_otf(s, fwd, info, psf, ax, real.as<float>(), otf.as<float>(), scale));
-    // deconFFT never sees psf_inv (decon.m:18): its adjoint is conj(otf).  For 'same'-convolution
-    // semantics an explicit psf_inv is just another kernel with the same placement rule.
-    have_adj = need_adjoint && psf_inv != nullptr && !deconfft_flavour;
+    // deconFFT never sees psf_inv (decon.m:18): its adjoint is conj(otf).  For 'same'-convolution semantics
+    // an explicit psf_inv is just another kernel with the same placement rule.
+    have_adj = need_adjoint && psf_inv != nullptr;
     if (have_adj) {
         MI_TRY(otf_adj.alloc(sizeof(float) * 2 * n_spec));
         MI_TRY(build_otf(s, fwd, info, psf_inv, ax, real.as<float>(), otf_adj.as<float>(), scale));
-    } else if (need_adjoint && !deconfft_flavour) {
-        // conj(OTF) equals the OTF of the flipped PSF only when the placement is symmetric (odd extents)
-        for (int d = 0; d < 3; ++d)
-            MI_REQUIRE(k[d] % 2 == 1, "FFT engine: PSF extent %d on axis %d must be odd when psf_inv is implied", k[d], d);
+    } else if (need_adjoint) {
+        MI_REQUIRE(conj_ok, "FFT engine: the implied adjoint (flipped PSF) needs odd PSF extents on non-circular axes");
     }
     return MI_OK;
 }
@@ -240,7 +249,8 @@ int FftEngine::conv(hipStream_t s, const float* in, bool adjoint, float* out, in
     if (padded) {
         hipLaunchKernelGGL(k_stage, dim3(stream_grid(n_real)), dim3(kThreads), 0, s, in, real.as<float>(), ax[0].n, ax[1].n, ax[2].n,
                            ax[0].F, ax[1].F, ax[2].F, ax[0].o, ax[1].o, ax[2].o, ax[0].k, ax[1].k, ax[2].k,
-                           boundary == MI_BOUNDARY_REPLICATE ? 1 : 0);
+                           ax[0].boundary == MI_BOUNDARY_REPLICATE, ax[1].boundary == MI_BOUNDARY_REPLICATE,
+                           ax[2].boundary == MI_BOUNDARY_REPLICATE);
         MI_TRY(launch_check("k_stage"));
         src = real.as<float>();
     }

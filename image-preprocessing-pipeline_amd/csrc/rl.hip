@@ -17,7 +17,7 @@ struct mi_rl_ctx {
     int dev = 0;
     int n[3] = {0, 0, 0};
     int k[3] = {0, 0, 0};
-    int boundary = MI_BOUNDARY_ZERO;
+    int bnd[3] = {MI_BOUNDARY_ZERO, MI_BOUNDARY_ZERO, MI_BOUNDARY_ZERO};
     int engine = MI_ENGINE_DIRECT;
     // direct engine: tap tables + window offsets for the forward and adjoint kernels
     DevBuf kf_fwd, kf_adj;
@@ -46,36 +46,47 @@ extern "C" int mi_engine_select(int nx, int ny, int nz, int kx, int ky, int kz, 
     return (odd && t_fft < t_direct) ? MI_ENGINE_FFT : MI_ENGINE_DIRECT;
 }
 
-extern "C" int mi_rl_create(int dev, void* stream, int nx, int ny, int nz, const float* psf, const float* psf_inv, int kx, int ky,
-                            int kz, int boundary, int engine, mi_rl_ctx** out) {
+// default PSF placement shift of one axis: sample j of the PSF sits at index (j - shift) of the circular kernel
+static int default_shift(int n, int k, int boundary) {
+    if (boundary == MI_BOUNDARY_CIRCULAR) return n / 2 - (n - k) / 2;  // ifftshift(zero-pad-centre(psf)), decon.m:131-133
+    return k - 1 - conv_kernel_offset(k, boundary);
+}
+
+extern "C" int mi_rl_create_ex(int dev, void* stream, int nx, int ny, int nz, const float* psf, const float* psf_inv, int kx, int ky,
+                               int kz, const int* boundary_xyz, const int* shift_xyz, int engine, mi_rl_ctx** out) {
     MI_TRY(use_device(dev));
     MI_REQUIRE(out, "mi_rl_create: null ctx pointer");
     *out = nullptr;
-    MI_REQUIRE(psf, "mi_rl_create: null psf");
+    MI_REQUIRE(psf && boundary_xyz, "mi_rl_create: null psf / boundary");
     MI_REQUIRE(nx > 0 && ny > 0 && nz > 0 && kx > 0 && ky > 0 && kz > 0, "mi_rl_create: bl and psf must be 3D and non-empty");
-    MI_REQUIRE(boundary >= MI_BOUNDARY_ZERO && boundary <= MI_BOUNDARY_CIRCULAR, "mi_rl_create: unknown boundary rule %d", boundary);
-    if (engine == MI_ENGINE_AUTO) engine = mi_engine_select(nx, ny, nz, kx, ky, kz, boundary);
+    const int n[3] = {nx, ny, nz}, k[3] = {kx, ky, kz};
+    int shift[3];
+    bool uniform = true;
+    for (int d = 0; d < 3; ++d) {
+        MI_REQUIRE(boundary_xyz[d] >= MI_BOUNDARY_ZERO && boundary_xyz[d] <= MI_BOUNDARY_CIRCULAR, "mi_rl_create: unknown boundary rule %d",
+                   boundary_xyz[d]);
+        if (boundary_xyz[d] == MI_BOUNDARY_CIRCULAR)
+            MI_REQUIRE(k[d] <= n[d], "pad_block_to_fft_shape: psf larger than FFT shape on axis %d", d);
+        shift[d] = (shift_xyz && shift_xyz[d] >= 0) ? shift_xyz[d] : default_shift(n[d], k[d], boundary_xyz[d]);
+        MI_REQUIRE(shift[d] >= 0 && shift[d] < k[d], "mi_rl_create: PSF shift %d outside [0,%d) on axis %d", shift[d], k[d], d);
+        uniform = uniform && boundary_xyz[d] == boundary_xyz[0];
+    }
+    if (engine == MI_ENGINE_AUTO) engine = mi_engine_select(nx, ny, nz, kx, ky, kz, uniform ? boundary_xyz[0] : MI_BOUNDARY_ZERO);
     MI_REQUIRE(engine == MI_ENGINE_DIRECT || engine == MI_ENGINE_FFT, "mi_rl_create: engine %d not available", engine);
     hipStream_t s = as_stream(stream);
-    const int n[3] = {nx, ny, nz}, k[3] = {kx, ky, kz};
-    if (boundary == MI_BOUNDARY_CIRCULAR)
-        for (int d = 0; d < 3; ++d) MI_REQUIRE(k[d] <= n[d], "pad_block_to_fft_shape: psf larger than FFT shape on axis %d", d);
     mi_rl_ctx* c = new (std::nothrow) mi_rl_ctx;
     if (!c) return fail(MI_ERR_NOMEM, "mi_rl_create: out of host memory");
     c->dev = dev;
-    c->boundary = boundary;
     c->engine = engine;
     for (int d = 0; d < 3; ++d) {
         c->n[d] = n[d];
         c->k[d] = k[d];
-        if (boundary == MI_BOUNDARY_CIRCULAR) {
-            // deconFFT placement ifftshift(zero-pad-centre(psf)) (decon.m:131-133): sample j sits at j - shift
-            const int shift = n[d] / 2 - (n[d] - k[d]) / 2;
-            c->off_fwd[d] = k[d] - 1 - shift;
-            c->off_adj[d] = shift;
-        } else {
-            c->off_fwd[d] = c->off_adj[d] = conv_kernel_offset(k[d], boundary);
-        }
+        c->bnd[d] = boundary_xyz[d];
+        // forward: out[x] = sum_j in[x - j + shift] psf[j]  -> window starts k-1-shift before x (flipped taps)
+        // adjoint (conj OTF): out[x] = sum_j in[x + j - shift] psf[j] -> window starts shift before x (plain taps);
+        // with an explicit psf_inv it is an ordinary convolution with that kernel
+        c->off_fwd[d] = k[d] - 1 - shift[d];
+        c->off_adj[d] = psf_inv ? k[d] - 1 - shift[d] : shift[d];
     }
     int rc = MI_OK;
     if (engine == MI_ENGINE_DIRECT) {
@@ -87,13 +98,7 @@ extern "C" int mi_rl_create(int dev, void* stream, int nx, int ny, int nz, const
     } else {
         c->fft = new (std::nothrow) FftEngine;
         if (!c->fft) rc = fail(MI_ERR_NOMEM, "mi_rl_create: out of host memory");
-        int F[3];
-        for (int d = 0; d < 3; ++d) {
-            F[d] = n[d];
-            if (boundary == MI_BOUNDARY_ZERO) F[d] = mi_next_fast_len(n[d] + std::max(c->off_fwd[d], k[d] - 1 - c->off_fwd[d]));
-            if (boundary == MI_BOUNDARY_REPLICATE) F[d] = mi_next_fast_len(n[d] + k[d] - 1);
-        }
-        if (rc == MI_OK) rc = c->fft->init(s, n, k, F, boundary, boundary == MI_BOUNDARY_CIRCULAR, psf, psf_inv, true);
+        if (rc == MI_OK) rc = c->fft->init(s, n, k, c->bnd, shift, psf, psf_inv, true);
     }
     if (rc == MI_OK) {
         hipError_t e = hipStreamSynchronize(s);
@@ -105,6 +110,14 @@ extern "C" int mi_rl_create(int dev, void* stream, int nx, int ny, int nz, const
     }
     *out = c;
     return MI_OK;
+}
+
+extern "C" int mi_rl_create(int dev, void* stream, int nx, int ny, int nz, const float* psf, const float* psf_inv, int kx, int ky,
+                            int kz, int boundary, int engine, mi_rl_ctx** out) {
+    const int b[3] = {boundary, boundary, boundary};
+    // deconFFT takes only psf.psf (decon.m:18): the circular flavour ignores psf_inv
+    return mi_rl_create_ex(dev, stream, nx, ny, nz, psf, boundary == MI_BOUNDARY_CIRCULAR ? nullptr : psf_inv, kx, ky, kz, b, nullptr,
+                           engine, out);
 }
 
 extern "C" int mi_rl_destroy(mi_rl_ctx* ctx) {
@@ -124,7 +137,7 @@ extern "C" size_t mi_rl_device_bytes(const mi_rl_ctx* ctx) {
 static int ctx_conv(mi_rl_ctx* c, hipStream_t s, const float* in, bool adjoint, float* out, int epi_kind, const ConvEpilogue& epi) {
     if (c->engine == MI_ENGINE_DIRECT)
         return direct_conv_launch(s, in, adjoint ? c->kf_adj.as<float>() : c->kf_fwd.as<float>(), out, c->n[0], c->n[1], c->n[2], c->k[0],
-                                  c->k[1], c->k[2], c->kxp, c->boundary, epi_kind, epi, adjoint ? c->off_adj : c->off_fwd);
+                                  c->k[1], c->k[2], c->kxp, c->bnd[0], epi_kind, epi, adjoint ? c->off_adj : c->off_fwd, c->bnd);
     return c->fft->conv(s, in, adjoint, out, epi_kind, epi);
 }
 
@@ -170,17 +183,14 @@ extern "C" int mi_conv3d(int dev, void* stream, const float* img, const float* k
     }
     MI_REQUIRE(engine == MI_ENGINE_FFT, "conv3d: engine %d not available", engine);
     FftEngine fe;
-    const int n[3] = {nx, ny, nz}, k[3] = {kx, ky, kz};
-    int F[3];
+    const int n[3] = {nx, ny, nz}, k[3] = {kx, ky, kz}, b[3] = {boundary, boundary, boundary};
+    int shift[3];
     for (int d = 0; d < 3; ++d) {
-        const int off = conv_kernel_offset(k[d], boundary);
-        F[d] = n[d];
-        if (boundary == MI_BOUNDARY_ZERO) F[d] = mi_next_fast_len(n[d] + std::max(off, k[d] - 1 - off));
-        if (boundary == MI_BOUNDARY_REPLICATE) F[d] = mi_next_fast_len(n[d] + k[d] - 1);
-        MI_REQUIRE(F[d] >= k[d], "conv3d: kernel larger than the circular shape on axis %d", d);
+        MI_REQUIRE(boundary != MI_BOUNDARY_CIRCULAR || k[d] <= n[d], "conv3d: kernel larger than the circular shape on axis %d", d);
+        // a plain circular convolution is centred like convn (no deconFFT placement quirk)
+        shift[d] = k[d] - 1 - conv_kernel_offset(k[d], boundary);
     }
-    // a plain circular convolution is centred like convn (no deconFFT placement quirk)
-    rc = fe.init(s, n, k, F, boundary, false, ker, nullptr, /*need_adjoint=*/false);
+    rc = fe.init(s, n, k, b, shift, ker, nullptr, /*need_adjoint=*/false);
     if (rc == MI_OK) rc = fe.conv(s, img, false, out, EPI_NONE, e);
     hipError_t he = hipStreamSynchronize(s);
     if (rc == MI_OK && he != hipSuccess) rc = fail(MI_ERR_HIP, "conv3d: %s", hipGetErrorString(he));

@@ -222,7 +222,10 @@ class RLContext:
     """The two fused half-steps of one RL iteration for arrays of a fixed shape (``mi_rl_create``): what the
     multi-GPU slab driver calls between halo exchanges."""
 
-    def __init__(self, shape_zyx, psf, psf_inv=None, boundary=BOUNDARY_ZERO, engine=ENGINE_AUTO, device=None):
+    def __init__(self, shape_zyx, psf, psf_inv=None, boundary=BOUNDARY_ZERO, engine=ENGINE_AUTO, device=None,
+                 shift_xyz=None):
+        """``boundary``: one mi_boundary or a triple (x, y, z); ``shift_xyz``: optional PSF placement per axis
+        (mi_rl_create_ex)."""
         self.device = _device(device)
         self.shape = tuple(int(s) for s in shape_zyx)
         p, _ = _to_dev(psf, self.device, name="psf")
@@ -232,9 +235,16 @@ class RLContext:
         nx, ny, nz = _xyz(self.shape)
         kx, ky, kz = _xyz(p.shape)
         self._h = C.c_void_p()
-        check(lib().mi_rl_create(self.device.index, capi.current_stream_ptr(self.device), nx, ny, nz, p.data_ptr(),
-                                 pi.data_ptr() if pi is not None else None, kx, ky, kz, boundary, engine,
-                                 C.byref(self._h)))
+        if np.isscalar(boundary) and shift_xyz is None:
+            check(lib().mi_rl_create(self.device.index, capi.current_stream_ptr(self.device), nx, ny, nz, p.data_ptr(),
+                                     pi.data_ptr() if pi is not None else None, kx, ky, kz, int(boundary), engine,
+                                     C.byref(self._h)))
+        else:
+            b = [int(boundary)] * 3 if np.isscalar(boundary) else [int(v) for v in boundary]
+            sh = [-1, -1, -1] if shift_xyz is None else [int(v) for v in shift_xyz]
+            check(lib().mi_rl_create_ex(self.device.index, capi.current_stream_ptr(self.device), nx, ny, nz,
+                                        p.data_ptr(), pi.data_ptr() if pi is not None else None, kx, ky, kz,
+                                        (C.c_int * 3)(*b), (C.c_int * 3)(*sh), engine, C.byref(self._h)))
         self.engine = int(lib().mi_rl_engine(self._h))
         self.device_bytes = int(lib().mi_rl_device_bytes(self._h))
 

@@ -1,0 +1,217 @@
+"""Multi-GPU Richardson-Lucy: one volume cut into Y-slabs, one rank per GPU, halo exchange over RCCL.
+
+The reference shards a volume into independent padded blocks (split_stack.m:9-26, LsDeconv.m:341,401-403,
+647-654) that never talk to each other.  Here the blocks of one row of that grid stay coupled: every rank owns
+``ny / world_size`` rows of the global volume plus ``h`` halo rows per side, and before each of the two
+convolutions of an iteration the halo rows are refreshed from the neighbouring ranks (``ncclSend/ncclRecv``
+through ``torch.distributed.batch_isend_irecv``; backend "nccl" is RCCL on ROCm).  The result equals the
+single-GPU result on the whole volume up to fp32 rounding:
+
+  flavour "fft"      deconFFT semantics (decon.m:127-204): circular on the GLOBAL shape, so the slab chain is a
+                     ring (last rank <-> first rank); the PSF placement (incl. the even-shape one-voxel offset) is
+                     taken from the global shape and handed to the local context (``mi_rl_create_ex``).
+  flavour "spatial"  deconSpatial semantics (decon.m:26-124): zeros outside the GLOBAL volume, so the outer
+                     halos of the first / last rank are zero-filled instead of exchanged.
+
+Y is sharded rather than Z because the halo is PSF-extent/2 rows of a 2048 x 512 plane instead of 30 of 64
+planes ("halo inflation": 1.12x instead of 1.94x on config C3).  No collective is on the
+data path; only the optional stop criterion all-reduces one double.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+
+from . import capi
+from .capi import BOUNDARY_CIRCULAR, BOUNDARY_ZERO, ENGINE_AUTO
+
+
+def slab_rows(ny: int, world_size: int):
+    """[y0, y1) per rank: ceil(ny / W) rows each, the last rank takes the remainder (split_stack.m:17-19 rule:
+    ``min(ys + block.y - 1, stack_info.y)``)."""
+    per = int(math.ceil(ny / world_size))
+    return [(min(r * per, ny), min((r + 1) * per, ny)) for r in range(world_size)]
+
+
+def psf_shift(n: int, k: int, flavour: str) -> int:
+    """Placement of PSF sample j at offset (j - shift): deconFFT = ifftshift(zero-pad-centre) on the global
+    extent (decon.m:131-133, 323-344); spatial = centred (convn 'same')."""
+    if flavour == "fft":
+        return n // 2 - (n - k) // 2
+    return k - 1 - (k - 1 - k // 2)
+
+
+class HipOps:
+    """Device operations of the slab driver, all through the C ABI (no CPU fallback)."""
+
+    def __init__(self, device):
+        capi.require_gpu()
+        self.device = torch.device(device)
+
+    def make_ctx(self, local_shape_zyx, psf, boundary_xyz, shift_xyz, engine):
+        from .decon import RLContext
+        return RLContext(local_shape_zyx, psf, None, boundary=boundary_xyz, engine=engine, device=self.device,
+                         shift_xyz=shift_xyz)
+
+    def pack(self, vol, y0, rows):
+        nz, ny, nx = vol.shape
+        out = torch.empty((nz, rows, nx), dtype=vol.dtype, device=vol.device)
+        capi.check(capi.lib().mi_pack_rows(vol.device.index, capi.current_stream_ptr(vol.device), vol.data_ptr(), nx, ny, nz,
+                                           y0, rows, out.data_ptr()))
+        return out
+
+    def unpack(self, packed, vol, y0):
+        nz, ny, nx = vol.shape
+        capi.check(capi.lib().mi_unpack_rows(vol.device.index, capi.current_stream_ptr(vol.device), packed.data_ptr(), nx, ny,
+                                             nz, y0, packed.shape[1], vol.data_ptr()))
+
+    def zero_rows(self, vol, y0, rows):
+        vol[:, y0:y0 + rows, :].zero_()
+
+
+class SlabRL:
+    def __init__(self, global_shape_zyx, psf, rank=0, world_size=1, device=None, flavour="fft", engine=ENGINE_AUTO,
+                 volume=None, seed=None, ops=None, group=None):
+        if flavour not in ("fft", "spatial"):
+            raise ValueError("flavour must be 'fft' (deconFFT) or 'spatial' (deconSpatial)")
+        self.rank, self.world, self.flavour, self.group = int(rank), int(world_size), flavour, group
+        self.gshape = tuple(int(s) for s in global_shape_zyx)
+        self.psf = np.ascontiguousarray(psf, dtype=np.float32)
+        gz, gy, gx = self.gshape
+        kz, ky, kx = self.psf.shape
+        self.ops = ops if ops is not None else HipOps(device)
+        self.device = self.ops.device
+        self.y0, self.y1 = slab_rows(gy, self.world)[self.rank]
+        self.n_loc = self.y1 - self.y0
+        sy = psf_shift(gy, ky, flavour)
+        self.h = max(sy, ky - 1 - sy)  # forward reads [-(k-1-shift), +shift], the adjoint the mirror image
+        if self.world > 1 and any(b - a < self.h for a, b in slab_rows(gy, self.world)):
+            raise ValueError(f"slab of {self.n_loc} rows is thinner than the halo ({self.h}); use fewer ranks")
+        rows = self.n_loc + 2 * self.h
+        self.rows = int(capi.lib().mi_next_fast_len(rows)) if ops is None else rows  # rocFFT-friendly local extent
+        bxz = BOUNDARY_CIRCULAR if flavour == "fft" else BOUNDARY_ZERO
+        # y is "circular on the local extent": wrap-around only ever reaches halo / padding rows
+        boundary_xyz = (bxz, BOUNDARY_CIRCULAR, bxz)
+        shift_xyz = (psf_shift(gx, kx, flavour), sy, psf_shift(gz, kz, flavour))
+        self.lshape = (gz, self.rows, gx)
+        self.ctx = self.ops.make_ctx(self.lshape, self.psf, boundary_xyz, shift_xyz, engine)
+        self.bl = torch.zeros(self.lshape, dtype=torch.float32, device=self.device)
+        self.ratio = torch.zeros(self.lshape, dtype=torch.float32, device=self.device)
+        if volume is not None:
+            v = volume[:, self.y0:self.y1, :]
+            v = torch.from_numpy(np.ascontiguousarray(v)) if isinstance(v, np.ndarray) else v
+            self.bl[:, self.h:self.h + self.n_loc, :] = v.to(self.device)
+        elif seed is not None:
+            # this rank's rows of the seeded synthetic volume (background + sparse beads, bench.py recipe)
+            g = torch.Generator(device=self.device).manual_seed(int(seed) + self.rank)
+            part = torch.empty((gz, self.n_loc, gx), dtype=torch.float32, device=self.device).uniform_(0.01, 0.02, generator=g)
+            idx = torch.randint(0, part.numel(), (max(1, part.numel() // 4096),), generator=g, device=self.device)
+            amp = torch.empty(idx.numel(), dtype=torch.float32, device=self.device).uniform_(0.2, 1.0, generator=g)
+            part.view(-1).index_put_((idx,), amp, accumulate=True)
+            self.bl[:, self.h:self.h + self.n_loc, :] = part
+
+    # ------------------------------------------------------------------ halo exchange
+    def neighbours(self):
+        """(rank whose top rows fill my lower halo, rank whose bottom rows fill my upper halo); None = global edge."""
+        W, r, ring = self.world, self.rank, self.flavour == "fft"
+        lo = r - 1 if r > 0 else (W - 1 if ring else None)
+        hi = r + 1 if r < W - 1 else (0 if ring else None)
+        return lo, hi
+
+    def pack_halos(self, vol):
+        """(rows for the upper neighbour's lower halo, rows for the lower neighbour's upper halo)."""
+        h, n = self.h, self.n_loc
+        return self.ops.pack(vol, n, h), self.ops.pack(vol, h, h)  # last h / first h interior rows
+
+    def unpack_halos(self, vol, recv_lo, recv_hi):
+        """Writes the received rows into the halos; None = global edge of the spatial flavour -> zeros."""
+        h, n = self.h, self.n_loc
+        if recv_lo is not None:
+            self.ops.unpack(recv_lo, vol, 0)
+        else:
+            self.ops.zero_rows(vol, 0, h)
+        if recv_hi is not None:
+            self.ops.unpack(recv_hi, vol, h + n)
+        else:
+            self.ops.zero_rows(vol, h + n, h)
+
+    def exchange(self, vol):
+        """Refresh the 2*h halo rows of ``vol`` from the neighbouring slabs (ring for the circular flavour, zeros
+        at the global edges for the spatial one)."""
+        if self.h == 0:
+            return
+        lo_src, hi_src = self.neighbours()
+        send_up, send_dn = self.pack_halos(vol)
+        if self.world == 1:  # self-ring: my own rows wrap around
+            self.unpack_halos(vol, send_up if lo_src is not None else None, send_dn if hi_src is not None else None)
+            return
+        import torch.distributed as dist
+        recv_lo = torch.empty_like(send_up) if lo_src is not None else None
+        recv_hi = torch.empty_like(send_dn) if hi_src is not None else None
+        # message tags / issue order: "up" traffic (my bottom rows -> next rank) first, then "down"; with two ranks
+        # on a ring both neighbours are the same peer and RCCL matches sends to receives by issue order
+        ops = []
+        if hi_src is not None:
+            ops.append(dist.P2POp(dist.isend, send_up, hi_src, self.group, 1))
+        if lo_src is not None:
+            ops.append(dist.P2POp(dist.isend, send_dn, lo_src, self.group, 2))
+        if lo_src is not None:
+            ops.append(dist.P2POp(dist.irecv, recv_lo, lo_src, self.group, 1))
+        if hi_src is not None:
+            ops.append(dist.P2POp(dist.irecv, recv_hi, hi_src, self.group, 2))
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        self.unpack_halos(vol, recv_lo, recv_hi)
+
+    # ------------------------------------------------------------------ iteration
+    def iterate(self):
+        """One RL iteration (decon.m:61-79 / 162-186, lambda = 0) on the sharded volume."""
+        self.exchange(self.bl)
+        self.ctx.forward_ratio(self.bl, self.ratio)
+        self.exchange(self.ratio)
+        self.ctx.adjoint_update(self.ratio, self.bl)
+
+    def run(self, niter, stop_criterion=0.0):
+        """``niter`` iterations with the reference's stop test on the GLOBAL norm (decon.m:108-118)."""
+        prev = self.norm2() if stop_criterion > 0 else 0.0
+        done = 0
+        for i in range(1, niter + 1):
+            self.iterate()
+            done = i
+            if stop_criterion > 0:
+                cur = self.norm2()
+                rel = abs(prev - cur) / prev * 100.0
+                prev = cur
+                if i > 1 and rel <= stop_criterion:
+                    break
+        return done
+
+    def interior(self):
+        return self.bl[:, self.h:self.h + self.n_loc, :]
+
+    def norm2(self) -> float:
+        import torch.distributed as dist
+        s = (self.interior().double() ** 2).sum().reshape(1)
+        if self.world > 1:
+            dist.all_reduce(s, op=dist.ReduceOp.SUM, group=self.group)
+        return float(s.sqrt().item())
+
+    def gather(self):
+        """The whole volume on every rank (tests / small volumes only)."""
+        import torch.distributed as dist
+        mine = self.interior().contiguous()
+        if self.world == 1:
+            return mine
+        rows = [b - a for a, b in slab_rows(self.gshape[1], self.world)]
+        parts = [torch.empty((self.gshape[0], n, self.gshape[2]), dtype=mine.dtype, device=mine.device) for n in rows]
+        dist.all_gather(parts, mine, group=self.group) if len(set(rows)) == 1 else self._gather_uneven(parts, mine)
+        return torch.cat(parts, dim=1)
+
+    def _gather_uneven(self, parts, mine):
+        import torch.distributed as dist
+        for r in range(self.world):
+            if r == self.rank:
+                parts[r].copy_(mine)
+            dist.broadcast(parts[r], src=r, group=self.group)

@@ -82,6 +82,13 @@ typedef struct mi_rl_ctx mi_rl_ctx;
  * psf_inv may be NULL (= psf flipped in all axes, LsDeconv.m:163).  Synchronises. */
 int mi_rl_create(int dev, void* stream, int nx, int ny, int nz, const float* psf, const float* psf_inv,
                  int kx, int ky, int kz, int boundary, int engine, mi_rl_ctx** ctx);
+/* Same with one boundary rule per axis {x, y, z} and an explicit PSF placement per axis: sample j of the
+ * PSF acts at offset (j - shift) (forward) / (shift - j) (adjoint); shift_xyz == NULL or an entry < 0 selects
+ * the default of that axis' rule.  The slab driver uses it to run an axis that is sharded across GPUs as
+ * "circular on the local extent" (valid away from the halos) with the placement of the GLOBAL volume. */
+int mi_rl_create_ex(int dev, void* stream, int nx, int ny, int nz, const float* psf, const float* psf_inv,
+                    int kx, int ky, int kz, const int* boundary_xyz, const int* shift_xyz, int engine,
+                    mi_rl_ctx** ctx);
 int mi_rl_destroy(mi_rl_ctx* ctx);
 /* engine actually chosen (mi_engine) and device bytes held by the context */
 int mi_rl_engine(const mi_rl_ctx* ctx);

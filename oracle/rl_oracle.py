@@ -168,7 +168,7 @@ def _norm2(a: np.ndarray) -> float:
 
 
 def decon_spatial(bl, psf, niter, lam=0.0, stop_criterion=0.0, regularize_interval=0,
-                  psf_inv=None, gauss_flavour="gpu", return_iters=False):
+                  psf_inv=None, gauss_flavour="gpu", return_iters=False, skip_edgetaper=False):
     """``deconSpatial`` (decon.m:26-124).  ``gauss_flavour``: "gpu" = gauss3d_gpu(bl,0.5)
     (5 taps), "cpu" = imgaussfilt3(bl,0.5) (3 taps, replicate) -- decon.m:58."""
     bl = bl.astype(np.float32)
@@ -177,7 +177,8 @@ def decon_spatial(bl, psf, niter, lam=0.0, stop_criterion=0.0, regularize_interv
     lam = np.float32(lam)
     R = _reg_kernel()
     delta_prev = _norm2(bl) if stop_criterion > 0 else 0.0
-    bl = edgetaper_3d(bl, psf)
+    if not skip_edgetaper:
+        bl = edgetaper_3d(bl, psf)
     done = 0
     for i in range(1, niter + 1):
         reg = is_regularization_time(i, niter, regularize_interval)
@@ -225,7 +226,7 @@ def otf_from_psf(psf, fft_shape_zyx):
 
 
 def decon_fft(bl, psf, fft_shape_zyx, niter, lam=0.0, stop_criterion=0.0, regularize_interval=0,
-              gauss_flavour="gpu", return_iters=False):
+              gauss_flavour="gpu", return_iters=False, skip_edgetaper=False):
     """``deconFFT`` (decon.m:127-204): circular convolution on ``fft_shape``; float64
     transforms rounded to float32 at each ``real(ifftn(..))`` like the single-precision
     reference buffers."""
@@ -234,7 +235,8 @@ def decon_fft(bl, psf, fft_shape_zyx, niter, lam=0.0, stop_criterion=0.0, regula
     lam = np.float32(lam)
     otf = otf_from_psf(psf, fft_shape_zyx)
     R = _reg_kernel()
-    bl = edgetaper_3d(bl, psf)
+    if not skip_edgetaper:
+        bl = edgetaper_3d(bl, psf)
     bl, pre, post = pad_block_to_fft_shape(bl, fft_shape_zyx)
     delta_prev = _norm2(bl) if stop_criterion > 0 else 0.0
     done = 0

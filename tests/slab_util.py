@@ -1,0 +1,74 @@
+"""Test doubles for the slab driver: a numpy convolution context (so the sharding / halo-exchange logic can run on
+CPU ranks under gloo) and a lock-step driver that runs several slabs in one process."""
+import numpy as np
+import torch
+
+from ipp_amd import capi
+
+
+class NumpyCtx:
+    """forward_ratio / adjoint_update with per-axis boundary + PSF placement, float64 FFTs (independent of the
+    product's kernels and of oracle/rl_oracle.py's loops)."""
+    engine = -1
+
+    def __init__(self, lshape, psf, boundary_xyz, shift_xyz):
+        self.n = tuple(lshape)
+        k = psf.shape
+        bnd = boundary_xyz[::-1]   # -> (z, y, x)
+        shift = shift_xyz[::-1]
+        self.pad = [0 if b == capi.BOUNDARY_CIRCULAR else kk for b, kk in zip(bnd, k)]
+        F = [nn + 2 * p for nn, p in zip(self.n, self.pad)]
+        img = np.zeros(F, np.float64)
+        img[:k[0], :k[1], :k[2]] = psf
+        img = np.roll(img, [-s for s in shift], axis=(0, 1, 2))
+        self.otf = np.fft.fftn(img)
+
+    def _conv(self, a, adjoint):
+        p = np.pad(a.astype(np.float64), [(q, q) for q in self.pad])
+        o = self.otf.conj() if adjoint else self.otf
+        c = np.real(np.fft.ifftn(np.fft.fftn(p) * o))
+        sl = tuple(slice(q, q + n) for q, n in zip(self.pad, self.n))
+        return c[sl].astype(np.float32)
+
+    def forward_ratio(self, bl, ratio):
+        b = bl.numpy()
+        ratio.copy_(torch.from_numpy((b / np.maximum(self._conv(b, False), np.float32(2.0 ** -23))).astype(np.float32)))
+
+    def adjoint_update(self, ratio, bl, lambda_=0.0, reg=None):
+        b = bl.numpy()
+        bl.copy_(torch.from_numpy(np.abs(b * self._conv(ratio.numpy(), True)).astype(np.float32)))
+
+
+class NumpyOps:
+    device = torch.device("cpu")
+
+    def make_ctx(self, lshape, psf, boundary_xyz, shift_xyz, engine):
+        return NumpyCtx(lshape, psf, boundary_xyz, shift_xyz)
+
+    def pack(self, vol, y0, rows):
+        return vol[:, y0:y0 + rows, :].contiguous()
+
+    def unpack(self, packed, vol, y0):
+        vol[:, y0:y0 + packed.shape[1], :] = packed
+
+    def zero_rows(self, vol, y0, rows):
+        vol[:, y0:y0 + rows, :] = 0
+
+
+def lockstep_iterate(slabs, niter):
+    """Runs all slabs of one volume in one process: pack everywhere, deliver, compute -- the same four phases
+    SlabRL.iterate() goes through on separate ranks."""
+    def exchange(attr):
+        packed = [s.pack_halos(getattr(s, attr)) for s in slabs]
+        for s in slabs:
+            lo, hi = s.neighbours()
+            s.unpack_halos(getattr(s, attr), packed[lo][0] if lo is not None else None,
+                           packed[hi][1] if hi is not None else None)
+    for _ in range(niter):
+        exchange("bl")
+        for s in slabs:
+            s.ctx.forward_ratio(s.bl, s.ratio)
+        exchange("ratio")
+        for s in slabs:
+            s.ctx.adjoint_update(s.ratio, s.bl)
+    return torch.cat([s.interior() for s in slabs], dim=1)

@@ -1,0 +1,83 @@
+"""CPU: the multi-GPU slab driver (sharding, halo exchange, ring / zero edges) with world_size-2 gloo ranks and a
+numpy convolution context injected in place of the HIP one; results must equal the un-sharded oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from oracle import rl_oracle as R
+from tests.slab_util import NumpyOps, lockstep_iterate
+
+
+def _case(seed=21, shape=(10, 40, 18), kshape=(5, 7, 3)):
+    psf = R.gaussian_psf(kshape, (1.2, 1.6, 0.8))
+    return R.bead_volume(shape, seed=seed, psf=psf), psf
+
+
+def _rel(a, b):
+    return float(np.abs(a.astype(np.float64) - b).max() / np.abs(b).max())
+
+
+def _worker(rank, world, port, flavour, vol, psf, niter, out):
+    import torch.distributed as dist
+    from ipp_amd import slab
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        drv = slab.SlabRL(vol.shape, psf, rank=rank, world_size=world, flavour=flavour, volume=vol, ops=NumpyOps())
+        n0 = drv.norm2()
+        drv.run(niter)
+        full = drv.gather()
+        if rank == 0:
+            out.put((full.numpy(), n0))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("flavour", ["fft", "spatial"])
+def test_two_gloo_ranks_equal_unsharded_oracle(flavour):
+    vol, psf = _case()
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = 29600 + (os.getpid() % 200) + (0 if flavour == "fft" else 1)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, flavour, vol, psf, 3, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got, n0 = out.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    if flavour == "fft":
+        want = R.decon_fft(vol, psf, vol.shape, 3, skip_edgetaper=True)
+    else:
+        want = R.decon_spatial(vol, psf, 3, skip_edgetaper=True)
+    assert got.shape == vol.shape and _rel(got, want) < 2e-5
+    assert n0 == pytest.approx(float(np.linalg.norm(vol.astype(np.float64))), rel=1e-6)
+
+
+@pytest.mark.parametrize("flavour", ["fft", "spatial"])
+@pytest.mark.parametrize("world", [1, 3, 4])
+def test_lockstep_slabs_uneven_rows(flavour, world):
+    from ipp_amd import slab
+    vol, psf = _case(seed=5, shape=(9, 41, 16))  # 41 rows: uneven split; odd extent: centred deconFFT placement
+    slabs = [slab.SlabRL(vol.shape, psf, rank=r, world_size=world, flavour=flavour, volume=vol, ops=NumpyOps())
+             for r in range(world)]
+    assert sum(s.n_loc for s in slabs) == 41
+    got = lockstep_iterate(slabs, 2).numpy()
+    want = (R.decon_fft(vol, psf, vol.shape, 2, skip_edgetaper=True) if flavour == "fft"
+            else R.decon_spatial(vol, psf, 2, skip_edgetaper=True))
+    assert _rel(got, want) < 2e-5
+
+
+def test_slab_rows_and_halo_rules():
+    from ipp_amd import slab
+    assert slab.slab_rows(2048, 8) == [(256 * r, 256 * (r + 1)) for r in range(8)]
+    assert slab.slab_rows(10, 4) == [(0, 3), (3, 6), (6, 9), (9, 10)]
+    assert slab.psf_shift(2048, 31, "fft") == 16 and slab.psf_shift(2047, 31, "fft") == 15  # decon.m:131-133 quirk
+    assert slab.psf_shift(2048, 31, "spatial") == 15
+    vol, psf = _case(shape=(6, 16, 8), kshape=(3, 9, 3))
+    with pytest.raises(ValueError, match="thinner than the halo"):
+        slab.SlabRL(vol.shape, psf, rank=0, world_size=4, flavour="fft", volume=vol, ops=NumpyOps())
