@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""Deconvolution launcher: the command line of the reference's LsDeconvolveMultiGPU/decwrap.py (:230-327) on top
+of the MI355X library -- no MATLAB script is written, no MATLAB is spawned (decwrap.py:408-494); the blocks are
+processed in this process through ``ipp_amd.lsdeconv.process_block``.
+
+Input: a folder of 2-D slices (``*.npy``, or ``*.tif`` when ``tifffile`` is installed) or one ``*.npy`` volume
+(Z, Y, X).  Output: ``<input>/deconvolved/deconvolved.npy`` (+ ``deconvolution_config.json`` like decwrap.py:474-478).
+TIFF series / LZ4 brick cache / resume of the reference are I/O rows outside this hot path.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import logging
+import os
+import sys
+from pathlib import Path
+
+logging.basicConfig(level=logging.INFO, format="%(message)s")
+log = logging.getLogger("decwrap")
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if _ROOT not in sys.path:
+    sys.path.insert(0, _ROOT)
+
+SUPPORTED_PAIRS = [(350, 460), (405, 450), (430, 470), (458, 480), (488, 525), (514, 530), (532, 555), (561, 600),
+                   (594, 620), (633, 660), (642, 690), (680, 710)]  # decwrap.py:181-194
+
+
+def get_all_gpu_indices():
+    """1-based device indices like the reference (decwrap.py:74-91 uses nvidia-smi; here HIP's device count)."""
+    try:
+        from ipp_amd import capi
+        return list(range(1, max(0, capi.lib().mi_device_count()) + 1))
+    except Exception:
+        return []
+
+
+def build_parser(default_gpus):
+    p = argparse.ArgumentParser(description="Python wrapper for MI355X deconvolution.",
+                                formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    p.add_argument("--version", action="version", version="DeconvWrapper v1.5 (MI355X)")
+    p.add_argument("-i", "--input", type=Path, required=True, help="Path to the input image folder")
+    p.add_argument("-dxy", "--dxy", type=float, required=True, help="Lateral resolution in micrometers")
+    p.add_argument("-dz", "--dz", type=float, help="Axial resolution in micrometers")
+    p.add_argument("-ex", "--lambda-ex", type=int, required=True, help="Excitation wavelength (488, 561, 642)")
+    p.add_argument("-em", "--lambda-em", type=int, required=True, help="Emission wavelength (525, 600, 690)")
+    p.add_argument("--use-fft", action="store_true", default=False, help="use FFT-based convolution (deconFFT semantics)")
+    p.add_argument("--adaptive-psf", action="store_true", default=False, help="Wiener PSF update (not built)")
+    p.add_argument("--cache-drive", type=str, default=None)
+    p.add_argument("-it", "--numit", type=int, default=6, help="Number of deconvolution iterations [1-50]")
+    p.add_argument("--na", type=float, default=0.40)
+    p.add_argument("--rf", type=float, default=1.42)
+    p.add_argument("--fcyl", type=int, default=240)
+    p.add_argument("--slitwidth", type=float, default=12.0)
+    p.add_argument("--lambda-damping", type=float, default=0.0)
+    p.add_argument("--clipval", type=float, default=99.99)
+    p.add_argument("--stop-criterion", type=float, default=0)
+    p.add_argument("--block-size-max", type=int, default=0, help="Max elements per GPU block (0: from free HBM)")
+    p.add_argument("--gpu-indices", type=int, nargs="+", default=default_gpus, help="1-based GPU indices")
+    p.add_argument("--gpu-workers-per-gpu", type=int, default=1)
+    p.add_argument("--cpu-workers", type=int, default=0)
+    p.add_argument("--signal-amp", type=float, default=1.0)
+    p.add_argument("--gaussian-sigma", type=float, nargs=3, default=[0.5, 0.5, 2.5])
+    p.add_argument("--gaussian-filter-size", type=int, nargs=3, default=[13, 13, 25])
+    p.add_argument("--denoise-strength", type=int, default=1)
+    p.add_argument("--destripe-sigma", type=float, default=0.0)
+    p.add_argument("--regularize-interval", type=int, default=3)
+    p.add_argument("--no-resume", dest="resume", action="store_false")
+    p.set_defaults(resume=True)
+    p.add_argument("--flip", action="store_true")
+    p.add_argument("--convert-to-8bit", action="store_true")
+    p.add_argument("--convert-to-16bit", action="store_true")
+    p.add_argument("--start-block", type=int, default=1)
+    p.add_argument("--dry-run", action="store_true", help="Print the plan and exit without executing it")
+    p.add_argument("--use-jemalloc", action="store_true", default=False)
+    p.add_argument("--use-tcmalloc", action="store_true", default=False)
+    return p
+
+
+def validate_args(args):
+    """decwrap.py:176-217."""
+    if not Path(args.input).exists():
+        raise ValueError(f"Path does not exist: {args.input}")
+    args.input = Path(args.input).resolve()
+    if (args.lambda_ex, args.lambda_em) not in SUPPORTED_PAIRS:
+        pairs = ", ".join(f"{e}/{m}" for e, m in SUPPORTED_PAIRS)
+        raise RuntimeError(f"Unsupported excitation/emission pair: {args.lambda_ex}/{args.lambda_em}. Valid pairs are: {pairs}")
+    if len(args.gaussian_sigma) != 3:
+        raise ValueError("Gaussian sigma must be a triplet, e.g., --gaussian-sigma 0.5 0.5 1.5")
+    if len(args.gaussian_filter_size) != 3:
+        raise ValueError("Gaussian filter size must be a triplet, e.g., --gaussian-filter-size 5 5 15")
+    if args.adaptive_psf and not args.use_fft:
+        raise RuntimeError("--adaptive-psf and --use-fft should be used simultaneously.")
+    if args.cpu_workers:
+        raise RuntimeError("--cpu-workers: this build has no CPU deconvolution path")
+
+
+def load_volume(path: Path):
+    import numpy as np
+    if path.is_file():
+        return np.load(path, mmap_mode="r")
+    files = sorted(path.glob("*.npy"))
+    if files:
+        return np.stack([np.load(f) for f in files])
+    files = sorted(list(path.glob("*.tif")) + list(path.glob("*.tiff")))
+    if files:
+        try:
+            import tifffile
+        except ImportError as e:
+            raise RuntimeError("reading TIFF slices needs the 'tifffile' module") from e
+        return np.stack([tifffile.imread(f) for f in files])
+    raise RuntimeError(f"no *.npy / *.tif slices in {path}")
+
+
+def main(argv=None):
+    gpus = get_all_gpu_indices()
+    args = build_parser(gpus).parse_args(argv)
+    validate_args(args)
+    out_dir = (args.input.parent if args.input.is_file() else args.input) / "deconvolved"
+    cfg = {k: (str(v) if isinstance(v, Path) else v) for k, v in vars(args).items()}
+    if args.dry_run:
+        print(json.dumps({"would_write": str(out_dir), "config": cfg}, indent=2))
+        return 0
+    if not args.gpu_indices:
+        raise RuntimeError("no GPU available: this build has no CPU deconvolution path")
+
+    import numpy as np
+    import torch
+    from ipp_amd import decon as D, lsdeconv as L, psf as P
+
+    out_dir.mkdir(exist_ok=True)
+    with open(out_dir / "deconvolution_config.json", "w") as f:
+        json.dump(cfg, f, indent=2)
+    vol = load_volume(args.input)
+    sz, sy, sx = vol.shape
+    dz = args.dz if args.dz else args.dxy
+    psf = P.LsMakePSF(args.dxy * 1000.0, dz * 1000.0, args.na, args.rf, float(args.lambda_ex), float(args.lambda_em),
+                      float(args.fcyl), args.slitwidth)                                    # LsDeconv.m:160 (nm units)
+    psf_struct = D.make_psf_struct(psf)
+    log.info(f"PSF size (x y z): {psf.shape[::-1]}")
+    filt = L.Filter(tuple(args.gaussian_sigma), tuple(args.gaussian_filter_size), 0.0, args.destripe_sigma,
+                    args.regularize_interval, args.use_fft, args.adaptive_psf)
+    gpu = args.gpu_indices[0]
+    bmax = args.block_size_max or L.estimate_block_size_max(gpu - 1, n_real=3, n_complex=2 if args.use_fft else 0)
+    block = L.autosplit((sx, sy, sz), psf.shape[::-1], filt, bmax, args.numit)
+    log.info(f"block grid {block.nx} x {block.ny} x {block.nz}, core ({block.x} {block.y} {block.z}), "
+             f"pad ({block.x_pad} {block.y_pad} {block.z_pad}), fft_shape {block.fft_shape}")
+    out = np.zeros(vol.shape, np.float32)
+    pad = (block.x_pad, block.y_pad, block.z_pad)
+    lo, hi = np.inf, -np.inf
+    for n, (p1, p2) in enumerate(zip(block.p1, block.p2), start=1):
+        if n < args.start_block:
+            continue
+        g = args.gpu_indices[(n - 1) % len(args.gpu_indices)]                             # blocks are independent
+        bl = L.load_block(vol, p1, p2, pad)
+        fshape = None
+        if args.use_fft:
+            fshape = L.next_fast_len(bl.shape[::-1])
+        blk = L.Block(block.x, block.y, block.z, block.nx, block.ny, block.nz, *pad, fft_shape=fshape)
+        t, lb, ub = L.process_block(bl, blk, psf_struct, args.numit, args.lambda_damping, args.stop_criterion, filt,
+                                    args.clipval, g)
+        lo, hi = min(lo, lb), max(hi, ub)
+        core = t[pad[2]:t.shape[0] - pad[2] or None, pad[1]:t.shape[1] - pad[1] or None, pad[0]:t.shape[2] - pad[0] or None]
+        out[p1[2] - 1:p2[2], p1[1] - 1:p2[1], p1[0] - 1:p2[0]] = core.cpu().numpy()        # strip pads, LsDeconv.m:750-752
+        log.info(f"block {n}/{len(block.p1)} done on GPU {g}: stats [{lb:.4g}, {ub:.4g}]")
+    np.save(out_dir / "deconvolved.npy", out)
+    with open(out_dir / "min_max.json", "w") as f:
+        json.dump({"lb": float(lo), "ub": float(hi)}, f)
+    log.info(f"wrote {out_dir / 'deconvolved.npy'}")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

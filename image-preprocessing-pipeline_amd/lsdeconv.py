@@ -1,0 +1,175 @@
+"""Block geometry and per-block processing around ``decon`` (host logic of LsDeconv.m that defines the inputs
+of the hot path: SURVEY.md R9 and the ``process_block`` row of section 8f).
+
+    split_stack(stack_info, block)           split_stack.m:1-27
+    decon_pad_size / gaussian_pad_size       LsDeconv.m:387-403
+    next_fast_len                            LsDeconv.m:405-419
+    autosplit(...)                           LsDeconv.m:308-385 (re-targeted to HBM capacity, Appendix C of SURVEY.md)
+    load_block(volume, p1, p2, pad)          LsDeconv.m:817-904 (in-memory volume; symmetric fill at the volume edge)
+    process_block(bl, ...)                   LsDeconv.m:906-948
+
+Coordinates follow the reference: 1-based inclusive boxes in [x y z] order; arrays are (Z, Y, X).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+
+from . import capi, decon as D
+
+
+@dataclass
+class Block:
+    """``block`` struct of LsDeconv.m:204-208."""
+    x: int
+    y: int
+    z: int
+    nx: int
+    ny: int
+    nz: int
+    x_pad: int = 0
+    y_pad: int = 0
+    z_pad: int = 0
+    fft_shape: tuple | None = None  # [x y z]
+    p1: np.ndarray = field(default=None, repr=False)
+    p2: np.ndarray = field(default=None, repr=False)
+
+
+@dataclass
+class Filter:
+    """``filter`` struct (decwrap.py:294-305 defaults)."""
+    gaussian_sigma: tuple = (0.5, 0.5, 2.5)
+    gaussian_size: tuple = (13, 13, 25)
+    dark: float = 0.0
+    destripe_sigma: float = 0.0
+    regularize_interval: int = 3
+    use_fft: bool = False
+    adaptive_psf: bool = False
+
+
+def split_stack(stack_xyz, block: Block):
+    """split_stack.m:9-26: boxes p1, p2 (n x 3, 1-based inclusive), x fastest, then y, then z."""
+    sx, sy, sz = stack_xyz
+    p1, p2 = [], []
+    for iz in range(block.nz):
+        zs = iz * block.z + 1
+        for iy in range(block.ny):
+            ys = iy * block.y + 1
+            for ix in range(block.nx):
+                xs = ix * block.x + 1
+                p1.append((xs, ys, zs))
+                p2.append((min(xs + block.x - 1, sx), min(ys + block.y - 1, sy), min(zs + block.z - 1, sz)))
+    return np.array(p1, np.int64), np.array(p2, np.int64)
+
+
+def decon_pad_size(psf_size_xyz):
+    """LsDeconv.m:401-403: the full PSF extent per side."""
+    return [int(math.ceil(k)) for k in psf_size_xyz]
+
+
+def gaussian_pad_size(sigma_xyz, kernel_xyz):
+    """LsDeconv.m:387-399: max(floor((2*ceil(3*sigma)+1)/2), kernel) per axis."""
+    return [int(math.ceil(max((2 * math.ceil(3 * s) + 1) // 2, k))) for s, k in zip(sigma_xyz, kernel_xyz)]
+
+
+def next_fast_len(n_vec):
+    return [D.next_fast_len(int(n)) for n in n_vec]
+
+
+def autosplit(stack_xyz, psf_size_xyz, filt: Filter, block_size_max: int, numit: int) -> Block:
+    """Largest block (core + 2*pad, 7-smooth for the FFT path) with fewer than ``block_size_max`` elements.
+
+    Same ingredients as LsDeconv.m:308-385 -- pad = max(PSF extent, Gaussian pad) per side, FFT shapes rounded
+    to 7-smooth, square xy blocks, score = core volume -- without MATLAB's 2^31-element / 1290-per-side gpuArray
+    limits and host-RAM terms, which do not exist here."""
+    pad = [0, 0, 0]
+    if numit > 0:
+        pad = [max(a, b) for a, b in zip(pad, decon_pad_size(psf_size_xyz))]
+    if any(s > 0 for s in filt.gaussian_sigma):
+        pad = [max(a, b) for a, b in zip(pad, gaussian_pad_size(filt.gaussian_sigma, filt.gaussian_size))]
+    sx, sy, sz = stack_xyz
+    best = None
+    z = sz
+    while z >= 1 and best is None:
+        xy = max(sx, sy)
+        while xy >= 1:
+            core = [min(xy, sx), min(xy, sy), z]
+            shape = [c + 2 * p for c, p in zip(core, pad)]
+            if filt.use_fft:
+                shape = next_fast_len(shape)
+            if shape[0] * shape[1] * shape[2] < block_size_max:
+                best = (core, shape)
+                break
+            xy = xy // 2 if xy > 64 else xy - 1
+        if best is None:
+            z = z // 2 if z > 16 else z - 1
+    if best is None:
+        raise RuntimeError("autosplit: No block shape fits in memory. Try increasing block_size_max or reducing min_block.")
+    core, shape = best
+    blk = Block(core[0], core[1], core[2], math.ceil(sx / core[0]), math.ceil(sy / core[1]), math.ceil(sz / core[2]),
+                pad[0], pad[1], pad[2], tuple(shape) if filt.use_fft else None)
+    blk.p1, blk.p2 = split_stack(stack_xyz, blk)
+    return blk
+
+
+def estimate_block_size_max(device=None, n_real=2, n_complex=0) -> int:
+    """decwrap.py:133-169 re-targeted: elements = usable HBM / 4 B / (#real + 2*#complex work volumes)."""
+    capi.require_gpu()
+    free, _total = torch.cuda.mem_get_info(device)
+    usable = max(0, free - (3 << 30))
+    return int(usable // 4 // max(1, n_real + 2 * n_complex))
+
+
+def load_block(volume: np.ndarray, p1, p2, pad_xyz) -> np.ndarray:
+    """LsDeconv.m:817-904 on an in-memory (Z, Y, X) volume: read the padded box where it exists, fill the rest with
+    ``padarray(..., 'symmetric')`` (edge-inclusive mirror), return float32 in [0,1] for integer inputs (im2single)."""
+    vol_xyz = volume.shape[::-1]
+    req_s = [int(a) - int(p) for a, p in zip(p1, pad_xyz)]
+    req_e = [int(b) + int(p) for b, p in zip(p2, pad_xyz)]
+    rd_s = [max(1, s) for s in req_s]
+    rd_e = [min(n, e) for n, e in zip(vol_xyz, req_e)]
+    sub = volume[rd_s[2] - 1:rd_e[2], rd_s[1] - 1:rd_e[1], rd_s[0] - 1:rd_e[0]]
+    if np.issubdtype(sub.dtype, np.integer):
+        sub = sub.astype(np.float32) / np.float32(np.iinfo(sub.dtype).max)
+    else:
+        sub = sub.astype(np.float32)
+    before = [a - b for a, b in zip(rd_s, req_s)]
+    after = [a - b for a, b in zip(req_e, rd_e)]
+    if any(before) or any(after):
+        sub = np.pad(sub, [(before[2], after[2]), (before[1], after[1]), (before[0], after[0])], mode="symmetric")
+    return np.ascontiguousarray(sub)
+
+
+def deconvolved_stats(bl: torch.Tensor, clipval: float):
+    """LsDeconv.m:1300-1307: ``prctile(bl(:), [100-clipval, clipval])`` (on the device)."""
+    if clipval <= 0:
+        return float(bl.min()), float(bl.max())
+    flat = bl.reshape(-1)
+    if flat.numel() > (1 << 24):  # torch.quantile input limit: strided sample, like a percentile on a sub-sample
+        flat = flat[:: flat.numel() // (1 << 24) + 1]
+    q = torch.quantile(flat, torch.tensor([(100.0 - clipval) / 100.0, clipval / 100.0], device=bl.device))
+    return float(q[0]), float(q[1])
+
+
+def process_block(bl, block: Block, psf, niter, lambda_, stop_criterion, filt: Filter, clipval=99.99, gpu=1):
+    """``[bl, lb, ub] = process_block(bl, block, psf, niter, lambda, stop_criterion, filter, clipval, gpu, ...)``
+    (LsDeconv.m:906-948) on device ``gpu`` (1-based like ``gpuDevice(gpu)``)."""
+    dev = torch.device("cuda", int(gpu) - 1)
+    t = torch.from_numpy(np.ascontiguousarray(bl, dtype=np.float32)).to(dev) if isinstance(bl, np.ndarray) else bl
+    size0 = tuple(t.shape)
+    if any(s > 0 for s in filt.gaussian_sigma):
+        D.gauss3d_gpu(t, list(filt.gaussian_sigma), list(filt.gaussian_size))                  # LsDeconv.m:917-919
+        if filt.dark > 0:
+            capi.check(capi.lib().mi_subtract_dark(dev.index, capi.current_stream_ptr(dev), t.data_ptr(), t.data_ptr(),
+                                                   t.numel(), float(filt.dark)))                # :924-927
+    if niter > 0 and float(t.max()) > 2.0 ** -23:                                               # :929
+        D.decon(t, psf, niter, lambda_, stop_criterion, filt.regularize_interval, gpu, filt.use_fft,
+                block.fft_shape if filt.use_fft else None, filt.adaptive_psf)
+    if filt.destripe_sigma > 0:
+        raise NotImplementedError("filter_subband_3d_z (destripe) is out of scope (SURVEY.md section 2.1)")
+    lb, ub = deconvolved_stats(t, clipval)
+    assert tuple(t.shape) == size0, "[process_block]: block size mismatch!"
+    return t, lb, ub

@@ -1,0 +1,131 @@
+#!/usr/bin/env python3
+"""Stitching step 2 ("pairwise displacement computation") entry point.
+
+The reference's process_images.py builds ``mpiexec ... Parastitcher.py -2 --sD=.. --subvoldim=.. --threshold=0.65
+--projin=.. --projout=..`` and toggles the GPU kernels with ``USECUDA_X_NCC`` (process_images.py:542-571,1552); the
+work behind that command is StackStitcher::computeDisplacements -> PDAlgoMIPNCC::execute -> norm_cross_corr_mips.
+This entry point keeps the step-2 flags and runs that work in-process on the MI355X library:
+
+    python process_images.py -2 --input TILES_DIR --oV 307 --oH 307 [--sV 25 --sH 25 --sD 10 --subvoldim 200]
+                                [--projout xml_displcomp.xml]
+
+``TILES_DIR`` holds ``tile_<row>_<col>.npy`` stacks (D, V, H), uint8/uint16 (scaled to [0,1] like loadImageStack,
+tiff2D.cpp:606-610) or float32.  One ``<Displacement TYPE="MIP_NCC">`` record per pair and z-layer is written in
+the shape of DisplacementMIPNCC::getXML (DisplacementMIPNCC.cpp:367-400).  Steps 1, 3-5 (import, projection,
+thresholding, placement) and the interactive pipeline around them are outside the hot path.
+With ``torchrun`` the pairs of a layer are dealt round-robin to the ranks (no collective; the per-rank XML fragments
+are merged by rank 0, like Parastitcher's mergedisplacements).
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import re
+import sys
+import xml.etree.ElementTree as ET
+from pathlib import Path
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if _ROOT not in sys.path:
+    sys.path.insert(0, _ROOT)
+
+
+def build_parser():
+    p = argparse.ArgumentParser(description="MIP-NCC pairwise displacement computation (stitching step 2)")
+    p.add_argument("-2", "--displcompute", dest="step2", action="store_true", help="step 2 (the only step built here)")
+    p.add_argument("--input", type=Path, required=True, help="folder with tile_<row>_<col>.npy stacks")
+    p.add_argument("--oV", type=int, required=True, help="overlap (pixels) between adjacent tiles along V")
+    p.add_argument("--oH", type=int, required=True, help="overlap (pixels) between adjacent tiles along H")
+    p.add_argument("--sV", type=int, default=25, help="displacement search radius along V (S_config.h:59)")
+    p.add_argument("--sH", type=int, default=25, help="displacement search radius along H")
+    p.add_argument("--sD", type=int, default=10, help="displacement search radius along D (process_images.py:562)")
+    p.add_argument("--subvoldim", type=int, default=200, help="slices per z-layer (S_config.h:60)")
+    p.add_argument("--threshold", type=float, default=0.65, help="reliability threshold recorded for step 4")
+    p.add_argument("--projout", type=Path, default=None, help="output XML (default <input>/xml_displcomp.xml)")
+    return p
+
+
+def load_tiles(folder: Path):
+    import numpy as np
+    grid = {}
+    for f in folder.glob("tile_*_*.npy"):
+        m = re.fullmatch(r"tile_(\d+)_(\d+)\.npy", f.name)
+        if m:
+            grid[(int(m.group(1)), int(m.group(2)))] = f
+    if not grid:
+        raise RuntimeError(f"no tile_<row>_<col>.npy stacks in {folder}")
+    rows, cols = 1 + max(r for r, _ in grid), 1 + max(c for _, c in grid)
+    if len(grid) != rows * cols:
+        raise RuntimeError("sparse tile grids are not supported")
+    tiles = []
+    for r in range(rows):
+        row = []
+        for c in range(cols):
+            a = np.load(grid[(r, c)])
+            if np.issubdtype(a.dtype, np.integer):
+                a = a.astype(np.float32) / np.float32(np.iinfo(a.dtype).max)
+            row.append(np.ascontiguousarray(a, dtype=np.float32))
+        tiles.append(row)
+    return tiles
+
+
+def displacement_xml(d, nominal):
+    """<Displacement TYPE="MIP_NCC"> with V/H/D children (DisplacementMIPNCC.cpp:367-400)."""
+    e = ET.Element("Displacement", TYPE="MIP_NCC")
+    for i, name in enumerate("VHD"):
+        ET.SubElement(e, name, displ=str(d.VHD_coords[i]), default_displ=str(nominal[i]),
+                      reliability=f"{d.evalReliability(i):.6f}", nccPeak=f"{d.NCC_maxs[i]:.6f}", nccWidth=str(d.NCC_widths[i]),
+                      nccWRangeThr=str(d.wRangeThrs[i]), nccInvWidth=str(d.invWidths[i]), delay=str(d.delays[i]))
+    return e
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    if not args.step2:
+        raise SystemExit("only step 2 (-2, pairwise displacement computation) is built; see SURVEY.md section 8f")
+    import torch
+    from ipp_amd import capi, crossmips
+    capi.require_gpu()
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(dev)
+    host_tiles = load_tiles(args.input)
+    dim_D, dim_V, dim_H = host_tiles[0][0].shape
+    root = ET.Element("TeraStitcher", step="2", threshold=str(args.threshold), sV=str(args.sV), sH=str(args.sH), sD=str(args.sD),
+                      subvoldim=str(args.subvoldim))
+    for layer, (z0, z1) in enumerate(crossmips.subvolume_layers(dim_D, args.subvoldim)):
+        tiles = [[torch.from_numpy(t[z0:z1]).to(dev) for t in row] for row in host_tiles]   # loadImageStack(z0, z1)
+        res = crossmips.compute_displacements(tiles, args.oV, args.oH, args.sV, args.sH, args.sD, rank=rank, world_size=world)
+        for (r, c, rb, cb, direction), d in sorted(res.items()):
+            nominal = [dim_V - args.oV if direction == crossmips.dir_vertical else 0,
+                       dim_H - args.oH if direction == crossmips.dir_horizontal else 0, 0]
+            pair = ET.SubElement(root, "Pair", layer=str(layer), z0=str(z0), z1=str(z1), rowA=str(r), colA=str(c), rowB=str(rb),
+                                 colB=str(cb), direction="NORTH_SOUTH" if direction == crossmips.dir_vertical else "WEST_EAST")
+            pair.append(displacement_xml(d, nominal))
+    out = args.projout or (args.input / "xml_displcomp.xml")
+    if world > 1:
+        part = Path(f"{out}.rank{rank}")
+        ET.ElementTree(root).write(part)
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.barrier()
+        if rank == 0:  # mergedisplacements
+            for k in range(1, world):
+                other = Path(f"{out}.rank{k}")
+                root.extend(ET.parse(other).getroot())
+                other.unlink()
+            part.unlink()
+            ET.indent(root)
+            ET.ElementTree(root).write(out, xml_declaration=True, encoding="utf-8")
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        ET.indent(root)
+        ET.ElementTree(root).write(out, xml_declaration=True, encoding="utf-8")
+    if rank == 0:
+        print(f"wrote {out} ({len(root)} displacement records)")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

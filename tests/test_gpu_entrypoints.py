@@ -1,0 +1,63 @@
+"""GPU: the preserved entry points (decwrap.py / process_images.py step 2) end to end on tiny inputs, checked
+against the oracle composition of the same steps."""
+import xml.etree.ElementTree as ET
+
+import numpy as np
+import pytest
+
+from oracle import ncc_oracle as N
+from oracle import rl_oracle as R
+
+pytestmark = pytest.mark.gpu
+
+
+def test_decwrap_end_to_end(dev, tmp_path):
+    from ipp_amd import decwrap, psf as P
+    rng = np.random.default_rng(8)
+    vol16 = (rng.random((20, 28, 30)) * 4000 + 500).astype(np.uint16)
+    np.save(tmp_path / "vol.npy", vol16)
+    rc = decwrap.main(["-i", str(tmp_path / "vol.npy"), "-dxy", "0.422", "-dz", "1.0", "-ex", "488", "-em", "525", "-it", "4",
+                       "--gaussian-sigma", "0.5", "0.5", "1.0", "--gaussian-filter-size", "3", "3", "5",
+                       "--regularize-interval", "2", "--gpu-indices", "1"])
+    assert rc == 0
+    got = np.load(tmp_path / "deconvolved" / "deconvolved.npy")
+    assert (tmp_path / "deconvolved" / "deconvolution_config.json").exists()
+    # oracle composition: symmetric-padded block -> Gaussian pre-filter -> deconSpatial -> strip pads
+    psf = P.LsMakePSF(422.0, 1000.0, 0.40, 1.42, 488.0, 525.0, 240.0, 12.0)
+    pad = [max(k, g) for k, g in zip(psf.shape, (5, 3, 3))]
+    bl = np.pad(vol16.astype(np.float32) / np.float32(65535), [(p, p) for p in pad], mode="symmetric")
+    bl = R.gauss3d(bl, [0.5, 0.5, 1.0], [3, 3, 5])
+    want = R.decon_spatial(bl, psf, 4, 0.0, 0.0, 2)
+    want = want[pad[0]:-pad[0], pad[1]:-pad[1], pad[2]:-pad[2]]
+    assert got.shape == vol16.shape
+    assert np.abs(got - want).max() / np.abs(want).max() < 1e-4
+
+
+def test_process_images_step2(dev, tmp_path):
+    from ipp_amd import process_images
+    tile, ov = (26, 96, 96), 32
+    step = tile[1] - ov
+    field = N.bead_field((tile[0], 2 * step + ov, 2 * step + ov), seed=4, density=1 / 300)
+    tiles = {}
+    for r in range(2):
+        for c in range(2):
+            t = field[:, r * step:r * step + tile[1], c * step:c * step + tile[2]]
+            q = np.clip(np.rint(t * 255), 0, 255).astype(np.uint8)
+            np.save(tmp_path / f"tile_{r}_{c}.npy", q)
+            tiles[(r, c)] = q.astype(np.float32) / np.float32(255)
+    assert process_images.main(["-2", "--input", str(tmp_path), "--oV", str(ov), "--oH", str(ov), "--sV", "6", "--sH", "6",
+                                "--sD", "1"]) == 0
+    root = ET.parse(tmp_path / "xml_displcomp.xml").getroot()
+    pairs = root.findall("Pair")
+    assert len(pairs) == 4
+    for p in pairs:
+        a = tiles[(int(p.get("rowA")), int(p.get("colA")))]
+        b = tiles[(int(p.get("rowB")), int(p.get("colB")))]
+        side = 0 if p.get("direction") == "NORTH_SOUTH" else 1
+        want = N.pdalgo_execute(a, b, 6, 6, 1, side, ov, kind="oracle")
+        d = p.find("Displacement")
+        assert d.get("TYPE") == "MIP_NCC"
+        for i, name in enumerate("VHD"):
+            e = d.find(name)
+            assert int(e.get("displ")) == want["coord"][i] and int(e.get("nccWidth")) == want["NCC_widths"][i]
+            assert int(e.get("nccWRangeThr")) == want["wRangeThr"][i] and int(e.get("nccInvWidth")) == want["INF_W"]

@@ -1,0 +1,69 @@
+"""CPU: host-side geometry and CLI logic (no kernels are launched)."""
+import json
+
+import numpy as np
+import pytest
+
+from oracle import rl_oracle as R
+
+
+def test_split_stack_matches_oracle_restatement():
+    from ipp_amd import lsdeconv as L
+    blk = L.Block(4, 4, 3, 3, 2, 2)
+    p1, p2 = L.split_stack((10, 7, 5), blk)
+    q1, q2 = R.split_stack((10, 7, 5), (4, 4, 3), (3, 2, 2))
+    assert np.array_equal(p1, q1) and np.array_equal(p2, q2)
+
+
+def test_load_block_symmetric_padding_and_im2single():
+    from ipp_amd import lsdeconv as L
+    vol = (np.arange(6 * 7 * 8) % 65536).astype(np.uint16).reshape(6, 7, 8)
+    bl = L.load_block(vol, (1, 1, 1), (4, 4, 3), (2, 3, 1))       # box at the volume corner: pre-pads are mirrored
+    assert bl.shape == (3 + 2, 4 + 6, 4 + 4) and bl.dtype == np.float32
+    ref = np.pad(vol[0:4, 0:7, 0:6].astype(np.float32) / 65535.0, [(1, 0), (3, 0), (2, 0)], mode="symmetric")
+    assert np.array_equal(bl, ref.astype(np.float32))
+    inner = L.load_block(vol, (3, 3, 2), (5, 5, 4), (1, 1, 1))    # interior box: real neighbours, no mirroring
+    assert np.array_equal(inner, vol[0:5, 1:6, 1:6].astype(np.float32) / np.float32(65535))
+
+
+def test_pad_rules_and_autosplit():
+    from ipp_amd import lsdeconv as L
+    assert L.decon_pad_size((9, 9, 19)) == [9, 9, 19]
+    assert L.gaussian_pad_size((0.5, 0.5, 2.5), (13, 13, 25)) == [13, 13, 25]
+    f = L.Filter(use_fft=True)
+    blk = L.autosplit((300, 300, 100), (9, 9, 19), f, block_size_max=200 ** 3, numit=6)
+    shape = [c + 2 * p for c, p in zip((blk.x, blk.y, blk.z), (blk.x_pad, blk.y_pad, blk.z_pad))]
+    assert blk.fft_shape == tuple(R.next_fast_len(s) for s in shape)
+    assert np.prod(blk.fft_shape) < 200 ** 3 and (blk.x_pad, blk.y_pad, blk.z_pad) == (13, 13, 25)
+    assert blk.nx * blk.x >= 300 and blk.nz * blk.z >= 100 and len(blk.p1) == blk.nx * blk.ny * blk.nz
+    with pytest.raises(RuntimeError, match="No block shape fits"):
+        L.autosplit((300, 300, 100), (9, 9, 19), f, block_size_max=10, numit=6)
+
+
+def test_decwrap_cli_validation_and_dry_run(tmp_path, capsys):
+    from ipp_amd import decwrap
+    np.save(tmp_path / "vol.npy", np.zeros((4, 4, 4), np.uint16))
+    base = ["-i", str(tmp_path / "vol.npy"), "-dxy", "0.4", "-dz", "1.0"]
+    assert decwrap.main(base + ["-ex", "488", "-em", "525", "--dry-run"]) == 0
+    cfg = json.loads(capsys.readouterr().out)["config"]
+    assert cfg["numit"] == 6 and cfg["regularize_interval"] == 3 and cfg["gaussian_sigma"] == [0.5, 0.5, 2.5]
+    assert cfg["gaussian_filter_size"] == [13, 13, 25] and cfg["clipval"] == 99.99 and cfg["lambda_damping"] == 0.0
+    with pytest.raises(RuntimeError, match="Unsupported excitation/emission pair"):
+        decwrap.main(base + ["-ex", "500", "-em", "525", "--dry-run"])
+    with pytest.raises(RuntimeError, match="adaptive-psf"):
+        decwrap.main(base + ["-ex", "488", "-em", "525", "--adaptive-psf", "--dry-run"])
+    with pytest.raises(ValueError, match="Path does not exist"):
+        decwrap.main(["-i", str(tmp_path / "nope"), "-dxy", "0.4", "-ex", "488", "-em", "525", "--dry-run"])
+
+
+def test_pair_enumeration_and_layers():
+    from ipp_amd import crossmips as X
+    pairs = list(X.enumerate_pairs(8, 8))
+    assert len(pairs) == 2 * 64 - 8 - 8  # StackStitcher.cpp:217
+    assert pairs[0] == (0, 0, 0, 1, X.dir_horizontal) and pairs[1] == (0, 0, 1, 0, X.dir_vertical)
+    assert X.subvolume_layers(32, 200) == [(0, 32)]
+    assert X.subvolume_layers(450, 200) == [(0, 150), (150, 300), (300, 450)]
+    assert X.subvolume_layers(401, 200) == [(0, 134), (134, 268), (268, 401)]  # first Z mod n layers one longer
+    p = X.NCC_parms_t(25, 25, 10)
+    assert (p.wRangeThr_i, p.wRangeThr_j, p.wRangeThr_k, p.INF_W) == (25, 25, 10, 26)
+    assert X.NCC_parms_t(40, 40, 40).wRangeThr_i == 29 and abs(p.widthThr - 0.8) < 1e-7 and p.maxIter == 2
