@@ -1,0 +1,28 @@
+// Internal interface of the hand-written FFT convolution pipeline (fft_native.hip).
+#pragma once
+#include "conv3d_direct.h"
+
+namespace mi {
+
+struct NativeDims {
+    int lhx, ly, lz;  // log2 of Hx = X/2, Y, Z
+    int ny, nz;
+    int ty, tc, tl;   // rows per x tile, columns per y tile, lines per z tile (A and B tiles each)
+};
+
+struct NativeFft {
+    NativeDims dims{};
+    DevBuf S, T, G, tw;
+    const float2* tw_x = nullptr;
+    const float2* tw_y = nullptr;
+    const float2* tw_z = nullptr;
+    size_t n_cplx = 0;
+
+    static bool supported(const int F[3]);
+    // otf_half_spectrum: R2C layout [Z][Y][X/2+1]; it is multiplied by `scale` while being repacked
+    int init(hipStream_t s, const int F[3], const float2* otf_half_spectrum, float scale);
+    int conv(hipStream_t s, const float* in, bool conj_otf, float* out, int epi_kind, const ConvEpilogue& epi);
+    size_t device_bytes() const { return S.bytes + T.bytes + G.bytes + tw.bytes; }
+};
+
+}  // namespace mi

@@ -3,6 +3,7 @@
 #include <rocfft/rocfft.h>
 
 #include "conv3d_direct.h"
+#include "fft_native.h"
 
 namespace mi {
 
@@ -26,6 +27,7 @@ struct FftEngine {
     DevBuf work, spec, real, otf, otf_adj;
     size_t n_real = 0, n_spec = 0;  // element counts (floats / complex)
     bool have_adj = false;
+    NativeFft* native = nullptr;  // hand-written pipeline, when the shape allows it
 
     ~FftEngine();
     // bnd/shift per axis (x, y, z): boundary rule and PSF placement shift (see AxisPlan)
@@ -33,7 +35,9 @@ struct FftEngine {
              const float* psf_inv, bool need_adjoint);
     // c = conv(in, psf or its adjoint), then the epilogue of `epi_kind` into out (shape n)
     int conv(hipStream_t s, const float* in, bool adjoint, float* out, int epi_kind, const ConvEpilogue& epi);
-    size_t device_bytes() const { return work.bytes + spec.bytes + real.bytes + otf.bytes + otf_adj.bytes; }
+    size_t device_bytes() const {
+        return work.bytes + spec.bytes + real.bytes + otf.bytes + otf_adj.bytes + (native ? native->device_bytes() : 0);
+    }
 };
 
 // writes the half-spectrum OTF of `psf` placed per `ax` (scaled) into `otf` using plan `fwd`

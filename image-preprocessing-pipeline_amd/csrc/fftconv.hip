@@ -11,6 +11,8 @@
 //     buffer (zeros or clamped samples) large enough that circular wrap never reaches the output.
 #include <mutex>
 
+#include <cstdlib>
+
 #include "fftconv.h"
 
 namespace mi {
@@ -166,6 +168,7 @@ int build_otf(hipStream_t s, rocfft_plan fwd, rocfft_execution_info info, const 
 }
 
 FftEngine::~FftEngine() {
+    delete native;
     if (info) rocfft_execution_info_destroy(info);
     if (fwd) rocfft_plan_destroy(fwd);
     if (inv) rocfft_plan_destroy(inv);
@@ -240,10 +243,25 @@ int FftEngine::init(hipStream_t s, const int n[3], const int k[3], const int bnd
     } else if (need_adjoint) {
         MI_REQUIRE(conj_ok, "FFT engine: the implied adjoint (flipped PSF) needs odd PSF extents on non-circular axes");
     }
+    // hand-written pipeline (fft_native.hip) when the transform shape allows it; MI_FFT_ROCFFT=1 forces rocFFT
+    const char* force = std::getenv("MI_FFT_ROCFFT");
+    if (!padded && !have_adj && NativeFft::supported(F) && !(force && force[0] == '1')) {
+        native = new (std::nothrow) NativeFft;
+        if (!native) return fail(MI_ERR_NOMEM, "FFT engine: out of host memory");
+        // the rocFFT-built OTF carries 1/(Fx Fy Fz); the complex pipeline of Fx/2 x Fy x Fz points needs twice that
+        MI_TRY(native->init(s, F, otf.as<float2>(), 2.0f));
+        // rocFFT plans and buffers were only needed to build the OTF
+        MI_HIP(hipStreamSynchronize(s));
+        rocfft_execution_info_destroy(info); info = nullptr;
+        rocfft_plan_destroy(fwd); fwd = nullptr;
+        rocfft_plan_destroy(inv); inv = nullptr;
+        work.release(); spec.release(); real.release(); otf.release();
+    }
     return MI_OK;
 }
 
 int FftEngine::conv(hipStream_t s, const float* in, bool adjoint, float* out, int epi_kind, const ConvEpilogue& epi) {
+    if (native) return native->conv(s, in, adjoint, out, epi_kind, epi);
     MI_FFT(rocfft_execution_info_set_stream(info, s));
     const float* src = in;
     if (padded) {

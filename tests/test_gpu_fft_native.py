@@ -1,0 +1,66 @@
+"""GPU: the hand-written FFT convolution pipeline (fft_native.hip: power-of-two shapes) against the oracle, against
+scipy's circular convolution and against the rocFFT route of the same engine (MI_FFT_ROCFFT=1)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+from scipy import ndimage
+
+from oracle import rl_oracle as R
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(8, 8, 16), (16, 32, 64), (32, 64, 128), (64, 16, 256), (8, 128, 32), (128, 8, 16), (16, 16, 1024)]
+
+
+def _rel(a, b):
+    return float(np.abs(a.astype(np.float64) - b).max() / np.abs(b).max())
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_circular_conv_native_vs_scipy_and_rocfft(dev, shape):
+    from ipp_amd import decon
+    rng = np.random.default_rng(sum(shape))
+    img = rng.random(shape, dtype=np.float32)
+    ker = rng.random((3, 5, 7), dtype=np.float32)
+    want = ndimage.convolve(img.astype(np.float64), ker.astype(np.float64), mode="wrap")
+    got = decon.convn_same(torch.from_numpy(img).to(dev), torch.from_numpy(ker).to(dev), boundary=2, engine=2).cpu().numpy()
+    assert _rel(got, want) < 2e-5
+    os.environ["MI_FFT_ROCFFT"] = "1"
+    try:
+        ref = decon.convn_same(torch.from_numpy(img).to(dev), torch.from_numpy(ker).to(dev), boundary=2, engine=2).cpu().numpy()
+    finally:
+        del os.environ["MI_FFT_ROCFFT"]
+    assert _rel(got, ref) < 2e-5
+
+
+@pytest.mark.parametrize("shape", [(16, 32, 64), (32, 16, 128), (8, 64, 32)])
+@pytest.mark.parametrize("niter,lam,interval", [(4, 0.0, 0), (6, 0.05, 2)])
+def test_decon_fft_native_matches_oracle(dev, shape, niter, lam, interval):
+    from ipp_amd import decon
+    psf = R.gaussian_psf((5, 7, 5), (1.0, 1.5, 1.0))
+    vol = R.bead_volume(shape, seed=17, psf=psf)
+    want = R.decon_fft(vol, psf, vol.shape, niter, lam, 0.0, interval)
+    got = decon.decon(torch.from_numpy(vol).to(dev), psf, niter, lam, 0.0, interval, 1, True,
+                      (shape[2], shape[1], shape[0]), False).cpu().numpy()
+    assert _rel(got, want) < 1e-4
+
+
+def test_adjoint_is_exact_transpose(dev):
+    """<conv(a), b> == <a, conv_adj(b)> for the circular operator pair (forward = OTF, adjoint = conj OTF)."""
+    from ipp_amd import capi, decon
+    shape = (16, 32, 64)
+    psf = R.gaussian_psf((5, 7, 9), (1.0, 1.5, 2.0))
+    ctx = decon.RLContext(shape, psf, None, boundary=capi.BOUNDARY_CIRCULAR, engine=capi.ENGINE_FFT, device=dev)
+    g = torch.Generator().manual_seed(3)
+    a = (torch.rand(shape, generator=g) + 0.5).to(dev)
+    b = (torch.rand(shape, generator=g) + 0.5).to(dev)
+    ra = torch.empty_like(a)
+    ctx.forward_ratio(a, ra)          # ra = a / conv(a)  ->  conv(a) = a / ra
+    conv_a = a / ra
+    ones = torch.ones_like(a)
+    ctx.adjoint_update(b, ones)       # ones <- |1 * conv_adj(b)| = conv_adj(b) for positive data
+    lhs = float((conv_a.double() * b.double()).sum())
+    rhs = float((a.double() * ones.double()).sum())
+    assert abs(lhs - rhs) / abs(lhs) < 1e-5
