@@ -8,6 +8,7 @@ struct NativeDims {
     int lhx, ly, lz;  // log2 of Hx = X/2, Y, Z
     int ny, nz;
     int ty, tc, tl;   // rows per x tile, columns per y tile, lines per z tile (A and B tiles each)
+    int dbg;          // timing experiments only: knocks out phases of the z pass (results are then wrong)
 };
 
 struct NativeFft {

@@ -10,10 +10,11 @@
 //   of size (Z, Y, Hx) is taken; the real-spectrum untangling, the OTF product and the re-tangling are done
 //   point-wise on mirror pairs (k, -k) in the middle pass, so no (X/2+1)-wide array ever exists.
 //
-//   P1  x forward   rows -> LDS -> DIF FFT(Hx) -> spectrum S[z][px][y]   (transposed write: y fastest)
-//   P2  y forward   contiguous columns of S, in place
-//   P3  z forward + untangle * OTF (or conj) + retangle + z inverse, on mirror line pairs, S -> T
-//   P4  y inverse   contiguous columns of T, in place
+//   P1  x forward   rows -> LDS -> DIF FFT(Hx) -> S[z][px][y]            (transposed write: y fastest, px stride 16 KB)
+//   P2  y forward   whole contiguous columns: S[z][px][.] -> T[px][z][.]   (the re-layout is free: 16-KB chunks)
+//   P3  z forward + untangle * OTF (or conj) + retangle + z inverse, on mirror line pairs, T -> S, both [px][z][py]
+//                   (z stride 16 KB instead of 16 MB in the [z][px][py] layout)
+//   P4  y inverse   S[px][z][.] -> T[z][px][.]
 //   P5  x inverse   T[z][px][y] -> LDS -> DIT IFFT(Hx) -> real row -> fused RL epilogue -> out
 //
 // Forward transforms are decimation-in-frequency (natural in, bit-reversed out), inverse ones
@@ -24,6 +25,7 @@
 // plus one per row) so that both the strided butterfly accesses and the transposed tile accesses are
 // bank-conflict free for ds_read/write_b64.
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #include "fft_native.h"
@@ -31,7 +33,8 @@
 namespace mi {
 namespace {
 
-constexpr int kThreads = 256;
+constexpr int kThreadsXZ = 1024;  // strided passes: one 135-KB work-group per CU, 16 waves
+constexpr int kThreadsY = 512;    // contiguous pass: two 68-KB work-groups per CU
 
 __device__ __forceinline__ int phys(int i) { return i + (i >> 5); }
 __host__ __device__ __forceinline__ int row_pitch(int n) { return n + (n >> 5) + 1; }
@@ -43,86 +46,100 @@ __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(
 __device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
 __device__ __forceinline__ unsigned brev_n(unsigned v, int bits) { return bits == 0 ? 0u : (__brev(v) >> (32 - bits)); }
 
-// One super-stage: R = 2^LR points per lane, radix-2 stages s_hi..s_lo (forward, DIF) or s_lo..s_hi (inverse, DIT)
-// on `batch` sequences of length N = 1 << logn stored at tile[b * pitch + phys(i)].  tw[e] = exp(-2 pi i e / N).
-template <int LR, bool INVERSE>
-__device__ __forceinline__ void super_stage(float2* tile, int batch, int pitch, int logn, int s_lo, const float2* __restrict__ tw) {
-    constexpr int R = 1 << LR;
-    const int groups = 1 << (logn - LR);
-    const int h_lo = 1 << s_lo;
-    const int total = batch * groups;
-    for (int idx = threadIdx.x; idx < total; idx += kThreads) {
-        const int b = idx >> (logn - LR), g = idx & (groups - 1);
-        const int base = ((g >> s_lo) << (s_lo + LR)) | (g & (h_lo - 1));
+// exp(-2 pi i m / 2^(bpos+1)), m < 2^bpos, bpos <= 3: the part of a butterfly twiddle that depends only on the
+// register index, as compile-time constants (cos/sin of multiples of 2 pi / 16)
+__device__ __forceinline__ constexpr float c16(int k) {
+    constexpr float c[8] = {1.0f, 0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f,
+                            0.0f, -0.38268343236508977f, -0.70710678118654752f, -0.92387953251128674f};
+    return c[k];
+}
+__device__ __forceinline__ constexpr float s16(int k) {
+    constexpr float sn[8] = {0.0f, 0.38268343236508977f, 0.70710678118654752f, 0.92387953251128674f,
+                             1.0f, 0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f};
+    return sn[k];
+}
+
+// One super-stage, everything about the transform compile-time: R = 2^LR points per lane, radix-2 stages
+// S_LO+LR-1..S_LO (forward, DIF) or S_LO..S_LO+LR-1 (inverse, DIT) on `batch` sequences of length 2^LOGN stored at
+// tile[b * pitch + phys(i)].  tw[e] = exp(-2 pi i e / N).  The twiddle of a butterfly factors into a per-lane
+// part (one table look-up per radix-2 stage; none when S_LO == 0) and a per-register constant.
+template <int LOGN, int LR, int S_LO, bool INVERSE, int NT>
+__device__ __forceinline__ void super_stage(float2* tile, int batch, int pitch, const float2* __restrict__ tw) {
+    constexpr int R = 1 << LR, GL = LOGN - LR, H_LO = 1 << S_LO;
+    const int total = batch << GL;
+    for (int idx = threadIdx.x; idx < total; idx += NT) {
+        const int b = idx >> GL, g = idx & ((1 << GL) - 1);
+        const int m = g & (H_LO - 1);
+        const int base = ((g >> S_LO) << (S_LO + LR)) | m;
         float2* row = tile + b * pitch;
         float2 v[R];
+        int pidx[R];
 #pragma unroll
-        for (int j = 0; j < R; ++j) v[j] = row[phys(base + j * h_lo)];
+        for (int j = 0; j < R; ++j) {
+            if (H_LO >= 32) pidx[j] = phys(base) + j * (H_LO + (H_LO >> 5));  // no carries between the bit fields
+            else pidx[j] = phys(base + j * H_LO);
+            v[j] = row[pidx[j]];
+        }
 #pragma unroll
         for (int step = 0; step < LR; ++step) {
             const int bpos = INVERSE ? step : LR - 1 - step;  // local bit handled by this radix-2 stage
-            const int s = s_lo + bpos;
-            const int h = 1 << s;
-            const int tshift = logn - 1 - s;  // exponent scale N / (2h)
+            const int s = S_LO + bpos;
+            float2 wb = make_float2(1.0f, 0.0f);
+            if (S_LO > 0) wb = tw[m << (LOGN - 1 - s)];
 #pragma unroll
             for (int j = 0; j < R; ++j) {
                 if (j & (1 << bpos)) continue;
                 const int jl = j & ((1 << bpos) - 1);
-                const int e = ((base & (h - 1)) + jl * h_lo) << tshift;
-                const float2 w = tw[e];
+                const int k16 = jl * (8 >> bpos);  // jl / 2^(bpos+1) turns = k16 / 16
+                float2 w;
+                if (S_LO == 0) w = make_float2(c16(k16), -s16(k16));
+                else if (jl == 0) w = wb;
+                else w = cmul(wb, make_float2(c16(k16), -s16(k16)));
                 const float2 a = v[j], c = v[j | (1 << bpos)];
                 if (INVERSE) {
-                    const float2 t = cmulc(c, w);
+                    const float2 t = (S_LO == 0 && jl == 0) ? c : cmulc(c, w);
                     v[j] = cadd(a, t);
                     v[j | (1 << bpos)] = csub(a, t);
                 } else {
                     v[j] = cadd(a, c);
-                    v[j | (1 << bpos)] = cmul(csub(a, c), w);
+                    const float2 dd = csub(a, c);
+                    v[j | (1 << bpos)] = (S_LO == 0 && jl == 0) ? dd : cmul(dd, w);
                 }
             }
         }
 #pragma unroll
-        for (int j = 0; j < R; ++j) row[phys(base + j * h_lo)] = v[j];
+        for (int j = 0; j < R; ++j) row[pidx[j]] = v[j];
     }
 }
 
-// full transform of `batch` LDS rows; callers place __syncthreads() before (data visible) -- one is issued after
-// every super-stage here, so the tile is consistent on return
-template <bool INVERSE>
-__device__ void lds_fft(float2* tile, int batch, int pitch, int logn, const float2* __restrict__ tw) {
-    // split logn into super-stages of at most 4 radix-2 stages; forward walks from the top stage down
-    int sizes[4], ns = 0, rem = logn;
-    while (rem > 0) {
-        int r = rem >= 8 ? 4 : (rem > 4 ? (rem + 1) / 2 : rem);
-        sizes[ns++] = r;
-        rem -= r;
-    }
-    int s_next = INVERSE ? 0 : logn;
-    for (int q = 0; q < ns; ++q) {
-        const int r = sizes[q];
-        const int s_lo = INVERSE ? s_next : s_next - r;
-        switch (r) {
-            case 1: super_stage<1, INVERSE>(tile, batch, pitch, logn, s_lo, tw); break;
-            case 2: super_stage<2, INVERSE>(tile, batch, pitch, logn, s_lo, tw); break;
-            case 3: super_stage<3, INVERSE>(tile, batch, pitch, logn, s_lo, tw); break;
-            default: super_stage<4, INVERSE>(tile, batch, pitch, logn, s_lo, tw); break;
-        }
-        s_next = INVERSE ? s_next + r : s_next - r;
+__host__ __device__ constexpr int first_r(int rem) { return rem >= 8 ? 4 : (rem > 4 ? (rem + 1) / 2 : rem); }
+
+// full transform of `batch` LDS rows as a compile-time chain of super-stages (at most 4 radix-2 stages each); the
+// caller issues __syncthreads() before (tile filled); one follows every super-stage, so the tile is consistent on return
+template <int LOGN, bool INVERSE, int NT, int DONE = 0>
+__device__ __forceinline__ void lds_fft(float2* tile, int batch, int pitch, const float2* __restrict__ tw) {
+    if constexpr (DONE < LOGN) {
+        constexpr int r = first_r(LOGN - DONE);
+        constexpr int s_lo = INVERSE ? DONE : LOGN - DONE - r;  // forward: top stages first; inverse: bottom first
+        super_stage<LOGN, r, s_lo, INVERSE, NT>(tile, batch, pitch, tw);
         __syncthreads();
+        lds_fft<LOGN, INVERSE, NT, DONE + r>(tile, batch, pitch, tw);
     }
 }
 
 // ---------------------------------------------------------------------------------------------- P1: x forward
 // grid: (Y / TY) * Z tiles; tile = TY consecutive rows of one z-plane
-__global__ __launch_bounds__(kThreads) void k_x_forward(const float* __restrict__ in, float2* __restrict__ S, NativeDims d,
+template <int LHX>
+__global__ __launch_bounds__(kThreadsXZ) void k_x_forward(const float* __restrict__ in, float2* __restrict__ S, NativeDims d,
                                                          const float2* __restrict__ tw) {
     extern __shared__ __attribute__((aligned(16))) float2 tile[];
-    const int Hx = 1 << d.lhx, TY = d.ty, pitch = row_pitch(Hx);
+    constexpr int Hx = 1 << LHX;
+    const int TY = d.ty, pitch = row_pitch(Hx);
     const int ytiles = d.ny / TY;
     const int z = blockIdx.x / ytiles, y0 = (blockIdx.x % ytiles) * TY;
     const float4* src = reinterpret_cast<const float4*>(in + ((size_t)z * d.ny + y0) * (size_t)(2 * Hx));
     const int quads = Hx / 2;  // float4 = 2 complex
-    for (int i = threadIdx.x; i < TY * quads; i += kThreads) {
+    for (int i = threadIdx.x; i < TY * quads; i += kThreadsXZ) {
         const int r = i / quads, q = i - r * quads;
         const float4 v = src[(size_t)r * quads + q];
         float2* row = tile + r * pitch;
@@ -130,24 +147,31 @@ __global__ __launch_bounds__(kThreads) void k_x_forward(const float* __restrict_
         row[phys(2 * q + 1)] = make_float2(v.z, v.w);
     }
     __syncthreads();
-    lds_fft<false>(tile, TY, pitch, d.lhx, tw);
-    // transposed store: S[z][px][y0 + r], r fastest
-    float2* dst = S + ((size_t)z * Hx) * d.ny + y0;
-    for (int i = threadIdx.x; i < TY * Hx; i += kThreads) {
-        const int px = i / TY, r = i - px * TY;
-        dst[(size_t)px * d.ny + r] = tile[r * pitch + phys(px)];
+    lds_fft<LHX, false, kThreadsXZ>(tile, TY, pitch, tw);
+    // transposed store: S[z][px][y0 + r], r fastest; one float4 = rows (2 rp, 2 rp + 1) of one px
+    float4* dst = reinterpret_cast<float4*>(S + ((size_t)z * Hx) * d.ny + y0);
+    const int hp = TY / 2, rowq = d.ny / 2;
+#pragma unroll 4
+    for (int i = threadIdx.x; i < hp * Hx; i += kThreadsXZ) {
+        const int px = i / hp, rp = i - px * hp;
+        const float2 a = tile[(2 * rp) * pitch + phys(px)], b = tile[(2 * rp + 1) * pitch + phys(px)];
+        dst[(size_t)px * rowq + rp] = make_float4(a.x, a.y, b.x, b.y);
     }
 }
 
 // ---------------------------------------------------------------------------------------------- P2 / P4: y passes
-// contiguous columns: column c of the (Z * Hx) columns is buf[c * Y .. c * Y + Y)
-template <bool INVERSE>
-__global__ __launch_bounds__(kThreads) void k_y_pass(float2* __restrict__ buf, NativeDims d, const float2* __restrict__ tw) {
+// whole contiguous columns.  Forward: column (z, px) of src[z][px][.] -> dst[px][z][.]; inverse: the way back.
+template <int LY, bool INVERSE>
+__global__ __launch_bounds__(kThreadsY) void k_y_pass(const float2* __restrict__ src, float2* __restrict__ dst, NativeDims d,
+                                                      const float2* __restrict__ tw) {
     extern __shared__ __attribute__((aligned(16))) float2 tile[];
-    const int M = d.ny, TC = d.tc, pitch = row_pitch(M);
-    float4* base = reinterpret_cast<float4*>(buf + (size_t)blockIdx.x * TC * M);
+    constexpr int M = 1 << LY;
+    const int TC = d.tc, pitch = row_pitch(M), Hx = 1 << d.lhx, L = d.nz;
+    const size_t c0 = (size_t)blockIdx.x * TC;
+    const float4* base = reinterpret_cast<const float4*>(src + c0 * M);
     const int quads = M / 2;
-    for (int i = threadIdx.x; i < TC * quads; i += kThreads) {
+#pragma unroll 4
+    for (int i = threadIdx.x; i < TC * quads; i += kThreadsY) {
         const int c = i / quads, q = i - c * quads;
         const float4 v = base[(size_t)c * quads + q];
         float2* row = tile + c * pitch;
@@ -155,12 +179,17 @@ __global__ __launch_bounds__(kThreads) void k_y_pass(float2* __restrict__ buf, N
         row[phys(2 * q + 1)] = make_float2(v.z, v.w);
     }
     __syncthreads();
-    lds_fft<INVERSE>(tile, TC, pitch, d.ly, tw);
-    for (int i = threadIdx.x; i < TC * quads; i += kThreads) {
+    lds_fft<LY, INVERSE, kThreadsY>(tile, TC, pitch, tw);
+#pragma unroll 4
+    for (int i = threadIdx.x; i < TC * quads; i += kThreadsY) {
         const int c = i / quads, q = i - c * quads;
+        const size_t sc = c0 + c;  // source column index
+        size_t dc;
+        if (INVERSE) { const size_t px = sc / L, z = sc - px * L; dc = z * Hx + px; }   // [px][z] -> [z][px]
+        else { const size_t z = sc / Hx, px = sc - z * Hx; dc = px * L + z; }           // [z][px] -> [px][z]
         const float2* row = tile + c * pitch;
         const float2 a = row[phys(2 * q)], b = row[phys(2 * q + 1)];
-        base[(size_t)c * quads + q] = make_float4(a.x, a.y, b.x, b.y);
+        reinterpret_cast<float4*>(dst + dc * M)[q] = make_float4(a.x, a.y, b.x, b.y);
     }
 }
 
@@ -170,11 +199,12 @@ __global__ __launch_bounds__(kThreads) void k_y_pass(float2* __restrict__ buf, N
 // line is still written exactly once; otherwise both lines of a pair are written by the one tile that owns the pair.
 // grid: (#A planes) * (Y / TL) tiles of TL consecutive py positions.
 // OTF layout: G[(plane index)][py][pz] as float4 {Ga.re, Ga.im, Gb.re, Gb.im}, already scaled by 1/(Hx*Y*Z).
-template <bool CONJ>
-__global__ __launch_bounds__(kThreads) void k_z_conv(const float2* __restrict__ S, float2* __restrict__ T, const float4* __restrict__ G,
+template <int LZ, bool CONJ>
+__global__ __launch_bounds__(kThreadsXZ) void k_z_conv(const float2* __restrict__ S, float2* __restrict__ T, const float4* __restrict__ G,
                                                       NativeDims d, const float2* __restrict__ tw) {
     extern __shared__ __attribute__((aligned(16))) float2 tile[];
-    const int Hx = 1 << d.lhx, M = d.ny, L = d.nz, TL = d.tl, pitch = row_pitch(L);
+    constexpr int L = 1 << LZ;
+    const int Hx = 1 << d.lhx, M = d.ny, TL = d.tl, pitch = row_pitch(L);
     const int ytiles = M / TL;
     const int plane = blockIdx.x / ytiles;                 // 0 .. Hx/2
     const int py0 = (blockIdx.x % ytiles) * TL;
@@ -188,22 +218,45 @@ __global__ __launch_bounds__(kThreads) void k_z_conv(const float2* __restrict__ 
     const bool self_plane = (px == 0 || px == 1);
     float2* tA = tile;
     float2* tB = tile + TL * pitch;
-    const size_t plane_stride = (size_t)M;              // S[z][px][py]: element (z, px, py) at ((z*Hx + px)*M + py)
-    // load both tiles: lanes walk py fastest (TL * 8 B contiguous), then z
-    for (int i = threadIdx.x; i < TL * L; i += kThreads) {
-        const int z = i / TL, j = i - z * TL;
-        const size_t zoff = (size_t)z * Hx;
-        tA[j * pitch + phys(z)] = S[(zoff + px) * plane_stride + py0 + j];
-        tB[j * pitch + phys(z)] = S[(zoff + pxB) * plane_stride + pyB0 + j];
+    // layout [px][z][py]: element (px, z, py) at ((px * L + z) * M + py); one float4 = lines (2 jp, 2 jp + 1)
+    const float4* sA = reinterpret_cast<const float4*>(S + (size_t)px * L * M + py0);
+    const float4* sB = reinterpret_cast<const float4*>(S + (size_t)pxB * L * M + pyB0);
+    const int hp = TL / 2, rowq = M / 2;
+#pragma unroll 4
+    for (int i = threadIdx.x; i < hp * L; i += kThreadsXZ) {
+        const int z = i / hp, jp = i - z * hp;
+        const float4 a = sA[(size_t)z * rowq + jp], b = sB[(size_t)z * rowq + jp];
+        tA[(2 * jp) * pitch + phys(z)] = make_float2(a.x, a.y);
+        tA[(2 * jp + 1) * pitch + phys(z)] = make_float2(a.z, a.w);
+        tB[(2 * jp) * pitch + phys(z)] = make_float2(b.x, b.y);
+        tB[(2 * jp + 1) * pitch + phys(z)] = make_float2(b.z, b.w);
+    }
+    // OTF pairs of this tile: issued now so the loads fly during the forward transform (8 float4 per lane at TL = 8)
+    constexpr int kMaxPre = 8;
+    const float4* Gp = G + ((size_t)plane * M + py0) * L;
+    float4 gpre[kMaxPre];
+#pragma unroll
+    for (int q = 0; q < kMaxPre; ++q) {
+        const int i = threadIdx.x + q * kThreadsXZ;
+        if (i < TL * L) gpre[q] = Gp[i];  // Gp[(size_t)j * L + pz] with i = j * L + pz
     }
     __syncthreads();
-    lds_fft<false>(tile, 2 * TL, pitch, d.lz, tw);
+    if (!(d.dbg & 1)) lds_fft<LZ, false, kThreadsXZ>(tile, 2 * TL, pitch, tw);
     // point-wise: element (line j, position pz) of A pairs with (line jB, position pzB) of B
     float sw, cw;
     sincospif(-2.0f * (float)xk / (float)(2 * Hx), &sw, &cw);  // w = exp(-2 pi i xk / Nx), Nx = 2 Hx
     const float2 w = make_float2(cw, sw);
-    const float4* Gp = G + ((size_t)plane * M + py0) * L;
-    for (int i = threadIdx.x; i < TL * L; i += kThreads) {
+    const int n_it = (TL * L + kThreadsXZ - 1) / kThreadsXZ;
+#pragma unroll 1
+    for (int q = 0; q < n_it; ++q) {
+        const int i = threadIdx.x + q * kThreadsXZ;
+        if (i >= TL * L || (d.dbg & 2)) break;
+        float4 g;
+        switch (q) {  // registers cannot be indexed dynamically: the first kMaxPre iterations use the prefetched values
+            case 0: g = gpre[0]; break; case 1: g = gpre[1]; break; case 2: g = gpre[2]; break; case 3: g = gpre[3]; break;
+            case 4: g = gpre[4]; break; case 5: g = gpre[5]; break; case 6: g = gpre[6]; break; case 7: g = gpre[7]; break;
+            default: g = Gp[i]; break;
+        }
         const int j = i / L, pz = i - j * L;
         const unsigned ky = brev_n((unsigned)(py0 + j), d.ly);
         const int jB = (int)brev_n((M - ky) & (M - 1), d.ly) - pyB0;
@@ -217,7 +270,6 @@ __global__ __launch_bounds__(kThreads) void k_z_conv(const float2* __restrict__ 
         const float2 O = make_float2(0.5f * dlt.y, -0.5f * dlt.x);  // -i/2 * (a - conj(b))
         const float2 wO = cmul(w, O);
         const float2 Xa = cadd(E, wO), Xb = csub(E, wO);
-        const float4 g = Gp[(size_t)j * L + pz];
         float2 Ga = make_float2(g.x, g.y), Gb = make_float2(g.z, g.w);
         if (CONJ) { Ga.y = -Ga.y; Gb.y = -Gb.y; }
         const float2 Ya = cmul(Xa, Ga), Yb = cmul(Xb, Gb);
@@ -229,36 +281,47 @@ __global__ __launch_bounds__(kThreads) void k_z_conv(const float2* __restrict__ 
         tB[jB * pitch + phys(pzB)] = make_float2(E2.x + O2.y, O2.x - E2.y);
     }
     __syncthreads();
-    lds_fft<true>(tile, 2 * TL, pitch, d.lz, tw);
-    for (int i = threadIdx.x; i < TL * L; i += kThreads) {
-        const int z = i / TL, j = i - z * TL;
-        const size_t zoff = (size_t)z * Hx;
-        T[(zoff + px) * plane_stride + py0 + j] = tA[j * pitch + phys(z)];
-        if (!self_plane) T[(zoff + pxB) * plane_stride + pyB0 + j] = tB[j * pitch + phys(z)];
+    if (!(d.dbg & 4)) lds_fft<LZ, true, kThreadsXZ>(tile, 2 * TL, pitch, tw);
+    float4* dA = reinterpret_cast<float4*>(T + (size_t)px * L * M + py0);
+    float4* dB = reinterpret_cast<float4*>(T + (size_t)pxB * L * M + pyB0);
+#pragma unroll 4
+    for (int i = threadIdx.x; i < hp * L; i += kThreadsXZ) {
+        const int z = i / hp, jp = i - z * hp;
+        const float2 a0 = tA[(2 * jp) * pitch + phys(z)], a1 = tA[(2 * jp + 1) * pitch + phys(z)];
+        dA[(size_t)z * rowq + jp] = make_float4(a0.x, a0.y, a1.x, a1.y);
+        if (!self_plane) {
+            const float2 b0 = tB[(2 * jp) * pitch + phys(z)], b1 = tB[(2 * jp + 1) * pitch + phys(z)];
+            dB[(size_t)z * rowq + jp] = make_float4(b0.x, b0.y, b1.x, b1.y);
+        }
     }
 }
 
 // ---------------------------------------------------------------------------------------------- P5: x inverse + epilogue
-template <int EPI>
-__global__ __launch_bounds__(kThreads) void k_x_inverse(const float2* __restrict__ T, float* __restrict__ out, ConvEpilogue e, NativeDims d,
+template <int LHX, int EPI>
+__global__ __launch_bounds__(kThreadsXZ) void k_x_inverse(const float2* __restrict__ T, float* __restrict__ out, ConvEpilogue e, NativeDims d,
                                                          const float2* __restrict__ tw) {
     extern __shared__ __attribute__((aligned(16))) float2 tile[];
-    const int Hx = 1 << d.lhx, TY = d.ty, pitch = row_pitch(Hx);
+    constexpr int Hx = 1 << LHX;
+    const int TY = d.ty, pitch = row_pitch(Hx);
     const int ytiles = d.ny / TY;
     const int z = blockIdx.x / ytiles, y0 = (blockIdx.x % ytiles) * TY;
-    const float2* src = T + ((size_t)z * Hx) * d.ny + y0;
-    for (int i = threadIdx.x; i < TY * Hx; i += kThreads) {
-        const int px = i / TY, r = i - px * TY;
-        tile[r * pitch + phys(px)] = src[(size_t)px * d.ny + r];
+    const float4* src = reinterpret_cast<const float4*>(T + ((size_t)z * Hx) * d.ny + y0);
+    const int hp = TY / 2, rowq = d.ny / 2;
+#pragma unroll 8
+    for (int i = threadIdx.x; i < hp * Hx; i += kThreadsXZ) {
+        const int px = i / hp, rp = i - px * hp;
+        const float4 v = src[(size_t)px * rowq + rp];
+        tile[(2 * rp) * pitch + phys(px)] = make_float2(v.x, v.y);
+        tile[(2 * rp + 1) * pitch + phys(px)] = make_float2(v.z, v.w);
     }
     __syncthreads();
-    lds_fft<true>(tile, TY, pitch, d.lhx, tw);
+    lds_fft<LHX, true, kThreadsXZ>(tile, TY, pitch, tw);
     const size_t row0 = ((size_t)z * d.ny + y0) * (size_t)(2 * Hx);
     const int quads = Hx / 2;
     float4* dst = reinterpret_cast<float4*>(out + row0);
     const float4* a4 = reinterpret_cast<const float4*>(e.a + row0);
     const float4* b4 = reinterpret_cast<const float4*>(e.b + row0);
-    for (int i = threadIdx.x; i < TY * quads; i += kThreads) {
+    for (int i = threadIdx.x; i < TY * quads; i += kThreadsXZ) {
         const int r = i / quads, q = i - r * quads;
         const float2* row = tile + r * pitch;
         const float2 c0 = row[phys(2 * q)], c1 = row[phys(2 * q + 1)];
@@ -287,7 +350,7 @@ __global__ __launch_bounds__(kThreads) void k_x_inverse(const float2* __restrict
 // ---------------------------------------------------------------------------------------------- OTF repack
 // From the R2C half spectrum H[kz][ky][kx], kx in [0, Hx] (rocFFT layout, unscaled or pre-scaled) to the pair
 // layout of k_z_conv: G[plane][py][pz] = {H_full[xk], H_full[xk + Hx]} at (ky, kz) = (brev(py), brev(pz)).
-__global__ __launch_bounds__(kThreads) void k_repack_otf(const float2* __restrict__ Hs, float4* __restrict__ G, NativeDims d, float scale) {
+__global__ __launch_bounds__(256) void k_repack_otf(const float2* __restrict__ Hs, float4* __restrict__ G, NativeDims d, float scale) {
     const int Hx = 1 << d.lhx, M = d.ny, L = d.nz;
     const size_t total = (size_t)(Hx / 2 + 1) * M * L;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -312,7 +375,7 @@ int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 bool NativeFft::supported(const int F[3]) {
     // x: real length 2*Hx with 8 <= Hx <= 4096; y, z: 4 .. 4096; LDS tiles must fit
     return is_pow2(F[0]) && is_pow2(F[1]) && is_pow2(F[2]) && F[0] >= 16 && F[0] <= 8192 && F[1] >= 8 && F[1] <= 4096 && F[2] >= 8 &&
-           F[2] <= 4096;
+           F[2] <= 2048;
 }
 
 static size_t lds_bytes(int rows, int n) { return sizeof(float2) * (size_t)rows * row_pitch(n); }
@@ -330,9 +393,21 @@ int NativeFft::init(hipStream_t s, const int F[3], const float2* otf_half_spectr
         while (rows > 1 && (lds_bytes(rows * mult, n) > budget)) rows >>= 1;
         return rows;
     };
-    dims.ty = std::min(fit(Hx, 16, 1), F[1]);
+    const size_t big = 140 * 1024;  // one work-group per CU for the strided passes: 16-wide tiles = full 128-B lines
+    auto fit_big = [&](int n, int maxrows, int mult) {
+        int rows = maxrows;
+        while (rows > 2 && (lds_bytes(rows * mult, n) > big)) rows >>= 1;
+        return rows;
+    };
+    dims.ty = std::min(fit_big(Hx, 16, 1), F[1]);
     dims.tc = std::min(fit(F[1], 16, 1), 1 << 30);
-    dims.tl = std::min(fit(F[2], 16, 2), F[1]);
+    dims.tl = std::min(fit_big(F[2], 16, 2), F[1]);
+    dims.dbg = 0;
+    if (const char* e = std::getenv("MI_FFT_ZDBG")) dims.dbg = atoi(e);  // phase knock-out for timing experiments
+    // tuning overrides (experiments only): MI_FFT_TY / MI_FFT_TC / MI_FFT_TL
+    if (const char* e = std::getenv("MI_FFT_TY")) dims.ty = std::max(2, std::min(atoi(e), F[1]));
+    if (const char* e = std::getenv("MI_FFT_TC")) dims.tc = std::max(1, atoi(e));
+    if (const char* e = std::getenv("MI_FFT_TL")) dims.tl = std::max(2, std::min(atoi(e), F[1]));
     while ((size_t)F[2] * Hx % dims.tc) dims.tc >>= 1;
     MI_REQUIRE(lds_bytes(dims.ty, Hx) <= 150 * 1024 && lds_bytes(dims.tc, F[1]) <= 150 * 1024 && lds_bytes(2 * dims.tl, F[2]) <= 150 * 1024,
                "native FFT: transform too long for LDS");
@@ -355,23 +430,24 @@ int NativeFft::init(hipStream_t s, const int F[3], const float2* otf_half_spectr
     tw_y = tw.as<float2>() + offs[1];
     tw_z = tw.as<float2>() + offs[2];
     const size_t total = (size_t)(Hx / 2 + 1) * F[1] * F[2];
-    size_t blocks = (total + kThreads - 1) / kThreads;
+    size_t blocks = (total + 256 - 1) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(k_repack_otf, dim3((unsigned)blocks), dim3(kThreads), 0, s, otf_half_spectrum, G.as<float4>(), dims, scale);
+    hipLaunchKernelGGL(k_repack_otf, dim3((unsigned)blocks), dim3(256), 0, s, otf_half_spectrum, G.as<float4>(), dims, scale);
     MI_TRY(launch_check("k_repack_otf"));
     MI_HIP(hipStreamSynchronize(s));  // host twiddle vector dies at scope exit
-    // opt in to > 64 KB of dynamic LDS where a tile needs it
-    const int big = 160 * 1024;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_x_forward), hipFuncAttributeMaxDynamicSharedMemorySize, big);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_y_pass<false>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_y_pass<true>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_z_conv<false>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_z_conv<true>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_x_inverse<EPI_NONE>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_x_inverse<EPI_RATIO>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_x_inverse<EPI_UPDATE>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_x_inverse<EPI_UPDATE_REG>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
     return MI_OK;
+}
+
+// ---- launch helpers: the kernels are templated on log2(length); lengths 2^3 .. 2^12 (z: 2^11) are instantiated
+#define MI_LOG_CASES(M) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12)
+#define MI_LOGZ_CASES(M) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11)
+
+template <class K, class... Args>
+static int launch_lds(K kernel, unsigned grid, int threads, size_t lds, hipStream_t s, const char* name, Args... args) {
+    if (lds > 64 * 1024)
+        MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), lds, s, args...);
+    return launch_check(name);
 }
 
 int NativeFft::conv(hipStream_t s, const float* in, bool conj_otf, float* out, int epi_kind, const ConvEpilogue& epi) {
@@ -381,29 +457,51 @@ int NativeFft::conv(hipStream_t s, const float* in, bool conj_otf, float* out, i
                "native FFT: volume pointers must be 16-byte aligned");
     float2* Sp = S.as<float2>();
     float2* Tp = T.as<float2>();
-    hipLaunchKernelGGL(k_x_forward, dim3((unsigned)((size_t)L * (M / dims.ty))), dim3(kThreads), lds_bytes(dims.ty, Hx), s, in, Sp, dims, tw_x);
-    MI_TRY(launch_check("k_x_forward"));
+    const float4* Gp = G.as<float4>();
+    const unsigned xtiles = (unsigned)((size_t)L * (M / dims.ty));
     const unsigned ycols = (unsigned)((size_t)L * Hx / dims.tc);
-    hipLaunchKernelGGL(k_y_pass<false>, dim3(ycols), dim3(kThreads), lds_bytes(dims.tc, M), s, Sp, dims, tw_y);
-    MI_TRY(launch_check("k_y_pass<fwd>"));
     const unsigned ztiles = (unsigned)((size_t)(Hx / 2 + 1) * (M / dims.tl));
-    if (conj_otf)
-        hipLaunchKernelGGL(k_z_conv<true>, dim3(ztiles), dim3(kThreads), lds_bytes(2 * dims.tl, L), s, Sp, Tp, G.as<float4>(), dims, tw_z);
-    else
-        hipLaunchKernelGGL(k_z_conv<false>, dim3(ztiles), dim3(kThreads), lds_bytes(2 * dims.tl, L), s, Sp, Tp, G.as<float4>(), dims, tw_z);
-    MI_TRY(launch_check("k_z_conv"));
-    hipLaunchKernelGGL(k_y_pass<true>, dim3(ycols), dim3(kThreads), lds_bytes(dims.tc, M), s, Tp, dims, tw_y);
-    MI_TRY(launch_check("k_y_pass<inv>"));
-    const dim3 xg((unsigned)((size_t)L * (M / dims.ty)));
-    const size_t xl = lds_bytes(dims.ty, Hx);
-    switch (epi_kind) {
-        case EPI_NONE: case EPI_TAPER_SHELL: hipLaunchKernelGGL(k_x_inverse<EPI_NONE>, xg, dim3(kThreads), xl, s, Tp, out, epi, dims, tw_x); break;
-        case EPI_RATIO: hipLaunchKernelGGL(k_x_inverse<EPI_RATIO>, xg, dim3(kThreads), xl, s, Tp, out, epi, dims, tw_x); break;
-        case EPI_UPDATE: hipLaunchKernelGGL(k_x_inverse<EPI_UPDATE>, xg, dim3(kThreads), xl, s, Tp, out, epi, dims, tw_x); break;
-        case EPI_UPDATE_REG: hipLaunchKernelGGL(k_x_inverse<EPI_UPDATE_REG>, xg, dim3(kThreads), xl, s, Tp, out, epi, dims, tw_x); break;
-        default: return fail(MI_ERR_INVALID, "native FFT: unknown epilogue %d", epi_kind);
-    }
-    return launch_check("k_x_inverse");
+    const size_t xl = lds_bytes(dims.ty, Hx), yl = lds_bytes(dims.tc, M), zl = lds_bytes(2 * dims.tl, L);
+    const NativeDims d = dims;
+    const float2 *twx = tw_x, *twy = tw_y, *twz = tw_z;
+    int rc = MI_ERR_INVALID;
+    // P1
+#define MI_X(LG) case LG: rc = launch_lds(k_x_forward<LG>, xtiles, kThreadsXZ, xl, s, "k_x_forward", in, Sp, d, twx); break;
+    switch (dims.lhx) { MI_LOG_CASES(MI_X) default: return fail(MI_ERR_UNSUPPORTED, "native FFT: x length 2^%d", dims.lhx); }
+#undef MI_X
+    MI_TRY(rc);
+    // P2: S[z][px][.] -> T[px][z][.]
+#define MI_Y(LG) case LG: rc = launch_lds(k_y_pass<LG, false>, ycols, kThreadsY, yl, s, "k_y_pass<fwd>", (const float2*)Sp, Tp, d, twy); break;
+    switch (dims.ly) { MI_LOG_CASES(MI_Y) default: return fail(MI_ERR_UNSUPPORTED, "native FFT: y length 2^%d", dims.ly); }
+#undef MI_Y
+    MI_TRY(rc);
+    // P3: T -> S, both [px][z][py]
+#define MI_Z(LG)                                                                                                          \
+    case LG:                                                                                                              \
+        rc = conj_otf ? launch_lds(k_z_conv<LG, true>, ztiles, kThreadsXZ, zl, s, "k_z_conv<conj>", (const float2*)Tp, Sp, Gp, d, twz) \
+                      : launch_lds(k_z_conv<LG, false>, ztiles, kThreadsXZ, zl, s, "k_z_conv", (const float2*)Tp, Sp, Gp, d, twz);     \
+        break;
+    switch (dims.lz) { MI_LOGZ_CASES(MI_Z) default: return fail(MI_ERR_UNSUPPORTED, "native FFT: z length 2^%d", dims.lz); }
+#undef MI_Z
+    MI_TRY(rc);
+    // P4: S[px][z][.] -> T[z][px][.]
+#define MI_Y(LG) case LG: rc = launch_lds(k_y_pass<LG, true>, ycols, kThreadsY, yl, s, "k_y_pass<inv>", (const float2*)Sp, Tp, d, twy); break;
+    switch (dims.ly) { MI_LOG_CASES(MI_Y) default: return fail(MI_ERR_UNSUPPORTED, "native FFT: y length 2^%d", dims.ly); }
+#undef MI_Y
+    MI_TRY(rc);
+    // P5
+    const int ek = epi_kind == EPI_TAPER_SHELL ? EPI_NONE : epi_kind;
+    MI_REQUIRE(ek == EPI_NONE || ek == EPI_RATIO || ek == EPI_UPDATE || ek == EPI_UPDATE_REG, "native FFT: unknown epilogue %d", epi_kind);
+#define MI_XI(LG)                                                                                                                     \
+    case LG:                                                                                                                          \
+        if (ek == EPI_NONE) rc = launch_lds(k_x_inverse<LG, EPI_NONE>, xtiles, kThreadsXZ, xl, s, "k_x_inverse", (const float2*)Tp, out, epi, d, twx); \
+        else if (ek == EPI_RATIO) rc = launch_lds(k_x_inverse<LG, EPI_RATIO>, xtiles, kThreadsXZ, xl, s, "k_x_inverse", (const float2*)Tp, out, epi, d, twx); \
+        else if (ek == EPI_UPDATE) rc = launch_lds(k_x_inverse<LG, EPI_UPDATE>, xtiles, kThreadsXZ, xl, s, "k_x_inverse", (const float2*)Tp, out, epi, d, twx); \
+        else rc = launch_lds(k_x_inverse<LG, EPI_UPDATE_REG>, xtiles, kThreadsXZ, xl, s, "k_x_inverse", (const float2*)Tp, out, epi, d, twx);     \
+        break;
+    switch (dims.lhx) { MI_LOG_CASES(MI_XI) default: return fail(MI_ERR_UNSUPPORTED, "native FFT: x length 2^%d", dims.lhx); }
+#undef MI_XI
+    return rc;
 }
 
 }  // namespace mi
