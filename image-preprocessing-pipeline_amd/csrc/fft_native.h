@@ -23,6 +23,11 @@ struct NativeFft {
     // otf_half_spectrum: R2C layout [Z][Y][X/2+1]; it is multiplied by `scale` while being repacked
     int init(hipStream_t s, const int F[3], const float2* otf_half_spectrum, float scale);
     int conv(hipStream_t s, const float* in, bool conj_otf, float* out, int epi_kind, const ConvEpilogue& epi);
+    // n fused RL iterations on bl in place (lambda = 0, no regularisation step in between)
+    int iterate(hipStream_t s, float* bl, int n_iters);
+    int x_forward(hipStream_t s, const float* in);
+    int middle(hipStream_t s, bool conj_otf);
+    int x_inverse(hipStream_t s, float* out, int epi_kind, const ConvEpilogue& epi, bool fuse_forward);
     size_t device_bytes() const { return S.bytes + T.bytes + G.bytes + tw.bytes; }
 };
 

@@ -297,9 +297,11 @@ __global__ __launch_bounds__(kThreadsXZ) void k_z_conv(const float2* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------- P5: x inverse + epilogue
-template <int LHX, int EPI>
+// FUSE: the epilogue result stays in LDS and is transformed forward again into S_next (the P1 of the NEXT
+// convolution): the ratio never touches HBM, and bl is read once and written once per iteration.
+template <int LHX, int EPI, bool FUSE>
 __global__ __launch_bounds__(kThreadsXZ) void k_x_inverse(const float2* __restrict__ T, float* __restrict__ out, ConvEpilogue e, NativeDims d,
-                                                         const float2* __restrict__ tw) {
+                                                         const float2* __restrict__ tw, float2* __restrict__ S_next) {
     extern __shared__ __attribute__((aligned(16))) float2 tile[];
     constexpr int Hx = 1 << LHX;
     const int TY = d.ty, pitch = row_pitch(Hx);
@@ -343,7 +345,23 @@ __global__ __launch_bounds__(kThreadsXZ) void k_x_inverse(const float2* __restri
                                 fabsf(av.w * c.w * m + bv.w * l));
             }
         }
-        dst[gi] = o;
+        if (!FUSE || out != nullptr) dst[gi] = o;
+        if (FUSE) {
+            float2* wrow = tile + r * pitch;
+            wrow[phys(2 * q)] = make_float2(o.x, o.y);
+            wrow[phys(2 * q + 1)] = make_float2(o.z, o.w);
+        }
+    }
+    if (FUSE) {
+        __syncthreads();
+        lds_fft<LHX, false, kThreadsXZ>(tile, TY, pitch, tw);
+        float4* sdst = reinterpret_cast<float4*>(S_next + ((size_t)z * Hx) * d.ny + y0);
+#pragma unroll 4
+        for (int i = threadIdx.x; i < hp * Hx; i += kThreadsXZ) {
+            const int px = i / hp, rp = i - px * hp;
+            const float2 a = tile[(2 * rp) * pitch + phys(px)], b = tile[(2 * rp + 1) * pitch + phys(px)];
+            sdst[(size_t)px * rowq + rp] = make_float4(a.x, a.y, b.x, b.y);
+        }
     }
 }
 
@@ -450,58 +468,113 @@ static int launch_lds(K kernel, unsigned grid, int threads, size_t lds, hipStrea
     return launch_check(name);
 }
 
-int NativeFft::conv(hipStream_t s, const float* in, bool conj_otf, float* out, int epi_kind, const ConvEpilogue& epi) {
+int NativeFft::x_forward(hipStream_t s, const float* in) {
     const int Hx = 1 << dims.lhx, M = dims.ny, L = dims.nz;
-    MI_REQUIRE(((uintptr_t)in % 16) == 0 && ((uintptr_t)out % 16) == 0 && (!epi.a || ((uintptr_t)epi.a % 16) == 0) &&
-                   (!epi.b || ((uintptr_t)epi.b % 16) == 0),
-               "native FFT: volume pointers must be 16-byte aligned");
-    float2* Sp = S.as<float2>();
-    float2* Tp = T.as<float2>();
-    const float4* Gp = G.as<float4>();
     const unsigned xtiles = (unsigned)((size_t)L * (M / dims.ty));
-    const unsigned ycols = (unsigned)((size_t)L * Hx / dims.tc);
-    const unsigned ztiles = (unsigned)((size_t)(Hx / 2 + 1) * (M / dims.tl));
-    const size_t xl = lds_bytes(dims.ty, Hx), yl = lds_bytes(dims.tc, M), zl = lds_bytes(2 * dims.tl, L);
+    const size_t xl = lds_bytes(dims.ty, Hx);
     const NativeDims d = dims;
-    const float2 *twx = tw_x, *twy = tw_y, *twz = tw_z;
+    float2* Sp = S.as<float2>();
+    const float2* twx = tw_x;
     int rc = MI_ERR_INVALID;
-    // P1
 #define MI_X(LG) case LG: rc = launch_lds(k_x_forward<LG>, xtiles, kThreadsXZ, xl, s, "k_x_forward", in, Sp, d, twx); break;
     switch (dims.lhx) { MI_LOG_CASES(MI_X) default: return fail(MI_ERR_UNSUPPORTED, "native FFT: x length 2^%d", dims.lhx); }
 #undef MI_X
-    MI_TRY(rc);
-    // P2: S[z][px][.] -> T[px][z][.]
+    return rc;
+}
+
+// P2, P3, P4: S[z][px][py] -> T[z][px][py] (x still transformed), multiplied by the OTF or its conjugate
+int NativeFft::middle(hipStream_t s, bool conj_otf) {
+    const int Hx = 1 << dims.lhx, M = dims.ny, L = dims.nz;
+    float2* Sp = S.as<float2>();
+    float2* Tp = T.as<float2>();
+    const float4* Gp = G.as<float4>();
+    const unsigned ycols = (unsigned)((size_t)L * Hx / dims.tc);
+    const unsigned ztiles = (unsigned)((size_t)(Hx / 2 + 1) * (M / dims.tl));
+    const size_t yl = lds_bytes(dims.tc, M), zl = lds_bytes(2 * dims.tl, L);
+    const NativeDims d = dims;
+    const float2 *twy = tw_y, *twz = tw_z;
+    int rc = MI_ERR_INVALID;
 #define MI_Y(LG) case LG: rc = launch_lds(k_y_pass<LG, false>, ycols, kThreadsY, yl, s, "k_y_pass<fwd>", (const float2*)Sp, Tp, d, twy); break;
     switch (dims.ly) { MI_LOG_CASES(MI_Y) default: return fail(MI_ERR_UNSUPPORTED, "native FFT: y length 2^%d", dims.ly); }
 #undef MI_Y
     MI_TRY(rc);
-    // P3: T -> S, both [px][z][py]
-#define MI_Z(LG)                                                                                                          \
-    case LG:                                                                                                              \
+#define MI_Z(LG)                                                                                                                       \
+    case LG:                                                                                                                           \
         rc = conj_otf ? launch_lds(k_z_conv<LG, true>, ztiles, kThreadsXZ, zl, s, "k_z_conv<conj>", (const float2*)Tp, Sp, Gp, d, twz) \
                       : launch_lds(k_z_conv<LG, false>, ztiles, kThreadsXZ, zl, s, "k_z_conv", (const float2*)Tp, Sp, Gp, d, twz);     \
         break;
     switch (dims.lz) { MI_LOGZ_CASES(MI_Z) default: return fail(MI_ERR_UNSUPPORTED, "native FFT: z length 2^%d", dims.lz); }
 #undef MI_Z
     MI_TRY(rc);
-    // P4: S[px][z][.] -> T[z][px][.]
 #define MI_Y(LG) case LG: rc = launch_lds(k_y_pass<LG, true>, ycols, kThreadsY, yl, s, "k_y_pass<inv>", (const float2*)Sp, Tp, d, twy); break;
     switch (dims.ly) { MI_LOG_CASES(MI_Y) default: return fail(MI_ERR_UNSUPPORTED, "native FFT: y length 2^%d", dims.ly); }
 #undef MI_Y
-    MI_TRY(rc);
-    // P5
+    return rc;
+}
+
+// P5 (+ P1 of the next convolution when fuse_forward): T -> out (may be null when fused) [-> S]
+int NativeFft::x_inverse(hipStream_t s, float* out, int epi_kind, const ConvEpilogue& epi, bool fuse_forward) {
+    const int Hx = 1 << dims.lhx, M = dims.ny, L = dims.nz;
+    const unsigned xtiles = (unsigned)((size_t)L * (M / dims.ty));
+    const size_t xl = lds_bytes(dims.ty, Hx);
+    const NativeDims d = dims;
+    const float2* Tp = T.as<float2>();
+    float2* Sp = S.as<float2>();
+    const float2* twx = tw_x;
     const int ek = epi_kind == EPI_TAPER_SHELL ? EPI_NONE : epi_kind;
     MI_REQUIRE(ek == EPI_NONE || ek == EPI_RATIO || ek == EPI_UPDATE || ek == EPI_UPDATE_REG, "native FFT: unknown epilogue %d", epi_kind);
-#define MI_XI(LG)                                                                                                                     \
-    case LG:                                                                                                                          \
-        if (ek == EPI_NONE) rc = launch_lds(k_x_inverse<LG, EPI_NONE>, xtiles, kThreadsXZ, xl, s, "k_x_inverse", (const float2*)Tp, out, epi, d, twx); \
-        else if (ek == EPI_RATIO) rc = launch_lds(k_x_inverse<LG, EPI_RATIO>, xtiles, kThreadsXZ, xl, s, "k_x_inverse", (const float2*)Tp, out, epi, d, twx); \
-        else if (ek == EPI_UPDATE) rc = launch_lds(k_x_inverse<LG, EPI_UPDATE>, xtiles, kThreadsXZ, xl, s, "k_x_inverse", (const float2*)Tp, out, epi, d, twx); \
-        else rc = launch_lds(k_x_inverse<LG, EPI_UPDATE_REG>, xtiles, kThreadsXZ, xl, s, "k_x_inverse", (const float2*)Tp, out, epi, d, twx);     \
+    MI_REQUIRE(!fuse_forward || ek == EPI_RATIO || ek == EPI_UPDATE, "native FFT: only the plain RL epilogues fuse");
+    int rc = MI_ERR_INVALID;
+#define MI_XI(LG)                                                                                                                          \
+    case LG:                                                                                                                               \
+        if (fuse_forward && ek == EPI_RATIO)                                                                                               \
+            rc = launch_lds(k_x_inverse<LG, EPI_RATIO, true>, xtiles, kThreadsXZ, xl, s, "k_x_inverse<fused>", Tp, out, epi, d, twx, Sp);   \
+        else if (fuse_forward)                                                                                                             \
+            rc = launch_lds(k_x_inverse<LG, EPI_UPDATE, true>, xtiles, kThreadsXZ, xl, s, "k_x_inverse<fused>", Tp, out, epi, d, twx, Sp);  \
+        else if (ek == EPI_NONE)                                                                                                           \
+            rc = launch_lds(k_x_inverse<LG, EPI_NONE, false>, xtiles, kThreadsXZ, xl, s, "k_x_inverse", Tp, out, epi, d, twx, Sp);          \
+        else if (ek == EPI_RATIO)                                                                                                          \
+            rc = launch_lds(k_x_inverse<LG, EPI_RATIO, false>, xtiles, kThreadsXZ, xl, s, "k_x_inverse", Tp, out, epi, d, twx, Sp);         \
+        else if (ek == EPI_UPDATE)                                                                                                         \
+            rc = launch_lds(k_x_inverse<LG, EPI_UPDATE, false>, xtiles, kThreadsXZ, xl, s, "k_x_inverse", Tp, out, epi, d, twx, Sp);        \
+        else                                                                                                                               \
+            rc = launch_lds(k_x_inverse<LG, EPI_UPDATE_REG, false>, xtiles, kThreadsXZ, xl, s, "k_x_inverse", Tp, out, epi, d, twx, Sp);    \
         break;
     switch (dims.lhx) { MI_LOG_CASES(MI_XI) default: return fail(MI_ERR_UNSUPPORTED, "native FFT: x length 2^%d", dims.lhx); }
 #undef MI_XI
     return rc;
+}
+
+static int check_aligned(const void* p, const char* what) {
+    MI_REQUIRE(p == nullptr || ((uintptr_t)p % 16) == 0, "native FFT: %s must be 16-byte aligned", what);
+    return MI_OK;
+}
+
+int NativeFft::conv(hipStream_t s, const float* in, bool conj_otf, float* out, int epi_kind, const ConvEpilogue& epi) {
+    MI_TRY(check_aligned(in, "input"));
+    MI_TRY(check_aligned(out, "output"));
+    MI_TRY(check_aligned(epi.a, "epilogue operand"));
+    MI_TRY(check_aligned(epi.b, "epilogue operand"));
+    MI_TRY(x_forward(s, in));
+    MI_TRY(middle(s, conj_otf));
+    return x_inverse(s, out, epi_kind, epi, false);
+}
+
+// n whole RL iterations (decon.m:162-186 with lambda = 0) in 8 passes each: the x passes of consecutive
+// convolutions are fused, so per iteration bl is read twice and written once and the ratio never exists in HBM.
+int NativeFft::iterate(hipStream_t s, float* bl, int n_iters) {
+    MI_TRY(check_aligned(bl, "bl"));
+    if (n_iters <= 0) return MI_OK;
+    ConvEpilogue e;
+    e.a = bl;
+    MI_TRY(x_forward(s, bl));
+    for (int it = 0; it < n_iters; ++it) {
+        MI_TRY(middle(s, false));
+        MI_TRY(x_inverse(s, nullptr, EPI_RATIO, e, true));   // ratio = bl ./ max(c, eps) -> S, not stored
+        MI_TRY(middle(s, true));
+        MI_TRY(x_inverse(s, bl, EPI_UPDATE, e, it + 1 < n_iters));  // bl = |bl .* a| (-> S for the next iteration)
+    }
+    return MI_OK;
 }
 
 }  // namespace mi

@@ -160,6 +160,19 @@ extern "C" int mi_rl_adjoint_update(mi_rl_ctx* ctx, void* stream, const float* r
     return ctx_conv(ctx, as_stream(stream), ratio, true, bl, with_reg ? EPI_UPDATE_REG : EPI_UPDATE, e);
 }
 
+extern "C" int mi_rl_iterate(mi_rl_ctx* ctx, void* stream, float* bl, float* ratio, int n_iters) {
+    MI_REQUIRE(ctx && bl, "mi_rl_iterate: null pointer");
+    MI_REQUIRE(n_iters >= 0, "mi_rl_iterate: negative iteration count");
+    MI_TRY(use_device(ctx->dev));
+    if (ctx->engine == MI_ENGINE_FFT && ctx->fft->native) return ctx->fft->native->iterate(as_stream(stream), bl, n_iters);
+    MI_REQUIRE(ratio && ratio != bl, "mi_rl_iterate: this engine needs a ratio scratch volume");
+    for (int i = 0; i < n_iters; ++i) {
+        MI_TRY(mi_rl_forward_ratio(ctx, stream, bl, ratio));
+        MI_TRY(mi_rl_adjoint_update(ctx, stream, ratio, bl, 0.0f, nullptr));
+    }
+    return MI_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 extern "C" int mi_conv3d(int dev, void* stream, const float* img, const float* ker, float* out, int nx, int ny, int nz, int kx, int ky,
                          int kz, int boundary, int engine) {
@@ -226,23 +239,33 @@ int rl_iterate(mi_rl_ctx* ctx, hipStream_t s, float* bl, float* ratio, float* re
     const float sig[3] = {0.5f, 0.5f, 0.5f};
     const int k3[3] = {3, 3, 3};
     int done = 0;
-    for (int i = 1; i <= o.niter; ++i) {
+    for (int i = 1; i <= o.niter;) {
         const bool reg_time = regularization_time(i, o.niter, o.regularize_interval);
-        if (reg_time) MI_TRY(gauss3d_async(s, bl, ratio, nx, ny, nz, sig, o.gauss_taps == 3 ? k3 : nullptr));  // decon.m:57-59
-        MI_TRY(mi_rl_forward_ratio(ctx, s, bl, ratio));
-        if (reg_time && o.lambda > 0.0f) {
-            MI_TRY(mi_rl_reg_term(ctx->dev, s, bl, reg, nx, ny, nz));
-            MI_TRY(mi_rl_adjoint_update(ctx, s, ratio, bl, o.lambda, reg));
+        int span = 1;
+        if (reg_time) {
+            MI_TRY(gauss3d_async(s, bl, ratio, nx, ny, nz, sig, o.gauss_taps == 3 ? k3 : nullptr));  // decon.m:57-59
+            MI_TRY(mi_rl_forward_ratio(ctx, s, bl, ratio));
+            if (o.lambda > 0.0f) {
+                MI_TRY(mi_rl_reg_term(ctx->dev, s, bl, reg, nx, ny, nz));
+                MI_TRY(mi_rl_adjoint_update(ctx, s, ratio, bl, o.lambda, reg));
+            } else {
+                MI_TRY(mi_rl_adjoint_update(ctx, s, ratio, bl, 0.0f, nullptr));
+            }
         } else {
-            MI_TRY(mi_rl_adjoint_update(ctx, s, ratio, bl, 0.0f, nullptr));
+            // run of plain iterations up to the next regularisation step: one call, so an engine that can fuse
+            // consecutive iterations (native FFT pipeline) does; the stop test needs the norm after every iteration
+            if (o.stop_criterion <= 0.0f)
+                while (i + span <= o.niter && !regularization_time(i + span, o.niter, o.regularize_interval)) ++span;
+            MI_TRY(mi_rl_iterate(ctx, s, bl, ratio, span));
         }
-        done = i;
+        i += span;
+        done = i - 1;
         if (o.stop_criterion > 0.0f) {  // decon.m:108-118
             double cur = 0.0;
             MI_TRY(host_norm(s, bl, N, d_scratch, &cur));
             const double rel = std::fabs(delta_prev - cur) / delta_prev * 100.0;
             delta_prev = cur;
-            if (i > 1 && rel <= (double)o.stop_criterion) break;
+            if (done > 1 && rel <= (double)o.stop_criterion) break;
         }
     }
     if (iters_done) *iters_done = done;

@@ -265,6 +265,15 @@ class RLContext:
         check(lib().mi_rl_adjoint_update(self._h, _stream(bl), ratio.data_ptr(), bl.data_ptr(), float(lambda_),
                                          reg.data_ptr() if reg is not None else None))
 
+    def iterate(self, bl, ratio=None, n_iters=1):
+        """``n_iters`` plain RL iterations on ``bl`` in place (mi_rl_iterate); ``ratio`` is scratch for engines
+        that cannot fuse the two convolutions."""
+        self._chk(bl)
+        if ratio is not None:
+            self._chk(ratio)
+        check(lib().mi_rl_iterate(self._h, _stream(bl), bl.data_ptr(), ratio.data_ptr() if ratio is not None else None,
+                                  int(n_iters)))
+
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
             lib().mi_rl_destroy(self._h)

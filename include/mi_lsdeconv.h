@@ -99,6 +99,10 @@ int mi_rl_forward_ratio(mi_rl_ctx* ctx, void* stream, const float* bl, float* ra
 /* bl = abs(bl .* conv(ratio, psf_inv))                      [decon.m:64,76,79 / :169-186]
  * or, with lambda > 0 and reg != NULL, abs(bl.*conv.*(1-lambda) + reg.*lambda)   [decon.m:69-71] */
 int mi_rl_adjoint_update(mi_rl_ctx* ctx, void* stream, const float* ratio, float* bl, float lambda, const float* reg);
+/* n_iters plain RL iterations (lambda = 0, no regularisation step) on bl in place.  Engines that can fuse across
+ * the two convolutions do (native FFT pipeline: 8 volume passes per iteration, the ratio never reaches HBM, `ratio`
+ * may then be NULL); the others run forward_ratio / adjoint_update n_iters times using `ratio` as scratch. */
+int mi_rl_iterate(mi_rl_ctx* ctx, void* stream, float* bl, float* ratio, int n_iters);
 /* reg = convn(bl, R, 'same'), R = ones(3,3,3)/26 with centre 0   [decon.m:42,70] */
 int mi_rl_reg_term(int dev, void* stream, const float* bl, float* reg, int nx, int ny, int nz);
 

@@ -64,3 +64,26 @@ def test_adjoint_is_exact_transpose(dev):
     lhs = float((conv_a.double() * b.double()).sum())
     rhs = float((a.double() * ones.double()).sum())
     assert abs(lhs - rhs) / abs(lhs) < 1e-5
+
+
+@pytest.mark.parametrize("shape", [(16, 32, 64), (8, 16, 256)])
+def test_fused_iterations_equal_unfused_and_direct_engine(dev, shape):
+    """mi_rl_iterate: the fused 8-pass iteration of the native pipeline vs the two half-steps vs the direct engine."""
+    from ipp_amd import capi, decon
+    psf = R.gaussian_psf((5, 5, 7), (1.0, 1.0, 1.5))
+    vol = torch.from_numpy(R.bead_volume(shape, seed=9, psf=psf)).to(dev)
+    fft = decon.RLContext(shape, psf, None, boundary=capi.BOUNDARY_CIRCULAR, engine=capi.ENGINE_FFT, device=dev)
+    direct = decon.RLContext(shape, psf, None, boundary=capi.BOUNDARY_CIRCULAR, engine=capi.ENGINE_DIRECT, device=dev)
+    a, b, c = vol.clone(), vol.clone(), vol.clone()
+    ratio = torch.empty_like(vol)
+    fft.iterate(a, None, 4)                      # fused, no ratio scratch needed
+    for _ in range(4):
+        fft.forward_ratio(b, ratio)
+        fft.adjoint_update(ratio, b)
+    direct.iterate(c, ratio, 4)
+    want = R.decon_fft(vol.cpu().numpy(), psf, shape, 4, skip_edgetaper=True)
+    assert _rel(a.cpu().numpy(), b.cpu().numpy()) < 1e-5
+    assert _rel(a.cpu().numpy(), c.cpu().numpy()) < 1e-4
+    assert _rel(a.cpu().numpy(), want) < 1e-4
+    with pytest.raises(capi.MiError, match="ratio scratch"):
+        direct.iterate(c, None, 1)
