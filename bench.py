@@ -160,8 +160,35 @@ def main():
         ms_per_step = elapsed * 1e3 / args.steps
         value = n_vox_global * args.steps / elapsed / 1e9
         local_vox = n_vox_global / world
-        # dominant "kernel": one RL iteration of the FFT pipeline on this rank's slab
-        achieved = ALGO_BYTES_PER_VOXEL_ITER * local_vox / (dev_ms / args.steps * 1e-3) / 1e9
+        iteration_gbs = ALGO_BYTES_PER_VOXEL_ITER * local_vox / (dev_ms / args.steps * 1e-3) / 1e9
+        roofline = None
+        if world == 1 and engine_used == 2:
+            try:
+                # per-pass launch durations, HIP events on the launch stream (mi_rl_time_pass); the dominant kernel
+                # is the one with the largest share of an iteration
+                per_iter = {"x_fused": 2, "y_forward": 2, "z_conv": 2, "y_inverse": 2}
+                times = {k: ctx.time_pass(k, bl, reps=5) for k in per_iter}
+                dom = max(times, key=lambda k: times[k] * per_iter[k])
+                algo_b = {"z_conv": 12, "y_forward": 8, "y_inverse": 8, "x_fused": 12}[dom]  # B per voxel per launch
+                ach = algo_b * local_vox / (times[dom] * 1e-3) / 1e9
+                roofline = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                            "kernel": {"z_conv": "k_z_conv (z-forward FFT + untangle*OTF + z-inverse FFT, one pass)",
+                                       "x_fused": "k_x_inverse<fused> (x-inverse FFT + RL epilogue + x-forward FFT)",
+                                       "y_forward": "k_y_pass<fwd>", "y_inverse": "k_y_pass<inv>"}[dom],
+                            "algorithmic_bytes_per_voxel_per_launch": algo_b,
+                            "launch_ms": round(times[dom], 4), "launches_per_iteration": per_iter[dom],
+                            "pass_ms": {k: round(v, 4) for k, v in times.items()}}
+            except Exception as e:  # e.g. rocFFT fallback: no per-pass hook
+                roofline = None
+                sys.stderr.write(f"per-pass timing unavailable: {e!r}\n")
+        if roofline is None:
+            roofline = {"bound": "hbm", "achieved": round(iteration_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(iteration_gbs / HBM_PEAK_GBS, 5), "traffic": None,
+                        "kernel": "rl_iteration (whole pipeline; no per-kernel hook on this engine)"}
+        roofline["iteration"] = {"algorithmic_bytes_per_voxel_iter": ALGO_BYTES_PER_VOXEL_ITER,
+                                 "achieved_GBps": round(iteration_gbs, 2), "frac": round(iteration_gbs / HBM_PEAK_GBS, 5),
+                                 "device_ms_per_iteration": round(dev_ms / args.steps, 4)}
         out = {
             "metric": "RL-deconv Gvoxels/sec", "value": round(value, 4), "unit": "Gvoxel*iter/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
@@ -170,11 +197,7 @@ def main():
             "config": {"workload": f"{args.workload}: {vshape[2]}x{vshape[1]}x{vshape[0]} fp32 volume, "
                                    f"{kshape[2]}x{kshape[1]}x{kshape[0]} PSF, deconFFT semantics, lambda=0, reg_interval=0",
                        "engine": {1: "direct", 2: "fft"}.get(engine_used, str(engine_used)), "parallelism": parallelism},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                         "kernel": "rl_iteration (R2C, OTF multiply, C2R, epilogue x2)",
-                         "algorithmic_bytes_per_voxel_iter": ALGO_BYTES_PER_VOXEL_ITER,
-                         "device_ms_per_iteration": round(dev_ms / args.steps, 4)},
+            "roofline": roofline,
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(kshape)

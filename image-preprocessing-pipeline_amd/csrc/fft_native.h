@@ -25,6 +25,7 @@ struct NativeFft {
     int conv(hipStream_t s, const float* in, bool conj_otf, float* out, int epi_kind, const ConvEpilogue& epi);
     // n fused RL iterations on bl in place (lambda = 0, no regularisation step in between)
     int iterate(hipStream_t s, float* bl, int n_iters);
+    int time_pass(hipStream_t s, int which, const float* bl, int reps, float* avg_ms);
     int x_forward(hipStream_t s, const float* in);
     int middle(hipStream_t s, bool conj_otf);
     int x_inverse(hipStream_t s, float* out, int epi_kind, const ConvEpilogue& epi, bool fuse_forward);

@@ -545,6 +545,58 @@ int NativeFft::x_inverse(hipStream_t s, float* out, int epi_kind, const ConvEpil
     return rc;
 }
 
+// Average duration (ms) of one launch of a single pass, measured with HIP events on `s` (bench.py's roofline leg).
+// which: 0 x forward, 1 y forward, 2 z convolution, 3 y inverse, 4 fused x inverse+ratio+forward.  The buffers
+// keep whatever the previous convolution left in them; `bl` is only read.
+int NativeFft::time_pass(hipStream_t s, int which, const float* bl, int reps, float* avg_ms) {
+    MI_REQUIRE(reps > 0 && avg_ms && which >= 0 && which <= 4, "time_pass: bad arguments");
+    const int Hx = 1 << dims.lhx, M = dims.ny, L = dims.nz;
+    float2* Sp = S.as<float2>();
+    float2* Tp = T.as<float2>();
+    const NativeDims d = dims;
+    hipEvent_t e0, e1;
+    MI_HIP(hipEventCreate(&e0));
+    MI_HIP(hipEventCreate(&e1));
+    int rc = MI_OK;
+    ConvEpilogue e;
+    e.a = bl;
+    for (int r = -1; r < reps && rc == MI_OK; ++r) {  // r == -1: warm-up launch
+        if (r == 0) (void)hipEventRecord(e0, s);
+        switch (which) {
+            case 0: rc = x_forward(s, bl); break;
+            case 4: rc = x_inverse(s, nullptr, EPI_RATIO, e, true); break;
+            default: {
+                const unsigned ycols = (unsigned)((size_t)L * Hx / dims.tc);
+                const unsigned ztiles = (unsigned)((size_t)(Hx / 2 + 1) * (M / dims.tl));
+                const size_t yl = lds_bytes(dims.tc, M), zl = lds_bytes(2 * dims.tl, L);
+                rc = MI_ERR_INVALID;
+                if (which == 1) {
+#define MI_Y(LG) case LG: rc = launch_lds(k_y_pass<LG, false>, ycols, kThreadsY, yl, s, "k_y_pass<fwd>", (const float2*)Sp, Tp, d, tw_y); break;
+                    switch (dims.ly) { MI_LOG_CASES(MI_Y) default: break; }
+#undef MI_Y
+                } else if (which == 3) {
+#define MI_Y(LG) case LG: rc = launch_lds(k_y_pass<LG, true>, ycols, kThreadsY, yl, s, "k_y_pass<inv>", (const float2*)Sp, Tp, d, tw_y); break;
+                    switch (dims.ly) { MI_LOG_CASES(MI_Y) default: break; }
+#undef MI_Y
+                } else {
+#define MI_Z(LG) case LG: rc = launch_lds(k_z_conv<LG, false>, ztiles, kThreadsXZ, zl, s, "k_z_conv", (const float2*)Tp, Sp, G.as<float4>(), d, tw_z); break;
+                    switch (dims.lz) { MI_LOGZ_CASES(MI_Z) default: break; }
+#undef MI_Z
+                }
+            }
+        }
+    }
+    (void)hipEventRecord(e1, s);
+    hipError_t he = hipEventSynchronize(e1);
+    float ms = 0.0f;
+    if (he == hipSuccess) he = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc == MI_OK && he != hipSuccess) rc = fail(MI_ERR_HIP, "time_pass: %s", hipGetErrorString(he));
+    *avg_ms = ms / (float)reps;
+    return rc;
+}
+
 static int check_aligned(const void* p, const char* what) {
     MI_REQUIRE(p == nullptr || ((uintptr_t)p % 16) == 0, "native FFT: %s must be 16-byte aligned", what);
     return MI_OK;

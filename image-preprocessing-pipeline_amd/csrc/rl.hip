@@ -173,6 +173,14 @@ extern "C" int mi_rl_iterate(mi_rl_ctx* ctx, void* stream, float* bl, float* rat
     return MI_OK;
 }
 
+extern "C" int mi_rl_time_pass(mi_rl_ctx* ctx, void* stream, int which, const float* bl, int reps, float* avg_ms) {
+    MI_REQUIRE(ctx && bl && avg_ms, "mi_rl_time_pass: null pointer");
+    MI_TRY(use_device(ctx->dev));
+    if (!(ctx->engine == MI_ENGINE_FFT && ctx->fft->native))
+        return fail(MI_ERR_UNSUPPORTED, "mi_rl_time_pass: only the native FFT pipeline exposes its passes");
+    return ctx->fft->native->time_pass(as_stream(stream), which, bl, reps, avg_ms);
+}
+
 // ------------------------------------------------------------------------------------------------
 extern "C" int mi_conv3d(int dev, void* stream, const float* img, const float* ker, float* out, int nx, int ny, int nz, int kx, int ky,
                          int kz, int boundary, int engine) {

@@ -274,6 +274,15 @@ class RLContext:
         check(lib().mi_rl_iterate(self._h, _stream(bl), bl.data_ptr(), ratio.data_ptr() if ratio is not None else None,
                                   int(n_iters)))
 
+    PASSES = {"x_forward": 0, "y_forward": 1, "z_conv": 2, "y_inverse": 3, "x_fused": 4}
+
+    def time_pass(self, which, bl, reps=5) -> float:
+        """Average ms of one launch of a single pass of the native FFT pipeline (HIP events, mi_rl_time_pass)."""
+        self._chk(bl)
+        ms = C.c_float()
+        check(lib().mi_rl_time_pass(self._h, _stream(bl), self.PASSES[which], bl.data_ptr(), int(reps), C.byref(ms)))
+        return float(ms.value)
+
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
             lib().mi_rl_destroy(self._h)
