@@ -82,6 +82,7 @@ SIGNATURES = {
     "mi_decon": (_i, [_i, _vp, _vp, _vp, _vp] + [_i] * 6 + [C.POINTER(RlOptions), _i, _ip, _i, _ip]),
     "mi_engine_select": (_i, [_i] * 7),
     "mi_next_fast_len": (_i, [_i]),
+    "mi_fft_good_size": (_i, [_i, _i]),
     "mi_pack_rows": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "mi_unpack_rows": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     # mi_crossmips.h

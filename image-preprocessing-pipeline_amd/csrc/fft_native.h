@@ -5,7 +5,8 @@
 namespace mi {
 
 struct NativeDims {
-    int lhx, ly, lz;  // log2 of Hx = X/2, Y, Z
+    int lhx, lz;      // log2 of Hx = X/2 and of Z
+    int ly2, r3;      // Y = r3 * 2^ly2, r3 in {1, 3, 9}
     int ny, nz;
     int ty, tc, tl;   // rows per x tile, columns per y tile, lines per z tile (A and B tiles each)
     int dbg;          // timing experiments only: knocks out phases of the z pass (results are then wrong)
@@ -20,6 +21,8 @@ struct NativeFft {
     size_t n_cplx = 0;
 
     static bool supported(const int F[3]);
+    // smallest supported y extent >= n (2^a, 3*2^a or 9*2^a)
+    static int good_size_y(int n);
     // otf_half_spectrum: R2C layout [Z][Y][X/2+1]; it is multiplied by `scale` while being repacked
     int init(hipStream_t s, const int F[3], const float2* otf_half_spectrum, float scale);
     int conv(hipStream_t s, const float* in, bool conj_otf, float* out, int epi_kind, const ConvEpilogue& epi);

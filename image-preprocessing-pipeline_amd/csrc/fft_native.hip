@@ -46,6 +46,21 @@ __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(
 __device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
 __device__ __forceinline__ unsigned brev_n(unsigned v, int bits) { return bits == 0 ? 0u : (__brev(v) >> (32 - bits)); }
 
+// y axis of length M = r3 * 2^ly2 (r3 in {1, 3, 9}): one radix-r3 DIF stage followed by r3 power-of-two sub-transforms.
+// Position p = k1 * 2^ly2 + p' holds frequency k1 + r3 * brev(p').
+__device__ __forceinline__ int y_pos2freq(int p, const NativeDims& d) {
+    const int k1 = p >> d.ly2, pp = p & ((1 << d.ly2) - 1);
+    return k1 + d.r3 * (int)brev_n((unsigned)pp, d.ly2);
+}
+__device__ __forceinline__ int y_freq2pos(int k, const NativeDims& d) {
+    const int k2 = k / d.r3, k1 = k - k2 * d.r3;
+    return (k1 << d.ly2) + (int)brev_n((unsigned)k2, d.ly2);
+}
+__device__ __forceinline__ int y_mirror_pos(int p, const NativeDims& d) {
+    const int k = y_pos2freq(p, d);
+    return y_freq2pos(k == 0 ? 0 : d.ny - k, d);
+}
+
 // exp(-2 pi i m / 2^(bpos+1)), m < 2^bpos, bpos <= 3: the part of a butterfly twiddle that depends only on the
 // register index, as compile-time constants (cos/sin of multiples of 2 pi / 16)
 __device__ __forceinline__ constexpr float c16(int k) {
@@ -63,7 +78,7 @@ __device__ __forceinline__ constexpr float s16(int k) {
 // S_LO+LR-1..S_LO (forward, DIF) or S_LO..S_LO+LR-1 (inverse, DIT) on `batch` sequences of length 2^LOGN stored at
 // tile[b * pitch + phys(i)].  tw[e] = exp(-2 pi i e / N).  The twiddle of a butterfly factors into a per-lane
 // part (one table look-up per radix-2 stage; none when S_LO == 0) and a per-register constant.
-template <int LOGN, int LR, int S_LO, bool INVERSE, int NT>
+template <int LOGN, int LR, int S_LO, bool INVERSE, int NT, int R3 = 1>
 __device__ __forceinline__ void super_stage(float2* tile, int batch, int pitch, const float2* __restrict__ tw) {
     constexpr int R = 1 << LR, GL = LOGN - LR, H_LO = 1 << S_LO;
     const int total = batch << GL;
@@ -71,7 +86,8 @@ __device__ __forceinline__ void super_stage(float2* tile, int batch, int pitch, 
         const int b = idx >> GL, g = idx & ((1 << GL) - 1);
         const int m = g & (H_LO - 1);
         const int base = ((g >> S_LO) << (S_LO + LR)) | m;
-        float2* row = tile + b * pitch;
+        // sequence b: row b / R3, sub-block b % R3 of length 2^LOGN (R3 == 1: a whole row)
+        float2* row = R3 == 1 ? tile + b * pitch : tile + (b / R3) * pitch + (b % R3) * ((1 << LOGN) + ((1 << LOGN) >> 5));
         float2 v[R];
         int pidx[R];
 #pragma unroll
@@ -116,14 +132,100 @@ __host__ __device__ constexpr int first_r(int rem) { return rem >= 8 ? 4 : (rem 
 
 // full transform of `batch` LDS rows as a compile-time chain of super-stages (at most 4 radix-2 stages each); the
 // caller issues __syncthreads() before (tile filled); one follows every super-stage, so the tile is consistent on return
-template <int LOGN, bool INVERSE, int NT, int DONE = 0>
+template <int LOGN, bool INVERSE, int NT, int R3 = 1, int DONE = 0>
 __device__ __forceinline__ void lds_fft(float2* tile, int batch, int pitch, const float2* __restrict__ tw) {
     if constexpr (DONE < LOGN) {
         constexpr int r = first_r(LOGN - DONE);
         constexpr int s_lo = INVERSE ? DONE : LOGN - DONE - r;  // forward: top stages first; inverse: bottom first
-        super_stage<LOGN, r, s_lo, INVERSE, NT>(tile, batch, pitch, tw);
+        super_stage<LOGN, r, s_lo, INVERSE, NT, R3>(tile, batch, pitch, tw);
         __syncthreads();
-        lds_fft<LOGN, INVERSE, NT, DONE + r>(tile, batch, pitch, tw);
+        lds_fft<LOGN, INVERSE, NT, R3, DONE + r>(tile, batch, pitch, tw);
+    }
+}
+
+// 3-point DFT in place (forward: exp(-2 pi i /3); inverse: conjugate)
+template <bool INVERSE>
+__device__ __forceinline__ void dft3(float2& a, float2& b, float2& c) {
+    const float hs = 0.86602540378443865f;  // sqrt(3)/2
+    const float2 t1 = cadd(b, c);
+    const float2 t2 = make_float2(a.x - 0.5f * t1.x, a.y - 0.5f * t1.y);
+    const float2 dd = csub(b, c);
+    // forward: -i * hs * (b - c) ; inverse: +i * hs * (b - c)
+    const float2 t3 = INVERSE ? make_float2(-hs * dd.y, hs * dd.x) : make_float2(hs * dd.y, -hs * dd.x);
+    a = cadd(a, t1);
+    b = cadd(t2, t3);
+    c = csub(t2, t3);
+}
+
+// radix-R3 stage of the y transform on `cols` LDS rows of length M = R3 * Msub: forward = DIF first stage
+// (DFT over n1 of x[n1 * Msub + n2], times W_M^(n2 k1), stored at k1 * Msub + n2); inverse = its exact reverse.
+// twM[e] = exp(-2 pi i e / M), e < M.
+template <int R3, bool INVERSE, int NT>
+__device__ __forceinline__ void radix3_stage(float2* tile, int cols, int pitch, int msub, const float2* __restrict__ twM) {
+    const int total = cols * msub;
+    for (int idx = threadIdx.x; idx < total; idx += NT) {
+        const int c = idx / msub, n2 = idx - c * msub;
+        float2* row = tile + c * pitch;
+        float2 v[R3];
+        const int sp = msub + (msub >> 5);  // phys() of a multiple of msub (msub is a multiple of 32)
+#pragma unroll
+        for (int q = 0; q < R3; ++q) v[q] = row[q * sp + phys(n2)];
+        if (INVERSE) {
+#pragma unroll
+            for (int q = 1; q < R3; ++q) v[q] = cmulc(v[q], twM[n2 * q]);
+        }
+        if constexpr (R3 == 3) {
+            dft3<INVERSE>(v[0], v[1], v[2]);
+        } else {  // 9 = 3 x 3: index n = 3 n1 + n2' , k = k1' + 3 k2'
+            // DIF order for the forward transform, reversed for the inverse (which takes k-ordered input)
+            if constexpr (!INVERSE) {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) dft3<false>(v[r], v[r + 3], v[r + 6]);       // over n1 (stride 3): -> A[n2'][k1'] at r + 3 k1'
+                const float c9[3] = {1.0f, 0.76604444311897801f, 0.17364817766693033f};   // cos(2 pi {0,1,2}/9)
+                const float s9[3] = {0.0f, 0.64278760968653933f, 0.98480775301220802f};   // sin(2 pi {0,1,2}/9)
+                const float c94 = -0.93969262078590843f, s94 = 0.34202014332566871f;      // 4/9 turn
+                v[4] = cmul(v[4], make_float2(c9[1], -s9[1]));   // n2'=1,k1'=1: W9^1
+                v[7] = cmul(v[7], make_float2(c9[2], -s9[2]));   // n2'=1,k1'=2: W9^2
+                v[5] = cmul(v[5], make_float2(c9[2], -s9[2]));   // n2'=2,k1'=1: W9^2
+                v[8] = cmul(v[8], make_float2(c94, -s94));       // n2'=2,k1'=2: W9^4
+                // over n2' for each k1': inputs v[0 + 3k1'], v[1 + 3k1'], v[2 + 3k1'] -> X[k1' + 3 k2'] for k2' = 0,1,2
+#pragma unroll
+                for (int k1 = 0; k1 < 3; ++k1) dft3<false>(v[3 * k1], v[3 * k1 + 1], v[3 * k1 + 2]);
+                // now v[3 k1' + k2'] = X[k1' + 3 k2'] : reorder to k order
+                float2 t[9];
+#pragma unroll
+                for (int k1 = 0; k1 < 3; ++k1)
+#pragma unroll
+                    for (int k2 = 0; k2 < 3; ++k2) t[k1 + 3 * k2] = v[3 * k1 + k2];
+#pragma unroll
+                for (int q = 0; q < 9; ++q) v[q] = t[q];
+            } else {
+                float2 t[9];
+#pragma unroll
+                for (int k1 = 0; k1 < 3; ++k1)
+#pragma unroll
+                    for (int k2 = 0; k2 < 3; ++k2) t[3 * k1 + k2] = v[k1 + 3 * k2];
+#pragma unroll
+                for (int q = 0; q < 9; ++q) v[q] = t[q];
+#pragma unroll
+                for (int k1 = 0; k1 < 3; ++k1) dft3<true>(v[3 * k1], v[3 * k1 + 1], v[3 * k1 + 2]);
+                const float c9[3] = {1.0f, 0.76604444311897801f, 0.17364817766693033f};
+                const float s9[3] = {0.0f, 0.64278760968653933f, 0.98480775301220802f};
+                const float c94 = -0.93969262078590843f, s94 = 0.34202014332566871f;
+                v[4] = cmul(v[4], make_float2(c9[1], s9[1]));
+                v[7] = cmul(v[7], make_float2(c9[2], s9[2]));
+                v[5] = cmul(v[5], make_float2(c9[2], s9[2]));
+                v[8] = cmul(v[8], make_float2(c94, s94));
+#pragma unroll
+                for (int r = 0; r < 3; ++r) dft3<true>(v[r], v[r + 3], v[r + 6]);
+            }
+        }
+        if (!INVERSE) {
+#pragma unroll
+            for (int q = 1; q < R3; ++q) v[q] = cmul(v[q], twM[n2 * q]);
+        }
+#pragma unroll
+        for (int q = 0; q < R3; ++q) row[q * sp + phys(n2)] = v[q];
     }
 }
 
@@ -161,11 +263,11 @@ __global__ __launch_bounds__(kThreadsXZ) void k_x_forward(const float* __restric
 
 // ---------------------------------------------------------------------------------------------- P2 / P4: y passes
 // whole contiguous columns.  Forward: column (z, px) of src[z][px][.] -> dst[px][z][.]; inverse: the way back.
-template <int LY, bool INVERSE>
+template <int LY2, int R3, bool INVERSE>
 __global__ __launch_bounds__(kThreadsY) void k_y_pass(const float2* __restrict__ src, float2* __restrict__ dst, NativeDims d,
                                                       const float2* __restrict__ tw) {
     extern __shared__ __attribute__((aligned(16))) float2 tile[];
-    constexpr int M = 1 << LY;
+    constexpr int M = R3 << LY2;
     const int TC = d.tc, pitch = row_pitch(M), Hx = 1 << d.lhx, L = d.nz;
     const size_t c0 = (size_t)blockIdx.x * TC;
     const float4* base = reinterpret_cast<const float4*>(src + c0 * M);
@@ -179,7 +281,17 @@ __global__ __launch_bounds__(kThreadsY) void k_y_pass(const float2* __restrict__
         row[phys(2 * q + 1)] = make_float2(v.z, v.w);
     }
     __syncthreads();
-    lds_fft<LY, INVERSE, kThreadsY>(tile, TC, pitch, tw);
+    // tw: [0, Msub/2) table of the power-of-two sub-transform, then [.. + M) full-circle table of the radix-R3 stage
+    const float2* twM = tw + (1 << LY2) / 2;
+    if constexpr (!INVERSE && R3 > 1) {
+        radix3_stage<R3, false, kThreadsY>(tile, TC, pitch, 1 << LY2, twM);
+        __syncthreads();
+    }
+    lds_fft<LY2, INVERSE, kThreadsY, R3>(tile, TC * R3, pitch, tw);
+    if constexpr (INVERSE && R3 > 1) {
+        radix3_stage<R3, true, kThreadsY>(tile, TC, pitch, 1 << LY2, twM);
+        __syncthreads();
+    }
 #pragma unroll 4
     for (int i = threadIdx.x; i < TC * quads; i += kThreadsY) {
         const int c = i / quads, q = i - c * quads;
@@ -212,8 +324,7 @@ __global__ __launch_bounds__(kThreadsXZ) void k_z_conv(const float2* __restrict_
     const unsigned xk = brev_n((unsigned)px, d.lhx);
     const int pxB = (int)brev_n((Hx - xk) & (Hx - 1), d.lhx);
     // mirror block of py positions: blocks of TL aligned positions map to blocks (see file header)
-    const unsigned ky0 = brev_n((unsigned)py0, d.ly);
-    const int pyB_any = (int)brev_n((M - ky0) & (M - 1), d.ly);
+    const int pyB_any = y_mirror_pos(py0, d);
     const int pyB0 = pyB_any & ~(TL - 1);
     const bool self_plane = (px == 0 || px == 1);
     float2* tA = tile;
@@ -258,8 +369,7 @@ __global__ __launch_bounds__(kThreadsXZ) void k_z_conv(const float2* __restrict_
             default: g = Gp[i]; break;
         }
         const int j = i / L, pz = i - j * L;
-        const unsigned ky = brev_n((unsigned)(py0 + j), d.ly);
-        const int jB = (int)brev_n((M - ky) & (M - 1), d.ly) - pyB0;
+        const int jB = y_mirror_pos(py0 + j, d) - pyB0;
         const unsigned kz = brev_n((unsigned)pz, d.lz);
         const int pzB = (int)brev_n((L - kz) & (L - 1), d.lz);
         const float2 a = tA[j * pitch + phys(pz)];
@@ -376,11 +486,11 @@ __global__ __launch_bounds__(256) void k_repack_otf(const float2* __restrict__ H
         const size_t r = i / L;
         const int py = (int)(r % M), plane = (int)(r / M);
         const int px = plane == Hx / 2 ? 1 : 2 * plane;
-        const int xk = (int)brev_n((unsigned)px, d.lhx), ky = (int)brev_n((unsigned)py, d.ly), kz = (int)brev_n((unsigned)pz, d.lz);
+        const int xk = (int)brev_n((unsigned)px, d.lhx), ky = y_pos2freq(py, d), kz = (int)brev_n((unsigned)pz, d.lz);
         const int W = Hx + 1;
         const float2 ga = Hs[((size_t)kz * M + ky) * W + xk];
         // H_full[xk + Hx, ky, kz] = conj(H[Hx - xk, -ky, -kz])
-        const float2 gb = Hs[((size_t)((L - kz) & (L - 1)) * M + ((M - ky) & (M - 1))) * W + (Hx - xk)];
+        const float2 gb = Hs[((size_t)((L - kz) & (L - 1)) * M + (ky == 0 ? 0 : M - ky)) * W + (Hx - xk)];
         G[i] = make_float4(ga.x * scale, ga.y * scale, gb.x * scale, -gb.y * scale);
     }
 }
@@ -390,17 +500,37 @@ int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
 }  // namespace
 
+// y = r3 * 2^a with r3 in {1, 3, 9}: the one axis that may carry a radix-3 factor (it is the axis the slab driver
+// shards, where local extent = slab + halos is rarely a power of two)
+static bool split_y(int ny, int* r3, int* ly2) {
+    for (int r : {1, 3, 9}) {
+        if (ny % r) continue;
+        const int m = ny / r;
+        if (!is_pow2(m)) continue;
+        const int l = ilog2(m);
+        if (r == 1 ? (l >= 3 && l <= 12) : (l >= 5 && l <= 9)) { *r3 = r; *ly2 = l; return true; }
+    }
+    return false;
+}
+
 bool NativeFft::supported(const int F[3]) {
-    // x: real length 2*Hx with 8 <= Hx <= 4096; y, z: 4 .. 4096; LDS tiles must fit
-    return is_pow2(F[0]) && is_pow2(F[1]) && is_pow2(F[2]) && F[0] >= 16 && F[0] <= 8192 && F[1] >= 8 && F[1] <= 4096 && F[2] >= 8 &&
-           F[2] <= 2048;
+    // x: real length 2*Hx with 8 <= Hx <= 4096; z: 8 .. 2048; y: see split_y; LDS tiles must fit
+    int r3, ly2;
+    return is_pow2(F[0]) && is_pow2(F[2]) && F[0] >= 16 && F[0] <= 8192 && F[2] >= 8 && F[2] <= 2048 && split_y(F[1], &r3, &ly2);
+}
+
+int NativeFft::good_size_y(int n) {
+    for (int m = n < 8 ? 8 : n;; ++m) {
+        int r3, ly2;
+        if (split_y(m, &r3, &ly2)) return m;
+    }
 }
 
 static size_t lds_bytes(int rows, int n) { return sizeof(float2) * (size_t)rows * row_pitch(n); }
 
 int NativeFft::init(hipStream_t s, const int F[3], const float2* otf_half_spectrum, float scale) {
     dims.lhx = ilog2(F[0] / 2);
-    dims.ly = ilog2(F[1]);
+    MI_REQUIRE(split_y(F[1], &dims.r3, &dims.ly2), "native FFT: unsupported y length %d", F[1]);
     dims.lz = ilog2(F[2]);
     dims.ny = F[1];
     dims.nz = F[2];
@@ -433,15 +563,19 @@ int NativeFft::init(hipStream_t s, const int F[3], const float2* otf_half_spectr
     MI_TRY(S.alloc(sizeof(float2) * n_cplx));
     MI_TRY(T.alloc(sizeof(float2) * n_cplx));
     MI_TRY(G.alloc(sizeof(float4) * (size_t)(Hx / 2 + 1) * F[1] * F[2]));
-    // twiddle tables exp(-2 pi i e / N), e < N/2, in double on the host
-    const int lens[3] = {Hx, F[1], F[2]};
+    // twiddle tables exp(-2 pi i e / N) in double on the host: e < N/2 for the power-of-two transforms (x: Hx, y: Msub,
+    // z: L), plus the full circle e < M behind the y table for the radix-3/9 stage
+    const int msub = 1 << dims.ly2;
+    const int lens[3] = {Hx, msub, F[2]};
     size_t off = 0, offs[3];
-    for (int a = 0; a < 3; ++a) { offs[a] = off; off += (size_t)std::max(1, lens[a] / 2); }
+    for (int a = 0; a < 3; ++a) { offs[a] = off; off += (size_t)std::max(1, lens[a] / 2) + (a == 1 ? (size_t)F[1] : 0); }
     std::vector<float2> h(off);
     const double two_pi = 6.283185307179586476925286766559;
     for (int a = 0; a < 3; ++a)
         for (int e = 0; e < lens[a] / 2; ++e)
             h[offs[a] + e] = make_float2((float)std::cos(two_pi * e / lens[a]), (float)-std::sin(two_pi * e / lens[a]));
+    for (int e = 0; e < F[1]; ++e)
+        h[offs[1] + msub / 2 + e] = make_float2((float)std::cos(two_pi * e / F[1]), (float)-std::sin(two_pi * e / F[1]));
     MI_TRY(tw.alloc(sizeof(float2) * off));
     MI_HIP(hipMemcpyAsync(tw.p, h.data(), sizeof(float2) * off, hipMemcpyHostToDevice, s));
     tw_x = tw.as<float2>() + offs[0];
@@ -459,6 +593,9 @@ int NativeFft::init(hipStream_t s, const int F[3], const float2* otf_half_spectr
 // ---- launch helpers: the kernels are templated on log2(length); lengths 2^3 .. 2^12 (z: 2^11) are instantiated
 #define MI_LOG_CASES(M) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12)
 #define MI_LOGZ_CASES(M) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11)
+// y: key = ly2 * 16 + r3
+#define MI_Y_CASES(M) M(3, 1) M(4, 1) M(5, 1) M(6, 1) M(7, 1) M(8, 1) M(9, 1) M(10, 1) M(11, 1) M(12, 1) \
+    M(5, 3) M(6, 3) M(7, 3) M(8, 3) M(9, 3) M(5, 9) M(6, 9) M(7, 9) M(8, 9) M(9, 9)
 
 template <class K, class... Args>
 static int launch_lds(K kernel, unsigned grid, int threads, size_t lds, hipStream_t s, const char* name, Args... args) {
@@ -494,8 +631,8 @@ int NativeFft::middle(hipStream_t s, bool conj_otf) {
     const NativeDims d = dims;
     const float2 *twy = tw_y, *twz = tw_z;
     int rc = MI_ERR_INVALID;
-#define MI_Y(LG) case LG: rc = launch_lds(k_y_pass<LG, false>, ycols, kThreadsY, yl, s, "k_y_pass<fwd>", (const float2*)Sp, Tp, d, twy); break;
-    switch (dims.ly) { MI_LOG_CASES(MI_Y) default: return fail(MI_ERR_UNSUPPORTED, "native FFT: y length 2^%d", dims.ly); }
+#define MI_Y(LG, R) case LG * 16 + R: rc = launch_lds(k_y_pass<LG, R, false>, ycols, kThreadsY, yl, s, "k_y_pass<fwd>", (const float2*)Sp, Tp, d, twy); break;
+    switch (dims.ly2 * 16 + dims.r3) { MI_Y_CASES(MI_Y) default: return fail(MI_ERR_UNSUPPORTED, "native FFT: y length %d", dims.ny); }
 #undef MI_Y
     MI_TRY(rc);
 #define MI_Z(LG)                                                                                                                       \
@@ -506,8 +643,8 @@ int NativeFft::middle(hipStream_t s, bool conj_otf) {
     switch (dims.lz) { MI_LOGZ_CASES(MI_Z) default: return fail(MI_ERR_UNSUPPORTED, "native FFT: z length 2^%d", dims.lz); }
 #undef MI_Z
     MI_TRY(rc);
-#define MI_Y(LG) case LG: rc = launch_lds(k_y_pass<LG, true>, ycols, kThreadsY, yl, s, "k_y_pass<inv>", (const float2*)Sp, Tp, d, twy); break;
-    switch (dims.ly) { MI_LOG_CASES(MI_Y) default: return fail(MI_ERR_UNSUPPORTED, "native FFT: y length 2^%d", dims.ly); }
+#define MI_Y(LG, R) case LG * 16 + R: rc = launch_lds(k_y_pass<LG, R, true>, ycols, kThreadsY, yl, s, "k_y_pass<inv>", (const float2*)Sp, Tp, d, twy); break;
+    switch (dims.ly2 * 16 + dims.r3) { MI_Y_CASES(MI_Y) default: return fail(MI_ERR_UNSUPPORTED, "native FFT: y length %d", dims.ny); }
 #undef MI_Y
     return rc;
 }
@@ -571,12 +708,12 @@ int NativeFft::time_pass(hipStream_t s, int which, const float* bl, int reps, fl
                 const size_t yl = lds_bytes(dims.tc, M), zl = lds_bytes(2 * dims.tl, L);
                 rc = MI_ERR_INVALID;
                 if (which == 1) {
-#define MI_Y(LG) case LG: rc = launch_lds(k_y_pass<LG, false>, ycols, kThreadsY, yl, s, "k_y_pass<fwd>", (const float2*)Sp, Tp, d, tw_y); break;
-                    switch (dims.ly) { MI_LOG_CASES(MI_Y) default: break; }
+#define MI_Y(LG, R) case LG * 16 + R: rc = launch_lds(k_y_pass<LG, R, false>, ycols, kThreadsY, yl, s, "k_y_pass<fwd>", (const float2*)Sp, Tp, d, tw_y); break;
+                    switch (dims.ly2 * 16 + dims.r3) { MI_Y_CASES(MI_Y) default: break; }
 #undef MI_Y
                 } else if (which == 3) {
-#define MI_Y(LG) case LG: rc = launch_lds(k_y_pass<LG, true>, ycols, kThreadsY, yl, s, "k_y_pass<inv>", (const float2*)Sp, Tp, d, tw_y); break;
-                    switch (dims.ly) { MI_LOG_CASES(MI_Y) default: break; }
+#define MI_Y(LG, R) case LG * 16 + R: rc = launch_lds(k_y_pass<LG, R, true>, ycols, kThreadsY, yl, s, "k_y_pass<inv>", (const float2*)Sp, Tp, d, tw_y); break;
+                    switch (dims.ly2 * 16 + dims.r3) { MI_Y_CASES(MI_Y) default: break; }
 #undef MI_Y
                 } else {
 #define MI_Z(LG) case LG: rc = launch_lds(k_z_conv<LG, false>, ztiles, kThreadsXZ, zl, s, "k_z_conv", (const float2*)Tp, Sp, G.as<float4>(), d, tw_z); break;

@@ -173,6 +173,15 @@ extern "C" int mi_rl_iterate(mi_rl_ctx* ctx, void* stream, float* bl, float* rat
     return MI_OK;
 }
 
+extern "C" int mi_fft_good_size(int n, int axis) {
+    // extents the hand-written FFT pipeline takes without falling back to rocFFT: powers of two on x and z,
+    // 2^a * {1, 3, 9} on y
+    if (axis == 1) return NativeFft::good_size_y(n);
+    int m = 8;
+    while (m < n) m <<= 1;
+    return m;
+}
+
 extern "C" int mi_rl_time_pass(mi_rl_ctx* ctx, void* stream, int which, const float* bl, int reps, float* avg_ms) {
     MI_REQUIRE(ctx && bl && avg_ms, "mi_rl_time_pass: null pointer");
     MI_TRY(use_device(ctx->dev));

@@ -90,7 +90,8 @@ class SlabRL:
         if self.world > 1 and any(b - a < self.h for a, b in slab_rows(gy, self.world)):
             raise ValueError(f"slab of {self.n_loc} rows is thinner than the halo ({self.h}); use fewer ranks")
         rows = self.n_loc + 2 * self.h
-        self.rows = int(capi.lib().mi_next_fast_len(rows)) if ops is None else rows  # rocFFT-friendly local extent
+        # local extent the FFT pipeline takes natively (2^a * {1,3,9}); the rows behind the upper halo stay zero
+        self.rows = int(capi.lib().mi_fft_good_size(rows, 1)) if ops is None else rows
         bxz = BOUNDARY_CIRCULAR if flavour == "fft" else BOUNDARY_ZERO
         # y is "circular on the local extent": wrap-around only ever reaches halo / padding rows
         boundary_xyz = (bxz, BOUNDARY_CIRCULAR, bxz)
@@ -148,6 +149,10 @@ class SlabRL:
             self.unpack_halos(vol, send_up if lo_src is not None else None, send_dn if hi_src is not None else None)
             return
         import torch.distributed as dist
+        # RCCL moves device buffers directly; a gloo group (CPU rehearsals of the multi-rank path) needs host staging
+        staged = send_up.is_cuda and dist.get_backend(self.group) == "gloo"
+        if staged:
+            send_up, send_dn = send_up.cpu(), send_dn.cpu()
         recv_lo = torch.empty_like(send_up) if lo_src is not None else None
         recv_hi = torch.empty_like(send_dn) if hi_src is not None else None
         # message tags / issue order: "up" traffic (my bottom rows -> next rank) first, then "down"; with two ranks
@@ -163,6 +168,9 @@ class SlabRL:
             ops.append(dist.P2POp(dist.irecv, recv_hi, hi_src, self.group, 2))
         for req in dist.batch_isend_irecv(ops):
             req.wait()
+        if staged:
+            recv_lo = recv_lo.to(vol.device) if recv_lo is not None else None
+            recv_hi = recv_hi.to(vol.device) if recv_hi is not None else None
         self.unpack_halos(vol, recv_lo, recv_hi)
 
     # ------------------------------------------------------------------ iteration

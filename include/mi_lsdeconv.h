@@ -141,6 +141,9 @@ int mi_decon(int dev, void* stream, float* bl, const float* psf, const float* ps
 /* cost model used by MI_ENGINE_AUTO: returns MI_ENGINE_DIRECT or MI_ENGINE_FFT */
 int mi_engine_select(int nx, int ny, int nz, int kx, int ky, int kz, int boundary);
 
+/* smallest extent >= n that the hand-written FFT pipeline handles natively on `axis` (0 = x, 1 = y, 2 = z):
+ * a power of two, or on y also 3 * 2^a / 9 * 2^a.  Other (7-smooth) shapes run through rocFFT. */
+int mi_fft_good_size(int n, int axis);
 /* next 7-smooth length >= n   [LsDeconv.m:405-419] */
 int mi_next_fast_len(int n);
 

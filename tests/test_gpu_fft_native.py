@@ -11,7 +11,8 @@ from oracle import rl_oracle as R
 
 pytestmark = pytest.mark.gpu
 
-SHAPES = [(8, 8, 16), (16, 32, 64), (32, 64, 128), (64, 16, 256), (8, 128, 32), (128, 8, 16), (16, 16, 1024)]
+SHAPES = [(8, 8, 16), (16, 32, 64), (32, 64, 128), (64, 16, 256), (8, 128, 32), (128, 8, 16), (16, 16, 1024),
+          (8, 96, 32), (16, 288, 64), (8, 192, 16), (8, 576, 16), (16, 1152, 32)]  # y = 3 * 2^a, 9 * 2^a: radix-3/9 stage
 
 
 def _rel(a, b):
@@ -35,7 +36,7 @@ def test_circular_conv_native_vs_scipy_and_rocfft(dev, shape):
     assert _rel(got, ref) < 2e-5
 
 
-@pytest.mark.parametrize("shape", [(16, 32, 64), (32, 16, 128), (8, 64, 32)])
+@pytest.mark.parametrize("shape", [(16, 32, 64), (32, 16, 128), (8, 64, 32), (8, 288, 32), (16, 96, 16)])
 @pytest.mark.parametrize("niter,lam,interval", [(4, 0.0, 0), (6, 0.05, 2)])
 def test_decon_fft_native_matches_oracle(dev, shape, niter, lam, interval):
     from ipp_amd import decon
