@@ -84,20 +84,22 @@ __global__ void k_tile_sums(const float* __restrict__ img, int height, int width
     ps[t] = s;
 }
 
+template <int NT = NCC_THREADS>
 __device__ __forceinline__ double block_sum(double v, double* sh) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
     __syncthreads();
     double r = 0.0;
-    for (int w = 0; w < NCC_THREADS / 64; ++w) r += sh[w];
+    for (int w = 0; w < NT / 64; ++w) r += sh[w];
     return r;
 }
 
 // sum of mip over rows [r0,r0+nr) x cols [c0,c0+nc) (per-lane partial): interior tiles from ps, border
 // pixels directly (compute_funcs.cu:1186-1262); falls back to all pixels when ps == nullptr
+template <int NT = NCC_THREADS>
 __device__ double window_partial(const float* __restrict__ mip, const float* __restrict__ ps, int dimv, int r0, int c0, int nr, int nc) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = NCC_THREADS / 64;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = NT / 64;
     double acc = 0.0;
     int su = r0, eu = r0, sv = c0, ev = c0;  // empty tiled region by default
     if (ps) {
@@ -107,7 +109,7 @@ __device__ double window_partial(const float* __restrict__ mip, const float* __r
         ev = (c0 + nc) / TILE * TILE;
         if (su >= eu || sv >= ev) { su = eu = r0; sv = ev = c0; }
         const int pw = dimv / TILE, tu = (eu - su) / TILE, tv = (ev - sv) / TILE;
-        for (int t = threadIdx.x; t < tu * tv; t += NCC_THREADS) acc += (double)ps[(su / TILE + t / tv) * pw + sv / TILE + t % tv];
+        for (int t = threadIdx.x; t < tu * tv; t += NT) acc += (double)ps[(su / TILE + t / tv) * pw + sv / TILE + t % tv];
     }
     for (int i = r0 + wave; i < r0 + nr; i += nw) {
         const float* row = mip + (size_t)i * dimv;
@@ -165,6 +167,99 @@ __global__ __launch_bounds__(NCC_THREADS) void k_ncc(const float* __restrict__ m
     f1 = block_sum(f1, sh);
     f2 = block_sum(f2, sh);
     if (threadIdx.x == 0) out[slot] = (float)(num / sqrt(f1 * f2));
+}
+
+// Full NCC map, VB = 4 consecutive v shifts of one u per work-group.  For a fixed u the four shifts pair the SAME
+// m2 pixel (r2, c2) with m1 pixels (r1, c2 + v0 + k), k = 0..3: each lane loads one m2 value and one m1 value per
+// 64-column chunk (plus the next chunk's m1 value, which becomes the current one of the next step) and receives the
+// three neighbours through wave shuffles -- 0.5 loads per pixel-shift instead of 2 (k_ncc).  Same two-pass fp64
+// arithmetic as compute_NCC (compute_funcs.cu:1163-1292) with a fixed reduction tree.
+constexpr int VB = 4;
+constexpr int MAP_THREADS = 1024;  // 16 waves: the map has only (2du+1)*ceil((2dv+1)/4) work-groups
+__global__ __launch_bounds__(MAP_THREADS) void k_ncc_map4(const float* __restrict__ m1, const float* __restrict__ m2, int dimu, int dimv,
+                                                           int du, int dv, const float* __restrict__ ps1, const float* __restrict__ ps2,
+                                                           const int* __restrict__ groups, float* __restrict__ out) {
+    __shared__ double sh[MAP_THREADS / 64];
+    // full map: group = (u, 4 consecutive v) in row-major order; list mode (neighbourhood refinement): group q =
+    // {u, v0, count <= 4, first output slot}, the count shifts share u and have consecutive v and consecutive slots
+    int u, v0, cnt, slot0;
+    if (groups) {
+        u = groups[4 * blockIdx.x];
+        v0 = groups[4 * blockIdx.x + 1];
+        cnt = groups[4 * blockIdx.x + 2];
+        slot0 = groups[4 * blockIdx.x + 3];
+    } else {
+        const int ngroups = (2 * dv + 1 + VB - 1) / VB;
+        u = (int)(blockIdx.x / ngroups) - du;
+        v0 = (int)(blockIdx.x % ngroups) * VB - dv;
+        cnt = min(VB, dv - v0 + 1);
+        slot0 = (u + du) * (2 * dv + 1) + (v0 + dv);
+    }
+    const int nr = dimu - abs(u);
+    const int a_u = max(u, 0), b_u = max(-u, 0);
+    const bool tiled = ps1 && ps2 && dimu >= TILE && dimv >= TILE;
+    double fm[VB], tm[VB];
+    int lo[VB], hi[VB];  // valid m2 columns of shift k: [lo, hi)
+    bool live[VB];
+#pragma unroll
+    for (int k = 0; k < VB; ++k) {
+        const int v = v0 + k;
+        const int nc = dimv - abs(v);
+        live[k] = k < cnt && nr > 0 && nc > 0;
+        lo[k] = max(-v, 0);
+        hi[k] = lo[k] + max(nc, 0);
+        fm[k] = tm[k] = 0.0;
+        if (k < cnt && (nr <= 0 || nc <= 0)) {  // reference: empty loops, 0/0
+            if (threadIdx.x == 0) out[slot0 + k] = __int_as_float(0x7fc00000);
+        }
+        if (live[k]) {  // uniform across the work-group
+            fm[k] = block_sum<MAP_THREADS>(window_partial<MAP_THREADS>(m1, tiled ? ps1 : nullptr, dimv, a_u, max(v, 0), nr, nc), sh) / (double)(nr * nc);
+            tm[k] = block_sum<MAP_THREADS>(window_partial<MAP_THREADS>(m2, tiled ? ps2 : nullptr, dimv, b_u, lo[k], nr, nc), sh) / (double)(nr * nc);
+        }
+    }
+    int c_lo = dimv, c_hi = 0;
+#pragma unroll
+    for (int k = 0; k < VB; ++k)
+        if (live[k]) { c_lo = min(c_lo, lo[k]); c_hi = max(c_hi, hi[k]); }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = MAP_THREADS / 64;
+    double num[VB], f1[VB], f2[VB];
+#pragma unroll
+    for (int k = 0; k < VB; ++k) num[k] = f1[k] = f2[k] = 0.0;
+    for (int i = wave; i < nr; i += nw) {
+        const float* p = m1 + (size_t)(a_u + i) * dimv;  // m1 row; column = c2 + v0 + k
+        const float* q = m2 + (size_t)(b_u + i) * dimv;  // m2 row; column = c2
+        int c = c_lo + lane;
+        int c1 = c + v0;
+        float fa = (c1 >= 0 && c1 < dimv) ? p[c1] : 0.0f;
+        for (int base = c_lo; base < c_hi; base += 64, c += 64, c1 += 64) {
+            const int c1n = c1 + 64;
+            const float fb = (c1n >= 0 && c1n < dimv) ? p[c1n] : 0.0f;  // next chunk (all lanes take part in the shuffles)
+            const float tv = c < dimv ? q[c] : 0.0f;
+            const double t = (double)tv;
+#pragma unroll
+            for (int k = 0; k < VB; ++k) {
+                float fk = fa;
+                if (k > 0) {
+                    const float from_a = __shfl(fa, (lane + k) & 63, 64), from_b = __shfl(fb, (lane + k) & 63, 64);
+                    fk = (lane + k < 64) ? from_a : from_b;
+                }
+                if (live[k] && c >= lo[k] && c < hi[k]) {
+                    const double f = (double)fk;
+                    const double fp = f - fm[k], tp = t - tm[k];
+                    num[k] += f * tp;
+                    f1[k] += fp * fp;
+                    f2[k] += tp * tp;
+                }
+            }
+            fa = fb;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < VB; ++k) {
+        if (!live[k]) continue;
+        const double n_ = block_sum<MAP_THREADS>(num[k], sh), a_ = block_sum<MAP_THREADS>(f1[k], sh), b_ = block_sum<MAP_THREADS>(f2[k], sh);
+        if (threadIdx.x == 0) out[slot0 + k] = (float)(n_ / sqrt(a_ * b_));
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ host logic
@@ -254,15 +349,17 @@ struct PlaneGeom {  // one of the three MIP planes
 
 struct Workspace {
     DevBuf buf;       // floats: MIPs | tile sums | maps | miss results
-    DevBuf list;      // ints: (u, v, slot) triples of missing entries
+    DevBuf list;      // ints: {u, v0, count, slot} groups of missing entries
     size_t floats = 0;
     int list_cap = 0;
+    std::vector<int> host_groups;
+    std::vector<float> host_res;
 };
 
-int ncc_list(hipStream_t s, const float* base, const PlaneGeom& g, const int* d_list, int n, float* d_out) {
-    hipLaunchKernelGGL(k_ncc, dim3(n), dim3(NCC_THREADS), 0, s, base + g.mip1, base + g.mip2, g.dimu, g.dimv, g.delayu, g.delayv,
-                       g.tiled ? base + g.ps1 : nullptr, g.tiled ? base + g.ps2 : nullptr, d_list, d_out);
-    return launch_check("k_ncc(list)");
+int ncc_groups(hipStream_t s, const float* base, const PlaneGeom& g, const int* d_groups, int n_groups, float* d_out) {
+    hipLaunchKernelGGL(k_ncc_map4, dim3(n_groups), dim3(MAP_THREADS), 0, s, base + g.mip1, base + g.mip2, g.dimu, g.dimv, g.delayu,
+                       g.delayv, g.tiled ? base + g.ps1 : nullptr, g.tiled ? base + g.ps2 : nullptr, d_groups, d_out);
+    return launch_check("k_ncc_map4(groups)");
 }
 
 // compute_Neighborhood (compute_funcs.cu:1324-1592): win = (2wu+1)x(2wv+1) window around the peak,
@@ -297,14 +394,28 @@ int refine_neighbourhood(hipStream_t s, const mi_ncc_params& P, const float* map
         const int n_miss = (int)miss.size() / 3;
         MI_REQUIRE(n_miss == H * W - (H - std::abs(deltau)) * (W - std::abs(deltav)), "CrossMIPs: incomplete NCC map in compute_Neighborhood");
         if (n_miss > 0) {
-            if (ws.list_cap < n_miss) {
-                MI_TRY(ws.list.alloc(sizeof(int) * 3 * (size_t)n_miss));
-                ws.list_cap = n_miss;
+            // entries arrive in row-major window order: runs with the same u, consecutive v and consecutive slots are
+            // served four at a time by k_ncc_map4
+            std::vector<int>& grp = ws.host_groups;
+            grp.clear();
+            for (int q = 0; q < n_miss;) {
+                int cnt = 1;
+                while (cnt < VB && q + cnt < n_miss && miss[3 * (q + cnt)] == miss[3 * q] && miss[3 * (q + cnt) + 1] == miss[3 * q + 1] + cnt &&
+                       miss[3 * (q + cnt) + 2] == miss[3 * q + 2] + cnt)
+                    ++cnt;
+                grp.push_back(miss[3 * q]); grp.push_back(miss[3 * q + 1]); grp.push_back(cnt); grp.push_back(miss[3 * q + 2]);
+                q += cnt;
+            }
+            const int n_groups = (int)grp.size() / 4;
+            if (ws.list_cap < n_groups) {
+                MI_TRY(ws.list.alloc(sizeof(int) * 4 * (size_t)n_groups));
+                ws.list_cap = n_groups;
             }
             float* d_res = ws.buf.as<float>() + ws.floats;  // H*W result slots reserved behind the maps
-            MI_HIP(hipMemcpyAsync(ws.list.p, miss.data(), sizeof(int) * miss.size(), hipMemcpyHostToDevice, s));
-            MI_TRY(ncc_list(s, d_base, g, ws.list.as<int>(), n_miss, d_res));
-            std::vector<float> res((size_t)H * W);
+            MI_HIP(hipMemcpyAsync(ws.list.p, grp.data(), sizeof(int) * grp.size(), hipMemcpyHostToDevice, s));
+            MI_TRY(ncc_groups(s, d_base, g, ws.list.as<int>(), n_groups, d_res));
+            std::vector<float>& res = ws.host_res;
+            res.resize((size_t)H * W);
             MI_HIP(hipMemcpyAsync(res.data(), d_res, sizeof(float) * H * W, hipMemcpyDeviceToHost, s));
             MI_HIP(hipStreamSynchronize(s));
             for (int q = 0; q < n_miss; ++q) win[miss[3 * q + 2]] = res[miss[3 * q + 2]];
@@ -408,9 +519,9 @@ int run_pair(hipStream_t s, const float* A, const float* B, int dimi, int dimj, 
             hipLaunchKernelGGL(k_tile_sums, dim3((nt + 63) / 64), dim3(64), 0, s, base + g.mip2, g.dimu, g.dimv, base + g.ps2);
             MI_TRY(launch_check("k_tile_sums"));
         }
-        hipLaunchKernelGGL(k_ncc, dim3((2 * g.delayu + 1) * (2 * g.delayv + 1)), dim3(NCC_THREADS), 0, s, base + g.mip1, base + g.mip2,
-                           g.dimu, g.dimv, g.delayu, g.delayv, g.tiled ? base + g.ps1 : nullptr, g.tiled ? base + g.ps2 : nullptr,
-                           (const int*)nullptr, base + g.map);
+        hipLaunchKernelGGL(k_ncc_map4, dim3((2 * g.delayu + 1) * ((2 * g.delayv + 1 + VB - 1) / VB)), dim3(MAP_THREADS), 0, s, base + g.mip1,
+                           base + g.mip2, g.dimu, g.dimv, g.delayu, g.delayv, g.tiled ? base + g.ps1 : nullptr,
+                           g.tiled ? base + g.ps2 : nullptr, (const int*)nullptr, base + g.map);
         MI_TRY(launch_check("k_ncc(map)"));
     }
     host_maps.resize(pl.map_floats);
@@ -540,8 +651,8 @@ extern "C" int mi_ncc_compute_map(int dev, void* stream, const float* mip1, cons
         hipLaunchKernelGGL(k_tile_sums, dim3((nt + 63) / 64), dim3(64), 0, s, mip2, dimu, dimv, ps.as<float>() + nt);
         MI_TRY(launch_check("k_tile_sums"));
     }
-    hipLaunchKernelGGL(k_ncc, dim3((2 * delayu + 1) * (2 * delayv + 1)), dim3(NCC_THREADS), 0, s, mip1, mip2, dimu, dimv, delayu, delayv,
-                       nt > 0 ? ps.as<float>() : nullptr, nt > 0 ? ps.as<float>() + nt : nullptr, (const int*)nullptr, map);
+    hipLaunchKernelGGL(k_ncc_map4, dim3((2 * delayu + 1) * ((2 * delayv + 1 + VB - 1) / VB)), dim3(MAP_THREADS), 0, s, mip1, mip2, dimu, dimv,
+                       delayu, delayv, nt > 0 ? ps.as<float>() : nullptr, nt > 0 ? ps.as<float>() + nt : nullptr, (const int*)nullptr, map);
     MI_TRY(launch_check("k_ncc(map)"));
     MI_HIP(hipStreamSynchronize(s));  // ps dies at scope exit
     return MI_OK;
