@@ -82,20 +82,19 @@ template <int LOGN, int LR, int S_LO, bool INVERSE, int NT, int R3 = 1>
 __device__ __forceinline__ void super_stage(float2* tile, int batch, int pitch, const float2* __restrict__ tw) {
     constexpr int R = 1 << LR, GL = LOGN - LR, H_LO = 1 << S_LO;
     const int total = batch << GL;
+#pragma unroll 1
     for (int idx = threadIdx.x; idx < total; idx += NT) {
         const int b = idx >> GL, g = idx & ((1 << GL) - 1);
         const int m = g & (H_LO - 1);
         const int base = ((g >> S_LO) << (S_LO + LR)) | m;
         // sequence b: row b / R3, sub-block b % R3 of length 2^LOGN (R3 == 1: a whole row)
         float2* row = R3 == 1 ? tile + b * pitch : tile + (b / R3) * pitch + (b % R3) * ((1 << LOGN) + ((1 << LOGN) >> 5));
+        // H_LO >= 32: phys(base + j H_LO) = phys(base) + j (H_LO + H_LO/32) (no carries between the bit fields);
+        // otherwise the R points are consecutive-ish and phys() is recomputed (cheap, compile-time strides)
+        float2* p0 = row + (H_LO >= 32 ? phys(base) : 0);
         float2 v[R];
-        int pidx[R];
 #pragma unroll
-        for (int j = 0; j < R; ++j) {
-            if (H_LO >= 32) pidx[j] = phys(base) + j * (H_LO + (H_LO >> 5));  // no carries between the bit fields
-            else pidx[j] = phys(base + j * H_LO);
-            v[j] = row[pidx[j]];
-        }
+        for (int j = 0; j < R; ++j) v[j] = H_LO >= 32 ? p0[j * (H_LO + (H_LO >> 5))] : p0[phys(base + j * H_LO)];
 #pragma unroll
         for (int step = 0; step < LR; ++step) {
             const int bpos = INVERSE ? step : LR - 1 - step;  // local bit handled by this radix-2 stage
@@ -124,11 +123,24 @@ __device__ __forceinline__ void super_stage(float2* tile, int batch, int pitch, 
             }
         }
 #pragma unroll
-        for (int j = 0; j < R; ++j) row[pidx[j]] = v[j];
+        for (int j = 0; j < R; ++j) {
+            if (H_LO >= 32) p0[j * (H_LO + (H_LO >> 5))] = v[j];
+            else p0[phys(base + j * H_LO)] = v[j];
+        }
     }
 }
 
-__host__ __device__ constexpr int first_r(int rem) { return rem >= 8 ? 4 : (rem > 4 ? (rem + 1) / 2 : rem); }
+// super-stage sizes: at most MAXLR radix-2 stages (2^MAXLR points = 2 * 2^MAXLR VGPRs of data per lane); never leave a
+// lone radix-2 stage at the end
+#ifndef MI_FFT_UNROLL
+#define MI_FFT_UNROLL 4
+#endif
+#ifndef MI_FFT_MAXLR
+#define MI_FFT_MAXLR 3
+#endif
+__host__ __device__ constexpr int first_r(int rem) {
+    return rem <= MI_FFT_MAXLR ? rem : (rem == MI_FFT_MAXLR + 1 ? (MI_FFT_MAXLR + 1) / 2 : MI_FFT_MAXLR);
+}
 
 // full transform of `batch` LDS rows as a compile-time chain of super-stages (at most 4 radix-2 stages each); the
 // caller issues __syncthreads() before (tile filled); one follows every super-stage, so the tile is consistent on return
@@ -232,7 +244,7 @@ __device__ __forceinline__ void radix3_stage(float2* tile, int cols, int pitch, 
 // ---------------------------------------------------------------------------------------------- P1: x forward
 // grid: (Y / TY) * Z tiles; tile = TY consecutive rows of one z-plane
 template <int LHX>
-__global__ __launch_bounds__(kThreadsXZ) void k_x_forward(const float* __restrict__ in, float2* __restrict__ S, NativeDims d,
+__global__ __launch_bounds__(kThreadsXZ, 4) void k_x_forward(const float* __restrict__ in, float2* __restrict__ S, NativeDims d,
                                                          const float2* __restrict__ tw) {
     extern __shared__ __attribute__((aligned(16))) float2 tile[];
     constexpr int Hx = 1 << LHX;
@@ -253,7 +265,7 @@ __global__ __launch_bounds__(kThreadsXZ) void k_x_forward(const float* __restric
     // transposed store: S[z][px][y0 + r], r fastest; one float4 = rows (2 rp, 2 rp + 1) of one px
     float4* dst = reinterpret_cast<float4*>(S + ((size_t)z * Hx) * d.ny + y0);
     const int hp = TY / 2, rowq = d.ny / 2;
-#pragma unroll 4
+#pragma unroll MI_FFT_UNROLL
     for (int i = threadIdx.x; i < hp * Hx; i += kThreadsXZ) {
         const int px = i / hp, rp = i - px * hp;
         const float2 a = tile[(2 * rp) * pitch + phys(px)], b = tile[(2 * rp + 1) * pitch + phys(px)];
@@ -264,7 +276,7 @@ __global__ __launch_bounds__(kThreadsXZ) void k_x_forward(const float* __restric
 // ---------------------------------------------------------------------------------------------- P2 / P4: y passes
 // whole contiguous columns.  Forward: column (z, px) of src[z][px][.] -> dst[px][z][.]; inverse: the way back.
 template <int LY2, int R3, bool INVERSE>
-__global__ __launch_bounds__(kThreadsY) void k_y_pass(const float2* __restrict__ src, float2* __restrict__ dst, NativeDims d,
+__global__ __launch_bounds__(kThreadsY, 4) void k_y_pass(const float2* __restrict__ src, float2* __restrict__ dst, NativeDims d,
                                                       const float2* __restrict__ tw) {
     extern __shared__ __attribute__((aligned(16))) float2 tile[];
     constexpr int M = R3 << LY2;
@@ -272,7 +284,7 @@ __global__ __launch_bounds__(kThreadsY) void k_y_pass(const float2* __restrict__
     const size_t c0 = (size_t)blockIdx.x * TC;
     const float4* base = reinterpret_cast<const float4*>(src + c0 * M);
     const int quads = M / 2;
-#pragma unroll 4
+#pragma unroll MI_FFT_UNROLL
     for (int i = threadIdx.x; i < TC * quads; i += kThreadsY) {
         const int c = i / quads, q = i - c * quads;
         const float4 v = base[(size_t)c * quads + q];
@@ -292,7 +304,7 @@ __global__ __launch_bounds__(kThreadsY) void k_y_pass(const float2* __restrict__
         radix3_stage<R3, true, kThreadsY>(tile, TC, pitch, 1 << LY2, twM);
         __syncthreads();
     }
-#pragma unroll 4
+#pragma unroll MI_FFT_UNROLL
     for (int i = threadIdx.x; i < TC * quads; i += kThreadsY) {
         const int c = i / quads, q = i - c * quads;
         const size_t sc = c0 + c;  // source column index
@@ -312,7 +324,7 @@ __global__ __launch_bounds__(kThreadsY) void k_y_pass(const float2* __restrict__
 // grid: (#A planes) * (Y / TL) tiles of TL consecutive py positions.
 // OTF layout: G[(plane index)][py][pz] as float4 {Ga.re, Ga.im, Gb.re, Gb.im}, already scaled by 1/(Hx*Y*Z).
 template <int LZ, bool CONJ>
-__global__ __launch_bounds__(kThreadsXZ) void k_z_conv(const float2* __restrict__ S, float2* __restrict__ T, const float4* __restrict__ G,
+__global__ __launch_bounds__(kThreadsXZ, 4) void k_z_conv(const float2* __restrict__ S, float2* __restrict__ T, const float4* __restrict__ G,
                                                       NativeDims d, const float2* __restrict__ tw) {
     extern __shared__ __attribute__((aligned(16))) float2 tile[];
     constexpr int L = 1 << LZ;
@@ -333,7 +345,7 @@ __global__ __launch_bounds__(kThreadsXZ) void k_z_conv(const float2* __restrict_
     const float4* sA = reinterpret_cast<const float4*>(S + (size_t)px * L * M + py0);
     const float4* sB = reinterpret_cast<const float4*>(S + (size_t)pxB * L * M + pyB0);
     const int hp = TL / 2, rowq = M / 2;
-#pragma unroll 4
+#pragma unroll MI_FFT_UNROLL
     for (int i = threadIdx.x; i < hp * L; i += kThreadsXZ) {
         const int z = i / hp, jp = i - z * hp;
         const float4 a = sA[(size_t)z * rowq + jp], b = sB[(size_t)z * rowq + jp];
@@ -342,15 +354,7 @@ __global__ __launch_bounds__(kThreadsXZ) void k_z_conv(const float2* __restrict_
         tB[(2 * jp) * pitch + phys(z)] = make_float2(b.x, b.y);
         tB[(2 * jp + 1) * pitch + phys(z)] = make_float2(b.z, b.w);
     }
-    // OTF pairs of this tile: issued now so the loads fly during the forward transform (8 float4 per lane at TL = 8)
-    constexpr int kMaxPre = 8;
     const float4* Gp = G + ((size_t)plane * M + py0) * L;
-    float4 gpre[kMaxPre];
-#pragma unroll
-    for (int q = 0; q < kMaxPre; ++q) {
-        const int i = threadIdx.x + q * kThreadsXZ;
-        if (i < TL * L) gpre[q] = Gp[i];  // Gp[(size_t)j * L + pz] with i = j * L + pz
-    }
     __syncthreads();
     if (!(d.dbg & 1)) lds_fft<LZ, false, kThreadsXZ>(tile, 2 * TL, pitch, tw);
     // point-wise: element (line j, position pz) of A pairs with (line jB, position pzB) of B
@@ -362,12 +366,7 @@ __global__ __launch_bounds__(kThreadsXZ) void k_z_conv(const float2* __restrict_
     for (int q = 0; q < n_it; ++q) {
         const int i = threadIdx.x + q * kThreadsXZ;
         if (i >= TL * L || (d.dbg & 2)) break;
-        float4 g;
-        switch (q) {  // registers cannot be indexed dynamically: the first kMaxPre iterations use the prefetched values
-            case 0: g = gpre[0]; break; case 1: g = gpre[1]; break; case 2: g = gpre[2]; break; case 3: g = gpre[3]; break;
-            case 4: g = gpre[4]; break; case 5: g = gpre[5]; break; case 6: g = gpre[6]; break; case 7: g = gpre[7]; break;
-            default: g = Gp[i]; break;
-        }
+        const float4 g = Gp[i];  // Gp[(size_t)j * L + pz] with i = j * L + pz
         const int j = i / L, pz = i - j * L;
         const int jB = y_mirror_pos(py0 + j, d) - pyB0;
         const unsigned kz = brev_n((unsigned)pz, d.lz);
@@ -394,7 +393,7 @@ __global__ __launch_bounds__(kThreadsXZ) void k_z_conv(const float2* __restrict_
     if (!(d.dbg & 4)) lds_fft<LZ, true, kThreadsXZ>(tile, 2 * TL, pitch, tw);
     float4* dA = reinterpret_cast<float4*>(T + (size_t)px * L * M + py0);
     float4* dB = reinterpret_cast<float4*>(T + (size_t)pxB * L * M + pyB0);
-#pragma unroll 4
+#pragma unroll MI_FFT_UNROLL
     for (int i = threadIdx.x; i < hp * L; i += kThreadsXZ) {
         const int z = i / hp, jp = i - z * hp;
         const float2 a0 = tA[(2 * jp) * pitch + phys(z)], a1 = tA[(2 * jp + 1) * pitch + phys(z)];
@@ -410,7 +409,7 @@ __global__ __launch_bounds__(kThreadsXZ) void k_z_conv(const float2* __restrict_
 // FUSE: the epilogue result stays in LDS and is transformed forward again into S_next (the P1 of the NEXT
 // convolution): the ratio never touches HBM, and bl is read once and written once per iteration.
 template <int LHX, int EPI, bool FUSE>
-__global__ __launch_bounds__(kThreadsXZ) void k_x_inverse(const float2* __restrict__ T, float* __restrict__ out, ConvEpilogue e, NativeDims d,
+__global__ __launch_bounds__(kThreadsXZ, 4) void k_x_inverse(const float2* __restrict__ T, float* __restrict__ out, ConvEpilogue e, NativeDims d,
                                                          const float2* __restrict__ tw, float2* __restrict__ S_next) {
     extern __shared__ __attribute__((aligned(16))) float2 tile[];
     constexpr int Hx = 1 << LHX;
@@ -419,7 +418,7 @@ __global__ __launch_bounds__(kThreadsXZ) void k_x_inverse(const float2* __restri
     const int z = blockIdx.x / ytiles, y0 = (blockIdx.x % ytiles) * TY;
     const float4* src = reinterpret_cast<const float4*>(T + ((size_t)z * Hx) * d.ny + y0);
     const int hp = TY / 2, rowq = d.ny / 2;
-#pragma unroll 8
+#pragma unroll MI_FFT_UNROLL
     for (int i = threadIdx.x; i < hp * Hx; i += kThreadsXZ) {
         const int px = i / hp, rp = i - px * hp;
         const float4 v = src[(size_t)px * rowq + rp];
@@ -466,7 +465,7 @@ __global__ __launch_bounds__(kThreadsXZ) void k_x_inverse(const float2* __restri
         __syncthreads();
         lds_fft<LHX, false, kThreadsXZ>(tile, TY, pitch, tw);
         float4* sdst = reinterpret_cast<float4*>(S_next + ((size_t)z * Hx) * d.ny + y0);
-#pragma unroll 4
+#pragma unroll MI_FFT_UNROLL
         for (int i = threadIdx.x; i < hp * Hx; i += kThreadsXZ) {
             const int px = i / hp, rp = i - px * hp;
             const float2 a = tile[(2 * rp) * pitch + phys(px)], b = tile[(2 * rp + 1) * pitch + phys(px)];

@@ -176,7 +176,7 @@ __global__ __launch_bounds__(NCC_THREADS) void k_ncc(const float* __restrict__ m
 // arithmetic as compute_NCC (compute_funcs.cu:1163-1292) with a fixed reduction tree.
 constexpr int VB = 4;
 constexpr int MAP_THREADS = 1024;  // 16 waves: the map has only (2du+1)*ceil((2dv+1)/4) work-groups
-__global__ __launch_bounds__(MAP_THREADS) void k_ncc_map4(const float* __restrict__ m1, const float* __restrict__ m2, int dimu, int dimv,
+__global__ __launch_bounds__(MAP_THREADS, 4) void k_ncc_map4(const float* __restrict__ m1, const float* __restrict__ m2, int dimu, int dimv,
                                                            int du, int dv, const float* __restrict__ ps1, const float* __restrict__ ps2,
                                                            const int* __restrict__ groups, float* __restrict__ out) {
     __shared__ double sh[MAP_THREADS / 64];
