@@ -52,6 +52,25 @@ def make_volume(shape, device, seed=1234):
     return vol
 
 
+def pmc_traffic(pass_name, workload):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r01_pmc_traffic.json:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this same command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes).
+    Counters cannot be collected from inside the timed process, so the profile of the default workload is quoted."""
+    if workload != "c3":
+        return None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            kern = json.load(f)["kernels"]
+    except OSError:
+        return None
+    want = {"z_conv": ("k_z_conv<", "false>"), "x_fused": ("k_x_inverse<", ", 1, true>"),
+            "y_forward": ("k_y_pass<", "false>"), "y_inverse": ("k_y_pass<", "true>")}[pass_name]
+    for name, v in kern.items():
+        if name.startswith(want[0]) and name.endswith(want[1]):
+            return round(v["hbm_bytes_per_launch"])
+    return None
+
+
 def cpu_baseline(kshape, seconds_budget=20.0):
     """The oracle (numpy restatement of deconFFT, 1 host thread) on a bounded sub-volume of the same workload."""
     import numpy as np
@@ -179,7 +198,7 @@ def main():
                 algo_b = {"z_conv": 12, "y_forward": 8, "y_inverse": 8, "x_fused": 12}[dom]  # B per voxel per launch
                 ach = algo_b * local_vox / (times[dom] * 1e-3) / 1e9
                 roofline = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                            "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(dom, args.workload),
                             "kernel": {"z_conv": "k_z_conv (z-forward FFT + untangle*OTF + z-inverse FFT, one pass)",
                                        "x_fused": "k_x_inverse<fused> (x-inverse FFT + RL epilogue + x-forward FFT)",
                                        "y_forward": "k_y_pass<fwd>", "y_inverse": "k_y_pass<inv>"}[dom],
