@@ -33,10 +33,37 @@
 namespace mi {
 namespace {
 
+#ifndef MI_FFT_HALF_TILES
+#define MI_FFT_HALF_TILES 0
+#endif
+#if MI_FFT_HALF_TILES
+constexpr int kThreadsXZ = 512;   // strided passes: two 68-KB work-groups per CU, 8-wide tiles; the two halves of a
+                                  // 128-B line are owned by consecutive work-groups of ONE XCD (pair_tile below)
+#elif defined(MI_FFT_XZ512)
+constexpr int kThreadsXZ = 512;   // experiment: 8 waves per CU, 256 VGPRs -> 16-point butterflies
+#else
 constexpr int kThreadsXZ = 1024;  // strided passes: one 135-KB work-group per CU, 16 waves
+#endif
+#ifdef MI_FFT_XZ512
+constexpr int kWavesXZ = 2, kMaxLrXZ = 4;
+#else
+constexpr int kWavesXZ = 4, kMaxLrXZ = MI_FFT_MAXLR;
+#endif
 constexpr int kThreadsY = 512;    // contiguous pass: two 68-KB work-groups per CU
 
 __device__ __forceinline__ int phys(int i) { return i + (i >> 5); }
+// Work-group -> tile numbering.  Dispatch deals consecutive block ids round-robin over the 8 XCDs, so ids b and b + 8
+// are neighbours on one XCD: with half tiles, those two take the two 64-B halves of the same 128-B lines and meet in that
+// XCD's L2.  (Placement only changes speed, never results.)
+__device__ __forceinline__ unsigned pair_tile(unsigned b) {
+#if MI_FFT_HALF_TILES
+    if (gridDim.x & 15u) return b;  // the pairing is a bijection only on multiples of 16 work-groups
+    const unsigned xcd = b & 7u, local = b >> 3;
+    return (local >> 1) * 16u + xcd * 2u + (local & 1u);
+#else
+    return b;
+#endif
+}
 __host__ __device__ __forceinline__ int row_pitch(int n) { return n + (n >> 5) + 1; }
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
@@ -138,20 +165,20 @@ __device__ __forceinline__ void super_stage(float2* tile, int batch, int pitch, 
 #ifndef MI_FFT_MAXLR
 #define MI_FFT_MAXLR 3
 #endif
-__host__ __device__ constexpr int first_r(int rem) {
-    return rem <= MI_FFT_MAXLR ? rem : (rem == MI_FFT_MAXLR + 1 ? (MI_FFT_MAXLR + 1) / 2 : MI_FFT_MAXLR);
+__host__ __device__ constexpr int first_r(int rem, int maxlr) {
+    return rem <= maxlr ? rem : (rem == maxlr + 1 ? (maxlr + 1) / 2 : maxlr);
 }
 
 // full transform of `batch` LDS rows as a compile-time chain of super-stages (at most 4 radix-2 stages each); the
 // caller issues __syncthreads() before (tile filled); one follows every super-stage, so the tile is consistent on return
-template <int LOGN, bool INVERSE, int NT, int R3 = 1, int DONE = 0>
+template <int LOGN, bool INVERSE, int NT, int R3 = 1, int MAXLR = MI_FFT_MAXLR, int DONE = 0>
 __device__ __forceinline__ void lds_fft(float2* tile, int batch, int pitch, const float2* __restrict__ tw) {
     if constexpr (DONE < LOGN) {
-        constexpr int r = first_r(LOGN - DONE);
+        constexpr int r = first_r(LOGN - DONE, MAXLR);
         constexpr int s_lo = INVERSE ? DONE : LOGN - DONE - r;  // forward: top stages first; inverse: bottom first
         super_stage<LOGN, r, s_lo, INVERSE, NT, R3>(tile, batch, pitch, tw);
         __syncthreads();
-        lds_fft<LOGN, INVERSE, NT, R3, DONE + r>(tile, batch, pitch, tw);
+        lds_fft<LOGN, INVERSE, NT, R3, MAXLR, DONE + r>(tile, batch, pitch, tw);
     }
 }
 
@@ -244,13 +271,14 @@ __device__ __forceinline__ void radix3_stage(float2* tile, int cols, int pitch, 
 // ---------------------------------------------------------------------------------------------- P1: x forward
 // grid: (Y / TY) * Z tiles; tile = TY consecutive rows of one z-plane
 template <int LHX>
-__global__ __launch_bounds__(kThreadsXZ, 4) void k_x_forward(const float* __restrict__ in, float2* __restrict__ S, NativeDims d,
+__global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_x_forward(const float* __restrict__ in, float2* __restrict__ S, NativeDims d,
                                                          const float2* __restrict__ tw) {
     extern __shared__ __attribute__((aligned(16))) float2 tile[];
     constexpr int Hx = 1 << LHX;
     const int TY = d.ty, pitch = row_pitch(Hx);
     const int ytiles = d.ny / TY;
-    const int z = blockIdx.x / ytiles, y0 = (blockIdx.x % ytiles) * TY;
+    const unsigned tid_ = pair_tile(blockIdx.x);
+    const int z = tid_ / ytiles, y0 = (tid_ % ytiles) * TY;
     const float4* src = reinterpret_cast<const float4*>(in + ((size_t)z * d.ny + y0) * (size_t)(2 * Hx));
     const int quads = Hx / 2;  // float4 = 2 complex
     for (int i = threadIdx.x; i < TY * quads; i += kThreadsXZ) {
@@ -261,7 +289,7 @@ __global__ __launch_bounds__(kThreadsXZ, 4) void k_x_forward(const float* __rest
         row[phys(2 * q + 1)] = make_float2(v.z, v.w);
     }
     __syncthreads();
-    lds_fft<LHX, false, kThreadsXZ>(tile, TY, pitch, tw);
+    lds_fft<LHX, false, kThreadsXZ, 1, kMaxLrXZ>(tile, TY, pitch, tw);
     // transposed store: S[z][px][y0 + r], r fastest; one float4 = rows (2 rp, 2 rp + 1) of one px
     float4* dst = reinterpret_cast<float4*>(S + ((size_t)z * Hx) * d.ny + y0);
     const int hp = TY / 2, rowq = d.ny / 2;
@@ -324,14 +352,15 @@ __global__ __launch_bounds__(kThreadsY, 4) void k_y_pass(const float2* __restric
 // grid: (#A planes) * (Y / TL) tiles of TL consecutive py positions.
 // OTF layout: G[(plane index)][py][pz] as float4 {Ga.re, Ga.im, Gb.re, Gb.im}, already scaled by 1/(Hx*Y*Z).
 template <int LZ, bool CONJ>
-__global__ __launch_bounds__(kThreadsXZ, 4) void k_z_conv(const float2* __restrict__ S, float2* __restrict__ T, const float4* __restrict__ G,
+__global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_z_conv(const float2* __restrict__ S, float2* __restrict__ T, const float4* __restrict__ G,
                                                       NativeDims d, const float2* __restrict__ tw) {
     extern __shared__ __attribute__((aligned(16))) float2 tile[];
     constexpr int L = 1 << LZ;
     const int Hx = 1 << d.lhx, M = d.ny, TL = d.tl, pitch = row_pitch(L);
     const int ytiles = M / TL;
-    const int plane = blockIdx.x / ytiles;                 // 0 .. Hx/2
-    const int py0 = (blockIdx.x % ytiles) * TL;
+    const unsigned tid_ = pair_tile(blockIdx.x);
+    const int plane = tid_ / ytiles;                 // 0 .. Hx/2
+    const int py0 = (tid_ % ytiles) * TL;
     const int px = plane == Hx / 2 ? 1 : 2 * plane;        // plane order: even px ascending, then px = 1
     const unsigned xk = brev_n((unsigned)px, d.lhx);
     const int pxB = (int)brev_n((Hx - xk) & (Hx - 1), d.lhx);
@@ -356,7 +385,7 @@ __global__ __launch_bounds__(kThreadsXZ, 4) void k_z_conv(const float2* __restri
     }
     const float4* Gp = G + ((size_t)plane * M + py0) * L;
     __syncthreads();
-    if (!(d.dbg & 1)) lds_fft<LZ, false, kThreadsXZ>(tile, 2 * TL, pitch, tw);
+    if (!(d.dbg & 1)) lds_fft<LZ, false, kThreadsXZ, 1, kMaxLrXZ>(tile, 2 * TL, pitch, tw);
     // point-wise: element (line j, position pz) of A pairs with (line jB, position pzB) of B
     float sw, cw;
     sincospif(-2.0f * (float)xk / (float)(2 * Hx), &sw, &cw);  // w = exp(-2 pi i xk / Nx), Nx = 2 Hx
@@ -390,7 +419,7 @@ __global__ __launch_bounds__(kThreadsXZ, 4) void k_z_conv(const float2* __restri
         tB[jB * pitch + phys(pzB)] = make_float2(E2.x + O2.y, O2.x - E2.y);
     }
     __syncthreads();
-    if (!(d.dbg & 4)) lds_fft<LZ, true, kThreadsXZ>(tile, 2 * TL, pitch, tw);
+    if (!(d.dbg & 4)) lds_fft<LZ, true, kThreadsXZ, 1, kMaxLrXZ>(tile, 2 * TL, pitch, tw);
     float4* dA = reinterpret_cast<float4*>(T + (size_t)px * L * M + py0);
     float4* dB = reinterpret_cast<float4*>(T + (size_t)pxB * L * M + pyB0);
 #pragma unroll MI_FFT_UNROLL
@@ -409,13 +438,14 @@ __global__ __launch_bounds__(kThreadsXZ, 4) void k_z_conv(const float2* __restri
 // FUSE: the epilogue result stays in LDS and is transformed forward again into S_next (the P1 of the NEXT
 // convolution): the ratio never touches HBM, and bl is read once and written once per iteration.
 template <int LHX, int EPI, bool FUSE>
-__global__ __launch_bounds__(kThreadsXZ, 4) void k_x_inverse(const float2* __restrict__ T, float* __restrict__ out, ConvEpilogue e, NativeDims d,
+__global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_x_inverse(const float2* __restrict__ T, float* __restrict__ out, ConvEpilogue e, NativeDims d,
                                                          const float2* __restrict__ tw, float2* __restrict__ S_next) {
     extern __shared__ __attribute__((aligned(16))) float2 tile[];
     constexpr int Hx = 1 << LHX;
     const int TY = d.ty, pitch = row_pitch(Hx);
     const int ytiles = d.ny / TY;
-    const int z = blockIdx.x / ytiles, y0 = (blockIdx.x % ytiles) * TY;
+    const unsigned tid_ = pair_tile(blockIdx.x);
+    const int z = tid_ / ytiles, y0 = (tid_ % ytiles) * TY;
     const float4* src = reinterpret_cast<const float4*>(T + ((size_t)z * Hx) * d.ny + y0);
     const int hp = TY / 2, rowq = d.ny / 2;
 #pragma unroll MI_FFT_UNROLL
@@ -426,7 +456,7 @@ __global__ __launch_bounds__(kThreadsXZ, 4) void k_x_inverse(const float2* __res
         tile[(2 * rp + 1) * pitch + phys(px)] = make_float2(v.z, v.w);
     }
     __syncthreads();
-    lds_fft<LHX, true, kThreadsXZ>(tile, TY, pitch, tw);
+    if (!(d.dbg & 8)) lds_fft<LHX, true, kThreadsXZ, 1, kMaxLrXZ>(tile, TY, pitch, tw);
     const size_t row0 = ((size_t)z * d.ny + y0) * (size_t)(2 * Hx);
     const int quads = Hx / 2;
     float4* dst = reinterpret_cast<float4*>(out + row0);
@@ -463,7 +493,7 @@ __global__ __launch_bounds__(kThreadsXZ, 4) void k_x_inverse(const float2* __res
     }
     if (FUSE) {
         __syncthreads();
-        lds_fft<LHX, false, kThreadsXZ>(tile, TY, pitch, tw);
+        if (!(d.dbg & 16)) lds_fft<LHX, false, kThreadsXZ, 1, kMaxLrXZ>(tile, TY, pitch, tw);
         float4* sdst = reinterpret_cast<float4*>(S_next + ((size_t)z * Hx) * d.ny + y0);
 #pragma unroll MI_FFT_UNROLL
         for (int i = threadIdx.x; i < hp * Hx; i += kThreadsXZ) {
@@ -540,7 +570,11 @@ int NativeFft::init(hipStream_t s, const int F[3], const float2* otf_half_spectr
         while (rows > 1 && (lds_bytes(rows * mult, n) > budget)) rows >>= 1;
         return rows;
     };
+#if MI_FFT_HALF_TILES
+    const size_t big = 68 * 1024;
+#else
     const size_t big = 140 * 1024;  // one work-group per CU for the strided passes: 16-wide tiles = full 128-B lines
+#endif
     auto fit_big = [&](int n, int maxrows, int mult) {
         int rows = maxrows;
         while (rows > 2 && (lds_bytes(rows * mult, n) > big)) rows >>= 1;
