@@ -33,6 +33,13 @@
 namespace mi {
 namespace {
 
+// super-stage size / unroll knobs (see first_r below)
+#ifndef MI_FFT_UNROLL
+#define MI_FFT_UNROLL 4
+#endif
+#ifndef MI_FFT_MAXLR
+#define MI_FFT_MAXLR 3
+#endif
 #ifndef MI_FFT_HALF_TILES
 #define MI_FFT_HALF_TILES 0
 #endif
@@ -159,12 +166,6 @@ __device__ __forceinline__ void super_stage(float2* tile, int batch, int pitch, 
 
 // super-stage sizes: at most MAXLR radix-2 stages (2^MAXLR points = 2 * 2^MAXLR VGPRs of data per lane); never leave a
 // lone radix-2 stage at the end
-#ifndef MI_FFT_UNROLL
-#define MI_FFT_UNROLL 4
-#endif
-#ifndef MI_FFT_MAXLR
-#define MI_FFT_MAXLR 3
-#endif
 __host__ __device__ constexpr int first_r(int rem, int maxlr) {
     return rem <= maxlr ? rem : (rem == maxlr + 1 ? (maxlr + 1) / 2 : maxlr);
 }
