@@ -8,10 +8,12 @@
 //                 integer atomicMax on the float bit pattern (all values >= 0 as the MIPs start at 0).
 //   k_tile_sums   32x32 tile sums with the reference's FLOAT running sum in row/column order
 //                 (seq_cpu_compute_partial_sums, :474-500) -- bit-identical, one lane per tile.
-//   k_ncc         one work-group per shift (u,v): window means from tile sums + border pixels in fp64,
-//                 then num / F1 / F2 in fp64 with a fixed reduction tree (compute_NCC, :1163-1292;
-//                 replaces gpu_NCC_map/gpu_NCC_miss :730-935).  Serves full maps and "missing entry"
-//                 lists of the neighbourhood refinement alike.
+//   k_mip_mean / k_sat_rows / k_sat_cols   fp64 summed-area tables of (f - c0), (f - c0)^2 and of the float tile sums:
+//                 every term of compute_NCC (:1163-1292) except the cross term sum f*t becomes O(1) per shift, with
+//                 the reference's means (float tile sums + border pixels) reproduced exactly.
+//   k_ncc_sat     one work-group per (u, 4 consecutive v): accumulates the four cross terms in fp64 from shared
+//                 loads (wave shuffles), fixed reduction tree; replaces gpu_NCC_map/gpu_NCC_miss (:730-935).
+//                 Serves full maps and the "missing entry" groups of the neighbourhood refinement alike.
 // Host side (this file, plain C++): argmax, neighbourhood refinement, peak widths and the final
 // alignment rules, kept bit-identical in float/int arithmetic to compute_funcs.cu:160-342,1294-1609.
 #include <cmath>
@@ -97,88 +99,139 @@ __device__ __forceinline__ double block_sum(double v, double* sh) {
 
 // sum of mip over rows [r0,r0+nr) x cols [c0,c0+nc) (per-lane partial): interior tiles from ps, border
 // pixels directly (compute_funcs.cu:1186-1262); falls back to all pixels when ps == nullptr
-template <int NT = NCC_THREADS>
-__device__ double window_partial(const float* __restrict__ mip, const float* __restrict__ ps, int dimv, int r0, int c0, int nr, int nc) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = NT / 64;
-    double acc = 0.0;
-    int su = r0, eu = r0, sv = c0, ev = c0;  // empty tiled region by default
-    if (ps) {
-        su = (r0 + TILE - 1) / TILE * TILE;
-        sv = (c0 + TILE - 1) / TILE * TILE;
-        eu = (r0 + nr) / TILE * TILE;
-        ev = (c0 + nc) / TILE * TILE;
-        if (su >= eu || sv >= ev) { su = eu = r0; sv = ev = c0; }
-        const int pw = dimv / TILE, tu = (eu - su) / TILE, tv = (ev - sv) / TILE;
-        for (int t = threadIdx.x; t < tu * tv; t += NT) acc += (double)ps[(su / TILE + t / tv) * pw + sv / TILE + t % tv];
-    }
-    for (int i = r0 + wave; i < r0 + nr; i += nw) {
-        const float* row = mip + (size_t)i * dimv;
-        if (i < su || i >= eu) {
-            for (int j = c0 + lane; j < c0 + nc; j += 64) acc += (double)row[j];
-        } else {
-            for (int j = c0 + lane; j < sv; j += 64) acc += (double)row[j];
-            for (int j = ev + lane; j < c0 + nc; j += 64) acc += (double)row[j];
-        }
-    }
-    return acc;
+// ------------------------------------------------------------------------------------------------ summed-area tables
+// Everything of compute_NCC (compute_funcs.cu:1163-1292) except the cross term  sum f*t  depends on ONE image window:
+//   mean'  = (sum of float tile sums inside the window + border pixels) / n        (the reference's means, :1186-1272)
+//   F      = sum (f - mean')^2 = Q - 2 g' P + n g'^2   with  P = sum (f - c0), Q = sum (f - c0)^2, g' = mean' - c0
+//   num    = sum f (t - tmean') = cross - tmean' * sum f
+// so per MIP three fp64 summed-area tables (P, Q over the pixels shifted by the global mean c0, TS over the float tile sums)
+// give all of them in O(1) per shift, and the NCC kernel only accumulates the cross term.
+struct SatView {
+    const double* P;   // (dimu+1) x (dimv+1): sum of (f - c0)
+    const double* Q;   // same shape: sum of (f - c0)^2
+    const double* TS;  // (ph+1) x (pw+1): sum of the float tile sums (nullptr when the MIP has no full tile)
+    const double* c0;  // global mean of the MIP
+};
+
+__device__ __forceinline__ double rect(const double* __restrict__ S, int w1, int r0, int c0, int nr, int nc) {
+    return S[(size_t)(r0 + nr) * w1 + c0 + nc] - S[(size_t)r0 * w1 + c0 + nc] - S[(size_t)(r0 + nr) * w1 + c0] + S[(size_t)r0 * w1 + c0];
 }
 
-// NCC for shift (u,v).  Full map: blockIdx.x -> (u,v) row-major over [-du,du] x [-dv,dv].  List mode
-// (list != nullptr): entry q = blockIdx.x has u = list[3q], v = list[3q+1], output slot list[3q+2].
-__global__ __launch_bounds__(NCC_THREADS) void k_ncc(const float* __restrict__ m1, const float* __restrict__ m2, int dimu, int dimv,
-                                                      int du, int dv, const float* __restrict__ ps1, const float* __restrict__ ps2,
-                                                      const int* __restrict__ list, float* __restrict__ out) {
-    __shared__ double sh[NCC_THREADS / 64];
-    int u, v, slot;
-    if (list) {
-        u = list[3 * blockIdx.x];
-        v = list[3 * blockIdx.x + 1];
-        slot = list[3 * blockIdx.x + 2];
-    } else {
-        u = (int)(blockIdx.x / (2 * dv + 1)) - du;
-        v = (int)(blockIdx.x % (2 * dv + 1)) - dv;
-        slot = blockIdx.x;
+// window statistics of one MIP: mean' (reference flavour), sum f, sum (f - mean')^2
+__device__ void window_stats(const SatView& sv, int dimu, int dimv, int r0, int c0, int nr, int nc, double* mean, double* sumf, double* ssd) {
+    const int w1 = dimv + 1;
+    const double n = (double)nr * (double)nc, cm = *sv.c0;
+    const double P = rect(sv.P, w1, r0, c0, nr, nc), Q = rect(sv.Q, w1, r0, c0, nr, nc);
+    const double sf = P + n * cm;
+    double m = sf / n;
+    if (sv.TS && dimu >= TILE && dimv >= TILE) {
+        int su = (r0 + TILE - 1) / TILE * TILE, tsv = (c0 + TILE - 1) / TILE * TILE;
+        int eu = (r0 + nr) / TILE * TILE, ev = (c0 + nc) / TILE * TILE;
+        if (su < eu && tsv < ev) {
+            const int pw = dimv / TILE;
+            const double tiles = rect(sv.TS, pw + 1, su / TILE, tsv / TILE, (eu - su) / TILE, (ev - tsv) / TILE);
+            const double nreg = (double)(eu - su) * (double)(ev - tsv);
+            const double region = rect(sv.P, w1, su, tsv, eu - su, ev - tsv) + nreg * cm;
+            m = (tiles + (sf - region)) / n;  // float tile sums + border pixels, like the reference
+        }
     }
-    const int nr = dimu - abs(u), nc = dimv - abs(v);
-    if (nr <= 0 || nc <= 0) {  // reference: empty loops, 0/0 (compute_funcs.cu:1277-1290)
-        if (threadIdx.x == 0) out[slot] = __int_as_float(0x7fc00000);
+    const double g = m - cm;
+    *mean = m;
+    *sumf = sf;
+    *ssd = Q - 2.0 * g * P + n * g * g;
+}
+
+// global mean c0 of each of the two MIPs of a plane (blockIdx.x = 0 / 1) and the table of its float tile sums
+__global__ __launch_bounds__(1024) void k_mip_mean(const float* __restrict__ m1, const float* __restrict__ m2, int dimu, int dimv,
+                                                   const float* __restrict__ ps1, const float* __restrict__ ps2, double* __restrict__ c0a,
+                                                   double* __restrict__ c0b, double* __restrict__ ts1, double* __restrict__ ts2) {
+    __shared__ double sh[16];
+    const float* m = blockIdx.x ? m2 : m1;
+    const float* ps = blockIdx.x ? ps2 : ps1;
+    double* ts = blockIdx.x ? ts2 : ts1;
+    const size_t n = (size_t)dimu * dimv;
+    double acc = 0.0;
+    for (size_t i = threadIdx.x; i < n; i += 1024) acc += (double)m[i];
+    acc = block_sum<1024>(acc, sh);
+    if (threadIdx.x == 0) *(blockIdx.x ? c0b : c0a) = acc / (double)n;
+    const int ph = dimu / TILE, pw = dimv / TILE;
+    if (ps && ph * pw > 0) {
+        // (ph+1) x (pw+1) inclusive table; a few hundred entries: one lane per row, then one per column
+        const int w1 = pw + 1;
+        for (int i = threadIdx.x; i < (ph + 1) * w1; i += 1024) ts[i] = 0.0;
+        __syncthreads();
+        for (int r = threadIdx.x; r < ph; r += 1024) {
+            double run = 0.0;
+            for (int c = 0; c < pw; ++c) { run += (double)ps[r * pw + c]; ts[(r + 1) * w1 + c + 1] = run; }
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < pw; c += 1024) {
+            double run = 0.0;
+            for (int r = 0; r < ph; ++r) { run += ts[(r + 1) * w1 + c + 1]; ts[(r + 1) * w1 + c + 1] = run; }
+        }
+    }
+}
+
+__device__ __forceinline__ double wave_inclusive_scan(double v) {
+    const int lane = threadIdx.x & 63;
+    for (int off = 1; off < 64; off <<= 1) {
+        const double o = __shfl_up(v, off, 64);
+        if (lane >= off) v += o;
+    }
+    return v;
+}
+
+// row pass: one wave per (row, MIP): P/Q[(i+1)][j+1] = prefix along j of (f - c0), (f - c0)^2; row 0 and column 0 are zero
+__global__ __launch_bounds__(64) void k_sat_rows(const float* __restrict__ m1, const float* __restrict__ m2, int dimu, int dimv,
+                                                 const double* __restrict__ c0a, const double* __restrict__ c0b, double* __restrict__ P1,
+                                                 double* __restrict__ Q1, double* __restrict__ P2, double* __restrict__ Q2) {
+    const float* m = blockIdx.y ? m2 : m1;
+    double* P = blockIdx.y ? P2 : P1;
+    double* Q = blockIdx.y ? Q2 : Q1;
+    const double cm = *(blockIdx.y ? c0b : c0a);
+    const int w1 = dimv + 1, lane = threadIdx.x;
+    const int i = blockIdx.x;  // 0 .. dimu (row i of the table; table row 0 is all zero)
+    if (i == 0) {
+        for (int j = lane; j < w1; j += 64) { P[j] = 0.0; Q[j] = 0.0; }
         return;
     }
-    const int a_u = max(u, 0), a_v = max(v, 0), b_u = max(-u, 0), b_v = max(-v, 0);
-    const bool tiled = ps1 && ps2 && dimu >= TILE && dimv >= TILE;
-    double fm = block_sum(window_partial(m1, tiled ? ps1 : nullptr, dimv, a_u, a_v, nr, nc), sh);
-    double tm = block_sum(window_partial(m2, tiled ? ps2 : nullptr, dimv, b_u, b_v, nr, nc), sh);
-    fm /= (double)(nr * nc);
-    tm /= (double)(nr * nc);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = NCC_THREADS / 64;
-    double num = 0.0, f1 = 0.0, f2 = 0.0;
-    for (int i = wave; i < nr; i += nw) {
-        const float* p = m1 + (size_t)(a_u + i) * dimv + a_v;
-        const float* q = m2 + (size_t)(b_u + i) * dimv + b_v;
-        for (int j = lane; j < nc; j += 64) {
-            const double f = (double)p[j], t = (double)q[j];
-            const double fp = f - fm, tp = t - tm;
-            num += f * tp;
-            f1 += fp * fp;
-            f2 += tp * tp;
-        }
+    const float* row = m + (size_t)(i - 1) * dimv;
+    double cp = 0.0, cq = 0.0;
+    if (lane == 0) { P[(size_t)i * w1] = 0.0; Q[(size_t)i * w1] = 0.0; }
+    for (int j0 = 0; j0 < dimv; j0 += 64) {
+        const int j = j0 + lane;
+        const double g = j < dimv ? (double)row[j] - cm : 0.0;
+        const double sp = wave_inclusive_scan(g) + cp, sq = wave_inclusive_scan(g * g) + cq;
+        if (j < dimv) { P[(size_t)i * w1 + j + 1] = sp; Q[(size_t)i * w1 + j + 1] = sq; }
+        cp = __shfl(sp, 63, 64);
+        cq = __shfl(sq, 63, 64);
     }
-    num = block_sum(num, sh);
-    f1 = block_sum(f1, sh);
-    f2 = block_sum(f2, sh);
-    if (threadIdx.x == 0) out[slot] = (float)(num / sqrt(f1 * f2));
 }
 
-// Full NCC map, VB = 4 consecutive v shifts of one u per work-group.  For a fixed u the four shifts pair the SAME
-// m2 pixel (r2, c2) with m1 pixels (r1, c2 + v0 + k), k = 0..3: each lane loads one m2 value and one m1 value per
-// 64-column chunk (plus the next chunk's m1 value, which becomes the current one of the next step) and receives the
-// three neighbours through wave shuffles -- 0.5 loads per pixel-shift instead of 2 (k_ncc).  Same two-pass fp64
-// arithmetic as compute_NCC (compute_funcs.cu:1163-1292) with a fixed reduction tree.
+// column pass, in place: one wave per (column, table): running sum down the rows
+__global__ __launch_bounds__(64) void k_sat_cols(int dimu, int dimv, double* __restrict__ P1, double* __restrict__ Q1, double* __restrict__ P2,
+                                                 double* __restrict__ Q2) {
+    double* S = blockIdx.y == 0 ? P1 : (blockIdx.y == 1 ? Q1 : (blockIdx.y == 2 ? P2 : Q2));
+    const int w1 = dimv + 1, lane = threadIdx.x, j = blockIdx.x + 1;
+    double carry = 0.0;
+    for (int i0 = 1; i0 <= dimu; i0 += 64) {
+        const int i = i0 + lane;
+        const double v = i <= dimu ? S[(size_t)i * w1 + j] : 0.0;
+        const double sc = wave_inclusive_scan(v) + carry;
+        if (i <= dimu) S[(size_t)i * w1 + j] = sc;
+        carry = __shfl(sc, 63, 64);
+    }
+}
+
+// NCC map / group lists: VB = 4 consecutive v shifts of one u per work-group.  For a fixed u the four shifts pair the SAME
+// m2 pixel (r2, c2) with m1 pixels (r1, c2 + v0 + k): each lane loads one value of each MIP per 64-column chunk and gets the
+// neighbours through wave shuffles; only the cross term  sum f*t  (exact fp32 products accumulated in fp64, fixed reduction
+// tree) is accumulated here, the window statistics come from the summed-area tables.
 constexpr int VB = 4;
-constexpr int MAP_THREADS = 1024;  // 16 waves: the map has only (2du+1)*ceil((2dv+1)/4) work-groups
-__global__ __launch_bounds__(MAP_THREADS, 4) void k_ncc_map4(const float* __restrict__ m1, const float* __restrict__ m2, int dimu, int dimv,
-                                                           int du, int dv, const float* __restrict__ ps1, const float* __restrict__ ps2,
-                                                           const int* __restrict__ groups, float* __restrict__ out) {
+constexpr int MAP_THREADS = 1024;  // 16 waves: a map has only (2du+1)*ceil((2dv+1)/4) work-groups
+__global__ __launch_bounds__(MAP_THREADS, 4) void k_ncc_sat(const float* __restrict__ m1, const float* __restrict__ m2, int dimu, int dimv,
+                                                            int du, int dv, SatView s1, SatView s2, const int* __restrict__ groups,
+                                                            float* __restrict__ out) {
     __shared__ double sh[MAP_THREADS / 64];
     // full map: group = (u, 4 consecutive v) in row-major order; list mode (neighbourhood refinement): group q =
     // {u, v0, count <= 4, first output slot}, the count shifts share u and have consecutive v and consecutive slots
@@ -197,10 +250,9 @@ __global__ __launch_bounds__(MAP_THREADS, 4) void k_ncc_map4(const float* __rest
     }
     const int nr = dimu - abs(u);
     const int a_u = max(u, 0), b_u = max(-u, 0);
-    const bool tiled = ps1 && ps2 && dimu >= TILE && dimv >= TILE;
-    double fm[VB], tm[VB];
     int lo[VB], hi[VB];  // valid m2 columns of shift k: [lo, hi)
     bool live[VB];
+    int c_lo = dimv, c_hi = 0;
 #pragma unroll
     for (int k = 0; k < VB; ++k) {
         const int v = v0 + k;
@@ -208,23 +260,13 @@ __global__ __launch_bounds__(MAP_THREADS, 4) void k_ncc_map4(const float* __rest
         live[k] = k < cnt && nr > 0 && nc > 0;
         lo[k] = max(-v, 0);
         hi[k] = lo[k] + max(nc, 0);
-        fm[k] = tm[k] = 0.0;
-        if (k < cnt && (nr <= 0 || nc <= 0)) {  // reference: empty loops, 0/0
-            if (threadIdx.x == 0) out[slot0 + k] = __int_as_float(0x7fc00000);
-        }
-        if (live[k]) {  // uniform across the work-group
-            fm[k] = block_sum<MAP_THREADS>(window_partial<MAP_THREADS>(m1, tiled ? ps1 : nullptr, dimv, a_u, max(v, 0), nr, nc), sh) / (double)(nr * nc);
-            tm[k] = block_sum<MAP_THREADS>(window_partial<MAP_THREADS>(m2, tiled ? ps2 : nullptr, dimv, b_u, lo[k], nr, nc), sh) / (double)(nr * nc);
-        }
-    }
-    int c_lo = dimv, c_hi = 0;
-#pragma unroll
-    for (int k = 0; k < VB; ++k)
+        if (k < cnt && !live[k] && threadIdx.x == 0) out[slot0 + k] = __int_as_float(0x7fc00000);  // reference: empty loops, 0/0
         if (live[k]) { c_lo = min(c_lo, lo[k]); c_hi = max(c_hi, hi[k]); }
+    }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = MAP_THREADS / 64;
-    double num[VB], f1[VB], f2[VB];
+    double cross[VB];
 #pragma unroll
-    for (int k = 0; k < VB; ++k) num[k] = f1[k] = f2[k] = 0.0;
+    for (int k = 0; k < VB; ++k) cross[k] = 0.0;
     for (int i = wave; i < nr; i += nw) {
         const float* p = m1 + (size_t)(a_u + i) * dimv;  // m1 row; column = c2 + v0 + k
         const float* q = m2 + (size_t)(b_u + i) * dimv;  // m2 row; column = c2
@@ -234,8 +276,7 @@ __global__ __launch_bounds__(MAP_THREADS, 4) void k_ncc_map4(const float* __rest
         for (int base = c_lo; base < c_hi; base += 64, c += 64, c1 += 64) {
             const int c1n = c1 + 64;
             const float fb = (c1n >= 0 && c1n < dimv) ? p[c1n] : 0.0f;  // next chunk (all lanes take part in the shuffles)
-            const float tv = c < dimv ? q[c] : 0.0f;
-            const double t = (double)tv;
+            const double t = c < dimv ? (double)q[c] : 0.0;
 #pragma unroll
             for (int k = 0; k < VB; ++k) {
                 float fk = fa;
@@ -243,22 +284,26 @@ __global__ __launch_bounds__(MAP_THREADS, 4) void k_ncc_map4(const float* __rest
                     const float from_a = __shfl(fa, (lane + k) & 63, 64), from_b = __shfl(fb, (lane + k) & 63, 64);
                     fk = (lane + k < 64) ? from_a : from_b;
                 }
-                if (live[k] && c >= lo[k] && c < hi[k]) {
-                    const double f = (double)fk;
-                    const double fp = f - fm[k], tp = t - tm[k];
-                    num[k] += f * tp;
-                    f1[k] += fp * fp;
-                    f2[k] += tp * tp;
-                }
+                if (live[k] && c >= lo[k] && c < hi[k]) cross[k] = fma((double)fk, t, cross[k]);
             }
             fa = fb;
         }
     }
 #pragma unroll
     for (int k = 0; k < VB; ++k) {
-        if (!live[k]) continue;
-        const double n_ = block_sum<MAP_THREADS>(num[k], sh), a_ = block_sum<MAP_THREADS>(f1[k], sh), b_ = block_sum<MAP_THREADS>(f2[k], sh);
-        if (threadIdx.x == 0) out[slot0 + k] = (float)(n_ / sqrt(a_ * b_));
+        if (!live[k]) continue;  // uniform
+        const double cr = block_sum<MAP_THREADS>(cross[k], sh);
+        if (threadIdx.x == 0) {
+            const int v = v0 + k, nc = dimv - abs(v);
+            double fm, sf, F1, tm, st, F2;
+            window_stats(s1, dimu, dimv, a_u, max(v, 0), nr, nc, &fm, &sf, &F1);
+            window_stats(s2, dimu, dimv, b_u, lo[k], nr, nc, &tm, &st, &F2);
+            (void)fm; (void)st;
+            const double num = cr - tm * sf;
+            // a window without variance: the reference's two-pass sums are exactly 0 there and it returns 0/0 = NaN
+            // (compute_funcs.cu:1277-1290); the table differences are exact for such data too, but the cross term is not
+            out[slot0 + k] = (F1 > 0.0 && F2 > 0.0) ? (float)(num / sqrt(F1 * F2)) : __int_as_float(0x7fc00000);
+        }
     }
 }
 
@@ -344,11 +389,48 @@ struct PlaneGeom {  // one of the three MIP planes
     int delayu, delayv; // search half ranges
     int wu, wv;         // window half extents (wRangeThr)
     size_t mip1, mip2, ps1, ps2, map;  // float offsets inside the workspace
+    size_t sat;                        // double offset of this plane's summed-area tables inside Workspace::sat
     bool tiled;
 };
 
+// layout of one plane's tables (doubles): c0a, c0b | P1 | Q1 | P2 | Q2 | TS1 | TS2
+struct SatLayout {
+    size_t tab, ts, total;
+    SatLayout(int dimu, int dimv) {
+        tab = (size_t)(dimu + 1) * (dimv + 1);
+        ts = (size_t)(dimu / TILE + 1) * (dimv / TILE + 1);
+        total = 2 + 4 * tab + 2 * ts;
+    }
+};
+
+// builds tile sums (float, reference order), global means and the summed-area tables of both MIPs of a plane
+int prepare_plane(hipStream_t s, const float* m1, const float* m2, int dimu, int dimv, float* ps1, float* ps2, double* sat, SatView* v1,
+                  SatView* v2) {
+    const SatLayout L(dimu, dimv);
+    const bool tiled = (dimu / TILE) * (dimv / TILE) > 0;
+    double *c0a = sat, *c0b = sat + 1, *P1 = sat + 2, *Q1 = P1 + L.tab, *P2 = Q1 + L.tab, *Q2 = P2 + L.tab, *T1 = Q2 + L.tab, *T2 = T1 + L.ts;
+    if (tiled) {
+        const int nt = (dimu / TILE) * (dimv / TILE);
+        hipLaunchKernelGGL(k_tile_sums, dim3((nt + 63) / 64), dim3(64), 0, s, m1, dimu, dimv, ps1);
+        hipLaunchKernelGGL(k_tile_sums, dim3((nt + 63) / 64), dim3(64), 0, s, m2, dimu, dimv, ps2);
+        MI_TRY(launch_check("k_tile_sums"));
+    }
+    hipLaunchKernelGGL(k_mip_mean, dim3(2), dim3(1024), 0, s, m1, m2, dimu, dimv, tiled ? ps1 : nullptr, tiled ? ps2 : nullptr, c0a, c0b, T1,
+                       T2);
+    MI_TRY(launch_check("k_mip_mean"));
+    hipLaunchKernelGGL(k_sat_rows, dim3(dimu + 1, 2), dim3(64), 0, s, m1, m2, dimu, dimv, c0a, c0b, P1, Q1, P2, Q2);
+    MI_TRY(launch_check("k_sat_rows"));
+    hipLaunchKernelGGL(k_sat_cols, dim3(dimv, 4), dim3(64), 0, s, dimu, dimv, P1, Q1, P2, Q2);
+    MI_TRY(launch_check("k_sat_cols"));
+    *v1 = SatView{P1, Q1, tiled ? T1 : nullptr, c0a};
+    *v2 = SatView{P2, Q2, tiled ? T2 : nullptr, c0b};
+    return MI_OK;
+}
+
 struct Workspace {
     DevBuf buf;       // floats: MIPs | tile sums | maps | miss results
+    DevBuf sat;       // doubles: per plane c0, P, Q, TS tables of both MIPs
+    SatView v1[3], v2[3];
     DevBuf list;      // ints: {u, v0, count, slot} groups of missing entries
     size_t floats = 0;
     int list_cap = 0;
@@ -356,15 +438,17 @@ struct Workspace {
     std::vector<float> host_res;
 };
 
-int ncc_groups(hipStream_t s, const float* base, const PlaneGeom& g, const int* d_groups, int n_groups, float* d_out) {
-    hipLaunchKernelGGL(k_ncc_map4, dim3(n_groups), dim3(MAP_THREADS), 0, s, base + g.mip1, base + g.mip2, g.dimu, g.dimv, g.delayu,
-                       g.delayv, g.tiled ? base + g.ps1 : nullptr, g.tiled ? base + g.ps2 : nullptr, d_groups, d_out);
-    return launch_check("k_ncc_map4(groups)");
+int ncc_groups(hipStream_t s, const float* base, const PlaneGeom& g, const SatView& v1, const SatView& v2, const int* d_groups, int n_groups,
+               float* d_out) {
+    hipLaunchKernelGGL(k_ncc_sat, dim3(n_groups), dim3(MAP_THREADS), 0, s, base + g.mip1, base + g.mip2, g.dimu, g.dimv, g.delayu,
+                       g.delayv, v1, v2, d_groups, d_out);
+    return launch_check("k_ncc_sat(groups)");
 }
 
 // compute_Neighborhood (compute_funcs.cu:1324-1592): win = (2wu+1)x(2wv+1) window around the peak,
 // re-centred up to maxIter times; entries exposed by a move are computed on the device.
-int refine_neighbourhood(hipStream_t s, const mi_ncc_params& P, const float* map, const PlaneGeom& g, const float* d_base, Workspace& ws,
+int refine_neighbourhood(hipStream_t s, const mi_ncc_params& P, const float* map, const PlaneGeom& g, int plane, const float* d_base,
+                         Workspace& ws,
                          std::vector<float>& win, int* du, int* dv, bool* failed) {
     const int H = 2 * g.wu + 1, W = 2 * g.wv + 1, Wm = 2 * g.delayv + 1;
     int ind_max = argmax_first(map, (2 * g.delayu + 1) * Wm);
@@ -395,7 +479,7 @@ int refine_neighbourhood(hipStream_t s, const mi_ncc_params& P, const float* map
         MI_REQUIRE(n_miss == H * W - (H - std::abs(deltau)) * (W - std::abs(deltav)), "CrossMIPs: incomplete NCC map in compute_Neighborhood");
         if (n_miss > 0) {
             // entries arrive in row-major window order: runs with the same u, consecutive v and consecutive slots are
-            // served four at a time by k_ncc_map4
+            // served four at a time by k_ncc_sat
             std::vector<int>& grp = ws.host_groups;
             grp.clear();
             for (int q = 0; q < n_miss;) {
@@ -413,7 +497,7 @@ int refine_neighbourhood(hipStream_t s, const mi_ncc_params& P, const float* map
             }
             float* d_res = ws.buf.as<float>() + ws.floats;  // H*W result slots reserved behind the maps
             MI_HIP(hipMemcpyAsync(ws.list.p, grp.data(), sizeof(int) * grp.size(), hipMemcpyHostToDevice, s));
-            MI_TRY(ncc_groups(s, d_base, g, ws.list.as<int>(), n_groups, d_res));
+            MI_TRY(ncc_groups(s, d_base, g, ws.v1[plane], ws.v2[plane], ws.list.as<int>(), n_groups, d_res));
             std::vector<float>& res = ws.host_res;
             res.resize((size_t)H * W);
             MI_HIP(hipMemcpyAsync(res.data(), d_res, sizeof(float) * H * W, hipMemcpyDeviceToHost, s));
@@ -435,7 +519,7 @@ struct PairPlan {
     int delayi, delayj, delayk;
     int ai0, aj0;
     PlaneGeom g[3];
-    size_t total_floats, map_floats, map_begin, res_floats;
+    size_t total_floats, map_floats, map_begin, res_floats, sat_doubles;
 };
 
 int plan_pair(int dimk, int dimi, int dimj, int nk, int ni, int nj, int delayk, int delayi, int delayj, int side, mi_ncc_params* p,
@@ -494,6 +578,12 @@ int plan_pair(int dimk, int dimi, int dimj, int nk, int ni, int nj, int delayk, 
     pl.map_floats = off - pl.map_begin;
     pl.res_floats = res;
     pl.total_floats = off;  // miss results live behind this
+    size_t soff = 0;
+    for (int m = 0; m < 3; ++m) {
+        pl.g[m].sat = soff;
+        soff += SatLayout(pl.g[m].dimu, pl.g[m].dimv).total;
+    }
+    pl.sat_doubles = soff;
     (void)mip_end;
     return MI_OK;
 }
@@ -511,18 +601,14 @@ int run_pair(hipStream_t s, const float* A, const float* B, int dimi, int dimj, 
                        base + pl.g[0].mip1, base + pl.g[1].mip1, base + pl.g[2].mip1, base + pl.g[0].mip2, base + pl.g[1].mip2,
                        base + pl.g[2].mip2);
     MI_TRY(launch_check("k_mips"));
+    if (ws.sat.bytes < sizeof(double) * pl.sat_doubles) MI_TRY(ws.sat.alloc(sizeof(double) * pl.sat_doubles));
     for (int m = 0; m < 3; ++m) {
         const PlaneGeom& g = pl.g[m];
-        if (g.tiled) {
-            const int nt = (g.dimu / TILE) * (g.dimv / TILE);
-            hipLaunchKernelGGL(k_tile_sums, dim3((nt + 63) / 64), dim3(64), 0, s, base + g.mip1, g.dimu, g.dimv, base + g.ps1);
-            hipLaunchKernelGGL(k_tile_sums, dim3((nt + 63) / 64), dim3(64), 0, s, base + g.mip2, g.dimu, g.dimv, base + g.ps2);
-            MI_TRY(launch_check("k_tile_sums"));
-        }
-        hipLaunchKernelGGL(k_ncc_map4, dim3((2 * g.delayu + 1) * ((2 * g.delayv + 1 + VB - 1) / VB)), dim3(MAP_THREADS), 0, s, base + g.mip1,
-                           base + g.mip2, g.dimu, g.dimv, g.delayu, g.delayv, g.tiled ? base + g.ps1 : nullptr,
-                           g.tiled ? base + g.ps2 : nullptr, (const int*)nullptr, base + g.map);
-        MI_TRY(launch_check("k_ncc(map)"));
+        MI_TRY(prepare_plane(s, base + g.mip1, base + g.mip2, g.dimu, g.dimv, base + g.ps1, base + g.ps2, ws.sat.as<double>() + g.sat,
+                             &ws.v1[m], &ws.v2[m]));
+        hipLaunchKernelGGL(k_ncc_sat, dim3((2 * g.delayu + 1) * ((2 * g.delayv + 1 + VB - 1) / VB)), dim3(MAP_THREADS), 0, s, base + g.mip1,
+                           base + g.mip2, g.dimu, g.dimv, g.delayu, g.delayv, ws.v1[m], ws.v2[m], (const int*)nullptr, base + g.map);
+        MI_TRY(launch_check("k_ncc_sat(map)"));
     }
     host_maps.resize(pl.map_floats);
     MI_HIP(hipMemcpyAsync(host_maps.data(), base + pl.map_begin, sizeof(float) * pl.map_floats, hipMemcpyDeviceToHost, s));
@@ -532,7 +618,7 @@ int run_pair(hipStream_t s, const float* A, const float* B, int dimi, int dimj, 
     int du[3], dv[3];
     bool failed[3] = {false, false, false};
     for (int m = 0; m < 3; ++m)
-        MI_TRY(refine_neighbourhood(s, *p, host_maps.data() + (pl.g[m].map - pl.map_begin), pl.g[m], base, ws, win[m], &du[m], &dv[m],
+        MI_TRY(refine_neighbourhood(s, *p, host_maps.data() + (pl.g[m].map - pl.map_begin), pl.g[m], m, base, ws, win[m], &du[m], &dv[m],
                                     &failed[m]));
     // compute_Alignment (compute_funcs.cu:1597-1609)
     int w1[3], w2[3];
@@ -644,16 +730,14 @@ extern "C" int mi_ncc_compute_map(int dev, void* stream, const float* mip1, cons
     MI_REQUIRE(dimu > 0 && dimv > 0 && delayu >= 0 && delayv >= 0, "compute_NCC_map: invalid extents");
     hipStream_t s = as_stream(stream);
     const int nt = (dimu / TILE) * (dimv / TILE);
-    DevBuf ps;
-    if (nt > 0) {
-        MI_TRY(ps.alloc(sizeof(float) * 2 * (size_t)nt));
-        hipLaunchKernelGGL(k_tile_sums, dim3((nt + 63) / 64), dim3(64), 0, s, mip1, dimu, dimv, ps.as<float>());
-        hipLaunchKernelGGL(k_tile_sums, dim3((nt + 63) / 64), dim3(64), 0, s, mip2, dimu, dimv, ps.as<float>() + nt);
-        MI_TRY(launch_check("k_tile_sums"));
-    }
-    hipLaunchKernelGGL(k_ncc_map4, dim3((2 * delayu + 1) * ((2 * delayv + 1 + VB - 1) / VB)), dim3(MAP_THREADS), 0, s, mip1, mip2, dimu, dimv,
-                       delayu, delayv, nt > 0 ? ps.as<float>() : nullptr, nt > 0 ? ps.as<float>() + nt : nullptr, (const int*)nullptr, map);
-    MI_TRY(launch_check("k_ncc(map)"));
-    MI_HIP(hipStreamSynchronize(s));  // ps dies at scope exit
+    DevBuf ps, sat;
+    MI_TRY(ps.alloc(sizeof(float) * 2 * (size_t)(nt > 0 ? nt : 1)));
+    MI_TRY(sat.alloc(sizeof(double) * SatLayout(dimu, dimv).total));
+    SatView v1, v2;
+    MI_TRY(prepare_plane(s, mip1, mip2, dimu, dimv, ps.as<float>(), ps.as<float>() + (nt > 0 ? nt : 0), sat.as<double>(), &v1, &v2));
+    hipLaunchKernelGGL(k_ncc_sat, dim3((2 * delayu + 1) * ((2 * delayv + 1 + VB - 1) / VB)), dim3(MAP_THREADS), 0, s, mip1, mip2, dimu, dimv,
+                       delayu, delayv, v1, v2, (const int*)nullptr, map);
+    MI_TRY(launch_check("k_ncc_sat(map)"));
+    MI_HIP(hipStreamSynchronize(s));  // ps / sat die at scope exit
     return MI_OK;
 }
