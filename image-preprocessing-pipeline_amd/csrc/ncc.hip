@@ -427,6 +427,27 @@ int prepare_plane(hipStream_t s, const float* m1, const float* m2, int dimu, int
     return MI_OK;
 }
 
+// pinned host staging: pageable destinations make every small D2H / H2D a ~0.14 ms staged blit
+struct PinnedBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    PinnedBuf() = default;
+    PinnedBuf(const PinnedBuf&) = delete;
+    PinnedBuf& operator=(const PinnedBuf&) = delete;
+    ~PinnedBuf() { if (p) (void)hipHostFree(p); }
+    int reserve(size_t n) {
+        if (n <= bytes) return MI_OK;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        bytes = 0;
+        hipError_t e = hipHostMalloc(&p, n, hipHostMallocDefault);
+        if (e != hipSuccess) { p = nullptr; return fail(MI_ERR_NOMEM, "hipHostMalloc(%zu) failed: %s", n, hipGetErrorString(e)); }
+        bytes = n;
+        return MI_OK;
+    }
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
 struct Workspace {
     DevBuf buf;       // floats: MIPs | tile sums | maps | miss results
     DevBuf sat;       // doubles: per plane c0, P, Q, TS tables of both MIPs
@@ -435,7 +456,7 @@ struct Workspace {
     size_t floats = 0;
     int list_cap = 0;
     std::vector<int> host_groups;
-    std::vector<float> host_res;
+    PinnedBuf pin_groups, pin_res, pin_maps;
 };
 
 int ncc_groups(hipStream_t s, const float* base, const PlaneGeom& g, const SatView& v1, const SatView& v2, const int* d_groups, int n_groups,
@@ -496,11 +517,13 @@ int refine_neighbourhood(hipStream_t s, const mi_ncc_params& P, const float* map
                 ws.list_cap = n_groups;
             }
             float* d_res = ws.buf.as<float>() + ws.floats;  // H*W result slots reserved behind the maps
-            MI_HIP(hipMemcpyAsync(ws.list.p, grp.data(), sizeof(int) * grp.size(), hipMemcpyHostToDevice, s));
+            MI_TRY(ws.pin_groups.reserve(sizeof(int) * grp.size()));
+            MI_TRY(ws.pin_res.reserve(sizeof(float) * (size_t)H * W));
+            std::memcpy(ws.pin_groups.p, grp.data(), sizeof(int) * grp.size());
+            MI_HIP(hipMemcpyAsync(ws.list.p, ws.pin_groups.p, sizeof(int) * grp.size(), hipMemcpyHostToDevice, s));
             MI_TRY(ncc_groups(s, d_base, g, ws.v1[plane], ws.v2[plane], ws.list.as<int>(), n_groups, d_res));
-            std::vector<float>& res = ws.host_res;
-            res.resize((size_t)H * W);
-            MI_HIP(hipMemcpyAsync(res.data(), d_res, sizeof(float) * H * W, hipMemcpyDeviceToHost, s));
+            const float* res = ws.pin_res.as<float>();
+            MI_HIP(hipMemcpyAsync(ws.pin_res.p, d_res, sizeof(float) * H * W, hipMemcpyDeviceToHost, s));
             MI_HIP(hipStreamSynchronize(s));
             for (int q = 0; q < n_miss; ++q) win[miss[3 * q + 2]] = res[miss[3 * q + 2]];
         }
@@ -611,8 +634,10 @@ int run_pair(hipStream_t s, const float* A, const float* B, int dimi, int dimj, 
         MI_TRY(launch_check("k_ncc_sat(map)"));
     }
     host_maps.resize(pl.map_floats);
-    MI_HIP(hipMemcpyAsync(host_maps.data(), base + pl.map_begin, sizeof(float) * pl.map_floats, hipMemcpyDeviceToHost, s));
+    MI_TRY(ws.pin_maps.reserve(sizeof(float) * pl.map_floats));
+    MI_HIP(hipMemcpyAsync(ws.pin_maps.p, base + pl.map_begin, sizeof(float) * pl.map_floats, hipMemcpyDeviceToHost, s));
     MI_HIP(hipStreamSynchronize(s));
+    std::memcpy(host_maps.data(), ws.pin_maps.p, sizeof(float) * pl.map_floats);
 
     std::vector<float> win[3];
     int du[3], dv[3];

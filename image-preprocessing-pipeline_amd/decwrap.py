@@ -156,7 +156,8 @@ def main(argv=None):
         bl = L.load_block(vol, p1, p2, pad)
         fshape = None
         if args.use_fft:
-            fshape = L.next_fast_len(bl.shape[::-1])
+            smooth, native = L.next_fast_len(bl.shape[::-1]), L.native_fft_shape(bl.shape[::-1])
+            fshape = native if np.prod(native) <= 1.3 * np.prod(smooth) else smooth
         blk = L.Block(block.x, block.y, block.z, block.nx, block.ny, block.nz, *pad, fft_shape=fshape)
         t, lb, ub = L.process_block(bl, blk, psf_struct, args.numit, args.lambda_damping, args.stop_criterion, filt,
                                     args.clipval, g)

@@ -79,6 +79,13 @@ def next_fast_len(n_vec):
     return [D.next_fast_len(int(n)) for n in n_vec]
 
 
+def native_fft_shape(shape_xyz):
+    """FFT shape >= ``shape_xyz`` that the hand-written FFT pipeline takes without the rocFFT fallback (powers of two
+    on x and z, 2^a * {1,3,9} on y: ``mi_fft_good_size``).  Like ``next_fast_len`` it only enlarges the zero padding of
+    deconFFT (decon.m:144), which the block's own pads absorb."""
+    return [int(capi.lib().mi_fft_good_size(int(n), axis)) for axis, n in enumerate(shape_xyz)]
+
+
 def autosplit(stack_xyz, psf_size_xyz, filt: Filter, block_size_max: int, numit: int) -> Block:
     """Largest block (core + 2*pad, 7-smooth for the FFT path) with fewer than ``block_size_max`` elements.
 
@@ -99,7 +106,9 @@ def autosplit(stack_xyz, psf_size_xyz, filt: Filter, block_size_max: int, numit:
             core = [min(xy, sx), min(xy, sy), z]
             shape = [c + 2 * p for c, p in zip(core, pad)]
             if filt.use_fft:
-                shape = next_fast_len(shape)
+                smooth, native = next_fast_len(shape), native_fft_shape(shape)
+                # prefer the native-pipeline shape unless it inflates the block by more than 30 % over the 7-smooth one
+                shape = native if np.prod(native) <= 1.3 * np.prod(smooth) else smooth
             if shape[0] * shape[1] * shape[2] < block_size_max:
                 best = (core, shape)
                 break

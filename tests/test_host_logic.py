@@ -33,7 +33,8 @@ def test_pad_rules_and_autosplit():
     f = L.Filter(use_fft=True)
     blk = L.autosplit((300, 300, 100), (9, 9, 19), f, block_size_max=200 ** 3, numit=6)
     shape = [c + 2 * p for c, p in zip((blk.x, blk.y, blk.z), (blk.x_pad, blk.y_pad, blk.z_pad))]
-    assert blk.fft_shape == tuple(R.next_fast_len(s) for s in shape)
+    smooth = tuple(R.next_fast_len(s) for s in shape)
+    assert all(f >= s for f, s in zip(blk.fft_shape, shape)) and np.prod(blk.fft_shape) <= 1.3 * np.prod(smooth)
     assert np.prod(blk.fft_shape) < 200 ** 3 and (blk.x_pad, blk.y_pad, blk.z_pad) == (13, 13, 25)
     assert blk.nx * blk.x >= 300 and blk.nz * blk.z >= 100 and len(blk.p1) == blk.nx * blk.ny * blk.nz
     with pytest.raises(RuntimeError, match="No block shape fits"):
