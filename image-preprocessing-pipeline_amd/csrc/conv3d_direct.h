@@ -27,6 +27,8 @@ int conv_kernel_offset(int k, int boundary);
 // kernel into the correlation taps the engine consumes (optionally sum-normalised)
 int direct_prepare_psf(hipStream_t s, const float* ker, int kx, int ky, int kz, bool normalise, bool flip, DevBuf& kf,
                        int* kxp_out);
+// device copy of ker / sum(ker) (n taps)
+int normalised_psf(hipStream_t s, const float* ker, int n, DevBuf& out);
 // offs (optional) = window start offsets {cx, cy, cz}; default conv_kernel_offset(k, boundary)
 // bnd3 (optional) = per-axis boundary rules {x, y, z}; default `boundary` on every axis
 int direct_conv_launch(hipStream_t s, const float* img, const float* kf, float* out, int nx, int ny, int nz, int kx, int ky,

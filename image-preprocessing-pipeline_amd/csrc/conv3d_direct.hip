@@ -201,6 +201,20 @@ __global__ __launch_bounds__(TX* TY) void k_conv3d_direct(const float* __restric
 
 }  // namespace
 
+// out[i] = ker[i] / sum(ker)  (edgetaper_3d.m:14), for engines that take the PSF as is
+__global__ void k_normalise_psf(const float* __restrict__ ker, const float* __restrict__ sum, float* __restrict__ out, int n) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = ker[i] / *sum;
+}
+
+int normalised_psf(hipStream_t s, const float* ker, int n, DevBuf& out) {
+    MI_TRY(out.alloc(sizeof(float) * ((size_t)n + 4)));
+    float* sum = out.as<float>() + n;
+    hipLaunchKernelGGL(k_sum_small, dim3(1), dim3(256), 0, s, ker, n, sum);
+    MI_TRY(launch_check("k_sum_small"));
+    hipLaunchKernelGGL(k_normalise_psf, dim3(cdiv((size_t)n, 256)), dim3(256), 0, s, ker, sum, out.as<float>(), n);
+    return launch_check("k_normalise_psf");
+}
+
 int conv_kernel_offset(int k, int boundary) {
     // conv3d_gpu centres at k/2 (conv3d_gpu.cu:77); convn 'same' keeps full[floor(k/2) : ...], i.e. the
     // window starts k-1-floor(k/2) before the output sample.  Identical for odd k.
