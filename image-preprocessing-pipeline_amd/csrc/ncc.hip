@@ -611,8 +611,8 @@ int plan_pair(int dimk, int dimi, int dimj, int nk, int ni, int nj, int delayk, 
     return MI_OK;
 }
 
-int run_pair(hipStream_t s, const float* A, const float* B, int dimi, int dimj, int ni, int nj, int side, mi_ncc_params* p,
-             const PairPlan& pl, Workspace& ws, mi_ncc_descr* out, std::vector<float>& host_maps) {
+// stage 1 of a pair: everything up to the D2H copy of the three NCC maps is enqueued on `s`, nothing is waited for
+int pair_enqueue(hipStream_t s, const float* A, const float* B, int dimi, int dimj, const PairPlan& pl, Workspace& ws) {
     const size_t need = pl.total_floats + pl.res_floats;
     if (ws.buf.bytes < sizeof(float) * need) MI_TRY(ws.buf.alloc(sizeof(float) * need));
     ws.floats = pl.total_floats;
@@ -633,17 +633,23 @@ int run_pair(hipStream_t s, const float* A, const float* B, int dimi, int dimj, 
                            base + g.mip2, g.dimu, g.dimv, g.delayu, g.delayv, ws.v1[m], ws.v2[m], (const int*)nullptr, base + g.map);
         MI_TRY(launch_check("k_ncc_sat(map)"));
     }
-    host_maps.resize(pl.map_floats);
     MI_TRY(ws.pin_maps.reserve(sizeof(float) * pl.map_floats));
     MI_HIP(hipMemcpyAsync(ws.pin_maps.p, base + pl.map_begin, sizeof(float) * pl.map_floats, hipMemcpyDeviceToHost, s));
+    return MI_OK;
+}
+
+// stage 2: wait for the maps, then the host-side logic (argmax, neighbourhood refinement with its small device
+// launches on the same stream, widths, alignment)
+int pair_finish(hipStream_t s, int ni, int nj, int side, mi_ncc_params* p, const PairPlan& pl, Workspace& ws, mi_ncc_descr* out) {
     MI_HIP(hipStreamSynchronize(s));
-    std::memcpy(host_maps.data(), ws.pin_maps.p, sizeof(float) * pl.map_floats);
+    float* base = ws.buf.as<float>();
+    const float* host_maps = ws.pin_maps.as<float>();
 
     std::vector<float> win[3];
     int du[3], dv[3];
     bool failed[3] = {false, false, false};
     for (int m = 0; m < 3; ++m)
-        MI_TRY(refine_neighbourhood(s, *p, host_maps.data() + (pl.g[m].map - pl.map_begin), pl.g[m], m, base, ws, win[m], &du[m], &dv[m],
+        MI_TRY(refine_neighbourhood(s, *p, host_maps + (pl.g[m].map - pl.map_begin), pl.g[m], m, base, ws, win[m], &du[m], &dv[m],
                                     &failed[m]));
     // compute_Alignment (compute_funcs.cu:1597-1609)
     int w1[3], w2[3];
@@ -690,8 +696,8 @@ extern "C" int mi_ncc_mips(int dev, void* stream, const float* A, const float* B
     PairPlan pl;
     MI_TRY(plan_pair(dimk, dimi, dimj, nk, ni, nj, delayk, delayi, delayj, side, p, pl));
     Workspace ws;
-    std::vector<float> maps;
-    return run_pair(as_stream(stream), A, B, dimi, dimj, ni, nj, side, p, pl, ws, out, maps);
+    MI_TRY(pair_enqueue(as_stream(stream), A, B, dimi, dimj, pl, ws));
+    return pair_finish(as_stream(stream), ni, nj, side, p, pl, ws, out);
 }
 
 extern "C" int mi_ncc_mips_host(int dev, void* stream, const float* A, const float* B, int dimk, int dimi, int dimj, int nk, int ni,
@@ -719,16 +725,37 @@ extern "C" int mi_ncc_mips_batch(int dev, void* stream, int n_pairs, const float
     MI_REQUIRE(n_pairs >= 0, "mi_ncc_mips_batch: negative pair count");
     if (n_pairs == 0) return MI_OK;
     MI_REQUIRE(tiles && a_idx && b_idx && ni && nj && side && params && out, "mi_ncc_mips_batch: null pointer");
-    Workspace ws;  // shared by all pairs: one allocation for the whole batch
-    std::vector<float> maps;
-    for (int q = 0; q < n_pairs; ++q) {
-        PairPlan pl;
-        MI_TRY(plan_pair(dimk, dimi, dimj, 0, ni[q], nj[q], delayk, delayi, delayj, side[q], &params[q], pl));
-        MI_REQUIRE(tiles[a_idx[q]] && tiles[b_idx[q]], "mi_ncc_mips_batch: null tile for pair %d", q);
-        MI_TRY(run_pair(as_stream(stream), tiles[a_idx[q]], tiles[b_idx[q]], dimi, dimj, ni[q], nj[q], side[q], &params[q], pl, ws, &out[q],
-                        maps));
+    // Two pairs in flight on two internal streams: while the host refines pair q (a few syncs and small launches), the
+    // MIP / table / map kernels of pair q + 1 run.  Both streams start after, and are joined back into, `stream`.
+    hipStream_t user = as_stream(stream);
+    struct Slot { Workspace ws; PairPlan pl; hipStream_t s = nullptr; int q = -1; } slot[2];
+    hipEvent_t ev = nullptr;
+    int rc = MI_OK;
+    auto cleanup = [&]() {
+        for (auto& sl : slot)
+            if (sl.s) { (void)hipStreamSynchronize(sl.s); (void)hipStreamDestroy(sl.s); sl.s = nullptr; }
+        if (ev) (void)hipEventDestroy(ev);
+    };
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, user) != hipSuccess)
+        rc = fail(MI_ERR_HIP, "mi_ncc_mips_batch: event setup failed");
+    for (auto& sl : slot)
+        if (rc == MI_OK && (hipStreamCreateWithFlags(&sl.s, hipStreamNonBlocking) != hipSuccess || hipStreamWaitEvent(sl.s, ev, 0) != hipSuccess))
+            rc = fail(MI_ERR_HIP, "mi_ncc_mips_batch: stream setup failed");
+    for (int q = 0; q <= n_pairs && rc == MI_OK; ++q) {
+        if (q < n_pairs) {
+            Slot& sl = slot[q & 1];
+            if (!tiles[a_idx[q]] || !tiles[b_idx[q]]) { rc = fail(MI_ERR_INVALID, "mi_ncc_mips_batch: null tile for pair %d", q); break; }
+            rc = plan_pair(dimk, dimi, dimj, 0, ni[q], nj[q], delayk, delayi, delayj, side[q], &params[q], sl.pl);
+            if (rc == MI_OK) rc = pair_enqueue(sl.s, tiles[a_idx[q]], tiles[b_idx[q]], dimi, dimj, sl.pl, sl.ws);
+            sl.q = q;
+        }
+        if (q >= 1 && rc == MI_OK) {
+            Slot& pr = slot[(q - 1) & 1];
+            rc = pair_finish(pr.s, ni[q - 1], nj[q - 1], side[q - 1], &params[q - 1], pr.pl, pr.ws, &out[q - 1]);
+        }
     }
-    return MI_OK;
+    cleanup();
+    return rc;
 }
 
 extern "C" int mi_ncc_compute_mips(int dev, void* stream, const float* A, const float* B, int dimk, int dimi, int dimj, int ni, int nj,
