@@ -1,10 +1,11 @@
 // In-place separable 3-D Gaussian (replaces gauss3d_gpu: LsDeconvolveMultiGPU/gauss3d_gpu.cu:81-204,209-311).
 //
 // Same arithmetic as the reference: taps exp(-0.5 i^2 / sigma^2) built on the host (double exp, float
-// store, double sum), three 1-D passes X, Y, Z with the index clamped to the volume, fp32 accumulate
-// in tap order.  Differences in execution: the taps travel in the kernel argument block (wave-uniform
-// scalar loads, no __constant__ upload + device sync per axis), and each lane produces 4 consecutive
-// x outputs (16-B stores); for the Y/Z passes the 4 outputs share one float4 load per tap.
+// store, double sum), filtered X, then Y, then Z with the index clamped to the volume, fp32 accumulate
+// in tap order, every 1-D result rounded to fp32.  Execution: TWO volume passes instead of three plus a
+// copy (the reference moves 32 B/voxel, this 16 B/voxel): x and y are fused in a kernel whose waves walk
+// along y with an LDS ring of x-filtered rows; z is a second walk with a per-lane ring; the result
+// lands back in `vol`, so no device-to-device copy is needed.  Taps travel in the kernel argument block.
 #include <cmath>
 
 #include "mi_internal.h"
@@ -32,57 +33,78 @@ void make_taps(float sigma, int ksize, Taps& t) {
     t.n = ksize;
 }
 
-// AXIS 0: along x (scalar path, neighbours of the 4 outputs overlap); AXIS 1/2: along y/z (float4 per tap)
-template <int AXIS>
-__global__ __launch_bounds__(256) void k_gauss_axis(const float* __restrict__ src, float* __restrict__ dst, int nx, int ny, int nz,
-                                                     Taps t) {
-    const int nxq = (nx + 3) / 4;
-    const size_t total = (size_t)nxq * ny * nz;
-    const int r = t.n / 2;
-    const bool vec_ok = (nx % 4) == 0;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int xq = (int)(i % nxq);
-        const size_t rest = i / nxq;
-        const int y = (int)(rest % ny), z = (int)(rest / ny);
-        const int x = xq * 4;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        if (AXIS == 0) {
-            const float* row = src + ((size_t)z * ny + y) * nx;
-            for (int s = 0; s < t.n; ++s) {
-                const float w = t.w[s];
-                const int o = s - r;
-                a0 = fmaf(row[min(max(x + o, 0), nx - 1)], w, a0);
-                a1 = fmaf(row[min(max(x + 1 + o, 0), nx - 1)], w, a1);
-                a2 = fmaf(row[min(max(x + 2 + o, 0), nx - 1)], w, a2);
-                a3 = fmaf(row[min(max(x + 3 + o, 0), nx - 1)], w, a3);
+// Pass 1 (x and y fused): a wave owns 64 consecutive x of one z-plane and walks along y.  Per step it stages one
+// clamped row segment (64 + 2 rx samples) in LDS, filters it along x (the result is rounded to fp32 exactly like the
+// reference's separate x pass), pushes it into a per-lane ring of the last ky x-filtered rows and emits one y-filtered
+// row.  Every input row is read once and every output row written once (plus ry halo rows per y-chunk).
+constexpr int GXY_WAVES = 4;
+constexpr int GXY_YCHUNK = 256;
+
+__global__ __launch_bounds__(64 * GXY_WAVES) void k_gauss_xy(const float* __restrict__ src, float* __restrict__ dst, int nx, int ny, int nz,
+                                                              Taps tx, Taps ty) {
+    extern __shared__ float lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int rx = tx.n / 2, ry = ty.n / 2;
+    const int seg = 64 + 2 * rx;
+    float* rb = lds + wave * (seg + ty.n * 64);  // row buffer, then ring[ty.n][64]
+    float* ring = rb + seg;
+    const int x0 = blockIdx.x * 64;
+    const int ya = blockIdx.y * GXY_YCHUNK, yb = min(ya + GXY_YCHUNK, ny);
+    const int z = blockIdx.z * GXY_WAVES + wave;
+    const bool zlive = z < nz;
+    const float* plane = src + (size_t)(zlive ? z : 0) * ny * nx;
+    float* oplane = dst + (size_t)(zlive ? z : 0) * ny * nx;
+    int slot = 0;  // ring slot of walk position p
+    for (int p = ya - ry; p < yb + ry; ++p) {
+        const float* row = plane + (size_t)min(max(p, 0), ny - 1) * nx;
+        // stage the clamped row segment: sample i is x = x0 - rx + i
+        rb[lane] = row[min(max(x0 - rx + lane, 0), nx - 1)];
+        if (lane + 64 < seg) rb[lane + 64] = row[min(max(x0 - rx + lane + 64, 0), nx - 1)];
+        __syncthreads();
+        float xf = 0.0f;
+        for (int s = 0; s < tx.n; ++s) xf = fmaf(rb[lane + s], tx.w[s], xf);
+        ring[slot * 64 + lane] = xf;  // private column of this lane: no barrier needed for the ring
+        const int yo = p - ry;        // output row whose window [yo - ry, yo + ry] is now complete
+        if (yo >= ya) {
+            float acc = 0.0f;
+            int rs = slot + 1;  // slot of walk position yo - ry = p - 2 ry  (ty.n = 2 ry + 1 slots back, wrapping)
+            if (rs >= ty.n) rs -= ty.n;
+            for (int s = 0; s < ty.n; ++s) {
+                acc = fmaf(ring[rs * 64 + lane], ty.w[s], acc);
+                if (++rs >= ty.n) rs = 0;
             }
-        } else {
-            for (int s = 0; s < t.n; ++s) {
-                const float w = t.w[s];
-                const int o = s - r;
-                const int yy = AXIS == 1 ? min(max(y + o, 0), ny - 1) : y;
-                const int zz = AXIS == 2 ? min(max(z + o, 0), nz - 1) : z;
-                const float* p = src + ((size_t)zz * ny + yy) * nx + x;
-                if (vec_ok) {
-                    const float4 v = *reinterpret_cast<const float4*>(p);
-                    a0 = fmaf(v.x, w, a0); a1 = fmaf(v.y, w, a1); a2 = fmaf(v.z, w, a2); a3 = fmaf(v.w, w, a3);
-                } else {
-                    a0 = fmaf(p[0], w, a0);
-                    if (x + 1 < nx) a1 = fmaf(p[1], w, a1);
-                    if (x + 2 < nx) a2 = fmaf(p[2], w, a2);
-                    if (x + 3 < nx) a3 = fmaf(p[3], w, a3);
-                }
+            if (zlive && x0 + lane < nx) oplane[(size_t)yo * nx + x0 + lane] = acc;
+        }
+        if (++slot >= ty.n) slot = 0;
+        __syncthreads();  // the row buffer is rewritten in the next step
+    }
+}
+
+// Pass 2 (z): a lane owns one (x, y) column and walks along z with a private LDS ring of the last kz samples.
+constexpr int GZ_ZCHUNK = 512;
+__global__ __launch_bounds__(256) void k_gauss_z(const float* __restrict__ src, float* __restrict__ dst, int nx, int ny, int nz, Taps tz) {
+    extern __shared__ float lds[];
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= nx) return;
+    const int rz = tz.n / 2;
+    const int za = blockIdx.z * GZ_ZCHUNK, zb = min(za + GZ_ZCHUNK, nz);
+    const size_t col = (size_t)y * nx + x, pstride = (size_t)ny * nx;
+    float* ring = lds + threadIdx.x;  // ring[slot * 256]
+    int slot = 0;
+    for (int p = za - rz; p < zb + rz; ++p) {
+        ring[slot * 256] = src[col + (size_t)min(max(p, 0), nz - 1) * pstride];
+        const int zo = p - rz;
+        if (zo >= za) {
+            float acc = 0.0f;
+            int rs = slot + 1;
+            if (rs >= tz.n) rs -= tz.n;
+            for (int s = 0; s < tz.n; ++s) {
+                acc = fmaf(ring[rs * 256], tz.w[s], acc);
+                if (++rs >= tz.n) rs = 0;
             }
+            dst[col + (size_t)zo * pstride] = acc;
         }
-        float* q = dst + ((size_t)z * ny + y) * nx + x;
-        if (vec_ok) {
-            *reinterpret_cast<float4*>(q) = make_float4(a0, a1, a2, a3);
-        } else {
-            q[0] = a0;
-            if (x + 1 < nx) q[1] = a1;
-            if (x + 2 < nx) q[2] = a2;
-            if (x + 3 < nx) q[3] = a3;
-        }
+        if (++slot >= tz.n) slot = 0;
     }
 }
 
@@ -98,22 +120,18 @@ int gauss3d_async(hipStream_t s, float* vol, float* work, int nx, int ny, int nz
         k[a] = ksize ? ksize[a] : 2 * (int)std::ceil(3.0 * (double)sigma[a]) + 1;  // gauss3d_gpu.cu:244-261
         MI_REQUIRE(k[a] >= 1 && k[a] <= kMaxTaps, "gauss3d_gpu: Kernel size exceeds MAX_KERNEL_SIZE (%d)", kMaxTaps);
     }
-    const size_t items = (size_t)((nx + 3) / 4) * ny * nz;
-    size_t blocks = (items + 255) / 256;
-    if (blocks > 256 * 32) blocks = 256 * 32;
-    float* src = vol;
-    float* dst = work;
-    for (int axis = 0; axis < 3; ++axis) {
-        Taps t;
-        make_taps(sigma[axis], k[axis], t);
-        if (axis == 0) hipLaunchKernelGGL(k_gauss_axis<0>, dim3((unsigned)blocks), dim3(256), 0, s, src, dst, nx, ny, nz, t);
-        if (axis == 1) hipLaunchKernelGGL(k_gauss_axis<1>, dim3((unsigned)blocks), dim3(256), 0, s, src, dst, nx, ny, nz, t);
-        if (axis == 2) hipLaunchKernelGGL(k_gauss_axis<2>, dim3((unsigned)blocks), dim3(256), 0, s, src, dst, nx, ny, nz, t);
-        MI_TRY(launch_check("k_gauss_axis"));
-        float* tmp = src; src = dst; dst = tmp;
-    }
-    // three passes leave the result in `work`; the reference copies it back too (gauss3d_gpu.cu:194-200)
-    if (src != vol) MI_HIP(hipMemcpyAsync(vol, src, sizeof(float) * (size_t)nx * ny * nz, hipMemcpyDeviceToDevice, s));
+    Taps tx, ty, tz;
+    make_taps(sigma[0], k[0], tx);
+    make_taps(sigma[1], k[1], ty);
+    make_taps(sigma[2], k[2], tz);
+    // pass 1: vol -> work (x then y, each rounded to fp32 like the reference's separate passes); pass 2: work -> vol (z)
+    const size_t lds_xy = sizeof(float) * GXY_WAVES * (size_t)(64 + 2 * (k[0] / 2) + k[1] * 64);
+    hipLaunchKernelGGL(k_gauss_xy, dim3((nx + 63) / 64, (ny + GXY_YCHUNK - 1) / GXY_YCHUNK, (nz + GXY_WAVES - 1) / GXY_WAVES),
+                       dim3(64 * GXY_WAVES), lds_xy, s, vol, work, nx, ny, nz, tx, ty);
+    MI_TRY(launch_check("k_gauss_xy"));
+    const size_t lds_z = sizeof(float) * 256 * (size_t)k[2];
+    hipLaunchKernelGGL(k_gauss_z, dim3((nx + 255) / 256, ny, (nz + GZ_ZCHUNK - 1) / GZ_ZCHUNK), dim3(256), lds_z, s, work, vol, nx, ny, nz, tz);
+    MI_TRY(launch_check("k_gauss_z"));
     return MI_OK;
 }
 
