@@ -5,34 +5,43 @@
 namespace mi {
 
 struct NativeDims {
-    int lhx, lz;      // log2 of Hx = X/2 and of Z
-    int ly2, r3;      // Y = r3 * 2^ly2, r3 in {1, 3, 9}
-    int ny, nz;
+    // every axis length is r3 * 2^l2 with r3 in {1, 3, 9}: x (Hx = X/2 complex points), y, z
+    int lhx2, r3x;
+    int ly2, r3;
+    int lz2, r3z;
+    int hx, ny, nz;
     int ty, tc, tl;   // rows per x tile, columns per y tile, lines per z tile (A and B tiles each)
     int dbg;          // timing experiments only: knocks out phases of the z pass (results are then wrong)
 };
 
 struct NativeFft {
     NativeDims dims{};
-    DevBuf S, T, G, tw;
+    DevBuf S, T, G, G_adj, tw;
+    bool have_adj = false;  // adjoint = second OTF (G_adj) instead of conj(G)
     const float2* tw_x = nullptr;
     const float2* tw_y = nullptr;
     const float2* tw_z = nullptr;
     size_t n_cplx = 0;
 
     static bool supported(const int F[3]);
-    // smallest supported y extent >= n (2^a, 3*2^a or 9*2^a)
-    static int good_size_y(int n);
-    // otf_half_spectrum: R2C layout [Z][Y][X/2+1]; it is multiplied by `scale` while being repacked
-    int init(hipStream_t s, const int F[3], const float2* otf_half_spectrum, float scale);
+    // smallest supported extent >= n of axis 0 (x), 1 (y), 2 (z); 0 when there is none
+    static int good_size(int n, int axis);
+    // buffers, tile sizes, twiddles; the OTF(s) are then built with build_otf
+    int init(hipStream_t s, const int F[3], bool explicit_adjoint);
+    // placed: the kernel on the circular grid (real, shape F; may alias scratch()); G (or G_adj) <- scale * FFT(placed)
+    int build_otf(hipStream_t s, const float* placed, bool adjoint_slot, float scale);
+    float* scratch() { return T.as<float>(); }  // F floats, free between convolutions
     int conv(hipStream_t s, const float* in, bool conj_otf, float* out, int epi_kind, const ConvEpilogue& epi);
+    // `conj_otf` selects the adjoint: conj(OTF), or the explicit adjoint OTF when one was given
     // n fused RL iterations on bl in place (lambda = 0, no regularisation step in between)
     int iterate(hipStream_t s, float* bl, int n_iters);
     int time_pass(hipStream_t s, int which, const float* bl, int reps, float* avg_ms);
     int x_forward(hipStream_t s, const float* in);
     int middle(hipStream_t s, bool conj_otf);
+    int y_pass(hipStream_t s, bool inverse);
+    int z_conv(hipStream_t s, bool conj_otf);
     int x_inverse(hipStream_t s, float* out, int epi_kind, const ConvEpilogue& epi, bool fuse_forward);
-    size_t device_bytes() const { return S.bytes + T.bytes + G.bytes + tw.bytes; }
+    size_t device_bytes() const { return S.bytes + T.bytes + G.bytes + G_adj.bytes + tw.bytes; }
 };
 
 }  // namespace mi

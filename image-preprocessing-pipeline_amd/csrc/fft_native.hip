@@ -80,20 +80,22 @@ __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(
 __device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
 __device__ __forceinline__ unsigned brev_n(unsigned v, int bits) { return bits == 0 ? 0u : (__brev(v) >> (32 - bits)); }
 
-// y axis of length M = r3 * 2^ly2 (r3 in {1, 3, 9}): one radix-r3 DIF stage followed by r3 power-of-two sub-transforms.
-// Position p = k1 * 2^ly2 + p' holds frequency k1 + r3 * brev(p').
-__device__ __forceinline__ int y_pos2freq(int p, const NativeDims& d) {
-    const int k1 = p >> d.ly2, pp = p & ((1 << d.ly2) - 1);
-    return k1 + d.r3 * (int)brev_n((unsigned)pp, d.ly2);
+// An axis of length N = r3 * 2^l2 (r3 in {1, 3, 9}) is transformed by one radix-r3 DIF stage followed by r3 power-of-two
+// sub-transforms; position p = k1 * 2^l2 + p' then holds frequency k1 + r3 * brev(p').
+__device__ __forceinline__ int pos2freq(int p, int l2, int r3) {
+    const int k1 = p >> l2, pp = p & ((1 << l2) - 1);
+    return k1 + r3 * (int)brev_n((unsigned)pp, l2);
 }
-__device__ __forceinline__ int y_freq2pos(int k, const NativeDims& d) {
-    const int k2 = k / d.r3, k1 = k - k2 * d.r3;
-    return (k1 << d.ly2) + (int)brev_n((unsigned)k2, d.ly2);
+__device__ __forceinline__ int freq2pos(int k, int l2, int r3) {
+    const int k2 = k / r3, k1 = k - k2 * r3;
+    return (k1 << l2) + (int)brev_n((unsigned)k2, l2);
 }
-__device__ __forceinline__ int y_mirror_pos(int p, const NativeDims& d) {
-    const int k = y_pos2freq(p, d);
-    return y_freq2pos(k == 0 ? 0 : d.ny - k, d);
+__device__ __forceinline__ int mirror_pos(int p, int n, int l2, int r3) {
+    const int k = pos2freq(p, l2, r3);
+    return freq2pos(k == 0 ? 0 : n - k, l2, r3);
 }
+__device__ __forceinline__ int y_pos2freq(int p, const NativeDims& d) { return pos2freq(p, d.ly2, d.r3); }
+__device__ __forceinline__ int y_mirror_pos(int p, const NativeDims& d) { return mirror_pos(p, d.ny, d.ly2, d.r3); }
 
 // exp(-2 pi i m / 2^(bpos+1)), m < 2^bpos, bpos <= 3: the part of a butterfly twiddle that depends only on the
 // register index, as compile-time constants (cos/sin of multiples of 2 pi / 16)
@@ -271,11 +273,11 @@ __device__ __forceinline__ void radix3_stage(float2* tile, int cols, int pitch, 
 
 // ---------------------------------------------------------------------------------------------- P1: x forward
 // grid: (Y / TY) * Z tiles; tile = TY consecutive rows of one z-plane
-template <int LHX>
+template <int LHX2, int R3>
 __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_x_forward(const float* __restrict__ in, float2* __restrict__ S, NativeDims d,
                                                          const float2* __restrict__ tw) {
     extern __shared__ __attribute__((aligned(16))) float2 tile[];
-    constexpr int Hx = 1 << LHX;
+    constexpr int Hx = R3 << LHX2;
     const int TY = d.ty, pitch = row_pitch(Hx);
     const int ytiles = d.ny / TY;
     const unsigned tid_ = pair_tile(blockIdx.x);
@@ -290,7 +292,11 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_x_forward(const float*
         row[phys(2 * q + 1)] = make_float2(v.z, v.w);
     }
     __syncthreads();
-    lds_fft<LHX, false, kThreadsXZ, 1, kMaxLrXZ>(tile, TY, pitch, tw);
+    if constexpr (R3 > 1) {
+        radix3_stage<R3, false, kThreadsXZ>(tile, TY, pitch, 1 << LHX2, tw + (1 << LHX2) / 2);
+        __syncthreads();
+    }
+    lds_fft<LHX2, false, kThreadsXZ, R3, kMaxLrXZ>(tile, TY * R3, pitch, tw);
     // transposed store: S[z][px][y0 + r], r fastest; one float4 = rows (2 rp, 2 rp + 1) of one px
     float4* dst = reinterpret_cast<float4*>(S + ((size_t)z * Hx) * d.ny + y0);
     const int hp = TY / 2, rowq = d.ny / 2;
@@ -309,7 +315,7 @@ __global__ __launch_bounds__(kThreadsY, 4) void k_y_pass(const float2* __restric
                                                       const float2* __restrict__ tw) {
     extern __shared__ __attribute__((aligned(16))) float2 tile[];
     constexpr int M = R3 << LY2;
-    const int TC = d.tc, pitch = row_pitch(M), Hx = 1 << d.lhx, L = d.nz;
+    const int TC = d.tc, pitch = row_pitch(M), Hx = d.hx, L = d.nz;
     const size_t c0 = (size_t)blockIdx.x * TC;
     const float4* base = reinterpret_cast<const float4*>(src + c0 * M);
     const int quads = M / 2;
@@ -352,23 +358,26 @@ __global__ __launch_bounds__(kThreadsY, 4) void k_y_pass(const float2* __restric
 // line is still written exactly once; otherwise both lines of a pair are written by the one tile that owns the pair.
 // grid: (#A planes) * (Y / TL) tiles of TL consecutive py positions.
 // OTF layout: G[(plane index)][py][pz] as float4 {Ga.re, Ga.im, Gb.re, Gb.im}, already scaled by 1/(Hx*Y*Z).
-template <int LZ, bool CONJ>
+// BUILD: instead of multiplying, the untangled spectrum of the (real) input -- a placed PSF -- is stored as the OTF in that
+// same layout, scaled: the pipeline builds its own OTF with the transform it will later apply.
+template <int LZ2, int R3, bool BUILD>
 __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_z_conv(const float2* __restrict__ S, float2* __restrict__ T, const float4* __restrict__ G,
-                                                      NativeDims d, const float2* __restrict__ tw) {
+                                                      NativeDims d, const float2* __restrict__ tw, int conj_otf, float4* __restrict__ Gout,
+                                                      float scale) {
     extern __shared__ __attribute__((aligned(16))) float2 tile[];
-    constexpr int L = 1 << LZ;
-    const int Hx = 1 << d.lhx, M = d.ny, TL = d.tl, pitch = row_pitch(L);
+    constexpr int L = R3 << LZ2;
+    const int Hx = d.hx, M = d.ny, TL = d.tl, pitch = row_pitch(L);
     const int ytiles = M / TL;
     const unsigned tid_ = pair_tile(blockIdx.x);
-    const int plane = tid_ / ytiles;                 // 0 .. Hx/2
+    const int plane = tid_ / ytiles;                 // = xk, 0 .. Hx/2: one representative of every mirror pair of planes
     const int py0 = (tid_ % ytiles) * TL;
-    const int px = plane == Hx / 2 ? 1 : 2 * plane;        // plane order: even px ascending, then px = 1
-    const unsigned xk = brev_n((unsigned)px, d.lhx);
-    const int pxB = (int)brev_n((Hx - xk) & (Hx - 1), d.lhx);
+    const int xk = plane;
+    const int px = freq2pos(xk, d.lhx2, d.r3x);
+    const int pxB = freq2pos(xk == 0 ? 0 : Hx - xk, d.lhx2, d.r3x);
     // mirror block of py positions: blocks of TL aligned positions map to blocks (see file header)
     const int pyB_any = y_mirror_pos(py0, d);
     const int pyB0 = pyB_any & ~(TL - 1);
-    const bool self_plane = (px == 0 || px == 1);
+    const bool self_plane = (px == pxB);  // xk == 0 or xk == Hx/2
     float2* tA = tile;
     float2* tB = tile + TL * pitch;
     // layout [px][z][py]: element (px, z, py) at ((px * L + z) * M + py); one float4 = lines (2 jp, 2 jp + 1)
@@ -386,7 +395,13 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_z_conv(const float2* _
     }
     const float4* Gp = G + ((size_t)plane * M + py0) * L;
     __syncthreads();
-    if (!(d.dbg & 1)) lds_fft<LZ, false, kThreadsXZ, 1, kMaxLrXZ>(tile, 2 * TL, pitch, tw);
+    if (!(d.dbg & 1)) {
+        if constexpr (R3 > 1) {
+            radix3_stage<R3, false, kThreadsXZ>(tile, 2 * TL, pitch, 1 << LZ2, tw + (1 << LZ2) / 2);
+            __syncthreads();
+        }
+        lds_fft<LZ2, false, kThreadsXZ, R3, kMaxLrXZ>(tile, 2 * TL * R3, pitch, tw);
+    }
     // point-wise: element (line j, position pz) of A pairs with (line jB, position pzB) of B
     float sw, cw;
     sincospif(-2.0f * (float)xk / (float)(2 * Hx), &sw, &cw);  // w = exp(-2 pi i xk / Nx), Nx = 2 Hx
@@ -396,11 +411,11 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_z_conv(const float2* _
     for (int q = 0; q < n_it; ++q) {
         const int i = threadIdx.x + q * kThreadsXZ;
         if (i >= TL * L || (d.dbg & 2)) break;
-        const float4 g = Gp[i];  // Gp[(size_t)j * L + pz] with i = j * L + pz
+        float4 g = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if constexpr (!BUILD) g = Gp[i];  // Gp[(size_t)j * L + pz] with i = j * L + pz
         const int j = i / L, pz = i - j * L;
         const int jB = y_mirror_pos(py0 + j, d) - pyB0;
-        const unsigned kz = brev_n((unsigned)pz, d.lz);
-        const int pzB = (int)brev_n((L - kz) & (L - 1), d.lz);
+        const int pzB = mirror_pos(pz, L, LZ2, R3);
         const float2 a = tA[j * pitch + phys(pz)];
         const float2 bm = tB[jB * pitch + phys(pzB)];
         const float2 bc = cconj(bm);
@@ -409,8 +424,12 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_z_conv(const float2* _
         const float2 O = make_float2(0.5f * dlt.y, -0.5f * dlt.x);  // -i/2 * (a - conj(b))
         const float2 wO = cmul(w, O);
         const float2 Xa = cadd(E, wO), Xb = csub(E, wO);
+        if constexpr (BUILD) {
+            Gout[((size_t)plane * M + py0) * L + i] = make_float4(Xa.x * scale, Xa.y * scale, Xb.x * scale, Xb.y * scale);
+            continue;
+        }
         float2 Ga = make_float2(g.x, g.y), Gb = make_float2(g.z, g.w);
-        if (CONJ) { Ga.y = -Ga.y; Gb.y = -Gb.y; }
+        if (conj_otf) { Ga.y = -Ga.y; Gb.y = -Gb.y; }
         const float2 Ya = cmul(Xa, Ga), Yb = cmul(Xb, Gb);
         const float2 E2 = make_float2(0.5f * (Ya.x + Yb.x), 0.5f * (Ya.y + Yb.y));
         const float2 dY = csub(Ya, Yb);
@@ -419,8 +438,15 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_z_conv(const float2* _
         tA[j * pitch + phys(pz)] = make_float2(E2.x - O2.y, E2.y + O2.x);
         tB[jB * pitch + phys(pzB)] = make_float2(E2.x + O2.y, O2.x - E2.y);
     }
+    if constexpr (BUILD) return;
     __syncthreads();
-    if (!(d.dbg & 4)) lds_fft<LZ, true, kThreadsXZ, 1, kMaxLrXZ>(tile, 2 * TL, pitch, tw);
+    if (!(d.dbg & 4)) {
+        lds_fft<LZ2, true, kThreadsXZ, R3, kMaxLrXZ>(tile, 2 * TL * R3, pitch, tw);
+        if constexpr (R3 > 1) {
+            radix3_stage<R3, true, kThreadsXZ>(tile, 2 * TL, pitch, 1 << LZ2, tw + (1 << LZ2) / 2);
+            __syncthreads();
+        }
+    }
     float4* dA = reinterpret_cast<float4*>(T + (size_t)px * L * M + py0);
     float4* dB = reinterpret_cast<float4*>(T + (size_t)pxB * L * M + pyB0);
 #pragma unroll MI_FFT_UNROLL
@@ -438,11 +464,11 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_z_conv(const float2* _
 // ---------------------------------------------------------------------------------------------- P5: x inverse + epilogue
 // FUSE: the epilogue result stays in LDS and is transformed forward again into S_next (the P1 of the NEXT
 // convolution): the ratio never touches HBM, and bl is read once and written once per iteration.
-template <int LHX, int EPI, bool FUSE>
+template <int LHX2, int R3, bool FUSE>
 __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_x_inverse(const float2* __restrict__ T, float* __restrict__ out, ConvEpilogue e, NativeDims d,
-                                                         const float2* __restrict__ tw, float2* __restrict__ S_next) {
+                                                         const float2* __restrict__ tw, float2* __restrict__ S_next, int EPI) {
     extern __shared__ __attribute__((aligned(16))) float2 tile[];
-    constexpr int Hx = 1 << LHX;
+    constexpr int Hx = R3 << LHX2;
     const int TY = d.ty, pitch = row_pitch(Hx);
     const int ytiles = d.ny / TY;
     const unsigned tid_ = pair_tile(blockIdx.x);
@@ -457,7 +483,13 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_x_inverse(const float2
         tile[(2 * rp + 1) * pitch + phys(px)] = make_float2(v.z, v.w);
     }
     __syncthreads();
-    if (!(d.dbg & 8)) lds_fft<LHX, true, kThreadsXZ, 1, kMaxLrXZ>(tile, TY, pitch, tw);
+    if (!(d.dbg & 8)) {
+        lds_fft<LHX2, true, kThreadsXZ, R3, kMaxLrXZ>(tile, TY * R3, pitch, tw);
+        if constexpr (R3 > 1) {
+            radix3_stage<R3, true, kThreadsXZ>(tile, TY, pitch, 1 << LHX2, tw + (1 << LHX2) / 2);
+            __syncthreads();
+        }
+    }
     const size_t row0 = ((size_t)z * d.ny + y0) * (size_t)(2 * Hx);
     const int quads = Hx / 2;
     float4* dst = reinterpret_cast<float4*>(out + row0);
@@ -494,7 +526,13 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_x_inverse(const float2
     }
     if (FUSE) {
         __syncthreads();
-        if (!(d.dbg & 16)) lds_fft<LHX, false, kThreadsXZ, 1, kMaxLrXZ>(tile, TY, pitch, tw);
+        if (!(d.dbg & 16)) {
+            if constexpr (R3 > 1) {
+                radix3_stage<R3, false, kThreadsXZ>(tile, TY, pitch, 1 << LHX2, tw + (1 << LHX2) / 2);
+                __syncthreads();
+            }
+            lds_fft<LHX2, false, kThreadsXZ, R3, kMaxLrXZ>(tile, TY * R3, pitch, tw);
+        }
         float4* sdst = reinterpret_cast<float4*>(S_next + ((size_t)z * Hx) * d.ny + y0);
 #pragma unroll MI_FFT_UNROLL
         for (int i = threadIdx.x; i < hp * Hx; i += kThreadsXZ) {
@@ -505,66 +543,54 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_x_inverse(const float2
     }
 }
 
-// ---------------------------------------------------------------------------------------------- OTF repack
-// From the R2C half spectrum H[kz][ky][kx], kx in [0, Hx] (rocFFT layout, unscaled or pre-scaled) to the pair
-// layout of k_z_conv: G[plane][py][pz] = {H_full[xk], H_full[xk + Hx]} at (ky, kz) = (brev(py), brev(pz)).
-__global__ __launch_bounds__(256) void k_repack_otf(const float2* __restrict__ Hs, float4* __restrict__ G, NativeDims d, float scale) {
-    const int Hx = 1 << d.lhx, M = d.ny, L = d.nz;
-    const size_t total = (size_t)(Hx / 2 + 1) * M * L;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int pz = (int)(i % L);
-        const size_t r = i / L;
-        const int py = (int)(r % M), plane = (int)(r / M);
-        const int px = plane == Hx / 2 ? 1 : 2 * plane;
-        const int xk = (int)brev_n((unsigned)px, d.lhx), ky = y_pos2freq(py, d), kz = (int)brev_n((unsigned)pz, d.lz);
-        const int W = Hx + 1;
-        const float2 ga = Hs[((size_t)kz * M + ky) * W + xk];
-        // H_full[xk + Hx, ky, kz] = conj(H[Hx - xk, -ky, -kz])
-        const float2 gb = Hs[((size_t)((L - kz) & (L - 1)) * M + (ky == 0 ? 0 : M - ky)) * W + (Hx - xk)];
-        G[i] = make_float4(ga.x * scale, ga.y * scale, gb.x * scale, -gb.y * scale);
-    }
-}
-
 bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
 }  // namespace
 
-// y = r3 * 2^a with r3 in {1, 3, 9}: the one axis that may carry a radix-3 factor (it is the axis the slab driver
-// shards, where local extent = slab + halos is rarely a power of two)
-static bool split_y(int ny, int* r3, int* ly2) {
+// An axis length n = r3 * 2^l2 with r3 in {1, 3, 9}: powers of two from 8 to 4096, or 3 * / 9 * (32 .. 512).  (A radix-3/9
+// factor matters most on y, the axis the slab driver shards, where slab + halos is rarely a power of two; on x and z it
+// keeps zero-padded deconFFT shapes close to the 7-smooth ones.)
+static bool split_axis(int n, int* r3, int* l2) {
     for (int r : {1, 3, 9}) {
-        if (ny % r) continue;
-        const int m = ny / r;
+        if (n % r) continue;
+        const int m = n / r;
         if (!is_pow2(m)) continue;
         const int l = ilog2(m);
-        if (r == 1 ? (l >= 3 && l <= 12) : (l >= 5 && l <= 9)) { *r3 = r; *ly2 = l; return true; }
+        if (r == 1 ? (l >= 3 && l <= 12) : (l >= 5 && l <= 9)) { *r3 = r; *l2 = l; return true; }
     }
     return false;
 }
 
+static const int kMaxZ = 2304;  // 2 * TL >= 4 rows of the z pass must fit the LDS tile
+
 bool NativeFft::supported(const int F[3]) {
-    // x: real length 2*Hx with 8 <= Hx <= 4096; z: 8 .. 2048; y: see split_y; LDS tiles must fit
-    int r3, ly2;
-    return is_pow2(F[0]) && is_pow2(F[2]) && F[0] >= 16 && F[0] <= 8192 && F[2] >= 8 && F[2] <= 2048 && split_y(F[1], &r3, &ly2);
+    // x: real length 2 * Hx, the transform runs on Hx complex points
+    int r3, l2;
+    return F[0] % 2 == 0 && split_axis(F[0] / 2, &r3, &l2) && split_axis(F[1], &r3, &l2) && split_axis(F[2], &r3, &l2) && F[2] <= kMaxZ;
 }
 
-int NativeFft::good_size_y(int n) {
-    for (int m = n < 8 ? 8 : n;; ++m) {
-        int r3, ly2;
-        if (split_y(m, &r3, &ly2)) return m;
+int NativeFft::good_size(int n, int axis) {
+    int r3, l2;
+    if (axis == 0) {
+        for (int h = n < 16 ? 8 : (n + 1) / 2;; ++h)
+            if (split_axis(h, &r3, &l2)) return 2 * h;
     }
+    for (int m = n < 8 ? 8 : n;; ++m)
+        if (split_axis(m, &r3, &l2)) return (axis == 2 && m > kMaxZ) ? 0 : m;
 }
 
 static size_t lds_bytes(int rows, int n) { return sizeof(float2) * (size_t)rows * row_pitch(n); }
 
-int NativeFft::init(hipStream_t s, const int F[3], const float2* otf_half_spectrum, float scale) {
-    dims.lhx = ilog2(F[0] / 2);
-    MI_REQUIRE(split_y(F[1], &dims.r3, &dims.ly2), "native FFT: unsupported y length %d", F[1]);
-    dims.lz = ilog2(F[2]);
+int NativeFft::init(hipStream_t s, const int F[3], bool explicit_adjoint) {
+    MI_REQUIRE(supported(F), "native FFT: unsupported shape %d x %d x %d", F[0], F[1], F[2]);
+    const int Hx = F[0] / 2;
+    split_axis(Hx, &dims.r3x, &dims.lhx2);
+    split_axis(F[1], &dims.r3, &dims.ly2);
+    split_axis(F[2], &dims.r3z, &dims.lz2);
+    dims.hx = Hx;
     dims.ny = F[1];
     dims.nz = F[2];
-    const int Hx = F[0] / 2;
     const size_t budget = 68 * 1024;  // two work-groups per CU inside 160 KB
     auto fit = [&](int n, int maxrows, int mult) {
         int rows = maxrows;
@@ -591,45 +617,49 @@ int NativeFft::init(hipStream_t s, const int F[3], const float2* otf_half_spectr
     if (const char* e = std::getenv("MI_FFT_TC")) dims.tc = std::max(1, atoi(e));
     if (const char* e = std::getenv("MI_FFT_TL")) dims.tl = std::max(2, std::min(atoi(e), F[1]));
     while ((size_t)F[2] * Hx % dims.tc) dims.tc >>= 1;
+    // tiles are whole float4 groups of rows / lines and must divide y; z tiles of TL positions must map onto aligned
+    // mirror blocks, which holds for TL <= 2^ly2 (positions inside one power-of-two sub-block mirror inside one)
+    MI_REQUIRE(dims.ty >= 2 && dims.ty % 2 == 0 && F[1] % dims.ty == 0, "native FFT: x tile of %d rows does not divide y = %d", dims.ty, F[1]);
+    MI_REQUIRE(dims.tl >= 2 && is_pow2(dims.tl) && dims.tl <= (1 << dims.ly2), "native FFT: z tile of %d lines does not fit y = %d", dims.tl, F[1]);
     MI_REQUIRE(lds_bytes(dims.ty, Hx) <= 150 * 1024 && lds_bytes(dims.tc, F[1]) <= 150 * 1024 && lds_bytes(2 * dims.tl, F[2]) <= 150 * 1024,
                "native FFT: transform too long for LDS");
     n_cplx = (size_t)Hx * F[1] * F[2];
     MI_TRY(S.alloc(sizeof(float2) * n_cplx));
     MI_TRY(T.alloc(sizeof(float2) * n_cplx));
     MI_TRY(G.alloc(sizeof(float4) * (size_t)(Hx / 2 + 1) * F[1] * F[2]));
-    // twiddle tables exp(-2 pi i e / N) in double on the host: e < N/2 for the power-of-two transforms (x: Hx, y: Msub,
-    // z: L), plus the full circle e < M behind the y table for the radix-3/9 stage
-    const int msub = 1 << dims.ly2;
-    const int lens[3] = {Hx, msub, F[2]};
+    // twiddle tables exp(-2 pi i e / N) in double on the host, per axis: e < sub/2 for the power-of-two sub-transform
+    // (sub = 2^l2), followed by the full circle e < n of the radix-3/9 stage when the axis has one
+    const int lens[3] = {Hx, F[1], F[2]};
+    const int subs[3] = {1 << dims.lhx2, 1 << dims.ly2, 1 << dims.lz2};
     size_t off = 0, offs[3];
-    for (int a = 0; a < 3; ++a) { offs[a] = off; off += (size_t)std::max(1, lens[a] / 2) + (a == 1 ? (size_t)F[1] : 0); }
+    for (int a = 0; a < 3; ++a) { offs[a] = off; off += (size_t)std::max(1, subs[a] / 2) + (lens[a] != subs[a] ? (size_t)lens[a] : 0); }
     std::vector<float2> h(off);
     const double two_pi = 6.283185307179586476925286766559;
-    for (int a = 0; a < 3; ++a)
-        for (int e = 0; e < lens[a] / 2; ++e)
-            h[offs[a] + e] = make_float2((float)std::cos(two_pi * e / lens[a]), (float)-std::sin(two_pi * e / lens[a]));
-    for (int e = 0; e < F[1]; ++e)
-        h[offs[1] + msub / 2 + e] = make_float2((float)std::cos(two_pi * e / F[1]), (float)-std::sin(two_pi * e / F[1]));
+    for (int a = 0; a < 3; ++a) {
+        for (int e = 0; e < subs[a] / 2; ++e)
+            h[offs[a] + e] = make_float2((float)std::cos(two_pi * e / subs[a]), (float)-std::sin(two_pi * e / subs[a]));
+        if (lens[a] != subs[a])
+            for (int e = 0; e < lens[a]; ++e)
+                h[offs[a] + subs[a] / 2 + e] = make_float2((float)std::cos(two_pi * e / lens[a]), (float)-std::sin(two_pi * e / lens[a]));
+    }
     MI_TRY(tw.alloc(sizeof(float2) * off));
     MI_HIP(hipMemcpyAsync(tw.p, h.data(), sizeof(float2) * off, hipMemcpyHostToDevice, s));
     tw_x = tw.as<float2>() + offs[0];
     tw_y = tw.as<float2>() + offs[1];
     tw_z = tw.as<float2>() + offs[2];
-    const size_t total = (size_t)(Hx / 2 + 1) * F[1] * F[2];
-    size_t blocks = (total + 256 - 1) / 256;
-    if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(k_repack_otf, dim3((unsigned)blocks), dim3(256), 0, s, otf_half_spectrum, G.as<float4>(), dims, scale);
-    MI_TRY(launch_check("k_repack_otf"));
+    have_adj = explicit_adjoint;
+    if (have_adj) MI_TRY(G_adj.alloc(G.bytes));  // explicit adjoint kernel (psf_inv of the 'same'-convolution flavour) instead of conj(OTF)
     MI_HIP(hipStreamSynchronize(s));  // host twiddle vector dies at scope exit
     return MI_OK;
 }
 
-// ---- launch helpers: the kernels are templated on log2(length); lengths 2^3 .. 2^12 (z: 2^11) are instantiated
-#define MI_LOG_CASES(M) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12)
-#define MI_LOGZ_CASES(M) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11)
-// y: key = ly2 * 16 + r3
-#define MI_Y_CASES(M) M(3, 1) M(4, 1) M(5, 1) M(6, 1) M(7, 1) M(8, 1) M(9, 1) M(10, 1) M(11, 1) M(12, 1) \
+// ---- launch helpers: the kernels are templated on (log2 of the power-of-two part, radix-3/9 factor) of their axis;
+// key = l2 * 16 + r3
+#define MI_AXIS_CASES(M) M(3, 1) M(4, 1) M(5, 1) M(6, 1) M(7, 1) M(8, 1) M(9, 1) M(10, 1) M(11, 1) M(12, 1) \
     M(5, 3) M(6, 3) M(7, 3) M(8, 3) M(9, 3) M(5, 9) M(6, 9) M(7, 9) M(8, 9) M(9, 9)
+// z: lengths up to kMaxZ
+#define MI_Z_CASES(M) M(3, 1) M(4, 1) M(5, 1) M(6, 1) M(7, 1) M(8, 1) M(9, 1) M(10, 1) M(11, 1) \
+    M(5, 3) M(6, 3) M(7, 3) M(8, 3) M(9, 3) M(5, 9) M(6, 9) M(7, 9) M(8, 9)
 
 template <class K, class... Args>
 static int launch_lds(K kernel, unsigned grid, int threads, size_t lds, hipStream_t s, const char* name, Args... args) {
@@ -640,52 +670,92 @@ static int launch_lds(K kernel, unsigned grid, int threads, size_t lds, hipStrea
 }
 
 int NativeFft::x_forward(hipStream_t s, const float* in) {
-    const int Hx = 1 << dims.lhx, M = dims.ny, L = dims.nz;
+    const int Hx = dims.hx, M = dims.ny, L = dims.nz;
     const unsigned xtiles = (unsigned)((size_t)L * (M / dims.ty));
     const size_t xl = lds_bytes(dims.ty, Hx);
     const NativeDims d = dims;
     float2* Sp = S.as<float2>();
     const float2* twx = tw_x;
     int rc = MI_ERR_INVALID;
-#define MI_X(LG) case LG: rc = launch_lds(k_x_forward<LG>, xtiles, kThreadsXZ, xl, s, "k_x_forward", in, Sp, d, twx); break;
-    switch (dims.lhx) { MI_LOG_CASES(MI_X) default: return fail(MI_ERR_UNSUPPORTED, "native FFT: x length 2^%d", dims.lhx); }
+#define MI_X(LG, R) case LG * 16 + R: rc = launch_lds(k_x_forward<LG, R>, xtiles, kThreadsXZ, xl, s, "k_x_forward", in, Sp, d, twx); break;
+    switch (dims.lhx2 * 16 + dims.r3x) { MI_AXIS_CASES(MI_X) default: return fail(MI_ERR_UNSUPPORTED, "native FFT: x length %d", 2 * Hx); }
 #undef MI_X
+    return rc;
+}
+
+int NativeFft::y_pass(hipStream_t s, bool inverse) {
+    const int Hx = dims.hx, M = dims.ny, L = dims.nz;
+    const unsigned ycols = (unsigned)((size_t)L * Hx / dims.tc);
+    const size_t yl = lds_bytes(dims.tc, M);
+    const NativeDims d = dims;
+    const float2* src = S.as<float2>();
+    float2* dst = T.as<float2>();
+    const float2* twy = tw_y;
+    int rc = MI_ERR_INVALID;
+#define MI_Y(LG, R)                                                                                                            \
+    case LG * 16 + R:                                                                                                          \
+        rc = inverse ? launch_lds(k_y_pass<LG, R, true>, ycols, kThreadsY, yl, s, "k_y_pass<inv>", src, dst, d, twy)            \
+                     : launch_lds(k_y_pass<LG, R, false>, ycols, kThreadsY, yl, s, "k_y_pass<fwd>", src, dst, d, twy);          \
+        break;
+    switch (dims.ly2 * 16 + dims.r3) { MI_AXIS_CASES(MI_Y) default: return fail(MI_ERR_UNSUPPORTED, "native FFT: y length %d", M); }
+#undef MI_Y
+    return rc;
+}
+
+int NativeFft::z_conv(hipStream_t s, bool conj_otf) {
+    const int Hx = dims.hx, M = dims.ny, L = dims.nz;
+    const unsigned ztiles = (unsigned)((size_t)(Hx / 2 + 1) * (M / dims.tl));
+    const size_t zl = lds_bytes(2 * dims.tl, L);
+    const NativeDims d = dims;
+    const float2* Tp = T.as<float2>();
+    float2* Sp = S.as<float2>();
+    const float4* Gp = (conj_otf && have_adj) ? G_adj.as<float4>() : G.as<float4>();
+    const float2* twz = tw_z;
+    const int cj = (conj_otf && !have_adj) ? 1 : 0;
+    int rc = MI_ERR_INVALID;
+#define MI_Z(LG, R)                                                                                                                      \
+    case LG * 16 + R:                                                                                                                    \
+        rc = launch_lds(k_z_conv<LG, R, false>, ztiles, kThreadsXZ, zl, s, "k_z_conv", Tp, Sp, Gp, d, twz, cj, (float4*)nullptr, 0.0f); \
+        break;
+    switch (dims.lz2 * 16 + dims.r3z) { MI_Z_CASES(MI_Z) default: return fail(MI_ERR_UNSUPPORTED, "native FFT: z length %d", L); }
+#undef MI_Z
+    return rc;
+}
+
+// OTF of the placed kernel volume `placed` (shape F, real; may be the T buffer itself): forward x, y and z transforms, then
+// the untangled spectrum is stored in the z pass' pair layout, times `scale`.
+int NativeFft::build_otf(hipStream_t s, const float* placed, bool adjoint_slot, float scale) {
+    MI_REQUIRE(!adjoint_slot || have_adj, "native FFT: no adjoint OTF slot");
+    MI_TRY(x_forward(s, placed));
+    MI_TRY(y_pass(s, false));
+    const int Hx = dims.hx, M = dims.ny, L = dims.nz;
+    const unsigned ztiles = (unsigned)((size_t)(Hx / 2 + 1) * (M / dims.tl));
+    const size_t zl = lds_bytes(2 * dims.tl, L);
+    const NativeDims d = dims;
+    const float2* Tp = T.as<float2>();
+    float2* Sp = S.as<float2>();
+    float4* Gp = adjoint_slot ? G_adj.as<float4>() : G.as<float4>();
+    const float2* twz = tw_z;
+    int rc = MI_ERR_INVALID;
+#define MI_Z(LG, R)                                                                                                                       \
+    case LG * 16 + R:                                                                                                                     \
+        rc = launch_lds(k_z_conv<LG, R, true>, ztiles, kThreadsXZ, zl, s, "k_z_conv<build>", Tp, Sp, (const float4*)nullptr, d, twz, 0, Gp, scale); \
+        break;
+    switch (dims.lz2 * 16 + dims.r3z) { MI_Z_CASES(MI_Z) default: return fail(MI_ERR_UNSUPPORTED, "native FFT: z length %d", L); }
+#undef MI_Z
     return rc;
 }
 
 // P2, P3, P4: S[z][px][py] -> T[z][px][py] (x still transformed), multiplied by the OTF or its conjugate
 int NativeFft::middle(hipStream_t s, bool conj_otf) {
-    const int Hx = 1 << dims.lhx, M = dims.ny, L = dims.nz;
-    float2* Sp = S.as<float2>();
-    float2* Tp = T.as<float2>();
-    const float4* Gp = G.as<float4>();
-    const unsigned ycols = (unsigned)((size_t)L * Hx / dims.tc);
-    const unsigned ztiles = (unsigned)((size_t)(Hx / 2 + 1) * (M / dims.tl));
-    const size_t yl = lds_bytes(dims.tc, M), zl = lds_bytes(2 * dims.tl, L);
-    const NativeDims d = dims;
-    const float2 *twy = tw_y, *twz = tw_z;
-    int rc = MI_ERR_INVALID;
-#define MI_Y(LG, R) case LG * 16 + R: rc = launch_lds(k_y_pass<LG, R, false>, ycols, kThreadsY, yl, s, "k_y_pass<fwd>", (const float2*)Sp, Tp, d, twy); break;
-    switch (dims.ly2 * 16 + dims.r3) { MI_Y_CASES(MI_Y) default: return fail(MI_ERR_UNSUPPORTED, "native FFT: y length %d", dims.ny); }
-#undef MI_Y
-    MI_TRY(rc);
-#define MI_Z(LG)                                                                                                                       \
-    case LG:                                                                                                                           \
-        rc = conj_otf ? launch_lds(k_z_conv<LG, true>, ztiles, kThreadsXZ, zl, s, "k_z_conv<conj>", (const float2*)Tp, Sp, Gp, d, twz) \
-                      : launch_lds(k_z_conv<LG, false>, ztiles, kThreadsXZ, zl, s, "k_z_conv", (const float2*)Tp, Sp, Gp, d, twz);     \
-        break;
-    switch (dims.lz) { MI_LOGZ_CASES(MI_Z) default: return fail(MI_ERR_UNSUPPORTED, "native FFT: z length 2^%d", dims.lz); }
-#undef MI_Z
-    MI_TRY(rc);
-#define MI_Y(LG, R) case LG * 16 + R: rc = launch_lds(k_y_pass<LG, R, true>, ycols, kThreadsY, yl, s, "k_y_pass<inv>", (const float2*)Sp, Tp, d, twy); break;
-    switch (dims.ly2 * 16 + dims.r3) { MI_Y_CASES(MI_Y) default: return fail(MI_ERR_UNSUPPORTED, "native FFT: y length %d", dims.ny); }
-#undef MI_Y
-    return rc;
+    MI_TRY(y_pass(s, false));
+    MI_TRY(z_conv(s, conj_otf));
+    return y_pass(s, true);
 }
 
 // P5 (+ P1 of the next convolution when fuse_forward): T -> out (may be null when fused) [-> S]
 int NativeFft::x_inverse(hipStream_t s, float* out, int epi_kind, const ConvEpilogue& epi, bool fuse_forward) {
-    const int Hx = 1 << dims.lhx, M = dims.ny, L = dims.nz;
+    const int Hx = dims.hx, M = dims.ny, L = dims.nz;
     const unsigned xtiles = (unsigned)((size_t)L * (M / dims.ty));
     const size_t xl = lds_bytes(dims.ty, Hx);
     const NativeDims d = dims;
@@ -696,22 +766,12 @@ int NativeFft::x_inverse(hipStream_t s, float* out, int epi_kind, const ConvEpil
     MI_REQUIRE(ek == EPI_NONE || ek == EPI_RATIO || ek == EPI_UPDATE || ek == EPI_UPDATE_REG, "native FFT: unknown epilogue %d", epi_kind);
     MI_REQUIRE(!fuse_forward || ek == EPI_RATIO || ek == EPI_UPDATE, "native FFT: only the plain RL epilogues fuse");
     int rc = MI_ERR_INVALID;
-#define MI_XI(LG)                                                                                                                          \
-    case LG:                                                                                                                               \
-        if (fuse_forward && ek == EPI_RATIO)                                                                                               \
-            rc = launch_lds(k_x_inverse<LG, EPI_RATIO, true>, xtiles, kThreadsXZ, xl, s, "k_x_inverse<fused>", Tp, out, epi, d, twx, Sp);   \
-        else if (fuse_forward)                                                                                                             \
-            rc = launch_lds(k_x_inverse<LG, EPI_UPDATE, true>, xtiles, kThreadsXZ, xl, s, "k_x_inverse<fused>", Tp, out, epi, d, twx, Sp);  \
-        else if (ek == EPI_NONE)                                                                                                           \
-            rc = launch_lds(k_x_inverse<LG, EPI_NONE, false>, xtiles, kThreadsXZ, xl, s, "k_x_inverse", Tp, out, epi, d, twx, Sp);          \
-        else if (ek == EPI_RATIO)                                                                                                          \
-            rc = launch_lds(k_x_inverse<LG, EPI_RATIO, false>, xtiles, kThreadsXZ, xl, s, "k_x_inverse", Tp, out, epi, d, twx, Sp);         \
-        else if (ek == EPI_UPDATE)                                                                                                         \
-            rc = launch_lds(k_x_inverse<LG, EPI_UPDATE, false>, xtiles, kThreadsXZ, xl, s, "k_x_inverse", Tp, out, epi, d, twx, Sp);        \
-        else                                                                                                                               \
-            rc = launch_lds(k_x_inverse<LG, EPI_UPDATE_REG, false>, xtiles, kThreadsXZ, xl, s, "k_x_inverse", Tp, out, epi, d, twx, Sp);    \
+#define MI_XI(LG, R)                                                                                                               \
+    case LG * 16 + R:                                                                                                              \
+        rc = fuse_forward ? launch_lds(k_x_inverse<LG, R, true>, xtiles, kThreadsXZ, xl, s, "k_x_inverse<fused>", Tp, out, epi, d, twx, Sp, ek) \
+                          : launch_lds(k_x_inverse<LG, R, false>, xtiles, kThreadsXZ, xl, s, "k_x_inverse", Tp, out, epi, d, twx, Sp, ek);    \
         break;
-    switch (dims.lhx) { MI_LOG_CASES(MI_XI) default: return fail(MI_ERR_UNSUPPORTED, "native FFT: x length 2^%d", dims.lhx); }
+    switch (dims.lhx2 * 16 + dims.r3x) { MI_AXIS_CASES(MI_XI) default: return fail(MI_ERR_UNSUPPORTED, "native FFT: x length %d", 2 * Hx); }
 #undef MI_XI
     return rc;
 }
@@ -721,10 +781,6 @@ int NativeFft::x_inverse(hipStream_t s, float* out, int epi_kind, const ConvEpil
 // keep whatever the previous convolution left in them; `bl` is only read.
 int NativeFft::time_pass(hipStream_t s, int which, const float* bl, int reps, float* avg_ms) {
     MI_REQUIRE(reps > 0 && avg_ms && which >= 0 && which <= 4, "time_pass: bad arguments");
-    const int Hx = 1 << dims.lhx, M = dims.ny, L = dims.nz;
-    float2* Sp = S.as<float2>();
-    float2* Tp = T.as<float2>();
-    const NativeDims d = dims;
     hipEvent_t e0, e1;
     MI_HIP(hipEventCreate(&e0));
     MI_HIP(hipEventCreate(&e1));
@@ -736,25 +792,9 @@ int NativeFft::time_pass(hipStream_t s, int which, const float* bl, int reps, fl
         switch (which) {
             case 0: rc = x_forward(s, bl); break;
             case 4: rc = x_inverse(s, nullptr, EPI_RATIO, e, true); break;
-            default: {
-                const unsigned ycols = (unsigned)((size_t)L * Hx / dims.tc);
-                const unsigned ztiles = (unsigned)((size_t)(Hx / 2 + 1) * (M / dims.tl));
-                const size_t yl = lds_bytes(dims.tc, M), zl = lds_bytes(2 * dims.tl, L);
-                rc = MI_ERR_INVALID;
-                if (which == 1) {
-#define MI_Y(LG, R) case LG * 16 + R: rc = launch_lds(k_y_pass<LG, R, false>, ycols, kThreadsY, yl, s, "k_y_pass<fwd>", (const float2*)Sp, Tp, d, tw_y); break;
-                    switch (dims.ly2 * 16 + dims.r3) { MI_Y_CASES(MI_Y) default: break; }
-#undef MI_Y
-                } else if (which == 3) {
-#define MI_Y(LG, R) case LG * 16 + R: rc = launch_lds(k_y_pass<LG, R, true>, ycols, kThreadsY, yl, s, "k_y_pass<inv>", (const float2*)Sp, Tp, d, tw_y); break;
-                    switch (dims.ly2 * 16 + dims.r3) { MI_Y_CASES(MI_Y) default: break; }
-#undef MI_Y
-                } else {
-#define MI_Z(LG) case LG: rc = launch_lds(k_z_conv<LG, false>, ztiles, kThreadsXZ, zl, s, "k_z_conv", (const float2*)Tp, Sp, G.as<float4>(), d, tw_z); break;
-                    switch (dims.lz) { MI_LOGZ_CASES(MI_Z) default: break; }
-#undef MI_Z
-                }
-            }
+            case 1: rc = y_pass(s, false); break;
+            case 2: rc = z_conv(s, false); break;
+            default: rc = y_pass(s, true); break;
         }
     }
     (void)hipEventRecord(e1, s);
@@ -787,6 +827,7 @@ int NativeFft::conv(hipStream_t s, const float* in, bool conj_otf, float* out, i
 // convolutions are fused, so per iteration bl is read twice and written once and the ratio never exists in HBM.
 int NativeFft::iterate(hipStream_t s, float* bl, int n_iters) {
     MI_TRY(check_aligned(bl, "bl"));
+    MI_REQUIRE(!have_adj, "native FFT: the fused iteration uses conj(OTF) as the adjoint");
     if (n_iters <= 0) return MI_OK;
     ConvEpilogue e;
     e.a = bl;

@@ -44,5 +44,7 @@ struct FftEngine {
 int build_otf(hipStream_t s, rocfft_plan fwd, rocfft_execution_info info, const float* psf, const AxisPlan ax[3], float* real_scratch,
               float* otf, float scale);
 int rocfft_global_setup();
+// transform lengths for the extents `need` (x, y, z) under the per-axis boundary rules; true: the hand-written pipeline takes them
+bool choose_fft_lengths(const int need[3], const int bnd[3], int F[3]);
 
 }  // namespace mi

@@ -167,6 +167,28 @@ int build_otf(hipStream_t s, rocfft_plan fwd, rocfft_execution_info info, const 
     return MI_OK;
 }
 
+// Transform lengths: circular axes keep their extent; padded axes get a 7-smooth length for rocFFT, or 2^a * {1,3,9} for the
+// hand-written pipeline, which is more than twice as fast per point -- taken unless it inflates the padded volume by more
+// than MI_FFT_NATIVE_INFLATE (default 1.6) over the 7-smooth one.  MI_FFT_ROCFFT=1 forces rocFFT.
+bool choose_fft_lengths(const int need[3], const int bnd[3], int F[3]) {
+    const char* force = std::getenv("MI_FFT_ROCFFT");
+    int Fn[3];
+    double vs = 1.0, vn = 1.0;
+    for (int d = 0; d < 3; ++d) {
+        const bool circ = bnd[d] == MI_BOUNDARY_CIRCULAR;
+        F[d] = circ ? need[d] : mi_next_fast_len(need[d]);
+        Fn[d] = circ ? need[d] : NativeFft::good_size(need[d], d);
+        vs *= F[d];
+        vn *= Fn[d];
+    }
+    double limit = 1.6;
+    if (const char* e = std::getenv("MI_FFT_NATIVE_INFLATE")) limit = atof(e);
+    const bool use_native = !(force && force[0] == '1') && Fn[0] > 0 && Fn[1] > 0 && Fn[2] > 0 && NativeFft::supported(Fn) && vn <= limit * vs;
+    if (use_native)
+        for (int d = 0; d < 3; ++d) F[d] = Fn[d];
+    return use_native;
+}
+
 FftEngine::~FftEngine() {
     delete native;
     if (info) rocfft_execution_info_destroy(info);
@@ -200,7 +222,7 @@ int FftEngine::init(hipStream_t s, const int n[3], const int k[3], const int bnd
                     const float* psf_inv, bool need_adjoint) {
     padded = false;
     bool conj_ok = true;
-    int F[3];
+    int F[3], need[3];
     for (int d = 0; d < 3; ++d) {
         AxisPlan& a = ax[d];
         a.n = n[d];
@@ -211,22 +233,47 @@ int FftEngine::init(hipStream_t s, const int n[3], const int k[3], const int bnd
         MI_REQUIRE(shift[d] >= 0 && off >= 0, "FFT engine: PSF placement shift %d outside [0, %d) on axis %d", shift[d], k[d], d);
         a.o = 0;
         if (bnd[d] == MI_BOUNDARY_CIRCULAR) {
-            F[d] = n[d];
+            need[d] = n[d];
         } else if (bnd[d] == MI_BOUNDARY_REPLICATE) {
-            F[d] = mi_next_fast_len(n[d] + k[d] - 1);
+            need[d] = n[d] + k[d] - 1;
             a.o = off;
         } else {
-            F[d] = mi_next_fast_len(n[d] + std::max(off, shift[d]));
+            need[d] = n[d] + std::max(off, shift[d]);
         }
-        a.F = F[d];
-        MI_REQUIRE(F[d] >= k[d], "FFT shape %d smaller than the PSF extent %d on axis %d", F[d], k[d], d);
-        if (a.F != a.n || a.o != 0) padded = true;
         // conj(OTF) is the adjoint the caller wants when the axis is circular (deconFFT: decon.m:168) or the
         // placement is symmetric (odd extent, centred)
         if (bnd[d] != MI_BOUNDARY_CIRCULAR && 2 * shift[d] != k[d] - 1) conj_ok = false;
     }
+    const bool use_native = choose_fft_lengths(need, bnd, F);
+    for (int d = 0; d < 3; ++d) {
+        AxisPlan& a = ax[d];
+        a.F = F[d];
+        MI_REQUIRE(F[d] >= k[d], "FFT shape %d smaller than the PSF extent %d on axis %d", F[d], k[d], d);
+        if (a.F != a.n || a.o != 0) padded = true;
+    }
     n_real = (size_t)F[0] * F[1] * F[2];
     n_spec = (size_t)(F[0] / 2 + 1) * F[1] * F[2];
+    // deconFFT never sees psf_inv (decon.m:18): its adjoint is conj(otf).  For 'same'-convolution semantics
+    // an explicit psf_inv is just another kernel with the same placement rule.
+    have_adj = need_adjoint && psf_inv != nullptr;
+    if (need_adjoint && !have_adj)
+        MI_REQUIRE(conj_ok, "FFT engine: the implied adjoint (flipped PSF) needs odd PSF extents on non-circular axes");
+    if (use_native) {
+        // the hand-written pipeline transforms the placed PSF itself: no rocFFT plan, no half-spectrum buffers
+        native = new (std::nothrow) NativeFft;
+        if (!native) return fail(MI_ERR_NOMEM, "FFT engine: out of host memory");
+        MI_TRY(native->init(s, F, have_adj));
+        // 1/(Fx Fy Fz) of the unnormalised inverse transform, times 2 for the half-length complex packing of x
+        const float nscale = 2.0f / (float)((double)F[0] * F[1] * F[2]);
+        for (int slot = 0; slot < (have_adj ? 2 : 1); ++slot) {
+            hipLaunchKernelGGL(k_place_psf, dim3(stream_grid(n_real)), dim3(kThreads), 0, s, slot ? psf_inv : psf, native->scratch(), ax[0].k,
+                               ax[1].k, ax[2].k, ax[0].F, ax[1].F, ax[2].F, ax[0].shift, ax[1].shift, ax[2].shift);
+            MI_TRY(launch_check("k_place_psf"));
+            MI_TRY(native->build_otf(s, native->scratch(), slot == 1, nscale));
+        }
+        if (padded) MI_TRY(real.alloc(sizeof(float) * n_real));  // staging volume of a padded engine
+        return MI_OK;
+    }
     const size_t lengths[3] = {(size_t)F[0], (size_t)F[1], (size_t)F[2]};  // rocFFT: fastest dimension first
     MI_TRY(make_plans(s, lengths, &fwd, &inv, &info, work));
     MI_TRY(real.alloc(sizeof(float) * n_real));
@@ -234,35 +281,16 @@ int FftEngine::init(hipStream_t s, const int n[3], const int k[3], const int bnd
     MI_TRY(otf.alloc(sizeof(float) * 2 * n_spec));
     const float scale = 1.0f / (float)((double)F[0] * F[1] * F[2]);
     MI_TRY(build_otf(s, fwd, info, psf, ax, real.as<float>(), otf.as<float>(), scale));
-    // deconFFT never sees psf_inv (decon.m:18): its adjoint is conj(otf).  For 'same'-convolution semantics
-    // an explicit psf_inv is just another kernel with the same placement rule.
-    have_adj = need_adjoint && psf_inv != nullptr;
     if (have_adj) {
         MI_TRY(otf_adj.alloc(sizeof(float) * 2 * n_spec));
         MI_TRY(build_otf(s, fwd, info, psf_inv, ax, real.as<float>(), otf_adj.as<float>(), scale));
-    } else if (need_adjoint) {
-        MI_REQUIRE(conj_ok, "FFT engine: the implied adjoint (flipped PSF) needs odd PSF extents on non-circular axes");
-    }
-    // hand-written pipeline (fft_native.hip) when the transform shape allows it; MI_FFT_ROCFFT=1 forces rocFFT
-    const char* force = std::getenv("MI_FFT_ROCFFT");
-    if (!padded && !have_adj && NativeFft::supported(F) && !(force && force[0] == '1')) {
-        native = new (std::nothrow) NativeFft;
-        if (!native) return fail(MI_ERR_NOMEM, "FFT engine: out of host memory");
-        // the rocFFT-built OTF carries 1/(Fx Fy Fz); the complex pipeline of Fx/2 x Fy x Fz points needs twice that
-        MI_TRY(native->init(s, F, otf.as<float2>(), 2.0f));
-        // rocFFT plans and buffers were only needed to build the OTF
-        MI_HIP(hipStreamSynchronize(s));
-        rocfft_execution_info_destroy(info); info = nullptr;
-        rocfft_plan_destroy(fwd); fwd = nullptr;
-        rocfft_plan_destroy(inv); inv = nullptr;
-        work.release(); spec.release(); real.release(); otf.release();
     }
     return MI_OK;
 }
 
 int FftEngine::conv(hipStream_t s, const float* in, bool adjoint, float* out, int epi_kind, const ConvEpilogue& epi) {
-    if (native) return native->conv(s, in, adjoint, out, epi_kind, epi);
-    MI_FFT(rocfft_execution_info_set_stream(info, s));
+    if (native && !padded) return native->conv(s, in, adjoint, out, epi_kind, epi);
+    if (!native) MI_FFT(rocfft_execution_info_set_stream(info, s));
     const float* src = in;
     if (padded) {
         hipLaunchKernelGGL(k_stage, dim3(stream_grid(n_real)), dim3(kThreads), 0, s, in, real.as<float>(), ax[0].n, ax[1].n, ax[2].n,
@@ -272,18 +300,22 @@ int FftEngine::conv(hipStream_t s, const float* in, bool adjoint, float* out, in
         MI_TRY(launch_check("k_stage"));
         src = real.as<float>();
     }
-    void* fin[1] = {const_cast<float*>(src)};
-    void* fout[1] = {spec.p};
-    MI_FFT(rocfft_execute(fwd, fin, fout, info));
-    const float2* o = reinterpret_cast<const float2*>(adjoint && have_adj ? otf_adj.p : otf.p);
-    if (adjoint && !have_adj)
-        hipLaunchKernelGGL(k_mul_otf<true>, dim3(stream_grid(n_spec)), dim3(kThreads), 0, s, spec.as<float2>(), o, n_spec);
-    else
-        hipLaunchKernelGGL(k_mul_otf<false>, dim3(stream_grid(n_spec)), dim3(kThreads), 0, s, spec.as<float2>(), o, n_spec);
-    MI_TRY(launch_check("k_mul_otf"));
-    void* iin[1] = {spec.p};
-    void* iout[1] = {real.p};
-    MI_FFT(rocfft_execute(inv, iin, iout, info));
+    if (native) {  // padded volume through the hand-written pipeline, in place; the crop + epilogue follows below
+        MI_TRY(native->conv(s, src, adjoint, real.as<float>(), EPI_NONE, ConvEpilogue{}));
+    } else {
+        void* fin[1] = {const_cast<float*>(src)};
+        void* fout[1] = {spec.p};
+        MI_FFT(rocfft_execute(fwd, fin, fout, info));
+        const float2* o = reinterpret_cast<const float2*>(adjoint && have_adj ? otf_adj.p : otf.p);
+        if (adjoint && !have_adj)
+            hipLaunchKernelGGL(k_mul_otf<true>, dim3(stream_grid(n_spec)), dim3(kThreads), 0, s, spec.as<float2>(), o, n_spec);
+        else
+            hipLaunchKernelGGL(k_mul_otf<false>, dim3(stream_grid(n_spec)), dim3(kThreads), 0, s, spec.as<float2>(), o, n_spec);
+        MI_TRY(launch_check("k_mul_otf"));
+        void* iin[1] = {spec.p};
+        void* iout[1] = {real.p};
+        MI_FFT(rocfft_execute(inv, iin, iout, info));
+    }
     const size_t n_out = (size_t)ax[0].n * ax[1].n * ax[2].n;
     const bool flat = !padded && ((uintptr_t)out % 16) == 0 && (!epi.a || ((uintptr_t)epi.a % 16) == 0) &&
                       (!epi.b || ((uintptr_t)epi.b % 16) == 0);

@@ -28,22 +28,24 @@ struct mi_rl_ctx {
 };
 
 extern "C" int mi_engine_select(int nx, int ny, int nz, int kx, int ky, int kz, int boundary) {
-    // direct: 2*K flop per voxel at ~60 TFLOP/s sustained fp32; FFT: ~200 B of HBM traffic per padded
-    // voxel per convolution at ~4 TB/s (3-4 rocFFT passes each way + multiply + epilogue).
+    // direct: 2*K flop per voxel at ~60 TFLOP/s sustained fp32.  FFT, per padded voxel and convolution (measured):
+    // ~15 ps through the hand-written pipeline (12 ps unpadded), ~30 ps through rocFFT.
     const double K = (double)kx * ky * kz;
     const double N = (double)nx * ny * nz;
-    double Nf = 1.0;
-    const int n[3] = {nx, ny, nz}, k[3] = {kx, ky, kz};
+    const int n[3] = {nx, ny, nz}, k[3] = {kx, ky, kz}, bnd[3] = {boundary, boundary, boundary};
+    int need[3], F[3];
     for (int d = 0; d < 3; ++d) {
-        int F = n[d];
-        if (boundary == MI_BOUNDARY_ZERO) F = mi_next_fast_len(n[d] + k[d] / 2);
-        if (boundary == MI_BOUNDARY_REPLICATE) F = mi_next_fast_len(n[d] + k[d] - 1);
-        Nf *= F;
+        need[d] = n[d];
+        if (boundary == MI_BOUNDARY_ZERO) need[d] = n[d] + k[d] / 2;
+        if (boundary == MI_BOUNDARY_REPLICATE) need[d] = n[d] + k[d] - 1;
     }
+    const bool native = choose_fft_lengths(need, bnd, F);
+    const double Nf = (double)F[0] * F[1] * F[2];
     const double t_direct = N * 2.0 * K / 60e12;
-    const double t_fft = Nf * 200.0 / 4e12 + 30e-6;
+    const double t_fft = Nf * (native ? (boundary == MI_BOUNDARY_CIRCULAR ? 12e-12 : 15e-12) : 30e-12) + 60e-6;
+    // without an explicit adjoint kernel the flipped PSF is conj(OTF), which needs centred odd extents off the circular rule
     const bool odd = (kx & 1) && (ky & 1) && (kz & 1);
-    return (odd && t_fft < t_direct) ? MI_ENGINE_FFT : MI_ENGINE_DIRECT;
+    return ((odd || boundary == MI_BOUNDARY_CIRCULAR) && t_fft < t_direct) ? MI_ENGINE_FFT : MI_ENGINE_DIRECT;
 }
 
 // default PSF placement shift of one axis: sample j of the PSF sits at index (j - shift) of the circular kernel
@@ -164,7 +166,8 @@ extern "C" int mi_rl_iterate(mi_rl_ctx* ctx, void* stream, float* bl, float* rat
     MI_REQUIRE(ctx && bl, "mi_rl_iterate: null pointer");
     MI_REQUIRE(n_iters >= 0, "mi_rl_iterate: negative iteration count");
     MI_TRY(use_device(ctx->dev));
-    if (ctx->engine == MI_ENGINE_FFT && ctx->fft->native) return ctx->fft->native->iterate(as_stream(stream), bl, n_iters);
+    if (ctx->engine == MI_ENGINE_FFT && ctx->fft->native && !ctx->fft->padded && !ctx->fft->native->have_adj)
+        return ctx->fft->native->iterate(as_stream(stream), bl, n_iters);
     MI_REQUIRE(ratio && ratio != bl, "mi_rl_iterate: this engine needs a ratio scratch volume");
     for (int i = 0; i < n_iters; ++i) {
         MI_TRY(mi_rl_forward_ratio(ctx, stream, bl, ratio));
@@ -174,19 +177,17 @@ extern "C" int mi_rl_iterate(mi_rl_ctx* ctx, void* stream, float* bl, float* rat
 }
 
 extern "C" int mi_fft_good_size(int n, int axis) {
-    // extents the hand-written FFT pipeline takes without falling back to rocFFT: powers of two on x and z,
-    // 2^a * {1, 3, 9} on y
-    if (axis == 1) return NativeFft::good_size_y(n);
-    int m = 8;
-    while (m < n) m <<= 1;
-    return m;
+    // extents the hand-written FFT pipeline takes without falling back to rocFFT: 2^a * {1, 3, 9} per axis (x: even, the
+    // transform runs on x/2 complex points); 0 when no such extent exists (z beyond the LDS tile)
+    if (axis < 0 || axis > 2 || n < 1) return 0;
+    return NativeFft::good_size(n, axis);
 }
 
 extern "C" int mi_rl_time_pass(mi_rl_ctx* ctx, void* stream, int which, const float* bl, int reps, float* avg_ms) {
     MI_REQUIRE(ctx && bl && avg_ms, "mi_rl_time_pass: null pointer");
     MI_TRY(use_device(ctx->dev));
-    if (!(ctx->engine == MI_ENGINE_FFT && ctx->fft->native))
-        return fail(MI_ERR_UNSUPPORTED, "mi_rl_time_pass: only the native FFT pipeline exposes its passes");
+    if (!(ctx->engine == MI_ENGINE_FFT && ctx->fft->native && !ctx->fft->padded))
+        return fail(MI_ERR_UNSUPPORTED, "mi_rl_time_pass: only the unpadded native FFT pipeline exposes its passes");
     return ctx->fft->native->time_pass(as_stream(stream), which, bl, reps, avg_ms);
 }
 

@@ -80,10 +80,14 @@ def next_fast_len(n_vec):
 
 
 def native_fft_shape(shape_xyz):
-    """FFT shape >= ``shape_xyz`` that the hand-written FFT pipeline takes without the rocFFT fallback (powers of two
-    on x and z, 2^a * {1,3,9} on y: ``mi_fft_good_size``).  Like ``next_fast_len`` it only enlarges the zero padding of
-    deconFFT (decon.m:144), which the block's own pads absorb."""
-    return [int(capi.lib().mi_fft_good_size(int(n), axis)) for axis, n in enumerate(shape_xyz)]
+    """FFT shape >= ``shape_xyz`` that the hand-written FFT pipeline takes without the rocFFT fallback (2^a * {1,3,9}
+    per axis, x even: ``mi_fft_good_size``).  Like ``next_fast_len`` it only enlarges the zero padding of deconFFT
+    (decon.m:144), which the block's own pads absorb.  An axis with no such extent (z > 2304) keeps its 7-smooth one."""
+    out = []
+    for axis, n in enumerate(shape_xyz):
+        g = int(capi.lib().mi_fft_good_size(int(n), axis))
+        out.append(g if g > 0 else D.next_fast_len(int(n)))
+    return out
 
 
 def autosplit(stack_xyz, psf_size_xyz, filt: Filter, block_size_max: int, numit: int) -> Block:

@@ -12,7 +12,10 @@ from oracle import rl_oracle as R
 pytestmark = pytest.mark.gpu
 
 SHAPES = [(8, 8, 16), (16, 32, 64), (32, 64, 128), (64, 16, 256), (8, 128, 32), (128, 8, 16), (16, 16, 1024),
-          (8, 96, 32), (16, 288, 64), (8, 192, 16), (8, 576, 16), (16, 1152, 32)]  # y = 3 * 2^a, 9 * 2^a: radix-3/9 stage
+          (8, 96, 32), (16, 288, 64), (8, 192, 16), (8, 576, 16), (16, 1152, 32),  # y = 3 * 2^a, 9 * 2^a: radix-3/9 stage
+          (8, 16, 192), (16, 8, 576), (8, 32, 384), (8, 8, 1152),                  # x/2 = 3 * 2^a, 9 * 2^a
+          (96, 16, 32), (288, 8, 16), (192, 16, 64), (576, 8, 16),                 # z = 3 * 2^a, 9 * 2^a
+          (96, 96, 192), (288, 192, 576), (96, 288, 64)]                           # mixed
 
 
 def _rel(a, b):
@@ -36,7 +39,7 @@ def test_circular_conv_native_vs_scipy_and_rocfft(dev, shape):
     assert _rel(got, ref) < 2e-5
 
 
-@pytest.mark.parametrize("shape", [(16, 32, 64), (32, 16, 128), (8, 64, 32), (8, 288, 32), (16, 96, 16)])
+@pytest.mark.parametrize("shape", [(16, 32, 64), (32, 16, 128), (8, 64, 32), (8, 288, 32), (16, 96, 16), (96, 32, 192), (8, 96, 576)])
 @pytest.mark.parametrize("niter,lam,interval", [(4, 0.0, 0), (6, 0.05, 2)])
 def test_decon_fft_native_matches_oracle(dev, shape, niter, lam, interval):
     from ipp_amd import decon
@@ -67,7 +70,7 @@ def test_adjoint_is_exact_transpose(dev):
     assert abs(lhs - rhs) / abs(lhs) < 1e-5
 
 
-@pytest.mark.parametrize("shape", [(16, 32, 64), (8, 16, 256)])
+@pytest.mark.parametrize("shape", [(16, 32, 64), (8, 16, 256), (96, 32, 192)])
 def test_fused_iterations_equal_unfused_and_direct_engine(dev, shape):
     """mi_rl_iterate: the fused 8-pass iteration of the native pipeline vs the two half-steps vs the direct engine."""
     from ipp_amd import capi, decon
@@ -88,3 +91,50 @@ def test_fused_iterations_equal_unfused_and_direct_engine(dev, shape):
     assert _rel(a.cpu().numpy(), want) < 1e-4
     with pytest.raises(capi.MiError, match="ratio scratch"):
         direct.iterate(c, None, 1)
+
+
+PADDED = [((13, 37, 50), (3, 5, 7)), ((40, 61, 90), (9, 11, 13)), ((7, 130, 33), (4, 6, 8)), ((100, 100, 100), (5, 31, 31))]
+
+
+@pytest.mark.parametrize("shape,kshape", PADDED)
+@pytest.mark.parametrize("boundary", [0, 1])
+def test_padded_conv_through_native_pipeline(dev, shape, kshape, boundary):
+    """Zero / replicate boundary 'same' convolution of arbitrary shapes on the FFT engine: the volume is staged into a
+    2^a * {1,3,9} padded array and runs through the hand-written pipeline; same numbers as the rocFFT route and as the
+    direct engine."""
+    from ipp_amd import decon
+    rng = np.random.default_rng(sum(shape) + boundary)
+    img = rng.random(shape, dtype=np.float32)
+    ker = rng.random(kshape, dtype=np.float32)
+    ker /= ker.sum()
+    t, k = torch.from_numpy(img).to(dev), torch.from_numpy(ker).to(dev)
+    got = decon.convn_same(t, k, boundary=boundary, engine=2).cpu().numpy()
+    direct = decon.convn_same(t, k, boundary=boundary, engine=1).cpu().numpy()
+    os.environ["MI_FFT_ROCFFT"] = "1"
+    try:
+        ref = decon.convn_same(t, k, boundary=boundary, engine=2).cpu().numpy()
+    finally:
+        del os.environ["MI_FFT_ROCFFT"]
+    assert _rel(got, direct.astype(np.float64)) < 2e-5
+    assert _rel(got, ref.astype(np.float64)) < 2e-5
+    if boundary == 0:
+        want = R.convn_same(img, ker)
+        assert _rel(got, want.astype(np.float64)) < 2e-5
+
+
+@pytest.mark.parametrize("kshape", [(5, 7, 9), (4, 6, 8)])
+def test_spatial_rl_on_fft_engine_uses_explicit_adjoint(dev, kshape):
+    """decon.m spatial flavour (zero boundary, psf_inv given explicitly) on the FFT engine: for even PSF extents the
+    adjoint is not conj(OTF), so the native pipeline carries a second OTF."""
+    from ipp_amd import capi, decon
+    shape = (20, 45, 70)
+    psf = R.gaussian_psf(kshape, (1.0, 1.5, 2.0))
+    psf_inv = np.ascontiguousarray(psf[::-1, ::-1, ::-1])
+    vol = torch.from_numpy(R.bead_volume(shape, seed=5, psf=R.gaussian_psf((5, 5, 5), (1.0, 1.0, 1.0)))).to(dev)
+    fft = decon.RLContext(shape, psf, psf_inv, boundary=capi.BOUNDARY_ZERO, engine=capi.ENGINE_FFT, device=dev)
+    direct = decon.RLContext(shape, psf, psf_inv, boundary=capi.BOUNDARY_ZERO, engine=capi.ENGINE_DIRECT, device=dev)
+    a, b = vol.clone(), vol.clone()
+    ratio = torch.empty_like(vol)
+    fft.iterate(a, ratio, 3)
+    direct.iterate(b, ratio, 3)
+    assert _rel(a.cpu().numpy(), b.cpu().numpy().astype(np.float64)) < 1e-4

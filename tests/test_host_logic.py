@@ -68,3 +68,17 @@ def test_pair_enumeration_and_layers():
     p = X.NCC_parms_t(25, 25, 10)
     assert (p.wRangeThr_i, p.wRangeThr_j, p.wRangeThr_k, p.INF_W) == (25, 25, 10, 26)
     assert X.NCC_parms_t(40, 40, 40).wRangeThr_i == 29 and abs(p.widthThr - 0.8) < 1e-7 and p.maxIter == 2
+
+
+def test_fft_good_size_per_axis():
+    """mi_fft_good_size: 2^a * {1,3,9} extents (x: twice such a number; z bounded by the LDS tile)."""
+    from ipp_amd import capi
+    g = capi.lib().mi_fft_good_size
+    assert [g(n, 1) for n in (1, 8, 9, 33, 97, 130, 257, 289, 600, 1100)] == [8, 8, 16, 64, 128, 192, 288, 384, 768, 1152]
+    assert [g(n, 0) for n in (10, 17, 70, 193, 200, 600, 2100)] == [16, 32, 128, 256, 256, 768, 2304]
+    assert [g(n, 2) for n in (61, 100, 530, 2049, 2305)] == [64, 128, 576, 2304, 0]
+    for axis in range(3):
+        for n in range(1, 700, 7):
+            m = g(n, axis)
+            h = m // 2 if axis == 0 else m
+            assert m >= n and any(h % r == 0 and (h // r) & (h // r - 1) == 0 for r in (1, 3, 9))
