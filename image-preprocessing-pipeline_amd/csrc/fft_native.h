@@ -14,8 +14,20 @@ struct NativeDims {
     int dbg;          // timing experiments only: knocks out phases of the z pass (results are then wrong)
 };
 
+// Padded mode: the caller's volume (extents n) sits at offset o inside the transform grid; the x passes apply the boundary
+// rule while loading (zero rule: zeros outside the data; replicate rule: clamped samples inside the window [0, w), zeros beyond)
+// and crop while storing, so no padded copy of the volume exists.
+struct PadWindow {
+    int on = 0;
+    int n[3] = {0, 0, 0};
+    int o[3] = {0, 0, 0};
+    int rep[3] = {0, 0, 0};
+    int w[3] = {0, 0, 0};
+};
+
 struct NativeFft {
     NativeDims dims{};
+    PadWindow pw{};
     DevBuf S, T, G, G_adj, tw;
     bool have_adj = false;  // adjoint = second OTF (G_adj) instead of conj(G)
     const float2* tw_x = nullptr;
@@ -31,6 +43,9 @@ struct NativeFft {
     // placed: the kernel on the circular grid (real, shape F; may alias scratch()); G (or G_adj) <- scale * FFT(placed)
     int build_otf(hipStream_t s, const float* placed, bool adjoint_slot, float scale);
     float* scratch() { return T.as<float>(); }  // F floats, free between convolutions
+    // after the OTFs are built: volumes handed to conv / iterate have extents n (x, y, z) and are padded on the fly
+    void set_window(const int n[3], const int o[3], const int rep[3], const int k[3]);
+    bool can_fuse() const;  // consecutive convolutions may share their x passes (every padded axis follows the zero rule)
     int conv(hipStream_t s, const float* in, bool conj_otf, float* out, int epi_kind, const ConvEpilogue& epi);
     // `conj_otf` selects the adjoint: conj(OTF), or the explicit adjoint OTF when one was given
     // n fused RL iterations on bl in place (lambda = 0, no regularisation step in between)

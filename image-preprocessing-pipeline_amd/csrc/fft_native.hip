@@ -110,6 +110,19 @@ __device__ __forceinline__ constexpr float s16(int k) {
     return sn[k];
 }
 
+// Padded mode (PadWindow::on): the transform grid is larger than the caller's volume.  Source sample of grid coordinate g
+// on axis a (-1: zero): zero rule = the data sits at [o, o + n); replicate rule = clamped samples inside the window [0, w).
+__device__ __forceinline__ int pad_src(const PadWindow& p, int a, int g) {
+    if (p.rep[a]) return g < p.w[a] ? min(max(g - p.o[a], 0), p.n[a] - 1) : -1;
+    const int s = g - p.o[a];
+    return (s >= 0 && s < p.n[a]) ? s : -1;
+}
+// Output sample of grid coordinate g (-1: the grid point is not part of the cropped result)
+__device__ __forceinline__ int pad_dst(const PadWindow& p, int a, int g) {
+    const int s = g - p.o[a];
+    return (s >= 0 && s < p.n[a]) ? s : -1;
+}
+
 // One super-stage, everything about the transform compile-time: R = 2^LR points per lane, radix-2 stages
 // S_LO+LR-1..S_LO (forward, DIF) or S_LO..S_LO+LR-1 (inverse, DIT) on `batch` sequences of length 2^LOGN stored at
 // tile[b * pitch + phys(i)].  tw[e] = exp(-2 pi i e / N).  The twiddle of a butterfly factors into a per-lane
@@ -275,21 +288,49 @@ __device__ __forceinline__ void radix3_stage(float2* tile, int cols, int pitch, 
 // grid: (Y / TY) * Z tiles; tile = TY consecutive rows of one z-plane
 template <int LHX2, int R3>
 __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_x_forward(const float* __restrict__ in, float2* __restrict__ S, NativeDims d,
-                                                         const float2* __restrict__ tw) {
+                                                         const float2* __restrict__ tw, PadWindow pw) {
     extern __shared__ __attribute__((aligned(16))) float2 tile[];
     constexpr int Hx = R3 << LHX2;
     const int TY = d.ty, pitch = row_pitch(Hx);
     const int ytiles = d.ny / TY;
     const unsigned tid_ = pair_tile(blockIdx.x);
     const int z = tid_ / ytiles, y0 = (tid_ % ytiles) * TY;
-    const float4* src = reinterpret_cast<const float4*>(in + ((size_t)z * d.ny + y0) * (size_t)(2 * Hx));
-    const int quads = Hx / 2;  // float4 = 2 complex
-    for (int i = threadIdx.x; i < TY * quads; i += kThreadsXZ) {
-        const int r = i / quads, q = i - r * quads;
-        const float4 v = src[(size_t)r * quads + q];
-        float2* row = tile + r * pitch;
-        row[phys(2 * q)] = make_float2(v.x, v.y);
-        row[phys(2 * q + 1)] = make_float2(v.z, v.w);
+    const int hp = TY / 2, rowq = d.ny / 2;
+    float4* dst = reinterpret_cast<float4*>(S + ((size_t)z * Hx) * d.ny + y0);
+    if (pw.on) {
+        // staged load with the boundary rule; a tile that lies entirely in the zero padding transforms to zeros
+        const int sz = pad_src(pw, 2, z);
+        bool live = false;
+        for (int r = 0; r < TY; ++r) live = live || pad_src(pw, 1, y0 + r) >= 0;
+        if (sz < 0 || !live) {
+            for (int i = threadIdx.x; i < hp * Hx; i += kThreadsXZ) {
+                const int px = i / hp, rp = i - px * hp;
+                dst[(size_t)px * rowq + rp] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+            return;
+        }
+        for (int i = threadIdx.x; i < TY * Hx; i += kThreadsXZ) {
+            const int r = i / Hx, q = i - r * Hx;
+            const int sy = pad_src(pw, 1, y0 + r);
+            float2 v = make_float2(0.0f, 0.0f);
+            if (sy >= 0) {
+                const float* row = in + ((size_t)sz * pw.n[1] + sy) * (size_t)pw.n[0];
+                const int s0 = pad_src(pw, 0, 2 * q), s1 = pad_src(pw, 0, 2 * q + 1);
+                if (s0 >= 0) v.x = row[s0];
+                if (s1 >= 0) v.y = row[s1];
+            }
+            tile[r * pitch + phys(q)] = v;
+        }
+    } else {
+        const float4* src = reinterpret_cast<const float4*>(in + ((size_t)z * d.ny + y0) * (size_t)(2 * Hx));
+        const int quads = Hx / 2;  // float4 = 2 complex
+        for (int i = threadIdx.x; i < TY * quads; i += kThreadsXZ) {
+            const int r = i / quads, q = i - r * quads;
+            const float4 v = src[(size_t)r * quads + q];
+            float2* row = tile + r * pitch;
+            row[phys(2 * q)] = make_float2(v.x, v.y);
+            row[phys(2 * q + 1)] = make_float2(v.z, v.w);
+        }
     }
     __syncthreads();
     if constexpr (R3 > 1) {
@@ -298,8 +339,6 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_x_forward(const float*
     }
     lds_fft<LHX2, false, kThreadsXZ, R3, kMaxLrXZ>(tile, TY * R3, pitch, tw);
     // transposed store: S[z][px][y0 + r], r fastest; one float4 = rows (2 rp, 2 rp + 1) of one px
-    float4* dst = reinterpret_cast<float4*>(S + ((size_t)z * Hx) * d.ny + y0);
-    const int hp = TY / 2, rowq = d.ny / 2;
 #pragma unroll MI_FFT_UNROLL
     for (int i = threadIdx.x; i < hp * Hx; i += kThreadsXZ) {
         const int px = i / hp, rp = i - px * hp;
@@ -466,7 +505,7 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_z_conv(const float2* _
 // convolution): the ratio never touches HBM, and bl is read once and written once per iteration.
 template <int LHX2, int R3, bool FUSE>
 __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_x_inverse(const float2* __restrict__ T, float* __restrict__ out, ConvEpilogue e, NativeDims d,
-                                                         const float2* __restrict__ tw, float2* __restrict__ S_next, int EPI) {
+                                                         const float2* __restrict__ tw, float2* __restrict__ S_next, int EPI, PadWindow pw) {
     extern __shared__ __attribute__((aligned(16))) float2 tile[];
     constexpr int Hx = R3 << LHX2;
     const int TY = d.ty, pitch = row_pitch(Hx);
@@ -475,6 +514,24 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_x_inverse(const float2
     const int z = tid_ / ytiles, y0 = (tid_ % ytiles) * TY;
     const float4* src = reinterpret_cast<const float4*>(T + ((size_t)z * Hx) * d.ny + y0);
     const int hp = TY / 2, rowq = d.ny / 2;
+    int oz = z;
+    if (pw.on) {
+        // rows outside the cropped result are never stored: a tile without any is skipped (fused: its part of the next
+        // convolution's input is the zero padding)
+        oz = pad_dst(pw, 2, z);
+        bool live = false;
+        for (int r = 0; r < TY; ++r) live = live || pad_dst(pw, 1, y0 + r) >= 0;
+        if (oz < 0 || !live) {
+            if (FUSE) {
+                float4* sdst = reinterpret_cast<float4*>(S_next + ((size_t)z * Hx) * d.ny + y0);
+                for (int i = threadIdx.x; i < hp * Hx; i += kThreadsXZ) {
+                    const int px = i / hp, rp = i - px * hp;
+                    sdst[(size_t)px * rowq + rp] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                }
+            }
+            return;
+        }
+    }
 #pragma unroll MI_FFT_UNROLL
     for (int i = threadIdx.x; i < hp * Hx; i += kThreadsXZ) {
         const int px = i / hp, rp = i - px * hp;
@@ -490,38 +547,68 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_x_inverse(const float2
             __syncthreads();
         }
     }
-    const size_t row0 = ((size_t)z * d.ny + y0) * (size_t)(2 * Hx);
-    const int quads = Hx / 2;
-    float4* dst = reinterpret_cast<float4*>(out + row0);
-    const float4* a4 = reinterpret_cast<const float4*>(e.a + row0);
-    const float4* b4 = reinterpret_cast<const float4*>(e.b + row0);
-    for (int i = threadIdx.x; i < TY * quads; i += kThreadsXZ) {
-        const int r = i / quads, q = i - r * quads;
-        const float2* row = tile + r * pitch;
-        const float2 c0 = row[phys(2 * q)], c1 = row[phys(2 * q + 1)];
-        float4 c = make_float4(c0.x, c0.y, c1.x, c1.y), o;
-        const size_t gi = (size_t)r * quads + q;
-        if (EPI == EPI_NONE) {
-            o = c;
-        } else {
-            const float4 av = a4[gi];
-            if (EPI == EPI_RATIO) {
-                o = make_float4(av.x / fmaxf(c.x, kEpsSingle), av.y / fmaxf(c.y, kEpsSingle), av.z / fmaxf(c.z, kEpsSingle),
-                                av.w / fmaxf(c.w, kEpsSingle));
-            } else if (EPI == EPI_UPDATE) {
-                o = make_float4(fabsf(av.x * c.x), fabsf(av.y * c.y), fabsf(av.z * c.z), fabsf(av.w * c.w));
-            } else {
-                const float4 bv = b4[gi];
-                const float l = e.lambda, m = 1.0f - e.lambda;
-                o = make_float4(fabsf(av.x * c.x * m + bv.x * l), fabsf(av.y * c.y * m + bv.y * l), fabsf(av.z * c.z * m + bv.z * l),
-                                fabsf(av.w * c.w * m + bv.w * l));
+    if (pw.on) {
+        // crop + epilogue on the caller's (unpadded) volume; fused: the zero padding of the next input is re-created
+        const float l = e.lambda, m = 1.0f - e.lambda;
+        for (int i = threadIdx.x; i < TY * Hx; i += kThreadsXZ) {
+            const int r = i / Hx, q = i - r * Hx;
+            const int oy = pad_dst(pw, 1, y0 + r);
+            float2* cell = tile + r * pitch + phys(q);
+            const float2 c = *cell;
+            float2 o = make_float2(0.0f, 0.0f);
+            if (oy >= 0) {
+                const size_t rbase = ((size_t)oz * pw.n[1] + oy) * (size_t)pw.n[0];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int ox = pad_dst(pw, 0, 2 * q + h);
+                    if (ox < 0) continue;
+                    const float cv = h ? c.y : c.x;
+                    const size_t gi = rbase + ox;
+                    float v;
+                    if (EPI == EPI_NONE) v = cv;
+                    else if (EPI == EPI_RATIO) v = e.a[gi] / fmaxf(cv, kEpsSingle);
+                    else if (EPI == EPI_UPDATE) v = fabsf(e.a[gi] * cv);
+                    else v = fabsf(e.a[gi] * cv * m + e.b[gi] * l);
+                    if (!FUSE || out != nullptr) out[gi] = v;
+                    if (h) o.y = v; else o.x = v;
+                }
             }
+            if (FUSE) *cell = o;
         }
-        if (!FUSE || out != nullptr) dst[gi] = o;
-        if (FUSE) {
-            float2* wrow = tile + r * pitch;
-            wrow[phys(2 * q)] = make_float2(o.x, o.y);
-            wrow[phys(2 * q + 1)] = make_float2(o.z, o.w);
+    } else {
+        const size_t row0 = ((size_t)z * d.ny + y0) * (size_t)(2 * Hx);
+        const int quads = Hx / 2;
+        float4* dst = reinterpret_cast<float4*>(out + row0);
+        const float4* a4 = reinterpret_cast<const float4*>(e.a + row0);
+        const float4* b4 = reinterpret_cast<const float4*>(e.b + row0);
+        for (int i = threadIdx.x; i < TY * quads; i += kThreadsXZ) {
+            const int r = i / quads, q = i - r * quads;
+            const float2* row = tile + r * pitch;
+            const float2 c0 = row[phys(2 * q)], c1 = row[phys(2 * q + 1)];
+            float4 c = make_float4(c0.x, c0.y, c1.x, c1.y), o;
+            const size_t gi = (size_t)r * quads + q;
+            if (EPI == EPI_NONE) {
+                o = c;
+            } else {
+                const float4 av = a4[gi];
+                if (EPI == EPI_RATIO) {
+                    o = make_float4(av.x / fmaxf(c.x, kEpsSingle), av.y / fmaxf(c.y, kEpsSingle), av.z / fmaxf(c.z, kEpsSingle),
+                                    av.w / fmaxf(c.w, kEpsSingle));
+                } else if (EPI == EPI_UPDATE) {
+                    o = make_float4(fabsf(av.x * c.x), fabsf(av.y * c.y), fabsf(av.z * c.z), fabsf(av.w * c.w));
+                } else {
+                    const float4 bv = b4[gi];
+                    const float l = e.lambda, m = 1.0f - e.lambda;
+                    o = make_float4(fabsf(av.x * c.x * m + bv.x * l), fabsf(av.y * c.y * m + bv.y * l), fabsf(av.z * c.z * m + bv.z * l),
+                                    fabsf(av.w * c.w * m + bv.w * l));
+                }
+            }
+            if (!FUSE || out != nullptr) dst[gi] = o;
+            if (FUSE) {
+                float2* wrow = tile + r * pitch;
+                wrow[phys(2 * q)] = make_float2(o.x, o.y);
+                wrow[phys(2 * q + 1)] = make_float2(o.z, o.w);
+            }
         }
     }
     if (FUSE) {
@@ -669,7 +756,20 @@ static int launch_lds(K kernel, unsigned grid, int threads, size_t lds, hipStrea
     return launch_check(name);
 }
 
+void NativeFft::set_window(const int n[3], const int o[3], const int rep[3], const int k[3]) {
+    pw.on = 1;
+    for (int a = 0; a < 3; ++a) {
+        pw.n[a] = n[a];
+        pw.o[a] = o[a];
+        pw.rep[a] = rep[a];
+        pw.w[a] = n[a] + k[a] - 1;
+    }
+}
+
+bool NativeFft::can_fuse() const { return !pw.on || !(pw.rep[0] || pw.rep[1] || pw.rep[2]); }
+
 int NativeFft::x_forward(hipStream_t s, const float* in) {
+    const PadWindow pw = this->pw;
     const int Hx = dims.hx, M = dims.ny, L = dims.nz;
     const unsigned xtiles = (unsigned)((size_t)L * (M / dims.ty));
     const size_t xl = lds_bytes(dims.ty, Hx);
@@ -677,7 +777,7 @@ int NativeFft::x_forward(hipStream_t s, const float* in) {
     float2* Sp = S.as<float2>();
     const float2* twx = tw_x;
     int rc = MI_ERR_INVALID;
-#define MI_X(LG, R) case LG * 16 + R: rc = launch_lds(k_x_forward<LG, R>, xtiles, kThreadsXZ, xl, s, "k_x_forward", in, Sp, d, twx); break;
+#define MI_X(LG, R) case LG * 16 + R: rc = launch_lds(k_x_forward<LG, R>, xtiles, kThreadsXZ, xl, s, "k_x_forward", in, Sp, d, twx, pw); break;
     switch (dims.lhx2 * 16 + dims.r3x) { MI_AXIS_CASES(MI_X) default: return fail(MI_ERR_UNSUPPORTED, "native FFT: x length %d", 2 * Hx); }
 #undef MI_X
     return rc;
@@ -726,6 +826,7 @@ int NativeFft::z_conv(hipStream_t s, bool conj_otf) {
 // the untangled spectrum is stored in the z pass' pair layout, times `scale`.
 int NativeFft::build_otf(hipStream_t s, const float* placed, bool adjoint_slot, float scale) {
     MI_REQUIRE(!adjoint_slot || have_adj, "native FFT: no adjoint OTF slot");
+    MI_REQUIRE(!pw.on, "native FFT: build the OTF before setting the pad window");
     MI_TRY(x_forward(s, placed));
     MI_TRY(y_pass(s, false));
     const int Hx = dims.hx, M = dims.ny, L = dims.nz;
@@ -765,11 +866,13 @@ int NativeFft::x_inverse(hipStream_t s, float* out, int epi_kind, const ConvEpil
     const int ek = epi_kind == EPI_TAPER_SHELL ? EPI_NONE : epi_kind;
     MI_REQUIRE(ek == EPI_NONE || ek == EPI_RATIO || ek == EPI_UPDATE || ek == EPI_UPDATE_REG, "native FFT: unknown epilogue %d", epi_kind);
     MI_REQUIRE(!fuse_forward || ek == EPI_RATIO || ek == EPI_UPDATE, "native FFT: only the plain RL epilogues fuse");
+    MI_REQUIRE(!fuse_forward || can_fuse(), "native FFT: a replicate-padded axis cannot fuse consecutive convolutions");
+    const PadWindow w = pw;
     int rc = MI_ERR_INVALID;
 #define MI_XI(LG, R)                                                                                                               \
     case LG * 16 + R:                                                                                                              \
-        rc = fuse_forward ? launch_lds(k_x_inverse<LG, R, true>, xtiles, kThreadsXZ, xl, s, "k_x_inverse<fused>", Tp, out, epi, d, twx, Sp, ek) \
-                          : launch_lds(k_x_inverse<LG, R, false>, xtiles, kThreadsXZ, xl, s, "k_x_inverse", Tp, out, epi, d, twx, Sp, ek);    \
+        rc = fuse_forward ? launch_lds(k_x_inverse<LG, R, true>, xtiles, kThreadsXZ, xl, s, "k_x_inverse<fused>", Tp, out, epi, d, twx, Sp, ek, w) \
+                          : launch_lds(k_x_inverse<LG, R, false>, xtiles, kThreadsXZ, xl, s, "k_x_inverse", Tp, out, epi, d, twx, Sp, ek, w);    \
         break;
     switch (dims.lhx2 * 16 + dims.r3x) { MI_AXIS_CASES(MI_XI) default: return fail(MI_ERR_UNSUPPORTED, "native FFT: x length %d", 2 * Hx); }
 #undef MI_XI
@@ -814,10 +917,12 @@ static int check_aligned(const void* p, const char* what) {
 }
 
 int NativeFft::conv(hipStream_t s, const float* in, bool conj_otf, float* out, int epi_kind, const ConvEpilogue& epi) {
-    MI_TRY(check_aligned(in, "input"));
-    MI_TRY(check_aligned(out, "output"));
-    MI_TRY(check_aligned(epi.a, "epilogue operand"));
-    MI_TRY(check_aligned(epi.b, "epilogue operand"));
+    if (!pw.on) {  // 16-byte accesses on the caller's volumes; the padded mode reads and writes them element-wise
+        MI_TRY(check_aligned(in, "input"));
+        MI_TRY(check_aligned(out, "output"));
+        MI_TRY(check_aligned(epi.a, "epilogue operand"));
+        MI_TRY(check_aligned(epi.b, "epilogue operand"));
+    }
     MI_TRY(x_forward(s, in));
     MI_TRY(middle(s, conj_otf));
     return x_inverse(s, out, epi_kind, epi, false);
@@ -826,8 +931,8 @@ int NativeFft::conv(hipStream_t s, const float* in, bool conj_otf, float* out, i
 // n whole RL iterations (decon.m:162-186 with lambda = 0) in 8 passes each: the x passes of consecutive
 // convolutions are fused, so per iteration bl is read twice and written once and the ratio never exists in HBM.
 int NativeFft::iterate(hipStream_t s, float* bl, int n_iters) {
-    MI_TRY(check_aligned(bl, "bl"));
-    MI_REQUIRE(!have_adj, "native FFT: the fused iteration uses conj(OTF) as the adjoint");
+    if (!pw.on) MI_TRY(check_aligned(bl, "bl"));
+    MI_REQUIRE(can_fuse(), "native FFT: a replicate-padded axis cannot fuse consecutive convolutions");
     if (n_iters <= 0) return MI_OK;
     ConvEpilogue e;
     e.a = bl;

@@ -271,7 +271,16 @@ int FftEngine::init(hipStream_t s, const int n[3], const int k[3], const int bnd
             MI_TRY(launch_check("k_place_psf"));
             MI_TRY(native->build_otf(s, native->scratch(), slot == 1, nscale));
         }
-        if (padded) MI_TRY(real.alloc(sizeof(float) * n_real));  // staging volume of a padded engine
+        if (padded) {  // the x passes pad and crop on the fly: no staging volume
+            int nn[3], oo[3], rep[3], kk[3];
+            for (int d = 0; d < 3; ++d) {
+                nn[d] = ax[d].n;
+                oo[d] = ax[d].o;
+                rep[d] = ax[d].boundary == MI_BOUNDARY_REPLICATE;
+                kk[d] = ax[d].k;
+            }
+            native->set_window(nn, oo, rep, kk);
+        }
         return MI_OK;
     }
     const size_t lengths[3] = {(size_t)F[0], (size_t)F[1], (size_t)F[2]};  // rocFFT: fastest dimension first
@@ -289,8 +298,8 @@ int FftEngine::init(hipStream_t s, const int n[3], const int k[3], const int bnd
 }
 
 int FftEngine::conv(hipStream_t s, const float* in, bool adjoint, float* out, int epi_kind, const ConvEpilogue& epi) {
-    if (native && !padded) return native->conv(s, in, adjoint, out, epi_kind, epi);
-    if (!native) MI_FFT(rocfft_execution_info_set_stream(info, s));
+    if (native) return native->conv(s, in, adjoint, out, epi_kind, epi);
+    MI_FFT(rocfft_execution_info_set_stream(info, s));
     const float* src = in;
     if (padded) {
         hipLaunchKernelGGL(k_stage, dim3(stream_grid(n_real)), dim3(kThreads), 0, s, in, real.as<float>(), ax[0].n, ax[1].n, ax[2].n,
@@ -300,22 +309,18 @@ int FftEngine::conv(hipStream_t s, const float* in, bool adjoint, float* out, in
         MI_TRY(launch_check("k_stage"));
         src = real.as<float>();
     }
-    if (native) {  // padded volume through the hand-written pipeline, in place; the crop + epilogue follows below
-        MI_TRY(native->conv(s, src, adjoint, real.as<float>(), EPI_NONE, ConvEpilogue{}));
-    } else {
-        void* fin[1] = {const_cast<float*>(src)};
-        void* fout[1] = {spec.p};
-        MI_FFT(rocfft_execute(fwd, fin, fout, info));
-        const float2* o = reinterpret_cast<const float2*>(adjoint && have_adj ? otf_adj.p : otf.p);
-        if (adjoint && !have_adj)
-            hipLaunchKernelGGL(k_mul_otf<true>, dim3(stream_grid(n_spec)), dim3(kThreads), 0, s, spec.as<float2>(), o, n_spec);
-        else
-            hipLaunchKernelGGL(k_mul_otf<false>, dim3(stream_grid(n_spec)), dim3(kThreads), 0, s, spec.as<float2>(), o, n_spec);
-        MI_TRY(launch_check("k_mul_otf"));
-        void* iin[1] = {spec.p};
-        void* iout[1] = {real.p};
-        MI_FFT(rocfft_execute(inv, iin, iout, info));
-    }
+    void* fin[1] = {const_cast<float*>(src)};
+    void* fout[1] = {spec.p};
+    MI_FFT(rocfft_execute(fwd, fin, fout, info));
+    const float2* o = reinterpret_cast<const float2*>(adjoint && have_adj ? otf_adj.p : otf.p);
+    if (adjoint && !have_adj)
+        hipLaunchKernelGGL(k_mul_otf<true>, dim3(stream_grid(n_spec)), dim3(kThreads), 0, s, spec.as<float2>(), o, n_spec);
+    else
+        hipLaunchKernelGGL(k_mul_otf<false>, dim3(stream_grid(n_spec)), dim3(kThreads), 0, s, spec.as<float2>(), o, n_spec);
+    MI_TRY(launch_check("k_mul_otf"));
+    void* iin[1] = {spec.p};
+    void* iout[1] = {real.p};
+    MI_FFT(rocfft_execute(inv, iin, iout, info));
     const size_t n_out = (size_t)ax[0].n * ax[1].n * ax[2].n;
     const bool flat = !padded && ((uintptr_t)out % 16) == 0 && (!epi.a || ((uintptr_t)epi.a % 16) == 0) &&
                       (!epi.b || ((uintptr_t)epi.b % 16) == 0);

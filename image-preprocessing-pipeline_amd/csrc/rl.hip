@@ -166,7 +166,7 @@ extern "C" int mi_rl_iterate(mi_rl_ctx* ctx, void* stream, float* bl, float* rat
     MI_REQUIRE(ctx && bl, "mi_rl_iterate: null pointer");
     MI_REQUIRE(n_iters >= 0, "mi_rl_iterate: negative iteration count");
     MI_TRY(use_device(ctx->dev));
-    if (ctx->engine == MI_ENGINE_FFT && ctx->fft->native && !ctx->fft->padded && !ctx->fft->native->have_adj)
+    if (ctx->engine == MI_ENGINE_FFT && ctx->fft->native && ctx->fft->native->can_fuse())
         return ctx->fft->native->iterate(as_stream(stream), bl, n_iters);
     MI_REQUIRE(ratio && ratio != bl, "mi_rl_iterate: this engine needs a ratio scratch volume");
     for (int i = 0; i < n_iters; ++i) {

@@ -98,7 +98,7 @@ PADDED = [((13, 37, 50), (3, 5, 7)), ((40, 61, 90), (9, 11, 13)), ((7, 130, 33),
 
 @pytest.mark.parametrize("shape,kshape", PADDED)
 @pytest.mark.parametrize("boundary", [0, 1])
-def test_padded_conv_through_native_pipeline(dev, shape, kshape, boundary):
+def test_padded_conv_through_native_pipeline(dev, shape, kshape, boundary, monkeypatch):
     """Zero / replicate boundary 'same' convolution of arbitrary shapes on the FFT engine: the volume is staged into a
     2^a * {1,3,9} padded array and runs through the hand-written pipeline; same numbers as the rocFFT route and as the
     direct engine."""
@@ -108,6 +108,7 @@ def test_padded_conv_through_native_pipeline(dev, shape, kshape, boundary):
     ker = rng.random(kshape, dtype=np.float32)
     ker /= ker.sum()
     t, k = torch.from_numpy(img).to(dev), torch.from_numpy(ker).to(dev)
+    monkeypatch.setenv("MI_FFT_NATIVE_INFLATE", "100")
     got = decon.convn_same(t, k, boundary=boundary, engine=2).cpu().numpy()
     direct = decon.convn_same(t, k, boundary=boundary, engine=1).cpu().numpy()
     os.environ["MI_FFT_ROCFFT"] = "1"
@@ -123,13 +124,14 @@ def test_padded_conv_through_native_pipeline(dev, shape, kshape, boundary):
 
 
 @pytest.mark.parametrize("kshape", [(5, 7, 9), (4, 6, 8)])
-def test_spatial_rl_on_fft_engine_uses_explicit_adjoint(dev, kshape):
+def test_spatial_rl_on_fft_engine_uses_explicit_adjoint(dev, kshape, monkeypatch):
     """decon.m spatial flavour (zero boundary, psf_inv given explicitly) on the FFT engine: for even PSF extents the
     adjoint is not conj(OTF), so the native pipeline carries a second OTF."""
     from ipp_amd import capi, decon
     shape = (20, 45, 70)
     psf = R.gaussian_psf(kshape, (1.0, 1.5, 2.0))
     psf_inv = np.ascontiguousarray(psf[::-1, ::-1, ::-1])
+    monkeypatch.setenv("MI_FFT_NATIVE_INFLATE", "100")
     vol = torch.from_numpy(R.bead_volume(shape, seed=5, psf=R.gaussian_psf((5, 5, 5), (1.0, 1.0, 1.0)))).to(dev)
     fft = decon.RLContext(shape, psf, psf_inv, boundary=capi.BOUNDARY_ZERO, engine=capi.ENGINE_FFT, device=dev)
     direct = decon.RLContext(shape, psf, psf_inv, boundary=capi.BOUNDARY_ZERO, engine=capi.ENGINE_DIRECT, device=dev)
@@ -138,3 +140,41 @@ def test_spatial_rl_on_fft_engine_uses_explicit_adjoint(dev, kshape):
     fft.iterate(a, ratio, 3)
     direct.iterate(b, ratio, 3)
     assert _rel(a.cpu().numpy(), b.cpu().numpy().astype(np.float64)) < 1e-4
+
+
+@pytest.mark.parametrize("shape,kshape", [((20, 45, 70), (5, 7, 9)), ((33, 64, 100), (4, 6, 8)), ((9, 200, 31), (3, 3, 5))])
+def test_spatial_rl_fused_iterations_on_padded_grid(dev, shape, kshape, monkeypatch):
+    """Zero-boundary RL (decon.m:25-120 flavour) on the FFT engine: the x passes pad and crop on the fly and consecutive
+    convolutions share them; no ratio scratch is needed.  Same result as half-step calls and as the direct engine."""
+    from ipp_amd import capi, decon
+    psf = R.gaussian_psf(kshape, (1.0, 1.5, 2.0))
+    psf_inv = np.ascontiguousarray(psf[::-1, ::-1, ::-1])
+    vol = torch.from_numpy(R.bead_volume(shape, seed=11, psf=R.gaussian_psf((5, 5, 5), (1.0, 1.0, 1.0)))).to(dev)
+    monkeypatch.setenv("MI_FFT_NATIVE_INFLATE", "100")   # small extents round up a lot: keep the hand-written pipeline anyway
+    fft = decon.RLContext(shape, psf, psf_inv, boundary=capi.BOUNDARY_ZERO, engine=capi.ENGINE_FFT, device=dev)
+    direct = decon.RLContext(shape, psf, psf_inv, boundary=capi.BOUNDARY_ZERO, engine=capi.ENGINE_DIRECT, device=dev)
+    a, b, c = vol.clone(), vol.clone(), vol.clone()
+    ratio = torch.empty_like(vol)
+    fft.iterate(a, None, 5)
+    for _ in range(5):
+        fft.forward_ratio(b, ratio)
+        fft.adjoint_update(ratio, b)
+    direct.iterate(c, ratio, 5)
+    assert _rel(a.cpu().numpy(), b.cpu().numpy().astype(np.float64)) < 1e-5
+    assert _rel(a.cpu().numpy(), c.cpu().numpy().astype(np.float64)) < 1e-4
+
+
+def test_replicate_padded_engine_does_not_fuse(dev, monkeypatch):
+    from ipp_amd import capi, decon
+    monkeypatch.setenv("MI_FFT_NATIVE_INFLATE", "100")
+    psf = R.gaussian_psf((5, 5, 5), (1.0, 1.0, 1.0))
+    ctx = decon.RLContext((16, 40, 50), psf, None, boundary=capi.BOUNDARY_REPLICATE, engine=capi.ENGINE_FFT, device=dev)
+    bl = torch.rand((16, 40, 50), device=dev) + 0.5
+    with pytest.raises(capi.MiError, match="ratio scratch"):
+        ctx.iterate(bl, None, 1)
+    want = bl.clone()
+    ratio = torch.empty_like(bl)
+    ctx.iterate(bl, ratio, 2)
+    direct = decon.RLContext((16, 40, 50), psf, None, boundary=capi.BOUNDARY_REPLICATE, engine=capi.ENGINE_DIRECT, device=dev)
+    direct.iterate(want, ratio, 2)
+    assert _rel(bl.cpu().numpy(), want.cpu().numpy().astype(np.float64)) < 1e-4
