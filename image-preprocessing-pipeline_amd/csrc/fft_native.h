@@ -34,6 +34,7 @@ struct NativeFft {
     const float2* tw_y = nullptr;
     const float2* tw_z = nullptr;
     size_t n_cplx = 0;
+    int n_cu = 256;  // persistent kernels launch one work-group per CU
 
     static bool supported(const int F[3]);
     // smallest supported extent >= n of axis 0 (x), 1 (y), 2 (z); 0 when there is none

@@ -59,6 +59,18 @@ constexpr int kWavesXZ = 4, kMaxLrXZ = MI_FFT_MAXLR;
 constexpr int kThreadsY = 512;    // contiguous pass: two 68-KB work-groups per CU
 
 __device__ __forceinline__ int phys(int i) { return i + (i >> 5); }
+// Work-group barrier that orders LDS traffic only.  Nothing in these kernels communicates through global memory inside a
+// launch, so the barrier must not drain the vector-memory queue: global loads issued before an FFT phase (the next tile,
+// the epilogue operand) stay in flight across the phase's barriers and are waited for at their first use.
+__device__ __forceinline__ int launder(int x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
 // Work-group -> tile numbering.  Dispatch deals consecutive block ids round-robin over the 8 XCDs, so ids b and b + 8
 // are neighbours on one XCD: with half tiles, those two take the two 64-B halves of the same 128-B lines and meet in that
 // XCD's L2.  (Placement only changes speed, never results.)
@@ -71,8 +83,7 @@ __device__ __forceinline__ unsigned pair_tile(unsigned b) {
     return b;
 #endif
 }
-__host__ __device__ __forceinline__ int row_pitch(int n) { return n + (n >> 5) + 1; }
-
+__host__ __device__ constexpr int row_pitch(int n) { return n + (n >> 5) + 1; }
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 __device__ __forceinline__ float2 cmulc(float2 a, float2 b) { return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }  // a*conj(b)
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
@@ -125,10 +136,10 @@ __device__ __forceinline__ int pad_dst(const PadWindow& p, int a, int g) {
 
 // One super-stage, everything about the transform compile-time: R = 2^LR points per lane, radix-2 stages
 // S_LO+LR-1..S_LO (forward, DIF) or S_LO..S_LO+LR-1 (inverse, DIT) on `batch` sequences of length 2^LOGN stored at
-// tile[b * pitch + phys(i)].  tw[e] = exp(-2 pi i e / N).  The twiddle of a butterfly factors into a per-lane
+// tile[b * pitch + phys(i)].  twl[m] = exp(-2 pi i m / 2^(S_LO+LR)), m < 2^S_LO (LDS).  The twiddle of a butterfly factors into a per-lane
 // part (one table look-up per radix-2 stage; none when S_LO == 0) and a per-register constant.
 template <int LOGN, int LR, int S_LO, bool INVERSE, int NT, int R3 = 1>
-__device__ __forceinline__ void super_stage(float2* tile, int batch, int pitch, const float2* __restrict__ tw) {
+__device__ __forceinline__ void super_stage(float2* tile, int batch, int pitch, const float2* twl) {
     constexpr int R = 1 << LR, GL = LOGN - LR, H_LO = 1 << S_LO;
     const int total = batch << GL;
 #pragma unroll 1
@@ -144,12 +155,19 @@ __device__ __forceinline__ void super_stage(float2* tile, int batch, int pitch, 
         float2 v[R];
 #pragma unroll
         for (int j = 0; j < R; ++j) v[j] = H_LO >= 32 ? p0[j * (H_LO + (H_LO >> 5))] : p0[phys(base + j * H_LO)];
+        // per-lane twiddle part of radix-2 stage S_LO + bpos: exp(-2 pi i m / 2^(S_LO + bpos + 1)).  One table look-up (the
+        // finest angle, bpos = LR - 1; the packed table of this super-stage sits in LDS) and LR - 1 squarings
+        float2 wst[LR];
+        if (S_LO > 0) {
+            wst[LR - 1] = twl[m];
+#pragma unroll
+            for (int b = LR - 2; b >= 0; --b) wst[b] = make_float2(wst[b + 1].x * wst[b + 1].x - wst[b + 1].y * wst[b + 1].y, 2.0f * wst[b + 1].x * wst[b + 1].y);
+        }
 #pragma unroll
         for (int step = 0; step < LR; ++step) {
             const int bpos = INVERSE ? step : LR - 1 - step;  // local bit handled by this radix-2 stage
-            const int s = S_LO + bpos;
             float2 wb = make_float2(1.0f, 0.0f);
-            if (S_LO > 0) wb = tw[m << (LOGN - 1 - s)];
+            if (S_LO > 0) wb = wst[bpos];
 #pragma unroll
             for (int j = 0; j < R; ++j) {
                 if (j & (1 << bpos)) continue;
@@ -185,16 +203,88 @@ __host__ __device__ constexpr int first_r(int rem, int maxlr) {
     return rem <= maxlr ? rem : (rem == maxlr + 1 ? (maxlr + 1) / 2 : maxlr);
 }
 
-// full transform of `batch` LDS rows as a compile-time chain of super-stages (at most 4 radix-2 stages each); the
-// caller issues __syncthreads() before (tile filled); one follows every super-stage, so the tile is consistent on return
+// LDS twiddle tables.  Every super-stage with S_LO > 0 owns a packed table of 2^S_LO entries (stride-1 look-ups: no bank
+// conflicts, and no vector-memory loads inside the FFT phases -- those would drain the prefetch queue, vmcnt being in order);
+// the tables of a chain lie one after the other in chain order.
+__host__ __device__ constexpr int chain_entries(int logn, bool inverse, int maxlr) {
+    int total = 0, done = 0;
+    while (done < logn) {
+        const int r = first_r(logn - done, maxlr);
+        const int s_lo = inverse ? done : logn - done - r;
+        if (s_lo > 0) total += 1 << s_lo;
+        done += r;
+    }
+    return total;
+}
+// twiddle entries in LDS for an axis of length n = r3 * 2^l2
+__host__ __device__ constexpr int axis_tw_entries(int n, int maxlr, bool fwd, bool inv) {
+    int r3 = 1, l2 = 0;
+    while (n % 3 == 0) { n /= 3; r3 *= 3; }
+    while ((1 << l2) < n) ++l2;
+    return (fwd ? chain_entries(l2, false, maxlr) : 0) + (inv ? chain_entries(l2, true, maxlr) : 0) + (r3 > 1 ? (1 << l2) : 0);
+}
+constexpr int kLdsOneWg = 152 * 1024;  // one work-group per CU (160 KB LDS)
+constexpr int kLdsTwoWg = 78 * 1024;   // two work-groups per CU
+// rows of an x tile / line pairs of a z tile: 16 (full 128-B lines in the transposed layouts) while tile + tables fit one
+// work-group per CU; columns of a y tile: two work-groups per CU
+__host__ __device__ constexpr int x_tile_rows(int hx, int maxlr) {
+    int rows = 16;
+    while (rows > 2 && 8 * (rows * row_pitch(hx) + axis_tw_entries(hx, maxlr, true, true)) > kLdsOneWg) rows >>= 1;
+    return rows;
+}
+__host__ __device__ constexpr int z_tile_lines(int nz, int maxlr) {
+    int tl = 16;
+    while (tl > 2 && 8 * (2 * tl * row_pitch(nz) + axis_tw_entries(nz, maxlr, true, true)) > kLdsOneWg) tl >>= 1;
+    return tl;
+}
+__host__ __device__ constexpr int y_tile_cols(int ny, int maxlr) {
+    int tc = 16;
+    while (tc > 1 && 8 * (tc * row_pitch(ny) + axis_tw_entries(ny, maxlr, true, true)) > kLdsTwoWg) tc >>= 1;
+    return tc;
+}
+
+// gather the chain's tables from the global table tw[e] = exp(-2 pi i e / 2^LOGN), e < 2^(LOGN-1)
+template <int LOGN, bool INVERSE, int NT, int MAXLR, int DONE = 0>
+__device__ __forceinline__ void fill_chain_tw(float2* twl, const float2* __restrict__ tw) {
+    if constexpr (DONE < LOGN) {
+        constexpr int r = first_r(LOGN - DONE, MAXLR);
+        constexpr int s_lo = INVERSE ? DONE : LOGN - DONE - r;
+        if constexpr (s_lo > 0) {
+            for (int m = threadIdx.x; m < (1 << s_lo); m += NT) twl[m] = tw[m << (LOGN - s_lo - r)];
+        }
+        fill_chain_tw<LOGN, INVERSE, NT, MAXLR, DONE + r>(twl + (s_lo > 0 ? (1 << s_lo) : 0), tw);
+    }
+}
+// LDS layout behind the tile of an axis kernel: [forward chain][inverse chain][radix-3/9 table: exp(-2 pi i n2 / N), n2 < 2^L2]
+template <int L2, int R3, int MAXLR, bool FWD, bool INV>
+struct TwLds {
+    static constexpr int fwd = 0;
+    static constexpr int inv = FWD ? chain_entries(L2, false, MAXLR) : 0;
+    static constexpr int r3 = inv + (INV ? chain_entries(L2, true, MAXLR) : 0);
+    static constexpr int total = r3 + (R3 > 1 ? (1 << L2) : 0);
+    // tw: global table of the axis ([sub/2 power-of-two part][full circle of N when R3 > 1])
+    template <int NT>
+    static __device__ __forceinline__ void fill(float2* twl, const float2* __restrict__ tw) {
+        if constexpr (FWD) fill_chain_tw<L2, false, NT, MAXLR>(twl + fwd, tw);
+        if constexpr (INV) fill_chain_tw<L2, true, NT, MAXLR>(twl + inv, tw);
+        if constexpr (R3 > 1) {
+            const float2* twM = tw + (1 << L2) / 2;
+            for (int n2 = threadIdx.x; n2 < (1 << L2); n2 += NT) twl[r3 + n2] = twM[n2];
+        }
+    }
+};
+
+// full transform of `batch` LDS rows as a compile-time chain of super-stages (at most MAXLR radix-2 stages each); twl: this
+// chain's LDS tables.  The caller issues lds_barrier() before (tile and tables filled); one follows every super-stage, so the
+// tile is consistent on return
 template <int LOGN, bool INVERSE, int NT, int R3 = 1, int MAXLR = MI_FFT_MAXLR, int DONE = 0>
-__device__ __forceinline__ void lds_fft(float2* tile, int batch, int pitch, const float2* __restrict__ tw) {
+__device__ __forceinline__ void lds_fft(float2* tile, int batch, int pitch, const float2* twl) {
     if constexpr (DONE < LOGN) {
         constexpr int r = first_r(LOGN - DONE, MAXLR);
         constexpr int s_lo = INVERSE ? DONE : LOGN - DONE - r;  // forward: top stages first; inverse: bottom first
-        super_stage<LOGN, r, s_lo, INVERSE, NT, R3>(tile, batch, pitch, tw);
-        __syncthreads();
-        lds_fft<LOGN, INVERSE, NT, R3, MAXLR, DONE + r>(tile, batch, pitch, tw);
+        super_stage<LOGN, r, s_lo, INVERSE, NT, R3>(tile, batch, pitch, twl);
+        lds_barrier();
+        lds_fft<LOGN, INVERSE, NT, R3, MAXLR, DONE + r>(tile, batch, pitch, twl + (s_lo > 0 ? (1 << s_lo) : 0));
     }
 }
 
@@ -214,9 +304,9 @@ __device__ __forceinline__ void dft3(float2& a, float2& b, float2& c) {
 
 // radix-R3 stage of the y transform on `cols` LDS rows of length M = R3 * Msub: forward = DIF first stage
 // (DFT over n1 of x[n1 * Msub + n2], times W_M^(n2 k1), stored at k1 * Msub + n2); inverse = its exact reverse.
-// twM[e] = exp(-2 pi i e / M), e < M.
+// tw3[n2] = exp(-2 pi i n2 / M), n2 < Msub (LDS); the twiddles W_M^(n2 q), q < R3, are its powers.
 template <int R3, bool INVERSE, int NT>
-__device__ __forceinline__ void radix3_stage(float2* tile, int cols, int pitch, int msub, const float2* __restrict__ twM) {
+__device__ __forceinline__ void radix3_stage(float2* tile, int cols, int pitch, int msub, const float2* tw3) {
     const int total = cols * msub;
     for (int idx = threadIdx.x; idx < total; idx += NT) {
         const int c = idx / msub, n2 = idx - c * msub;
@@ -225,9 +315,13 @@ __device__ __forceinline__ void radix3_stage(float2* tile, int cols, int pitch, 
         const int sp = msub + (msub >> 5);  // phys() of a multiple of msub (msub is a multiple of 32)
 #pragma unroll
         for (int q = 0; q < R3; ++q) v[q] = row[q * sp + phys(n2)];
+        float2 wq[R3];  // wq[q] = w1^q, by squaring / one multiplication from lower powers (depth <= 3)
+        wq[1] = tw3[n2];
+#pragma unroll
+        for (int q = 2; q < R3; ++q) wq[q] = (q & 1) ? cmul(wq[q - 1], wq[1]) : cmul(wq[q / 2], wq[q / 2]);
         if (INVERSE) {
 #pragma unroll
-            for (int q = 1; q < R3; ++q) v[q] = cmulc(v[q], twM[n2 * q]);
+            for (int q = 1; q < R3; ++q) v[q] = cmulc(v[q], wq[q]);
         }
         if constexpr (R3 == 3) {
             dft3<INVERSE>(v[0], v[1], v[2]);
@@ -277,7 +371,7 @@ __device__ __forceinline__ void radix3_stage(float2* tile, int cols, int pitch, 
         }
         if (!INVERSE) {
 #pragma unroll
-            for (int q = 1; q < R3; ++q) v[q] = cmul(v[q], twM[n2 * q]);
+            for (int q = 1; q < R3; ++q) v[q] = cmul(v[q], wq[q]);
         }
 #pragma unroll
         for (int q = 0; q < R3; ++q) row[q * sp + phys(n2)] = v[q];
@@ -332,12 +426,15 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_x_forward(const float*
             row[phys(2 * q + 1)] = make_float2(v.z, v.w);
         }
     }
-    __syncthreads();
+    using TW = TwLds<LHX2, R3, kMaxLrXZ, true, false>;
+    float2* twl = tile + TY * pitch;
+    TW::template fill<kThreadsXZ>(twl, tw);
+    lds_barrier();
     if constexpr (R3 > 1) {
-        radix3_stage<R3, false, kThreadsXZ>(tile, TY, pitch, 1 << LHX2, tw + (1 << LHX2) / 2);
-        __syncthreads();
+        radix3_stage<R3, false, kThreadsXZ>(tile, TY, pitch, 1 << LHX2, twl + TW::r3);
+        lds_barrier();
     }
-    lds_fft<LHX2, false, kThreadsXZ, R3, kMaxLrXZ>(tile, TY * R3, pitch, tw);
+    lds_fft<LHX2, false, kThreadsXZ, R3, kMaxLrXZ>(tile, TY * R3, pitch, twl + TW::fwd);
     // transposed store: S[z][px][y0 + r], r fastest; one float4 = rows (2 rp, 2 rp + 1) of one px
 #pragma unroll MI_FFT_UNROLL
     for (int i = threadIdx.x; i < hp * Hx; i += kThreadsXZ) {
@@ -366,17 +463,19 @@ __global__ __launch_bounds__(kThreadsY, 4) void k_y_pass(const float2* __restric
         row[phys(2 * q)] = make_float2(v.x, v.y);
         row[phys(2 * q + 1)] = make_float2(v.z, v.w);
     }
-    __syncthreads();
     // tw: [0, Msub/2) table of the power-of-two sub-transform, then [.. + M) full-circle table of the radix-R3 stage
-    const float2* twM = tw + (1 << LY2) / 2;
+    using TW = TwLds<LY2, R3, MI_FFT_MAXLR, !INVERSE, INVERSE>;
+    float2* twl = tile + TC * pitch;
+    TW::template fill<kThreadsY>(twl, tw);
+    lds_barrier();
     if constexpr (!INVERSE && R3 > 1) {
-        radix3_stage<R3, false, kThreadsY>(tile, TC, pitch, 1 << LY2, twM);
-        __syncthreads();
+        radix3_stage<R3, false, kThreadsY>(tile, TC, pitch, 1 << LY2, twl + TW::r3);
+        lds_barrier();
     }
-    lds_fft<LY2, INVERSE, kThreadsY, R3>(tile, TC * R3, pitch, tw);
+    lds_fft<LY2, INVERSE, kThreadsY, R3>(tile, TC * R3, pitch, twl + (INVERSE ? TW::inv : TW::fwd));
     if constexpr (INVERSE && R3 > 1) {
-        radix3_stage<R3, true, kThreadsY>(tile, TC, pitch, 1 << LY2, twM);
-        __syncthreads();
+        radix3_stage<R3, true, kThreadsY>(tile, TC, pitch, 1 << LY2, twl + TW::r3);
+        lds_barrier();
     }
 #pragma unroll MI_FFT_UNROLL
     for (int i = threadIdx.x; i < TC * quads; i += kThreadsY) {
@@ -433,13 +532,16 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_z_conv(const float2* _
         tB[(2 * jp + 1) * pitch + phys(z)] = make_float2(b.z, b.w);
     }
     const float4* Gp = G + ((size_t)plane * M + py0) * L;
-    __syncthreads();
+    using TW = TwLds<LZ2, R3, kMaxLrXZ, true, !BUILD>;
+    float2* twl = tile + 2 * TL * pitch;
+    TW::template fill<kThreadsXZ>(twl, tw);
+    lds_barrier();
     if (!(d.dbg & 1)) {
         if constexpr (R3 > 1) {
-            radix3_stage<R3, false, kThreadsXZ>(tile, 2 * TL, pitch, 1 << LZ2, tw + (1 << LZ2) / 2);
-            __syncthreads();
+            radix3_stage<R3, false, kThreadsXZ>(tile, 2 * TL, pitch, 1 << LZ2, twl + TW::r3);
+            lds_barrier();
         }
-        lds_fft<LZ2, false, kThreadsXZ, R3, kMaxLrXZ>(tile, 2 * TL * R3, pitch, tw);
+        lds_fft<LZ2, false, kThreadsXZ, R3, kMaxLrXZ>(tile, 2 * TL * R3, pitch, twl + TW::fwd);
     }
     // point-wise: element (line j, position pz) of A pairs with (line jB, position pzB) of B
     float sw, cw;
@@ -478,12 +580,12 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_z_conv(const float2* _
         tB[jB * pitch + phys(pzB)] = make_float2(E2.x + O2.y, O2.x - E2.y);
     }
     if constexpr (BUILD) return;
-    __syncthreads();
+    lds_barrier();
     if (!(d.dbg & 4)) {
-        lds_fft<LZ2, true, kThreadsXZ, R3, kMaxLrXZ>(tile, 2 * TL * R3, pitch, tw);
+        lds_fft<LZ2, true, kThreadsXZ, R3, kMaxLrXZ>(tile, 2 * TL * R3, pitch, twl + TW::inv);
         if constexpr (R3 > 1) {
-            radix3_stage<R3, true, kThreadsXZ>(tile, 2 * TL, pitch, 1 << LZ2, tw + (1 << LZ2) / 2);
-            __syncthreads();
+            radix3_stage<R3, true, kThreadsXZ>(tile, 2 * TL, pitch, 1 << LZ2, twl + TW::r3);
+            lds_barrier();
         }
     }
     float4* dA = reinterpret_cast<float4*>(T + (size_t)px * L * M + py0);
@@ -539,12 +641,15 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_x_inverse(const float2
         tile[(2 * rp) * pitch + phys(px)] = make_float2(v.x, v.y);
         tile[(2 * rp + 1) * pitch + phys(px)] = make_float2(v.z, v.w);
     }
-    __syncthreads();
+    using TW = TwLds<LHX2, R3, kMaxLrXZ, FUSE, true>;
+    float2* twl = tile + TY * pitch;
+    TW::template fill<kThreadsXZ>(twl, tw);
+    lds_barrier();
     if (!(d.dbg & 8)) {
-        lds_fft<LHX2, true, kThreadsXZ, R3, kMaxLrXZ>(tile, TY * R3, pitch, tw);
+        lds_fft<LHX2, true, kThreadsXZ, R3, kMaxLrXZ>(tile, TY * R3, pitch, twl + TW::inv);
         if constexpr (R3 > 1) {
-            radix3_stage<R3, true, kThreadsXZ>(tile, TY, pitch, 1 << LHX2, tw + (1 << LHX2) / 2);
-            __syncthreads();
+            radix3_stage<R3, true, kThreadsXZ>(tile, TY, pitch, 1 << LHX2, twl + TW::r3);
+            lds_barrier();
         }
     }
     if (pw.on) {
@@ -612,13 +717,13 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_x_inverse(const float2
         }
     }
     if (FUSE) {
-        __syncthreads();
+        lds_barrier();
         if (!(d.dbg & 16)) {
             if constexpr (R3 > 1) {
-                radix3_stage<R3, false, kThreadsXZ>(tile, TY, pitch, 1 << LHX2, tw + (1 << LHX2) / 2);
-                __syncthreads();
+                radix3_stage<R3, false, kThreadsXZ>(tile, TY, pitch, 1 << LHX2, twl + TW::r3);
+                lds_barrier();
             }
-            lds_fft<LHX2, false, kThreadsXZ, R3, kMaxLrXZ>(tile, TY * R3, pitch, tw);
+            lds_fft<LHX2, false, kThreadsXZ, R3, kMaxLrXZ>(tile, TY * R3, pitch, twl + TW::fwd);
         }
         float4* sdst = reinterpret_cast<float4*>(S_next + ((size_t)z * Hx) * d.ny + y0);
 #pragma unroll MI_FFT_UNROLL
@@ -627,6 +732,112 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_x_inverse(const float2
             const float2 a = tile[(2 * rp) * pitch + phys(px)], b = tile[(2 * rp + 1) * pitch + phys(px)];
             sdst[(size_t)px * rowq + rp] = make_float4(a.x, a.y, b.x, b.y);
         }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------- P5 + P1, pipelined
+// The fused x pass as a persistent kernel: one work-group per CU walks over tiles and keeps HBM busy during the LDS-bound
+// FFT phases -- the epilogue operand of the current tile is requested before the inverse transform and the next tile's
+// spectrum before the forward transform, both into registers (8 float4 each for a 16 x 1024 tile); stores drain behind.
+// Unpadded volumes only (the padded mode keeps k_x_inverse).
+template <int LHX2, int R3>
+__global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_x_fused_pipe(const float2* __restrict__ T, float* __restrict__ out, ConvEpilogue e, NativeDims d,
+                                                            const float2* __restrict__ tw, float2* __restrict__ S_next, int EPI, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) float2 tile[];
+    constexpr int Hx = R3 << LHX2;
+    constexpr int TY = x_tile_rows(Hx, kMaxLrXZ), hp = TY / 2, quads = Hx / 2;
+    constexpr int NQ = hp * Hx;  // float4 per tile, in the transposed (T / S) and in the row (bl) view alike
+    constexpr int NPF = (NQ + kThreadsXZ - 1) / kThreadsXZ;
+    constexpr int pitch = row_pitch(Hx);
+    const int ytiles = d.ny / TY, rowq = d.ny / 2;
+    float4 pre[NPF];
+    auto tile_base = [&](int t) { const int z = t / ytiles, y0 = (t - z * ytiles) * TY; return ((size_t)z * Hx) * d.ny + y0; };
+    auto load_T = [&](int t) {
+        const int tid = launder(threadIdx.x);
+        const float4* src = reinterpret_cast<const float4*>(T + tile_base(t));
+#pragma unroll
+        for (int j = 0; j < NPF; ++j) {
+            const int i = tid + j * kThreadsXZ;
+            if (NQ % kThreadsXZ == 0 || i < NQ) { const int px = i / hp, rp = i - px * hp; pre[j] = src[(size_t)px * rowq + rp]; }
+        }
+    };
+    using TW = TwLds<LHX2, R3, kMaxLrXZ, true, true>;
+    float2* twl = tile + TY * pitch;
+    TW::template fill<kThreadsXZ>(twl, tw);
+    int t = blockIdx.x;
+    if (t < ntiles) load_T(t);
+    for (; t < ntiles; t += gridDim.x) {
+        // launder(): the per-lane index arithmetic is tile-invariant, and hoisted out of this loop it would pin dozens of
+        // address registers across the FFT phases (spills); recomputing it per phase costs a few VALU ops
+        int tid = launder(threadIdx.x);
+#pragma unroll
+        for (int j = 0; j < NPF; ++j) {
+            const int i = tid + j * kThreadsXZ;
+            if (NQ % kThreadsXZ == 0 || i < NQ) {
+                const int px = i / hp, rp = i - px * hp;
+                tile[(2 * rp) * pitch + phys(px)] = make_float2(pre[j].x, pre[j].y);
+                tile[(2 * rp + 1) * pitch + phys(px)] = make_float2(pre[j].z, pre[j].w);
+            }
+        }
+        // rows of this tile in the real volume: contiguous TY * 2 Hx floats
+        const int z = t / ytiles, y0 = (t - z * ytiles) * TY;
+        const size_t row0 = ((size_t)z * d.ny + y0) * (size_t)(2 * Hx);
+        const float4* a4 = reinterpret_cast<const float4*>(e.a + row0);
+        float4 av[NPF];
+        tid = launder(threadIdx.x);
+#pragma unroll
+        for (int j = 0; j < NPF; ++j) {
+            const int i = tid + j * kThreadsXZ;
+            if (NQ % kThreadsXZ == 0 || i < NQ) av[j] = a4[i];
+        }
+        lds_barrier();
+        lds_fft<LHX2, true, kThreadsXZ, R3, kMaxLrXZ>(tile, TY * R3, pitch, twl + TW::inv);
+        if constexpr (R3 > 1) {
+            radix3_stage<R3, true, kThreadsXZ>(tile, TY, pitch, 1 << LHX2, twl + TW::r3);
+            lds_barrier();
+        }
+        float4* dst = reinterpret_cast<float4*>(out + row0);
+        tid = launder(threadIdx.x);
+#pragma unroll
+        for (int j = 0; j < NPF; ++j) {
+            const int i = tid + j * kThreadsXZ;
+            if (NQ % kThreadsXZ == 0 || i < NQ) {
+                const int r = i / quads, q = i - r * quads;
+                float2* row = tile + r * pitch;
+                const float2 c0 = row[phys(2 * q)], c1 = row[phys(2 * q + 1)];
+                const float4 a = av[j];
+                float4 o;
+                if (EPI == EPI_RATIO)
+                    o = make_float4(a.x / fmaxf(c0.x, kEpsSingle), a.y / fmaxf(c0.y, kEpsSingle), a.z / fmaxf(c1.x, kEpsSingle),
+                                    a.w / fmaxf(c1.y, kEpsSingle));
+                else
+                    o = make_float4(fabsf(a.x * c0.x), fabsf(a.y * c0.y), fabsf(a.z * c1.x), fabsf(a.w * c1.y));
+                if (out != nullptr) dst[i] = o;
+                row[phys(2 * q)] = make_float2(o.x, o.y);
+                row[phys(2 * q + 1)] = make_float2(o.z, o.w);
+            }
+        }
+        const int tn = t + gridDim.x;
+        if (tn < ntiles) load_T(tn);
+        lds_barrier();
+        if constexpr (R3 > 1) {
+            radix3_stage<R3, false, kThreadsXZ>(tile, TY, pitch, 1 << LHX2, twl + TW::r3);
+            lds_barrier();
+        }
+        lds_fft<LHX2, false, kThreadsXZ, R3, kMaxLrXZ>(tile, TY * R3, pitch, twl + TW::fwd);
+        float4* sdst = reinterpret_cast<float4*>(S_next + tile_base(t));
+        tid = launder(threadIdx.x);
+#pragma unroll
+        for (int j = 0; j < NPF; ++j) {
+            const int i = tid + j * kThreadsXZ;
+            if (NQ % kThreadsXZ == 0 || i < NQ) {
+                const int px = i / hp, rp = i - px * hp;
+                const float2 a = tile[(2 * rp) * pitch + phys(px)], b = tile[(2 * rp + 1) * pitch + phys(px)];
+                sdst[(size_t)px * rowq + rp] = make_float4(a.x, a.y, b.x, b.y);
+            }
+        }
+        lds_barrier();  // the tile is free for the next fill
     }
 }
 
@@ -667,7 +878,11 @@ int NativeFft::good_size(int n, int axis) {
         if (split_axis(m, &r3, &l2)) return (axis == 2 && m > kMaxZ) ? 0 : m;
 }
 
-static size_t lds_bytes(int rows, int n) { return sizeof(float2) * (size_t)rows * row_pitch(n); }
+// LDS of an axis kernel: the tile, then the twiddle tables (both chains and the radix-3/9 table: what the fused kernels of
+// the axis use, an upper bound for the others; see TwLds)
+static size_t lds_bytes(int rows, int n, int maxlr) {
+    return sizeof(float2) * ((size_t)rows * row_pitch(n) + axis_tw_entries(n, maxlr, true, true));
+}
 
 int NativeFft::init(hipStream_t s, const int F[3], bool explicit_adjoint) {
     MI_REQUIRE(supported(F), "native FFT: unsupported shape %d x %d x %d", F[0], F[1], F[2]);
@@ -678,25 +893,9 @@ int NativeFft::init(hipStream_t s, const int F[3], bool explicit_adjoint) {
     dims.hx = Hx;
     dims.ny = F[1];
     dims.nz = F[2];
-    const size_t budget = 68 * 1024;  // two work-groups per CU inside 160 KB
-    auto fit = [&](int n, int maxrows, int mult) {
-        int rows = maxrows;
-        while (rows > 1 && (lds_bytes(rows * mult, n) > budget)) rows >>= 1;
-        return rows;
-    };
-#if MI_FFT_HALF_TILES
-    const size_t big = 68 * 1024;
-#else
-    const size_t big = 140 * 1024;  // one work-group per CU for the strided passes: 16-wide tiles = full 128-B lines
-#endif
-    auto fit_big = [&](int n, int maxrows, int mult) {
-        int rows = maxrows;
-        while (rows > 2 && (lds_bytes(rows * mult, n) > big)) rows >>= 1;
-        return rows;
-    };
-    dims.ty = std::min(fit_big(Hx, 16, 1), F[1]);
-    dims.tc = std::min(fit(F[1], 16, 1), 1 << 30);
-    dims.tl = std::min(fit_big(F[2], 16, 2), F[1]);
+    dims.ty = std::min(x_tile_rows(Hx, kMaxLrXZ), F[1]);
+    dims.tc = y_tile_cols(F[1], MI_FFT_MAXLR);
+    dims.tl = std::min(z_tile_lines(F[2], kMaxLrXZ), F[1]);
     dims.dbg = 0;
     if (const char* e = std::getenv("MI_FFT_ZDBG")) dims.dbg = atoi(e);  // phase knock-out for timing experiments
     // tuning overrides (experiments only): MI_FFT_TY / MI_FFT_TC / MI_FFT_TL
@@ -708,7 +907,8 @@ int NativeFft::init(hipStream_t s, const int F[3], bool explicit_adjoint) {
     // mirror blocks, which holds for TL <= 2^ly2 (positions inside one power-of-two sub-block mirror inside one)
     MI_REQUIRE(dims.ty >= 2 && dims.ty % 2 == 0 && F[1] % dims.ty == 0, "native FFT: x tile of %d rows does not divide y = %d", dims.ty, F[1]);
     MI_REQUIRE(dims.tl >= 2 && is_pow2(dims.tl) && dims.tl <= (1 << dims.ly2), "native FFT: z tile of %d lines does not fit y = %d", dims.tl, F[1]);
-    MI_REQUIRE(lds_bytes(dims.ty, Hx) <= 150 * 1024 && lds_bytes(dims.tc, F[1]) <= 150 * 1024 && lds_bytes(2 * dims.tl, F[2]) <= 150 * 1024,
+    MI_REQUIRE(lds_bytes(dims.ty, Hx, kMaxLrXZ) <= 160 * 1024 && lds_bytes(dims.tc, F[1], MI_FFT_MAXLR) <= 160 * 1024 &&
+                   lds_bytes(2 * dims.tl, F[2], kMaxLrXZ) <= 160 * 1024,
                "native FFT: transform too long for LDS");
     n_cplx = (size_t)Hx * F[1] * F[2];
     MI_TRY(S.alloc(sizeof(float2) * n_cplx));
@@ -734,6 +934,12 @@ int NativeFft::init(hipStream_t s, const int F[3], bool explicit_adjoint) {
     tw_x = tw.as<float2>() + offs[0];
     tw_y = tw.as<float2>() + offs[1];
     tw_z = tw.as<float2>() + offs[2];
+    {
+        int devid = 0, cus = 0;
+        MI_HIP(hipGetDevice(&devid));
+        MI_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, devid));
+        n_cu = cus > 0 ? cus : 256;
+    }
     have_adj = explicit_adjoint;
     if (have_adj) MI_TRY(G_adj.alloc(G.bytes));  // explicit adjoint kernel (psf_inv of the 'same'-convolution flavour) instead of conj(OTF)
     MI_HIP(hipStreamSynchronize(s));  // host twiddle vector dies at scope exit
@@ -772,7 +978,7 @@ int NativeFft::x_forward(hipStream_t s, const float* in) {
     const PadWindow pw = this->pw;
     const int Hx = dims.hx, M = dims.ny, L = dims.nz;
     const unsigned xtiles = (unsigned)((size_t)L * (M / dims.ty));
-    const size_t xl = lds_bytes(dims.ty, Hx);
+    const size_t xl = lds_bytes(dims.ty, Hx, kMaxLrXZ);
     const NativeDims d = dims;
     float2* Sp = S.as<float2>();
     const float2* twx = tw_x;
@@ -786,7 +992,7 @@ int NativeFft::x_forward(hipStream_t s, const float* in) {
 int NativeFft::y_pass(hipStream_t s, bool inverse) {
     const int Hx = dims.hx, M = dims.ny, L = dims.nz;
     const unsigned ycols = (unsigned)((size_t)L * Hx / dims.tc);
-    const size_t yl = lds_bytes(dims.tc, M);
+    const size_t yl = lds_bytes(dims.tc, M, MI_FFT_MAXLR);
     const NativeDims d = dims;
     const float2* src = S.as<float2>();
     float2* dst = T.as<float2>();
@@ -805,7 +1011,7 @@ int NativeFft::y_pass(hipStream_t s, bool inverse) {
 int NativeFft::z_conv(hipStream_t s, bool conj_otf) {
     const int Hx = dims.hx, M = dims.ny, L = dims.nz;
     const unsigned ztiles = (unsigned)((size_t)(Hx / 2 + 1) * (M / dims.tl));
-    const size_t zl = lds_bytes(2 * dims.tl, L);
+    const size_t zl = lds_bytes(2 * dims.tl, L, kMaxLrXZ);
     const NativeDims d = dims;
     const float2* Tp = T.as<float2>();
     float2* Sp = S.as<float2>();
@@ -831,7 +1037,7 @@ int NativeFft::build_otf(hipStream_t s, const float* placed, bool adjoint_slot, 
     MI_TRY(y_pass(s, false));
     const int Hx = dims.hx, M = dims.ny, L = dims.nz;
     const unsigned ztiles = (unsigned)((size_t)(Hx / 2 + 1) * (M / dims.tl));
-    const size_t zl = lds_bytes(2 * dims.tl, L);
+    const size_t zl = lds_bytes(2 * dims.tl, L, kMaxLrXZ);
     const NativeDims d = dims;
     const float2* Tp = T.as<float2>();
     float2* Sp = S.as<float2>();
@@ -858,7 +1064,7 @@ int NativeFft::middle(hipStream_t s, bool conj_otf) {
 int NativeFft::x_inverse(hipStream_t s, float* out, int epi_kind, const ConvEpilogue& epi, bool fuse_forward) {
     const int Hx = dims.hx, M = dims.ny, L = dims.nz;
     const unsigned xtiles = (unsigned)((size_t)L * (M / dims.ty));
-    const size_t xl = lds_bytes(dims.ty, Hx);
+    const size_t xl = lds_bytes(dims.ty, Hx, kMaxLrXZ);
     const NativeDims d = dims;
     const float2* Tp = T.as<float2>();
     float2* Sp = S.as<float2>();
@@ -869,6 +1075,15 @@ int NativeFft::x_inverse(hipStream_t s, float* out, int epi_kind, const ConvEpil
     MI_REQUIRE(!fuse_forward || can_fuse(), "native FFT: a replicate-padded axis cannot fuse consecutive convolutions");
     const PadWindow w = pw;
     int rc = MI_ERR_INVALID;
+    static const bool no_pipe = std::getenv("MI_FFT_NO_PIPE") != nullptr;
+    if (fuse_forward && !pw.on && dims.dbg == 0 && !no_pipe && dims.ty == x_tile_rows(Hx, kMaxLrXZ)) {
+        const int ntiles = (int)xtiles;
+        const unsigned grid = (unsigned)std::min(ntiles, n_cu);
+#define MI_XP(LG, R) case LG * 16 + R: rc = launch_lds(k_x_fused_pipe<LG, R>, grid, kThreadsXZ, xl, s, "k_x_fused_pipe", Tp, out, epi, d, twx, Sp, ek, ntiles); break;
+        switch (dims.lhx2 * 16 + dims.r3x) { MI_AXIS_CASES(MI_XP) default: return fail(MI_ERR_UNSUPPORTED, "native FFT: x length %d", 2 * Hx); }
+#undef MI_XP
+        return rc;
+    }
 #define MI_XI(LG, R)                                                                                                               \
     case LG * 16 + R:                                                                                                              \
         rc = fuse_forward ? launch_lds(k_x_inverse<LG, R, true>, xtiles, kThreadsXZ, xl, s, "k_x_inverse<fused>", Tp, out, epi, d, twx, Sp, ek, w) \
