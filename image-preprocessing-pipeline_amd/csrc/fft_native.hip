@@ -33,57 +33,72 @@
 namespace mi {
 namespace {
 
-// super-stage size / unroll knobs (see first_r below)
 #ifndef MI_FFT_UNROLL
 #define MI_FFT_UNROLL 4
 #endif
-#ifndef MI_FFT_MAXLR
-#define MI_FFT_MAXLR 3
-#endif
-#ifndef MI_FFT_HALF_TILES
-#define MI_FFT_HALF_TILES 0
-#endif
-#if MI_FFT_HALF_TILES
-constexpr int kThreadsXZ = 512;   // strided passes: two 68-KB work-groups per CU, 8-wide tiles; the two halves of a
-                                  // 128-B line are owned by consecutive work-groups of ONE XCD (pair_tile below)
-#elif defined(MI_FFT_XZ512)
-constexpr int kThreadsXZ = 512;   // experiment: 8 waves per CU, 256 VGPRs -> 16-point butterflies
-#else
-constexpr int kThreadsXZ = 1024;  // strided passes: one 135-KB work-group per CU, 16 waves
-#endif
-#ifdef MI_FFT_XZ512
-constexpr int kWavesXZ = 2, kMaxLrXZ = 4;
-#else
-constexpr int kWavesXZ = 4, kMaxLrXZ = MI_FFT_MAXLR;
-#endif
-constexpr int kThreadsY = 512;    // contiguous pass: two 68-KB work-groups per CU
+constexpr int kThreadsXZ = 1024;  // strided passes: one ~140-KB work-group of 16 waves per CU
+constexpr int kWavesXZ = 4;       // waves per SIMD the register budget is sized for (128 VGPRs)
+constexpr int kThreadsY = 512;    // contiguous pass: two work-groups per CU
 
-__device__ __forceinline__ int phys(int i) { return i + (i >> 5); }
-// Work-group barrier that orders LDS traffic only.  Nothing in these kernels communicates through global memory inside a
-// launch, so the barrier must not drain the vector-memory queue: global loads issued before an FFT phase (the next tile,
-// the epilogue operand) stay in flight across the phase's barriers and are waited for at their first use.
+// ------------------------------------------------------------------------------------------------ LDS image
+// Element i (8 B) of a row sits at slot i ^ G(bits 4..7 of i) ^ rmask(row).  DS traffic is banked per instruction
+// (MI355X_MICROARCH.md "LDS"): ds_read_b64 serves 32 lanes per LDS cycle from 64 dword banks, i.e. it is conflict-free when
+// the 32 slots differ mod 32; ds_write_b64 serves 16 lanes from 32 dword banks (slots must differ mod 16).  G is GF(2)-linear
+// with columns (15, 13, 25, 16) for bits 4..7: with it every butterfly pattern of the super-stage chains below ((0,3), (3,3),
+// (3,2), (3,1) and all S_LO >= 5), the stride-2 row accesses and -- together with rmask -- the transposed tile accesses are
+// conflict-free under both rules.  (An additive pad of one slot per 32 leaves 2- and 4-way conflicts on the stages with
+// 0 < S_LO < 5: 43 % of the LDS cycles of the x pass were conflict cycles, profiles/r01_sq_counters.txt.)
+__host__ __device__ constexpr int swz_g(int t) { return ((t & 1) ? 15 : 0) ^ ((t & 2) ? 13 : 0) ^ ((t & 4) ? 25 : 0) ^ ((t & 8) ? 16 : 0); }
+__host__ __device__ constexpr int swz_c(int i) { return i ^ swz_g((i >> 4) & 15); }
+__host__ __device__ constexpr unsigned long long swz_table_hi() {  // G restricted to bits 5..7, 8 entries of 5 bits
+    unsigned long long v = 0;
+    for (int t = 0; t < 8; ++t) v |= (unsigned long long)swz_g(2 * t) << (5 * t);
+    return v;
+}
+__device__ __forceinline__ int phys(int i) {
+    constexpr unsigned long long T = swz_table_hi();
+    const int hi = (int)((T >> (5 * ((i >> 5) & 7))) & 31ull);
+    return i ^ hi ^ (__builtin_amdgcn_sbfe(i, 4, 1) & 15);
+}
+// Rows: the transposed accesses of the x and z passes put `hp` row pairs x (32 / hp) consecutive elements into one lane group
+// (16 / hp for a store); row 2 rp (+1) is XOR-ed with a mask that spreads the rp bits over the banks the elements leave free.
+__device__ __forceinline__ int rmask(int row, int hp) {
+    const int rp = (row >> 1) & (hp - 1);
+    const int s = hp == 8 ? 1 : hp == 4 ? 2 : hp == 2 ? 3 : 0;
+    return (rp << s) ^ ((rp & 1) << 4);
+}
+// rows start on a multiple of 32 slots, so that only the masks decide the banks
+__host__ __device__ constexpr int row_pitch(int n) { return (n + 31) & ~31; }
+
 __device__ __forceinline__ int launder(int x) {
     asm volatile("" : "+v"(x));
     return x;
 }
+// Work-group barrier that orders LDS traffic only.  Nothing in these kernels communicates through global memory inside a
+// launch, so the barrier must not drain the vector-memory queue: global loads issued before an FFT phase (the next tile,
+// the epilogue operand) stay in flight across the phase's barriers and are waited for at their first use.
 __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
-// Work-group -> tile numbering.  Dispatch deals consecutive block ids round-robin over the 8 XCDs, so ids b and b + 8
-// are neighbours on one XCD: with half tiles, those two take the two 64-B halves of the same 128-B lines and meet in that
-// XCD's L2.  (Placement only changes speed, never results.)
-__device__ __forceinline__ unsigned pair_tile(unsigned b) {
-#if MI_FFT_HALF_TILES
-    if (gridDim.x & 15u) return b;  // the pairing is a bijection only on multiples of 16 work-groups
-    const unsigned xcd = b & 7u, local = b >> 3;
-    return (local >> 1) * 16u + xcd * 2u + (local & 1u);
-#else
-    return b;
-#endif
+// Wave-level ordering of LDS traffic: DS operations of one wave execute in order, so data a wave wrote is visible to its own
+// later reads (any lane) without a barrier; the fence only keeps the compiler from reordering them.
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
 }
-__host__ __device__ constexpr int row_pitch(int n) { return n + (n >> 5) + 1; }
+
+// between two phases on a tile: rows private to their owner waves need no work-group barrier
+__device__ __forceinline__ void stage_sync(bool priv) {
+    if (priv) wave_lds_fence();
+    else lds_barrier();
+}
+
+// 1 / max(c, eps) of the RL ratio step (decon.m:164) with the hardware reciprocal (1 ulp): the IEEE division sequence costs
+// 11 VALU instructions per value, a sixth of the fused x pass, for a difference far inside the fp32 noise of the transforms
+__device__ __forceinline__ float rcp_eps(float c) { return __builtin_amdgcn_rcpf(fmaxf(c, kEpsSingle)); }
+
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 __device__ __forceinline__ float2 cmulc(float2 a, float2 b) { return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }  // a*conj(b)
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
@@ -108,19 +123,6 @@ __device__ __forceinline__ int mirror_pos(int p, int n, int l2, int r3) {
 __device__ __forceinline__ int y_pos2freq(int p, const NativeDims& d) { return pos2freq(p, d.ly2, d.r3); }
 __device__ __forceinline__ int y_mirror_pos(int p, const NativeDims& d) { return mirror_pos(p, d.ny, d.ly2, d.r3); }
 
-// exp(-2 pi i m / 2^(bpos+1)), m < 2^bpos, bpos <= 3: the part of a butterfly twiddle that depends only on the
-// register index, as compile-time constants (cos/sin of multiples of 2 pi / 16)
-__device__ __forceinline__ constexpr float c16(int k) {
-    constexpr float c[8] = {1.0f, 0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f,
-                            0.0f, -0.38268343236508977f, -0.70710678118654752f, -0.92387953251128674f};
-    return c[k];
-}
-__device__ __forceinline__ constexpr float s16(int k) {
-    constexpr float sn[8] = {0.0f, 0.38268343236508977f, 0.70710678118654752f, 0.92387953251128674f,
-                             1.0f, 0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f};
-    return sn[k];
-}
-
 // Padded mode (PadWindow::on): the transform grid is larger than the caller's volume.  Source sample of grid coordinate g
 // on axis a (-1: zero): zero rule = the data sits at [o, o + n); replicate rule = clamped samples inside the window [0, w).
 __device__ __forceinline__ int pad_src(const PadWindow& p, int a, int g) {
@@ -134,29 +136,161 @@ __device__ __forceinline__ int pad_dst(const PadWindow& p, int a, int g) {
     return (s >= 0 && s < p.n[a]) ? s : -1;
 }
 
+// exp(-2 pi i m / 2^(bpos+1)), m < 2^bpos, bpos <= 3: the part of a butterfly twiddle that depends only on the
+// register index, as compile-time constants (cos/sin of multiples of 2 pi / 16)
+__device__ __forceinline__ constexpr float c16(int k) {
+    constexpr float c[8] = {1.0f, 0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f,
+                            0.0f, -0.38268343236508977f, -0.70710678118654752f, -0.92387953251128674f};
+    return c[k];
+}
+__device__ __forceinline__ constexpr float s16(int k) {
+    constexpr float sn[8] = {0.0f, 0.38268343236508977f, 0.70710678118654752f, 0.92387953251128674f,
+                             1.0f, 0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f};
+    return sn[k];
+}
+
+// ------------------------------------------------------------------------------------------------ super-stage chains
+// The log2(N) radix-2 stages of a transform are cut, bottom-up, into super-stages of 3 stages (8 points per lane in
+// registers; a remainder of 4 becomes 2 + 2, a remainder of 1 or 2 sits at the top): seg_r(logn, s) is the length of the
+// super-stage that starts at stage s.  The same cut serves both directions (forward walks it top-down, inverse bottom-up),
+// and all its (S_LO, LR) pairs below stage 5 are among the conflict-free patterns of the swizzle.
+__host__ __device__ constexpr int seg_r(int logn, int s) {
+    const int rem = logn - s;
+    if (logn == 4) return s == 0 ? 3 : 1;
+    return rem >= 5 ? 3 : rem == 4 ? 2 : rem;  // rem in {1, 2, 3}: all of it
+}
+// start of the super-stage that ends at stage `top` (exclusive)
+__host__ __device__ constexpr int seg_below(int logn, int top) {
+    int s = 0;
+    while (s + seg_r(logn, s) < top) s += seg_r(logn, s);
+    return s;
+}
+// LDS twiddle tables: every super-stage with S_LO > 0 owns a packed table of 2^S_LO entries, exp(-2 pi i m / 2^(S_LO+LR))
+// (stride-1 look-ups: no bank conflicts, and no vector-memory loads inside the FFT phases -- those would drain the prefetch
+// queue, vmcnt being in order); the tables lie one after the other, bottom-up.  tw_off: offset of the table of stage s.
+__host__ __device__ constexpr int tw_off(int logn, int s) {
+    int off = 0, t = 0;
+    while (t < s) {
+        if (t > 0) off += 1 << t;
+        t += seg_r(logn, t);
+    }
+    return off;
+}
+__host__ __device__ constexpr int chain_entries(int logn) { return tw_off(logn, logn); }
+// gather the tables from the global table tw[e] = exp(-2 pi i e / 2^LOGN), e < 2^(LOGN-1)
+template <int LOGN, int NT, int S = 0>
+__device__ __forceinline__ void fill_chain_tw(float2* twl, const float2* __restrict__ tw) {
+    if constexpr (S < LOGN) {
+        constexpr int r = seg_r(LOGN, S);
+        if constexpr (S > 0) {
+            for (int m = threadIdx.x; m < (1 << S); m += NT) twl[tw_off(LOGN, S) + m] = tw[m << (LOGN - S - r)];
+        }
+        fill_chain_tw<LOGN, NT, S + r>(twl, tw);
+    }
+}
+// LDS layout behind the tile of an axis kernel: [chain tables][radix-3/9 table: exp(-2 pi i n2 / N), n2 < 2^L2]
+template <int L2, int R3>
+struct TwLds {
+    static constexpr int r3 = chain_entries(L2);
+    static constexpr int total = r3 + (R3 > 1 ? (1 << L2) : 0);
+    // tw: global table of the axis ([sub/2 power-of-two part][full circle of N when R3 > 1])
+    template <int NT>
+    static __device__ __forceinline__ void fill(float2* twl, const float2* __restrict__ tw) {
+        fill_chain_tw<L2, NT>(twl, tw);
+        if constexpr (R3 > 1) {
+            const float2* twM = tw + (1 << L2) / 2;
+            for (int n2 = threadIdx.x; n2 < (1 << L2); n2 += NT) twl[r3 + n2] = twM[n2];
+        }
+    }
+};
+// twiddle entries in LDS for an axis of length n = r3 * 2^l2
+__host__ __device__ constexpr int axis_tw_entries(int n) {
+    int r3 = 1, l2 = 0;
+    while (n % 3 == 0) { n /= 3; r3 *= 3; }
+    while ((1 << l2) < n) ++l2;
+    return chain_entries(l2) + (r3 > 1 ? (1 << l2) : 0);
+}
+constexpr int kLdsOneWg = 156 * 1024;  // one work-group per CU (160 KB LDS)
+constexpr int kLdsTwoWg = 78 * 1024;   // two work-groups per CU
+// rows of an x tile / line pairs of a z tile: 16 (full 128-B lines in the transposed layouts) while tile + tables fit one
+// work-group per CU; columns of a y tile: two work-groups per CU
+__host__ __device__ constexpr int x_tile_rows(int hx) {
+    int rows = 16;
+    while (rows > 2 && 8 * (rows * row_pitch(hx) + axis_tw_entries(hx)) > kLdsOneWg) rows >>= 1;
+    return rows;
+}
+__host__ __device__ constexpr int z_tile_lines(int nz) {
+    int tl = 16;
+    while (tl > 2 && 8 * (2 * tl * row_pitch(nz) + axis_tw_entries(nz)) > kLdsOneWg) tl >>= 1;
+    return tl;
+}
+__host__ __device__ constexpr int y_tile_cols(int ny) {
+    int tc = 16;
+    while (tc > 1 && 8 * (tc * row_pitch(ny) + axis_tw_entries(ny)) > kLdsTwoWg) tc >>= 1;
+    return tc;
+}
+
+// Sequences of a tile: `batch` = rows * R3 power-of-two sub-transforms of length 2^LOGN; sequence b = row b / R3, sub-block
+// b % R3 (elements [sub << LOGN, (sub + 1) << LOGN) of the row).  PRIV: the rows are dealt to the waves (row r belongs to
+// wave r mod NW) and every phase between two tile-wide barriers touches a row only through its owner, so the super-stages of
+// a chain follow each other without work-group barriers and the waves drift apart (LDS and VALU phases of different waves
+// overlap).  Otherwise the sequences are split over all lanes and a barrier follows every super-stage.
+template <int LOGN, int LR, int NT, int R3>
+struct SeqMap {
+    static constexpr int GL = LOGN - LR, NW = NT / 64;
+    int total, first, step;
+    int wave;
+    bool PRIV;
+    __device__ __forceinline__ SeqMap(int batch, bool priv) : PRIV(priv) {
+        if (PRIV) {
+            wave = threadIdx.x >> 6;
+            total = ((batch / R3) / NW * R3) << GL;  // rows % NW == 0 (checked by the caller)
+            first = threadIdx.x & 63;
+            step = 64;
+        } else {
+            wave = 0;
+            total = batch << GL;
+            first = threadIdx.x;
+            step = NT;
+        }
+    }
+    // work item u -> (row, sub-block, group g)
+    __device__ __forceinline__ void at(int u, int& row, int& sub, int& g) const {
+        int bl = u >> GL;
+        if (GL >= 6) bl = __builtin_amdgcn_readfirstlane(bl);  // 64 consecutive items of a wave share the sequence: SALU row math
+        g = u & ((1 << GL) - 1);
+        if (R3 == 1) {
+            sub = 0;
+            row = PRIV ? bl * NW + wave : bl;
+        } else {
+            const int rl = bl / R3;
+            sub = bl - rl * R3;
+            row = PRIV ? rl * NW + wave : rl;
+        }
+    }
+};
+
 // One super-stage, everything about the transform compile-time: R = 2^LR points per lane, radix-2 stages
-// S_LO+LR-1..S_LO (forward, DIF) or S_LO..S_LO+LR-1 (inverse, DIT) on `batch` sequences of length 2^LOGN stored at
-// tile[b * pitch + phys(i)].  twl[m] = exp(-2 pi i m / 2^(S_LO+LR)), m < 2^S_LO (LDS).  The twiddle of a butterfly factors into a per-lane
-// part (one table look-up per radix-2 stage; none when S_LO == 0) and a per-register constant.
-template <int LOGN, int LR, int S_LO, bool INVERSE, int NT, int R3 = 1>
-__device__ __forceinline__ void super_stage(float2* tile, int batch, int pitch, const float2* twl) {
-    constexpr int R = 1 << LR, GL = LOGN - LR, H_LO = 1 << S_LO;
-    const int total = batch << GL;
+// S_LO+LR-1..S_LO (forward, DIF) or S_LO..S_LO+LR-1 (inverse, DIT) on the sequences of the tile.
+// twl[m] = exp(-2 pi i m / 2^(S_LO+LR)), m < 2^S_LO (LDS).  The twiddle of a butterfly factors into a per-lane
+// part (one table look-up per super-stage and LR - 1 squarings; none when S_LO == 0) and a per-register constant.
+template <int LOGN, int LR, int S_LO, bool INVERSE, int NT, int R3>
+__device__ __forceinline__ void super_stage(float2* tile, int batch, int pitch, int hp, bool priv, const float2* twl) {
+    constexpr int R = 1 << LR, H_LO = 1 << S_LO;
+    const SeqMap<LOGN, LR, NT, R3> map(batch, priv);
 #pragma unroll 1
-    for (int idx = threadIdx.x; idx < total; idx += NT) {
-        const int b = idx >> GL, g = idx & ((1 << GL) - 1);
+    for (int u = map.first; u < map.total; u += map.step) {
+        int rowi, sub, g;
+        map.at(u, rowi, sub, g);
         const int m = g & (H_LO - 1);
-        const int base = ((g >> S_LO) << (S_LO + LR)) | m;
-        // sequence b: row b / R3, sub-block b % R3 of length 2^LOGN (R3 == 1: a whole row)
-        float2* row = R3 == 1 ? tile + b * pitch : tile + (b / R3) * pitch + (b % R3) * ((1 << LOGN) + ((1 << LOGN) >> 5));
-        // H_LO >= 32: phys(base + j H_LO) = phys(base) + j (H_LO + H_LO/32) (no carries between the bit fields);
-        // otherwise the R points are consecutive-ish and phys() is recomputed (cheap, compile-time strides)
-        float2* p0 = row + (H_LO >= 32 ? phys(base) : 0);
+        const int p0 = (sub << LOGN) | ((g >> S_LO) << (S_LO + LR)) | m;  // element of register 0; register j: p0 | (j << S_LO)
+        float2* row = tile + rowi * pitch;
+        // slot(p0 | J) = slot(p0) ^ swz_c(J) (the swizzle is linear and the j field of p0 is zero); for H_LO >= 256 the j
+        // field lies above the swizzled bits and the R slots are slot(p0) + j * H_LO: immediate offsets
+        const int a0 = phys(p0) ^ rmask(rowi, hp);
         float2 v[R];
 #pragma unroll
-        for (int j = 0; j < R; ++j) v[j] = H_LO >= 32 ? p0[j * (H_LO + (H_LO >> 5))] : p0[phys(base + j * H_LO)];
-        // per-lane twiddle part of radix-2 stage S_LO + bpos: exp(-2 pi i m / 2^(S_LO + bpos + 1)).  One table look-up (the
-        // finest angle, bpos = LR - 1; the packed table of this super-stage sits in LDS) and LR - 1 squarings
+        for (int j = 0; j < R; ++j) v[j] = H_LO >= 256 ? row[a0 + j * H_LO] : row[a0 ^ swz_c(j << S_LO)];
         float2 wst[LR];
         if (S_LO > 0) {
             wst[LR - 1] = twl[m];
@@ -191,100 +325,23 @@ __device__ __forceinline__ void super_stage(float2* tile, int batch, int pitch, 
         }
 #pragma unroll
         for (int j = 0; j < R; ++j) {
-            if (H_LO >= 32) p0[j * (H_LO + (H_LO >> 5))] = v[j];
-            else p0[phys(base + j * H_LO)] = v[j];
+            if (H_LO >= 256) row[a0 + j * H_LO] = v[j];
+            else row[a0 ^ swz_c(j << S_LO)] = v[j];
         }
     }
 }
 
-// super-stage sizes: at most MAXLR radix-2 stages (2^MAXLR points = 2 * 2^MAXLR VGPRs of data per lane); never leave a
-// lone radix-2 stage at the end
-__host__ __device__ constexpr int first_r(int rem, int maxlr) {
-    return rem <= maxlr ? rem : (rem == maxlr + 1 ? (maxlr + 1) / 2 : maxlr);
-}
-
-// LDS twiddle tables.  Every super-stage with S_LO > 0 owns a packed table of 2^S_LO entries (stride-1 look-ups: no bank
-// conflicts, and no vector-memory loads inside the FFT phases -- those would drain the prefetch queue, vmcnt being in order);
-// the tables of a chain lie one after the other in chain order.
-__host__ __device__ constexpr int chain_entries(int logn, bool inverse, int maxlr) {
-    int total = 0, done = 0;
-    while (done < logn) {
-        const int r = first_r(logn - done, maxlr);
-        const int s_lo = inverse ? done : logn - done - r;
-        if (s_lo > 0) total += 1 << s_lo;
-        done += r;
-    }
-    return total;
-}
-// twiddle entries in LDS for an axis of length n = r3 * 2^l2
-__host__ __device__ constexpr int axis_tw_entries(int n, int maxlr, bool fwd, bool inv) {
-    int r3 = 1, l2 = 0;
-    while (n % 3 == 0) { n /= 3; r3 *= 3; }
-    while ((1 << l2) < n) ++l2;
-    return (fwd ? chain_entries(l2, false, maxlr) : 0) + (inv ? chain_entries(l2, true, maxlr) : 0) + (r3 > 1 ? (1 << l2) : 0);
-}
-constexpr int kLdsOneWg = 152 * 1024;  // one work-group per CU (160 KB LDS)
-constexpr int kLdsTwoWg = 78 * 1024;   // two work-groups per CU
-// rows of an x tile / line pairs of a z tile: 16 (full 128-B lines in the transposed layouts) while tile + tables fit one
-// work-group per CU; columns of a y tile: two work-groups per CU
-__host__ __device__ constexpr int x_tile_rows(int hx, int maxlr) {
-    int rows = 16;
-    while (rows > 2 && 8 * (rows * row_pitch(hx) + axis_tw_entries(hx, maxlr, true, true)) > kLdsOneWg) rows >>= 1;
-    return rows;
-}
-__host__ __device__ constexpr int z_tile_lines(int nz, int maxlr) {
-    int tl = 16;
-    while (tl > 2 && 8 * (2 * tl * row_pitch(nz) + axis_tw_entries(nz, maxlr, true, true)) > kLdsOneWg) tl >>= 1;
-    return tl;
-}
-__host__ __device__ constexpr int y_tile_cols(int ny, int maxlr) {
-    int tc = 16;
-    while (tc > 1 && 8 * (tc * row_pitch(ny) + axis_tw_entries(ny, maxlr, true, true)) > kLdsTwoWg) tc >>= 1;
-    return tc;
-}
-
-// gather the chain's tables from the global table tw[e] = exp(-2 pi i e / 2^LOGN), e < 2^(LOGN-1)
-template <int LOGN, bool INVERSE, int NT, int MAXLR, int DONE = 0>
-__device__ __forceinline__ void fill_chain_tw(float2* twl, const float2* __restrict__ tw) {
+// full transform of the tile's sequences as the chain of super-stages; twl: the axis' LDS tables.  The caller synchronises
+// before (tile and tables filled): with a work-group barrier, or -- PRIV, and the rows were filled by their owners -- not at
+// all.  On return the tile is consistent for the work-group (!PRIV) or for each row's owner (PRIV).
+template <int LOGN, bool INVERSE, int NT, int R3 = 1, int DONE = 0>
+__device__ __forceinline__ void lds_fft(float2* tile, int batch, int pitch, int hp, bool priv, const float2* twl) {
     if constexpr (DONE < LOGN) {
-        constexpr int r = first_r(LOGN - DONE, MAXLR);
-        constexpr int s_lo = INVERSE ? DONE : LOGN - DONE - r;
-        if constexpr (s_lo > 0) {
-            for (int m = threadIdx.x; m < (1 << s_lo); m += NT) twl[m] = tw[m << (LOGN - s_lo - r)];
-        }
-        fill_chain_tw<LOGN, INVERSE, NT, MAXLR, DONE + r>(twl + (s_lo > 0 ? (1 << s_lo) : 0), tw);
-    }
-}
-// LDS layout behind the tile of an axis kernel: [forward chain][inverse chain][radix-3/9 table: exp(-2 pi i n2 / N), n2 < 2^L2]
-template <int L2, int R3, int MAXLR, bool FWD, bool INV>
-struct TwLds {
-    static constexpr int fwd = 0;
-    static constexpr int inv = FWD ? chain_entries(L2, false, MAXLR) : 0;
-    static constexpr int r3 = inv + (INV ? chain_entries(L2, true, MAXLR) : 0);
-    static constexpr int total = r3 + (R3 > 1 ? (1 << L2) : 0);
-    // tw: global table of the axis ([sub/2 power-of-two part][full circle of N when R3 > 1])
-    template <int NT>
-    static __device__ __forceinline__ void fill(float2* twl, const float2* __restrict__ tw) {
-        if constexpr (FWD) fill_chain_tw<L2, false, NT, MAXLR>(twl + fwd, tw);
-        if constexpr (INV) fill_chain_tw<L2, true, NT, MAXLR>(twl + inv, tw);
-        if constexpr (R3 > 1) {
-            const float2* twM = tw + (1 << L2) / 2;
-            for (int n2 = threadIdx.x; n2 < (1 << L2); n2 += NT) twl[r3 + n2] = twM[n2];
-        }
-    }
-};
-
-// full transform of `batch` LDS rows as a compile-time chain of super-stages (at most MAXLR radix-2 stages each); twl: this
-// chain's LDS tables.  The caller issues lds_barrier() before (tile and tables filled); one follows every super-stage, so the
-// tile is consistent on return
-template <int LOGN, bool INVERSE, int NT, int R3 = 1, int MAXLR = MI_FFT_MAXLR, int DONE = 0>
-__device__ __forceinline__ void lds_fft(float2* tile, int batch, int pitch, const float2* twl) {
-    if constexpr (DONE < LOGN) {
-        constexpr int r = first_r(LOGN - DONE, MAXLR);
-        constexpr int s_lo = INVERSE ? DONE : LOGN - DONE - r;  // forward: top stages first; inverse: bottom first
-        super_stage<LOGN, r, s_lo, INVERSE, NT, R3>(tile, batch, pitch, twl);
-        lds_barrier();
-        lds_fft<LOGN, INVERSE, NT, R3, MAXLR, DONE + r>(tile, batch, pitch, twl + (s_lo > 0 ? (1 << s_lo) : 0));
+        constexpr int s_lo = INVERSE ? DONE : seg_below(LOGN, LOGN - DONE);  // forward: top stages first; inverse: bottom first
+        constexpr int r = INVERSE ? seg_r(LOGN, DONE) : LOGN - DONE - s_lo;
+        super_stage<LOGN, r, s_lo, INVERSE, NT, R3>(tile, batch, pitch, hp, priv, twl + tw_off(LOGN, s_lo));
+        stage_sync(priv);
+        lds_fft<LOGN, INVERSE, NT, R3, DONE + r>(tile, batch, pitch, hp, priv, twl);
     }
 }
 
@@ -306,15 +363,23 @@ __device__ __forceinline__ void dft3(float2& a, float2& b, float2& c) {
 // (DFT over n1 of x[n1 * Msub + n2], times W_M^(n2 k1), stored at k1 * Msub + n2); inverse = its exact reverse.
 // tw3[n2] = exp(-2 pi i n2 / M), n2 < Msub (LDS); the twiddles W_M^(n2 q), q < R3, are its powers.
 template <int R3, bool INVERSE, int NT>
-__device__ __forceinline__ void radix3_stage(float2* tile, int cols, int pitch, int msub, const float2* tw3) {
-    const int total = cols * msub;
-    for (int idx = threadIdx.x; idx < total; idx += NT) {
-        const int c = idx / msub, n2 = idx - c * msub;
+__device__ __forceinline__ void radix3_stage(float2* tile, int cols, int pitch, int hp, bool PRIV, int msub, const float2* tw3) {
+    constexpr int NW = NT / 64;
+    const int wave = threadIdx.x >> 6;
+    const int total = PRIV ? (cols / NW) * msub : cols * msub;
+    for (int idx = PRIV ? (threadIdx.x & 63) : threadIdx.x; idx < total; idx += PRIV ? 64 : NT) {
+        int cl = idx / msub;
+        if (msub >= 64) cl = __builtin_amdgcn_readfirstlane(cl);  // msub is a power of two: a wave's 64 items share the row
+        const int n2 = idx - cl * msub;
+        const int c = PRIV ? cl * NW + wave : cl;
         float2* row = tile + c * pitch;
         float2 v[R3];
-        const int sp = msub + (msub >> 5);  // phys() of a multiple of msub (msub is a multiple of 32)
+        int slot[R3];
+        const int rm = rmask(c, hp);
 #pragma unroll
-        for (int q = 0; q < R3; ++q) v[q] = row[q * sp + phys(n2)];
+        for (int q = 0; q < R3; ++q) slot[q] = phys(q * msub + n2) ^ rm;
+#pragma unroll
+        for (int q = 0; q < R3; ++q) v[q] = row[slot[q]];
         float2 wq[R3];  // wq[q] = w1^q, by squaring / one multiplication from lower powers (depth <= 3)
         wq[1] = tw3[n2];
 #pragma unroll
@@ -374,9 +439,12 @@ __device__ __forceinline__ void radix3_stage(float2* tile, int cols, int pitch, 
             for (int q = 1; q < R3; ++q) v[q] = cmul(v[q], wq[q]);
         }
 #pragma unroll
-        for (int q = 0; q < R3; ++q) row[q * sp + phys(n2)] = v[q];
+        for (int q = 0; q < R3; ++q) row[slot[q]] = v[q];
     }
 }
+
+// slot of element e in row `row` of a tile (in float2 units from the tile start)
+__device__ __forceinline__ int cell(int row, int pitch, int hp, int e) { return row * pitch + (phys(e) ^ rmask(row, hp)); }
 
 // ---------------------------------------------------------------------------------------------- P1: x forward
 // grid: (Y / TY) * Z tiles; tile = TY consecutive rows of one z-plane
@@ -384,12 +452,11 @@ template <int LHX2, int R3>
 __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_x_forward(const float* __restrict__ in, float2* __restrict__ S, NativeDims d,
                                                          const float2* __restrict__ tw, PadWindow pw) {
     extern __shared__ __attribute__((aligned(16))) float2 tile[];
-    constexpr int Hx = R3 << LHX2;
-    const int TY = d.ty, pitch = row_pitch(Hx);
+    constexpr int Hx = R3 << LHX2, NW = kThreadsXZ / 64;
+    const int TY = d.ty, hp = TY / 2, pitch = row_pitch(Hx);
     const int ytiles = d.ny / TY;
-    const unsigned tid_ = pair_tile(blockIdx.x);
-    const int z = tid_ / ytiles, y0 = (tid_ % ytiles) * TY;
-    const int hp = TY / 2, rowq = d.ny / 2;
+    const int z = blockIdx.x / ytiles, y0 = (blockIdx.x % ytiles) * TY;
+    const int rowq = d.ny / 2;
     float4* dst = reinterpret_cast<float4*>(S + ((size_t)z * Hx) * d.ny + y0);
     if (pw.on) {
         // staged load with the boundary rule; a tile that lies entirely in the zero padding transforms to zeros
@@ -413,7 +480,7 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_x_forward(const float*
                 if (s0 >= 0) v.x = row[s0];
                 if (s1 >= 0) v.y = row[s1];
             }
-            tile[r * pitch + phys(q)] = v;
+            tile[cell(r, pitch, hp, q)] = v;
         }
     } else {
         const float4* src = reinterpret_cast<const float4*>(in + ((size_t)z * d.ny + y0) * (size_t)(2 * Hx));
@@ -421,25 +488,28 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_x_forward(const float*
         for (int i = threadIdx.x; i < TY * quads; i += kThreadsXZ) {
             const int r = i / quads, q = i - r * quads;
             const float4 v = src[(size_t)r * quads + q];
-            float2* row = tile + r * pitch;
-            row[phys(2 * q)] = make_float2(v.x, v.y);
-            row[phys(2 * q + 1)] = make_float2(v.z, v.w);
+            const int c0 = cell(r, pitch, hp, 2 * q);  // elements 2q, 2q + 1 are slot neighbours (same bits 4..7)
+            tile[c0] = make_float2(v.x, v.y);
+            tile[c0 ^ 1] = make_float2(v.z, v.w);
         }
     }
-    using TW = TwLds<LHX2, R3, kMaxLrXZ, true, false>;
+    using TW = TwLds<LHX2, R3>;
     float2* twl = tile + TY * pitch;
     TW::template fill<kThreadsXZ>(twl, tw);
     lds_barrier();
+    const bool priv = (TY % NW) == 0;
     if constexpr (R3 > 1) {
-        radix3_stage<R3, false, kThreadsXZ>(tile, TY, pitch, 1 << LHX2, twl + TW::r3);
-        lds_barrier();
+        radix3_stage<R3, false, kThreadsXZ>(tile, TY, pitch, hp, priv, 1 << LHX2, twl + TW::r3);
+        stage_sync(priv);
     }
-    lds_fft<LHX2, false, kThreadsXZ, R3, kMaxLrXZ>(tile, TY * R3, pitch, twl + TW::fwd);
+    lds_fft<LHX2, false, kThreadsXZ, R3>(tile, TY * R3, pitch, hp, priv, twl);
+    if (priv) lds_barrier();
     // transposed store: S[z][px][y0 + r], r fastest; one float4 = rows (2 rp, 2 rp + 1) of one px
 #pragma unroll MI_FFT_UNROLL
     for (int i = threadIdx.x; i < hp * Hx; i += kThreadsXZ) {
         const int px = i / hp, rp = i - px * hp;
-        const float2 a = tile[(2 * rp) * pitch + phys(px)], b = tile[(2 * rp + 1) * pitch + phys(px)];
+        const int c0 = cell(2 * rp, pitch, hp, px);
+        const float2 a = tile[c0], b = tile[c0 + pitch];
         dst[(size_t)px * rowq + rp] = make_float4(a.x, a.y, b.x, b.y);
     }
 }
@@ -450,52 +520,59 @@ template <int LY2, int R3, bool INVERSE>
 __global__ __launch_bounds__(kThreadsY, 4) void k_y_pass(const float2* __restrict__ src, float2* __restrict__ dst, NativeDims d,
                                                       const float2* __restrict__ tw) {
     extern __shared__ __attribute__((aligned(16))) float2 tile[];
-    constexpr int M = R3 << LY2;
+    constexpr int M = R3 << LY2, NW = kThreadsY / 64;
     const int TC = d.tc, pitch = row_pitch(M), Hx = d.hx, L = d.nz;
     const size_t c0 = (size_t)blockIdx.x * TC;
     const float4* base = reinterpret_cast<const float4*>(src + c0 * M);
     const int quads = M / 2;
-#pragma unroll MI_FFT_UNROLL
-    for (int i = threadIdx.x; i < TC * quads; i += kThreadsY) {
-        const int c = i / quads, q = i - c * quads;
-        const float4 v = base[(size_t)c * quads + q];
-        float2* row = tile + c * pitch;
-        row[phys(2 * q)] = make_float2(v.x, v.y);
-        row[phys(2 * q + 1)] = make_float2(v.z, v.w);
-    }
-    // tw: [0, Msub/2) table of the power-of-two sub-transform, then [.. + M) full-circle table of the radix-R3 stage
-    using TW = TwLds<LY2, R3, MI_FFT_MAXLR, !INVERSE, INVERSE>;
+    // columns dealt to the waves when there are enough of them: then the fill, the transform and the drain of a column all
+    // belong to one wave and the kernel has no work-group barrier besides the one behind the table fill
+    const bool priv = (TC % NW) == 0;
+    using TW = TwLds<LY2, R3>;
     float2* twl = tile + TC * pitch;
     TW::template fill<kThreadsY>(twl, tw);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n_items = priv ? (TC / NW) * quads : TC * quads, first = priv ? lane : threadIdx.x, step = priv ? 64 : kThreadsY;
+#pragma unroll MI_FFT_UNROLL
+    for (int i = first; i < n_items; i += step) {
+        const int cl = i / quads, q = i - cl * quads;
+        const int c = priv ? cl * NW + wave : cl;
+        const float4 v = base[(size_t)c * quads + q];
+        const int s0 = c * pitch + phys(2 * q);
+        tile[s0] = make_float2(v.x, v.y);
+        tile[s0 ^ 1] = make_float2(v.z, v.w);
+    }
     lds_barrier();
     if constexpr (!INVERSE && R3 > 1) {
-        radix3_stage<R3, false, kThreadsY>(tile, TC, pitch, 1 << LY2, twl + TW::r3);
-        lds_barrier();
+        radix3_stage<R3, false, kThreadsY>(tile, TC, pitch, 1, priv, 1 << LY2, twl + TW::r3);
+        stage_sync(priv);
     }
-    lds_fft<LY2, INVERSE, kThreadsY, R3>(tile, TC * R3, pitch, twl + (INVERSE ? TW::inv : TW::fwd));
+    lds_fft<LY2, INVERSE, kThreadsY, R3>(tile, TC * R3, pitch, 1, priv, twl);
     if constexpr (INVERSE && R3 > 1) {
-        radix3_stage<R3, true, kThreadsY>(tile, TC, pitch, 1 << LY2, twl + TW::r3);
-        lds_barrier();
+        radix3_stage<R3, true, kThreadsY>(tile, TC, pitch, 1, priv, 1 << LY2, twl + TW::r3);
+        stage_sync(priv);
     }
 #pragma unroll MI_FFT_UNROLL
-    for (int i = threadIdx.x; i < TC * quads; i += kThreadsY) {
-        const int c = i / quads, q = i - c * quads;
+    for (int i = first; i < n_items; i += step) {
+        const int cl = i / quads, q = i - cl * quads;
+        const int c = priv ? cl * NW + wave : cl;
         const size_t sc = c0 + c;  // source column index
         size_t dc;
         if (INVERSE) { const size_t px = sc / L, z = sc - px * L; dc = z * Hx + px; }   // [px][z] -> [z][px]
         else { const size_t z = sc / Hx, px = sc - z * Hx; dc = px * L + z; }           // [z][px] -> [px][z]
-        const float2* row = tile + c * pitch;
-        const float2 a = row[phys(2 * q)], b = row[phys(2 * q + 1)];
+        const int s0 = c * pitch + phys(2 * q);
+        const float2 a = tile[s0], b = tile[s0 ^ 1];
         reinterpret_cast<float4*>(dst + dc * M)[q] = make_float4(a.x, a.y, b.x, b.y);
     }
 }
 
 // ---------------------------------------------------------------------------------------------- P3: z pass + OTF
-// A-role planes: px even (xk = brev(px) < Hx/2) and px == 1 (xk == Hx/2).  For px in {0, 1} the mirror line lies in
-// the same plane: every tile is processed in the A role (its mirror tile is only read) and only A is written, so each
-// line is still written exactly once; otherwise both lines of a pair are written by the one tile that owns the pair.
-// grid: (#A planes) * (Y / TL) tiles of TL consecutive py positions.
-// OTF layout: G[(plane index)][py][pz] as float4 {Ga.re, Ga.im, Gb.re, Gb.im}, already scaled by 1/(Hx*Y*Z).
+// One tile = the TL lines (py0 .. py0 + TL) of plane xk ("A", rows 0 .. TL-1 of the LDS tile) and their mirror lines in plane
+// Hx - xk ("B", rows TL .. 2 TL - 1): xk runs over 0 .. Hx/2, one representative of every mirror pair of planes.  For
+// xk in {0, Hx/2} the mirror line lies in the same plane: every tile is processed in the A role (its mirror tile is only read)
+// and only A is written, so each line is still written exactly once; otherwise both lines of a pair are written by the one
+// tile that owns the pair.  grid: (Hx/2 + 1) * (Y / TL) tiles.
+// OTF layout: G[xk][py][pz] as float4 {Ga.re, Ga.im, Gb.re, Gb.im}, already scaled by 2/(X*Y*Z).
 // BUILD: instead of multiplying, the untangled spectrum of the (real) input -- a placed PSF -- is stored as the OTF in that
 // same layout, scaled: the pipeline builds its own OTF with the transform it will later apply.
 template <int LZ2, int R3, bool BUILD>
@@ -503,46 +580,47 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_z_conv(const float2* _
                                                       NativeDims d, const float2* __restrict__ tw, int conj_otf, float4* __restrict__ Gout,
                                                       float scale) {
     extern __shared__ __attribute__((aligned(16))) float2 tile[];
-    constexpr int L = R3 << LZ2;
-    const int Hx = d.hx, M = d.ny, TL = d.tl, pitch = row_pitch(L);
+    constexpr int L = R3 << LZ2, NW = kThreadsXZ / 64;
+    const int Hx = d.hx, M = d.ny, TL = d.tl, hp = TL / 2, pitch = row_pitch(L);
     const int ytiles = M / TL;
-    const unsigned tid_ = pair_tile(blockIdx.x);
-    const int plane = tid_ / ytiles;                 // = xk, 0 .. Hx/2: one representative of every mirror pair of planes
-    const int py0 = (tid_ % ytiles) * TL;
+    const int plane = blockIdx.x / ytiles;
+    const int py0 = (blockIdx.x % ytiles) * TL;
     const int xk = plane;
     const int px = freq2pos(xk, d.lhx2, d.r3x);
     const int pxB = freq2pos(xk == 0 ? 0 : Hx - xk, d.lhx2, d.r3x);
-    // mirror block of py positions: blocks of TL aligned positions map to blocks (see file header)
+    // mirror block of py positions: an aligned block of TL positions maps onto an aligned block (within one power-of-two
+    // sub-block: low bits of the frequency fixed -> low bits of its negative fixed)
     const int pyB_any = y_mirror_pos(py0, d);
     const int pyB0 = pyB_any & ~(TL - 1);
     const bool self_plane = (px == pxB);  // xk == 0 or xk == Hx/2
-    float2* tA = tile;
-    float2* tB = tile + TL * pitch;
     // layout [px][z][py]: element (px, z, py) at ((px * L + z) * M + py); one float4 = lines (2 jp, 2 jp + 1)
     const float4* sA = reinterpret_cast<const float4*>(S + (size_t)px * L * M + py0);
     const float4* sB = reinterpret_cast<const float4*>(S + (size_t)pxB * L * M + pyB0);
-    const int hp = TL / 2, rowq = M / 2;
+    const int rowq = M / 2;
 #pragma unroll MI_FFT_UNROLL
     for (int i = threadIdx.x; i < hp * L; i += kThreadsXZ) {
         const int z = i / hp, jp = i - z * hp;
         const float4 a = sA[(size_t)z * rowq + jp], b = sB[(size_t)z * rowq + jp];
-        tA[(2 * jp) * pitch + phys(z)] = make_float2(a.x, a.y);
-        tA[(2 * jp + 1) * pitch + phys(z)] = make_float2(a.z, a.w);
-        tB[(2 * jp) * pitch + phys(z)] = make_float2(b.x, b.y);
-        tB[(2 * jp + 1) * pitch + phys(z)] = make_float2(b.z, b.w);
+        const int cA = cell(2 * jp, pitch, hp, z), cB = cA + TL * pitch;  // rows TL + 2 jp carry the same mask
+        tile[cA] = make_float2(a.x, a.y);
+        tile[cA + pitch] = make_float2(a.z, a.w);
+        tile[cB] = make_float2(b.x, b.y);
+        tile[cB + pitch] = make_float2(b.z, b.w);
     }
     const float4* Gp = G + ((size_t)plane * M + py0) * L;
-    using TW = TwLds<LZ2, R3, kMaxLrXZ, true, !BUILD>;
+    using TW = TwLds<LZ2, R3>;
     float2* twl = tile + 2 * TL * pitch;
     TW::template fill<kThreadsXZ>(twl, tw);
     lds_barrier();
+    const bool priv = ((2 * TL) % NW) == 0;
     if (!(d.dbg & 1)) {
         if constexpr (R3 > 1) {
-            radix3_stage<R3, false, kThreadsXZ>(tile, 2 * TL, pitch, 1 << LZ2, twl + TW::r3);
-            lds_barrier();
+            radix3_stage<R3, false, kThreadsXZ>(tile, 2 * TL, pitch, hp, priv, 1 << LZ2, twl + TW::r3);
+            stage_sync(priv);
         }
-        lds_fft<LZ2, false, kThreadsXZ, R3, kMaxLrXZ>(tile, 2 * TL * R3, pitch, twl + TW::fwd);
+        lds_fft<LZ2, false, kThreadsXZ, R3>(tile, 2 * TL * R3, pitch, hp, priv, twl);
     }
+    if (priv) lds_barrier();  // the point-wise step pairs rows of different owners
     // point-wise: element (line j, position pz) of A pairs with (line jB, position pzB) of B
     float sw, cw;
     sincospif(-2.0f * (float)xk / (float)(2 * Hx), &sw, &cw);  // w = exp(-2 pi i xk / Nx), Nx = 2 Hx
@@ -554,11 +632,14 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_z_conv(const float2* _
         if (i >= TL * L || (d.dbg & 2)) break;
         float4 g = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if constexpr (!BUILD) g = Gp[i];  // Gp[(size_t)j * L + pz] with i = j * L + pz
-        const int j = i / L, pz = i - j * L;
+        int j = i / L;
+        if (L % 64 == 0) j = __builtin_amdgcn_readfirstlane(j);  // a wave's 64 items share the line: scalar mirror math
+        const int pz = i - j * L;
         const int jB = y_mirror_pos(py0 + j, d) - pyB0;
         const int pzB = mirror_pos(pz, L, LZ2, R3);
-        const float2 a = tA[j * pitch + phys(pz)];
-        const float2 bm = tB[jB * pitch + phys(pzB)];
+        const int cA = cell(j, pitch, hp, pz), cB = cell(TL + jB, pitch, hp, pzB);
+        const float2 a = tile[cA];
+        const float2 bm = tile[cB];
         const float2 bc = cconj(bm);
         const float2 E = make_float2(0.5f * (a.x + bc.x), 0.5f * (a.y + bc.y));
         const float2 dlt = csub(a, bc);                          // a - conj(b)
@@ -576,29 +657,171 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_z_conv(const float2* _
         const float2 dY = csub(Ya, Yb);
         const float2 O2 = cmulc(make_float2(0.5f * dY.x, 0.5f * dY.y), w);  // (Ya - Yb) conj(w) / 2
         // Z'[k] = E' + i O' ; Z'[-k] = conj(E') + i conj(O')
-        tA[j * pitch + phys(pz)] = make_float2(E2.x - O2.y, E2.y + O2.x);
-        tB[jB * pitch + phys(pzB)] = make_float2(E2.x + O2.y, O2.x - E2.y);
+        tile[cA] = make_float2(E2.x - O2.y, E2.y + O2.x);
+        tile[cB] = make_float2(E2.x + O2.y, O2.x - E2.y);
     }
     if constexpr (BUILD) return;
     lds_barrier();
     if (!(d.dbg & 4)) {
-        lds_fft<LZ2, true, kThreadsXZ, R3, kMaxLrXZ>(tile, 2 * TL * R3, pitch, twl + TW::inv);
+        lds_fft<LZ2, true, kThreadsXZ, R3>(tile, 2 * TL * R3, pitch, hp, priv, twl);
         if constexpr (R3 > 1) {
-            radix3_stage<R3, true, kThreadsXZ>(tile, 2 * TL, pitch, 1 << LZ2, twl + TW::r3);
-            lds_barrier();
+            radix3_stage<R3, true, kThreadsXZ>(tile, 2 * TL, pitch, hp, priv, 1 << LZ2, twl + TW::r3);
+            stage_sync(priv);
         }
     }
+    if (priv) lds_barrier();
     float4* dA = reinterpret_cast<float4*>(T + (size_t)px * L * M + py0);
     float4* dB = reinterpret_cast<float4*>(T + (size_t)pxB * L * M + pyB0);
 #pragma unroll MI_FFT_UNROLL
     for (int i = threadIdx.x; i < hp * L; i += kThreadsXZ) {
         const int z = i / hp, jp = i - z * hp;
-        const float2 a0 = tA[(2 * jp) * pitch + phys(z)], a1 = tA[(2 * jp + 1) * pitch + phys(z)];
+        const int cA = cell(2 * jp, pitch, hp, z), cB = cA + TL * pitch;
+        const float2 a0 = tile[cA], a1 = tile[cA + pitch];
         dA[(size_t)z * rowq + jp] = make_float4(a0.x, a0.y, a1.x, a1.y);
         if (!self_plane) {
-            const float2 b0 = tB[(2 * jp) * pitch + phys(z)], b1 = tB[(2 * jp + 1) * pitch + phys(z)];
+            const float2 b0 = tile[cB], b1 = tile[cB + pitch];
             dB[(size_t)z * rowq + jp] = make_float4(b0.x, b0.y, b1.x, b1.y);
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- P3, pipelined
+// The z pass as a persistent kernel (one work-group per CU): the OTF of the current tile is requested before the forward
+// transform and the next tile's lines before the inverse transform, both into registers, so HBM stays busy during the FFT
+// phases; stores drain behind.
+template <int LZ2, int R3>
+__global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_z_conv_pipe(const float2* __restrict__ S, float2* __restrict__ T, const float4* __restrict__ G,
+                                                           NativeDims d, const float2* __restrict__ tw, int conj_otf, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) float2 tile[];
+    constexpr int L = R3 << LZ2, NW = kThreadsXZ / 64;
+    constexpr int TL = z_tile_lines(L), hp = TL / 2, pitch = row_pitch(L);
+    constexpr int NA = hp * L;                                   // float4 of the A lines (and of the B lines) of a tile
+    constexpr int NPA = (NA + kThreadsXZ - 1) / kThreadsXZ;
+    constexpr int NG = TL * L;                                   // OTF float4 of a tile = point-wise items
+    constexpr int NPG = (NG + kThreadsXZ - 1) / kThreadsXZ;
+    constexpr bool PRIV = ((2 * TL) % NW) == 0;
+    const int Hx = d.hx, M = d.ny;
+    const int ytiles = M / TL, rowq = M / 2;
+    float4 preA[NPA], preB[NPA];
+    struct Where { int plane, py0, px, pxB, pyB0; };
+    auto where = [&](int t) {
+        Where w;
+        w.plane = t / ytiles;
+        w.py0 = (t - w.plane * ytiles) * TL;
+        w.px = freq2pos(w.plane, d.lhx2, d.r3x);
+        w.pxB = freq2pos(w.plane == 0 ? 0 : Hx - w.plane, d.lhx2, d.r3x);
+        w.pyB0 = y_mirror_pos(w.py0, d) & ~(TL - 1);
+        return w;
+    };
+    auto load_S = [&](int t) {
+        const Where w = where(t);
+        const int tid = launder(threadIdx.x);
+        const float4* sA = reinterpret_cast<const float4*>(S + (size_t)w.px * L * M + w.py0);
+        const float4* sB = reinterpret_cast<const float4*>(S + (size_t)w.pxB * L * M + w.pyB0);
+#pragma unroll
+        for (int k = 0; k < NPA; ++k) {
+            const int i = tid + k * kThreadsXZ;
+            if (NA % kThreadsXZ == 0 || i < NA) {
+                const int z = i / hp, jp = i - z * hp;
+                preA[k] = sA[(size_t)z * rowq + jp];
+                preB[k] = sB[(size_t)z * rowq + jp];
+            }
+        }
+    };
+    using TW = TwLds<LZ2, R3>;
+    float2* twl = tile + 2 * TL * pitch;
+    TW::template fill<kThreadsXZ>(twl, tw);
+    int t = blockIdx.x;
+    if (t < ntiles) load_S(t);
+    for (; t < ntiles; t += gridDim.x) {
+        const Where w = where(t);
+        int tid = launder(threadIdx.x);
+#pragma unroll
+        for (int k = 0; k < NPA; ++k) {
+            const int i = tid + k * kThreadsXZ;
+            if (NA % kThreadsXZ == 0 || i < NA) {
+                const int z = i / hp, jp = i - z * hp;
+                const int cA = cell(2 * jp, pitch, hp, z), cB = cA + TL * pitch;
+                tile[cA] = make_float2(preA[k].x, preA[k].y);
+                tile[cA + pitch] = make_float2(preA[k].z, preA[k].w);
+                tile[cB] = make_float2(preB[k].x, preB[k].y);
+                tile[cB + pitch] = make_float2(preB[k].z, preB[k].w);
+            }
+        }
+        const float4* Gp = G + ((size_t)w.plane * M + w.py0) * L;
+        float4 gv[NPG];
+        tid = launder(threadIdx.x);
+#pragma unroll
+        for (int k = 0; k < NPG; ++k) {
+            const int i = tid + k * kThreadsXZ;
+            if (NG % kThreadsXZ == 0 || i < NG) gv[k] = Gp[i];
+        }
+        lds_barrier();
+        if constexpr (R3 > 1) {
+            radix3_stage<R3, false, kThreadsXZ>(tile, 2 * TL, pitch, hp, PRIV, 1 << LZ2, twl + TW::r3);
+            stage_sync(PRIV);
+        }
+        lds_fft<LZ2, false, kThreadsXZ, R3>(tile, 2 * TL * R3, pitch, hp, PRIV, twl);
+        if (PRIV) lds_barrier();  // the point-wise step pairs rows of different owners
+        float sw, cw;
+        sincospif(-2.0f * (float)w.plane / (float)(2 * Hx), &sw, &cw);  // exp(-2 pi i xk / Nx), Nx = 2 Hx
+        const float2 wx = make_float2(cw, sw);
+        tid = launder(threadIdx.x);
+#pragma unroll
+        for (int k = 0; k < NPG; ++k) {
+            const int i = tid + k * kThreadsXZ;
+            if (NG % kThreadsXZ == 0 || i < NG) {
+                int j = i / L;
+                if (L % 64 == 0) j = __builtin_amdgcn_readfirstlane(j);  // a wave's 64 items share the line: scalar mirror math
+                const int pz = i - j * L;
+                const int jB = y_mirror_pos(w.py0 + j, d) - w.pyB0;
+                const int pzB = mirror_pos(pz, L, LZ2, R3);
+                const int cA = cell(j, pitch, hp, pz), cB = cell(TL + jB, pitch, hp, pzB);
+                const float2 a = tile[cA];
+                const float2 bc = cconj(tile[cB]);
+                const float2 E = make_float2(0.5f * (a.x + bc.x), 0.5f * (a.y + bc.y));
+                const float2 dlt = csub(a, bc);
+                const float2 O = make_float2(0.5f * dlt.y, -0.5f * dlt.x);  // -i/2 * (a - conj(b))
+                const float2 wO = cmul(wx, O);
+                const float2 Xa = cadd(E, wO), Xb = csub(E, wO);
+                float2 Ga = make_float2(gv[k].x, gv[k].y), Gb = make_float2(gv[k].z, gv[k].w);
+                if (conj_otf) { Ga.y = -Ga.y; Gb.y = -Gb.y; }
+                const float2 Ya = cmul(Xa, Ga), Yb = cmul(Xb, Gb);
+                const float2 E2 = make_float2(0.5f * (Ya.x + Yb.x), 0.5f * (Ya.y + Yb.y));
+                const float2 dY = csub(Ya, Yb);
+                const float2 O2 = cmulc(make_float2(0.5f * dY.x, 0.5f * dY.y), wx);
+                tile[cA] = make_float2(E2.x - O2.y, E2.y + O2.x);
+                tile[cB] = make_float2(E2.x + O2.y, O2.x - E2.y);
+            }
+        }
+        const int tn = t + gridDim.x;
+        if (tn < ntiles) load_S(tn);
+        lds_barrier();
+        lds_fft<LZ2, true, kThreadsXZ, R3>(tile, 2 * TL * R3, pitch, hp, PRIV, twl);
+        if constexpr (R3 > 1) {
+            radix3_stage<R3, true, kThreadsXZ>(tile, 2 * TL, pitch, hp, PRIV, 1 << LZ2, twl + TW::r3);
+            stage_sync(PRIV);
+        }
+        if (PRIV) lds_barrier();
+        const bool self_plane = (w.px == w.pxB);
+        float4* dA = reinterpret_cast<float4*>(T + (size_t)w.px * L * M + w.py0);
+        float4* dB = reinterpret_cast<float4*>(T + (size_t)w.pxB * L * M + w.pyB0);
+        tid = launder(threadIdx.x);
+#pragma unroll
+        for (int k = 0; k < NPA; ++k) {
+            const int i = tid + k * kThreadsXZ;
+            if (NA % kThreadsXZ == 0 || i < NA) {
+                const int z = i / hp, jp = i - z * hp;
+                const int cA = cell(2 * jp, pitch, hp, z), cB = cA + TL * pitch;
+                const float2 a0 = tile[cA], a1 = tile[cA + pitch];
+                dA[(size_t)z * rowq + jp] = make_float4(a0.x, a0.y, a1.x, a1.y);
+                if (!self_plane) {
+                    const float2 b0 = tile[cB], b1 = tile[cB + pitch];
+                    dB[(size_t)z * rowq + jp] = make_float4(b0.x, b0.y, b1.x, b1.y);
+                }
+            }
+        }
+        lds_barrier();  // the tile is free for the next fill
     }
 }
 
@@ -609,13 +832,12 @@ template <int LHX2, int R3, bool FUSE>
 __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_x_inverse(const float2* __restrict__ T, float* __restrict__ out, ConvEpilogue e, NativeDims d,
                                                          const float2* __restrict__ tw, float2* __restrict__ S_next, int EPI, PadWindow pw) {
     extern __shared__ __attribute__((aligned(16))) float2 tile[];
-    constexpr int Hx = R3 << LHX2;
-    const int TY = d.ty, pitch = row_pitch(Hx);
+    constexpr int Hx = R3 << LHX2, NW = kThreadsXZ / 64;
+    const int TY = d.ty, hp = TY / 2, pitch = row_pitch(Hx);
     const int ytiles = d.ny / TY;
-    const unsigned tid_ = pair_tile(blockIdx.x);
-    const int z = tid_ / ytiles, y0 = (tid_ % ytiles) * TY;
+    const int z = blockIdx.x / ytiles, y0 = (blockIdx.x % ytiles) * TY;
     const float4* src = reinterpret_cast<const float4*>(T + ((size_t)z * Hx) * d.ny + y0);
-    const int hp = TY / 2, rowq = d.ny / 2;
+    const int rowq = d.ny / 2;
     int oz = z;
     if (pw.on) {
         // rows outside the cropped result are never stored: a tile without any is skipped (fused: its part of the next
@@ -638,28 +860,34 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_x_inverse(const float2
     for (int i = threadIdx.x; i < hp * Hx; i += kThreadsXZ) {
         const int px = i / hp, rp = i - px * hp;
         const float4 v = src[(size_t)px * rowq + rp];
-        tile[(2 * rp) * pitch + phys(px)] = make_float2(v.x, v.y);
-        tile[(2 * rp + 1) * pitch + phys(px)] = make_float2(v.z, v.w);
+        const int c0 = cell(2 * rp, pitch, hp, px);
+        tile[c0] = make_float2(v.x, v.y);
+        tile[c0 + pitch] = make_float2(v.z, v.w);
     }
-    using TW = TwLds<LHX2, R3, kMaxLrXZ, FUSE, true>;
+    using TW = TwLds<LHX2, R3>;
     float2* twl = tile + TY * pitch;
     TW::template fill<kThreadsXZ>(twl, tw);
     lds_barrier();
+    // rows dealt to the waves: the inverse transform, the epilogue and the forward transform of a row all belong to its owner
+    const bool priv = (TY % NW) == 0;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (!(d.dbg & 8)) {
-        lds_fft<LHX2, true, kThreadsXZ, R3, kMaxLrXZ>(tile, TY * R3, pitch, twl + TW::inv);
+        lds_fft<LHX2, true, kThreadsXZ, R3>(tile, TY * R3, pitch, hp, priv, twl);
         if constexpr (R3 > 1) {
-            radix3_stage<R3, true, kThreadsXZ>(tile, TY, pitch, 1 << LHX2, twl + TW::r3);
-            lds_barrier();
+            radix3_stage<R3, true, kThreadsXZ>(tile, TY, pitch, hp, priv, 1 << LHX2, twl + TW::r3);
+            stage_sync(priv);
         }
     }
     if (pw.on) {
         // crop + epilogue on the caller's (unpadded) volume; fused: the zero padding of the next input is re-created
         const float l = e.lambda, m = 1.0f - e.lambda;
-        for (int i = threadIdx.x; i < TY * Hx; i += kThreadsXZ) {
-            const int r = i / Hx, q = i - r * Hx;
+        const int n_items = priv ? (TY / NW) * Hx : TY * Hx;
+        for (int i = priv ? lane : threadIdx.x; i < n_items; i += priv ? 64 : kThreadsXZ) {
+            const int rl = i / Hx, q = i - rl * Hx;
+            const int r = priv ? rl * NW + wave : rl;
             const int oy = pad_dst(pw, 1, y0 + r);
-            float2* cell = tile + r * pitch + phys(q);
-            const float2 c = *cell;
+            float2* cl = tile + cell(r, pitch, hp, q);
+            const float2 c = *cl;
             float2 o = make_float2(0.0f, 0.0f);
             if (oy >= 0) {
                 const size_t rbase = ((size_t)oz * pw.n[1] + oy) * (size_t)pw.n[0];
@@ -671,14 +899,14 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_x_inverse(const float2
                     const size_t gi = rbase + ox;
                     float v;
                     if (EPI == EPI_NONE) v = cv;
-                    else if (EPI == EPI_RATIO) v = e.a[gi] / fmaxf(cv, kEpsSingle);
+                    else if (EPI == EPI_RATIO) v = e.a[gi] * rcp_eps(cv);
                     else if (EPI == EPI_UPDATE) v = fabsf(e.a[gi] * cv);
                     else v = fabsf(e.a[gi] * cv * m + e.b[gi] * l);
                     if (!FUSE || out != nullptr) out[gi] = v;
                     if (h) o.y = v; else o.x = v;
                 }
             }
-            if (FUSE) *cell = o;
+            if (FUSE) *cl = o;
         }
     } else {
         const size_t row0 = ((size_t)z * d.ny + y0) * (size_t)(2 * Hx);
@@ -686,10 +914,12 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_x_inverse(const float2
         float4* dst = reinterpret_cast<float4*>(out + row0);
         const float4* a4 = reinterpret_cast<const float4*>(e.a + row0);
         const float4* b4 = reinterpret_cast<const float4*>(e.b + row0);
-        for (int i = threadIdx.x; i < TY * quads; i += kThreadsXZ) {
-            const int r = i / quads, q = i - r * quads;
-            const float2* row = tile + r * pitch;
-            const float2 c0 = row[phys(2 * q)], c1 = row[phys(2 * q + 1)];
+        const int n_items = priv ? (TY / NW) * quads : TY * quads;
+        for (int i = priv ? lane : threadIdx.x; i < n_items; i += priv ? 64 : kThreadsXZ) {
+            const int rl = i / quads, q = i - rl * quads;
+            const int r = priv ? rl * NW + wave : rl;
+            const int c0i = cell(r, pitch, hp, 2 * q);
+            const float2 c0 = tile[c0i], c1 = tile[c0i ^ 1];
             float4 c = make_float4(c0.x, c0.y, c1.x, c1.y), o;
             const size_t gi = (size_t)r * quads + q;
             if (EPI == EPI_NONE) {
@@ -697,8 +927,7 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_x_inverse(const float2
             } else {
                 const float4 av = a4[gi];
                 if (EPI == EPI_RATIO) {
-                    o = make_float4(av.x / fmaxf(c.x, kEpsSingle), av.y / fmaxf(c.y, kEpsSingle), av.z / fmaxf(c.z, kEpsSingle),
-                                    av.w / fmaxf(c.w, kEpsSingle));
+                    o = make_float4(av.x * rcp_eps(c.x), av.y * rcp_eps(c.y), av.z * rcp_eps(c.z), av.w * rcp_eps(c.w));
                 } else if (EPI == EPI_UPDATE) {
                     o = make_float4(fabsf(av.x * c.x), fabsf(av.y * c.y), fabsf(av.z * c.z), fabsf(av.w * c.w));
                 } else {
@@ -710,46 +939,49 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_x_inverse(const float2
             }
             if (!FUSE || out != nullptr) dst[gi] = o;
             if (FUSE) {
-                float2* wrow = tile + r * pitch;
-                wrow[phys(2 * q)] = make_float2(o.x, o.y);
-                wrow[phys(2 * q + 1)] = make_float2(o.z, o.w);
+                tile[c0i] = make_float2(o.x, o.y);
+                tile[c0i ^ 1] = make_float2(o.z, o.w);
             }
         }
     }
     if (FUSE) {
-        lds_barrier();
+        stage_sync(priv);
         if (!(d.dbg & 16)) {
             if constexpr (R3 > 1) {
-                radix3_stage<R3, false, kThreadsXZ>(tile, TY, pitch, 1 << LHX2, twl + TW::r3);
-                lds_barrier();
+                radix3_stage<R3, false, kThreadsXZ>(tile, TY, pitch, hp, priv, 1 << LHX2, twl + TW::r3);
+                stage_sync(priv);
             }
-            lds_fft<LHX2, false, kThreadsXZ, R3, kMaxLrXZ>(tile, TY * R3, pitch, twl + TW::fwd);
+            lds_fft<LHX2, false, kThreadsXZ, R3>(tile, TY * R3, pitch, hp, priv, twl);
         }
+        if (priv) lds_barrier();
         float4* sdst = reinterpret_cast<float4*>(S_next + ((size_t)z * Hx) * d.ny + y0);
 #pragma unroll MI_FFT_UNROLL
         for (int i = threadIdx.x; i < hp * Hx; i += kThreadsXZ) {
             const int px = i / hp, rp = i - px * hp;
-            const float2 a = tile[(2 * rp) * pitch + phys(px)], b = tile[(2 * rp + 1) * pitch + phys(px)];
+            const int c0 = cell(2 * rp, pitch, hp, px);
+            const float2 a = tile[c0], b = tile[c0 + pitch];
             sdst[(size_t)px * rowq + rp] = make_float4(a.x, a.y, b.x, b.y);
         }
     }
 }
 
-
 // ---------------------------------------------------------------------------------------------- P5 + P1, pipelined
-// The fused x pass as a persistent kernel: one work-group per CU walks over tiles and keeps HBM busy during the LDS-bound
-// FFT phases -- the epilogue operand of the current tile is requested before the inverse transform and the next tile's
-// spectrum before the forward transform, both into registers (8 float4 each for a 16 x 1024 tile); stores drain behind.
+// The fused x pass as a persistent kernel: one work-group per CU walks over tiles and keeps HBM busy during the FFT phases --
+// the epilogue operand of the current tile is requested before the inverse transform and the next tile's spectrum before the
+// forward transform, both into registers (8 float4 each for a 16 x 1024 tile); stores drain behind.
 // Unpadded volumes only (the padded mode keeps k_x_inverse).
 template <int LHX2, int R3>
 __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_x_fused_pipe(const float2* __restrict__ T, float* __restrict__ out, ConvEpilogue e, NativeDims d,
                                                             const float2* __restrict__ tw, float2* __restrict__ S_next, int EPI, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) float2 tile[];
-    constexpr int Hx = R3 << LHX2;
-    constexpr int TY = x_tile_rows(Hx, kMaxLrXZ), hp = TY / 2, quads = Hx / 2;
+    constexpr int Hx = R3 << LHX2, NW = kThreadsXZ / 64;
+    constexpr int TY = x_tile_rows(Hx), hp = TY / 2, quads = Hx / 2;
     constexpr int NQ = hp * Hx;  // float4 per tile, in the transposed (T / S) and in the row (bl) view alike
     constexpr int NPF = (NQ + kThreadsXZ - 1) / kThreadsXZ;
     constexpr int pitch = row_pitch(Hx);
+    // rows dealt to the waves: the inverse transform, the epilogue and the forward transform of a row all belong to its owner
+    // and run without work-group barriers; only the transposed fill and drain are tile-wide
+    constexpr bool PRIV = (TY % NW == 0) && (NQ % kThreadsXZ == 0);
     const int ytiles = d.ny / TY, rowq = d.ny / 2;
     float4 pre[NPF];
     auto tile_base = [&](int t) { const int z = t / ytiles, y0 = (t - z * ytiles) * TY; return ((size_t)z * Hx) * d.ny + y0; };
@@ -762,7 +994,22 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_x_fused_pipe(const flo
             if (NQ % kThreadsXZ == 0 || i < NQ) { const int px = i / hp, rp = i - px * hp; pre[j] = src[(size_t)px * rowq + rp]; }
         }
     };
-    using TW = TwLds<LHX2, R3, kMaxLrXZ, true, true>;
+    // row-side item j of this lane: float4 `i` of the tile's rows (contiguous in bl) = row r, quad q
+    auto row_item = [&](int tid, int j, int& i, int& r, int& q) {
+        if (PRIV) {
+            const int u = (tid & 63) + j * 64;
+            int rl = u / quads;
+            if (quads % 64 == 0) rl = __builtin_amdgcn_readfirstlane(rl);
+            q = u - rl * quads;
+            r = rl * NW + __builtin_amdgcn_readfirstlane(tid >> 6);
+            i = r * quads + q;
+        } else {
+            i = tid + j * kThreadsXZ;
+            r = i / quads;
+            q = i - r * quads;
+        }
+    };
+    using TW = TwLds<LHX2, R3>;
     float2* twl = tile + TY * pitch;
     TW::template fill<kThreadsXZ>(twl, tw);
     int t = blockIdx.x;
@@ -776,8 +1023,9 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_x_fused_pipe(const flo
             const int i = tid + j * kThreadsXZ;
             if (NQ % kThreadsXZ == 0 || i < NQ) {
                 const int px = i / hp, rp = i - px * hp;
-                tile[(2 * rp) * pitch + phys(px)] = make_float2(pre[j].x, pre[j].y);
-                tile[(2 * rp + 1) * pitch + phys(px)] = make_float2(pre[j].z, pre[j].w);
+                const int c0 = cell(2 * rp, pitch, hp, px);
+                tile[c0] = make_float2(pre[j].x, pre[j].y);
+                tile[c0 + pitch] = make_float2(pre[j].z, pre[j].w);
             }
         }
         // rows of this tile in the real volume: contiguous TY * 2 Hx floats
@@ -788,44 +1036,45 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_x_fused_pipe(const flo
         tid = launder(threadIdx.x);
 #pragma unroll
         for (int j = 0; j < NPF; ++j) {
-            const int i = tid + j * kThreadsXZ;
+            int i, r, q;
+            row_item(tid, j, i, r, q);
             if (NQ % kThreadsXZ == 0 || i < NQ) av[j] = a4[i];
         }
         lds_barrier();
-        lds_fft<LHX2, true, kThreadsXZ, R3, kMaxLrXZ>(tile, TY * R3, pitch, twl + TW::inv);
+        lds_fft<LHX2, true, kThreadsXZ, R3>(tile, TY * R3, pitch, hp, PRIV, twl);
         if constexpr (R3 > 1) {
-            radix3_stage<R3, true, kThreadsXZ>(tile, TY, pitch, 1 << LHX2, twl + TW::r3);
-            lds_barrier();
+            radix3_stage<R3, true, kThreadsXZ>(tile, TY, pitch, hp, PRIV, 1 << LHX2, twl + TW::r3);
+            stage_sync(PRIV);
         }
         float4* dst = reinterpret_cast<float4*>(out + row0);
         tid = launder(threadIdx.x);
 #pragma unroll
         for (int j = 0; j < NPF; ++j) {
-            const int i = tid + j * kThreadsXZ;
+            int i, r, q;
+            row_item(tid, j, i, r, q);
             if (NQ % kThreadsXZ == 0 || i < NQ) {
-                const int r = i / quads, q = i - r * quads;
-                float2* row = tile + r * pitch;
-                const float2 c0 = row[phys(2 * q)], c1 = row[phys(2 * q + 1)];
+                const int s0 = cell(r, pitch, hp, 2 * q);  // elements 2q and 2q + 1 are slot neighbours
+                const float2 c0 = tile[s0], c1 = tile[s0 ^ 1];
                 const float4 a = av[j];
                 float4 o;
                 if (EPI == EPI_RATIO)
-                    o = make_float4(a.x / fmaxf(c0.x, kEpsSingle), a.y / fmaxf(c0.y, kEpsSingle), a.z / fmaxf(c1.x, kEpsSingle),
-                                    a.w / fmaxf(c1.y, kEpsSingle));
+                    o = make_float4(a.x * rcp_eps(c0.x), a.y * rcp_eps(c0.y), a.z * rcp_eps(c1.x), a.w * rcp_eps(c1.y));
                 else
                     o = make_float4(fabsf(a.x * c0.x), fabsf(a.y * c0.y), fabsf(a.z * c1.x), fabsf(a.w * c1.y));
                 if (out != nullptr) dst[i] = o;
-                row[phys(2 * q)] = make_float2(o.x, o.y);
-                row[phys(2 * q + 1)] = make_float2(o.z, o.w);
+                tile[s0] = make_float2(o.x, o.y);
+                tile[s0 ^ 1] = make_float2(o.z, o.w);
             }
         }
         const int tn = t + gridDim.x;
         if (tn < ntiles) load_T(tn);
-        lds_barrier();
+        stage_sync(PRIV);
         if constexpr (R3 > 1) {
-            radix3_stage<R3, false, kThreadsXZ>(tile, TY, pitch, 1 << LHX2, twl + TW::r3);
-            lds_barrier();
+            radix3_stage<R3, false, kThreadsXZ>(tile, TY, pitch, hp, PRIV, 1 << LHX2, twl + TW::r3);
+            stage_sync(PRIV);
         }
-        lds_fft<LHX2, false, kThreadsXZ, R3, kMaxLrXZ>(tile, TY * R3, pitch, twl + TW::fwd);
+        lds_fft<LHX2, false, kThreadsXZ, R3>(tile, TY * R3, pitch, hp, PRIV, twl);
+        if (PRIV) lds_barrier();  // rows complete for everybody before the transposed drain
         float4* sdst = reinterpret_cast<float4*>(S_next + tile_base(t));
         tid = launder(threadIdx.x);
 #pragma unroll
@@ -833,7 +1082,8 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_x_fused_pipe(const flo
             const int i = tid + j * kThreadsXZ;
             if (NQ % kThreadsXZ == 0 || i < NQ) {
                 const int px = i / hp, rp = i - px * hp;
-                const float2 a = tile[(2 * rp) * pitch + phys(px)], b = tile[(2 * rp + 1) * pitch + phys(px)];
+                const int c0 = cell(2 * rp, pitch, hp, px);
+                const float2 a = tile[c0], b = tile[c0 + pitch];
                 sdst[(size_t)px * rowq + rp] = make_float4(a.x, a.y, b.x, b.y);
             }
         }
@@ -880,9 +1130,7 @@ int NativeFft::good_size(int n, int axis) {
 
 // LDS of an axis kernel: the tile, then the twiddle tables (both chains and the radix-3/9 table: what the fused kernels of
 // the axis use, an upper bound for the others; see TwLds)
-static size_t lds_bytes(int rows, int n, int maxlr) {
-    return sizeof(float2) * ((size_t)rows * row_pitch(n) + axis_tw_entries(n, maxlr, true, true));
-}
+static size_t lds_bytes(int rows, int n) { return sizeof(float2) * ((size_t)rows * row_pitch(n) + axis_tw_entries(n)); }
 
 int NativeFft::init(hipStream_t s, const int F[3], bool explicit_adjoint) {
     MI_REQUIRE(supported(F), "native FFT: unsupported shape %d x %d x %d", F[0], F[1], F[2]);
@@ -893,9 +1141,9 @@ int NativeFft::init(hipStream_t s, const int F[3], bool explicit_adjoint) {
     dims.hx = Hx;
     dims.ny = F[1];
     dims.nz = F[2];
-    dims.ty = std::min(x_tile_rows(Hx, kMaxLrXZ), F[1]);
-    dims.tc = y_tile_cols(F[1], MI_FFT_MAXLR);
-    dims.tl = std::min(z_tile_lines(F[2], kMaxLrXZ), F[1]);
+    dims.ty = std::min(x_tile_rows(Hx), F[1]);
+    dims.tc = y_tile_cols(F[1]);
+    dims.tl = std::min(z_tile_lines(F[2]), F[1]);
     dims.dbg = 0;
     if (const char* e = std::getenv("MI_FFT_ZDBG")) dims.dbg = atoi(e);  // phase knock-out for timing experiments
     // tuning overrides (experiments only): MI_FFT_TY / MI_FFT_TC / MI_FFT_TL
@@ -907,8 +1155,8 @@ int NativeFft::init(hipStream_t s, const int F[3], bool explicit_adjoint) {
     // mirror blocks, which holds for TL <= 2^ly2 (positions inside one power-of-two sub-block mirror inside one)
     MI_REQUIRE(dims.ty >= 2 && dims.ty % 2 == 0 && F[1] % dims.ty == 0, "native FFT: x tile of %d rows does not divide y = %d", dims.ty, F[1]);
     MI_REQUIRE(dims.tl >= 2 && is_pow2(dims.tl) && dims.tl <= (1 << dims.ly2), "native FFT: z tile of %d lines does not fit y = %d", dims.tl, F[1]);
-    MI_REQUIRE(lds_bytes(dims.ty, Hx, kMaxLrXZ) <= 160 * 1024 && lds_bytes(dims.tc, F[1], MI_FFT_MAXLR) <= 160 * 1024 &&
-                   lds_bytes(2 * dims.tl, F[2], kMaxLrXZ) <= 160 * 1024,
+    MI_REQUIRE(lds_bytes(dims.ty, Hx) <= 160 * 1024 && lds_bytes(dims.tc, F[1]) <= 160 * 1024 &&
+                   lds_bytes(2 * dims.tl, F[2]) <= 160 * 1024,
                "native FFT: transform too long for LDS");
     n_cplx = (size_t)Hx * F[1] * F[2];
     MI_TRY(S.alloc(sizeof(float2) * n_cplx));
@@ -978,7 +1226,7 @@ int NativeFft::x_forward(hipStream_t s, const float* in) {
     const PadWindow pw = this->pw;
     const int Hx = dims.hx, M = dims.ny, L = dims.nz;
     const unsigned xtiles = (unsigned)((size_t)L * (M / dims.ty));
-    const size_t xl = lds_bytes(dims.ty, Hx, kMaxLrXZ);
+    const size_t xl = lds_bytes(dims.ty, Hx);
     const NativeDims d = dims;
     float2* Sp = S.as<float2>();
     const float2* twx = tw_x;
@@ -992,7 +1240,7 @@ int NativeFft::x_forward(hipStream_t s, const float* in) {
 int NativeFft::y_pass(hipStream_t s, bool inverse) {
     const int Hx = dims.hx, M = dims.ny, L = dims.nz;
     const unsigned ycols = (unsigned)((size_t)L * Hx / dims.tc);
-    const size_t yl = lds_bytes(dims.tc, M, MI_FFT_MAXLR);
+    const size_t yl = lds_bytes(dims.tc, M);
     const NativeDims d = dims;
     const float2* src = S.as<float2>();
     float2* dst = T.as<float2>();
@@ -1011,7 +1259,7 @@ int NativeFft::y_pass(hipStream_t s, bool inverse) {
 int NativeFft::z_conv(hipStream_t s, bool conj_otf) {
     const int Hx = dims.hx, M = dims.ny, L = dims.nz;
     const unsigned ztiles = (unsigned)((size_t)(Hx / 2 + 1) * (M / dims.tl));
-    const size_t zl = lds_bytes(2 * dims.tl, L, kMaxLrXZ);
+    const size_t zl = lds_bytes(2 * dims.tl, L);
     const NativeDims d = dims;
     const float2* Tp = T.as<float2>();
     float2* Sp = S.as<float2>();
@@ -1019,6 +1267,15 @@ int NativeFft::z_conv(hipStream_t s, bool conj_otf) {
     const float2* twz = tw_z;
     const int cj = (conj_otf && !have_adj) ? 1 : 0;
     int rc = MI_ERR_INVALID;
+    static const bool no_pipe = std::getenv("MI_FFT_NO_PIPE") != nullptr;
+    if (dims.dbg == 0 && !no_pipe && dims.tl == z_tile_lines(L)) {
+        const int ntiles = (int)ztiles;
+        const unsigned grid = (unsigned)std::min(ntiles, n_cu);
+#define MI_ZP(LG, R) case LG * 16 + R: rc = launch_lds(k_z_conv_pipe<LG, R>, grid, kThreadsXZ, zl, s, "k_z_conv_pipe", Tp, Sp, Gp, d, twz, cj, ntiles); break;
+        switch (dims.lz2 * 16 + dims.r3z) { MI_Z_CASES(MI_ZP) default: return fail(MI_ERR_UNSUPPORTED, "native FFT: z length %d", L); }
+#undef MI_ZP
+        return rc;
+    }
 #define MI_Z(LG, R)                                                                                                                      \
     case LG * 16 + R:                                                                                                                    \
         rc = launch_lds(k_z_conv<LG, R, false>, ztiles, kThreadsXZ, zl, s, "k_z_conv", Tp, Sp, Gp, d, twz, cj, (float4*)nullptr, 0.0f); \
@@ -1037,7 +1294,7 @@ int NativeFft::build_otf(hipStream_t s, const float* placed, bool adjoint_slot, 
     MI_TRY(y_pass(s, false));
     const int Hx = dims.hx, M = dims.ny, L = dims.nz;
     const unsigned ztiles = (unsigned)((size_t)(Hx / 2 + 1) * (M / dims.tl));
-    const size_t zl = lds_bytes(2 * dims.tl, L, kMaxLrXZ);
+    const size_t zl = lds_bytes(2 * dims.tl, L);
     const NativeDims d = dims;
     const float2* Tp = T.as<float2>();
     float2* Sp = S.as<float2>();
@@ -1064,7 +1321,7 @@ int NativeFft::middle(hipStream_t s, bool conj_otf) {
 int NativeFft::x_inverse(hipStream_t s, float* out, int epi_kind, const ConvEpilogue& epi, bool fuse_forward) {
     const int Hx = dims.hx, M = dims.ny, L = dims.nz;
     const unsigned xtiles = (unsigned)((size_t)L * (M / dims.ty));
-    const size_t xl = lds_bytes(dims.ty, Hx, kMaxLrXZ);
+    const size_t xl = lds_bytes(dims.ty, Hx);
     const NativeDims d = dims;
     const float2* Tp = T.as<float2>();
     float2* Sp = S.as<float2>();
@@ -1076,7 +1333,7 @@ int NativeFft::x_inverse(hipStream_t s, float* out, int epi_kind, const ConvEpil
     const PadWindow w = pw;
     int rc = MI_ERR_INVALID;
     static const bool no_pipe = std::getenv("MI_FFT_NO_PIPE") != nullptr;
-    if (fuse_forward && !pw.on && dims.dbg == 0 && !no_pipe && dims.ty == x_tile_rows(Hx, kMaxLrXZ)) {
+    if (fuse_forward && !pw.on && dims.dbg == 0 && !no_pipe && dims.ty == x_tile_rows(Hx)) {
         const int ntiles = (int)xtiles;
         const unsigned grid = (unsigned)std::min(ntiles, n_cu);
 #define MI_XP(LG, R) case LG * 16 + R: rc = launch_lds(k_x_fused_pipe<LG, R>, grid, kThreadsXZ, xl, s, "k_x_fused_pipe", Tp, out, epi, d, twx, Sp, ek, ntiles); break;
