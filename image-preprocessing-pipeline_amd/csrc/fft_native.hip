@@ -99,10 +99,26 @@ __device__ __forceinline__ void stage_sync(bool priv) {
 // 11 VALU instructions per value, a sixth of the fused x pass, for a difference far inside the fp32 noise of the transforms
 __device__ __forceinline__ float rcp_eps(float c) { return __builtin_amdgcn_rcpf(fmaxf(c, kEpsSingle)); }
 
-__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
-__device__ __forceinline__ float2 cmulc(float2 a, float2 b) { return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }  // a*conj(b)
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+// Complex arithmetic on packed pairs: written on 2-vectors with explicit lane shuffles so that every complex product becomes
+// v_pk_mul_f32 + v_pk_fma_f32 (lane selects and the swapped / negated twiddle are operand modifiers or hoisted set-up);
+// from the scalar formulas the compiler emits one v_pk_mul + two half-used v_pk_fma + a move per product.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f V2(float2 a) { return v2f{a.x, a.y}; }
+__device__ __forceinline__ float2 F2(v2f a) { return make_float2(a.x, a.y); }
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+    const v2f A = V2(a), B = V2(b);
+    const v2f axx = __builtin_shufflevector(A, A, 0, 0), ayy = __builtin_shufflevector(A, A, 1, 1);
+    const v2f bs = {-B.y, B.x};
+    return F2(__builtin_elementwise_fma(ayy, bs, axx * B));
+}
+__device__ __forceinline__ float2 cmulc(float2 a, float2 b) {  // a * conj(b)
+    const v2f A = V2(a), B = V2(b);
+    const v2f axx = __builtin_shufflevector(A, A, 0, 0), ayy = __builtin_shufflevector(A, A, 1, 1);
+    const v2f bc = {B.x, -B.y}, bsw = {B.y, B.x};
+    return F2(__builtin_elementwise_fma(ayy, bsw, axx * bc));
+}
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return F2(V2(a) + V2(b)); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return F2(V2(a) - V2(b)); }
 __device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
 __device__ __forceinline__ unsigned brev_n(unsigned v, int bits) { return bits == 0 ? 0u : (__brev(v) >> (32 - bits)); }
 
@@ -270,20 +286,97 @@ struct SeqMap {
     }
 };
 
+// The LR radix-2 stages of a super-stage on the R = 2^LR points of one lane.  wf = exp(-2 pi i m / 2^(S_LO+LR)) is the lane's
+// finest twiddle (unused when S_LO == 0); the twiddle of a butterfly factors into a power of it (LR - 1 squarings) and a
+// per-register constant.
+template <int LR, int S_LO, bool INVERSE>
+__device__ __forceinline__ void butterflies(float2 (&v)[1 << LR], float2 wf) {
+    constexpr int R = 1 << LR;
+    float2 wst[LR];
+    if (S_LO > 0) {
+        wst[LR - 1] = wf;
+#pragma unroll
+        for (int b = LR - 2; b >= 0; --b) wst[b] = cmul(wst[b + 1], wst[b + 1]);
+    }
+#pragma unroll
+    for (int step = 0; step < LR; ++step) {
+        const int bpos = INVERSE ? step : LR - 1 - step;  // local bit handled by this radix-2 stage
+        float2 wb = make_float2(1.0f, 0.0f);
+        if (S_LO > 0) wb = wst[bpos];
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            if (j & (1 << bpos)) continue;
+            const int jl = j & ((1 << bpos) - 1);
+            const int k16 = jl * (8 >> bpos);  // jl / 2^(bpos+1) turns = k16 / 16
+            float2 w;
+            if (S_LO == 0) w = make_float2(c16(k16), -s16(k16));
+            else if (jl == 0) w = wb;
+            else w = cmul(wb, make_float2(c16(k16), -s16(k16)));
+            const float2 a = v[j], c = v[j | (1 << bpos)];
+            if (INVERSE) {
+                const float2 t = (S_LO == 0 && jl == 0) ? c : cmulc(c, w);
+                v[j] = cadd(a, t);
+                v[j | (1 << bpos)] = csub(a, t);
+            } else {
+                v[j] = cadd(a, c);
+                const float2 dd = csub(a, c);
+                v[j | (1 << bpos)] = (S_LO == 0 && jl == 0) ? dd : cmul(dd, w);
+            }
+        }
+    }
+}
+
+// element of register 0 of group g: the LR-bit register field is inserted at bit S_LO (register j: | (j << S_LO)).  The map is
+// a bit permutation, hence OR/XOR-linear: p0(g1 | g2) = p0(g1) | p0(g2) for disjoint g1, g2.
+template <int LR, int S_LO>
+__host__ __device__ constexpr int group_elem(int g) { return ((g >> S_LO) << (S_LO + LR)) | (g & ((1 << S_LO) - 1)); }
+
 // One super-stage, everything about the transform compile-time: R = 2^LR points per lane, radix-2 stages
 // S_LO+LR-1..S_LO (forward, DIF) or S_LO..S_LO+LR-1 (inverse, DIT) on the sequences of the tile.
-// twl[m] = exp(-2 pi i m / 2^(S_LO+LR)), m < 2^S_LO (LDS).  The twiddle of a butterfly factors into a per-lane
-// part (one table look-up per super-stage and LR - 1 squarings; none when S_LO == 0) and a per-register constant.
+// twl[m] = exp(-2 pi i m / 2^(S_LO+LR)), m < 2^S_LO (LDS).
 template <int LOGN, int LR, int S_LO, bool INVERSE, int NT, int R3>
 __device__ __forceinline__ void super_stage(float2* tile, int batch, int pitch, int hp, bool priv, const float2* twl) {
-    constexpr int R = 1 << LR, H_LO = 1 << S_LO;
+    constexpr int R = 1 << LR, H_LO = 1 << S_LO, GL = LOGN - LR, NW = NT / 64;
+    if constexpr (GL >= 6) {
+        if (priv) {
+            // Wave-private rows, 64 groups per step: the group index is lane | (k << 6), so everything that depends on the
+            // sequence and on k is wave-uniform (SALU) and, the swizzle being XOR-linear, a lane's slots are its own
+            // constants XOR one scalar per step.
+            const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+            const int a_lane = phys(group_elem<LR, S_LO>(lane));
+            const int m_lane = lane & (H_LO - 1);
+            const int nseq = (batch / R3) / NW * R3;
+            for (int bl = 0; bl < nseq; ++bl) {
+                const int rl = bl / R3, sub = bl - rl * R3, rowi = rl * NW + wave;
+                float2* row = tile + rowi * pitch;
+                const int s_seq = swz_c(sub << LOGN) ^ rmask(rowi, hp);
+#pragma unroll 1
+                for (int k = 0; k < (1 << GL) / 64; ++k) {
+                    const int gk = k << 6;
+                    const int a0 = a_lane ^ (s_seq ^ swz_c(group_elem<LR, S_LO>(gk)));
+                    float2 v[R];
+#pragma unroll
+                    for (int j = 0; j < R; ++j) v[j] = H_LO >= 256 ? row[a0 + j * H_LO] : row[a0 ^ swz_c(j << S_LO)];
+                    float2 wf = make_float2(1.0f, 0.0f);
+                    if (S_LO > 0) wf = twl[m_lane | (gk & (H_LO - 1))];
+                    butterflies<LR, S_LO, INVERSE>(v, wf);
+#pragma unroll
+                    for (int j = 0; j < R; ++j) {
+                        if (H_LO >= 256) row[a0 + j * H_LO] = v[j];
+                        else row[a0 ^ swz_c(j << S_LO)] = v[j];
+                    }
+                }
+            }
+            return;
+        }
+    }
     const SeqMap<LOGN, LR, NT, R3> map(batch, priv);
 #pragma unroll 1
     for (int u = map.first; u < map.total; u += map.step) {
         int rowi, sub, g;
         map.at(u, rowi, sub, g);
         const int m = g & (H_LO - 1);
-        const int p0 = (sub << LOGN) | ((g >> S_LO) << (S_LO + LR)) | m;  // element of register 0; register j: p0 | (j << S_LO)
+        const int p0 = (sub << LOGN) | group_elem<LR, S_LO>(g);  // element of register 0; register j: p0 | (j << S_LO)
         float2* row = tile + rowi * pitch;
         // slot(p0 | J) = slot(p0) ^ swz_c(J) (the swizzle is linear and the j field of p0 is zero); for H_LO >= 256 the j
         // field lies above the swizzled bits and the R slots are slot(p0) + j * H_LO: immediate offsets
@@ -291,38 +384,9 @@ __device__ __forceinline__ void super_stage(float2* tile, int batch, int pitch, 
         float2 v[R];
 #pragma unroll
         for (int j = 0; j < R; ++j) v[j] = H_LO >= 256 ? row[a0 + j * H_LO] : row[a0 ^ swz_c(j << S_LO)];
-        float2 wst[LR];
-        if (S_LO > 0) {
-            wst[LR - 1] = twl[m];
-#pragma unroll
-            for (int b = LR - 2; b >= 0; --b) wst[b] = make_float2(wst[b + 1].x * wst[b + 1].x - wst[b + 1].y * wst[b + 1].y, 2.0f * wst[b + 1].x * wst[b + 1].y);
-        }
-#pragma unroll
-        for (int step = 0; step < LR; ++step) {
-            const int bpos = INVERSE ? step : LR - 1 - step;  // local bit handled by this radix-2 stage
-            float2 wb = make_float2(1.0f, 0.0f);
-            if (S_LO > 0) wb = wst[bpos];
-#pragma unroll
-            for (int j = 0; j < R; ++j) {
-                if (j & (1 << bpos)) continue;
-                const int jl = j & ((1 << bpos) - 1);
-                const int k16 = jl * (8 >> bpos);  // jl / 2^(bpos+1) turns = k16 / 16
-                float2 w;
-                if (S_LO == 0) w = make_float2(c16(k16), -s16(k16));
-                else if (jl == 0) w = wb;
-                else w = cmul(wb, make_float2(c16(k16), -s16(k16)));
-                const float2 a = v[j], c = v[j | (1 << bpos)];
-                if (INVERSE) {
-                    const float2 t = (S_LO == 0 && jl == 0) ? c : cmulc(c, w);
-                    v[j] = cadd(a, t);
-                    v[j | (1 << bpos)] = csub(a, t);
-                } else {
-                    v[j] = cadd(a, c);
-                    const float2 dd = csub(a, c);
-                    v[j | (1 << bpos)] = (S_LO == 0 && jl == 0) ? dd : cmul(dd, w);
-                }
-            }
-        }
+        float2 wf = make_float2(1.0f, 0.0f);
+        if (S_LO > 0) wf = twl[m];
+        butterflies<LR, S_LO, INVERSE>(v, wf);
 #pragma unroll
         for (int j = 0; j < R; ++j) {
             if (H_LO >= 256) row[a0 + j * H_LO] = v[j];
@@ -979,35 +1043,41 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_x_fused_pipe(const flo
     constexpr int NQ = hp * Hx;  // float4 per tile, in the transposed (T / S) and in the row (bl) view alike
     constexpr int NPF = (NQ + kThreadsXZ - 1) / kThreadsXZ;
     constexpr int pitch = row_pitch(Hx);
+    constexpr int P = kThreadsXZ / hp;  // item j of a lane in the transposed view: column px0 + j * P, row pair rp
     // rows dealt to the waves: the inverse transform, the epilogue and the forward transform of a row all belong to its owner
     // and run without work-group barriers; only the transposed fill and drain are tile-wide
-    constexpr bool PRIV = (TY % NW == 0) && (NQ % kThreadsXZ == 0);
+    constexpr bool PRIV = (TY % NW == 0) && (NQ % kThreadsXZ == 0) && (quads % 64 == 0);
     const int ytiles = d.ny / TY, rowq = d.ny / 2;
+    // Lane constants of the two views (tile-invariant, a handful of registers).  The swizzle is XOR-linear, so the slot of
+    // item j is the slot of item 0 XOR a compile-time constant: px0 < P and j * P (2 * lane < 128 and the multiples of 128 of
+    // the row view) occupy disjoint bits.
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int px0 = tid / hp, rp = tid - px0 * hp;
+    const int t_row = (2 * rp) * pitch, t_slot = phys(px0) ^ rmask(2 * rp, hp);
+    const size_t t_off = (size_t)px0 * rowq + rp;
+    const int r_slot = phys(2 * lane);
+    auto t_cell = [&](int j) { return t_row + (t_slot ^ swz_c(j * P)); };
+    // row view, item j: PRIV: float4 u = lane + 64 j of the wave's rows -> row rl * NW + wave, quad q; else float4 tid + j * NT
+    auto r_item = [&](int j, int& i, int& c) {
+        if (PRIV) {
+            const int rl = (64 * j) / quads, q0 = (64 * j) % quads;  // compile-time after unrolling
+            const int r = rl * NW + wave;                              // scalar
+            i = r * quads + q0 + lane;
+            c = r * pitch + (r_slot ^ swz_c(2 * q0) ^ rmask(r, hp));
+        } else {
+            i = tid + j * kThreadsXZ;
+            const int r = i / quads, q = i - r * quads;
+            c = cell(r, pitch, hp, 2 * q);
+        }
+    };
     float4 pre[NPF];
     auto tile_base = [&](int t) { const int z = t / ytiles, y0 = (t - z * ytiles) * TY; return ((size_t)z * Hx) * d.ny + y0; };
     auto load_T = [&](int t) {
-        const int tid = launder(threadIdx.x);
-        const float4* src = reinterpret_cast<const float4*>(T + tile_base(t));
+        const float4* src = reinterpret_cast<const float4*>(T + tile_base(t)) + t_off;
 #pragma unroll
-        for (int j = 0; j < NPF; ++j) {
-            const int i = tid + j * kThreadsXZ;
-            if (NQ % kThreadsXZ == 0 || i < NQ) { const int px = i / hp, rp = i - px * hp; pre[j] = src[(size_t)px * rowq + rp]; }
-        }
-    };
-    // row-side item j of this lane: float4 `i` of the tile's rows (contiguous in bl) = row r, quad q
-    auto row_item = [&](int tid, int j, int& i, int& r, int& q) {
-        if (PRIV) {
-            const int u = (tid & 63) + j * 64;
-            int rl = u / quads;
-            if (quads % 64 == 0) rl = __builtin_amdgcn_readfirstlane(rl);
-            q = u - rl * quads;
-            r = rl * NW + __builtin_amdgcn_readfirstlane(tid >> 6);
-            i = r * quads + q;
-        } else {
-            i = tid + j * kThreadsXZ;
-            r = i / quads;
-            q = i - r * quads;
-        }
+        for (int j = 0; j < NPF; ++j)
+            if (NQ % kThreadsXZ == 0 || tid + j * kThreadsXZ < NQ) pre[j] = src[(size_t)(j * P) * rowq];
     };
     using TW = TwLds<LHX2, R3>;
     float2* twl = tile + TY * pitch;
@@ -1015,15 +1085,10 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_x_fused_pipe(const flo
     int t = blockIdx.x;
     if (t < ntiles) load_T(t);
     for (; t < ntiles; t += gridDim.x) {
-        // launder(): the per-lane index arithmetic is tile-invariant, and hoisted out of this loop it would pin dozens of
-        // address registers across the FFT phases (spills); recomputing it per phase costs a few VALU ops
-        int tid = launder(threadIdx.x);
 #pragma unroll
         for (int j = 0; j < NPF; ++j) {
-            const int i = tid + j * kThreadsXZ;
-            if (NQ % kThreadsXZ == 0 || i < NQ) {
-                const int px = i / hp, rp = i - px * hp;
-                const int c0 = cell(2 * rp, pitch, hp, px);
+            if (NQ % kThreadsXZ == 0 || tid + j * kThreadsXZ < NQ) {
+                const int c0 = t_cell(j);
                 tile[c0] = make_float2(pre[j].x, pre[j].y);
                 tile[c0 + pitch] = make_float2(pre[j].z, pre[j].w);
             }
@@ -1033,11 +1098,10 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_x_fused_pipe(const flo
         const size_t row0 = ((size_t)z * d.ny + y0) * (size_t)(2 * Hx);
         const float4* a4 = reinterpret_cast<const float4*>(e.a + row0);
         float4 av[NPF];
-        tid = launder(threadIdx.x);
 #pragma unroll
         for (int j = 0; j < NPF; ++j) {
-            int i, r, q;
-            row_item(tid, j, i, r, q);
+            int i, c;
+            r_item(j, i, c);
             if (NQ % kThreadsXZ == 0 || i < NQ) av[j] = a4[i];
         }
         lds_barrier();
@@ -1047,13 +1111,11 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_x_fused_pipe(const flo
             stage_sync(PRIV);
         }
         float4* dst = reinterpret_cast<float4*>(out + row0);
-        tid = launder(threadIdx.x);
 #pragma unroll
         for (int j = 0; j < NPF; ++j) {
-            int i, r, q;
-            row_item(tid, j, i, r, q);
+            int i, s0;
+            r_item(j, i, s0);  // elements 2q and 2q + 1 are slot neighbours
             if (NQ % kThreadsXZ == 0 || i < NQ) {
-                const int s0 = cell(r, pitch, hp, 2 * q);  // elements 2q and 2q + 1 are slot neighbours
                 const float2 c0 = tile[s0], c1 = tile[s0 ^ 1];
                 const float4 a = av[j];
                 float4 o;
@@ -1075,16 +1137,13 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_x_fused_pipe(const flo
         }
         lds_fft<LHX2, false, kThreadsXZ, R3>(tile, TY * R3, pitch, hp, PRIV, twl);
         if (PRIV) lds_barrier();  // rows complete for everybody before the transposed drain
-        float4* sdst = reinterpret_cast<float4*>(S_next + tile_base(t));
-        tid = launder(threadIdx.x);
+        float4* sdst = reinterpret_cast<float4*>(S_next + tile_base(t)) + t_off;
 #pragma unroll
         for (int j = 0; j < NPF; ++j) {
-            const int i = tid + j * kThreadsXZ;
-            if (NQ % kThreadsXZ == 0 || i < NQ) {
-                const int px = i / hp, rp = i - px * hp;
-                const int c0 = cell(2 * rp, pitch, hp, px);
+            if (NQ % kThreadsXZ == 0 || tid + j * kThreadsXZ < NQ) {
+                const int c0 = t_cell(j);
                 const float2 a = tile[c0], b = tile[c0 + pitch];
-                sdst[(size_t)px * rowq + rp] = make_float4(a.x, a.y, b.x, b.y);
+                sdst[(size_t)(j * P) * rowq] = make_float4(a.x, a.y, b.x, b.y);
             }
         }
         lds_barrier();  // the tile is free for the next fill
