@@ -763,9 +763,21 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_z_conv_pipe(const floa
     constexpr int NPA = (NA + kThreadsXZ - 1) / kThreadsXZ;
     constexpr int NG = TL * L;                                   // OTF float4 of a tile = point-wise items
     constexpr int NPG = (NG + kThreadsXZ - 1) / kThreadsXZ;
+    constexpr int P = kThreadsXZ / hp;                           // transposed view: item k of a lane is position z0 + k * P
     constexpr bool PRIV = ((2 * TL) % NW) == 0;
+    // point-wise view: item k of a lane is element pz0 of line j0 + k * JS when the lines divide the work-group evenly
+    constexpr bool EVEN = (kThreadsXZ % L == 0) && (L % 64 == 0) && (NG % kThreadsXZ == 0) && ((kThreadsXZ / L) % 2 == 0 || kThreadsXZ == L);
+    constexpr int JS = kThreadsXZ / (L > 0 ? L : 1);
     const int Hx = d.hx, M = d.ny;
     const int ytiles = M / TL, rowq = M / 2;
+    // lane constants (tile-invariant): the swizzle is XOR-linear, so item k's slot is item 0's slot XOR a constant
+    const int tid = threadIdx.x;
+    const int z0 = tid / hp, jp = tid - z0 * hp;
+    const int f_row = (2 * jp) * pitch, f_slot = phys(z0) ^ rmask(2 * jp, hp);
+    const size_t f_off = (size_t)z0 * rowq + jp;
+    auto f_cell = [&](int k) { return f_row + (f_slot ^ swz_c(k * P)); };
+    const int pz0 = tid % L, j0 = __builtin_amdgcn_readfirstlane(tid / L);
+    const int pA = phys(pz0), pB = phys(mirror_pos(pz0, L, LZ2, R3));
     float4 preA[NPA], preB[NPA];
     struct Where { int plane, py0, px, pxB, pyB0; };
     auto where = [&](int t) {
@@ -779,16 +791,13 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_z_conv_pipe(const floa
     };
     auto load_S = [&](int t) {
         const Where w = where(t);
-        const int tid = launder(threadIdx.x);
-        const float4* sA = reinterpret_cast<const float4*>(S + (size_t)w.px * L * M + w.py0);
-        const float4* sB = reinterpret_cast<const float4*>(S + (size_t)w.pxB * L * M + w.pyB0);
+        const float4* sA = reinterpret_cast<const float4*>(S + (size_t)w.px * L * M + w.py0) + f_off;
+        const float4* sB = reinterpret_cast<const float4*>(S + (size_t)w.pxB * L * M + w.pyB0) + f_off;
 #pragma unroll
         for (int k = 0; k < NPA; ++k) {
-            const int i = tid + k * kThreadsXZ;
-            if (NA % kThreadsXZ == 0 || i < NA) {
-                const int z = i / hp, jp = i - z * hp;
-                preA[k] = sA[(size_t)z * rowq + jp];
-                preB[k] = sB[(size_t)z * rowq + jp];
+            if (NA % kThreadsXZ == 0 || tid + k * kThreadsXZ < NA) {
+                preA[k] = sA[(size_t)(k * P) * rowq];
+                preB[k] = sB[(size_t)(k * P) * rowq];
             }
         }
     };
@@ -799,13 +808,10 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_z_conv_pipe(const floa
     if (t < ntiles) load_S(t);
     for (; t < ntiles; t += gridDim.x) {
         const Where w = where(t);
-        int tid = launder(threadIdx.x);
 #pragma unroll
         for (int k = 0; k < NPA; ++k) {
-            const int i = tid + k * kThreadsXZ;
-            if (NA % kThreadsXZ == 0 || i < NA) {
-                const int z = i / hp, jp = i - z * hp;
-                const int cA = cell(2 * jp, pitch, hp, z), cB = cA + TL * pitch;
+            if (NA % kThreadsXZ == 0 || tid + k * kThreadsXZ < NA) {
+                const int cA = f_cell(k), cB = cA + TL * pitch;  // rows TL + 2 jp carry the same mask
                 tile[cA] = make_float2(preA[k].x, preA[k].y);
                 tile[cA + pitch] = make_float2(preA[k].z, preA[k].w);
                 tile[cB] = make_float2(preB[k].x, preB[k].y);
@@ -814,12 +820,9 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_z_conv_pipe(const floa
         }
         const float4* Gp = G + ((size_t)w.plane * M + w.py0) * L;
         float4 gv[NPG];
-        tid = launder(threadIdx.x);
 #pragma unroll
-        for (int k = 0; k < NPG; ++k) {
-            const int i = tid + k * kThreadsXZ;
-            if (NG % kThreadsXZ == 0 || i < NG) gv[k] = Gp[i];
-        }
+        for (int k = 0; k < NPG; ++k)
+            if (NG % kThreadsXZ == 0 || tid + k * kThreadsXZ < NG) gv[k] = Gp[tid + k * kThreadsXZ];
         lds_barrier();
         if constexpr (R3 > 1) {
             radix3_stage<R3, false, kThreadsXZ>(tile, 2 * TL, pitch, hp, PRIV, 1 << LZ2, twl + TW::r3);
@@ -830,17 +833,24 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_z_conv_pipe(const floa
         float sw, cw;
         sincospif(-2.0f * (float)w.plane / (float)(2 * Hx), &sw, &cw);  // exp(-2 pi i xk / Nx), Nx = 2 Hx
         const float2 wx = make_float2(cw, sw);
-        tid = launder(threadIdx.x);
 #pragma unroll
         for (int k = 0; k < NPG; ++k) {
             const int i = tid + k * kThreadsXZ;
             if (NG % kThreadsXZ == 0 || i < NG) {
-                int j = i / L;
-                if (L % 64 == 0) j = __builtin_amdgcn_readfirstlane(j);  // a wave's 64 items share the line: scalar mirror math
-                const int pz = i - j * L;
-                const int jB = y_mirror_pos(w.py0 + j, d) - w.pyB0;
-                const int pzB = mirror_pos(pz, L, LZ2, R3);
-                const int cA = cell(j, pitch, hp, pz), cB = cell(TL + jB, pitch, hp, pzB);
+                int cA, cB;
+                if (EVEN) {
+                    const int j = j0 + k * JS;                                // scalar: the line is shared by the wave
+                    const int jB = y_mirror_pos(w.py0 + j, d) - w.pyB0;       // scalar mirror math
+                    cA = j * pitch + (pA ^ rmask(j, hp));
+                    cB = (TL + jB) * pitch + (pB ^ rmask(TL + jB, hp));
+                } else {
+                    int j = i / L;
+                    if (L % 64 == 0) j = __builtin_amdgcn_readfirstlane(j);
+                    const int pz = i - j * L;
+                    const int jB = y_mirror_pos(w.py0 + j, d) - w.pyB0;
+                    cA = cell(j, pitch, hp, pz);
+                    cB = cell(TL + jB, pitch, hp, mirror_pos(pz, L, LZ2, R3));
+                }
                 const float2 a = tile[cA];
                 const float2 bc = cconj(tile[cB]);
                 const float2 E = make_float2(0.5f * (a.x + bc.x), 0.5f * (a.y + bc.y));
@@ -868,20 +878,17 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_z_conv_pipe(const floa
         }
         if (PRIV) lds_barrier();
         const bool self_plane = (w.px == w.pxB);
-        float4* dA = reinterpret_cast<float4*>(T + (size_t)w.px * L * M + w.py0);
-        float4* dB = reinterpret_cast<float4*>(T + (size_t)w.pxB * L * M + w.pyB0);
-        tid = launder(threadIdx.x);
+        float4* dA = reinterpret_cast<float4*>(T + (size_t)w.px * L * M + w.py0) + f_off;
+        float4* dB = reinterpret_cast<float4*>(T + (size_t)w.pxB * L * M + w.pyB0) + f_off;
 #pragma unroll
         for (int k = 0; k < NPA; ++k) {
-            const int i = tid + k * kThreadsXZ;
-            if (NA % kThreadsXZ == 0 || i < NA) {
-                const int z = i / hp, jp = i - z * hp;
-                const int cA = cell(2 * jp, pitch, hp, z), cB = cA + TL * pitch;
+            if (NA % kThreadsXZ == 0 || tid + k * kThreadsXZ < NA) {
+                const int cA = f_cell(k), cB = cA + TL * pitch;
                 const float2 a0 = tile[cA], a1 = tile[cA + pitch];
-                dA[(size_t)z * rowq + jp] = make_float4(a0.x, a0.y, a1.x, a1.y);
+                dA[(size_t)(k * P) * rowq] = make_float4(a0.x, a0.y, a1.x, a1.y);
                 if (!self_plane) {
                     const float2 b0 = tile[cB], b1 = tile[cB + pitch];
-                    dB[(size_t)z * rowq + jp] = make_float4(b0.x, b0.y, b1.x, b1.y);
+                    dB[(size_t)(k * P) * rowq] = make_float4(b0.x, b0.y, b1.x, b1.y);
                 }
             }
         }
