@@ -770,14 +770,14 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_z_conv_pipe(const floa
     constexpr int JS = kThreadsXZ / (L > 0 ? L : 1);
     const int Hx = d.hx, M = d.ny;
     const int ytiles = M / TL, rowq = M / 2;
-    // lane constants (tile-invariant): the swizzle is XOR-linear, so item k's slot is item 0's slot XOR a constant
-    const int tid = threadIdx.x;
-    const int z0 = tid / hp, jp = tid - z0 * hp;
-    const int f_row = (2 * jp) * pitch, f_slot = phys(z0) ^ rmask(2 * jp, hp);
-    const size_t f_off = (size_t)z0 * rowq + jp;
-    auto f_cell = [&](int k) { return f_row + (f_slot ^ swz_c(k * P)); };
-    const int pz0 = tid % L, j0 = __builtin_amdgcn_readfirstlane(tid / L);
-    const int pA = phys(pz0), pB = phys(mirror_pos(pz0, L, LZ2, R3));
+    // lane constants (tile-invariant; recomputed per phase from a laundered thread index so that they do not occupy registers
+    // across the FFT phases): the swizzle is XOR-linear, so item k's slot is item 0's slot XOR a constant
+    struct FView { int row, slot; size_t off; };  // transposed view: item k = position z0 + k * P, line pair jp
+    auto f_view = [&]() {
+        const int tid = launder(threadIdx.x);
+        const int z0 = tid / hp, jp = tid - z0 * hp;
+        return FView{(2 * jp) * pitch, phys(z0) ^ rmask(2 * jp, hp), (size_t)z0 * rowq + jp};
+    };
     float4 preA[NPA], preB[NPA];
     struct Where { int plane, py0, px, pxB, pyB0; };
     auto where = [&](int t) {
@@ -791,11 +791,12 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_z_conv_pipe(const floa
     };
     auto load_S = [&](int t) {
         const Where w = where(t);
-        const float4* sA = reinterpret_cast<const float4*>(S + (size_t)w.px * L * M + w.py0) + f_off;
-        const float4* sB = reinterpret_cast<const float4*>(S + (size_t)w.pxB * L * M + w.pyB0) + f_off;
+        const FView fv = f_view();
+        const float4* sA = reinterpret_cast<const float4*>(S + (size_t)w.px * L * M + w.py0) + fv.off;
+        const float4* sB = reinterpret_cast<const float4*>(S + (size_t)w.pxB * L * M + w.pyB0) + fv.off;
 #pragma unroll
         for (int k = 0; k < NPA; ++k) {
-            if (NA % kThreadsXZ == 0 || tid + k * kThreadsXZ < NA) {
+            if (NA % kThreadsXZ == 0 || (int)threadIdx.x + k * kThreadsXZ < NA) {
                 preA[k] = sA[(size_t)(k * P) * rowq];
                 preB[k] = sB[(size_t)(k * P) * rowq];
             }
@@ -808,21 +809,27 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_z_conv_pipe(const floa
     if (t < ntiles) load_S(t);
     for (; t < ntiles; t += gridDim.x) {
         const Where w = where(t);
+        {
+        const FView fv = f_view();
 #pragma unroll
         for (int k = 0; k < NPA; ++k) {
-            if (NA % kThreadsXZ == 0 || tid + k * kThreadsXZ < NA) {
-                const int cA = f_cell(k), cB = cA + TL * pitch;  // rows TL + 2 jp carry the same mask
+            if (NA % kThreadsXZ == 0 || (int)threadIdx.x + k * kThreadsXZ < NA) {
+                const int cA = fv.row + (fv.slot ^ swz_c(k * P)), cB = cA + TL * pitch;  // rows TL + 2 jp carry the same mask
                 tile[cA] = make_float2(preA[k].x, preA[k].y);
                 tile[cA + pitch] = make_float2(preA[k].z, preA[k].w);
                 tile[cB] = make_float2(preB[k].x, preB[k].y);
                 tile[cB + pitch] = make_float2(preB[k].z, preB[k].w);
             }
         }
+        }
         const float4* Gp = G + ((size_t)w.plane * M + w.py0) * L;
         float4 gv[NPG];
+        {
+            const int tid = launder(threadIdx.x);
 #pragma unroll
-        for (int k = 0; k < NPG; ++k)
-            if (NG % kThreadsXZ == 0 || tid + k * kThreadsXZ < NG) gv[k] = Gp[tid + k * kThreadsXZ];
+            for (int k = 0; k < NPG; ++k)
+                if (NG % kThreadsXZ == 0 || tid + k * kThreadsXZ < NG) gv[k] = Gp[tid + k * kThreadsXZ];
+        }
         lds_barrier();
         if constexpr (R3 > 1) {
             radix3_stage<R3, false, kThreadsXZ>(tile, 2 * TL, pitch, hp, PRIV, 1 << LZ2, twl + TW::r3);
@@ -833,6 +840,9 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_z_conv_pipe(const floa
         float sw, cw;
         sincospif(-2.0f * (float)w.plane / (float)(2 * Hx), &sw, &cw);  // exp(-2 pi i xk / Nx), Nx = 2 Hx
         const float2 wx = make_float2(cw, sw);
+        const int tid = launder(threadIdx.x);
+        const int pz0 = tid % L, j0 = __builtin_amdgcn_readfirstlane(tid / L);
+        const int pA = phys(pz0), pB = phys(mirror_pos(pz0, L, LZ2, R3));
 #pragma unroll
         for (int k = 0; k < NPG; ++k) {
             const int i = tid + k * kThreadsXZ;
@@ -878,12 +888,13 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_z_conv_pipe(const floa
         }
         if (PRIV) lds_barrier();
         const bool self_plane = (w.px == w.pxB);
-        float4* dA = reinterpret_cast<float4*>(T + (size_t)w.px * L * M + w.py0) + f_off;
-        float4* dB = reinterpret_cast<float4*>(T + (size_t)w.pxB * L * M + w.pyB0) + f_off;
+        const FView fv = f_view();
+        float4* dA = reinterpret_cast<float4*>(T + (size_t)w.px * L * M + w.py0) + fv.off;
+        float4* dB = reinterpret_cast<float4*>(T + (size_t)w.pxB * L * M + w.pyB0) + fv.off;
 #pragma unroll
         for (int k = 0; k < NPA; ++k) {
-            if (NA % kThreadsXZ == 0 || tid + k * kThreadsXZ < NA) {
-                const int cA = f_cell(k), cB = cA + TL * pitch;
+            if (NA % kThreadsXZ == 0 || (int)threadIdx.x + k * kThreadsXZ < NA) {
+                const int cA = fv.row + (fv.slot ^ swz_c(k * P)), cB = cA + TL * pitch;
                 const float2 a0 = tile[cA], a1 = tile[cA + pitch];
                 dA[(size_t)(k * P) * rowq] = make_float4(a0.x, a0.y, a1.x, a1.y);
                 if (!self_plane) {
@@ -1058,22 +1069,29 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_x_fused_pipe(const flo
     // Lane constants of the two views (tile-invariant, a handful of registers).  The swizzle is XOR-linear, so the slot of
     // item j is the slot of item 0 XOR a compile-time constant: px0 < P and j * P (2 * lane < 128 and the multiples of 128 of
     // the row view) occupy disjoint bits.
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int px0 = tid / hp, rp = tid - px0 * hp;
-    const int t_row = (2 * rp) * pitch, t_slot = phys(px0) ^ rmask(2 * rp, hp);
-    const size_t t_off = (size_t)px0 * rowq + rp;
-    const int r_slot = phys(2 * lane);
-    auto t_cell = [&](int j) { return t_row + (t_slot ^ swz_c(j * P)); };
+    // (They are recomputed at the start of every phase from a laundered thread index: kept live across the FFT phases they
+    // push the kernel over its 128 VGPRs, and every spilled dword costs ~0.5 GB of scratch traffic per launch.)
+    struct TView { int row, slot; size_t off; };   // transposed view: item j = column px0 + j * P, row pair rp
+    auto t_view = [&]() {
+        const int tid = launder(threadIdx.x);
+        const int px0 = tid / hp, rp = tid - px0 * hp;
+        return TView{(2 * rp) * pitch, phys(px0) ^ rmask(2 * rp, hp), (size_t)px0 * rowq + rp};
+    };
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // row view, item j: PRIV: float4 u = lane + 64 j of the wave's rows -> row rl * NW + wave, quad q; else float4 tid + j * NT
-    auto r_item = [&](int j, int& i, int& c) {
+    struct RView { int tid, lane, slot; };
+    auto r_view = [&]() {
+        const int tid = launder(threadIdx.x);
+        return RView{tid, tid & 63, phys(2 * (tid & 63))};
+    };
+    auto r_item = [&](const RView& rv, int j, int& i, int& c) {
         if (PRIV) {
             const int rl = (64 * j) / quads, q0 = (64 * j) % quads;  // compile-time after unrolling
             const int r = rl * NW + wave;                              // scalar
-            i = r * quads + q0 + lane;
-            c = r * pitch + (r_slot ^ swz_c(2 * q0) ^ rmask(r, hp));
+            i = r * quads + q0 + rv.lane;
+            c = r * pitch + (rv.slot ^ swz_c(2 * q0) ^ rmask(r, hp));
         } else {
-            i = tid + j * kThreadsXZ;
+            i = rv.tid + j * kThreadsXZ;
             const int r = i / quads, q = i - r * quads;
             c = cell(r, pitch, hp, 2 * q);
         }
@@ -1081,10 +1099,11 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_x_fused_pipe(const flo
     float4 pre[NPF];
     auto tile_base = [&](int t) { const int z = t / ytiles, y0 = (t - z * ytiles) * TY; return ((size_t)z * Hx) * d.ny + y0; };
     auto load_T = [&](int t) {
-        const float4* src = reinterpret_cast<const float4*>(T + tile_base(t)) + t_off;
+        const TView tv = t_view();
+        const float4* src = reinterpret_cast<const float4*>(T + tile_base(t)) + tv.off;
 #pragma unroll
         for (int j = 0; j < NPF; ++j)
-            if (NQ % kThreadsXZ == 0 || tid + j * kThreadsXZ < NQ) pre[j] = src[(size_t)(j * P) * rowq];
+            if (NQ % kThreadsXZ == 0 || (int)threadIdx.x + j * kThreadsXZ < NQ) pre[j] = src[(size_t)(j * P) * rowq];
     };
     using TW = TwLds<LHX2, R3>;
     float2* twl = tile + TY * pitch;
@@ -1092,12 +1111,15 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_x_fused_pipe(const flo
     int t = blockIdx.x;
     if (t < ntiles) load_T(t);
     for (; t < ntiles; t += gridDim.x) {
+        {
+            const TView tv = t_view();
 #pragma unroll
-        for (int j = 0; j < NPF; ++j) {
-            if (NQ % kThreadsXZ == 0 || tid + j * kThreadsXZ < NQ) {
-                const int c0 = t_cell(j);
-                tile[c0] = make_float2(pre[j].x, pre[j].y);
-                tile[c0 + pitch] = make_float2(pre[j].z, pre[j].w);
+            for (int j = 0; j < NPF; ++j) {
+                if (NQ % kThreadsXZ == 0 || (int)threadIdx.x + j * kThreadsXZ < NQ) {
+                    const int c0 = tv.row + (tv.slot ^ swz_c(j * P));
+                    tile[c0] = make_float2(pre[j].x, pre[j].y);
+                    tile[c0 + pitch] = make_float2(pre[j].z, pre[j].w);
+                }
             }
         }
         // rows of this tile in the real volume: contiguous TY * 2 Hx floats
@@ -1105,11 +1127,14 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_x_fused_pipe(const flo
         const size_t row0 = ((size_t)z * d.ny + y0) * (size_t)(2 * Hx);
         const float4* a4 = reinterpret_cast<const float4*>(e.a + row0);
         float4 av[NPF];
+        {
+            const RView rv = r_view();
 #pragma unroll
-        for (int j = 0; j < NPF; ++j) {
-            int i, c;
-            r_item(j, i, c);
-            if (NQ % kThreadsXZ == 0 || i < NQ) av[j] = a4[i];
+            for (int j = 0; j < NPF; ++j) {
+                int i, c;
+                r_item(rv, j, i, c);
+                if (NQ % kThreadsXZ == 0 || i < NQ) av[j] = a4[i];
+            }
         }
         lds_barrier();
         lds_fft<LHX2, true, kThreadsXZ, R3>(tile, TY * R3, pitch, hp, PRIV, twl);
@@ -1118,10 +1143,11 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_x_fused_pipe(const flo
             stage_sync(PRIV);
         }
         float4* dst = reinterpret_cast<float4*>(out + row0);
+        const RView rv = r_view();
 #pragma unroll
         for (int j = 0; j < NPF; ++j) {
             int i, s0;
-            r_item(j, i, s0);  // elements 2q and 2q + 1 are slot neighbours
+            r_item(rv, j, i, s0);  // elements 2q and 2q + 1 are slot neighbours
             if (NQ % kThreadsXZ == 0 || i < NQ) {
                 const float2 c0 = tile[s0], c1 = tile[s0 ^ 1];
                 const float4 a = av[j];
@@ -1144,11 +1170,12 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_x_fused_pipe(const flo
         }
         lds_fft<LHX2, false, kThreadsXZ, R3>(tile, TY * R3, pitch, hp, PRIV, twl);
         if (PRIV) lds_barrier();  // rows complete for everybody before the transposed drain
-        float4* sdst = reinterpret_cast<float4*>(S_next + tile_base(t)) + t_off;
+        const TView tv = t_view();
+        float4* sdst = reinterpret_cast<float4*>(S_next + tile_base(t)) + tv.off;
 #pragma unroll
         for (int j = 0; j < NPF; ++j) {
-            if (NQ % kThreadsXZ == 0 || tid + j * kThreadsXZ < NQ) {
-                const int c0 = t_cell(j);
+            if (NQ % kThreadsXZ == 0 || (int)threadIdx.x + j * kThreadsXZ < NQ) {
+                const int c0 = tv.row + (tv.slot ^ swz_c(j * P));
                 const float2 a = tile[c0], b = tile[c0 + pitch];
                 sdst[(size_t)(j * P) * rowq] = make_float4(a.x, a.y, b.x, b.y);
             }
@@ -1418,10 +1445,11 @@ int NativeFft::x_inverse(hipStream_t s, float* out, int epi_kind, const ConvEpil
 }
 
 // Average duration (ms) of one launch of a single pass, measured with HIP events on `s` (bench.py's roofline leg).
-// which: 0 x forward, 1 y forward, 2 z convolution, 3 y inverse, 4 fused x inverse+ratio+forward.  The buffers
+// which: 0 x forward, 1 y forward, 2 z convolution, 3 y inverse, 4 fused x inverse+ratio+forward, 5 fused x inverse+update+
+// forward (this one overwrites bl with |bl .* c| of whatever the buffers hold).  The buffers
 // keep whatever the previous convolution left in them; `bl` is only read.
 int NativeFft::time_pass(hipStream_t s, int which, const float* bl, int reps, float* avg_ms) {
-    MI_REQUIRE(reps > 0 && avg_ms && which >= 0 && which <= 4, "time_pass: bad arguments");
+    MI_REQUIRE(reps > 0 && avg_ms && which >= 0 && which <= 5, "time_pass: bad arguments");
     hipEvent_t e0, e1;
     MI_HIP(hipEventCreate(&e0));
     MI_HIP(hipEventCreate(&e1));
@@ -1433,6 +1461,7 @@ int NativeFft::time_pass(hipStream_t s, int which, const float* bl, int reps, fl
         switch (which) {
             case 0: rc = x_forward(s, bl); break;
             case 4: rc = x_inverse(s, nullptr, EPI_RATIO, e, true); break;
+            case 5: rc = x_inverse(s, const_cast<float*>(bl), EPI_UPDATE, e, true); break;
             case 1: rc = y_pass(s, false); break;
             case 2: rc = z_conv(s, false); break;
             default: rc = y_pass(s, true); break;

@@ -274,10 +274,11 @@ class RLContext:
         check(lib().mi_rl_iterate(self._h, _stream(bl), bl.data_ptr(), ratio.data_ptr() if ratio is not None else None,
                                   int(n_iters)))
 
-    PASSES = {"x_forward": 0, "y_forward": 1, "z_conv": 2, "y_inverse": 3, "x_fused": 4}
+    PASSES = {"x_forward": 0, "y_forward": 1, "z_conv": 2, "y_inverse": 3, "x_fused": 4, "x_fused_update": 5}
 
     def time_pass(self, which, bl, reps=5) -> float:
-        """Average ms of one launch of a single pass of the native FFT pipeline (HIP events, mi_rl_time_pass)."""
+        """Average ms of one launch of a single pass of the native FFT pipeline (HIP events, mi_rl_time_pass).
+        ``x_fused_update`` overwrites ``bl`` with meaningless values."""
         self._chk(bl)
         ms = C.c_float()
         check(lib().mi_rl_time_pass(self._h, _stream(bl), self.PASSES[which], bl.data_ptr(), int(reps), C.byref(ms)))

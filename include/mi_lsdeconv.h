@@ -105,7 +105,8 @@ int mi_rl_adjoint_update(mi_rl_ctx* ctx, void* stream, const float* ratio, float
 int mi_rl_iterate(mi_rl_ctx* ctx, void* stream, float* bl, float* ratio, int n_iters);
 /* Measurement hook: average duration in ms of `reps` back-to-back launches of ONE pass of the native FFT pipeline,
  * taken with HIP events on `stream` (which: 0 x-forward, 1 y-forward, 2 z-forward*OTF*z-inverse, 3 y-inverse,
- * 4 fused x-inverse+ratio+x-forward).  MI_ERR_UNSUPPORTED for other engines.  Synchronises. */
+ * 4 fused x-inverse+ratio+x-forward, 5 fused x-inverse+update+x-forward -- this one OVERWRITES bl with values that mean
+ * nothing).  MI_ERR_UNSUPPORTED for other engines.  Synchronises. */
 int mi_rl_time_pass(mi_rl_ctx* ctx, void* stream, int which, const float* bl, int reps, float* avg_ms);
 /* reg = convn(bl, R, 'same'), R = ones(3,3,3)/26 with centre 0   [decon.m:42,70] */
 int mi_rl_reg_term(int dev, void* stream, const float* bl, float* reg, int nx, int ny, int nz);

@@ -14,7 +14,7 @@ def main(db, out):
         w.writerow(["kernel", "calls", "total_ms", "avg_ms", "percent"])
         for name, calls, total, avg, pct in rows:
             short = name if len(name) < 160 else name[:157] + "..."
-            w.writerow([short, calls, round(total / 1e3, 1), round(avg / 1e3, 1), round(pct, 2)])
+            w.writerow([short, calls, round(total / 1e3, 2), round(avg / 1e3, 3), round(pct, 2)])
     print(f"{len(rows)} kernels -> {out}")
 
 
