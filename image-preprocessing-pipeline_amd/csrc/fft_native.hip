@@ -338,37 +338,41 @@ template <int LOGN, int LR, int S_LO, bool INVERSE, int NT, int R3>
 __device__ __forceinline__ void super_stage(float2* tile, int batch, int pitch, int hp, bool priv, const float2* twl) {
     constexpr int R = 1 << LR, H_LO = 1 << S_LO, GL = LOGN - LR, NW = NT / 64;
     if constexpr (GL >= 6) {
-        if (priv) {
-            // Wave-private rows, 64 groups per step: the group index is lane | (k << 6), so everything that depends on the
-            // sequence and on k is wave-uniform (SALU) and, the swizzle being XOR-linear, a lane's slots are its own
-            // constants XOR one scalar per step.
-            const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-            const int a_lane = phys(group_elem<LR, S_LO>(lane));
-            const int m_lane = lane & (H_LO - 1);
-            const int nseq = (batch / R3) / NW * R3;
-            for (int bl = 0; bl < nseq; ++bl) {
-                const int rl = bl / R3, sub = bl - rl * R3, rowi = rl * NW + wave;
-                float2* row = tile + rowi * pitch;
-                const int s_seq = swz_c(sub << LOGN) ^ rmask(rowi, hp);
+        // The group index of a lane is (lane part) | (step part): `coop` lanes work on one sequence (the wave's 64 when rows are
+        // private, else min(NT, groups)), so everything that depends on the sequence and on the step is wave-uniform (SALU)
+        // and, the swizzle being XOR-linear, a lane's slots are its own constants XOR one scalar per step.
+        constexpr int G = 1 << GL;
+        const int coop = priv ? 64 : (NT < G ? NT : G);           // power of two >= 64
+        const int lid = priv ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
+        const int gl = lid & (coop - 1);
+        const int a_lane = phys(group_elem<LR, S_LO>(gl));
+        const int m_lane = gl & (H_LO - 1);
+        // sequences: private rows -> those of the wave's rows; else sequence (lid / coop) + kb * (NT / coop)
+        const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const int b0 = priv ? 0 : __builtin_amdgcn_readfirstlane(lid / coop);
+        const int bstep = priv ? 1 : NT / coop;
+        const int nseq = priv ? (batch / R3) / NW * R3 : batch;
+        for (int bl = b0; bl < nseq; bl += bstep) {
+            const int rl = bl / R3, sub = bl - rl * R3, rowi = priv ? rl * NW + wave : rl;
+            float2* row = tile + rowi * pitch;
+            const int s_seq = swz_c(sub << LOGN) ^ rmask(rowi, hp);
 #pragma unroll 1
-                for (int k = 0; k < (1 << GL) / 64; ++k) {
-                    const int gk = k << 6;
-                    const int a0 = a_lane ^ (s_seq ^ swz_c(group_elem<LR, S_LO>(gk)));
-                    float2 v[R];
+            for (int gk = 0; gk < G; gk += coop) {
+                const int a0 = a_lane ^ (s_seq ^ swz_c(group_elem<LR, S_LO>(gk)));
+                float2 v[R];
 #pragma unroll
-                    for (int j = 0; j < R; ++j) v[j] = H_LO >= 256 ? row[a0 + j * H_LO] : row[a0 ^ swz_c(j << S_LO)];
-                    float2 wf = make_float2(1.0f, 0.0f);
-                    if (S_LO > 0) wf = twl[m_lane | (gk & (H_LO - 1))];
-                    butterflies<LR, S_LO, INVERSE>(v, wf);
+                for (int j = 0; j < R; ++j) v[j] = H_LO >= 256 ? row[a0 + j * H_LO] : row[a0 ^ swz_c(j << S_LO)];
+                float2 wf = make_float2(1.0f, 0.0f);
+                if (S_LO > 0) wf = twl[m_lane | (gk & (H_LO - 1))];
+                butterflies<LR, S_LO, INVERSE>(v, wf);
 #pragma unroll
-                    for (int j = 0; j < R; ++j) {
-                        if (H_LO >= 256) row[a0 + j * H_LO] = v[j];
-                        else row[a0 ^ swz_c(j << S_LO)] = v[j];
-                    }
+                for (int j = 0; j < R; ++j) {
+                    if (H_LO >= 256) row[a0 + j * H_LO] = v[j];
+                    else row[a0 ^ swz_c(j << S_LO)] = v[j];
                 }
             }
-            return;
         }
+        return;
     }
     const SeqMap<LOGN, LR, NT, R3> map(batch, priv);
 #pragma unroll 1
@@ -585,26 +589,50 @@ __global__ __launch_bounds__(kThreadsY, 4) void k_y_pass(const float2* __restric
                                                       const float2* __restrict__ tw) {
     extern __shared__ __attribute__((aligned(16))) float2 tile[];
     constexpr int M = R3 << LY2, NW = kThreadsY / 64;
-    const int TC = d.tc, pitch = row_pitch(M), Hx = d.hx, L = d.nz;
+    constexpr int pitch = row_pitch(M), quads = M / 2;
+    constexpr int TCC = y_tile_cols(M);  // the tile height the host normally picks: compile-time item decomposition
+    const int TC = d.tc, Hx = d.hx, L = d.nz;
     const size_t c0 = (size_t)blockIdx.x * TC;
     const float4* base = reinterpret_cast<const float4*>(src + c0 * M);
-    const int quads = M / 2;
     // columns dealt to the waves when there are enough of them: then the fill, the transform and the drain of a column all
     // belong to one wave and the kernel has no work-group barrier besides the one behind the table fill
     const bool priv = (TC % NW) == 0;
     using TW = TwLds<LY2, R3>;
     float2* twl = tile + TC * pitch;
     TW::template fill<kThreadsY>(twl, tw);
+    // destination of source column sc: forward [z][px] -> [px][z], inverse [px][z] -> [z][px]
+    auto dest_col = [&](size_t sc) {
+        if (INVERSE) { const size_t px = sc / L, z = sc - px * L; return z * Hx + px; }
+        const size_t z = sc / Hx, px = sc - z * Hx;
+        return px * L + z;
+    };
+    // fast path: float4 item k of a lane is quad tid + (k NT mod quads) of column (k NT) / quads -- the column is a
+    // compile-time number (its addresses are scalar), the slot is the lane's constant XOR a compile-time constant
+    constexpr bool FAST_OK = (quads % kThreadsY == 0) && ((TCC * quads) % kThreadsY == 0);
+    constexpr int NIT = FAST_OK ? TCC * quads / kThreadsY : 1;
+    const bool fast = FAST_OK && TC == TCC && !priv;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n_items = priv ? (TC / NW) * quads : TC * quads, first = priv ? lane : threadIdx.x, step = priv ? 64 : kThreadsY;
+    if (fast) {
+        const int s_lane = phys(2 * (int)threadIdx.x);
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int c = (k * kThreadsY) / quads, qk = (k * kThreadsY) % quads;
+            const float4 v = base[(size_t)c * quads + qk + threadIdx.x];
+            const int s0 = c * pitch + (s_lane ^ swz_c(2 * qk));
+            tile[s0] = make_float2(v.x, v.y);
+            tile[s0 ^ 1] = make_float2(v.z, v.w);
+        }
+    } else {
 #pragma unroll MI_FFT_UNROLL
-    for (int i = first; i < n_items; i += step) {
-        const int cl = i / quads, q = i - cl * quads;
-        const int c = priv ? cl * NW + wave : cl;
-        const float4 v = base[(size_t)c * quads + q];
-        const int s0 = c * pitch + phys(2 * q);
-        tile[s0] = make_float2(v.x, v.y);
-        tile[s0 ^ 1] = make_float2(v.z, v.w);
+        for (int i = first; i < n_items; i += step) {
+            const int cl = i / quads, q = i - cl * quads;
+            const int c = priv ? cl * NW + wave : cl;
+            const float4 v = base[(size_t)c * quads + q];
+            const int s0 = c * pitch + phys(2 * q);
+            tile[s0] = make_float2(v.x, v.y);
+            tile[s0 ^ 1] = make_float2(v.z, v.w);
+        }
     }
     lds_barrier();
     if constexpr (!INVERSE && R3 > 1) {
@@ -616,17 +644,25 @@ __global__ __launch_bounds__(kThreadsY, 4) void k_y_pass(const float2* __restric
         radix3_stage<R3, true, kThreadsY>(tile, TC, pitch, 1, priv, 1 << LY2, twl + TW::r3);
         stage_sync(priv);
     }
+    if (fast) {
+        const int s_lane = phys(2 * (int)threadIdx.x);
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int c = (k * kThreadsY) / quads, qk = (k * kThreadsY) % quads;
+            const int s0 = c * pitch + (s_lane ^ swz_c(2 * qk));
+            const float2 a = tile[s0], b = tile[s0 ^ 1];
+            float4* dcol = reinterpret_cast<float4*>(dst + dest_col(c0 + c) * M);  // scalar
+            dcol[qk + threadIdx.x] = make_float4(a.x, a.y, b.x, b.y);
+        }
+    } else {
 #pragma unroll MI_FFT_UNROLL
-    for (int i = first; i < n_items; i += step) {
-        const int cl = i / quads, q = i - cl * quads;
-        const int c = priv ? cl * NW + wave : cl;
-        const size_t sc = c0 + c;  // source column index
-        size_t dc;
-        if (INVERSE) { const size_t px = sc / L, z = sc - px * L; dc = z * Hx + px; }   // [px][z] -> [z][px]
-        else { const size_t z = sc / Hx, px = sc - z * Hx; dc = px * L + z; }           // [z][px] -> [px][z]
-        const int s0 = c * pitch + phys(2 * q);
-        const float2 a = tile[s0], b = tile[s0 ^ 1];
-        reinterpret_cast<float4*>(dst + dc * M)[q] = make_float4(a.x, a.y, b.x, b.y);
+        for (int i = first; i < n_items; i += step) {
+            const int cl = i / quads, q = i - cl * quads;
+            const int c = priv ? cl * NW + wave : cl;
+            const int s0 = c * pitch + phys(2 * q);
+            const float2 a = tile[s0], b = tile[s0 ^ 1];
+            reinterpret_cast<float4*>(dst + dest_col(c0 + c) * M)[q] = make_float4(a.x, a.y, b.x, b.y);
+        }
     }
 }
 
