@@ -1,5 +1,5 @@
-// Hand-written FFT convolution pipeline for gfx950 (engine MI_ENGINE_FFT when every transform length is a
-// power of two and no padding is needed; rocFFT remains the fallback for other shapes).
+// Hand-written FFT convolution pipeline for gfx950 (engine MI_ENGINE_FFT whenever every transform length is 2^a * {1,3,9};
+// rocFFT remains the fallback for other shapes).
 //
 // Why: the rocFFT R2C/C2R route costs 12 transform kernels + multiply + epilogue per convolution
 // (profiles/r01_bench_c3_rocfft_kernel_stats.csv: 62 ms per convolution on C3, its strided z pass alone
@@ -12,18 +12,18 @@
 //
 //   P1  x forward   rows -> LDS -> DIF FFT(Hx) -> S[z][px][y]            (transposed write: y fastest, px stride 16 KB)
 //   P2  y forward   whole contiguous columns: S[z][px][.] -> T[px][z][.]   (the re-layout is free: 16-KB chunks)
-//   P3  z forward + untangle * OTF (or conj) + retangle + z inverse, on mirror line pairs, T -> S, both [px][z][py]
-//                   (z stride 16 KB instead of 16 MB in the [z][px][py] layout)
+//   P3  z forward + untangle * OTF (or conj / explicit adjoint OTF) + retangle + z inverse, on mirror line pairs,
+//                   T -> S, both [px][z][py] (z stride 16 KB instead of 16 MB in the [z][px][py] layout)
 //   P4  y inverse   S[px][z][.] -> T[z][px][.]
 //   P5  x inverse   T[z][px][y] -> LDS -> DIT IFFT(Hx) -> real row -> fused RL epilogue -> out
+//   P5+P1 fused     ... -> epilogue result stays in LDS -> DIF FFT(Hx) -> S of the NEXT convolution (8 passes / RL iteration)
 //
-// Forward transforms are decimation-in-frequency (natural in, bit-reversed out), inverse ones
-// decimation-in-time (bit-reversed in, natural out), so no reordering pass exists: frequency-domain arrays
-// simply live in bit-reversed positions (px, py, pz) and the OTF is pre-permuted once to match.
-// Each transform runs inside LDS as "super-stages" of up to 4 fused radix-2 stages held in registers
-// (16 points per lane), i.e. 3 LDS round trips for 512..4096 points.  LDS rows are padded (one slot per 32
-// plus one per row) so that both the strided butterfly accesses and the transposed tile accesses are
-// bank-conflict free for ds_read/write_b64.
+// Forward transforms are decimation-in-frequency (natural in, permuted out), inverse ones decimation-in-time
+// (permuted in, natural out), so no reordering pass exists: frequency-domain arrays simply live in permuted
+// positions (px, py, pz) and the OTF is built by the pipeline itself in that order (k_z_conv<BUILD>).
+// Each transform runs inside LDS as super-stages of 3 fused radix-2 stages held in registers (8 points per lane);
+// see "LDS image", "super-stage chains" and the pipelined kernels below for how the LDS, VALU and HBM phases are
+// kept conflict-free, short and overlapped.
 #include <cmath>
 #include <cstdlib>
 #include <vector>
