@@ -65,6 +65,8 @@ SIGNATURES = {
     "mi_u16_to_f32": (_i, [_i, _vp, _vp, _vp, _sz, _f]),
     "mi_subtract_dark": (_i, [_i, _vp, _vp, _vp, _sz, _f]),
     "mi_norm2": (_i, [_i, _vp, _vp, _sz, C.POINTER(C.c_double)]),
+    "mi_prctile": (_i, [_i, _vp, _vp, _sz, C.POINTER(C.c_double), _i, C.POINTER(C.c_float)]),
+    "mi_rescale_block": (_i, [_i, _vp, _vp, _vp, _sz, _i, _f, _f, _f, _f]),
     "mi_pad_center": (_i, [_i, _vp, _vp, _i, _i, _i, _vp, _i, _i, _i]),
     "mi_crop_center": (_i, [_i, _vp, _vp, _i, _i, _i, _vp, _i, _i, _i]),
     "mi_rl_create": (_i, [_i, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, C.POINTER(_vp)]),

@@ -28,7 +28,7 @@ from .capi import (BOUNDARY_CIRCULAR, BOUNDARY_REPLICATE, BOUNDARY_ZERO, ENGINE_
                    RlOptions, check, lib)
 
 __all__ = ["decon", "conv3d_gpu", "convn_same", "gauss3d_gpu", "edgetaper_3d", "otf_gpu", "im2single", "RLContext",
-           "make_psf_struct", "norm2", "pad_block_to_fft_shape", "unpad_block", "next_fast_len", "engine_select"]
+           "make_psf_struct", "norm2", "prctile", "rescale_block", "pad_block_to_fft_shape", "unpad_block", "next_fast_len", "engine_select"]
 
 
 def _device(device_id=None) -> torch.device:
@@ -179,6 +179,37 @@ def norm2(x) -> float:
     out = C.c_double()
     check(lib().mi_norm2(x.device.index, _stream(x), x.data_ptr(), x.numel(), C.byref(out)))
     return out.value
+
+
+def prctile(x, pct):
+    """``prctile(x, pct, "all")`` of a device volume (LsDeconv.m:1301): exact, MATLAB's interpolation rule; ``pct`` = one or
+    two percentiles in [0, 100]; returns a list of floats."""
+    if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()):
+        raise ValueError("prctile: x must be a contiguous float32 device tensor")
+    p = [float(v) for v in (pct if hasattr(pct, "__len__") else [pct])]
+    if not 1 <= len(p) <= 2:
+        raise ValueError("prctile: one or two percentiles per call")
+    pa = (C.c_double * len(p))(*p)
+    out = (C.c_float * len(p))()
+    check(lib().mi_prctile(x.device.index, _stream(x), x.data_ptr(), x.numel(), pa, len(p), out))
+    return [float(v) for v in out]
+
+
+def rescale_block(x, scal, ampl, dmin, dmax, out=None):
+    """The float -> uint8/uint16 conversion of ``load_slab_lz4`` (load_slab_lz4.cpp:134-157): rescale by the global
+    [dmin, dmax] of the deconvolved stack, amplification, round half away from zero, clamp to [0, scal].  ``scal`` <= 255
+    gives uint8, else uint16 (LsDeconv.m:1017-1024)."""
+    if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()):
+        raise ValueError("rescale_block: x must be a contiguous float32 device tensor")
+    bits = 8 if scal <= 255 else 16
+    dt = torch.uint8 if bits == 8 else torch.uint16
+    if out is None:
+        out = torch.empty(x.shape, dtype=dt, device=x.device)
+    elif out.dtype != dt or out.shape != x.shape or not out.is_contiguous() or out.device != x.device:
+        raise ValueError("rescale_block: out must be a contiguous device tensor of the target integer type and x's shape")
+    check(lib().mi_rescale_block(x.device.index, _stream(x), x.data_ptr(), out.data_ptr(), x.numel(), bits, float(scal),
+                                 float(ampl), float(dmin), float(dmax)))
+    return out
 
 
 def next_fast_len(n: int) -> int:

@@ -4,7 +4,10 @@ of the MI355X library -- no MATLAB script is written, no MATLAB is spawned (decw
 processed in this process through ``ipp_amd.lsdeconv.process_block``.
 
 Input: a folder of 2-D slices (``*.npy``, or ``*.tif`` when ``tifffile`` is installed) or one ``*.npy`` volume
-(Z, Y, X).  Output: ``<input>/deconvolved/deconvolved.npy`` (+ ``deconvolution_config.json`` like decwrap.py:474-478).
+(Z, Y, X).  Output: ``<input>/deconvolved/deconvolved.npy`` (float32; + ``deconvolution_config.json`` like
+decwrap.py:474-478, ``min_max.json``) and the rescaled integer stack ``deconvolved_{8,16}bit.npy`` that the reference's
+postprocess_save writes as a TIFF series (LsDeconv.m:950-1100: percentile clip range of all blocks, amplification, round,
+clamp; ``mi_rescale_block``).
 TIFF series / LZ4 brick cache / resume of the reference are I/O rows outside this hot path.
 """
 from __future__ import annotations
@@ -166,9 +169,27 @@ def main(argv=None):
         out[p1[2] - 1:p2[2], p1[1] - 1:p2[1], p1[0] - 1:p2[0]] = core.cpu().numpy()        # strip pads, LsDeconv.m:750-752
         log.info(f"block {n}/{len(block.p1)} done on GPU {g}: stats [{lb:.4g}, {ub:.4g}]")
     np.save(out_dir / "deconvolved.npy", out)
+    # postprocess_save (LsDeconv.m:996-1024, 1091-1093): rawmax from the input class, target scale, rescale every slab with the
+    # clip range [deconvmin, deconvmax] collected over the blocks
+    if np.issubdtype(vol.dtype, np.integer):
+        rawmax = float(np.iinfo(vol.dtype).max)
+    else:
+        rawmax = float(np.max(vol))
+    scal = L.output_scale(rawmax, args.convert_to_8bit, args.convert_to_16bit)
     with open(out_dir / "min_max.json", "w") as f:
-        json.dump({"lb": float(lo), "ub": float(hi)}, f)
-    log.info(f"wrote {out_dir / 'deconvolved.npy'}")
+        json.dump({"deconvmin": float(lo), "deconvmax": float(hi), "rawmax": rawmax, "scal": scal}, f)
+    bits = 8 if scal <= 255 else 16
+    out_int = np.empty(vol.shape, np.uint8 if bits == 8 else np.uint16)
+    dev = torch.device("cuda", args.gpu_indices[0] - 1)
+    slab = max(1, (1 << 28) // max(1, sy * sx))                                           # <= 1 GiB of float32 per slab
+    for z0 in range(0, sz, slab):
+        t = torch.from_numpy(out[z0:z0 + slab]).to(dev)
+        q = D.rescale_block(t, scal, args.signal_amp, lo, hi)
+        out_int[z0:z0 + slab] = q.cpu().numpy()
+    if args.flip:
+        out_int = out_int[::-1]                                                            # flip_upside_down: reversed z order
+    np.save(out_dir / f"deconvolved_{bits}bit.npy", out_int)
+    log.info(f"wrote {out_dir / 'deconvolved.npy'} and deconvolved_{bits}bit.npy (scale {scal:g}, clip [{lo:.4g}, {hi:.4g}])")
     return 0
 
 

@@ -157,14 +157,22 @@ def load_block(volume: np.ndarray, p1, p2, pad_xyz) -> np.ndarray:
 
 
 def deconvolved_stats(bl: torch.Tensor, clipval: float):
-    """LsDeconv.m:1300-1307: ``prctile(bl(:), [100-clipval, clipval])`` (on the device)."""
-    if clipval <= 0:
-        return float(bl.min()), float(bl.max())
-    flat = bl.reshape(-1)
-    if flat.numel() > (1 << 24):  # torch.quantile input limit: strided sample, like a percentile on a sub-sample
-        flat = flat[:: flat.numel() // (1 << 24) + 1]
-    q = torch.quantile(flat, torch.tensor([(100.0 - clipval) / 100.0, clipval / 100.0], device=bl.device))
-    return float(q[0]), float(q[1])
+    """LsDeconv.m:1300-1307: ``prctile(bl, [100-clipval, clipval], "all")`` -- exact, on the device (``mi_prctile``)."""
+    lb, ub = D.prctile(bl, [100.0 - clipval, clipval])
+    return lb, ub
+
+
+def output_scale(rawmax: float, convert_to_8bit=False, convert_to_16bit=False) -> float:
+    """Target data-type maximum of postprocess_save (LsDeconv.m:1009-1024)."""
+    if convert_to_8bit:
+        rawmax = 255
+    elif convert_to_16bit:
+        rawmax = 65535
+    if convert_to_8bit or rawmax <= 255:
+        return 255.0
+    if convert_to_16bit or rawmax <= 65535:
+        return 65535.0
+    return float(rawmax)
 
 
 def process_block(bl, block: Block, psf, niter, lambda_, stop_criterion, filt: Filter, clipval=99.99, gpu=1):

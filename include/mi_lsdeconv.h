@@ -68,6 +68,20 @@ int mi_subtract_dark(int dev, void* stream, const float* src, float* dst, size_t
 /* *norm2 [host] = sqrt(sum(x.^2)) accumulated in double (norm(bl(:)), decon.m:47,109). Synchronises. */
 int mi_norm2(int dev, void* stream, const float* x, size_t n, double* norm2);
 
+/* [lb, ub] = deconvolved_stats(bl, clipval) = prctile(bl, [100-clipval clipval], "all")   [LsDeconv.m:1300-1307, called from
+ * process_block :945].  Exact percentiles of the whole device volume (MATLAB's definition: the i-th sorted sample is the
+ * 100(i-0.5)/n percentile, linear in between, clamped to min / max; NaN ignored), found by a three-level radix select on the
+ * device: no sorted copy, no sub-sampling, only histograms cross PCIe.  n_pct = 1 or 2; out = n_pct host floats.  Synchronises. */
+int mi_prctile(int dev, void* stream, const float* x, size_t n, const double* pct, int n_pct, float* out);
+
+/* The rescale / round / clamp / convert that load_slab_lz4 applies to every float brick while it assembles the output slab
+ * [load_slab_lz4.cpp:134-157; called from postprocess_save, LsDeconv.m:1091-1093]:
+ *   val = (dmin > 0) ? (val - dmin) * (scal*ampl/(dmax-dmin)) : val * (scal*ampl/dmax);  val -= ampl;
+ *   val = round-half-away-from-zero(val);  val = clamp(val, 0, scal);  dst = (uint8|uint16) val
+ * in float arithmetic in that order.  out_bits = 8 or 16; dst is a device buffer of n elements of that type. */
+int mi_rescale_block(int dev, void* stream, const float* src, void* dst, size_t n, int out_bits, float scal, float ampl,
+                     float dmin, float dmax);
+
 /* zero-pad-centre / crop   [decon.m:323-374: pre = floor(missing/2), post = ceil] */
 int mi_pad_center(int dev, void* stream, const float* src, int nx, int ny, int nz, float* dst, int fx, int fy, int fz);
 int mi_crop_center(int dev, void* stream, const float* src, int fx, int fy, int fz, float* dst, int nx, int ny, int nz);

@@ -331,3 +331,38 @@ def bead_volume(shape_zyx, seed=1234, psf=None) -> np.ndarray:
         vol = signal.fftconvolve(vol.astype(np.float64), psf.astype(np.float64), mode="same").astype(np.float32)
     vol *= (1.0 + rng.normal(0.0, 0.01, size=shape_zyx)).astype(np.float32)
     return np.clip(vol, 0.0, None).astype(np.float32)
+
+
+def prctile(x, pct):
+    """MATLAB ``prctile(x, pct, "all")`` (LsDeconv.m:1301): sorted sample i (1-based) is the 100 (i - 0.5) / n percentile,
+    linear interpolation in between, clamped to min / max, NaN ignored -- numpy's "hazen" rule, spelled out."""
+    v = np.sort(np.asarray(x, dtype=np.float32).ravel())
+    v = v[~np.isnan(v)]
+    n = v.size
+    out = []
+    for p in np.atleast_1d(pct):
+        if n == 0:
+            out.append(np.float32(np.nan))
+            continue
+        pos = min(max(float(p) / 100.0 * n - 0.5, 0.0), n - 1.0)
+        lo = int(np.floor(pos))
+        hi = min(lo + 1, n - 1)
+        out.append(np.float32(np.float64(v[lo]) + (pos - lo) * (np.float64(v[hi]) - np.float64(v[lo]))))
+    return out
+
+
+def rescale_block(x, scal, ampl, dmin, dmax, dtype):
+    """load_slab_lz4.cpp:134-157 in float32 arithmetic, in the reference's order of operations."""
+    f = np.float32
+    x = np.asarray(x, dtype=f)
+    scal, ampl, dmin, dmax = f(scal), f(ampl), f(dmin), f(dmax)
+    k_linear = f(f(scal * ampl) / dmax)
+    if dmin > 0:
+        k = f(f(scal * ampl) / f(dmax - dmin))
+        val = (x - dmin).astype(f) * k
+    else:
+        val = x * k_linear
+    val = (val.astype(f) - ampl).astype(f)
+    val = np.where(val >= 0, np.floor(val + f(0.5)), np.ceil(val - f(0.5))).astype(f)
+    val = np.clip(val, f(0), scal)
+    return val.astype(dtype)

@@ -31,6 +31,16 @@ def test_decwrap_end_to_end(dev, tmp_path):
     want = want[pad[0]:-pad[0], pad[1]:-pad[1], pad[2]:-pad[2]]
     assert got.shape == vol16.shape
     assert np.abs(got - want).max() / np.abs(want).max() < 1e-4
+    # postprocess: clip range = percentiles of the whole padded block (one block here), uint16 input -> 16-bit output
+    import json
+    mm = json.load(open(tmp_path / "deconvolved" / "min_max.json"))
+    padded = R.decon_spatial(bl, psf, 4, 0.0, 0.0, 2)
+    wl, wu = R.prctile(padded, [0.01, 99.99])
+    assert mm["deconvmin"] == pytest.approx(float(wl), rel=1e-3) and mm["deconvmax"] == pytest.approx(float(wu), rel=1e-3)
+    assert mm["rawmax"] == 65535 and mm["scal"] == 65535
+    q = np.load(tmp_path / "deconvolved" / "deconvolved_16bit.npy")
+    assert q.dtype == np.uint16 and q.shape == vol16.shape
+    assert np.array_equal(q, R.rescale_block(got, 65535, 1.0, mm["deconvmin"], mm["deconvmax"], np.uint16))
 
 
 def test_process_images_step2(dev, tmp_path):

@@ -144,3 +144,25 @@ def test_pad_unpad_roundtrip():
     assert p.shape == (5, 6, 4) and pre == [1, 1, 0] and post == [2, 2, 0]
     assert np.array_equal(R.unpad_block(p, pre, post), a)
     assert R.u16_to_f32(np.array([0, 65535], np.uint16)).tolist() == [0.0, 1.0]
+
+
+def test_prctile_is_matlab_hazen_rule():
+    """prctile (LsDeconv.m:1301): sample i of n sorted values is the 100 (i - 0.5) / n percentile -- numpy's 'hazen' method;
+    MATLAB's documented example: prctile([1 2 3 4 5], 50) = 3, the 10th percentile of 1..5 is 1 (clamped below 100 * 0.5 / 5)."""
+    rng = np.random.default_rng(0)
+    x = rng.normal(size=1001).astype(np.float32)
+    for p in (0.0, 0.01, 10.0, 33.3, 50.0, 99.99, 100.0):
+        assert R.prctile(x, [p])[0] == pytest.approx(np.percentile(x.astype(np.float64), p, method="hazen"), rel=1e-6, abs=1e-7)
+    assert R.prctile([1, 2, 3, 4, 5], [50, 10, 30, 100]) == [3.0, 1.0, 2.0, 5.0]
+    assert np.isnan(R.prctile([np.nan], [50])[0])
+    assert R.prctile([1.0, np.nan, 3.0], [50])[0] == 2.0
+
+
+def test_rescale_block_literal_values():
+    """load_slab_lz4.cpp:134-157: linear branch when dmin <= 0, min-max branch otherwise; val -= ampl; round half away;
+    clamp [0, scal]."""
+    x = np.array([0.0, 0.5, 1.0, 2.0, -1.0], np.float32)
+    # dmin = 0: val * (255 * 1 / 1) - 1 -> -1, 126.5 -> 127, 254, 509 -> 255, -256 -> 0
+    assert R.rescale_block(x, 255, 1.0, 0.0, 1.0, np.uint8).tolist() == [0, 127, 254, 255, 0]
+    # dmin = 0.5, dmax = 1.5: (val - 0.5) * 65535 - 1
+    assert R.rescale_block(x, 65535, 1.0, 0.5, 1.5, np.uint16).tolist() == [0, 0, 32767, 65535, 0]
