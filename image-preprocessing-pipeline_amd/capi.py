@@ -65,6 +65,12 @@ SIGNATURES = {
     "mi_u16_to_f32": (_i, [_i, _vp, _vp, _vp, _sz, _f]),
     "mi_subtract_dark": (_i, [_i, _vp, _vp, _vp, _sz, _f]),
     "mi_norm2": (_i, [_i, _vp, _vp, _sz, C.POINTER(C.c_double)]),
+    "mi_rl_fuses": (_i, [_vp]),
+    "mi_rl_sharded_begin": (_i, [_vp, _vp, _vp]),
+    "mi_rl_sharded_ratio": (_i, [_vp, _vp, _vp]),
+    "mi_rl_sharded_update": (_i, [_vp, _vp, _vp, _i]),
+    "mi_rl_spectrum_rows": (_i, [_vp, _vp, _i, _i, _vp, _i]),
+    "mi_rl_spectrum_row_floats": (_sz, [_vp]),
     "mi_prctile": (_i, [_i, _vp, _vp, _sz, C.POINTER(C.c_double), _i, C.POINTER(C.c_float)]),
     "mi_rescale_block": (_i, [_i, _vp, _vp, _vp, _sz, _i, _f, _f, _f, _f]),
     "mi_pad_center": (_i, [_i, _vp, _vp, _i, _i, _i, _vp, _i, _i, _i]),

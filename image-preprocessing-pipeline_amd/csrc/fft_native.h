@@ -52,6 +52,9 @@ struct NativeFft {
     // n fused RL iterations on bl in place (lambda = 0, no regularisation step in between)
     int iterate(hipStream_t s, float* bl, int n_iters);
     int time_pass(hipStream_t s, int which, const float* bl, int reps, float* avg_ms);
+    // rows [y0, y0 + rows) of S (the x-transformed input of the next convolution): dir 0 pack into buf, 1 unpack from buf, 2 zero
+    int spectrum_rows(hipStream_t s, int y0, int rows, float2* buf, int dir);
+    size_t spectrum_row_floats() const { return (size_t)2 * dims.nz * dims.hx; }
     int x_forward(hipStream_t s, const float* in);
     int middle(hipStream_t s, bool conj_otf);
     int y_pass(hipStream_t s, bool inverse);

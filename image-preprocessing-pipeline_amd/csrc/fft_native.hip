@@ -1220,6 +1220,21 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_x_fused_pipe(const flo
     }
 }
 
+// rows [y0, y0 + rows) of the x-transformed buffer S[z][px][py] <-> a contiguous buffer [z * Hx + px][rows] (halo exchange of
+// the sharded iteration); dir 0: pack, 1: unpack, 2: zero-fill
+__global__ __launch_bounds__(256) void k_spectrum_rows(float2* __restrict__ S, float2* __restrict__ buf, size_t lines, int M, int y0, int rows,
+                                                       int dir) {
+    const size_t total = lines * (size_t)rows;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t line = i / rows;
+        const int j = (int)(i - line * rows);
+        float2* cell = S + line * M + (y0 + j);
+        if (dir == 0) buf[i] = *cell;
+        else if (dir == 1) *cell = buf[i];
+        else *cell = make_float2(0.0f, 0.0f);
+    }
+}
+
 bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
@@ -1478,6 +1493,16 @@ int NativeFft::x_inverse(hipStream_t s, float* out, int epi_kind, const ConvEpil
     switch (dims.lhx2 * 16 + dims.r3x) { MI_AXIS_CASES(MI_XI) default: return fail(MI_ERR_UNSUPPORTED, "native FFT: x length %d", 2 * Hx); }
 #undef MI_XI
     return rc;
+}
+
+int NativeFft::spectrum_rows(hipStream_t s, int y0, int rows, float2* buf, int dir) {
+    MI_REQUIRE(y0 >= 0 && rows > 0 && y0 + rows <= dims.ny, "spectrum rows [%d, %d) outside [0, %d)", y0, y0 + rows, dims.ny);
+    MI_REQUIRE(dir == 2 || buf, "spectrum rows: null buffer");
+    const size_t lines = (size_t)dims.nz * dims.hx, total = lines * (size_t)rows;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(k_spectrum_rows, dim3((unsigned)blocks), dim3(256), 0, s, S.as<float2>(), buf, lines, dims.ny, y0, rows, dir);
+    return launch_check("k_spectrum_rows");
 }
 
 // Average duration (ms) of one launch of a single pass, measured with HIP events on `s` (bench.py's roofline leg).

@@ -183,6 +183,58 @@ extern "C" int mi_fft_good_size(int n, int axis) {
     return NativeFft::good_size(n, axis);
 }
 
+// ---- sharded fused iteration (slab driver): mi_rl_iterate cut where the y halos of a convolution's input are refreshed
+static int sharded_native(mi_rl_ctx* ctx, NativeFft** out) {
+    MI_REQUIRE(ctx, "mi_rl_sharded: null context");
+    MI_TRY(use_device(ctx->dev));
+    if (!(ctx->engine == MI_ENGINE_FFT && ctx->fft->native && ctx->fft->native->can_fuse()))
+        return fail(MI_ERR_UNSUPPORTED, "mi_rl_sharded: only the native FFT pipeline fuses consecutive convolutions");
+    *out = ctx->fft->native;
+    return MI_OK;
+}
+
+extern "C" int mi_rl_fuses(mi_rl_ctx* ctx) {
+    return ctx && ctx->engine == MI_ENGINE_FFT && ctx->fft->native && ctx->fft->native->can_fuse() ? 1 : 0;
+}
+
+extern "C" int mi_rl_sharded_begin(mi_rl_ctx* ctx, void* stream, const float* bl) {
+    NativeFft* nf = nullptr;
+    MI_TRY(sharded_native(ctx, &nf));
+    MI_REQUIRE(bl, "mi_rl_sharded_begin: null pointer");
+    return nf->x_forward(as_stream(stream), bl);
+}
+
+extern "C" int mi_rl_sharded_ratio(mi_rl_ctx* ctx, void* stream, const float* bl) {
+    NativeFft* nf = nullptr;
+    MI_TRY(sharded_native(ctx, &nf));
+    MI_REQUIRE(bl, "mi_rl_sharded_ratio: null pointer");
+    ConvEpilogue e;
+    e.a = bl;
+    MI_TRY(nf->middle(as_stream(stream), false));
+    return nf->x_inverse(as_stream(stream), nullptr, EPI_RATIO, e, true);
+}
+
+extern "C" int mi_rl_sharded_update(mi_rl_ctx* ctx, void* stream, float* bl, int more) {
+    NativeFft* nf = nullptr;
+    MI_TRY(sharded_native(ctx, &nf));
+    MI_REQUIRE(bl, "mi_rl_sharded_update: null pointer");
+    ConvEpilogue e;
+    e.a = bl;
+    MI_TRY(nf->middle(as_stream(stream), true));
+    return nf->x_inverse(as_stream(stream), bl, EPI_UPDATE, e, more != 0);
+}
+
+extern "C" int mi_rl_spectrum_rows(mi_rl_ctx* ctx, void* stream, int y0, int rows, float* buf, int dir) {
+    NativeFft* nf = nullptr;
+    MI_TRY(sharded_native(ctx, &nf));
+    MI_REQUIRE(dir >= 0 && dir <= 2, "mi_rl_spectrum_rows: dir must be 0 (pack), 1 (unpack) or 2 (zero)");
+    return nf->spectrum_rows(as_stream(stream), y0, rows, reinterpret_cast<float2*>(buf), dir);
+}
+
+extern "C" size_t mi_rl_spectrum_row_floats(mi_rl_ctx* ctx) {
+    return mi_rl_fuses(ctx) ? ctx->fft->native->spectrum_row_floats() : 0;
+}
+
 extern "C" int mi_rl_time_pass(mi_rl_ctx* ctx, void* stream, int which, const float* bl, int reps, float* avg_ms) {
     MI_REQUIRE(ctx && bl && avg_ms, "mi_rl_time_pass: null pointer");
     MI_TRY(use_device(ctx->dev));

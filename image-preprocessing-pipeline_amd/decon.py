@@ -305,6 +305,38 @@ class RLContext:
         check(lib().mi_rl_iterate(self._h, _stream(bl), bl.data_ptr(), ratio.data_ptr() if ratio is not None else None,
                                   int(n_iters)))
 
+    # ---- sharded fused iteration (slab driver): see include/mi_lsdeconv.h "Sharded fused iteration"
+    @property
+    def fuses(self) -> bool:
+        return bool(lib().mi_rl_fuses(self._h))
+
+    def sharded_begin(self, bl):
+        self._chk(bl)
+        check(lib().mi_rl_sharded_begin(self._h, _stream(bl), bl.data_ptr()))
+
+    def sharded_ratio(self, bl):
+        self._chk(bl)
+        check(lib().mi_rl_sharded_ratio(self._h, _stream(bl), bl.data_ptr()))
+
+    def sharded_update(self, bl, more=True):
+        self._chk(bl)
+        check(lib().mi_rl_sharded_update(self._h, _stream(bl), bl.data_ptr(), int(bool(more))))
+
+    def spectrum_pack(self, y0, rows):
+        """Rows [y0, y0+rows) of the x-transformed input buffer as a contiguous float32 device tensor."""
+        buf = torch.empty(int(rows) * int(lib().mi_rl_spectrum_row_floats(self._h)), dtype=torch.float32, device=self.device)
+        check(lib().mi_rl_spectrum_rows(self._h, _stream(buf), int(y0), int(rows), buf.data_ptr(), 0))
+        return buf
+
+    def spectrum_unpack(self, buf, y0, rows):
+        if buf is None:
+            check(lib().mi_rl_spectrum_rows(self._h, capi.current_stream_ptr(self.device), int(y0), int(rows), None, 2))
+            return
+        if not (buf.is_cuda and buf.dtype == torch.float32 and buf.is_contiguous()
+                and buf.numel() == int(rows) * int(lib().mi_rl_spectrum_row_floats(self._h))):
+            raise ValueError("spectrum_unpack: buffer does not hold `rows` spectrum rows")
+        check(lib().mi_rl_spectrum_rows(self._h, _stream(buf), int(y0), int(rows), buf.data_ptr(), 1))
+
     PASSES = {"x_forward": 0, "y_forward": 1, "z_conv": 2, "y_inverse": 3, "x_fused": 4, "x_fused_update": 5}
 
     def time_pass(self, which, bl, reps=5) -> float:

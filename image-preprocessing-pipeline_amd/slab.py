@@ -13,6 +13,12 @@ single-GPU result on the whole volume up to fp32 rounding:
   flavour "spatial"  deconSpatial semantics (decon.m:26-124): zeros outside the GLOBAL volume, so the outer
                      halos of the first / last rank are zero-filled instead of exchanged.
 
+When the local context runs the fused native FFT pipeline (``ctx.fuses``), the halo exchange moves from real space to the
+pipeline's x-transformed buffer: the input of every convolution is kept there (the ratio never reaches HBM, ``bl`` is read
+twice and written once per iteration, exactly like the single-GPU ``mi_rl_iterate``), the x transform of a row does not
+depend on other rows, so each rank sends the x-transformed rows of its interior edges and receives its halo rows in that form
+(same bytes as real rows).  The halo rows of ``bl`` are then never read again and hold meaningless values.
+
 Y is sharded rather than Z because the halo is PSF-extent/2 rows of a 2048 x 512 plane instead of 30 of 64
 planes ("halo inflation": 1.12x instead of 1.94x on config C3).  No collective is on the
 data path; only the optional stop criterion all-reduces one double.
@@ -70,6 +76,13 @@ class HipOps:
     def zero_rows(self, vol, y0, rows):
         vol[:, y0:y0 + rows, :].zero_()
 
+    # x-transformed rows of the fused pipeline (ctx.fuses)
+    def pack_spec(self, ctx, y0, rows):
+        return ctx.spectrum_pack(y0, rows)
+
+    def unpack_spec(self, ctx, packed, y0, rows):
+        ctx.spectrum_unpack(packed, y0, rows)
+
 
 class SlabRL:
     def __init__(self, global_shape_zyx, psf, rank=0, world_size=1, device=None, flavour="fft", engine=ENGINE_AUTO,
@@ -99,7 +112,10 @@ class SlabRL:
         self.lshape = (gz, self.rows, gx)
         self.ctx = self.ops.make_ctx(self.lshape, self.psf, boundary_xyz, shift_xyz, engine)
         self.bl = torch.zeros(self.lshape, dtype=torch.float32, device=self.device)
-        self.ratio = torch.zeros(self.lshape, dtype=torch.float32, device=self.device)
+        # fused pipeline: halos travel as x-transformed rows, no ratio volume exists
+        self.sharded = bool(getattr(self.ctx, "fuses", False))
+        self._begun = False
+        self.ratio = None if self.sharded else torch.zeros(self.lshape, dtype=torch.float32, device=self.device)
         if volume is not None:
             v = volume[:, self.y0:self.y1, :]
             v = torch.from_numpy(np.ascontiguousarray(v)) if isinstance(v, np.ndarray) else v
@@ -138,15 +154,27 @@ class SlabRL:
         else:
             self.ops.zero_rows(vol, h + n, h)
 
-    def exchange(self, vol):
-        """Refresh the 2*h halo rows of ``vol`` from the neighbouring slabs (ring for the circular flavour, zeros
-        at the global edges for the spatial one)."""
+    def pack_spec_halos(self):
+        h, n = self.h, self.n_loc
+        return self.ops.pack_spec(self.ctx, n, h), self.ops.pack_spec(self.ctx, h, h)
+
+    def unpack_spec_halos(self, recv_lo, recv_hi):
+        h, n = self.h, self.n_loc
+        self.ops.unpack_spec(self.ctx, recv_lo, 0, h)          # None = global edge of the spatial flavour -> zero rows
+        self.ops.unpack_spec(self.ctx, recv_hi, h + n, h)
+
+    def exchange(self, vol=None):
+        """Refresh the 2*h halo rows from the neighbouring slabs (ring for the circular flavour, zeros at the global
+        edges for the spatial one): of ``vol`` in real space, or -- ``vol`` None, fused pipeline -- of the context's
+        x-transformed input buffer."""
         if self.h == 0:
             return
+        spec = vol is None
         lo_src, hi_src = self.neighbours()
-        send_up, send_dn = self.pack_halos(vol)
+        send_up, send_dn = self.pack_spec_halos() if spec else self.pack_halos(vol)
+        deliver = self.unpack_spec_halos if spec else (lambda lo, hi: self.unpack_halos(vol, lo, hi))
         if self.world == 1:  # self-ring: my own rows wrap around
-            self.unpack_halos(vol, send_up if lo_src is not None else None, send_dn if hi_src is not None else None)
+            deliver(send_up if lo_src is not None else None, send_dn if hi_src is not None else None)
             return
         import torch.distributed as dist
         # RCCL moves device buffers directly; a gloo group (CPU rehearsals of the multi-rank path) needs host staging
@@ -169,13 +197,23 @@ class SlabRL:
         for req in dist.batch_isend_irecv(ops):
             req.wait()
         if staged:
-            recv_lo = recv_lo.to(vol.device) if recv_lo is not None else None
-            recv_hi = recv_hi.to(vol.device) if recv_hi is not None else None
-        self.unpack_halos(vol, recv_lo, recv_hi)
+            recv_lo = recv_lo.to(self.device) if recv_lo is not None else None
+            recv_hi = recv_hi.to(self.device) if recv_hi is not None else None
+        deliver(recv_lo, recv_hi)
 
     # ------------------------------------------------------------------ iteration
     def iterate(self):
         """One RL iteration (decon.m:61-79 / 162-186, lambda = 0) on the sharded volume."""
+        if self.sharded:
+            if not self._begun:                  # x-forward of the start volume; later iterations get it from the update
+                self.ctx.sharded_begin(self.bl)
+                self.exchange()
+                self._begun = True
+            self.ctx.sharded_ratio(self.bl)
+            self.exchange()
+            self.ctx.sharded_update(self.bl, True)
+            self.exchange()
+            return
         self.exchange(self.bl)
         self.ctx.forward_ratio(self.bl, self.ratio)
         self.exchange(self.ratio)

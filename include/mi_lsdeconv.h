@@ -117,6 +117,24 @@ int mi_rl_adjoint_update(mi_rl_ctx* ctx, void* stream, const float* ratio, float
  * the two convolutions do (native FFT pipeline: 8 volume passes per iteration, the ratio never reaches HBM, `ratio`
  * may then be NULL); the others run forward_ratio / adjoint_update n_iters times using `ratio` as scratch. */
 int mi_rl_iterate(mi_rl_ctx* ctx, void* stream, float* bl, float* ratio, int n_iters);
+/* Sharded fused iteration (the multi-GPU slab driver; no reference counterpart -- the reference's blocks never talk to each
+ * other, LsDeconv.m:647-654): mi_rl_iterate cut at the two places of an iteration where the y halo rows of a convolution's input
+ * must be refreshed from the neighbouring slabs.  The input of every convolution lives in the pipeline's x-transformed buffer
+ * ("spectrum rows": the x-FFT of the rows, still indexed by y), so the halo rows are exchanged THERE and the ratio still never
+ * reaches HBM:
+ *     mi_rl_sharded_begin(ctx, s, bl)         S <- x-forward(bl)                                     [then exchange rows of S]
+ *     mi_rl_sharded_ratio(ctx, s, bl)         S <- x-forward(bl ./ max(conv(S), eps))                [then exchange rows of S]
+ *     mi_rl_sharded_update(ctx, s, bl, more)  bl <- |bl .* conv_adj(S)|; more != 0: S <- x-forward(bl)  [then exchange rows of S]
+ * The halo rows of `bl` itself are never read again (each row's x transform is independent) and hold meaningless values.
+ * mi_rl_spectrum_rows packs (dir 0) / unpacks (dir 1) / zero-fills (dir 2) rows [y0, y0+rows) of S into / from a contiguous
+ * device buffer of rows * mi_rl_spectrum_row_floats(ctx) floats.  mi_rl_fuses: 1 when the context runs the fused native
+ * pipeline (else the calls return MI_ERR_UNSUPPORTED and the driver uses forward_ratio / adjoint_update on real halos). */
+int mi_rl_fuses(mi_rl_ctx* ctx);
+int mi_rl_sharded_begin(mi_rl_ctx* ctx, void* stream, const float* bl);
+int mi_rl_sharded_ratio(mi_rl_ctx* ctx, void* stream, const float* bl);
+int mi_rl_sharded_update(mi_rl_ctx* ctx, void* stream, float* bl, int more);
+int mi_rl_spectrum_rows(mi_rl_ctx* ctx, void* stream, int y0, int rows, float* buf, int dir);
+size_t mi_rl_spectrum_row_floats(mi_rl_ctx* ctx);
 /* Measurement hook: average duration in ms of `reps` back-to-back launches of ONE pass of the native FFT pipeline,
  * taken with HIP events on `stream` (which: 0 x-forward, 1 y-forward, 2 z-forward*OTF*z-inverse, 3 y-inverse,
  * 4 fused x-inverse+ratio+x-forward, 5 fused x-inverse+update+x-forward -- this one OVERWRITES bl with values that mean

@@ -30,6 +30,39 @@ class NumpyCtx:
         sl = tuple(slice(q, q + n) for q, n in zip(self.pad, self.n))
         return c[sl].astype(np.float32)
 
+    # ---- the fused protocol of the native pipeline (ctx.fuses): the convolution input lives in an x-transformed buffer S
+    # (here: numpy FFT along x of the padded array), halos are exchanged as rows of S
+    fuses = False
+
+    def _to_S(self, a):
+        self.S = np.fft.fft(np.pad(a.astype(np.float64), [(q, q) for q in self.pad]), axis=2)
+
+    def _conv_S(self, adjoint):
+        o = self.otf.conj() if adjoint else self.otf
+        c = np.real(np.fft.ifftn(np.fft.fft2(self.S, axes=(0, 1)) * o))
+        sl = tuple(slice(q, q + n) for q, n in zip(self.pad, self.n))
+        return c[sl].astype(np.float32)
+
+    def sharded_begin(self, bl):
+        self._to_S(bl.numpy())
+
+    def sharded_ratio(self, bl):
+        b = bl.numpy()
+        self._to_S((b / np.maximum(self._conv_S(False), np.float32(2.0 ** -23))).astype(np.float32))
+
+    def sharded_update(self, bl, more=True):
+        b = bl.numpy()
+        bl.copy_(torch.from_numpy(np.abs(b * self._conv_S(True)).astype(np.float32)))
+        if more:
+            self._to_S(bl.numpy())
+
+    def spectrum_pack(self, y0, rows):
+        assert self.pad[1] == 0  # y is circular on the local extent
+        return torch.view_as_real(torch.from_numpy(np.ascontiguousarray(self.S[:, y0:y0 + rows, :]))).contiguous()
+
+    def spectrum_unpack(self, buf, y0, rows):
+        self.S[:, y0:y0 + rows, :] = 0 if buf is None else torch.view_as_complex(buf).numpy()
+
     def forward_ratio(self, bl, ratio):
         b = bl.numpy()
         ratio.copy_(torch.from_numpy((b / np.maximum(self._conv(b, False), np.float32(2.0 ** -23))).astype(np.float32)))
@@ -42,8 +75,19 @@ class NumpyCtx:
 class NumpyOps:
     device = torch.device("cpu")
 
+    def __init__(self, fuses=False):
+        self.fuses = fuses
+
     def make_ctx(self, lshape, psf, boundary_xyz, shift_xyz, engine):
-        return NumpyCtx(lshape, psf, boundary_xyz, shift_xyz)
+        ctx = NumpyCtx(lshape, psf, boundary_xyz, shift_xyz)
+        ctx.fuses = self.fuses
+        return ctx
+
+    def pack_spec(self, ctx, y0, rows):
+        return ctx.spectrum_pack(y0, rows)
+
+    def unpack_spec(self, ctx, packed, y0, rows):
+        ctx.spectrum_unpack(packed, y0, rows)
 
     def pack(self, vol, y0, rows):
         return vol[:, y0:y0 + rows, :].contiguous()
@@ -64,6 +108,25 @@ def lockstep_iterate(slabs, niter):
             lo, hi = s.neighbours()
             s.unpack_halos(getattr(s, attr), packed[lo][0] if lo is not None else None,
                            packed[hi][1] if hi is not None else None)
+
+    def exchange_spec():
+        packed = [s.pack_spec_halos() for s in slabs]
+        for s in slabs:
+            lo, hi = s.neighbours()
+            s.unpack_spec_halos(packed[lo][0] if lo is not None else None, packed[hi][1] if hi is not None else None)
+
+    if slabs[0].sharded:  # fused pipeline: halos travel as x-transformed rows
+        for s in slabs:
+            s.ctx.sharded_begin(s.bl)
+        exchange_spec()
+        for _ in range(niter):
+            for s in slabs:
+                s.ctx.sharded_ratio(s.bl)
+            exchange_spec()
+            for s in slabs:
+                s.ctx.sharded_update(s.bl, True)
+            exchange_spec()
+        return torch.cat([s.interior() for s in slabs], dim=1)
     for _ in range(niter):
         exchange("bl")
         for s in slabs:

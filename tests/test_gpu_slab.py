@@ -37,6 +37,55 @@ def test_lockstep_slabs_on_gpu(dev, flavour, engine, world):
     assert _rel(got, want) < 1e-4 and _rel(got, single) < 2e-5
 
 
+@pytest.mark.parametrize("flavour", ["fft", "spatial"])
+@pytest.mark.parametrize("world", [1, 2, 4])
+def test_lockstep_slabs_fused_pipeline_spectrum_halos(dev, flavour, world, monkeypatch):
+    """Shapes the native FFT pipeline takes: the slabs run the fused iteration and exchange x-transformed halo rows; the result
+    equals the un-sharded fused run and the oracle.  No ratio volume exists."""
+    from ipp_amd import decon, slab
+    monkeypatch.setenv("MI_FFT_NATIVE_INFLATE", "100")   # small padded grids round up a lot: keep the native pipeline
+    psf = R.gaussian_psf((5, 7, 5), (1.0, 1.5, 1.0))
+    vol = R.bead_volume((16, 128, 32), seed=33, psf=psf)
+    slabs = [slab.SlabRL(vol.shape, psf, rank=r, world_size=world, device=dev, flavour=flavour, engine=2, volume=vol)
+             for r in range(world)]
+    assert all(s.sharded and s.ratio is None for s in slabs)
+    got = lockstep_iterate(slabs, 4).cpu().numpy()
+    if flavour == "fft":
+        want = R.decon_fft(vol, psf, vol.shape, 4, skip_edgetaper=True)
+    else:
+        want = R.decon_spatial(vol, psf, 4, skip_edgetaper=True)
+    assert _rel(got, want) < 1e-4
+    # the driver's own iterate() on a single self-ring slab goes through the same protocol
+    one = slab.SlabRL(vol.shape, psf, rank=0, world_size=1, device=dev, flavour=flavour, engine=2, volume=vol)
+    one.run(4)
+    assert _rel(one.interior().cpu().numpy(), want) < 1e-4
+
+
+def test_spectrum_rows_pack_unpack(dev):
+    from ipp_amd import capi, decon
+    psf = R.gaussian_psf((3, 3, 3), (1.0, 1.0, 1.0))
+    shape = (8, 32, 16)
+    ctx = decon.RLContext(shape, psf, None, boundary=capi.BOUNDARY_CIRCULAR, engine=capi.ENGINE_FFT, device=dev)
+    assert ctx.fuses
+    bl = torch.rand(shape, device=dev) + 0.5
+    ctx.sharded_begin(bl)
+    a = ctx.spectrum_pack(4, 6)
+    assert a.numel() == 6 * 8 * 16          # rows * nz * nx floats: as many bytes as the real rows
+    # x-transformed rows of y = 4..9: compare with torch's FFT of the half-length packed rows (any order along x: sums agree)
+    packed = torch.view_as_complex(bl[:, 4:10, :].reshape(8, 6, 8, 2).contiguous())
+    want = torch.fft.fft(packed, dim=2)
+    got = torch.view_as_complex(a.reshape(8, 8, 6, 2))          # [z][px][row]
+    assert torch.allclose(got.abs().pow(2).sum(dim=1), want.abs().pow(2).sum(dim=2), rtol=1e-4)
+    ctx.spectrum_unpack(None, 4, 6)
+    assert float(ctx.spectrum_pack(4, 6).abs().sum()) == 0.0
+    ctx.spectrum_unpack(a, 4, 6)
+    assert torch.equal(ctx.spectrum_pack(4, 6), a)
+    direct = decon.RLContext(shape, psf, None, boundary=capi.BOUNDARY_CIRCULAR, engine=capi.ENGINE_DIRECT, device=dev)
+    assert not direct.fuses
+    with pytest.raises(capi.MiError, match="only the native FFT pipeline"):
+        direct.sharded_begin(bl)
+
+
 def test_pack_unpack_rows(dev):
     from ipp_amd import slab
     ops = slab.HipOps(dev)

@@ -20,14 +20,15 @@ def _rel(a, b):
     return float(np.abs(a.astype(np.float64) - b).max() / np.abs(b).max())
 
 
-def _worker(rank, world, port, flavour, vol, psf, niter, out):
+def _worker(rank, world, port, flavour, vol, psf, niter, out, fuses=False):
     import torch.distributed as dist
     from ipp_amd import slab
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        drv = slab.SlabRL(vol.shape, psf, rank=rank, world_size=world, flavour=flavour, volume=vol, ops=NumpyOps())
+        drv = slab.SlabRL(vol.shape, psf, rank=rank, world_size=world, flavour=flavour, volume=vol, ops=NumpyOps(fuses))
+        assert drv.sharded == fuses
         n0 = drv.norm2()
         drv.run(niter)
         full = drv.gather()
@@ -38,12 +39,15 @@ def _worker(rank, world, port, flavour, vol, psf, niter, out):
 
 
 @pytest.mark.parametrize("flavour", ["fft", "spatial"])
-def test_two_gloo_ranks_equal_unsharded_oracle(flavour):
+@pytest.mark.parametrize("fuses", [False, True], ids=["real_halos", "spectrum_halos"])
+def test_two_gloo_ranks_equal_unsharded_oracle(flavour, fuses):
+    """Both halo protocols: real-space rows around forward_ratio / adjoint_update, and x-transformed rows around the fused
+    steps (the protocol of the native FFT pipeline)."""
     vol, psf = _case()
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
-    port = 29600 + (os.getpid() % 200) + (0 if flavour == "fft" else 1)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, flavour, vol, psf, 3, out)) for r in range(2)]
+    port = 29600 + (os.getpid() % 200) + (0 if flavour == "fft" else 1) + (2 if fuses else 0)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, flavour, vol, psf, 3, out, fuses)) for r in range(2)]
     for p in procs:
         p.start()
     got, n0 = out.get(timeout=120)
@@ -60,10 +64,11 @@ def test_two_gloo_ranks_equal_unsharded_oracle(flavour):
 
 @pytest.mark.parametrize("flavour", ["fft", "spatial"])
 @pytest.mark.parametrize("world", [1, 3, 4])
-def test_lockstep_slabs_uneven_rows(flavour, world):
+@pytest.mark.parametrize("fuses", [False, True], ids=["real_halos", "spectrum_halos"])
+def test_lockstep_slabs_uneven_rows(flavour, world, fuses):
     from ipp_amd import slab
     vol, psf = _case(seed=5, shape=(9, 41, 16))  # 41 rows: uneven split; odd extent: centred deconFFT placement
-    slabs = [slab.SlabRL(vol.shape, psf, rank=r, world_size=world, flavour=flavour, volume=vol, ops=NumpyOps())
+    slabs = [slab.SlabRL(vol.shape, psf, rank=r, world_size=world, flavour=flavour, volume=vol, ops=NumpyOps(fuses))
              for r in range(world)]
     assert sum(s.n_loc for s in slabs) == 41
     got = lockstep_iterate(slabs, 2).numpy()
