@@ -67,8 +67,8 @@ SIGNATURES = {
     "mi_norm2": (_i, [_i, _vp, _vp, _sz, C.POINTER(C.c_double)]),
     "mi_rl_fuses": (_i, [_vp]),
     "mi_rl_sharded_begin": (_i, [_vp, _vp, _vp]),
-    "mi_rl_sharded_ratio": (_i, [_vp, _vp, _vp]),
-    "mi_rl_sharded_update": (_i, [_vp, _vp, _vp, _i]),
+    "mi_rl_sharded_ratio": (_i, [_vp, _vp, _vp, _i, C.POINTER(C.c_int)]),
+    "mi_rl_sharded_update": (_i, [_vp, _vp, _vp, _i, _i, C.POINTER(C.c_int)]),
     "mi_rl_spectrum_rows": (_i, [_vp, _vp, _i, _i, _vp, _i]),
     "mi_rl_spectrum_row_floats": (_sz, [_vp]),
     "mi_prctile": (_i, [_i, _vp, _vp, _sz, C.POINTER(C.c_double), _i, C.POINTER(C.c_float)]),

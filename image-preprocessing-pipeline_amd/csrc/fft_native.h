@@ -25,6 +25,11 @@ struct PadWindow {
     int w[3] = {0, 0, 0};
 };
 
+// Subset of the y tiles of the fused x pass: mode 0 all, 1 only the tiles [lo0, lo0+n0) and [lo1, lo1+n1), 2 all the others
+struct TileSelect {
+    int mode = 0, lo0 = 0, n0 = 0, lo1 = 0, n1 = 0;
+};
+
 struct NativeFft {
     NativeDims dims{};
     PadWindow pw{};
@@ -59,7 +64,9 @@ struct NativeFft {
     int middle(hipStream_t s, bool conj_otf);
     int y_pass(hipStream_t s, bool inverse);
     int z_conv(hipStream_t s, bool conj_otf);
-    int x_inverse(hipStream_t s, float* out, int epi_kind, const ConvEpilogue& epi, bool fuse_forward);
+    int x_inverse(hipStream_t s, float* out, int epi_kind, const ConvEpilogue& epi, bool fuse_forward, const TileSelect* part = nullptr);
+    bool splits() const;  // the fused x pass can run a subset of its tiles
+    TileSelect edge_tiles(int mode, int a0, int a1, int b0, int b1) const;
     size_t device_bytes() const { return S.bytes + T.bytes + G.bytes + G_adj.bytes + tw.bytes; }
 };
 

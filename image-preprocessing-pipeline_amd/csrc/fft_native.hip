@@ -1090,7 +1090,8 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_x_inverse(const float2
 // Unpadded volumes only (the padded mode keeps k_x_inverse).
 template <int LHX2, int R3>
 __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_x_fused_pipe(const float2* __restrict__ T, float* __restrict__ out, ConvEpilogue e, NativeDims d,
-                                                            const float2* __restrict__ tw, float2* __restrict__ S_next, int EPI, int ntiles) {
+                                                            const float2* __restrict__ tw, float2* __restrict__ S_next, int EPI, int ntiles,
+                                                            TileSelect sel) {
     extern __shared__ __attribute__((aligned(16))) float2 tile[];
     constexpr int Hx = R3 << LHX2, NW = kThreadsXZ / 64;
     constexpr int TY = x_tile_rows(Hx), hp = TY / 2, quads = Hx / 2;
@@ -1133,7 +1134,21 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_x_fused_pipe(const flo
         }
     };
     float4 pre[NPF];
-    auto tile_base = [&](int t) { const int z = t / ytiles, y0 = (t - z * ytiles) * TY; return ((size_t)z * Hx) * d.ny + y0; };
+    // tile number -> (z, first row): all y tiles of a plane, or only / all but the tiles of two row ranges (the slab driver
+    // sends the edge rows off while the rest of the pass runs)
+    auto tile_zy = [&](int t, int& z, int& y0) {
+        const int per = sel.mode == 0 ? ytiles : (sel.mode == 1 ? sel.n0 + sel.n1 : ytiles - sel.n0 - sel.n1);
+        z = t / per;
+        int ty = t - z * per;
+        if (sel.mode == 1) {
+            ty = ty < sel.n0 ? sel.lo0 + ty : sel.lo1 + (ty - sel.n0);
+        } else if (sel.mode == 2) {
+            if (ty >= sel.lo0) ty += sel.n0;
+            if (ty >= sel.lo1) ty += sel.n1;
+        }
+        y0 = ty * TY;
+    };
+    auto tile_base = [&](int t) { int z, y0; tile_zy(t, z, y0); return ((size_t)z * Hx) * d.ny + y0; };
     auto load_T = [&](int t) {
         const TView tv = t_view();
         const float4* src = reinterpret_cast<const float4*>(T + tile_base(t)) + tv.off;
@@ -1159,7 +1174,8 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_x_fused_pipe(const flo
             }
         }
         // rows of this tile in the real volume: contiguous TY * 2 Hx floats
-        const int z = t / ytiles, y0 = (t - z * ytiles) * TY;
+        int z, y0;
+        tile_zy(t, z, y0);
         const size_t row0 = ((size_t)z * d.ny + y0) * (size_t)(2 * Hx);
         const float4* a4 = reinterpret_cast<const float4*>(e.a + row0);
         float4 av[NPF];
@@ -1366,6 +1382,24 @@ void NativeFft::set_window(const int n[3], const int o[3], const int rep[3], con
 
 bool NativeFft::can_fuse() const { return !pw.on || !(pw.rep[0] || pw.rep[1] || pw.rep[2]); }
 
+// the fused x pass runs as the persistent pipelined kernel, which can also process a subset of its tiles
+bool NativeFft::splits() const {
+    static const bool no_pipe = std::getenv("MI_FFT_NO_PIPE") != nullptr;
+    return !pw.on && dims.dbg == 0 && !no_pipe && dims.ty == x_tile_rows(dims.hx);
+}
+
+// tiles of the fused x pass that hold rows of [a0, a1) or [b0, b1) (a before b): mode 1 = only those, 2 = all the others
+TileSelect NativeFft::edge_tiles(int mode, int a0, int a1, int b0, int b1) const {
+    TileSelect t{};
+    const int ty = dims.ty;
+    t.mode = mode;
+    t.lo0 = a0 / ty;
+    t.n0 = (a1 + ty - 1) / ty - t.lo0;
+    t.lo1 = std::max(b0 / ty, t.lo0 + t.n0);   // overlapping ranges: the second one starts behind the first
+    t.n1 = std::max((b1 + ty - 1) / ty - t.lo1, 0);
+    return t;
+}
+
 int NativeFft::x_forward(hipStream_t s, const float* in) {
     const PadWindow pw = this->pw;
     const int Hx = dims.hx, M = dims.ny, L = dims.nz;
@@ -1462,7 +1496,7 @@ int NativeFft::middle(hipStream_t s, bool conj_otf) {
 }
 
 // P5 (+ P1 of the next convolution when fuse_forward): T -> out (may be null when fused) [-> S]
-int NativeFft::x_inverse(hipStream_t s, float* out, int epi_kind, const ConvEpilogue& epi, bool fuse_forward) {
+int NativeFft::x_inverse(hipStream_t s, float* out, int epi_kind, const ConvEpilogue& epi, bool fuse_forward, const TileSelect* part) {
     const int Hx = dims.hx, M = dims.ny, L = dims.nz;
     const unsigned xtiles = (unsigned)((size_t)L * (M / dims.ty));
     const size_t xl = lds_bytes(dims.ty, Hx);
@@ -1476,15 +1510,22 @@ int NativeFft::x_inverse(hipStream_t s, float* out, int epi_kind, const ConvEpil
     MI_REQUIRE(!fuse_forward || can_fuse(), "native FFT: a replicate-padded axis cannot fuse consecutive convolutions");
     const PadWindow w = pw;
     int rc = MI_ERR_INVALID;
-    static const bool no_pipe = std::getenv("MI_FFT_NO_PIPE") != nullptr;
-    if (fuse_forward && !pw.on && dims.dbg == 0 && !no_pipe && dims.ty == x_tile_rows(Hx)) {
-        const int ntiles = (int)xtiles;
+    if (fuse_forward && splits()) {
+        TileSelect sel{};
+        int per = M / dims.ty;
+        if (part && part->mode != 0) {
+            sel = *part;
+            per = sel.mode == 1 ? sel.n0 + sel.n1 : per - sel.n0 - sel.n1;
+        }
+        const int ntiles = L * per;
+        if (ntiles <= 0) return MI_OK;
         const unsigned grid = (unsigned)std::min(ntiles, n_cu);
-#define MI_XP(LG, R) case LG * 16 + R: rc = launch_lds(k_x_fused_pipe<LG, R>, grid, kThreadsXZ, xl, s, "k_x_fused_pipe", Tp, out, epi, d, twx, Sp, ek, ntiles); break;
+#define MI_XP(LG, R) case LG * 16 + R: rc = launch_lds(k_x_fused_pipe<LG, R>, grid, kThreadsXZ, xl, s, "k_x_fused_pipe", Tp, out, epi, d, twx, Sp, ek, ntiles, sel); break;
         switch (dims.lhx2 * 16 + dims.r3x) { MI_AXIS_CASES(MI_XP) default: return fail(MI_ERR_UNSUPPORTED, "native FFT: x length %d", 2 * Hx); }
 #undef MI_XP
         return rc;
     }
+    MI_REQUIRE(!part || part->mode == 0, "native FFT: this kernel cannot run a subset of its tiles");
 #define MI_XI(LG, R)                                                                                                               \
     case LG * 16 + R:                                                                                                              \
         rc = fuse_forward ? launch_lds(k_x_inverse<LG, R, true>, xtiles, kThreadsXZ, xl, s, "k_x_inverse<fused>", Tp, out, epi, d, twx, Sp, ek, w) \

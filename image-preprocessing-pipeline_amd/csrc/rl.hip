@@ -194,7 +194,8 @@ static int sharded_native(mi_rl_ctx* ctx, NativeFft** out) {
 }
 
 extern "C" int mi_rl_fuses(mi_rl_ctx* ctx) {
-    return ctx && ctx->engine == MI_ENGINE_FFT && ctx->fft->native && ctx->fft->native->can_fuse() ? 1 : 0;
+    if (!(ctx && ctx->engine == MI_ENGINE_FFT && ctx->fft->native && ctx->fft->native->can_fuse())) return 0;
+    return ctx->fft->native->splits() ? 2 : 1;
 }
 
 extern "C" int mi_rl_sharded_begin(mi_rl_ctx* ctx, void* stream, const float* bl) {
@@ -204,24 +205,33 @@ extern "C" int mi_rl_sharded_begin(mi_rl_ctx* ctx, void* stream, const float* bl
     return nf->x_forward(as_stream(stream), bl);
 }
 
-extern "C" int mi_rl_sharded_ratio(mi_rl_ctx* ctx, void* stream, const float* bl) {
+// part 0: the whole step; 1: the y/z passes and the x tiles holding rows of [a0,a1) or [b0,b1); 2: the remaining x tiles
+static int sharded_step(mi_rl_ctx* ctx, void* stream, float* bl, bool update, int more, int part, const int* edges) {
     NativeFft* nf = nullptr;
     MI_TRY(sharded_native(ctx, &nf));
-    MI_REQUIRE(bl, "mi_rl_sharded_ratio: null pointer");
+    MI_REQUIRE(bl, "mi_rl_sharded: null pointer");
+    MI_REQUIRE(part >= 0 && part <= 2, "mi_rl_sharded: part must be 0, 1 or 2");
+    TileSelect sel{};
+    if (part != 0) {
+        MI_REQUIRE(nf->splits(), "mi_rl_sharded: this context cannot split the x pass (mi_rl_fuses() != 2)");
+        MI_REQUIRE(edges && edges[0] >= 0 && edges[0] < edges[1] && edges[1] <= edges[2] && edges[2] < edges[3] && edges[3] <= ctx->n[1],
+                   "mi_rl_sharded: edge row ranges must be ordered and inside the volume");
+        sel = nf->edge_tiles(part, edges[0], edges[1], edges[2], edges[3]);
+    }
     ConvEpilogue e;
     e.a = bl;
-    MI_TRY(nf->middle(as_stream(stream), false));
-    return nf->x_inverse(as_stream(stream), nullptr, EPI_RATIO, e, true);
+    if (part != 2) MI_TRY(nf->middle(as_stream(stream), update));
+    return update ? nf->x_inverse(as_stream(stream), bl, EPI_UPDATE, e, more != 0, &sel)
+                  : nf->x_inverse(as_stream(stream), nullptr, EPI_RATIO, e, true, &sel);
 }
 
-extern "C" int mi_rl_sharded_update(mi_rl_ctx* ctx, void* stream, float* bl, int more) {
-    NativeFft* nf = nullptr;
-    MI_TRY(sharded_native(ctx, &nf));
-    MI_REQUIRE(bl, "mi_rl_sharded_update: null pointer");
-    ConvEpilogue e;
-    e.a = bl;
-    MI_TRY(nf->middle(as_stream(stream), true));
-    return nf->x_inverse(as_stream(stream), bl, EPI_UPDATE, e, more != 0);
+extern "C" int mi_rl_sharded_ratio(mi_rl_ctx* ctx, void* stream, const float* bl, int part, const int* edge_rows) {
+    return sharded_step(ctx, stream, const_cast<float*>(bl), false, 1, part, edge_rows);
+}
+
+extern "C" int mi_rl_sharded_update(mi_rl_ctx* ctx, void* stream, float* bl, int more, int part, const int* edge_rows) {
+    MI_REQUIRE(part == 0 || more, "mi_rl_sharded_update: a split step must produce the next input (more != 0)");
+    return sharded_step(ctx, stream, bl, true, more, part, edge_rows);
 }
 
 extern "C" int mi_rl_spectrum_rows(mi_rl_ctx* ctx, void* stream, int y0, int rows, float* buf, int dir) {

@@ -307,20 +307,27 @@ class RLContext:
 
     # ---- sharded fused iteration (slab driver): see include/mi_lsdeconv.h "Sharded fused iteration"
     @property
-    def fuses(self) -> bool:
-        return bool(lib().mi_rl_fuses(self._h))
+    def fuses(self) -> int:
+        """0: no fused iteration; 1: fused; 2: fused, and the x pass can be split around the halo sends (``part``)."""
+        return int(lib().mi_rl_fuses(self._h))
 
     def sharded_begin(self, bl):
         self._chk(bl)
         check(lib().mi_rl_sharded_begin(self._h, _stream(bl), bl.data_ptr()))
 
-    def sharded_ratio(self, bl):
-        self._chk(bl)
-        check(lib().mi_rl_sharded_ratio(self._h, _stream(bl), bl.data_ptr()))
+    @staticmethod
+    def _edges(edge_rows):
+        return (C.c_int * 4)(*[int(v) for v in edge_rows]) if edge_rows is not None else None
 
-    def sharded_update(self, bl, more=True):
+    def sharded_ratio(self, bl, part=0, edge_rows=None):
+        """S <- x-forward(bl ./ max(conv(S), eps)).  part 1: y/z passes + the x tiles holding ``edge_rows`` =
+        (a0, a1, b0, b1); part 2: the remaining x tiles."""
         self._chk(bl)
-        check(lib().mi_rl_sharded_update(self._h, _stream(bl), bl.data_ptr(), int(bool(more))))
+        check(lib().mi_rl_sharded_ratio(self._h, _stream(bl), bl.data_ptr(), int(part), self._edges(edge_rows)))
+
+    def sharded_update(self, bl, more=True, part=0, edge_rows=None):
+        self._chk(bl)
+        check(lib().mi_rl_sharded_update(self._h, _stream(bl), bl.data_ptr(), int(bool(more)), int(part), self._edges(edge_rows)))
 
     def spectrum_pack(self, y0, rows):
         """Rows [y0, y0+rows) of the x-transformed input buffer as a contiguous float32 device tensor."""

@@ -113,8 +113,11 @@ class SlabRL:
         self.ctx = self.ops.make_ctx(self.lshape, self.psf, boundary_xyz, shift_xyz, engine)
         self.bl = torch.zeros(self.lshape, dtype=torch.float32, device=self.device)
         # fused pipeline: halos travel as x-transformed rows, no ratio volume exists
-        self.sharded = bool(getattr(self.ctx, "fuses", False))
+        self.sharded = bool(getattr(self.ctx, "fuses", 0))
         self._begun = False
+        # rows sent to the neighbours: the first and the last h interior rows
+        self.edge_rows = (self.h, 2 * self.h, self.n_loc, self.n_loc + self.h)
+        self.overlap = (int(getattr(self.ctx, "fuses", 0)) == 2 and self.h > 0 and self.n_loc >= 2 * self.h)
         self.ratio = None if self.sharded else torch.zeros(self.lshape, dtype=torch.float32, device=self.device)
         if volume is not None:
             v = volume[:, self.y0:self.y1, :]
@@ -163,19 +166,16 @@ class SlabRL:
         self.ops.unpack_spec(self.ctx, recv_lo, 0, h)          # None = global edge of the spatial flavour -> zero rows
         self.ops.unpack_spec(self.ctx, recv_hi, h + n, h)
 
-    def exchange(self, vol=None):
-        """Refresh the 2*h halo rows from the neighbouring slabs (ring for the circular flavour, zeros at the global
-        edges for the spatial one): of ``vol`` in real space, or -- ``vol`` None, fused pipeline -- of the context's
-        x-transformed input buffer."""
+    def exchange_start(self, vol=None):
+        """Pack the rows the neighbours need and issue the sends / receives; returns the state ``exchange_finish`` needs.
+        ``vol`` None: the rows of the context's x-transformed input buffer (fused pipeline)."""
         if self.h == 0:
-            return
+            return None
         spec = vol is None
         lo_src, hi_src = self.neighbours()
         send_up, send_dn = self.pack_spec_halos() if spec else self.pack_halos(vol)
-        deliver = self.unpack_spec_halos if spec else (lambda lo, hi: self.unpack_halos(vol, lo, hi))
         if self.world == 1:  # self-ring: my own rows wrap around
-            deliver(send_up if lo_src is not None else None, send_dn if hi_src is not None else None)
-            return
+            return (vol, [], send_up if lo_src is not None else None, send_dn if hi_src is not None else None, False)
         import torch.distributed as dist
         # RCCL moves device buffers directly; a gloo group (CPU rehearsals of the multi-rank path) needs host staging
         staged = send_up.is_cuda and dist.get_backend(self.group) == "gloo"
@@ -194,12 +194,28 @@ class SlabRL:
             ops.append(dist.P2POp(dist.irecv, recv_lo, lo_src, self.group, 1))
         if hi_src is not None:
             ops.append(dist.P2POp(dist.irecv, recv_hi, hi_src, self.group, 2))
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()
+        reqs = dist.batch_isend_irecv(ops)
+        return (vol, reqs, recv_lo, recv_hi, staged, (send_up, send_dn))  # the send buffers stay alive until the wait
+
+    def exchange_finish(self, state):
+        if state is None:
+            return
+        vol, reqs, recv_lo, recv_hi, staged = state[:5]
+        for req in reqs:
+            req.wait()  # RCCL: makes the current stream wait for the transfer; gloo: blocks the host
         if staged:
             recv_lo = recv_lo.to(self.device) if recv_lo is not None else None
             recv_hi = recv_hi.to(self.device) if recv_hi is not None else None
-        deliver(recv_lo, recv_hi)
+        if vol is None:
+            self.unpack_spec_halos(recv_lo, recv_hi)
+        else:
+            self.unpack_halos(vol, recv_lo, recv_hi)
+
+    def exchange(self, vol=None):
+        """Refresh the 2*h halo rows from the neighbouring slabs (ring for the circular flavour, zeros at the global
+        edges for the spatial one): of ``vol`` in real space, or -- ``vol`` None, fused pipeline -- of the context's
+        x-transformed input buffer."""
+        self.exchange_finish(self.exchange_start(vol))
 
     # ------------------------------------------------------------------ iteration
     def iterate(self):
@@ -209,6 +225,18 @@ class SlabRL:
                 self.ctx.sharded_begin(self.bl)
                 self.exchange()
                 self._begun = True
+            if self.overlap:
+                # the x tiles that hold the rows to be sent run first; the transfer then overlaps with the rest of the x pass
+                e = self.edge_rows
+                self.ctx.sharded_ratio(self.bl, 1, e)
+                st = self.exchange_start()
+                self.ctx.sharded_ratio(self.bl, 2, e)
+                self.exchange_finish(st)
+                self.ctx.sharded_update(self.bl, True, 1, e)
+                st = self.exchange_start()
+                self.ctx.sharded_update(self.bl, True, 2, e)
+                self.exchange_finish(st)
+                return
             self.ctx.sharded_ratio(self.bl)
             self.exchange()
             self.ctx.sharded_update(self.bl, True)

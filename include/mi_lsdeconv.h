@@ -127,12 +127,15 @@ int mi_rl_iterate(mi_rl_ctx* ctx, void* stream, float* bl, float* ratio, int n_i
  *     mi_rl_sharded_update(ctx, s, bl, more)  bl <- |bl .* conv_adj(S)|; more != 0: S <- x-forward(bl)  [then exchange rows of S]
  * The halo rows of `bl` itself are never read again (each row's x transform is independent) and hold meaningless values.
  * mi_rl_spectrum_rows packs (dir 0) / unpacks (dir 1) / zero-fills (dir 2) rows [y0, y0+rows) of S into / from a contiguous
- * device buffer of rows * mi_rl_spectrum_row_floats(ctx) floats.  mi_rl_fuses: 1 when the context runs the fused native
- * pipeline (else the calls return MI_ERR_UNSUPPORTED and the driver uses forward_ratio / adjoint_update on real halos). */
+ * device buffer of rows * mi_rl_spectrum_row_floats(ctx) floats.  mi_rl_fuses: 0 = the context does not run the fused native
+ * pipeline (the calls return MI_ERR_UNSUPPORTED and the driver uses forward_ratio / adjoint_update on real halos), 1 = fused,
+ * 2 = fused and the x pass can be split so that the exchange overlaps with it: part 0 = the whole step; part 1 = the y/z passes
+ * and only the x tiles that hold rows of edge_rows = {a0, a1, b0, b1} ([a0,a1) and [b0,b1): the rows about to be sent); part 2 =
+ * the remaining x tiles (launch it after the sends have been issued). */
 int mi_rl_fuses(mi_rl_ctx* ctx);
 int mi_rl_sharded_begin(mi_rl_ctx* ctx, void* stream, const float* bl);
-int mi_rl_sharded_ratio(mi_rl_ctx* ctx, void* stream, const float* bl);
-int mi_rl_sharded_update(mi_rl_ctx* ctx, void* stream, float* bl, int more);
+int mi_rl_sharded_ratio(mi_rl_ctx* ctx, void* stream, const float* bl, int part, const int* edge_rows);
+int mi_rl_sharded_update(mi_rl_ctx* ctx, void* stream, float* bl, int more, int part, const int* edge_rows);
 int mi_rl_spectrum_rows(mi_rl_ctx* ctx, void* stream, int y0, int rows, float* buf, int dir);
 size_t mi_rl_spectrum_row_floats(mi_rl_ctx* ctx);
 /* Measurement hook: average duration in ms of `reps` back-to-back launches of ONE pass of the native FFT pipeline,

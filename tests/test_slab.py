@@ -20,7 +20,7 @@ def _rel(a, b):
     return float(np.abs(a.astype(np.float64) - b).max() / np.abs(b).max())
 
 
-def _worker(rank, world, port, flavour, vol, psf, niter, out, fuses=False):
+def _worker(rank, world, port, flavour, vol, psf, niter, out, fuses=0):
     import torch.distributed as dist
     from ipp_amd import slab
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -28,7 +28,7 @@ def _worker(rank, world, port, flavour, vol, psf, niter, out, fuses=False):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         drv = slab.SlabRL(vol.shape, psf, rank=rank, world_size=world, flavour=flavour, volume=vol, ops=NumpyOps(fuses))
-        assert drv.sharded == fuses
+        assert drv.sharded == bool(fuses) and drv.overlap == (fuses == 2)
         n0 = drv.norm2()
         drv.run(niter)
         full = drv.gather()
@@ -39,14 +39,14 @@ def _worker(rank, world, port, flavour, vol, psf, niter, out, fuses=False):
 
 
 @pytest.mark.parametrize("flavour", ["fft", "spatial"])
-@pytest.mark.parametrize("fuses", [False, True], ids=["real_halos", "spectrum_halos"])
+@pytest.mark.parametrize("fuses", [0, 1, 2], ids=["real_halos", "spectrum_halos", "spectrum_halos_overlapped"])
 def test_two_gloo_ranks_equal_unsharded_oracle(flavour, fuses):
     """Both halo protocols: real-space rows around forward_ratio / adjoint_update, and x-transformed rows around the fused
     steps (the protocol of the native FFT pipeline)."""
     vol, psf = _case()
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
-    port = 29600 + (os.getpid() % 200) + (0 if flavour == "fft" else 1) + (2 if fuses else 0)
+    port = 29600 + (os.getpid() % 200) + (0 if flavour == "fft" else 1) + 2 * fuses
     procs = [ctx.Process(target=_worker, args=(r, 2, port, flavour, vol, psf, 3, out, fuses)) for r in range(2)]
     for p in procs:
         p.start()
@@ -64,7 +64,7 @@ def test_two_gloo_ranks_equal_unsharded_oracle(flavour, fuses):
 
 @pytest.mark.parametrize("flavour", ["fft", "spatial"])
 @pytest.mark.parametrize("world", [1, 3, 4])
-@pytest.mark.parametrize("fuses", [False, True], ids=["real_halos", "spectrum_halos"])
+@pytest.mark.parametrize("fuses", [0, 1, 2], ids=["real_halos", "spectrum_halos", "spectrum_halos_overlapped"])
 def test_lockstep_slabs_uneven_rows(flavour, world, fuses):
     from ipp_amd import slab
     vol, psf = _case(seed=5, shape=(9, 41, 16))  # 41 rows: uneven split; odd extent: centred deconFFT placement
