@@ -11,6 +11,9 @@ struct NativeDims {
     int lz2, r3z;
     int hx, ny, nz;
     int ty, tc, tl;   // rows per x tile, columns per y tile, lines per z tile (A and B tiles each)
+    // padded grids: planes z >= z_in_hi of a convolution's input are all zero (never stored, never loaded); of its result only
+    // planes [z_out_lo, z_out_hi) and rows < y_out_hi are ever read.  Whole grid when nothing is padded.
+    int z_in_hi, z_out_lo, z_out_hi, y_out_hi;
     int dbg;          // timing experiments only: knocks out phases of the z pass (results are then wrong)
 };
 

@@ -532,6 +532,7 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_x_forward(const float*
         bool live = false;
         for (int r = 0; r < TY; ++r) live = live || pad_src(pw, 1, y0 + r) >= 0;
         if (sz < 0 || !live) {
+            if (z >= d.z_in_hi) return;  // the y pass does not read these planes
             for (int i = threadIdx.x; i < hp * Hx; i += kThreadsXZ) {
                 const int px = i / hp, rp = i - px * hp;
                 dst[(size_t)px * rowq + rp] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -593,6 +594,14 @@ __global__ __launch_bounds__(kThreadsY, 4) void k_y_pass(const float2* __restric
     constexpr int TCC = y_tile_cols(M);  // the tile height the host normally picks: compile-time item decomposition
     const int TC = d.tc, Hx = d.hx, L = d.nz;
     const size_t c0 = (size_t)blockIdx.x * TC;
+    // padded grids: forward, the columns of all-zero input planes are neither read nor produced (the z pass knows they are
+    // zero); inverse, only the planes that survive the crop are transformed
+    if (!INVERSE) {
+        if ((int)(c0 / Hx) >= d.z_in_hi) return;
+    } else if (L % TC == 0) {
+        const int z_first = (int)(c0 % L);
+        if (z_first >= d.z_out_hi || z_first + TC <= d.z_out_lo) return;
+    }
     const float4* base = reinterpret_cast<const float4*>(src + c0 * M);
     // columns dealt to the waves when there are enough of them: then the fill, the transform and the drain of a column all
     // belong to one wave and the kernel has no work-group barrier besides the one behind the table fill
@@ -652,7 +661,7 @@ __global__ __launch_bounds__(kThreadsY, 4) void k_y_pass(const float2* __restric
             const int s0 = c * pitch + (s_lane ^ swz_c(2 * qk));
             const float2 a = tile[s0], b = tile[s0 ^ 1];
             float4* dcol = reinterpret_cast<float4*>(dst + dest_col(c0 + c) * M);  // scalar
-            dcol[qk + threadIdx.x] = make_float4(a.x, a.y, b.x, b.y);
+            if (!INVERSE || 2 * (qk + (int)threadIdx.x) < d.y_out_hi) dcol[qk + threadIdx.x] = make_float4(a.x, a.y, b.x, b.y);
         }
     } else {
 #pragma unroll MI_FFT_UNROLL
@@ -661,7 +670,7 @@ __global__ __launch_bounds__(kThreadsY, 4) void k_y_pass(const float2* __restric
             const int c = priv ? cl * NW + wave : cl;
             const int s0 = c * pitch + phys(2 * q);
             const float2 a = tile[s0], b = tile[s0 ^ 1];
-            reinterpret_cast<float4*>(dst + dest_col(c0 + c) * M)[q] = make_float4(a.x, a.y, b.x, b.y);
+            if (!INVERSE || 2 * q < d.y_out_hi) reinterpret_cast<float4*>(dst + dest_col(c0 + c) * M)[q] = make_float4(a.x, a.y, b.x, b.y);
         }
     }
 }
@@ -700,7 +709,8 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_z_conv(const float2* _
 #pragma unroll MI_FFT_UNROLL
     for (int i = threadIdx.x; i < hp * L; i += kThreadsXZ) {
         const int z = i / hp, jp = i - z * hp;
-        const float4 a = sA[(size_t)z * rowq + jp], b = sB[(size_t)z * rowq + jp];
+        float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f), b = a;
+        if (z < d.z_in_hi) { a = sA[(size_t)z * rowq + jp]; b = sB[(size_t)z * rowq + jp]; }  // planes beyond: all zero, not stored
         const int cA = cell(2 * jp, pitch, hp, z), cB = cA + TL * pitch;  // rows TL + 2 jp carry the same mask
         tile[cA] = make_float2(a.x, a.y);
         tile[cA + pitch] = make_float2(a.z, a.w);
@@ -775,6 +785,7 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_z_conv(const float2* _
 #pragma unroll MI_FFT_UNROLL
     for (int i = threadIdx.x; i < hp * L; i += kThreadsXZ) {
         const int z = i / hp, jp = i - z * hp;
+        if (z < d.z_out_lo || z >= d.z_out_hi) continue;  // planes the crop drops
         const int cA = cell(2 * jp, pitch, hp, z), cB = cA + TL * pitch;
         const float2 a0 = tile[cA], a1 = tile[cA + pitch];
         dA[(size_t)z * rowq + jp] = make_float4(a0.x, a0.y, a1.x, a1.y);
@@ -808,11 +819,11 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_z_conv_pipe(const floa
     const int ytiles = M / TL, rowq = M / 2;
     // lane constants (tile-invariant; recomputed per phase from a laundered thread index so that they do not occupy registers
     // across the FFT phases): the swizzle is XOR-linear, so item k's slot is item 0's slot XOR a constant
-    struct FView { int row, slot; size_t off; };  // transposed view: item k = position z0 + k * P, line pair jp
+    struct FView { int row, slot, z0; size_t off; };  // transposed view: item k = position z0 + k * P, line pair jp
     auto f_view = [&]() {
         const int tid = launder(threadIdx.x);
         const int z0 = tid / hp, jp = tid - z0 * hp;
-        return FView{(2 * jp) * pitch, phys(z0) ^ rmask(2 * jp, hp), (size_t)z0 * rowq + jp};
+        return FView{(2 * jp) * pitch, phys(z0) ^ rmask(2 * jp, hp), z0, (size_t)z0 * rowq + jp};
     };
     float4 preA[NPA], preB[NPA];
     struct Where { int plane, py0, px, pxB, pyB0; };
@@ -833,8 +844,13 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_z_conv_pipe(const floa
 #pragma unroll
         for (int k = 0; k < NPA; ++k) {
             if (NA % kThreadsXZ == 0 || (int)threadIdx.x + k * kThreadsXZ < NA) {
-                preA[k] = sA[(size_t)(k * P) * rowq];
-                preB[k] = sB[(size_t)(k * P) * rowq];
+                float4 va = make_float4(0.0f, 0.0f, 0.0f, 0.0f), vb = va;
+                if (fv.z0 + k * P < d.z_in_hi) {  // planes beyond: all-zero input of a padded grid, never stored
+                    va = sA[(size_t)(k * P) * rowq];
+                    vb = sB[(size_t)(k * P) * rowq];
+                }
+                preA[k] = va;
+                preB[k] = vb;
             }
         }
     };
@@ -929,7 +945,8 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_z_conv_pipe(const floa
         float4* dB = reinterpret_cast<float4*>(T + (size_t)w.pxB * L * M + w.pyB0) + fv.off;
 #pragma unroll
         for (int k = 0; k < NPA; ++k) {
-            if (NA % kThreadsXZ == 0 || (int)threadIdx.x + k * kThreadsXZ < NA) {
+            const int zk = fv.z0 + k * P;
+            if ((NA % kThreadsXZ == 0 || (int)threadIdx.x + k * kThreadsXZ < NA) && zk >= d.z_out_lo && zk < d.z_out_hi) {
                 const int cA = fv.row + (fv.slot ^ swz_c(k * P)), cB = cA + TL * pitch;
                 const float2 a0 = tile[cA], a1 = tile[cA + pitch];
                 dA[(size_t)(k * P) * rowq] = make_float4(a0.x, a0.y, a1.x, a1.y);
@@ -964,7 +981,7 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_x_inverse(const float2
         bool live = false;
         for (int r = 0; r < TY; ++r) live = live || pad_dst(pw, 1, y0 + r) >= 0;
         if (oz < 0 || !live) {
-            if (FUSE) {
+            if (FUSE && z < d.z_in_hi) {  // planes beyond are never read by the next y pass
                 float4* sdst = reinterpret_cast<float4*>(S_next + ((size_t)z * Hx) * d.ny + y0);
                 for (int i = threadIdx.x; i < hp * Hx; i += kThreadsXZ) {
                     const int px = i / hp, rp = i - px * hp;
@@ -1304,6 +1321,10 @@ int NativeFft::init(hipStream_t s, const int F[3], bool explicit_adjoint) {
     dims.ty = std::min(x_tile_rows(Hx), F[1]);
     dims.tc = y_tile_cols(F[1]);
     dims.tl = std::min(z_tile_lines(F[2]), F[1]);
+    dims.z_in_hi = F[2];
+    dims.z_out_lo = 0;
+    dims.z_out_hi = F[2];
+    dims.y_out_hi = F[1];
     dims.dbg = 0;
     if (const char* e = std::getenv("MI_FFT_ZDBG")) dims.dbg = atoi(e);  // phase knock-out for timing experiments
     // tuning overrides (experiments only): MI_FFT_TY / MI_FFT_TC / MI_FFT_TL
@@ -1378,6 +1399,14 @@ void NativeFft::set_window(const int n[3], const int o[3], const int rep[3], con
         pw.rep[a] = rep[a];
         pw.w[a] = n[a] + k[a] - 1;
     }
+    // what the padding leaves to prune (MI_FFT_NO_PRUNE=1 keeps the full passes, for A/B measurements)
+    if (std::getenv("MI_FFT_NO_PRUNE") != nullptr) return;
+    const int in_hi = rep[2] ? pw.w[2] : o[2] + n[2];
+    dims.z_in_hi = std::min(in_hi, dims.nz);
+    dims.z_out_lo = o[2];
+    dims.z_out_hi = std::min(o[2] + n[2], dims.nz);
+    const int yh = ((o[1] + n[1] + dims.ty - 1) / dims.ty) * dims.ty;  // the x pass reads whole tiles of rows
+    dims.y_out_hi = std::min(yh, dims.ny);
 }
 
 bool NativeFft::can_fuse() const { return !pw.on || !(pw.rep[0] || pw.rep[1] || pw.rep[2]); }
