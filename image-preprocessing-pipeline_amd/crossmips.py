@@ -64,22 +64,152 @@ def norm_cross_corr_mips(A, B, dimk=None, dimi=None, dimj=None, nk=0, ni=0, nj=0
     return out
 
 
+S_NCC_WIDTH_MAX = 30        # S_config.h:86
+S_NCC_PEAK_WEIGHT = 0.5     # S_config.h:87
+S_NCC_WIDTH_WEIGHT = 0.5    # S_config.h:88
+_INT_MAX = 2 ** 31 - 1
+
+
 @dataclass
 class DisplacementMIPNCC:
-    """What PDAlgoMIPNCC::execute stores on the displacement (PDAlgoMIPNCC.cpp:100-109,
-    DisplacementMIPNCC.h): offsets (V,H,D), peak values, half widths + the search parameters."""
+    """The displacement record of a pair of adjacent stacks (stitcher/DisplacementMIPNCC.{h,cpp}): what
+    PDAlgoMIPNCC::execute stores (offsets (V,H,D), peak values, half widths + the search parameters,
+    PDAlgoMIPNCC.cpp:100-109) and the steps that follow the pairwise computation: reliability, combination of the
+    per-layer records, thresholding, XML."""
     VHD_coords: list
     NCC_maxs: list
     NCC_widths: list
     delays: list
     wRangeThrs: list
     invWidths: list
+    VHD_def_coords: list = field(default_factory=lambda: [_INT_MAX] * 3)   # Displacement.cpp:40
+    rel_factors: list = field(default_factory=lambda: [-1.0] * 3)           # DisplacementMIPNCC.cpp:72
     extra: dict = field(default_factory=dict)
 
+    @classmethod
+    def nominal(cls, V, H, D):
+        """DisplacementMIPNCC(int Vnominal, int Hnominal, int Dnominal) (DisplacementMIPNCC.cpp:81-98)."""
+        return cls([V, H, D], [0.0] * 3, [S_NCC_WIDTH_MAX] * 3, [-1] * 3, [S_NCC_WIDTH_MAX - 1] * 3, [S_NCC_WIDTH_MAX] * 3,
+                   [V, H, D], [0.0] * 3)
+
     def evalReliability(self, axis: int) -> float:
-        """DisplacementMIPNCC.cpp:130-147: sqrt(0.5*(1 - w/invW)^2 + 0.5*peak^2)."""
-        w, inv, peak = self.NCC_widths[axis], self.invWidths[axis], self.NCC_maxs[axis]
-        return math.sqrt(0.5 * (1.0 - w / inv) ** 2 + 0.5 * peak * peak)
+        """DisplacementMIPNCC.cpp:130-147: ``sqrt(0.5*((100 - w*100/invW)/100)^2 + 0.5*peak^2)`` -- the width term in
+        float, the weighted sum and the root in double (the weights are double literals), the result cast to float."""
+        if axis not in (0, 1, 2):
+            raise ValueError("in DisplacementMIPNCC::evalReliability(...): wrong direction value")
+        f = np.float32
+        wn = (f(100.0) - (f(self.NCC_widths[axis]) * f(100.0) / f(self.invWidths[axis]))) / f(100.0)
+        peak = f(self.NCC_maxs[axis])
+        r = math.sqrt(S_NCC_WIDTH_WEIGHT * float(wn) * float(wn) + S_NCC_PEAK_WEIGHT * float(peak) * float(peak))
+        self.rel_factors[axis] = float(f(r))
+        return self.rel_factors[axis]
+
+    def getReliability(self, axis: int) -> float:
+        if axis not in (0, 1, 2):
+            raise ValueError("in DisplacementMIPNCC::evalReliability(...): wrong direction value")
+        if self.rel_factors[axis] == -1.0:
+            raise RuntimeError("in DisplacementMIPNCC::evalReliability(direction _direction): reliability factor not yet computed")
+        return self.rel_factors[axis]
+
+    _PER_AXIS = ("rel_factors", "NCC_maxs", "NCC_widths", "VHD_coords", "VHD_def_coords", "delays", "wRangeThrs", "invWidths")
+
+    def combine(self, other: "DisplacementMIPNCC"):
+        """DisplacementMIPNCC::combine (:312-346): per axis the more reliable of the two records wins and is copied into
+        the other, so both are equal afterwards (ties keep ``self``)."""
+        for k in range(3):
+            self.evalReliability(k)
+            other.evalReliability(k)
+            src, dst = (other, self) if self.rel_factors[k] < other.rel_factors[k] else (self, other)
+            for name in self._PER_AXIS:
+                getattr(dst, name)[k] = getattr(src, name)[k]
+
+    def isBetter(self, other: "DisplacementMIPNCC") -> bool:
+        """:349-364: true when ``other``'s reliabilities sum to at least this record's."""
+        cur = sum(np.float32(self.evalReliability(k)) for k in range(3))
+        oth = sum(np.float32(other.evalReliability(k)) for k in range(3))
+        return bool(oth >= cur)
+
+    def threshold(self, rel_threshold: float):
+        """:217-235: axes whose reliability is below the threshold fall back to the default (stage) displacement."""
+        for k in range(3):
+            self.evalReliability(k)
+        for k in range(3):
+            if self.rel_factors[k] < np.float32(rel_threshold):
+                self.VHD_coords[k] = self.VHD_def_coords[k]
+                self.NCC_maxs[k] = 0.0
+                self.NCC_widths[k] = self.invWidths[k]
+                self.evalReliability(k)
+
+    def getMirrored(self, direction: int = -1):
+        """:237-306; ``direction`` -1 = dir_all (what VirtualVolume::insertDisplacement stores on the other stack)."""
+        m = DisplacementMIPNCC(list(self.VHD_coords), list(self.NCC_maxs), list(self.NCC_widths), list(self.delays),
+                               list(self.wRangeThrs), list(self.invWidths), list(self.VHD_def_coords), list(self.rel_factors))
+        if direction not in (-1, 0, 1, 2):
+            raise ValueError("in DisplacementMIPNCC::getMirrored(...): unsupported or wrong given mirroring direction")
+        for k in range(3):
+            if direction == -1 or direction == k:
+                m.VHD_coords[k] = -self.VHD_coords[k]
+                m.VHD_def_coords[k] = -self.VHD_def_coords[k]
+        return m
+
+    def getXML(self):
+        """<Displacement TYPE="MIP_NCC"> with V/H/D children (DisplacementMIPNCC::getXML, :367-400)."""
+        import xml.etree.ElementTree as ET
+        e = ET.Element("Displacement", TYPE="MIP_NCC")
+        for i, name in enumerate("VHD"):
+            ET.SubElement(e, name, displ=str(self.VHD_coords[i]), default_displ=str(self.VHD_def_coords[i]),
+                          reliability=repr(float(self.rel_factors[i])), nccPeak=repr(float(self.NCC_maxs[i])),
+                          nccWidth=str(self.NCC_widths[i]), nccWRangeThr=str(self.wRangeThrs[i]),
+                          nccInvWidth=str(self.invWidths[i]), delay=str(self.delays[i]))
+        return e
+
+    @classmethod
+    def loadXML(cls, node):
+        """DisplacementMIPNCC::loadXML (:401-434) incl. the defaults of records written before 2013."""
+        d = cls([_INT_MAX] * 3, [0.0] * 3, [0] * 3, [-1] * 3, [-1] * 3, [-1] * 3)
+        for i, name in enumerate("VHD"):
+            e = node.find(name)
+            if e is None:
+                raise ValueError(f"Displacement record without <{name}>")
+            d.VHD_coords[i] = int(e.get("displ"))
+            d.VHD_def_coords[i] = int(e.get("default_displ"))
+            d.rel_factors[i] = float(e.get("reliability"))
+            d.NCC_maxs[i] = float(e.get("nccPeak"))
+            d.NCC_widths[i] = int(e.get("nccWidth"))
+            d.wRangeThrs[i] = int(e.get("nccWRangeThr")) if e.get("nccWRangeThr") is not None else S_NCC_WIDTH_MAX - 1
+            d.invWidths[i] = int(e.get("nccInvWidth")) if e.get("nccInvWidth") is not None else S_NCC_WIDTH_MAX
+            d.delays[i] = int(e.get("delay")) if e.get("delay") is not None else -1
+        return d
+
+
+def project_displacements(displacements):
+    """Displacement::projectDisplacements (Displacement.cpp:84-106): the per-layer records of one pair are combined pairwise,
+    front to back; the last one carries the result."""
+    if not displacements:
+        raise ValueError("in Displacement::projectDisplacements(...): the given vector of displacements is EMPTY. Nothing to project.")
+    for i in range(len(displacements) - 1):
+        displacements[i].combine(displacements[i + 1])
+    return displacements[-1]
+
+
+def threshold_displacements(grid_pairs, n_rows, n_cols, rel_threshold):
+    """StackStitcher::thresholdDisplacements (StackStitcher.cpp:1626-1720) on the projected records: ``grid_pairs`` maps
+    (rowA, colA, rowB, colB) -> the ONE record of an adjacent pair (east and south neighbours).  Thresholds every record and
+    returns the stitchable flag of every stack: at least one single-direction displacement of one of its pairs is reliable."""
+    for r in range(n_rows):
+        for c in range(n_cols):
+            if c + 1 < n_cols and (r, c, r, c + 1) not in grid_pairs or r + 1 < n_rows and (r, c, r + 1, c) not in grid_pairs:
+                raise ValueError("in StackStitcher::thresholdDisplacements(...): one and only displacement must exist for each "
+                                 "pair of adjacent stacks.")
+    for d in grid_pairs.values():
+        d.threshold(rel_threshold)
+    stitchable = {}
+    thr = np.float32(rel_threshold)
+    for r in range(n_rows):
+        for c in range(n_cols):
+            mine = [grid_pairs[k] for k in ((r - 1, c, r, c), (r, c, r, c + 1), (r, c, r + 1, c), (r, c - 1, r, c)) if k in grid_pairs]
+            stitchable[(r, c)] = any(np.float32(d.getReliability(k)) >= thr for d in mine for k in range(3))
+    return stitchable
 
 
 class PDAlgoMIPNCC:
@@ -99,9 +229,16 @@ class PDAlgoMIPNCC:
                                  nj=dim_H - overlap if overlap_direction == dir_horizontal else 0,
                                  delayk=displ_max_D, delayi=displ_max_V, delayj=displ_max_H, side=overlap_direction,
                                  NCC_params=params, device=device)
-        return DisplacementMIPNCC(list(d.coord), [float(v) for v in d.NCC_maxs], list(d.NCC_widths),
-                                  [displ_max_V, displ_max_H, displ_max_D],
-                                  [params.wRangeThr_i, params.wRangeThr_j, params.wRangeThr_k], [params.INF_W] * 3)
+        out = DisplacementMIPNCC(list(d.coord), [float(v) for v in d.NCC_maxs], list(d.NCC_widths),
+                                 [displ_max_V, displ_max_H, displ_max_D],
+                                 [params.wRangeThr_i, params.wRangeThr_j, params.wRangeThr_k], [params.INF_W] * 3)
+        # VirtualVolume::insertDisplacement (vmVirtualVolume.cpp:279-306): reliabilities evaluated, default = the stage offset
+        # along the overlap direction (the nominal offset the search was centred on), 0 elsewhere
+        for k in range(3):
+            out.evalReliability(k)
+        out.VHD_def_coords = [dim_V - overlap if overlap_direction == dir_vertical else 0,
+                              dim_H - overlap if overlap_direction == dir_horizontal else 0, 0]
+        return out
 
 
 def enumerate_pairs(n_rows: int, n_cols: int):
@@ -165,9 +302,13 @@ def compute_displacements(tiles, overlap_V: int, overlap_H: int, displ_max_V=S_D
     res = {}
     for q, key in enumerate(pairs):
         d, p = out[q], params[q]
-        res[key] = DisplacementMIPNCC(list(d.coord), [float(v) for v in d.NCC_maxs], list(d.NCC_widths),
-                                      [displ_max_V, displ_max_H, displ_max_D],
-                                      [p.wRangeThr_i, p.wRangeThr_j, p.wRangeThr_k], [inf_w] * 3)
+        rec = DisplacementMIPNCC(list(d.coord), [float(v) for v in d.NCC_maxs], list(d.NCC_widths),
+                                 [displ_max_V, displ_max_H, displ_max_D],
+                                 [p.wRangeThr_i, p.wRangeThr_j, p.wRangeThr_k], [inf_w] * 3)
+        for k in range(3):  # VirtualVolume::insertDisplacement (vmVirtualVolume.cpp:279-306)
+            rec.evalReliability(k)
+        rec.VHD_def_coords = [int(ni[q]), int(nj[q]), 0]
+        res[key] = rec
     return res
 
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Stitching step 2 ("pairwise displacement computation") entry point.
+"""Stitching steps 2-4 ("pairwise displacement computation", projection, thresholding) entry point.
 
 The reference's process_images.py builds ``mpiexec ... Parastitcher.py -2 --sD=.. --subvoldim=.. --threshold=0.65
 --projin=.. --projout=..`` and toggles the GPU kernels with ``USECUDA_X_NCC`` (process_images.py:542-571,1552); the
@@ -11,8 +11,16 @@ This entry point keeps the step-2 flags and runs that work in-process on the MI3
 
 ``TILES_DIR`` holds ``tile_<row>_<col>.npy`` stacks (D, V, H), uint8/uint16 (scaled to [0,1] like loadImageStack,
 tiff2D.cpp:606-610) or float32.  One ``<Displacement TYPE="MIP_NCC">`` record per pair and z-layer is written in
-the shape of DisplacementMIPNCC::getXML (DisplacementMIPNCC.cpp:367-400).  Steps 1, 3-5 (import, projection,
-thresholding, placement) and the interactive pipeline around them are outside the hot path.
+the shape of DisplacementMIPNCC::getXML (DisplacementMIPNCC.cpp:367-400).
+
+    python process_images.py -3 --input TILES_DIR [--projin xml_displcomp.xml --projout xml_displproj.xml]
+    python process_images.py -4 --input TILES_DIR [--threshold 0.65 --projin xml_displproj.xml --projout xml_displthres.xml]
+
+Step 3 combines the per-layer records of every pair into the most reliable one per direction
+(StackStitcher::projectDisplacements, Displacement::projectDisplacements, DisplacementMIPNCC::combine); step 4 resets the
+directions whose reliability is below the threshold to the stage displacement and flags the stitchable stacks
+(StackStitcher::thresholdDisplacements).  Both are host-side bookkeeping on the XML (SURVEY.md 8f item 3).  Steps 1 and 5
+(import, global placement + merge) and the interactive pipeline around them stay with the reference's tools.
 With ``torchrun`` the pairs of a layer are dealt round-robin to the ranks (no collective; the per-rank XML fragments
 are merged by rank 0, like Parastitcher's mergedisplacements).
 """
@@ -32,10 +40,13 @@ if _ROOT not in sys.path:
 
 def build_parser():
     p = argparse.ArgumentParser(description="MIP-NCC pairwise displacement computation (stitching step 2)")
-    p.add_argument("-2", "--displcompute", dest="step2", action="store_true", help="step 2 (the only step built here)")
+    p.add_argument("-2", "--displcompute", dest="step2", action="store_true", help="step 2: pairwise displacements (GPU)")
+    p.add_argument("-3", "--displproj", dest="step3", action="store_true", help="step 3: projection of the per-layer records")
+    p.add_argument("-4", "--displthres", dest="step4", action="store_true", help="step 4: reliability thresholding")
     p.add_argument("--input", type=Path, required=True, help="folder with tile_<row>_<col>.npy stacks")
-    p.add_argument("--oV", type=int, required=True, help="overlap (pixels) between adjacent tiles along V")
-    p.add_argument("--oH", type=int, required=True, help="overlap (pixels) between adjacent tiles along H")
+    p.add_argument("--oV", type=int, default=None, help="overlap (pixels) between adjacent tiles along V (step 2)")
+    p.add_argument("--oH", type=int, default=None, help="overlap (pixels) between adjacent tiles along H (step 2)")
+    p.add_argument("--projin", type=Path, default=None, help="input XML of steps 3 / 4")
     p.add_argument("--sV", type=int, default=25, help="displacement search radius along V (S_config.h:59)")
     p.add_argument("--sH", type=int, default=25, help="displacement search radius along H")
     p.add_argument("--sD", type=int, default=10, help="displacement search radius along D (process_images.py:562)")
@@ -69,20 +80,78 @@ def load_tiles(folder: Path):
     return tiles
 
 
-def displacement_xml(d, nominal):
-    """<Displacement TYPE="MIP_NCC"> with V/H/D children (DisplacementMIPNCC.cpp:367-400)."""
-    e = ET.Element("Displacement", TYPE="MIP_NCC")
-    for i, name in enumerate("VHD"):
-        ET.SubElement(e, name, displ=str(d.VHD_coords[i]), default_displ=str(nominal[i]),
-                      reliability=f"{d.evalReliability(i):.6f}", nccPeak=f"{d.NCC_maxs[i]:.6f}", nccWidth=str(d.NCC_widths[i]),
-                      nccWRangeThr=str(d.wRangeThrs[i]), nccInvWidth=str(d.invWidths[i]), delay=str(d.delays[i]))
-    return e
+def read_pairs(path):
+    """(root attributes, [(pair attributes, DisplacementMIPNCC)]) of an XML written by one of the steps."""
+    from ipp_amd import crossmips
+    root = ET.parse(path).getroot()
+    recs = [(dict(p.attrib), crossmips.DisplacementMIPNCC.loadXML(p.find("Displacement"))) for p in root.findall("Pair")]
+    return dict(root.attrib), recs
+
+
+def write_pairs(path, root_attrib, recs, stacks=None):
+    root = ET.Element("TeraStitcher", **{k: str(v) for k, v in root_attrib.items()})
+    for attrib, d in recs:
+        ET.SubElement(root, "Pair", **{k: str(v) for k, v in attrib.items()}).append(d.getXML())
+    for (r, c), flag in sorted((stacks or {}).items()):
+        ET.SubElement(root, "Stack", row=str(r), col=str(c), stitchable="yes" if flag else "no")
+    ET.indent(root)
+    ET.ElementTree(root).write(path, xml_declaration=True, encoding="utf-8")
+
+
+def _pair_key(attrib):
+    return tuple(int(attrib[k]) for k in ("rowA", "colA", "rowB", "colB"))
+
+
+def step3_project(args):
+    """projectDisplacements: one record per pair, per direction the most reliable of its layers."""
+    from ipp_amd import crossmips
+    src = args.projin or (args.input / "xml_displcomp.xml")
+    root_attrib, recs = read_pairs(src)
+    groups = {}
+    for attrib, d in sorted(recs, key=lambda r: int(r[0].get("layer", 0))):
+        groups.setdefault(_pair_key(attrib), []).append((attrib, d))
+    out = []
+    for key in sorted(groups):
+        attrib = {k: v for k, v in groups[key][0][0].items() if k not in ("layer", "z0", "z1")}
+        out.append((attrib, crossmips.project_displacements([d for _, d in groups[key]])))
+    root_attrib["step"] = "3"
+    dst = args.projout or (args.input / "xml_displproj.xml")
+    write_pairs(dst, root_attrib, out)
+    print(f"wrote {dst} ({len(out)} projected displacement records from {len(recs)})")
+    return 0
+
+
+def step4_threshold(args):
+    """thresholdDisplacements: unreliable directions fall back to the stage displacement; stitchable stacks are flagged."""
+    from ipp_amd import crossmips
+    src = args.projin or (args.input / "xml_displproj.xml")
+    root_attrib, recs = read_pairs(src)
+    grid = {}
+    for attrib, d in recs:
+        if _pair_key(attrib) in grid:
+            raise RuntimeError("in StackStitcher::thresholdDisplacements(...): one and only displacement must exist for each pair "
+                               "of adjacent stacks.")
+        grid[_pair_key(attrib)] = d
+    n_rows = 1 + max(k[2] for k in grid)
+    n_cols = 1 + max(k[3] for k in grid)
+    stacks = crossmips.threshold_displacements(grid, n_rows, n_cols, args.threshold)
+    root_attrib.update(step="4", threshold=str(args.threshold))
+    dst = args.projout or (args.input / "xml_displthres.xml")
+    write_pairs(dst, root_attrib, recs, stacks)
+    print(f"wrote {dst} ({sum(stacks.values())} of {len(stacks)} stacks stitchable at threshold {args.threshold})")
+    return 0
 
 
 def main(argv=None):
     args = build_parser().parse_args(argv)
+    if args.step3:
+        return step3_project(args)
+    if args.step4:
+        return step4_threshold(args)
     if not args.step2:
-        raise SystemExit("only step 2 (-2, pairwise displacement computation) is built; see SURVEY.md section 8f")
+        raise SystemExit("steps 2 (-2, pairwise displacement computation), 3 (-3) and 4 (-4) are built; see SURVEY.md section 8f")
+    if args.oV is None or args.oH is None:
+        raise SystemExit("step 2 needs --oV and --oH")
     import torch
     from ipp_amd import capi, crossmips
     capi.require_gpu()
@@ -97,11 +166,9 @@ def main(argv=None):
         tiles = [[torch.from_numpy(t[z0:z1]).to(dev) for t in row] for row in host_tiles]   # loadImageStack(z0, z1)
         res = crossmips.compute_displacements(tiles, args.oV, args.oH, args.sV, args.sH, args.sD, rank=rank, world_size=world)
         for (r, c, rb, cb, direction), d in sorted(res.items()):
-            nominal = [dim_V - args.oV if direction == crossmips.dir_vertical else 0,
-                       dim_H - args.oH if direction == crossmips.dir_horizontal else 0, 0]
             pair = ET.SubElement(root, "Pair", layer=str(layer), z0=str(z0), z1=str(z1), rowA=str(r), colA=str(c), rowB=str(rb),
                                  colB=str(cb), direction="NORTH_SOUTH" if direction == crossmips.dir_vertical else "WEST_EAST")
-            pair.append(displacement_xml(d, nominal))
+            pair.append(d.getXML())
     out = args.projout or (args.input / "xml_displcomp.xml")
     if world > 1:
         part = Path(f"{out}.rank{rank}")

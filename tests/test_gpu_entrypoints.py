@@ -67,7 +67,46 @@ def test_process_images_step2(dev, tmp_path):
         want = N.pdalgo_execute(a, b, 6, 6, 1, side, ov, kind="oracle")
         d = p.find("Displacement")
         assert d.get("TYPE") == "MIP_NCC"
+        assert int(d.find("V").get("default_displ")) == (step if side == 0 else 0)
+        assert int(d.find("H").get("default_displ")) == (step if side == 1 else 0)
         for i, name in enumerate("VHD"):
             e = d.find(name)
             assert int(e.get("displ")) == want["coord"][i] and int(e.get("nccWidth")) == want["NCC_widths"][i]
             assert int(e.get("nccWRangeThr")) == want["wRangeThr"][i] and int(e.get("nccInvWidth")) == want["INF_W"]
+
+
+def test_process_images_steps_3_and_4(dev, tmp_path):
+    """Step 2 on two z-layers, then projection (one record per pair) and thresholding of the XML (host logic of
+    StackStitcher::projectDisplacements / thresholdDisplacements)."""
+    from ipp_amd import process_images
+    tile, ov = (52, 96, 96), 32
+    step = tile[1] - ov
+    field = N.bead_field((tile[0], 2 * step + ov, 2 * step + ov), seed=6, density=1 / 300)
+    for r in range(2):
+        for c in range(2):
+            t = field[:, r * step:r * step + tile[1], c * step:c * step + tile[2]]
+            np.save(tmp_path / f"tile_{r}_{c}.npy", np.clip(np.rint(t * 255), 0, 255).astype(np.uint8))
+    common = ["--input", str(tmp_path)]
+    assert process_images.main(["-2", *common, "--oV", str(ov), "--oH", str(ov), "--sV", "6", "--sH", "6", "--sD", "1",
+                                "--subvoldim", "26"]) == 0
+    comp = ET.parse(tmp_path / "xml_displcomp.xml").getroot().findall("Pair")
+    assert len(comp) == 8 and {p.get("layer") for p in comp} == {"0", "1"}
+    assert process_images.main(["-3", *common]) == 0
+    proj = ET.parse(tmp_path / "xml_displproj.xml").getroot().findall("Pair")
+    assert len(proj) == 4 and all(p.get("layer") is None for p in proj)
+    for p in proj:  # per direction the projected reliability is the maximum over the pair's layers
+        key = [p.get(k) for k in ("rowA", "colA", "rowB", "colB")]
+        layers = [q for q in comp if [q.get(k) for k in ("rowA", "colA", "rowB", "colB")] == key]
+        for ax in "VHD":
+            best = max(float(q.find("Displacement").find(ax).get("reliability")) for q in layers)
+            assert float(p.find("Displacement").find(ax).get("reliability")) == best
+    assert process_images.main(["-4", *common, "--threshold", "0.65"]) == 0
+    root = ET.parse(tmp_path / "xml_displthres.xml").getroot()
+    assert root.get("step") == "4" and len(root.findall("Stack")) == 4
+    for p in root.findall("Pair"):
+        for ax in "VHD":
+            e = p.find("Displacement").find(ax)
+            rel = float(e.get("reliability"))
+            assert rel >= 0.65 or (rel == 0.0 and e.get("displ") == e.get("default_displ") and float(e.get("nccPeak")) == 0.0)
+    # exact copies of one bead field: the in-plane offsets are reliable, every stack is stitchable
+    assert all(s.get("stitchable") == "yes" for s in root.findall("Stack"))

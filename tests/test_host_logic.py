@@ -82,3 +82,84 @@ def test_fft_good_size_per_axis():
             m = g(n, axis)
             h = m // 2 if axis == 0 else m
             assert m >= n and any(h % r == 0 and (h // r) & (h // r - 1) == 0 for r in (1, 3, 9))
+
+
+def _displ(coords, peaks, widths, inv=26, default=(0, 717, 0)):
+    from ipp_amd import crossmips
+    d = crossmips.DisplacementMIPNCC(list(coords), list(peaks), list(widths), [25, 25, 10], [25, 25, 10], [inv] * 3)
+    d.VHD_def_coords = list(default)
+    return d
+
+
+def test_displacement_reliability_formula():
+    """DisplacementMIPNCC::evalReliability (:130-147): sqrt(0.5*((100 - w*100/invW)/100)^2 + 0.5*peak^2) as float."""
+    d = _displ((3, 720, -1), (0.9, 0.5, 0.0), (2, 13, 26))
+    want = [np.float32(np.sqrt(0.5 * (1 - 2 / 26) ** 2 + 0.5 * 0.81)), np.float32(np.sqrt(0.5 * 0.25 + 0.5 * 0.25)), 0.0]
+    got = [d.evalReliability(k) for k in range(3)]
+    assert got == pytest.approx([float(w) for w in want], rel=2e-7, abs=1e-7)
+    assert got[2] == 0.0 and d.rel_factors == got
+    fresh = _displ((0, 0, 0), (0, 0, 0), (1, 1, 1))
+    with pytest.raises(RuntimeError, match="not yet computed"):
+        fresh.getReliability(0)
+    nominal = __import__("ipp_amd.crossmips", fromlist=["x"]).DisplacementMIPNCC.nominal(0, 717, 0)
+    assert [nominal.evalReliability(k) for k in range(3)] == [0.0, 0.0, 0.0]  # width == invWidth == 30, peak 0
+
+
+def test_combine_projection_and_threshold():
+    """combine (:312-346) keeps, per direction, the more reliable record in BOTH objects (ties keep the first);
+    projectDisplacements (Displacement.cpp:84-106) folds the layers front to back; threshold (:217-235) resets unreliable
+    directions to the default displacement with peak 0 / width invW (reliability 0)."""
+    from ipp_amd import crossmips
+    a = _displ((1, 715, 0), (0.95, 0.30, 0.2), (1, 20, 26))   # strong V, weak H, D unreliable
+    b = _displ((4, 718, 2), (0.40, 0.90, 0.2), (15, 2, 26))   # weak V, strong H, same D as a (tie)
+    c = _displ((9, 700, 5), (0.10, 0.10, 0.8), (25, 25, 3))   # only D is good
+    last = crossmips.project_displacements([a, b, c])
+    assert last is c and last.VHD_coords == [1, 718, 5]
+    assert last.NCC_maxs == pytest.approx([0.95, 0.90, 0.8]) and last.NCC_widths == [1, 2, 3]
+    assert a.VHD_coords[0] == b.VHD_coords[0] == 1           # combine made the first two equal in V
+    # tie: equal reliabilities keep self (a's D record was copied into b, not the other way round)
+    x, y = _displ((1, 1, 7), (0.5, 0.5, 0.5), (5, 5, 5)), _displ((2, 2, 8), (0.5, 0.5, 0.5), (5, 5, 5))
+    x.combine(y)
+    assert x.VHD_coords == [1, 1, 7] and y.VHD_coords == [1, 1, 7]
+    with pytest.raises(ValueError, match="EMPTY"):
+        crossmips.project_displacements([])
+    t = _displ((3, 720, -4), (0.9, 0.2, 0.7), (2, 25, 20), default=(0, 717, 0))
+    t.threshold(0.65)
+    assert t.VHD_coords == [3, 717, 0]                       # H and D fell back to the stage displacement
+    assert t.NCC_maxs[1:] == [0.0, 0.0] and t.NCC_widths[1:] == [26, 26] and t.rel_factors[1:] == [0.0, 0.0]
+    assert t.rel_factors[0] > 0.65
+    m = t.getMirrored()
+    assert m.VHD_coords == [-3, -717, 0] and m.VHD_def_coords == [0, -717, 0] and m.NCC_widths == t.NCC_widths
+    assert t.getMirrored(0).VHD_coords == [-3, 717, 0]
+    better = _displ((0, 0, 0), (0.99, 0.99, 0.99), (1, 1, 1))
+    assert t.isBetter(better) and not better.isBetter(t)
+
+
+def test_displacement_xml_round_trip_and_threshold_grid(tmp_path):
+    import xml.etree.ElementTree as ET
+    from ipp_amd import crossmips, process_images
+    recs = []
+    grid = {(0, 0, 0, 1): _displ((0, 716, 1), (0.9, 0.9, 0.9), (2, 2, 2)), (0, 0, 1, 0): _displ((715, 2, 0), (0.1, 0.1, 0.1), (25, 25, 25), default=(717, 0, 0)),
+            (0, 1, 1, 1): _displ((718, 0, 0), (0.8, 0.2, 0.2), (3, 20, 20), default=(717, 0, 0)), (1, 0, 1, 1): _displ((0, 717, 0), (0.3, 0.2, 0.1), (20, 22, 24))}
+    for (ra, ca, rb, cb), d in grid.items():
+        for k in range(3):
+            d.evalReliability(k)
+        recs.append(({"rowA": ra, "colA": ca, "rowB": rb, "colB": cb, "direction": "x"}, d))
+    process_images.write_pairs(tmp_path / "p.xml", {"step": "3"}, recs)
+    attrib, back = process_images.read_pairs(tmp_path / "p.xml")
+    assert attrib["step"] == "3" and len(back) == 4
+    for (_, d0), (_, d1) in zip(recs, back):
+        assert d0.VHD_coords == d1.VHD_coords and d0.NCC_widths == d1.NCC_widths and d0.VHD_def_coords == d1.VHD_def_coords
+        assert d1.rel_factors == d0.rel_factors and d1.NCC_maxs == pytest.approx(d0.NCC_maxs)
+    old = ET.fromstring('<Displacement TYPE="MIP_NCC"><V displ="1" default_displ="0" reliability="0.5" nccPeak="0.5" nccWidth="3"/>'
+                        '<H displ="2" default_displ="9" reliability="0.5" nccPeak="0.5" nccWidth="3"/>'
+                        '<D displ="3" default_displ="0" reliability="0.5" nccPeak="0.5" nccWidth="3"/></Displacement>')
+    d = crossmips.DisplacementMIPNCC.loadXML(old)          # records written before 2013 carry no search parameters
+    assert d.wRangeThrs == [29] * 3 and d.invWidths == [30] * 3 and d.delays == [-1] * 3
+    stacks = crossmips.threshold_displacements(grid, 2, 2, 0.65)
+    # (1,0)'s two pairs are both unreliable in every direction; (1,1) keeps the V displacement of its northern pair
+    assert stacks == {(0, 0): True, (0, 1): True, (1, 0): False, (1, 1): True}
+    assert grid[(0, 0, 1, 0)].VHD_coords == [717, 0, 0] and grid[(0, 1, 1, 1)].VHD_coords == [718, 0, 0]
+    del grid[(1, 0, 1, 1)]
+    with pytest.raises(ValueError, match="one and only displacement"):
+        crossmips.threshold_displacements(grid, 2, 2, 0.65)
