@@ -50,7 +50,9 @@ def test_lockstep_slabs_fused_pipeline_spectrum_halos(dev, flavour, world, monke
              for r in range(world)]
     assert all(s.sharded and s.ratio is None for s in slabs)
     # circular grids run the persistent x kernel, which can process the edge tiles ahead of the others (overlapped sends)
-    assert all(s.overlap == (flavour == "fft" and world > 1 or flavour == "fft") for s in slabs)
+    import os
+    if not os.environ.get("MI_FFT_NO_PIPE"):
+        assert all(s.overlap == (flavour == "fft") for s in slabs)
     got = lockstep_iterate(slabs, 4).cpu().numpy()
     if flavour == "fft":
         want = R.decon_fft(vol, psf, vol.shape, 4, skip_edgetaper=True)
