@@ -37,6 +37,8 @@ struct NativeFft {
     NativeDims dims{};
     PadWindow pw{};
     DevBuf S, T, G, G_adj, tw;
+    DevBuf Gr, Gr_adj, ph;  // real form of the OTF(s) + phase tables (symmetric PSFs), see try_real_otf
+    bool real_otf = false;
     bool have_adj = false;  // adjoint = second OTF (G_adj) instead of conj(G)
     const float2* tw_x = nullptr;
     const float2* tw_y = nullptr;
@@ -51,6 +53,9 @@ struct NativeFft {
     int init(hipStream_t s, const int F[3], bool explicit_adjoint);
     // placed: the kernel on the circular grid (real, shape F; may alias scratch()); G (or G_adj) <- scale * FFT(placed)
     int build_otf(hipStream_t s, const float* placed, bool adjoint_slot, float scale);
+    // after build_otf: switch to the real OTF form when the PSF allows it (delta: centre offset from the grid origin)
+    int try_real_otf(hipStream_t s, const int delta[3]);
+    bool z_pipelined() const;
     float* scratch() { return T.as<float>(); }  // F floats, free between convolutions
     // after the OTFs are built: volumes handed to conv / iterate have extents n (x, y, z) and are padded on the fly
     void set_window(const int n[3], const int o[3], const int rep[3], const int k[3]);
@@ -70,7 +75,7 @@ struct NativeFft {
     int x_inverse(hipStream_t s, float* out, int epi_kind, const ConvEpilogue& epi, bool fuse_forward, const TileSelect* part = nullptr);
     bool splits() const;  // the fused x pass can run a subset of its tiles
     TileSelect edge_tiles(int mode, int a0, int a1, int b0, int b1) const;
-    size_t device_bytes() const { return S.bytes + T.bytes + G.bytes + G_adj.bytes + tw.bytes; }
+    size_t device_bytes() const { return S.bytes + T.bytes + G.bytes + G_adj.bytes + Gr.bytes + Gr_adj.bytes + ph.bytes + tw.bytes; }
 };
 
 }  // namespace mi

@@ -800,9 +800,23 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_z_conv(const float2* _
 // The z pass as a persistent kernel (one work-group per CU): the OTF of the current tile is requested before the forward
 // transform and the next tile's lines before the inverse transform, both into registers, so HBM stays busy during the FFT
 // phases; stores drain behind.
-template <int LZ2, int R3>
+// REALG: the OTF of a PSF that is mirror-symmetric about its centre sample is a real function times the phase ramp of the
+// centre's offset from the grid origin: G holds the two real factors of a pair (float2 instead of float4: 4 instead of 8 B per
+// voxel of OTF traffic, a sixth of this pass) and the ramp exp(-2 pi i (kx dx/Fx + ky dy/Fy + kz dz/Fz)) is put back from three
+// small per-axis tables (x and y: scalar loads, z: one look-up per lane and tile).
+constexpr bool z_pipe_even(int L) {
+    return (kThreadsXZ % L == 0) && (L % 64 == 0) && ((z_tile_lines(L) * L) % kThreadsXZ == 0);
+}
+struct RealOtf {
+    const float2* g;     // [xk][py][pz] {Ra, Rb}
+    const float2* ph_x;  // by xk
+    const float2* ph_y;  // by ky
+    const float2* ph_z;  // by kz
+};
+
+template <int LZ2, int R3, bool REALG>
 __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_z_conv_pipe(const float2* __restrict__ S, float2* __restrict__ T, const float4* __restrict__ G,
-                                                           NativeDims d, const float2* __restrict__ tw, int conj_otf, int ntiles) {
+                                                           NativeDims d, const float2* __restrict__ tw, int conj_otf, int ntiles, RealOtf ro) {
     extern __shared__ __attribute__((aligned(16))) float2 tile[];
     constexpr int L = R3 << LZ2, NW = kThreadsXZ / 64;
     constexpr int TL = z_tile_lines(L), hp = TL / 2, pitch = row_pitch(L);
@@ -874,13 +888,28 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_z_conv_pipe(const floa
             }
         }
         }
-        const float4* Gp = G + ((size_t)w.plane * M + w.py0) * L;
-        float4 gv[NPG];
+        const size_t g0 = ((size_t)w.plane * M + w.py0) * L;
+        float4 gv[REALG ? 1 : NPG];
+        float2 gr[REALG ? NPG : 1];
+        // REALG: phase of (this tile's xk) x (this lane's kz), and of the ky of the line of every item (wave-uniform); requested
+        // here, together with the OTF, so that they have arrived long before the point-wise step
+        float2 ph_xz = make_float2(1.0f, 0.0f), ph_yk[REALG ? NPG : 1];
+        if constexpr (REALG) {
+            const int tid = launder(threadIdx.x);
+            ph_xz = cmul(ro.ph_x[w.plane], ro.ph_z[pos2freq(tid % L, LZ2, R3)]);
+            const int j0e = __builtin_amdgcn_readfirstlane(tid / L);
+#pragma unroll
+            for (int k = 0; k < NPG; ++k) ph_yk[k] = ro.ph_y[y_pos2freq(w.py0 + j0e + k * JS, d)];
+        }
         {
             const int tid = launder(threadIdx.x);
 #pragma unroll
-            for (int k = 0; k < NPG; ++k)
-                if (NG % kThreadsXZ == 0 || tid + k * kThreadsXZ < NG) gv[k] = Gp[tid + k * kThreadsXZ];
+            for (int k = 0; k < NPG; ++k) {
+                if (NG % kThreadsXZ == 0 || tid + k * kThreadsXZ < NG) {
+                    if constexpr (REALG) gr[k] = ro.g[g0 + tid + k * kThreadsXZ];
+                    else gv[k] = G[g0 + tid + k * kThreadsXZ];
+                }
+            }
         }
         lds_barrier();
         if constexpr (R3 > 1) {
@@ -920,9 +949,19 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_z_conv_pipe(const floa
                 const float2 O = make_float2(0.5f * dlt.y, -0.5f * dlt.x);  // -i/2 * (a - conj(b))
                 const float2 wO = cmul(wx, O);
                 const float2 Xa = cadd(E, wO), Xb = csub(E, wO);
-                float2 Ga = make_float2(gv[k].x, gv[k].y), Gb = make_float2(gv[k].z, gv[k].w);
-                if (conj_otf) { Ga.y = -Ga.y; Gb.y = -Gb.y; }
-                const float2 Ya = cmul(Xa, Ga), Yb = cmul(Xb, Gb);
+                float2 Ya, Yb;
+                if constexpr (REALG) {
+                    float2 P = cmul(ph_xz, ph_yk[k]);                         // (REALG requires the EVEN item layout)
+                    if (conj_otf) P.y = -P.y;
+                    const float2 XaP = cmul(Xa, P), XbP = cmul(Xb, P);
+                    Ya = make_float2(XaP.x * gr[k].x, XaP.y * gr[k].x);
+                    Yb = make_float2(XbP.x * gr[k].y, XbP.y * gr[k].y);
+                } else {
+                    float2 Ga = make_float2(gv[k].x, gv[k].y), Gb = make_float2(gv[k].z, gv[k].w);
+                    if (conj_otf) { Ga.y = -Ga.y; Gb.y = -Gb.y; }
+                    Ya = cmul(Xa, Ga);
+                    Yb = cmul(Xb, Gb);
+                }
                 const float2 E2 = make_float2(0.5f * (Ya.x + Yb.x), 0.5f * (Ya.y + Yb.y));
                 const float2 dY = csub(Ya, Yb);
                 const float2 O2 = cmulc(make_float2(0.5f * dY.x, 0.5f * dY.y), wx);
@@ -1268,6 +1307,27 @@ __global__ __launch_bounds__(256) void k_spectrum_rows(float2* __restrict__ S, f
     }
 }
 
+// Complex pair OTF -> real pair OTF: Gr = Re(G * conj(P)) with P the phase ramp of the PSF centre's offset; the largest
+// imaginary part that is dropped and the largest magnitude are returned (float bits, atomic max) for the host's decision.
+__global__ __launch_bounds__(256) void k_g_to_real(const float4* __restrict__ G, float2* __restrict__ Gr, NativeDims d, RealOtf ro,
+                                                    size_t total, unsigned* __restrict__ stats) {
+    const int M = d.ny, L = d.nz;
+    float max_im = 0.0f, max_re = 0.0f;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int pz = (int)(i % L);
+        const size_t r = i / L;
+        const int py = (int)(r % M), xk = (int)(r / M);
+        const float2 P = cmul(cmul(ro.ph_x[xk], ro.ph_y[y_pos2freq(py, d)]), ro.ph_z[pos2freq(pz, d.lz2, d.r3z)]);
+        const float4 g = G[i];
+        const float2 a = cmulc(make_float2(g.x, g.y), P), b = cmulc(make_float2(g.z, g.w), P);
+        Gr[i] = make_float2(a.x, b.x);
+        max_im = fmaxf(max_im, fmaxf(fabsf(a.y), fabsf(b.y)));
+        max_re = fmaxf(max_re, fmaxf(fabsf(a.x), fabsf(b.x)));
+    }
+    atomicMax(&stats[0], __float_as_uint(max_im));  // non-negative floats order like their bit patterns
+    atomicMax(&stats[1], __float_as_uint(max_re));
+}
+
 bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
@@ -1470,19 +1530,36 @@ int NativeFft::z_conv(hipStream_t s, bool conj_otf) {
     const NativeDims d = dims;
     const float2* Tp = T.as<float2>();
     float2* Sp = S.as<float2>();
-    const float4* Gp = (conj_otf && have_adj) ? G_adj.as<float4>() : G.as<float4>();
+    const bool adj_slot = conj_otf && have_adj;
+    const float4* Gp = adj_slot ? G_adj.as<float4>() : G.as<float4>();
     const float2* twz = tw_z;
     const int cj = (conj_otf && !have_adj) ? 1 : 0;
     int rc = MI_ERR_INVALID;
-    static const bool no_pipe = std::getenv("MI_FFT_NO_PIPE") != nullptr;
-    if (dims.dbg == 0 && !no_pipe && dims.tl == z_tile_lines(L)) {
+    if (z_pipelined()) {
         const int ntiles = (int)ztiles;
         const unsigned grid = (unsigned)std::min(ntiles, n_cu);
-#define MI_ZP(LG, R) case LG * 16 + R: rc = launch_lds(k_z_conv_pipe<LG, R>, grid, kThreadsXZ, zl, s, "k_z_conv_pipe", Tp, Sp, Gp, d, twz, cj, ntiles); break;
+        RealOtf ro{};
+        if (real_otf) {
+            ro.g = adj_slot ? Gr_adj.as<float2>() : Gr.as<float2>();
+            ro.ph_x = ph.as<float2>();
+            ro.ph_y = ro.ph_x + (Hx / 2 + 1);
+            ro.ph_z = ro.ph_y + M;
+        }
+#define MI_ZP(LG, R)                                                                                                                     \
+    case LG * 16 + R:                                                                                                                    \
+        if constexpr (z_pipe_even(R << LG)) {                                                                                            \
+            if (real_otf) {                                                                                                              \
+                rc = launch_lds(k_z_conv_pipe<LG, R, true>, grid, kThreadsXZ, zl, s, "k_z_conv_pipe<real OTF>", Tp, Sp, Gp, d, twz, cj, ntiles, ro); \
+                break;                                                                                                                   \
+            }                                                                                                                            \
+        }                                                                                                                                \
+        rc = launch_lds(k_z_conv_pipe<LG, R, false>, grid, kThreadsXZ, zl, s, "k_z_conv_pipe", Tp, Sp, Gp, d, twz, cj, ntiles, ro);      \
+        break;
         switch (dims.lz2 * 16 + dims.r3z) { MI_Z_CASES(MI_ZP) default: return fail(MI_ERR_UNSUPPORTED, "native FFT: z length %d", L); }
 #undef MI_ZP
         return rc;
     }
+    MI_REQUIRE(!real_otf, "native FFT: the real OTF form needs the pipelined z pass");
 #define MI_Z(LG, R)                                                                                                                      \
     case LG * 16 + R:                                                                                                                    \
         rc = launch_lds(k_z_conv<LG, R, false>, ztiles, kThreadsXZ, zl, s, "k_z_conv", Tp, Sp, Gp, d, twz, cj, (float4*)nullptr, 0.0f); \
@@ -1490,6 +1567,70 @@ int NativeFft::z_conv(hipStream_t s, bool conj_otf) {
     switch (dims.lz2 * 16 + dims.r3z) { MI_Z_CASES(MI_Z) default: return fail(MI_ERR_UNSUPPORTED, "native FFT: z length %d", L); }
 #undef MI_Z
     return rc;
+}
+
+bool NativeFft::z_pipelined() const {
+    static const bool no_pipe = std::getenv("MI_FFT_NO_PIPE") != nullptr;
+    return dims.dbg == 0 && !no_pipe && dims.tl == z_tile_lines(dims.nz);
+}
+
+// Tries the real form of the OTF(s): `delta` = offset (x, y, z) of the PSF's centre sample from the grid origin.  Keeps the
+// complex form when the PSF is not mirror-symmetric about that sample (the imaginary parts left after removing the phase ramp
+// exceed the rounding noise of the transform) or when the z pass of this shape cannot take it.
+int NativeFft::try_real_otf(hipStream_t s, const int delta[3]) {
+    const bool off = std::getenv("MI_FFT_COMPLEX_OTF") != nullptr;
+    const int Hx = dims.hx, M = dims.ny, L = dims.nz;
+    bool even = false;
+#define MI_EV(LG, R) case LG * 16 + R: even = z_pipe_even(R << LG); break;
+    switch (dims.lz2 * 16 + dims.r3z) { MI_Z_CASES(MI_EV) default: break; }
+#undef MI_EV
+    if (off || !z_pipelined() || !even) return MI_OK;
+    // phase tables exp(-2 pi i (k delta mod F) / F) in double on the host: x by xk <= Hx/2 (F = 2 Hx), y by ky, z by kz
+    const int nx = Hx / 2 + 1;
+    std::vector<float2> h((size_t)nx + M + L);
+    const double two_pi = 6.283185307179586476925286766559;
+    auto fill = [&](float2* dst, int n, long long F, int dl) {
+        for (int k = 0; k < n; ++k) {
+            const long long t = (((long long)k * dl) % F + F) % F;
+            dst[k] = make_float2((float)std::cos(two_pi * (double)t / (double)F), (float)-std::sin(two_pi * (double)t / (double)F));
+        }
+    };
+    fill(h.data(), nx, 2LL * Hx, delta[0]);
+    fill(h.data() + nx, M, M, delta[1]);
+    fill(h.data() + nx + M, L, L, delta[2]);
+    MI_TRY(ph.alloc(sizeof(float2) * h.size()));
+    MI_HIP(hipMemcpyAsync(ph.p, h.data(), sizeof(float2) * h.size(), hipMemcpyHostToDevice, s));
+    RealOtf ro{};
+    ro.ph_x = ph.as<float2>();
+    ro.ph_y = ro.ph_x + nx;
+    ro.ph_z = ro.ph_y + M;
+    const size_t total = (size_t)nx * M * L;
+    DevBuf st;
+    MI_TRY(st.alloc(4 * sizeof(unsigned)));
+    MI_HIP(hipMemsetAsync(st.p, 0, 4 * sizeof(unsigned), s));
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    for (int slot = 0; slot < (have_adj ? 2 : 1); ++slot) {
+        DevBuf& dst = slot ? Gr_adj : Gr;
+        MI_TRY(dst.alloc(sizeof(float2) * total));
+        hipLaunchKernelGGL(k_g_to_real, dim3((unsigned)blocks), dim3(256), 0, s, (slot ? G_adj : G).as<float4>(), dst.as<float2>(), dims, ro,
+                           total, st.as<unsigned>() + 2 * slot);
+        MI_TRY(launch_check("k_g_to_real"));
+    }
+    float hs[4] = {0, 0, 0, 0};
+    MI_HIP(hipMemcpyAsync(hs, st.p, sizeof(hs), hipMemcpyDeviceToHost, s));
+    MI_HIP(hipStreamSynchronize(s));
+    bool ok = hs[0] <= 4e-6f * hs[1] && (!have_adj || hs[2] <= 4e-6f * hs[3]);
+    if (ok) {
+        real_otf = true;
+        G.release();
+        G_adj.release();
+    } else {
+        Gr.release();
+        Gr_adj.release();
+        ph.release();
+    }
+    return MI_OK;
 }
 
 // OTF of the placed kernel volume `placed` (shape F, real; may be the T buffer itself): forward x, y and z transforms, then

@@ -271,6 +271,12 @@ int FftEngine::init(hipStream_t s, const int n[3], const int k[3], const int bnd
             MI_TRY(launch_check("k_place_psf"));
             MI_TRY(native->build_otf(s, native->scratch(), slot == 1, nscale));
         }
+        // PSFs of odd extents that are mirror-symmetric about their centre sample (every LsMakePSF PSF) have a real OTF up to the
+        // phase ramp of the centre's offset from the grid origin: sample j sits at j - shift, the centre at (k-1)/2 - shift
+        if ((ax[0].k & 1) && (ax[1].k & 1) && (ax[2].k & 1)) {
+            const int delta[3] = {(ax[0].k - 1) / 2 - ax[0].shift, (ax[1].k - 1) / 2 - ax[1].shift, (ax[2].k - 1) / 2 - ax[2].shift};
+            MI_TRY(native->try_real_otf(s, delta));
+        }
         if (padded) {  // the x passes pad and crop on the fly: no staging volume
             int nn[3], oo[3], rep[3], kk[3];
             for (int d = 0; d < 3; ++d) {

@@ -178,3 +178,39 @@ def test_replicate_padded_engine_does_not_fuse(dev, monkeypatch):
     direct = decon.RLContext((16, 40, 50), psf, None, boundary=capi.BOUNDARY_REPLICATE, engine=capi.ENGINE_DIRECT, device=dev)
     direct.iterate(want, ratio, 2)
     assert _rel(bl.cpu().numpy(), want.cpu().numpy().astype(np.float64)) < 1e-4
+
+
+@pytest.mark.parametrize("shape,flavour", [((64, 64, 128), "circular"), ((64, 64, 129), "circular_odd_x_is_rocfft"), ((40, 50, 100), "zero")])
+def test_real_otf_form_for_symmetric_psfs(dev, shape, flavour, monkeypatch):
+    """A PSF that is mirror-symmetric about its centre sample has a real OTF up to the phase ramp of its placement: the z pass
+    then reads half the OTF bytes.  Same result as the complex form; asymmetric PSFs keep the complex form."""
+    from ipp_amd import capi, decon
+    monkeypatch.setenv("MI_FFT_NATIVE_INFLATE", "100")
+    if shape[2] % 2:
+        pytest.skip("odd x extents run through rocFFT")
+    bnd = capi.BOUNDARY_CIRCULAR if flavour == "circular" else capi.BOUNDARY_ZERO
+    psf = R.gaussian_psf((7, 5, 9), (1.5, 1.0, 2.0))
+    vol = torch.from_numpy(R.bead_volume(shape, seed=3, psf=psf)).to(dev)
+
+    def run(p, complex_only):
+        if complex_only:
+            monkeypatch.setenv("MI_FFT_COMPLEX_OTF", "1")
+        else:
+            monkeypatch.delenv("MI_FFT_COMPLEX_OTF", raising=False)
+        ctx = decon.RLContext(shape, p, None, boundary=bnd, engine=capi.ENGINE_FFT, device=dev)
+        bl = vol.clone()
+        ctx.iterate(bl, None, 3)
+        return bl.cpu().numpy(), ctx.device_bytes
+
+    got_r, bytes_r = run(psf, False)
+    got_c, bytes_c = run(psf, True)
+    assert _rel(got_r, got_c.astype(np.float64)) < 2e-6
+    assert bytes_r < bytes_c                      # the real form stores 8 instead of 16 bytes per OTF pair
+    skew = psf.copy()
+    skew[0, 0, 0] *= 3.0                           # not symmetric any more: complex form, same memory as the forced one
+    skew /= skew.sum()
+    _, bytes_s = run(skew, False)
+    assert bytes_s == bytes_c
+    want = (R.decon_fft(vol.cpu().numpy(), psf, shape, 3, skip_edgetaper=True) if flavour == "circular"
+            else R.decon_spatial(vol.cpu().numpy(), psf, 3, skip_edgetaper=True))
+    assert _rel(got_r, want) < 1e-4
