@@ -200,7 +200,7 @@ def main():
                 t_update = ctx.time_pass("x_fused_update", bl, reps=5)  # overwrites bl: the timed region is over
                 times["x_fused"] = 0.5 * (t_ratio + t_update)
                 dom = max(times, key=lambda k: times[k] * per_iter[k])
-                algo_b = {"z_conv": 12, "y_forward": 8, "y_inverse": 8, "x_fused": 14}[dom]  # B per voxel per launch
+                algo_b = {"z_conv": 10 if ctx.otf_is_real else 12, "y_forward": 8, "y_inverse": 8, "x_fused": 14}[dom]  # B/voxel/launch
                 ach = algo_b * local_vox / (times[dom] * 1e-3) / 1e9
                 roofline = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(dom, args.workload),

@@ -66,6 +66,7 @@ SIGNATURES = {
     "mi_subtract_dark": (_i, [_i, _vp, _vp, _vp, _sz, _f]),
     "mi_norm2": (_i, [_i, _vp, _vp, _sz, C.POINTER(C.c_double)]),
     "mi_rl_fuses": (_i, [_vp]),
+    "mi_rl_otf_is_real": (_i, [_vp]),
     "mi_rl_sharded_begin": (_i, [_vp, _vp, _vp]),
     "mi_rl_sharded_ratio": (_i, [_vp, _vp, _vp, _i, C.POINTER(C.c_int)]),
     "mi_rl_sharded_update": (_i, [_vp, _vp, _vp, _i, _i, C.POINTER(C.c_int)]),

@@ -198,6 +198,10 @@ extern "C" int mi_rl_fuses(mi_rl_ctx* ctx) {
     return ctx->fft->native->splits() ? 2 : 1;
 }
 
+extern "C" int mi_rl_otf_is_real(mi_rl_ctx* ctx) {
+    return ctx && ctx->engine == MI_ENGINE_FFT && ctx->fft->native && ctx->fft->native->real_otf ? 1 : 0;
+}
+
 extern "C" int mi_rl_sharded_begin(mi_rl_ctx* ctx, void* stream, const float* bl) {
     NativeFft* nf = nullptr;
     MI_TRY(sharded_native(ctx, &nf));

@@ -311,6 +311,10 @@ class RLContext:
         """0: no fused iteration; 1: fused; 2: fused, and the x pass can be split around the halo sends (``part``)."""
         return int(lib().mi_rl_fuses(self._h))
 
+    @property
+    def otf_is_real(self) -> bool:
+        return bool(lib().mi_rl_otf_is_real(self._h))
+
     def sharded_begin(self, bl):
         self._chk(bl)
         check(lib().mi_rl_sharded_begin(self._h, _stream(bl), bl.data_ptr()))

@@ -133,6 +133,9 @@ int mi_rl_iterate(mi_rl_ctx* ctx, void* stream, float* bl, float* ratio, int n_i
  * and only the x tiles that hold rows of edge_rows = {a0, a1, b0, b1} ([a0,a1) and [b0,b1): the rows about to be sent); part 2 =
  * the remaining x tiles (launch it after the sends have been issued). */
 int mi_rl_fuses(mi_rl_ctx* ctx);
+/* 1 when the context keeps its OTF in the real form (PSF mirror-symmetric about its centre sample: 2 floats per spectrum pair
+ * plus per-axis phase tables instead of 4 floats; the z pass then moves 10 instead of 12 bytes per voxel). */
+int mi_rl_otf_is_real(mi_rl_ctx* ctx);
 int mi_rl_sharded_begin(mi_rl_ctx* ctx, void* stream, const float* bl);
 int mi_rl_sharded_ratio(mi_rl_ctx* ctx, void* stream, const float* bl, int part, const int* edge_rows);
 int mi_rl_sharded_update(mi_rl_ctx* ctx, void* stream, float* bl, int more, int part, const int* edge_rows);
