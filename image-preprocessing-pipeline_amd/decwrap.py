@@ -151,23 +151,45 @@ def main(argv=None):
              f"pad ({block.x_pad} {block.y_pad} {block.z_pad}), fft_shape {block.fft_shape}")
     out = np.zeros(vol.shape, np.float32)
     pad = (block.x_pad, block.y_pad, block.z_pad)
-    lo, hi = np.inf, -np.inf
-    for n, (p1, p2) in enumerate(zip(block.p1, block.p2), start=1):
-        if n < args.start_block:
-            continue
-        g = args.gpu_indices[(n - 1) % len(args.gpu_indices)]                             # blocks are independent
-        bl = L.load_block(vol, p1, p2, pad)
-        fshape = None
-        if args.use_fft:
-            smooth, native = L.next_fast_len(bl.shape[::-1]), L.native_fft_shape(bl.shape[::-1])
-            fshape = native if np.prod(native) <= 1.3 * np.prod(smooth) else smooth
-        blk = L.Block(block.x, block.y, block.z, block.nx, block.ny, block.nz, *pad, fft_shape=fshape)
-        t, lb, ub = L.process_block(bl, blk, psf_struct, args.numit, args.lambda_damping, args.stop_criterion, filt,
-                                    args.clipval, g)
-        lo, hi = min(lo, lb), max(hi, ub)
-        core = t[pad[2]:t.shape[0] - pad[2] or None, pad[1]:t.shape[1] - pad[1] or None, pad[0]:t.shape[2] - pad[0] or None]
-        out[p1[2] - 1:p2[2], p1[1] - 1:p2[1], p1[0] - 1:p2[0]] = core.cpu().numpy()        # strip pads, LsDeconv.m:750-752
-        log.info(f"block {n}/{len(block.p1)} done on GPU {g}: stats [{lb:.4g}, {ub:.4g}]")
+    # One worker per entry of the device list (--gpu-indices x --gpu-workers-per-gpu, like the reference's pool of parfeval
+    # workers, LsDeconv.m:620-668): blocks are independent, a worker takes the next unprocessed block, runs it on its device
+    # and on its own stream, and writes the core of the result into the output volume.
+    import threading
+    from concurrent.futures import ThreadPoolExecutor
+    workers = [g for g in args.gpu_indices for _ in range(max(1, args.gpu_workers_per_gpu))]
+    todo = [(n, p1, p2) for n, (p1, p2) in enumerate(zip(block.p1, block.p2), start=1) if n >= args.start_block]
+    lock = threading.Lock()
+    stats = []
+
+    def run(worker_id):
+        g = workers[worker_id]
+        stream = torch.cuda.Stream(device=g - 1)
+        while True:
+            with lock:
+                if not todo:
+                    return
+                n, p1, p2 = todo.pop(0)
+            bl = L.load_block(vol, p1, p2, pad)
+            fshape = None
+            if args.use_fft:
+                smooth, native = L.next_fast_len(bl.shape[::-1]), L.native_fft_shape(bl.shape[::-1])
+                fshape = native if np.prod(native) <= 1.3 * np.prod(smooth) else smooth
+            blk = L.Block(block.x, block.y, block.z, block.nx, block.ny, block.nz, *pad, fft_shape=fshape)
+            with torch.cuda.device(g - 1), torch.cuda.stream(stream):
+                t, lb, ub = L.process_block(bl, blk, psf_struct, args.numit, args.lambda_damping, args.stop_criterion, filt,
+                                            args.clipval, g)
+                core = t[pad[2]:t.shape[0] - pad[2] or None, pad[1]:t.shape[1] - pad[1] or None, pad[0]:t.shape[2] - pad[0] or None]
+                core = core.cpu().numpy()                                                  # strip pads, LsDeconv.m:750-752
+            out[p1[2] - 1:p2[2], p1[1] - 1:p2[1], p1[0] - 1:p2[0]] = core                  # disjoint boxes: no lock needed
+            with lock:
+                stats.append((lb, ub))
+            log.info(f"block {n}/{len(block.p1)} done on GPU {g}: stats [{lb:.4g}, {ub:.4g}]")
+
+    with ThreadPoolExecutor(max_workers=len(workers)) as pool:
+        for f in [pool.submit(run, w) for w in range(len(workers))]:
+            f.result()                                                                     # re-raises a worker's exception
+    lo = min((s[0] for s in stats), default=np.inf)
+    hi = max((s[1] for s in stats), default=-np.inf)
     np.save(out_dir / "deconvolved.npy", out)
     # postprocess_save (LsDeconv.m:996-1024, 1091-1093): rawmax from the input class, target scale, rescale every slab with the
     # clip range [deconvmin, deconvmax] collected over the blocks

@@ -110,3 +110,23 @@ def test_process_images_steps_3_and_4(dev, tmp_path):
             assert rel >= 0.65 or (rel == 0.0 and e.get("displ") == e.get("default_displ") and float(e.get("nccPeak")) == 0.0)
     # exact copies of one bead field: the in-plane offsets are reliable, every stack is stitchable
     assert all(s.get("stitchable") == "yes" for s in root.findall("Stack"))
+
+
+def test_decwrap_block_parallel_workers_equal_sequential(dev, tmp_path):
+    """Several blocks, two workers on one device (--gpu-workers-per-gpu 2: own streams, shared output volume) against one
+    worker: identical stacks -- the blocks are independent (LsDeconv.m:620-668)."""
+    from ipp_amd import decwrap
+    rng = np.random.default_rng(11)
+    vol16 = (rng.random((24, 40, 44)) * 3000 + 200).astype(np.uint16)
+    outs = []
+    for k, workers in enumerate((1, 2)):
+        d = tmp_path / f"w{workers}"
+        d.mkdir()
+        np.save(d / "vol.npy", vol16)
+        rc = decwrap.main(["-i", str(d / "vol.npy"), "-dxy", "0.422", "-dz", "1.0", "-ex", "488", "-em", "525", "-it", "3",
+                           "--gaussian-sigma", "0", "0", "0", "--block-size-max", "60000", "--gpu-indices", "1",
+                           "--gpu-workers-per-gpu", str(workers)])
+        assert rc == 0
+        outs.append((np.load(d / "deconvolved" / "deconvolved.npy"), np.load(d / "deconvolved" / "deconvolved_16bit.npy")))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    assert float(np.abs(outs[0][0]).max()) > 0
