@@ -28,8 +28,8 @@ struct mi_rl_ctx {
 };
 
 extern "C" int mi_engine_select(int nx, int ny, int nz, int kx, int ky, int kz, int boundary) {
-    // direct: 2*K flop per voxel at ~60 TFLOP/s sustained fp32.  FFT, per padded voxel and convolution (measured):
-    // ~15 ps through the hand-written pipeline (12 ps unpadded), ~30 ps through rocFFT.
+    // direct: 2*K flop per voxel at ~60 TFLOP/s sustained fp32.  FFT, per grid point and convolution (measured):
+    // ~9.5 ps through the hand-written pipeline on a padded grid (8.2 ps on a circular one), ~29 ps through rocFFT.
     const double K = (double)kx * ky * kz;
     const double N = (double)nx * ny * nz;
     const int n[3] = {nx, ny, nz}, k[3] = {kx, ky, kz}, bnd[3] = {boundary, boundary, boundary};
@@ -42,7 +42,7 @@ extern "C" int mi_engine_select(int nx, int ny, int nz, int kx, int ky, int kz, 
     const bool native = choose_fft_lengths(need, bnd, F);
     const double Nf = (double)F[0] * F[1] * F[2];
     const double t_direct = N * 2.0 * K / 60e12;
-    const double t_fft = Nf * (native ? (boundary == MI_BOUNDARY_CIRCULAR ? 12e-12 : 15e-12) : 30e-12) + 60e-6;
+    const double t_fft = Nf * (native ? (boundary == MI_BOUNDARY_CIRCULAR ? 8.2e-12 : 9.5e-12) : 29e-12) + 60e-6;
     // without an explicit adjoint kernel the flipped PSF is conj(OTF), which needs centred odd extents off the circular rule
     const bool odd = (kx & 1) && (ky & 1) && (kz & 1);
     return ((odd || boundary == MI_BOUNDARY_CIRCULAR) && t_fft < t_direct) ? MI_ENGINE_FFT : MI_ENGINE_DIRECT;
