@@ -65,6 +65,8 @@ SIGNATURES = {
     "mi_u16_to_f32": (_i, [_i, _vp, _vp, _vp, _sz, _f]),
     "mi_subtract_dark": (_i, [_i, _vp, _vp, _vp, _sz, _f]),
     "mi_norm2": (_i, [_i, _vp, _vp, _sz, C.POINTER(C.c_double)]),
+    "mi_release_cached_memory": (_sz, [_i]),
+    "mi_cached_memory_bytes": (_sz, []),
     "mi_rl_fuses": (_i, [_vp]),
     "mi_rl_otf_is_real": (_i, [_vp]),
     "mi_rl_sharded_begin": (_i, [_vp, _vp, _vp]),
@@ -141,6 +143,11 @@ def require_gpu() -> None:
     if n <= 0:
         raise RuntimeError(f"no HIP device available (mi_device_count() = {n}: {last_error()}); "
                            "the MI355X path has no CPU fallback")
+
+
+def release_cached_memory(device=None) -> int:
+    """Gives the device memory the library keeps for reuse back to the driver (``mi_release_cached_memory``); returns bytes."""
+    return int(lib().mi_release_cached_memory(-1 if device is None else int(device)))
 
 
 def current_stream_ptr(device) -> int:

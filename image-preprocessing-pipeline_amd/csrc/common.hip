@@ -1,5 +1,8 @@
 // Error sink, device queries and the element-wise / data-movement kernels of the RL path.
 // All of these are pure HBM streaming kernels: 16 B per lane, grid-stride, >= 4 waves per SIMD.
+#include <map>
+#include <mutex>
+
 #include "mi_internal.h"
 #include "mi_lsdeconv.h"
 
@@ -37,6 +40,100 @@ extern "C" int mi_next_fast_len(int n) {
             while (m % p == 0) m /= p;
         if (m == 1) return n;
     }
+}
+
+// ------------------------------------------------------------------------------------------------ device memory pool
+namespace mi {
+namespace {
+struct Pool {
+    std::mutex mu;
+    std::multimap<std::pair<int, size_t>, void*> free_blocks;  // (device, bytes) -> block
+    size_t cached_bytes = 0;
+    bool enabled = std::getenv("MI_NO_MEMORY_POOL") == nullptr;
+    // every cached block of one device (or of all, dev < 0) goes back to the driver; returns the bytes released
+    size_t trim(int dev) {
+        size_t freed = 0;
+        for (auto it = free_blocks.begin(); it != free_blocks.end();) {
+            if (dev < 0 || it->first.first == dev) {
+                (void)hipFree(it->second);
+                freed += it->first.second;
+                it = free_blocks.erase(it);
+            } else {
+                ++it;
+            }
+        }
+        cached_bytes -= freed;
+        return freed;
+    }
+};
+Pool& pool() {
+    static Pool* p = new Pool;  // never destroyed: blocks may be released during static destruction of other objects
+    return *p;
+}
+}  // namespace
+
+int pool_alloc(size_t n, void** out) {
+    int dev = 0;
+    MI_HIP(hipGetDevice(&dev));
+    Pool& P = pool();
+    if (P.enabled) {
+        std::lock_guard<std::mutex> g(P.mu);
+        auto it = P.free_blocks.find({dev, n});
+        if (it != P.free_blocks.end()) {
+            *out = it->second;
+            P.cached_bytes -= n;
+            P.free_blocks.erase(it);
+            return MI_OK;
+        }
+    }
+    hipError_t e = hipMalloc(out, n);
+    if (e != hipSuccess && P.enabled) {  // give the cached blocks back and try once more
+        (void)hipGetLastError();
+        std::lock_guard<std::mutex> g(P.mu);
+        if (P.trim(dev) > 0) e = hipMalloc(out, n);
+    }
+    if (e != hipSuccess) {
+        *out = nullptr;
+        (void)hipGetLastError();
+        return fail(MI_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", n, hipGetErrorString(e));
+    }
+    return MI_OK;
+}
+
+void pool_free(void* p, size_t n) {
+    if (!p) return;
+    Pool& P = pool();
+    if (!P.enabled || n < (size_t)(1 << 20)) {  // small blocks are cheap to allocate: straight back to the driver
+        (void)hipFree(p);
+        return;
+    }
+    // hipFree waits for the device before it releases memory; a cached block may be handed out to another stream, so the same
+    // guarantee is kept here
+    int cur = 0, dev = 0;
+    (void)hipGetDevice(&cur);
+    dev = cur;
+    hipPointerAttribute_t attr{};
+    if (hipPointerGetAttributes(&attr, p) == hipSuccess) dev = attr.device;
+    if (dev != cur) (void)hipSetDevice(dev);
+    (void)hipDeviceSynchronize();
+    if (dev != cur) (void)hipSetDevice(cur);
+    std::lock_guard<std::mutex> g(P.mu);
+    P.free_blocks.insert({{dev, n}, p});
+    P.cached_bytes += n;
+}
+
+}  // namespace mi
+
+extern "C" size_t mi_release_cached_memory(int dev) {
+    mi::Pool& P = mi::pool();
+    std::lock_guard<std::mutex> g(P.mu);
+    return P.trim(dev);
+}
+
+extern "C" size_t mi_cached_memory_bytes(void) {
+    mi::Pool& P = mi::pool();
+    std::lock_guard<std::mutex> g(P.mu);
+    return P.cached_bytes;
 }
 
 // ------------------------------------------------------------------------------------------------

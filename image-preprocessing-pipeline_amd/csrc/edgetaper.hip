@@ -75,16 +75,22 @@ int edgetaper_async(hipStream_t s, float* bl, float* work, const float* psf, int
     std::vector<float> host(tot);
     for (int d = 0; d < 3; ++d) std::copy(taper[d].begin(), taper[d].end(), host.begin() + off[d]);
     MI_HIP(hipMemcpyAsync(dtaper.p, host.data(), sizeof(float) * tot, hipMemcpyHostToDevice, s));
-    // blur = conv3d_gpu(bl, psf / sum): direct engine on the shell tiles, or -- when even the shell is too expensive
-    // (C4-sized PSFs) -- one FFT convolution of the replicate-padded volume (same result within fp32 rounding)
-    double shell = 1.0, nf = 1.0;
+    // blur = conv3d_gpu(bl, psf / sum): direct engine on the shell tiles only, or one FFT convolution of the replicate-padded
+    // volume (same result within fp32 rounding).  Measured on C3 (31x31x61 PSF): 980 ms on the shell, 73 ms through the
+    // hand-written FFT pipeline incl. building its OTF (24 ps per grid point), 2.8 s through rocFFT incl. plan creation.
+    double shell = 1.0;
+    int need[3], F[3];
+    const int bnd_rep[3] = {MI_BOUNDARY_REPLICATE, MI_BOUNDARY_REPLICATE, MI_BOUNDARY_REPLICATE};
     for (int d = 0; d < 3; ++d) {
         shell *= (double)std::max(0, epi.plat_hi[d] - epi.plat_lo[d]) / n[d];
-        nf *= mi_next_fast_len(n[d] + k[d] - 1);
+        need[d] = n[d] + k[d] - 1;
     }
+    const bool native_grid = choose_fft_lengths(need, bnd_rep, F);
+    const double nf = (double)F[0] * F[1] * F[2];
     shell = 1.0 - shell;
     const double taps = (double)kx * ky * kz, nvox = (double)nx * ny * nz;
-    const double t_direct = shell * nvox * 2.0 * taps / 50e12, t_fft = nf * 220.0 / 4e12 + 2.5;  // + rocFFT plan creation for a one-off shape (measured: 2.8 s vs 0.96 s direct on C3)
+    const double t_direct = shell * nvox * 2.0 * taps / 50e12;
+    const double t_fft = native_grid ? nf * 25e-12 + 0.02 : nf * 220.0 / 4e12 + 2.5;
     const bool odd = (kx & 1) && (ky & 1) && (kz & 1);
     bool use_fft = odd && t_fft < t_direct;
     if (const char* f = std::getenv("MI_EDGETAPER_ENGINE")) use_fft = odd && f[0] == 'f';  // tests / experiments: "fft" | "direct"

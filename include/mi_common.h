@@ -6,8 +6,9 @@
  * `stream` unless their comment says "synchronises".  Every function returns MI_OK (0) or a
  * negative mi_status and never calls exit()/abort(); the message of the last failure on the calling
  * thread is returned by mi_last_error().  The library is re-entrant per (device, stream): it keeps
- * no static device buffers (contrast compute_funcs.cu:621-629 of the reference); FFT plans are
- * cached per device under a mutex.
+ * no static device buffers bound to a call (contrast compute_funcs.cu:621-629 of the reference); FFT
+ * plans are cached per device under a mutex; scratch memory that a call releases is kept in a per-device
+ * pool and reused by the next request of the same size (see mi_release_cached_memory).
  *
  * Array convention: volumes are C-order (Z, Y, X) with X fastest == MATLAB [X,Y,Z] column-major
  * (conv3d_gpu.cu:93,98) == TeraStitcher (k, i, j) slice/row/column (CrossMIPs.h:109).  Dimensions
@@ -40,6 +41,12 @@ int mi_device_count(void);
 int mi_abi_version(void);
 /* blocks until `stream` has drained (hipStreamSynchronize) */
 int mi_stream_synchronize(int dev, void* stream);
+/* The library keeps the device memory its calls release (>= 1 MiB blocks) and reuses it for later requests of the same size:
+ * a per-block pipeline (edge taper, RL context, ...) otherwise pays hipMalloc/hipFree of tens of GB per stage.  Cached blocks are
+ * given back automatically when an allocation fails; mi_release_cached_memory returns them to the driver now (dev < 0: all
+ * devices) and reports the bytes released; MI_NO_MEMORY_POOL=1 in the environment disables the pool. */
+size_t mi_release_cached_memory(int dev);
+size_t mi_cached_memory_bytes(void);
 
 #ifdef __cplusplus
 }

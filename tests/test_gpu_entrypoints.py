@@ -130,3 +130,26 @@ def test_decwrap_block_parallel_workers_equal_sequential(dev, tmp_path):
         outs.append((np.load(d / "deconvolved" / "deconvolved.npy"), np.load(d / "deconvolved" / "deconvolved_16bit.npy")))
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
     assert float(np.abs(outs[0][0]).max()) > 0
+
+
+def test_device_memory_pool_reuses_and_releases(dev):
+    """Scratch memory a call releases stays in the library's per-device pool and is handed out again; it goes back to the driver
+    on request (mi_release_cached_memory)."""
+    from ipp_amd import capi, decon
+    capi.release_cached_memory()
+    assert capi.lib().mi_cached_memory_bytes() == 0
+    psf = R.gaussian_psf((5, 5, 5), (1.0, 1.0, 1.0))
+    shape = (64, 128, 128)
+    ctx = decon.RLContext(shape, psf, None, boundary=capi.BOUNDARY_CIRCULAR, engine=capi.ENGINE_FFT, device=dev)
+    held = ctx.device_bytes
+    assert held > 3 * 4 * 64 * 128 * 128
+    ctx.close()
+    cached = capi.lib().mi_cached_memory_bytes()
+    assert cached >= held // 2                        # the big buffers are kept (blocks under 1 MiB are not)
+    ctx2 = decon.RLContext(shape, psf, None, boundary=capi.BOUNDARY_CIRCULAR, engine=capi.ENGINE_FFT, device=dev)
+    assert capi.lib().mi_cached_memory_bytes() < cached  # ... and reused by the next context of that shape
+    bl = torch.rand(shape, device=dev) + 0.5
+    ctx2.iterate(bl, None, 2)
+    assert bool(torch.isfinite(bl).all())
+    ctx2.close()
+    assert capi.release_cached_memory() >= cached and capi.lib().mi_cached_memory_bytes() == 0
