@@ -164,6 +164,7 @@ def main(argv=None):
     def run(worker_id):
         g = workers[worker_id]
         stream = torch.cuda.Stream(device=g - 1)
+        staging = {}  # pinned host buffers by core shape: D2H at PCIe rate instead of page-faulting a fresh pageable array
         while True:
             with lock:
                 if not todo:
@@ -179,7 +180,13 @@ def main(argv=None):
                 t, lb, ub = L.process_block(bl, blk, psf_struct, args.numit, args.lambda_damping, args.stop_criterion, filt,
                                             args.clipval, g)
                 core = t[pad[2]:t.shape[0] - pad[2] or None, pad[1]:t.shape[1] - pad[1] or None, pad[0]:t.shape[2] - pad[0] or None]
-                core = core.cpu().numpy()                                                  # strip pads, LsDeconv.m:750-752
+                core = core.contiguous()                                                   # strip pads, LsDeconv.m:750-752
+                if tuple(core.shape) not in staging:
+                    staging[tuple(core.shape)] = torch.empty(core.shape, dtype=torch.float32, pin_memory=True)
+                host = staging[tuple(core.shape)]
+                host.copy_(core, non_blocking=True)
+                stream.synchronize()
+                core = host.numpy()
             out[p1[2] - 1:p2[2], p1[1] - 1:p2[1], p1[0] - 1:p2[0]] = core                  # disjoint boxes: no lock needed
             with lock:
                 stats.append((lb, ub))

@@ -4,6 +4,7 @@ import xml.etree.ElementTree as ET
 
 import numpy as np
 import pytest
+import torch
 
 from oracle import ncc_oracle as N
 from oracle import rl_oracle as R
@@ -142,7 +143,7 @@ def test_device_memory_pool_reuses_and_releases(dev):
     shape = (64, 128, 128)
     ctx = decon.RLContext(shape, psf, None, boundary=capi.BOUNDARY_CIRCULAR, engine=capi.ENGINE_FFT, device=dev)
     held = ctx.device_bytes
-    assert held > 3 * 4 * 64 * 128 * 128
+    assert held > 2 * 4 * 64 * 128 * 128          # the two spectrum buffers at least
     ctx.close()
     cached = capi.lib().mi_cached_memory_bytes()
     assert cached >= held // 2                        # the big buffers are kept (blocks under 1 MiB are not)
