@@ -328,12 +328,13 @@ int rl_iterate(mi_rl_ctx* ctx, hipStream_t s, float* bl, float* ratio, float* re
         int span = 1;
         if (reg_time) {
             MI_TRY(gauss3d_async(s, bl, ratio, nx, ny, nz, sig, o.gauss_taps == 3 ? k3 : nullptr));  // decon.m:57-59
-            MI_TRY(mi_rl_forward_ratio(ctx, s, bl, ratio));
             if (o.lambda > 0.0f) {
+                MI_TRY(mi_rl_forward_ratio(ctx, s, bl, ratio));
                 MI_TRY(mi_rl_reg_term(ctx->dev, s, bl, reg, nx, ny, nz));
                 MI_TRY(mi_rl_adjoint_update(ctx, s, ratio, bl, o.lambda, reg));
             } else {
-                MI_TRY(mi_rl_adjoint_update(ctx, s, ratio, bl, 0.0f, nullptr));
+                // without the Tikhonov term the smoothed estimate simply goes through a plain iteration (fused on the native pipeline)
+                MI_TRY(mi_rl_iterate(ctx, s, bl, ratio, 1));
             }
         } else {
             // run of plain iterations up to the next regularisation step: one call, so an engine that can fuse
