@@ -40,7 +40,7 @@ def test_circular_conv_native_vs_scipy_and_rocfft(dev, shape):
 
 
 @pytest.mark.parametrize("shape", [(16, 32, 64), (32, 16, 128), (8, 64, 32), (8, 288, 32), (16, 96, 16), (96, 32, 192), (8, 96, 576)])
-@pytest.mark.parametrize("niter,lam,interval", [(4, 0.0, 0), (6, 0.05, 2)])
+@pytest.mark.parametrize("niter,lam,interval", [(4, 0.0, 0), (6, 0.05, 2), (7, 0.0, 3)])
 def test_decon_fft_native_matches_oracle(dev, shape, niter, lam, interval):
     from ipp_amd import decon
     psf = R.gaussian_psf((5, 7, 5), (1.0, 1.5, 1.0))
