@@ -826,6 +826,11 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_z_conv_pipe(const floa
     constexpr int NPG = (NG + kThreadsXZ - 1) / kThreadsXZ;
     constexpr int P = kThreadsXZ / hp;                           // transposed view: item k of a lane is position z0 + k * P
     constexpr bool PRIV = ((2 * TL) % NW) == 0;
+    // WP: with one A line and one B line per wave, the B lines are stored so that LDS row TL + j holds the MIRROR PARTNER of A
+    // line j -- both rows of a pair then belong to wave j and the point-wise step needs no work-group barrier either: forward
+    // transforms, point-wise product and inverse transforms of a pair run back to back inside its wave (3 barriers per tile
+    // instead of 5, all of them around the transposed fill and drain)
+    constexpr bool WP = PRIV && TL == NW && (L % 64 == 0) && (NG % kThreadsXZ == 0) && (NA % kThreadsXZ == 0);
     // point-wise view: item k of a lane is element pz0 of line j0 + k * JS when the lines divide the work-group evenly
     constexpr bool EVEN = (kThreadsXZ % L == 0) && (L % 64 == 0) && (NG % kThreadsXZ == 0) && ((kThreadsXZ / L) % 2 == 0 || kThreadsXZ == L);
     constexpr int JS = kThreadsXZ / (L > 0 ? L : 1);
@@ -833,11 +838,24 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_z_conv_pipe(const floa
     const int ytiles = M / TL, rowq = M / 2;
     // lane constants (tile-invariant; recomputed per phase from a laundered thread index so that they do not occupy registers
     // across the FFT phases): the swizzle is XOR-linear, so item k's slot is item 0's slot XOR a constant
-    struct FView { int row, slot, z0; size_t off; };  // transposed view: item k = position z0 + k * P, line pair jp
+    struct FView { int row, slot, z0, jp, pz; size_t off; };  // transposed view: item k = position z0 + k * P, line pair jp
     auto f_view = [&]() {
         const int tid = launder(threadIdx.x);
         const int z0 = tid / hp, jp = tid - z0 * hp;
-        return FView{(2 * jp) * pitch, phys(z0) ^ rmask(2 * jp, hp), z0, (size_t)z0 * rowq + jp};
+        const int pz = phys(z0);
+        return FView{(2 * jp) * pitch, pz ^ rmask(2 * jp, hp), z0, jp, pz, (size_t)z0 * rowq + jp};
+    };
+    // WP: A line index (0..TL-1) whose mirror partner is B line jb, 4 bits each (wave-uniform, recomputed per tile)
+    auto partner_table = [&](const auto& w) {
+        unsigned long long tab = 0;
+        for (int jb = 0; jb < TL; ++jb) tab |= (unsigned long long)((y_mirror_pos(w.pyB0 + jb, d) - w.py0) & 15) << (4 * jb);
+        return tab;
+    };
+    // WP: LDS cells of the B lines (2 jp, 2 jp + 1) at position slot `pzs` (unmasked)
+    auto b_cells = [&](unsigned long long tab, int jp, int pzs, int& c0, int& c1) {
+        const int r0 = TL + (int)((tab >> (8 * jp)) & 15), r1 = TL + (int)((tab >> (8 * jp + 4)) & 15);
+        c0 = r0 * pitch + (pzs ^ rmask(r0, hp));
+        c1 = r1 * pitch + (pzs ^ rmask(r1, hp));
     };
     float4 preA[NPA], preB[NPA];
     struct Where { int plane, py0, px, pxB, pyB0; };
@@ -875,16 +893,20 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_z_conv_pipe(const floa
     if (t < ntiles) load_S(t);
     for (; t < ntiles; t += gridDim.x) {
         const Where w = where(t);
+        unsigned long long ptab = 0;
+        if constexpr (WP) ptab = partner_table(w);
         {
         const FView fv = f_view();
 #pragma unroll
         for (int k = 0; k < NPA; ++k) {
             if (NA % kThreadsXZ == 0 || (int)threadIdx.x + k * kThreadsXZ < NA) {
-                const int cA = fv.row + (fv.slot ^ swz_c(k * P)), cB = cA + TL * pitch;  // rows TL + 2 jp carry the same mask
+                const int cA = fv.row + (fv.slot ^ swz_c(k * P));
+                int cB0 = cA + TL * pitch, cB1 = cB0 + pitch;  // rows TL + 2 jp (+1) carry the same mask
+                if constexpr (WP) b_cells(ptab, fv.jp, fv.pz ^ swz_c(k * P), cB0, cB1);
                 tile[cA] = make_float2(preA[k].x, preA[k].y);
                 tile[cA + pitch] = make_float2(preA[k].z, preA[k].w);
-                tile[cB] = make_float2(preB[k].x, preB[k].y);
-                tile[cB + pitch] = make_float2(preB[k].z, preB[k].w);
+                tile[cB0] = make_float2(preB[k].x, preB[k].y);
+                tile[cB1] = make_float2(preB[k].z, preB[k].w);
             }
         }
         }
@@ -893,21 +915,30 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_z_conv_pipe(const floa
         float2 gr[REALG ? NPG : 1];
         // REALG: phase of (this tile's xk) x (this lane's kz), and of the ky of the line of every item (wave-uniform); requested
         // here, together with the OTF, so that they have arrived long before the point-wise step
+        // (WP: item k of a lane is position lane + 64 k of its wave's line: one ky per wave, one kz per item)
         float2 ph_xz = make_float2(1.0f, 0.0f), ph_yk[REALG ? NPG : 1];
         if constexpr (REALG) {
             const int tid = launder(threadIdx.x);
-            ph_xz = cmul(ro.ph_x[w.plane], ro.ph_z[pos2freq(tid % L, LZ2, R3)]);
-            const int j0e = __builtin_amdgcn_readfirstlane(tid / L);
+            if constexpr (WP) {
+                ph_xz = cmul(ro.ph_x[w.plane], ro.ph_y[y_pos2freq(w.py0 + __builtin_amdgcn_readfirstlane(tid >> 6), d)]);
 #pragma unroll
-            for (int k = 0; k < NPG; ++k) ph_yk[k] = ro.ph_y[y_pos2freq(w.py0 + j0e + k * JS, d)];
+                for (int k = 0; k < NPG; ++k) ph_yk[k] = ro.ph_z[pos2freq((tid & 63) + 64 * k, LZ2, R3)];
+            } else {
+                ph_xz = cmul(ro.ph_x[w.plane], ro.ph_z[pos2freq(tid % L, LZ2, R3)]);
+                const int j0e = __builtin_amdgcn_readfirstlane(tid / L);
+#pragma unroll
+                for (int k = 0; k < NPG; ++k) ph_yk[k] = ro.ph_y[y_pos2freq(w.py0 + j0e + k * JS, d)];
+            }
         }
         {
             const int tid = launder(threadIdx.x);
+            // WP: the OTF entries of line `wave`, positions lane + 64 k
+            const size_t gl = WP ? g0 + (size_t)(tid >> 6) * L + (tid & 63) : g0 + tid;
 #pragma unroll
             for (int k = 0; k < NPG; ++k) {
                 if (NG % kThreadsXZ == 0 || tid + k * kThreadsXZ < NG) {
-                    if constexpr (REALG) gr[k] = ro.g[g0 + tid + k * kThreadsXZ];
-                    else gv[k] = G[g0 + tid + k * kThreadsXZ];
+                    if constexpr (REALG) gr[k] = ro.g[gl + (WP ? 64 : kThreadsXZ) * k];
+                    else gv[k] = G[gl + (WP ? 64 : kThreadsXZ) * k];
                 }
             }
         }
@@ -917,19 +948,23 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_z_conv_pipe(const floa
             stage_sync(PRIV);
         }
         lds_fft<LZ2, false, kThreadsXZ, R3>(tile, 2 * TL * R3, pitch, hp, PRIV, twl);
-        if (PRIV) lds_barrier();  // the point-wise step pairs rows of different owners
+        if (PRIV && !WP) lds_barrier();  // the point-wise step pairs rows of different owners
         float sw, cw;
         sincospif(-2.0f * (float)w.plane / (float)(2 * Hx), &sw, &cw);  // exp(-2 pi i xk / Nx), Nx = 2 Hx
         const float2 wx = make_float2(cw, sw);
         const int tid = launder(threadIdx.x);
         const int pz0 = tid % L, j0 = __builtin_amdgcn_readfirstlane(tid / L);
-        const int pA = phys(pz0), pB = phys(mirror_pos(pz0, L, LZ2, R3));
+        const int pA = phys(WP ? (tid & 63) : pz0), pB = phys(mirror_pos(pz0, L, LZ2, R3));
+        const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
 #pragma unroll
         for (int k = 0; k < NPG; ++k) {
             const int i = tid + k * kThreadsXZ;
             if (NG % kThreadsXZ == 0 || i < NG) {
                 int cA, cB;
-                if (EVEN) {
+                if constexpr (WP) {  // lines A[wave] and its partner in row TL + wave, position lane + 64 k
+                    cA = wv * pitch + (pA ^ swz_c(64 * k) ^ rmask(wv, hp));
+                    cB = (TL + wv) * pitch + (phys(mirror_pos((tid & 63) + 64 * k, L, LZ2, R3)) ^ rmask(TL + wv, hp));
+                } else if (EVEN) {
                     const int j = j0 + k * JS;                                // scalar: the line is shared by the wave
                     const int jB = y_mirror_pos(w.py0 + j, d) - w.pyB0;       // scalar mirror math
                     cA = j * pitch + (pA ^ rmask(j, hp));
@@ -971,7 +1006,8 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_z_conv_pipe(const floa
         }
         const int tn = t + gridDim.x;
         if (tn < ntiles) load_S(tn);
-        lds_barrier();
+        if (WP) wave_lds_fence();
+        else lds_barrier();
         lds_fft<LZ2, true, kThreadsXZ, R3>(tile, 2 * TL * R3, pitch, hp, PRIV, twl);
         if constexpr (R3 > 1) {
             radix3_stage<R3, true, kThreadsXZ>(tile, 2 * TL, pitch, hp, PRIV, 1 << LZ2, twl + TW::r3);
@@ -986,11 +1022,13 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_z_conv_pipe(const floa
         for (int k = 0; k < NPA; ++k) {
             const int zk = fv.z0 + k * P;
             if ((NA % kThreadsXZ == 0 || (int)threadIdx.x + k * kThreadsXZ < NA) && zk >= d.z_out_lo && zk < d.z_out_hi) {
-                const int cA = fv.row + (fv.slot ^ swz_c(k * P)), cB = cA + TL * pitch;
+                const int cA = fv.row + (fv.slot ^ swz_c(k * P));
+                int cB0 = cA + TL * pitch, cB1 = cB0 + pitch;
+                if constexpr (WP) b_cells(ptab, fv.jp, fv.pz ^ swz_c(k * P), cB0, cB1);
                 const float2 a0 = tile[cA], a1 = tile[cA + pitch];
                 dA[(size_t)(k * P) * rowq] = make_float4(a0.x, a0.y, a1.x, a1.y);
                 if (!self_plane) {
-                    const float2 b0 = tile[cB], b1 = tile[cB + pitch];
+                    const float2 b0 = tile[cB0], b1 = tile[cB1];
                     dB[(size_t)(k * P) * rowq] = make_float4(b0.x, b0.y, b1.x, b1.y);
                 }
             }
