@@ -184,22 +184,32 @@ __host__ __device__ constexpr int seg_below(int logn, int top) {
 // LDS twiddle tables: every super-stage with S_LO > 0 owns a packed table of 2^S_LO entries, exp(-2 pi i m / 2^(S_LO+LR))
 // (stride-1 look-ups: no bank conflicts, and no vector-memory loads inside the FFT phases -- those would drain the prefetch
 // queue, vmcnt being in order); the tables lie one after the other, bottom-up.  tw_off: offset of the table of stage s.
+// Powers kept per lane-twiddle index: all R - 1 of them while the table stays small (stage <= 6), else only the first (the
+// others are derived by multiplications).
+__host__ __device__ constexpr int tw_powers(int s, int r) { return s <= 6 ? (1 << r) - 1 : 1; }
 __host__ __device__ constexpr int tw_off(int logn, int s) {
     int off = 0, t = 0;
     while (t < s) {
-        if (t > 0) off += 1 << t;
+        if (t > 0) off += tw_powers(t, seg_r(logn, t)) << t;
         t += seg_r(logn, t);
     }
     return off;
 }
 __host__ __device__ constexpr int chain_entries(int logn) { return tw_off(logn, logn); }
-// gather the tables from the global table tw[e] = exp(-2 pi i e / 2^LOGN), e < 2^(LOGN-1)
+// gather the tables from the global table tw[e] = exp(-2 pi i e / 2^LOGN), e < 2^(LOGN-1): entry [p - 1][m] of the super-stage
+// at S is exp(-2 pi i m p / 2^(S+r)), the p-th power of the lane twiddle of group element m
 template <int LOGN, int NT, int S = 0>
 __device__ __forceinline__ void fill_chain_tw(float2* twl, const float2* __restrict__ tw) {
     if constexpr (S < LOGN) {
         constexpr int r = seg_r(LOGN, S);
         if constexpr (S > 0) {
-            for (int m = threadIdx.x; m < (1 << S); m += NT) twl[tw_off(LOGN, S) + m] = tw[m << (LOGN - S - r)];
+            constexpr int np = tw_powers(S, r);
+            for (int i = threadIdx.x; i < (np << S); i += NT) {
+                const int p = (i >> S) + 1, m = i & ((1 << S) - 1);
+                const int e = (m * p) << (LOGN - S - r);  // < 2^LOGN
+                const float2 t = tw[e & ((1 << (LOGN - 1)) - 1)];
+                twl[tw_off(LOGN, S) + i] = (e >> (LOGN - 1)) ? make_float2(-t.x, -t.y) : t;  // exp(-i(x + pi)) = -exp(-ix)
+            }
         }
         fill_chain_tw<LOGN, NT, S + r>(twl, tw);
     }
@@ -286,43 +296,65 @@ struct SeqMap {
     }
 };
 
-// The LR radix-2 stages of a super-stage on the R = 2^LR points of one lane.  wf = exp(-2 pi i m / 2^(S_LO+LR)) is the lane's
-// finest twiddle (unused when S_LO == 0); the twiddle of a butterfly factors into a power of it (LR - 1 squarings) and a
-// per-register constant.
+// multiplication by exp(-2 pi i k16 / 16) (forward) or its conjugate (inverse): compile-time constants; -i / +i are swaps
+template <bool CONJ>
+__device__ __forceinline__ float2 mul_c16(float2 a, int k16) {
+    if (k16 == 0) return a;
+    if (k16 == 4) return CONJ ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x);
+    const float2 c = make_float2(c16(k16), CONJ ? s16(k16) : -s16(k16));
+    return cmul(a, c);
+}
+__host__ __device__ constexpr int bit_rev(int j, int bits) {
+    int r = 0;
+    for (int b = 0; b < bits; ++b) r |= ((j >> b) & 1) << (bits - 1 - b);
+    return r;
+}
+
+// The LR radix-2 stages of a super-stage on the R = 2^LR points of one lane, as one radix-R butterfly: the stages only carry
+// their compile-time constants exp(-2 pi i jl / 2^(bpos+1)); the lane-dependent part of all twiddles on the path of register j
+// collapses to ONE factor w^rev(j), w = exp(-2 pi i m / 2^(S_LO+LR)), applied after the stages (forward, DIF) or, conjugated,
+// before them (inverse, DIT) -- R - 1 complex products instead of LR * R / 2.  twl: the super-stage's table, [p - 1][m] = w^p
+// for the tw_powers() powers it keeps (unused when S_LO == 0).
 template <int LR, int S_LO, bool INVERSE>
-__device__ __forceinline__ void butterflies(float2 (&v)[1 << LR], float2 wf) {
-    constexpr int R = 1 << LR;
-    float2 wst[LR];
-    if (S_LO > 0) {
-        wst[LR - 1] = wf;
+__device__ __forceinline__ void butterflies(float2 (&v)[1 << LR], const float2* twl, int m) {
+    constexpr int R = 1 << LR, NP = tw_powers(S_LO, LR);
+    float2 w[R];
+    if constexpr (S_LO > 0) {
+        if constexpr (NP == R - 1) {
 #pragma unroll
-        for (int b = LR - 2; b >= 0; --b) wst[b] = cmul(wst[b + 1], wst[b + 1]);
+            for (int p = 1; p < R; ++p) w[p] = twl[((p - 1) << S_LO) + m];
+        } else {
+            w[1] = twl[m];
+#pragma unroll
+            for (int p = 2; p < R; ++p) w[p] = (p & 1) ? cmul(w[p - 1], w[1]) : cmul(w[p / 2], w[p / 2]);
+        }
+        if constexpr (INVERSE) {
+#pragma unroll
+            for (int j = 1; j < R; ++j) v[j] = cmulc(v[j], w[bit_rev(j, LR)]);
+        }
     }
 #pragma unroll
     for (int step = 0; step < LR; ++step) {
         const int bpos = INVERSE ? step : LR - 1 - step;  // local bit handled by this radix-2 stage
-        float2 wb = make_float2(1.0f, 0.0f);
-        if (S_LO > 0) wb = wst[bpos];
 #pragma unroll
         for (int j = 0; j < R; ++j) {
             if (j & (1 << bpos)) continue;
             const int jl = j & ((1 << bpos) - 1);
             const int k16 = jl * (8 >> bpos);  // jl / 2^(bpos+1) turns = k16 / 16
-            float2 w;
-            if (S_LO == 0) w = make_float2(c16(k16), -s16(k16));
-            else if (jl == 0) w = wb;
-            else w = cmul(wb, make_float2(c16(k16), -s16(k16)));
             const float2 a = v[j], c = v[j | (1 << bpos)];
             if (INVERSE) {
-                const float2 t = (S_LO == 0 && jl == 0) ? c : cmulc(c, w);
+                const float2 t = mul_c16<true>(c, k16);
                 v[j] = cadd(a, t);
                 v[j | (1 << bpos)] = csub(a, t);
             } else {
                 v[j] = cadd(a, c);
-                const float2 dd = csub(a, c);
-                v[j | (1 << bpos)] = (S_LO == 0 && jl == 0) ? dd : cmul(dd, w);
+                v[j | (1 << bpos)] = mul_c16<false>(csub(a, c), k16);
             }
         }
+    }
+    if constexpr (S_LO > 0 && !INVERSE) {
+#pragma unroll
+        for (int j = 1; j < R; ++j) v[j] = cmul(v[j], w[bit_rev(j, LR)]);
     }
 }
 
@@ -333,7 +365,7 @@ __host__ __device__ constexpr int group_elem(int g) { return ((g >> S_LO) << (S_
 
 // One super-stage, everything about the transform compile-time: R = 2^LR points per lane, radix-2 stages
 // S_LO+LR-1..S_LO (forward, DIF) or S_LO..S_LO+LR-1 (inverse, DIT) on the sequences of the tile.
-// twl[m] = exp(-2 pi i m / 2^(S_LO+LR)), m < 2^S_LO (LDS).
+// twl: the super-stage's LDS table of lane twiddles and their powers (see butterflies).
 template <int LOGN, int LR, int S_LO, bool INVERSE, int NT, int R3>
 __device__ __forceinline__ void super_stage(float2* tile, int batch, int pitch, int hp, bool priv, const float2* twl) {
     constexpr int R = 1 << LR, H_LO = 1 << S_LO, GL = LOGN - LR, NW = NT / 64;
@@ -362,9 +394,7 @@ __device__ __forceinline__ void super_stage(float2* tile, int batch, int pitch, 
                 float2 v[R];
 #pragma unroll
                 for (int j = 0; j < R; ++j) v[j] = H_LO >= 256 ? row[a0 + j * H_LO] : row[a0 ^ swz_c(j << S_LO)];
-                float2 wf = make_float2(1.0f, 0.0f);
-                if (S_LO > 0) wf = twl[m_lane | (gk & (H_LO - 1))];
-                butterflies<LR, S_LO, INVERSE>(v, wf);
+                butterflies<LR, S_LO, INVERSE>(v, twl, m_lane | (gk & (H_LO - 1)));
 #pragma unroll
                 for (int j = 0; j < R; ++j) {
                     if (H_LO >= 256) row[a0 + j * H_LO] = v[j];
@@ -388,9 +418,7 @@ __device__ __forceinline__ void super_stage(float2* tile, int batch, int pitch, 
         float2 v[R];
 #pragma unroll
         for (int j = 0; j < R; ++j) v[j] = H_LO >= 256 ? row[a0 + j * H_LO] : row[a0 ^ swz_c(j << S_LO)];
-        float2 wf = make_float2(1.0f, 0.0f);
-        if (S_LO > 0) wf = twl[m];
-        butterflies<LR, S_LO, INVERSE>(v, wf);
+        butterflies<LR, S_LO, INVERSE>(v, twl, m);
 #pragma unroll
         for (int j = 0; j < R; ++j) {
             if (H_LO >= 256) row[a0 + j * H_LO] = v[j];
