@@ -47,7 +47,7 @@ constexpr int kThreadsY = 512;    // contiguous pass: two work-groups per CU
 // with columns (15, 13, 25, 16) for bits 4..7: with it every butterfly pattern of the super-stage chains below ((0,3), (3,3),
 // (3,2), (3,1) and all S_LO >= 5), the stride-2 row accesses and -- together with rmask -- the transposed tile accesses are
 // conflict-free under both rules.  (An additive pad of one slot per 32 leaves 2- and 4-way conflicts on the stages with
-// 0 < S_LO < 5: 43 % of the LDS cycles of the x pass were conflict cycles, profiles/r01_sq_counters.txt.)
+// 0 < S_LO < 5: 43 % of the LDS cycles of the x pass were conflict cycles, profiles/r01_sq_counters_padded_layout.txt.)
 __host__ __device__ constexpr int swz_g(int t) { return ((t & 1) ? 15 : 0) ^ ((t & 2) ? 13 : 0) ^ ((t & 4) ? 25 : 0) ^ ((t & 8) ? 16 : 0); }
 __host__ __device__ constexpr int swz_c(int i) { return i ^ swz_g((i >> 4) & 15); }
 __host__ __device__ constexpr unsigned long long swz_table_hi() {  // G restricted to bits 5..7, 8 entries of 5 bits
