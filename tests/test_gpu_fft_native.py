@@ -214,3 +214,44 @@ def test_real_otf_form_for_symmetric_psfs(dev, shape, flavour, monkeypatch):
     want = (R.decon_fft(vol.cpu().numpy(), psf, shape, 3, skip_edgetaper=True) if flavour == "circular"
             else R.decon_spatial(vol.cpu().numpy(), psf, 3, skip_edgetaper=True))
     assert _rel(got_r, want) < 1e-4
+
+
+def _random_cases(n=14, seed=2026):
+    rng = np.random.default_rng(seed)
+    sizes = [8, 16, 32, 64, 96, 128, 192, 288]          # native extents: 2^a and 3 * / 9 * 2^a
+    out = []
+    for i in range(n):
+        circular = bool(rng.integers(0, 2))
+        if circular:
+            shape = tuple(int(rng.choice(sizes[:6])) for _ in range(3))
+        else:
+            shape = tuple(int(rng.integers(9, 90)) for _ in range(3))
+        # (extent-1 axes only off the circular rule: deconFFT's even-shape placement puts a 1-sample PSF at index -1, which the
+        # context rejects as a shift outside the PSF)
+        k = tuple(int(rng.choice([3, 5, 7] if circular else [1, 3, 5, 7])) for _ in range(3))
+        k = tuple(min(kk, s) for kk, s in zip(k, shape))
+        out.append((shape, k, 2 if circular else int(rng.integers(0, 2)), bool(rng.integers(0, 2)), i))
+    return out
+
+
+@pytest.mark.parametrize("shape,kshape,boundary,symmetric,seed", _random_cases())
+def test_random_shapes_fft_engine_equals_direct_engine(dev, shape, kshape, boundary, symmetric, seed, monkeypatch):
+    """Seeded sweep over shapes, PSF extents, boundary rules and (a)symmetric PSFs: three RL iterations on the FFT engine (native
+    grids incl. radix-3/9 axes, tiny transforms, padded + pruned grids, real and complex OTF forms) against the direct engine."""
+    from ipp_amd import capi, decon
+    monkeypatch.setenv("MI_FFT_NATIVE_INFLATE", "100")
+    rng = np.random.default_rng(100 + seed)
+    if symmetric:
+        psf = R.gaussian_psf(kshape, (1.0, 1.3, 0.8))
+    else:
+        psf = rng.random(kshape, dtype=np.float32) + 0.05
+        psf /= psf.sum()
+    psf_inv = np.ascontiguousarray(psf[::-1, ::-1, ::-1]) if boundary != 2 else None
+    vol = torch.from_numpy(rng.random(shape, dtype=np.float32) + 0.2).to(dev)
+    fft = decon.RLContext(shape, psf, psf_inv, boundary=boundary, engine=capi.ENGINE_FFT, device=dev)
+    direct = decon.RLContext(shape, psf, psf_inv, boundary=boundary, engine=capi.ENGINE_DIRECT, device=dev)
+    a, b = vol.clone(), vol.clone()
+    ratio = torch.empty_like(vol)
+    fft.iterate(a, ratio, 3)
+    direct.iterate(b, ratio, 3)
+    assert _rel(a.cpu().numpy(), b.cpu().numpy().astype(np.float64)) < 1e-4
