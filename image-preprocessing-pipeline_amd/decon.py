@@ -47,7 +47,10 @@ def _device(device_id=None) -> torch.device:
 def _to_dev(x, device, dtype=torch.float32, name="array"):
     """Returns (tensor_on_device, was_numpy)."""
     if isinstance(x, np.ndarray):
-        t = torch.from_numpy(np.ascontiguousarray(x)).to(device=device, dtype=dtype)
+        a = np.ascontiguousarray(x)
+        if any(st < 0 for st in a.strides):  # flipped axes of extent 1 keep their negative stride through ascontiguousarray
+            a = a.copy(order="C")
+        t = torch.from_numpy(a).to(device=device, dtype=dtype)
         return t, True
     if not isinstance(x, torch.Tensor):
         raise TypeError(f"{name} must be a torch tensor or numpy array")
