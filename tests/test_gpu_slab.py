@@ -37,6 +37,24 @@ def test_lockstep_slabs_on_gpu(dev, flavour, engine, world):
     assert _rel(got, want) < 1e-4 and _rel(got, single) < 2e-5
 
 
+@pytest.mark.parametrize("gshape,kshape,world", [((16, 200, 64), (3, 9, 5), 3), ((32, 96, 32), (5, 5, 7), 2), ((16, 330, 32), (7, 11, 3), 5)])
+@pytest.mark.parametrize("flavour", ["fft", "spatial"])
+def test_lockstep_slabs_uneven_rows_fused_pipeline(dev, gshape, kshape, world, flavour, monkeypatch):
+    """Uneven slabs (the last rank takes the remainder), odd global extents on y, different halo widths: every rank rounds its
+    local extent to a native one on its own; spectrum halos, overlapped split of the x pass where the context allows it."""
+    from ipp_amd import slab
+    monkeypatch.setenv("MI_FFT_NATIVE_INFLATE", "100")
+    psf = R.gaussian_psf(kshape, (1.0, 1.5, 1.0))
+    vol = R.bead_volume(gshape, seed=sum(gshape), psf=psf)
+    slabs = [slab.SlabRL(vol.shape, psf, rank=r, world_size=world, device=dev, flavour=flavour, engine=2, volume=vol)
+             for r in range(world)]
+    assert all(s.sharded for s in slabs) and sum(s.n_loc for s in slabs) == gshape[1]
+    got = lockstep_iterate(slabs, 3).cpu().numpy()
+    want = (R.decon_fft(vol, psf, vol.shape, 3, skip_edgetaper=True) if flavour == "fft"
+            else R.decon_spatial(vol, psf, 3, skip_edgetaper=True))
+    assert _rel(got, want) < 1e-4
+
+
 @pytest.mark.parametrize("flavour", ["fft", "spatial"])
 @pytest.mark.parametrize("world", [1, 2, 4])
 def test_lockstep_slabs_fused_pipeline_spectrum_halos(dev, flavour, world, monkeypatch):
