@@ -73,7 +73,8 @@ struct NativeFft {
     int y_pass(hipStream_t s, bool inverse);
     int z_conv(hipStream_t s, bool conj_otf);
     int x_inverse(hipStream_t s, float* out, int epi_kind, const ConvEpilogue& epi, bool fuse_forward, const TileSelect* part = nullptr);
-    bool splits() const;  // the fused x pass can run a subset of its tiles
+    bool pipe_ok() const;  // the fused x pass can run as the persistent pipelined kernel
+    bool splits() const;   // ... and a subset of its tiles (unpadded grids)
     TileSelect edge_tiles(int mode, int a0, int a1, int b0, int b1) const;
     size_t device_bytes() const { return S.bytes + T.bytes + G.bytes + G_adj.bytes + Gr.bytes + Gr_adj.bytes + ph.bytes + tw.bytes; }
 };

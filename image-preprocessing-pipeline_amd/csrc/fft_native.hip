@@ -470,12 +470,11 @@ __device__ __forceinline__ void radix3_stage(float2* tile, int cols, int pitch, 
         const int c = PRIV ? cl * NW + wave : cl;
         float2* row = tile + c * pitch;
         float2 v[R3];
-        int slot[R3];
-        const int rm = rmask(c, hp);
+        // slot of element q * msub + n2: n2 < msub and the multiples of msub occupy disjoint bits and the swizzle is XOR-linear,
+        // so it is the slot of n2 XOR a constant (no per-q address registers)
+        const int s0 = phys(n2) ^ rmask(c, hp);
 #pragma unroll
-        for (int q = 0; q < R3; ++q) slot[q] = phys(q * msub + n2) ^ rm;
-#pragma unroll
-        for (int q = 0; q < R3; ++q) v[q] = row[slot[q]];
+        for (int q = 0; q < R3; ++q) v[q] = row[s0 ^ swz_c(q * msub)];
         float2 wq[R3];  // wq[q] = w1^q, by squaring / one multiplication from lower powers (depth <= 3)
         wq[1] = tw3[n2];
 #pragma unroll
@@ -535,7 +534,7 @@ __device__ __forceinline__ void radix3_stage(float2* tile, int cols, int pitch, 
             for (int q = 1; q < R3; ++q) v[q] = cmul(v[q], wq[q]);
         }
 #pragma unroll
-        for (int q = 0; q < R3; ++q) row[slot[q]] = v[q];
+        for (int q = 0; q < R3; ++q) row[s0 ^ swz_c(q * msub)] = v[q];
     }
 }
 
@@ -941,40 +940,44 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_z_conv_pipe(const floa
         const size_t g0 = ((size_t)w.plane * M + w.py0) * L;
         float4 gv[REALG ? 1 : NPG];
         float2 gr[REALG ? NPG : 1];
-        // REALG: phase of (this tile's xk) x (this lane's kz), and of the ky of the line of every item (wave-uniform); requested
-        // here, together with the OTF, so that they have arrived long before the point-wise step
-        // (WP: item k of a lane is position lane + 64 k of its wave's line: one ky per wave, one kz per item)
         float2 ph_xz = make_float2(1.0f, 0.0f), ph_yk[REALG ? NPG : 1];
-        if constexpr (REALG) {
-            const int tid = launder(threadIdx.x);
-            if constexpr (WP) {
-                ph_xz = cmul(ro.ph_x[w.plane], ro.ph_y[y_pos2freq(w.py0 + __builtin_amdgcn_readfirstlane(tid >> 6), d)]);
-#pragma unroll
-                for (int k = 0; k < NPG; ++k) ph_yk[k] = ro.ph_z[pos2freq((tid & 63) + 64 * k, LZ2, R3)];
-            } else {
-                ph_xz = cmul(ro.ph_x[w.plane], ro.ph_z[pos2freq(tid % L, LZ2, R3)]);
-                const int j0e = __builtin_amdgcn_readfirstlane(tid / L);
-#pragma unroll
-                for (int k = 0; k < NPG; ++k) ph_yk[k] = ro.ph_y[y_pos2freq(w.py0 + j0e + k * JS, d)];
-            }
-        }
-        {
-            const int tid = launder(threadIdx.x);
-            // WP: the OTF entries of line `wave`, positions lane + 64 k
-            const size_t gl = WP ? g0 + (size_t)(tid >> 6) * L + (tid & 63) : g0 + tid;
-#pragma unroll
-            for (int k = 0; k < NPG; ++k) {
-                if (NG % kThreadsXZ == 0 || tid + k * kThreadsXZ < NG) {
-                    if constexpr (REALG) gr[k] = ro.g[gl + (WP ? 64 : kThreadsXZ) * k];
-                    else gv[k] = G[gl + (WP ? 64 : kThreadsXZ) * k];
+        auto load_G = [&]() {
+            // REALG: phase of (this tile's xk) x (this lane's kz), and of the ky of the line of every item (wave-uniform); requested
+            // here, together with the OTF, so that they have arrived long before the point-wise step
+            // (WP: item k of a lane is position lane + 64 k of its wave's line: one ky per wave, one kz per item)
+            if constexpr (REALG) {
+                const int tid = launder(threadIdx.x);
+                if constexpr (WP) {
+                    ph_xz = cmul(ro.ph_x[w.plane], ro.ph_y[y_pos2freq(w.py0 + __builtin_amdgcn_readfirstlane(tid >> 6), d)]);
+    #pragma unroll
+                    for (int k = 0; k < NPG; ++k) ph_yk[k] = ro.ph_z[pos2freq((tid & 63) + 64 * k, LZ2, R3)];
+                } else {
+                    ph_xz = cmul(ro.ph_x[w.plane], ro.ph_z[pos2freq(tid % L, LZ2, R3)]);
+                    const int j0e = __builtin_amdgcn_readfirstlane(tid / L);
+    #pragma unroll
+                    for (int k = 0; k < NPG; ++k) ph_yk[k] = ro.ph_y[y_pos2freq(w.py0 + j0e + k * JS, d)];
                 }
             }
-        }
+            {
+                const int tid = launder(threadIdx.x);
+                // WP: the OTF entries of line `wave`, positions lane + 64 k
+                const size_t gl = WP ? g0 + (size_t)(tid >> 6) * L + (tid & 63) : g0 + tid;
+    #pragma unroll
+                for (int k = 0; k < NPG; ++k) {
+                    if (NG % kThreadsXZ == 0 || tid + k * kThreadsXZ < NG) {
+                        if constexpr (REALG) gr[k] = ro.g[gl + (WP ? 64 : kThreadsXZ) * k];
+                        else gv[k] = G[gl + (WP ? 64 : kThreadsXZ) * k];
+                    }
+                }
+            }
+        };
+        if (R3 != 9) load_G();  // (radix-9 lines: requested behind the 9-point stage, which needs the registers)
         lds_barrier();
         if constexpr (R3 > 1) {
             radix3_stage<R3, false, kThreadsXZ>(tile, 2 * TL, pitch, hp, PRIV, 1 << LZ2, twl + TW::r3);
             stage_sync(PRIV);
         }
+        if (R3 == 9) load_G();
         lds_fft<LZ2, false, kThreadsXZ, R3>(tile, 2 * TL * R3, pitch, hp, PRIV, twl);
         if (PRIV && !WP) lds_barrier();  // the point-wise step pairs rows of different owners
         float sw, cw;
@@ -1033,7 +1036,7 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_z_conv_pipe(const floa
             }
         }
         const int tn = t + gridDim.x;
-        if (tn < ntiles) load_S(tn);
+        if (R3 != 9 && tn < ntiles) load_S(tn);
         if (WP) wave_lds_fence();
         else lds_barrier();
         lds_fft<LZ2, true, kThreadsXZ, R3>(tile, 2 * TL * R3, pitch, hp, PRIV, twl);
@@ -1041,6 +1044,7 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_z_conv_pipe(const floa
             radix3_stage<R3, true, kThreadsXZ>(tile, 2 * TL, pitch, hp, PRIV, 1 << LZ2, twl + TW::r3);
             stage_sync(PRIV);
         }
+        if (R3 == 9 && tn < ntiles) load_S(tn);
         if (PRIV) lds_barrier();
         const bool self_plane = (w.px == w.pxB);
         const FView fv = f_view();
@@ -1213,7 +1217,7 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_x_inverse(const float2
 template <int LHX2, int R3>
 __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_x_fused_pipe(const float2* __restrict__ T, float* __restrict__ out, ConvEpilogue e, NativeDims d,
                                                             const float2* __restrict__ tw, float2* __restrict__ S_next, int EPI, int ntiles,
-                                                            TileSelect sel) {
+                                                            TileSelect sel, PadWindow pw) {
     extern __shared__ __attribute__((aligned(16))) float2 tile[];
     constexpr int Hx = R3 << LHX2, NW = kThreadsXZ / 64;
     constexpr int TY = x_tile_rows(Hx), hp = TY / 2, quads = Hx / 2;
@@ -1243,23 +1247,41 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_x_fused_pipe(const flo
         const int tid = launder(threadIdx.x);
         return RView{tid, tid & 63, phys(2 * (tid & 63))};
     };
-    auto r_item = [&](const RView& rv, int j, int& i, int& c) {
+    auto r_item = [&](const RView& rv, int j, int& i, int& c, int& r, int& q) {
         if (PRIV) {
             const int rl = (64 * j) / quads, q0 = (64 * j) % quads;  // compile-time after unrolling
-            const int r = rl * NW + wave;                              // scalar
-            i = r * quads + q0 + rv.lane;
+            r = rl * NW + wave;                                        // scalar
+            q = q0 + rv.lane;
+            i = r * quads + q;
             c = r * pitch + (rv.slot ^ swz_c(2 * q0) ^ rmask(r, hp));
         } else {
             i = rv.tid + j * kThreadsXZ;
-            const int r = i / quads, q = i - r * quads;
+            r = i / quads;
+            q = i - r * quads;
             c = cell(r, pitch, hp, 2 * q);
         }
     };
+    // Padded grids (zero rule, data at the origin, nx a multiple of 4): row r of a tile is row y0 + r of the caller's volume when
+    // that is < ny, its quads q < nx / 4 hold data; everything else is padding (epilogue result 0).  Only the live tiles are
+    // enumerated (mode 3); the tiles of live planes that lie entirely in the y padding are zero-filled first.
+    const int data_quads = pw.on ? pw.n[0] / 4 : quads;
+    if (pw.on) {
+        const int nty = sel.n0, nzl = pw.n[2];
+        for (int u = blockIdx.x; u < d.z_in_hi * ytiles; u += gridDim.x) {  // every tile the next y pass reads ...
+            const int z = u / ytiles, ty = u - z * ytiles;
+            if (z < nzl && ty < nty) continue;                               // ... that the loop below does not produce
+            float4* sdst = reinterpret_cast<float4*>(S_next + ((size_t)z * Hx) * d.ny + ty * TY);
+            for (int i = threadIdx.x; i < hp * Hx; i += kThreadsXZ) {
+                const int px = i / hp, rp = i - px * hp;
+                sdst[(size_t)px * rowq + rp] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+        }
+    }
     float4 pre[NPF];
     // tile number -> (z, first row): all y tiles of a plane, or only / all but the tiles of two row ranges (the slab driver
     // sends the edge rows off while the rest of the pass runs)
     auto tile_zy = [&](int t, int& z, int& y0) {
-        const int per = sel.mode == 0 ? ytiles : (sel.mode == 1 ? sel.n0 + sel.n1 : ytiles - sel.n0 - sel.n1);
+        const int per = sel.mode == 0 ? ytiles : (sel.mode == 1 ? sel.n0 + sel.n1 : sel.mode == 3 ? sel.n0 : ytiles - sel.n0 - sel.n1);
         z = t / per;
         int ty = t - z * per;
         if (sel.mode == 1) {
@@ -1298,50 +1320,64 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_x_fused_pipe(const flo
         // rows of this tile in the real volume: contiguous TY * 2 Hx floats
         int z, y0;
         tile_zy(t, z, y0);
-        const size_t row0 = ((size_t)z * d.ny + y0) * (size_t)(2 * Hx);
-        const float4* a4 = reinterpret_cast<const float4*>(e.a + row0);
+        // float4 index of (row r, quad q) of this tile in the caller's volume: rows are 2 Hx floats apart, or nx on a padded grid
+        const size_t row0 = pw.on ? ((size_t)z * pw.n[1] + y0) * (size_t)data_quads : ((size_t)z * d.ny + y0) * (size_t)quads;
+        const int rows_live = pw.on ? pw.n[1] - y0 : TY;  // rows of the tile that exist in the caller's volume
+        auto g_index = [&](int i, int r, int q) { return pw.on ? row0 + (size_t)r * data_quads + q : row0 + i; };
+        const float4* a4 = reinterpret_cast<const float4*>(e.a);
         float4 av[NPF];
-        {
-            const RView rv = r_view();
-#pragma unroll
-            for (int j = 0; j < NPF; ++j) {
-                int i, c;
-                r_item(rv, j, i, c);
-                if (NQ % kThreadsXZ == 0 || i < NQ) av[j] = a4[i];
+        auto load_a = [&]() {
+            {
+                const RView rv = r_view();
+    #pragma unroll
+                for (int j = 0; j < NPF; ++j) {
+                    int i, c, r, q;
+                    r_item(rv, j, i, c, r, q);
+                    if (NQ % kThreadsXZ == 0 || i < NQ) {
+                        const bool live = r < rows_live && q < data_quads;
+                        av[j] = live ? a4[g_index(i, r, q)] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    }
+                }
             }
-        }
+        };
+        if (R3 != 9) load_a();  // (radix-9 rows: requested behind the 9-point stage, which needs the registers)
         lds_barrier();
         lds_fft<LHX2, true, kThreadsXZ, R3>(tile, TY * R3, pitch, hp, PRIV, twl);
         if constexpr (R3 > 1) {
             radix3_stage<R3, true, kThreadsXZ>(tile, TY, pitch, hp, PRIV, 1 << LHX2, twl + TW::r3);
             stage_sync(PRIV);
         }
-        float4* dst = reinterpret_cast<float4*>(out + row0);
+        if (R3 == 9) load_a();
+        float4* dst = reinterpret_cast<float4*>(out);
         const RView rv = r_view();
 #pragma unroll
         for (int j = 0; j < NPF; ++j) {
-            int i, s0;
-            r_item(rv, j, i, s0);  // elements 2q and 2q + 1 are slot neighbours
+            int i, s0, r, q;
+            r_item(rv, j, i, s0, r, q);  // elements 2q and 2q + 1 are slot neighbours
             if (NQ % kThreadsXZ == 0 || i < NQ) {
                 const float2 c0 = tile[s0], c1 = tile[s0 ^ 1];
                 const float4 a = av[j];
+                const bool live = r < rows_live && q < data_quads;
                 float4 o;
                 if (EPI == EPI_RATIO)
                     o = make_float4(a.x * rcp_eps(c0.x), a.y * rcp_eps(c0.y), a.z * rcp_eps(c1.x), a.w * rcp_eps(c1.y));
                 else
                     o = make_float4(fabsf(a.x * c0.x), fabsf(a.y * c0.y), fabsf(a.z * c1.x), fabsf(a.w * c1.y));
-                if (out != nullptr) dst[i] = o;
+                if (!live) o = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // the zero padding of the next convolution's input
+                if (out != nullptr && live) dst[g_index(i, r, q)] = o;
                 tile[s0] = make_float2(o.x, o.y);
                 tile[s0 ^ 1] = make_float2(o.z, o.w);
             }
         }
+        // (radix-9 rows: the 9-point stage needs the registers, so the next tile is requested behind it)
         const int tn = t + gridDim.x;
-        if (tn < ntiles) load_T(tn);
+        if (R3 != 9 && tn < ntiles) load_T(tn);
         stage_sync(PRIV);
         if constexpr (R3 > 1) {
             radix3_stage<R3, false, kThreadsXZ>(tile, TY, pitch, hp, PRIV, 1 << LHX2, twl + TW::r3);
             stage_sync(PRIV);
         }
+        if (R3 == 9 && tn < ntiles) load_T(tn);
         lds_fft<LHX2, false, kThreadsXZ, R3>(tile, TY * R3, pitch, hp, PRIV, twl);
         if (PRIV) lds_barrier();  // rows complete for everybody before the transposed drain
         const TView tv = t_view();
@@ -1538,10 +1574,11 @@ void NativeFft::set_window(const int n[3], const int o[3], const int rep[3], con
 bool NativeFft::can_fuse() const { return !pw.on || !(pw.rep[0] || pw.rep[1] || pw.rep[2]); }
 
 // the fused x pass runs as the persistent pipelined kernel, which can also process a subset of its tiles
-bool NativeFft::splits() const {
+bool NativeFft::pipe_ok() const {
     static const bool no_pipe = std::getenv("MI_FFT_NO_PIPE") != nullptr;
-    return !pw.on && dims.dbg == 0 && !no_pipe && dims.ty == x_tile_rows(dims.hx);
+    return dims.dbg == 0 && !no_pipe && dims.ty == x_tile_rows(dims.hx);
 }
+bool NativeFft::splits() const { return !pw.on && pipe_ok(); }
 
 // tiles of the fused x pass that hold rows of [a0, a1) or [b0, b1) (a before b): mode 1 = only those, 2 = all the others
 TileSelect NativeFft::edge_tiles(int mode, int a0, int a1, int b0, int b1) const {
@@ -1746,17 +1783,26 @@ int NativeFft::x_inverse(hipStream_t s, float* out, int epi_kind, const ConvEpil
     MI_REQUIRE(!fuse_forward || can_fuse(), "native FFT: a replicate-padded axis cannot fuse consecutive convolutions");
     const PadWindow w = pw;
     int rc = MI_ERR_INVALID;
-    if (fuse_forward && splits()) {
+    // padded grids go through the persistent kernel too when every padded axis follows the zero rule with the data at the origin
+    // and the caller's rows are whole float4 groups
+    const bool pad_pipe = pw.on && can_fuse() && pipe_ok() && pw.o[0] == 0 && pw.o[1] == 0 && pw.o[2] == 0 && pw.n[0] % 4 == 0 &&
+                          ((uintptr_t)epi.a % 16) == 0 && ((uintptr_t)out % 16) == 0 && !(part && part->mode != 0);
+    if (fuse_forward && (splits() || pad_pipe)) {
         TileSelect sel{};
-        int per = M / dims.ty;
-        if (part && part->mode != 0) {
+        int per = M / dims.ty, planes = L;
+        if (pad_pipe) {  // only the tiles that hold rows of the caller's volume
+            sel.mode = 3;
+            sel.n0 = (pw.n[1] + dims.ty - 1) / dims.ty;
+            per = sel.n0;
+            planes = pw.n[2];
+        } else if (part && part->mode != 0) {
             sel = *part;
             per = sel.mode == 1 ? sel.n0 + sel.n1 : per - sel.n0 - sel.n1;
         }
-        const int ntiles = L * per;
+        const int ntiles = planes * per;
         if (ntiles <= 0) return MI_OK;
         const unsigned grid = (unsigned)std::min(ntiles, n_cu);
-#define MI_XP(LG, R) case LG * 16 + R: rc = launch_lds(k_x_fused_pipe<LG, R>, grid, kThreadsXZ, xl, s, "k_x_fused_pipe", Tp, out, epi, d, twx, Sp, ek, ntiles, sel); break;
+#define MI_XP(LG, R) case LG * 16 + R: rc = launch_lds(k_x_fused_pipe<LG, R>, grid, kThreadsXZ, xl, s, "k_x_fused_pipe", Tp, out, epi, d, twx, Sp, ek, ntiles, sel, w); break;
         switch (dims.lhx2 * 16 + dims.r3x) { MI_AXIS_CASES(MI_XP) default: return fail(MI_ERR_UNSUPPORTED, "native FFT: x length %d", 2 * Hx); }
 #undef MI_XP
         return rc;
