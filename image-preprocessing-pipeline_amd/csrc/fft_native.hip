@@ -832,7 +832,9 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_z_conv(const float2* _
 // voxel of OTF traffic, a sixth of this pass) and the ramp exp(-2 pi i (kx dx/Fx + ky dy/Fy + kz dz/Fz)) is put back from three
 // small per-axis tables (x and y: scalar loads, z: one look-up per lane and tile).
 constexpr bool z_pipe_even(int L) {
-    return (kThreadsXZ % L == 0) && (L % 64 == 0) && ((z_tile_lines(L) * L) % kThreadsXZ == 0);
+    // the real form needs line-uniform phases per item: either the lines divide the work-group evenly, or every wave owns one
+    // pair of lines (the WP layout of k_z_conv_pipe)
+    return (L % 64 == 0) && ((z_tile_lines(L) * L) % kThreadsXZ == 0) && ((kThreadsXZ % L == 0) || z_tile_lines(L) == kThreadsXZ / 64);
 }
 struct RealOtf {
     const float2* g;     // [xk][py][pz] {Ra, Rb}
@@ -857,7 +859,7 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_z_conv_pipe(const floa
     // line j -- both rows of a pair then belong to wave j and the point-wise step needs no work-group barrier either: forward
     // transforms, point-wise product and inverse transforms of a pair run back to back inside its wave (3 barriers per tile
     // instead of 5, all of them around the transposed fill and drain)
-    constexpr bool WP = PRIV && TL == NW && (L % 64 == 0) && (NG % kThreadsXZ == 0) && (NA % kThreadsXZ == 0);
+    constexpr bool WP = PRIV && TL == NW && (L % 64 == 0) && (NG % kThreadsXZ == 0);
     // point-wise view: item k of a lane is element pz0 of line j0 + k * JS when the lines divide the work-group evenly
     constexpr bool EVEN = (kThreadsXZ % L == 0) && (L % 64 == 0) && (NG % kThreadsXZ == 0) && ((kThreadsXZ / L) % 2 == 0 || kThreadsXZ == L);
     constexpr int JS = kThreadsXZ / (L > 0 ? L : 1);
