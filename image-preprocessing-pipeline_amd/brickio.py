@@ -1,0 +1,184 @@
+"""Block / slab file formats around the deconvolution path (host-side I/O, no GPU):
+
+  save_lz4 / load_lz4     the LZ4 brick cache of LsDeconv.m (``bl_<n>.lz4``): save_lz4_mex.c:50-175, load_lz4_mex.c,
+                          load_slab_lz4.cpp:60-90.  33280-byte header (magic 'LZC1', dtype, dims in MATLAB order,
+                          chunk table) followed by LZ4 *block*-compressed chunks of at most 1 GiB, back to back.
+  load_tiff_series        the input reader (LsDeconv.m:585-588, load_bl_tif.cpp): a folder of 2-D ``*.tif`` slices,
+                          sorted by name, 8 / 16-bit integers or 32-bit float -> (Z, Y, X) array.
+  save_tiff_series        the output writer (LsDeconv.m:1120-1145, save_bl_tif.cpp): ``img_%06d.tif`` per z slice,
+                          existing slices are skipped (resume).
+
+Arrays are C-order (Z, Y, X) == MATLAB [X, Y, Z] column-major, so the raw bytes of a brick are identical and ``dims`` is stored
+as (X, Y, Z).  liblz4 (the system's ``liblz4.so.1``) is bound with ctypes; TIFF goes through Pillow.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import ctypes.util
+import os
+from pathlib import Path
+
+import numpy as np
+
+MAGIC = 0x4C5A4331          # 'LZC1' (save_lz4_mex.c:52)
+HEADER_SIZE = 33280         # save_lz4_mex.c:49
+MAX_DIMS, MAX_CHUNKS = 16, 2048
+CHUNK_SIZE = 1 << 30        # save_lz4_mex.c:50
+DT_DOUBLE, DT_SINGLE, DT_UINT16 = 1, 2, 3
+_DTYPES = {DT_DOUBLE: np.float64, DT_SINGLE: np.float32, DT_UINT16: np.uint16}
+_CODES = {np.dtype(v): k for k, v in _DTYPES.items()}
+
+# file_header_t with the natural alignment both C files compile it with (save_lz4_mex.c:56-67, load_slab_lz4.cpp:66-74)
+HEADER = np.dtype({
+    "names": ["magic", "dtype", "ndims", "dims", "total_uncompressed", "chunk_size", "num_chunks", "chunk_uncomp", "chunk_comp"],
+    "formats": ["<u4", "u1", "u1", ("<u8", MAX_DIMS), "<u8", "<u8", "<u4", ("<u8", MAX_CHUNKS), ("<u8", MAX_CHUNKS)],
+    "offsets": [0, 4, 5, 8, 136, 144, 152, 160, 160 + 8 * MAX_CHUNKS],
+    "itemsize": HEADER_SIZE,
+})
+
+_lz4 = None
+
+
+def _lib():
+    global _lz4
+    if _lz4 is None:
+        name = ctypes.util.find_library("lz4") or "liblz4.so.1"
+        try:
+            lib = C.CDLL(name)
+        except OSError as e:
+            raise RuntimeError("the LZ4 brick format needs liblz4 (liblz4.so.1)") from e
+        lib.LZ4_compressBound.restype = C.c_int
+        lib.LZ4_compressBound.argtypes = [C.c_int]
+        lib.LZ4_compress_default.restype = C.c_int
+        lib.LZ4_compress_default.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        lib.LZ4_decompress_safe.restype = C.c_int
+        lib.LZ4_decompress_safe.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        _lz4 = lib
+    return _lz4
+
+
+def save_lz4(filename, array, chunk_size=CHUNK_SIZE):
+    """``save_lz4_mex(filename, array)``: the header is written twice -- a placeholder first, the final one with the chunk sizes
+    at the end (save_lz4_mex.c:131-175); the file appears under its name only when complete (callers write ``*.tmp`` and rename,
+    LsDeconv.m:805-806)."""
+    a = np.ascontiguousarray(array)
+    if a.dtype not in _CODES:
+        raise TypeError("save_lz4_mex:BadType: Only double, single, and uint16 arrays are supported.")
+    if not 1 <= chunk_size <= 0x7E000000:
+        raise ValueError("chunk size outside LZ4's input limit")
+    raw = a.reshape(-1).view(np.uint8)
+    total = raw.size
+    n_chunks = (total + chunk_size - 1) // chunk_size
+    if n_chunks > MAX_CHUNKS:
+        raise ValueError("save_lz4_mex:TooManyChunks: Too many chunks. Increase MAX_CHUNKS or chunk size.")
+    h = np.zeros((), dtype=HEADER)
+    h["magic"], h["dtype"], h["ndims"] = MAGIC, _CODES[a.dtype], a.ndim
+    h["dims"][:a.ndim] = a.shape[::-1]                                   # MATLAB order: fastest axis first
+    h["total_uncompressed"], h["chunk_size"], h["num_chunks"] = total, chunk_size, n_chunks
+    lib = _lib()
+    with open(filename, "wb") as f:
+        f.write(h.tobytes())
+        bound = lib.LZ4_compressBound(int(min(chunk_size, max(total, 1))))
+        dst = np.empty(bound, np.uint8)
+        for i in range(n_chunks):
+            src = raw[i * chunk_size:(i + 1) * chunk_size]
+            n = lib.LZ4_compress_default(src.ctypes.data, dst.ctypes.data, int(src.size), int(bound))
+            if n <= 0:
+                raise RuntimeError(f"save_lz4_mex:CompressionFailed: chunk {i}")
+            f.write(dst[:n].tobytes())
+            h["chunk_uncomp"][i], h["chunk_comp"][i] = src.size, n
+        f.seek(0)
+        f.write(h.tobytes())
+
+
+def read_header(f):
+    h = np.frombuffer(f.read(HEADER_SIZE), dtype=HEADER, count=1)[0]
+    if h["magic"] != MAGIC:
+        raise ValueError("bad magic")
+    if int(h["dtype"]) not in _DTYPES:
+        raise ValueError("unknown dtype code")
+    if not 0 < int(h["num_chunks"]) <= MAX_CHUNKS and int(h["total_uncompressed"]) > 0:
+        raise ValueError("bad chunk count")
+    return h
+
+
+def load_lz4(filename):
+    """``load_lz4_mex(filename)`` -> array in (Z, Y, X) order (the reverse of the stored MATLAB dims)."""
+    lib = _lib()
+    with open(filename, "rb") as f:
+        try:
+            h = read_header(f)
+        except ValueError as e:
+            raise ValueError(f"{filename}: {e}") from None
+        dt = np.dtype(_DTYPES[int(h["dtype"])])
+        total = int(h["total_uncompressed"])
+        out = np.empty(total, np.uint8)
+        off = 0
+        for i in range(int(h["num_chunks"])):
+            clen, ulen = int(h["chunk_comp"][i]), int(h["chunk_uncomp"][i])
+            comp = np.frombuffer(f.read(clen), np.uint8)
+            if comp.size != clen:
+                raise ValueError(f"{filename}: chunk: I/O error")
+            n = lib.LZ4_decompress_safe(comp.ctypes.data, out[off:].ctypes.data, clen, ulen) if ulen else 0
+            if n != ulen:
+                raise ValueError(f"{filename}: LZ4 error")
+            off += ulen
+        if off != total:
+            raise ValueError(f"{filename}: size mismatch")
+    dims = [int(v) for v in h["dims"][:int(h["ndims"])]][::-1]
+    return out.view(dt).reshape(dims)
+
+
+# ------------------------------------------------------------------------------------------------ TIFF series
+def _pil():
+    try:
+        from PIL import Image
+    except ImportError as e:
+        raise RuntimeError("reading / writing TIFF slices needs Pillow") from e
+    return Image
+
+
+def list_tiff_series(folder):
+    folder = Path(folder)
+    files = sorted(folder.glob("*.tif")) or sorted(folder.glob("*.tiff"))   # LsDeconv.m:585-588
+    return files
+
+
+def load_tiff_series(folder, z0=0, z1=None):
+    """Slices ``[z0, z1)`` of a folder of 2-D grayscale TIFFs as one (Z, Y, X) array (uint8 / uint16 / float32)."""
+    Image = _pil()
+    files = list_tiff_series(folder)[z0:z1]
+    if not files:
+        raise RuntimeError(f"no *.tif slices in {folder}")
+    first = np.asarray(Image.open(files[0]))
+    if first.ndim != 2 or first.dtype not in (np.uint8, np.uint16, np.float32):
+        raise TypeError(f"{files[0]}: 16-bit or 32bit float grayscale images supported (LsDeconv.m:1231), got {first.dtype} {first.shape}")
+    vol = np.empty((len(files),) + first.shape, first.dtype)
+    vol[0] = first
+    for k, f in enumerate(files[1:], start=1):
+        a = np.asarray(Image.open(f))
+        if a.shape != first.shape or a.dtype != first.dtype:
+            raise ValueError(f"{f}: slice shape / type differs from the first slice")
+        vol[k] = a
+    return vol
+
+
+def save_tiff_series(folder, vol, first_index=1, compression="tiff_adobe_deflate"):
+    """``img_%06d.tif`` per z slice, deflate-compressed; slices that already exist are left alone (LsDeconv.m:1120-1145).
+    Returns the number of slices written."""
+    Image = _pil()
+    folder = Path(folder)
+    folder.mkdir(parents=True, exist_ok=True)
+    vol = np.asarray(vol)
+    if vol.ndim != 3 or vol.dtype not in (np.uint8, np.uint16, np.float32):
+        raise TypeError("save_tiff_series: a 3-D uint8 / uint16 / float32 volume is expected")
+    written = 0
+    for k in range(vol.shape[0]):
+        path = folder / f"img_{first_index + k:06d}.tif"
+        if path.exists():
+            continue
+        tmp = path.with_suffix(".tif.tmp")
+        Image.fromarray(np.ascontiguousarray(vol[k])).save(tmp, format="TIFF", compression=compression)
+        os.replace(tmp, path)
+        written += 1
+    return written

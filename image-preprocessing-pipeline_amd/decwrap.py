@@ -3,11 +3,14 @@
 of the MI355X library -- no MATLAB script is written, no MATLAB is spawned (decwrap.py:408-494); the blocks are
 processed in this process through ``ipp_amd.lsdeconv.process_block``.
 
-Input: a folder of 2-D slices (``*.npy``, or ``*.tif`` when ``tifffile`` is installed) or one ``*.npy`` volume
-(Z, Y, X).  Output: ``<input>/deconvolved/deconvolved.npy`` (float32; + ``deconvolution_config.json`` like
+Input: a folder of 2-D slices (``*.tif`` / ``*.tiff`` like the reference, LsDeconv.m:585-588, or ``*.npy``) or one ``*.npy``
+volume (Z, Y, X).  Output: ``<input>/deconvolved/deconvolved.npy`` (float32; + ``deconvolution_config.json`` like
 decwrap.py:474-478, ``min_max.json``) and the rescaled integer stack ``deconvolved_{8,16}bit.npy`` that the reference's
 postprocess_save writes as a TIFF series (LsDeconv.m:950-1100: percentile clip range of all blocks, amplification, round,
-clamp; ``mi_rescale_block``).
+clamp; ``mi_rescale_block``); for a TIFF input also the ``img_%06d.tif`` series itself (LsDeconv.m:1120-1145).
+Every finished block is kept as ``bl_<n>.lz4`` in the cache folder (``--cache-drive``, default ``<out>/cache``) in the
+reference's brick format (save_lz4_mex.c), so an interrupted run resumes with the blocks that are missing (LsDeconv.m:695-705;
+``--no-resume`` starts over); the cache is removed after a complete run like LsDeconv.m:286-296.
 TIFF series / LZ4 brick cache / resume of the reference are I/O rows outside this hot path.
 """
 from __future__ import annotations
@@ -106,13 +109,9 @@ def load_volume(path: Path):
     files = sorted(path.glob("*.npy"))
     if files:
         return np.stack([np.load(f) for f in files])
-    files = sorted(list(path.glob("*.tif")) + list(path.glob("*.tiff")))
-    if files:
-        try:
-            import tifffile
-        except ImportError as e:
-            raise RuntimeError("reading TIFF slices needs the 'tifffile' module") from e
-        return np.stack([tifffile.imread(f) for f in files])
+    from ipp_amd import brickio
+    if brickio.list_tiff_series(path):
+        return brickio.load_tiff_series(path)
     raise RuntimeError(f"no *.npy / *.tif slices in {path}")
 
 
@@ -154,10 +153,18 @@ def main(argv=None):
     # One worker per entry of the device list (--gpu-indices x --gpu-workers-per-gpu, like the reference's pool of parfeval
     # workers, LsDeconv.m:620-668): blocks are independent, a worker takes the next unprocessed block, runs it on its device
     # and on its own stream, and writes the core of the result into the output volume.
+    import shutil
     import threading
     from concurrent.futures import ThreadPoolExecutor
+    from ipp_amd import brickio
+    cache = Path(args.cache_drive) if args.cache_drive else out_dir / "cache"
+    if not args.resume and cache.exists():
+        shutil.rmtree(cache)                                                               # LsDeconv.m:136-139
+    cache.mkdir(parents=True, exist_ok=True)
     workers = [g for g in args.gpu_indices for _ in range(max(1, args.gpu_workers_per_gpu))]
-    todo = [(n, p1, p2) for n, (p1, p2) in enumerate(zip(block.p1, block.p2), start=1) if n >= args.start_block]
+    # --start-block only matters to the reference's multi-process start-up; here every block is either taken from the cache
+    # or processed
+    todo = [(n, p1, p2) for n, (p1, p2) in enumerate(zip(block.p1, block.p2), start=1)]
     lock = threading.Lock()
     stats = []
 
@@ -170,6 +177,17 @@ def main(argv=None):
                 if not todo:
                     return
                 n, p1, p2 = todo.pop(0)
+            brick = cache / f"bl_{n}.lz4"
+            if brick.exists() and brick.stat().st_size > 0:                                # resume: LsDeconv.m:695-705, 799-801
+                core = brickio.load_lz4(brick)
+                if core.shape == (p2[2] - p1[2] + 1, p2[1] - p1[1] + 1, p2[0] - p1[0] + 1):
+                    out[p1[2] - 1:p2[2], p1[1] - 1:p2[1], p1[0] - 1:p2[0]] = core
+                    with open(brick.with_suffix(".json")) as f:
+                        st = json.load(f)
+                    with lock:
+                        stats.append((st["lb"], st["ub"]))
+                    log.info(f"block {n}/{len(block.p1)} taken from the cache")
+                    continue
             bl = L.load_block(vol, p1, p2, pad)
             fshape = None
             if args.use_fft:
@@ -188,6 +206,10 @@ def main(argv=None):
                 stream.synchronize()
                 core = host.numpy()
             out[p1[2] - 1:p2[2], p1[1] - 1:p2[1], p1[0] - 1:p2[0]] = core                  # disjoint boxes: no lock needed
+            with open(brick.with_suffix(".json"), "w") as f:                               # the block's clip range (min_max.mat entry)
+                json.dump({"lb": lb, "ub": ub}, f)
+            brickio.save_lz4(brick.with_suffix(".lz4.tmp"), core)                          # LsDeconv.m:805-806
+            os.replace(brick.with_suffix(".lz4.tmp"), brick)
             with lock:
                 stats.append((lb, ub))
             log.info(f"block {n}/{len(block.p1)} done on GPU {g}: stats [{lb:.4g}, {ub:.4g}]")
@@ -218,6 +240,10 @@ def main(argv=None):
     if args.flip:
         out_int = out_int[::-1]                                                            # flip_upside_down: reversed z order
     np.save(out_dir / f"deconvolved_{bits}bit.npy", out_int)
+    if not args.input.is_file() and brickio.list_tiff_series(args.input):
+        n_tif = brickio.save_tiff_series(out_dir, out_int)                                 # img_%06d.tif, existing slices kept
+        log.info(f"wrote {n_tif} TIFF slices to {out_dir}")
+    shutil.rmtree(cache, ignore_errors=True)                                               # LsDeconv.m:286-296
     log.info(f"wrote {out_dir / 'deconvolved.npy'} and deconvolved_{bits}bit.npy (scale {scal:g}, clip [{lo:.4g}, {hi:.4g}])")
     return 0
 

@@ -1,0 +1,79 @@
+"""CPU: block / slab file formats: LZ4 brick files in the layout of save_lz4_mex.c / load_slab_lz4.cpp and
+the TIFF series reader / writer."""
+import subprocess
+
+import numpy as np
+import pytest
+
+from ipp_amd import brickio
+
+
+def test_header_layout_matches_a_naturally_aligned_c_struct(tmp_path):
+    """Both C files of the reference declare the header as a plain struct and read / write 33280 bytes of it; the numpy dtype
+    must therefore have the compiler's natural alignment.  Checked against gcc's offsetof on a struct of the same field types."""
+    src = tmp_path / "hdr.c"
+    src.write_text("""
+#include <stdint.h>
+#include <stddef.h>
+#include <stdio.h>
+typedef struct { uint32_t a; uint8_t b; uint8_t c; uint64_t d[16]; uint64_t e; uint64_t f; uint32_t g; uint64_t h[2048]; uint64_t i[2048]; } hdr_t;
+int main(void) { printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu", offsetof(hdr_t, a), offsetof(hdr_t, b), offsetof(hdr_t, c), offsetof(hdr_t, d),
+                        offsetof(hdr_t, e), offsetof(hdr_t, f), offsetof(hdr_t, g), offsetof(hdr_t, h), offsetof(hdr_t, i)); return 0; }
+""")
+    exe = tmp_path / "hdr"
+    subprocess.run(["gcc", "-O0", "-o", str(exe), str(src)], check=True)
+    offs = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    names = ["magic", "dtype", "ndims", "dims", "total_uncompressed", "chunk_size", "num_chunks", "chunk_uncomp", "chunk_comp"]
+    assert [brickio.HEADER.fields[n][1] for n in names] == offs
+    assert brickio.HEADER.itemsize == 33280 and brickio.MAGIC == 0x4C5A4331
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.uint16, np.float64])
+@pytest.mark.parametrize("chunk", [brickio.CHUNK_SIZE, 4096, 1000])
+def test_lz4_brick_round_trip(tmp_path, dtype, chunk):
+    rng = np.random.default_rng(3)
+    a = (rng.random((7, 33, 21)) * 1000).astype(dtype)
+    a[2:4] = 5                                        # compressible planes
+    p = tmp_path / "bl_1.lz4"
+    brickio.save_lz4(p, a, chunk_size=chunk)
+    b = brickio.load_lz4(p)
+    assert b.dtype == a.dtype and b.shape == a.shape and np.array_equal(a, b)
+    with open(p, "rb") as f:
+        h = brickio.read_header(f)
+    assert [int(v) for v in h["dims"][:3]] == [21, 33, 7]                 # MATLAB [X Y Z]
+    assert int(h["total_uncompressed"]) == a.nbytes and int(h["num_chunks"]) == -(-a.nbytes // chunk)
+    assert int(h["chunk_uncomp"][:int(h["num_chunks"])].sum()) == a.nbytes
+    assert p.stat().st_size == brickio.HEADER_SIZE + int(h["chunk_comp"][:int(h["num_chunks"])].sum())
+
+
+def test_lz4_brick_errors(tmp_path):
+    with pytest.raises(TypeError, match="Only double, single, and uint16"):
+        brickio.save_lz4(tmp_path / "x.lz4", np.zeros((2, 2), np.int32))
+    p = tmp_path / "bad.lz4"
+    p.write_bytes(b"\0" * brickio.HEADER_SIZE)
+    with pytest.raises(ValueError, match="bad magic"):
+        brickio.load_lz4(p)
+    a = np.arange(5000, dtype=np.float32)
+    brickio.save_lz4(p, a)
+    raw = bytearray(p.read_bytes())
+    raw[brickio.HEADER_SIZE + 10] ^= 0xFF              # corrupt the stream
+    raw = raw[:-7]
+    p.write_bytes(bytes(raw))
+    with pytest.raises(ValueError, match="LZ4 error|I/O error"):
+        brickio.load_lz4(p)
+
+
+@pytest.mark.parametrize("dtype,scale", [(np.uint8, 255), (np.uint16, 65535), (np.float32, 1.0)])
+def test_tiff_series_round_trip_and_resume(tmp_path, dtype, scale):
+    rng = np.random.default_rng(1)
+    vol = (rng.random((5, 12, 17)) * scale).astype(dtype)
+    assert brickio.save_tiff_series(tmp_path, vol) == 5
+    names = sorted(p.name for p in tmp_path.glob("*.tif"))
+    assert names == [f"img_{k:06d}.tif" for k in range(1, 6)]
+    back = brickio.load_tiff_series(tmp_path)
+    assert back.dtype == vol.dtype and np.array_equal(back, vol)
+    assert np.array_equal(brickio.load_tiff_series(tmp_path, 1, 3), vol[1:3])
+    (tmp_path / "img_000003.tif").unlink()
+    assert brickio.save_tiff_series(tmp_path, vol) == 1            # only the missing slice is written again
+    with pytest.raises(RuntimeError, match="no \\*.tif"):
+        brickio.load_tiff_series(tmp_path / "nothing_here")
