@@ -53,6 +53,10 @@ struct NativeFft {
     int init(hipStream_t s, const int F[3], bool explicit_adjoint);
     // placed: the kernel on the circular grid (real, shape F; may alias scratch()); G (or G_adj) <- scale * FFT(placed)
     int build_otf(hipStream_t s, const float* placed, bool adjoint_slot, float scale);
+    // the same transform into a caller buffer of otf_items() float4: spectrum of any real F volume, scaled (deconFFT_Wiener)
+    int spectrum(hipStream_t s, const float* vol, float4* dst, float scale);
+    size_t otf_items() const { return G.bytes / sizeof(float4); }
+    float4* otf() { return G.as<float4>(); }
     // after build_otf: switch to the real OTF form when the PSF allows it (delta: centre offset from the grid origin)
     int try_real_otf(hipStream_t s, const int delta[3]);
     bool z_pipelined() const;

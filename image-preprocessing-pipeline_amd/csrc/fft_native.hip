@@ -1742,8 +1742,13 @@ int NativeFft::try_real_otf(hipStream_t s, const int delta[3]) {
 // the untangled spectrum is stored in the z pass' pair layout, times `scale`.
 int NativeFft::build_otf(hipStream_t s, const float* placed, bool adjoint_slot, float scale) {
     MI_REQUIRE(!adjoint_slot || have_adj, "native FFT: no adjoint OTF slot");
-    MI_REQUIRE(!pw.on, "native FFT: build the OTF before setting the pad window");
-    MI_TRY(x_forward(s, placed));
+    return spectrum(s, placed, adjoint_slot ? G_adj.as<float4>() : G.as<float4>(), scale);
+}
+
+// untangled half spectrum of a real F volume in the OTF layout (pairs (X[k], X[mirror k]) per point-wise item of the z pass)
+int NativeFft::spectrum(hipStream_t s, const float* vol, float4* Gp, float scale) {
+    MI_REQUIRE(!pw.on, "native FFT: spectra are taken on the unpadded grid (before the pad window is set)");
+    MI_TRY(x_forward(s, vol));
     MI_TRY(y_pass(s, false));
     const int Hx = dims.hx, M = dims.ny, L = dims.nz;
     const unsigned ztiles = (unsigned)((size_t)(Hx / 2 + 1) * (M / dims.tl));
@@ -1751,7 +1756,6 @@ int NativeFft::build_otf(hipStream_t s, const float* placed, bool adjoint_slot, 
     const NativeDims d = dims;
     const float2* Tp = T.as<float2>();
     float2* Sp = S.as<float2>();
-    float4* Gp = adjoint_slot ? G_adj.as<float4>() : G.as<float4>();
     const float2* twz = tw_z;
     int rc = MI_ERR_INVALID;
 #define MI_Z(LG, R)                                                                                                                       \

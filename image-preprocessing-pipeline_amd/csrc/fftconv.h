@@ -31,8 +31,11 @@ struct FftEngine {
 
     ~FftEngine();
     // bnd/shift per axis (x, y, z): boundary rule and PSF placement shift (see AxisPlan)
+    // fixed_psf = false: the PSF will be replaced with set_psf (deconFFT_Wiener), so the OTF keeps its general complex form
     int init(hipStream_t s, const int n[3], const int k[3], const int bnd[3], const int shift[3], const float* psf,
-             const float* psf_inv, bool need_adjoint);
+             const float* psf_inv, bool need_adjoint, bool fixed_psf = true);
+    // native pipeline only: rebuild the forward OTF from a new PSF of the same extents and placement (device pointer)
+    int set_psf(hipStream_t s, const float* psf);
     // c = conv(in, psf or its adjoint), then the epilogue of `epi_kind` into out (shape n)
     int conv(hipStream_t s, const float* in, bool adjoint, float* out, int epi_kind, const ConvEpilogue& epi);
     size_t device_bytes() const {

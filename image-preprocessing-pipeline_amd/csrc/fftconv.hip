@@ -219,8 +219,17 @@ static int make_plans(hipStream_t s, const size_t lengths[3], rocfft_plan* fwd, 
     return MI_OK;
 }
 
+int FftEngine::set_psf(hipStream_t s, const float* psf) {
+    MI_REQUIRE(native && !padded && !native->real_otf, "FFT engine: set_psf needs the hand-written pipeline on an unpadded grid");
+    hipLaunchKernelGGL(k_place_psf, dim3(stream_grid(n_real)), dim3(kThreads), 0, s, psf, native->scratch(), ax[0].k, ax[1].k, ax[2].k,
+                       ax[0].F, ax[1].F, ax[2].F, ax[0].shift, ax[1].shift, ax[2].shift);
+    MI_TRY(launch_check("k_place_psf"));
+    const float nscale = 2.0f / (float)((double)ax[0].F * ax[1].F * ax[2].F);
+    return native->build_otf(s, native->scratch(), false, nscale);
+}
+
 int FftEngine::init(hipStream_t s, const int n[3], const int k[3], const int bnd[3], const int shift[3], const float* psf,
-                    const float* psf_inv, bool need_adjoint) {
+                    const float* psf_inv, bool need_adjoint, bool fixed_psf) {
     padded = false;
     bool conj_ok = true;
     int F[3], need[3];
@@ -274,7 +283,7 @@ int FftEngine::init(hipStream_t s, const int n[3], const int k[3], const int bnd
         }
         // PSFs of odd extents that are mirror-symmetric about their centre sample (every LsMakePSF PSF) have a real OTF up to the
         // phase ramp of the centre's offset from the grid origin: sample j sits at j - shift, the centre at (k-1)/2 - shift
-        if ((ax[0].k & 1) && (ax[1].k & 1) && (ax[2].k & 1)) {
+        if (fixed_psf && (ax[0].k & 1) && (ax[1].k & 1) && (ax[2].k & 1)) {
             const int delta[3] = {(ax[0].k - 1) / 2 - ax[0].shift, (ax[1].k - 1) / 2 - ax[1].shift, (ax[2].k - 1) / 2 - ax[2].shift};
             MI_TRY(native->try_real_otf(s, delta));
         }

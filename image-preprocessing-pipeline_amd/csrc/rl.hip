@@ -8,6 +8,7 @@
 // the GPU path), the Tikhonov blend and the ||bl||_2 stop test follow decon.m:41-59,67-79,108-118.
 #include <cmath>
 #include <new>
+#include <utility>
 
 #include "fftconv.h"
 
@@ -54,8 +55,8 @@ static int default_shift(int n, int k, int boundary) {
     return k - 1 - conv_kernel_offset(k, boundary);
 }
 
-extern "C" int mi_rl_create_ex(int dev, void* stream, int nx, int ny, int nz, const float* psf, const float* psf_inv, int kx, int ky,
-                               int kz, const int* boundary_xyz, const int* shift_xyz, int engine, mi_rl_ctx** out) {
+static int rl_create(int dev, void* stream, int nx, int ny, int nz, const float* psf, const float* psf_inv, int kx, int ky, int kz,
+                     const int* boundary_xyz, const int* shift_xyz, int engine, bool fixed_psf, mi_rl_ctx** out) {
     MI_TRY(use_device(dev));
     MI_REQUIRE(out, "mi_rl_create: null ctx pointer");
     *out = nullptr;
@@ -100,7 +101,7 @@ extern "C" int mi_rl_create_ex(int dev, void* stream, int nx, int ny, int nz, co
     } else {
         c->fft = new (std::nothrow) FftEngine;
         if (!c->fft) rc = fail(MI_ERR_NOMEM, "mi_rl_create: out of host memory");
-        if (rc == MI_OK) rc = c->fft->init(s, n, k, c->bnd, shift, psf, psf_inv, true);
+        if (rc == MI_OK) rc = c->fft->init(s, n, k, c->bnd, shift, psf, psf_inv, true, fixed_psf);
     }
     if (rc == MI_OK) {
         hipError_t e = hipStreamSynchronize(s);
@@ -112,6 +113,11 @@ extern "C" int mi_rl_create_ex(int dev, void* stream, int nx, int ny, int nz, co
     }
     *out = c;
     return MI_OK;
+}
+
+extern "C" int mi_rl_create_ex(int dev, void* stream, int nx, int ny, int nz, const float* psf, const float* psf_inv, int kx, int ky,
+                               int kz, const int* boundary_xyz, const int* shift_xyz, int engine, mi_rl_ctx** out) {
+    return rl_create(dev, stream, nx, ny, nz, psf, psf_inv, kx, ky, kz, boundary_xyz, shift_xyz, engine, true, out);
 }
 
 extern "C" int mi_rl_create(int dev, void* stream, int nx, int ny, int nz, const float* psf, const float* psf_inv, int kx, int ky,
@@ -430,14 +436,160 @@ extern "C" int mi_rl_fft(int dev, void* stream, float* bl, const float* psf, int
     return rc;
 }
 
+// ------------------------------------------------------------------------------------------------ deconFFT_Wiener
+namespace {
+
+constexpr int kThreads = 256;
+inline unsigned stream_grid(size_t n_items) {
+    const size_t b = (n_items + kThreads - 1) / kThreads, cap = 256 * 16;  // grid-stride beyond 16 work-groups per CU
+    return static_cast<unsigned>(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+// otf_new = F{Y} conj(F{X}) / max(|F{X}|^2, eps) (decon.m:282-288), element-wise on the untangled half spectra; `scale` folds in
+// the 2 / (Fx Fy Fz) of the pipeline's unnormalised inverse
+__global__ __launch_bounds__(kThreads) void k_wiener_otf(const float2* __restrict__ fy, const float2* __restrict__ fx, float2* __restrict__ otf,
+                                                       size_t n, float scale) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float2 y = fy[i], x = fx[i];
+        const float den = fmaxf(x.x * x.x + x.y * x.y, kEpsSingle);
+        const float re = y.x * x.x + y.y * x.y, im = y.y * x.x - y.x * x.y;  // y * conj(x)
+        otf[i] = make_float2(re / den * scale, im / den * scale);
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void k_delta(float* __restrict__ v, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) v[i] = i == 0 ? 1.0f : 0.0f;
+}
+
+// psf = max(full(centre box), 0); psf /= sum(psf) when the sum is positive (decon.m:293-301).  One work-group: a PSF is small.
+__global__ __launch_bounds__(256) void k_wiener_psf(const float* __restrict__ full, float* __restrict__ psf, int fx, int fy, int kx, int ky,
+                                                     int kz, int cx, int cy, int cz) {
+    __shared__ float part[256];
+    const int n = kx * ky * kz;
+    float acc = 0.0f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int x = i % kx, r = i / kx, y = r % ky, z = r / ky;
+        const float v = fmaxf(full[((size_t)(cz + z) * fy + (cy + y)) * fx + (cx + x)], 0.0f);
+        psf[i] = v;
+        acc += v;
+    }
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
+        __syncthreads();
+    }
+    const float sum = part[0];
+    if (sum > 0.0f)
+        for (int i = threadIdx.x; i < n; i += 256) psf[i] = psf[i] / sum;
+}
+
+}  // namespace
+
+extern "C" int mi_rl_fft_wiener(int dev, void* stream, float* bl, float* psf, int nx, int ny, int nz, int kx, int ky, int kz, int fx,
+                                int fy, int fz, const mi_rl_options* opt, int* iters_done) {
+    MI_TRY(use_device(dev));
+    MI_TRY(check_options(opt));
+    MI_REQUIRE(bl && psf, "deconFFT_Wiener: null pointer");
+    MI_REQUIRE(nx > 0 && ny > 0 && nz > 0 && kx > 0 && ky > 0 && kz > 0, "deconFFT_Wiener: bl and psf must be 3D and non-empty");
+    MI_REQUIRE(fx >= nx && fy >= ny && fz >= nz, "pad_block_to_fft_shape: bl [%d %d %d] is larger than FFT shape [%d %d %d], cannot pad",
+               nx, ny, nz, fx, fy, fz);
+    MI_REQUIRE(fx >= kx && fy >= ky && fz >= kz, "pad_block_to_fft_shape: psf [%d %d %d] is larger than FFT shape [%d %d %d], cannot pad",
+               kx, ky, kz, fx, fy, fz);
+    // the spectra F{Y}, F{X} live in the hand-written pipeline's own layout; rocFFT-only shapes are not served
+    if (!(mi_fft_good_size(fx, 0) == fx && mi_fft_good_size(fy, 1) == fy && mi_fft_good_size(fz, 2) == fz))
+        return fail(MI_ERR_UNSUPPORTED, "deconFFT_Wiener: fft_shape [%d %d %d] must be made of extents mi_fft_good_size accepts (2^a, 3 * 2^a or 9 * 2^a; x even)", fx, fy, fz);
+    hipStream_t s = as_stream(stream);
+    const size_t NF = (size_t)fx * fy * fz;
+    const bool padded = fx != nx || fy != ny || fz != nz;
+    const int nk = kx * ky * kz;
+    DevBuf ratio, reg, scratch, blF, psf_cur, FY, FX;
+    MI_TRY(ratio.alloc(sizeof(float) * NF));
+    if (opt->lambda > 0.0f && opt->regularize_interval > 0) MI_TRY(reg.alloc(sizeof(float) * NF));
+    MI_TRY(scratch.alloc(sizeof(double)));
+    MI_TRY(psf_cur.alloc(sizeof(float) * nk));
+    MI_HIP(hipMemcpyAsync(psf_cur.p, psf, sizeof(float) * nk, hipMemcpyDeviceToDevice, s));
+    if (!opt->skip_edgetaper) MI_TRY(edgetaper_async(s, bl, ratio.as<float>(), psf, nx, ny, nz, kx, ky, kz));  // decon.m:212
+    float* work_bl = bl;
+    if (padded) {  // decon.m:213
+        MI_TRY(blF.alloc(sizeof(float) * NF));
+        MI_TRY(mi_pad_center(dev, stream, bl, nx, ny, nz, blF.as<float>(), fx, fy, fz));
+        work_bl = blF.as<float>();
+    }
+    double delta_prev = 0.0;
+    if (opt->stop_criterion > 0.0f) MI_TRY(host_norm(s, work_bl, NF, scratch.as<double>(), &delta_prev));  // decon.m:215
+    mi_rl_ctx* ctx = nullptr;
+    const int b[3] = {MI_BOUNDARY_CIRCULAR, MI_BOUNDARY_CIRCULAR, MI_BOUNDARY_CIRCULAR};
+    MI_TRY(rl_create(dev, stream, fx, fy, fz, psf, nullptr, kx, ky, kz, b, nullptr, MI_ENGINE_FFT, /*fixed_psf=*/false, &ctx));
+    struct Guard { mi_rl_ctx* c; hipStream_t s; ~Guard() { (void)hipStreamSynchronize(s); mi_rl_destroy(c); } } guard{ctx, s};
+    FftEngine* fe = ctx->fft;
+    MI_REQUIRE(fe->native, "deconFFT_Wiener: the hand-written FFT pipeline refused fft_shape [%d %d %d]", fx, fy, fz);
+    NativeFft* nf = fe->native;
+    const size_t items = nf->otf_items();
+    MI_TRY(FY.alloc(sizeof(float4) * items));
+    MI_TRY(FX.alloc(sizeof(float4) * items));
+    float4 *fy_p = FY.as<float4>(), *fx_p = FX.as<float4>();
+    const float nscale = 2.0f / (float)((double)fx * fy * fz);
+    const float sig[3] = {0.5f, 0.5f, 0.5f};
+    const int k3[3] = {3, 3, 3};
+    const int cx = (fx - kx) / 2, cy = (fy - ky) / 2, cz = (fz - kz) / 2;  // floor((fft_shape - psf_sz) / 2) + 1, 0-based (decon.m:236)
+    ConvEpilogue none;
+    int done = 0;
+    for (int i = 1; i <= opt->niter; ++i) {
+        if (i > 1) MI_TRY(fe->set_psf(s, psf_cur.as<float>()));  // decon.m:243-245 (iteration 1: the OTF mi_rl_create built)
+        const bool reg_i = opt->regularize_interval > 0 && (i % opt->regularize_interval) == 0;
+        // F{Y} (decon.m:248-256) only feeds the Wiener quotient here: the RL step transforms bl itself
+        if (i > 1 && reg_i) MI_TRY(gauss3d_async(s, work_bl, ratio.as<float>(), fx, fy, fz, sig, opt->gauss_taps == 3 ? k3 : nullptr));
+        if (i < opt->niter && (i == 1 || reg_i)) MI_TRY(nf->spectrum(s, work_bl, fy_p, 1.0f));
+        if (reg_i && opt->lambda > 0.0f && i < opt->niter) {  // decon.m:273-275
+            MI_TRY(mi_rl_forward_ratio(ctx, s, work_bl, ratio.as<float>()));
+            MI_TRY(mi_rl_reg_term(dev, s, work_bl, reg.as<float>(), fx, fy, fz));
+            MI_TRY(mi_rl_adjoint_update(ctx, s, ratio.as<float>(), work_bl, opt->lambda, reg.as<float>()));
+        } else {
+            MI_TRY(mi_rl_iterate(ctx, s, work_bl, ratio.as<float>(), 1));
+        }
+        if (i < opt->niter) {  // decon.m:281-307
+            MI_TRY(nf->spectrum(s, work_bl, fx_p, 1.0f));
+            hipLaunchKernelGGL(k_wiener_otf, dim3(stream_grid(2 * items)), dim3(kThreads), 0, s, reinterpret_cast<const float2*>(fy_p),
+                               reinterpret_cast<const float2*>(fx_p), reinterpret_cast<float2*>(nf->otf()), 2 * items, nscale);
+            MI_TRY(launch_check("k_wiener_otf"));
+            std::swap(fy_p, fx_p);  // F{X} is the next iteration's F{Y}
+            // real(ifftn(otf_new)): the response of the new OTF to a unit impulse at the origin
+            hipLaunchKernelGGL(k_delta, dim3(stream_grid(NF)), dim3(kThreads), 0, s, ratio.as<float>(), NF);
+            MI_TRY(launch_check("k_delta"));
+            MI_TRY(fe->conv(s, ratio.as<float>(), false, ratio.as<float>(), EPI_NONE, none));
+            hipLaunchKernelGGL(k_wiener_psf, dim3(1), dim3(256), 0, s, ratio.as<float>(), psf_cur.as<float>(), fx, fy, kx, ky, kz, cx, cy, cz);
+            MI_TRY(launch_check("k_wiener_psf"));
+        }
+        done = i;
+        if (opt->stop_criterion > 0.0f) {  // decon.m:310-317: no i > 1 guard in this variant
+            double cur = 0.0;
+            MI_TRY(host_norm(s, work_bl, NF, scratch.as<double>(), &cur));
+            if (std::fabs(delta_prev - cur) / delta_prev * 100.0 <= (double)opt->stop_criterion) break;
+            delta_prev = cur;
+        }
+    }
+    if (iters_done) *iters_done = done;
+    if (padded) MI_TRY(mi_crop_center(dev, stream, work_bl, fx, fy, fz, bl, nx, ny, nz));  // decon.m:320
+    MI_HIP(hipMemcpyAsync(psf, psf_cur.p, sizeof(float) * nk, hipMemcpyDeviceToDevice, s));
+    MI_HIP(hipStreamSynchronize(s));
+    return MI_OK;
+}
+
 extern "C" int mi_decon(int dev, void* stream, float* bl, const float* psf, const float* psf_inv, int nx, int ny, int nz, int kx, int ky,
                         int kz, const mi_rl_options* opt, int use_fft, const int* fft_shape_xyz, int adaptive_psf, int* iters_done) {
-    if (adaptive_psf)
-        return fail(MI_ERR_UNSUPPORTED, "decon: adaptive_psf (deconFFT_Wiener, decon.m:206-321) is not built (SURVEY.md R4)");
     if (use_fft) {
         int f[3] = {nx, ny, nz};
         if (fft_shape_xyz) { f[0] = fft_shape_xyz[0]; f[1] = fft_shape_xyz[1]; f[2] = fft_shape_xyz[2]; }
+        if (adaptive_psf) {  // decon.m:15-16; the caller's PSF stays as it was (the refined one is deconFFT_Wiener's local)
+            MI_REQUIRE(psf && kx > 0 && ky > 0 && kz > 0, "deconFFT_Wiener: null pointer");
+            MI_TRY(use_device(dev));
+            DevBuf p;
+            MI_TRY(p.alloc(sizeof(float) * (size_t)kx * ky * kz));
+            MI_HIP(hipMemcpyAsync(p.p, psf, sizeof(float) * (size_t)kx * ky * kz, hipMemcpyDeviceToDevice, as_stream(stream)));
+            return mi_rl_fft_wiener(dev, stream, bl, p.as<float>(), nx, ny, nz, kx, ky, kz, f[0], f[1], f[2], opt, iters_done);
+        }
         return mi_rl_fft(dev, stream, bl, psf, nx, ny, nz, kx, ky, kz, f[0], f[1], f[2], opt, iters_done);
     }
-    return mi_rl_spatial(dev, stream, bl, psf, psf_inv, nx, ny, nz, kx, ky, kz, opt, iters_done);
+    return mi_rl_spatial(dev, stream, bl, psf, psf_inv, nx, ny, nz, kx, ky, kz, opt, iters_done);  // adaptive_psf: FFT path only (decon.m:14-22)
 }

@@ -375,18 +375,18 @@ class RLContext:
 
 def decon(bl, psf, niter, lambda_=0.0, stop_criterion=0.0, regularize_interval=0, device_id=None, use_fft=False,
           fft_shape=None, adaptive_psf=False, *, engine=ENGINE_AUTO, skip_edgetaper=False, gauss_taps=0,
-          return_iters=False):
+          return_iters=False, return_psf=False):
     """``bl = decon(bl, psf, niter, lambda, stop_criterion, regularize_interval, device_id, use_fft, fft_shape,
-    adaptive_psf)`` (decon.m:1-23).
+    adaptive_psf)`` (decon.m:1-23).  ``adaptive_psf`` with ``use_fft`` runs ``deconFFT_Wiener`` (decon.m:206-321), whose
+    ``fft_shape`` must be made of extents the hand-written FFT takes (``fft_good_size``); ``return_psf`` then also hands
+    back the refined PSF, which the reference keeps local.
 
     ``psf`` is the reference's struct with fields ``psf`` and ``inv`` (anything with those attributes / keys), or
     a bare array (``inv`` is then the flipped PSF).  ``fft_shape`` is [x y z].  A CUDA tensor ``bl`` is updated
     in place and returned; a numpy ``bl`` is uploaded and gathered.  Keyword-only extras select the convolution
     engine and let a caller that already tapered the block skip the taper (used by the benchmark)."""
-    if adaptive_psf:
-        if not use_fft:
-            raise ValueError("--adaptive-psf requires --use-fft")  # decwrap.py:216-217
-        raise NotImplementedError("deconFFT_Wiener (decon.m:206-321) is not part of this build (SURVEY.md R4)")
+    if adaptive_psf and not use_fft:
+        raise ValueError("--adaptive-psf requires --use-fft")  # decwrap.py:216-217
     dev = _device(device_id if device_id is not None else
                   (bl.device if isinstance(bl, torch.Tensor) and bl.is_cuda else None))
     if isinstance(psf, dict):
@@ -413,7 +413,14 @@ def decon(bl, psf, niter, lambda_=0.0, stop_criterion=0.0, regularize_interval=0
     fs = None
     if use_fft:
         fs = (C.c_int * 3)(*(int(v) for v in (fft_shape if fft_shape is not None else (nx, ny, nz))))
-    check(lib().mi_decon(dev.index, _stream(t), t.data_ptr(), p.data_ptr(), pi_ptr, nx, ny, nz, kx, ky, kz,
-                         C.byref(opt), 1 if use_fft else 0, fs, 0, C.byref(done)))
+    refined = None
+    if adaptive_psf:
+        refined = p.clone()
+        check(lib().mi_rl_fft_wiener(dev.index, _stream(t), t.data_ptr(), refined.data_ptr(), nx, ny, nz, kx, ky, kz,
+                                     fs[0], fs[1], fs[2], C.byref(opt), C.byref(done)))
+    else:
+        check(lib().mi_decon(dev.index, _stream(t), t.data_ptr(), p.data_ptr(), pi_ptr, nx, ny, nz, kx, ky, kz,
+                             C.byref(opt), 1 if use_fft else 0, fs, 0, C.byref(done)))
     out = t.cpu().numpy() if was_np else t
-    return (out, done.value) if return_iters else out
+    res = (out,) + ((done.value,) if return_iters else ()) + ((refined.cpu().numpy() if was_np else refined,) if return_psf else ())
+    return res if len(res) > 1 else out

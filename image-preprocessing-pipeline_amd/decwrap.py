@@ -52,7 +52,7 @@ def build_parser(default_gpus):
     p.add_argument("-ex", "--lambda-ex", type=int, required=True, help="Excitation wavelength (488, 561, 642)")
     p.add_argument("-em", "--lambda-em", type=int, required=True, help="Emission wavelength (525, 600, 690)")
     p.add_argument("--use-fft", action="store_true", default=False, help="use FFT-based convolution (deconFFT semantics)")
-    p.add_argument("--adaptive-psf", action="store_true", default=False, help="Wiener PSF update (not built)")
+    p.add_argument("--adaptive-psf", action="store_true", default=False, help="Wiener PSF update (deconFFT_Wiener)")
     p.add_argument("--cache-drive", type=str, default=None)
     p.add_argument("-it", "--numit", type=int, default=6, help="Number of deconvolution iterations [1-50]")
     p.add_argument("--na", type=float, default=0.40)

@@ -171,8 +171,18 @@ int mi_rl_spatial(int dev, void* stream, float* bl, const float* psf, const floa
 int mi_rl_fft(int dev, void* stream, float* bl, const float* psf, int nx, int ny, int nz, int kx, int ky, int kz,
               int fx, int fy, int fz, const mi_rl_options* opt, int* iters_done);
 
+/* bl = deconFFT_Wiener(bl, psf, fft_shape, ...)   [decon.m:206-321]  RL with a Wiener re-estimate of the PSF after every
+ * iteration but the last: otf_new = F{Y} conj(F{X}) / max(|F{X}|^2, eps), new psf = the centre box of real(ifftn(otf_new))
+ * clamped at 0 and renormalised (decon.m:281-301).  bl in place; psf [kz][ky][kx] is READ AND OVERWRITTEN with the last
+ * refined PSF (the reference keeps it local).  The quirks of the .m are kept: Gaussian smoothing whenever
+ * regularize_interval > 0 && i %% interval == 0 (i > 1), Tikhonov blend only with lambda > 0 && i < niter, stop test without
+ * the i > 1 guard.  fft_shape extents must satisfy mi_fft_good_size(f, axis) == f (the spectra live in the hand-written
+ * pipeline's layout), else MI_ERR_UNSUPPORTED.  opt->engine is ignored.  Synchronises. */
+int mi_rl_fft_wiener(int dev, void* stream, float* bl, float* psf, int nx, int ny, int nz, int kx, int ky, int kz,
+                     int fx, int fy, int fz, const mi_rl_options* opt, int* iters_done);
+
 /* bl = decon(bl, psf, niter, lambda, stop_criterion, regularize_interval, device_id, use_fft, fft_shape,
- *            adaptive_psf)   [decon.m:1-23]; adaptive_psf != 0 returns MI_ERR_UNSUPPORTED. */
+ *            adaptive_psf)   [decon.m:1-23]; adaptive_psf != 0 with use_fft runs mi_rl_fft_wiener on a private copy of psf. */
 int mi_decon(int dev, void* stream, float* bl, const float* psf, const float* psf_inv,
              int nx, int ny, int nz, int kx, int ky, int kz, const mi_rl_options* opt,
              int use_fft, const int* fft_shape_xyz, int adaptive_psf, int* iters_done);

@@ -265,6 +265,72 @@ def decon_fft(bl, psf, fft_shape_zyx, niter, lam=0.0, stop_criterion=0.0, regula
     return (out, done) if return_iters else out
 
 
+def decon_fft_wiener(bl, psf, fft_shape_zyx, niter, lam=0.0, stop_criterion=0.0, regularize_interval=0,
+                     gauss_flavour="gpu", skip_edgetaper=False, return_psf=False, forced_psfs=None, trace=None):
+    """``deconFFT_Wiener`` (decon.m:206-321): RL on ``fft_shape`` with a Wiener re-estimate of the PSF after every
+    iteration but the last.  Quirks kept as written: the Gaussian pre-smoothing happens whenever
+    ``regularize_interval > 0 and mod(i, interval) == 0`` (no ``1 < i < niter`` window, :252-256), the Tikhonov blend needs
+    ``lambda > 0 and i < niter`` (:273), the new PSF is cut out of ``real(ifftn(otf_new))`` at the CENTRE of the array without
+    an fftshift (:298-301), clamped at 0 and renormalised if its sum is positive, the stop test has no ``i > 1`` guard (:311-317).
+    float64 transforms, float32 buffers.
+
+    The PSF update is numerically unstable (the new PSF is the far field of a spectral quotient: a 1e-5 perturbation of the
+    transforms grows ~100x per iteration), so implementations can only be compared step by step.  Test hooks for that:
+    ``trace`` (a list) receives the PSF estimated after every iteration; ``forced_psfs`` ({iteration: psf}) replaces the
+    PSF an iteration starts from, e.g. with the one another implementation estimated."""
+    f32 = np.float32
+    bl = bl.astype(f32)
+    psf = psf.astype(f32)
+    lam = f32(lam)
+    R = _reg_kernel()
+    if not skip_edgetaper:
+        bl = edgetaper_3d(bl, psf)
+    bl, pre, post = pad_block_to_fft_shape(bl, fft_shape_zyx)
+    delta_prev = _norm2(bl) if stop_criterion > 0 else 0.0
+    center = [(f - k) // 2 for f, k in zip(fft_shape_zyx, psf.shape)]     # floor((fft_shape - psf_sz)/2) + 1, 0-based here
+    fy = None
+    for i in range(1, niter + 1):
+        if forced_psfs and i in forced_psfs:
+            psf = forced_psfs[i].astype(f32)
+        otf = otf_from_psf(psf, fft_shape_zyx)
+        reg_i = regularize_interval > 0 and i % regularize_interval == 0
+        if i == 1:
+            fy = np.fft.fftn(bl.astype(np.float64))
+        elif reg_i:
+            bl = gauss3d(bl, 0.5) if gauss_flavour == "gpu" else gauss3d(bl, 0.5, 3)
+            fy = np.fft.fftn(bl.astype(np.float64))
+        buf = np.real(np.fft.ifftn(fy * otf)).astype(f32)
+        buf = np.maximum(buf, EPS_SINGLE)
+        buf = (bl / buf).astype(f32)
+        buf = np.real(np.fft.ifftn(np.fft.fftn(buf.astype(np.float64)) * np.conj(otf))).astype(f32)
+        if reg_i and lam > 0 and i < niter:
+            regv = convn_same(bl, R)
+            bl = (bl * buf * (f32(1) - lam) + regv * lam).astype(f32)
+        else:
+            bl = (bl * buf).astype(f32)
+        bl = np.abs(bl)
+        if i < niter:
+            fx = np.fft.fftn(bl.astype(np.float64))
+            den = np.maximum((fx * np.conj(fx)).real.astype(f32), EPS_SINGLE)
+            otf_new = (fy * np.conj(fx)).astype(np.complex64) / den
+            fy = fx
+            full = np.real(np.fft.ifftn(otf_new.astype(np.complex128))).astype(f32)
+            sl = tuple(slice(c, c + k) for c, k in zip(center, psf.shape))
+            psf = np.maximum(full[sl], f32(0))
+            tot = psf.sum(dtype=np.float64)
+            if tot > 0:
+                psf = (psf / f32(tot)).astype(f32)
+            if trace is not None:
+                trace.append(psf.copy())
+        if stop_criterion > 0:
+            cur = _norm2(bl)
+            if abs(delta_prev - cur) / delta_prev * 100.0 <= stop_criterion:
+                break
+            delta_prev = cur
+    out = unpad_block(bl, pre, post)
+    return (out, psf) if return_psf else out
+
+
 def decon(bl, psf, niter, lam, stop_criterion, regularize_interval, use_fft=False, fft_shape_zyx=None, **kw):
     """``decon`` dispatcher (decon.m:1-23), non-adaptive variants."""
     if use_fft:

@@ -170,6 +170,74 @@ def test_decon_fft_matches_oracle(dev, F_xyz, niter, lam, interval):
     assert got.shape == vol.shape and _rel(got, want) < REL
 
 
+# deconFFT_Wiener cuts the new PSF out of the far field of a spectral quotient (F{Y} conj F{X} / |F{X}|^2): the update is
+# unstable -- the float64 oracle run with float32 transforms drifts from itself by ~100x per iteration (1e-5 after two
+# iterations, 5 % after four) -- so whole runs are compared for niter = 2 and longer runs step by step: the oracle starts
+# every iteration from the PSF the device estimated for it (device runs of niter = i return the PSF iteration i starts from),
+# which holds the volume to the RL tolerance and each single PSF update to 2e-3 of the PSF's peak.
+WIENER_F = [(64, 96, 32), (64, 64, 96)]
+
+
+def _wiener_case():
+    vol, psf = _case((20, 36, 44), (7, 5, 5), (1.5, 1.0, 1.0), 13)
+    rng = np.random.default_rng(5)
+    return rng.poisson(vol * 200 + 10).astype(np.float32), psf
+
+
+@pytest.mark.parametrize("F_xyz", WIENER_F)
+@pytest.mark.parametrize("lam,interval", [(0.0, 0), (0.05, 1), (0.0, 2)])
+def test_decon_fft_wiener_two_iterations_match_oracle(dev, F_xyz, lam, interval):
+    from ipp_amd import decon
+    vol, psf = _wiener_case()
+    Fz = (F_xyz[2], F_xyz[1], F_xyz[0])
+    want, want_psf = R.decon_fft_wiener(vol, psf, Fz, 2, lam, 0.0, interval, return_psf=True)
+    got, got_psf = decon.decon(_t(vol, dev), psf, 2, lam, 0.0, interval, 1, True, F_xyz, True, return_psf=True)
+    got, got_psf = got.cpu().numpy(), got_psf.cpu().numpy()
+    assert got.shape == vol.shape and got_psf.shape == psf.shape
+    assert np.abs(got_psf - want_psf).max() <= 2e-3 * want_psf.max()
+    assert abs(float(got_psf.sum()) - 1.0) < 1e-5 and got_psf.min() >= 0
+    assert _rel(got, want) < 5 * REL
+
+
+@pytest.mark.parametrize("F_xyz", WIENER_F)
+@pytest.mark.parametrize("niter,interval", [(5, 0), (6, 3)])
+def test_decon_fft_wiener_step_locked(dev, F_xyz, niter, interval):
+    from ipp_amd import decon
+    vol, psf = _wiener_case()
+    Fz = (F_xyz[2], F_xyz[1], F_xyz[0])
+    run = lambda n: decon.decon(_t(vol, dev), psf, n, 0.0, 0.0, interval, 1, True, F_xyz, True, return_psf=True)
+    starts = {i: run(i)[1].cpu().numpy() for i in range(2, niter + 1)}    # PSF iteration i starts from
+    got = run(niter)[0].cpu().numpy()
+    trace = []
+    want = R.decon_fft_wiener(vol, psf, Fz, niter, 0.0, 0.0, interval, forced_psfs=starts, trace=trace)
+    assert _rel(got, want) < 5 * REL
+    assert len(trace) == niter - 1
+    for i, est in enumerate(trace, start=2):                               # the oracle's own update from the same state
+        assert np.abs(starts[i] - est).max() <= 2e-3 * est.max(), i
+
+
+def test_decon_fft_wiener_stop_criterion(dev):
+    # decon.m:310-317: no i > 1 guard, so a loose criterion stops after the first iteration already
+    from ipp_amd import decon
+    vol, psf = _wiener_case()
+    _, n1 = decon.decon(_t(vol, dev), psf, 6, 0.0, 99.0, 0, 1, True, (64, 64, 32), True, return_iters=True)
+    _, n2 = decon.decon(_t(vol, dev), psf, 3, 0.0, 1e-9, 0, 1, True, (64, 64, 32), True, return_iters=True)
+    assert n1 == 1 and n2 == 3
+    want = R.decon_fft_wiener(vol, psf, (32, 64, 64), 6, 0.0, 99.0, 0)
+    got = decon.decon(_t(vol, dev), psf, 6, 0.0, 99.0, 0, 1, True, (64, 64, 32), True).cpu().numpy()
+    assert _rel(got, want) < REL
+
+
+def test_decon_fft_wiener_single_iteration_is_decon_fft(dev):
+    # with one iteration there is no PSF update: deconFFT_Wiener == deconFFT, and the PSF comes back untouched
+    from ipp_amd import decon
+    vol, psf = _case((16, 32, 32), (5, 5, 5), (1.2, 1.0, 1.0), 14)
+    a = decon.decon(_t(vol, dev), psf, 1, 0.0, 0.0, 0, 1, True, (32, 32, 16), False).cpu().numpy()
+    b, p2 = decon.decon(_t(vol, dev), psf, 1, 0.0, 0.0, 0, 1, True, (32, 32, 16), True, return_psf=True)
+    assert _rel(b.cpu().numpy(), a) < 1e-6
+    assert np.array_equal(p2.cpu().numpy(), psf)
+
+
 def test_decon_fft_semantics_on_direct_engine(dev):
     # the deconFFT placement quirk (even fft_shape -> one-voxel offset) reproduced by both engines
     from ipp_amd import decon
@@ -205,8 +273,8 @@ def test_decon_errors(dev):
     psf = np.ones((3, 3, 3), np.float32)
     with pytest.raises(ValueError):
         decon.decon(vol, psf, 1, 0, 0, 0, 1, False, None, True)  # adaptive needs use_fft (decwrap.py:216-217)
-    with pytest.raises(NotImplementedError):
-        decon.decon(vol, psf, 1, 0, 0, 0, 1, True, (8, 8, 8), True)
+    with pytest.raises(capi.MiError, match="mi_fft_good_size"):
+        decon.decon(vol, psf, 1, 0, 0, 0, 1, True, (10, 8, 8), True)  # deconFFT_Wiener: hand-written FFT extents only
     with pytest.raises(capi.MiError, match="cannot pad"):
         decon.decon(vol, psf, 1, 0, 0, 0, 1, True, (4, 8, 8), False)
     with pytest.raises(ValueError):

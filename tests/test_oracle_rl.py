@@ -118,6 +118,34 @@ def test_spatial_and_fft_variants_agree_away_from_borders():
     assert np.abs(a[core] - b[core]).max() / np.abs(a[core]).max() < 1e-3
 
 
+def test_wiener_variant_structure():
+    # decon.m:206-321 restated: one iteration has no PSF update (== deconFFT); the refined PSF is the clamped, renormalised
+    # centre box of real(ifftn(F{Y} conj F{X} / max(|F{X}|^2, eps))); forcing the run's own PSFs reproduces it exactly
+    rng = np.random.default_rng(9)
+    psf = R.gaussian_psf((5, 5, 7), (1.0, 1.0, 1.5))
+    vol = rng.poisson(R.bead_volume((12, 20, 24), seed=3, psf=psf) * 100 + 5).astype(np.float32)
+    F = (16, 24, 32)
+    one, p1 = R.decon_fft_wiener(vol, psf, F, 1, return_psf=True)
+    assert np.array_equal(one, R.decon_fft(vol, psf, F, 1)) and np.array_equal(p1, psf)
+    trace = []
+    out, p = R.decon_fft_wiener(vol, psf, F, 4, return_psf=True, trace=trace)
+    assert len(trace) == 3 and np.array_equal(trace[-1], p)
+    assert p.shape == psf.shape and p.min() >= 0 and abs(float(p.sum()) - 1) < 1e-6
+    # first update by hand from the state after iteration 1
+    x0, _, _ = R.pad_block_to_fft_shape(R.edgetaper_3d(vol, psf), F)
+    x1, _, _ = R.pad_block_to_fft_shape(R.decon_fft(vol, psf, F, 1), F)
+    fy, fx = np.fft.fftn(x0.astype(np.float64)), np.fft.fftn(x1.astype(np.float64))
+    full = np.real(np.fft.ifftn(fy * np.conj(fx) / np.maximum(np.abs(fx) ** 2, R.EPS_SINGLE)))
+    c = [(f - k) // 2 for f, k in zip(F, psf.shape)]
+    box = np.maximum(full[c[0]:c[0] + 5, c[1]:c[1] + 5, c[2]:c[2] + 7], 0)
+    assert np.abs(box / box.sum() - trace[0]).max() < 1e-4 * trace[0].max()
+    again = R.decon_fft_wiener(vol, psf, F, 4, forced_psfs={i + 2: t for i, t in enumerate(trace)})
+    assert np.array_equal(again, out)
+    # quirks: no i > 1 guard on the stop test (:311-317); Tikhonov needs i < niter (:273)
+    assert np.array_equal(R.decon_fft_wiener(vol, psf, F, 5, 0.0, 99.0), one)
+    assert np.array_equal(R.decon_fft_wiener(vol, psf, F, 1, 0.2, 0.0, 1), R.decon_fft_wiener(vol, psf, F, 1, 0.0, 0.0, 1))
+
+
 def test_regularisation_schedule_and_stop():
     # decon.m:54-55: i>1, i<niter, mod(i,interval)==0, 0<interval<niter
     assert [i for i in range(1, 10) if R.is_regularization_time(i, 9, 3)] == [3, 6]
