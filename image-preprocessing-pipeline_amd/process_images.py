@@ -16,6 +16,16 @@ the shape of DisplacementMIPNCC::getXML (DisplacementMIPNCC.cpp:367-400).
     python process_images.py -3 --input TILES_DIR [--projin xml_displcomp.xml --projout xml_displproj.xml]
     python process_images.py -4 --input TILES_DIR [--threshold 0.65 --projin xml_displproj.xml --projout xml_displthres.xml]
 
+With a TeraStitcher project file the three steps are drop-ins for ``terastitcher -2 / -3 / -4`` between the reference's
+import (``-1``) and placement (``-5``) steps (process_images.py:461-576 builds exactly these command lines):
+
+    python process_images.py -2 --projin xml_import_step_1.xml --projout xml_import_step_2.xml [--sD 10 --subvoldim 100]
+    python process_images.py -3 --projin xml_import_step_2.xml --projout xml_import_step_3.xml
+    python process_images.py -4 --projin xml_import_step_3.xml --projout xml_import_step_4.xml --threshold 0.65
+
+The tiles are then the 2-D TIFF series the project names (``stacks_dir/DIR_NAME``), the overlaps default to the stage
+geometry of the project (``ipp_amd.tsproject``), and the output is the same project with the displacement lists filled in.
+
 Step 3 combines the per-layer records of every pair into the most reliable one per direction
 (StackStitcher::projectDisplacements, Displacement::projectDisplacements, DisplacementMIPNCC::combine); step 4 resets the
 directions whose reliability is below the threshold to the stage displacement and flags the stitchable stacks
@@ -43,7 +53,7 @@ def build_parser():
     p.add_argument("-2", "--displcompute", dest="step2", action="store_true", help="step 2: pairwise displacements (GPU)")
     p.add_argument("-3", "--displproj", dest="step3", action="store_true", help="step 3: projection of the per-layer records")
     p.add_argument("-4", "--displthres", dest="step4", action="store_true", help="step 4: reliability thresholding")
-    p.add_argument("--input", type=Path, required=True, help="folder with tile_<row>_<col>.npy stacks")
+    p.add_argument("--input", type=Path, default=None, help="folder with tile_<row>_<col>.npy stacks (or --projin PROJECT.xml)")
     p.add_argument("--oV", type=int, default=None, help="overlap (pixels) between adjacent tiles along V (step 2)")
     p.add_argument("--oH", type=int, default=None, help="overlap (pixels) between adjacent tiles along H (step 2)")
     p.add_argument("--projin", type=Path, default=None, help="input XML of steps 3 / 4")
@@ -142,8 +152,69 @@ def step4_threshold(args):
     return 0
 
 
+def _is_project(path):
+    """True for a TeraStitcher project file (<TeraStitcher> with <STACKS>), false for the flat pair list of the .npy mode."""
+    if path is None or not Path(path).exists():
+        return False
+    root = ET.parse(path).getroot()
+    return root.tag == "TeraStitcher" and root.find("STACKS") is not None
+
+
+def project_steps(args):
+    """terastitcher -2 / -3 / -4 on a project file: --projin -> --projout."""
+    from ipp_amd import tsproject
+    if args.projout is None:
+        raise SystemExit("--projout is required with a TeraStitcher project")
+    proj = tsproject.Project.load(args.projin)
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if args.step2:
+        import torch
+        from ipp_amd import capi
+        capi.require_gpu()
+        dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+        torch.cuda.set_device(dev)
+        n = proj.computeDisplacements(-1 if args.oV is None else args.oV, -1 if args.oH is None else args.oH, args.sV, args.sH,
+                                      args.sD, args.subvoldim, device=dev, rank=rank, world_size=world)
+        if world > 1:   # per-rank partial projects, merged by rank 0 (mergedisplacements)
+            import torch.distributed as dist
+            proj.save(f"{args.projout}.rank{rank}")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.barrier()
+            if rank == 0:
+                for k in range(1, world):
+                    part = Path(f"{args.projout}.rank{k}")
+                    # adjustDisplacements on load rebuilt the mirrors; only the owning side's lists are merged
+                    other = tsproject.Project.load(part)
+                    for row_a, row_b in zip(proj.STACKS, other.STACKS):
+                        for a, b in zip(row_a, row_b):
+                            a.EAST.extend(b.EAST)
+                            a.SOUTH.extend(b.SOUTH)
+                    part.unlink()
+                Path(f"{args.projout}.rank0").unlink()
+                proj.adjustDisplacements()
+                proj.save(args.projout)
+            dist.barrier()
+            dist.destroy_process_group()
+        else:
+            proj.save(args.projout)
+        if rank == 0:
+            print(f"wrote {args.projout} ({n} displacement records computed by this rank)")
+        return 0
+    if args.step3:
+        proj.projectDisplacements()
+    else:
+        proj.thresholdDisplacements(args.threshold)
+    proj.save(args.projout)
+    print(f"wrote {args.projout}")
+    return 0
+
+
 def main(argv=None):
     args = build_parser().parse_args(argv)
+    if (args.step2 or args.step3 or args.step4) and _is_project(args.projin):
+        return project_steps(args)
+    if args.input is None:
+        raise SystemExit("--input TILES_DIR (tile_<row>_<col>.npy stacks) or --projin PROJECT.xml is required")
     if args.step3:
         return step3_project(args)
     if args.step4:

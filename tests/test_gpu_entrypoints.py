@@ -113,6 +113,59 @@ def test_process_images_steps_3_and_4(dev, tmp_path):
     assert all(s.get("stitchable") == "yes" for s in root.findall("Stack"))
 
 
+def test_process_images_on_a_terastitcher_project(dev, tmp_path):
+    """Steps 2 -> 3 -> 4 as drop-ins for ``terastitcher -2/-3/-4``: a project file in (xml_import), TIFF tiles from its
+    stacks_dir, project files out.  Every per-layer record equals the oracle's PDAlgoMIPNCC::execute on the same slices."""
+    from PIL import Image
+    from ipp_amd import process_images, tsproject
+    tile, ov, slices = (96, 96), 32, 40
+    step = tile[0] - ov
+    field = N.bead_field((slices, 2 * step + ov, 2 * step + ov), seed=9, density=1 / 300)
+    proj = tsproject.Project(tmp_path / "tiles", 2, 2, slices, VXL=(0.8, 0.8, 2.0), MEC=(step * 0.8, step * 0.8))
+    tiles = {}
+    for r in range(2):
+        for c in range(2):
+            name = f"{r:03d}/{r:03d}_{c:03d}"
+            (tmp_path / "tiles" / name).mkdir(parents=True)
+            # a real shift on the east tiles so that the displacement differs from the stage offset
+            dv, dh = (2, -3) if c == 1 else (0, 0)
+            t = np.roll(field, (dv, dh), axis=(1, 2))[:, r * step:r * step + tile[0], c * step:c * step + tile[1]]
+            q = np.clip(np.rint(t * 65535), 0, 65535).astype(np.uint16)
+            for z in range(slices):
+                Image.fromarray(q[z]).save(tmp_path / "tiles" / name / f"{z:06d}.tif")
+            tiles[(r, c)] = q.astype(np.float32) / np.float32(65535)
+            proj.STACKS[r][c] = tsproject.Stack(r, c, name, ABS_V=r * step, ABS_H=c * step, N_BYTESxCHAN=2, z_ranges=[(0, slices)])
+    x1, x2, x3, x4 = (tmp_path / f"xml_import_step_{k}.xml" for k in (1, 2, 3, 4))
+    proj.save(x1)
+    assert process_images.main(["-2", "--sV", "6", "--sH", "6", "--sD", "1", "--subvoldim", "20", "--threshold", "0.65",
+                                f"--projin={x1}", f"--projout={x2}"]) == 0
+    comp = tsproject.Project.load(x2)
+    assert comp.getOVERLAP_V() == ov and comp.getDEFAULT_DISPLACEMENT_H() == step
+    layers = [(0, 20), (20, 40)]
+    for (r, c, rb, cb, side_name, side) in [(0, 0, 0, 1, "EAST", 1), (1, 0, 1, 1, "EAST", 1), (0, 0, 1, 0, "SOUTH", 0), (0, 1, 1, 1, "SOUTH", 0)]:
+        recs = getattr(comp.STACKS[r][c], side_name)
+        assert len(recs) == 2
+        for (z0, z1), d in zip(layers, recs):
+            want = N.pdalgo_execute(tiles[(r, c)][z0:z1], tiles[(rb, cb)][z0:z1], 6, 6, 1, side, ov, kind="oracle")
+            assert d.VHD_coords == list(want["coord"]) and d.NCC_widths == list(want["NCC_widths"])
+            assert d.NCC_maxs == pytest.approx([float(v) for v in want["NCC_maxs"]], rel=2e-5)
+            assert d.VHD_def_coords == ([step, 0, 0] if side == 0 else [0, step, 0])
+        mirrored = getattr(comp.STACKS[rb][cb], "WEST" if side else "NORTH")
+        assert [m.VHD_coords for m in mirrored] == [[-v for v in d.VHD_coords] for d in recs]
+    found = comp.STACKS[0][0].EAST[0].VHD_coords[:2]
+    assert found != [0, step] and abs(found[0]) == 2 and abs(found[1] - step) == 3   # the shift of the east tiles was found
+    assert process_images.main(["-3", f"--projin={x2}", f"--projout={x3}"]) == 0
+    assert process_images.main(["-4", "--threshold", "0.65", f"--projin={x3}", f"--projout={x4}"]) == 0
+    done = tsproject.Project.load(x4)
+    for row in done.STACKS:
+        for s in row:
+            assert s.stitchable
+            for lst, n in ((s.NORTH, s.ROW_INDEX == 1), (s.SOUTH, s.ROW_INDEX == 0), (s.WEST, s.COL_INDEX == 1), (s.EAST, s.COL_INDEX == 0)):
+                assert len(lst) == int(n)
+    e = done.STACKS[0][0].EAST[0]
+    assert e.VHD_coords[:2] == found and min(e.rel_factors[:2]) >= 0.65
+
+
 def test_decwrap_block_parallel_workers_equal_sequential(dev, tmp_path):
     """Several blocks, two workers on one device (--gpu-workers-per-gpu 2: own streams, shared output volume) against one
     worker: identical stacks -- the blocks are independent (LsDeconv.m:620-668)."""
