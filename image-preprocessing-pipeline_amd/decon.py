@@ -146,6 +146,19 @@ def gauss3d_gpu(x, sigma, ksize=None):
     return t.cpu().numpy() if was_np else t
 
 
+def filter_subband_3d_z(bl, sigma, levels=0, wavelet="db9"):
+    """``bl = filter_subband_3d_z(bl, sigma, levels, wavelet)`` (filter_subband_3d_z.m:1-43): wavelet + Gaussian-notch destripe
+    of every XZ slice; a CUDA tensor is modified in place.  Only "db9" exists here (what LsDeconv.m:935 passes)."""
+    if str(wavelet) != "db9":
+        raise ValueError(f"filter_subband_3d_z: wavelet {wavelet!r} is not built (LsDeconv.m:935 uses \"db9\")")
+    dev = _device(bl.device if isinstance(bl, torch.Tensor) and bl.is_cuda else None)
+    t, was_np = _to_dev(bl, dev, name="bl")
+    _check3d(t, "bl")
+    nx, ny, nz = _xyz(t.shape)
+    check(lib().mi_destripe_z(dev.index, _stream(t), t.data_ptr(), nx, ny, nz, float(sigma), int(levels)))
+    return t.cpu().numpy() if was_np else t
+
+
 def edgetaper_3d(bl, psf):
     """``bl = edgetaper_3d(bl, psf)`` (edgetaper_3d.m:1-45); a CUDA tensor is modified in place."""
     dev = _device(bl.device if isinstance(bl, torch.Tensor) and bl.is_cuda else None)

@@ -96,7 +96,7 @@ def autosplit(stack_xyz, psf_size_xyz, filt: Filter, block_size_max: int, numit:
     Same ingredients as LsDeconv.m:308-385 -- pad = max(PSF extent, Gaussian pad) per side, FFT shapes rounded
     to 7-smooth, square xy blocks, score = core volume -- without MATLAB's 2^31-element / 1290-per-side gpuArray
     limits and host-RAM terms, which do not exist here."""
-    pad = [0, 0, 0]
+    pad = [1, 1, 1] if filt.destripe_sigma > 0 else [0, 0, 0]                                   # LsDeconv.m:339-340
     if numit > 0:
         pad = [max(a, b) for a, b in zip(pad, decon_pad_size(psf_size_xyz))]
     if any(s > 0 for s in filt.gaussian_sigma):
@@ -190,7 +190,7 @@ def process_block(bl, block: Block, psf, niter, lambda_, stop_criterion, filt: F
         D.decon(t, psf, niter, lambda_, stop_criterion, filt.regularize_interval, gpu, filt.use_fft,
                 block.fft_shape if filt.use_fft else None, filt.adaptive_psf)
     if filt.destripe_sigma > 0:
-        raise NotImplementedError("filter_subband_3d_z (destripe) is out of scope (SURVEY.md section 2.1)")
+        D.filter_subband_3d_z(t, filt.destripe_sigma, 0, "db9")                                 # :934-936
     lb, ub = deconvolved_stats(t, clipval)
     assert tuple(t.shape) == size0, "[process_block]: block size mismatch!"
     return t, lb, ub

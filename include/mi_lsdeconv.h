@@ -187,6 +187,16 @@ int mi_decon(int dev, void* stream, float* bl, const float* psf, const float* ps
              int nx, int ny, int nz, int kx, int ky, int kz, const mi_rl_options* opt,
              int use_fft, const int* fft_shape_xyz, int adaptive_psf, int* iters_done);
 
+/* bl = filter_subband_3d_z(bl, sigma, levels, "db9")   [filter_subband_3d_z.m:1-123; called by process_block, LsDeconv.m:934-936]
+ * log1p, db9 wavelet decomposition of every XZ slice ('sym' extension; odd extents zero-padded to even and cropped again),
+ * Gaussian notch along z on the horizontal-detail sub-bands (g(k) = 1 - exp(-k^2 / (2 (sigma / n)^2)), n = coefficients along z),
+ * reconstruction, expm1.  In place on bl [nz][ny][nx]; levels = 0 picks wmaxlev (mi_destripe_max_levels); with zero levels
+ * (min(nx, nz) < 34) the block is returned unchanged.  Work memory (about 2.5 volumes) comes from the library's pool.
+ * Synchronises. */
+int mi_destripe_z(int dev, void* stream, float* bl, int nx, int ny, int nz, float sigma, int levels);
+/* wmaxlev([nx nz] rounded up to even, 'db9') = fix(log2(min / 17)) */
+int mi_destripe_max_levels(int nx, int nz);
+
 /* cost model used by MI_ENGINE_AUTO: returns MI_ENGINE_DIRECT or MI_ENGINE_FFT */
 int mi_engine_select(int nx, int ny, int nz, int kx, int ky, int kz, int boundary);
 
