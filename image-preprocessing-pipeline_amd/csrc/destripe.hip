@@ -12,7 +12,9 @@
 //              with sigma / n << 1 that is the mean along z only
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
+#include <cstdint>
 #include <utility>
 #include <vector>
 
@@ -63,94 +65,183 @@ inline unsigned grid_for(size_t n_items) {
     return static_cast<unsigned>(b < 1 ? 1 : (b > cap ? cap : b));
 }
 
-// analysis along z: in [nz_in][rows] (rows = Y * nx, unit stride) -> lo, hi [mz][rows].  n_valid <= nz_in: planes at and beyond
-// n_valid are the zero padding to an even extent (:50-51); LOG1P: the input is the raw block (level 1)
-template <bool LOG1P>
+// analysis along z: in [n_valid][rows] (rows = Y * nx, unit stride) -> lo, hi [m][rows].  One thread per column and z chunk,
+// sliding an 18-sample window down the column: every input is read (and its log1p taken) once per chunk, two new samples per
+// output.  Planes at and beyond n_valid are the zero padding to the even extent n (:50-51); LOG1P: the input is the raw block.
+// With w[q] = x[2 i - 16 + q]: out[i] = sum_t F_D[t] x[2 i + 1 - t] = sum_q F_R[q] w[q]  (F_D is F_R reversed)
+template <int V> struct VecOf;
+template <> struct VecOf<1> { using type = float; };
+template <> struct VecOf<4> { using type = float4; };
+__device__ __forceinline__ float vget(const float& v, int) { return v; }
+__device__ __forceinline__ float& vref(float& v, int) { return v; }
+__device__ __forceinline__ float vget(const float4& v, int c) { return c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w; }
+__device__ __forceinline__ float& vref(float4& v, int c) { return c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w; }
+
+// V = 4: a lane owns four neighbouring columns (16-byte accesses; rows % 4 == 0 and aligned bases), which keeps enough bytes
+// in flight per lane for the two loads per step to cover the HBM latency
+template <bool LOG1P, int V>
 __global__ __launch_bounds__(kThreads) void k_dwt_z(const float* __restrict__ in, float* __restrict__ lo, float* __restrict__ hi,
-                                                   size_t rows, int n, int n_valid, int m, Filters f) {
-    const size_t total = rows * (size_t)m;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int i = (int)(idx / rows);
-        const size_t r = idx - (size_t)i * rows;
-        float al = 0.0f, ah = 0.0f;
+                                                   size_t rows, int n, int n_valid, int m, int chunk, Filters f) {
+    using T = typename VecOf<V>::type;
+    const size_t r = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * V;
+    if (r >= rows) return;
+    const int i0 = blockIdx.y * chunk, i1 = min(m, i0 + chunk);
+    auto sample = [&](int j) {
+        const int jj = sym_index(j, n);
+        T v = T();
+        if (jj < n_valid) {
+            v = *reinterpret_cast<const T*>(in + (size_t)jj * rows + r);
+            if (LOG1P) {
 #pragma unroll
-        for (int t = 0; t < LF; ++t) {
-            const int j = sym_index(2 * i + 1 - t, n);
-            float v = 0.0f;
-            if (j < n_valid) {
-                v = in[(size_t)j * rows + r];
-                if (LOG1P) v = log1pf(v);
+                for (int c = 0; c < V; ++c) vref(v, c) = log1pf(vget(v, c));
             }
-            al += f.lo_d[t] * v;
-            ah += f.hi_d[t] * v;
         }
-        lo[idx] = al;
-        hi[idx] = ah;
-    }
-}
-
-// analysis along x: in [lines][n] -> lo, hi [lines][m]; columns at and beyond n_valid (of the stored row pitch n_pitch) are zero
-// padding.  LOG1P never applies here (z runs first)
-__global__ __launch_bounds__(kThreads) void k_dwt_x(const float* __restrict__ in, float* __restrict__ lo, float* __restrict__ hi,
-                                                   size_t lines, int n, int n_valid, int n_pitch, int m, Filters f) {
-    const size_t total = lines * (size_t)m;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const size_t line = idx / m;
-        const int i = (int)(idx - line * m);
-        const float* row = in + line * n_pitch;
-        float al = 0.0f, ah = 0.0f;
+        return v;
+    };
+    T w[LF];
 #pragma unroll
-        for (int t = 0; t < LF; ++t) {
-            const int j = sym_index(2 * i + 1 - t, n);
-            const float v = j < n_valid ? row[j] : 0.0f;
-            al += f.lo_d[t] * v;
-            ah += f.hi_d[t] * v;
+    for (int q = 2; q < LF; ++q) w[q] = sample(2 * i0 - 16 + q - 2);  // the first step shifts these into place
+    for (int i = i0; i < i1; ++i) {
+#pragma unroll
+        for (int q = 0; q < LF - 2; ++q) w[q] = w[q + 2];
+        w[LF - 2] = sample(2 * i);
+        w[LF - 1] = sample(2 * i + 1);
+        T al = T(), ah = T();
+#pragma unroll
+        for (int q = 0; q < LF; ++q) {
+#pragma unroll
+            for (int c = 0; c < V; ++c) {
+                vref(al, c) += f.lo_r[q] * vget(w[q], c);
+                vref(ah, c) += f.hi_r[q] * vget(w[q], c);
+            }
         }
-        lo[idx] = al;
-        hi[idx] = ah;
+        *reinterpret_cast<T*>(lo + (size_t)i * rows + r) = al;
+        *reinterpret_cast<T*>(hi + (size_t)i * rows + r) = ah;
     }
 }
 
-// synthesis along x: a, d [lines][m] -> out [lines][s]
+constexpr int kTileX = kThreads;       // pairs of the x synthesis per work-group (one per lane)
+constexpr int kTileA = 2 * kThreads;   // outputs of the x analysis per work-group (two per lane)
+
+// analysis along x: in [lines][n_pitch] -> lo, hi [lines][m].  One work-group per line segment: the 2 * kTileA + 16 inputs of
+// kTileA outputs are staged in LDS with unit-stride loads (columns at and beyond n_valid are the zero padding); a lane takes
+// the 20 inputs of its two outputs as five 16-byte LDS reads
+__global__ __launch_bounds__(kThreads) void k_dwt_x(const float* __restrict__ in, float* __restrict__ lo, float* __restrict__ hi,
+                                                   int n, int n_valid, int n_pitch, int m, int tiles, Filters f) {
+    __shared__ __attribute__((aligned(16))) float seg[2 * kTileA + 20];
+    const size_t line = blockIdx.x / tiles;
+    const int i0 = (int)(blockIdx.x - line * tiles) * kTileA;
+    const float* row = in + line * (size_t)n_pitch;
+    const int j0 = 2 * i0 - 16;                                          // seg[q] = x[j0 + q]
+    if (j0 >= 0 && j0 + 2 * kTileA + 20 <= n_valid) {                    // interior segment: no reflection, no padding
+        for (int q = threadIdx.x; q < 2 * kTileA + 20; q += kThreads) seg[q] = row[j0 + q];
+    } else {
+        for (int q = threadIdx.x; q < 2 * kTileA + 20; q += kThreads) {
+            const int j = sym_index(j0 + q, n);
+            seg[q] = j < n_valid ? row[j] : 0.0f;
+        }
+    }
+    __syncthreads();
+    const int i = i0 + 2 * threadIdx.x;
+    if (i >= m) return;
+    float w[20];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        const float4 v = *reinterpret_cast<const float4*>(&seg[4 * threadIdx.x + 4 * q]);
+        w[4 * q] = v.x;
+        w[4 * q + 1] = v.y;
+        w[4 * q + 2] = v.z;
+        w[4 * q + 3] = v.w;
+    }
+    float al0 = 0.0f, ah0 = 0.0f, al1 = 0.0f, ah1 = 0.0f;
+#pragma unroll
+    for (int q = 0; q < LF; ++q) {
+        al0 += f.lo_r[q] * w[q];
+        ah0 += f.hi_r[q] * w[q];
+        al1 += f.lo_r[q] * w[q + 2];
+        ah1 += f.hi_r[q] * w[q + 2];
+    }
+    const size_t o = line * (size_t)m + i;
+    lo[o] = al0;
+    hi[o] = ah0;
+    if (i + 1 < m) {
+        lo[o + 1] = al1;
+        hi[o + 1] = ah1;
+    }
+}
+
+// synthesis along x: a, d [lines][m] -> out [lines][s].  Both outputs of a pair (2 p, 2 p + 1) use a[p .. p + 8], d[p .. p + 8]
+// (taps 2 (8 - c) and 2 (8 - c) + 1 for k = p + c); coefficients beyond m do not exist (zero)
 __global__ __launch_bounds__(kThreads) void k_idwt_x(const float* __restrict__ a, const float* __restrict__ d, float* __restrict__ out,
-                                                    size_t lines, int m, int s, Filters f) {
-    const size_t total = lines * (size_t)s;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const size_t line = idx / s;
-        const int j = (int)(idx - line * s);
-        const float* ra = a + line * m;
-        const float* rd = d + line * m;
-        // taps t = j + LF - 2 - 2k in [0, LF): k from ceil((j - 1) / 2) to floor((j + LF - 2) / 2)
-        const int k0 = j <= 0 ? 0 : j / 2, k1 = min(m - 1, (j + LF - 2) / 2);
-        float acc = 0.0f;
-        for (int k = k0; k <= k1; ++k) {
-            const int t = j + LF - 2 - 2 * k;
-            acc += ra[k] * f.lo_r[t] + rd[k] * f.hi_r[t];
-        }
-        out[idx] = acc;
+                                                    int m, int s, int tiles, Filters f) {
+    __shared__ float sa[kTileX + 8], sd[kTileX + 8];
+    const size_t line = blockIdx.x / tiles;
+    const int p0 = (int)(blockIdx.x - line * tiles) * kTileX;
+    for (int q = threadIdx.x; q < kTileX + 8; q += kThreads) {
+        const int k = p0 + q;
+        sa[q] = k < m ? a[line * (size_t)m + k] : 0.0f;
+        sd[q] = k < m ? d[line * (size_t)m + k] : 0.0f;
     }
+    __syncthreads();
+    const int p = p0 + threadIdx.x;
+    if (2 * p >= s) return;
+    float e = 0.0f, o = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+        const float va = sa[threadIdx.x + c], vd = sd[threadIdx.x + c];
+        e += va * f.lo_r[2 * (8 - c)] + vd * f.hi_r[2 * (8 - c)];
+        o += va * f.lo_r[2 * (8 - c) + 1] + vd * f.hi_r[2 * (8 - c) + 1];
+    }
+    float* dst = out + line * (size_t)s + 2 * p;
+    dst[0] = e;
+    if (2 * p + 1 < s) dst[1] = o;
 }
 
-// synthesis along z: a, d [m][rows] -> out [s_out][rows_out]; EXPM1: the final level writes expm1 into the block, whose rows are
-// narrower than the even-padded working rows when nx is odd (crop, :86-88)
+// synthesis along z: a, d [m][rows] -> out [s][rows_out]; one thread per output column and z chunk, a 9-coefficient window of
+// a and of d slides down the column.  EXPM1: the final level writes expm1 into the block, whose rows are narrower than the
+// even-padded working rows when nx is odd (crop, :86-88)
 template <bool EXPM1>
 __global__ __launch_bounds__(kThreads) void k_idwt_z(const float* __restrict__ a, const float* __restrict__ d, float* __restrict__ out,
-                                                    int ny, int nx_work, int nx_out, int m, int s, Filters f) {
+                                                    int ny, int nx_work, int nx_out, int m, int s, int chunk, Filters f) {
     const size_t rows_out = (size_t)ny * nx_out, rows = (size_t)ny * nx_work;
-    const size_t total = rows_out * (size_t)s;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int j = (int)(idx / rows_out);
-        const size_t r = idx - (size_t)j * rows_out;
-        const size_t y = r / nx_out, x = r - y * nx_out;
-        const size_t rw = y * nx_work + x;
-        const int k0 = j <= 0 ? 0 : j / 2, k1 = min(m - 1, (j + LF - 2) / 2);
-        float acc = 0.0f;
-        for (int k = k0; k <= k1; ++k) {
-            const int t = j + LF - 2 - 2 * k;
-            acc += a[(size_t)k * rows + rw] * f.lo_r[t] + d[(size_t)k * rows + rw] * f.hi_r[t];
-        }
-        out[idx] = EXPM1 ? expm1f(acc) : acc;
+    const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows_out) return;
+    const size_t y = r / nx_out, x = r - y * nx_out;
+    const size_t rw = y * nx_work + x;
+    const int p0 = blockIdx.y * chunk, p1 = min((s + 1) / 2, p0 + chunk);
+    float wa[9], wd[9];
+#pragma unroll
+    for (int c = 1; c < 9; ++c) {
+        const int k = p0 + c - 1;
+        wa[c] = k < m ? a[(size_t)k * rows + rw] : 0.0f;
+        wd[c] = k < m ? d[(size_t)k * rows + rw] : 0.0f;
     }
+    for (int p = p0; p < p1; ++p) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            wa[c] = wa[c + 1];
+            wd[c] = wd[c + 1];
+        }
+        const int k = p + 8;
+        wa[8] = k < m ? a[(size_t)k * rows + rw] : 0.0f;
+        wd[8] = k < m ? d[(size_t)k * rows + rw] : 0.0f;
+        float e = 0.0f, o = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) {
+            e += wa[c] * f.lo_r[2 * (8 - c)] + wd[c] * f.hi_r[2 * (8 - c)];
+            o += wa[c] * f.lo_r[2 * (8 - c) + 1] + wd[c] * f.hi_r[2 * (8 - c) + 1];
+        }
+        out[(size_t)(2 * p) * rows_out + r] = EXPM1 ? expm1f(e) : e;
+        if (2 * p + 1 < s) out[(size_t)(2 * p + 1) * rows_out + r] = EXPM1 ? expm1f(o) : o;
+    }
+}
+
+// z chunking of the column kernels: enough threads for the device when a level has few columns
+inline int z_chunks(size_t columns, int steps) {
+    const size_t want = 256 * 2048;  // lanes in flight on 256 CUs
+    size_t c = columns >= want ? 1 : (want + columns - 1) / columns;
+    const size_t most = (size_t)std::max(1, steps / 16);
+    return (int)std::min(c, most);
 }
 
 // notch along z on H [n][rows]: one frequency bin per launch, one thread per column.  F_k in double; the bin's share of the
@@ -267,21 +358,29 @@ extern "C" int mi_destripe_z(int dev, void* stream, float* bl, int nx, int ny, i
     for (int l = 1; l <= levels; ++l) {
         const int nzl = sz[l - 1], nxl = sx[l - 1], mz = sz[l], mx = sx[l];
         const size_t lines = (size_t)mz * Y;
-        if (l == 1) {
-            // the block's rows are nx wide (no x padding stored): z analysis over [nz][Y * nx], the pad column appears in x
-            hipLaunchKernelGGL(k_dwt_z<true>, dim3(grid_for((size_t)mz * Y * nx)), dim3(kThreads), 0, s, bl, ZL.as<float>(), ZH.as<float>(),
-                               Y * nx, nzl, nz, mz, f);
-        } else {
-            hipLaunchKernelGGL(k_dwt_z<false>, dim3(grid_for((size_t)mz * Y * nxl)), dim3(kThreads), 0, s, A[l - 1].as<float>(),
-                               ZL.as<float>(), ZH.as<float>(), Y * nxl, nzl, nzl, mz, f);
-        }
+        // level 1 reads the block itself: rows are nx wide (no x padding stored), planes beyond nz are the zero padding
+        const int pitch = l == 1 ? nx : nxl;
+        const size_t cols = Y * (size_t)pitch;
+        const int zc = z_chunks(cols, mz), zchunk = (mz + zc - 1) / zc;
+        const float* zin = l == 1 ? bl : A[l - 1].as<float>();
+        const bool vec4 = cols % 4 == 0 && ((uintptr_t)zin % 16) == 0;  // pool blocks are 256-byte aligned
+        const size_t lanes = vec4 ? cols / 4 : cols;
+        const dim3 zgrid((unsigned)((lanes + kThreads - 1) / kThreads), (unsigned)((mz + zchunk - 1) / zchunk));
+        const int zvalid = l == 1 ? nz : nzl;
+#define MI_DWT_Z(LOG, VW) \
+    hipLaunchKernelGGL((k_dwt_z<LOG, VW>), zgrid, dim3(kThreads), 0, s, zin, ZL.as<float>(), ZH.as<float>(), cols, nzl, zvalid, mz, zchunk, f)
+        if (l == 1) { if (vec4) MI_DWT_Z(true, 4); else MI_DWT_Z(true, 1); }
+        else { if (vec4) MI_DWT_Z(false, 4); else MI_DWT_Z(false, 1); }
+#undef MI_DWT_Z
         MI_TRY(launch_check("k_dwt_z"));
-        const int valid = l == 1 ? nx : nxl, pitch = l == 1 ? nx : nxl;
-        hipLaunchKernelGGL(k_dwt_x, dim3(grid_for(lines * mx)), dim3(kThreads), 0, s, ZL.as<float>(), A[l].as<float>(), H[l].as<float>(),
-                           lines, nxl, valid, pitch, mx, f);
+        const int tiles = (mx + kTileA - 1) / kTileA;
+        MI_REQUIRE(lines * (size_t)tiles < 0x7fffffffull, "filter_subband_3d_z: block too large for one launch");
+        const dim3 xgrid((unsigned)(lines * tiles));
+        hipLaunchKernelGGL(k_dwt_x, xgrid, dim3(kThreads), 0, s, ZL.as<float>(), A[l].as<float>(), H[l].as<float>(), nxl, pitch, pitch, mx,
+                           tiles, f);
         MI_TRY(launch_check("k_dwt_x"));
-        hipLaunchKernelGGL(k_dwt_x, dim3(grid_for(lines * mx)), dim3(kThreads), 0, s, ZH.as<float>(), V[l].as<float>(), D[l].as<float>(),
-                           lines, nxl, valid, pitch, mx, f);
+        hipLaunchKernelGGL(k_dwt_x, xgrid, dim3(kThreads), 0, s, ZH.as<float>(), V[l].as<float>(), D[l].as<float>(), nxl, pitch, pitch, mx,
+                           tiles, f);
         MI_TRY(launch_check("k_dwt_x"));
         // horizontal details of this level: notch along z with sigma / size(H, 2) (:69-73)
         MI_TRY(notch_z(s, H[l].as<float>(), ZL.as<float>(), Y * mx, mz, (double)sigma / (double)mz));  // ZL is free again
@@ -290,19 +389,22 @@ extern "C" int mi_destripe_z(int dev, void* stream, float* bl, int nx, int ny, i
     for (int l = levels; l >= 1; --l) {
         const int mz = sz[l], mx = sx[l], sxo = sx[l - 1], szo = sz[l - 1];
         const size_t lines = (size_t)mz * Y;
-        hipLaunchKernelGGL(k_idwt_x, dim3(grid_for(lines * sxo)), dim3(kThreads), 0, s, A[l].as<float>(), H[l].as<float>(), ZL.as<float>(),
-                           lines, mx, sxo, f);
+        const int tiles = ((sxo + 1) / 2 + kTileX - 1) / kTileX;
+        const dim3 xgrid((unsigned)(lines * tiles));
+        hipLaunchKernelGGL(k_idwt_x, xgrid, dim3(kThreads), 0, s, A[l].as<float>(), H[l].as<float>(), ZL.as<float>(), mx, sxo, tiles, f);
         MI_TRY(launch_check("k_idwt_x"));
-        hipLaunchKernelGGL(k_idwt_x, dim3(grid_for(lines * sxo)), dim3(kThreads), 0, s, V[l].as<float>(), D[l].as<float>(), ZH.as<float>(),
-                           lines, mx, sxo, f);
+        hipLaunchKernelGGL(k_idwt_x, xgrid, dim3(kThreads), 0, s, V[l].as<float>(), D[l].as<float>(), ZH.as<float>(), mx, sxo, tiles, f);
         MI_TRY(launch_check("k_idwt_x"));
-        if (l == 1) {  // into the block: crop the even padding (:86-88), expm1 (:30)
-            hipLaunchKernelGGL(k_idwt_z<true>, dim3(grid_for((size_t)nz * Y * nx)), dim3(kThreads), 0, s, ZL.as<float>(), ZH.as<float>(), bl,
-                               ny, sxo, nx, mz, nz, f);
-        } else {
-            hipLaunchKernelGGL(k_idwt_z<false>, dim3(grid_for((size_t)szo * Y * sxo)), dim3(kThreads), 0, s, ZL.as<float>(), ZH.as<float>(),
-                               A[l - 1].as<float>(), ny, sxo, sxo, mz, szo, f);
-        }
+        const int s_out = l == 1 ? nz : szo, nx_out = l == 1 ? nx : sxo;  // level 1: crop the even padding (:86-88), expm1 (:30)
+        const size_t cols = Y * (size_t)nx_out;
+        const int pairs = (s_out + 1) / 2, zc = z_chunks(cols, pairs), zchunk = (pairs + zc - 1) / zc;
+        const dim3 zgrid((unsigned)((cols + kThreads - 1) / kThreads), (unsigned)((pairs + zchunk - 1) / zchunk));
+        if (l == 1)
+            hipLaunchKernelGGL(k_idwt_z<true>, zgrid, dim3(kThreads), 0, s, ZL.as<float>(), ZH.as<float>(), bl, ny, sxo, nx_out, mz, s_out,
+                               zchunk, f);
+        else
+            hipLaunchKernelGGL(k_idwt_z<false>, zgrid, dim3(kThreads), 0, s, ZL.as<float>(), ZH.as<float>(), A[l - 1].as<float>(), ny, sxo,
+                               nx_out, mz, s_out, zchunk, f);
         MI_TRY(launch_check("k_idwt_z"));
     }
     MI_HIP(hipStreamSynchronize(s));  // the work buffers die here

@@ -1,8 +1,8 @@
 """Time of mi_destripe_z (filter_subband_3d_z) on block-sized volumes; prints ms and the effective GB/s over the 2 x volume
 bytes the filter must move at least (read + write of the block)."""
-import sys, time
+import os, sys, time
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ipp_amd import decon
 
 dev = torch.device("cuda", 0)
