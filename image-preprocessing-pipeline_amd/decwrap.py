@@ -119,7 +119,8 @@ def main(argv=None):
     gpus = get_all_gpu_indices()
     args = build_parser(gpus).parse_args(argv)
     validate_args(args)
-    out_dir = (args.input.parent if args.input.is_file() else args.input) / "deconvolved"
+    out_dir = (args.input.parent if args.input.is_file() else args.input) / (
+        "deconvolved_flipped_upside_down" if args.flip else "deconvolved")                  # LsDeconv.m:91-94
     cfg = {k: (str(v) if isinstance(v, Path) else v) for k, v in vars(args).items()}
     if args.dry_run:
         print(json.dumps({"would_write": str(out_dir), "config": cfg}, indent=2))
@@ -238,7 +239,7 @@ def main(argv=None):
         q = D.rescale_block(t, scal, args.signal_amp, lo, hi)
         out_int[z0:z0 + slab] = q.cpu().numpy()
     if args.flip:
-        out_int = out_int[::-1]                                                            # flip_upside_down: reversed z order
+        out_int = np.ascontiguousarray(out_int[:, ::-1])                                   # R = flip(R, 2): the y axis (LsDeconv.m:1097-1099)
     np.save(out_dir / f"deconvolved_{bits}bit.npy", out_int)
     if not args.input.is_file() and brickio.list_tiff_series(args.input):
         n_tif = brickio.save_tiff_series(out_dir, out_int)                                 # img_%06d.tif, existing slices kept

@@ -250,3 +250,26 @@ def test_decwrap_tiff_folder_cache_and_resume(dev, tmp_path):
     assert np.array_equal(got[mask], ref[mask])                       # ... the other blocks recomputed, identical
     assert decwrap.main(base + ["--no-resume"]) == 0
     assert np.array_equal(np.load(out / "deconvolved.npy"), ref)
+
+
+def test_decwrap_flip_and_destripe_options(dev, tmp_path):
+    """--flip writes into deconvolved_flipped_upside_down with every slice mirrored along y (LsDeconv.m:91-94, 1097-1099);
+    --destripe-sigma runs filter_subband_3d_z after the deconvolution of a block (LsDeconv.m:934-936)."""
+    from ipp_amd import brickio, decwrap
+    rng = np.random.default_rng(14)
+    vol16 = (rng.random((40, 36, 48)) * 3000 + 200).astype(np.uint16)
+    src = tmp_path / "stack"
+    brickio.save_tiff_series(src, vol16)
+    base = ["-i", str(src), "-dxy", "0.422", "-dz", "1.0", "-ex", "488", "-em", "525", "-it", "2", "--gaussian-sigma", "0", "0", "0",
+            "--gpu-indices", "1"]
+    assert decwrap.main(base) == 0
+    assert decwrap.main(base + ["--flip"]) == 0
+    plain = brickio.load_tiff_series(src / "deconvolved")
+    flipped = brickio.load_tiff_series(src / "deconvolved_flipped_upside_down")
+    assert np.array_equal(flipped, plain[:, ::-1, :])
+    assert np.array_equal(np.load(src / "deconvolved_flipped_upside_down" / "deconvolved.npy"), np.load(src / "deconvolved" / "deconvolved.npy"))
+    # destripe changes the float result, and what it changes it by is the oracle's filter on the padded block
+    (src / "deconvolved").rename(src / "plain")
+    assert decwrap.main(base + ["--destripe-sigma", "2.0"]) == 0
+    a, b = np.load(src / "plain" / "deconvolved.npy"), np.load(src / "deconvolved" / "deconvolved.npy")
+    assert a.shape == b.shape and not np.allclose(a, b, rtol=1e-3)
