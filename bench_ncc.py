@@ -17,13 +17,19 @@ OVERLAP = 307
 DISPL = (25, 25, 10)
 
 
-def make_grid(dev, rows=2, cols=2, seed=1234):
-    """rows x cols tiles cut from one seeded, 3x box-blurred bead field with per-tile integer jitter."""
+GRID = int(os.environ.get("MI_NCC_GRID", "8"))   # BASELINE config 5: an 8 x 8 grid (112 adjacent pairs)
+
+
+def make_grid(dev, rows=GRID, cols=GRID, seed=1234):
+    """rows x cols tiles cut, with per-tile integer jitter, from one seeded, 3x box-blurred bead field that is periodic in y and x
+    with period 2 * step: every pair of adjacent tiles truly overlaps while the field stays small (the 8 x 8 mosaic itself would
+    be 32 GB before blurring)."""
     import torch
     import torch.nn.functional as F
     g = torch.Generator(device=dev).manual_seed(seed)
     step = TILE[1] - OVERLAP
-    shape = (TILE[0] + 8, rows * step + OVERLAP + 16, cols * step + OVERLAP + 16)
+    period = 2 * step
+    shape = (TILE[0] + 8, period, period)
     field = torch.empty(shape, dtype=torch.float32, device=dev).uniform_(0.01, 0.02, generator=g)
     n = field.numel()
     nb = n // 512
@@ -31,17 +37,20 @@ def make_grid(dev, rows=2, cols=2, seed=1234):
     field.view(-1)[idx] = torch.empty(nb, dtype=torch.float32, device=dev).uniform_(0.2, 1.0, generator=g) * 27.0
     f = field[None, None]
     for _ in range(3):
-        f = F.avg_pool3d(F.pad(f, (1, 1, 1, 1, 1, 1), mode="replicate"), 3, stride=1)
+        f = F.pad(F.pad(f, (1, 1, 1, 1, 0, 0), mode="circular"), (0, 0, 0, 0, 1, 1), mode="replicate")
+        f = F.avg_pool3d(f, 3, stride=1)
     field = (f[0, 0] / f.max()).clamp_(0, 1).contiguous()
+    del f
     cpu_g = torch.Generator().manual_seed(seed)
     jit = torch.randint(-5, 6, (rows, cols, 3), generator=cpu_g)
     jit[..., 2] = torch.randint(-2, 3, (rows, cols), generator=cpu_g)
+    ar_v, ar_h = torch.arange(TILE[1], device=dev), torch.arange(TILE[2], device=dev)
     tiles = [[None] * cols for _ in range(rows)]
     for r in range(rows):
         for c in range(cols):
             v, h, d = (int(x) for x in jit[r, c])
-            z0, y0, x0 = 4 + d, 8 + r * step + v, 8 + c * step + h
-            tiles[r][c] = field[z0:z0 + TILE[0], y0:y0 + TILE[1], x0:x0 + TILE[2]].contiguous()
+            ys, xs = (r * step + v + ar_v) % period, (c * step + h + ar_h) % period
+            tiles[r][c] = field[4 + d:4 + d + TILE[0]].index_select(1, ys).index_select(2, xs).contiguous()
     return tiles, jit, step
 
 
@@ -64,7 +73,7 @@ def run(dev, repeats=3, cpu=True):
     n_pairs = len(res)
     out = {"metric": "NCC tile-pairs/sec", "value": round(n_pairs * repeats / dt, 3), "unit": "pairs/s",
            "ms_per_pair": round(dt * 1e3 / (n_pairs * repeats), 3),
-           "workload": f"2x2 grid of {TILE[2]}x{TILE[1]}x{TILE[0]} tiles, overlap {OVERLAP}, search {DISPL}",
+           "workload": f"{len(tiles)}x{len(tiles[0])} grid of {TILE[2]}x{TILE[1]}x{TILE[0]} tiles, overlap {OVERLAP}, search {DISPL}",
            "pairs_with_exact_VH_offsets": f"{ok}/{n_pairs}"}
     if cpu:
         from oracle import ncc_oracle

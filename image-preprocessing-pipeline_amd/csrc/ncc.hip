@@ -307,6 +307,77 @@ __global__ __launch_bounds__(MAP_THREADS, 4) void k_ncc_sat(const float* __restr
     }
 }
 
+// Full maps, register-blocked: one work-group per (2 u) x (8 v) block of shifts and chunk of m2 rows.  A lane owns 4
+// neighbouring m2 columns of a row and, per u, the 11 m1 values its 8 shifts pair them with: 26 loads feed 64 fp64 FMAs, no
+// shuffles, and every MIP row is read once per block instead of once per 4 shifts.  m1 values outside the MIP count as 0,
+// which restricts every shift's sum to its own window.  The chunks' partial cross terms are added up in a fixed order by
+// k_ncc_finish, which also applies the window statistics (deterministic, like the per-group kernel).
+constexpr int BU = 2, BV = 8, BC = 4, BLK_THREADS = 256;
+__global__ __launch_bounds__(BLK_THREADS) void k_ncc_cross_blk(const float* __restrict__ m1, const float* __restrict__ m2, int dimu, int dimv,
+                                                               int du, int dv, int rows_per_chunk, int pu, int pv,
+                                                               double* __restrict__ partial) {
+    __shared__ double sh[BLK_THREADS / 64];
+    const int u0 = (int)blockIdx.y * BU - du, v0 = (int)blockIdx.x * BV - dv;
+    const int r_begin = (int)blockIdx.z * rows_per_chunk, r_end = min(dimu, r_begin + rows_per_chunk);
+    double acc[BU][BV];
+#pragma unroll
+    for (int a = 0; a < BU; ++a)
+#pragma unroll
+        for (int b = 0; b < BV; ++b) acc[a][b] = 0.0;
+    // items = (row, 4-column group) of the chunk, dealt to the lanes in row-major order: narrow MIPs keep every lane busy
+    const int quads = (dimv + BC - 1) / BC, items = (r_end - r_begin) * quads;
+    for (int it = threadIdx.x; it < items; it += BLK_THREADS) {
+        const int rr = it / quads, c = (it - rr * quads) * BC, r2 = r_begin + rr;
+        const float* q = m2 + (size_t)r2 * dimv;
+        double t[BC];
+#pragma unroll
+        for (int x = 0; x < BC; ++x) t[x] = c + x < dimv ? (double)q[c + x] : 0.0;
+#pragma unroll
+        for (int a = 0; a < BU; ++a) {
+            const int r1 = r2 + u0 + a;
+            if (r1 < 0 || r1 >= dimu || u0 + a > du) continue;
+            const float* p = m1 + (size_t)r1 * dimv;
+            double f[BC + BV - 1];
+#pragma unroll
+            for (int k = 0; k < BC + BV - 1; ++k) {
+                const int c1 = c + v0 + k;
+                f[k] = (c1 >= 0 && c1 < dimv) ? (double)p[c1] : 0.0;
+            }
+#pragma unroll
+            for (int b = 0; b < BV; ++b)
+#pragma unroll
+                for (int x = 0; x < BC; ++x) acc[a][b] = fma(f[x + b], t[x], acc[a][b]);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < BU; ++a)
+#pragma unroll
+        for (int b = 0; b < BV; ++b) {
+            const double v = block_sum<BLK_THREADS>(acc[a][b], sh);
+            if (threadIdx.x == 0)
+                partial[((size_t)blockIdx.z * pu + blockIdx.y * BU + a) * pv + blockIdx.x * BV + b] = v;
+        }
+}
+
+// one lane per map entry: cross term = sum of the chunks' partials (fixed order), then the NCC value as in k_ncc_sat
+__global__ __launch_bounds__(256) void k_ncc_finish(const double* __restrict__ partial, int n_chunks, int pu, int pv, int dimu, int dimv, int du,
+                                                    int dv, SatView s1, SatView s2, float* __restrict__ out) {
+    const int W = 2 * dv + 1, n = (2 * du + 1) * W;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const int iu = e / W, iv = e - iu * W, u = iu - du, v = iv - dv;
+    const int nr = dimu - abs(u), nc = dimv - abs(v);
+    if (nr <= 0 || nc <= 0) { out[e] = __int_as_float(0x7fc00000); return; }  // reference: empty loops, 0/0
+    double cr = 0.0;
+    for (int ch = 0; ch < n_chunks; ++ch) cr += partial[((size_t)ch * pu + iu) * pv + iv];
+    double fm, sf, F1, tm, st, F2;
+    window_stats(s1, dimu, dimv, max(u, 0), max(v, 0), nr, nc, &fm, &sf, &F1);
+    window_stats(s2, dimu, dimv, max(-u, 0), max(-v, 0), nr, nc, &tm, &st, &F2);
+    (void)fm; (void)st;
+    const double num = cr - tm * sf;
+    out[e] = (F1 > 0.0 && F2 > 0.0) ? (float)(num / sqrt(F1 * F2)) : __int_as_float(0x7fc00000);
+}
+
 // ------------------------------------------------------------------------------------------------ host logic
 inline int imin(int a, int b) { return a < b ? a : b; }
 inline int imax(int a, int b) { return a > b ? a : b; }
@@ -453,6 +524,7 @@ struct Workspace {
     DevBuf sat;       // doubles: per plane c0, P, Q, TS tables of both MIPs
     SatView v1[3], v2[3];
     DevBuf list;      // ints: {u, v0, count, slot} groups of missing entries
+    DevBuf partial[3]; // doubles: per plane, the row chunks' partial cross terms of a full map
     size_t floats = 0;
     int list_cap = 0;
     std::vector<int> host_groups;
@@ -464,6 +536,29 @@ int ncc_groups(hipStream_t s, const float* base, const PlaneGeom& g, const SatVi
     hipLaunchKernelGGL(k_ncc_sat, dim3(n_groups), dim3(MAP_THREADS), 0, s, base + g.mip1, base + g.mip2, g.dimu, g.dimv, g.delayu,
                        g.delayv, v1, v2, d_groups, d_out);
     return launch_check("k_ncc_sat(groups)");
+}
+
+// full NCC map of one plane: blocked cross terms + finishing pass; `partial` grows as needed
+int ncc_full_map(hipStream_t s, const float* m1, const float* m2, int dimu, int dimv, int delayu, int delayv, const SatView& v1,
+                 const SatView& v2, DevBuf& partial, float* d_map) {
+    const int nub = (2 * delayu + 1 + BU - 1) / BU, nvb = (2 * delayv + 1 + BV - 1) / BV;
+    const int pu = nub * BU, pv = nvb * BV;
+    int chunks = (1536 + nub * nvb - 1) / (nub * nvb);          // enough work-groups for 256 CUs
+    chunks = imax(1, imin(chunks, (dimu + 7) / 8));
+    const int rows_per_chunk = (dimu + chunks - 1) / chunks;
+    chunks = (dimu + rows_per_chunk - 1) / rows_per_chunk;
+    const size_t need = sizeof(double) * (size_t)chunks * pu * pv;
+    if (partial.bytes < need) {
+        MI_HIP(hipStreamSynchronize(s));  // an earlier map of this stream may still read the old buffer
+        MI_TRY(partial.alloc(need));
+    }
+    hipLaunchKernelGGL(k_ncc_cross_blk, dim3(nvb, nub, chunks), dim3(BLK_THREADS), 0, s, m1, m2, dimu, dimv, delayu, delayv, rows_per_chunk, pu,
+                       pv, partial.as<double>());
+    MI_TRY(launch_check("k_ncc_cross_blk"));
+    const int n = (2 * delayu + 1) * (2 * delayv + 1);
+    hipLaunchKernelGGL(k_ncc_finish, dim3((n + 255) / 256), dim3(256), 0, s, partial.as<double>(), chunks, pu, pv, dimu, dimv, delayu, delayv, v1,
+                       v2, d_map);
+    return launch_check("k_ncc_finish");
 }
 
 // compute_Neighborhood (compute_funcs.cu:1324-1592): win = (2wu+1)x(2wv+1) window around the peak,
@@ -629,9 +724,8 @@ int pair_enqueue(hipStream_t s, const float* A, const float* B, int dimi, int di
         const PlaneGeom& g = pl.g[m];
         MI_TRY(prepare_plane(s, base + g.mip1, base + g.mip2, g.dimu, g.dimv, base + g.ps1, base + g.ps2, ws.sat.as<double>() + g.sat,
                              &ws.v1[m], &ws.v2[m]));
-        hipLaunchKernelGGL(k_ncc_sat, dim3((2 * g.delayu + 1) * ((2 * g.delayv + 1 + VB - 1) / VB)), dim3(MAP_THREADS), 0, s, base + g.mip1,
-                           base + g.mip2, g.dimu, g.dimv, g.delayu, g.delayv, ws.v1[m], ws.v2[m], (const int*)nullptr, base + g.map);
-        MI_TRY(launch_check("k_ncc_sat(map)"));
+        MI_TRY(ncc_full_map(s, base + g.mip1, base + g.mip2, g.dimu, g.dimv, g.delayu, g.delayv, ws.v1[m], ws.v2[m], ws.partial[m],
+                            base + g.map));
     }
     MI_TRY(ws.pin_maps.reserve(sizeof(float) * pl.map_floats));
     MI_HIP(hipMemcpyAsync(ws.pin_maps.p, base + pl.map_begin, sizeof(float) * pl.map_floats, hipMemcpyDeviceToHost, s));
@@ -725,10 +819,12 @@ extern "C" int mi_ncc_mips_batch(int dev, void* stream, int n_pairs, const float
     MI_REQUIRE(n_pairs >= 0, "mi_ncc_mips_batch: negative pair count");
     if (n_pairs == 0) return MI_OK;
     MI_REQUIRE(tiles && a_idx && b_idx && ni && nj && side && params && out, "mi_ncc_mips_batch: null pointer");
-    // Two pairs in flight on two internal streams: while the host refines pair q (a few syncs and small launches), the
-    // MIP / table / map kernels of pair q + 1 run.  Both streams start after, and are joined back into, `stream`.
+    // NS pairs in flight on NS internal streams: while the host refines pair q (a few syncs and small launches), the MIP /
+    // table / map kernels of the following pairs run; few of those kernels fill the device on their own, so the streams also
+    // overlap each other.  All streams start after, and are joined back into, `stream`.
+    constexpr int NS = 4;
     hipStream_t user = as_stream(stream);
-    struct Slot { Workspace ws; PairPlan pl; hipStream_t s = nullptr; int q = -1; } slot[2];
+    struct Slot { Workspace ws; PairPlan pl; hipStream_t s = nullptr; int q = -1; } slot[NS];
     hipEvent_t ev = nullptr;
     int rc = MI_OK;
     auto cleanup = [&]() {
@@ -741,17 +837,18 @@ extern "C" int mi_ncc_mips_batch(int dev, void* stream, int n_pairs, const float
     for (auto& sl : slot)
         if (rc == MI_OK && (hipStreamCreateWithFlags(&sl.s, hipStreamNonBlocking) != hipSuccess || hipStreamWaitEvent(sl.s, ev, 0) != hipSuccess))
             rc = fail(MI_ERR_HIP, "mi_ncc_mips_batch: stream setup failed");
-    for (int q = 0; q <= n_pairs && rc == MI_OK; ++q) {
+    for (int q = 0; q < n_pairs + NS - 1 && rc == MI_OK; ++q) {
         if (q < n_pairs) {
-            Slot& sl = slot[q & 1];
+            Slot& sl = slot[q % NS];  // its previous pair, q - NS, was finished in the step before
             if (!tiles[a_idx[q]] || !tiles[b_idx[q]]) { rc = fail(MI_ERR_INVALID, "mi_ncc_mips_batch: null tile for pair %d", q); break; }
             rc = plan_pair(dimk, dimi, dimj, 0, ni[q], nj[q], delayk, delayi, delayj, side[q], &params[q], sl.pl);
             if (rc == MI_OK) rc = pair_enqueue(sl.s, tiles[a_idx[q]], tiles[b_idx[q]], dimi, dimj, sl.pl, sl.ws);
             sl.q = q;
         }
-        if (q >= 1 && rc == MI_OK) {
-            Slot& pr = slot[(q - 1) & 1];
-            rc = pair_finish(pr.s, ni[q - 1], nj[q - 1], side[q - 1], &params[q - 1], pr.pl, pr.ws, &out[q - 1]);
+        const int f = q - (NS - 1);
+        if (f >= 0 && f < n_pairs && rc == MI_OK) {
+            Slot& pr = slot[f % NS];
+            rc = pair_finish(pr.s, ni[f], nj[f], side[f], &params[f], pr.pl, pr.ws, &out[f]);
         }
     }
     cleanup();
@@ -787,9 +884,8 @@ extern "C" int mi_ncc_compute_map(int dev, void* stream, const float* mip1, cons
     MI_TRY(sat.alloc(sizeof(double) * SatLayout(dimu, dimv).total));
     SatView v1, v2;
     MI_TRY(prepare_plane(s, mip1, mip2, dimu, dimv, ps.as<float>(), ps.as<float>() + (nt > 0 ? nt : 0), sat.as<double>(), &v1, &v2));
-    hipLaunchKernelGGL(k_ncc_sat, dim3((2 * delayu + 1) * ((2 * delayv + 1 + VB - 1) / VB)), dim3(MAP_THREADS), 0, s, mip1, mip2, dimu, dimv,
-                       delayu, delayv, v1, v2, (const int*)nullptr, map);
-    MI_TRY(launch_check("k_ncc_sat(map)"));
-    MI_HIP(hipStreamSynchronize(s));  // ps / sat die at scope exit
+    DevBuf partial;
+    MI_TRY(ncc_full_map(s, mip1, mip2, dimu, dimv, delayu, delayv, v1, v2, partial, map));
+    MI_HIP(hipStreamSynchronize(s));  // ps / sat / partial die at scope exit
     return MI_OK;
 }
