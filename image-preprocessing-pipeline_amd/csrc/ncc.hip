@@ -11,9 +11,9 @@
 //   k_mip_mean / k_sat_rows / k_sat_cols   fp64 summed-area tables of (f - c0), (f - c0)^2 and of the float tile sums:
 //                 every term of compute_NCC (:1163-1292) except the cross term sum f*t becomes O(1) per shift, with
 //                 the reference's means (float tile sums + border pixels) reproduced exactly.
-//   k_ncc_sat     one work-group per (u, 4 consecutive v): accumulates the four cross terms in fp64 from shared
-//                 loads (wave shuffles), fixed reduction tree; replaces gpu_NCC_map/gpu_NCC_miss (:730-935).
-//                 Serves full maps and the "missing entry" groups of the neighbourhood refinement alike.
+//   k_ncc_blk / k_ncc_finish   cross terms sum f*t in fp64 for blocks of 2 x 8 shifts from LDS-staged MIP rows, partial sums per
+//                 row chunk added in a fixed order; replaces gpu_NCC_map/gpu_NCC_miss (:730-935).  Serves full maps and the
+//                 "missing entries" of the neighbourhood refinement alike.
 // Host side (this file, plain C++): argmax, neighbourhood refinement, peak widths and the final
 // alignment rules, kept bit-identical in float/int arithmetic to compute_funcs.cu:160-342,1294-1609.
 #include <cmath>
@@ -223,130 +223,65 @@ __global__ __launch_bounds__(64) void k_sat_cols(int dimu, int dimv, double* __r
     }
 }
 
-// NCC map / group lists: VB = 4 consecutive v shifts of one u per work-group.  For a fixed u the four shifts pair the SAME
-// m2 pixel (r2, c2) with m1 pixels (r1, c2 + v0 + k): each lane loads one value of each MIP per 64-column chunk and gets the
-// neighbours through wave shuffles; only the cross term  sum f*t  (exact fp32 products accumulated in fp64, fixed reduction
-// tree) is accumulated here, the window statistics come from the summed-area tables.
-constexpr int VB = 4;
-constexpr int MAP_THREADS = 1024;  // 16 waves: a map has only (2du+1)*ceil((2dv+1)/4) work-groups
-__global__ __launch_bounds__(MAP_THREADS, 4) void k_ncc_sat(const float* __restrict__ m1, const float* __restrict__ m2, int dimu, int dimv,
-                                                            int du, int dv, SatView s1, SatView s2, const int* __restrict__ groups,
-                                                            float* __restrict__ out) {
-    __shared__ double sh[MAP_THREADS / 64];
-    // full map: group = (u, 4 consecutive v) in row-major order; list mode (neighbourhood refinement): group q =
-    // {u, v0, count <= 4, first output slot}, the count shifts share u and have consecutive v and consecutive slots
-    int u, v0, cnt, slot0;
-    if (groups) {
-        u = groups[4 * blockIdx.x];
-        v0 = groups[4 * blockIdx.x + 1];
-        cnt = groups[4 * blockIdx.x + 2];
-        slot0 = groups[4 * blockIdx.x + 3];
-    } else {
-        const int ngroups = (2 * dv + 1 + VB - 1) / VB;
-        u = (int)(blockIdx.x / ngroups) - du;
-        v0 = (int)(blockIdx.x % ngroups) * VB - dv;
-        cnt = min(VB, dv - v0 + 1);
-        slot0 = (u + du) * (2 * dv + 1) + (v0 + dv);
-    }
-    const int nr = dimu - abs(u);
-    const int a_u = max(u, 0), b_u = max(-u, 0);
-    int lo[VB], hi[VB];  // valid m2 columns of shift k: [lo, hi)
-    bool live[VB];
-    int c_lo = dimv, c_hi = 0;
-#pragma unroll
-    for (int k = 0; k < VB; ++k) {
-        const int v = v0 + k;
-        const int nc = dimv - abs(v);
-        live[k] = k < cnt && nr > 0 && nc > 0;
-        lo[k] = max(-v, 0);
-        hi[k] = lo[k] + max(nc, 0);
-        if (k < cnt && !live[k] && threadIdx.x == 0) out[slot0 + k] = __int_as_float(0x7fc00000);  // reference: empty loops, 0/0
-        if (live[k]) { c_lo = min(c_lo, lo[k]); c_hi = max(c_hi, hi[k]); }
-    }
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = MAP_THREADS / 64;
-    double cross[VB];
-#pragma unroll
-    for (int k = 0; k < VB; ++k) cross[k] = 0.0;
-    for (int i = wave; i < nr; i += nw) {
-        const float* p = m1 + (size_t)(a_u + i) * dimv;  // m1 row; column = c2 + v0 + k
-        const float* q = m2 + (size_t)(b_u + i) * dimv;  // m2 row; column = c2
-        int c = c_lo + lane;
-        int c1 = c + v0;
-        float fa = (c1 >= 0 && c1 < dimv) ? p[c1] : 0.0f;
-        for (int base = c_lo; base < c_hi; base += 64, c += 64, c1 += 64) {
-            const int c1n = c1 + 64;
-            const float fb = (c1n >= 0 && c1n < dimv) ? p[c1n] : 0.0f;  // next chunk (all lanes take part in the shuffles)
-            const double t = c < dimv ? (double)q[c] : 0.0;
-#pragma unroll
-            for (int k = 0; k < VB; ++k) {
-                float fk = fa;
-                if (k > 0) {
-                    const float from_a = __shfl(fa, (lane + k) & 63, 64), from_b = __shfl(fb, (lane + k) & 63, 64);
-                    fk = (lane + k < 64) ? from_a : from_b;
-                }
-                if (live[k] && c >= lo[k] && c < hi[k]) cross[k] = fma((double)fk, t, cross[k]);
-            }
-            fa = fb;
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < VB; ++k) {
-        if (!live[k]) continue;  // uniform
-        const double cr = block_sum<MAP_THREADS>(cross[k], sh);
-        if (threadIdx.x == 0) {
-            const int v = v0 + k, nc = dimv - abs(v);
-            double fm, sf, F1, tm, st, F2;
-            window_stats(s1, dimu, dimv, a_u, max(v, 0), nr, nc, &fm, &sf, &F1);
-            window_stats(s2, dimu, dimv, b_u, lo[k], nr, nc, &tm, &st, &F2);
-            (void)fm; (void)st;
-            const double num = cr - tm * sf;
-            // a window without variance: the reference's two-pass sums are exactly 0 there and it returns 0/0 = NaN
-            // (compute_funcs.cu:1277-1290); the table differences are exact for such data too, but the cross term is not
-            out[slot0 + k] = (F1 > 0.0 && F2 > 0.0) ? (float)(num / sqrt(F1 * F2)) : __int_as_float(0x7fc00000);
-        }
-    }
-}
-
-// Full maps, register-blocked: one work-group per (2 u) x (8 v) block of shifts and chunk of m2 rows.  A lane owns 4
-// neighbouring m2 columns of a row and, per u, the 11 m1 values its 8 shifts pair them with: 26 loads feed 64 fp64 FMAs, no
-// shuffles, and every MIP row is read once per block instead of once per 4 shifts.  m1 values outside the MIP count as 0,
-// which restricts every shift's sum to its own window.  The chunks' partial cross terms are added up in a fixed order by
-// k_ncc_finish, which also applies the window statistics (deterministic, like the per-group kernel).
+// NCC cross terms, register-blocked: one work-group per block of (2 u) x (8 v) shifts and chunk of m2 rows.  The m1 rows of
+// the block (shifted by v0, zero outside the MIP) and the m2 rows are staged in LDS with unit-stride loads; a lane then owns 4
+// neighbouring m2 columns of a row and, per u, the 11 m1 values its 8 shifts pair them with -- seven 16-byte LDS reads feed
+// 64 fp64 FMAs (exact fp32 products accumulated in fp64).  Zeros outside the MIP restrict every shift's sum to its own window.
+// Blocks come from a regular grid (full maps) or from a list (the "missing entries" of the neighbourhood refinement,
+// gpu_NCC_miss).  The chunks' partial sums are added up in a fixed order by k_ncc_finish, which also applies the window
+// statistics from the summed-area tables: deterministic, whatever the launch geometry.  Replaces gpu_NCC_map / gpu_NCC_miss
+// (compute_funcs.cu:730-935).
 constexpr int BU = 2, BV = 8, BC = 4, BLK_THREADS = 256;
-__global__ __launch_bounds__(BLK_THREADS) void k_ncc_cross_blk(const float* __restrict__ m1, const float* __restrict__ m2, int dimu, int dimv,
-                                                               int du, int dv, int rows_per_chunk, int pu, int pv,
-                                                               double* __restrict__ partial) {
+__global__ __launch_bounds__(BLK_THREADS) void k_ncc_blk(const float* __restrict__ m1, const float* __restrict__ m2, int dimu, int dimv, int du,
+                                                         int dv, int nvb, const int* __restrict__ blocks, int n_blocks, int rows_per_chunk,
+                                                         int R, double* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ double sh[BLK_THREADS / 64];
-    const int u0 = (int)blockIdx.y * BU - du, v0 = (int)blockIdx.x * BV - dv;
-    const int r_begin = (int)blockIdx.z * rows_per_chunk, r_end = min(dimu, r_begin + rows_per_chunk);
+    int u0, v0;
+    if (blocks) {
+        u0 = blocks[2 * blockIdx.x];
+        v0 = blocks[2 * blockIdx.x + 1];
+    } else {
+        u0 = (int)(blockIdx.x / nvb) * BU - du;
+        v0 = (int)(blockIdx.x % nvb) * BV - dv;
+    }
+    const int r_begin = (int)blockIdx.y * rows_per_chunk, r_end = min(dimu, r_begin + rows_per_chunk);
+    const int quads = (dimv + BC - 1) / BC, pitch1 = quads * BC + BV, pitch2 = quads * BC;
+    float* l1 = lds;                            // R + BU - 1 rows of m1: l1[j][x] = m1[rb + u0 + j][v0 + x]
+    float* l2 = lds + (R + BU - 1) * pitch1;    // R rows of m2
     double acc[BU][BV];
 #pragma unroll
     for (int a = 0; a < BU; ++a)
 #pragma unroll
         for (int b = 0; b < BV; ++b) acc[a][b] = 0.0;
-    // items = (row, 4-column group) of the chunk, dealt to the lanes in row-major order: narrow MIPs keep every lane busy
-    const int quads = (dimv + BC - 1) / BC, items = (r_end - r_begin) * quads;
-    for (int it = threadIdx.x; it < items; it += BLK_THREADS) {
-        const int rr = it / quads, c = (it - rr * quads) * BC, r2 = r_begin + rr;
-        const float* q = m2 + (size_t)r2 * dimv;
-        double t[BC];
+    for (int rb = r_begin; rb < r_end; rb += R) {
+        const int nrow = min(R, r_end - rb);
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < (nrow + BU - 1) * pitch1; idx += BLK_THREADS) {
+            const int j = idx / pitch1, x = idx - j * pitch1;
+            const int r1 = rb + u0 + j, c1 = v0 + x;
+            l1[idx] = (r1 >= 0 && r1 < dimu && c1 >= 0 && c1 < dimv) ? m1[(size_t)r1 * dimv + c1] : 0.0f;
+        }
+        for (int idx = threadIdx.x; idx < nrow * pitch2; idx += BLK_THREADS) {
+            const int j = idx / pitch2, x = idx - j * pitch2;
+            l2[idx] = x < dimv ? m2[(size_t)(rb + j) * dimv + x] : 0.0f;
+        }
+        __syncthreads();
+        for (int it = threadIdx.x; it < nrow * quads; it += BLK_THREADS) {
+            const int rr = it / quads, c = (it - rr * quads) * BC;
+            const float4 tq = *reinterpret_cast<const float4*>(l2 + rr * pitch2 + c);
+            const double t[BC] = {(double)tq.x, (double)tq.y, (double)tq.z, (double)tq.w};
 #pragma unroll
-        for (int x = 0; x < BC; ++x) t[x] = c + x < dimv ? (double)q[c + x] : 0.0;
+            for (int a = 0; a < BU; ++a) {
+                const float4* row = reinterpret_cast<const float4*>(l1 + (rr + a) * pitch1 + c);
+                const float4 f0 = row[0], f1 = row[1], f2 = row[2];
+                const double f[12] = {(double)f0.x, (double)f0.y, (double)f0.z, (double)f0.w, (double)f1.x, (double)f1.y,
+                                      (double)f1.z, (double)f1.w, (double)f2.x, (double)f2.y, (double)f2.z, (double)f2.w};
 #pragma unroll
-        for (int a = 0; a < BU; ++a) {
-            const int r1 = r2 + u0 + a;
-            if (r1 < 0 || r1 >= dimu || u0 + a > du) continue;
-            const float* p = m1 + (size_t)r1 * dimv;
-            double f[BC + BV - 1];
+                for (int b = 0; b < BV; ++b)
 #pragma unroll
-            for (int k = 0; k < BC + BV - 1; ++k) {
-                const int c1 = c + v0 + k;
-                f[k] = (c1 >= 0 && c1 < dimv) ? (double)p[c1] : 0.0;
+                    for (int x = 0; x < BC; ++x) acc[a][b] = fma(f[x + b], t[x], acc[a][b]);
             }
-#pragma unroll
-            for (int b = 0; b < BV; ++b)
-#pragma unroll
-                for (int x = 0; x < BC; ++x) acc[a][b] = fma(f[x + b], t[x], acc[a][b]);
         }
     }
 #pragma unroll
@@ -354,28 +289,43 @@ __global__ __launch_bounds__(BLK_THREADS) void k_ncc_cross_blk(const float* __re
 #pragma unroll
         for (int b = 0; b < BV; ++b) {
             const double v = block_sum<BLK_THREADS>(acc[a][b], sh);
-            if (threadIdx.x == 0)
-                partial[((size_t)blockIdx.z * pu + blockIdx.y * BU + a) * pv + blockIdx.x * BV + b] = v;
+            if (threadIdx.x == 0) partial[(((size_t)blockIdx.y * n_blocks + blockIdx.x) * BU + a) * BV + b] = v;
         }
 }
 
-// one lane per map entry: cross term = sum of the chunks' partials (fixed order), then the NCC value as in k_ncc_sat
-__global__ __launch_bounds__(256) void k_ncc_finish(const double* __restrict__ partial, int n_chunks, int pu, int pv, int dimu, int dimv, int du,
-                                                    int dv, SatView s1, SatView s2, float* __restrict__ out) {
-    const int W = 2 * dv + 1, n = (2 * du + 1) * W;
+// one lane per requested entry: cross term = sum of the chunks' partials (fixed order), then the NCC value of
+// compute_NCC (compute_funcs.cu:1163-1292).  entries == nullptr: the full (2du+1) x (2dv+1) map in row-major order;
+// else entry e = {u, v, slot in the block's 2 x 8 partials (block * 16 + a * 8 + b), output slot}
+__global__ __launch_bounds__(256) void k_ncc_finish(const double* __restrict__ partial, int n_chunks, int n_blocks, int nvb,
+                                                    const int* __restrict__ entries, int n_entries, int dimu, int dimv, int du, int dv,
+                                                    SatView s1, SatView s2, float* __restrict__ out) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n) return;
-    const int iu = e / W, iv = e - iu * W, u = iu - du, v = iv - dv;
+    if (e >= n_entries) return;
+    int u, v, pidx, slot;
+    if (entries) {
+        u = entries[4 * e];
+        v = entries[4 * e + 1];
+        pidx = entries[4 * e + 2];
+        slot = entries[4 * e + 3];
+    } else {
+        const int W = 2 * dv + 1, iu = e / W, iv = e - iu * W;
+        u = iu - du;
+        v = iv - dv;
+        pidx = (((iu / BU) * nvb + iv / BV) * BU + iu % BU) * BV + iv % BV;
+        slot = e;
+    }
     const int nr = dimu - abs(u), nc = dimv - abs(v);
-    if (nr <= 0 || nc <= 0) { out[e] = __int_as_float(0x7fc00000); return; }  // reference: empty loops, 0/0
+    if (nr <= 0 || nc <= 0) { out[slot] = __int_as_float(0x7fc00000); return; }  // reference: empty loops, 0/0
     double cr = 0.0;
-    for (int ch = 0; ch < n_chunks; ++ch) cr += partial[((size_t)ch * pu + iu) * pv + iv];
+    for (int ch = 0; ch < n_chunks; ++ch) cr += partial[(size_t)ch * n_blocks * (BU * BV) + pidx];
     double fm, sf, F1, tm, st, F2;
     window_stats(s1, dimu, dimv, max(u, 0), max(v, 0), nr, nc, &fm, &sf, &F1);
     window_stats(s2, dimu, dimv, max(-u, 0), max(-v, 0), nr, nc, &tm, &st, &F2);
     (void)fm; (void)st;
     const double num = cr - tm * sf;
-    out[e] = (F1 > 0.0 && F2 > 0.0) ? (float)(num / sqrt(F1 * F2)) : __int_as_float(0x7fc00000);
+    // a window without variance: the reference's two-pass sums are exactly 0 there and it returns 0/0 = NaN
+    // (compute_funcs.cu:1277-1290); the table differences are exact for such data too, but the cross term is not
+    out[slot] = (F1 > 0.0 && F2 > 0.0) ? (float)(num / sqrt(F1 * F2)) : __int_as_float(0x7fc00000);
 }
 
 // ------------------------------------------------------------------------------------------------ host logic
@@ -527,37 +477,39 @@ struct Workspace {
     DevBuf partial[3]; // doubles: per plane, the row chunks' partial cross terms of a full map
     size_t floats = 0;
     int list_cap = 0;
-    std::vector<int> host_groups;
+    std::vector<int> host_groups, host_entries;
+    std::vector<long long> host_keys;
     PinnedBuf pin_groups, pin_res, pin_maps;
 };
 
-int ncc_groups(hipStream_t s, const float* base, const PlaneGeom& g, const SatView& v1, const SatView& v2, const int* d_groups, int n_groups,
-               float* d_out) {
-    hipLaunchKernelGGL(k_ncc_sat, dim3(n_groups), dim3(MAP_THREADS), 0, s, base + g.mip1, base + g.mip2, g.dimu, g.dimv, g.delayu,
-                       g.delayv, v1, v2, d_groups, d_out);
-    return launch_check("k_ncc_sat(groups)");
-}
-
-// full NCC map of one plane: blocked cross terms + finishing pass; `partial` grows as needed
-int ncc_full_map(hipStream_t s, const float* m1, const float* m2, int dimu, int dimv, int delayu, int delayv, const SatView& v1,
-                 const SatView& v2, DevBuf& partial, float* d_map) {
-    const int nub = (2 * delayu + 1 + BU - 1) / BU, nvb = (2 * delayv + 1 + BV - 1) / BV;
-    const int pu = nub * BU, pv = nvb * BV;
-    int chunks = (1536 + nub * nvb - 1) / (nub * nvb);          // enough work-groups for 256 CUs
+// NCC values of one plane: the blocked cross terms + the finishing pass.  d_blocks / d_entries == nullptr: the full map into
+// d_out; else the listed blocks {u0, v0} and entries {u, v, partial index, output slot}.  `partial` grows as needed.
+int ncc_launch(hipStream_t s, const float* m1, const float* m2, int dimu, int dimv, int delayu, int delayv, const SatView& v1, const SatView& v2,
+               const int* d_blocks, int n_blocks, const int* d_entries, int n_entries, DevBuf& partial, float* d_out) {
+    const int nvb = (2 * delayv + 1 + BV - 1) / BV;
+    if (!d_blocks) {
+        n_blocks = ((2 * delayu + 1 + BU - 1) / BU) * nvb;
+        n_entries = (2 * delayu + 1) * (2 * delayv + 1);
+    }
+    if (n_blocks <= 0 || n_entries <= 0) return MI_OK;
+    int chunks = (1536 + n_blocks - 1) / n_blocks;              // enough work-groups for 256 CUs
     chunks = imax(1, imin(chunks, (dimu + 7) / 8));
     const int rows_per_chunk = (dimu + chunks - 1) / chunks;
     chunks = (dimu + rows_per_chunk - 1) / rows_per_chunk;
-    const size_t need = sizeof(double) * (size_t)chunks * pu * pv;
+    const int quads = (dimv + BC - 1) / BC;
+    const int R = imax(1, imin(rows_per_chunk, 512 / quads));   // rows staged together: about two items per lane
+    const size_t lds = sizeof(float) * ((size_t)(R + BU - 1) * (quads * BC + BV) + (size_t)R * quads * BC);
+    MI_REQUIRE(lds <= 60 * 1024, "CrossMIPs: MIP rows of %d pixels do not fit the NCC kernel's LDS tile", dimv);
+    const size_t need = sizeof(double) * (size_t)chunks * n_blocks * BU * BV;
     if (partial.bytes < need) {
-        MI_HIP(hipStreamSynchronize(s));  // an earlier map of this stream may still read the old buffer
+        MI_HIP(hipStreamSynchronize(s));  // an earlier launch of this stream may still read the old buffer
         MI_TRY(partial.alloc(need));
     }
-    hipLaunchKernelGGL(k_ncc_cross_blk, dim3(nvb, nub, chunks), dim3(BLK_THREADS), 0, s, m1, m2, dimu, dimv, delayu, delayv, rows_per_chunk, pu,
-                       pv, partial.as<double>());
-    MI_TRY(launch_check("k_ncc_cross_blk"));
-    const int n = (2 * delayu + 1) * (2 * delayv + 1);
-    hipLaunchKernelGGL(k_ncc_finish, dim3((n + 255) / 256), dim3(256), 0, s, partial.as<double>(), chunks, pu, pv, dimu, dimv, delayu, delayv, v1,
-                       v2, d_map);
+    hipLaunchKernelGGL(k_ncc_blk, dim3(n_blocks, chunks), dim3(BLK_THREADS), lds, s, m1, m2, dimu, dimv, delayu, delayv, nvb, d_blocks, n_blocks,
+                       rows_per_chunk, R, partial.as<double>());
+    MI_TRY(launch_check("k_ncc_blk"));
+    hipLaunchKernelGGL(k_ncc_finish, dim3((n_entries + 255) / 256), dim3(256), 0, s, partial.as<double>(), chunks, n_blocks, nvb, d_entries,
+                       n_entries, dimu, dimv, delayu, delayv, v1, v2, d_out);
     return launch_check("k_ncc_finish");
 }
 
@@ -594,29 +546,47 @@ int refine_neighbourhood(hipStream_t s, const mi_ncc_params& P, const float* map
         const int n_miss = (int)miss.size() / 3;
         MI_REQUIRE(n_miss == H * W - (H - std::abs(deltau)) * (W - std::abs(deltav)), "CrossMIPs: incomplete NCC map in compute_Neighborhood");
         if (n_miss > 0) {
-            // entries arrive in row-major window order: runs with the same u, consecutive v and consecutive slots are
-            // served four at a time by k_ncc_sat
-            std::vector<int>& grp = ws.host_groups;
-            grp.clear();
-            for (int q = 0; q < n_miss;) {
-                int cnt = 1;
-                while (cnt < VB && q + cnt < n_miss && miss[3 * (q + cnt)] == miss[3 * q] && miss[3 * (q + cnt) + 1] == miss[3 * q + 1] + cnt &&
-                       miss[3 * (q + cnt) + 2] == miss[3 * q + 2] + cnt)
-                    ++cnt;
-                grp.push_back(miss[3 * q]); grp.push_back(miss[3 * q + 1]); grp.push_back(cnt); grp.push_back(miss[3 * q + 2]);
-                q += cnt;
+            // the missing entries are covered by 2 x 8 blocks of shifts anchored at the smallest missing (u, v)
+            int ub = miss[0], vb = miss[1];
+            for (int q = 1; q < n_miss; ++q) { ub = imin(ub, miss[3 * q]); vb = imin(vb, miss[3 * q + 1]); }
+            std::vector<int>& lst = ws.host_groups;   // blocks {u0, v0} ..., then entries {u, v, partial index, slot} ...
+            lst.clear();
+            std::vector<int>& ent = ws.host_entries;
+            ent.clear();
+            std::vector<long long>& keys = ws.host_keys;
+            keys.clear();
+            for (int q = 0; q < n_miss; ++q) {
+                const int u = miss[3 * q], v = miss[3 * q + 1];
+                const int bu = (u - ub) / BU, bv = (v - vb) / BV;
+                const long long key = (long long)bu * (1 << 20) + bv;
+                int blk = -1;
+                for (int k = (int)keys.size() - 1; k >= 0; --k)      // row-major order: a recent block almost always
+                    if (keys[k] == key) { blk = k; break; }
+                if (blk < 0) {
+                    blk = (int)keys.size();
+                    keys.push_back(key);
+                    lst.push_back(ub + bu * BU);
+                    lst.push_back(vb + bv * BV);
+                }
+                ent.push_back(u); ent.push_back(v);
+                ent.push_back((blk * BU + (u - ub) % BU) * BV + (v - vb) % BV);
+                ent.push_back(miss[3 * q + 2]);
             }
-            const int n_groups = (int)grp.size() / 4;
-            if (ws.list_cap < n_groups) {
-                MI_TRY(ws.list.alloc(sizeof(int) * 4 * (size_t)n_groups));
-                ws.list_cap = n_groups;
+            const int n_blocks = (int)keys.size();
+            const size_t ints = lst.size() + ent.size();
+            if ((size_t)ws.list_cap < ints) {
+                MI_HIP(hipStreamSynchronize(s));
+                MI_TRY(ws.list.alloc(sizeof(int) * ints));
+                ws.list_cap = (int)ints;
             }
             float* d_res = ws.buf.as<float>() + ws.floats;  // H*W result slots reserved behind the maps
-            MI_TRY(ws.pin_groups.reserve(sizeof(int) * grp.size()));
+            MI_TRY(ws.pin_groups.reserve(sizeof(int) * ints));
             MI_TRY(ws.pin_res.reserve(sizeof(float) * (size_t)H * W));
-            std::memcpy(ws.pin_groups.p, grp.data(), sizeof(int) * grp.size());
-            MI_HIP(hipMemcpyAsync(ws.list.p, ws.pin_groups.p, sizeof(int) * grp.size(), hipMemcpyHostToDevice, s));
-            MI_TRY(ncc_groups(s, d_base, g, ws.v1[plane], ws.v2[plane], ws.list.as<int>(), n_groups, d_res));
+            std::memcpy(ws.pin_groups.p, lst.data(), sizeof(int) * lst.size());
+            std::memcpy(ws.pin_groups.as<int>() + lst.size(), ent.data(), sizeof(int) * ent.size());
+            MI_HIP(hipMemcpyAsync(ws.list.p, ws.pin_groups.p, sizeof(int) * ints, hipMemcpyHostToDevice, s));
+            MI_TRY(ncc_launch(s, d_base + g.mip1, d_base + g.mip2, g.dimu, g.dimv, g.delayu, g.delayv, ws.v1[plane], ws.v2[plane],
+                              ws.list.as<int>(), n_blocks, ws.list.as<int>() + lst.size(), n_miss, ws.partial[plane], d_res));
             const float* res = ws.pin_res.as<float>();
             MI_HIP(hipMemcpyAsync(ws.pin_res.p, d_res, sizeof(float) * H * W, hipMemcpyDeviceToHost, s));
             MI_HIP(hipStreamSynchronize(s));
@@ -724,8 +694,8 @@ int pair_enqueue(hipStream_t s, const float* A, const float* B, int dimi, int di
         const PlaneGeom& g = pl.g[m];
         MI_TRY(prepare_plane(s, base + g.mip1, base + g.mip2, g.dimu, g.dimv, base + g.ps1, base + g.ps2, ws.sat.as<double>() + g.sat,
                              &ws.v1[m], &ws.v2[m]));
-        MI_TRY(ncc_full_map(s, base + g.mip1, base + g.mip2, g.dimu, g.dimv, g.delayu, g.delayv, ws.v1[m], ws.v2[m], ws.partial[m],
-                            base + g.map));
+        MI_TRY(ncc_launch(s, base + g.mip1, base + g.mip2, g.dimu, g.dimv, g.delayu, g.delayv, ws.v1[m], ws.v2[m], nullptr, 0, nullptr, 0,
+                          ws.partial[m], base + g.map));
     }
     MI_TRY(ws.pin_maps.reserve(sizeof(float) * pl.map_floats));
     MI_HIP(hipMemcpyAsync(ws.pin_maps.p, base + pl.map_begin, sizeof(float) * pl.map_floats, hipMemcpyDeviceToHost, s));
@@ -885,7 +855,7 @@ extern "C" int mi_ncc_compute_map(int dev, void* stream, const float* mip1, cons
     SatView v1, v2;
     MI_TRY(prepare_plane(s, mip1, mip2, dimu, dimv, ps.as<float>(), ps.as<float>() + (nt > 0 ? nt : 0), sat.as<double>(), &v1, &v2));
     DevBuf partial;
-    MI_TRY(ncc_full_map(s, mip1, mip2, dimu, dimv, delayu, delayv, v1, v2, partial, map));
+    MI_TRY(ncc_launch(s, mip1, mip2, dimu, dimv, delayu, delayv, v1, v2, nullptr, 0, nullptr, 0, partial, map));
     MI_HIP(hipStreamSynchronize(s));  // ps / sat / partial die at scope exit
     return MI_OK;
 }
