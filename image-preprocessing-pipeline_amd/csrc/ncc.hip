@@ -17,7 +17,11 @@
 // Host side (this file, plain C++): argmax, neighbourhood refinement, peak widths and the final
 // alignment rules, kept bit-identical in float/int arithmetic to compute_funcs.cu:160-342,1294-1609.
 #include <cmath>
+#include <algorithm>
 #include <cstring>
+#include <string>
+#include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "mi_crossmips.h"
@@ -33,6 +37,23 @@ constexpr int NCC_THREADS = 256;
 
 __device__ __forceinline__ void atomic_max_nonneg(float* addr, float v) {
     atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
+}
+
+// maximum of a non-negative value over the 64 lanes of a wave, valid in lane 63: DPP moves inside the VALU (quad permutes, row
+// mirrors, row broadcasts) instead of six trips through the LDS crossbar
+__device__ __forceinline__ float wave_max_nonneg(float v) {
+    auto step = [](float x, auto ctrl, auto row_mask) {
+        const int y = __builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, decltype(row_mask)::value, 0xf, false);
+        return fmaxf(x, __int_as_float(y));  // lanes without a source keep 0 = the neutral element
+    };
+    using std::integral_constant;
+    v = step(v, integral_constant<int, 0xB1>{}, integral_constant<int, 0xf>{});   // quad_perm [1,0,3,2]
+    v = step(v, integral_constant<int, 0x4E>{}, integral_constant<int, 0xf>{});   // quad_perm [2,3,0,1]
+    v = step(v, integral_constant<int, 0x141>{}, integral_constant<int, 0xf>{});  // row_half_mirror
+    v = step(v, integral_constant<int, 0x140>{}, integral_constant<int, 0xf>{});  // row_mirror: every lane holds its row's max
+    v = step(v, integral_constant<int, 0x142>{}, integral_constant<int, 0xa>{});  // row_bcast:15 into rows 1 and 3
+    v = step(v, integral_constant<int, 0x143>{}, integral_constant<int, 0xc>{});  // row_bcast:31 into rows 2 and 3
+    return v;
 }
 
 // view(k,i,j) = vol[k*slice + (i+i0)*pitch + (j+j0)], z = 0: A, z = 1: B
@@ -61,9 +82,8 @@ __global__ __launch_bounds__(256) void k_mips(const float* __restrict__ A, const
             if (live && r < rows) v = p[(size_t)r * pitch];
             best[r] = fmaxf(best[r], v);
             colmax = fmaxf(colmax, v);
-            float rowmax = v;  // max over the 64 columns of this wave
-            for (int off = 32; off > 0; off >>= 1) rowmax = fmaxf(rowmax, __shfl_xor(rowmax, off, 64));
-            if ((threadIdx.x & 63) == 0 && r < rows) atomic_max_nonneg(&xz[(size_t)(i0 + r) * dimk + k], rowmax);
+            const float rowmax = wave_max_nonneg(v);  // max over the 64 columns of this wave, in lane 63
+            if ((threadIdx.x & 63) == 63 && r < rows) atomic_max_nonneg(&xz[(size_t)(i0 + r) * dimk + k], rowmax);
         }
         if (live) atomic_max_nonneg(&yz[(size_t)j * dimk + k], colmax);
     }
@@ -789,40 +809,53 @@ extern "C" int mi_ncc_mips_batch(int dev, void* stream, int n_pairs, const float
     MI_REQUIRE(n_pairs >= 0, "mi_ncc_mips_batch: negative pair count");
     if (n_pairs == 0) return MI_OK;
     MI_REQUIRE(tiles && a_idx && b_idx && ni && nj && side && params && out, "mi_ncc_mips_batch: null pointer");
-    // NS pairs in flight on NS internal streams: while the host refines pair q (a few syncs and small launches), the MIP /
-    // table / map kernels of the following pairs run; few of those kernels fill the device on their own, so the streams also
-    // overlap each other.  All streams start after, and are joined back into, `stream`.
-    constexpr int NS = 4;
+    // The host side of a pair (argmax, neighbourhood refinement with its small launches and stream syncs, widths, alignment)
+    // is a serial latency chain of about a millisecond, and few of a pair's kernels fill the device on their own: NT host
+    // threads, each with its own stream and workspace, take every NT-th pair; within a thread the next pair's kernels are
+    // enqueued before the current pair is refined.  All streams start after, and are joined back into, `stream`.
+    const int NT = std::min(n_pairs, 6);
     hipStream_t user = as_stream(stream);
-    struct Slot { Workspace ws; PairPlan pl; hipStream_t s = nullptr; int q = -1; } slot[NS];
     hipEvent_t ev = nullptr;
-    int rc = MI_OK;
-    auto cleanup = [&]() {
-        for (auto& sl : slot)
-            if (sl.s) { (void)hipStreamSynchronize(sl.s); (void)hipStreamDestroy(sl.s); sl.s = nullptr; }
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, user) != hipSuccess) {
         if (ev) (void)hipEventDestroy(ev);
-    };
-    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, user) != hipSuccess)
-        rc = fail(MI_ERR_HIP, "mi_ncc_mips_batch: event setup failed");
-    for (auto& sl : slot)
-        if (rc == MI_OK && (hipStreamCreateWithFlags(&sl.s, hipStreamNonBlocking) != hipSuccess || hipStreamWaitEvent(sl.s, ev, 0) != hipSuccess))
-            rc = fail(MI_ERR_HIP, "mi_ncc_mips_batch: stream setup failed");
-    for (int q = 0; q < n_pairs + NS - 1 && rc == MI_OK; ++q) {
-        if (q < n_pairs) {
-            Slot& sl = slot[q % NS];  // its previous pair, q - NS, was finished in the step before
-            if (!tiles[a_idx[q]] || !tiles[b_idx[q]]) { rc = fail(MI_ERR_INVALID, "mi_ncc_mips_batch: null tile for pair %d", q); break; }
-            rc = plan_pair(dimk, dimi, dimj, 0, ni[q], nj[q], delayk, delayi, delayj, side[q], &params[q], sl.pl);
-            if (rc == MI_OK) rc = pair_enqueue(sl.s, tiles[a_idx[q]], tiles[b_idx[q]], dimi, dimj, sl.pl, sl.ws);
-            sl.q = q;
-        }
-        const int f = q - (NS - 1);
-        if (f >= 0 && f < n_pairs && rc == MI_OK) {
-            Slot& pr = slot[f % NS];
-            rc = pair_finish(pr.s, ni[f], nj[f], side[f], &params[f], pr.pl, pr.ws, &out[f]);
-        }
+        return fail(MI_ERR_HIP, "mi_ncc_mips_batch: event setup failed");
     }
-    cleanup();
-    return rc;
+    std::vector<int> rcs(NT, MI_OK);
+    std::vector<std::string> msgs(NT);
+    auto worker = [&](int t) {
+        struct Slot { Workspace ws; PairPlan pl; hipStream_t s = nullptr; } slot[2];
+        int rc = use_device(dev);
+        for (auto& sl : slot)
+            if (rc == MI_OK && (hipStreamCreateWithFlags(&sl.s, hipStreamNonBlocking) != hipSuccess || hipStreamWaitEvent(sl.s, ev, 0) != hipSuccess))
+                rc = fail(MI_ERR_HIP, "mi_ncc_mips_batch: stream setup failed");
+        int k = 0;  // index of the pair within this thread's sequence t, t + NT, ...
+        for (int q = t; rc == MI_OK; q += NT, ++k) {
+            if (q < n_pairs) {
+                Slot& sl = slot[k & 1];
+                if (!tiles[a_idx[q]] || !tiles[b_idx[q]]) { rc = fail(MI_ERR_INVALID, "mi_ncc_mips_batch: null tile for pair %d", q); break; }
+                rc = plan_pair(dimk, dimi, dimj, 0, ni[q], nj[q], delayk, delayi, delayj, side[q], &params[q], sl.pl);
+                if (rc == MI_OK) rc = pair_enqueue(sl.s, tiles[a_idx[q]], tiles[b_idx[q]], dimi, dimj, sl.pl, sl.ws);
+            }
+            const int f = q - NT;
+            if (f >= 0 && f < n_pairs && rc == MI_OK) {
+                Slot& pr = slot[(k - 1) & 1];
+                rc = pair_finish(pr.s, ni[f], nj[f], side[f], &params[f], pr.pl, pr.ws, &out[f]);
+            }
+            if (q >= n_pairs) break;
+        }
+        if (rc != MI_OK) msgs[t] = mi_last_error();
+        for (auto& sl : slot)
+            if (sl.s) { (void)hipStreamSynchronize(sl.s); (void)hipStreamDestroy(sl.s); }
+        rcs[t] = rc;
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < NT; ++t) pool.emplace_back(worker, t);
+    worker(0);
+    for (auto& th : pool) th.join();
+    (void)hipEventDestroy(ev);
+    for (int t = 0; t < NT; ++t)
+        if (rcs[t] != MI_OK) return fail(rcs[t], "%s", msgs[t].c_str());
+    return MI_OK;
 }
 
 extern "C" int mi_ncc_compute_mips(int dev, void* stream, const float* A, const float* B, int dimk, int dimi, int dimj, int ni, int nj,
