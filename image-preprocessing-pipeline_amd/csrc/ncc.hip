@@ -18,6 +18,7 @@
 // alignment rules, kept bit-identical in float/int arithmetic to compute_funcs.cu:160-342,1294-1609.
 #include <cmath>
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -161,19 +162,30 @@ __device__ void window_stats(const SatView& sv, int dimu, int dimv, int r0, int 
     *ssd = Q - 2.0 * g * P + n * g * g;
 }
 
-// global mean c0 of each of the two MIPs of a plane (blockIdx.x = 0 / 1) and the table of its float tile sums
-__global__ __launch_bounds__(1024) void k_mip_mean(const float* __restrict__ m1, const float* __restrict__ m2, int dimu, int dimv,
-                                                   const float* __restrict__ ps1, const float* __restrict__ ps2, double* __restrict__ c0a,
-                                                   double* __restrict__ c0b, double* __restrict__ ts1, double* __restrict__ ts2) {
-    __shared__ double sh[16];
-    const float* m = blockIdx.x ? m2 : m1;
+// pixel sums of both MIPs of a plane in MEAN_PARTS slices each (blockIdx.y = MIP), for the global means
+constexpr int MEAN_PARTS = 64;
+__global__ __launch_bounds__(256) void k_mip_partial(const float* __restrict__ m1, const float* __restrict__ m2, size_t n, double* __restrict__ part) {
+    __shared__ double sh[4];
+    const float* m = blockIdx.y ? m2 : m1;
+    const size_t per = (n + MEAN_PARTS - 1) / MEAN_PARTS, lo = blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+    double acc = 0.0;
+    for (size_t i = lo + threadIdx.x; i < hi; i += 256) acc += (double)m[i];
+    acc = block_sum<256>(acc, sh);
+    if (threadIdx.x == 0) part[blockIdx.y * MEAN_PARTS + blockIdx.x] = acc;
+}
+
+// global mean c0 of each of the two MIPs of a plane (blockIdx.x = 0 / 1) from the slices' sums (fixed order) and the table of
+// its float tile sums
+__global__ __launch_bounds__(1024) void k_mip_mean(const double* __restrict__ part, int dimu, int dimv, const float* __restrict__ ps1,
+                                                   const float* __restrict__ ps2, double* __restrict__ c0a, double* __restrict__ c0b,
+                                                   double* __restrict__ ts1, double* __restrict__ ts2) {
     const float* ps = blockIdx.x ? ps2 : ps1;
     double* ts = blockIdx.x ? ts2 : ts1;
-    const size_t n = (size_t)dimu * dimv;
-    double acc = 0.0;
-    for (size_t i = threadIdx.x; i < n; i += 1024) acc += (double)m[i];
-    acc = block_sum<1024>(acc, sh);
-    if (threadIdx.x == 0) *(blockIdx.x ? c0b : c0a) = acc / (double)n;
+    if (threadIdx.x == 0) {
+        double acc = 0.0;
+        for (int k = 0; k < MEAN_PARTS; ++k) acc += part[blockIdx.x * MEAN_PARTS + k];
+        *(blockIdx.x ? c0b : c0a) = acc / ((double)dimu * (double)dimv);
+    }
     const int ph = dimu / TILE, pw = dimv / TILE;
     if (ps && ph * pw > 0) {
         // (ph+1) x (pw+1) inclusive table; a few hundred entries: one lane per row, then one per column
@@ -277,14 +289,34 @@ __global__ __launch_bounds__(BLK_THREADS) void k_ncc_blk(const float* __restrict
     for (int rb = r_begin; rb < r_end; rb += R) {
         const int nrow = min(R, r_end - rb);
         __syncthreads();
-        for (int idx = threadIdx.x; idx < (nrow + BU - 1) * pitch1; idx += BLK_THREADS) {
-            const int j = idx / pitch1, x = idx - j * pitch1;
-            const int r1 = rb + u0 + j, c1 = v0 + x;
-            l1[idx] = (r1 >= 0 && r1 < dimu && c1 >= 0 && c1 < dimv) ? m1[(size_t)r1 * dimv + c1] : 0.0f;
-        }
-        for (int idx = threadIdx.x; idx < nrow * pitch2; idx += BLK_THREADS) {
-            const int j = idx / pitch2, x = idx - j * pitch2;
-            l2[idx] = x < dimv ? m2[(size_t)(rb + j) * dimv + x] : 0.0f;
+        {   // staging, eight independent loads per lane in flight before the first LDS store
+            constexpr int UNR = 8;
+            const int n1 = (nrow + BU - 1) * pitch1, n2 = nrow * pitch2;
+            for (int base = threadIdx.x; base < n1; base += BLK_THREADS * UNR) {
+                float v[UNR];
+#pragma unroll
+                for (int q = 0; q < UNR; ++q) {
+                    const int idx = base + q * BLK_THREADS;
+                    const int j = idx / pitch1, x = idx - j * pitch1;
+                    const int r1 = rb + u0 + j, c1 = v0 + x;
+                    v[q] = (idx < n1 && r1 >= 0 && r1 < dimu && c1 >= 0 && c1 < dimv) ? m1[(size_t)r1 * dimv + c1] : 0.0f;
+                }
+#pragma unroll
+                for (int q = 0; q < UNR; ++q)
+                    if (base + q * BLK_THREADS < n1) l1[base + q * BLK_THREADS] = v[q];
+            }
+            for (int base = threadIdx.x; base < n2; base += BLK_THREADS * UNR) {
+                float v[UNR];
+#pragma unroll
+                for (int q = 0; q < UNR; ++q) {
+                    const int idx = base + q * BLK_THREADS;
+                    const int j = idx / pitch2, x = idx - j * pitch2;
+                    v[q] = (idx < n2 && x < dimv) ? m2[(size_t)(rb + j) * dimv + x] : 0.0f;
+                }
+#pragma unroll
+                for (int q = 0; q < UNR; ++q)
+                    if (base + q * BLK_THREADS < n2) l2[base + q * BLK_THREADS] = v[q];
+            }
         }
         __syncthreads();
         for (int it = threadIdx.x; it < nrow * quads; it += BLK_THREADS) {
@@ -440,7 +472,7 @@ struct SatLayout {
     SatLayout(int dimu, int dimv) {
         tab = (size_t)(dimu + 1) * (dimv + 1);
         ts = (size_t)(dimu / TILE + 1) * (dimv / TILE + 1);
-        total = 2 + 4 * tab + 2 * ts;
+        total = 2 + 4 * tab + 2 * ts + 2 * MEAN_PARTS;  // c0a, c0b | P1 Q1 P2 Q2 | TS1 TS2 | partial pixel sums
     }
 };
 
@@ -456,8 +488,10 @@ int prepare_plane(hipStream_t s, const float* m1, const float* m2, int dimu, int
         hipLaunchKernelGGL(k_tile_sums, dim3((nt + 63) / 64), dim3(64), 0, s, m2, dimu, dimv, ps2);
         MI_TRY(launch_check("k_tile_sums"));
     }
-    hipLaunchKernelGGL(k_mip_mean, dim3(2), dim3(1024), 0, s, m1, m2, dimu, dimv, tiled ? ps1 : nullptr, tiled ? ps2 : nullptr, c0a, c0b, T1,
-                       T2);
+    double* part = T2 + L.ts;
+    hipLaunchKernelGGL(k_mip_partial, dim3(MEAN_PARTS, 2), dim3(256), 0, s, m1, m2, (size_t)dimu * dimv, part);
+    MI_TRY(launch_check("k_mip_partial"));
+    hipLaunchKernelGGL(k_mip_mean, dim3(2), dim3(1024), 0, s, part, dimu, dimv, tiled ? ps1 : nullptr, tiled ? ps2 : nullptr, c0a, c0b, T1, T2);
     MI_TRY(launch_check("k_mip_mean"));
     hipLaunchKernelGGL(k_sat_rows, dim3(dimu + 1, 2), dim3(64), 0, s, m1, m2, dimu, dimv, c0a, c0b, P1, Q1, P2, Q2);
     MI_TRY(launch_check("k_sat_rows"));
@@ -517,7 +551,7 @@ int ncc_launch(hipStream_t s, const float* m1, const float* m2, int dimu, int di
     const int rows_per_chunk = (dimu + chunks - 1) / chunks;
     chunks = (dimu + rows_per_chunk - 1) / rows_per_chunk;
     const int quads = (dimv + BC - 1) / BC;
-    const int R = imax(1, imin(rows_per_chunk, 512 / quads));   // rows staged together: about two items per lane
+    const int R = imax(1, imin(rows_per_chunk, 1536 / quads));  // rows staged together: about six items per lane
     const size_t lds = sizeof(float) * ((size_t)(R + BU - 1) * (quads * BC + BV) + (size_t)R * quads * BC);
     MI_REQUIRE(lds <= 60 * 1024, "CrossMIPs: MIP rows of %d pixels do not fit the NCC kernel's LDS tile", dimv);
     const size_t need = sizeof(double) * (size_t)chunks * n_blocks * BU * BV;
@@ -813,7 +847,9 @@ extern "C" int mi_ncc_mips_batch(int dev, void* stream, int n_pairs, const float
     // is a serial latency chain of about a millisecond, and few of a pair's kernels fill the device on their own: NT host
     // threads, each with its own stream and workspace, take every NT-th pair; within a thread the next pair's kernels are
     // enqueued before the current pair is refined.  All streams start after, and are joined back into, `stream`.
-    const int NT = std::min(n_pairs, 6);
+    int want = 3;
+    if (const char* e = std::getenv("MI_NCC_THREADS")) want = std::max(1, std::min(32, std::atoi(e)));
+    const int NT = std::min(n_pairs, want);
     hipStream_t user = as_stream(stream);
     hipEvent_t ev = nullptr;
     if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, user) != hipSuccess) {
