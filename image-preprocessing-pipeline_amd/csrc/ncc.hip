@@ -268,7 +268,6 @@ __global__ __launch_bounds__(BLK_THREADS) void k_ncc_blk(const float* __restrict
                                                          int dv, int nvb, const int* __restrict__ blocks, int n_blocks, int rows_per_chunk,
                                                          int R, double* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    __shared__ double sh[BLK_THREADS / 64];
     int u0, v0;
     if (blocks) {
         u0 = blocks[2 * blockIdx.x];
@@ -336,13 +335,22 @@ __global__ __launch_bounds__(BLK_THREADS) void k_ncc_blk(const float* __restrict
             }
         }
     }
+    // one reduction for the 16 sums: wave trees, then lane (a, b) adds the four waves' values in wave order
+    __shared__ double red[BLK_THREADS / 64][BU * BV];
 #pragma unroll
     for (int a = 0; a < BU; ++a)
 #pragma unroll
         for (int b = 0; b < BV; ++b) {
-            const double v = block_sum<BLK_THREADS>(acc[a][b], sh);
-            if (threadIdx.x == 0) partial[(((size_t)blockIdx.y * n_blocks + blockIdx.x) * BU + a) * BV + b] = v;
+            double v = acc[a][b];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][a * BV + b] = v;
         }
+    __syncthreads();
+    if (threadIdx.x < BU * BV) {
+        double v = 0.0;
+        for (int w = 0; w < BLK_THREADS / 64; ++w) v += red[w][threadIdx.x];
+        partial[((size_t)blockIdx.y * n_blocks + blockIdx.x) * (BU * BV) + threadIdx.x] = v;
+    }
 }
 
 // one lane per requested entry: cross term = sum of the chunks' partials (fixed order), then the NCC value of
