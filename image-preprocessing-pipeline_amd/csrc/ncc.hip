@@ -11,7 +11,7 @@
 //   k_mip_mean / k_sat_rows / k_sat_cols   fp64 summed-area tables of (f - c0), (f - c0)^2 and of the float tile sums:
 //                 every term of compute_NCC (:1163-1292) except the cross term sum f*t becomes O(1) per shift, with
 //                 the reference's means (float tile sums + border pixels) reproduced exactly.
-//   k_ncc_blk / k_ncc_finish   cross terms sum f*t in fp64 for blocks of 2 x 8 shifts from LDS-staged MIP rows, partial sums per
+//   k_ncc_blk / k_ncc_finish   cross terms sum f*t in fp64 for blocks of 4 x 8 shifts from LDS-staged MIP rows, partial sums per
 //                 row chunk added in a fixed order; replaces gpu_NCC_map/gpu_NCC_miss (:730-935).  Serves full maps and the
 //                 "missing entries" of the neighbourhood refinement alike.
 // Host side (this file, plain C++): argmax, neighbourhood refinement, peak widths and the final
@@ -62,36 +62,47 @@ __global__ __launch_bounds__(256) void k_mips(const float* __restrict__ A, const
                                                size_t slice, int pitch, int ai0, int aj0, float* __restrict__ xy1, float* __restrict__ xz1,
                                                float* __restrict__ yz1, float* __restrict__ xy2, float* __restrict__ xz2,
                                                float* __restrict__ yz2) {
+    // a work-group owns a 16-row x 64-column patch of the view; its four waves share the slices (wave w: k = w, w + 4, ...),
+    // so a patch keeps four times as many loads in flight as one wave walking all slices
+    __shared__ float comb[3][MIP_ROWS][64];
     const bool second = blockIdx.z == 1;
     const float* vol = second ? B : A + (size_t)ai0 * pitch + aj0;
     float* xy = second ? xy2 : xy1;
     float* xz = second ? xz2 : xz1;
     float* yz = second ? yz2 : yz1;
-    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 64 + lane;
     const int i0 = blockIdx.y * MIP_ROWS;
     const int rows = min(MIP_ROWS, dimi_v - i0);
     const bool live = j < dimj_v;
     float best[MIP_ROWS];
 #pragma unroll
     for (int r = 0; r < MIP_ROWS; ++r) best[r] = 0.0f;
-    for (int k = 0; k < dimk; ++k) {
+    for (int k = wave; k < dimk; k += 4) {
         const float* p = vol + (size_t)k * slice + (size_t)i0 * pitch + j;
+        float v[MIP_ROWS];
+#pragma unroll
+        for (int r = 0; r < MIP_ROWS; ++r) v[r] = (live && r < rows) ? p[(size_t)r * pitch] : 0.0f;
         float colmax = 0.0f;
 #pragma unroll
         for (int r = 0; r < MIP_ROWS; ++r) {
-            float v = 0.0f;
-            if (live && r < rows) v = p[(size_t)r * pitch];
-            best[r] = fmaxf(best[r], v);
-            colmax = fmaxf(colmax, v);
-            const float rowmax = wave_max_nonneg(v);  // max over the 64 columns of this wave, in lane 63
-            if ((threadIdx.x & 63) == 63 && r < rows) atomic_max_nonneg(&xz[(size_t)(i0 + r) * dimk + k], rowmax);
+            best[r] = fmaxf(best[r], v[r]);
+            colmax = fmaxf(colmax, v[r]);
+            const float rowmax = wave_max_nonneg(v[r]);  // max over the 64 columns of the patch, in lane 63
+            if (lane == 63 && r < rows) atomic_max_nonneg(&xz[(size_t)(i0 + r) * dimk + k], rowmax);
         }
         if (live) atomic_max_nonneg(&yz[(size_t)j * dimk + k], colmax);
     }
-    if (live) {
+    // xy: maximum over the four waves' slices
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < MIP_ROWS; ++r) comb[wave - 1][r][lane] = best[r];
+    }
+    __syncthreads();
+    if (wave == 0 && live) {
 #pragma unroll
         for (int r = 0; r < MIP_ROWS; ++r)
-            if (r < rows) xy[(size_t)(i0 + r) * dimj_v + j] = best[r];
+            if (r < rows) xy[(size_t)(i0 + r) * dimj_v + j] = fmaxf(fmaxf(best[r], comb[0][r][lane]), fmaxf(comb[1][r][lane], comb[2][r][lane]));
     }
 }
 
@@ -255,18 +266,18 @@ __global__ __launch_bounds__(64) void k_sat_cols(int dimu, int dimv, double* __r
     }
 }
 
-// NCC cross terms, register-blocked: one work-group per block of (2 u) x (8 v) shifts and chunk of m2 rows.  The m1 rows of
+// NCC cross terms, register-blocked: one work-group per block of (4 u) x (8 v) shifts and chunk of m2 rows.  The m1 rows of
 // the block (shifted by v0, zero outside the MIP) and the m2 rows are staged in LDS with unit-stride loads; a lane then owns 4
-// neighbouring m2 columns of a row and, per u, the 11 m1 values its 8 shifts pair them with -- seven 16-byte LDS reads feed
-// 64 fp64 FMAs (exact fp32 products accumulated in fp64).  Zeros outside the MIP restrict every shift's sum to its own window.
+// neighbouring m2 columns of a row and, per u, the 11 m1 values its 8 shifts pair them with -- thirteen 16-byte LDS reads feed
+// 128 fp64 FMAs (exact fp32 products accumulated in fp64).  Zeros outside the MIP restrict every shift's sum to its own window.
 // Blocks come from a regular grid (full maps) or from a list (the "missing entries" of the neighbourhood refinement,
 // gpu_NCC_miss).  The chunks' partial sums are added up in a fixed order by k_ncc_finish, which also applies the window
 // statistics from the summed-area tables: deterministic, whatever the launch geometry.  Replaces gpu_NCC_map / gpu_NCC_miss
 // (compute_funcs.cu:730-935).
-constexpr int BU = 2, BV = 8, BC = 4, BLK_THREADS = 256;
+constexpr int BU = 4, BV = 8, BC = 4, BLK_THREADS = 256;
 __global__ __launch_bounds__(BLK_THREADS) void k_ncc_blk(const float* __restrict__ m1, const float* __restrict__ m2, int dimu, int dimv, int du,
                                                          int dv, int nvb, const int* __restrict__ blocks, int n_blocks, int rows_per_chunk,
-                                                         int R, double* __restrict__ partial) {
+                                                         int R, double* __restrict__ partial, int dbg) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     int u0, v0;
     if (blocks) {
@@ -288,37 +299,41 @@ __global__ __launch_bounds__(BLK_THREADS) void k_ncc_blk(const float* __restrict
     for (int rb = r_begin; rb < r_end; rb += R) {
         const int nrow = min(R, r_end - rb);
         __syncthreads();
-        {   // staging, eight independent loads per lane in flight before the first LDS store
-            constexpr int UNR = 8;
-            const int n1 = (nrow + BU - 1) * pitch1, n2 = nrow * pitch2;
-            for (int base = threadIdx.x; base < n1; base += BLK_THREADS * UNR) {
-                float v[UNR];
+        if (!(dbg & 2)) {   // staging: a wave per row (no index division), four independent 64-column loads per lane in flight
+            constexpr int UNR = 4;
+            const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+            for (int j = wave; j < nrow + BU - 1; j += BLK_THREADS / 64) {
+                const int r1 = rb + u0 + j;
+                const bool row_ok = r1 >= 0 && r1 < dimu;
+                const float* src = m1 + (size_t)(row_ok ? r1 : 0) * dimv + v0;
+                float* dst = l1 + j * pitch1;
+                for (int x0 = lane; x0 < pitch1; x0 += 64 * UNR) {
+                    float v[UNR];
 #pragma unroll
-                for (int q = 0; q < UNR; ++q) {
-                    const int idx = base + q * BLK_THREADS;
-                    const int j = idx / pitch1, x = idx - j * pitch1;
-                    const int r1 = rb + u0 + j, c1 = v0 + x;
-                    v[q] = (idx < n1 && r1 >= 0 && r1 < dimu && c1 >= 0 && c1 < dimv) ? m1[(size_t)r1 * dimv + c1] : 0.0f;
+                    for (int q = 0; q < UNR; ++q) {
+                        const int x = x0 + 64 * q, c1 = v0 + x;
+                        v[q] = (row_ok && x < pitch1 && c1 >= 0 && c1 < dimv) ? src[x] : 0.0f;
+                    }
+#pragma unroll
+                    for (int q = 0; q < UNR; ++q)
+                        if (x0 + 64 * q < pitch1) dst[x0 + 64 * q] = v[q];
                 }
-#pragma unroll
-                for (int q = 0; q < UNR; ++q)
-                    if (base + q * BLK_THREADS < n1) l1[base + q * BLK_THREADS] = v[q];
             }
-            for (int base = threadIdx.x; base < n2; base += BLK_THREADS * UNR) {
-                float v[UNR];
+            for (int j = wave; j < nrow; j += BLK_THREADS / 64) {
+                const float* src = m2 + (size_t)(rb + j) * dimv;
+                float* dst = l2 + j * pitch2;
+                for (int x0 = lane; x0 < pitch2; x0 += 64 * UNR) {
+                    float v[UNR];
 #pragma unroll
-                for (int q = 0; q < UNR; ++q) {
-                    const int idx = base + q * BLK_THREADS;
-                    const int j = idx / pitch2, x = idx - j * pitch2;
-                    v[q] = (idx < n2 && x < dimv) ? m2[(size_t)(rb + j) * dimv + x] : 0.0f;
+                    for (int q = 0; q < UNR; ++q) v[q] = x0 + 64 * q < dimv ? src[x0 + 64 * q] : 0.0f;
+#pragma unroll
+                    for (int q = 0; q < UNR; ++q)
+                        if (x0 + 64 * q < pitch2) dst[x0 + 64 * q] = v[q];
                 }
-#pragma unroll
-                for (int q = 0; q < UNR; ++q)
-                    if (base + q * BLK_THREADS < n2) l2[base + q * BLK_THREADS] = v[q];
             }
         }
         __syncthreads();
-        for (int it = threadIdx.x; it < nrow * quads; it += BLK_THREADS) {
+        if (!(dbg & 1)) for (int it = threadIdx.x; it < nrow * quads; it += BLK_THREADS) {
             const int rr = it / quads, c = (it - rr * quads) * BC;
             const float4 tq = *reinterpret_cast<const float4*>(l2 + rr * pitch2 + c);
             const double t[BC] = {(double)tq.x, (double)tq.y, (double)tq.z, (double)tq.w};
@@ -355,7 +370,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_ncc_blk(const float* __restrict
 
 // one lane per requested entry: cross term = sum of the chunks' partials (fixed order), then the NCC value of
 // compute_NCC (compute_funcs.cu:1163-1292).  entries == nullptr: the full (2du+1) x (2dv+1) map in row-major order;
-// else entry e = {u, v, slot in the block's 2 x 8 partials (block * 16 + a * 8 + b), output slot}
+// else entry e = {u, v, slot in the block's 4 x 8 partials (block * 32 + a * 8 + b), output slot}
 __global__ __launch_bounds__(256) void k_ncc_finish(const double* __restrict__ partial, int n_chunks, int n_blocks, int nvb,
                                                     const int* __restrict__ entries, int n_entries, int dimu, int dimv, int du, int dv,
                                                     SatView s1, SatView s2, float* __restrict__ out) {
@@ -559,16 +574,27 @@ int ncc_launch(hipStream_t s, const float* m1, const float* m2, int dimu, int di
     const int rows_per_chunk = (dimu + chunks - 1) / chunks;
     chunks = (dimu + rows_per_chunk - 1) / rows_per_chunk;
     const int quads = (dimv + BC - 1) / BC;
-    const int R = imax(1, imin(rows_per_chunk, 1536 / quads));  // rows staged together: about six items per lane
-    const size_t lds = sizeof(float) * ((size_t)(R + BU - 1) * (quads * BC + BV) + (size_t)R * quads * BC);
-    MI_REQUIRE(lds <= 60 * 1024, "CrossMIPs: MIP rows of %d pixels do not fit the NCC kernel's LDS tile", dimv);
+    // rows staged together: about six items per lane, within 60 KB of LDS (three work-groups per CU); rows too wide for that
+    // take up to the CU's whole LDS, one row at a time
+    const int pitch1 = quads * BC + BV, pitch2 = quads * BC;
+    const int fit = ((60 * 1024) / (int)sizeof(float) - (BU - 1) * pitch1) / (pitch1 + pitch2);
+    const int R = imax(1, imin(imin(rows_per_chunk, 1536 / quads), fit));
+    const size_t lds = sizeof(float) * ((size_t)(R + BU - 1) * pitch1 + (size_t)R * pitch2);
+    MI_REQUIRE(lds <= 156 * 1024, "CrossMIPs: MIP rows of %d pixels do not fit the NCC kernel's LDS tile", dimv);
+    if (lds > 60 * 1024) {
+        static bool raised = false;  // benign race: the attribute is idempotent
+        if (!raised) {
+            MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ncc_blk), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+            raised = true;
+        }
+    }
     const size_t need = sizeof(double) * (size_t)chunks * n_blocks * BU * BV;
     if (partial.bytes < need) {
         MI_HIP(hipStreamSynchronize(s));  // an earlier launch of this stream may still read the old buffer
         MI_TRY(partial.alloc(need));
     }
     hipLaunchKernelGGL(k_ncc_blk, dim3(n_blocks, chunks), dim3(BLK_THREADS), lds, s, m1, m2, dimu, dimv, delayu, delayv, nvb, d_blocks, n_blocks,
-                       rows_per_chunk, R, partial.as<double>());
+                       rows_per_chunk, R, partial.as<double>(), std::getenv("MI_NCC_DBG") ? std::atoi(std::getenv("MI_NCC_DBG")) : 0);
     MI_TRY(launch_check("k_ncc_blk"));
     hipLaunchKernelGGL(k_ncc_finish, dim3((n_entries + 255) / 256), dim3(256), 0, s, partial.as<double>(), chunks, n_blocks, nvb, d_entries,
                        n_entries, dimu, dimv, delayu, delayv, v1, v2, d_out);
@@ -608,7 +634,7 @@ int refine_neighbourhood(hipStream_t s, const mi_ncc_params& P, const float* map
         const int n_miss = (int)miss.size() / 3;
         MI_REQUIRE(n_miss == H * W - (H - std::abs(deltau)) * (W - std::abs(deltav)), "CrossMIPs: incomplete NCC map in compute_Neighborhood");
         if (n_miss > 0) {
-            // the missing entries are covered by 2 x 8 blocks of shifts anchored at the smallest missing (u, v)
+            // the missing entries are covered by 4 x 8 blocks of shifts anchored at the smallest missing (u, v)
             int ub = miss[0], vb = miss[1];
             for (int q = 1; q < n_miss; ++q) { ub = imin(ub, miss[3 * q]); vb = imin(vb, miss[3 * q + 1]); }
             std::vector<int>& lst = ws.host_groups;   // blocks {u0, v0} ..., then entries {u, v, partial index, slot} ...
@@ -746,7 +772,7 @@ int pair_enqueue(hipStream_t s, const float* A, const float* B, int dimi, int di
     float* base = ws.buf.as<float>();
     // six MIPs start at 0 (libcrossmips.cpp:319-337)
     MI_HIP(hipMemsetAsync(base, 0, sizeof(float) * pl.g[0].ps1, s));
-    dim3 grid((pl.dimj_v + 255) / 256, (pl.dimi_v + MIP_ROWS - 1) / MIP_ROWS, 2);
+    dim3 grid((pl.dimj_v + 63) / 64, (pl.dimi_v + MIP_ROWS - 1) / MIP_ROWS, 2);
     hipLaunchKernelGGL(k_mips, grid, dim3(256), 0, s, A, B, pl.dimk, pl.dimi_v, pl.dimj_v, (size_t)dimi * dimj, dimj, pl.ai0, pl.aj0,
                        base + pl.g[0].mip1, base + pl.g[1].mip1, base + pl.g[2].mip1, base + pl.g[0].mip2, base + pl.g[1].mip2,
                        base + pl.g[2].mip2);
@@ -913,7 +939,7 @@ extern "C" int mi_ncc_compute_mips(int dev, void* stream, const float* A, const 
     float* outs[6] = {xy1, xz1, yz1, xy2, xz2, yz2};
     const size_t sz[3] = {(size_t)dimi_v * dimj_v, (size_t)dimi_v * dimk, (size_t)dimj_v * dimk};
     for (int m = 0; m < 6; ++m) MI_HIP(hipMemsetAsync(outs[m], 0, sizeof(float) * sz[m % 3], s));
-    dim3 grid((dimj_v + 255) / 256, (dimi_v + MIP_ROWS - 1) / MIP_ROWS, 2);
+    dim3 grid((dimj_v + 63) / 64, (dimi_v + MIP_ROWS - 1) / MIP_ROWS, 2);
     hipLaunchKernelGGL(k_mips, grid, dim3(256), 0, s, A, B, dimk, dimi_v, dimj_v, (size_t)dimi * dimj, dimj, side == MI_NORTH_SOUTH ? ni : 0,
                        side == MI_WEST_EAST ? nj : 0, xy1, xz1, yz1, xy2, xz2, yz2);
     return launch_check("k_mips");
