@@ -277,7 +277,7 @@ __global__ __launch_bounds__(64) void k_sat_cols(int dimu, int dimv, double* __r
 constexpr int BU = 4, BV = 8, BC = 4, BLK_THREADS = 256;
 __global__ __launch_bounds__(BLK_THREADS) void k_ncc_blk(const float* __restrict__ m1, const float* __restrict__ m2, int dimu, int dimv, int du,
                                                          int dv, int nvb, const int* __restrict__ blocks, int n_blocks, int rows_per_chunk,
-                                                         int R, double* __restrict__ partial, int dbg) {
+                                                         int R, int seg_w, int nseg, double* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     int u0, v0;
     if (blocks) {
@@ -287,8 +287,11 @@ __global__ __launch_bounds__(BLK_THREADS) void k_ncc_blk(const float* __restrict
         u0 = (int)(blockIdx.x / nvb) * BU - du;
         v0 = (int)(blockIdx.x % nvb) * BV - dv;
     }
-    const int r_begin = (int)blockIdx.y * rows_per_chunk, r_end = min(dimu, r_begin + rows_per_chunk);
-    const int quads = (dimv + BC - 1) / BC, pitch1 = quads * BC + BV, pitch2 = quads * BC;
+    // chunk = (row chunk, column segment of seg_w m2 columns): wide MIPs are cut so that many rows fit one LDS stage
+    const int rc = (int)blockIdx.y / nseg, sg = (int)blockIdx.y - rc * nseg;
+    const int r_begin = rc * rows_per_chunk, r_end = min(dimu, r_begin + rows_per_chunk);
+    const int cbeg = sg * seg_w, cw = min(seg_w, dimv - cbeg);                 // m2 columns [cbeg, cbeg + cw)
+    const int quads = (cw + BC - 1) / BC, pitch1 = seg_w + BV, pitch2 = seg_w;  // seg_w is a multiple of BC
     float* l1 = lds;                            // R + BU - 1 rows of m1: l1[j][x] = m1[rb + u0 + j][v0 + x]
     float* l2 = lds + (R + BU - 1) * pitch1;    // R rows of m2
     double acc[BU][BV];
@@ -299,19 +302,19 @@ __global__ __launch_bounds__(BLK_THREADS) void k_ncc_blk(const float* __restrict
     for (int rb = r_begin; rb < r_end; rb += R) {
         const int nrow = min(R, r_end - rb);
         __syncthreads();
-        if (!(dbg & 2)) {   // staging: a wave per row (no index division), four independent 64-column loads per lane in flight
+        {   // staging: a wave per row (no index division), four independent 64-column loads per lane in flight
             constexpr int UNR = 4;
             const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
             for (int j = wave; j < nrow + BU - 1; j += BLK_THREADS / 64) {
                 const int r1 = rb + u0 + j;
                 const bool row_ok = r1 >= 0 && r1 < dimu;
-                const float* src = m1 + (size_t)(row_ok ? r1 : 0) * dimv + v0;
+                const float* src = m1 + (size_t)(row_ok ? r1 : 0) * dimv + cbeg + v0;
                 float* dst = l1 + j * pitch1;
                 for (int x0 = lane; x0 < pitch1; x0 += 64 * UNR) {
                     float v[UNR];
 #pragma unroll
                     for (int q = 0; q < UNR; ++q) {
-                        const int x = x0 + 64 * q, c1 = v0 + x;
+                        const int x = x0 + 64 * q, c1 = cbeg + v0 + x;
                         v[q] = (row_ok && x < pitch1 && c1 >= 0 && c1 < dimv) ? src[x] : 0.0f;
                     }
 #pragma unroll
@@ -320,12 +323,12 @@ __global__ __launch_bounds__(BLK_THREADS) void k_ncc_blk(const float* __restrict
                 }
             }
             for (int j = wave; j < nrow; j += BLK_THREADS / 64) {
-                const float* src = m2 + (size_t)(rb + j) * dimv;
+                const float* src = m2 + (size_t)(rb + j) * dimv + cbeg;
                 float* dst = l2 + j * pitch2;
                 for (int x0 = lane; x0 < pitch2; x0 += 64 * UNR) {
                     float v[UNR];
 #pragma unroll
-                    for (int q = 0; q < UNR; ++q) v[q] = x0 + 64 * q < dimv ? src[x0 + 64 * q] : 0.0f;
+                    for (int q = 0; q < UNR; ++q) v[q] = x0 + 64 * q < cw ? src[x0 + 64 * q] : 0.0f;
 #pragma unroll
                     for (int q = 0; q < UNR; ++q)
                         if (x0 + 64 * q < pitch2) dst[x0 + 64 * q] = v[q];
@@ -333,7 +336,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_ncc_blk(const float* __restrict
             }
         }
         __syncthreads();
-        if (!(dbg & 1)) for (int it = threadIdx.x; it < nrow * quads; it += BLK_THREADS) {
+        for (int it = threadIdx.x; it < nrow * quads; it += BLK_THREADS) {
             const int rr = it / quads, c = (it - rr * quads) * BC;
             const float4 tq = *reinterpret_cast<const float4*>(l2 + rr * pitch2 + c);
             const double t[BC] = {(double)tq.x, (double)tq.y, (double)tq.z, (double)tq.w};
@@ -569,32 +572,26 @@ int ncc_launch(hipStream_t s, const float* m1, const float* m2, int dimu, int di
         n_entries = (2 * delayu + 1) * (2 * delayv + 1);
     }
     if (n_blocks <= 0 || n_entries <= 0) return MI_OK;
-    int chunks = (1536 + n_blocks - 1) / n_blocks;              // enough work-groups for 256 CUs
-    chunks = imax(1, imin(chunks, (dimu + 7) / 8));
-    const int rows_per_chunk = (dimu + chunks - 1) / chunks;
-    chunks = (dimu + rows_per_chunk - 1) / rows_per_chunk;
-    const int quads = (dimv + BC - 1) / BC;
-    // rows staged together: about six items per lane, within 60 KB of LDS (three work-groups per CU); rows too wide for that
-    // take up to the CU's whole LDS, one row at a time
-    const int pitch1 = quads * BC + BV, pitch2 = quads * BC;
+    // column segments of at most 512 m2 columns, row chunks so that about 1536 work-groups exist
+    const int nseg = (dimv + 511) / 512;
+    const int seg_w = ((dimv + nseg - 1) / nseg + BC - 1) / BC * BC;
+    int rchunks = (1536 + n_blocks * nseg - 1) / (n_blocks * nseg);
+    rchunks = imax(1, imin(rchunks, (dimu + 7) / 8));
+    const int rows_per_chunk = (dimu + rchunks - 1) / rchunks;
+    rchunks = (dimu + rows_per_chunk - 1) / rows_per_chunk;
+    const int chunks = rchunks * nseg;
+    // rows staged together: about six items per lane, within 60 KB of LDS (three work-groups per CU)
+    const int quads = seg_w / BC, pitch1 = seg_w + BV, pitch2 = seg_w;
     const int fit = ((60 * 1024) / (int)sizeof(float) - (BU - 1) * pitch1) / (pitch1 + pitch2);
     const int R = imax(1, imin(imin(rows_per_chunk, 1536 / quads), fit));
     const size_t lds = sizeof(float) * ((size_t)(R + BU - 1) * pitch1 + (size_t)R * pitch2);
-    MI_REQUIRE(lds <= 156 * 1024, "CrossMIPs: MIP rows of %d pixels do not fit the NCC kernel's LDS tile", dimv);
-    if (lds > 60 * 1024) {
-        static bool raised = false;  // benign race: the attribute is idempotent
-        if (!raised) {
-            MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ncc_blk), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
-            raised = true;
-        }
-    }
     const size_t need = sizeof(double) * (size_t)chunks * n_blocks * BU * BV;
     if (partial.bytes < need) {
         MI_HIP(hipStreamSynchronize(s));  // an earlier launch of this stream may still read the old buffer
         MI_TRY(partial.alloc(need));
     }
     hipLaunchKernelGGL(k_ncc_blk, dim3(n_blocks, chunks), dim3(BLK_THREADS), lds, s, m1, m2, dimu, dimv, delayu, delayv, nvb, d_blocks, n_blocks,
-                       rows_per_chunk, R, partial.as<double>(), std::getenv("MI_NCC_DBG") ? std::atoi(std::getenv("MI_NCC_DBG")) : 0);
+                       rows_per_chunk, R, seg_w, nseg, partial.as<double>());
     MI_TRY(launch_check("k_ncc_blk"));
     hipLaunchKernelGGL(k_ncc_finish, dim3((n_entries + 255) / 256), dim3(256), 0, s, partial.as<double>(), chunks, n_blocks, nvb, d_entries,
                        n_entries, dimu, dimv, delayu, delayv, v1, v2, d_out);
