@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <string>
 #include <thread>
 #include <type_traits>
@@ -916,9 +917,14 @@ extern "C" int mi_ncc_mips_batch(int dev, void* stream, int n_pairs, const float
         rcs[t] = rc;
     };
     std::vector<std::thread> pool;
-    for (int t = 1; t < NT; ++t) pool.emplace_back(worker, t);
+    int started = 1;  // this thread is worker 0
+    try {
+        for (int t = 1; t < NT; ++t) { pool.emplace_back(worker, t); ++started; }
+    } catch (const std::exception&) {  // no more threads: the pairs of the missing workers are taken below
+    }
     worker(0);
     for (auto& th : pool) th.join();
+    for (int t = started; t < NT; ++t) worker(t);
     (void)hipEventDestroy(ev);
     for (int t = 0; t < NT; ++t)
         if (rcs[t] != MI_OK) return fail(rcs[t], "%s", msgs[t].c_str());
