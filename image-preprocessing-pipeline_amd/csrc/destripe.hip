@@ -86,26 +86,30 @@ __global__ __launch_bounds__(kThreads) void k_dwt_z(const float* __restrict__ in
     const size_t r = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * V;
     if (r >= rows) return;
     const int i0 = blockIdx.y * chunk, i1 = min(m, i0 + chunk);
-    auto sample = [&](int j) {
+    auto raw = [&](int j) {  // zero padding: log1p(0) = 0
         const int jj = sym_index(j, n);
-        T v = T();
-        if (jj < n_valid) {
-            v = *reinterpret_cast<const T*>(in + (size_t)jj * rows + r);
-            if (LOG1P) {
+        return jj < n_valid ? *reinterpret_cast<const T*>(in + (size_t)jj * rows + r) : T();
+    };
+    auto xf = [&](T v) {
+        if (LOG1P) {
 #pragma unroll
-                for (int c = 0; c < V; ++c) vref(v, c) = log1pf(vget(v, c));
-            }
+            for (int c = 0; c < V; ++c) vref(v, c) = log1pf(vget(v, c));
         }
         return v;
     };
     T w[LF];
 #pragma unroll
-    for (int q = 2; q < LF; ++q) w[q] = sample(2 * i0 - 16 + q - 2);  // the first step shifts these into place
+    for (int q = 2; q < LF; ++q) w[q] = xf(raw(2 * i0 - 16 + q - 2));  // the first step shifts these into place
+    T n0 = raw(2 * i0), n1 = raw(2 * i0 + 1);  // the two new samples of a step are requested one step ahead
     for (int i = i0; i < i1; ++i) {
 #pragma unroll
         for (int q = 0; q < LF - 2; ++q) w[q] = w[q + 2];
-        w[LF - 2] = sample(2 * i);
-        w[LF - 1] = sample(2 * i + 1);
+        w[LF - 2] = xf(n0);
+        w[LF - 1] = xf(n1);
+        if (i + 1 < i1) {
+            n0 = raw(2 * i + 2);
+            n1 = raw(2 * i + 3);
+        }
         T al = T(), ah = T();
 #pragma unroll
         for (int q = 0; q < LF; ++q) {
@@ -216,15 +220,20 @@ __global__ __launch_bounds__(kThreads) void k_idwt_z(const float* __restrict__ a
         wa[c] = k < m ? a[(size_t)k * rows + rw] : 0.0f;
         wd[c] = k < m ? d[(size_t)k * rows + rw] : 0.0f;
     }
+    auto coef = [&](const float* __restrict__ src, int k) { return k < m ? src[(size_t)k * rows + rw] : 0.0f; };
+    float na = coef(a, p0 + 8), nd = coef(d, p0 + 8);  // requested one step ahead
     for (int p = p0; p < p1; ++p) {
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             wa[c] = wa[c + 1];
             wd[c] = wd[c + 1];
         }
-        const int k = p + 8;
-        wa[8] = k < m ? a[(size_t)k * rows + rw] : 0.0f;
-        wd[8] = k < m ? d[(size_t)k * rows + rw] : 0.0f;
+        wa[8] = na;
+        wd[8] = nd;
+        if (p + 1 < p1) {
+            na = coef(a, p + 9);
+            nd = coef(d, p + 9);
+        }
         float e = 0.0f, o = 0.0f;
 #pragma unroll
         for (int c = 0; c < 9; ++c) {
