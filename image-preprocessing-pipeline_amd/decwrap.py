@@ -64,7 +64,8 @@ def build_parser(default_gpus):
     p.add_argument("--stop-criterion", type=float, default=0)
     p.add_argument("--block-size-max", type=int, default=0, help="Max elements per GPU block (0: from free HBM)")
     p.add_argument("--gpu-indices", type=int, nargs="+", default=default_gpus, help="1-based GPU indices")
-    p.add_argument("--gpu-workers-per-gpu", type=int, default=1)
+    p.add_argument("--gpu-workers-per-gpu", type=int, default=2,
+                   help="workers (own stream + pinned staging) per GPU: two overlap one block's PCIe / host staging with another's kernels")
     p.add_argument("--cpu-workers", type=int, default=0)
     p.add_argument("--signal-amp", type=float, default=1.0)
     p.add_argument("--gaussian-sigma", type=float, nargs=3, default=[0.5, 0.5, 2.5])
@@ -145,7 +146,9 @@ def main(argv=None):
     filt = L.Filter(tuple(args.gaussian_sigma), tuple(args.gaussian_filter_size), 0.0, args.destripe_sigma,
                     args.regularize_interval, args.use_fft, args.adaptive_psf)
     gpu = args.gpu_indices[0]
-    bmax = args.block_size_max or L.estimate_block_size_max(gpu - 1, n_real=3, n_complex=2 if args.use_fft else 0)
+    # workers that share a device share its memory (decwrap.py:133-169 divides by the workers per GPU as well)
+    per_dev = max(1, args.gpu_workers_per_gpu) * max(1, args.gpu_indices.count(gpu))
+    bmax = args.block_size_max or L.estimate_block_size_max(gpu - 1, n_real=3, n_complex=2 if args.use_fft else 0) // per_dev
     block = L.autosplit((sx, sy, sz), psf.shape[::-1], filt, bmax, args.numit)
     log.info(f"block grid {block.nx} x {block.ny} x {block.nz}, core ({block.x} {block.y} {block.z}), "
              f"pad ({block.x_pad} {block.y_pad} {block.z_pad}), fft_shape {block.fft_shape}")
