@@ -27,8 +27,8 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int LF = 18;  // db9
 
-// Lo_R = sqrt(2) * dbwavf('db9'): the extremal-phase Daubechies filter with 9 vanishing moments (published table; recomputed
-// by spectral factorisation in oracle/destripe_oracle.py::db_filters, agreement 3e-11)
+// Lo_R = sqrt(2) * dbwavf('db9'): the extremal-phase Daubechies filter with 9 vanishing moments (published table; the tests
+// recompute it by spectral factorisation of the half-band polynomial, agreement 3e-11)
 const double kLoR[LF] = {3.80779473638783381e-02,  2.43834674612590230e-01,  6.04823123690111153e-01,  6.57288078051299962e-01,
                          1.33197385825007591e-01,  -2.93273783279174305e-01, -9.68407832229760124e-02, 1.48540749338105876e-01,
                          3.07256814793338794e-02,  -6.76328290613307237e-02, 2.50947114831909018e-04,  2.23616621236789742e-02,
