@@ -11,7 +11,7 @@
 //   k_mip_mean / k_sat_rows / k_sat_cols   fp64 summed-area tables of (f - c0), (f - c0)^2 and of the float tile sums:
 //                 every term of compute_NCC (:1163-1292) except the cross term sum f*t becomes O(1) per shift, with
 //                 the reference's means (float tile sums + border pixels) reproduced exactly.
-//   k_ncc_blk / k_ncc_finish   cross terms sum f*t in fp64 for blocks of 4 x 8 shifts from LDS-staged MIP rows, partial sums per
+//   k_ncc_blk / k_ncc_finish   cross terms sum f*t in fp64 for groups of 8 blocks of 4 x 8 shifts from LDS-staged MIP rows, partial sums per
 //                 row chunk added in a fixed order; replaces gpu_NCC_map/gpu_NCC_miss (:730-935).  Serves full maps and the
 //                 "missing entries" of the neighbourhood refinement alike.
 // Host side (this file, plain C++): argmax, neighbourhood refinement, peak widths and the final
@@ -267,33 +267,44 @@ __global__ __launch_bounds__(64) void k_sat_cols(int dimu, int dimv, double* __r
     }
 }
 
-// NCC cross terms, register-blocked: one work-group per block of (4 u) x (8 v) shifts and chunk of m2 rows.  The m1 rows of
-// the block (shifted by v0, zero outside the MIP) and the m2 rows are staged in LDS with unit-stride loads; a lane then owns 4
-// neighbouring m2 columns of a row and, per u, the 11 m1 values its 8 shifts pair them with -- thirteen 16-byte LDS reads feed
-// 128 fp64 FMAs (exact fp32 products accumulated in fp64).  Zeros outside the MIP restrict every shift's sum to its own window.
-// Blocks come from a regular grid (full maps) or from a list (the "missing entries" of the neighbourhood refinement,
-// gpu_NCC_miss).  The chunks' partial sums are added up in a fixed order by k_ncc_finish, which also applies the window
-// statistics from the summed-area tables: deterministic, whatever the launch geometry.  Replaces gpu_NCC_map / gpu_NCC_miss
-// (compute_funcs.cu:730-935).
-constexpr int BU = 4, BV = 8, BC = 4, BLK_THREADS = 256;
+// NCC cross terms, register-blocked.  A block is (4 u) x (8 v) shifts; a work-group takes a GROUP of up to 8 blocks that share
+// u0 (a "row" of the shift map), a chunk of m2 rows and a segment of <= 512 m2 columns: wave w owns block w.  The m2 rows and
+// the window of m1 rows all the group's blocks need (columns from the smallest v0 on, zero outside the MIP) are staged in LDS
+// ONCE for the eight blocks with unit-stride loads -- staging, not the fp64 pipe, was the bound when every block staged its
+// own window.  A lane then owns 4 neighbouring m2 columns of a row and, per u, the 11 m1 values its 8 shifts pair them with:
+// thirteen 16-byte LDS reads feed 128 fp64 FMAs (exact fp32 products accumulated in fp64).  Zeros outside the MIP restrict
+// every shift's sum to its own window.  Each wave reduces its own 32 sums (no work-group reduction).  Groups come from the
+// regular grid (full maps: group = u-block, wave = v-block) or from a list (the "missing entries" of the neighbourhood
+// refinement, gpu_NCC_miss).  The chunks' partial sums are added up in a fixed order by k_ncc_finish, which also applies the
+// window statistics from the summed-area tables: deterministic, whatever the launch geometry.  Replaces gpu_NCC_map /
+// gpu_NCC_miss (compute_funcs.cu:730-935).
+constexpr int BU = 4, BV = 8, BC = 4, GW = 8, BLK_THREADS = 64 * GW;
+// groups (list mode): 2 + GW ints each: {u0, number of blocks nb <= GW, v0[0] <= v0[1] <= ... (multiples of BV apart)}
 __global__ __launch_bounds__(BLK_THREADS) void k_ncc_blk(const float* __restrict__ m1, const float* __restrict__ m2, int dimu, int dimv, int du,
-                                                         int dv, int nvb, const int* __restrict__ blocks, int n_blocks, int rows_per_chunk,
-                                                         int R, int seg_w, int nseg, double* __restrict__ partial) {
+                                                         int dv, int nvb, const int* __restrict__ groups, int n_groups, int rows_per_chunk,
+                                                         int R, int seg_w, int nseg, int pitch1, double* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    int u0, v0;
-    if (blocks) {
-        u0 = blocks[2 * blockIdx.x];
-        v0 = blocks[2 * blockIdx.x + 1];
-    } else {
-        u0 = (int)(blockIdx.x / nvb) * BU - du;
-        v0 = (int)(blockIdx.x % nvb) * BV - dv;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int u0, nb, vmin, voff;  // voff: this wave's v0 - vmin
+    if (groups) {
+        const int* g = groups + (size_t)blockIdx.x * (2 + GW);
+        u0 = g[0];
+        nb = g[1];
+        vmin = g[2];
+        voff = g[2 + min(wave, nb - 1)] - vmin;
+    } else {  // group = (u-block, run of GW v-blocks)
+        const int nvg = (nvb + GW - 1) / GW, ub = (int)blockIdx.x / nvg, vg = (int)blockIdx.x - ub * nvg;
+        u0 = ub * BU - du;
+        nb = min(GW, nvb - vg * GW);
+        vmin = vg * GW * BV - dv;
+        voff = min(wave, nb - 1) * BV;
     }
     // chunk = (row chunk, column segment of seg_w m2 columns): wide MIPs are cut so that many rows fit one LDS stage
     const int rc = (int)blockIdx.y / nseg, sg = (int)blockIdx.y - rc * nseg;
     const int r_begin = rc * rows_per_chunk, r_end = min(dimu, r_begin + rows_per_chunk);
-    const int cbeg = sg * seg_w, cw = min(seg_w, dimv - cbeg);                 // m2 columns [cbeg, cbeg + cw)
-    const int quads = (cw + BC - 1) / BC, pitch1 = seg_w + BV, pitch2 = seg_w;  // seg_w is a multiple of BC
-    float* l1 = lds;                            // R + BU - 1 rows of m1: l1[j][x] = m1[rb + u0 + j][v0 + x]
+    const int cbeg = sg * seg_w, cw = min(seg_w, dimv - cbeg);  // m2 columns [cbeg, cbeg + cw)
+    const int quads = (cw + BC - 1) / BC, pitch2 = seg_w;        // seg_w and pitch1 are multiples of BC
+    float* l1 = lds;                            // R + BU - 1 rows of m1: l1[j][x] = m1[rb + u0 + j][cbeg + vmin + x]
     float* l2 = lds + (R + BU - 1) * pitch1;    // R rows of m2
     double acc[BU][BV];
 #pragma unroll
@@ -305,17 +316,16 @@ __global__ __launch_bounds__(BLK_THREADS) void k_ncc_blk(const float* __restrict
         __syncthreads();
         {   // staging: a wave per row (no index division), four independent 64-column loads per lane in flight
             constexpr int UNR = 4;
-            const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-            for (int j = wave; j < nrow + BU - 1; j += BLK_THREADS / 64) {
+            for (int j = wave; j < nrow + BU - 1; j += GW) {
                 const int r1 = rb + u0 + j;
                 const bool row_ok = r1 >= 0 && r1 < dimu;
-                const float* src = m1 + (size_t)(row_ok ? r1 : 0) * dimv + cbeg + v0;
+                const float* src = m1 + (size_t)(row_ok ? r1 : 0) * dimv + cbeg + vmin;
                 float* dst = l1 + j * pitch1;
                 for (int x0 = lane; x0 < pitch1; x0 += 64 * UNR) {
                     float v[UNR];
 #pragma unroll
                     for (int q = 0; q < UNR; ++q) {
-                        const int x = x0 + 64 * q, c1 = cbeg + v0 + x;
+                        const int x = x0 + 64 * q, c1 = cbeg + vmin + x;
                         v[q] = (row_ok && x < pitch1 && c1 >= 0 && c1 < dimv) ? src[x] : 0.0f;
                     }
 #pragma unroll
@@ -323,7 +333,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_ncc_blk(const float* __restrict
                         if (x0 + 64 * q < pitch1) dst[x0 + 64 * q] = v[q];
                 }
             }
-            for (int j = wave; j < nrow; j += BLK_THREADS / 64) {
+            for (int j = wave; j < nrow; j += GW) {
                 const float* src = m2 + (size_t)(rb + j) * dimv + cbeg;
                 float* dst = l2 + j * pitch2;
                 for (int x0 = lane; x0 < pitch2; x0 += 64 * UNR) {
@@ -337,45 +347,42 @@ __global__ __launch_bounds__(BLK_THREADS) void k_ncc_blk(const float* __restrict
             }
         }
         __syncthreads();
-        for (int it = threadIdx.x; it < nrow * quads; it += BLK_THREADS) {
-            const int rr = it / quads, c = (it - rr * quads) * BC;
-            const float4 tq = *reinterpret_cast<const float4*>(l2 + rr * pitch2 + c);
-            const double t[BC] = {(double)tq.x, (double)tq.y, (double)tq.z, (double)tq.w};
+        if (wave < nb) {
+            for (int it = lane; it < nrow * quads; it += 64) {
+                const int rr = it / quads, c = (it - rr * quads) * BC;
+                const float4 tq = *reinterpret_cast<const float4*>(l2 + rr * pitch2 + c);
+                const double t[BC] = {(double)tq.x, (double)tq.y, (double)tq.z, (double)tq.w};
 #pragma unroll
-            for (int a = 0; a < BU; ++a) {
-                const float4* row = reinterpret_cast<const float4*>(l1 + (rr + a) * pitch1 + c);
-                const float4 f0 = row[0], f1 = row[1], f2 = row[2];
-                const double f[12] = {(double)f0.x, (double)f0.y, (double)f0.z, (double)f0.w, (double)f1.x, (double)f1.y,
-                                      (double)f1.z, (double)f1.w, (double)f2.x, (double)f2.y, (double)f2.z, (double)f2.w};
+                for (int a = 0; a < BU; ++a) {
+                    const float4* row = reinterpret_cast<const float4*>(l1 + (rr + a) * pitch1 + voff + c);
+                    const float4 f0 = row[0], f1 = row[1], f2 = row[2];
+                    const double f[12] = {(double)f0.x, (double)f0.y, (double)f0.z, (double)f0.w, (double)f1.x, (double)f1.y,
+                                          (double)f1.z, (double)f1.w, (double)f2.x, (double)f2.y, (double)f2.z, (double)f2.w};
 #pragma unroll
-                for (int b = 0; b < BV; ++b)
+                    for (int b = 0; b < BV; ++b)
 #pragma unroll
-                    for (int x = 0; x < BC; ++x) acc[a][b] = fma(f[x + b], t[x], acc[a][b]);
+                        for (int x = 0; x < BC; ++x) acc[a][b] = fma(f[x + b], t[x], acc[a][b]);
+                }
             }
         }
     }
-    // one reduction for the 16 sums: wave trees, then lane (a, b) adds the four waves' values in wave order
-    __shared__ double red[BLK_THREADS / 64][BU * BV];
+    if (wave >= nb) return;
+    // the wave's own 32 sums: shuffle tree, lane 0 stores
+    double* dst = partial + (((size_t)blockIdx.y * n_groups + blockIdx.x) * GW + wave) * (BU * BV);
 #pragma unroll
     for (int a = 0; a < BU; ++a)
 #pragma unroll
         for (int b = 0; b < BV; ++b) {
             double v = acc[a][b];
             for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][a * BV + b] = v;
+            if (lane == 0) dst[a * BV + b] = v;
         }
-    __syncthreads();
-    if (threadIdx.x < BU * BV) {
-        double v = 0.0;
-        for (int w = 0; w < BLK_THREADS / 64; ++w) v += red[w][threadIdx.x];
-        partial[((size_t)blockIdx.y * n_blocks + blockIdx.x) * (BU * BV) + threadIdx.x] = v;
-    }
 }
 
 // one lane per requested entry: cross term = sum of the chunks' partials (fixed order), then the NCC value of
 // compute_NCC (compute_funcs.cu:1163-1292).  entries == nullptr: the full (2du+1) x (2dv+1) map in row-major order;
-// else entry e = {u, v, slot in the block's 4 x 8 partials (block * 32 + a * 8 + b), output slot}
-__global__ __launch_bounds__(256) void k_ncc_finish(const double* __restrict__ partial, int n_chunks, int n_blocks, int nvb,
+// else entry e = {u, v, slot in the partials of a chunk ((group * GW + wave) * 32 + a * 8 + b), output slot}
+__global__ __launch_bounds__(256) void k_ncc_finish(const double* __restrict__ partial, int n_chunks, int n_groups,
                                                     const int* __restrict__ entries, int n_entries, int dimu, int dimv, int du, int dv,
                                                     SatView s1, SatView s2, float* __restrict__ out) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -390,13 +397,14 @@ __global__ __launch_bounds__(256) void k_ncc_finish(const double* __restrict__ p
         const int W = 2 * dv + 1, iu = e / W, iv = e - iu * W;
         u = iu - du;
         v = iv - dv;
-        pidx = (((iu / BU) * nvb + iv / BV) * BU + iu % BU) * BV + iv % BV;
+        const int nvb = (W + BV - 1) / BV, slots = (nvb + GW - 1) / GW * GW;  // block slots per u-block: its groups x GW
+        pidx = (((iu / BU) * slots + iv / BV) * BU + iu % BU) * BV + iv % BV;
         slot = e;
     }
     const int nr = dimu - abs(u), nc = dimv - abs(v);
     if (nr <= 0 || nc <= 0) { out[slot] = __int_as_float(0x7fc00000); return; }  // reference: empty loops, 0/0
     double cr = 0.0;
-    for (int ch = 0; ch < n_chunks; ++ch) cr += partial[(size_t)ch * n_blocks * (BU * BV) + pidx];
+    for (int ch = 0; ch < n_chunks; ++ch) cr += partial[(size_t)ch * n_groups * (GW * BU * BV) + pidx];
     double fm, sf, F1, tm, st, F2;
     window_stats(s1, dimu, dimv, max(u, 0), max(v, 0), nr, nc, &fm, &sf, &F1);
     window_stats(s2, dimu, dimv, max(-u, 0), max(-v, 0), nr, nc, &tm, &st, &F2);
@@ -558,44 +566,45 @@ struct Workspace {
     DevBuf partial[3]; // doubles: per plane, the row chunks' partial cross terms of a full map
     size_t floats = 0;
     int list_cap = 0;
-    std::vector<int> host_groups, host_entries;
+    std::vector<int> host_groups, host_entries, host_slots;
     std::vector<long long> host_keys;
     PinnedBuf pin_groups, pin_res, pin_maps;
 };
 
-// NCC values of one plane: the blocked cross terms + the finishing pass.  d_blocks / d_entries == nullptr: the full map into
-// d_out; else the listed blocks {u0, v0} and entries {u, v, partial index, output slot}.  `partial` grows as needed.
+// NCC values of one plane: the blocked cross terms + the finishing pass.  d_groups / d_entries == nullptr: the full map into
+// d_out; else the listed groups {u0, nb, v0[GW]} and entries {u, v, partial index, output slot}.  `partial` grows as needed.
 int ncc_launch(hipStream_t s, const float* m1, const float* m2, int dimu, int dimv, int delayu, int delayv, const SatView& v1, const SatView& v2,
-               const int* d_blocks, int n_blocks, const int* d_entries, int n_entries, DevBuf& partial, float* d_out) {
+               const int* d_groups, int n_groups, const int* d_entries, int n_entries, DevBuf& partial, float* d_out) {
     const int nvb = (2 * delayv + 1 + BV - 1) / BV;
-    if (!d_blocks) {
-        n_blocks = ((2 * delayu + 1 + BU - 1) / BU) * nvb;
+    if (!d_groups) {
+        n_groups = ((2 * delayu + 1 + BU - 1) / BU) * ((nvb + GW - 1) / GW);
         n_entries = (2 * delayu + 1) * (2 * delayv + 1);
     }
-    if (n_blocks <= 0 || n_entries <= 0) return MI_OK;
-    // column segments of at most 512 m2 columns, row chunks so that about 1536 work-groups exist
+    if (n_groups <= 0 || n_entries <= 0) return MI_OK;
+    // column segments of at most 512 m2 columns, row chunks so that about 768 work-groups of 8 waves exist
     const int nseg = (dimv + 511) / 512;
     const int seg_w = ((dimv + nseg - 1) / nseg + BC - 1) / BC * BC;
-    int rchunks = (1536 + n_blocks * nseg - 1) / (n_blocks * nseg);
+    int rchunks = (768 + n_groups * nseg - 1) / (n_groups * nseg);
     rchunks = imax(1, imin(rchunks, (dimu + 7) / 8));
     const int rows_per_chunk = (dimu + rchunks - 1) / rchunks;
     rchunks = (dimu + rows_per_chunk - 1) / rows_per_chunk;
     const int chunks = rchunks * nseg;
-    // rows staged together: about six items per lane, within 60 KB of LDS (three work-groups per CU)
-    const int quads = seg_w / BC, pitch1 = seg_w + BV, pitch2 = seg_w;
+    // the m1 window of a group: its blocks start at most (GW - 1) * BV columns apart
+    const int quads = seg_w / BC, pitch1 = seg_w + GW * BV, pitch2 = seg_w;
+    // rows staged together: a few items per lane and stage, within 60 KB of LDS (two work-groups per CU)
     const int fit = ((60 * 1024) / (int)sizeof(float) - (BU - 1) * pitch1) / (pitch1 + pitch2);
     const int R = imax(1, imin(imin(rows_per_chunk, 1536 / quads), fit));
     const size_t lds = sizeof(float) * ((size_t)(R + BU - 1) * pitch1 + (size_t)R * pitch2);
-    const size_t need = sizeof(double) * (size_t)chunks * n_blocks * BU * BV;
+    const size_t need = sizeof(double) * (size_t)chunks * n_groups * GW * BU * BV;
     if (partial.bytes < need) {
         MI_HIP(hipStreamSynchronize(s));  // an earlier launch of this stream may still read the old buffer
         MI_TRY(partial.alloc(need));
     }
-    hipLaunchKernelGGL(k_ncc_blk, dim3(n_blocks, chunks), dim3(BLK_THREADS), lds, s, m1, m2, dimu, dimv, delayu, delayv, nvb, d_blocks, n_blocks,
-                       rows_per_chunk, R, seg_w, nseg, partial.as<double>());
+    hipLaunchKernelGGL(k_ncc_blk, dim3(n_groups, chunks), dim3(BLK_THREADS), lds, s, m1, m2, dimu, dimv, delayu, delayv, nvb, d_groups, n_groups,
+                       rows_per_chunk, R, seg_w, nseg, pitch1, partial.as<double>());
     MI_TRY(launch_check("k_ncc_blk"));
-    hipLaunchKernelGGL(k_ncc_finish, dim3((n_entries + 255) / 256), dim3(256), 0, s, partial.as<double>(), chunks, n_blocks, nvb, d_entries,
-                       n_entries, dimu, dimv, delayu, delayv, v1, v2, d_out);
+    hipLaunchKernelGGL(k_ncc_finish, dim3((n_entries + 255) / 256), dim3(256), 0, s, partial.as<double>(), chunks, n_groups, d_entries, n_entries,
+                       dimu, dimv, delayu, delayv, v1, v2, d_out);
     return launch_check("k_ncc_finish");
 }
 
@@ -632,33 +641,46 @@ int refine_neighbourhood(hipStream_t s, const mi_ncc_params& P, const float* map
         const int n_miss = (int)miss.size() / 3;
         MI_REQUIRE(n_miss == H * W - (H - std::abs(deltau)) * (W - std::abs(deltav)), "CrossMIPs: incomplete NCC map in compute_Neighborhood");
         if (n_miss > 0) {
-            // the missing entries are covered by 4 x 8 blocks of shifts anchored at the smallest missing (u, v)
+            // the missing entries are covered by 4 x 8 blocks of shifts anchored at the smallest missing (u, v); blocks of one
+            // u-row form groups of up to GW blocks (one wave each) that share their staged rows
             int ub = miss[0], vb = miss[1];
             for (int q = 1; q < n_miss; ++q) { ub = imin(ub, miss[3 * q]); vb = imin(vb, miss[3 * q + 1]); }
-            std::vector<int>& lst = ws.host_groups;   // blocks {u0, v0} ..., then entries {u, v, partial index, slot} ...
-            lst.clear();
-            std::vector<int>& ent = ws.host_entries;
-            ent.clear();
-            std::vector<long long>& keys = ws.host_keys;
+            std::vector<long long>& keys = ws.host_keys;   // distinct blocks (bu << 20 | bv), sorted
             keys.clear();
+            for (int q = 0; q < n_miss; ++q) keys.push_back((long long)((miss[3 * q] - ub) / BU) * (1 << 20) + (miss[3 * q + 1] - vb) / BV);
+            std::sort(keys.begin(), keys.end());
+            keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+            std::vector<int>& lst = ws.host_groups;        // groups {u0, nb, v0[GW]}
+            lst.clear();
+            std::vector<int>& slot_of = ws.host_slots;     // per block (in `keys` order): group * GW + wave
+            slot_of.assign(keys.size(), 0);
+            int n_groups = 0;
+            for (size_t k = 0; k < keys.size();) {
+                const int bu = (int)(keys[k] >> 20), bv0 = (int)(keys[k] & ((1 << 20) - 1));
+                const size_t base = lst.size();
+                lst.resize(base + 2 + GW, 0);
+                int nb = 0;
+                while (k < keys.size() && nb < GW && (int)(keys[k] >> 20) == bu && (int)(keys[k] & ((1 << 20) - 1)) - bv0 < GW) {
+                    lst[base + 2 + nb] = vb + (int)(keys[k] & ((1 << 20) - 1)) * BV;
+                    slot_of[k] = n_groups * GW + nb;
+                    ++nb;
+                    ++k;
+                }
+                lst[base] = ub + bu * BU;
+                lst[base + 1] = nb;
+                for (int w = nb; w < GW; ++w) lst[base + 2 + w] = lst[base + 2 + nb - 1];
+                ++n_groups;
+            }
+            std::vector<int>& ent = ws.host_entries;       // entries {u, v, partial index, output slot}
+            ent.clear();
             for (int q = 0; q < n_miss; ++q) {
                 const int u = miss[3 * q], v = miss[3 * q + 1];
-                const int bu = (u - ub) / BU, bv = (v - vb) / BV;
-                const long long key = (long long)bu * (1 << 20) + bv;
-                int blk = -1;
-                for (int k = (int)keys.size() - 1; k >= 0; --k)      // row-major order: a recent block almost always
-                    if (keys[k] == key) { blk = k; break; }
-                if (blk < 0) {
-                    blk = (int)keys.size();
-                    keys.push_back(key);
-                    lst.push_back(ub + bu * BU);
-                    lst.push_back(vb + bv * BV);
-                }
+                const long long key = (long long)((u - ub) / BU) * (1 << 20) + (v - vb) / BV;
+                const size_t k = std::lower_bound(keys.begin(), keys.end(), key) - keys.begin();
                 ent.push_back(u); ent.push_back(v);
-                ent.push_back((blk * BU + (u - ub) % BU) * BV + (v - vb) % BV);
+                ent.push_back((slot_of[k] * BU + (u - ub) % BU) * BV + (v - vb) % BV);
                 ent.push_back(miss[3 * q + 2]);
             }
-            const int n_blocks = (int)keys.size();
             const size_t ints = lst.size() + ent.size();
             if ((size_t)ws.list_cap < ints) {
                 MI_HIP(hipStreamSynchronize(s));
@@ -672,7 +694,7 @@ int refine_neighbourhood(hipStream_t s, const mi_ncc_params& P, const float* map
             std::memcpy(ws.pin_groups.as<int>() + lst.size(), ent.data(), sizeof(int) * ent.size());
             MI_HIP(hipMemcpyAsync(ws.list.p, ws.pin_groups.p, sizeof(int) * ints, hipMemcpyHostToDevice, s));
             MI_TRY(ncc_launch(s, d_base + g.mip1, d_base + g.mip2, g.dimu, g.dimv, g.delayu, g.delayv, ws.v1[plane], ws.v2[plane],
-                              ws.list.as<int>(), n_blocks, ws.list.as<int>() + lst.size(), n_miss, ws.partial[plane], d_res));
+                              ws.list.as<int>(), n_groups, ws.list.as<int>() + lst.size(), n_miss, ws.partial[plane], d_res));
             const float* res = ws.pin_res.as<float>();
             MI_HIP(hipMemcpyAsync(ws.pin_res.p, d_res, sizeof(float) * H * W, hipMemcpyDeviceToHost, s));
             MI_HIP(hipStreamSynchronize(s));
