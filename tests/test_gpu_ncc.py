@@ -58,6 +58,22 @@ def test_random_pairs_vs_oracle(dev):
         assert np.allclose(np.array(got.NCC_maxs, np.float32), want["NCC_maxs"], atol=2e-6, equal_nan=True)
 
 
+def test_wide_search_and_wide_mips_vs_oracle(dev):
+    """Launch geometries the golden cases do not reach: a search range of 40 (81 shifts = 11 blocks of 8 -> two groups of
+    blocks per u-row), MIPs wider than one 512-column segment, and the refinement's block lists on such maps."""
+    from ipp_amd import crossmips
+    for side, shape, ov, shift in ((0, (12, 150, 1100), 120, (3, -4, 1)), (1, (10, 1100, 160), 130, (-6, 2, 0))):
+        A, B = N.tile_pair(shape, ov, side, shift, seed=77 + side)
+        want = N.pdalgo_execute(A, B, 40, 40, 3, side, ov, kind="oracle", debug=True)
+        got = crossmips.PDAlgoMIPNCC.execute(torch.from_numpy(A).to(dev), torch.from_numpy(B).to(dev), 40, 40, 3, side, ov)
+        assert got.VHD_coords == want["coord"] and got.NCC_widths == want["NCC_widths"]
+        assert np.allclose(np.array(got.NCC_maxs, np.float32), want["NCC_maxs"], atol=2e-6, equal_nan=True)
+        di, dj, dk = want["delays"]
+        for m, (du, dv) in enumerate([(di, dj), (di, dk), (dj, dk)]):
+            mp = crossmips.compute_NCC_map(torch.from_numpy(want["mips"][m]).to(dev), torch.from_numpy(want["mips"][m + 3]).to(dev), du, dv)
+            assert np.allclose(mp.cpu().numpy(), want["maps"][m], rtol=0, atol=2e-6, equal_nan=True), (side, m)
+
+
 def test_host_pointer_entry_and_errors(dev):
     import ctypes as C
     from ipp_amd import capi, crossmips
