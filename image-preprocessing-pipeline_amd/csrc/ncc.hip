@@ -62,7 +62,7 @@ __device__ __forceinline__ float wave_max_nonneg(float v) {
 __global__ __launch_bounds__(256) void k_mips(const float* __restrict__ A, const float* __restrict__ B, int dimk, int dimi_v, int dimj_v,
                                                size_t slice, int pitch, int ai0, int aj0, float* __restrict__ xy1, float* __restrict__ xz1,
                                                float* __restrict__ yz1, float* __restrict__ xy2, float* __restrict__ xz2,
-                                               float* __restrict__ yz2) {
+                                               float* __restrict__ yz2, float* __restrict__ yz_tmp) {
     // a work-group owns a 16-row x 64-column patch of the view; its four waves share the slices (wave w: k = w, w + 4, ...),
     // so a patch keeps four times as many loads in flight as one wave walking all slices
     __shared__ float comb[3][MIP_ROWS][64];
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void k_mips(const float* __restrict__ A, const
     const float* vol = second ? B : A + (size_t)ai0 * pitch + aj0;
     float* xy = second ? xy2 : xy1;
     float* xz = second ? xz2 : xz1;
-    float* yz = second ? yz2 : yz1;
+    (void)yz1; (void)yz2;  // written by k_mips_yz
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int j = blockIdx.x * 64 + lane;
     const int i0 = blockIdx.y * MIP_ROWS;
@@ -92,7 +92,9 @@ __global__ __launch_bounds__(256) void k_mips(const float* __restrict__ A, const
             const float rowmax = wave_max_nonneg(v[r]);  // max over the 64 columns of the patch, in lane 63
             if (lane == 63 && r < rows) atomic_max_nonneg(&xz[(size_t)(i0 + r) * dimk + k], rowmax);
         }
-        if (live) atomic_max_nonneg(&yz[(size_t)j * dimk + k], colmax);
+        // yz: the column maxima of this row band go to yz_tmp[tile][band][k][j] (unit-stride stores); k_mips_yz takes the
+        // maximum over the bands -- 2.6 million atomics per pair on the yz MIPs cost more than the whole streaming pass
+        if (live) yz_tmp[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * dimk + k) * dimj_v + j] = colmax;
     }
     // xy: maximum over the four waves' slices
     if (wave > 0) {
@@ -105,6 +107,18 @@ __global__ __launch_bounds__(256) void k_mips(const float* __restrict__ A, const
         for (int r = 0; r < MIP_ROWS; ++r)
             if (r < rows) xy[(size_t)(i0 + r) * dimj_v + j] = fmaxf(fmaxf(best[r], comb[0][r][lane]), fmaxf(comb[1][r][lane], comb[2][r][lane]));
     }
+}
+
+// yz[j][k] = max over the row bands of yz_tmp[tile][band][k][j]; one lane per (k, j), tile = blockIdx.y
+__global__ __launch_bounds__(256) void k_mips_yz(const float* __restrict__ yz_tmp, int bands, int dimk, int dimj_v, float* __restrict__ yz1,
+                                                  float* __restrict__ yz2) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= dimk * dimj_v) return;
+    const int k = e / dimj_v, j = e - k * dimj_v;
+    const float* p = yz_tmp + (size_t)blockIdx.y * bands * dimk * dimj_v + e;
+    float m = 0.0f;
+    for (int b = 0; b < bands; ++b) m = fmaxf(m, p[(size_t)b * dimk * dimj_v]);
+    (blockIdx.y ? yz2 : yz1)[(size_t)j * dimk + k] = m;
 }
 
 __global__ void k_tile_sums(const float* __restrict__ img, int height, int width, float* __restrict__ ps) {
@@ -561,6 +575,7 @@ struct PinnedBuf {
 struct Workspace {
     DevBuf buf;       // floats: MIPs | tile sums | maps | miss results
     DevBuf sat;       // doubles: per plane c0, P, Q, TS tables of both MIPs
+    DevBuf mip_tmp;   // floats: per tile and row band, the column maxima the yz MIPs are reduced from
     SatView v1[3], v2[3];
     DevBuf list;      // ints: {u, v0, count, slot} groups of missing entries
     DevBuf partial[3]; // doubles: per plane, the row chunks' partial cross terms of a full map
@@ -793,10 +808,20 @@ int pair_enqueue(hipStream_t s, const float* A, const float* B, int dimi, int di
     // six MIPs start at 0 (libcrossmips.cpp:319-337)
     MI_HIP(hipMemsetAsync(base, 0, sizeof(float) * pl.g[0].ps1, s));
     dim3 grid((pl.dimj_v + 63) / 64, (pl.dimi_v + MIP_ROWS - 1) / MIP_ROWS, 2);
+    {
+        const size_t tmp = sizeof(float) * 2 * (size_t)grid.y * pl.dimk * pl.dimj_v;
+        if (ws.mip_tmp.bytes < tmp) {
+            MI_HIP(hipStreamSynchronize(s));
+            MI_TRY(ws.mip_tmp.alloc(tmp));
+        }
+    }
     hipLaunchKernelGGL(k_mips, grid, dim3(256), 0, s, A, B, pl.dimk, pl.dimi_v, pl.dimj_v, (size_t)dimi * dimj, dimj, pl.ai0, pl.aj0,
                        base + pl.g[0].mip1, base + pl.g[1].mip1, base + pl.g[2].mip1, base + pl.g[0].mip2, base + pl.g[1].mip2,
-                       base + pl.g[2].mip2);
+                       base + pl.g[2].mip2, ws.mip_tmp.as<float>());
     MI_TRY(launch_check("k_mips"));
+    hipLaunchKernelGGL(k_mips_yz, dim3((pl.dimk * pl.dimj_v + 255) / 256, 2), dim3(256), 0, s, ws.mip_tmp.as<float>(), (int)grid.y, pl.dimk,
+                       pl.dimj_v, base + pl.g[2].mip1, base + pl.g[2].mip2);
+    MI_TRY(launch_check("k_mips_yz"));
     if (ws.sat.bytes < sizeof(double) * pl.sat_doubles) MI_TRY(ws.sat.alloc(sizeof(double) * pl.sat_doubles));
     for (int m = 0; m < 3; ++m) {
         const PlaneGeom& g = pl.g[m];
@@ -965,9 +990,15 @@ extern "C" int mi_ncc_compute_mips(int dev, void* stream, const float* A, const 
     const size_t sz[3] = {(size_t)dimi_v * dimj_v, (size_t)dimi_v * dimk, (size_t)dimj_v * dimk};
     for (int m = 0; m < 6; ++m) MI_HIP(hipMemsetAsync(outs[m], 0, sizeof(float) * sz[m % 3], s));
     dim3 grid((dimj_v + 63) / 64, (dimi_v + MIP_ROWS - 1) / MIP_ROWS, 2);
+    DevBuf tmp;
+    MI_TRY(tmp.alloc(sizeof(float) * 2 * (size_t)grid.y * dimk * dimj_v));
     hipLaunchKernelGGL(k_mips, grid, dim3(256), 0, s, A, B, dimk, dimi_v, dimj_v, (size_t)dimi * dimj, dimj, side == MI_NORTH_SOUTH ? ni : 0,
-                       side == MI_WEST_EAST ? nj : 0, xy1, xz1, yz1, xy2, xz2, yz2);
-    return launch_check("k_mips");
+                       side == MI_WEST_EAST ? nj : 0, xy1, xz1, yz1, xy2, xz2, yz2, tmp.as<float>());
+    MI_TRY(launch_check("k_mips"));
+    hipLaunchKernelGGL(k_mips_yz, dim3((dimk * dimj_v + 255) / 256, 2), dim3(256), 0, s, tmp.as<float>(), (int)grid.y, dimk, dimj_v, yz1, yz2);
+    MI_TRY(launch_check("k_mips_yz"));
+    MI_HIP(hipStreamSynchronize(s));  // tmp dies at scope exit
+    return MI_OK;
 }
 
 extern "C" int mi_ncc_compute_map(int dev, void* stream, const float* mip1, const float* mip2, int dimu, int dimv, int delayu, int delayv,
