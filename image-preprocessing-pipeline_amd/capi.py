@@ -122,6 +122,14 @@ def lib() -> C.CDLL:
             f"{LIB_PATH} not found: build the HIP extension first "
             f"(python -c 'import __graft_entry__ as g; g.build()' or make -C {os.path.join(_HERE, 'csrc')}). "
             "There is no CPU fallback.")
+    # One HIP / HSA runtime per process: PyTorch ships its own copies of libamdhip64 / libhsa-runtime64.  When they are loaded
+    # first, this library binds to them (same sonames); the other way round the process ends up with the system's HIP runtime
+    # under this library and torch's HSA runtime under torch, and torch then finds "No HIP GPUs".  The host layer uses torch
+    # for device memory and streams anyway, so it goes first.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     handle = C.CDLL(LIB_PATH)
     for name, (restype, argtypes) in SIGNATURES.items():
         fn = getattr(handle, name)  # AttributeError if the library does not export it

@@ -131,7 +131,13 @@ def main(argv=None):
 
     import numpy as np
     import torch
-    from ipp_amd import decon as D, lsdeconv as L, psf as P
+    from ipp_amd import capi, decon as D, lsdeconv as L, psf as P
+    capi.require_gpu()
+    # torch's lazy device initialisation has to happen on this thread: the workers below only create streams and tensors
+    torch.cuda.init()
+    for g in sorted(set(args.gpu_indices)):
+        if not 1 <= g <= torch.cuda.device_count():
+            raise RuntimeError(f"--gpu-indices {g}: this host has {torch.cuda.device_count()} GPU(s) (indices are 1-based)")
 
     out_dir.mkdir(exist_ok=True)
     with open(out_dir / "deconvolution_config.json", "w") as f:

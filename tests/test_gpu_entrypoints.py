@@ -273,3 +273,29 @@ def test_decwrap_flip_and_destripe_options(dev, tmp_path):
     assert decwrap.main(base + ["--destripe-sigma", "2.0"]) == 0
     a, b = np.load(src / "plain" / "deconvolved.npy"), np.load(src / "deconvolved" / "deconvolved.npy")
     assert a.shape == b.shape and not np.allclose(a, b, rtol=1e-3)
+
+
+def test_entry_points_in_a_fresh_process(dev, tmp_path):
+    """``python decwrap.py ...`` / ``python process_images.py ...`` as their own processes: nothing has initialised torch or the
+    HIP runtime before the entry point does (the library must come up after torch's bundled runtime, see capi.lib)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "image-preprocessing-pipeline_amd")
+    rng = np.random.default_rng(3)
+    np.save(tmp_path / "vol.npy", (rng.random((16, 24, 28)) * 3000 + 100).astype(np.uint16))
+    r = subprocess.run([sys.executable, os.path.join(pkg, "decwrap.py"), "-i", str(tmp_path / "vol.npy"), "-dxy", "0.422", "-dz", "1.0",
+                        "-ex", "488", "-em", "525", "-it", "2", "--gaussian-sigma", "0", "0", "0", "--gpu-indices", "1",
+                        "--block-size-max", "50000"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert (tmp_path / "deconvolved" / "deconvolved.npy").exists()
+    tile, ov = (26, 64, 64), 24
+    field = N.bead_field((tile[0], 2 * (tile[1] - ov) + ov, tile[2]), seed=8, density=1 / 300)
+    for rr in range(2):
+        t = field[:, rr * (tile[1] - ov):rr * (tile[1] - ov) + tile[1], :]
+        np.save(tmp_path / f"tile_{rr}_0.npy", np.clip(np.rint(t * 255), 0, 255).astype(np.uint8))
+    r = subprocess.run([sys.executable, os.path.join(pkg, "process_images.py"), "-2", "--input", str(tmp_path), "--oV", str(ov), "--oH", str(ov),
+                        "--sV", "5", "--sH", "5", "--sD", "1"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert (tmp_path / "xml_displcomp.xml").exists()
