@@ -125,6 +125,7 @@ void pool_free(void* p, size_t n) {
 }  // namespace mi
 
 extern "C" size_t mi_release_cached_memory(int dev) {
+    mi::ncc_drop_cached_slots(dev);  // their buffers go back to the pool first
     mi::Pool& P = mi::pool();
     std::lock_guard<std::mutex> g(P.mu);
     return P.trim(dev);

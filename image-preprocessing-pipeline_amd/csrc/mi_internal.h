@@ -96,4 +96,7 @@ struct DevBuf {
     template <class T> T* as() const { return static_cast<T*>(p); }
 };
 
+// ncc.hip: destroys the pair working sets kept between mi_ncc_mips_batch calls (dev < 0: of every device)
+void ncc_drop_cached_slots(int dev);
+
 }  // namespace mi

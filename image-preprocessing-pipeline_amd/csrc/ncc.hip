@@ -21,6 +21,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <exception>
+#include <memory>
+#include <mutex>
+#include <new>
 #include <string>
 #include <thread>
 #include <type_traits>
@@ -866,7 +869,59 @@ int pair_finish(hipStream_t s, int ni, int nj, int side, mi_ncc_params* p, const
     return MI_OK;
 }
 
+// a pair's working set between batch calls: workspace + stream, per device
+struct PairSlot {
+    int dev = 0;
+    Workspace ws;
+    hipStream_t s = nullptr;
+    ~PairSlot() {
+        if (s) {
+            (void)hipSetDevice(dev);
+            (void)hipStreamDestroy(s);
+        }
+    }
+};
+// never destroyed: at process exit the HIP runtime may already be gone
+std::mutex& g_slot_mu = *new std::mutex;
+std::vector<std::unique_ptr<PairSlot>>& g_slots = *new std::vector<std::unique_ptr<PairSlot>>;
+
+std::unique_ptr<PairSlot> take_pair_slot(int dev) {
+    {
+        std::lock_guard<std::mutex> g(g_slot_mu);
+        for (size_t i = 0; i < g_slots.size(); ++i)
+            if (g_slots[i]->dev == dev) {
+                std::unique_ptr<PairSlot> r = std::move(g_slots[i]);
+                g_slots.erase(g_slots.begin() + i);
+                return r;
+            }
+    }
+    std::unique_ptr<PairSlot> r(new (std::nothrow) PairSlot);
+    if (!r) return r;
+    r->dev = dev;
+    if (hipStreamCreateWithFlags(&r->s, hipStreamNonBlocking) != hipSuccess) r->s = nullptr;
+    return r;
+}
+
+void give_pair_slot(std::unique_ptr<PairSlot> r) {
+    if (!r) return;
+    std::lock_guard<std::mutex> g(g_slot_mu);
+    if (g_slots.size() < 16) g_slots.push_back(std::move(r));  // beyond that the slot is simply destroyed
+}
+
 }  // namespace
+
+namespace mi {
+// the cached pair slots of a device (-1: all) are destroyed; their buffers return to the pool (mi_release_cached_memory)
+void ncc_drop_cached_slots(int dev) {
+    std::vector<std::unique_ptr<PairSlot>> drop;
+    {
+        std::lock_guard<std::mutex> g(g_slot_mu);
+        for (size_t i = 0; i < g_slots.size();)
+            if (dev < 0 || g_slots[i]->dev == dev) { drop.push_back(std::move(g_slots[i])); g_slots.erase(g_slots.begin() + i); }
+            else ++i;
+    }
+}
+}  // namespace mi
 
 extern "C" void mi_ncc_default_params(int displ_max_V, int displ_max_H, int displ_max_D, mi_ncc_params* p) {
     if (!p) return;
@@ -938,11 +993,15 @@ extern "C" int mi_ncc_mips_batch(int dev, void* stream, int n_pairs, const float
     std::vector<int> rcs(NT, MI_OK);
     std::vector<std::string> msgs(NT);
     auto worker = [&](int t) {
-        struct Slot { Workspace ws; PairPlan pl; hipStream_t s = nullptr; } slot[2];
+        // workspaces (device tables, pinned staging) and streams are kept between calls: setting them up costs milliseconds
+        struct Slot { std::unique_ptr<PairSlot> r; Workspace& ws; PairPlan pl; hipStream_t s; };
         int rc = use_device(dev);
-        for (auto& sl : slot)
-            if (rc == MI_OK && (hipStreamCreateWithFlags(&sl.s, hipStreamNonBlocking) != hipSuccess || hipStreamWaitEvent(sl.s, ev, 0) != hipSuccess))
+        std::unique_ptr<PairSlot> res[2] = {take_pair_slot(dev), take_pair_slot(dev)};
+        for (auto& r : res)
+            if (rc == MI_OK && (!r || !r->s || hipStreamWaitEvent(r->s, ev, 0) != hipSuccess))
                 rc = fail(MI_ERR_HIP, "mi_ncc_mips_batch: stream setup failed");
+        if (rc != MI_OK) { msgs[t] = mi_last_error(); rcs[t] = rc; return; }
+        Slot slot[2] = {{nullptr, res[0]->ws, PairPlan(), res[0]->s}, {nullptr, res[1]->ws, PairPlan(), res[1]->s}};
         int k = 0;  // index of the pair within this thread's sequence t, t + NT, ...
         for (int q = t; rc == MI_OK; q += NT, ++k) {
             if (q < n_pairs) {
@@ -959,8 +1018,10 @@ extern "C" int mi_ncc_mips_batch(int dev, void* stream, int n_pairs, const float
             if (q >= n_pairs) break;
         }
         if (rc != MI_OK) msgs[t] = mi_last_error();
-        for (auto& sl : slot)
-            if (sl.s) { (void)hipStreamSynchronize(sl.s); (void)hipStreamDestroy(sl.s); }
+        for (auto& r : res) {
+            (void)hipStreamSynchronize(r->s);
+            give_pair_slot(std::move(r));
+        }
         rcs[t] = rc;
     };
     std::vector<std::thread> pool;
