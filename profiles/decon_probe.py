@@ -18,3 +18,5 @@ for i in range(2):
     t(f"edgetaper after decon #{i}", lambda: decon.edgetaper_3d(bl, psf_t))
 t("decon 2 it", lambda: decon.decon(bl, psf, 2, 0.0, 0.0, 0, 1, True, fs, False))
 t("decon 2 it", lambda: decon.decon(bl, psf, 2, 0.0, 0.0, 0, 1, True, fs, False))
+t("decon 0 it skip_edgetaper (context build only)", lambda: decon.decon(bl, psf, 0, 0.0, 0.0, 0, 1, True, fs, False, skip_edgetaper=True))
+t("decon 6 it skip_edgetaper", lambda: decon.decon(bl, psf, 6, 0.0, 0.0, 0, 1, True, fs, False, skip_edgetaper=True))
