@@ -421,7 +421,8 @@ __global__ __launch_bounds__(256) void k_ncc_finish(const double* __restrict__ p
     const int nr = dimu - abs(u), nc = dimv - abs(v);
     if (nr <= 0 || nc <= 0) { out[slot] = __int_as_float(0x7fc00000); return; }  // reference: empty loops, 0/0
     double cr = 0.0;
-    for (int ch = 0; ch < n_chunks; ++ch) cr += partial[(size_t)ch * n_groups * (GW * BU * BV) + pidx];
+#pragma unroll 8
+    for (int ch = 0; ch < n_chunks; ++ch) cr += partial[(size_t)ch * n_groups * (GW * BU * BV) + pidx];  // fixed order
     double fm, sf, F1, tm, st, F2;
     window_stats(s1, dimu, dimv, max(u, 0), max(v, 0), nr, nc, &fm, &sf, &F1);
     window_stats(s2, dimu, dimv, max(-u, 0), max(-v, 0), nr, nc, &tm, &st, &F2);
