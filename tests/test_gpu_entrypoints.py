@@ -187,11 +187,11 @@ def test_decwrap_block_parallel_workers_equal_sequential(dev, tmp_path):
 
 
 def test_device_memory_pool_reuses_and_releases(dev):
+    """Scratch memory a call releases stays in the library's per-device pool and is handed out again; it goes back to the driver
+    on request (mi_release_cached_memory)."""
     import os
     if os.environ.get("MI_NO_MEMORY_POOL"):
         pytest.skip("the pool is switched off")
-    """Scratch memory a call releases stays in the library's per-device pool and is handed out again; it goes back to the driver
-    on request (mi_release_cached_memory)."""
     from ipp_amd import capi, decon
     capi.release_cached_memory()
     assert capi.lib().mi_cached_memory_bytes() == 0
