@@ -124,16 +124,26 @@ __global__ __launch_bounds__(256) void k_mips_yz(const float* __restrict__ yz_tm
     (blockIdx.y ? yz2 : yz1)[(size_t)j * dimk + k] = m;
 }
 
-__global__ void k_tile_sums(const float* __restrict__ img, int height, int width, float* __restrict__ ps) {
-    const int ph = height / TILE, pw = width / TILE;
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= ph * pw) return;
-    const int ti = t / pw, tj = t % pw;
+// one wave per tile (blockIdx.y = MIP of the plane): the tile is staged in LDS with coalesced loads, then lane 0 adds its 1024
+// pixels in the reference's row-major order with a FLOAT running sum (bit-identical by construction)
+__global__ __launch_bounds__(64) void k_tile_sums(const float* __restrict__ img1, const float* __restrict__ img2, int height, int width,
+                                                  float* __restrict__ ps1, float* __restrict__ ps2) {
+    __shared__ float tile[TILE * TILE];
+    const float* img = blockIdx.y ? img2 : img1;
+    float* ps = blockIdx.y ? ps2 : ps1;
+    const int pw = width / TILE, t = blockIdx.x;
+    const int ti = t / pw, tj = t - ti * pw;
     const float* p = img + (size_t)ti * TILE * width + tj * TILE;
-    float s = 0.0f;
-    for (int l = 0; l < TILE; ++l)
-        for (int k = 0; k < TILE; ++k) s += p[(size_t)l * width + k];
-    ps[t] = s;
+    const int lane = threadIdx.x, half = lane >> 5, col = lane & 31;
+#pragma unroll
+    for (int l = 0; l < TILE; l += 2) tile[(l + half) * TILE + col] = p[(size_t)(l + half) * width + col];
+    __syncthreads();
+    if (lane == 0) {
+        float s = 0.0f;
+#pragma unroll 32
+        for (int i = 0; i < TILE * TILE; ++i) s += tile[i];
+        ps[t] = s;
+    }
 }
 
 template <int NT = NCC_THREADS>
@@ -537,8 +547,7 @@ int prepare_plane(hipStream_t s, const float* m1, const float* m2, int dimu, int
     double *c0a = sat, *c0b = sat + 1, *P1 = sat + 2, *Q1 = P1 + L.tab, *P2 = Q1 + L.tab, *Q2 = P2 + L.tab, *T1 = Q2 + L.tab, *T2 = T1 + L.ts;
     if (tiled) {
         const int nt = (dimu / TILE) * (dimv / TILE);
-        hipLaunchKernelGGL(k_tile_sums, dim3((nt + 63) / 64), dim3(64), 0, s, m1, dimu, dimv, ps1);
-        hipLaunchKernelGGL(k_tile_sums, dim3((nt + 63) / 64), dim3(64), 0, s, m2, dimu, dimv, ps2);
+        hipLaunchKernelGGL(k_tile_sums, dim3(nt, 2), dim3(64), 0, s, m1, m2, dimu, dimv, ps1, ps2);
         MI_TRY(launch_check("k_tile_sums"));
     }
     double* part = T2 + L.ts;
