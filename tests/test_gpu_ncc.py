@@ -45,17 +45,23 @@ def test_golden_cases(dev, ncc_golden, idx):
 
 
 def test_random_pairs_vs_oracle(dev):
+    """Random tile shapes, overlaps, shifts and search ranges against the oracle (MI_TEST_SWEEP: number of trials, default 8)."""
+    import os
     from ipp_amd import crossmips
-    rng = np.random.default_rng(2024)
-    for trial in range(6):
+    rng = np.random.default_rng(int(os.environ.get("MI_TEST_SWEEP_SEED", "2024")))
+    for trial in range(int(os.environ.get("MI_TEST_SWEEP", "8"))):
         side = trial % 2
+        shape = (int(rng.integers(26, 40)), int(rng.integers(90, 200)), int(rng.integers(90, 200)))
+        ov = int(rng.integers(30, 60))
+        sv, sh, sd = int(rng.integers(3, 14)), int(rng.integers(3, 14)), int(rng.integers(0, 5))
         shift = tuple(int(v) for v in rng.integers(-5, 6, size=3))
-        A, B = N.tile_pair((30, 120, 136), 40, side, shift, seed=300 + trial)
-        want = N.pdalgo_execute(A, B, 9, 9, 4, side, 40, kind="oracle")
-        got = crossmips.PDAlgoMIPNCC.execute(torch.from_numpy(A).to(dev), torch.from_numpy(B).to(dev), 9, 9, 4, side, 40)
-        assert got.VHD_coords == want["coord"] and got.NCC_widths == want["NCC_widths"]
-        assert got.wRangeThrs == want["wRangeThr"]
-        assert np.allclose(np.array(got.NCC_maxs, np.float32), want["NCC_maxs"], atol=2e-6, equal_nan=True)
+        A, B = N.tile_pair(shape, ov, side, shift, seed=300 + trial)
+        want = N.pdalgo_execute(A, B, sv, sh, sd, side, ov, kind="oracle")
+        got = crossmips.PDAlgoMIPNCC.execute(torch.from_numpy(A).to(dev), torch.from_numpy(B).to(dev), sv, sh, sd, side, ov)
+        case = (trial, shape, ov, (sv, sh, sd), shift)
+        assert got.VHD_coords == want["coord"] and got.NCC_widths == want["NCC_widths"], case
+        assert got.wRangeThrs == want["wRangeThr"], case
+        assert np.allclose(np.array(got.NCC_maxs, np.float32), want["NCC_maxs"], atol=2e-6, equal_nan=True), case
 
 
 def test_wide_search_and_wide_mips_vs_oracle(dev):
