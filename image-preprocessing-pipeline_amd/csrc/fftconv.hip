@@ -42,17 +42,22 @@ inline unsigned stream_grid(size_t n_items) {
     return static_cast<unsigned>(b < 1 ? 1 : (b > cap ? cap : b));
 }
 
-// circular kernel image: dst[p] = psf[j] where p == (j - shift) mod F per axis, else 0
-__global__ __launch_bounds__(kThreads) void k_place_psf(const float* __restrict__ psf, float* __restrict__ dst, int kx, int ky, int kz,
-                                                         int Fx, int Fy, int Fz, int sx, int sy, int sz) {
-    const size_t total = (size_t)Fx * Fy * Fz;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int x = (int)(i % Fx);
-        const size_t r = i / Fx;
-        const int y = (int)(r % Fy), z = (int)(r / Fy);
-        const int jx = (x + sx) % Fx, jy = (y + sy) % Fy, jz = (z + sz) % Fz;
-        dst[i] = (jx < kx && jy < ky && jz < kz) ? psf[((size_t)jz * ky + jy) * kx + jx] : 0.0f;
+// circular kernel image: dst[p] = psf[j] where p == (j - shift) mod F per axis, else 0.  The image is a few thousand samples
+// in a grid of up to billions: one memset, then one lane per PSF sample (k <= F: the targets are distinct)
+__global__ __launch_bounds__(kThreads) void k_scatter_psf(const float* __restrict__ psf, float* __restrict__ dst, int kx, int ky, int kz,
+                                                           int Fx, int Fy, int Fz, int sx, int sy, int sz) {
+    const int total = kx * ky * kz;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int jx = i % kx, r = i / kx, jy = r % ky, jz = r / ky;
+        const int x = ((jx - sx) % Fx + Fx) % Fx, y = ((jy - sy) % Fy + Fy) % Fy, z = ((jz - sz) % Fz + Fz) % Fz;
+        dst[((size_t)z * Fy + y) * Fx + x] = psf[i];
     }
+}
+
+int place_psf(hipStream_t s, const float* psf, float* dst, int kx, int ky, int kz, int Fx, int Fy, int Fz, int sx, int sy, int sz) {
+    MI_HIP(hipMemsetAsync(dst, 0, sizeof(float) * (size_t)Fx * Fy * Fz, s));
+    hipLaunchKernelGGL(k_scatter_psf, dim3(stream_grid((size_t)kx * ky * kz)), dim3(kThreads), 0, s, psf, dst, kx, ky, kz, Fx, Fy, Fz, sx, sy, sz);
+    return launch_check("k_scatter_psf");
 }
 
 __global__ __launch_bounds__(kThreads) void k_scale_c(float2* __restrict__ a, size_t n, float scale) {
@@ -152,11 +157,9 @@ __global__ __launch_bounds__(kThreads) void k_fft_epilogue_flat(const float* __r
 
 int build_otf(hipStream_t s, rocfft_plan fwd, rocfft_execution_info info, const float* psf, const AxisPlan ax[3], float* real_scratch,
               float* otf, float scale) {
-    const size_t n_real = (size_t)ax[0].F * ax[1].F * ax[2].F;
     const size_t n_spec = (size_t)(ax[0].F / 2 + 1) * ax[1].F * ax[2].F;
-    hipLaunchKernelGGL(k_place_psf, dim3(stream_grid(n_real)), dim3(kThreads), 0, s, psf, real_scratch, ax[0].k, ax[1].k, ax[2].k,
-                       ax[0].F, ax[1].F, ax[2].F, ax[0].shift, ax[1].shift, ax[2].shift);
-    MI_TRY(launch_check("k_place_psf"));
+    MI_TRY(place_psf(s, psf, real_scratch, ax[0].k, ax[1].k, ax[2].k,
+                       ax[0].F, ax[1].F, ax[2].F, ax[0].shift, ax[1].shift, ax[2].shift));
     void* in[1] = {real_scratch};
     void* out[1] = {otf};
     MI_FFT(rocfft_execute(fwd, in, out, info));
@@ -221,9 +224,8 @@ static int make_plans(hipStream_t s, const size_t lengths[3], rocfft_plan* fwd, 
 
 int FftEngine::set_psf(hipStream_t s, const float* psf) {
     MI_REQUIRE(native && !padded && !native->real_otf, "FFT engine: set_psf needs the hand-written pipeline on an unpadded grid");
-    hipLaunchKernelGGL(k_place_psf, dim3(stream_grid(n_real)), dim3(kThreads), 0, s, psf, native->scratch(), ax[0].k, ax[1].k, ax[2].k,
-                       ax[0].F, ax[1].F, ax[2].F, ax[0].shift, ax[1].shift, ax[2].shift);
-    MI_TRY(launch_check("k_place_psf"));
+    MI_TRY(place_psf(s, psf, native->scratch(), ax[0].k, ax[1].k, ax[2].k,
+                       ax[0].F, ax[1].F, ax[2].F, ax[0].shift, ax[1].shift, ax[2].shift));
     const float nscale = 2.0f / (float)((double)ax[0].F * ax[1].F * ax[2].F);
     return native->build_otf(s, native->scratch(), false, nscale);
 }
@@ -276,9 +278,8 @@ int FftEngine::init(hipStream_t s, const int n[3], const int k[3], const int bnd
         // 1/(Fx Fy Fz) of the unnormalised inverse transform, times 2 for the half-length complex packing of x
         const float nscale = 2.0f / (float)((double)F[0] * F[1] * F[2]);
         for (int slot = 0; slot < (have_adj ? 2 : 1); ++slot) {
-            hipLaunchKernelGGL(k_place_psf, dim3(stream_grid(n_real)), dim3(kThreads), 0, s, slot ? psf_inv : psf, native->scratch(), ax[0].k,
-                               ax[1].k, ax[2].k, ax[0].F, ax[1].F, ax[2].F, ax[0].shift, ax[1].shift, ax[2].shift);
-            MI_TRY(launch_check("k_place_psf"));
+            MI_TRY(place_psf(s, slot ? psf_inv : psf, native->scratch(), ax[0].k,
+                               ax[1].k, ax[2].k, ax[0].F, ax[1].F, ax[2].F, ax[0].shift, ax[1].shift, ax[2].shift));
             MI_TRY(native->build_otf(s, native->scratch(), slot == 1, nscale));
         }
         // PSFs of odd extents that are mirror-symmetric about their centre sample (every LsMakePSF PSF) have a real OTF up to the
