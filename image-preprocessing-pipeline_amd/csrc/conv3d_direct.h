@@ -35,7 +35,10 @@ int direct_conv_launch(hipStream_t s, const float* img, const float* kf, float* 
                        int kz, int kxp, int boundary, int epi_kind, const ConvEpilogue& epi, const int* offs = nullptr,
                        const int* bnd3 = nullptr);
 int gauss3d_async(hipStream_t s, float* vol, float* work, int nx, int ny, int nz, const float* sigma, const int* ksize);
-int edgetaper_async(hipStream_t s, float* bl, float* work, const float* psf, int nx, int ny, int nz, int kx, int ky, int kz);
+struct FftEngine;
+// keep != nullptr: the FFT engine of the blur is created into / reused from *keep (see mi_decon_plan); the caller owns it
+int edgetaper_async(hipStream_t s, float* bl, float* work, const float* psf, int nx, int ny, int nz, int kx, int ky, int kz,
+                    FftEngine** keep = nullptr);
 
 // common.hip
 int sumsq_async(hipStream_t s, const float* x, size_t n, double* d_out);

@@ -6,6 +6,7 @@
 // removes 85-90 % of the reference's work for this step.
 #include <cmath>
 #include <cstdlib>
+#include <new>
 #include <vector>
 
 #include "fftconv.h"
@@ -49,7 +50,8 @@ __global__ __launch_bounds__(256) void k_taper_blend(float* __restrict__ bl, con
 
 }  // namespace
 
-int edgetaper_async(hipStream_t s, float* bl, float* work, const float* psf, int nx, int ny, int nz, int kx, int ky, int kz) {
+int edgetaper_async(hipStream_t s, float* bl, float* work, const float* psf, int nx, int ny, int nz, int kx, int ky, int kz,
+                    FftEngine** keep) {
     MI_REQUIRE(bl && work && psf && bl != work, "edgetaper_3d: null or aliased buffers");
     MI_REQUIRE(nx > 0 && ny > 0 && nz > 0 && kx > 0 && ky > 0 && kz > 0, "edgetaper_3d: bl and psf must be 3D");
     const int n[3] = {nx, ny, nz}, k[3] = {kx, ky, kz};
@@ -95,15 +97,34 @@ int edgetaper_async(hipStream_t s, float* bl, float* work, const float* psf, int
     bool use_fft = odd && t_fft < t_direct;
     if (const char* f = std::getenv("MI_EDGETAPER_ENGINE")) use_fft = odd && f[0] == 'f';  // tests / experiments: "fft" | "direct"
     if (use_fft) {
-        DevBuf pn;
-        MI_TRY(normalised_psf(s, psf, kx * ky * kz, pn));
-        FftEngine fe;
-        const int bnd[3] = {MI_BOUNDARY_REPLICATE, MI_BOUNDARY_REPLICATE, MI_BOUNDARY_REPLICATE};
-        int shift[3];
-        for (int d = 0; d < 3; ++d) shift[d] = k[d] - 1 - conv_kernel_offset(k[d], MI_BOUNDARY_REPLICATE);
-        MI_TRY(fe.init(s, n, k, bnd, shift, pn.as<float>(), nullptr, false));
-        MI_TRY(fe.conv(s, bl, false, work, EPI_NONE, ConvEpilogue()));
-        MI_HIP(hipStreamSynchronize(s));  // the engine's buffers die here
+        // `keep` (a deconvolution plan): the engine -- the OTF of the normalised PSF on the replicate-padded grid -- outlives
+        // the call and serves the next block of the same shape and PSF
+        FftEngine local, *fe = &local;
+        bool built = false;
+        if (keep && *keep) fe = *keep;
+        else {
+            if (keep) {
+                fe = new (std::nothrow) FftEngine;
+                if (!fe) return fail(MI_ERR_NOMEM, "edgetaper_3d: out of host memory");
+            }
+            DevBuf pn;
+            int rc = normalised_psf(s, psf, kx * ky * kz, pn);
+            const int bnd[3] = {MI_BOUNDARY_REPLICATE, MI_BOUNDARY_REPLICATE, MI_BOUNDARY_REPLICATE};
+            int shift[3];
+            for (int d = 0; d < 3; ++d) shift[d] = k[d] - 1 - conv_kernel_offset(k[d], MI_BOUNDARY_REPLICATE);
+            if (rc == MI_OK) rc = fe->init(s, n, k, bnd, shift, pn.as<float>(), nullptr, false);
+            hipError_t e = hipStreamSynchronize(s);  // pn dies here
+            if (rc == MI_OK && e != hipSuccess) rc = fail(MI_ERR_HIP, "edgetaper_3d: %s", hipGetErrorString(e));
+            if (rc != MI_OK) {
+                if (keep) delete fe;
+                return rc;
+            }
+            if (keep) *keep = fe;
+            built = true;
+        }
+        (void)built;
+        MI_TRY(fe->conv(s, bl, false, work, EPI_NONE, ConvEpilogue()));
+        if (!keep) MI_HIP(hipStreamSynchronize(s));  // the local engine's buffers die at scope exit
     } else {
         int kxp = 0;
         MI_TRY(direct_prepare_psf(s, psf, kx, ky, kz, /*normalise=*/true, /*flip=*/true, kf, &kxp));
@@ -125,5 +146,5 @@ int edgetaper_async(hipStream_t s, float* bl, float* work, const float* psf, int
 extern "C" int mi_edgetaper3d(int dev, void* stream, float* bl, float* work, const float* psf, int nx, int ny, int nz, int kx,
                               int ky, int kz) {
     MI_TRY(mi::use_device(dev));
-    return mi::edgetaper_async(mi::as_stream(stream), bl, work, psf, nx, ny, nz, kx, ky, kz);
+    return mi::edgetaper_async(mi::as_stream(stream), bl, work, psf, nx, ny, nz, kx, ky, kz, nullptr);
 }

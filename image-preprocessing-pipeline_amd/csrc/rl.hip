@@ -7,8 +7,10 @@
 // exactly as the reference does.  The regularisation schedule, the Gaussian pre-smooth (5 taps on
 // the GPU path), the Tikhonov blend and the ||bl||_2 stop test follow decon.m:41-59,67-79,108-118.
 #include <cmath>
+#include <cstring>
 #include <new>
 #include <utility>
+#include <vector>
 
 #include "fftconv.h"
 
@@ -373,8 +375,9 @@ int check_options(const mi_rl_options* o) {
 
 }  // namespace
 
-extern "C" int mi_rl_spatial(int dev, void* stream, float* bl, const float* psf, const float* psf_inv, int nx, int ny, int nz, int kx,
-                             int ky, int kz, const mi_rl_options* opt, int* iters_done) {
+// keep_ctx / keep_taper (a deconvolution plan): the RL context and the taper's FFT engine are created into / reused from them
+static int rl_spatial_impl(int dev, void* stream, float* bl, const float* psf, const float* psf_inv, int nx, int ny, int nz, int kx, int ky,
+                           int kz, const mi_rl_options* opt, int* iters_done, mi_rl_ctx** keep_ctx, FftEngine** keep_taper) {
     MI_TRY(use_device(dev));
     MI_TRY(check_options(opt));
     MI_REQUIRE(bl && psf, "deconSpatial: null pointer");
@@ -388,18 +391,24 @@ extern "C" int mi_rl_spatial(int dev, void* stream, float* bl, const float* psf,
     MI_TRY(scratch.alloc(sizeof(double)));
     double delta_prev = 0.0;
     if (opt->stop_criterion > 0.0f) MI_TRY(host_norm(s, bl, N, scratch.as<double>(), &delta_prev));  // before the taper (decon.m:46-50)
-    if (!opt->skip_edgetaper) MI_TRY(edgetaper_async(s, bl, ratio.as<float>(), psf, nx, ny, nz, kx, ky, kz));
-    mi_rl_ctx* ctx = nullptr;
-    MI_TRY(mi_rl_create(dev, stream, nx, ny, nz, psf, psf_inv, kx, ky, kz, MI_BOUNDARY_ZERO, opt->engine, &ctx));
+    if (!opt->skip_edgetaper) MI_TRY(edgetaper_async(s, bl, ratio.as<float>(), psf, nx, ny, nz, kx, ky, kz, keep_taper));
+    mi_rl_ctx* ctx = keep_ctx ? *keep_ctx : nullptr;
+    if (!ctx) MI_TRY(mi_rl_create(dev, stream, nx, ny, nz, psf, psf_inv, kx, ky, kz, MI_BOUNDARY_ZERO, opt->engine, &ctx));
+    if (keep_ctx) *keep_ctx = ctx;
     int rc = rl_iterate(ctx, s, bl, ratio.as<float>(), reg.as<float>(), scratch.as<double>(), nx, ny, nz, *opt, delta_prev, iters_done);
     hipError_t e = hipStreamSynchronize(s);
-    mi_rl_destroy(ctx);
+    if (!keep_ctx) mi_rl_destroy(ctx);
     if (rc == MI_OK && e != hipSuccess) rc = fail(MI_ERR_HIP, "deconSpatial: %s", hipGetErrorString(e));
     return rc;
 }
 
-extern "C" int mi_rl_fft(int dev, void* stream, float* bl, const float* psf, int nx, int ny, int nz, int kx, int ky, int kz, int fx,
-                         int fy, int fz, const mi_rl_options* opt, int* iters_done) {
+extern "C" int mi_rl_spatial(int dev, void* stream, float* bl, const float* psf, const float* psf_inv, int nx, int ny, int nz, int kx,
+                             int ky, int kz, const mi_rl_options* opt, int* iters_done) {
+    return rl_spatial_impl(dev, stream, bl, psf, psf_inv, nx, ny, nz, kx, ky, kz, opt, iters_done, nullptr, nullptr);
+}
+
+static int rl_fft_impl(int dev, void* stream, float* bl, const float* psf, int nx, int ny, int nz, int kx, int ky, int kz, int fx, int fy,
+                       int fz, const mi_rl_options* opt, int* iters_done, mi_rl_ctx** keep_ctx, FftEngine** keep_taper) {
     MI_TRY(use_device(dev));
     MI_TRY(check_options(opt));
     MI_REQUIRE(bl && psf, "deconFFT: null pointer");
@@ -416,7 +425,7 @@ extern "C" int mi_rl_fft(int dev, void* stream, float* bl, const float* psf, int
     MI_TRY(ratio.alloc(sizeof(float) * NF));
     if (need_reg) MI_TRY(reg.alloc(sizeof(float) * NF));
     MI_TRY(scratch.alloc(sizeof(double)));
-    if (!opt->skip_edgetaper) MI_TRY(edgetaper_async(s, bl, ratio.as<float>(), psf, nx, ny, nz, kx, ky, kz));  // decon.m:143
+    if (!opt->skip_edgetaper) MI_TRY(edgetaper_async(s, bl, ratio.as<float>(), psf, nx, ny, nz, kx, ky, kz, keep_taper));  // decon.m:143
     float* work_bl = bl;
     if (padded) {  // decon.m:144
         MI_TRY(blF.alloc(sizeof(float) * NF));
@@ -425,15 +434,21 @@ extern "C" int mi_rl_fft(int dev, void* stream, float* bl, const float* psf, int
     }
     double delta_prev = 0.0;
     if (opt->stop_criterion > 0.0f) MI_TRY(host_norm(s, work_bl, NF, scratch.as<double>(), &delta_prev));  // decon.m:145-147
-    mi_rl_ctx* ctx = nullptr;
+    mi_rl_ctx* ctx = keep_ctx ? *keep_ctx : nullptr;
     const int engine = opt->engine == MI_ENGINE_DIRECT ? MI_ENGINE_DIRECT : MI_ENGINE_FFT;
-    MI_TRY(mi_rl_create(dev, stream, fx, fy, fz, psf, nullptr, kx, ky, kz, MI_BOUNDARY_CIRCULAR, engine, &ctx));
+    if (!ctx) MI_TRY(mi_rl_create(dev, stream, fx, fy, fz, psf, nullptr, kx, ky, kz, MI_BOUNDARY_CIRCULAR, engine, &ctx));
+    if (keep_ctx) *keep_ctx = ctx;
     int rc = rl_iterate(ctx, s, work_bl, ratio.as<float>(), reg.as<float>(), scratch.as<double>(), fx, fy, fz, *opt, delta_prev, iters_done);
     if (rc == MI_OK && padded) rc = mi_crop_center(dev, stream, work_bl, fx, fy, fz, bl, nx, ny, nz);  // decon.m:203
     hipError_t e = hipStreamSynchronize(s);
-    mi_rl_destroy(ctx);
+    if (!keep_ctx) mi_rl_destroy(ctx);
     if (rc == MI_OK && e != hipSuccess) rc = fail(MI_ERR_HIP, "deconFFT: %s", hipGetErrorString(e));
     return rc;
+}
+
+extern "C" int mi_rl_fft(int dev, void* stream, float* bl, const float* psf, int nx, int ny, int nz, int kx, int ky, int kz, int fx,
+                         int fy, int fz, const mi_rl_options* opt, int* iters_done) {
+    return rl_fft_impl(dev, stream, bl, psf, nx, ny, nz, kx, ky, kz, fx, fy, fz, opt, iters_done, nullptr, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------ deconFFT_Wiener
@@ -592,4 +607,79 @@ extern "C" int mi_decon(int dev, void* stream, float* bl, const float* psf, cons
         return mi_rl_fft(dev, stream, bl, psf, nx, ny, nz, kx, ky, kz, f[0], f[1], f[2], opt, iters_done);
     }
     return mi_rl_spatial(dev, stream, bl, psf, psf_inv, nx, ny, nz, kx, ky, kz, opt, iters_done);  // adaptive_psf: FFT path only (decon.m:14-22)
+}
+
+// ------------------------------------------------------------------------------------------------ deconvolution plans
+// The blocks of a volume share shape and PSF (LsDeconv.m:620-668): a plan keeps what `decon` would rebuild for every block --
+// the RL context (OTF, twiddles, scratch) and the FFT engine of edgetaper_3d's blur -- and rebuilds it only when shape, PSF or
+// engine change.  One plan per worker thread (it is not re-entrant).
+struct mi_decon_plan {
+    int dev = 0;
+    int key[12] = {0};          // nx ny nz kx ky kz use_fft fx fy fz engine has_inv
+    std::vector<float> psf, psf_inv;
+    mi_rl_ctx* ctx = nullptr;
+    FftEngine* taper = nullptr;
+    void drop() {
+        if (ctx) mi_rl_destroy(ctx);
+        delete taper;
+        ctx = nullptr;
+        taper = nullptr;
+    }
+};
+
+extern "C" int mi_decon_plan_create(int dev, mi_decon_plan** out) {
+    MI_TRY(use_device(dev));
+    MI_REQUIRE(out, "mi_decon_plan_create: null pointer");
+    *out = new (std::nothrow) mi_decon_plan;
+    if (!*out) return fail(MI_ERR_NOMEM, "mi_decon_plan_create: out of host memory");
+    (*out)->dev = dev;
+    return MI_OK;
+}
+
+extern "C" int mi_decon_plan_destroy(mi_decon_plan* plan) {
+    if (!plan) return MI_OK;
+    (void)hipSetDevice(plan->dev);
+    (void)hipDeviceSynchronize();
+    plan->drop();
+    delete plan;
+    return MI_OK;
+}
+
+extern "C" int mi_decon_plan_run(mi_decon_plan* plan, void* stream, float* bl, const float* psf, const float* psf_inv, int nx, int ny, int nz,
+                                 int kx, int ky, int kz, const mi_rl_options* opt, int use_fft, const int* fft_shape_xyz, int adaptive_psf,
+                                 int* iters_done) {
+    MI_REQUIRE(plan && opt && psf, "mi_decon_plan_run: null pointer");
+    const int dev = plan->dev;
+    if (adaptive_psf && use_fft)  // the Wiener variant rebuilds its OTF every iteration: nothing to keep
+        return mi_decon(dev, stream, bl, psf, psf_inv, nx, ny, nz, kx, ky, kz, opt, use_fft, fft_shape_xyz, adaptive_psf, iters_done);
+    MI_TRY(use_device(dev));
+    MI_REQUIRE(kx > 0 && ky > 0 && kz > 0, "decon: psf must be 3D and non-empty");
+    int f[3] = {nx, ny, nz};
+    if (use_fft && fft_shape_xyz) { f[0] = fft_shape_xyz[0]; f[1] = fft_shape_xyz[1]; f[2] = fft_shape_xyz[2]; }
+    const int key[12] = {nx, ny, nz, kx, ky, kz, use_fft ? 1 : 0, f[0], f[1], f[2], opt->engine, (!use_fft && psf_inv) ? 1 : 0};
+    // the PSFs are small: compare their values with the ones the kept objects were built from
+    hipStream_t s = as_stream(stream);
+    const size_t nk = (size_t)kx * ky * kz;
+    std::vector<float> h(nk), hi;
+    MI_HIP(hipMemcpyAsync(h.data(), psf, sizeof(float) * nk, hipMemcpyDeviceToHost, s));
+    if (key[11]) {
+        hi.resize(nk);
+        MI_HIP(hipMemcpyAsync(hi.data(), psf_inv, sizeof(float) * nk, hipMemcpyDeviceToHost, s));
+    }
+    MI_HIP(hipStreamSynchronize(s));
+    if (std::memcmp(key, plan->key, sizeof(key)) != 0 || h != plan->psf || hi != plan->psf_inv) {
+        MI_HIP(hipStreamSynchronize(s));
+        plan->drop();
+        std::memcpy(plan->key, key, sizeof(key));
+        plan->psf.swap(h);
+        plan->psf_inv.swap(hi);
+    }
+    int rc = use_fft ? rl_fft_impl(dev, stream, bl, psf, nx, ny, nz, kx, ky, kz, f[0], f[1], f[2], opt, iters_done, &plan->ctx, &plan->taper)
+                     : rl_spatial_impl(dev, stream, bl, psf, psf_inv, nx, ny, nz, kx, ky, kz, opt, iters_done, &plan->ctx, &plan->taper);
+    if (rc != MI_OK) {  // whatever was half built is not trusted
+        (void)hipStreamSynchronize(s);
+        plan->drop();
+        plan->key[0] = 0;
+    }
+    return rc;
 }

@@ -386,9 +386,39 @@ class RLContext:
             pass
 
 
+class DeconPlan:
+    """What ``decon`` would rebuild for every block of a volume -- the RL context (OTF, twiddles, scratch) and the FFT engine of
+    the edge taper's blur -- kept between calls (``mi_decon_plan``).  Pass it as ``decon(..., plan=plan)``; shape, options and
+    PSF values are compared on every call and the kept objects rebuilt when they differ, results are bit-identical to a call
+    without a plan.  One plan per worker thread."""
+
+    def __init__(self, device=None):
+        self.device = _device(device)
+        h = C.c_void_p()
+        check(lib().mi_decon_plan_create(self.device.index, C.byref(h)))
+        self.handle = h
+
+    def close(self):
+        if self.handle is not None:
+            check(lib().mi_decon_plan_destroy(self.handle))
+            self.handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def decon(bl, psf, niter, lambda_=0.0, stop_criterion=0.0, regularize_interval=0, device_id=None, use_fft=False,
           fft_shape=None, adaptive_psf=False, *, engine=ENGINE_AUTO, skip_edgetaper=False, gauss_taps=0,
-          return_iters=False, return_psf=False):
+          return_iters=False, return_psf=False, plan=None):
     """``bl = decon(bl, psf, niter, lambda, stop_criterion, regularize_interval, device_id, use_fft, fft_shape,
     adaptive_psf)`` (decon.m:1-23).  ``adaptive_psf`` with ``use_fft`` runs ``deconFFT_Wiener`` (decon.m:206-321), whose
     ``fft_shape`` must be made of extents the hand-written FFT takes (``fft_good_size``); ``return_psf`` then also hands
@@ -431,6 +461,11 @@ def decon(bl, psf, niter, lambda_=0.0, stop_criterion=0.0, regularize_interval=0
         refined = p.clone()
         check(lib().mi_rl_fft_wiener(dev.index, _stream(t), t.data_ptr(), refined.data_ptr(), nx, ny, nz, kx, ky, kz,
                                      fs[0], fs[1], fs[2], C.byref(opt), C.byref(done)))
+    elif plan is not None:
+        if plan.device != dev:
+            raise ValueError(f"decon: the plan lives on {plan.device}, the block on {dev}")
+        check(lib().mi_decon_plan_run(plan.handle, _stream(t), t.data_ptr(), p.data_ptr(), pi_ptr, nx, ny, nz, kx, ky, kz,
+                                      C.byref(opt), 1 if use_fft else 0, fs, 0, C.byref(done)))
     else:
         check(lib().mi_decon(dev.index, _stream(t), t.data_ptr(), p.data_ptr(), pi_ptr, nx, ny, nz, kx, ky, kz,
                              C.byref(opt), 1 if use_fft else 0, fs, 0, C.byref(done)))

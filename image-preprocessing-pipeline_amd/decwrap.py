@@ -182,6 +182,16 @@ def main(argv=None):
         g = workers[worker_id]
         stream = torch.cuda.Stream(device=g - 1)
         staging = {}  # pinned host buffers by core shape: D2H at PCIe rate instead of page-faulting a fresh pageable array
+        # blocks of equal shape share the RL context and the taper's FFT engine (MI_NO_DECON_PLAN: rebuild them per block)
+        plan = None if os.environ.get("MI_NO_DECON_PLAN") else D.DeconPlan(g)
+        try:
+            run_blocks(g, stream, staging, plan)
+        finally:
+            if plan is not None:
+                with torch.cuda.device(g - 1):
+                    plan.close()
+
+    def run_blocks(g, stream, staging, plan):
         while True:
             with lock:
                 if not todo:
@@ -206,7 +216,7 @@ def main(argv=None):
             blk = L.Block(block.x, block.y, block.z, block.nx, block.ny, block.nz, *pad, fft_shape=fshape)
             with torch.cuda.device(g - 1), torch.cuda.stream(stream):
                 t, lb, ub = L.process_block(bl, blk, psf_struct, args.numit, args.lambda_damping, args.stop_criterion, filt,
-                                            args.clipval, g)
+                                            args.clipval, g, plan=plan)
                 core = t[pad[2]:t.shape[0] - pad[2] or None, pad[1]:t.shape[1] - pad[1] or None, pad[0]:t.shape[2] - pad[0] or None]
                 core = core.contiguous()                                                   # strip pads, LsDeconv.m:750-752
                 if tuple(core.shape) not in staging:

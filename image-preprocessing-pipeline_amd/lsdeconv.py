@@ -175,7 +175,7 @@ def output_scale(rawmax: float, convert_to_8bit=False, convert_to_16bit=False) -
     return float(rawmax)
 
 
-def process_block(bl, block: Block, psf, niter, lambda_, stop_criterion, filt: Filter, clipval=99.99, gpu=1):
+def process_block(bl, block: Block, psf, niter, lambda_, stop_criterion, filt: Filter, clipval=99.99, gpu=1, plan=None):
     """``[bl, lb, ub] = process_block(bl, block, psf, niter, lambda, stop_criterion, filter, clipval, gpu, ...)``
     (LsDeconv.m:906-948) on device ``gpu`` (1-based like ``gpuDevice(gpu)``)."""
     dev = torch.device("cuda", int(gpu) - 1)
@@ -188,7 +188,7 @@ def process_block(bl, block: Block, psf, niter, lambda_, stop_criterion, filt: F
                                                    t.numel(), float(filt.dark)))                # :924-927
     if niter > 0 and float(t.max()) > 2.0 ** -23:                                               # :929
         D.decon(t, psf, niter, lambda_, stop_criterion, filt.regularize_interval, gpu, filt.use_fft,
-                block.fft_shape if filt.use_fft else None, filt.adaptive_psf)
+                block.fft_shape if filt.use_fft else None, filt.adaptive_psf, plan=plan)
     if filt.destripe_sigma > 0:
         D.filter_subband_3d_z(t, filt.destripe_sigma, 0, "db9")                                 # :934-936
     lb, ub = deconvolved_stats(t, clipval)

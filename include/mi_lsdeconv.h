@@ -197,6 +197,18 @@ int mi_destripe_z(int dev, void* stream, float* bl, int nx, int ny, int nz, floa
 /* wmaxlev([nx nz] rounded up to even, 'db9') = fix(log2(min / 17)) */
 int mi_destripe_max_levels(int nx, int nz);
 
+/* Deconvolution plan: the blocks of a volume share shape and PSF (the parfeval workers of LsDeconv.m:620-668 call decon once
+ * per block), so a worker keeps what mi_decon would rebuild every time -- the RL context (OTF, twiddles, scratch) and the FFT
+ * engine of edgetaper_3d's blur -- in a plan.  mi_decon_plan_run has the semantics and arguments of mi_decon; it compares
+ * shape, options and the PSF values with what the kept objects were built from and rebuilds them when they differ.  Results
+ * are bit-identical to mi_decon.  One plan per worker thread (not re-entrant); destroy it on the thread's device. */
+typedef struct mi_decon_plan mi_decon_plan;
+int mi_decon_plan_create(int dev, mi_decon_plan** out);
+int mi_decon_plan_run(mi_decon_plan* plan, void* stream, float* bl, const float* psf, const float* psf_inv,
+                      int nx, int ny, int nz, int kx, int ky, int kz, const mi_rl_options* opt,
+                      int use_fft, const int* fft_shape_xyz, int adaptive_psf, int* iters_done);
+int mi_decon_plan_destroy(mi_decon_plan* plan);
+
 /* cost model used by MI_ENGINE_AUTO: returns MI_ENGINE_DIRECT or MI_ENGINE_FFT */
 int mi_engine_select(int nx, int ny, int nz, int kx, int ky, int kz, int boundary);
 

@@ -311,3 +311,23 @@ def test_edgetaper_fft_route_equals_direct_route(dev, engine, monkeypatch):
     psf = R.gaussian_psf((21, 9, 9), (4.0, 2.0, 2.0))
     got = decon.edgetaper_3d(_t(bl, dev), _t(psf, dev)).cpu().numpy()
     assert np.abs(got - R.edgetaper_3d(bl, psf)).max() < 1e-5
+
+
+def test_decon_plan_is_bit_identical_and_rebuilds(dev):
+    """mi_decon_plan keeps the RL context and the taper engine between blocks: same bits as decon without a plan, for repeated
+    blocks, a changed PSF, a changed shape and the spatial flavour."""
+    from ipp_amd import decon
+    vol, psf = _case((20, 36, 44), (7, 5, 5), (1.5, 1.0, 1.0), 21)
+    vol2 = np.ascontiguousarray(vol[::-1])
+    psf2 = np.ascontiguousarray(psf[::-1] * 0.5 + psf * 0.5)
+    F = (64, 64, 32)
+    with decon.DeconPlan(1) as plan:
+        for v, p_, fshape, use_fft in ((vol, psf, F, True), (vol2, psf, F, True), (vol, psf2, F, True), (vol[:, :32, :40], psf, F, True),
+                                       (vol, psf, None, False), (vol2, decon.make_psf_struct(psf), None, False), (vol, psf, F, True)):
+            want = decon.decon(_t(v, dev), p_, 4, 0.0, 0.0, 2, 1, use_fft, fshape, False).cpu().numpy()
+            got = decon.decon(_t(v, dev), p_, 4, 0.0, 0.0, 2, 1, use_fft, fshape, False, plan=plan).cpu().numpy()
+            assert np.array_equal(got, want)
+        # the adaptive variant passes through
+        a = decon.decon(_t(vol, dev), psf, 2, 0.0, 0.0, 0, 1, True, F, True).cpu().numpy()
+        b = decon.decon(_t(vol, dev), psf, 2, 0.0, 0.0, 0, 1, True, F, True, plan=plan).cpu().numpy()
+        assert np.array_equal(a, b)
