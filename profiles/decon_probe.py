@@ -20,3 +20,7 @@ t("decon 2 it", lambda: decon.decon(bl, psf, 2, 0.0, 0.0, 0, 1, True, fs, False)
 t("decon 2 it", lambda: decon.decon(bl, psf, 2, 0.0, 0.0, 0, 1, True, fs, False))
 t("decon 0 it skip_edgetaper (context build only)", lambda: decon.decon(bl, psf, 0, 0.0, 0.0, 0, 1, True, fs, False, skip_edgetaper=True))
 t("decon 6 it skip_edgetaper", lambda: decon.decon(bl, psf, 6, 0.0, 0.0, 0, 1, True, fs, False, skip_edgetaper=True))
+with decon.DeconPlan(1) as plan:
+    for i in range(3):
+        t(f"decon 6 it with a plan #{i}", lambda: decon.decon(bl, psf, 6, 0.0, 0.0, 0, 1, True, fs, False, plan=plan))
+t("decon 6 it without a plan", lambda: decon.decon(bl, psf, 6, 0.0, 0.0, 0, 1, True, fs, False))
