@@ -94,6 +94,7 @@ SIGNATURES = {
     "mi_decon_plan_create": (_i, [_i, C.POINTER(_vp)]),
     "mi_decon_plan_run": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 6 + [C.POINTER(RlOptions), _i, _ip, _i, _ip]),
     "mi_decon_plan_destroy": (_i, [_vp]),
+    "mi_load_block": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _vp] + [_i] * 6),
     "mi_destripe_z": (_i, [_i, _vp, _vp, _i, _i, _i, _f, _i]),
     "mi_destripe_max_levels": (_i, [_i, _i]),
     "mi_decon": (_i, [_i, _vp, _vp, _vp, _vp] + [_i] * 6 + [C.POINTER(RlOptions), _i, _ip, _i, _ip]),

@@ -283,6 +283,48 @@ extern "C" int mi_u16_to_f32(int dev, void* stream, const uint16_t* src, float* 
     return launch_check("k_u16_to_f32");
 }
 
+namespace {
+// load_block (LsDeconv.m:817-904) on the device: dst (the padded block) <- the sub-box read from the volume, converted like
+// im2single (integer types: value / max of the type, a float32 division) and extended by padarray(..., 'symmetric')
+// (edge-inclusive mirror, repeated when the pad exceeds the box) where the padded block reaches beyond the volume
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_load_block(const T* __restrict__ src, int sx, int sy, int sz, float* __restrict__ dst, int nx,
+                                                          int ny, int nz, int bx, int by, int bz, float maxv) {
+    const size_t total = (size_t)nx * ny * nz;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % nx);
+        const size_t r = i / nx;
+        const int y = (int)(r % ny), z = (int)(r / ny);
+        auto mirror = [](int j, int n) {
+            const int p = 2 * n;
+            j %= p;
+            if (j < 0) j += p;
+            return j < n ? j : p - 1 - j;
+        };
+        const float v = (float)src[((size_t)mirror(z - bz, sz) * sy + mirror(y - by, sy)) * sx + mirror(x - bx, sx)];
+        dst[i] = maxv > 0.0f ? v / maxv : v;
+    }
+}
+}  // namespace
+
+extern "C" int mi_load_block(int dev, void* stream, const void* src, int dtype, int sx, int sy, int sz, float* dst, int nx, int ny, int nz,
+                             int bx, int by, int bz) {
+    MI_TRY(use_device(dev));
+    MI_REQUIRE(src && dst, "load_block: null pointer");
+    MI_REQUIRE(sx > 0 && sy > 0 && sz > 0 && nx > 0 && ny > 0 && nz > 0, "load_block: empty box");
+    MI_REQUIRE(bx >= 0 && by >= 0 && bz >= 0 && bx + sx <= nx && by + sy <= ny && bz + sz <= nz,
+               "load_block: the box read from the volume must lie inside the padded block");
+    const dim3 grid(stream_grid((size_t)nx * ny * nz)), block(kThreads);
+    hipStream_t s = as_stream(stream);
+    switch (dtype) {
+        case 1: hipLaunchKernelGGL(k_load_block<uint8_t>, grid, block, 0, s, (const uint8_t*)src, sx, sy, sz, dst, nx, ny, nz, bx, by, bz, 255.0f); break;
+        case 2: hipLaunchKernelGGL(k_load_block<uint16_t>, grid, block, 0, s, (const uint16_t*)src, sx, sy, sz, dst, nx, ny, nz, bx, by, bz, 65535.0f); break;
+        case 4: hipLaunchKernelGGL(k_load_block<float>, grid, block, 0, s, (const float*)src, sx, sy, sz, dst, nx, ny, nz, bx, by, bz, 0.0f); break;
+        default: return fail(MI_ERR_INVALID, "load_block: dtype code %d (1 = uint8, 2 = uint16, 4 = float32)", dtype);
+    }
+    return launch_check("k_load_block");
+}
+
 extern "C" int mi_subtract_dark(int dev, void* stream, const float* src, float* dst, size_t n, float dark) {
     MI_TRY(use_device(dev));
     MI_REQUIRE(src && dst, "mi_subtract_dark: null pointer");

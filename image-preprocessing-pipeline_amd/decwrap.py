@@ -208,13 +208,15 @@ def main(argv=None):
                         stats.append((st["lb"], st["ub"]))
                     log.info(f"block {n}/{len(block.p1)} taken from the cache")
                     continue
-            bl = L.load_block(vol, p1, p2, pad)
+            bl_xyz = tuple(int(b) - int(a) + 1 + 2 * int(q) for a, b, q in zip(p1, p2, pad))   # padded block, [x y z]
             fshape = None
             if args.use_fft:
-                smooth, native = L.next_fast_len(bl.shape[::-1]), L.native_fft_shape(bl.shape[::-1])
+                smooth, native = L.next_fast_len(bl_xyz), L.native_fft_shape(bl_xyz)
                 fshape = native if np.prod(native) <= 1.3 * np.prod(smooth) else smooth
             blk = L.Block(block.x, block.y, block.z, block.nx, block.ny, block.nz, *pad, fft_shape=fshape)
             with torch.cuda.device(g - 1), torch.cuda.stream(stream):
+                # load_block on the device: the raw samples cross PCIe, conversion and symmetric padding happen there
+                bl = L.load_block_device(vol, p1, p2, pad, torch.device("cuda", g - 1), staging)
                 t, lb, ub = L.process_block(bl, blk, psf_struct, args.numit, args.lambda_damping, args.stop_criterion, filt,
                                             args.clipval, g, plan=plan)
                 core = t[pad[2]:t.shape[0] - pad[2] or None, pad[1]:t.shape[1] - pad[1] or None, pad[0]:t.shape[2] - pad[0] or None]

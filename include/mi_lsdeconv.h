@@ -62,6 +62,13 @@ int mi_otf(int dev, void* stream, const float* psf, int kx, int ky, int kz, floa
 /* dst = single(src) * scale : im2single of uint16 blocks (LsDeconv.m:860,873; scale = 1/65535) */
 int mi_u16_to_f32(int dev, void* stream, const uint16_t* src, float* dst, size_t n, float scale);
 
+/* load_block (LsDeconv.m:817-904) on the device: dst [nz][ny][nx] (the padded block, float32) <- the box src [sz][sy][sx] that was
+ * read from the volume where the padded block overlaps it, placed at offset (bx, by, bz); integer inputs are converted like
+ * im2single (value / 255 or / 65535, a float32 division); where the block reaches beyond the volume it is extended like
+ * padarray(..., 'symmetric') (edge-inclusive mirror of the box).  dtype: 1 = uint8, 2 = uint16, 4 = float32.  Only enqueues. */
+int mi_load_block(int dev, void* stream, const void* src, int dtype, int sx, int sy, int sz,
+                  float* dst, int nx, int ny, int nz, int bx, int by, int bz);
+
 /* dst = max(src - dark, 0)   [LsDeconv.m:924-927], in place allowed */
 int mi_subtract_dark(int dev, void* stream, const float* src, float* dst, size_t n, float dark);
 

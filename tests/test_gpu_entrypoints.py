@@ -302,3 +302,19 @@ def test_entry_points_in_a_fresh_process(dev, tmp_path):
                         "--sV", "5", "--sH", "5", "--sD", "1"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     assert (tmp_path / "xml_displcomp.xml").exists()
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.float32])
+def test_load_block_on_the_device_is_bit_identical(dev, dtype):
+    """mi_load_block (conversion like im2single + padarray 'symmetric' on the device) against lsdeconv.load_block on the host:
+    interior blocks, blocks at every face of the volume, pads larger than what the volume offers."""
+    from ipp_amd import lsdeconv as L
+    rng = np.random.default_rng(17)
+    vol = (rng.random((20, 26, 30)) * (250 if dtype == np.uint8 else 60000)).astype(dtype)
+    staging = {}
+    for p1, p2, pad in (((1, 1, 1), (30, 26, 20), (5, 4, 3)), ((9, 7, 5), (20, 18, 14), (4, 4, 4)), ((1, 9, 1), (12, 26, 8), (6, 2, 9)),
+                        ((19, 1, 13), (30, 10, 20), (7, 7, 7)), ((11, 11, 11), (12, 12, 12), (25, 3, 22))):
+        want = L.load_block(vol, p1, p2, pad)
+        got = L.load_block_device(vol, p1, p2, pad, dev, staging)
+        assert got.dtype == torch.float32 and tuple(got.shape) == want.shape
+        assert np.array_equal(got.cpu().numpy(), want), (p1, p2, pad)
