@@ -227,18 +227,27 @@ def main(argv=None):
                 host.copy_(core, non_blocking=True)
                 stream.synchronize()
                 core = host.numpy()
-            out[p1[2] - 1:p2[2], p1[1] - 1:p2[1], p1[0] - 1:p2[0]] = core                  # disjoint boxes: no lock needed
-            with open(brick.with_suffix(".json"), "w") as f:                               # the block's clip range (min_max.mat entry)
-                json.dump({"lb": lb, "ub": ub}, f)
-            brickio.save_lz4(brick.with_suffix(".lz4.tmp"), core)                          # LsDeconv.m:805-806
-            os.replace(brick.with_suffix(".lz4.tmp"), brick)
+            box = (slice(p1[2] - 1, p2[2]), slice(p1[1] - 1, p2[1]), slice(p1[0] - 1, p2[0]))
+            out[box] = core                                                                # disjoint boxes: no lock needed
+            # the brick cache (resume) is written behind the worker's back: LZ4 of a float32 core takes longer than its kernels
             with lock:
                 stats.append((lb, ub))
+                pending.append(writers.submit(save_brick, brick, box, lb, ub))
             log.info(f"block {n}/{len(block.p1)} done on GPU {g}: stats [{lb:.4g}, {ub:.4g}]")
 
-    with ThreadPoolExecutor(max_workers=len(workers)) as pool:
-        for f in [pool.submit(run, w) for w in range(len(workers))]:
-            f.result()                                                                     # re-raises a worker's exception
+    def save_brick(brick, box, lb, ub):
+        with open(brick.with_suffix(".json"), "w") as f:                                   # the block's clip range (min_max.mat entry)
+            json.dump({"lb": lb, "ub": ub}, f)
+        brickio.save_lz4(brick.with_suffix(".lz4.tmp"), np.ascontiguousarray(out[box]))    # LsDeconv.m:805-806
+        os.replace(brick.with_suffix(".lz4.tmp"), brick)
+
+    pending = []
+    with ThreadPoolExecutor(max_workers=max(2, min(8, (os.cpu_count() or 4) // 2))) as writers:   # liblz4 runs outside the GIL
+        with ThreadPoolExecutor(max_workers=len(workers)) as pool:
+            for f in [pool.submit(run, w) for w in range(len(workers))]:
+                f.result()                                                                 # re-raises a worker's exception
+        for f in pending:
+            f.result()
     lo = min((s[0] for s in stats), default=np.inf)
     hi = max((s[1] for s in stats), default=-np.inf)
     np.save(out_dir / "deconvolved.npy", out)
