@@ -219,8 +219,8 @@ class Project:
             raise RuntimeError(f"in Stack[{stk.ROW_INDEX},{stk.COL_INDEX}]: no TIFF slices in {folder}")
         return files
 
-    def loadImageStack(self, stk: Stack, z0: int, z1: int):
-        """Stack::loadImageStack(first, last) (vmStack.cpp:562-640): slices [z0, z1] inclusive as float32 (D, V, H) in [0, 1]."""
+    def _read_slices(self, stk: Stack, z0: int, z1: int):
+        """Raw slices [z0, z1] (inclusive) of a stack as one (D, V, H) uint8 / uint16 array."""
         from PIL import Image
         if not stk.isComplete(z0, z1):
             raise ValueError(f"in Stack[{stk.ROW_INDEX},{stk.COL_INDEX}]::loadImageStack: slices [{z0},{z1}] are not all present")
@@ -236,9 +236,31 @@ class Project:
             if a.ndim != 2 or a.dtype not in (np.uint8, np.uint16):
                 raise TypeError(f"{files[index[z]]}: 8 or 16 bits per channel, single-channel slices are supported (tiff2D.cpp:600-612)")
             if out is None:
-                out = np.empty((z1 - z0 + 1,) + a.shape, np.float32)
-            out[k] = a.astype(np.float32) / np.float32(255.0 if a.dtype == np.uint8 else 65535.0)
+                out = np.empty((z1 - z0 + 1,) + a.shape, a.dtype)
+            elif a.shape != out.shape[1:] or a.dtype != out.dtype:
+                raise ValueError(f"{files[index[z]]}: slice shape / type differs from the first slice of the stack")
+            out[k] = a
         return out
+
+    def loadImageStack(self, stk: Stack, z0: int, z1: int):
+        """Stack::loadImageStack(first, last) (vmStack.cpp:562-640): slices [z0, z1] inclusive as float32 (D, V, H) in [0, 1]
+        (value / 255 or / 65535, tiff2D.cpp:606-610)."""
+        raw = self._read_slices(stk, z0, z1)
+        return raw.astype(np.float32) / np.float32(255.0 if raw.dtype == np.uint8 else 65535.0)
+
+    def loadImageStackDevice(self, stk: Stack, z0: int, z1: int, device):
+        """The same stack as a float32 CUDA tensor: the raw samples cross PCIe, the conversion (the same float32 division) runs
+        on the device (``mi_load_block`` without padding)."""
+        import torch
+        from . import capi
+        raw = self._read_slices(stk, z0, z1)
+        d_raw = torch.from_numpy(raw.view(np.uint8).reshape(-1)).to(device)
+        dst = torch.empty(raw.shape, dtype=torch.float32, device=device)
+        dk, dv, dh = raw.shape
+        capi.check(capi.lib().mi_load_block(device.index, capi.current_stream_ptr(device), d_raw.data_ptr(), raw.dtype.itemsize, dh, dv, dk,
+                                            dst.data_ptr(), dh, dv, dk, 0, 0, 0))
+        d_raw.record_stream(torch.cuda.current_stream(device))
+        return dst
 
     # ---- displacement bookkeeping
     def insertDisplacement(self, stk_A: Stack, stk_B: Stack, d: DisplacementMIPNCC):
@@ -323,7 +345,7 @@ class Project:
             za, zb = z0 + a, z0 + b - 1
             complete = [[s.isComplete(za, zb) for s in row] for row in self.STACKS]
             if all(all(r) for r in complete):
-                tiles = [[torch.from_numpy(self.loadImageStack(s, za, zb)).to(dev) for s in row] for row in self.STACKS]
+                tiles = [[self.loadImageStackDevice(s, za, zb, dev) for s in row] for row in self.STACKS]
                 res = crossmips.compute_displacements(tiles, overlap_V, overlap_H, displ_max_V, displ_max_H, displ_max_D,
                                                       rank=rank, world_size=world_size)
             else:   # sparse layer: pair by pair over the tiles that exist
@@ -334,8 +356,8 @@ class Project:
                     q += 1
                     if (q - 1) % world_size != rank:
                         continue
-                    A = torch.from_numpy(self.loadImageStack(self.STACKS[r][c], za, zb)).to(dev)
-                    B = torch.from_numpy(self.loadImageStack(self.STACKS[rb][cb], za, zb)).to(dev)
+                    A = self.loadImageStackDevice(self.STACKS[r][c], za, zb, dev)
+                    B = self.loadImageStackDevice(self.STACKS[rb][cb], za, zb, dev)
                     res[(r, c, rb, cb, direction)] = crossmips.PDAlgoMIPNCC.execute(
                         A, B, displ_max_V, displ_max_H, displ_max_D, direction,
                         overlap_V if direction == dir_vertical else overlap_H, device=dev)

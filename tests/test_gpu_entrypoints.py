@@ -137,6 +137,8 @@ def test_process_images_on_a_terastitcher_project(dev, tmp_path):
             proj.STACKS[r][c] = tsproject.Stack(r, c, name, ABS_V=r * step, ABS_H=c * step, N_BYTESxCHAN=2, z_ranges=[(0, slices)])
     x1, x2, x3, x4 = (tmp_path / f"xml_import_step_{k}.xml" for k in (1, 2, 3, 4))
     proj.save(x1)
+    on_dev = proj.loadImageStackDevice(proj.STACKS[1][0], 3, 9, dev)            # same bits as the host conversion
+    assert np.array_equal(on_dev.cpu().numpy(), proj.loadImageStack(proj.STACKS[1][0], 3, 9))
     assert process_images.main(["-2", "--sV", "6", "--sH", "6", "--sD", "1", "--subvoldim", "20", "--threshold", "0.65",
                                 f"--projin={x1}", f"--projout={x2}"]) == 0
     comp = tsproject.Project.load(x2)
