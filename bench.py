@@ -71,29 +71,60 @@ def pmc_traffic(pass_name, workload):
     return None
 
 
-def cpu_baseline(kshape, seconds_budget=20.0):
-    """The oracle (numpy restatement of deconFFT, 1 host thread) on a bounded sub-volume of the same workload."""
+def cpu_baseline(vshape, kshape, seconds_budget=20.0):
+    """The oracle's deconFFT loop (oracle/rl_oracle.py:decon_fft_f32 -- scipy.fft, float32 / complex64, every host core)
+    on a bounded sub-volume of the same workload: 1/8 of the volume (every extent halved) when one iteration fits the
+    budget, else 1/64 (every extent quartered) for as many iterations as fit."""
     import numpy as np
     from oracle import rl_oracle
-    shape = (max(64, kshape[0] + 3), 192, 192)
-    rng = np.random.default_rng(1234)
-    vol = rng.uniform(0.01, 0.02, size=shape).astype(np.float32)
+    cores = os.cpu_count() or 1
     psf = make_psf(kshape)
-    otf = rl_oracle.otf_from_psf(psf, shape)
-    iters, t0 = 0, time.perf_counter()
-    bl = vol
-    while True:
-        buf = np.real(np.fft.ifftn(np.fft.fftn(bl.astype(np.float64)) * otf)).astype(np.float32)
-        buf = (bl / np.maximum(buf, rl_oracle.EPS_SINGLE)).astype(np.float32)
-        buf = np.real(np.fft.ifftn(np.fft.fftn(buf.astype(np.float64)) * np.conj(otf))).astype(np.float32)
-        bl = np.abs(bl * buf)
-        iters += 1
-        dt = time.perf_counter() - t0
-        if dt > seconds_budget * 0.5 or iters >= 8:
-            break
-    return {"value": float(np.prod(shape)) * iters / dt / 1e9, "unit": "Gvoxel*iter/s", "cores": 1, "kind": "port",
-            "sample": f"{iters} deconFFT iterations (oracle/rl_oracle.py loop body) on a {shape[2]}x{shape[1]}x{shape[0]} "
-                      f"sub-volume with the {kshape[2]}x{kshape[1]}x{kshape[0]} PSF, numpy pocketfft, 1 thread"}
+    rng = np.random.default_rng(1234)
+
+    def run(shape, iters):
+        vol = rng.uniform(0.01, 0.02, size=shape).astype(np.float32)
+        otf = rl_oracle.otf_half_f32(psf, shape, workers=cores)
+        t0 = time.perf_counter()
+        rl_oracle.decon_fft_f32(vol, otf, iters, workers=cores)
+        return time.perf_counter() - t0
+
+    target = tuple(max(k + 3, v // 2) for v, k in zip(vshape, kshape))      # 1/8 of the volume
+    probe = tuple(max(k + 3, v // 4) for v, k in zip(vshape, kshape))       # 1/64: calibrates the host
+    run(probe, 1)                                                             # page in scipy / warm the thread pool
+    t_probe = run(probe, 1)
+    scale = float(np.prod(target)) / float(np.prod(probe))
+    shape = target if t_probe * scale * 1.15 <= seconds_budget else probe
+    iters = 1 if shape == target else max(1, min(8, int(seconds_budget / max(t_probe, 1e-3))))
+    dt = run(shape, iters)
+    return {"value": float(np.prod(shape)) * iters / dt / 1e9, "unit": "Gvoxel*iter/s", "cores": cores, "kind": "port",
+            "OMP_NUM_THREADS": os.environ.get("OMP_NUM_THREADS"),
+            "sample": f"{iters} deconFFT iteration(s) (oracle/rl_oracle.py:decon_fft_f32, scipy.fft rfftn/irfftn, float32/complex64, "
+                      f"workers={cores}) on a {shape[2]}x{shape[1]}x{shape[0]} sub-volume "
+                      f"({float(np.prod(shape)) / float(np.prod(vshape)):.4f} of the workload) with the "
+                      f"{kshape[2]}x{kshape[1]}x{kshape[0]} PSF, {dt:.1f} s"}
+
+
+def launch_ranks(n, argv):
+    """``python bench.py --gpus N`` from a plain shell: start the N ranks as a CHILD process tree (torch.distributed.run, one rank
+    per GPU, rendezvous on 127.0.0.1), relay rank 0's JSON line and return the child's exit code.  Nothing in this process has
+    touched the GPU (no torch import, no HIP call) -- the reference fans its workers out itself too (LsDeconv.m:643-654)."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *argv]
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout.splitlines():
+        if line.startswith('{"metric"'):
+            print(line, flush=True)
+        elif line.strip():
+            sys.stderr.write(line + "\n")
+    return proc.returncode
 
 
 def main():
@@ -110,6 +141,10 @@ def main():
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: all ranks on cuda:0 (with --backend gloo)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under a launcher: fan the ranks out as a child process tree before anything here touches the GPU
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+
     import torch
     from ipp_amd import capi, decon
     capi.require_gpu()
@@ -118,8 +153,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU")
     dev = torch.device("cuda", 0 if args.share_gpu else local_rank)
     torch.cuda.set_device(dev)
     dist = None
@@ -154,6 +188,7 @@ def main():
         run_steps = None
         parallelism = f"y-slabs x{world}, RCCL halo exchange"
         engine_used = drv.ctx.engine
+        ctx, bl = drv.ctx, drv.bl                # rank-local context / slab (interior + halo rows) for the per-pass timing
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -186,9 +221,11 @@ def main():
         ms_per_step = elapsed * 1e3 / args.steps
         value = n_vox_global * args.steps / elapsed / 1e9
         local_vox = n_vox_global / world
+        # voxels one launch of a pass processes: the rank-local grid (interior + halo rows, rounded to a native FFT extent)
+        launch_vox = float(bl.numel())
         iteration_gbs = ALGO_BYTES_PER_VOXEL_ITER * local_vox / (dev_ms / args.steps * 1e-3) / 1e9
         roofline = None
-        if world == 1 and engine_used == 2:
+        if engine_used == 2:
             try:
                 # per-pass launch durations, HIP events on the launch stream (mi_rl_time_pass); the dominant kernel
                 # is the one with the largest share of an iteration
@@ -201,14 +238,14 @@ def main():
                 times["x_fused"] = 0.5 * (t_ratio + t_update)
                 dom = max(times, key=lambda k: times[k] * per_iter[k])
                 algo_b = {"z_conv": 10 if ctx.otf_is_real else 12, "y_forward": 8, "y_inverse": 8, "x_fused": 14}[dom]  # B/voxel/launch
-                ach = algo_b * local_vox / (times[dom] * 1e-3) / 1e9
+                ach = algo_b * launch_vox / (times[dom] * 1e-3) / 1e9
                 roofline = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(dom, args.workload),
+                            "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(dom, args.workload) if world == 1 else None,
                             "kernel": {"z_conv": "k_z_conv_pipe (z-forward FFT + untangle*OTF + z-inverse FFT, one pass)",
                                        "x_fused": "k_x_fused_pipe (x-inverse FFT + RL epilogue + x-forward FFT; mean of the "
                                                   "ratio and the update launch)",
                                        "y_forward": "k_y_pass<fwd>", "y_inverse": "k_y_pass<inv>"}[dom],
-                            "algorithmic_bytes_per_voxel_per_launch": algo_b,
+                            "algorithmic_bytes_per_voxel_per_launch": algo_b, "voxels_per_launch": int(launch_vox),
                             "launch_ms": round(times[dom], 4), "launches_per_iteration": per_iter[dom],
                             "pass_ms": dict({k: round(v, 4) for k, v in times.items()},
                                             x_fused_ratio=round(t_ratio, 4), x_fused_update=round(t_update, 4))}
@@ -233,7 +270,7 @@ def main():
             "roofline": roofline,
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(kshape)
+            out["cpu_baseline"] = cpu_baseline(vshape, kshape)
         if not args.no_ncc and world == 1:
             try:
                 import bench_ncc

@@ -265,6 +265,32 @@ def decon_fft(bl, psf, fft_shape_zyx, niter, lam=0.0, stop_criterion=0.0, regula
     return (out, done) if return_iters else out
 
 
+def otf_half_f32(psf, fft_shape_zyx, workers=1):
+    """:func:`otf_from_psf` in single precision as the R2C half spectrum (scipy.fft, ``workers`` threads): the OTF of the
+    timing leg :func:`decon_fft_f32`."""
+    from scipy import fft as sfft
+    p, _, _ = pad_block_to_fft_shape(psf.astype(np.float32), fft_shape_zyx)
+    return sfft.rfftn(np.fft.ifftshift(p), workers=workers)
+
+
+def decon_fft_f32(bl, otf_half, niter, workers=1):
+    """The loop body of ``deconFFT`` (decon.m:162-186, lambda = 0, no regularisation, no stop test) with single-precision
+    transforms on all host cores -- what the reference's MATLAB CPU path does with ``single`` arrays (multithreaded
+    fftn).  ``bl`` already has the FFT shape.  bench.py's ``cpu_baseline`` times this; tests/test_oracle_rl.py holds it to
+    :func:`decon_fft` (float64 transforms) within 1e-4."""
+    from scipy import fft as sfft
+    bl = bl.astype(np.float32)
+    shape = bl.shape
+    otf_c = np.conj(otf_half)
+    for _ in range(niter):
+        buf = sfft.irfftn(sfft.rfftn(bl, workers=workers) * otf_half, s=shape, workers=workers)
+        np.maximum(buf, EPS_SINGLE, out=buf)
+        np.divide(bl, buf, out=buf)
+        buf = sfft.irfftn(sfft.rfftn(buf, workers=workers) * otf_c, s=shape, workers=workers)
+        bl = np.abs(bl * buf)
+    return bl
+
+
 def decon_fft_wiener(bl, psf, fft_shape_zyx, niter, lam=0.0, stop_criterion=0.0, regularize_interval=0,
                      gauss_flavour="gpu", skip_edgetaper=False, return_psf=False, forced_psfs=None, trace=None):
     """``deconFFT_Wiener`` (decon.m:206-321): RL on ``fft_shape`` with a Wiener re-estimate of the PSF after every

@@ -8,6 +8,7 @@ import torch
 from scipy import ndimage
 
 from oracle import rl_oracle as R
+from tests.rl_util import assert_close
 
 pytestmark = pytest.mark.gpu
 
@@ -48,7 +49,7 @@ def test_decon_fft_native_matches_oracle(dev, shape, niter, lam, interval):
     want = R.decon_fft(vol, psf, vol.shape, niter, lam, 0.0, interval)
     got = decon.decon(torch.from_numpy(vol).to(dev), psf, niter, lam, 0.0, interval, 1, True,
                       (shape[2], shape[1], shape[0]), False).cpu().numpy()
-    assert _rel(got, want) < 1e-4
+    assert_close(got, want)
 
 
 def test_adjoint_is_exact_transpose(dev):
@@ -88,7 +89,8 @@ def test_fused_iterations_equal_unfused_and_direct_engine(dev, shape):
     want = R.decon_fft(vol.cpu().numpy(), psf, shape, 4, skip_edgetaper=True)
     assert _rel(a.cpu().numpy(), b.cpu().numpy()) < 1e-5
     assert _rel(a.cpu().numpy(), c.cpu().numpy()) < 1e-4
-    assert _rel(a.cpu().numpy(), want) < 1e-4
+    assert_close(a.cpu().numpy(), want)
+    assert_close(c.cpu().numpy(), want)
     with pytest.raises(capi.MiError, match="ratio scratch"):
         direct.iterate(c, None, 1)
 
@@ -213,7 +215,7 @@ def test_real_otf_form_for_symmetric_psfs(dev, shape, flavour, monkeypatch):
     assert bytes_s == bytes_c
     want = (R.decon_fft(vol.cpu().numpy(), psf, shape, 3, skip_edgetaper=True) if flavour == "circular"
             else R.decon_spatial(vol.cpu().numpy(), psf, 3, skip_edgetaper=True))
-    assert _rel(got_r, want) < 1e-4
+    assert_close(got_r, want)
 
 
 def _random_cases(n=int(__import__("os").environ.get("MI_TEST_SWEEP", "14")), seed=int(__import__("os").environ.get("MI_TEST_SWEEP_SEED", "2026"))):

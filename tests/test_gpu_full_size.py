@@ -61,29 +61,95 @@ def test_rl_full_size_properties(dev, workload):
         assert float((a - b).abs().max()) <= 1e-4 * float(a.abs().max())
 
 
-def test_c4_shaped_slab_rank(dev):
-    """One rank of BASELINE config 4 (4096 x 4096 x 1024 over 8 GPUs, 63 x 63 x 127 PSF): local extent 512 + 2 x 32 halo
-    rows -> 576 = 9 * 64 (radix-9 stage).  Flux conservation is a property of the whole ring, so only the interior
-    response to an impulse is checked here."""
-    from ipp_amd import capi, decon, slab
+C4_G, C4_K = (1024, 4096, 4096), (127, 63, 63)
+
+
+def _c4_rank_geometry():
+    from ipp_amd import capi, slab
+    sy = slab.psf_shift(C4_G[1], C4_K[1], "fft")
+    h = max(sy, C4_K[1] - 1 - sy)
+    rows = capi.lib().mi_fft_good_size(C4_G[1] // 8 + 2 * h, 1)
+    assert rows == 576 and h == 32                      # 512 interior + 2 x 32 halo rows -> 576 = 9 * 64 (radix-9 stage)
+    shifts = (slab.psf_shift(C4_G[2], C4_K[2], "fft"), sy, slab.psf_shift(C4_G[0], C4_K[0], "fft"))
+    return (C4_G[0], rows, C4_G[2]), shifts, h
+
+
+def test_c4_shaped_slab_rank_impulse_forward_and_adjoint(dev):
+    """One rank of BASELINE config 4 (4096 x 4096 x 1024 over 8 GPUs, 63 x 63 x 127 PSF): forward impulse response == PSF at
+    deconFFT's placement, adjoint impulse response == mirrored PSF (decon.m:131-133,162-172)."""
     import bench
-    gshape, kshape = (1024, 4096, 4096), (127, 63, 63)
-    psf = bench.make_psf(kshape)
-    sy = slab.psf_shift(gshape[1], kshape[1], "fft")
-    h = max(sy, kshape[1] - 1 - sy)
-    rows = capi.lib().mi_fft_good_size(gshape[1] // 8 + 2 * h, 1)
-    assert rows == 576
-    shape = (gshape[0], rows, gshape[2])
-    shifts = (slab.psf_shift(gshape[2], kshape[2], "fft"), sy, slab.psf_shift(gshape[0], kshape[0], "fft"))
+    from ipp_amd import capi, decon
+    shape, shifts, h = _c4_rank_geometry()
+    psf = bench.make_psf(C4_K)
     ctx = decon.RLContext(shape, psf, None, boundary=(2, 2, 2), engine=capi.ENGINE_FFT, device=dev, shift_xyz=shifts)
     assert ctx.engine == capi.ENGINE_FFT
-    at = (100, h + 50, 77)
-    bl = torch.zeros(shape, device=dev)
-    bl[at] = 1.0
-    ratio = torch.empty_like(bl)
-    ctx.forward_ratio(bl, ratio)
-    want = float(psf[shifts[2], shifts[1], shifts[0]])
-    assert 1.0 / float(ratio[at]) == pytest.approx(want, rel=2e-4)
+    # _impulse_response_check derives the shifts from the array shape; the rank-local y extent (576) gives the same y shift (32)
+    assert [n // 2 - (n - k) // 2 for n, k in zip(shape, psf.shape)] == [shifts[2], shifts[1], shifts[0]]
+    _impulse_response_check(ctx, shape, psf, dev, (100, h + 50, 77))
+
+
+def test_c4_shaped_slab_rank_fused_iterations(dev):
+    """Two fused iterations on a ring-closed single slab of a C4 rank's local shape (1024 x 576 x 4096: 512 interior rows + 2 x 32
+    halo rows, x-transformed halo rows wrap around onto the slab itself): flux conservation and non-negativity -- properties of
+    the whole ring, which one slab closes on itself."""
+    import bench
+    from ipp_amd import slab
+    psf = bench.make_psf(C4_K)
+    drv = slab.SlabRL((C4_G[0], C4_G[1] // 8, C4_G[2]), psf, rank=0, world_size=1, device=dev, flavour="fft", engine=2, seed=7)
+    assert drv.lshape == (1024, 576, 4096) and drv.h == 32 and drv.sharded
+    s0 = float(drv.interior().double().sum())
+    m0 = float(drv.interior().max())
+    drv.run(2)
+    out = drv.interior()
+    assert float(out.min()) >= 0.0 and bool(torch.isfinite(out).all())
+    assert abs(float(out.double().sum()) - s0) / s0 < 1e-4
+    assert float(out.max()) > m0                         # beads sharpen
+
+
+def test_c4_shaped_slab_rank_edgetaper(dev):
+    """edgetaper_3d (edgetaper_3d.m:13-44) with the 63 x 63 x 127 PSF on an array of a C4 rank's shape.  The volume is
+    a(z) + b(y) + c(x), so the replicate-boundary blur is the sum of three 1-D blurs with the PSF's marginals and every
+    voxel of the result is known in closed form (float64) -- checked on whole lines through the shell and the interior."""
+    import bench
+    from ipp_amd import decon
+    shape, _, _ = _c4_rank_geometry()
+    psf = bench.make_psf(C4_K)
+    nz, ny, nx = shape
+    rng = np.random.default_rng(11)
+    comp = [0.2 + 0.1 * np.sin(np.arange(n) * w) + 0.05 * rng.random(n) for n, w in zip(shape, (0.05, 0.11, 0.013))]
+    a, b, c = (torch.from_numpy(v.astype(np.float32)).to(dev) for v in comp)
+    vol = (a[:, None, None] + b[None, :, None]) + c[None, None, :]
+    vol_in = {}
+    lines = [(0, 5, 9), (0, 300, 2000), (1, 3, 4090), (1, 512, 1000), (2, 2, 2), (2, 1020, 570), (2, 500, 288)]  # (axis, i, j)
+    def take(t, ax, i, j):
+        return (t[:, i, j] if ax == 0 else t[i, :, j] if ax == 1 else t[i, j, :]).cpu().numpy().astype(np.float64)
+    for ln in lines:
+        vol_in[ln] = take(vol, *ln)
+    out = decon.edgetaper_3d(vol, torch.from_numpy(psf).to(dev))
+    pn = psf.astype(np.float64) / float(psf.astype(np.float32).sum(dtype=np.float32))
+    marg = [pn.sum(axis=(1, 2)), pn.sum(axis=(0, 2)), pn.sum(axis=(0, 1))]
+    comp32 = [v.astype(np.float32).astype(np.float64) for v in comp]
+    blur1 = []
+    for v, m in zip(comp32, marg):                       # conv3d_gpu.cu:77-98 along one axis: centre k/2, clamped index
+        k = m.size
+        idx = np.clip(np.arange(v.size)[:, None] + (k // 2) - np.arange(k)[None, :], 0, v.size - 1)
+        blur1.append((v[idx] * m[None, :]).sum(axis=1))
+    tz, ty, tx = R.edgetaper_mask_vectors(shape, psf.shape)
+    for ax, i, j in lines:
+        if ax == 0:
+            blur = blur1[0] + blur1[1][i] + blur1[2][j]; mask = tz.astype(np.float64) * float(ty[i]) * float(tx[j])
+        elif ax == 1:
+            blur = blur1[0][i] + blur1[1] + blur1[2][j]; mask = float(tz[i]) * ty.astype(np.float64) * float(tx[j])
+        else:
+            blur = blur1[0][i] + blur1[1][j] + blur1[2]; mask = float(tz[i]) * float(ty[j]) * tx.astype(np.float64)
+        want = mask * vol_in[(ax, i, j)] + (1.0 - mask) * blur
+        got = take(out, ax, i, j)
+        assert np.abs(got - want).max() < 1e-5, (ax, i, j, float(np.abs(got - want).max()))   # edgetaper_3d_test.m:4,40
+    # where the mask is exactly one the block is untouched
+    zi, yi, xi = 500, 288, 2000
+    assert tz[zi] == 1 and ty[yi] == 1 and tx[xi] == 1
+    core = out[zi, yi, 1000:3000].cpu().numpy().astype(np.float64)
+    assert np.array_equal(core, vol_in[(2, 500, 288)][1000:3000])
 
 
 def test_ncc_full_size_pair_vs_oracle(dev):

@@ -1,11 +1,13 @@
 """GPU parity: the HIP Richardson-Lucy path (through the C ABI) against the CPU oracle on the same seeded inputs.
-Tolerance for floating point: 1e-4 relative to the array maximum (BASELINE.json north_star), tighter where
-the reference's own scripts use a tighter bound."""
+Tolerance for floating point (BASELINE.json north_star: 1e-4 relative): tests/rl_util.py:assert_close -- 1e-4 of the
+maximum AND relative L2 < 1e-5 AND point-wise |d| <= 1e-4 |want| + 1e-7; tighter where the reference's own scripts
+use a tighter bound.  The unstable Wiener variant keeps the max-relative metric (see below)."""
 import numpy as np
 import pytest
 import torch
 
 from oracle import rl_oracle as R
+from tests.rl_util import assert_close
 
 pytestmark = pytest.mark.gpu
 
@@ -155,7 +157,7 @@ def test_decon_spatial_matches_oracle(dev, engine, niter, lam, interval):
     want = R.decon_spatial(vol, psf, niter, lam, 0.0, interval)
     got = decon.decon(_t(vol, dev), decon.make_psf_struct(psf), niter, lam, 0.0, interval, 1, False, None, False,
                       engine=engine).cpu().numpy()
-    assert _rel(got, want) < REL
+    assert_close(got, want)
 
 
 @pytest.mark.parametrize("F_xyz", [None, (48, 40, 24)])
@@ -167,7 +169,8 @@ def test_decon_fft_matches_oracle(dev, F_xyz, niter, lam, interval):
     want = R.decon_fft(vol, psf, Fz, niter, lam, 0.0, interval)
     got = decon.decon(_t(vol, dev), psf, niter, lam, 0.0, interval, 1, True,
                       F_xyz if F_xyz is not None else (vol.shape[2], vol.shape[1], vol.shape[0]), False).cpu().numpy()
-    assert got.shape == vol.shape and _rel(got, want) < REL
+    assert got.shape == vol.shape
+    assert_close(got, want)
 
 
 # deconFFT_Wiener cuts the new PSF out of the far field of a spectral quotient (F{Y} conj F{X} / |F{X}|^2): the update is
@@ -245,7 +248,9 @@ def test_decon_fft_semantics_on_direct_engine(dev):
     F = (vol.shape[2], vol.shape[1], vol.shape[0])
     a = decon.decon(_t(vol, dev), psf, 4, 0.0, 0.0, 0, 1, True, F, False, engine=1).cpu().numpy()
     b = decon.decon(_t(vol, dev), psf, 4, 0.0, 0.0, 0, 1, True, F, False, engine=2).cpu().numpy()
-    assert _rel(a, b) < REL and _rel(a, R.decon_fft(vol, psf, vol.shape, 4)) < REL
+    assert _rel(a, b) < REL
+    assert_close(a, R.decon_fft(vol, psf, vol.shape, 4))
+    assert_close(b, R.decon_fft(vol, psf, vol.shape, 4))
 
 
 def test_decon_stop_criterion_and_numpy_roundtrip(dev):
@@ -253,7 +258,8 @@ def test_decon_stop_criterion_and_numpy_roundtrip(dev):
     vol, psf = _case((12, 16, 16), (5, 5, 5), (1, 1, 1), 4)
     want, it_want = R.decon_spatial(vol, psf, 50, stop_criterion=5.0, return_iters=True)
     got, it = decon.decon(vol, psf, 50, 0.0, 5.0, 0, 1, False, None, False, return_iters=True)
-    assert isinstance(got, np.ndarray) and it == it_want and _rel(got, want) < REL
+    assert isinstance(got, np.ndarray) and it == it_want
+    assert_close(got, want)
 
 
 def test_decon_config1_shape_parity(dev):
@@ -264,7 +270,7 @@ def test_decon_config1_shape_parity(dev):
     want = R.decon_spatial(vol, psf, 10, 0.0, 0.0, 3)
     for engine in (1, 2):
         got = decon.decon(_t(vol, dev), psf, 10, 0.0, 0.0, 3, 1, False, None, False, engine=engine).cpu().numpy()
-        assert _rel(got, want) < REL
+        assert_close(got, want)
 
 
 def test_decon_errors(dev):

@@ -7,6 +7,7 @@ import pytest
 import torch
 
 from oracle import rl_oracle as R
+from tests.rl_util import assert_close
 from tests.slab_util import lockstep_iterate
 
 pytestmark = pytest.mark.gpu
@@ -34,7 +35,8 @@ def test_lockstep_slabs_on_gpu(dev, flavour, engine, world):
         want = R.decon_spatial(vol, psf, 3, skip_edgetaper=True)
         single = decon.decon(torch.from_numpy(vol).to(dev), psf, 3, 0, 0, 0, 1, False, None, False, skip_edgetaper=True,
                              engine=engine).cpu().numpy()
-    assert _rel(got, want) < 1e-4 and _rel(got, single) < 2e-5
+    assert_close(got, want)
+    assert _rel(got, single) < 2e-5
 
 
 @pytest.mark.parametrize("gshape,kshape,world", [((16, 200, 64), (3, 9, 5), 3), ((32, 96, 32), (5, 5, 7), 2), ((16, 330, 32), (7, 11, 3), 5)])
@@ -52,7 +54,7 @@ def test_lockstep_slabs_uneven_rows_fused_pipeline(dev, gshape, kshape, world, f
     got = lockstep_iterate(slabs, 3).cpu().numpy()
     want = (R.decon_fft(vol, psf, vol.shape, 3, skip_edgetaper=True) if flavour == "fft"
             else R.decon_spatial(vol, psf, 3, skip_edgetaper=True))
-    assert _rel(got, want) < 1e-4
+    assert_close(got, want)
 
 
 @pytest.mark.parametrize("flavour", ["fft", "spatial"])
@@ -76,11 +78,11 @@ def test_lockstep_slabs_fused_pipeline_spectrum_halos(dev, flavour, world, monke
         want = R.decon_fft(vol, psf, vol.shape, 4, skip_edgetaper=True)
     else:
         want = R.decon_spatial(vol, psf, 4, skip_edgetaper=True)
-    assert _rel(got, want) < 1e-4
+    assert_close(got, want)
     # the driver's own iterate() on a single self-ring slab goes through the same protocol
     one = slab.SlabRL(vol.shape, psf, rank=0, world_size=1, device=dev, flavour=flavour, engine=2, volume=vol)
     one.run(4)
-    assert _rel(one.interior().cpu().numpy(), want) < 1e-4
+    assert_close(one.interior().cpu().numpy(), want)
 
 
 def test_spectrum_rows_pack_unpack(dev):

@@ -194,3 +194,13 @@ def test_rescale_block_literal_values():
     assert R.rescale_block(x, 255, 1.0, 0.0, 1.0, np.uint8).tolist() == [0, 127, 254, 255, 0]
     # dmin = 0.5, dmax = 1.5: (val - 0.5) * 65535 - 1
     assert R.rescale_block(x, 65535, 1.0, 0.5, 1.5, np.uint16).tolist() == [0, 0, 32767, 65535, 0]
+
+
+def test_float32_timing_leg_equals_decon_fft():
+    # bench.py's cpu_baseline times decon_fft_f32 (scipy.fft, complex64, all cores): same loop as decon_fft
+    psf = R.gaussian_psf((7, 5, 5), (1.5, 1.0, 1.0))
+    psf = (psf * np.linspace(0.5, 1.5, psf.shape[2])[None, None, :]).astype(np.float32)   # asymmetric on purpose
+    vol = R.bead_volume((20, 36, 44), seed=3, psf=psf)
+    want = R.decon_fft(vol, psf, vol.shape, 4, skip_edgetaper=True)
+    got = R.decon_fft_f32(vol, R.otf_half_f32(psf, vol.shape, workers=2), 4, workers=2)
+    assert got.dtype == np.float32 and np.abs(got - want).max() <= 1e-4 * np.abs(want).max()
