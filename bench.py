@@ -71,13 +71,26 @@ def pmc_traffic(pass_name, workload):
     return None
 
 
+def host_cores():
+    """Host cores this process may use: the affinity mask, capped by the cgroup CPU quota when one is set."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(vshape, kshape, seconds_budget=20.0):
     """The oracle's deconFFT loop (oracle/rl_oracle.py:decon_fft_f32 -- scipy.fft, float32 / complex64, every host core)
     on a bounded sub-volume of the same workload: 1/8 of the volume (every extent halved) when one iteration fits the
     budget, else 1/64 (every extent quartered) for as many iterations as fit."""
     import numpy as np
     from oracle import rl_oracle
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     psf = make_psf(kshape)
     rng = np.random.default_rng(1234)
 

@@ -57,6 +57,12 @@ static int default_shift(int n, int k, int boundary) {
     return k - 1 - conv_kernel_offset(k, boundary);
 }
 
+// psf(end:-1:1,end:-1:1,end:-1:1) of a contiguous array = its samples in reverse linear order (LsDeconv.m:163)
+__global__ void k_reverse(const float* __restrict__ in, float* __restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[n - 1 - i];
+}
+
 static int rl_create(int dev, void* stream, int nx, int ny, int nz, const float* psf, const float* psf_inv, int kx, int ky, int kz,
                      const int* boundary_xyz, const int* shift_xyz, int engine, bool fixed_psf, mi_rl_ctx** out) {
     MI_TRY(use_device(dev));
@@ -79,6 +85,29 @@ static int rl_create(int dev, void* stream, int nx, int ny, int nz, const float*
     if (engine == MI_ENGINE_AUTO) engine = mi_engine_select(nx, ny, nz, kx, ky, kz, uniform ? boundary_xyz[0] : MI_BOUNDARY_ZERO);
     MI_REQUIRE(engine == MI_ENGINE_DIRECT || engine == MI_ENGINE_FFT, "mi_rl_create: engine %d not available", engine);
     hipStream_t s = as_stream(stream);
+    // psf_inv == NULL stands for the flipped PSF of LsDeconv.m:163, which decon.m:64 convolves with convn(., 'same'): the same
+    // centre as the forward convolution.  On a circular axis (deconFFT: conj(otf), decon.m:168) and on every axis whose placement
+    // is mirror-symmetric (k - 1 - shift == shift: odd extents, centred) that is the transpose of the forward operator, which both
+    // engines get for free; on a non-circular axis of EVEN extent it is one sample off the transpose, so the flipped kernel is
+    // materialised and takes the explicit-psf_inv path.
+    DevBuf flipped;
+    if (!psf_inv) {
+        bool off_transpose = false, circular_skew = false;
+        for (int d = 0; d < 3; ++d) {
+            const bool skew = (k[d] - 1 - shift[d]) != shift[d];
+            off_transpose = off_transpose || (skew && boundary_xyz[d] != MI_BOUNDARY_CIRCULAR);
+            circular_skew = circular_skew || (skew && boundary_xyz[d] == MI_BOUNDARY_CIRCULAR);
+        }
+        if (off_transpose) {
+            MI_REQUIRE(!circular_skew, "mi_rl_create: psf_inv == NULL is ambiguous for even PSF extents on a mix of circular and "
+                                       "non-circular axes; pass the adjoint kernel explicitly");
+            const int nk = kx * ky * kz;
+            MI_TRY(flipped.alloc(sizeof(float) * (size_t)nk));
+            k_reverse<<<cdiv(nk, 256), 256, 0, s>>>(psf, flipped.as<float>(), nk);
+            MI_TRY(launch_check("k_reverse"));
+            psf_inv = flipped.as<float>();
+        }
+    }
     mi_rl_ctx* c = new (std::nothrow) mi_rl_ctx;
     if (!c) return fail(MI_ERR_NOMEM, "mi_rl_create: out of host memory");
     c->dev = dev;

@@ -56,9 +56,9 @@ class HipOps:
         capi.require_gpu()
         self.device = torch.device(device)
 
-    def make_ctx(self, local_shape_zyx, psf, boundary_xyz, shift_xyz, engine):
+    def make_ctx(self, local_shape_zyx, psf, boundary_xyz, shift_xyz, engine, psf_inv=None):
         from .decon import RLContext
-        return RLContext(local_shape_zyx, psf, None, boundary=boundary_xyz, engine=engine, device=self.device,
+        return RLContext(local_shape_zyx, psf, psf_inv, boundary=boundary_xyz, engine=engine, device=self.device,
                          shift_xyz=shift_xyz)
 
     def pack(self, vol, y0, rows):
@@ -110,7 +110,12 @@ class SlabRL:
         boundary_xyz = (bxz, BOUNDARY_CIRCULAR, bxz)
         shift_xyz = (psf_shift(gx, kx, flavour), sy, psf_shift(gz, kz, flavour))
         self.lshape = (gz, self.rows, gx)
-        self.ctx = self.ops.make_ctx(self.lshape, self.psf, boundary_xyz, shift_xyz, engine)
+        # deconSpatial convolves with psf.inv = the flipped PSF (LsDeconv.m:163, decon.m:64); for even extents that is not the
+        # transpose of the forward operator, and the sharded axis only LOOKS circular to the context: hand the kernel over
+        inv = None
+        if flavour == "spatial" and any(k % 2 == 0 for k in self.psf.shape):
+            inv = np.ascontiguousarray(self.psf[::-1, ::-1, ::-1])
+        self.ctx = self.ops.make_ctx(self.lshape, self.psf, boundary_xyz, shift_xyz, engine, inv)
         self.bl = torch.zeros(self.lshape, dtype=torch.float32, device=self.device)
         # fused pipeline: halos travel as x-transformed rows, no ratio volume exists
         self.sharded = bool(getattr(self.ctx, "fuses", 0))

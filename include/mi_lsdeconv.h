@@ -100,7 +100,9 @@ typedef struct mi_rl_ctx mi_rl_ctx;
 
 /* Prepares PSF-derived constants for arrays of shape (nz, ny, nx): flipped/padded PSF for the direct
  * engines, OTF + rocFFT plans + padded work buffers for the FFT engine (all owned by the context).
- * psf_inv may be NULL (= psf flipped in all axes, LsDeconv.m:163).  Synchronises. */
+ * psf_inv may be NULL (= psf flipped in all axes, LsDeconv.m:163, convolved like decon.m:64 does: with convn 'same', so for even
+ * extents under a non-circular rule it is NOT the transpose of the forward operator; the circular rule uses conj(otf),
+ * decon.m:168).  Synchronises. */
 int mi_rl_create(int dev, void* stream, int nx, int ny, int nz, const float* psf, const float* psf_inv,
                  int kx, int ky, int kz, int boundary, int engine, mi_rl_ctx** ctx);
 /* Same with one boundary rule per axis {x, y, z} and an explicit PSF placement per axis: sample j of the

@@ -29,15 +29,22 @@ EPS_SINGLE = np.float32(2.0 ** -23)  # eps('single'), decon.m:62,154
 # --------------------------------------------------------------------------- convolutions
 def convn_same(a: np.ndarray, h: np.ndarray) -> np.ndarray:
     """MATLAB ``convn(a, h, 'same')``: true convolution, zero outside, central part
-    (decon.m:61,64,70).  Computed in float64 and rounded once to float32."""
+    (decon.m:61,64,70): ``full[ceil((k-1)/2) : ...]``, i.e. centre ``k/2`` (integer division) also for
+    even extents -- ndimage's convention (tests/test_oracle_rl.py checks it against the full
+    convolution).  Computed in float64 and rounded once to float32."""
     out = ndimage.convolve(a.astype(np.float64), h.astype(np.float64), mode="constant", cval=0.0)
     return out.astype(np.float32)
 
 
 def conv3d_replicate(a: np.ndarray, h: np.ndarray) -> np.ndarray:
     """``conv3d_gpu(a, h)``: same-size true convolution with the input index clamped
-    to the array (conv3d_gpu.cu:77-98: centre k/2, clamp, flipped kernel index)."""
-    out = ndimage.convolve(a.astype(np.float64), h.astype(np.float64), mode="nearest")
+    to the array (conv3d_gpu.cu:77-98: offset ``d - k/2`` paired with the flipped kernel
+    index ``k-1-d``, i.e. kernel sample m reads ``a[n + (k-1-k/2) - m]``: centre
+    ``(k-1)/2`` -- for EVEN extents one sample before convn's 'same' centre ``k/2``,
+    which is what ndimage uses; ``origin=-1`` on even axes moves it there, pinned by
+    :func:`conv3d_replicate_loops`)."""
+    origin = [-1 if k % 2 == 0 else 0 for k in h.shape]
+    out = ndimage.convolve(a.astype(np.float64), h.astype(np.float64), mode="nearest", origin=origin)
     return out.astype(np.float32)
 
 

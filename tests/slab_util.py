@@ -11,7 +11,7 @@ class NumpyCtx:
     product's kernels and of oracle/rl_oracle.py's loops)."""
     engine = -1
 
-    def __init__(self, lshape, psf, boundary_xyz, shift_xyz):
+    def __init__(self, lshape, psf, boundary_xyz, shift_xyz, psf_inv=None):
         self.n = tuple(lshape)
         k = psf.shape
         bnd = boundary_xyz[::-1]   # -> (z, y, x)
@@ -22,10 +22,15 @@ class NumpyCtx:
         img[:k[0], :k[1], :k[2]] = psf
         img = np.roll(img, [-s for s in shift], axis=(0, 1, 2))
         self.otf = np.fft.fftn(img)
+        self.otf_adj = self.otf.conj()
+        if psf_inv is not None:            # an explicit adjoint kernel: an ordinary convolution at the forward placement
+            img = np.zeros(F, np.float64)
+            img[:k[0], :k[1], :k[2]] = psf_inv
+            self.otf_adj = np.fft.fftn(np.roll(img, [-s for s in shift], axis=(0, 1, 2)))
 
     def _conv(self, a, adjoint):
         p = np.pad(a.astype(np.float64), [(q, q) for q in self.pad])
-        o = self.otf.conj() if adjoint else self.otf
+        o = self.otf_adj if adjoint else self.otf
         c = np.real(np.fft.ifftn(np.fft.fftn(p) * o))
         sl = tuple(slice(q, q + n) for q, n in zip(self.pad, self.n))
         return c[sl].astype(np.float32)
@@ -38,7 +43,7 @@ class NumpyCtx:
         self.S = np.fft.fft(np.pad(a.astype(np.float64), [(q, q) for q in self.pad]), axis=2)
 
     def _conv_S(self, adjoint):
-        o = self.otf.conj() if adjoint else self.otf
+        o = self.otf_adj if adjoint else self.otf
         c = np.real(np.fft.ifftn(np.fft.fft2(self.S, axes=(0, 1)) * o))
         sl = tuple(slice(q, q + n) for q, n in zip(self.pad, self.n))
         return c[sl].astype(np.float32)
@@ -82,8 +87,8 @@ class NumpyOps:
     def __init__(self, fuses=0):
         self.fuses = int(fuses)
 
-    def make_ctx(self, lshape, psf, boundary_xyz, shift_xyz, engine):
-        ctx = NumpyCtx(lshape, psf, boundary_xyz, shift_xyz)
+    def make_ctx(self, lshape, psf, boundary_xyz, shift_xyz, engine, psf_inv=None):
+        ctx = NumpyCtx(lshape, psf, boundary_xyz, shift_xyz, psf_inv)
         ctx.fuses = self.fuses
         return ctx
 

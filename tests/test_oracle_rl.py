@@ -204,3 +204,19 @@ def test_float32_timing_leg_equals_decon_fft():
     want = R.decon_fft(vol, psf, vol.shape, 4, skip_edgetaper=True)
     got = R.decon_fft_f32(vol, R.otf_half_f32(psf, vol.shape, workers=2), 4, workers=2)
     assert got.dtype == np.float32 and np.abs(got - want).max() <= 1e-4 * np.abs(want).max()
+
+
+def test_even_kernel_centres():
+    # convn(a, h, 'same') = full[ceil((k-1)/2):...] -> centre k/2; conv3d_gpu.cu:77-98 -> centre (k-1)/2 (literal loops)
+    from scipy import signal
+    rng = np.random.default_rng(0)
+    a = rng.random((6, 7, 9)).astype(np.float32)
+    h = rng.random((4, 2, 6)).astype(np.float32)
+    full = signal.convolve(a.astype(np.float64), h.astype(np.float64), "full")
+    c = [k // 2 for k in h.shape]
+    same = full[c[0]:c[0] + 6, c[1]:c[1] + 7, c[2]:c[2] + 9]
+    assert np.abs(R.convn_same(a, h) - same).max() < 1e-5
+    assert np.array_equal(np.convolve([1., 2, 3, 4], [1., 1])[1:5], [3., 5, 7, 4])   # MATLAB: conv([1 2 3 4],[1 1],'same')
+    assert np.abs(R.conv3d_replicate(a, h) - R.conv3d_replicate_loops(a, h)).max() < 1e-5
+    h5 = rng.random((3, 5, 4)).astype(np.float32)
+    assert np.abs(R.conv3d_replicate(a, h5) - R.conv3d_replicate_loops(a, h5)).max() < 1e-5

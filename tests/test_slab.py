@@ -86,3 +86,20 @@ def test_slab_rows_and_halo_rules():
     vol, psf = _case(shape=(6, 16, 8), kshape=(3, 9, 3))
     with pytest.raises(ValueError, match="thinner than the halo"):
         slab.SlabRL(vol.shape, psf, rank=0, world_size=4, flavour="fft", volume=vol, ops=NumpyOps())
+
+
+@pytest.mark.parametrize("flavour", ["fft", "spatial"])
+@pytest.mark.parametrize("kshape", [(5, 7, 3), (4, 6, 2)])
+@pytest.mark.parametrize("fuses", [0, 2], ids=["real_halos", "spectrum_halos_overlapped"])
+def test_lockstep_slabs_asymmetric_psf(flavour, kshape, fuses):
+    """Asymmetric PSFs (odd and even extents): the halo widths of the forward and the adjoint convolution differ and, for the
+    spatial flavour with even extents, the adjoint kernel is the flipped PSF at convn's 'same' centre, not the transpose."""
+    from ipp_amd import slab
+    from tests.rl_util import asymmetric_psf
+    psf = asymmetric_psf(kshape, seed=4)
+    vol = R.bead_volume((9, 44, 16), seed=8, psf=R.gaussian_psf((3, 3, 3), (1, 1, 1)))
+    slabs = [slab.SlabRL(vol.shape, psf, rank=r, world_size=3, flavour=flavour, volume=vol, ops=NumpyOps(fuses)) for r in range(3)]
+    got = lockstep_iterate(slabs, 3).numpy()
+    want = (R.decon_fft(vol, psf, vol.shape, 3, skip_edgetaper=True) if flavour == "fft"
+            else R.decon_spatial(vol, psf, 3, skip_edgetaper=True))
+    assert _rel(got, want) < 2e-5
