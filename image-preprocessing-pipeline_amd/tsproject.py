@@ -142,10 +142,14 @@ class Project:
 
     def getStacksHeight(self): return self._stack_dims()[0]
     def getStacksWidth(self): return self._stack_dims()[1]
-    def getOVERLAP_V(self): return int(self.getStacksHeight() - self.MEC_V / self.VXL_V)
-    def getOVERLAP_H(self): return int(self.getStacksWidth() - self.MEC_H / self.VXL_H)
-    def getDEFAULT_DISPLACEMENT_V(self): return int(abs(self.MEC_V / self.VXL_V))
-    def getDEFAULT_DISPLACEMENT_H(self): return int(abs(self.MEC_H / self.VXL_H))
+    # MEC / VXL are float members and the quotient is a single-precision division (57.6f / 0.8f == 72.0f, while the same
+    # quotient in double is 71.99999999999999 and truncates to 71) -- pinned by tests/golden/terastitcher (the reference binary)
+    @staticmethod
+    def _fdiv(a, b): return np.float32(a) / np.float32(b)
+    def getOVERLAP_V(self): return int(np.float32(self.getStacksHeight()) - self._fdiv(self.MEC_V, self.VXL_V))
+    def getOVERLAP_H(self): return int(np.float32(self.getStacksWidth()) - self._fdiv(self.MEC_H, self.VXL_H))
+    def getDEFAULT_DISPLACEMENT_V(self): return int(abs(self._fdiv(self.MEC_V, self.VXL_V)))
+    def getDEFAULT_DISPLACEMENT_H(self): return int(abs(self._fdiv(self.MEC_H, self.VXL_H)))
     def getDEFAULT_DISPLACEMENT_D(self): return 0
 
     # ---- files

@@ -144,3 +144,14 @@ def test_merge_of_partial_projects(tmp_path):
     a.mergeDisplacements(b)
     assert [d.VHD_coords for d in a.STACKS[0][0].EAST] == [[0, 26, 0], [1, 27, 0]] and len(a.STACKS[0][1].WEST) == 2
     assert a.STACKS[1][1].WEST[0].VHD_coords == [0, -25, -1]
+
+
+def test_default_displacement_is_a_single_precision_quotient():
+    # vmVirtualVolume.cpp:75-79 on float members: 57.6f / 0.8f = 72 (the double quotient truncates to 71); the reference
+    # binary wrote default_displ="72" for this geometry (tests/golden/terastitcher/xml_displcomp.xml)
+    import os
+    from ipp_amd import tsproject
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "terastitcher", "xml_import.xml")
+    p = tsproject.Project.load(gold)
+    assert (p.MEC_V, p.MEC_H) == pytest.approx((51.2, 57.6), rel=1e-6)
+    assert p.getDEFAULT_DISPLACEMENT_V() == 64 and p.getDEFAULT_DISPLACEMENT_H() == 72
