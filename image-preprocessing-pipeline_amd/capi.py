@@ -111,6 +111,7 @@ SIGNATURES = {
                                C.POINTER(NccParams), C.POINTER(NccDescr)]),
     "mi_ncc_compute_mips": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i] + [_vp] * 6),
     "mi_ncc_compute_map": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "mi_ncc_compute_map_lag": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
 }
 
 _lib = None

@@ -328,13 +328,15 @@ def compute_mips(A, B, ni, nj, side):
     return outs
 
 
-def compute_NCC_map(MIP_1, MIP_2, delayu, delayv):
-    """compute_NCC_map (compute_funcs.cu:939): (2*delayu+1, 2*delayv+1) float32 CUDA tensor."""
+def compute_NCC_map(MIP_1, MIP_2, delayu, delayv, lag=False):
+    """compute_NCC_map (compute_funcs.cu:939): (2*delayu+1, 2*delayv+1) float32 CUDA tensor.  ``lag``: cross terms through the
+    lag transform of the batched pair pipeline instead of shift by shift."""
     capi.require_gpu()
     dev = MIP_1.device if isinstance(MIP_1, torch.Tensor) and MIP_1.is_cuda else torch.device("cuda", torch.cuda.current_device())
     m1, m2 = _dev_tensor(MIP_1, dev), _dev_tensor(MIP_2, dev)
     dimu, dimv = (int(s) for s in m1.shape)
     out = torch.empty((2 * delayu + 1, 2 * delayv + 1), dtype=torch.float32, device=dev)
-    check(lib().mi_ncc_compute_map(dev.index, capi.current_stream_ptr(dev), m1.data_ptr(), m2.data_ptr(), dimu, dimv,
-                                   int(delayu), int(delayv), out.data_ptr()))
+    fn = lib().mi_ncc_compute_map_lag if lag else lib().mi_ncc_compute_map
+    check(fn(dev.index, capi.current_stream_ptr(dev), m1.data_ptr(), m2.data_ptr(), dimu, dimv, int(delayu), int(delayv),
+             out.data_ptr()))
     return out

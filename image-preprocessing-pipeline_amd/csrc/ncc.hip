@@ -16,909 +16,10 @@
 //                 "missing entries" of the neighbourhood refinement alike.
 // Host side (this file, plain C++): argmax, neighbourhood refinement, peak widths and the final
 // alignment rules, kept bit-identical in float/int arithmetic to compute_funcs.cu:160-342,1294-1609.
-#include <cmath>
-#include <algorithm>
-#include <cstdlib>
-#include <cstring>
-#include <exception>
-#include <memory>
-#include <mutex>
-#include <new>
-#include <string>
-#include <thread>
-#include <type_traits>
-#include <vector>
+#include <map>
 
-#include "mi_crossmips.h"
-#include "mi_internal.h"
-
-using namespace mi;
-
-namespace {
-
-constexpr int TILE = 32;  // TILE_SIDE, compute_funcs.h:66
-constexpr int MIP_ROWS = 16;
-constexpr int NCC_THREADS = 256;
-
-__device__ __forceinline__ void atomic_max_nonneg(float* addr, float v) {
-    atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
-}
-
-// maximum of a non-negative value over the 64 lanes of a wave, valid in lane 63: DPP moves inside the VALU (quad permutes, row
-// mirrors, row broadcasts) instead of six trips through the LDS crossbar
-__device__ __forceinline__ float wave_max_nonneg(float v) {
-    auto step = [](float x, auto ctrl, auto row_mask) {
-        const int y = __builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, decltype(row_mask)::value, 0xf, false);
-        return fmaxf(x, __int_as_float(y));  // lanes without a source keep 0 = the neutral element
-    };
-    using std::integral_constant;
-    v = step(v, integral_constant<int, 0xB1>{}, integral_constant<int, 0xf>{});   // quad_perm [1,0,3,2]
-    v = step(v, integral_constant<int, 0x4E>{}, integral_constant<int, 0xf>{});   // quad_perm [2,3,0,1]
-    v = step(v, integral_constant<int, 0x141>{}, integral_constant<int, 0xf>{});  // row_half_mirror
-    v = step(v, integral_constant<int, 0x140>{}, integral_constant<int, 0xf>{});  // row_mirror: every lane holds its row's max
-    v = step(v, integral_constant<int, 0x142>{}, integral_constant<int, 0xa>{});  // row_bcast:15 into rows 1 and 3
-    v = step(v, integral_constant<int, 0x143>{}, integral_constant<int, 0xc>{});  // row_bcast:31 into rows 2 and 3
-    return v;
-}
-
-// view(k,i,j) = vol[k*slice + (i+i0)*pitch + (j+j0)], z = 0: A, z = 1: B
-__global__ __launch_bounds__(256) void k_mips(const float* __restrict__ A, const float* __restrict__ B, int dimk, int dimi_v, int dimj_v,
-                                               size_t slice, int pitch, int ai0, int aj0, float* __restrict__ xy1, float* __restrict__ xz1,
-                                               float* __restrict__ yz1, float* __restrict__ xy2, float* __restrict__ xz2,
-                                               float* __restrict__ yz2, float* __restrict__ yz_tmp) {
-    // a work-group owns a 16-row x 64-column patch of the view; its four waves share the slices (wave w: k = w, w + 4, ...),
-    // so a patch keeps four times as many loads in flight as one wave walking all slices
-    __shared__ float comb[3][MIP_ROWS][64];
-    const bool second = blockIdx.z == 1;
-    const float* vol = second ? B : A + (size_t)ai0 * pitch + aj0;
-    float* xy = second ? xy2 : xy1;
-    float* xz = second ? xz2 : xz1;
-    (void)yz1; (void)yz2;  // written by k_mips_yz
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int j = blockIdx.x * 64 + lane;
-    const int i0 = blockIdx.y * MIP_ROWS;
-    const int rows = min(MIP_ROWS, dimi_v - i0);
-    const bool live = j < dimj_v;
-    float best[MIP_ROWS];
-#pragma unroll
-    for (int r = 0; r < MIP_ROWS; ++r) best[r] = 0.0f;
-    for (int k = wave; k < dimk; k += 4) {
-        const float* p = vol + (size_t)k * slice + (size_t)i0 * pitch + j;
-        float v[MIP_ROWS];
-#pragma unroll
-        for (int r = 0; r < MIP_ROWS; ++r) v[r] = (live && r < rows) ? p[(size_t)r * pitch] : 0.0f;
-        float colmax = 0.0f;
-#pragma unroll
-        for (int r = 0; r < MIP_ROWS; ++r) {
-            best[r] = fmaxf(best[r], v[r]);
-            colmax = fmaxf(colmax, v[r]);
-            const float rowmax = wave_max_nonneg(v[r]);  // max over the 64 columns of the patch, in lane 63
-            if (lane == 63 && r < rows) atomic_max_nonneg(&xz[(size_t)(i0 + r) * dimk + k], rowmax);
-        }
-        // yz: the column maxima of this row band go to yz_tmp[tile][band][k][j] (unit-stride stores); k_mips_yz takes the
-        // maximum over the bands -- 2.6 million atomics per pair on the yz MIPs cost more than the whole streaming pass
-        if (live) yz_tmp[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * dimk + k) * dimj_v + j] = colmax;
-    }
-    // xy: maximum over the four waves' slices
-    if (wave > 0) {
-#pragma unroll
-        for (int r = 0; r < MIP_ROWS; ++r) comb[wave - 1][r][lane] = best[r];
-    }
-    __syncthreads();
-    if (wave == 0 && live) {
-#pragma unroll
-        for (int r = 0; r < MIP_ROWS; ++r)
-            if (r < rows) xy[(size_t)(i0 + r) * dimj_v + j] = fmaxf(fmaxf(best[r], comb[0][r][lane]), fmaxf(comb[1][r][lane], comb[2][r][lane]));
-    }
-}
-
-// yz[j][k] = max over the row bands of yz_tmp[tile][band][k][j]; one lane per (k, j), tile = blockIdx.y
-__global__ __launch_bounds__(256) void k_mips_yz(const float* __restrict__ yz_tmp, int bands, int dimk, int dimj_v, float* __restrict__ yz1,
-                                                  float* __restrict__ yz2) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= dimk * dimj_v) return;
-    const int k = e / dimj_v, j = e - k * dimj_v;
-    const float* p = yz_tmp + (size_t)blockIdx.y * bands * dimk * dimj_v + e;
-    float m = 0.0f;
-    for (int b = 0; b < bands; ++b) m = fmaxf(m, p[(size_t)b * dimk * dimj_v]);
-    (blockIdx.y ? yz2 : yz1)[(size_t)j * dimk + k] = m;
-}
-
-// one wave per tile (blockIdx.y = MIP of the plane): the tile is staged in LDS with coalesced loads, then lane 0 adds its 1024
-// pixels in the reference's row-major order with a FLOAT running sum (bit-identical by construction)
-__global__ __launch_bounds__(64) void k_tile_sums(const float* __restrict__ img1, const float* __restrict__ img2, int height, int width,
-                                                  float* __restrict__ ps1, float* __restrict__ ps2) {
-    __shared__ float tile[TILE * TILE];
-    const float* img = blockIdx.y ? img2 : img1;
-    float* ps = blockIdx.y ? ps2 : ps1;
-    const int pw = width / TILE, t = blockIdx.x;
-    const int ti = t / pw, tj = t - ti * pw;
-    const float* p = img + (size_t)ti * TILE * width + tj * TILE;
-    const int lane = threadIdx.x, half = lane >> 5, col = lane & 31;
-#pragma unroll
-    for (int l = 0; l < TILE; l += 2) tile[(l + half) * TILE + col] = p[(size_t)(l + half) * width + col];
-    __syncthreads();
-    if (lane == 0) {
-        float s = 0.0f;
-#pragma unroll 32
-        for (int i = 0; i < TILE * TILE; ++i) s += tile[i];
-        ps[t] = s;
-    }
-}
-
-template <int NT = NCC_THREADS>
-__device__ __forceinline__ double block_sum(double v, double* sh) {
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
-    __syncthreads();
-    double r = 0.0;
-    for (int w = 0; w < NT / 64; ++w) r += sh[w];
-    return r;
-}
-
-// sum of mip over rows [r0,r0+nr) x cols [c0,c0+nc) (per-lane partial): interior tiles from ps, border
-// pixels directly (compute_funcs.cu:1186-1262); falls back to all pixels when ps == nullptr
-// ------------------------------------------------------------------------------------------------ summed-area tables
-// Everything of compute_NCC (compute_funcs.cu:1163-1292) except the cross term  sum f*t  depends on ONE image window:
-//   mean'  = (sum of float tile sums inside the window + border pixels) / n        (the reference's means, :1186-1272)
-//   F      = sum (f - mean')^2 = Q - 2 g' P + n g'^2   with  P = sum (f - c0), Q = sum (f - c0)^2, g' = mean' - c0
-//   num    = sum f (t - tmean') = cross - tmean' * sum f
-// so per MIP three fp64 summed-area tables (P, Q over the pixels shifted by the global mean c0, TS over the float tile sums)
-// give all of them in O(1) per shift, and the NCC kernel only accumulates the cross term.
-struct SatView {
-    const double* P;   // (dimu+1) x (dimv+1): sum of (f - c0)
-    const double* Q;   // same shape: sum of (f - c0)^2
-    const double* TS;  // (ph+1) x (pw+1): sum of the float tile sums (nullptr when the MIP has no full tile)
-    const double* c0;  // global mean of the MIP
-};
-
-__device__ __forceinline__ double rect(const double* __restrict__ S, int w1, int r0, int c0, int nr, int nc) {
-    return S[(size_t)(r0 + nr) * w1 + c0 + nc] - S[(size_t)r0 * w1 + c0 + nc] - S[(size_t)(r0 + nr) * w1 + c0] + S[(size_t)r0 * w1 + c0];
-}
-
-// window statistics of one MIP: mean' (reference flavour), sum f, sum (f - mean')^2
-__device__ void window_stats(const SatView& sv, int dimu, int dimv, int r0, int c0, int nr, int nc, double* mean, double* sumf, double* ssd) {
-    const int w1 = dimv + 1;
-    const double n = (double)nr * (double)nc, cm = *sv.c0;
-    const double P = rect(sv.P, w1, r0, c0, nr, nc), Q = rect(sv.Q, w1, r0, c0, nr, nc);
-    const double sf = P + n * cm;
-    double m = sf / n;
-    if (sv.TS && dimu >= TILE && dimv >= TILE) {
-        int su = (r0 + TILE - 1) / TILE * TILE, tsv = (c0 + TILE - 1) / TILE * TILE;
-        int eu = (r0 + nr) / TILE * TILE, ev = (c0 + nc) / TILE * TILE;
-        if (su < eu && tsv < ev) {
-            const int pw = dimv / TILE;
-            const double tiles = rect(sv.TS, pw + 1, su / TILE, tsv / TILE, (eu - su) / TILE, (ev - tsv) / TILE);
-            const double nreg = (double)(eu - su) * (double)(ev - tsv);
-            const double region = rect(sv.P, w1, su, tsv, eu - su, ev - tsv) + nreg * cm;
-            m = (tiles + (sf - region)) / n;  // float tile sums + border pixels, like the reference
-        }
-    }
-    const double g = m - cm;
-    *mean = m;
-    *sumf = sf;
-    *ssd = Q - 2.0 * g * P + n * g * g;
-}
-
-// pixel sums of both MIPs of a plane in MEAN_PARTS slices each (blockIdx.y = MIP), for the global means
-constexpr int MEAN_PARTS = 64;
-__global__ __launch_bounds__(256) void k_mip_partial(const float* __restrict__ m1, const float* __restrict__ m2, size_t n, double* __restrict__ part) {
-    __shared__ double sh[4];
-    const float* m = blockIdx.y ? m2 : m1;
-    const size_t per = (n + MEAN_PARTS - 1) / MEAN_PARTS, lo = blockIdx.x * per, hi = lo + per < n ? lo + per : n;
-    double acc = 0.0;
-    for (size_t i = lo + threadIdx.x; i < hi; i += 256) acc += (double)m[i];
-    acc = block_sum<256>(acc, sh);
-    if (threadIdx.x == 0) part[blockIdx.y * MEAN_PARTS + blockIdx.x] = acc;
-}
-
-// global mean c0 of each of the two MIPs of a plane (blockIdx.x = 0 / 1) from the slices' sums (fixed order) and the table of
-// its float tile sums
-__global__ __launch_bounds__(1024) void k_mip_mean(const double* __restrict__ part, int dimu, int dimv, const float* __restrict__ ps1,
-                                                   const float* __restrict__ ps2, double* __restrict__ c0a, double* __restrict__ c0b,
-                                                   double* __restrict__ ts1, double* __restrict__ ts2) {
-    const float* ps = blockIdx.x ? ps2 : ps1;
-    double* ts = blockIdx.x ? ts2 : ts1;
-    if (threadIdx.x == 0) {
-        double acc = 0.0;
-        for (int k = 0; k < MEAN_PARTS; ++k) acc += part[blockIdx.x * MEAN_PARTS + k];
-        *(blockIdx.x ? c0b : c0a) = acc / ((double)dimu * (double)dimv);
-    }
-    const int ph = dimu / TILE, pw = dimv / TILE;
-    if (ps && ph * pw > 0) {
-        // (ph+1) x (pw+1) inclusive table; a few hundred entries: one lane per row, then one per column
-        const int w1 = pw + 1;
-        for (int i = threadIdx.x; i < (ph + 1) * w1; i += 1024) ts[i] = 0.0;
-        __syncthreads();
-        for (int r = threadIdx.x; r < ph; r += 1024) {
-            double run = 0.0;
-            for (int c = 0; c < pw; ++c) { run += (double)ps[r * pw + c]; ts[(r + 1) * w1 + c + 1] = run; }
-        }
-        __syncthreads();
-        for (int c = threadIdx.x; c < pw; c += 1024) {
-            double run = 0.0;
-            for (int r = 0; r < ph; ++r) { run += ts[(r + 1) * w1 + c + 1]; ts[(r + 1) * w1 + c + 1] = run; }
-        }
-    }
-}
-
-__device__ __forceinline__ double wave_inclusive_scan(double v) {
-    const int lane = threadIdx.x & 63;
-    for (int off = 1; off < 64; off <<= 1) {
-        const double o = __shfl_up(v, off, 64);
-        if (lane >= off) v += o;
-    }
-    return v;
-}
-
-// row pass: one wave per (row, MIP): P/Q[(i+1)][j+1] = prefix along j of (f - c0), (f - c0)^2; row 0 and column 0 are zero
-__global__ __launch_bounds__(64) void k_sat_rows(const float* __restrict__ m1, const float* __restrict__ m2, int dimu, int dimv,
-                                                 const double* __restrict__ c0a, const double* __restrict__ c0b, double* __restrict__ P1,
-                                                 double* __restrict__ Q1, double* __restrict__ P2, double* __restrict__ Q2) {
-    const float* m = blockIdx.y ? m2 : m1;
-    double* P = blockIdx.y ? P2 : P1;
-    double* Q = blockIdx.y ? Q2 : Q1;
-    const double cm = *(blockIdx.y ? c0b : c0a);
-    const int w1 = dimv + 1, lane = threadIdx.x;
-    const int i = blockIdx.x;  // 0 .. dimu (row i of the table; table row 0 is all zero)
-    if (i == 0) {
-        for (int j = lane; j < w1; j += 64) { P[j] = 0.0; Q[j] = 0.0; }
-        return;
-    }
-    const float* row = m + (size_t)(i - 1) * dimv;
-    double cp = 0.0, cq = 0.0;
-    if (lane == 0) { P[(size_t)i * w1] = 0.0; Q[(size_t)i * w1] = 0.0; }
-    for (int j0 = 0; j0 < dimv; j0 += 64) {
-        const int j = j0 + lane;
-        const double g = j < dimv ? (double)row[j] - cm : 0.0;
-        const double sp = wave_inclusive_scan(g) + cp, sq = wave_inclusive_scan(g * g) + cq;
-        if (j < dimv) { P[(size_t)i * w1 + j + 1] = sp; Q[(size_t)i * w1 + j + 1] = sq; }
-        cp = __shfl(sp, 63, 64);
-        cq = __shfl(sq, 63, 64);
-    }
-}
-
-// column pass, in place: one wave per (column, table): running sum down the rows
-__global__ __launch_bounds__(64) void k_sat_cols(int dimu, int dimv, double* __restrict__ P1, double* __restrict__ Q1, double* __restrict__ P2,
-                                                 double* __restrict__ Q2) {
-    double* S = blockIdx.y == 0 ? P1 : (blockIdx.y == 1 ? Q1 : (blockIdx.y == 2 ? P2 : Q2));
-    const int w1 = dimv + 1, lane = threadIdx.x, j = blockIdx.x + 1;
-    double carry = 0.0;
-    for (int i0 = 1; i0 <= dimu; i0 += 64) {
-        const int i = i0 + lane;
-        const double v = i <= dimu ? S[(size_t)i * w1 + j] : 0.0;
-        const double sc = wave_inclusive_scan(v) + carry;
-        if (i <= dimu) S[(size_t)i * w1 + j] = sc;
-        carry = __shfl(sc, 63, 64);
-    }
-}
-
-// NCC cross terms, register-blocked.  A block is (4 u) x (8 v) shifts; a work-group takes a GROUP of up to 8 blocks that share
-// u0 (a "row" of the shift map), a chunk of m2 rows and a segment of <= 512 m2 columns: wave w owns block w.  The m2 rows and
-// the window of m1 rows all the group's blocks need (columns from the smallest v0 on, zero outside the MIP) are staged in LDS
-// ONCE for the eight blocks with unit-stride loads -- staging, not the fp64 pipe, was the bound when every block staged its
-// own window.  A lane then owns 4 neighbouring m2 columns of a row and, per u, the 11 m1 values its 8 shifts pair them with:
-// thirteen 16-byte LDS reads feed 128 fp64 FMAs (exact fp32 products accumulated in fp64).  Zeros outside the MIP restrict
-// every shift's sum to its own window.  Each wave reduces its own 32 sums (no work-group reduction).  Groups come from the
-// regular grid (full maps: group = u-block, wave = v-block) or from a list (the "missing entries" of the neighbourhood
-// refinement, gpu_NCC_miss).  The chunks' partial sums are added up in a fixed order by k_ncc_finish, which also applies the
-// window statistics from the summed-area tables: deterministic, whatever the launch geometry.  Replaces gpu_NCC_map /
-// gpu_NCC_miss (compute_funcs.cu:730-935).
-constexpr int BU = 4, BV = 8, BC = 4, GW = 8, BLK_THREADS = 64 * GW;
-// groups (list mode): 2 + GW ints each: {u0, number of blocks nb <= GW, v0[0] <= v0[1] <= ... (multiples of BV apart)}
-__global__ __launch_bounds__(BLK_THREADS) void k_ncc_blk(const float* __restrict__ m1, const float* __restrict__ m2, int dimu, int dimv, int du,
-                                                         int dv, int nvb, const int* __restrict__ groups, int n_groups, int rows_per_chunk,
-                                                         int R, int seg_w, int nseg, int pitch1, double* __restrict__ partial) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    int u0, nb, vmin, voff;  // voff: this wave's v0 - vmin
-    if (groups) {
-        const int* g = groups + (size_t)blockIdx.x * (2 + GW);
-        u0 = g[0];
-        nb = g[1];
-        vmin = g[2];
-        voff = g[2 + min(wave, nb - 1)] - vmin;
-    } else {  // group = (u-block, run of GW v-blocks)
-        const int nvg = (nvb + GW - 1) / GW, ub = (int)blockIdx.x / nvg, vg = (int)blockIdx.x - ub * nvg;
-        u0 = ub * BU - du;
-        nb = min(GW, nvb - vg * GW);
-        vmin = vg * GW * BV - dv;
-        voff = min(wave, nb - 1) * BV;
-    }
-    // chunk = (row chunk, column segment of seg_w m2 columns): wide MIPs are cut so that many rows fit one LDS stage
-    const int rc = (int)blockIdx.y / nseg, sg = (int)blockIdx.y - rc * nseg;
-    const int r_begin = rc * rows_per_chunk, r_end = min(dimu, r_begin + rows_per_chunk);
-    const int cbeg = sg * seg_w, cw = min(seg_w, dimv - cbeg);  // m2 columns [cbeg, cbeg + cw)
-    const int quads = (cw + BC - 1) / BC, pitch2 = seg_w;        // seg_w and pitch1 are multiples of BC
-    float* l1 = lds;                            // R + BU - 1 rows of m1: l1[j][x] = m1[rb + u0 + j][cbeg + vmin + x]
-    float* l2 = lds + (R + BU - 1) * pitch1;    // R rows of m2
-    double acc[BU][BV];
-#pragma unroll
-    for (int a = 0; a < BU; ++a)
-#pragma unroll
-        for (int b = 0; b < BV; ++b) acc[a][b] = 0.0;
-    for (int rb = r_begin; rb < r_end; rb += R) {
-        const int nrow = min(R, r_end - rb);
-        __syncthreads();
-        {   // staging: a wave per row (no index division), four independent 64-column loads per lane in flight
-            constexpr int UNR = 4;
-            for (int j = wave; j < nrow + BU - 1; j += GW) {
-                const int r1 = rb + u0 + j;
-                const bool row_ok = r1 >= 0 && r1 < dimu;
-                const float* src = m1 + (size_t)(row_ok ? r1 : 0) * dimv + cbeg + vmin;
-                float* dst = l1 + j * pitch1;
-                for (int x0 = lane; x0 < pitch1; x0 += 64 * UNR) {
-                    float v[UNR];
-#pragma unroll
-                    for (int q = 0; q < UNR; ++q) {
-                        const int x = x0 + 64 * q, c1 = cbeg + vmin + x;
-                        v[q] = (row_ok && x < pitch1 && c1 >= 0 && c1 < dimv) ? src[x] : 0.0f;
-                    }
-#pragma unroll
-                    for (int q = 0; q < UNR; ++q)
-                        if (x0 + 64 * q < pitch1) dst[x0 + 64 * q] = v[q];
-                }
-            }
-            for (int j = wave; j < nrow; j += GW) {
-                const float* src = m2 + (size_t)(rb + j) * dimv + cbeg;
-                float* dst = l2 + j * pitch2;
-                for (int x0 = lane; x0 < pitch2; x0 += 64 * UNR) {
-                    float v[UNR];
-#pragma unroll
-                    for (int q = 0; q < UNR; ++q) v[q] = x0 + 64 * q < cw ? src[x0 + 64 * q] : 0.0f;
-#pragma unroll
-                    for (int q = 0; q < UNR; ++q)
-                        if (x0 + 64 * q < pitch2) dst[x0 + 64 * q] = v[q];
-                }
-            }
-        }
-        __syncthreads();
-        if (wave < nb) {
-            for (int it = lane; it < nrow * quads; it += 64) {
-                const int rr = it / quads, c = (it - rr * quads) * BC;
-                const float4 tq = *reinterpret_cast<const float4*>(l2 + rr * pitch2 + c);
-                const double t[BC] = {(double)tq.x, (double)tq.y, (double)tq.z, (double)tq.w};
-#pragma unroll
-                for (int a = 0; a < BU; ++a) {
-                    const float4* row = reinterpret_cast<const float4*>(l1 + (rr + a) * pitch1 + voff + c);
-                    const float4 f0 = row[0], f1 = row[1], f2 = row[2];
-                    const double f[12] = {(double)f0.x, (double)f0.y, (double)f0.z, (double)f0.w, (double)f1.x, (double)f1.y,
-                                          (double)f1.z, (double)f1.w, (double)f2.x, (double)f2.y, (double)f2.z, (double)f2.w};
-#pragma unroll
-                    for (int b = 0; b < BV; ++b)
-#pragma unroll
-                        for (int x = 0; x < BC; ++x) acc[a][b] = fma(f[x + b], t[x], acc[a][b]);
-                }
-            }
-        }
-    }
-    if (wave >= nb) return;
-    // the wave's own 32 sums: shuffle tree, lane 0 stores
-    double* dst = partial + (((size_t)blockIdx.y * n_groups + blockIdx.x) * GW + wave) * (BU * BV);
-#pragma unroll
-    for (int a = 0; a < BU; ++a)
-#pragma unroll
-        for (int b = 0; b < BV; ++b) {
-            double v = acc[a][b];
-            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-            if (lane == 0) dst[a * BV + b] = v;
-        }
-}
-
-// one lane per requested entry: cross term = sum of the chunks' partials (fixed order), then the NCC value of
-// compute_NCC (compute_funcs.cu:1163-1292).  entries == nullptr: the full (2du+1) x (2dv+1) map in row-major order;
-// else entry e = {u, v, slot in the partials of a chunk ((group * GW + wave) * 32 + a * 8 + b), output slot}
-__global__ __launch_bounds__(256) void k_ncc_finish(const double* __restrict__ partial, int n_chunks, int n_groups,
-                                                    const int* __restrict__ entries, int n_entries, int dimu, int dimv, int du, int dv,
-                                                    SatView s1, SatView s2, float* __restrict__ out) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n_entries) return;
-    int u, v, pidx, slot;
-    if (entries) {
-        u = entries[4 * e];
-        v = entries[4 * e + 1];
-        pidx = entries[4 * e + 2];
-        slot = entries[4 * e + 3];
-    } else {
-        const int W = 2 * dv + 1, iu = e / W, iv = e - iu * W;
-        u = iu - du;
-        v = iv - dv;
-        const int nvb = (W + BV - 1) / BV, slots = (nvb + GW - 1) / GW * GW;  // block slots per u-block: its groups x GW
-        pidx = (((iu / BU) * slots + iv / BV) * BU + iu % BU) * BV + iv % BV;
-        slot = e;
-    }
-    const int nr = dimu - abs(u), nc = dimv - abs(v);
-    if (nr <= 0 || nc <= 0) { out[slot] = __int_as_float(0x7fc00000); return; }  // reference: empty loops, 0/0
-    double cr = 0.0;
-#pragma unroll 8
-    for (int ch = 0; ch < n_chunks; ++ch) cr += partial[(size_t)ch * n_groups * (GW * BU * BV) + pidx];  // fixed order
-    double fm, sf, F1, tm, st, F2;
-    window_stats(s1, dimu, dimv, max(u, 0), max(v, 0), nr, nc, &fm, &sf, &F1);
-    window_stats(s2, dimu, dimv, max(-u, 0), max(-v, 0), nr, nc, &tm, &st, &F2);
-    (void)fm; (void)st;
-    const double num = cr - tm * sf;
-    // a window without variance: the reference's two-pass sums are exactly 0 there and it returns 0/0 = NaN
-    // (compute_funcs.cu:1277-1290); the table differences are exact for such data too, but the cross term is not
-    out[slot] = (F1 > 0.0 && F2 > 0.0) ? (float)(num / sqrt(F1 * F2)) : __int_as_float(0x7fc00000);
-}
-
-// ------------------------------------------------------------------------------------------------ host logic
-inline int imin(int a, int b) { return a < b ? a : b; }
-inline int imax(int a, int b) { return a > b ? a : b; }
-
-// compute_MAX_ind (compute_funcs.cu:1294-1305)
-int argmax_first(const float* v, int len) {
-    float best = v[0];
-    int ind = 0;
-    for (int i = 0; i < len; ++i)
-        if (v[i] > best) { best = v[i]; ind = i; }
-    return ind;
-}
-
-// half width of the peak at `ind` along one direction of the (2*wR1+1) x (2*wR2+1) window
-// (compute_NCC_width, compute_funcs.cu:160-282).  `second_bound` is the limit of the slope-projection
-// loops, which the reference takes from the horizontal range for both directions (:252,267); where it
-// exceeds this direction's own range the reference indexes outside the window, so it is clamped.
-int peak_half_width(const mi_ncc_params& P, const float* M, int ind, int step, int range, int second_bound) {
-#pragma clang fp contract(off)  // the float expression order below is part of the specification
-    if (range < P.minDim_NCCmap) return P.INF_W;
-    second_bound = imin(second_bound, range);
-    const float thr = P.widthThr * M[ind];
-    bool found = false;
-    int w = 1;
-    while (w <= range && !found) {
-        if (M[ind - w * step] <= thr) found = true; else ++w;
-    }
-    found = false;
-    while (w <= range && !found) {
-        if (M[ind + w * step] <= thr) found = true; else ++w;
-    }
-    if (found) return w;
-    float prec = M[ind - P.minPoints * step];
-    int dist = P.minPoints + 1;
-    while (dist <= second_bound && !found) {
-        if (M[ind - dist * step] >= prec) found = true;
-        else { prec = M[ind - dist * step]; ++dist; }
-    }
-    if (dist < 2 * P.minPoints) w = P.INF_W;
-    else w = (int)std::floor((float)((dist - 1) * (M[ind] - thr) / (M[ind] - prec)));
-    found = false;
-    prec = M[ind + P.minPoints * step];
-    dist = P.minPoints + 1;
-    while (dist <= second_bound && !found) {
-        if (M[ind + dist * step] >= prec) found = true;
-        else { prec = M[ind + dist * step]; ++dist; }
-    }
-    if (dist < 2 * P.minPoints) w = P.INF_W;
-    else w = imin(imax(w, (int)std::floor((float)((dist - 1) * (M[ind] - thr) / (M[ind] - prec)))), P.INF_W - 1);
-    return w;
-}
-
-// compute_NCC_alignment (compute_funcs.cu:297-342)
-void combine_axis(const mi_ncc_params& P, mi_ncc_descr* R, int ax, int d1, float p1, int w1, int d2, float p2, int w2) {
-#pragma clang fp contract(off)
-    if (w1 == 1) w1 = P.INF_W;
-    if (w2 == 1) w2 = P.INF_W;
-    const bool ok1 = p1 >= P.maxThr && w1 < P.INF_W, ok2 = p2 >= P.maxThr && w2 < P.INF_W;
-    int d;
-    float p;
-    int w;
-    if (ok1 && ok2) {
-        if (std::abs(d1 - d2) < imin(w1, w2)) {
-            const float mean = (p1 * d1 + p2 * d2) / (p1 + p2);
-            d = (int)std::floor((double)mean + 0.5);
-            p = (p1 * p1 + p2 * p2) / (p1 + p2);
-            w = imax(w1, w2);
-        } else if (p1 / w1 > p2 / w2) { d = d1; p = p1; w = w1; }
-        else { d = d2; p = p2; w = w2; }
-    } else if (ok1) { d = d1; p = p1; w = w1; }
-    else if (ok2) { d = d2; p = p2; w = w2; }
-    else { d = P.INV_COORD; p = P.UNR_NCC; w = P.INF_W; }
-    R->coord[ax] = d;
-    R->NCC_maxs[ax] = p;
-    R->NCC_widths[ax] = w;
-}
-
-struct PlaneGeom {  // one of the three MIP planes
-    int dimu, dimv;     // MIP extents
-    int delayu, delayv; // search half ranges
-    int wu, wv;         // window half extents (wRangeThr)
-    size_t mip1, mip2, ps1, ps2, map;  // float offsets inside the workspace
-    size_t sat;                        // double offset of this plane's summed-area tables inside Workspace::sat
-    bool tiled;
-};
-
-// layout of one plane's tables (doubles): c0a, c0b | P1 | Q1 | P2 | Q2 | TS1 | TS2
-struct SatLayout {
-    size_t tab, ts, total;
-    SatLayout(int dimu, int dimv) {
-        tab = (size_t)(dimu + 1) * (dimv + 1);
-        ts = (size_t)(dimu / TILE + 1) * (dimv / TILE + 1);
-        total = 2 + 4 * tab + 2 * ts + 2 * MEAN_PARTS;  // c0a, c0b | P1 Q1 P2 Q2 | TS1 TS2 | partial pixel sums
-    }
-};
-
-// builds tile sums (float, reference order), global means and the summed-area tables of both MIPs of a plane
-int prepare_plane(hipStream_t s, const float* m1, const float* m2, int dimu, int dimv, float* ps1, float* ps2, double* sat, SatView* v1,
-                  SatView* v2) {
-    const SatLayout L(dimu, dimv);
-    const bool tiled = (dimu / TILE) * (dimv / TILE) > 0;
-    double *c0a = sat, *c0b = sat + 1, *P1 = sat + 2, *Q1 = P1 + L.tab, *P2 = Q1 + L.tab, *Q2 = P2 + L.tab, *T1 = Q2 + L.tab, *T2 = T1 + L.ts;
-    if (tiled) {
-        const int nt = (dimu / TILE) * (dimv / TILE);
-        hipLaunchKernelGGL(k_tile_sums, dim3(nt, 2), dim3(64), 0, s, m1, m2, dimu, dimv, ps1, ps2);
-        MI_TRY(launch_check("k_tile_sums"));
-    }
-    double* part = T2 + L.ts;
-    hipLaunchKernelGGL(k_mip_partial, dim3(MEAN_PARTS, 2), dim3(256), 0, s, m1, m2, (size_t)dimu * dimv, part);
-    MI_TRY(launch_check("k_mip_partial"));
-    hipLaunchKernelGGL(k_mip_mean, dim3(2), dim3(1024), 0, s, part, dimu, dimv, tiled ? ps1 : nullptr, tiled ? ps2 : nullptr, c0a, c0b, T1, T2);
-    MI_TRY(launch_check("k_mip_mean"));
-    hipLaunchKernelGGL(k_sat_rows, dim3(dimu + 1, 2), dim3(64), 0, s, m1, m2, dimu, dimv, c0a, c0b, P1, Q1, P2, Q2);
-    MI_TRY(launch_check("k_sat_rows"));
-    hipLaunchKernelGGL(k_sat_cols, dim3(dimv, 4), dim3(64), 0, s, dimu, dimv, P1, Q1, P2, Q2);
-    MI_TRY(launch_check("k_sat_cols"));
-    *v1 = SatView{P1, Q1, tiled ? T1 : nullptr, c0a};
-    *v2 = SatView{P2, Q2, tiled ? T2 : nullptr, c0b};
-    return MI_OK;
-}
-
-// pinned host staging: pageable destinations make every small D2H / H2D a ~0.14 ms staged blit
-struct PinnedBuf {
-    void* p = nullptr;
-    size_t bytes = 0;
-    PinnedBuf() = default;
-    PinnedBuf(const PinnedBuf&) = delete;
-    PinnedBuf& operator=(const PinnedBuf&) = delete;
-    ~PinnedBuf() { if (p) (void)hipHostFree(p); }
-    int reserve(size_t n) {
-        if (n <= bytes) return MI_OK;
-        if (p) (void)hipHostFree(p);
-        p = nullptr;
-        bytes = 0;
-        hipError_t e = hipHostMalloc(&p, n, hipHostMallocDefault);
-        if (e != hipSuccess) { p = nullptr; return fail(MI_ERR_NOMEM, "hipHostMalloc(%zu) failed: %s", n, hipGetErrorString(e)); }
-        bytes = n;
-        return MI_OK;
-    }
-    template <class T> T* as() const { return static_cast<T*>(p); }
-};
-
-struct Workspace {
-    DevBuf buf;       // floats: MIPs | tile sums | maps | miss results
-    DevBuf sat;       // doubles: per plane c0, P, Q, TS tables of both MIPs
-    DevBuf mip_tmp;   // floats: per tile and row band, the column maxima the yz MIPs are reduced from
-    SatView v1[3], v2[3];
-    DevBuf list;      // ints: {u, v0, count, slot} groups of missing entries
-    DevBuf partial[3]; // doubles: per plane, the row chunks' partial cross terms of a full map
-    size_t floats = 0;
-    int list_cap = 0;
-    std::vector<int> host_groups, host_entries, host_slots;
-    std::vector<long long> host_keys;
-    PinnedBuf pin_groups, pin_res, pin_maps;
-};
-
-// NCC values of one plane: the blocked cross terms + the finishing pass.  d_groups / d_entries == nullptr: the full map into
-// d_out; else the listed groups {u0, nb, v0[GW]} and entries {u, v, partial index, output slot}.  `partial` grows as needed.
-int ncc_launch(hipStream_t s, const float* m1, const float* m2, int dimu, int dimv, int delayu, int delayv, const SatView& v1, const SatView& v2,
-               const int* d_groups, int n_groups, const int* d_entries, int n_entries, DevBuf& partial, float* d_out) {
-    const int nvb = (2 * delayv + 1 + BV - 1) / BV;
-    if (!d_groups) {
-        n_groups = ((2 * delayu + 1 + BU - 1) / BU) * ((nvb + GW - 1) / GW);
-        n_entries = (2 * delayu + 1) * (2 * delayv + 1);
-    }
-    if (n_groups <= 0 || n_entries <= 0) return MI_OK;
-    // column segments of at most 512 m2 columns, row chunks so that about 768 work-groups of 8 waves exist
-    const int nseg = (dimv + 511) / 512;
-    const int seg_w = ((dimv + nseg - 1) / nseg + BC - 1) / BC * BC;
-    int rchunks = (768 + n_groups * nseg - 1) / (n_groups * nseg);
-    rchunks = imax(1, imin(rchunks, (dimu + 7) / 8));
-    const int rows_per_chunk = (dimu + rchunks - 1) / rchunks;
-    rchunks = (dimu + rows_per_chunk - 1) / rows_per_chunk;
-    const int chunks = rchunks * nseg;
-    // the m1 window of a group: its blocks start at most (GW - 1) * BV columns apart
-    const int quads = seg_w / BC, pitch1 = seg_w + GW * BV, pitch2 = seg_w;
-    // rows staged together: a few items per lane and stage, within 60 KB of LDS (two work-groups per CU)
-    const int fit = ((60 * 1024) / (int)sizeof(float) - (BU - 1) * pitch1) / (pitch1 + pitch2);
-    const int R = imax(1, imin(imin(rows_per_chunk, 1536 / quads), fit));
-    const size_t lds = sizeof(float) * ((size_t)(R + BU - 1) * pitch1 + (size_t)R * pitch2);
-    const size_t need = sizeof(double) * (size_t)chunks * n_groups * GW * BU * BV;
-    if (partial.bytes < need) {
-        MI_HIP(hipStreamSynchronize(s));  // an earlier launch of this stream may still read the old buffer
-        MI_TRY(partial.alloc(need));
-    }
-    hipLaunchKernelGGL(k_ncc_blk, dim3(n_groups, chunks), dim3(BLK_THREADS), lds, s, m1, m2, dimu, dimv, delayu, delayv, nvb, d_groups, n_groups,
-                       rows_per_chunk, R, seg_w, nseg, pitch1, partial.as<double>());
-    MI_TRY(launch_check("k_ncc_blk"));
-    hipLaunchKernelGGL(k_ncc_finish, dim3((n_entries + 255) / 256), dim3(256), 0, s, partial.as<double>(), chunks, n_groups, d_entries, n_entries,
-                       dimu, dimv, delayu, delayv, v1, v2, d_out);
-    return launch_check("k_ncc_finish");
-}
-
-// compute_Neighborhood (compute_funcs.cu:1324-1592): win = (2wu+1)x(2wv+1) window around the peak,
-// re-centred up to maxIter times; entries exposed by a move are computed on the device.
-int refine_neighbourhood(hipStream_t s, const mi_ncc_params& P, const float* map, const PlaneGeom& g, int plane, const float* d_base,
-                         Workspace& ws,
-                         std::vector<float>& win, int* du, int* dv, bool* failed) {
-    const int H = 2 * g.wu + 1, W = 2 * g.wv + 1, Wm = 2 * g.delayv + 1;
-    int ind_max = argmax_first(map, (2 * g.delayu + 1) * Wm);
-    const int initu = imin(imax(0, ind_max / Wm - g.wu), 2 * (g.delayu - g.wu));
-    const int initv = imin(imax(0, ind_max % Wm - g.wv), 2 * (g.delayv - g.wv));
-    MI_REQUIRE(initu >= 0 && initv >= 0, "CrossMIPs: negative index detected (initi)");
-    win.assign((size_t)H * W, 0.0f);
-    for (int r = 0; r < H; ++r) std::memcpy(&win[(size_t)r * W], &map[(size_t)(initu + r) * Wm + initv], sizeof(float) * W);
-    *du = initu - g.delayu + g.wu;
-    *dv = initv - g.delayv + g.wv;
-    ind_max = W * (ind_max / Wm - initu) + (ind_max % Wm - initv);
-    const int ind_ref = W * g.wu + g.wv;
-    std::vector<float> old;
-    std::vector<int> miss;
-    for (int it = 0; it < P.maxIter && ind_max != ind_ref; ++it) {
-        const int deltau = ind_max / W - g.wu, deltav = ind_max % W - g.wv;
-        old = win;
-        *du += deltau;
-        *dv += deltav;
-        miss.clear();
-        for (int r = 0; r < H; ++r)
-            for (int c = 0; c < W; ++c) {
-                const int sr = r + deltau, sc = c + deltav;
-                if (sr >= 0 && sr < H && sc >= 0 && sc < W) win[(size_t)r * W + c] = old[(size_t)sr * W + sc];
-                else { miss.push_back(r - g.wu + *du); miss.push_back(c - g.wv + *dv); miss.push_back(r * W + c); }
-            }
-        const int n_miss = (int)miss.size() / 3;
-        MI_REQUIRE(n_miss == H * W - (H - std::abs(deltau)) * (W - std::abs(deltav)), "CrossMIPs: incomplete NCC map in compute_Neighborhood");
-        if (n_miss > 0) {
-            // the missing entries are covered by 4 x 8 blocks of shifts anchored at the smallest missing (u, v); blocks of one
-            // u-row form groups of up to GW blocks (one wave each) that share their staged rows
-            int ub = miss[0], vb = miss[1];
-            for (int q = 1; q < n_miss; ++q) { ub = imin(ub, miss[3 * q]); vb = imin(vb, miss[3 * q + 1]); }
-            std::vector<long long>& keys = ws.host_keys;   // distinct blocks (bu << 20 | bv), sorted
-            keys.clear();
-            for (int q = 0; q < n_miss; ++q) keys.push_back((long long)((miss[3 * q] - ub) / BU) * (1 << 20) + (miss[3 * q + 1] - vb) / BV);
-            std::sort(keys.begin(), keys.end());
-            keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
-            std::vector<int>& lst = ws.host_groups;        // groups {u0, nb, v0[GW]}
-            lst.clear();
-            std::vector<int>& slot_of = ws.host_slots;     // per block (in `keys` order): group * GW + wave
-            slot_of.assign(keys.size(), 0);
-            int n_groups = 0;
-            for (size_t k = 0; k < keys.size();) {
-                const int bu = (int)(keys[k] >> 20), bv0 = (int)(keys[k] & ((1 << 20) - 1));
-                const size_t base = lst.size();
-                lst.resize(base + 2 + GW, 0);
-                int nb = 0;
-                while (k < keys.size() && nb < GW && (int)(keys[k] >> 20) == bu && (int)(keys[k] & ((1 << 20) - 1)) - bv0 < GW) {
-                    lst[base + 2 + nb] = vb + (int)(keys[k] & ((1 << 20) - 1)) * BV;
-                    slot_of[k] = n_groups * GW + nb;
-                    ++nb;
-                    ++k;
-                }
-                lst[base] = ub + bu * BU;
-                lst[base + 1] = nb;
-                for (int w = nb; w < GW; ++w) lst[base + 2 + w] = lst[base + 2 + nb - 1];
-                ++n_groups;
-            }
-            std::vector<int>& ent = ws.host_entries;       // entries {u, v, partial index, output slot}
-            ent.clear();
-            for (int q = 0; q < n_miss; ++q) {
-                const int u = miss[3 * q], v = miss[3 * q + 1];
-                const long long key = (long long)((u - ub) / BU) * (1 << 20) + (v - vb) / BV;
-                const size_t k = std::lower_bound(keys.begin(), keys.end(), key) - keys.begin();
-                ent.push_back(u); ent.push_back(v);
-                ent.push_back((slot_of[k] * BU + (u - ub) % BU) * BV + (v - vb) % BV);
-                ent.push_back(miss[3 * q + 2]);
-            }
-            const size_t ints = lst.size() + ent.size();
-            if ((size_t)ws.list_cap < ints) {
-                MI_HIP(hipStreamSynchronize(s));
-                MI_TRY(ws.list.alloc(sizeof(int) * ints));
-                ws.list_cap = (int)ints;
-            }
-            float* d_res = ws.buf.as<float>() + ws.floats;  // H*W result slots reserved behind the maps
-            MI_TRY(ws.pin_groups.reserve(sizeof(int) * ints));
-            MI_TRY(ws.pin_res.reserve(sizeof(float) * (size_t)H * W));
-            std::memcpy(ws.pin_groups.p, lst.data(), sizeof(int) * lst.size());
-            std::memcpy(ws.pin_groups.as<int>() + lst.size(), ent.data(), sizeof(int) * ent.size());
-            MI_HIP(hipMemcpyAsync(ws.list.p, ws.pin_groups.p, sizeof(int) * ints, hipMemcpyHostToDevice, s));
-            MI_TRY(ncc_launch(s, d_base + g.mip1, d_base + g.mip2, g.dimu, g.dimv, g.delayu, g.delayv, ws.v1[plane], ws.v2[plane],
-                              ws.list.as<int>(), n_groups, ws.list.as<int>() + lst.size(), n_miss, ws.partial[plane], d_res));
-            const float* res = ws.pin_res.as<float>();
-            MI_HIP(hipMemcpyAsync(ws.pin_res.p, d_res, sizeof(float) * H * W, hipMemcpyDeviceToHost, s));
-            MI_HIP(hipStreamSynchronize(s));
-            for (int q = 0; q < n_miss; ++q) win[miss[3 * q + 2]] = res[miss[3 * q + 2]];
-        }
-        ind_max = argmax_first(win.data(), H * W);
-    }
-    if (ind_ref != ind_max) {
-        *du += ind_max / W - g.wu;
-        *dv += ind_max % W - g.wv;
-        *failed = true;
-    }
-    return MI_OK;
-}
-
-struct PairPlan {
-    int dimk, dimi_v, dimj_v;
-    int delayi, delayj, delayk;
-    int ai0, aj0;
-    PlaneGeom g[3];
-    size_t total_floats, map_floats, map_begin, res_floats, sat_doubles;
-};
-
-int plan_pair(int dimk, int dimi, int dimj, int nk, int ni, int nj, int delayk, int delayi, int delayj, int side, mi_ncc_params* p,
-              PairPlan& pl) {
-    MI_REQUIRE(p, "CrossMIPs: missing configuration parameters");
-    if (p->enhance) return fail(MI_ERR_UNSUPPORTED, "CrossMIPs: enhance is not built (PDAlgoMIPNCC.cpp:81 never enables it)");
-    MI_REQUIRE(dimk > 0 && dimi > 0 && dimj > 0, "CrossMIPs: empty stack");
-    MI_REQUIRE(nk == 0, "CrossMIPs: nk must be 0 (CrossMIPs.h: assumed 0 by the current implementation)");
-    MI_REQUIRE(side == MI_NORTH_SOUTH || side == MI_WEST_EAST, "CrossMIPs: unexpected alignment configuration");
-    MI_REQUIRE(ni >= 0 && nj >= 0 && ni < dimi && nj < dimj, "CrossMIPs: initial offsets outside the stack");
-    MI_REQUIRE(delayi >= 0 && delayj >= 0 && delayk >= 0, "CrossMIPs: negative search range");
-    MI_REQUIRE(!(p->wRangeThr_i > delayi || p->wRangeThr_j > delayj || p->wRangeThr_k > delayk),
-               "CrossMIPs: one or more parameters: wRangeThr_i[=%d], wRangeThr_j[=%d], wRangeThr_k[=%d] are too large with respect to: "
-               "delayi[=%d], delayj[=%d], delayik[=%d]",
-               p->wRangeThr_i, p->wRangeThr_j, p->wRangeThr_k, delayi, delayj, delayk);
-    MI_REQUIRE(p->wRangeThr_i >= 0 && p->wRangeThr_j >= 0 && p->wRangeThr_k >= 0 && p->minPoints >= 1 && p->maxIter >= 0,
-               "CrossMIPs: invalid parameters");
-    // libcrossmips.cpp:260-262,275-277
-    delayi = imin(delayi, imax(0, dimi - ni - p->minDim_NCCsrc));
-    delayj = imin(delayj, imax(0, dimj - nj - p->minDim_NCCsrc));
-    delayk = imin(delayk, imax(0, dimk - nk - p->minDim_NCCsrc));
-    p->wRangeThr_i = imin(p->wRangeThr_i, delayi);
-    p->wRangeThr_j = imin(p->wRangeThr_j, delayj);
-    p->wRangeThr_k = imin(p->wRangeThr_k, delayk);
-    pl.dimk = dimk;
-    pl.dimi_v = side == MI_NORTH_SOUTH ? dimi - ni : dimi;
-    pl.dimj_v = side == MI_WEST_EAST ? dimj - nj : dimj;
-    pl.ai0 = side == MI_NORTH_SOUTH ? ni : 0;
-    pl.aj0 = side == MI_WEST_EAST ? nj : 0;
-    pl.delayi = delayi; pl.delayj = delayj; pl.delayk = delayk;
-    const int mu[3] = {pl.dimi_v, pl.dimi_v, pl.dimj_v}, mv[3] = {pl.dimj_v, dimk, dimk};
-    const int du[3] = {delayi, delayi, delayj}, dv[3] = {delayj, delayk, delayk};
-    const int wu[3] = {p->wRangeThr_i, p->wRangeThr_i, p->wRangeThr_j}, wv[3] = {p->wRangeThr_j, p->wRangeThr_k, p->wRangeThr_k};
-    size_t off = 0;
-    auto take = [&off](size_t n) { size_t o = off; off += (n + 3) / 4 * 4; return o; };
-    for (int m = 0; m < 3; ++m) {
-        PlaneGeom& g = pl.g[m];
-        g.dimu = mu[m]; g.dimv = mv[m]; g.delayu = du[m]; g.delayv = dv[m]; g.wu = wu[m]; g.wv = wv[m];
-        g.tiled = (g.dimu / TILE) * (g.dimv / TILE) > 0;
-    }
-    // MIPs first (one memset covers them), then tile sums, then maps (one D2H covers them)
-    for (int m = 0; m < 3; ++m) pl.g[m].mip1 = take((size_t)pl.g[m].dimu * pl.g[m].dimv);
-    for (int m = 0; m < 3; ++m) pl.g[m].mip2 = take((size_t)pl.g[m].dimu * pl.g[m].dimv);
-    const size_t mip_end = off;
-    for (int m = 0; m < 3; ++m) {
-        const size_t nt = (size_t)(pl.g[m].dimu / TILE) * (pl.g[m].dimv / TILE);
-        pl.g[m].ps1 = take(nt);
-        pl.g[m].ps2 = take(nt);
-    }
-    pl.map_begin = off;
-    size_t res = 0;
-    for (int m = 0; m < 3; ++m) {
-        pl.g[m].map = take((size_t)(2 * du[m] + 1) * (2 * dv[m] + 1));
-        res = std::max(res, (size_t)(2 * wu[m] + 1) * (2 * wv[m] + 1));
-    }
-    pl.map_floats = off - pl.map_begin;
-    pl.res_floats = res;
-    pl.total_floats = off;  // miss results live behind this
-    size_t soff = 0;
-    for (int m = 0; m < 3; ++m) {
-        pl.g[m].sat = soff;
-        soff += SatLayout(pl.g[m].dimu, pl.g[m].dimv).total;
-    }
-    pl.sat_doubles = soff;
-    (void)mip_end;
-    return MI_OK;
-}
-
-// stage 1 of a pair: everything up to the D2H copy of the three NCC maps is enqueued on `s`, nothing is waited for
-int pair_enqueue(hipStream_t s, const float* A, const float* B, int dimi, int dimj, const PairPlan& pl, Workspace& ws) {
-    const size_t need = pl.total_floats + pl.res_floats;
-    if (ws.buf.bytes < sizeof(float) * need) MI_TRY(ws.buf.alloc(sizeof(float) * need));
-    ws.floats = pl.total_floats;
-    float* base = ws.buf.as<float>();
-    // six MIPs start at 0 (libcrossmips.cpp:319-337)
-    MI_HIP(hipMemsetAsync(base, 0, sizeof(float) * pl.g[0].ps1, s));
-    dim3 grid((pl.dimj_v + 63) / 64, (pl.dimi_v + MIP_ROWS - 1) / MIP_ROWS, 2);
-    {
-        const size_t tmp = sizeof(float) * 2 * (size_t)grid.y * pl.dimk * pl.dimj_v;
-        if (ws.mip_tmp.bytes < tmp) {
-            MI_HIP(hipStreamSynchronize(s));
-            MI_TRY(ws.mip_tmp.alloc(tmp));
-        }
-    }
-    hipLaunchKernelGGL(k_mips, grid, dim3(256), 0, s, A, B, pl.dimk, pl.dimi_v, pl.dimj_v, (size_t)dimi * dimj, dimj, pl.ai0, pl.aj0,
-                       base + pl.g[0].mip1, base + pl.g[1].mip1, base + pl.g[2].mip1, base + pl.g[0].mip2, base + pl.g[1].mip2,
-                       base + pl.g[2].mip2, ws.mip_tmp.as<float>());
-    MI_TRY(launch_check("k_mips"));
-    hipLaunchKernelGGL(k_mips_yz, dim3((pl.dimk * pl.dimj_v + 255) / 256, 2), dim3(256), 0, s, ws.mip_tmp.as<float>(), (int)grid.y, pl.dimk,
-                       pl.dimj_v, base + pl.g[2].mip1, base + pl.g[2].mip2);
-    MI_TRY(launch_check("k_mips_yz"));
-    if (ws.sat.bytes < sizeof(double) * pl.sat_doubles) MI_TRY(ws.sat.alloc(sizeof(double) * pl.sat_doubles));
-    for (int m = 0; m < 3; ++m) {
-        const PlaneGeom& g = pl.g[m];
-        MI_TRY(prepare_plane(s, base + g.mip1, base + g.mip2, g.dimu, g.dimv, base + g.ps1, base + g.ps2, ws.sat.as<double>() + g.sat,
-                             &ws.v1[m], &ws.v2[m]));
-        MI_TRY(ncc_launch(s, base + g.mip1, base + g.mip2, g.dimu, g.dimv, g.delayu, g.delayv, ws.v1[m], ws.v2[m], nullptr, 0, nullptr, 0,
-                          ws.partial[m], base + g.map));
-    }
-    MI_TRY(ws.pin_maps.reserve(sizeof(float) * pl.map_floats));
-    MI_HIP(hipMemcpyAsync(ws.pin_maps.p, base + pl.map_begin, sizeof(float) * pl.map_floats, hipMemcpyDeviceToHost, s));
-    return MI_OK;
-}
-
-// stage 2: wait for the maps, then the host-side logic (argmax, neighbourhood refinement with its small device
-// launches on the same stream, widths, alignment)
-int pair_finish(hipStream_t s, int ni, int nj, int side, mi_ncc_params* p, const PairPlan& pl, Workspace& ws, mi_ncc_descr* out) {
-    MI_HIP(hipStreamSynchronize(s));
-    float* base = ws.buf.as<float>();
-    const float* host_maps = ws.pin_maps.as<float>();
-
-    std::vector<float> win[3];
-    int du[3], dv[3];
-    bool failed[3] = {false, false, false};
-    for (int m = 0; m < 3; ++m)
-        MI_TRY(refine_neighbourhood(s, *p, host_maps + (pl.g[m].map - pl.map_begin), pl.g[m], m, base, ws, win[m], &du[m], &dv[m],
-                                    &failed[m]));
-    // compute_Alignment (compute_funcs.cu:1597-1609)
-    int w1[3], w2[3];
-    float peak[3];
-    for (int m = 0; m < 3; ++m) {
-        const PlaneGeom& g = pl.g[m];
-        const int rowlen = 2 * g.wv + 1, c = g.wu * rowlen + g.wv;
-        peak[m] = win[m][c];
-        if (failed[m]) { w1[m] = w2[m] = p->INF_W; continue; }
-        w2[m] = peak_half_width(*p, win[m].data(), c, 1, g.wv, g.wv);
-        w1[m] = peak_half_width(*p, win[m].data(), c, rowlen, g.wu, g.wv);
-    }
-    combine_axis(*p, out, 0, du[0], peak[0], w1[0], du[1], peak[1], w1[1]);  // V: xy rows, xz rows
-    combine_axis(*p, out, 1, dv[0], peak[0], w2[0], du[2], peak[2], w1[2]);  // H: xy cols, yz rows
-    combine_axis(*p, out, 2, dv[1], peak[1], w2[1], dv[2], peak[2], w2[2]);  // D: xz cols, yz cols
-    if (side == MI_NORTH_SOUTH) out->coord[0] += ni; else out->coord[1] += nj;  // libcrossmips.cpp:483-486
-    return MI_OK;
-}
-
-// a pair's working set between batch calls: workspace + stream, per device
-struct PairSlot {
-    int dev = 0;
-    Workspace ws;
-    hipStream_t s = nullptr;
-    ~PairSlot() {
-        if (s) {
-            (void)hipSetDevice(dev);
-            (void)hipStreamDestroy(s);
-        }
-    }
-};
-// never destroyed: at process exit the HIP runtime may already be gone
-std::mutex& g_slot_mu = *new std::mutex;
-std::vector<std::unique_ptr<PairSlot>>& g_slots = *new std::vector<std::unique_ptr<PairSlot>>;
-
-std::unique_ptr<PairSlot> take_pair_slot(int dev) {
-    {
-        std::lock_guard<std::mutex> g(g_slot_mu);
-        for (size_t i = 0; i < g_slots.size(); ++i)
-            if (g_slots[i]->dev == dev) {
-                std::unique_ptr<PairSlot> r = std::move(g_slots[i]);
-                g_slots.erase(g_slots.begin() + i);
-                return r;
-            }
-    }
-    std::unique_ptr<PairSlot> r(new (std::nothrow) PairSlot);
-    if (!r) return r;
-    r->dev = dev;
-    if (hipStreamCreateWithFlags(&r->s, hipStreamNonBlocking) != hipSuccess) r->s = nullptr;
-    return r;
-}
-
-void give_pair_slot(std::unique_ptr<PairSlot> r) {
-    if (!r) return;
-    std::lock_guard<std::mutex> g(g_slot_mu);
-    if (g_slots.size() < 16) g_slots.push_back(std::move(r));  // beyond that the slot is simply destroyed
-}
-
-}  // namespace
+#include "ncc_core.h"
+#include "ncc_lag.h"
 
 namespace mi {
 // the cached pair slots of a device (-1: all) are destroyed; their buffers return to the pool (mi_release_cached_memory)
@@ -930,8 +31,28 @@ void ncc_drop_cached_slots(int dev) {
             if (dev < 0 || g_slots[i]->dev == dev) { drop.push_back(std::move(g_slots[i])); g_slots.erase(g_slots.begin() + i); }
             else ++i;
     }
+    ncc_lag_drop_cached(dev);
 }
 }  // namespace mi
+
+namespace {
+// MI_NCC_DIRECT=1: every pair takes the per-pair path (shift-by-shift fp64 cross terms, host-driven refinement) -- the A/B
+// reference of the batched lag-transform pipeline and its fallback
+bool force_direct() {
+    const char* e = std::getenv("MI_NCC_DIRECT");
+    return e && *e && *e != '0';
+}
+
+// the per-pair path of one pair (also the careful path of pairs the batched pipeline hands back)
+int pair_direct(hipStream_t s, const float* A, const float* B, int dimk, int dimi, int dimj, int ni, int nj, int delayk, int delayi, int delayj,
+                int side, mi_ncc_params* p, mi_ncc_descr* out) {
+    PairPlan pl;
+    MI_TRY(plan_pair(dimk, dimi, dimj, 0, ni, nj, delayk, delayi, delayj, side, p, pl));
+    Workspace ws;
+    MI_TRY(pair_enqueue(s, A, B, dimi, dimj, pl, ws));
+    return pair_finish(s, ni, nj, side, p, pl, ws, out);
+}
+}  // namespace
 
 extern "C" void mi_ncc_default_params(int displ_max_V, int displ_max_H, int displ_max_D, mi_ncc_params* p) {
     if (!p) return;
@@ -955,11 +76,18 @@ extern "C" int mi_ncc_mips(int dev, void* stream, const float* A, const float* B
                            int delayk, int delayi, int delayj, int side, mi_ncc_params* p, mi_ncc_descr* out) {
     MI_TRY(use_device(dev));
     MI_REQUIRE(A && B && out, "CrossMIPs: null pointer");
-    PairPlan pl;
-    MI_TRY(plan_pair(dimk, dimi, dimj, nk, ni, nj, delayk, delayi, delayj, side, p, pl));
-    Workspace ws;
-    MI_TRY(pair_enqueue(as_stream(stream), A, B, dimi, dimj, pl, ws));
-    return pair_finish(as_stream(stream), ni, nj, side, p, pl, ws, out);
+    {   // parameter checks first (the messages of the reference), on a copy: the paths below clamp `p` themselves
+        mi_ncc_params probe = p ? *p : mi_ncc_params{};
+        PairPlan pl;
+        MI_TRY(plan_pair(dimk, dimi, dimj, nk, ni, nj, delayk, delayi, delayj, side, p ? &probe : nullptr, pl));
+    }
+    hipStream_t s = as_stream(stream);
+    if (!force_direct() && ncc_lag_supported(dimk, dimi, dimj, ni, nj, delayk, delayi, delayj, side, p)) {
+        unsigned char careful = 1;
+        MI_TRY(ncc_lag_group(dev, s, 1, &A, &B, dimk, dimi, dimj, ni, nj, delayk, delayi, delayj, side, p, out, &careful));
+        if (!careful) return MI_OK;
+    }
+    return pair_direct(s, A, B, dimk, dimi, dimj, ni, nj, delayk, delayi, delayj, side, p, out);
 }
 
 extern "C" int mi_ncc_mips_host(int dev, void* stream, const float* A, const float* B, int dimk, int dimi, int dimj, int nk, int ni,
@@ -987,14 +115,64 @@ extern "C" int mi_ncc_mips_batch(int dev, void* stream, int n_pairs, const float
     MI_REQUIRE(n_pairs >= 0, "mi_ncc_mips_batch: negative pair count");
     if (n_pairs == 0) return MI_OK;
     MI_REQUIRE(tiles && a_idx && b_idx && ni && nj && side && params && out, "mi_ncc_mips_batch: null pointer");
-    // The host side of a pair (argmax, neighbourhood refinement with its small launches and stream syncs, widths, alignment)
-    // is a serial latency chain of about a millisecond, and few of a pair's kernels fill the device on their own: NT host
-    // threads, each with its own stream and workspace, take every NT-th pair; within a thread the next pair's kernels are
+    hipStream_t user = as_stream(stream);
+    for (int q = 0; q < n_pairs; ++q)
+        MI_REQUIRE(tiles[a_idx[q]] && tiles[b_idx[q]], "mi_ncc_mips_batch: null tile for pair %d", q);
+    // Batched pipeline (ncc_lag.hip): pairs of equal geometry (side, nominal offsets, parameters) go through the device together,
+    // one synchronisation per group.  Pairs it hands back (a decision inside the resolution of its values, a move outside the
+    // transformed lags) and geometries it does not take continue on the per-pair path below.
+    std::vector<int> todo;
+    if (!force_direct()) {
+        struct Key {
+            int side, ni, nj;
+            mi_ncc_params p;
+            bool operator<(const Key& o) const { return std::memcmp(this, &o, sizeof(Key)) < 0; }
+        };
+        std::map<Key, std::vector<int>> groups;
+        for (int q = 0; q < n_pairs; ++q) {
+            Key k;
+            std::memset(&k, 0, sizeof k);
+            k.side = side[q]; k.ni = ni[q]; k.nj = nj[q]; k.p = params[q];
+            groups[k].push_back(q);
+        }
+        for (auto& kv : groups) {
+            const std::vector<int>& idx = kv.second;
+            const int q0 = idx[0], n = (int)idx.size();
+            {   // the reference's parameter checks, on a copy
+                mi_ncc_params probe = params[q0];
+                PairPlan pl;
+                MI_TRY(plan_pair(dimk, dimi, dimj, 0, ni[q0], nj[q0], delayk, delayi, delayj, side[q0], &probe, pl));
+            }
+            if (!ncc_lag_supported(dimk, dimi, dimj, ni[q0], nj[q0], delayk, delayi, delayj, side[q0], &params[q0])) {
+                todo.insert(todo.end(), idx.begin(), idx.end());
+                continue;
+            }
+            std::vector<const float*> pa(n), pb(n);
+            std::vector<mi_ncc_params> pp(n);
+            std::vector<mi_ncc_descr> po(n);
+            std::vector<unsigned char> careful(n, 1);
+            for (int i = 0; i < n; ++i) { pa[i] = tiles[a_idx[idx[i]]]; pb[i] = tiles[b_idx[idx[i]]]; pp[i] = params[idx[i]]; }
+            MI_TRY(ncc_lag_group(dev, user, n, pa.data(), pb.data(), dimk, dimi, dimj, ni[q0], nj[q0], delayk, delayi, delayj, side[q0], pp.data(),
+                                 po.data(), careful.data()));
+            for (int i = 0; i < n; ++i) {
+                if (careful[i]) { todo.push_back(idx[i]); continue; }
+                params[idx[i]] = pp[i];
+                out[idx[i]] = po[i];
+            }
+        }
+        if (todo.empty()) return MI_OK;
+        std::sort(todo.begin(), todo.end());
+    } else {
+        for (int q = 0; q < n_pairs; ++q) todo.push_back(q);
+    }
+    const int n_todo = (int)todo.size();
+    // Per-pair path.  The host side of a pair (argmax, neighbourhood refinement with its small launches and stream syncs, widths,
+    // alignment) is a serial latency chain of about a millisecond, and few of a pair's kernels fill the device on their own: NT
+    // host threads, each with its own stream and workspace, take every NT-th pair; within a thread the next pair's kernels are
     // enqueued before the current pair is refined.  All streams start after, and are joined back into, `stream`.
     int want = 3;
     if (const char* e = std::getenv("MI_NCC_THREADS")) want = std::max(1, std::min(32, std::atoi(e)));
-    const int NT = std::min(n_pairs, want);
-    hipStream_t user = as_stream(stream);
+    const int NT = std::min(n_todo, want);
     hipEvent_t ev = nullptr;
     if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, user) != hipSuccess) {
         if (ev) (void)hipEventDestroy(ev);
@@ -1013,19 +191,20 @@ extern "C" int mi_ncc_mips_batch(int dev, void* stream, int n_pairs, const float
         if (rc != MI_OK) { msgs[t] = mi_last_error(); rcs[t] = rc; return; }
         Slot slot[2] = {{nullptr, res[0]->ws, PairPlan(), res[0]->s}, {nullptr, res[1]->ws, PairPlan(), res[1]->s}};
         int k = 0;  // index of the pair within this thread's sequence t, t + NT, ...
-        for (int q = t; rc == MI_OK; q += NT, ++k) {
-            if (q < n_pairs) {
+        for (int qi = t; rc == MI_OK; qi += NT, ++k) {
+            if (qi < n_todo) {
+                const int q = todo[qi];
                 Slot& sl = slot[k & 1];
-                if (!tiles[a_idx[q]] || !tiles[b_idx[q]]) { rc = fail(MI_ERR_INVALID, "mi_ncc_mips_batch: null tile for pair %d", q); break; }
                 rc = plan_pair(dimk, dimi, dimj, 0, ni[q], nj[q], delayk, delayi, delayj, side[q], &params[q], sl.pl);
                 if (rc == MI_OK) rc = pair_enqueue(sl.s, tiles[a_idx[q]], tiles[b_idx[q]], dimi, dimj, sl.pl, sl.ws);
             }
-            const int f = q - NT;
-            if (f >= 0 && f < n_pairs && rc == MI_OK) {
+            const int fi = qi - NT;
+            if (fi >= 0 && fi < n_todo && rc == MI_OK) {
+                const int f = todo[fi];
                 Slot& pr = slot[(k - 1) & 1];
                 rc = pair_finish(pr.s, ni[f], nj[f], side[f], &params[f], pr.pl, pr.ws, &out[f]);
             }
-            if (q >= n_pairs) break;
+            if (qi >= n_todo) break;
         }
         if (rc != MI_OK) msgs[t] = mi_last_error();
         for (auto& r : res) {
@@ -1063,13 +242,22 @@ extern "C" int mi_ncc_compute_mips(int dev, void* stream, const float* A, const 
     dim3 grid((dimj_v + 63) / 64, (dimi_v + MIP_ROWS - 1) / MIP_ROWS, 2);
     DevBuf tmp;
     MI_TRY(tmp.alloc(sizeof(float) * 2 * (size_t)grid.y * dimk * dimj_v));
-    hipLaunchKernelGGL(k_mips, grid, dim3(256), 0, s, A, B, dimk, dimi_v, dimj_v, (size_t)dimi * dimj, dimj, side == MI_NORTH_SOUTH ? ni : 0,
-                       side == MI_WEST_EAST ? nj : 0, xy1, xz1, yz1, xy2, xz2, yz2, tmp.as<float>());
+    hipLaunchKernelGGL(k_mips, grid, dim3(256), 0, s, A, B, (const float* const*)nullptr, (size_t)0, dimk, dimi_v, dimj_v, (size_t)dimi * dimj,
+                       dimj, side == MI_NORTH_SOUTH ? ni : 0, side == MI_WEST_EAST ? nj : 0, xy1, xz1, yz1, xy2, xz2, yz2, tmp.as<float>());
     MI_TRY(launch_check("k_mips"));
-    hipLaunchKernelGGL(k_mips_yz, dim3((dimk * dimj_v + 255) / 256, 2), dim3(256), 0, s, tmp.as<float>(), (int)grid.y, dimk, dimj_v, yz1, yz2);
+    hipLaunchKernelGGL(k_mips_yz, dim3((dimk * dimj_v + 255) / 256, 2), dim3(256), 0, s, tmp.as<float>(), (size_t)0, (int)grid.y, dimk, dimj_v,
+                       yz1, yz2);
     MI_TRY(launch_check("k_mips_yz"));
     MI_HIP(hipStreamSynchronize(s));  // tmp dies at scope exit
     return MI_OK;
+}
+
+extern "C" int mi_ncc_compute_map_lag(int dev, void* stream, const float* mip1, const float* mip2, int dimu, int dimv, int delayu, int delayv,
+                                      float* map) {
+    MI_TRY(use_device(dev));
+    MI_REQUIRE(mip1 && mip2 && map, "compute_NCC_map: null pointer");
+    MI_REQUIRE(dimu > 0 && dimv > 0 && delayu >= 0 && delayv >= 0, "compute_NCC_map: invalid extents");
+    return ncc_lag_map(dev, as_stream(stream), mip1, mip2, dimu, dimv, delayu, delayv, map);
 }
 
 extern "C" int mi_ncc_compute_map(int dev, void* stream, const float* mip1, const float* mip2, int dimu, int dimv, int delayu, int delayv,

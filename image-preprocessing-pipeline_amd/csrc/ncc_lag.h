@@ -1,0 +1,19 @@
+// Batched lag-transform MIP-NCC pipeline (ncc_lag.hip), called by the C ABI entry points in ncc.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "mi_crossmips.h"
+
+namespace mi {
+
+// resolution below which a decision is not taken on lag-transform / summed-area-table values (MI_NCC_MARGIN, default 4e-6)
+float ncc_margin();
+// whether every plane of this geometry fits the lag transform (FFT length <= 8192, LDS)
+bool ncc_lag_supported(int dimk, int dimi, int dimj, int ni, int nj, int delayk, int delayi, int delayj, int side, const mi_ncc_params* p);
+// n pairs of one geometry; careful[q] != 0: pair q must be redone by the per-pair path, out[q] untouched.  One stream sync.
+int ncc_lag_group(int dev, hipStream_t s, int n, const float* const* a_ptrs, const float* const* b_ptrs, int dimk, int dimi, int dimj, int ni,
+                  int nj, int delayk, int delayi, int delayj, int side, mi_ncc_params* params, mi_ncc_descr* out, unsigned char* careful);
+int ncc_lag_map(int dev, hipStream_t s, const float* mip1, const float* mip2, int dimu, int dimv, int delayu, int delayv, float* map);
+void ncc_lag_drop_cached(int dev);
+
+}  // namespace mi

@@ -1,0 +1,645 @@
+// Batched MIP-NCC: all pairs of a batch go through the device together, one stream synchronisation per batch.
+//
+// Replaces, for n pairs at once, libcrossmips.cpp:319-481 (6 MIPs, 3 NCC maps, 3 neighbourhood refinements) and the pair loop
+// of StackStitcher.cpp:223-374 around it.  What differs from the per-pair path of ncc.hip / ncc_core.h:
+//
+//   * every kernel is launched once per (group of equal-geometry pairs, plane) with the pair index in the grid;
+//   * the cross terms  sum f[i+u][j+v] t[i][j]  -- the only part of compute_NCC (compute_funcs.cu:1163-1292) that is not O(1) per
+//     shift once the summed-area tables exist -- are no longer accumulated shift by shift (1.6e9 fp64 FMA for a 2048 x 307
+//     MIP and 51 x 51 shifts) but through a LAG TRANSFORM along the long axis of the MIP, in fp64:
+//       k_lag_fwd   column j of both MIPs -> one zero-padded complex FFT of length N >= n_long + E (f in the real, t in the
+//                   imaginary part), untangled into F_j[k], T_j[k], k = 0 .. N/2;
+//       k_lag_mac   per frequency k a direct correlation along the SHORT axis:  C_s[k] = sum_j F_{j+s}[k] conj(T_j[k])
+//                   for every short-axis lag s in [-Es, Es];
+//       k_lag_inv   per short-axis lag the inverse transform over k (two lags per complex FFT) -> cross[u][v] for EVERY long-axis
+//                   lag, of which [-El, El] are kept.
+//     That is ~10x fewer fp64 operations than the shift-by-shift sums and -- because every lag within E = delay + (re-centring
+//     moves) * wRangeThr exists afterwards -- the neighbourhood refinement (compute_Neighborhood, :1324-1592) needs no further
+//     pass over the MIPs: k_lag_refine does argmax, window extraction, the re-centring moves and the evaluation of the newly
+//     exposed entries on the device, one work-group per (pair, plane), and only the final window + 4 ints per plane return.
+//   * the host finishes with the unchanged bit-identical width / alignment rules (ncc_core.h).
+//
+// Accuracy: the transforms are fp64 with table twiddles; a cross term differs from the sequential fp64 sum by ~1e-15 of
+// ||f|| ||t||, i.e. an NCC value by ~1e-13 -- six orders below the float the reference rounds to.  Decisions whose margin is
+// below MI_NCC_MARGIN (4e-6: argmax runner-up on the device, threshold crossings / slope steps / rounding steps on the host) are
+// not taken here: the pair is handed to the careful per-pair path (ncc.hip), which recomputes the entries involved with the
+// reference's two-pass fp64 form.  The same happens when a re-centring move leaves the lag range that was transformed.
+#include <cfloat>
+#include <map>
+
+#include "ncc_core.h"
+#include "ncc_lag.h"
+
+namespace {
+
+typedef double2 cplx;
+
+__device__ __forceinline__ cplx cmul(cplx a, cplx b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ cplx cadd(cplx a, cplx b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ cplx csub(cplx a, cplx b) { return make_double2(a.x - b.x, a.y - b.y); }
+
+// In-place decimation-in-frequency transform of x[0 .. 2^lgN) in LDS: radix-4 stages, then one radix-2 stage when lgN is odd.
+// Natural order in, digit-reversed order out: frequency k sits at pos_of_freq(k).  tw[n] = exp(-2 pi i n / N).
+__device__ __forceinline__ int pos_of_freq(int k, int lgN) {
+    int p = 0, rem = lgN;
+    while (rem >= 2) {  // the digits of k, least significant first, are the digits of the position, most significant first
+        p |= (k & 3) << (rem - 2);
+        k >>= 2;
+        rem -= 2;
+    }
+    if (rem == 1) p |= (k & 1);
+    return p;
+}
+
+__device__ void fft_dif(cplx* __restrict__ x, int lgN, const cplx* __restrict__ tw) {
+    const int N = 1 << lgN;
+    int lgL = lgN;
+    while (lgL >= 2) {
+        const int lgq = lgL - 2, q = 1 << lgq, sh = lgN - lgL;
+        for (int idx = threadIdx.x; idx < (N >> 2); idx += blockDim.x) {
+            const int t = idx & (q - 1), b = (idx >> lgq) << lgL;
+            cplx* p = x + b + t;
+            const cplx a0 = p[0], a1 = p[q], a2 = p[2 * q], a3 = p[3 * q];
+            const cplx s02 = cadd(a0, a2), d02 = csub(a0, a2), s13 = cadd(a1, a3), d13 = csub(a1, a3);
+            const cplx y1 = make_double2(d02.x + d13.y, d02.y - d13.x);  // d02 - i d13
+            const cplx y3 = make_double2(d02.x - d13.y, d02.y + d13.x);  // d02 + i d13
+            p[0] = cadd(s02, s13);
+            p[q] = cmul(y1, tw[t << sh]);
+            p[2 * q] = cmul(csub(s02, s13), tw[(2 * t) << sh]);
+            p[3 * q] = cmul(y3, tw[(3 * t) << sh]);
+        }
+        __syncthreads();
+        lgL -= 2;
+    }
+    if (lgL == 1) {
+        for (int idx = threadIdx.x; idx < (N >> 1); idx += blockDim.x) {
+            const cplx a0 = x[2 * idx], a1 = x[2 * idx + 1];
+            x[2 * idx] = cadd(a0, a1);
+            x[2 * idx + 1] = csub(a0, a1);
+        }
+        __syncthreads();
+    }
+}
+
+// forward lag transform of short-axis line j (blockIdx.x) of pair blockIdx.y: element i of the line = m[i * ls + j * ss]
+__global__ __launch_bounds__(256) void k_lag_fwd(const float* __restrict__ m1, const float* __restrict__ m2, size_t pstride, int n_long, int n_short,
+                                                 int ls, int ss, int lgN, const cplx* __restrict__ tw, cplx* __restrict__ SF, cplx* __restrict__ ST) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lag_lds[];
+    cplx* x = reinterpret_cast<cplx*>(lag_lds);
+    const int N = 1 << lgN, NK = N / 2 + 1, j = blockIdx.x;
+    const float* a = m1 + (size_t)blockIdx.y * pstride + (size_t)j * ss;
+    const float* b = m2 + (size_t)blockIdx.y * pstride + (size_t)j * ss;
+    for (int i = threadIdx.x; i < N; i += blockDim.x)
+        x[i] = i < n_long ? make_double2((double)a[(size_t)i * ls], (double)b[(size_t)i * ls]) : make_double2(0.0, 0.0);
+    __syncthreads();
+    fft_dif(x, lgN, tw);
+    cplx* of = SF + ((size_t)blockIdx.y * n_short + j) * NK;
+    cplx* ot = ST + ((size_t)blockIdx.y * n_short + j) * NK;
+    for (int k = threadIdx.x; k < NK; k += blockDim.x) {
+        const cplx zk = x[pos_of_freq(k, lgN)], zn = x[pos_of_freq((N - k) & (N - 1), lgN)];
+        of[k] = make_double2(0.5 * (zk.x + zn.x), 0.5 * (zk.y - zn.y));   // (Z[k] + conj Z[N-k]) / 2
+        ot[k] = make_double2(0.5 * (zk.y + zn.y), -0.5 * (zk.x - zn.x));  // (Z[k] - conj Z[N-k]) / (2 i)
+    }
+}
+
+// per frequency: C_s[k] = sum_j F_{j+s}[k] conj(T_j[k]),  s = -Es .. Es.  A work-group takes KT frequencies; a thread one
+// frequency, four neighbouring lags and one of JP parts of the j range (sliding registers: two LDS reads feed 16 FMAs).
+__global__ __launch_bounds__(256) void k_lag_mac(const cplx* __restrict__ SF, const cplx* __restrict__ ST, int n_short, int NK, int Es, int KT, int JP,
+                                                 int FW, int TW, cplx* __restrict__ CH) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lag_lds[];
+    cplx* Fs = reinterpret_cast<cplx*>(lag_lds);  // KT rows of FW: PAD zeros | n_short samples | zeros
+    cplx* Ts = Fs + (size_t)KT * FW;              // KT rows of TW
+    const int PAD = Es + 3, k0 = blockIdx.x * KT, nk = min(KT, NK - k0);
+    const size_t pbase = (size_t)blockIdx.y * n_short;
+    for (int e = threadIdx.x; e < KT * FW; e += blockDim.x) Fs[e] = make_double2(0.0, 0.0);
+    __syncthreads();
+    for (int e = threadIdx.x; e < n_short * KT; e += blockDim.x) {  // kl fastest: 16 * KT contiguous bytes per line j
+        const int x = e / KT, kl = e - x * KT;
+        if (kl < nk) {
+            Fs[(size_t)kl * FW + PAD + x] = SF[(pbase + x) * NK + k0 + kl];
+            Ts[(size_t)kl * TW + x] = ST[(pbase + x) * NK + k0 + kl];
+        }
+    }
+    __syncthreads();
+    const int nlag = 2 * Es + 1, nvb = (nlag + 3) / 4, nlp = nvb * 4;
+    const int jlen = (n_short + JP - 1) / JP;
+    cplx acc[4];
+    const int item = threadIdx.x;  // (jp, vb, kl), kl fastest
+    const int kl = item % KT, vb = (item / KT) % nvb, jp = item / (KT * nvb);
+    const bool live = jp < JP && kl < nk;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = make_double2(0.0, 0.0);
+    if (live) {
+        const int v0 = -Es + 4 * vb, jb = jp * jlen, je = min(n_short, jb + jlen);
+        const cplx* fr = Fs + (size_t)kl * FW + PAD + v0;
+        const cplx* tr = Ts + (size_t)kl * TW;
+        cplx f0 = fr[jb], f1 = fr[jb + 1], f2 = fr[jb + 2];
+        for (int j = jb; j < je; ++j) {
+            const cplx f3 = fr[j + 3], t = tr[j];
+            acc[0].x = fma(f0.x, t.x, fma(f0.y, t.y, acc[0].x)); acc[0].y = fma(f0.y, t.x, fma(-f0.x, t.y, acc[0].y));
+            acc[1].x = fma(f1.x, t.x, fma(f1.y, t.y, acc[1].x)); acc[1].y = fma(f1.y, t.x, fma(-f1.x, t.y, acc[1].y));
+            acc[2].x = fma(f2.x, t.x, fma(f2.y, t.y, acc[2].x)); acc[2].y = fma(f2.y, t.x, fma(-f2.x, t.y, acc[2].y));
+            acc[3].x = fma(f3.x, t.x, fma(f3.y, t.y, acc[3].x)); acc[3].y = fma(f3.y, t.x, fma(-f3.x, t.y, acc[3].y));
+            f0 = f1; f1 = f2; f2 = f3;
+        }
+    }
+    // the JP parts of a (kl, vb) are added in a fixed order through LDS (the spectra are no longer needed)
+    __syncthreads();
+    cplx* red = Fs;  // [jp][vb][kl][4]
+    if (live && jp > 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) red[(((size_t)(jp - 1) * nvb + vb) * KT + kl) * 4 + q] = acc[q];
+    }
+    __syncthreads();
+    if (live && jp == 0) {
+        for (int p = 1; p < JP; ++p)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = cadd(acc[q], red[(((size_t)(p - 1) * nvb + vb) * KT + kl) * 4 + q]);
+        cplx* dst = CH + ((size_t)blockIdx.y * NK + k0 + kl) * nlp + 4 * vb;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dst[q] = acc[q];
+    }
+}
+
+// inverse lag transform of two short-axis lags (2 * blockIdx.x, + 1) of pair blockIdx.y: c_a[n] + i c_b[n] = FFT(conj C_a + i conj C_b) / N
+// (both c real); the long-axis lags [-El, El] go to cross[(u + Eu) * (2 Ev + 1) + (v + Ev)]
+__global__ __launch_bounds__(256) void k_lag_inv(const cplx* __restrict__ CH, int NK, int lgN, int Es, int El, int long_is_u, int Eu, int Ev,
+                                                 const cplx* __restrict__ tw, double* __restrict__ cross) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lag_lds[];
+    cplx* x = reinterpret_cast<cplx*>(lag_lds);
+    const int N = 1 << lgN, nlag = 2 * Es + 1, nlp = (nlag + 3) / 4 * 4;
+    const int sa = 2 * blockIdx.x, sb = sa + 1;
+    const bool has_b = sb < nlag;
+    const cplx* src = CH + (size_t)blockIdx.y * NK * nlp;
+    for (int k = threadIdx.x; k < NK; k += blockDim.x) {
+        const cplx xa = src[(size_t)k * nlp + sa];
+        const cplx xb = has_b ? src[(size_t)k * nlp + sb] : make_double2(0.0, 0.0);
+        x[k] = make_double2(xa.x + xb.y, -xa.y + xb.x);                              // conj(Xa) + i conj(Xb)
+        if (k > 0 && k < N / 2) x[N - k] = make_double2(xa.x - xb.y, xa.y + xb.x);   // Xa + i Xb  (= conj X[N-k] terms)
+    }
+    __syncthreads();
+    fft_dif(x, lgN, tw);
+    const double inv = 1.0 / (double)N;
+    const int W = 2 * Ev + 1;
+    double* out = cross + (size_t)blockIdx.y * (2 * Eu + 1) * W;
+    for (int e = threadIdx.x; e < 2 * El + 1; e += blockDim.x) {
+        const int l = e - El;
+        const cplx v = x[pos_of_freq((l + N) & (N - 1), lgN)];
+        if (long_is_u) {
+            out[(size_t)(l + Eu) * W + (sa - Es + Ev)] = v.x * inv;
+            if (has_b) out[(size_t)(l + Eu) * W + (sb - Es + Ev)] = v.y * inv;
+        } else {
+            out[(size_t)(sa - Es + Eu) * W + (l + Ev)] = v.x * inv;
+            if (has_b) out[(size_t)(sb - Es + Eu) * W + (l + Ev)] = v.y * inv;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ refinement on the device
+struct RefineGeom {
+    int dimu, dimv, delayu, delayv, wu, wv, Eu, Ev, maxIter, tiled;
+    size_t sstride, sat_off, tab, ts;  // doubles: per-pair stride of the table block, offset of this plane, table sizes
+    float margin;
+};
+
+// first index of the strict maximum like compute_MAX_ind (compute_funcs.cu:1294-1305: a leading NaN stays the maximum, later NaNs never
+// win) + the distance of the runner-up.  All threads return the same values.
+__device__ int block_argmax(const float* __restrict__ arr, int len, float* red_v, int* red_i, float* gap) {
+    float bv = -FLT_MAX;
+    int bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < len; i += blockDim.x) {
+        const float v = arr[i];
+        if (v == v && (v > bv || (v == bv && i < bi) || bi == 0x7fffffff)) { bv = v; bi = i; }
+    }
+    auto reduce = [&](float& v, int& i) {
+        red_v[threadIdx.x] = v;
+        red_i[threadIdx.x] = i;
+        __syncthreads();
+        for (int off = blockDim.x >> 1; off > 0; off >>= 1) {
+            if ((int)threadIdx.x < off) {
+                const float ov = red_v[threadIdx.x + off];
+                const int oi = red_i[threadIdx.x + off];
+                const float mv = red_v[threadIdx.x];
+                const int mi_ = red_i[threadIdx.x];
+                if (oi != 0x7fffffff && (mi_ == 0x7fffffff || ov > mv || (ov == mv && oi < mi_))) { red_v[threadIdx.x] = ov; red_i[threadIdx.x] = oi; }
+            }
+            __syncthreads();
+        }
+        v = red_v[0];
+        i = red_i[0];
+        __syncthreads();
+    };
+    reduce(bv, bi);
+    const float a0 = arr[0];
+    const int ind = (a0 != a0 || bi == 0x7fffffff) ? 0 : bi;
+    // runner-up: the largest value at any other index
+    float sv = -FLT_MAX;
+    int si = 0x7fffffff;
+    for (int i = threadIdx.x; i < len; i += blockDim.x) {
+        const float v = arr[i];
+        if (i != ind && v == v && (si == 0x7fffffff || v > sv)) { sv = v; si = i; }
+    }
+    reduce(sv, si);
+    *gap = (si == 0x7fffffff || a0 != a0 || bi == 0x7fffffff) ? FLT_MAX : bv - sv;
+    return ind;
+}
+
+// one work-group per pair: the NCC map of a plane from the cross table + summed-area tables (compute_NCC, :1163-1292), then
+// compute_Neighborhood (:1324-1592) entirely on the device.  Returns the final window, du, dv, failed and flags
+// (1: an entry outside the transformed lag range was needed, 2: an argmax was decided by less than `margin`).
+__global__ __launch_bounds__(256) void k_lag_refine(RefineGeom g, const double* __restrict__ sat_base, const double* __restrict__ cross, int wcap,
+                                                    float* __restrict__ out_win, int* __restrict__ out_int, float* __restrict__ out_map) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lag_lds[];
+    __shared__ float red_v[256];
+    __shared__ int red_i[256];
+    __shared__ int sh_flags;
+    const int Hm = 2 * g.delayu + 1, Wm = 2 * g.delayv + 1, H = 2 * g.wu + 1, W = 2 * g.wv + 1;
+    float* map = reinterpret_cast<float*>(lag_lds);
+    float* win = map + Hm * Wm;
+    float* alt = win + H * W;
+    const int pair = blockIdx.x;
+    const double* sat = sat_base + (size_t)pair * g.sstride + g.sat_off;
+    const double *P1 = sat + 2, *Q1 = P1 + g.tab, *P2 = Q1 + g.tab, *Q2 = P2 + g.tab, *T1 = Q2 + g.tab, *T2 = T1 + g.ts;
+    const SatView v1{P1, Q1, g.tiled ? T1 : nullptr, sat}, v2{P2, Q2, g.tiled ? T2 : nullptr, sat + 1};
+    const int CW = 2 * g.Ev + 1;
+    const double* cr = cross + (size_t)pair * (2 * g.Eu + 1) * CW;
+    if (threadIdx.x == 0) sh_flags = 0;
+    __syncthreads();
+    auto ncc_at = [&](int u, int v) -> float {
+        const float nan = __int_as_float(0x7fc00000);
+        const int nr = g.dimu - abs(u), nc = g.dimv - abs(v);
+        if (nr <= 0 || nc <= 0) return nan;  // reference: empty loops, 0/0
+        if (abs(u) > g.Eu || abs(v) > g.Ev) { atomicOr(&sh_flags, 1); return nan; }
+        double fm, sf, F1, tm, st, F2;
+        window_stats(v1, g.dimu, g.dimv, max(u, 0), max(v, 0), nr, nc, &fm, &sf, &F1);
+        window_stats(v2, g.dimu, g.dimv, max(-u, 0), max(-v, 0), nr, nc, &tm, &st, &F2);
+        const double num = cr[(size_t)(u + g.Eu) * CW + (v + g.Ev)] - tm * sf;
+        return (F1 > 0.0 && F2 > 0.0) ? (float)(num / sqrt(F1 * F2)) : nan;
+    };
+    for (int e = threadIdx.x; e < Hm * Wm; e += blockDim.x) {
+        const float val = ncc_at(e / Wm - g.delayu, e % Wm - g.delayv);
+        map[e] = val;
+        if (out_map) out_map[(size_t)pair * Hm * Wm + e] = val;
+    }
+    __syncthreads();
+    float gap;
+    int ind_max = block_argmax(map, Hm * Wm, red_v, red_i, &gap);
+    int flags = gap < g.margin ? 2 : 0;
+    const int initu = min(max(0, ind_max / Wm - g.wu), 2 * (g.delayu - g.wu));
+    const int initv = min(max(0, ind_max % Wm - g.wv), 2 * (g.delayv - g.wv));
+    for (int e = threadIdx.x; e < H * W; e += blockDim.x) win[e] = map[(initu + e / W) * Wm + initv + e % W];
+    int du = initu - g.delayu + g.wu, dv = initv - g.delayv + g.wv;
+    ind_max = W * (ind_max / Wm - initu) + (ind_max % Wm - initv);
+    const int ind_ref = W * g.wu + g.wv;
+    __syncthreads();
+    for (int it = 0; it < g.maxIter && ind_max != ind_ref; ++it) {
+        const int deltau = ind_max / W - g.wu, deltav = ind_max % W - g.wv;
+        du += deltau;
+        dv += deltav;
+        for (int e = threadIdx.x; e < H * W; e += blockDim.x) {
+            const int r = e / W, c = e - r * W, sr = r + deltau, sc = c + deltav;
+            alt[e] = (sr >= 0 && sr < H && sc >= 0 && sc < W) ? win[sr * W + sc] : ncc_at(r - g.wu + du, c - g.wv + dv);
+        }
+        __syncthreads();
+        float* t = win; win = alt; alt = t;
+        ind_max = block_argmax(win, H * W, red_v, red_i, &gap);
+        if (gap < g.margin) flags |= 2;
+    }
+    int failed = 0;
+    if (ind_ref != ind_max) {
+        du += ind_max / W - g.wu;
+        dv += ind_max % W - g.wv;
+        failed = 1;
+    }
+    for (int e = threadIdx.x; e < H * W; e += blockDim.x) out_win[(size_t)pair * wcap + e] = win[e];
+    if (threadIdx.x == 0) {
+        int* o = out_int + (size_t)pair * 4;
+        o[0] = du;
+        o[1] = dv;
+        o[2] = failed;
+        o[3] = flags | sh_flags;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+struct LagPlane {
+    bool long_is_u;
+    int n_long, n_short, ls, ss, lgN, El, Es, Eu, Ev;
+    int KT, JP, FW, TW;
+    size_t lds_fft, lds_mac, lds_refine;
+    bool ok;
+};
+
+int ilog2_ceil(int n) {
+    int lg = 0;
+    while ((1 << lg) < n) ++lg;
+    return lg;
+}
+
+LagPlane plan_lag_plane(const PlaneGeom& g, int maxIter) {
+    LagPlane p{};
+    p.long_is_u = g.dimu >= g.dimv;
+    p.n_long = p.long_is_u ? g.dimu : g.dimv;
+    p.n_short = p.long_is_u ? g.dimv : g.dimu;
+    p.ls = p.long_is_u ? g.dimv : 1;
+    p.ss = p.long_is_u ? 1 : g.dimv;
+    const int dl = p.long_is_u ? g.delayu : g.delayv, ds = p.long_is_u ? g.delayv : g.delayu;
+    const int wl = p.long_is_u ? g.wu : g.wv, wsh = p.long_is_u ? g.wv : g.wu;
+    // every long-axis lag comes out of the inverse transform: keep all that the re-centring moves can reach; along the short axis a
+    // lag costs a correlation: keep one move's worth (a second move beyond it is rare and sends the pair to the careful path)
+    p.El = dl + maxIter * wl;
+    p.Es = ds + (maxIter > 0 ? wsh : 0);
+    p.Eu = p.long_is_u ? p.El : p.Es;
+    p.Ev = p.long_is_u ? p.Es : p.El;
+    p.lgN = ilog2_ceil(p.n_long + p.El);
+    if (p.lgN < 2) p.lgN = 2;
+    p.lds_fft = sizeof(double) * 2 * ((size_t)1 << p.lgN);
+    const int PAD = p.Es + 3;
+    p.FW = (p.n_short + 2 * PAD + 15) / 16 * 16 + 1;  // rows one 16-byte slot apart in the banks
+    p.TW = (p.n_short + 15) / 16 * 16 + 1;
+    const size_t row = sizeof(double) * 2 * (size_t)(p.FW + p.TW);
+    p.KT = (int)std::min<size_t>(8, (64 * 1024) / row);
+    if (p.KT < 1) p.KT = 1;
+    const int nvb = (2 * p.Es + 1 + 3) / 4;
+    while (p.KT > 1 && p.KT * nvb > 256) --p.KT;
+    p.JP = std::max(1, std::min(8, 256 / (p.KT * nvb)));
+    p.lds_mac = std::max(row * p.KT, sizeof(double) * 2 * 4 * (size_t)p.JP * nvb * p.KT);
+    const int Hm = 2 * g.delayu + 1, Wm = 2 * g.delayv + 1, H = 2 * g.wu + 1, W = 2 * g.wv + 1;
+    p.lds_refine = sizeof(float) * ((size_t)Hm * Wm + 2 * (size_t)H * W);
+    p.ok = p.lgN <= 13 && p.lds_mac <= 150 * 1024 && nvb <= 256 && p.lds_refine <= 120 * 1024;
+    return p;
+}
+
+// exp(-2 pi i n / N) in fp64 for N = 2^lg, one table per (device, lg), kept for the life of the process
+struct TwiddleKey { int dev, lg; bool operator<(const TwiddleKey& o) const { return dev != o.dev ? dev < o.dev : lg < o.lg; } };
+std::mutex& g_tw_mu = *new std::mutex;
+std::map<TwiddleKey, void*>& g_tw = *new std::map<TwiddleKey, void*>;
+
+int twiddles(int dev, int lg, hipStream_t s, const cplx** out) {
+    std::lock_guard<std::mutex> lock(g_tw_mu);
+    auto it = g_tw.find(TwiddleKey{dev, lg});
+    if (it != g_tw.end()) { *out = static_cast<const cplx*>(it->second); return MI_OK; }
+    const size_t N = (size_t)1 << lg;
+    std::vector<double> h(2 * N);
+    const long double step = 2.0L * 3.14159265358979323846264338327950288L / (long double)N;
+    for (size_t n = 0; n < N; ++n) {  // octant symmetry keeps the table exact where it matters: n = 0, N/4, N/2, ...
+        h[2 * n] = (double)cosl(step * (long double)n);
+        h[2 * n + 1] = (double)-sinl(step * (long double)n);
+    }
+    if (N >= 4) { h[2 * (N / 4)] = 0.0; h[2 * (N / 4) + 1] = -1.0; h[2 * (N / 2)] = -1.0; h[2 * (N / 2) + 1] = 0.0; h[2 * (3 * N / 4)] = 0.0; h[2 * (3 * N / 4) + 1] = 1.0; }
+    void* d = nullptr;
+    MI_HIP(hipMalloc(&d, sizeof(double) * 2 * N));
+    MI_HIP(hipMemcpyAsync(d, h.data(), sizeof(double) * 2 * N, hipMemcpyHostToDevice, s));
+    MI_HIP(hipStreamSynchronize(s));
+    g_tw[TwiddleKey{dev, lg}] = d;
+    *out = static_cast<const cplx*>(d);
+    return MI_OK;
+}
+
+// device + pinned buffers of the batched pipeline, kept between calls (one set per concurrent caller and device)
+struct LagWorkspace {
+    int dev = -1;
+    DevBuf fbuf, sat, mip_tmp, SF, ST, CH, cross, outw, outi, tab;
+    PinnedBuf pin_tab, pin_w, pin_i;
+};
+std::mutex& g_lag_mu = *new std::mutex;
+std::vector<std::unique_ptr<LagWorkspace>>& g_lag_ws = *new std::vector<std::unique_ptr<LagWorkspace>>;
+
+std::unique_ptr<LagWorkspace> take_lag_ws(int dev) {
+    {
+        std::lock_guard<std::mutex> lock(g_lag_mu);
+        for (size_t i = 0; i < g_lag_ws.size(); ++i)
+            if (g_lag_ws[i]->dev == dev) {
+                std::unique_ptr<LagWorkspace> r = std::move(g_lag_ws[i]);
+                g_lag_ws.erase(g_lag_ws.begin() + i);
+                return r;
+            }
+    }
+    std::unique_ptr<LagWorkspace> r(new (std::nothrow) LagWorkspace);
+    if (r) r->dev = dev;
+    return r;
+}
+
+void give_lag_ws(std::unique_ptr<LagWorkspace> r) {
+    if (!r) return;
+    std::lock_guard<std::mutex> lock(g_lag_mu);
+    if (g_lag_ws.size() < 4) g_lag_ws.push_back(std::move(r));
+}
+
+int grow(DevBuf& b, size_t bytes) { return b.bytes >= bytes ? MI_OK : b.alloc(bytes); }
+
+// cross terms of `np` pairs of one plane through the lag transform (MIPs at m1 / m2 + q * pstride) into ws.cross
+int lag_cross(int dev, hipStream_t s, const LagPlane& lp, const float* m1, const float* m2, size_t pstride, int np, LagWorkspace& ws) {
+    const int N = 1 << lp.lgN, NK = N / 2 + 1, nlag = 2 * lp.Es + 1, nlp = (nlag + 3) / 4 * 4;
+    const cplx* tw = nullptr;
+    MI_TRY(twiddles(dev, lp.lgN, s, &tw));
+    MI_TRY(grow(ws.SF, sizeof(double) * 2 * (size_t)np * lp.n_short * NK));
+    MI_TRY(grow(ws.ST, sizeof(double) * 2 * (size_t)np * lp.n_short * NK));
+    MI_TRY(grow(ws.CH, sizeof(double) * 2 * (size_t)np * NK * nlp));
+    MI_TRY(grow(ws.cross, sizeof(double) * (size_t)np * (2 * lp.Eu + 1) * (2 * lp.Ev + 1)));
+    if (lp.lds_fft > 64 * 1024)
+        MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lag_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp.lds_fft));
+    hipLaunchKernelGGL(k_lag_fwd, dim3(lp.n_short, np), dim3(256), lp.lds_fft, s, m1, m2, pstride, lp.n_long, lp.n_short, lp.ls, lp.ss, lp.lgN, tw,
+                       ws.SF.as<cplx>(), ws.ST.as<cplx>());
+    MI_TRY(launch_check("k_lag_fwd"));
+    if (lp.lds_mac > 64 * 1024)
+        MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lag_mac), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp.lds_mac));
+    hipLaunchKernelGGL(k_lag_mac, dim3((NK + lp.KT - 1) / lp.KT, np), dim3(256), lp.lds_mac, s, ws.SF.as<cplx>(), ws.ST.as<cplx>(), lp.n_short, NK,
+                       lp.Es, lp.KT, lp.JP, lp.FW, lp.TW, ws.CH.as<cplx>());
+    MI_TRY(launch_check("k_lag_mac"));
+    if (lp.lds_fft > 64 * 1024)
+        MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lag_inv), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp.lds_fft));
+    hipLaunchKernelGGL(k_lag_inv, dim3((nlag + 1) / 2, np), dim3(256), lp.lds_fft, s, ws.CH.as<cplx>(), NK, lp.lgN, lp.Es, lp.El, lp.long_is_u ? 1 : 0,
+                       lp.Eu, lp.Ev, tw, ws.cross.as<double>());
+    return launch_check("k_lag_inv");
+}
+
+RefineGeom refine_geom(const PlaneGeom& g, const LagPlane& lp, int maxIter, size_t sstride, float margin) {
+    const SatLayout L(g.dimu, g.dimv);
+    RefineGeom r{};
+    r.dimu = g.dimu; r.dimv = g.dimv; r.delayu = g.delayu; r.delayv = g.delayv; r.wu = g.wu; r.wv = g.wv;
+    r.Eu = lp.Eu; r.Ev = lp.Ev; r.maxIter = maxIter; r.tiled = g.tiled ? 1 : 0;
+    r.sstride = sstride; r.sat_off = g.sat; r.tab = L.tab; r.ts = L.ts; r.margin = margin;
+    return r;
+}
+
+}  // namespace
+
+namespace mi {
+
+float ncc_margin() {
+    static const float m = [] {
+        const char* e = std::getenv("MI_NCC_MARGIN");
+        return e ? (float)std::atof(e) : 4e-6f;
+    }();
+    return m;
+}
+
+bool ncc_lag_supported(int dimk, int dimi, int dimj, int ni, int nj, int delayk, int delayi, int delayj, int side, const mi_ncc_params* p) {
+    mi_ncc_params q = *p;
+    PairPlan pl;
+    if (plan_pair(dimk, dimi, dimj, 0, ni, nj, delayk, delayi, delayj, side, &q, pl) != MI_OK) return false;
+    for (int m = 0; m < 3; ++m)
+        if (!plan_lag_plane(pl.g[m], q.maxIter).ok) return false;
+    return true;
+}
+
+// n pairs of ONE geometry (same side, nominal offsets and parameters): device stage of all of them, then the host rules.
+// careful[q] is set for pairs whose result was not taken here (see the header of this file); out[q] is then untouched.
+int ncc_lag_group(int dev, hipStream_t s, int n, const float* const* a_ptrs, const float* const* b_ptrs, int dimk, int dimi, int dimj, int ni,
+                  int nj, int delayk, int delayi, int delayj, int side, mi_ncc_params* params, mi_ncc_descr* out, unsigned char* careful) {
+    if (n <= 0) return MI_OK;
+    PairPlan pl;
+    for (int q = 0; q < n; ++q) MI_TRY(plan_pair(dimk, dimi, dimj, 0, ni, nj, delayk, delayi, delayj, side, &params[q], pl));
+    const mi_ncc_params& P = params[0];
+    LagPlane lp[3];
+    for (int m = 0; m < 3; ++m) {
+        lp[m] = plan_lag_plane(pl.g[m], P.maxIter);
+        MI_REQUIRE(lp[m].ok, "mi_ncc_mips_batch: plane %d does not fit the lag transform", m);
+    }
+    std::unique_ptr<LagWorkspace> wsp = take_lag_ws(dev);
+    if (!wsp) return fail(MI_ERR_NOMEM, "mi_ncc_mips_batch: out of host memory");
+    LagWorkspace& ws = *wsp;
+    struct Giver { std::unique_ptr<LagWorkspace>& p; ~Giver() { give_lag_ws(std::move(p)); } } giver{wsp};
+
+    // per-pair footprint -> chunk size
+    const size_t pstride = (pl.total_floats + 3) / 4 * 4, sstride = pl.sat_doubles;
+    const int bands = (pl.dimi_v + MIP_ROWS - 1) / MIP_ROWS;
+    const size_t tmp_floats = 2 * (size_t)bands * pl.dimk * pl.dimj_v;
+    size_t spec = 0, crs = 0;
+    int wcap = 1;
+    for (int m = 0; m < 3; ++m) {
+        const size_t NK = ((size_t)1 << lp[m].lgN) / 2 + 1, nlp = (2 * lp[m].Es + 1 + 3) / 4 * 4;
+        spec = std::max(spec, 16 * (2 * (size_t)lp[m].n_short * NK + NK * nlp));
+        crs = std::max(crs, 8 * (size_t)(2 * lp[m].Eu + 1) * (2 * lp[m].Ev + 1));
+        wcap = std::max(wcap, (2 * pl.g[m].wu + 1) * (2 * pl.g[m].wv + 1));
+    }
+    const size_t per_pair = 4 * (pstride + tmp_floats) + 8 * sstride + spec + crs + 3 * 4 * (size_t)wcap + 64;
+    size_t budget = (size_t)6 << 30;
+    if (const char* e = std::getenv("MI_NCC_CHUNK_MB")) budget = (size_t)std::max(64, std::atoi(e)) << 20;
+    const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, budget / per_pair));
+
+    MI_TRY(grow(ws.fbuf, 4 * pstride * chunk));
+    MI_TRY(grow(ws.sat, 8 * sstride * chunk));
+    MI_TRY(grow(ws.mip_tmp, 4 * tmp_floats * chunk));
+    MI_TRY(grow(ws.outw, 4 * (size_t)3 * wcap * chunk));
+    MI_TRY(grow(ws.outi, sizeof(int) * 3 * 4 * chunk));
+    MI_TRY(grow(ws.tab, sizeof(void*) * 2 * chunk));
+    // host staging for ALL chunks: the single synchronisation comes after the last chunk
+    MI_TRY(ws.pin_tab.reserve(sizeof(void*) * 2 * (size_t)n));
+    MI_TRY(ws.pin_w.reserve(4 * (size_t)3 * wcap * n));
+    MI_TRY(ws.pin_i.reserve(sizeof(int) * 3 * 4 * (size_t)n));
+    const float** htab = ws.pin_tab.as<const float*>();
+    for (int q = 0; q < n; ++q) {
+        MI_REQUIRE(a_ptrs[q] && b_ptrs[q], "mi_ncc_mips_batch: null tile");
+        htab[2 * q] = a_ptrs[q];
+        htab[2 * q + 1] = b_ptrs[q];
+    }
+    const float margin = ncc_margin();
+    float* base = ws.fbuf.as<float>();
+    for (int c0 = 0; c0 < n; c0 += chunk) {
+        const int nc = std::min(chunk, n - c0);
+        MI_HIP(hipMemcpyAsync(ws.tab.p, htab + 2 * c0, sizeof(void*) * 2 * nc, hipMemcpyHostToDevice, s));
+        // the xz MIPs are merged with atomicMax and must start at 0 (libcrossmips.cpp:319-337); everything else is overwritten
+        MI_HIP(hipMemset2DAsync(base + pl.g[1].mip1, 4 * pstride, 0, 4 * (size_t)pl.g[1].dimu * pl.g[1].dimv, nc, s));
+        MI_HIP(hipMemset2DAsync(base + pl.g[1].mip2, 4 * pstride, 0, 4 * (size_t)pl.g[1].dimu * pl.g[1].dimv, nc, s));
+        dim3 grid((pl.dimj_v + 63) / 64, bands, 2 * nc);
+        hipLaunchKernelGGL(k_mips, grid, dim3(256), 0, s, (const float*)nullptr, (const float*)nullptr, ws.tab.as<const float*>(), pstride, pl.dimk,
+                           pl.dimi_v, pl.dimj_v, (size_t)dimi * dimj, dimj, pl.ai0, pl.aj0, base + pl.g[0].mip1, base + pl.g[1].mip1,
+                           base + pl.g[2].mip1, base + pl.g[0].mip2, base + pl.g[1].mip2, base + pl.g[2].mip2, ws.mip_tmp.as<float>());
+        MI_TRY(launch_check("k_mips"));
+        hipLaunchKernelGGL(k_mips_yz, dim3((pl.dimk * pl.dimj_v + 255) / 256, 2 * nc), dim3(256), 0, s, ws.mip_tmp.as<float>(), pstride, bands,
+                           pl.dimk, pl.dimj_v, base + pl.g[2].mip1, base + pl.g[2].mip2);
+        MI_TRY(launch_check("k_mips_yz"));
+        for (int m = 0; m < 3; ++m) {
+            const PlaneGeom& g = pl.g[m];
+            SatView v1, v2;
+            MI_TRY(prepare_plane(s, base + g.mip1, base + g.mip2, g.dimu, g.dimv, base + g.ps1, base + g.ps2, ws.sat.as<double>() + g.sat, &v1, &v2,
+                                 nc, pstride, sstride));
+            MI_TRY(lag_cross(dev, s, lp[m], base + g.mip1, base + g.mip2, pstride, nc, ws));
+            const RefineGeom rg = refine_geom(g, lp[m], P.maxIter, sstride, margin);
+            if (lp[m].lds_refine > 64 * 1024)
+                MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lag_refine), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp[m].lds_refine));
+            hipLaunchKernelGGL(k_lag_refine, dim3(nc), dim3(256), lp[m].lds_refine, s, rg, ws.sat.as<double>(), ws.cross.as<double>(), wcap,
+                               ws.outw.as<float>() + (size_t)m * chunk * wcap, ws.outi.as<int>() + (size_t)m * chunk * 4, (float*)nullptr);
+            MI_TRY(launch_check("k_lag_refine"));
+            MI_HIP(hipMemcpyAsync(ws.pin_w.as<float>() + ((size_t)m * n + c0) * wcap, ws.outw.as<float>() + (size_t)m * chunk * wcap,
+                                  4 * (size_t)nc * wcap, hipMemcpyDeviceToHost, s));
+            MI_HIP(hipMemcpyAsync(ws.pin_i.as<int>() + ((size_t)m * n + c0) * 4, ws.outi.as<int>() + (size_t)m * chunk * 4, sizeof(int) * 4 * nc,
+                                  hipMemcpyDeviceToHost, s));
+        }
+    }
+    MI_HIP(hipStreamSynchronize(s));
+
+    // compute_Alignment (compute_funcs.cu:1597-1609) on the returned windows
+    for (int q = 0; q < n; ++q) {
+        const mi_ncc_params& Pq = params[q];
+        int w1[3], w2[3], du[3], dv[3];
+        float peak[3];
+        float tight = FLT_MAX;  // smallest margin of any comparison the host rules made
+        bool redo = false;
+        for (int m = 0; m < 3; ++m) {
+            const PlaneGeom& g = pl.g[m];
+            const float* win = ws.pin_w.as<float>() + ((size_t)m * n + q) * wcap;
+            const int* oi = ws.pin_i.as<int>() + ((size_t)m * n + q) * 4;
+            du[m] = oi[0];
+            dv[m] = oi[1];
+            if (oi[3]) redo = true;
+            const int rowlen = 2 * g.wv + 1, c = g.wu * rowlen + g.wv;
+            peak[m] = win[c];
+            if (oi[2]) { w1[m] = w2[m] = Pq.INF_W; continue; }
+            w2[m] = peak_half_width(Pq, win, c, 1, g.wv, g.wv, &tight);
+            w1[m] = peak_half_width(Pq, win, c, rowlen, g.wu, g.wv, &tight);
+        }
+        mi_ncc_descr r;
+        combine_axis(Pq, &r, 0, du[0], peak[0], w1[0], du[1], peak[1], w1[1], &tight);  // V: xy rows, xz rows
+        combine_axis(Pq, &r, 1, dv[0], peak[0], w2[0], du[2], peak[2], w1[2], &tight);  // H: xy cols, yz rows
+        combine_axis(Pq, &r, 2, dv[1], peak[1], w2[1], dv[2], peak[2], w2[2], &tight);  // D: xz cols, yz cols
+        if (side == MI_NORTH_SOUTH) r.coord[0] += ni; else r.coord[1] += nj;           // libcrossmips.cpp:483-486
+        if (redo || tight < margin) { careful[q] = 1; continue; }
+        careful[q] = 0;
+        out[q] = r;
+    }
+    return MI_OK;
+}
+
+// NCC map of one pair of MIPs through the lag transform (building block for the parity tests)
+int ncc_lag_map(int dev, hipStream_t s, const float* mip1, const float* mip2, int dimu, int dimv, int delayu, int delayv, float* map) {
+    PlaneGeom g{};
+    g.dimu = dimu; g.dimv = dimv; g.delayu = delayu; g.delayv = delayv; g.wu = 0; g.wv = 0; g.sat = 0;
+    g.tiled = (dimu / TILE) * (dimv / TILE) > 0;
+    const LagPlane lp = plan_lag_plane(g, 0);
+    MI_REQUIRE(lp.ok, "compute_NCC_map: extents do not fit the lag transform");
+    std::unique_ptr<LagWorkspace> wsp = take_lag_ws(dev);
+    if (!wsp) return fail(MI_ERR_NOMEM, "compute_NCC_map: out of host memory");
+    LagWorkspace& ws = *wsp;
+    struct Giver { std::unique_ptr<LagWorkspace>& p; ~Giver() { give_lag_ws(std::move(p)); } } giver{wsp};
+    const int nt = (dimu / TILE) * (dimv / TILE);
+    const SatLayout L(dimu, dimv);
+    DevBuf ps;
+    MI_TRY(ps.alloc(sizeof(float) * 2 * (size_t)(nt > 0 ? nt : 1)));
+    MI_TRY(grow(ws.sat, 8 * L.total));
+    MI_TRY(grow(ws.outw, 4 * 4));
+    MI_TRY(grow(ws.outi, sizeof(int) * 4));
+    SatView v1, v2;
+    MI_TRY(prepare_plane(s, mip1, mip2, dimu, dimv, ps.as<float>(), ps.as<float>() + (nt > 0 ? nt : 0), ws.sat.as<double>(), &v1, &v2));
+    MI_TRY(lag_cross(dev, s, lp, mip1, mip2, 0, 1, ws));
+    const RefineGeom rg = refine_geom(g, lp, 0, L.total, 0.0f);
+    if (lp.lds_refine > 64 * 1024)
+        MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lag_refine), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp.lds_refine));
+    hipLaunchKernelGGL(k_lag_refine, dim3(1), dim3(256), lp.lds_refine, s, rg, ws.sat.as<double>(), ws.cross.as<double>(), 1, ws.outw.as<float>(),
+                       ws.outi.as<int>(), map);
+    MI_TRY(launch_check("k_lag_refine"));
+    MI_HIP(hipStreamSynchronize(s));
+    return MI_OK;
+}
+
+void ncc_lag_drop_cached(int dev) {
+    std::vector<std::unique_ptr<LagWorkspace>> drop;
+    std::lock_guard<std::mutex> lock(g_lag_mu);
+    for (size_t i = 0; i < g_lag_ws.size();)
+        if (dev < 0 || g_lag_ws[i]->dev == dev) { drop.push_back(std::move(g_lag_ws[i])); g_lag_ws.erase(g_lag_ws.begin() + i); }
+        else ++i;
+}
+
+}  // namespace mi

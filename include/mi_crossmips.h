@@ -62,7 +62,10 @@ int mi_ncc_mips_host(int dev, void* stream, const float* A, const float* B, int 
 
 /* n_pairs independent pairs with device-resident tiles: pair q aligns tiles[a_idx[q]] and
  * tiles[b_idx[q]] (all tiles dimk*dimi*dimj) with side[q], nominal offsets ni[q]/nj[q] and its own
- * in-out params[q]; results in out[q].  All index/param arrays are [host].  Synchronises. */
+ * in-out params[q]; results in out[q].  All index/param arrays are [host].  Pairs of equal geometry go
+ * through the device together (MIPs, tables, lag-transform cross terms, neighbourhood refinement: a fixed
+ * number of launches and ONE synchronisation per group); only the final windows return to the host rules.
+ * Synchronises. */
 int mi_ncc_mips_batch(int dev, void* stream, int n_pairs, const float* const* tiles,
                       const int* a_idx, const int* b_idx, int dimk, int dimi, int dimj,
                       const int* ni, const int* nj, int delayk, int delayi, int delayj, const int* side,
@@ -77,9 +80,14 @@ int mi_ncc_compute_mips(int dev, void* stream, const float* A, const float* B, i
                         float* xy2, float* xz2, float* yz2);
 
 /* compute_NCC_map (compute_funcs.cu:939-1160): map[(2*delayu+1)*(2*delayv+1)] (device) from two
- * dimu x dimv MIPs (device); fp64 accumulation, one work-group per (u, v). */
+ * dimu x dimv MIPs (device).  Window means / variances from fp64 summed-area tables (with the reference's
+ * float tile sums), cross terms in fp64: shift by shift from LDS-staged MIP rows (mi_ncc_compute_map: blocks of
+ * 4 x 8 shifts per wave), or through the lag transform along the long axis of the MIP that the batched pair
+ * pipeline uses (mi_ncc_compute_map_lag: fp64 FFT along the long axis, direct correlation along the short one). */
 int mi_ncc_compute_map(int dev, void* stream, const float* mip1, const float* mip2, int dimu, int dimv,
                        int delayu, int delayv, float* map);
+int mi_ncc_compute_map_lag(int dev, void* stream, const float* mip1, const float* mip2, int dimu, int dimv,
+                           int delayu, int delayv, float* map);
 
 #ifdef __cplusplus
 }
