@@ -241,6 +241,14 @@ class PDAlgoMIPNCC:
         return out
 
 
+def ncc_stats(reset=False) -> dict:
+    """Counters of the library (mi_ncc_stats): pairs finished by the batched pipeline / by the per-pair path, and map entries
+    recomputed in the reference's two-pass form to take decisions that were inside the resolution of the map values."""
+    out = (C.c_longlong * 3)()
+    lib().mi_ncc_stats(out, 1 if reset else 0)
+    return {"pairs_batched": int(out[0]), "pairs_per_pair_path": int(out[1]), "entries_recomputed_exactly": int(out[2])}
+
+
 def enumerate_pairs(n_rows: int, n_cols: int):
     """East and south neighbour pairs of an n_rows x n_cols tile grid: 2RC - R - C pairs
     (StackStitcher.cpp:217,223-374).  Yields (row, col, row_b, col_b, direction)."""
@@ -292,23 +300,40 @@ def compute_displacements(tiles, overlap_V: int, overlap_H: int, displ_max_V=S_D
     ni = (C.c_int * n)(*[dim_V - overlap_V if d == dir_vertical else 0 for *_, d in pairs])
     nj = (C.c_int * n)(*[dim_H - overlap_H if d == dir_horizontal else 0 for *_, d in pairs])
     side = (C.c_int * n)(*[d for *_, d in pairs])
+    p0 = NccParams()
+    lib().mi_ncc_default_params(displ_max_V, displ_max_H, displ_max_D, C.byref(p0))
+    inf_w = p0.INF_W
     params = (NccParams * n)()
-    for q in range(n):
-        lib().mi_ncc_default_params(displ_max_V, displ_max_H, displ_max_D, C.byref(params[q]))
-    inf_w = params[0].INF_W
+    for q in range(n):                       # one parameter block per pair (the callee clamps wRangeThr_* in place)
+        C.memmove(C.byref(params[q]), C.byref(p0), C.sizeof(NccParams))
     out = (NccDescr * n)()
     check(lib().mi_ncc_mips_batch(dev.index, capi.current_stream_ptr(dev), n, ptrs, a_idx, b_idx, dim_D, dim_V, dim_H,
                                   ni, nj, displ_max_D, displ_max_V, displ_max_H, side, params, out))
+    # the records of all pairs at once: NccDescr = 3 ints, 3 floats, 3 ints; evalReliability (DisplacementMIPNCC.cpp:130-147)
+    # vectorised with the same float / double steps as the per-record method
+    raw = np.frombuffer(out, dtype=np.int32).reshape(n, 9)
+    coords, widths = raw[:, 0:3], raw[:, 6:9]
+    peaks = raw[:, 3:6].copy().view(np.float32)
+    f = np.float32
+    wn = (f(100.0) - (widths.astype(f) * f(100.0) / f(inf_w))) / f(100.0)
+    with np.errstate(invalid="ignore"):
+        rel = np.sqrt(S_NCC_WIDTH_WEIGHT * wn.astype(np.float64) ** 2 + S_NCC_PEAK_WEIGHT * peaks.astype(np.float64) ** 2).astype(f)
+    praw = np.frombuffer(params, dtype=np.int32).reshape(n, C.sizeof(NccParams) // 4)
+    o_i = NccParams.wRangeThr_i.offset // 4
+    thr = praw[:, o_i:o_i + 3]
+    delays = [displ_max_V, displ_max_H, displ_max_D]
     res = {}
-    for q, key in enumerate(pairs):
-        d, p = out[q], params[q]
-        rec = DisplacementMIPNCC(list(d.coord), [float(v) for v in d.NCC_maxs], list(d.NCC_widths),
-                                 [displ_max_V, displ_max_H, displ_max_D],
-                                 [p.wRangeThr_i, p.wRangeThr_j, p.wRangeThr_k], [inf_w] * 3)
-        for k in range(3):  # VirtualVolume::insertDisplacement (vmVirtualVolume.cpp:279-306)
-            rec.evalReliability(k)
-        rec.VHD_def_coords = [int(ni[q]), int(nj[q]), 0]
-        res[key] = rec
+    import gc
+    gc_on = gc.isenabled()
+    gc.disable()    # a few thousand small containers: the cyclic collector's passes over a torch-sized heap cost 0.1 ms per record
+    try:
+        cl, pl, wl, tl, rl = coords.tolist(), peaks.astype(np.float64).tolist(), widths.tolist(), thr.tolist(), rel.astype(np.float64).tolist()
+        for q, key in enumerate(pairs):
+            res[key] = DisplacementMIPNCC(cl[q], pl[q], wl[q], list(delays), tl[q], [inf_w] * 3,
+                                          [int(ni[q]), int(nj[q]), 0], rl[q])                       # vmVirtualVolume.cpp:279-306
+    finally:
+        if gc_on:
+            gc.enable()
     return res
 
 

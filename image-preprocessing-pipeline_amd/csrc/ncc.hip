@@ -16,10 +16,23 @@
 //                 "missing entries" of the neighbourhood refinement alike.
 // Host side (this file, plain C++): argmax, neighbourhood refinement, peak widths and the final
 // alignment rules, kept bit-identical in float/int arithmetic to compute_funcs.cu:160-342,1294-1609.
+#include <atomic>
 #include <map>
 
 #include "ncc_core.h"
 #include "ncc_lag.h"
+
+namespace mi {
+static std::atomic<long long> g_ncc_stats[3];
+void ncc_count(int which, long long n) { g_ncc_stats[which] += n; }
+}  // namespace mi
+
+extern "C" void mi_ncc_stats(long long* out3, int reset) {
+    for (int i = 0; i < 3; ++i) {
+        if (out3) out3[i] = mi::g_ncc_stats[i].load();
+        if (reset) mi::g_ncc_stats[i].store(0);
+    }
+}
 
 namespace mi {
 // the cached pair slots of a device (-1: all) are destroyed; their buffers return to the pool (mi_release_cached_memory)
@@ -50,6 +63,7 @@ int pair_direct(hipStream_t s, const float* A, const float* B, int dimk, int dim
     MI_TRY(plan_pair(dimk, dimi, dimj, 0, ni, nj, delayk, delayi, delayj, side, p, pl));
     Workspace ws;
     MI_TRY(pair_enqueue(s, A, B, dimi, dimj, pl, ws));
+    ncc_count(1, 1);
     return pair_finish(s, ni, nj, side, p, pl, ws, out);
 }
 }  // namespace
@@ -203,6 +217,7 @@ extern "C" int mi_ncc_mips_batch(int dev, void* stream, int n_pairs, const float
                 const int f = todo[fi];
                 Slot& pr = slot[(k - 1) & 1];
                 rc = pair_finish(pr.s, ni[f], nj[f], side[f], &params[f], pr.pl, pr.ws, &out[f]);
+                ncc_count(1, 1);
             }
             if (qi >= n_todo) break;
         }

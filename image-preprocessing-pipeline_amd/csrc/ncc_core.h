@@ -20,6 +20,12 @@
 
 using namespace mi;
 
+namespace mi {
+// cumulative counters behind mi_ncc_stats (defined in ncc.hip): pairs finished by the batched pipeline, pairs finished by the
+// per-pair (careful) path, entries recomputed in the two-pass form
+void ncc_count(int which, long long n);
+}
+
 namespace {
 
 constexpr int TILE = 32;  // TILE_SIDE, compute_funcs.h:66
@@ -276,19 +282,27 @@ __global__ __launch_bounds__(64) void k_sat_rows(const float* __restrict__ m1, c
     }
 }
 
-// column pass, in place: one wave per (column, table): running sum down the rows
+// column pass, in place: a wave owns 64 neighbouring columns of one table (blockIdx.y) and walks down the rows with a running
+// sum per lane -- every access is a 512-byte row segment; the loads of UNR rows are in flight together (they do not depend on
+// the running sums).  The first version gave each wave ONE column (lanes = rows, stride of a whole table row between lanes):
+// 88 us per C5 pair, more than the six MIPs.
 __global__ __launch_bounds__(64) void k_sat_cols(size_t sstride, int dimu, int dimv, double* __restrict__ P1, double* __restrict__ Q1,
                                                  double* __restrict__ P2, double* __restrict__ Q2) {
     double* S = (blockIdx.y == 0 ? P1 : (blockIdx.y == 1 ? Q1 : (blockIdx.y == 2 ? P2 : Q2))) + (size_t)blockIdx.z * sstride;
-    const int w1 = dimv + 1, lane = threadIdx.x, j = blockIdx.x + 1;
-    double carry = 0.0;
-    for (int i0 = 1; i0 <= dimu; i0 += 64) {
-        const int i = i0 + lane;
-        const double v = i <= dimu ? S[(size_t)i * w1 + j] : 0.0;
-        const double sc = wave_inclusive_scan(v) + carry;
-        if (i <= dimu) S[(size_t)i * w1 + j] = sc;
-        carry = __shfl(sc, 63, 64);
+    const int w1 = dimv + 1, j = blockIdx.x * 64 + threadIdx.x + 1;
+    if (j > dimv) return;
+    constexpr int UNR = 8;
+    double run = 0.0;
+    double* p = S + (size_t)w1 + j;  // table row 1
+    int i = 1;
+    for (; i + UNR - 1 <= dimu; i += UNR, p += (size_t)UNR * w1) {
+        double v[UNR];
+#pragma unroll
+        for (int q = 0; q < UNR; ++q) v[q] = p[(size_t)q * w1];
+#pragma unroll
+        for (int q = 0; q < UNR; ++q) { run += v[q]; p[(size_t)q * w1] = run; }
     }
+    for (; i <= dimu; ++i, p += w1) { run += *p; *p = run; }
 }
 
 // NCC cross terms, register-blocked.  A block is (4 u) x (8 v) shifts; a work-group takes a GROUP of up to 8 blocks that share
@@ -589,11 +603,53 @@ int prepare_plane(hipStream_t s, const float* m1, const float* m2, int dimu, int
     MI_TRY(launch_check("k_mip_mean"));
     hipLaunchKernelGGL(k_sat_rows, dim3(dimu + 1, 2, np), dim3(64), 0, s, m1, m2, pstride, sstride, dimu, dimv, c0a, c0b, P1, Q1, P2, Q2);
     MI_TRY(launch_check("k_sat_rows"));
-    hipLaunchKernelGGL(k_sat_cols, dim3(dimv, 4, np), dim3(64), 0, s, sstride, dimu, dimv, P1, Q1, P2, Q2);
+    hipLaunchKernelGGL(k_sat_cols, dim3((dimv + 63) / 64, 4, np), dim3(64), 0, s, sstride, dimu, dimv, P1, Q1, P2, Q2);
     MI_TRY(launch_check("k_sat_cols"));
     *v1 = SatView{P1, Q1, tiled ? T1 : nullptr, c0a};
     *v2 = SatView{P2, Q2, tiled ? T2 : nullptr, c0b};
     return MI_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ exact entries (two-pass form)
+// Resolution of the map values the fast paths produce (summed-area tables + blocked / lag-transform cross terms): a decision
+// whose operands are closer than this is re-taken on entries recomputed by k_ncc_exact.  MI_NCC_MARGIN overrides (tests).
+inline float decision_margin() {
+    static const float m = [] {
+        const char* e = std::getenv("MI_NCC_MARGIN");
+        return e ? (float)std::atof(e) : 4e-6f;
+    }();
+    return m;
+}
+
+// One work-group per listed entry {u, v, slot}: compute_NCC's own two-pass form (compute_funcs.cu:1163-1292) -- the window means
+// first (the reference's flavour: float tile sums + border pixels, here from the tables, identical to 1e-16), then
+//   num = sum f (t - tmean),  F1 = sum (f - fmean)^2,  F2 = sum (t - tmean)^2
+// by direct fp64 summation over the window (no algebraic rearrangement, no cancellation), lanes and waves added in a fixed order.
+__global__ __launch_bounds__(256) void k_ncc_exact(const float* __restrict__ m1, const float* __restrict__ m2, int dimu, int dimv, SatView s1, SatView s2,
+                                                   const int* __restrict__ entries, float* __restrict__ out) {
+    __shared__ double sh[4];
+    const int u = entries[3 * blockIdx.x], v = entries[3 * blockIdx.x + 1], slot = entries[3 * blockIdx.x + 2];
+    const int nr = dimu - abs(u), nc = dimv - abs(v);
+    if (nr <= 0 || nc <= 0) { if (threadIdx.x == 0) out[slot] = __int_as_float(0x7fc00000); return; }
+    const int r1 = max(u, 0), c1 = max(v, 0), r2 = max(-u, 0), c2 = max(-v, 0);
+    double fm, sf, F1s, tm, st, F2s;
+    window_stats(s1, dimu, dimv, r1, c1, nr, nc, &fm, &sf, &F1s);
+    window_stats(s2, dimu, dimv, r2, c2, nr, nc, &tm, &st, &F2s);
+    (void)sf; (void)st; (void)F1s; (void)F2s;
+    double num = 0.0, F1 = 0.0, F2 = 0.0;
+    const size_t n = (size_t)nr * nc;
+    for (size_t e = threadIdx.x; e < n; e += 256) {
+        const int i = (int)(e / nc), j = (int)(e - (size_t)i * nc);
+        const double f = (double)m1[(size_t)(r1 + i) * dimv + c1 + j], t = (double)m2[(size_t)(r2 + i) * dimv + c2 + j];
+        const double df = f - fm, dt = t - tm;
+        num += f * dt;
+        F1 += df * df;
+        F2 += dt * dt;
+    }
+    num = block_sum<256>(num, sh);
+    F1 = block_sum<256>(F1, sh);
+    F2 = block_sum<256>(F2, sh);
+    if (threadIdx.x == 0) out[slot] = (float)(num / sqrt(F1 * F2));  // flat window: 0 / 0 = NaN like the reference
 }
 
 // pinned host staging: pageable destinations make every small D2H / H2D a ~0.14 ms staged blit
@@ -629,7 +685,64 @@ struct Workspace {
     std::vector<int> host_groups, host_entries, host_slots;
     std::vector<long long> host_keys;
     PinnedBuf pin_groups, pin_res, pin_maps;
+    DevBuf exact_list, exact_out;   // k_ncc_exact: {u, v, slot} entries and their values
+    PinnedBuf pin_exact_in, pin_exact_out;
+    int n_exact = 0;                // entries recomputed exactly for the current pair (statistics / tests)
 };
+
+// values[q] = the exact NCC of shift uv[2q], uv[2q+1] of a plane.  Synchronises `s`.
+int exact_entries(hipStream_t s, const PlaneGeom& g, int plane, const float* d_base, Workspace& ws, const std::vector<int>& uv,
+                  std::vector<float>& values) {
+    const int n = (int)uv.size() / 2;
+    values.assign(n, 0.0f);
+    if (n == 0) return MI_OK;
+    MI_TRY(ws.pin_exact_in.reserve(sizeof(int) * 3 * (size_t)n));
+    MI_TRY(ws.pin_exact_out.reserve(sizeof(float) * (size_t)n));
+    if (ws.exact_list.bytes < sizeof(int) * 3 * (size_t)n || ws.exact_out.bytes < sizeof(float) * (size_t)n) {
+        MI_HIP(hipStreamSynchronize(s));
+        MI_TRY(ws.exact_list.alloc(sizeof(int) * 3 * (size_t)n * 2));
+        MI_TRY(ws.exact_out.alloc(sizeof(float) * (size_t)n * 2));
+    }
+    int* h = ws.pin_exact_in.as<int>();
+    for (int q = 0; q < n; ++q) { h[3 * q] = uv[2 * q]; h[3 * q + 1] = uv[2 * q + 1]; h[3 * q + 2] = q; }
+    MI_HIP(hipMemcpyAsync(ws.exact_list.p, h, sizeof(int) * 3 * (size_t)n, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_ncc_exact, dim3(n), dim3(256), 0, s, d_base + g.mip1, d_base + g.mip2, g.dimu, g.dimv, ws.v1[plane], ws.v2[plane],
+                       ws.exact_list.as<int>(), ws.exact_out.as<float>());
+    MI_TRY(launch_check("k_ncc_exact"));
+    MI_HIP(hipMemcpyAsync(ws.pin_exact_out.p, ws.exact_out.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, s));
+    MI_HIP(hipStreamSynchronize(s));
+    std::memcpy(values.data(), ws.pin_exact_out.p, sizeof(float) * (size_t)n);
+    ws.n_exact += n;
+    ncc_count(2, n);
+    return MI_OK;
+}
+
+// compute_MAX_ind (compute_funcs.cu:1294-1305) decided on exact values: every entry within the decision margin of the largest
+// value is recomputed by k_ncc_exact (once: `exact` remembers) before the first strict maximum is taken.  `to_uv(i, &u, &v)` maps
+// an index of `v` to its shift.
+template <class ToUV>
+int argmax_exact(hipStream_t s, const PlaneGeom& g, int plane, const float* d_base, Workspace& ws, float* v, int len, std::vector<unsigned char>& exact,
+                 ToUV to_uv, int* ind) {
+    const float margin = decision_margin();
+    for (int round = 0; round < 2; ++round) {
+        const int best = argmax_first(v, len);
+        if (!(v[best] == v[best])) { *ind = best; return MI_OK; }  // leading NaN: the reference keeps it whatever follows
+        std::vector<int> uv, idx;
+        int close = 0;
+        for (int i = 0; i < len; ++i)
+            if (v[i] == v[i] && v[best] - v[i] < margin) {
+                ++close;
+                if (!exact[i]) { int a, b; to_uv(i, &a, &b); uv.push_back(a); uv.push_back(b); idx.push_back(i); }
+            }
+        if (close < 2 || idx.empty()) { *ind = best; return MI_OK; }
+        std::vector<float> val;
+        MI_TRY(exact_entries(s, g, plane, d_base, ws, uv, val));
+        for (size_t q = 0; q < idx.size(); ++q) { v[idx[q]] = val[q]; exact[idx[q]] = 1; }
+    }
+    *ind = argmax_first(v, len);
+    return MI_OK;
+}
+
 
 // NCC values of one plane: the blocked cross terms + the finishing pass.  d_groups / d_entries == nullptr: the full map into
 // d_out; else the listed groups {u0, nb, v0[GW]} and entries {u, v, partial index, output slot}.  `partial` grows as needed.
@@ -672,14 +785,23 @@ int ncc_launch(hipStream_t s, const float* m1, const float* m2, int dimu, int di
 // re-centred up to maxIter times; entries exposed by a move are computed on the device.
 int refine_neighbourhood(hipStream_t s, const mi_ncc_params& P, const float* map, const PlaneGeom& g, int plane, const float* d_base,
                          Workspace& ws,
-                         std::vector<float>& win, int* du, int* dv, bool* failed) {
-    const int H = 2 * g.wu + 1, W = 2 * g.wv + 1, Wm = 2 * g.delayv + 1;
-    int ind_max = argmax_first(map, (2 * g.delayu + 1) * Wm);
+                         std::vector<float>& win, int* du, int* dv, bool* failed, std::vector<unsigned char>* exact_out = nullptr) {
+    const int H = 2 * g.wu + 1, W = 2 * g.wv + 1, Wm = 2 * g.delayv + 1, Hm = 2 * g.delayu + 1;
+    std::vector<float> mapv(map, map + (size_t)Hm * Wm);
+    std::vector<unsigned char> map_exact((size_t)Hm * Wm, 0);
+    int ind_max = 0;
+    MI_TRY(argmax_exact(s, g, plane, d_base, ws, mapv.data(), Hm * Wm, map_exact,
+                        [&](int i, int* a, int* b) { *a = i / Wm - g.delayu; *b = i % Wm - g.delayv; }, &ind_max));
+    map = mapv.data();
     const int initu = imin(imax(0, ind_max / Wm - g.wu), 2 * (g.delayu - g.wu));
     const int initv = imin(imax(0, ind_max % Wm - g.wv), 2 * (g.delayv - g.wv));
     MI_REQUIRE(initu >= 0 && initv >= 0, "CrossMIPs: negative index detected (initi)");
     win.assign((size_t)H * W, 0.0f);
-    for (int r = 0; r < H; ++r) std::memcpy(&win[(size_t)r * W], &map[(size_t)(initu + r) * Wm + initv], sizeof(float) * W);
+    std::vector<unsigned char> win_exact((size_t)H * W, 0), old_exact;
+    for (int r = 0; r < H; ++r) {
+        std::memcpy(&win[(size_t)r * W], &map[(size_t)(initu + r) * Wm + initv], sizeof(float) * W);
+        std::memcpy(&win_exact[(size_t)r * W], &map_exact[(size_t)(initu + r) * Wm + initv], W);
+    }
     *du = initu - g.delayu + g.wu;
     *dv = initv - g.delayv + g.wv;
     ind_max = W * (ind_max / Wm - initu) + (ind_max % Wm - initv);
@@ -689,14 +811,20 @@ int refine_neighbourhood(hipStream_t s, const mi_ncc_params& P, const float* map
     for (int it = 0; it < P.maxIter && ind_max != ind_ref; ++it) {
         const int deltau = ind_max / W - g.wu, deltav = ind_max % W - g.wv;
         old = win;
+        old_exact = win_exact;
         *du += deltau;
         *dv += deltav;
         miss.clear();
         for (int r = 0; r < H; ++r)
             for (int c = 0; c < W; ++c) {
                 const int sr = r + deltau, sc = c + deltav;
-                if (sr >= 0 && sr < H && sc >= 0 && sc < W) win[(size_t)r * W + c] = old[(size_t)sr * W + sc];
-                else { miss.push_back(r - g.wu + *du); miss.push_back(c - g.wv + *dv); miss.push_back(r * W + c); }
+                if (sr >= 0 && sr < H && sc >= 0 && sc < W) {
+                    win[(size_t)r * W + c] = old[(size_t)sr * W + sc];
+                    win_exact[(size_t)r * W + c] = old_exact[(size_t)sr * W + sc];
+                } else {
+                    miss.push_back(r - g.wu + *du); miss.push_back(c - g.wv + *dv); miss.push_back(r * W + c);
+                    win_exact[(size_t)r * W + c] = 0;
+                }
             }
         const int n_miss = (int)miss.size() / 3;
         MI_REQUIRE(n_miss == H * W - (H - std::abs(deltau)) * (W - std::abs(deltav)), "CrossMIPs: incomplete NCC map in compute_Neighborhood");
@@ -760,8 +888,11 @@ int refine_neighbourhood(hipStream_t s, const mi_ncc_params& P, const float* map
             MI_HIP(hipStreamSynchronize(s));
             for (int q = 0; q < n_miss; ++q) win[miss[3 * q + 2]] = res[miss[3 * q + 2]];
         }
-        ind_max = argmax_first(win.data(), H * W);
+        const int cu = *du, cv = *dv;
+        MI_TRY(argmax_exact(s, g, plane, d_base, ws, win.data(), H * W, win_exact,
+                            [&](int i, int* a, int* b) { *a = i / W - g.wu + cu; *b = i % W - g.wv + cv; }, &ind_max));
     }
+    if (exact_out) *exact_out = win_exact;
     if (ind_ref != ind_max) {
         *du += ind_max / W - g.wu;
         *dv += ind_max % W - g.wv;
@@ -889,25 +1020,46 @@ int pair_finish(hipStream_t s, int ni, int nj, int side, mi_ncc_params* p, const
     const float* host_maps = ws.pin_maps.as<float>();
 
     std::vector<float> win[3];
+    std::vector<unsigned char> wex[3];
     int du[3], dv[3];
     bool failed[3] = {false, false, false};
+    ws.n_exact = 0;
     for (int m = 0; m < 3; ++m)
         MI_TRY(refine_neighbourhood(s, *p, host_maps + (pl.g[m].map - pl.map_begin), pl.g[m], m, base, ws, win[m], &du[m], &dv[m],
-                                    &failed[m]));
-    // compute_Alignment (compute_funcs.cu:1597-1609)
-    int w1[3], w2[3];
-    float peak[3];
-    for (int m = 0; m < 3; ++m) {
-        const PlaneGeom& g = pl.g[m];
-        const int rowlen = 2 * g.wv + 1, c = g.wu * rowlen + g.wv;
-        peak[m] = win[m][c];
-        if (failed[m]) { w1[m] = w2[m] = p->INF_W; continue; }
-        w2[m] = peak_half_width(*p, win[m].data(), c, 1, g.wv, g.wv);
-        w1[m] = peak_half_width(*p, win[m].data(), c, rowlen, g.wu, g.wv);
+                                    &failed[m], &wex[m]));
+    // compute_Alignment (compute_funcs.cu:1597-1609).  Every comparison of the width / alignment rules reads entries of the row
+    // and the column through the window centre only: when one of them is decided by less than the resolution of the map values
+    // those entries are recomputed in the two-pass form and the rules run again on them.
+    for (int pass = 0; pass < 2; ++pass) {
+        int w1[3], w2[3];
+        float peak[3];
+        float tight = 3.0e38f;
+        for (int m = 0; m < 3; ++m) {
+            const PlaneGeom& g = pl.g[m];
+            const int rowlen = 2 * g.wv + 1, c = g.wu * rowlen + g.wv;
+            peak[m] = win[m][c];
+            if (failed[m]) { w1[m] = w2[m] = p->INF_W; continue; }
+            w2[m] = peak_half_width(*p, win[m].data(), c, 1, g.wv, g.wv, &tight);
+            w1[m] = peak_half_width(*p, win[m].data(), c, rowlen, g.wu, g.wv, &tight);
+        }
+        combine_axis(*p, out, 0, du[0], peak[0], w1[0], du[1], peak[1], w1[1], &tight);  // V: xy rows, xz rows
+        combine_axis(*p, out, 1, dv[0], peak[0], w2[0], du[2], peak[2], w1[2], &tight);  // H: xy cols, yz rows
+        combine_axis(*p, out, 2, dv[1], peak[1], w2[1], dv[2], peak[2], w2[2], &tight);  // D: xz cols, yz cols
+        if (pass == 1 || !(tight < decision_margin())) break;
+        for (int m = 0; m < 3; ++m) {
+            const PlaneGeom& g = pl.g[m];
+            const int H = 2 * g.wu + 1, W = 2 * g.wv + 1;
+            std::vector<int> uv, idx;
+            for (int r = 0; r < H; ++r)
+                for (int c = 0; c < W; ++c)
+                    if ((r == g.wu || c == g.wv) && !wex[m][(size_t)r * W + c]) {
+                        uv.push_back(r - g.wu + du[m]); uv.push_back(c - g.wv + dv[m]); idx.push_back(r * W + c);
+                    }
+            std::vector<float> val;
+            MI_TRY(exact_entries(s, g, m, base, ws, uv, val));
+            for (size_t q = 0; q < idx.size(); ++q) { win[m][idx[q]] = val[q]; wex[m][idx[q]] = 1; }
+        }
     }
-    combine_axis(*p, out, 0, du[0], peak[0], w1[0], du[1], peak[1], w1[1]);  // V: xy rows, xz rows
-    combine_axis(*p, out, 1, dv[0], peak[0], w2[0], du[2], peak[2], w1[2]);  // H: xy cols, yz rows
-    combine_axis(*p, out, 2, dv[1], peak[1], w2[1], dv[2], peak[2], w2[2]);  // D: xz cols, yz cols
     if (side == MI_NORTH_SOUTH) out->coord[0] += ni; else out->coord[1] += nj;  // libcrossmips.cpp:483-486
     return MI_OK;
 }

@@ -51,22 +51,60 @@ __device__ __forceinline__ int pos_of_freq(int k, int lgN) {
     return p;
 }
 
+// the inverse map: the frequency held at position p
+__device__ __forceinline__ int freq_of_pos(int p, int lgN) {
+    int k = 0, rem = lgN, sh = 0;
+    while (rem >= 2) {
+        k |= ((p >> (rem - 2)) & 3) << sh;
+        sh += 2;
+        rem -= 2;
+    }
+    if (rem == 1) k |= (p & 1) << sh;
+    return k;
+}
+
+// The N/2 + 1 frequencies 0 .. N/2 of a real signal's spectrum are kept in POSITION order ("slots"): slot s < N/2 is the s-th
+// position whose frequency is below N/2 (the top digit of the frequency is the lowest digit of the position: positions 4m, 4m+1
+// after a radix-4 last stage, 2m after a radix-2 one), slot N/2 is the position of frequency N/2.  The untangling pass of the
+// forward transform then reads LDS in (nearly) contiguous order -- in frequency order consecutive lanes sit N/4 elements apart,
+// a 16-way bank conflict -- and the per-frequency correlation does not care about the order of its frequencies.
+__device__ __forceinline__ int pos_of_slot(int s, int lgN) {
+    const int half = 1 << (lgN - 1);
+    if (lgN & 1) return s < half ? 2 * s : 1;
+    return s < half ? 4 * (s >> 1) + (s & 1) : 2;
+}
+
 __device__ void fft_dif(cplx* __restrict__ x, int lgN, const cplx* __restrict__ tw) {
     const int N = 1 << lgN;
     int lgL = lgN;
+    constexpr int BF = 4;  // butterflies per thread and step: their 16 LDS reads and 12 table loads are issued before any store
     while (lgL >= 2) {
         const int lgq = lgL - 2, q = 1 << lgq, sh = lgN - lgL;
-        for (int idx = threadIdx.x; idx < (N >> 2); idx += blockDim.x) {
-            const int t = idx & (q - 1), b = (idx >> lgq) << lgL;
-            cplx* p = x + b + t;
-            const cplx a0 = p[0], a1 = p[q], a2 = p[2 * q], a3 = p[3 * q];
-            const cplx s02 = cadd(a0, a2), d02 = csub(a0, a2), s13 = cadd(a1, a3), d13 = csub(a1, a3);
-            const cplx y1 = make_double2(d02.x + d13.y, d02.y - d13.x);  // d02 - i d13
-            const cplx y3 = make_double2(d02.x - d13.y, d02.y + d13.x);  // d02 + i d13
-            p[0] = cadd(s02, s13);
-            p[q] = cmul(y1, tw[t << sh]);
-            p[2 * q] = cmul(csub(s02, s13), tw[(2 * t) << sh]);
-            p[3 * q] = cmul(y3, tw[(3 * t) << sh]);
+        for (int i0 = threadIdx.x; i0 < (N >> 2); i0 += BF * blockDim.x) {
+            cplx a[BF][4], w[BF][3];
+            cplx* ptr[BF];
+#pragma unroll
+            for (int u = 0; u < BF; ++u) {
+                const int idx = i0 + u * blockDim.x;
+                const bool ok = idx < (N >> 2);
+                const int t = idx & (q - 1), b = (idx >> lgq) << lgL;
+                ptr[u] = ok ? x + b + t : nullptr;
+                if (ok) {
+                    a[u][0] = ptr[u][0]; a[u][1] = ptr[u][q]; a[u][2] = ptr[u][2 * q]; a[u][3] = ptr[u][3 * q];
+                    w[u][0] = tw[t << sh]; w[u][1] = tw[(2 * t) << sh]; w[u][2] = tw[(3 * t) << sh];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < BF; ++u) {
+                if (!ptr[u]) continue;
+                const cplx s02 = cadd(a[u][0], a[u][2]), d02 = csub(a[u][0], a[u][2]), s13 = cadd(a[u][1], a[u][3]), d13 = csub(a[u][1], a[u][3]);
+                const cplx y1 = make_double2(d02.x + d13.y, d02.y - d13.x);  // d02 - i d13
+                const cplx y3 = make_double2(d02.x - d13.y, d02.y + d13.x);  // d02 + i d13
+                ptr[u][0] = cadd(s02, s13);
+                ptr[u][q] = cmul(y1, w[u][0]);
+                ptr[u][2 * q] = cmul(csub(s02, s13), w[u][1]);
+                ptr[u][3 * q] = cmul(y3, w[u][2]);
+            }
         }
         __syncthreads();
         lgL -= 2;
@@ -82,7 +120,7 @@ __device__ void fft_dif(cplx* __restrict__ x, int lgN, const cplx* __restrict__ 
 }
 
 // forward lag transform of short-axis line j (blockIdx.x) of pair blockIdx.y: element i of the line = m[i * ls + j * ss]
-__global__ __launch_bounds__(256) void k_lag_fwd(const float* __restrict__ m1, const float* __restrict__ m2, size_t pstride, int n_long, int n_short,
+__global__ __launch_bounds__(512) void k_lag_fwd(const float* __restrict__ m1, const float* __restrict__ m2, size_t pstride, int n_long, int n_short,
                                                  int ls, int ss, int lgN, const cplx* __restrict__ tw, cplx* __restrict__ SF, cplx* __restrict__ ST) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lag_lds[];
     cplx* x = reinterpret_cast<cplx*>(lag_lds);
@@ -95,10 +133,11 @@ __global__ __launch_bounds__(256) void k_lag_fwd(const float* __restrict__ m1, c
     fft_dif(x, lgN, tw);
     cplx* of = SF + ((size_t)blockIdx.y * n_short + j) * NK;
     cplx* ot = ST + ((size_t)blockIdx.y * n_short + j) * NK;
-    for (int k = threadIdx.x; k < NK; k += blockDim.x) {
-        const cplx zk = x[pos_of_freq(k, lgN)], zn = x[pos_of_freq((N - k) & (N - 1), lgN)];
-        of[k] = make_double2(0.5 * (zk.x + zn.x), 0.5 * (zk.y - zn.y));   // (Z[k] + conj Z[N-k]) / 2
-        ot[k] = make_double2(0.5 * (zk.y + zn.y), -0.5 * (zk.x - zn.x));  // (Z[k] - conj Z[N-k]) / (2 i)
+    for (int sl = threadIdx.x; sl < NK; sl += blockDim.x) {
+        const int p = pos_of_slot(sl, lgN), k = freq_of_pos(p, lgN);
+        const cplx zk = x[p], zn = x[pos_of_freq((N - k) & (N - 1), lgN)];
+        of[sl] = make_double2(0.5 * (zk.x + zn.x), 0.5 * (zk.y - zn.y));   // (Z[k] + conj Z[N-k]) / 2
+        ot[sl] = make_double2(0.5 * (zk.y + zn.y), -0.5 * (zk.x - zn.x));  // (Z[k] - conj Z[N-k]) / (2 i)
     }
 }
 
@@ -163,7 +202,7 @@ __global__ __launch_bounds__(256) void k_lag_mac(const cplx* __restrict__ SF, co
 
 // inverse lag transform of two short-axis lags (2 * blockIdx.x, + 1) of pair blockIdx.y: c_a[n] + i c_b[n] = FFT(conj C_a + i conj C_b) / N
 // (both c real); the long-axis lags [-El, El] go to cross[(u + Eu) * (2 Ev + 1) + (v + Ev)]
-__global__ __launch_bounds__(256) void k_lag_inv(const cplx* __restrict__ CH, int NK, int lgN, int Es, int El, int long_is_u, int Eu, int Ev,
+__global__ __launch_bounds__(512) void k_lag_inv(const cplx* __restrict__ CH, int NK, int lgN, int Es, int El, int long_is_u, int Eu, int Ev,
                                                  const cplx* __restrict__ tw, double* __restrict__ cross) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lag_lds[];
     cplx* x = reinterpret_cast<cplx*>(lag_lds);
@@ -171,9 +210,10 @@ __global__ __launch_bounds__(256) void k_lag_inv(const cplx* __restrict__ CH, in
     const int sa = 2 * blockIdx.x, sb = sa + 1;
     const bool has_b = sb < nlag;
     const cplx* src = CH + (size_t)blockIdx.y * NK * nlp;
-    for (int k = threadIdx.x; k < NK; k += blockDim.x) {
-        const cplx xa = src[(size_t)k * nlp + sa];
-        const cplx xb = has_b ? src[(size_t)k * nlp + sb] : make_double2(0.0, 0.0);
+    for (int sl = threadIdx.x; sl < NK; sl += blockDim.x) {
+        const int k = freq_of_pos(pos_of_slot(sl, lgN), lgN);
+        const cplx xa = src[(size_t)sl * nlp + sa];
+        const cplx xb = has_b ? src[(size_t)sl * nlp + sb] : make_double2(0.0, 0.0);
         x[k] = make_double2(xa.x + xb.y, -xa.y + xb.x);                              // conj(Xa) + i conj(Xb)
         if (k > 0 && k < N / 2) x[N - k] = make_double2(xa.x - xb.y, xa.y + xb.x);   // Xa + i Xb  (= conj X[N-k] terms)
     }
@@ -325,7 +365,7 @@ __global__ __launch_bounds__(256) void k_lag_refine(RefineGeom g, const double* 
 struct LagPlane {
     bool long_is_u;
     int n_long, n_short, ls, ss, lgN, El, Es, Eu, Ev;
-    int KT, JP, FW, TW;
+    int KT, JP, FW, TW, fft_threads;
     size_t lds_fft, lds_mac, lds_refine;
     bool ok;
 };
@@ -358,11 +398,14 @@ LagPlane plan_lag_plane(const PlaneGeom& g, int maxIter) {
     p.FW = (p.n_short + 2 * PAD + 15) / 16 * 16 + 1;  // rows one 16-byte slot apart in the banks
     p.TW = (p.n_short + 15) / 16 * 16 + 1;
     const size_t row = sizeof(double) * 2 * (size_t)(p.FW + p.TW);
-    p.KT = (int)std::min<size_t>(8, (64 * 1024) / row);
+    // four frequencies per work-group: with rows one 16-byte slot apart and lanes ordered (frequency fastest, then lag block) the
+    // 16-byte LDS reads of a wave are conflict-free; the j range is cut into JP parts so that all 256 threads have an item
+    p.KT = (int)std::min<size_t>(4, (48 * 1024) / row);
     if (p.KT < 1) p.KT = 1;
     const int nvb = (2 * p.Es + 1 + 3) / 4;
     while (p.KT > 1 && p.KT * nvb > 256) --p.KT;
     p.JP = std::max(1, std::min(8, 256 / (p.KT * nvb)));
+    p.fft_threads = p.lgN >= 11 ? 512 : 256;
     p.lds_mac = std::max(row * p.KT, sizeof(double) * 2 * 4 * (size_t)p.JP * nvb * p.KT);
     const int Hm = 2 * g.delayu + 1, Wm = 2 * g.delayv + 1, H = 2 * g.wu + 1, W = 2 * g.wv + 1;
     p.lds_refine = sizeof(float) * ((size_t)Hm * Wm + 2 * (size_t)H * W);
@@ -439,7 +482,7 @@ int lag_cross(int dev, hipStream_t s, const LagPlane& lp, const float* m1, const
     MI_TRY(grow(ws.cross, sizeof(double) * (size_t)np * (2 * lp.Eu + 1) * (2 * lp.Ev + 1)));
     if (lp.lds_fft > 64 * 1024)
         MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lag_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp.lds_fft));
-    hipLaunchKernelGGL(k_lag_fwd, dim3(lp.n_short, np), dim3(256), lp.lds_fft, s, m1, m2, pstride, lp.n_long, lp.n_short, lp.ls, lp.ss, lp.lgN, tw,
+    hipLaunchKernelGGL(k_lag_fwd, dim3(lp.n_short, np), dim3(lp.fft_threads), lp.lds_fft, s, m1, m2, pstride, lp.n_long, lp.n_short, lp.ls, lp.ss, lp.lgN, tw,
                        ws.SF.as<cplx>(), ws.ST.as<cplx>());
     MI_TRY(launch_check("k_lag_fwd"));
     if (lp.lds_mac > 64 * 1024)
@@ -449,7 +492,7 @@ int lag_cross(int dev, hipStream_t s, const LagPlane& lp, const float* m1, const
     MI_TRY(launch_check("k_lag_mac"));
     if (lp.lds_fft > 64 * 1024)
         MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lag_inv), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp.lds_fft));
-    hipLaunchKernelGGL(k_lag_inv, dim3((nlag + 1) / 2, np), dim3(256), lp.lds_fft, s, ws.CH.as<cplx>(), NK, lp.lgN, lp.Es, lp.El, lp.long_is_u ? 1 : 0,
+    hipLaunchKernelGGL(k_lag_inv, dim3((nlag + 1) / 2, np), dim3(lp.fft_threads), lp.lds_fft, s, ws.CH.as<cplx>(), NK, lp.lgN, lp.Es, lp.El, lp.long_is_u ? 1 : 0,
                        lp.Eu, lp.Ev, tw, ws.cross.as<double>());
     return launch_check("k_lag_inv");
 }
@@ -467,13 +510,7 @@ RefineGeom refine_geom(const PlaneGeom& g, const LagPlane& lp, int maxIter, size
 
 namespace mi {
 
-float ncc_margin() {
-    static const float m = [] {
-        const char* e = std::getenv("MI_NCC_MARGIN");
-        return e ? (float)std::atof(e) : 4e-6f;
-    }();
-    return m;
-}
+float ncc_margin() { return decision_margin(); }
 
 bool ncc_lag_supported(int dimk, int dimi, int dimj, int ni, int nj, int delayk, int delayi, int delayj, int side, const mi_ncc_params* p) {
     mi_ncc_params q = *p;
@@ -599,6 +636,7 @@ int ncc_lag_group(int dev, hipStream_t s, int n, const float* const* a_ptrs, con
         if (redo || tight < margin) { careful[q] = 1; continue; }
         careful[q] = 0;
         out[q] = r;
+        ncc_count(0, 1);
     }
     return MI_OK;
 }

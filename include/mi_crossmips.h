@@ -71,6 +71,12 @@ int mi_ncc_mips_batch(int dev, void* stream, int n_pairs, const float* const* ti
                       const int* ni, const int* nj, int delayk, int delayi, int delayj, const int* side,
                       mi_ncc_params* params, mi_ncc_descr* out);
 
+/* Cumulative counters of this process: out3[0] pairs finished by the batched pipeline, out3[1] pairs finished by the per-pair
+ * path (geometries the lag transform does not take, MI_NCC_DIRECT=1, and pairs handed back because a decision was inside the
+ * resolution of the map values), out3[2] map entries recomputed in the reference's two-pass fp64 form
+ * (compute_funcs.cu:1163-1292) to take such decisions.  reset != 0 clears them after reading. */
+void mi_ncc_stats(long long* out3, int reset);
+
 /* ---- building blocks (exposed for parity tests against the reference's exported helpers) ------ */
 
 /* compute_3_MIPs (compute_funcs.cu:502-521) on the overlap views selected by (side, ni, nj):

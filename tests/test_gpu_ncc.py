@@ -201,3 +201,49 @@ def test_grid_batch_recovers_jitter(dev):
     shards = [crossmips.compute_displacements(tiles, ov, ov, 8, 8, 3, rank=k, world_size=2) for k in range(2)]
     assert set(shards[0]) | set(shards[1]) == set(res) and not (set(shards[0]) & set(shards[1]))
     assert 0.0 <= next(iter(res.values())).evalReliability(0) <= 1.0
+
+
+# ------------------------------------------------------------------ cases that sit on a tie (tests/golden/make_ncc_tie_golden.py)
+def _tie_golden():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ncc_golden_ties.npz"))
+
+
+@pytest.mark.parametrize("direct", [False, True], ids=["batched_pipeline", "per_pair_path"])
+@pytest.mark.parametrize("name", ["dup_0", "dup_1", "dup_2", "thr_0", "thr_1", "thr_2", "amax_0", "amax_1", "amax_2"])
+def test_tie_cases_are_decided_like_the_reference(dev, name, direct, monkeypatch):
+    """Duplicate maxima (several map entries equal to 1.0f: compute_MAX_ind's first strict maximum decides), an entry within
+    1e-6 of widthThr * peak (the `<= thr` scans of compute_NCC_width decide on the last bits), two largest entries < 2e-6 apart.
+    Such decisions lie inside the resolution of the fast map values: the pair is re-decided on entries recomputed in the
+    reference's two-pass form (k_ncc_exact) -- the counters show that path was taken -- and every integer equals the
+    reference's."""
+    from ipp_amd import crossmips
+    if direct:
+        monkeypatch.setenv("MI_NCC_DIRECT", "1")
+    g = _tie_golden()
+    side, overlap, *dmax = (int(v) for v in g[f"{name}/recipe"])
+    A = g[f"{name}/A_u8"].astype(np.float32) / np.float32(255.0)
+    B = g[f"{name}/B_u8"].astype(np.float32) / np.float32(255.0)
+    crossmips.ncc_stats(reset=True)
+    d = crossmips.PDAlgoMIPNCC.execute(torch.from_numpy(A).to(dev), torch.from_numpy(B).to(dev), dmax[0], dmax[1], dmax[2], side, overlap)
+    st = crossmips.ncc_stats()
+    assert d.VHD_coords == list(g[f"{name}/coord"]) and d.NCC_widths == list(g[f"{name}/NCC_widths"])
+    assert d.wRangeThrs == list(g[f"{name}/wRangeThr"])
+    assert np.allclose(np.array(d.NCC_maxs, np.float32), g[f"{name}/NCC_maxs"], rtol=0, atol=2e-6, equal_nan=True)
+    assert st["pairs_per_pair_path"] + st["pairs_batched"] == 1
+    # the near-threshold entry of a thr_* case only matters when the scans of compute_NCC_width reach it (the second scan starts at
+    # the width the first one found, :186-200): thr_2 is decided on it, thr_0 / thr_1 are not
+    if not name.startswith("thr_") or name == "thr_2":
+        assert st["pairs_per_pair_path"] == 1 and st["pairs_batched"] == 0    # handed to the careful path
+        assert st["entries_recomputed_exactly"] > 0
+    # the maps themselves, both routes, against the reference's
+    dimk, dimi, dimj = A.shape
+    ni, nj = (dimi - overlap if side == 0 else 0), (dimj - overlap if side == 1 else 0)
+    mips = crossmips.compute_mips(torch.from_numpy(A).to(dev), torch.from_numpy(B).to(dev), ni, nj, side)
+    dl = N.clamp_delays((dimk, dimi, dimj), (0, ni, nj), (dmax[2], dmax[0], dmax[1]))
+    dk, di, dj = dl
+    for m, (nm, du, dv) in enumerate([("xy", di, dj), ("xz", di, dk), ("yz", dj, dk)]):
+        want = g[f"{name}/map_{nm}"]
+        for lag in (False, True):
+            got = crossmips.compute_NCC_map(mips[m], mips[m + 3], du, dv, lag=lag).cpu().numpy()
+            assert np.array_equal(np.isnan(got), np.isnan(want)) and _ulps(got, want) <= MAX_ULPS, (nm, lag)
