@@ -54,6 +54,37 @@ def make_grid(dev, rows=GRID, cols=GRID, seed=1234):
     return tiles, jit, step
 
 
+def mips_roofline(dev, tiles):
+    """Dominant kernel of the pair pipeline: k_mips, the one streaming pass over both overlap views (compute_3_MIPs,
+    compute_funcs.cu:502-521).  ALGORITHMIC bytes per launch = pairs x 2 tiles x dimk x dimi_v x dimj_v x 4 B (161 MB
+    per C5 pair); duration = HIP events around 5 launches on the launch stream (mi_ncc_time_mips), per side of the grid."""
+    import ctypes as C
+    from ipp_amd import capi, crossmips
+    R, Cc = len(tiles), len(tiles[0])
+    flat = [tiles[r][c] for r in range(R) for c in range(Cc)]
+    dk, di, dj = (int(v) for v in flat[0].shape)
+    ptrs = (C.c_void_p * len(flat))(*[t.data_ptr() for t in flat])
+    out = {}
+    tot_bytes, tot_ms = 0.0, 0.0
+    for side, name in ((1, "west_east"), (0, "north_south")):
+        pairs = [p for p in crossmips.enumerate_pairs(R, Cc) if p[4] == side]
+        n = len(pairs)
+        a_idx = (C.c_int * n)(*[r * Cc + c for r, c, _, _, _ in pairs])
+        b_idx = (C.c_int * n)(*[rb * Cc + cb for _, _, rb, cb, _ in pairs])
+        ni, nj = (di - OVERLAP if side == 0 else 0), (dj - OVERLAP if side == 1 else 0)
+        ms = C.c_float()
+        capi.check(capi.lib().mi_ncc_time_mips(dev.index, capi.current_stream_ptr(dev), n, ptrs, a_idx, b_idx, dk, di, dj, ni, nj, side, 5,
+                                               C.byref(ms)))
+        nbytes = n * 2.0 * dk * (di - ni) * (dj - nj) * 4
+        out[name] = {"pairs_per_launch": n, "launch_ms": round(ms.value, 4), "GBps": round(nbytes / (ms.value * 1e-3) / 1e9, 1)}
+        tot_bytes += nbytes
+        tot_ms += ms.value
+    ach = tot_bytes / (tot_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": "k_mips (six MIPs of every pair of a group in one streaming pass)", "achieved": round(ach, 1),
+            "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": None,
+            "algorithmic_bytes_per_pair": int(2 * dk * (di - 0) * OVERLAP * 4), "launches": out}
+
+
 def run(dev, repeats=3, cpu=True):
     import torch
     from ipp_amd import crossmips
@@ -71,8 +102,14 @@ def run(dev, repeats=3, cpu=True):
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     n_pairs = len(res)
+    stats = crossmips.ncc_stats()
+    per_pair_s = dt / (n_pairs * repeats)
+    roof = mips_roofline(dev, tiles)
+    # whole pipeline against the same byte count, and its fp64 work (lag transforms + per-frequency correlation)
+    roof["pipeline"] = {"algorithmic_GBps": round(roof["algorithmic_bytes_per_pair"] / per_pair_s / 1e9, 1),
+                        "frac": round(roof["algorithmic_bytes_per_pair"] / per_pair_s / 8e12, 4)}
     out = {"metric": "NCC tile-pairs/sec", "value": round(n_pairs * repeats / dt, 3), "unit": "pairs/s",
-           "ms_per_pair": round(dt * 1e3 / (n_pairs * repeats), 3),
+           "ms_per_pair": round(dt * 1e3 / (n_pairs * repeats), 3), "roofline": roof, "path_counters": stats,
            "workload": f"{len(tiles)}x{len(tiles[0])} grid of {TILE[2]}x{TILE[1]}x{TILE[0]} tiles, overlap {OVERLAP}, search {DISPL}",
            "pairs_with_exact_VH_offsets": f"{ok}/{n_pairs}"}
     if cpu:

@@ -251,20 +251,21 @@ extern "C" int mi_ncc_compute_mips(int dev, void* stream, const float* A, const 
     MI_REQUIRE(dimk > 0 && ni >= 0 && nj >= 0 && ni < dimi && nj < dimj, "compute_3_MIPs: invalid extents");
     hipStream_t s = as_stream(stream);
     const int dimi_v = side == MI_NORTH_SOUTH ? dimi - ni : dimi, dimj_v = side == MI_WEST_EAST ? dimj - nj : dimj;
-    float* outs[6] = {xy1, xz1, yz1, xy2, xz2, yz2};
-    const size_t sz[3] = {(size_t)dimi_v * dimj_v, (size_t)dimi_v * dimk, (size_t)dimj_v * dimk};
-    for (int m = 0; m < 6; ++m) MI_HIP(hipMemsetAsync(outs[m], 0, sizeof(float) * sz[m % 3], s));
-    dim3 grid((dimj_v + 63) / 64, (dimi_v + MIP_ROWS - 1) / MIP_ROWS, 2);
     DevBuf tmp;
-    MI_TRY(tmp.alloc(sizeof(float) * 2 * (size_t)grid.y * dimk * dimj_v));
-    hipLaunchKernelGGL(k_mips, grid, dim3(256), 0, s, A, B, (const float* const*)nullptr, (size_t)0, dimk, dimi_v, dimj_v, (size_t)dimi * dimj,
-                       dimj, side == MI_NORTH_SOUTH ? ni : 0, side == MI_WEST_EAST ? nj : 0, xy1, xz1, yz1, xy2, xz2, yz2, tmp.as<float>());
-    MI_TRY(launch_check("k_mips"));
-    hipLaunchKernelGGL(k_mips_yz, dim3((dimk * dimj_v + 255) / 256, 2), dim3(256), 0, s, tmp.as<float>(), (size_t)0, (int)grid.y, dimk, dimj_v,
-                       yz1, yz2);
-    MI_TRY(launch_check("k_mips_yz"));
+    MI_TRY(tmp.alloc(sizeof(float) * mips_tmp_floats(dimk, dimi_v, dimj_v)));
+    MI_TRY(launch_mips(s, A, B, nullptr, 1, 0, dimk, dimi_v, dimj_v, (size_t)dimi * dimj, dimj, side == MI_NORTH_SOUTH ? ni : 0,
+                       side == MI_WEST_EAST ? nj : 0, xy1, xz1, yz1, xy2, xz2, yz2, tmp.as<float>()));
     MI_HIP(hipStreamSynchronize(s));  // tmp dies at scope exit
     return MI_OK;
+}
+
+extern "C" int mi_ncc_time_mips(int dev, void* stream, int n_pairs, const float* const* tiles, const int* a_idx, const int* b_idx, int dimk, int dimi,
+                                int dimj, int ni, int nj, int side, int reps, float* ms_per_launch) {
+    MI_TRY(use_device(dev));
+    MI_REQUIRE(n_pairs > 0 && tiles && a_idx && b_idx, "mi_ncc_time_mips: null pointer");
+    std::vector<const float*> pa(n_pairs), pb(n_pairs);
+    for (int q = 0; q < n_pairs; ++q) { pa[q] = tiles[a_idx[q]]; pb[q] = tiles[b_idx[q]]; }
+    return ncc_time_mips(dev, as_stream(stream), n_pairs, pa.data(), pb.data(), dimk, dimi, dimj, ni, nj, side, reps, ms_per_launch);
 }
 
 extern "C" int mi_ncc_compute_map_lag(int dev, void* stream, const float* mip1, const float* mip2, int dimu, int dimv, int delayu, int delayv,

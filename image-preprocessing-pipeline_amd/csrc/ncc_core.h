@@ -59,10 +59,11 @@ __global__ __launch_bounds__(256) void k_mips(const float* __restrict__ A, const
                                                size_t pstride, int dimk, int dimi_v, int dimj_v,
                                                size_t slice, int pitch, int ai0, int aj0, float* __restrict__ xy1, float* __restrict__ xz1,
                                                float* __restrict__ yz1, float* __restrict__ xy2, float* __restrict__ xz2,
-                                               float* __restrict__ yz2, float* __restrict__ yz_tmp) {
+                                               float* __restrict__ yz2, float* __restrict__ yz_tmp, float* __restrict__ xz_tmp) {
     // a work-group owns a 16-row x 64-column patch of the view; its four waves share the slices (wave w: k = w, w + 4, ...),
     // so a patch keeps four times as many loads in flight as one wave walking all slices
     __shared__ float comb[3][MIP_ROWS][64];
+    extern __shared__ float xzp[];  // [MIP_ROWS][dimk] row maxima of this patch (xz_tmp != nullptr)
     const bool second = blockIdx.z & 1;
     const size_t poff = (size_t)(blockIdx.z >> 1) * pstride;
     const float* vol = tab ? tab[blockIdx.z] : (second ? B : A);
@@ -89,7 +90,12 @@ __global__ __launch_bounds__(256) void k_mips(const float* __restrict__ A, const
             best[r] = fmaxf(best[r], v[r]);
             colmax = fmaxf(colmax, v[r]);
             const float rowmax = wave_max_nonneg(v[r]);  // max over the 64 columns of the patch, in lane 63
-            if (lane == 63 && r < rows) atomic_max_nonneg(&xz[(size_t)(i0 + r) * dimk + k], rowmax);
+            // xz: per patch through LDS into xz_tmp[tile][column block][i][k] (k_mips_xz takes the maximum over the column blocks);
+            // as atomics on the MIP they were 655 thousand single-lane atomics per C5 pair
+            if (lane == 63) {
+                if (xz_tmp) xzp[r * dimk + k] = rowmax;
+                else if (r < rows) atomic_max_nonneg(&xz[(size_t)(i0 + r) * dimk + k], rowmax);
+            }
         }
         // yz: the column maxima of this row band go to yz_tmp[tile][band][k][j] (unit-stride stores); k_mips_yz takes the
         // maximum over the bands -- 2.6 million atomics per pair on the yz MIPs cost more than the whole streaming pass
@@ -106,6 +112,10 @@ __global__ __launch_bounds__(256) void k_mips(const float* __restrict__ A, const
         for (int r = 0; r < MIP_ROWS; ++r)
             if (r < rows) xy[(size_t)(i0 + r) * dimj_v + j] = fmaxf(fmaxf(best[r], comb[0][r][lane]), fmaxf(comb[1][r][lane], comb[2][r][lane]));
     }
+    if (xz_tmp) {  // rows * dimk contiguous floats
+        float* dst = xz_tmp + (((size_t)blockIdx.z * gridDim.x + blockIdx.x) * dimi_v + i0) * dimk;
+        for (int e = threadIdx.x; e < rows * dimk; e += 256) dst[e] = xzp[e];
+    }
 }
 
 // yz[j][k] = max over the row bands of yz_tmp[tile][band][k][j]; one lane per (k, j), tile = blockIdx.y = 2 * pair + which
@@ -118,6 +128,47 @@ __global__ __launch_bounds__(256) void k_mips_yz(const float* __restrict__ yz_tm
     float m = 0.0f;
     for (int b = 0; b < bands; ++b) m = fmaxf(m, p[(size_t)b * dimk * dimj_v]);
     ((blockIdx.y & 1) ? yz2 : yz1)[(size_t)(blockIdx.y >> 1) * pstride + (size_t)j * dimk + k] = m;
+}
+
+// xz[i][k] = max over the column blocks of xz_tmp[tile][block][i][k]; one lane per (i, k), tile = blockIdx.y = 2 * pair + which
+__global__ __launch_bounds__(256) void k_mips_xz(const float* __restrict__ xz_tmp, size_t pstride, int blocks, int dimk, int dimi_v,
+                                                  float* __restrict__ xz1, float* __restrict__ xz2) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= dimk * dimi_v) return;
+    const float* p = xz_tmp + (size_t)blockIdx.y * blocks * dimk * dimi_v + e;
+    float m = 0.0f;
+    for (int b = 0; b < blocks; ++b) m = fmaxf(m, p[(size_t)b * dimk * dimi_v]);
+    ((blockIdx.y & 1) ? xz2 : xz1)[(size_t)(blockIdx.y >> 1) * pstride + e] = m;
+}
+
+// the six MIPs of `np` pairs (np == 1 and tab == nullptr: the pair A, B): k_mips + the reductions of its partial maxima.
+// `tmp` must hold mips_tmp_floats(...) floats per pair.
+inline size_t mips_tmp_floats(int dimk, int dimi_v, int dimj_v) {
+    const size_t bands = (dimi_v + MIP_ROWS - 1) / MIP_ROWS, cblocks = (dimj_v + 63) / 64;
+    return 2 * (bands * dimk * dimj_v + cblocks * (size_t)dimi_v * dimk);
+}
+int launch_mips(hipStream_t s, const float* A, const float* B, const float* const* tab, int np, size_t pstride, int dimk, int dimi_v, int dimj_v,
+                size_t slice, int pitch, int ai0, int aj0, float* xy1, float* xz1, float* yz1, float* xy2, float* xz2, float* yz2, float* tmp) {
+    const int bands = (dimi_v + MIP_ROWS - 1) / MIP_ROWS, cblocks = (dimj_v + 63) / 64;
+    float* yz_tmp = tmp;
+    float* xz_tmp = tmp + 2 * (size_t)np * bands * dimk * dimj_v;
+    const size_t lds = sizeof(float) * MIP_ROWS * (size_t)dimk;
+    const bool via_lds = lds <= 32 * 1024;
+    if (!via_lds) {  // very deep stacks: the xz MIPs are merged with atomicMax and must start at 0 (libcrossmips.cpp:319-337)
+        MI_HIP(hipMemset2DAsync(xz1, sizeof(float) * (pstride ? pstride : 1), 0, sizeof(float) * (size_t)dimi_v * dimk, np, s));
+        MI_HIP(hipMemset2DAsync(xz2, sizeof(float) * (pstride ? pstride : 1), 0, sizeof(float) * (size_t)dimi_v * dimk, np, s));
+    }
+    dim3 grid(cblocks, bands, 2 * np);
+    hipLaunchKernelGGL(k_mips, grid, dim3(256), via_lds ? lds : 0, s, A, B, tab, pstride, dimk, dimi_v, dimj_v, slice, pitch, ai0, aj0, xy1, xz1, yz1,
+                       xy2, xz2, yz2, yz_tmp, via_lds ? xz_tmp : (float*)nullptr);
+    MI_TRY(launch_check("k_mips"));
+    hipLaunchKernelGGL(k_mips_yz, dim3((dimk * dimj_v + 255) / 256, 2 * np), dim3(256), 0, s, yz_tmp, pstride, bands, dimk, dimj_v, yz1, yz2);
+    MI_TRY(launch_check("k_mips_yz"));
+    if (via_lds) {
+        hipLaunchKernelGGL(k_mips_xz, dim3((dimk * dimi_v + 255) / 256, 2 * np), dim3(256), 0, s, xz_tmp, pstride, cblocks, dimk, dimi_v, xz1, xz2);
+        MI_TRY(launch_check("k_mips_xz"));
+    }
+    return MI_OK;
 }
 
 // one wave per tile (blockIdx.y = MIP of the plane): the tile is staged in LDS with coalesced loads, then lane 0 adds its 1024
@@ -981,24 +1032,16 @@ int pair_enqueue(hipStream_t s, const float* A, const float* B, int dimi, int di
     if (ws.buf.bytes < sizeof(float) * need) MI_TRY(ws.buf.alloc(sizeof(float) * need));
     ws.floats = pl.total_floats;
     float* base = ws.buf.as<float>();
-    // six MIPs start at 0 (libcrossmips.cpp:319-337)
-    MI_HIP(hipMemsetAsync(base, 0, sizeof(float) * pl.g[0].ps1, s));
-    dim3 grid((pl.dimj_v + 63) / 64, (pl.dimi_v + MIP_ROWS - 1) / MIP_ROWS, 2);
     {
-        const size_t tmp = sizeof(float) * 2 * (size_t)grid.y * pl.dimk * pl.dimj_v;
+        const size_t tmp = sizeof(float) * mips_tmp_floats(pl.dimk, pl.dimi_v, pl.dimj_v);
         if (ws.mip_tmp.bytes < tmp) {
             MI_HIP(hipStreamSynchronize(s));
             MI_TRY(ws.mip_tmp.alloc(tmp));
         }
     }
-    hipLaunchKernelGGL(k_mips, grid, dim3(256), 0, s, A, B, (const float* const*)nullptr, (size_t)0, pl.dimk, pl.dimi_v, pl.dimj_v,
-                       (size_t)dimi * dimj, dimj, pl.ai0, pl.aj0,
-                       base + pl.g[0].mip1, base + pl.g[1].mip1, base + pl.g[2].mip1, base + pl.g[0].mip2, base + pl.g[1].mip2,
-                       base + pl.g[2].mip2, ws.mip_tmp.as<float>());
-    MI_TRY(launch_check("k_mips"));
-    hipLaunchKernelGGL(k_mips_yz, dim3((pl.dimk * pl.dimj_v + 255) / 256, 2), dim3(256), 0, s, ws.mip_tmp.as<float>(), (size_t)0, (int)grid.y,
-                       pl.dimk, pl.dimj_v, base + pl.g[2].mip1, base + pl.g[2].mip2);
-    MI_TRY(launch_check("k_mips_yz"));
+    MI_TRY(launch_mips(s, A, B, nullptr, 1, 0, pl.dimk, pl.dimi_v, pl.dimj_v, (size_t)dimi * dimj, dimj, pl.ai0, pl.aj0, base + pl.g[0].mip1,
+                       base + pl.g[1].mip1, base + pl.g[2].mip1, base + pl.g[0].mip2, base + pl.g[1].mip2, base + pl.g[2].mip2,
+                       ws.mip_tmp.as<float>()));
     if (ws.sat.bytes < sizeof(double) * pl.sat_doubles) MI_TRY(ws.sat.alloc(sizeof(double) * pl.sat_doubles));
     for (int m = 0; m < 3; ++m) {
         const PlaneGeom& g = pl.g[m];

@@ -14,6 +14,8 @@ bool ncc_lag_supported(int dimk, int dimi, int dimj, int ni, int nj, int delayk,
 int ncc_lag_group(int dev, hipStream_t s, int n, const float* const* a_ptrs, const float* const* b_ptrs, int dimk, int dimi, int dimj, int ni,
                   int nj, int delayk, int delayi, int delayj, int side, mi_ncc_params* params, mi_ncc_descr* out, unsigned char* careful);
 int ncc_lag_map(int dev, hipStream_t s, const float* mip1, const float* mip2, int dimu, int dimv, int delayu, int delayv, float* map);
+int ncc_time_mips(int dev, hipStream_t s, int n, const float* const* a_ptrs, const float* const* b_ptrs, int dimk, int dimi, int dimj, int ni, int nj,
+                  int side, int reps, float* ms);
 void ncc_lag_drop_cached(int dev);
 
 }  // namespace mi

@@ -541,8 +541,7 @@ int ncc_lag_group(int dev, hipStream_t s, int n, const float* const* a_ptrs, con
 
     // per-pair footprint -> chunk size
     const size_t pstride = (pl.total_floats + 3) / 4 * 4, sstride = pl.sat_doubles;
-    const int bands = (pl.dimi_v + MIP_ROWS - 1) / MIP_ROWS;
-    const size_t tmp_floats = 2 * (size_t)bands * pl.dimk * pl.dimj_v;
+    const size_t tmp_floats = mips_tmp_floats(pl.dimk, pl.dimi_v, pl.dimj_v);
     size_t spec = 0, crs = 0;
     int wcap = 1;
     for (int m = 0; m < 3; ++m) {
@@ -577,17 +576,9 @@ int ncc_lag_group(int dev, hipStream_t s, int n, const float* const* a_ptrs, con
     for (int c0 = 0; c0 < n; c0 += chunk) {
         const int nc = std::min(chunk, n - c0);
         MI_HIP(hipMemcpyAsync(ws.tab.p, htab + 2 * c0, sizeof(void*) * 2 * nc, hipMemcpyHostToDevice, s));
-        // the xz MIPs are merged with atomicMax and must start at 0 (libcrossmips.cpp:319-337); everything else is overwritten
-        MI_HIP(hipMemset2DAsync(base + pl.g[1].mip1, 4 * pstride, 0, 4 * (size_t)pl.g[1].dimu * pl.g[1].dimv, nc, s));
-        MI_HIP(hipMemset2DAsync(base + pl.g[1].mip2, 4 * pstride, 0, 4 * (size_t)pl.g[1].dimu * pl.g[1].dimv, nc, s));
-        dim3 grid((pl.dimj_v + 63) / 64, bands, 2 * nc);
-        hipLaunchKernelGGL(k_mips, grid, dim3(256), 0, s, (const float*)nullptr, (const float*)nullptr, ws.tab.as<const float*>(), pstride, pl.dimk,
-                           pl.dimi_v, pl.dimj_v, (size_t)dimi * dimj, dimj, pl.ai0, pl.aj0, base + pl.g[0].mip1, base + pl.g[1].mip1,
-                           base + pl.g[2].mip1, base + pl.g[0].mip2, base + pl.g[1].mip2, base + pl.g[2].mip2, ws.mip_tmp.as<float>());
-        MI_TRY(launch_check("k_mips"));
-        hipLaunchKernelGGL(k_mips_yz, dim3((pl.dimk * pl.dimj_v + 255) / 256, 2 * nc), dim3(256), 0, s, ws.mip_tmp.as<float>(), pstride, bands,
-                           pl.dimk, pl.dimj_v, base + pl.g[2].mip1, base + pl.g[2].mip2);
-        MI_TRY(launch_check("k_mips_yz"));
+        MI_TRY(launch_mips(s, nullptr, nullptr, ws.tab.as<const float*>(), nc, pstride, pl.dimk, pl.dimi_v, pl.dimj_v, (size_t)dimi * dimj, dimj,
+                           pl.ai0, pl.aj0, base + pl.g[0].mip1, base + pl.g[1].mip1, base + pl.g[2].mip1, base + pl.g[0].mip2, base + pl.g[1].mip2,
+                           base + pl.g[2].mip2, ws.mip_tmp.as<float>()));
         for (int m = 0; m < 3; ++m) {
             const PlaneGeom& g = pl.g[m];
             SatView v1, v2;
@@ -670,6 +661,47 @@ int ncc_lag_map(int dev, hipStream_t s, const float* mip1, const float* mip2, in
     MI_TRY(launch_check("k_lag_refine"));
     MI_HIP(hipStreamSynchronize(s));
     return MI_OK;
+}
+
+// average duration of ONE k_mips launch over n pairs (HIP events on `s` around `reps` launches; bench.py's roofline hook)
+int ncc_time_mips(int dev, hipStream_t s, int n, const float* const* a_ptrs, const float* const* b_ptrs, int dimk, int dimi, int dimj, int ni, int nj,
+                  int side, int reps, float* ms) {
+    MI_REQUIRE(n > 0 && reps > 0 && ms && a_ptrs && b_ptrs, "mi_ncc_time_mips: invalid arguments");
+    MI_REQUIRE(side == MI_NORTH_SOUTH || side == MI_WEST_EAST, "CrossMIPs: unexpected alignment configuration");
+    const int dimi_v = side == MI_NORTH_SOUTH ? dimi - ni : dimi, dimj_v = side == MI_WEST_EAST ? dimj - nj : dimj;
+    MI_REQUIRE(dimi_v > 0 && dimj_v > 0 && dimk > 0, "mi_ncc_time_mips: empty view");
+    const size_t xy = (size_t)dimi_v * dimj_v, xz = (size_t)dimi_v * dimk, yz = (size_t)dimj_v * dimk;
+    const size_t pstride = (2 * (xy + xz + yz) + 3) / 4 * 4, tmpf = mips_tmp_floats(dimk, dimi_v, dimj_v);
+    DevBuf out, tmp, tab;
+    MI_TRY(out.alloc(4 * pstride * n));
+    MI_TRY(tmp.alloc(4 * tmpf * n));
+    MI_TRY(tab.alloc(sizeof(void*) * 2 * n));
+    std::vector<const float*> h(2 * (size_t)n);
+    for (int q = 0; q < n; ++q) { h[2 * q] = a_ptrs[q]; h[2 * q + 1] = b_ptrs[q]; }
+    MI_HIP(hipMemcpyAsync(tab.p, h.data(), sizeof(void*) * 2 * n, hipMemcpyHostToDevice, s));
+    MI_HIP(hipStreamSynchronize(s));
+    float* o = out.as<float>();
+    const int bands = (dimi_v + MIP_ROWS - 1) / MIP_ROWS, cblocks = (dimj_v + 63) / 64;
+    const size_t lds = sizeof(float) * MIP_ROWS * (size_t)dimk;
+    MI_REQUIRE(lds <= 32 * 1024, "mi_ncc_time_mips: stack too deep for the timed variant");
+    float* xz_tmp = tmp.as<float>() + 2 * (size_t)n * bands * dimk * dimj_v;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    MI_HIP(hipEventCreate(&e0));
+    MI_HIP(hipEventCreate(&e1));
+    for (int r = -1; r < reps; ++r) {  // r = -1: warm-up
+        if (r == 0) MI_HIP(hipEventRecord(e0, s));
+        hipLaunchKernelGGL(k_mips, dim3(cblocks, bands, 2 * n), dim3(256), lds, s, (const float*)nullptr, (const float*)nullptr, tab.as<const float*>(),
+                           pstride, dimk, dimi_v, dimj_v, (size_t)dimi * dimj, dimj, side == MI_NORTH_SOUTH ? ni : 0, side == MI_WEST_EAST ? nj : 0, o,
+                           o + xy, o + xy + xz, o + xy + xz + yz, o + 2 * xy + xz + yz, o + 2 * xy + 2 * xz + yz, tmp.as<float>(), xz_tmp);
+    }
+    MI_HIP(hipEventRecord(e1, s));
+    MI_HIP(hipEventSynchronize(e1));
+    float total = 0.0f;
+    MI_HIP(hipEventElapsedTime(&total, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *ms = total / (float)reps;
+    return launch_check("k_mips");
 }
 
 void ncc_lag_drop_cached(int dev) {

@@ -77,6 +77,12 @@ int mi_ncc_mips_batch(int dev, void* stream, int n_pairs, const float* const* ti
  * (compute_funcs.cu:1163-1292) to take such decisions.  reset != 0 clears them after reading. */
 void mi_ncc_stats(long long* out3, int reset);
 
+/* Measurement hook (bench.py's roofline object): average duration in ms of ONE launch of the MIP kernel -- the streaming pass
+ * over both overlap views, compute_3_MIPs (compute_funcs.cu:502-521), 2 * dimk * dimi_v * dimj_v * 4 bytes per pair -- over
+ * n_pairs pairs of one geometry, HIP events on `stream` around `reps` launches.  Synchronises. */
+int mi_ncc_time_mips(int dev, void* stream, int n_pairs, const float* const* tiles, const int* a_idx, const int* b_idx,
+                     int dimk, int dimi, int dimj, int ni, int nj, int side, int reps, float* ms_per_launch);
+
 /* ---- building blocks (exposed for parity tests against the reference's exported helpers) ------ */
 
 /* compute_3_MIPs (compute_funcs.cu:502-521) on the overlap views selected by (side, ni, nj):
