@@ -185,8 +185,8 @@ def main():
 
     if world == 1:
         bl = make_volume(vshape, dev)
-        ratio = torch.empty_like(bl)
         ctx = decon.RLContext(vshape, psf_np, None, boundary=capi.BOUNDARY_CIRCULAR, engine=engine, device=dev)
+        ratio = None if ctx.fuses else torch.empty_like(bl)   # scratch only for engines that cannot fuse an iteration
 
         def step():
             ctx.iterate(bl, ratio, 1)

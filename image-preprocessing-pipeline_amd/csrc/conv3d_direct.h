@@ -35,6 +35,9 @@ int direct_conv_launch(hipStream_t s, const float* img, const float* kf, float* 
                        int kz, int kxp, int boundary, int epi_kind, const ConvEpilogue& epi, const int* offs = nullptr,
                        const int* bnd3 = nullptr);
 int gauss3d_async(hipStream_t s, float* vol, float* work, int nx, int ny, int nz, const float* sigma, const int* ksize);
+// dst = G(src) in ONE pass when the filter fits the fused kernel (*fused = true); else the two-pass route, which uses dst as
+// its intermediate and leaves the result in src (*fused = false)
+int gauss3d_to(hipStream_t s, float* src, float* dst, int nx, int ny, int nz, const float* sigma, const int* ksize, bool* fused);
 struct FftEngine;
 // keep != nullptr: the FFT engine of the blur is created into / reused from *keep (see mi_decon_plan); the caller owns it
 int edgetaper_async(hipStream_t s, float* bl, float* work, const float* psf, int nx, int ny, int nz, int kx, int ky, int kz,

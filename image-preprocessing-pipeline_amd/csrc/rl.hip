@@ -360,11 +360,18 @@ int rl_iterate(mi_rl_ctx* ctx, hipStream_t s, float* bl, float* ratio, float* re
     const float sig[3] = {0.5f, 0.5f, 0.5f};
     const int k3[3] = {3, 3, 3};
     int done = 0;
+    // the estimate ping-pongs between the caller's array and the scratch volume: the single-pass Gaussian of the regularisation
+    // step writes into the other buffer (8 B/voxel, no copy back), which then IS the estimate; the buffer it leaves is the
+    // scratch of the following steps.  One copy at the end when the estimate sits in the scratch volume.
+    float* const home = bl;
     for (int i = 1; i <= o.niter;) {
         const bool reg_time = regularization_time(i, o.niter, o.regularize_interval);
         int span = 1;
         if (reg_time) {
-            MI_TRY(gauss3d_async(s, bl, ratio, nx, ny, nz, sig, o.gauss_taps == 3 ? k3 : nullptr));  // decon.m:57-59
+            MI_REQUIRE(ratio, "decon: the regularisation step needs the scratch volume");
+            bool fused = false;
+            MI_TRY(gauss3d_to(s, bl, ratio, nx, ny, nz, sig, o.gauss_taps == 3 ? k3 : nullptr, &fused));  // decon.m:57-59
+            if (fused) std::swap(bl, ratio);
             if (o.lambda > 0.0f) {
                 MI_TRY(mi_rl_forward_ratio(ctx, s, bl, ratio));
                 MI_TRY(mi_rl_reg_term(ctx->dev, s, bl, reg, nx, ny, nz));
@@ -390,6 +397,7 @@ int rl_iterate(mi_rl_ctx* ctx, hipStream_t s, float* bl, float* ratio, float* re
             if (done > 1 && rel <= (double)o.stop_criterion) break;
         }
     }
+    if (bl != home) MI_HIP(hipMemcpyAsync(home, bl, sizeof(float) * N, hipMemcpyDeviceToDevice, s));
     if (iters_done) *iters_done = done;
     return MI_OK;
 }
@@ -414,16 +422,27 @@ static int rl_spatial_impl(int dev, void* stream, float* bl, const float* psf, c
     hipStream_t s = as_stream(stream);
     const size_t N = (size_t)nx * ny * nz;
     const bool need_reg = opt->lambda > 0.0f && opt->regularize_interval > 0 && opt->regularize_interval < opt->niter;
+    // the scratch volume serves the edge taper's blur, the regularisation step's Gaussian and the ratio of engines that do not
+    // fuse an iteration: a fused loop without regularisation never touches it and does not allocate it (8.6 GB on config C3)
+    const bool reg_sched = opt->regularize_interval > 0 && opt->regularize_interval < opt->niter;
     DevBuf ratio, reg, scratch;
-    MI_TRY(ratio.alloc(sizeof(float) * N));
     if (need_reg) MI_TRY(reg.alloc(sizeof(float) * N));
     MI_TRY(scratch.alloc(sizeof(double)));
     double delta_prev = 0.0;
     if (opt->stop_criterion > 0.0f) MI_TRY(host_norm(s, bl, N, scratch.as<double>(), &delta_prev));  // before the taper (decon.m:46-50)
-    if (!opt->skip_edgetaper) MI_TRY(edgetaper_async(s, bl, ratio.as<float>(), psf, nx, ny, nz, kx, ky, kz, keep_taper));
+    if (!opt->skip_edgetaper) {
+        MI_TRY(ratio.alloc(sizeof(float) * N));
+        MI_TRY(edgetaper_async(s, bl, ratio.as<float>(), psf, nx, ny, nz, kx, ky, kz, keep_taper));
+    }
     mi_rl_ctx* ctx = keep_ctx ? *keep_ctx : nullptr;
     if (!ctx) MI_TRY(mi_rl_create(dev, stream, nx, ny, nz, psf, psf_inv, kx, ky, kz, MI_BOUNDARY_ZERO, opt->engine, &ctx));
     if (keep_ctx) *keep_ctx = ctx;
+    if (reg_sched || !mi_rl_fuses(ctx)) {
+        if (!ratio.p) MI_TRY(ratio.alloc(sizeof(float) * N));
+    } else {
+        MI_HIP(hipStreamSynchronize(s));  // the taper may still be reading it
+        ratio.release();
+    }
     int rc = rl_iterate(ctx, s, bl, ratio.as<float>(), reg.as<float>(), scratch.as<double>(), nx, ny, nz, *opt, delta_prev, iters_done);
     hipError_t e = hipStreamSynchronize(s);
     if (!keep_ctx) mi_rl_destroy(ctx);
@@ -450,11 +469,14 @@ static int rl_fft_impl(int dev, void* stream, float* bl, const float* psf, int n
     const size_t NF = (size_t)fx * fy * fz;
     const bool padded = fx != nx || fy != ny || fz != nz;
     const bool need_reg = opt->lambda > 0.0f && opt->regularize_interval > 0 && opt->regularize_interval < opt->niter;
+    const bool reg_sched = opt->regularize_interval > 0 && opt->regularize_interval < opt->niter;
     DevBuf ratio, reg, scratch, blF;
-    MI_TRY(ratio.alloc(sizeof(float) * NF));
     if (need_reg) MI_TRY(reg.alloc(sizeof(float) * NF));
     MI_TRY(scratch.alloc(sizeof(double)));
-    if (!opt->skip_edgetaper) MI_TRY(edgetaper_async(s, bl, ratio.as<float>(), psf, nx, ny, nz, kx, ky, kz, keep_taper));  // decon.m:143
+    if (!opt->skip_edgetaper) {  // decon.m:143
+        MI_TRY(ratio.alloc(sizeof(float) * NF));
+        MI_TRY(edgetaper_async(s, bl, ratio.as<float>(), psf, nx, ny, nz, kx, ky, kz, keep_taper));
+    }
     float* work_bl = bl;
     if (padded) {  // decon.m:144
         MI_TRY(blF.alloc(sizeof(float) * NF));
@@ -467,6 +489,12 @@ static int rl_fft_impl(int dev, void* stream, float* bl, const float* psf, int n
     const int engine = opt->engine == MI_ENGINE_DIRECT ? MI_ENGINE_DIRECT : MI_ENGINE_FFT;
     if (!ctx) MI_TRY(mi_rl_create(dev, stream, fx, fy, fz, psf, nullptr, kx, ky, kz, MI_BOUNDARY_CIRCULAR, engine, &ctx));
     if (keep_ctx) *keep_ctx = ctx;
+    if (reg_sched || !mi_rl_fuses(ctx)) {  // (see rl_spatial_impl)
+        if (!ratio.p) MI_TRY(ratio.alloc(sizeof(float) * NF));
+    } else {
+        MI_HIP(hipStreamSynchronize(s));
+        ratio.release();
+    }
     int rc = rl_iterate(ctx, s, work_bl, ratio.as<float>(), reg.as<float>(), scratch.as<double>(), fx, fy, fz, *opt, delta_prev, iters_done);
     if (rc == MI_OK && padded) rc = mi_crop_center(dev, stream, work_bl, fx, fy, fz, bl, nx, ny, nz);  // decon.m:203
     hipError_t e = hipStreamSynchronize(s);
