@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libmi_ipp.so")
 MI_OK = 0
 # mi_boundary / mi_engine (include/mi_lsdeconv.h)
 BOUNDARY_ZERO, BOUNDARY_REPLICATE, BOUNDARY_CIRCULAR = 0, 1, 2
-ENGINE_AUTO, ENGINE_DIRECT, ENGINE_FFT, ENGINE_MFMA = 0, 1, 2, 3
+ENGINE_AUTO, ENGINE_DIRECT, ENGINE_FFT = 0, 1, 2
 NORTH_SOUTH, WEST_EAST = 0, 1
 
 
@@ -82,6 +82,7 @@ SIGNATURES = {
     "mi_rl_create_ex": (_i, [_i, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _ip, _ip, _i, C.POINTER(_vp)]),
     "mi_rl_destroy": (_i, [_vp]),
     "mi_rl_engine": (_i, [_vp]),
+    "mi_rl_separable": (_i, [_vp]),
     "mi_rl_device_bytes": (_sz, [_vp]),
     "mi_rl_forward_ratio": (_i, [_vp, _vp, _vp, _vp]),
     "mi_rl_adjoint_update": (_i, [_vp, _vp, _vp, _vp, _f, _vp]),

@@ -26,9 +26,55 @@ struct mi_rl_ctx {
     DevBuf kf_fwd, kf_adj;
     int kxp = 0;
     int off_fwd[3] = {0, 0, 0}, off_adj[3] = {0, 0, 0};
+    // separable fast path of the direct engine: a PSF that is an outer product a (x) b (x) c (a Gaussian: BASELINE config 1) is
+    // applied as three 1-D convolutions -- kx + ky + kz instead of kx * ky * kz taps per voxel; the RL epilogue rides on the last
+    bool separable = false;
+    DevBuf sep_fwd[3], sep_adj[3];  // 1-D tap tables per axis
+    int sep_kxp[3] = {0, 0, 0};
+    DevBuf sep_t0, sep_t1;          // intermediate volumes (allocated with the first convolution)
     FftEngine* fft = nullptr;
     ~mi_rl_ctx() { delete fft; }
 };
+
+namespace {
+// Rank-1 test on the host: with the largest sample p0 at (z0, y0, x0), psf is separable iff psf[z][y][x] = a[z] b[y] c[x] / p0^2
+// for the lines a, b, c through that sample, to fp32 rounding.  factors[0..2] = taps along x, y, z (product = the PSF).
+bool factor_rank1(const std::vector<float>& p, int kx, int ky, int kz, std::vector<float> (&factors)[3]) {
+    size_t best = 0;
+    for (size_t i = 1; i < p.size(); ++i)
+        if (std::fabs(p[i]) > std::fabs(p[best])) best = i;
+    const double p0 = p[best];
+    if (!(std::fabs(p0) > 0.0) || kx * ky * kz == 1) return false;
+    const int z0 = (int)(best / ((size_t)ky * kx)), y0 = (int)((best / kx) % ky), x0 = (int)(best % kx);
+    auto at = [&](int z, int y, int x) { return (double)p[((size_t)z * ky + y) * kx + x]; };
+    double worst = 0.0;
+    for (int z = 0; z < kz; ++z)
+        for (int y = 0; y < ky; ++y)
+            for (int x = 0; x < kx; ++x)
+                worst = std::max(worst, std::fabs(at(z, y, x) - at(z, y0, x0) * at(z0, y, x0) * at(z0, y0, x) / (p0 * p0)));
+    if (worst > 4e-7 * std::fabs(p0)) return false;
+    factors[0].resize(kx);
+    factors[1].resize(ky);
+    factors[2].resize(kz);
+    for (int x = 0; x < kx; ++x) factors[0][x] = (float)at(z0, y0, x);
+    for (int y = 0; y < ky; ++y) factors[1][y] = (float)(at(z0, y, x0) / p0);
+    for (int z = 0; z < kz; ++z) factors[2][z] = (float)(at(z, y0, x0) / p0);
+    return true;
+}
+
+// the three 1-D tap tables of a rank-1 kernel for the direct engine
+int prepare_separable(hipStream_t s, const std::vector<float> (&f)[3], bool flip, DevBuf (&tabs)[3], int (&kxp)[3]) {
+    for (int d = 0; d < 3; ++d) {
+        DevBuf line;
+        const int n = (int)f[d].size();
+        MI_TRY(line.alloc(sizeof(float) * (size_t)n));
+        MI_HIP(hipMemcpyAsync(line.p, f[d].data(), sizeof(float) * (size_t)n, hipMemcpyHostToDevice, s));
+        MI_TRY(direct_prepare_psf(s, line.as<float>(), d == 0 ? n : 1, d == 1 ? n : 1, d == 2 ? n : 1, false, flip, tabs[d], &kxp[d]));
+        MI_HIP(hipStreamSynchronize(s));  // `line` and the host vector die at scope exit
+    }
+    return MI_OK;
+}
+}  // namespace
 
 extern "C" int mi_engine_select(int nx, int ny, int nz, int kx, int ky, int kz, int boundary) {
     // direct: 2*K flop per voxel at ~60 TFLOP/s sustained fp32.  FFT, per grid point and convolution (measured):
@@ -123,7 +169,23 @@ static int rl_create(int dev, void* stream, int nx, int ny, int nz, const float*
         c->off_adj[d] = psf_inv ? k[d] - 1 - shift[d] : shift[d];
     }
     int rc = MI_OK;
-    if (engine == MI_ENGINE_DIRECT) {
+    if (engine == MI_ENGINE_DIRECT && !std::getenv("MI_NO_SEPARABLE")) {
+        // rank-1 PSF (and adjoint kernel): three 1-D passes instead of the dense taps
+        const size_t nk = (size_t)kx * ky * kz;
+        std::vector<float> hp(nk), hi(psf_inv ? nk : 0);
+        std::vector<float> ff[3], fi[3];
+        hipError_t e = hipMemcpyAsync(hp.data(), psf, sizeof(float) * nk, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess && psf_inv) e = hipMemcpyAsync(hi.data(), psf_inv, sizeof(float) * nk, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) rc = fail(MI_ERR_HIP, "mi_rl_create: %s", hipGetErrorString(e));
+        if (rc == MI_OK && factor_rank1(hp, kx, ky, kz, ff) && (!psf_inv || factor_rank1(hi, kx, ky, kz, fi))) {
+            rc = prepare_separable(s, ff, /*flip=*/true, c->sep_fwd, c->sep_kxp);
+            // adjoint taps: flip(psf_inv); without psf_inv the transpose of the forward operator = the plain taps of psf
+            if (rc == MI_OK) rc = psf_inv ? prepare_separable(s, fi, true, c->sep_adj, c->sep_kxp) : prepare_separable(s, ff, false, c->sep_adj, c->sep_kxp);
+            c->separable = rc == MI_OK;
+        }
+    }
+    if (rc == MI_OK && engine == MI_ENGINE_DIRECT) {
         rc = direct_prepare_psf(s, psf, kx, ky, kz, false, /*flip=*/true, c->kf_fwd, &c->kxp);
         // adjoint taps: flip(psf_inv); with psf_inv = flip(psf) (LsDeconv.m:163) that is psf itself
         if (rc == MI_OK)
@@ -170,10 +232,29 @@ extern "C" int mi_rl_engine(const mi_rl_ctx* ctx) { return ctx ? ctx->engine : M
 
 extern "C" size_t mi_rl_device_bytes(const mi_rl_ctx* ctx) {
     if (!ctx) return 0;
-    return ctx->kf_fwd.bytes + ctx->kf_adj.bytes + (ctx->fft ? ctx->fft->device_bytes() : 0);
+    return ctx->kf_fwd.bytes + ctx->kf_adj.bytes + ctx->sep_t0.bytes + ctx->sep_t1.bytes + (ctx->fft ? ctx->fft->device_bytes() : 0);
 }
 
+extern "C" int mi_rl_separable(const mi_rl_ctx* ctx) { return ctx && ctx->separable ? 1 : 0; }
+
 static int ctx_conv(mi_rl_ctx* c, hipStream_t s, const float* in, bool adjoint, float* out, int epi_kind, const ConvEpilogue& epi) {
+    if (c->engine == MI_ENGINE_DIRECT && c->separable) {
+        const size_t bytes = sizeof(float) * (size_t)c->n[0] * c->n[1] * c->n[2];
+        if (!c->sep_t0.p) MI_TRY(c->sep_t0.alloc(bytes));
+        if (!c->sep_t1.p) MI_TRY(c->sep_t1.alloc(bytes));
+        const int* off = adjoint ? c->off_adj : c->off_fwd;
+        DevBuf* tab = adjoint ? c->sep_adj : c->sep_fwd;
+        const float* src = in;
+        float* dsts[3] = {c->sep_t0.as<float>(), c->sep_t1.as<float>(), out};
+        for (int d = 0; d < 3; ++d) {  // x, then y, then z; window offsets of the other axes are 0 for a 1-tap kernel
+            const int o[3] = {d == 0 ? off[0] : 0, d == 1 ? off[1] : 0, d == 2 ? off[2] : 0};
+            MI_TRY(direct_conv_launch(s, src, tab[d].as<float>(), dsts[d], c->n[0], c->n[1], c->n[2], d == 0 ? c->k[0] : 1, d == 1 ? c->k[1] : 1,
+                                      d == 2 ? c->k[2] : 1, c->sep_kxp[d], c->bnd[0], d == 2 ? epi_kind : EPI_NONE, d == 2 ? epi : ConvEpilogue(), o,
+                                      c->bnd));
+            src = dsts[d];
+        }
+        return MI_OK;
+    }
     if (c->engine == MI_ENGINE_DIRECT)
         return direct_conv_launch(s, in, adjoint ? c->kf_adj.as<float>() : c->kf_fwd.as<float>(), out, c->n[0], c->n[1], c->n[2], c->k[0],
                                   c->k[1], c->k[2], c->kxp, c->bnd[0], epi_kind, epi, adjoint ? c->off_adj : c->off_fwd, c->bnd);

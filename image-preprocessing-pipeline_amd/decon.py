@@ -328,6 +328,11 @@ class RLContext:
         return int(lib().mi_rl_fuses(self._h))
 
     @property
+    def separable(self) -> bool:
+        """The direct engine found the PSF to be an outer product and applies it as three 1-D convolutions."""
+        return bool(lib().mi_rl_separable(self._h))
+
+    @property
     def otf_is_real(self) -> bool:
         return bool(lib().mi_rl_otf_is_real(self._h))
 

@@ -23,9 +23,12 @@ typedef enum {
 /* convolution engine */
 typedef enum {
     MI_ENGINE_AUTO = 0,   /* cost model on PSF taps / volume size (mi_engine_select) */
-    MI_ENGINE_DIRECT = 1, /* LDS-tiled direct convolution (fp32 FMA) */
-    MI_ENGINE_FFT = 2,    /* rocFFT R2C/C2R convolution, padded as the boundary rule requires */
-    MI_ENGINE_MFMA = 3    /* direct convolution as a banded implicit GEMM on fp32 MFMA */
+    MI_ENGINE_DIRECT = 1, /* LDS-tiled direct convolution (fp32 FMA); three 1-D passes for rank-1 PSFs (mi_rl_separable) */
+    MI_ENGINE_FFT = 2     /* FFT convolution on the grid the boundary rule requires: hand-written pipeline (fft_native.hip), rocFFT
+                             for extents it does not take */
+    /* (a matrix-core direct engine was prototyped and measured -- banded-Toeplitz v_mfma_f32_16x16x4_f32, bit-identical results,
+       70 ms against 58 ms of the fp32 FMA engine on BASELINE config 2: profiles/mfma_toeplitz_probe.hip,
+       profiles/r02_mfma_toeplitz_probe.txt -- and is not part of the library) */
 } mi_engine;
 
 /* ---- single kernels -------------------------------------------------------------------------- */
@@ -112,6 +115,11 @@ int mi_rl_create(int dev, void* stream, int nx, int ny, int nz, const float* psf
 int mi_rl_create_ex(int dev, void* stream, int nx, int ny, int nz, const float* psf, const float* psf_inv,
                     int kx, int ky, int kz, const int* boundary_xyz, const int* shift_xyz, int engine,
                     mi_rl_ctx** ctx);
+/* 1 when the context applies the PSF as three 1-D convolutions: the direct engine does so for PSFs (and explicit adjoint
+ * kernels) that are an outer product of three lines to fp32 rounding, e.g. the Gaussian PSF of BASELINE config 1 --
+ * kx + ky + kz instead of kx * ky * kz taps per voxel [no reference counterpart: conv3d_gpu.cu:68-99 always runs the dense loop].
+ * MI_NO_SEPARABLE=1 disables the test. */
+int mi_rl_separable(const mi_rl_ctx* ctx);
 int mi_rl_destroy(mi_rl_ctx* ctx);
 /* engine actually chosen (mi_engine) and device bytes held by the context */
 int mi_rl_engine(const mi_rl_ctx* ctx);

@@ -337,3 +337,38 @@ def test_decon_plan_is_bit_identical_and_rebuilds(dev):
         a = decon.decon(_t(vol, dev), psf, 2, 0.0, 0.0, 0, 1, True, F, True).cpu().numpy()
         b = decon.decon(_t(vol, dev), psf, 2, 0.0, 0.0, 0, 1, True, F, True, plan=plan).cpu().numpy()
         assert np.array_equal(a, b)
+
+
+# ------------------------------------------------------------------ separable fast path of the direct engine
+@pytest.mark.parametrize("boundary", [0, 1, 2])
+@pytest.mark.parametrize("kshape", [(7, 5, 9), (4, 6, 5)])
+def test_separable_psf_takes_three_1d_passes(dev, boundary, kshape, monkeypatch):
+    """A rank-1 PSF (Gaussian, BASELINE config 1) runs as three 1-D convolutions on the direct engine; same result as the dense
+    tap loop (MI_NO_SEPARABLE=1) and as the oracle; a PSF that is not an outer product keeps the dense loop."""
+    from ipp_amd import decon
+    from tests.rl_util import asymmetric_psf
+    shape = (20, 36, 44)
+    psf = R.gaussian_psf(kshape, (1.5, 1.0, 2.0))
+    psf = (psf * np.linspace(0.7, 1.3, kshape[2])[None, None, :]).astype(np.float32)   # still rank 1, not symmetric
+    vol = R.bead_volume(shape, seed=5, psf=R.gaussian_psf((5, 5, 5), (1, 1, 1)))
+    inv = R.flip3(psf) if boundary != 2 else None
+
+    def run(p, pinv):
+        ctx = decon.RLContext(shape, p, pinv, boundary=boundary, engine=1, device=dev)
+        bl = _t(vol, dev)
+        ratio = torch.empty_like(bl)
+        ctx.iterate(bl, ratio, 3)
+        return bl.cpu().numpy(), ctx.separable
+
+    got, sep = run(psf, inv)
+    assert sep
+    monkeypatch.setenv("MI_NO_SEPARABLE", "1")
+    dense, sep_off = run(psf, inv)
+    monkeypatch.delenv("MI_NO_SEPARABLE")
+    assert not sep_off and _rel(got, dense) < 5e-6
+    if boundary == 0:
+        assert_close(got, R.decon_spatial(vol, psf, 3, skip_edgetaper=True))
+    elif boundary == 2:
+        assert_close(got, R.decon_fft(vol, psf, shape, 3, skip_edgetaper=True))
+    _, sep_asym = run(asymmetric_psf(kshape, seed=1), R.flip3(asymmetric_psf(kshape, seed=1)) if boundary != 2 else None)
+    assert not sep_asym
