@@ -8,10 +8,14 @@ volume (Z, Y, X).  Output: ``<input>/deconvolved/deconvolved.npy`` (float32; + `
 decwrap.py:474-478, ``min_max.json``) and the rescaled integer stack ``deconvolved_{8,16}bit.npy`` that the reference's
 postprocess_save writes as a TIFF series (LsDeconv.m:950-1100: percentile clip range of all blocks, amplification, round,
 clamp; ``mi_rescale_block``); for a TIFF input also the ``img_%06d.tif`` series itself (LsDeconv.m:1120-1145).
-Every finished block is kept as ``bl_<n>.lz4`` in the cache folder (``--cache-drive``, default ``<out>/cache``) in the
-reference's brick format (save_lz4_mex.c), so an interrupted run resumes with the blocks that are missing (LsDeconv.m:695-705;
-``--no-resume`` starts over); the cache is removed after a complete run like LsDeconv.m:286-296.
-TIFF series / LZ4 brick cache / resume of the reference are I/O rows outside this hot path.
+Nothing of volume size lives in host memory: the input is read box by box (memory-mapped ``*.npy`` or lazily decoded TIFF
+slices), every finished block goes to the cache folder (``--cache-drive``, default ``<out>/cache``) as ``bl_<n>.lz4`` in the
+reference's brick format (save_lz4_mex.c), and the output is assembled one z slab of bricks at a time (postprocess_save).
+A block is claimed by creating its brick file, so several workers -- or several machines sharing the cache folder, started
+with different ``--start-block`` (decwrap.py:317-321; only ``--start-block 1`` assembles the output) -- split the work
+(LsDeconv.m:696-706); ``block.json`` / ``min_max.json`` in the cache play the part of block.mat / min_max.mat, an interrupted
+run resumes with the blocks that are missing (``--no-resume`` starts over), bricks are validated by header (type + core
+shape) and the cache is removed after a complete run like LsDeconv.m:286-296.
 """
 from __future__ import annotations
 
@@ -103,7 +107,58 @@ def validate_args(args):
         raise RuntimeError("--cpu-workers: this build has no CPU deconvolution path")
 
 
-def load_volume(path: Path):
+class LazyTiffVolume:
+    """A folder of 2-D TIFF slices as a (Z, Y, X) array that is never whole in memory: ``vol[z0:z1, y0:y1, x0:x1]`` reads the
+    slices it needs (the reference's load_block reads its box from the files too, LsDeconv.m:817-904, load_bl_tif.cpp) and keeps
+    the most recently used ones -- the blocks of one z slab share their slices -- within ``cache_bytes``."""
+
+    def __init__(self, folder: Path, cache_bytes: int):
+        import threading
+        from collections import OrderedDict
+        import numpy as np
+        from ipp_amd import brickio
+        self.files = brickio.list_tiff_series(folder)
+        if not self.files:
+            raise RuntimeError(f"no *.tif slices in {folder}")
+        first = brickio.load_tiff_series(folder, 0, 1)
+        self.dtype, self.ndim = first.dtype, 3
+        self.shape = (len(self.files),) + first.shape[1:]
+        self._folder, self._np, self._brickio = folder, np, brickio
+        self._cache, self._lock = OrderedDict(), threading.Lock()
+        self._budget = max(1, int(cache_bytes) // max(1, first[0].nbytes))
+
+    def _slice(self, z):
+        with self._lock:
+            a = self._cache.get(z)
+            if a is not None:
+                self._cache.move_to_end(z)
+                return a
+        a = self._brickio.load_tiff_series(self._folder, z, z + 1)[0]
+        if a.shape != self.shape[1:] or a.dtype != self.dtype:
+            raise ValueError(f"{self.files[z]}: slice shape / type differs from the first slice")
+        with self._lock:
+            self._cache[z] = a
+            while len(self._cache) > self._budget:
+                self._cache.popitem(last=False)
+        return a
+
+    def __getitem__(self, key):
+        np = self._np
+        kz, ky, kx = key
+        zs = range(*kz.indices(self.shape[0]))
+        out = None
+        for i, z in enumerate(zs):
+            a = self._slice(z)[ky, kx]
+            if out is None:
+                out = np.empty((len(zs),) + a.shape, self.dtype)
+            out[i] = a
+        return out if out is not None else np.empty((0,) + self._slice(0)[ky, kx].shape, self.dtype)
+
+
+def open_volume(path: Path):
+    """The input as something that answers ``.shape``, ``.dtype`` and box reads: a memory-mapped ``*.npy`` volume, a stack of
+    ``*.npy`` slices, or a lazily read TIFF series (nothing of reference scale -- hundreds of Gvoxels, README.md:55-63 -- can be
+    loaded whole)."""
     import numpy as np
     if path.is_file():
         return np.load(path, mmap_mode="r")
@@ -112,7 +167,12 @@ def load_volume(path: Path):
         return np.stack([np.load(f) for f in files])
     from ipp_amd import brickio
     if brickio.list_tiff_series(path):
-        return brickio.load_tiff_series(path)
+        try:
+            import psutil
+            budget = int(psutil.virtual_memory().available * 0.25)
+        except Exception:
+            budget = 8 << 30
+        return LazyTiffVolume(path, int(os.environ.get("MI_DECWRAP_SLICE_CACHE_BYTES", budget)))
     raise RuntimeError(f"no *.npy / *.tif slices in {path}")
 
 
@@ -142,7 +202,7 @@ def main(argv=None):
     out_dir.mkdir(exist_ok=True)
     with open(out_dir / "deconvolution_config.json", "w") as f:
         json.dump(cfg, f, indent=2)
-    vol = load_volume(args.input)
+    vol = open_volume(args.input)
     sz, sy, sx = vol.shape
     dz = args.dz if args.dz else args.dxy
     psf = P.LsMakePSF(args.dxy * 1000.0, dz * 1000.0, args.na, args.rf, float(args.lambda_ex), float(args.lambda_em),
@@ -155,127 +215,253 @@ def main(argv=None):
     # workers that share a device share its memory (decwrap.py:133-169 divides by the workers per GPU as well)
     per_dev = max(1, args.gpu_workers_per_gpu) * max(1, args.gpu_indices.count(gpu))
     bmax = args.block_size_max or L.estimate_block_size_max(gpu - 1, n_real=3, n_complex=2 if args.use_fft else 0) // per_dev
-    block = L.autosplit((sx, sy, sz), psf.shape[::-1], filt, bmax, args.numit)
-    log.info(f"block grid {block.nx} x {block.ny} x {block.nz}, core ({block.x} {block.y} {block.z}), "
-             f"pad ({block.x_pad} {block.y_pad} {block.z_pad}), fft_shape {block.fft_shape}")
-    out = np.zeros(vol.shape, np.float32)
-    pad = (block.x_pad, block.y_pad, block.z_pad)
-    # One worker per entry of the device list (--gpu-indices x --gpu-workers-per-gpu, like the reference's pool of parfeval
-    # workers, LsDeconv.m:620-668): blocks are independent, a worker takes the next unprocessed block, runs it on its device
-    # and on its own stream, and writes the core of the result into the output volume.
+
     import shutil
     import threading
+    import time
     from concurrent.futures import ThreadPoolExecutor
     from ipp_amd import brickio
     cache = Path(args.cache_drive) if args.cache_drive else out_dir / "cache"
-    if not args.resume and cache.exists():
-        shutil.rmtree(cache)                                                               # LsDeconv.m:136-139
+    if not args.resume and args.start_block == 1:
+        if cache.exists():
+            shutil.rmtree(cache)                                                           # LsDeconv.m:136-139
+        for f in out_dir.glob("img_*.tif"):
+            f.unlink()                                                                     # LsDeconv.m:124
     cache.mkdir(parents=True, exist_ok=True)
-    workers = [g for g in args.gpu_indices for _ in range(max(1, args.gpu_workers_per_gpu))]
-    # --start-block only matters to the reference's multi-process start-up; here every block is either taken from the cache
-    # or processed
-    todo = [(n, p1, p2) for n, (p1, p2) in enumerate(zip(block.p1, block.p2), start=1)]
-    lock = threading.Lock()
-    stats = []
 
-    def run(worker_id):
+    # ---- block geometry: kept in the cache folder (block.mat of LsDeconv.m:176-193) and checked against this run on resume
+    stack_info = {"x": int(sx), "y": int(sy), "z": int(sz), "dtype": str(np.dtype(vol.dtype))}
+    block_path = cache / "block.json"
+    block = None
+    if args.resume and block_path.exists():
+        with open(block_path) as f:
+            saved = json.load(f)
+        for k, v in stack_info.items():
+            if saved["stack_info"].get(k) != v:
+                raise RuntimeError(f"Loaded block.json stack_info.{k} ({saved['stack_info'].get(k)}) does not match current stack_info ({v})")
+        b = saved["block"]
+        block = L.Block(b["x"], b["y"], b["z"], b["nx"], b["ny"], b["nz"], b["x_pad"], b["y_pad"], b["z_pad"],
+                        tuple(b["fft_shape"]) if b["fft_shape"] else None)
+        block.p1, block.p2 = L.split_stack((sx, sy, sz), block)
+        if len(block.p1) != block.nx * block.ny * block.nz:
+            raise RuntimeError("block.p1 shape mismatch with block.nx, block.ny, block.nz")
+        log.info("Resuming by loading block info ...")
+    if block is None:
+        block = L.autosplit((sx, sy, sz), psf.shape[::-1], filt, bmax, args.numit)
+        tmp = block_path.with_suffix(".json.tmp")
+        with open(tmp, "w") as f:
+            json.dump({"stack_info": stack_info,
+                       "block": {k: (list(getattr(block, k)) if k == "fft_shape" and block.fft_shape else getattr(block, k))
+                                 for k in ("x", "y", "z", "nx", "ny", "nz", "x_pad", "y_pad", "z_pad", "fft_shape")}}, f)
+        os.replace(tmp, block_path)
+    num_blocks = len(block.p1)
+    log.info(f"block grid {block.nx} x {block.ny} x {block.nz}, core ({block.x} {block.y} {block.z}), "
+             f"pad ({block.x_pad} {block.y_pad} {block.z_pad}), fft_shape {block.fft_shape}")
+    pad = (block.x_pad, block.y_pad, block.z_pad)
+
+    def core_shape(n):
+        p1, p2 = block.p1[n - 1], block.p2[n - 1]
+        return (int(p2[2] - p1[2] + 1), int(p2[1] - p1[1] + 1), int(p2[0] - p1[0] + 1))
+
+    def brick_path(n):
+        return cache / f"bl_{n}.lz4"
+
+    def brick_complete(n):
+        """a finished brick of this block: non-empty, readable header, float32, the block's core shape"""
+        p = brick_path(n)
+        try:
+            if p.stat().st_size == 0:
+                return False
+            with open(p, "rb") as f:
+                h = brickio.read_header(f)
+            dims = tuple(int(v) for v in h["dims"][:int(h["ndims"])])[::-1]
+            return int(h["dtype"]) == brickio.DT_SINGLE and dims == core_shape(n)
+        except (OSError, ValueError):
+            return False
+
+    # ---- running statistics shared through the cache folder (min_max.mat of LsDeconv.m:760-790): clip range over the blocks
+    # finished so far and the largest raw sample (only needed for inputs that are not 8 / 16 bit)
+    lock = threading.Lock()
+    mm_path = cache / "min_max.json"
+    int_input = np.issubdtype(np.dtype(vol.dtype), np.integer)
+    state = {"deconvmin": float("inf"), "deconvmax": 0.0, "rawmax": float(np.iinfo(vol.dtype).max) if int_input else float("-inf")}
+
+    def merge_min_max(lb=None, ub=None, rawmax=None):
+        with lock:
+            if mm_path.exists():                                                           # another process may have updated it
+                try:
+                    with open(mm_path) as f:
+                        disk = json.load(f)
+                    state["deconvmin"] = min(state["deconvmin"], disk["deconvmin"])
+                    state["deconvmax"] = max(state["deconvmax"], disk["deconvmax"])
+                    state["rawmax"] = max(state["rawmax"], disk["rawmax"])
+                except (OSError, ValueError, KeyError):
+                    pass
+            if lb is not None:
+                state["deconvmin"], state["deconvmax"] = min(state["deconvmin"], lb), max(state["deconvmax"], ub)
+            if rawmax is not None:
+                state["rawmax"] = max(state["rawmax"], rawmax)
+            tmp = mm_path.with_suffix(".json.tmp")
+            with open(tmp, "w") as f:
+                json.dump(state, f)
+            os.replace(tmp, mm_path)
+
+    # One worker per entry of the device list (--gpu-indices x --gpu-workers-per-gpu, like the reference's pool of parfeval
+    # workers, LsDeconv.m:620-668).  Blocks are independent; a block is CLAIMED by creating its (empty) brick file, so several
+    # workers -- and several machines started with different --start-block on one shared cache folder (decwrap.py:317-321) --
+    # never take the same block (LsDeconv.m:696-706); the result reaches the cache as bl_<n>.lz4.tmp + rename (:805-806).
+    workers = [g for g in args.gpu_indices for _ in range(max(1, args.gpu_workers_per_gpu))]
+
+    def claim(n):
+        try:
+            os.close(os.open(brick_path(n), os.O_CREAT | os.O_EXCL | os.O_WRONLY))
+            return True
+        except FileExistsError:
+            return False
+
+    def run(worker_id, first_block):
         g = workers[worker_id]
         stream = torch.cuda.Stream(device=g - 1)
         staging = {}  # pinned host buffers by core shape: D2H at PCIe rate instead of page-faulting a fresh pageable array
         # blocks of equal shape share the RL context and the taper's FFT engine (MI_NO_DECON_PLAN: rebuild them per block)
         plan = None if os.environ.get("MI_NO_DECON_PLAN") else D.DeconPlan(g)
         try:
-            run_blocks(g, stream, staging, plan)
+            for n in range(first_block, num_blocks + 1):
+                if not claim(n):
+                    continue                                                               # finished or being worked on elsewhere
+                run_block(n, g, stream, staging, plan)
         finally:
             if plan is not None:
                 with torch.cuda.device(g - 1):
                     plan.close()
 
-    def run_blocks(g, stream, staging, plan):
-        while True:
-            with lock:
-                if not todo:
-                    return
-                n, p1, p2 = todo.pop(0)
-            brick = cache / f"bl_{n}.lz4"
-            if brick.exists() and brick.stat().st_size > 0:                                # resume: LsDeconv.m:695-705, 799-801
-                core = brickio.load_lz4(brick)
-                if core.shape == (p2[2] - p1[2] + 1, p2[1] - p1[1] + 1, p2[0] - p1[0] + 1):
-                    out[p1[2] - 1:p2[2], p1[1] - 1:p2[1], p1[0] - 1:p2[0]] = core
-                    with open(brick.with_suffix(".json")) as f:
-                        st = json.load(f)
-                    with lock:
-                        stats.append((st["lb"], st["ub"]))
-                    log.info(f"block {n}/{len(block.p1)} taken from the cache")
-                    continue
-            bl_xyz = tuple(int(b) - int(a) + 1 + 2 * int(q) for a, b, q in zip(p1, p2, pad))   # padded block, [x y z]
-            fshape = None
-            if args.use_fft:
-                smooth, native = L.next_fast_len(bl_xyz), L.native_fft_shape(bl_xyz)
-                fshape = native if np.prod(native) <= 1.3 * np.prod(smooth) else smooth
-            blk = L.Block(block.x, block.y, block.z, block.nx, block.ny, block.nz, *pad, fft_shape=fshape)
-            with torch.cuda.device(g - 1), torch.cuda.stream(stream):
-                # load_block on the device: the raw samples cross PCIe, conversion and symmetric padding happen there
-                bl = L.load_block_device(vol, p1, p2, pad, torch.device("cuda", g - 1), staging)
-                t, lb, ub = L.process_block(bl, blk, psf_struct, args.numit, args.lambda_damping, args.stop_criterion, filt,
-                                            args.clipval, g, plan=plan)
-                core = t[pad[2]:t.shape[0] - pad[2] or None, pad[1]:t.shape[1] - pad[1] or None, pad[0]:t.shape[2] - pad[0] or None]
-                core = core.contiguous()                                                   # strip pads, LsDeconv.m:750-752
-                if tuple(core.shape) not in staging:
-                    staging[tuple(core.shape)] = torch.empty(core.shape, dtype=torch.float32, pin_memory=True)
-                host = staging[tuple(core.shape)]
-                host.copy_(core, non_blocking=True)
-                stream.synchronize()
-                core = host.numpy()
-            box = (slice(p1[2] - 1, p2[2]), slice(p1[1] - 1, p2[1]), slice(p1[0] - 1, p2[0]))
-            out[box] = core                                                                # disjoint boxes: no lock needed
-            # the brick cache (resume) is written behind the worker's back: LZ4 of a float32 core takes longer than its kernels
-            with lock:
-                stats.append((lb, ub))
-                pending.append(writers.submit(save_brick, brick, box, lb, ub))
-            log.info(f"block {n}/{len(block.p1)} done on GPU {g}: stats [{lb:.4g}, {ub:.4g}]")
+    def run_block(n, g, stream, staging, plan):
+        p1, p2 = block.p1[n - 1], block.p2[n - 1]
+        bl_xyz = tuple(int(b) - int(a) + 1 + 2 * int(q) for a, b, q in zip(p1, p2, pad))   # padded block, [x y z]
+        fshape = None
+        if args.use_fft:
+            smooth, native = L.next_fast_len(bl_xyz), L.native_fft_shape(bl_xyz)
+            fshape = native if np.prod(native) <= 1.3 * np.prod(smooth) else smooth
+        blk = L.Block(block.x, block.y, block.z, block.nx, block.ny, block.nz, *pad, fft_shape=fshape)
+        with torch.cuda.device(g - 1), torch.cuda.stream(stream):
+            # load_block on the device: the raw samples cross PCIe, conversion and symmetric padding happen there
+            bl = L.load_block_device(vol, p1, p2, pad, torch.device("cuda", g - 1), staging)
+            rawmax = None if int_input else float(bl.max())                               # LsDeconv.m:717-721
+            t, lb, ub = L.process_block(bl, blk, psf_struct, args.numit, args.lambda_damping, args.stop_criterion, filt,
+                                        args.clipval, g, plan=plan)
+            core = t[pad[2]:t.shape[0] - pad[2] or None, pad[1]:t.shape[1] - pad[1] or None, pad[0]:t.shape[2] - pad[0] or None]
+            core = core.contiguous()                                                       # strip pads, LsDeconv.m:750-752
+            assert tuple(core.shape) == core_shape(n), "[remove padding]: Output block size mismatch!"
+            if tuple(core.shape) not in staging:
+                staging[tuple(core.shape)] = torch.empty(core.shape, dtype=torch.float32, pin_memory=True)
+            host = staging[tuple(core.shape)]
+            host.copy_(core, non_blocking=True)
+            stream.synchronize()
+            arr = np.array(host.numpy())                                                   # the staging buffer is reused by the next block
+        merge_min_max(lb, ub, rawmax)
+        # the brick is compressed and written behind the worker's back: LZ4 of a float32 core takes longer than its kernels
+        with lock:
+            pending.append(writers.submit(save_brick, n, arr, lb, ub))
+        log.info(f"block {n}/{num_blocks} done on GPU {g}: stats [{lb:.4g}, {ub:.4g}]")
 
-    def save_brick(brick, box, lb, ub):
-        with open(brick.with_suffix(".json"), "w") as f:                                   # the block's clip range (min_max.mat entry)
+    def save_brick(n, arr, lb, ub):
+        brick = brick_path(n)
+        with open(brick.with_suffix(".json"), "w") as f:                                   # the block's own clip range
             json.dump({"lb": lb, "ub": ub}, f)
-        brickio.save_lz4(brick.with_suffix(".lz4.tmp"), np.ascontiguousarray(out[box]))    # LsDeconv.m:805-806
+        brickio.save_lz4(brick.with_suffix(".lz4.tmp"), arr)                               # LsDeconv.m:805-806
         os.replace(brick.with_suffix(".lz4.tmp"), brick)
 
+    # ---- the deconvolution rounds (LsDeconv.m:618-660): stale claims and half-written bricks of an earlier run are removed,
+    # the workers take what is missing from --start-block on; whatever is still missing afterwards (blocks below the start
+    # block, claims of a process that died) is taken by another round from block 1
+    start = max(1, min(int(args.start_block), num_blocks))
     pending = []
     with ThreadPoolExecutor(max_workers=max(2, min(8, (os.cpu_count() or 4) // 2))) as writers:   # liblz4 runs outside the GIL
-        with ThreadPoolExecutor(max_workers=len(workers)) as pool:
-            for f in [pool.submit(run, w) for w in range(len(workers))]:
-                f.result()                                                                 # re-raises a worker's exception
-        for f in pending:
-            f.result()
-    lo = min((s[0] for s in stats), default=np.inf)
-    hi = max((s[1] for s in stats), default=-np.inf)
-    np.save(out_dir / "deconvolved.npy", out)
-    # postprocess_save (LsDeconv.m:996-1024, 1091-1093): rawmax from the input class, target scale, rescale every slab with the
-    # clip range [deconvmin, deconvmax] collected over the blocks
-    if np.issubdtype(vol.dtype, np.integer):
-        rawmax = float(np.iinfo(vol.dtype).max)
-    else:
-        rawmax = float(np.max(vol))
+        while True:
+            missing = 0
+            for n in range(1, num_blocks + 1):
+                if brick_complete(n):
+                    if n >= start:
+                        log.info(f"block {n}/{num_blocks} taken from the cache")
+                    continue
+                missing += 1
+                if n >= start:
+                    for q in (brick_path(n), brick_path(n).with_suffix(".lz4.tmp")):
+                        try:
+                            q.unlink()
+                        except FileNotFoundError:
+                            pass
+            if missing == 0:
+                break
+            with ThreadPoolExecutor(max_workers=len(workers)) as pool:
+                for f in [pool.submit(run, w, min(num_blocks, start + w)) for w in range(len(workers))]:
+                    f.result()                                                             # re-raises a worker's exception
+            for f in pending:
+                f.result()
+            pending.clear()
+            if start > 1 and all(brick_complete(n) for n in range(start, num_blocks + 1)):
+                break                                                                      # a helper machine is done with its share
+            start = 1
+    if int(args.start_block) != 1:
+        log.info("--start-block > 1: the blocks are in the cache; the process started with --start-block 1 assembles the output")
+        return 0                                                                           # LsDeconv.m:579-583, 667-670
+
+    # ---- postprocess_save (LsDeconv.m:950-1111): clip range over all blocks, target scale, then one z slab of bricks at a time:
+    # rescale on the device (mi_rescale_block = load_slab_lz4.cpp:134-157), optional flip, slices out.  Only the integer slab is
+    # held in memory.
+    merge_min_max()
+    lo, hi = state["deconvmin"], state["deconvmax"]
+    for n in range(1, num_blocks + 1):                                                     # bricks placed by hand carry their own range
+        try:
+            with open(brick_path(n).with_suffix(".json")) as f:
+                st = json.load(f)
+            lo, hi = min(lo, st["lb"]), max(hi, st["ub"])
+        except (OSError, ValueError, KeyError):
+            pass
+    rawmax = state["rawmax"]
     scal = L.output_scale(rawmax, args.convert_to_8bit, args.convert_to_16bit)
     with open(out_dir / "min_max.json", "w") as f:
         json.dump({"deconvmin": float(lo), "deconvmax": float(hi), "rawmax": rawmax, "scal": scal}, f)
     bits = 8 if scal <= 255 else 16
-    out_int = np.empty(vol.shape, np.uint8 if bits == 8 else np.uint16)
+    tiff_out = not args.input.is_file() and bool(brickio.list_tiff_series(args.input))
+    # whole-volume *.npy copies (float32 result, integer stack): always for *.npy inputs, for TIFF inputs only while they are small
+    want_npy = os.environ.get("MI_DECWRAP_NPY", "1" if (not tiff_out or sz * sy * sx <= (1 << 31)) else "0") == "1"
+    npy_f = np.lib.format.open_memmap(out_dir / "deconvolved.npy", mode="w+", dtype=np.float32, shape=(sz, sy, sx)) if want_npy else None
+    npy_i = (np.lib.format.open_memmap(out_dir / f"deconvolved_{bits}bit.npy", mode="w+", dtype=np.uint8 if bits == 8 else np.uint16,
+                                       shape=(sz, sy, sx)) if want_npy else None)
     dev = torch.device("cuda", args.gpu_indices[0] - 1)
-    slab = max(1, (1 << 28) // max(1, sy * sx))                                           # <= 1 GiB of float32 per slab
-    for z0 in range(0, sz, slab):
-        t = torch.from_numpy(out[z0:z0 + slab]).to(dev)
-        q = D.rescale_block(t, scal, args.signal_amp, lo, hi)
-        out_int[z0:z0 + slab] = q.cpu().numpy()
-    if args.flip:
-        out_int = np.ascontiguousarray(out_int[:, ::-1])                                   # R = flip(R, 2): the y axis (LsDeconv.m:1097-1099)
-    np.save(out_dir / f"deconvolved_{bits}bit.npy", out_int)
-    if not args.input.is_file() and brickio.list_tiff_series(args.input):
-        n_tif = brickio.save_tiff_series(out_dir, out_int)                                 # img_%06d.tif, existing slices kept
+    per_slab = block.nx * block.ny
+    n_tif = 0
+    for iz in range(block.nz):
+        ids = range(iz * per_slab + 1, (iz + 1) * per_slab + 1)
+        z1, z2 = int(block.p1[ids[0] - 1][2]), int(block.p2[ids[0] - 1][2])
+        if tiff_out and all((out_dir / f"img_{z:06d}.tif").exists() for z in range(z1, z2 + 1)) and not want_npy:
+            continue                                                                       # resume: this slab's slices exist (:1037-1054)
+        slab = np.empty((z2 - z1 + 1, sy, sx), np.uint8 if bits == 8 else np.uint16)
+        for n in ids:
+            p1, p2 = block.p1[n - 1], block.p2[n - 1]
+            core = brickio.load_lz4(brick_path(n))
+            if core.shape != core_shape(n):
+                raise RuntimeError(f"brick {brick_path(n)} has shape {core.shape}, block {n} needs {core_shape(n)}")
+            box = (slice(int(p1[2]) - z1, int(p2[2]) - z1 + 1), slice(int(p1[1]) - 1, int(p2[1])), slice(int(p1[0]) - 1, int(p2[0])))
+            if npy_f is not None:
+                npy_f[int(p1[2]) - 1:int(p2[2]), box[1], box[2]] = core
+            q = D.rescale_block(torch.from_numpy(np.ascontiguousarray(core, dtype=np.float32)).to(dev), scal, args.signal_amp, lo, hi)
+            slab[box] = q.cpu().numpy()
+        if args.flip:
+            slab = np.ascontiguousarray(slab[:, ::-1])                                     # R = flip(R, 2): the y axis (LsDeconv.m:1097-1099)
+        if npy_i is not None:
+            npy_i[z1 - 1:z2] = slab
+        if tiff_out:
+            n_tif += brickio.save_tiff_series(out_dir, slab, first_index=z1)               # img_%06d.tif, existing slices kept
+    for m in (npy_f, npy_i):
+        if m is not None:
+            m.flush()
+    del npy_f, npy_i
+    if tiff_out:
         log.info(f"wrote {n_tif} TIFF slices to {out_dir}")
     shutil.rmtree(cache, ignore_errors=True)                                               # LsDeconv.m:286-296
-    log.info(f"wrote {out_dir / 'deconvolved.npy'} and deconvolved_{bits}bit.npy (scale {scal:g}, clip [{lo:.4g}, {hi:.4g}])")
+    log.info(f"wrote {out_dir} (scale {scal:g}, clip [{lo:.4g}, {hi:.4g}])")
     return 0
 
 

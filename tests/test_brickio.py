@@ -77,3 +77,19 @@ def test_tiff_series_round_trip_and_resume(tmp_path, dtype, scale):
     assert brickio.save_tiff_series(tmp_path, vol) == 1            # only the missing slice is written again
     with pytest.raises(RuntimeError, match="no \\*.tif"):
         brickio.load_tiff_series(tmp_path / "nothing_here")
+
+
+def test_lazy_tiff_volume_reads_boxes(tmp_path):
+    """decwrap's input for TIFF folders: box reads equal the same box of the fully loaded series; the slice cache stays
+    within its budget."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "image-preprocessing-pipeline_amd"))
+    from ipp_amd import brickio, decwrap
+    rng = np.random.default_rng(5)
+    vol = (rng.random((9, 20, 23)) * 60000).astype(np.uint16)
+    brickio.save_tiff_series(tmp_path / "s", vol)
+    lazy = decwrap.LazyTiffVolume(tmp_path / "s", cache_bytes=3 * vol[0].nbytes)
+    assert lazy.shape == vol.shape and lazy.dtype == vol.dtype
+    for box in [(slice(0, 9), slice(0, 20), slice(0, 23)), (slice(2, 5), slice(3, 17), slice(1, 8)), (slice(8, 9), slice(19, 20), slice(0, 23))]:
+        assert np.array_equal(lazy[box], vol[box])
+    assert len(lazy._cache) <= 3

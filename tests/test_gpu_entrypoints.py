@@ -320,3 +320,48 @@ def test_load_block_on_the_device_is_bit_identical(dev, dtype):
         got = L.load_block_device(vol, p1, p2, pad, dev, staging)
         assert got.dtype == torch.float32 and tuple(got.shape) == want.shape
         assert np.array_equal(got.cpu().numpy(), want), (p1, p2, pad)
+
+
+def test_decwrap_start_block_claims_and_brick_validation(dev, tmp_path):
+    """Block streaming at the reference's semantics: a helper started with --start-block 3 works from block 3 on and leaves
+    the output alone (decwrap.py:317-321, LsDeconv.m:579-583); the run with --start-block 1 takes what is missing, assembles the
+    slabs and equals a single run; a brick whose header does not fit its block (wrong shape) is recomputed, a block.json of
+    another stack is refused (LsDeconv.m:176-193)."""
+    import json
+    from ipp_amd import brickio, decwrap
+    rng = np.random.default_rng(21)
+    vol16 = (rng.random((24, 40, 44)) * 3000 + 200).astype(np.uint16)
+    common = ["-dxy", "0.422", "-dz", "1.0", "-ex", "488", "-em", "525", "-it", "2", "--gaussian-sigma", "0", "0", "0",
+              "--block-size-max", "60000", "--gpu-indices", "1"]
+    ref_dir = tmp_path / "ref"
+    ref_dir.mkdir()
+    np.save(ref_dir / "vol.npy", vol16)
+    assert decwrap.main(["-i", str(ref_dir / "vol.npy")] + common) == 0
+    want = np.load(ref_dir / "deconvolved" / "deconvolved.npy")
+    want16 = np.load(ref_dir / "deconvolved" / "deconvolved_16bit.npy")
+
+    d = tmp_path / "shared"
+    d.mkdir()
+    np.save(d / "vol.npy", vol16)
+    base = ["-i", str(d / "vol.npy")] + common
+    assert decwrap.main(base + ["--start-block", "3"]) == 0            # helper: bricks only
+    cache = d / "deconvolved" / "cache"
+    geom = json.load(open(cache / "block.json"))
+    n_blocks = geom["block"]["nx"] * geom["block"]["ny"] * geom["block"]["nz"]
+    assert n_blocks >= 4
+    done = sorted(int(p.stem.split("_")[1]) for p in cache.glob("bl_*.lz4") if p.stat().st_size > 0)
+    assert done == list(range(3, n_blocks + 1))
+    assert not (d / "deconvolved" / "deconvolved.npy").exists()
+    # a brick of the wrong shape and a stale claim (empty file) of a process that died
+    brickio.save_lz4(cache / "bl_3.lz4", np.zeros((2, 2, 2), np.float32))
+    (cache / "bl_1.lz4").touch()
+    assert decwrap.main(base) == 0                                      # master: blocks 1, 2 and 3, then the output
+    assert np.array_equal(np.load(d / "deconvolved" / "deconvolved.npy"), want)
+    assert np.array_equal(np.load(d / "deconvolved" / "deconvolved_16bit.npy"), want16)
+    assert not cache.exists()
+    # block.json of another stack: refused
+    cache.mkdir()
+    geom["stack_info"]["x"] += 1
+    json.dump(geom, open(cache / "block.json", "w"))
+    with pytest.raises(RuntimeError, match="does not match current stack_info"):
+        decwrap.main(base)
