@@ -213,22 +213,46 @@ __device__ __forceinline__ double block_sum(double v, double* sh) {
 //   num    = sum f (t - tmean') = cross - tmean' * sum f
 // so per MIP three fp64 summed-area tables (P, Q over the pixels shifted by the global mean c0, TS over the float tile sums)
 // give all of them in O(1) per shift, and the NCC kernel only accumulates the cross term.
+__device__ __forceinline__ double rect(const double* __restrict__ S, int w1, int r0, int c0, int nr, int nc) {
+    return S[(size_t)(r0 + nr) * w1 + c0 + nc] - S[(size_t)r0 * w1 + c0 + nc] - S[(size_t)(r0 + nr) * w1 + c0] + S[(size_t)r0 * w1 + c0];
+}
+
 struct SatView {
     const double* P;   // (dimu+1) x (dimv+1): sum of (f - c0)
     const double* Q;   // same shape: sum of (f - c0)^2
     const double* TS;  // (ph+1) x (pw+1): sum of the float tile sums (nullptr when the MIP has no full tile)
     const double* c0;  // global mean of the MIP
+    int w1;            // dimv + 1
+    __device__ __forceinline__ double rectP(int r0, int c0_, int nr, int nc) const { return rect(P, w1, r0, c0_, nr, nc); }
+    __device__ __forceinline__ double rectQ(int r0, int c0_, int nr, int nc) const { return rect(Q, w1, r0, c0_, nr, nc); }
 };
 
-__device__ __forceinline__ double rect(const double* __restrict__ S, int w1, int r0, int c0, int nr, int nc) {
-    return S[(size_t)(r0 + nr) * w1 + c0 + nc] - S[(size_t)r0 * w1 + c0 + nc] - S[(size_t)(r0 + nr) * w1 + c0] + S[(size_t)r0 * w1 + c0];
-}
+// The same tables kept only where the window statistics ever look.  Shift (u, v) pairs the windows [max(u,0), dimu - max(-u,0)) x
+// [max(v,0), ...): every row index a table is read at lies within E of an end of the axis (E = largest |shift|), the tile-aligned
+// ones within E + 31.  Along the LONG axis of a MIP (2048 of 2048 x 307) that is a small band at either end: the tables are stored
+// over logical coordinates (a = long axis, b = short axis) for a in [0, B] and [n_long - B, n_long] only -- 2 (B + 1) rows
+// instead of n_long + 1 (C5: 216 of 2049) -- and are built from chunk-parallel column sums instead of two full-table passes.
+struct BandView {
+    const double* P;
+    const double* Q;
+    const double* TS;
+    const double* c0;
+    int n_long, n_short, B, long_is_u;  // B >= n_long: every row is kept
+    __device__ __forceinline__ int row(int a) const { return (B >= n_long || a <= B) ? a : a - (n_long - B) + B + 1; }
+    __device__ __forceinline__ double at(const double* S, int a, int b) const { return S[(size_t)row(a) * (n_short + 1) + b]; }
+    __device__ __forceinline__ double rectS(const double* S, int r0, int c0_, int nr, int nc) const {
+        const int a0 = long_is_u ? r0 : c0_, b0 = long_is_u ? c0_ : r0, na = long_is_u ? nr : nc, nb = long_is_u ? nc : nr;
+        return at(S, a0 + na, b0 + nb) - at(S, a0, b0 + nb) - at(S, a0 + na, b0) + at(S, a0, b0);
+    }
+    __device__ __forceinline__ double rectP(int r0, int c0_, int nr, int nc) const { return rectS(P, r0, c0_, nr, nc); }
+    __device__ __forceinline__ double rectQ(int r0, int c0_, int nr, int nc) const { return rectS(Q, r0, c0_, nr, nc); }
+};
 
 // window statistics of one MIP: mean' (reference flavour), sum f, sum (f - mean')^2
-__device__ void window_stats(const SatView& sv, int dimu, int dimv, int r0, int c0, int nr, int nc, double* mean, double* sumf, double* ssd) {
-    const int w1 = dimv + 1;
+template <class View>
+__device__ void window_stats(const View& sv, int dimu, int dimv, int r0, int c0, int nr, int nc, double* mean, double* sumf, double* ssd) {
     const double n = (double)nr * (double)nc, cm = *sv.c0;
-    const double P = rect(sv.P, w1, r0, c0, nr, nc), Q = rect(sv.Q, w1, r0, c0, nr, nc);
+    const double P = sv.rectP(r0, c0, nr, nc), Q = sv.rectQ(r0, c0, nr, nc);
     const double sf = P + n * cm;
     double m = sf / n;
     if (sv.TS && dimu >= TILE && dimv >= TILE) {
@@ -238,7 +262,7 @@ __device__ void window_stats(const SatView& sv, int dimu, int dimv, int r0, int 
             const int pw = dimv / TILE;
             const double tiles = rect(sv.TS, pw + 1, su / TILE, tsv / TILE, (eu - su) / TILE, (ev - tsv) / TILE);
             const double nreg = (double)(eu - su) * (double)(ev - tsv);
-            const double region = rect(sv.P, w1, su, tsv, eu - su, ev - tsv) + nreg * cm;
+            const double region = sv.rectP(su, tsv, eu - su, ev - tsv) + nreg * cm;
             m = (tiles + (sf - region)) / n;  // float tile sums + border pixels, like the reference
         }
     }
@@ -656,8 +680,8 @@ int prepare_plane(hipStream_t s, const float* m1, const float* m2, int dimu, int
     MI_TRY(launch_check("k_sat_rows"));
     hipLaunchKernelGGL(k_sat_cols, dim3((dimv + 63) / 64, 4, np), dim3(64), 0, s, sstride, dimu, dimv, P1, Q1, P2, Q2);
     MI_TRY(launch_check("k_sat_cols"));
-    *v1 = SatView{P1, Q1, tiled ? T1 : nullptr, c0a};
-    *v2 = SatView{P2, Q2, tiled ? T2 : nullptr, c0b};
+    *v1 = SatView{P1, Q1, tiled ? T1 : nullptr, c0a, dimv + 1};
+    *v2 = SatView{P2, Q2, tiled ? T2 : nullptr, c0b, dimv + 1};
     return MI_OK;
 }
 

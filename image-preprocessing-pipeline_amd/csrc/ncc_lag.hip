@@ -38,104 +38,103 @@ __device__ __forceinline__ cplx cmul(cplx a, cplx b) { return make_double2(a.x *
 __device__ __forceinline__ cplx cadd(cplx a, cplx b) { return make_double2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ cplx csub(cplx a, cplx b) { return make_double2(a.x - b.x, a.y - b.y); }
 
-// In-place decimation-in-frequency transform of x[0 .. 2^lgN) in LDS: radix-4 stages, then one radix-2 stage when lgN is odd.
-// Natural order in, digit-reversed order out: frequency k sits at pos_of_freq(k).  tw[n] = exp(-2 pi i n / N).
-__device__ __forceinline__ int pos_of_freq(int k, int lgN) {
-    int p = 0, rem = lgN;
-    while (rem >= 2) {  // the digits of k, least significant first, are the digits of the position, most significant first
-        p |= (k & 3) << (rem - 2);
-        k >>= 2;
-        rem -= 2;
+// Transform length N = 2^a * 3^b (b <= 2): the radices of the decimation-in-frequency stages, in order (4s, then a 2, then 3s).
+// 2048-row MIPs with 75 lags need N >= 2123: 2304 = 4^4 * 9 instead of 4096 cuts every lag kernel by 44 %.
+struct FftPlan {
+    int N, nstages;
+    int radix[14];
+};
+
+// In-place decimation-in-frequency transform of x[0 .. N) in LDS.  Natural order in, digit-reversed order out: with position
+// digits d_1 d_2 ... (most significant first, radices r_1 r_2 ...) the frequency is k = d_1 + r_1 (d_2 + r_2 (...)).
+// tw[n] = exp(-2 pi i n / N).
+__device__ __forceinline__ int pos_of_freq(int k, const FftPlan& pl) {
+    int p = 0, rem = pl.N;
+    for (int s = 0; s < pl.nstages; ++s) {
+        const int r = pl.radix[s];
+        rem /= r;
+        p += (k % r) * rem;
+        k /= r;
     }
-    if (rem == 1) p |= (k & 1);
     return p;
 }
 
-// the inverse map: the frequency held at position p
-__device__ __forceinline__ int freq_of_pos(int p, int lgN) {
-    int k = 0, rem = lgN, sh = 0;
-    while (rem >= 2) {
-        k |= ((p >> (rem - 2)) & 3) << sh;
-        sh += 2;
-        rem -= 2;
-    }
-    if (rem == 1) k |= (p & 1) << sh;
-    return k;
-}
-
-// The N/2 + 1 frequencies 0 .. N/2 of a real signal's spectrum are kept in POSITION order ("slots"): slot s < N/2 is the s-th
-// position whose frequency is below N/2 (the top digit of the frequency is the lowest digit of the position: positions 4m, 4m+1
-// after a radix-4 last stage, 2m after a radix-2 one), slot N/2 is the position of frequency N/2.  The untangling pass of the
-// forward transform then reads LDS in (nearly) contiguous order -- in frequency order consecutive lanes sit N/4 elements apart,
-// a 16-way bank conflict -- and the per-frequency correlation does not care about the order of its frequencies.
-__device__ __forceinline__ int pos_of_slot(int s, int lgN) {
-    const int half = 1 << (lgN - 1);
-    if (lgN & 1) return s < half ? 2 * s : 1;
-    return s < half ? 4 * (s >> 1) + (s & 1) : 2;
-}
-
-__device__ void fft_dif(cplx* __restrict__ x, int lgN, const cplx* __restrict__ tw) {
-    const int N = 1 << lgN;
-    int lgL = lgN;
-    constexpr int BF = 4;  // butterflies per thread and step: their 16 LDS reads and 12 table loads are issued before any store
-    while (lgL >= 2) {
-        const int lgq = lgL - 2, q = 1 << lgq, sh = lgN - lgL;
-        for (int i0 = threadIdx.x; i0 < (N >> 2); i0 += BF * blockDim.x) {
+__device__ void fft_dif(cplx* __restrict__ x, const FftPlan& pl, const cplx* __restrict__ tw) {
+    const int N = pl.N;
+    int L = N;
+    constexpr int BF = 2;  // butterflies per thread and step: their LDS reads and table loads are issued before any store
+    for (int st = 0; st < pl.nstages; ++st) {
+        const int r = pl.radix[st], q = L / r, tstep = N / L, nb = N / r;
+        for (int i0 = threadIdx.x; i0 < nb; i0 += BF * blockDim.x) {
             cplx a[BF][4], w[BF][3];
             cplx* ptr[BF];
 #pragma unroll
             for (int u = 0; u < BF; ++u) {
                 const int idx = i0 + u * blockDim.x;
-                const bool ok = idx < (N >> 2);
-                const int t = idx & (q - 1), b = (idx >> lgq) << lgL;
-                ptr[u] = ok ? x + b + t : nullptr;
+                const bool ok = idx < nb;
+                const int g = idx / q, t = idx - g * q;
+                ptr[u] = ok ? x + g * L + t : nullptr;
                 if (ok) {
-                    a[u][0] = ptr[u][0]; a[u][1] = ptr[u][q]; a[u][2] = ptr[u][2 * q]; a[u][3] = ptr[u][3 * q];
-                    w[u][0] = tw[t << sh]; w[u][1] = tw[(2 * t) << sh]; w[u][2] = tw[(3 * t) << sh];
+                    a[u][0] = ptr[u][0];
+                    a[u][1] = ptr[u][q];
+                    if (r > 2) a[u][2] = ptr[u][2 * q];
+                    if (r > 3) a[u][3] = ptr[u][3 * q];
+                    w[u][0] = tw[t * tstep];
+                    if (r > 2) w[u][1] = tw[2 * t * tstep];
+                    if (r > 3) w[u][2] = tw[3 * t * tstep];
                 }
             }
 #pragma unroll
             for (int u = 0; u < BF; ++u) {
                 if (!ptr[u]) continue;
-                const cplx s02 = cadd(a[u][0], a[u][2]), d02 = csub(a[u][0], a[u][2]), s13 = cadd(a[u][1], a[u][3]), d13 = csub(a[u][1], a[u][3]);
-                const cplx y1 = make_double2(d02.x + d13.y, d02.y - d13.x);  // d02 - i d13
-                const cplx y3 = make_double2(d02.x - d13.y, d02.y + d13.x);  // d02 + i d13
-                ptr[u][0] = cadd(s02, s13);
-                ptr[u][q] = cmul(y1, w[u][0]);
-                ptr[u][2 * q] = cmul(csub(s02, s13), w[u][1]);
-                ptr[u][3 * q] = cmul(y3, w[u][2]);
+                if (r == 4) {
+                    const cplx s02 = cadd(a[u][0], a[u][2]), d02 = csub(a[u][0], a[u][2]), s13 = cadd(a[u][1], a[u][3]), d13 = csub(a[u][1], a[u][3]);
+                    const cplx y1 = make_double2(d02.x + d13.y, d02.y - d13.x);  // d02 - i d13
+                    const cplx y3 = make_double2(d02.x - d13.y, d02.y + d13.x);  // d02 + i d13
+                    ptr[u][0] = cadd(s02, s13);
+                    ptr[u][q] = cmul(y1, w[u][0]);
+                    ptr[u][2 * q] = cmul(csub(s02, s13), w[u][1]);
+                    ptr[u][3 * q] = cmul(y3, w[u][2]);
+                } else if (r == 3) {
+                    const cplx t1 = cadd(a[u][1], a[u][2]), dd = csub(a[u][1], a[u][2]);
+                    const cplx t2 = make_double2(a[u][0].x - 0.5 * t1.x, a[u][0].y - 0.5 * t1.y);
+                    const double h = 0.86602540378443864676;  // sqrt(3) / 2
+                    const cplx sv = make_double2(h * dd.x, h * dd.y);
+                    ptr[u][0] = cadd(a[u][0], t1);
+                    ptr[u][q] = cmul(make_double2(t2.x + sv.y, t2.y - sv.x), w[u][0]);      // t2 - i sv
+                    ptr[u][2 * q] = cmul(make_double2(t2.x - sv.y, t2.y + sv.x), w[u][1]);  // t2 + i sv
+                } else {
+                    ptr[u][0] = cadd(a[u][0], a[u][1]);
+                    ptr[u][q] = cmul(csub(a[u][0], a[u][1]), w[u][0]);
+                }
             }
         }
         __syncthreads();
-        lgL -= 2;
-    }
-    if (lgL == 1) {
-        for (int idx = threadIdx.x; idx < (N >> 1); idx += blockDim.x) {
-            const cplx a0 = x[2 * idx], a1 = x[2 * idx + 1];
-            x[2 * idx] = cadd(a0, a1);
-            x[2 * idx + 1] = csub(a0, a1);
-        }
-        __syncthreads();
+        L = q;
     }
 }
 
 // forward lag transform of short-axis line j (blockIdx.x) of pair blockIdx.y: element i of the line = m[i * ls + j * ss]
 __global__ __launch_bounds__(512) void k_lag_fwd(const float* __restrict__ m1, const float* __restrict__ m2, size_t pstride, int n_long, int n_short,
-                                                 int ls, int ss, int lgN, const cplx* __restrict__ tw, cplx* __restrict__ SF, cplx* __restrict__ ST) {
+                                                 int ls, int ss, FftPlan pl, const cplx* __restrict__ tw, const int* __restrict__ slot_pos,
+                                                 const int* __restrict__ slot_neg, cplx* __restrict__ SF, cplx* __restrict__ ST) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lag_lds[];
     cplx* x = reinterpret_cast<cplx*>(lag_lds);
-    const int N = 1 << lgN, NK = N / 2 + 1, j = blockIdx.x;
+    const int N = pl.N, NK = N / 2 + 1, j = blockIdx.x;
     const float* a = m1 + (size_t)blockIdx.y * pstride + (size_t)j * ss;
     const float* b = m2 + (size_t)blockIdx.y * pstride + (size_t)j * ss;
     for (int i = threadIdx.x; i < N; i += blockDim.x)
         x[i] = i < n_long ? make_double2((double)a[(size_t)i * ls], (double)b[(size_t)i * ls]) : make_double2(0.0, 0.0);
     __syncthreads();
-    fft_dif(x, lgN, tw);
+    fft_dif(x, pl, tw);
     cplx* of = SF + ((size_t)blockIdx.y * n_short + j) * NK;
     cplx* ot = ST + ((size_t)blockIdx.y * n_short + j) * NK;
+    // The N/2 + 1 frequencies 0 .. N/2 of a real signal's spectrum are kept in POSITION order ("slots": slot_pos ascending; slot_neg =
+    // position of the mirror frequency N - k): the untangling pass then reads LDS in nearly contiguous order -- in frequency
+    // order consecutive lanes sit N/4 elements apart, a 16-way bank conflict -- and the per-frequency correlation does not care
+    // about the order of its frequencies.
     for (int sl = threadIdx.x; sl < NK; sl += blockDim.x) {
-        const int p = pos_of_slot(sl, lgN), k = freq_of_pos(p, lgN);
-        const cplx zk = x[p], zn = x[pos_of_freq((N - k) & (N - 1), lgN)];
+        const cplx zk = x[slot_pos[sl]], zn = x[slot_neg[sl]];
         of[sl] = make_double2(0.5 * (zk.x + zn.x), 0.5 * (zk.y - zn.y));   // (Z[k] + conj Z[N-k]) / 2
         ot[sl] = make_double2(0.5 * (zk.y + zn.y), -0.5 * (zk.x - zn.x));  // (Z[k] - conj Z[N-k]) / (2 i)
     }
@@ -202,29 +201,29 @@ __global__ __launch_bounds__(256) void k_lag_mac(const cplx* __restrict__ SF, co
 
 // inverse lag transform of two short-axis lags (2 * blockIdx.x, + 1) of pair blockIdx.y: c_a[n] + i c_b[n] = FFT(conj C_a + i conj C_b) / N
 // (both c real); the long-axis lags [-El, El] go to cross[(u + Eu) * (2 Ev + 1) + (v + Ev)]
-__global__ __launch_bounds__(512) void k_lag_inv(const cplx* __restrict__ CH, int NK, int lgN, int Es, int El, int long_is_u, int Eu, int Ev,
-                                                 const cplx* __restrict__ tw, double* __restrict__ cross) {
+__global__ __launch_bounds__(512) void k_lag_inv(const cplx* __restrict__ CH, int NK, FftPlan pl, int Es, int El, int long_is_u, int Eu, int Ev,
+                                                 const cplx* __restrict__ tw, const int* __restrict__ slot_freq, double* __restrict__ cross) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lag_lds[];
     cplx* x = reinterpret_cast<cplx*>(lag_lds);
-    const int N = 1 << lgN, nlag = 2 * Es + 1, nlp = (nlag + 3) / 4 * 4;
+    const int N = pl.N, nlag = 2 * Es + 1, nlp = (nlag + 3) / 4 * 4;
     const int sa = 2 * blockIdx.x, sb = sa + 1;
     const bool has_b = sb < nlag;
     const cplx* src = CH + (size_t)blockIdx.y * NK * nlp;
     for (int sl = threadIdx.x; sl < NK; sl += blockDim.x) {
-        const int k = freq_of_pos(pos_of_slot(sl, lgN), lgN);
+        const int k = slot_freq[sl];
         const cplx xa = src[(size_t)sl * nlp + sa];
         const cplx xb = has_b ? src[(size_t)sl * nlp + sb] : make_double2(0.0, 0.0);
         x[k] = make_double2(xa.x + xb.y, -xa.y + xb.x);                              // conj(Xa) + i conj(Xb)
         if (k > 0 && k < N / 2) x[N - k] = make_double2(xa.x - xb.y, xa.y + xb.x);   // Xa + i Xb  (= conj X[N-k] terms)
     }
     __syncthreads();
-    fft_dif(x, lgN, tw);
+    fft_dif(x, pl, tw);
     const double inv = 1.0 / (double)N;
     const int W = 2 * Ev + 1;
     double* out = cross + (size_t)blockIdx.y * (2 * Eu + 1) * W;
     for (int e = threadIdx.x; e < 2 * El + 1; e += blockDim.x) {
         const int l = e - El;
-        const cplx v = x[pos_of_freq((l + N) & (N - 1), lgN)];
+        const cplx v = x[pos_of_freq((l + N) % N, pl)];
         if (long_is_u) {
             out[(size_t)(l + Eu) * W + (sa - Es + Ev)] = v.x * inv;
             if (has_b) out[(size_t)(l + Eu) * W + (sb - Es + Ev)] = v.y * inv;
@@ -235,10 +234,113 @@ __global__ __launch_bounds__(512) void k_lag_inv(const cplx* __restrict__ CH, in
     }
 }
 
+// ------------------------------------------------------------------------------------------------ banded summed-area tables
+// (BandView, ncc_core.h).  Logical coordinates: a = long axis, b = short axis, element (a, b) = m[a * ls + b * ss].
+constexpr int BAND_CH = 128;  // rows per chunk of the column sums
+
+// chunk column sums of (f - c0) and (f - c0)^2: T[((2 z + {0,1}) * nch + chunk) * n_short + b], z = blockIdx.z = 2 * pair + MIP.
+// LONG_CONTIG = false: rows a are n_short apart in memory, a wave owns 64 neighbouring columns b (coalesced rows);
+// LONG_CONTIG = true : the long axis is the contiguous one, a wave owns ONE b and strides along a.
+template <bool LONG_CONTIG>
+__global__ __launch_bounds__(64) void k_band_chunksum(const float* __restrict__ m1, const float* __restrict__ m2, size_t pstride, size_t sstride,
+                                                      const double* __restrict__ c0a, int n_long, int n_short, int ls, int ss, int nch,
+                                                      double* __restrict__ T) {
+    const int z = blockIdx.z, pair = z >> 1, which = z & 1, ca = blockIdx.y;
+    const float* m = (which ? m2 : m1) + (size_t)pair * pstride;
+    const double cm = c0a[(size_t)pair * sstride + which];
+    double* Tp = T + (size_t)pair * sstride + ((size_t)(2 * which) * nch + ca) * n_short;
+    double* Tq = Tp + (size_t)nch * n_short;
+    const int a0 = ca * BAND_CH, a1 = min(n_long, a0 + BAND_CH);
+    double p = 0.0, q = 0.0;
+    if (!LONG_CONTIG) {
+        const int b = blockIdx.x * 64 + threadIdx.x;
+        if (b >= n_short) return;
+        const float* col = m + (size_t)b * ss;
+#pragma unroll 4
+        for (int a = a0; a < a1; ++a) {
+            const double g = (double)col[(size_t)a * ls] - cm;
+            p += g;
+            q += g * g;
+        }
+        Tp[b] = p;
+        Tq[b] = q;
+    } else {
+        const int b = blockIdx.x;
+        const float* row = m + (size_t)b * ss;
+        for (int a = a0 + threadIdx.x; a < a1; a += 64) {
+            const double g = (double)row[(size_t)a * ls] - cm;
+            p += g;
+            q += g * g;
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            p += __shfl_down(p, off, 64);
+            q += __shfl_down(q, off, 64);
+        }
+        if (threadIdx.x == 0) { Tp[b] = p; Tq[b] = q; }
+    }
+}
+
+// column running sums at the band rows: tab[row(a)][b + 1] = sum_{a' < a} g[a'][b]  (P and Q of one MIP); blockIdx.y = band
+// (0: rows [0, B], 1: rows [n_long - B, n_long]), a lane owns one column b
+__global__ __launch_bounds__(64) void k_band_cols(const float* __restrict__ m1, const float* __restrict__ m2, size_t pstride, size_t sstride,
+                                                  const double* __restrict__ c0a, int n_long, int n_short, int ls, int ss, int nch, int B, size_t tab,
+                                                  const double* __restrict__ T, double* __restrict__ P1) {
+    const int z = blockIdx.z, pair = z >> 1, which = z & 1, band = blockIdx.y;
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= n_short) return;
+    const bool full = B >= n_long;
+    if (full && band == 1) return;
+    const float* col = (which ? m2 : m1) + (size_t)pair * pstride + (size_t)b * ss;
+    const double cm = c0a[(size_t)pair * sstride + which];
+    double* P = P1 + (size_t)pair * sstride + (size_t)(2 * which) * tab;  // P1 | Q1 | P2 | Q2
+    double* Q = P + tab;
+    const int w1 = n_short + 1;
+    auto rowof = [&](int a) { return (full || a <= B) ? a : a - (n_long - B) + B + 1; };
+    double p = 0.0, q = 0.0;
+    int a = 0;
+    if (band == 1) {  // everything below the band: whole chunks from their sums, the rest row by row
+        const int a_start = n_long - B, cs = a_start / BAND_CH;
+        const double* Tp = T + (size_t)pair * sstride + (size_t)(2 * which) * nch * n_short;
+        const double* Tq = Tp + (size_t)nch * n_short;
+        for (int c = 0; c < cs; ++c) { p += Tp[(size_t)c * n_short + b]; q += Tq[(size_t)c * n_short + b]; }
+        for (a = cs * BAND_CH; a < a_start; ++a) {
+            const double g = (double)col[(size_t)a * ls] - cm;
+            p += g;
+            q += g * g;
+        }
+    }
+    const int a_end = band == 0 ? min(n_long, full ? n_long : B) : n_long;
+    P[(size_t)rowof(a) * w1 + b + 1] = p;
+    Q[(size_t)rowof(a) * w1 + b + 1] = q;
+    for (; a < a_end; ++a) {
+        const double g = (double)col[(size_t)a * ls] - cm;
+        p += g;
+        q += g * g;
+        P[(size_t)rowof(a + 1) * w1 + b + 1] = p;
+        Q[(size_t)rowof(a + 1) * w1 + b + 1] = q;
+    }
+}
+
+// prefix along b of every kept row, in place; column 0 = 0.  One wave per (row, table); blockIdx.y = table (P1, Q1, P2, Q2)
+__global__ __launch_bounds__(64) void k_band_rows(size_t sstride, int n_short, size_t tab, double* __restrict__ P1) {
+    double* S = P1 + (size_t)blockIdx.z * sstride + (size_t)blockIdx.y * tab + (size_t)blockIdx.x * (n_short + 1);
+    const int lane = threadIdx.x;
+    double carry = 0.0;
+    if (lane == 0) S[0] = 0.0;
+    for (int b0 = 0; b0 < n_short; b0 += 64) {
+        const int b = b0 + lane;
+        const double v = b < n_short ? S[b + 1] : 0.0;
+        const double sc = wave_inclusive_scan(v) + carry;
+        if (b < n_short) S[b + 1] = sc;
+        carry = __shfl(sc, 63, 64);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ refinement on the device
 struct RefineGeom {
     int dimu, dimv, delayu, delayv, wu, wv, Eu, Ev, maxIter, tiled;
     size_t sstride, sat_off, tab, ts;  // doubles: per-pair stride of the table block, offset of this plane, table sizes
+    int n_long, n_short, B, long_is_u;  // band geometry of the tables (BandView)
     float margin;
 };
 
@@ -300,7 +402,8 @@ __global__ __launch_bounds__(256) void k_lag_refine(RefineGeom g, const double* 
     const int pair = blockIdx.x;
     const double* sat = sat_base + (size_t)pair * g.sstride + g.sat_off;
     const double *P1 = sat + 2, *Q1 = P1 + g.tab, *P2 = Q1 + g.tab, *Q2 = P2 + g.tab, *T1 = Q2 + g.tab, *T2 = T1 + g.ts;
-    const SatView v1{P1, Q1, g.tiled ? T1 : nullptr, sat}, v2{P2, Q2, g.tiled ? T2 : nullptr, sat + 1};
+    const BandView v1{P1, Q1, g.tiled ? T1 : nullptr, sat, g.n_long, g.n_short, g.B, g.long_is_u};
+    const BandView v2{P2, Q2, g.tiled ? T2 : nullptr, sat + 1, g.n_long, g.n_short, g.B, g.long_is_u};
     const int CW = 2 * g.Ev + 1;
     const double* cr = cross + (size_t)pair * (2 * g.Eu + 1) * CW;
     if (threadIdx.x == 0) sh_flags = 0;
@@ -364,16 +467,41 @@ __global__ __launch_bounds__(256) void k_lag_refine(RefineGeom g, const double* 
 // ------------------------------------------------------------------------------------------------ host side
 struct LagPlane {
     bool long_is_u;
-    int n_long, n_short, ls, ss, lgN, El, Es, Eu, Ev;
+    int n_long, n_short, ls, ss, El, Es, Eu, Ev;
+    FftPlan fft;
     int KT, JP, FW, TW, fft_threads;
     size_t lds_fft, lds_mac, lds_refine;
     bool ok;
 };
 
-int ilog2_ceil(int n) {
-    int lg = 0;
-    while ((1 << lg) < n) ++lg;
-    return lg;
+// smallest N = 2^a * {1, 3, 9} >= need (a >= 2), as radix-4 stages, then a radix-2 stage, then the radix-3 stages
+FftPlan make_fft_plan(int need) {
+    long best = 0;
+    int best_a = 0, best_b = 0;
+    for (int b = 0; b <= 2; ++b) {
+        long n = b == 0 ? 1 : (b == 1 ? 3 : 9);
+        int a = 0;
+        while (a < 2 || n < need) { n *= 2; ++a; }
+        if (best == 0 || n < best) { best = n; best_a = a; best_b = b; }
+    }
+    FftPlan pl{};
+    pl.N = (int)best;
+    int a = best_a;
+    while (a >= 2) { pl.radix[pl.nstages++] = 4; a -= 2; }
+    if (a == 1) pl.radix[pl.nstages++] = 2;
+    for (int b = 0; b < best_b; ++b) pl.radix[pl.nstages++] = 3;
+    return pl;
+}
+
+int host_pos_of_freq(int k, const FftPlan& pl) {
+    int p = 0, rem = pl.N;
+    for (int s = 0; s < pl.nstages; ++s) {
+        const int r = pl.radix[s];
+        rem /= r;
+        p += (k % r) * rem;
+        k /= r;
+    }
+    return p;
 }
 
 LagPlane plan_lag_plane(const PlaneGeom& g, int maxIter) {
@@ -391,9 +519,8 @@ LagPlane plan_lag_plane(const PlaneGeom& g, int maxIter) {
     p.Es = ds + (maxIter > 0 ? wsh : 0);
     p.Eu = p.long_is_u ? p.El : p.Es;
     p.Ev = p.long_is_u ? p.Es : p.El;
-    p.lgN = ilog2_ceil(p.n_long + p.El);
-    if (p.lgN < 2) p.lgN = 2;
-    p.lds_fft = sizeof(double) * 2 * ((size_t)1 << p.lgN);
+    p.fft = make_fft_plan(p.n_long + p.El);
+    p.lds_fft = sizeof(double) * 2 * (size_t)p.fft.N;
     const int PAD = p.Es + 3;
     p.FW = (p.n_short + 2 * PAD + 15) / 16 * 16 + 1;  // rows one 16-byte slot apart in the banks
     p.TW = (p.n_short + 15) / 16 * 16 + 1;
@@ -405,37 +532,59 @@ LagPlane plan_lag_plane(const PlaneGeom& g, int maxIter) {
     const int nvb = (2 * p.Es + 1 + 3) / 4;
     while (p.KT > 1 && p.KT * nvb > 256) --p.KT;
     p.JP = std::max(1, std::min(8, 256 / (p.KT * nvb)));
-    p.fft_threads = p.lgN >= 11 ? 512 : 256;
+    p.fft_threads = p.fft.N >= 2048 ? 512 : 256;
     p.lds_mac = std::max(row * p.KT, sizeof(double) * 2 * 4 * (size_t)p.JP * nvb * p.KT);
     const int Hm = 2 * g.delayu + 1, Wm = 2 * g.delayv + 1, H = 2 * g.wu + 1, W = 2 * g.wv + 1;
     p.lds_refine = sizeof(float) * ((size_t)Hm * Wm + 2 * (size_t)H * W);
-    p.ok = p.lgN <= 13 && p.lds_mac <= 150 * 1024 && nvb <= 256 && p.lds_refine <= 120 * 1024;
+    p.ok = p.fft.N <= 8192 && p.lds_mac <= 150 * 1024 && nvb <= 256 && p.lds_refine <= 120 * 1024;
     return p;
 }
 
-// exp(-2 pi i n / N) in fp64 for N = 2^lg, one table per (device, lg), kept for the life of the process
-struct TwiddleKey { int dev, lg; bool operator<(const TwiddleKey& o) const { return dev != o.dev ? dev < o.dev : lg < o.lg; } };
+// Per (device, N), kept for the life of the process: exp(-2 pi i n / N) in fp64, and the slot tables of the half spectrum
+// (position of slot s in ascending order, position of its mirror frequency, its frequency).
+struct FftTables {
+    const cplx* tw;
+    const int *slot_pos, *slot_neg, *slot_freq;
+};
+struct TwiddleKey { int dev, n; bool operator<(const TwiddleKey& o) const { return dev != o.dev ? dev < o.dev : n < o.n; } };
 std::mutex& g_tw_mu = *new std::mutex;
-std::map<TwiddleKey, void*>& g_tw = *new std::map<TwiddleKey, void*>;
+std::map<TwiddleKey, FftTables>& g_tw = *new std::map<TwiddleKey, FftTables>;
 
-int twiddles(int dev, int lg, hipStream_t s, const cplx** out) {
+int fft_tables(int dev, const FftPlan& pl, hipStream_t s, FftTables* out) {
     std::lock_guard<std::mutex> lock(g_tw_mu);
-    auto it = g_tw.find(TwiddleKey{dev, lg});
-    if (it != g_tw.end()) { *out = static_cast<const cplx*>(it->second); return MI_OK; }
-    const size_t N = (size_t)1 << lg;
+    auto it = g_tw.find(TwiddleKey{dev, pl.N});
+    if (it != g_tw.end()) { *out = it->second; return MI_OK; }
+    const size_t N = (size_t)pl.N, NK = N / 2 + 1;
     std::vector<double> h(2 * N);
     const long double step = 2.0L * 3.14159265358979323846264338327950288L / (long double)N;
-    for (size_t n = 0; n < N; ++n) {  // octant symmetry keeps the table exact where it matters: n = 0, N/4, N/2, ...
+    for (size_t n = 0; n < N; ++n) {
         h[2 * n] = (double)cosl(step * (long double)n);
         h[2 * n + 1] = (double)-sinl(step * (long double)n);
     }
-    if (N >= 4) { h[2 * (N / 4)] = 0.0; h[2 * (N / 4) + 1] = -1.0; h[2 * (N / 2)] = -1.0; h[2 * (N / 2) + 1] = 0.0; h[2 * (3 * N / 4)] = 0.0; h[2 * (3 * N / 4) + 1] = 1.0; }
-    void* d = nullptr;
+    if (N % 4 == 0) {  // exact at the quarter points
+        h[2 * (N / 4)] = 0.0; h[2 * (N / 4) + 1] = -1.0;
+        h[2 * (N / 2)] = -1.0; h[2 * (N / 2) + 1] = 0.0;
+        h[2 * (3 * N / 4)] = 0.0; h[2 * (3 * N / 4) + 1] = 1.0;
+    }
+    std::vector<std::pair<int, int>> order(NK);  // (position, frequency)
+    for (size_t k = 0; k < NK; ++k) order[k] = {host_pos_of_freq((int)k, pl), (int)k};
+    std::sort(order.begin(), order.end());
+    std::vector<int> tabs(3 * NK);
+    for (size_t sl = 0; sl < NK; ++sl) {
+        tabs[sl] = order[sl].first;
+        tabs[NK + sl] = host_pos_of_freq((int)((N - (size_t)order[sl].second) % N), pl);
+        tabs[2 * NK + sl] = order[sl].second;
+    }
+    void *d = nullptr, *di = nullptr;
     MI_HIP(hipMalloc(&d, sizeof(double) * 2 * N));
+    MI_HIP(hipMalloc(&di, sizeof(int) * 3 * NK));
     MI_HIP(hipMemcpyAsync(d, h.data(), sizeof(double) * 2 * N, hipMemcpyHostToDevice, s));
+    MI_HIP(hipMemcpyAsync(di, tabs.data(), sizeof(int) * 3 * NK, hipMemcpyHostToDevice, s));
     MI_HIP(hipStreamSynchronize(s));
-    g_tw[TwiddleKey{dev, lg}] = d;
-    *out = static_cast<const cplx*>(d);
+    const int* ti = static_cast<const int*>(di);
+    FftTables t{static_cast<const cplx*>(d), ti, ti + NK, ti + 2 * NK};
+    g_tw[TwiddleKey{dev, pl.N}] = t;
+    *out = t;
     return MI_OK;
 }
 
@@ -473,17 +622,18 @@ int grow(DevBuf& b, size_t bytes) { return b.bytes >= bytes ? MI_OK : b.alloc(by
 
 // cross terms of `np` pairs of one plane through the lag transform (MIPs at m1 / m2 + q * pstride) into ws.cross
 int lag_cross(int dev, hipStream_t s, const LagPlane& lp, const float* m1, const float* m2, size_t pstride, int np, LagWorkspace& ws) {
-    const int N = 1 << lp.lgN, NK = N / 2 + 1, nlag = 2 * lp.Es + 1, nlp = (nlag + 3) / 4 * 4;
-    const cplx* tw = nullptr;
-    MI_TRY(twiddles(dev, lp.lgN, s, &tw));
+    const int N = lp.fft.N, NK = N / 2 + 1, nlag = 2 * lp.Es + 1, nlp = (nlag + 3) / 4 * 4;
+    FftTables ft;
+    MI_TRY(fft_tables(dev, lp.fft, s, &ft));
+    const cplx* tw = ft.tw;
     MI_TRY(grow(ws.SF, sizeof(double) * 2 * (size_t)np * lp.n_short * NK));
     MI_TRY(grow(ws.ST, sizeof(double) * 2 * (size_t)np * lp.n_short * NK));
     MI_TRY(grow(ws.CH, sizeof(double) * 2 * (size_t)np * NK * nlp));
     MI_TRY(grow(ws.cross, sizeof(double) * (size_t)np * (2 * lp.Eu + 1) * (2 * lp.Ev + 1)));
     if (lp.lds_fft > 64 * 1024)
         MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lag_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp.lds_fft));
-    hipLaunchKernelGGL(k_lag_fwd, dim3(lp.n_short, np), dim3(lp.fft_threads), lp.lds_fft, s, m1, m2, pstride, lp.n_long, lp.n_short, lp.ls, lp.ss, lp.lgN, tw,
-                       ws.SF.as<cplx>(), ws.ST.as<cplx>());
+    hipLaunchKernelGGL(k_lag_fwd, dim3(lp.n_short, np), dim3(lp.fft_threads), lp.lds_fft, s, m1, m2, pstride, lp.n_long, lp.n_short, lp.ls, lp.ss, lp.fft, tw,
+                       ft.slot_pos, ft.slot_neg, ws.SF.as<cplx>(), ws.ST.as<cplx>());
     MI_TRY(launch_check("k_lag_fwd"));
     if (lp.lds_mac > 64 * 1024)
         MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lag_mac), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp.lds_mac));
@@ -492,17 +642,65 @@ int lag_cross(int dev, hipStream_t s, const LagPlane& lp, const float* m1, const
     MI_TRY(launch_check("k_lag_mac"));
     if (lp.lds_fft > 64 * 1024)
         MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lag_inv), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp.lds_fft));
-    hipLaunchKernelGGL(k_lag_inv, dim3((nlag + 1) / 2, np), dim3(lp.fft_threads), lp.lds_fft, s, ws.CH.as<cplx>(), NK, lp.lgN, lp.Es, lp.El, lp.long_is_u ? 1 : 0,
-                       lp.Eu, lp.Ev, tw, ws.cross.as<double>());
+    hipLaunchKernelGGL(k_lag_inv, dim3((nlag + 1) / 2, np), dim3(lp.fft_threads), lp.lds_fft, s, ws.CH.as<cplx>(), NK, lp.fft, lp.Es, lp.El, lp.long_is_u ? 1 : 0,
+                       lp.Eu, lp.Ev, tw, ft.slot_freq, ws.cross.as<double>());
     return launch_check("k_lag_inv");
 }
 
-RefineGeom refine_geom(const PlaneGeom& g, const LagPlane& lp, int maxIter, size_t sstride, float margin) {
-    const SatLayout L(g.dimu, g.dimv);
+// layout of one plane's banded tables (doubles): c0a, c0b | P1 | Q1 | P2 | Q2 | TS1 | TS2 | partial pixel sums | chunk column sums
+struct BandLayout {
+    int B, rows, nch;
+    size_t tab, ts, total;
+    BandLayout(const PlaneGeom& g, const LagPlane& lp) {
+        B = lp.El + TILE;                                   // rows read: within E (+ 31 for the tile-aligned ones) of either end
+        if (2 * (B + 1) >= lp.n_long + 1) B = lp.n_long;    // no gain: keep every row
+        rows = B >= lp.n_long ? lp.n_long + 1 : 2 * (B + 1);
+        nch = (lp.n_long + BAND_CH - 1) / BAND_CH;
+        tab = (size_t)rows * (lp.n_short + 1);
+        ts = (size_t)(g.dimu / TILE + 1) * (g.dimv / TILE + 1);
+        total = 2 + 4 * tab + 2 * ts + 2 * MEAN_PARTS + 4 * (size_t)nch * lp.n_short;
+    }
+};
+
+// float tile sums (reference order), global means and the banded tables of both MIPs of a plane, `np` pairs at once
+int prepare_plane_band(hipStream_t s, const float* m1, const float* m2, const PlaneGeom& g, const LagPlane& lp, float* ps1, float* ps2, double* sat,
+                       int np, size_t pstride, size_t sstride) {
+    const BandLayout L(g, lp);
+    double *c0a = sat, *c0b = sat + 1, *P1 = sat + 2, *T1 = P1 + 4 * L.tab, *T2 = T1 + L.ts, *part = T2 + L.ts, *chunks = part + 2 * MEAN_PARTS;
+    if (g.tiled) {
+        const int nt = (g.dimu / TILE) * (g.dimv / TILE);
+        hipLaunchKernelGGL(k_tile_sums, dim3(nt, 2, np), dim3(64), 0, s, m1, m2, pstride, g.dimu, g.dimv, ps1, ps2);
+        MI_TRY(launch_check("k_tile_sums"));
+    }
+    hipLaunchKernelGGL(k_mip_partial, dim3(MEAN_PARTS, 2, np), dim3(256), 0, s, m1, m2, pstride, sstride, (size_t)g.dimu * g.dimv, part);
+    MI_TRY(launch_check("k_mip_partial"));
+    hipLaunchKernelGGL(k_mip_mean, dim3(2, 1, np), dim3(1024), 0, s, part, pstride, sstride, g.dimu, g.dimv, g.tiled ? ps1 : nullptr,
+                       g.tiled ? ps2 : nullptr, c0a, c0b, T1, T2);
+    MI_TRY(launch_check("k_mip_mean"));
+    const int cblocks = (lp.n_short + 63) / 64;
+    if (L.B < lp.n_long) {  // the lower band starts from the chunk sums
+        if (lp.long_is_u)
+            hipLaunchKernelGGL(k_band_chunksum<false>, dim3(cblocks, L.nch, 2 * np), dim3(64), 0, s, m1, m2, pstride, sstride, c0a, lp.n_long, lp.n_short,
+                               lp.ls, lp.ss, L.nch, chunks);
+        else
+            hipLaunchKernelGGL(k_band_chunksum<true>, dim3(lp.n_short, L.nch, 2 * np), dim3(64), 0, s, m1, m2, pstride, sstride, c0a, lp.n_long, lp.n_short,
+                               lp.ls, lp.ss, L.nch, chunks);
+        MI_TRY(launch_check("k_band_chunksum"));
+    }
+    hipLaunchKernelGGL(k_band_cols, dim3(cblocks, 2, 2 * np), dim3(64), 0, s, m1, m2, pstride, sstride, c0a, lp.n_long, lp.n_short, lp.ls, lp.ss, L.nch,
+                       L.B, L.tab, chunks, P1);
+    MI_TRY(launch_check("k_band_cols"));
+    hipLaunchKernelGGL(k_band_rows, dim3(L.rows, 4, np), dim3(64), 0, s, sstride, lp.n_short, L.tab, P1);
+    return launch_check("k_band_rows");
+}
+
+RefineGeom refine_geom(const PlaneGeom& g, const LagPlane& lp, int maxIter, size_t sstride, size_t sat_off, float margin) {
+    const BandLayout L(g, lp);
     RefineGeom r{};
     r.dimu = g.dimu; r.dimv = g.dimv; r.delayu = g.delayu; r.delayv = g.delayv; r.wu = g.wu; r.wv = g.wv;
     r.Eu = lp.Eu; r.Ev = lp.Ev; r.maxIter = maxIter; r.tiled = g.tiled ? 1 : 0;
-    r.sstride = sstride; r.sat_off = g.sat; r.tab = L.tab; r.ts = L.ts; r.margin = margin;
+    r.sstride = sstride; r.sat_off = sat_off; r.tab = L.tab; r.ts = L.ts; r.margin = margin;
+    r.n_long = lp.n_long; r.n_short = lp.n_short; r.B = L.B; r.long_is_u = lp.long_is_u ? 1 : 0;
     return r;
 }
 
@@ -540,12 +738,17 @@ int ncc_lag_group(int dev, hipStream_t s, int n, const float* const* a_ptrs, con
     struct Giver { std::unique_ptr<LagWorkspace>& p; ~Giver() { give_lag_ws(std::move(p)); } } giver{wsp};
 
     // per-pair footprint -> chunk size
-    const size_t pstride = (pl.total_floats + 3) / 4 * 4, sstride = pl.sat_doubles;
+    size_t sat_off[3], sstride = 0;
+    for (int m = 0; m < 3; ++m) {
+        sat_off[m] = sstride;
+        sstride += BandLayout(pl.g[m], lp[m]).total;
+    }
+    const size_t pstride = (pl.total_floats + 3) / 4 * 4;
     const size_t tmp_floats = mips_tmp_floats(pl.dimk, pl.dimi_v, pl.dimj_v);
     size_t spec = 0, crs = 0;
     int wcap = 1;
     for (int m = 0; m < 3; ++m) {
-        const size_t NK = ((size_t)1 << lp[m].lgN) / 2 + 1, nlp = (2 * lp[m].Es + 1 + 3) / 4 * 4;
+        const size_t NK = (size_t)lp[m].fft.N / 2 + 1, nlp = (2 * lp[m].Es + 1 + 3) / 4 * 4;
         spec = std::max(spec, 16 * (2 * (size_t)lp[m].n_short * NK + NK * nlp));
         crs = std::max(crs, 8 * (size_t)(2 * lp[m].Eu + 1) * (2 * lp[m].Ev + 1));
         wcap = std::max(wcap, (2 * pl.g[m].wu + 1) * (2 * pl.g[m].wv + 1));
@@ -581,11 +784,10 @@ int ncc_lag_group(int dev, hipStream_t s, int n, const float* const* a_ptrs, con
                            base + pl.g[2].mip2, ws.mip_tmp.as<float>()));
         for (int m = 0; m < 3; ++m) {
             const PlaneGeom& g = pl.g[m];
-            SatView v1, v2;
-            MI_TRY(prepare_plane(s, base + g.mip1, base + g.mip2, g.dimu, g.dimv, base + g.ps1, base + g.ps2, ws.sat.as<double>() + g.sat, &v1, &v2,
-                                 nc, pstride, sstride));
+            MI_TRY(prepare_plane_band(s, base + g.mip1, base + g.mip2, g, lp[m], base + g.ps1, base + g.ps2, ws.sat.as<double>() + sat_off[m], nc,
+                                      pstride, sstride));
             MI_TRY(lag_cross(dev, s, lp[m], base + g.mip1, base + g.mip2, pstride, nc, ws));
-            const RefineGeom rg = refine_geom(g, lp[m], P.maxIter, sstride, margin);
+            const RefineGeom rg = refine_geom(g, lp[m], P.maxIter, sstride, sat_off[m], margin);
             if (lp[m].lds_refine > 64 * 1024)
                 MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lag_refine), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp[m].lds_refine));
             hipLaunchKernelGGL(k_lag_refine, dim3(nc), dim3(256), lp[m].lds_refine, s, rg, ws.sat.as<double>(), ws.cross.as<double>(), wcap,
@@ -644,16 +846,15 @@ int ncc_lag_map(int dev, hipStream_t s, const float* mip1, const float* mip2, in
     LagWorkspace& ws = *wsp;
     struct Giver { std::unique_ptr<LagWorkspace>& p; ~Giver() { give_lag_ws(std::move(p)); } } giver{wsp};
     const int nt = (dimu / TILE) * (dimv / TILE);
-    const SatLayout L(dimu, dimv);
+    const BandLayout L(g, lp);
     DevBuf ps;
     MI_TRY(ps.alloc(sizeof(float) * 2 * (size_t)(nt > 0 ? nt : 1)));
     MI_TRY(grow(ws.sat, 8 * L.total));
     MI_TRY(grow(ws.outw, 4 * 4));
     MI_TRY(grow(ws.outi, sizeof(int) * 4));
-    SatView v1, v2;
-    MI_TRY(prepare_plane(s, mip1, mip2, dimu, dimv, ps.as<float>(), ps.as<float>() + (nt > 0 ? nt : 0), ws.sat.as<double>(), &v1, &v2));
+    MI_TRY(prepare_plane_band(s, mip1, mip2, g, lp, ps.as<float>(), ps.as<float>() + (nt > 0 ? nt : 0), ws.sat.as<double>(), 1, 0, L.total));
     MI_TRY(lag_cross(dev, s, lp, mip1, mip2, 0, 1, ws));
-    const RefineGeom rg = refine_geom(g, lp, 0, L.total, 0.0f);
+    const RefineGeom rg = refine_geom(g, lp, 0, L.total, 0, 0.0f);
     if (lp.lds_refine > 64 * 1024)
         MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lag_refine), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp.lds_refine));
     hipLaunchKernelGGL(k_lag_refine, dim3(1), dim3(256), lp.lds_refine, s, rg, ws.sat.as<double>(), ws.cross.as<double>(), 1, ws.outw.as<float>(),
