@@ -53,6 +53,49 @@ __device__ __forceinline__ float wave_max_nonneg(float v) {
     return v;
 }
 
+// Maxima of 16 per-lane values over the 64 lanes of a wave, all 16 rows at once (transpose reduction): in each of four steps a lane
+// hands one half of its rows to the partner lane^m and keeps the other half, taking the maximum with what it receives -- 8 + 4 +
+// 2 + 1 exchanges instead of 16 x 4 -- then two more exchanges merge the four 16-lane groups.  Returns, in EVERY lane, the maximum
+// of row rows_of_lane(lane) = bit-reversal of (lane & 15).  Values >= 0.
+__device__ __forceinline__ int row_of_lane(int lane) { return ((lane & 1) << 3) | ((lane & 2) << 1) | ((lane & 4) >> 1) | ((lane & 8) >> 3); }
+__device__ __forceinline__ float rows_max16(const float (&v)[MIP_ROWS], int lane) {
+    float w[8];
+    {   // partner lane ^ 1 (DPP quad_perm [1,0,3,2])
+        const bool up = lane & 1;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float mine = up ? v[i + 8] : v[i], send = up ? v[i] : v[i + 8];
+            const float recv = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0xB1, 0xf, 0xf, false));
+            w[i] = fmaxf(mine, recv);
+        }
+    }
+    {   // partner lane ^ 2 (DPP quad_perm [2,3,0,1])
+        const bool up = lane & 2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float mine = up ? w[i + 4] : w[i], send = up ? w[i] : w[i + 4];
+            const float recv = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0x4E, 0xf, 0xf, false));
+            w[i] = fmaxf(mine, recv);
+        }
+    }
+    {
+        const bool up = lane & 4;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float mine = up ? w[i + 2] : w[i], send = up ? w[i] : w[i + 2];
+            w[i] = fmaxf(mine, __shfl_xor(send, 4, 64));
+        }
+    }
+    {
+        const bool up = lane & 8;
+        const float mine = up ? w[1] : w[0], send = up ? w[0] : w[1];
+        w[0] = fmaxf(mine, __shfl_xor(send, 8, 64));
+    }
+    w[0] = fmaxf(w[0], __shfl_xor(w[0], 16, 64));
+    w[0] = fmaxf(w[0], __shfl_xor(w[0], 32, 64));
+    return w[0];
+}
+
 // view(k,i,j) = vol[k*slice + (i+i0)*pitch + (j+j0)]; blockIdx.z = 2 * pair + (0: A, 1: B).  A batch hands the tile pointers
 // over as a device table (tab[2 * pair + which]); every output array of pair q sits q * pstride floats behind pair 0's.
 __global__ __launch_bounds__(256) void k_mips(const float* __restrict__ A, const float* __restrict__ B, const float* const* __restrict__ tab,
@@ -89,10 +132,14 @@ __global__ __launch_bounds__(256) void k_mips(const float* __restrict__ A, const
         for (int r = 0; r < MIP_ROWS; ++r) {
             best[r] = fmaxf(best[r], v[r]);
             colmax = fmaxf(colmax, v[r]);
-            const float rowmax = wave_max_nonneg(v[r]);  // max over the 64 columns of the patch, in lane 63
-            // xz: per patch through LDS into xz_tmp[tile][column block][i][k] (k_mips_xz takes the maximum over the column blocks);
-            // as atomics on the MIP they were 655 thousand single-lane atomics per C5 pair
-            if (lane == 63) {
+        }
+        // xz: the 16 row maxima over the 64 columns of the patch, per patch through LDS into xz_tmp[tile][column block][i][k]
+        // (k_mips_xz takes the maximum over the column blocks); as atomics on the MIP they were 655 thousand single-lane
+        // atomics per C5 pair, as 16 separate wave reductions 96 DPP steps per slice
+        {
+            const float rowmax = rows_max16(v, lane);
+            const int r = row_of_lane(lane);
+            if (lane < 16) {
                 if (xz_tmp) xzp[r * dimk + k] = rowmax;
                 else if (r < rows) atomic_max_nonneg(&xz[(size_t)(i0 + r) * dimk + k], rowmax);
             }
