@@ -38,10 +38,12 @@ int gauss3d_async(hipStream_t s, float* vol, float* work, int nx, int ny, int nz
 // dst = G(src) in ONE pass when the filter fits the fused kernel (*fused = true); else the two-pass route, which uses dst as
 // its intermediate and leaves the result in src (*fused = false)
 int gauss3d_to(hipStream_t s, float* src, float* dst, int nx, int ny, int nz, const float* sigma, const int* ksize, bool* fused);
-struct FftEngine;
-// keep != nullptr: the FFT engine of the blur is created into / reused from *keep (see mi_decon_plan); the caller owns it
+struct TaperKeep;  // the FFT engines of edgetaper_3d's blur (edgetaper.hip)
+void taper_keep_free(TaperKeep* k);
+// keep != nullptr: the engines of the blur are created into / reused from *keep (see mi_decon_plan); the caller owns it and frees it
+// with taper_keep_free
 int edgetaper_async(hipStream_t s, float* bl, float* work, const float* psf, int nx, int ny, int nz, int kx, int ky, int kz,
-                    FftEngine** keep = nullptr);
+                    TaperKeep** keep = nullptr);
 
 // common.hip
 int sumsq_async(hipStream_t s, const float* x, size_t n, double* d_out);

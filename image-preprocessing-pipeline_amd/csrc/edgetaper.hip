@@ -48,10 +48,154 @@ __global__ __launch_bounds__(256) void k_taper_blend(float* __restrict__ bl, con
     }
 }
 
+// dst (grid F, x fastest) = src[clamp(origin + q)] for q < extent per axis, 0 beyond: the replicate-padded neighbourhood of a face slab
+__global__ __launch_bounds__(256) void k_pack_clamped(const float* __restrict__ src, int nx, int ny, int nz, float* __restrict__ dst, int Fx, int Fy,
+                                                      int Fz, int ox, int oy, int oz, int ex, int ey, int ez) {
+    const size_t total = (size_t)Fx * Fy * Fz;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % Fx);
+        const size_t r = i / Fx;
+        const int y = (int)(r % Fy), z = (int)(r / Fy);
+        float v = 0.0f;
+        if (x < ex && y < ey && z < ez) {
+            const int sx = min(max(ox + x, 0), nx - 1), sy = min(max(oy + y, 0), ny - 1), sz = min(max(oz + z, 0), nz - 1);
+            v = src[((size_t)sz * ny + sy) * nx + sx];
+        }
+        dst[i] = v;
+    }
+}
+
+// work[box] = grid[(p - box.lo) + c]: the owned region of a slab out of its convolved grid
+__global__ __launch_bounds__(256) void k_unpack_box(const float* __restrict__ grid, int Fx, int Fy, float* __restrict__ work, int nx, int ny, int x0,
+                                                    int y0, int z0, int bx, int by, int bz, int cx, int cy, int cz) {
+    const size_t total = (size_t)bx * by * bz;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % bx);
+        const size_t r = i / bx;
+        const int y = (int)(r % by), z = (int)(r / by);
+        work[((size_t)(z0 + z) * ny + y0 + y) * nx + x0 + x] = grid[((size_t)(z + cz) * Fy + y + cy) * Fx + x + cx];
+    }
+}
+
+unsigned stream_blocks(size_t n) {
+    size_t b = (n + 255) / 256;
+    return (unsigned)(b > 256 * 32 ? 256 * 32 : (b < 1 ? 1 : b));
+}
+
+}  // namespace
+
+// what a deconvolution plan keeps of the taper between blocks of one shape and PSF: the engine of the whole replicate-padded
+// block, or the three engines of the face slabs (x, y, z)
+struct TaperKeep {
+    FftEngine* full = nullptr;
+    FftEngine* slab[3] = {nullptr, nullptr, nullptr};
+    ~TaperKeep() {
+        delete full;
+        for (FftEngine* e : slab) delete e;
+    }
+};
+void taper_keep_free(TaperKeep* k) { delete k; }
+
+namespace {
+
+// The blur is only needed where the mask is below 1: the shell of the block.  Shell = six face slabs, cut so that they do not
+// overlap (x slabs: full y, z; y slabs: x plateau only; z slabs: x and y plateau): each pair of opposite slabs goes through ONE
+// circular FFT engine on a grid just large enough for the slab plus the PSF's reach -- its input is the clamped (= replicate
+// padded, conv3d_gpu.cu:82-91) neighbourhood of the slab gathered from the block, its output lands in `work` at the slab's
+// voxels.  On config C3 that is 1.3 G grid points at the circular pipeline's 8 ps instead of 3.1 G at the padded one's 24 ps.
+struct SlabPlan {
+    int lo[3], hi[3];      // plateau [lo, hi) per axis: the shell is [0, lo) and [hi, n)
+    int F[3][3];           // grid of the slabs of axis d
+    int thick[3];          // owned thickness of the thicker of the two slabs of axis d
+    double points;         // grid points of all six convolutions
+    bool ok;
+};
+
+SlabPlan plan_slabs(const int n[3], const int k[3], const ConvEpilogue& epi) {
+    SlabPlan sp{};
+    sp.ok = true;
+    sp.points = 0.0;
+    for (int d = 0; d < 3; ++d) {
+        sp.lo[d] = epi.plat_lo[d];
+        sp.hi[d] = epi.plat_hi[d];
+        sp.thick[d] = std::max(sp.lo[d], n[d] - sp.hi[d]);
+        if (!(sp.hi[d] > sp.lo[d]) || (k[d] & 1) == 0) sp.ok = false;  // no plateau on this axis: the shell is the whole block
+    }
+    if (!sp.ok) return sp;
+    for (int d = 0; d < 3; ++d) {
+        if (sp.thick[d] == 0) { sp.F[d][0] = sp.F[d][1] = sp.F[d][2] = 0; continue; }
+        for (int a = 0; a < 3; ++a) {
+            // owned extent along a: the slab's thickness on its own axis; on the others the whole block (x slabs), or the plateau
+            // of the axes already covered by earlier slabs
+            int owned = a == d ? sp.thick[d] : (a < d ? sp.hi[a] - sp.lo[a] : n[a]);
+            const int e = owned + k[a] - 1;
+            const int g = mi_fft_good_size(e, a);
+            if (g <= 0) { sp.ok = false; return sp; }
+            sp.F[d][a] = g;
+        }
+        sp.points += 2.0 * (double)sp.F[d][0] * sp.F[d][1] * sp.F[d][2];
+    }
+    return sp;
+}
+
+int edgetaper_slabs(hipStream_t s, const float* bl, float* work, const float* psf_norm, const int n[3], const int k[3], const SlabPlan& sp,
+                    TaperKeep* keep) {
+    const int circ[3] = {MI_BOUNDARY_CIRCULAR, MI_BOUNDARY_CIRCULAR, MI_BOUNDARY_CIRCULAR};
+    int shift[3], c[3];
+    for (int a = 0; a < 3; ++a) {
+        shift[a] = k[a] - 1 - conv_kernel_offset(k[a], MI_BOUNDARY_REPLICATE);  // sample j acts at offset j - shift
+        c[a] = k[a] / 2;                                                         // reach towards lower indices (odd k)
+    }
+    DevBuf gin, gout;
+    for (int d = 0; d < 3; ++d) {
+        if (sp.thick[d] == 0) continue;
+        const int* F = sp.F[d];
+        const size_t G = (size_t)F[0] * F[1] * F[2];
+        if (gin.bytes < sizeof(float) * G) {
+            MI_HIP(hipStreamSynchronize(s));
+            MI_TRY(gin.alloc(sizeof(float) * G));
+            MI_TRY(gout.alloc(sizeof(float) * G));
+        }
+        FftEngine local, *fe = &local;
+        if (keep) {
+            if (!keep->slab[d]) {
+                keep->slab[d] = new (std::nothrow) FftEngine;
+                if (!keep->slab[d]) return fail(MI_ERR_NOMEM, "edgetaper_3d: out of host memory");
+                int rc = keep->slab[d]->init(s, F, k, circ, shift, psf_norm, nullptr, false);
+                if (rc != MI_OK) { delete keep->slab[d]; keep->slab[d] = nullptr; return rc; }
+            }
+            fe = keep->slab[d];
+        } else {
+            MI_TRY(local.init(s, F, k, circ, shift, psf_norm, nullptr, false));
+        }
+        for (int side = 0; side < 2; ++side) {
+            int b0[3], b1[3];  // owned box
+            for (int a = 0; a < 3; ++a) {
+                if (a == d) { b0[a] = side == 0 ? 0 : sp.hi[a]; b1[a] = side == 0 ? sp.lo[a] : n[a]; }
+                else if (a < d) { b0[a] = sp.lo[a]; b1[a] = sp.hi[a]; }
+                else { b0[a] = 0; b1[a] = n[a]; }
+            }
+            if (b1[d] <= b0[d]) continue;
+            const int ex = b1[0] - b0[0] + k[0] - 1, ey = b1[1] - b0[1] + k[1] - 1, ez = b1[2] - b0[2] + k[2] - 1;
+            hipLaunchKernelGGL(k_pack_clamped, dim3(stream_blocks(G)), dim3(256), 0, s, bl, n[0], n[1], n[2], gin.as<float>(), F[0], F[1], F[2],
+                               b0[0] - c[0], b0[1] - c[1], b0[2] - c[2], ex, ey, ez);
+            MI_TRY(launch_check("k_pack_clamped"));
+            MI_TRY(fe->conv(s, gin.as<float>(), false, gout.as<float>(), EPI_NONE, ConvEpilogue()));
+            const size_t box = (size_t)(b1[0] - b0[0]) * (b1[1] - b0[1]) * (b1[2] - b0[2]);
+            hipLaunchKernelGGL(k_unpack_box, dim3(stream_blocks(box)), dim3(256), 0, s, gout.as<float>(), F[0], F[1], work, n[0], n[1], b0[0], b0[1],
+                               b0[2], b1[0] - b0[0], b1[1] - b0[1], b1[2] - b0[2], c[0], c[1], c[2]);
+            MI_TRY(launch_check("k_unpack_box"));
+        }
+        if (!keep) MI_HIP(hipStreamSynchronize(s));  // the local engine's buffers die at scope exit
+    }
+    MI_HIP(hipStreamSynchronize(s));  // gin / gout die at scope exit
+    return MI_OK;
+}
+
 }  // namespace
 
 int edgetaper_async(hipStream_t s, float* bl, float* work, const float* psf, int nx, int ny, int nz, int kx, int ky, int kz,
-                    FftEngine** keep) {
+                    TaperKeep** keep) {
     MI_REQUIRE(bl && work && psf && bl != work, "edgetaper_3d: null or aliased buffers");
     MI_REQUIRE(nx > 0 && ny > 0 && nz > 0 && kx > 0 && ky > 0 && kz > 0, "edgetaper_3d: bl and psf must be 3D");
     const int n[3] = {nx, ny, nz}, k[3] = {kx, ky, kz};
@@ -95,13 +239,39 @@ int edgetaper_async(hipStream_t s, float* bl, float* work, const float* psf, int
     const double t_fft = native_grid ? nf * 25e-12 + 0.02 : nf * 220.0 / 4e12 + 2.5;
     const bool odd = (kx & 1) && (ky & 1) && (kz & 1);
     bool use_fft = odd && t_fft < t_direct;
-    if (const char* f = std::getenv("MI_EDGETAPER_ENGINE")) use_fft = odd && f[0] == 'f';  // tests / experiments: "fft" | "direct"
-    if (use_fft) {
+    // six face slabs through circular engines instead of the whole replicate-padded block
+    const SlabPlan sp = plan_slabs(n, k, epi);
+    const double t_slabs = sp.ok ? sp.points * 9e-12 + nvox * shell * 8.0 / 3e12 + 0.005 : 1e30;
+    bool use_slabs = odd && sp.ok && t_slabs < t_fft && t_slabs < t_direct;
+    if (const char* f = std::getenv("MI_EDGETAPER_ENGINE")) {  // tests / experiments: "fft" | "direct" | "slabs"
+        use_fft = odd && f[0] == 'f';
+        use_slabs = odd && sp.ok && f[0] == 's';
+    }
+    if (use_slabs) {
+        TaperKeep local_keep;
+        TaperKeep* kp = nullptr;
+        if (keep) {
+            if (!*keep) *keep = new (std::nothrow) TaperKeep;
+            if (!*keep) return fail(MI_ERR_NOMEM, "edgetaper_3d: out of host memory");
+            kp = *keep;
+        }
+        DevBuf pn;
+        MI_TRY(normalised_psf(s, psf, kx * ky * kz, pn));
+        int rc = edgetaper_slabs(s, bl, work, pn.as<float>(), n, k, sp, kp);
+        hipError_t e = hipStreamSynchronize(s);  // pn dies here
+        if (rc == MI_OK && e != hipSuccess) rc = fail(MI_ERR_HIP, "edgetaper_3d: %s", hipGetErrorString(e));
+        MI_TRY(rc);
+        (void)local_keep;
+    } else if (use_fft) {
         // `keep` (a deconvolution plan): the engine -- the OTF of the normalised PSF on the replicate-padded grid -- outlives
         // the call and serves the next block of the same shape and PSF
         FftEngine local, *fe = &local;
         bool built = false;
-        if (keep && *keep) fe = *keep;
+        if (keep && !*keep) {
+            *keep = new (std::nothrow) TaperKeep;
+            if (!*keep) return fail(MI_ERR_NOMEM, "edgetaper_3d: out of host memory");
+        }
+        if (keep && (*keep)->full) fe = (*keep)->full;
         else {
             if (keep) {
                 fe = new (std::nothrow) FftEngine;
@@ -119,7 +289,7 @@ int edgetaper_async(hipStream_t s, float* bl, float* work, const float* psf, int
                 if (keep) delete fe;
                 return rc;
             }
-            if (keep) *keep = fe;
+            if (keep) (*keep)->full = fe;
             built = true;
         }
         (void)built;

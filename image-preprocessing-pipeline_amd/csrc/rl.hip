@@ -495,7 +495,7 @@ int check_options(const mi_rl_options* o) {
 
 // keep_ctx / keep_taper (a deconvolution plan): the RL context and the taper's FFT engine are created into / reused from them
 static int rl_spatial_impl(int dev, void* stream, float* bl, const float* psf, const float* psf_inv, int nx, int ny, int nz, int kx, int ky,
-                           int kz, const mi_rl_options* opt, int* iters_done, mi_rl_ctx** keep_ctx, FftEngine** keep_taper) {
+                           int kz, const mi_rl_options* opt, int* iters_done, mi_rl_ctx** keep_ctx, TaperKeep** keep_taper) {
     MI_TRY(use_device(dev));
     MI_TRY(check_options(opt));
     MI_REQUIRE(bl && psf, "deconSpatial: null pointer");
@@ -537,7 +537,7 @@ extern "C" int mi_rl_spatial(int dev, void* stream, float* bl, const float* psf,
 }
 
 static int rl_fft_impl(int dev, void* stream, float* bl, const float* psf, int nx, int ny, int nz, int kx, int ky, int kz, int fx, int fy,
-                       int fz, const mi_rl_options* opt, int* iters_done, mi_rl_ctx** keep_ctx, FftEngine** keep_taper) {
+                       int fz, const mi_rl_options* opt, int* iters_done, mi_rl_ctx** keep_ctx, TaperKeep** keep_taper) {
     MI_TRY(use_device(dev));
     MI_TRY(check_options(opt));
     MI_REQUIRE(bl && psf, "deconFFT: null pointer");
@@ -756,10 +756,10 @@ struct mi_decon_plan {
     int key[12] = {0};          // nx ny nz kx ky kz use_fft fx fy fz engine has_inv
     std::vector<float> psf, psf_inv;
     mi_rl_ctx* ctx = nullptr;
-    FftEngine* taper = nullptr;
+    TaperKeep* taper = nullptr;
     void drop() {
         if (ctx) mi_rl_destroy(ctx);
-        delete taper;
+        taper_keep_free(taper);
         ctx = nullptr;
         taper = nullptr;
     }

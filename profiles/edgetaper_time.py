@@ -6,7 +6,7 @@ dev = torch.device("cuda", 0)
 shape, kshape = bench.WORKLOADS["c3"]
 psf = torch.from_numpy(bench.make_psf(kshape)).to(dev)
 decon.edgetaper_3d(bench.make_volume((64, 64, 64), dev), psf[:9, :9, :9].contiguous())  # loads the code objects
-for eng in ("fft", "direct", "fft", "direct"):
+for eng in ("slabs", "fft", "slabs", "fft", "direct"):
     os.environ["MI_EDGETAPER_ENGINE"] = eng
     bl = bench.make_volume(shape, dev)
     torch.cuda.synchronize(); t0 = time.perf_counter()

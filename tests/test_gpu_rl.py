@@ -306,10 +306,10 @@ def test_properties_at_scale(dev):
     assert float(out.min()) >= 0.0 and abs(float(out.double().sum()) - s0) / s0 < 1e-4
 
 
-@pytest.mark.parametrize("engine", ["fft", "direct"])
+@pytest.mark.parametrize("engine", ["fft", "direct", "slabs"])
 def test_edgetaper_fft_route_equals_direct_route(dev, engine, monkeypatch):
-    """edgetaper's blur through the FFT engine (replicate-padded volume; chosen for large PSFs) vs the shell-only
-    direct convolution: same result within fp32 rounding."""
+    """edgetaper's blur through the FFT engine on the replicate-padded volume, through six face slabs on circular FFT grids
+    (the route of large blocks) and as shell-only direct convolution: same result within fp32 rounding."""
     from ipp_amd import decon
     monkeypatch.setenv("MI_EDGETAPER_ENGINE", engine)
     rng = np.random.default_rng(42)
@@ -317,6 +317,12 @@ def test_edgetaper_fft_route_equals_direct_route(dev, engine, monkeypatch):
     psf = R.gaussian_psf((21, 9, 9), (4.0, 2.0, 2.0))
     got = decon.edgetaper_3d(_t(bl, dev), _t(psf, dev)).cpu().numpy()
     assert np.abs(got - R.edgetaper_3d(bl, psf)).max() < 1e-5
+    # an asymmetric, un-normalised PSF and extents where the two slabs of an axis differ in thickness
+    from tests.rl_util import asymmetric_psf
+    bl2 = rng.random((45, 70, 100), dtype=np.float32)
+    psf2 = asymmetric_psf((9, 5, 13), seed=2) * 2.5
+    got2 = decon.edgetaper_3d(_t(bl2, dev), _t(psf2, dev)).cpu().numpy()
+    assert np.abs(got2 - R.edgetaper_3d(bl2, psf2)).max() < 1e-5
 
 
 def test_decon_plan_is_bit_identical_and_rebuilds(dev):
