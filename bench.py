@@ -53,15 +53,20 @@ def make_volume(shape, device, seed=1234):
 
 
 def pmc_traffic(pass_name, workload):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r01_pmc_traffic.json:
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r02_pmc_traffic.json:
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this same command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes).
     Counters cannot be collected from inside the timed process, so the profile of the default workload is quoted."""
     if workload != "c3":
         return None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-            kern = json.load(f)["kernels"]
-    except OSError:
+    kern = None
+    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                kern = json.load(f)["kernels"]
+            break
+        except OSError:
+            continue
+    if kern is None:
         return None
     want = {"z_conv": ("k_z_conv_pipe<", ">"), "x_fused": ("k_x_fused_pipe<", ">"),
             "y_forward": ("k_y_pass<", "false>"), "y_inverse": ("k_y_pass<", "true>")}[pass_name]

@@ -80,9 +80,15 @@ def mips_roofline(dev, tiles):
         tot_bytes += nbytes
         tot_ms += ms.value
     ach = tot_bytes / (tot_ms * 1e-3) / 1e9
+    traffic = None   # HBM bytes per launch from the committed PMC passes (profiles/collect.sh: FETCH_SIZE x 2 + WRITE_SIZE, 56 pairs)
+    try:
+        with open(os.path.join(ROOT, "profiles", "r02_ncc_pmc_traffic.json")) as f:
+            traffic = round(json.load(f)["kernels"]["k_mips"]["hbm_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        pass
     return {"bound": "hbm", "kernel": "k_mips (six MIPs of every pair of a group in one streaming pass)", "achieved": round(ach, 1),
-            "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": None,
-            "algorithmic_bytes_per_pair": int(2 * dk * (di - 0) * OVERLAP * 4), "launches": out}
+            "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": traffic,
+            "algorithmic_bytes_per_launch": int(tot_bytes / 2), "algorithmic_bytes_per_pair": int(2 * dk * (di - 0) * OVERLAP * 4), "launches": out}
 
 
 def run(dev, repeats=3, cpu=True):
