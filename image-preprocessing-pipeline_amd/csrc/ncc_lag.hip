@@ -755,7 +755,7 @@ int ncc_lag_group(int dev, hipStream_t s, int n, const float* const* a_ptrs, con
     }
     const size_t per_pair = 4 * (pstride + tmp_floats) + 8 * sstride + spec + crs + 3 * 4 * (size_t)wcap + 64;
     size_t budget = (size_t)6 << 30;
-    if (const char* e = std::getenv("MI_NCC_CHUNK_MB")) budget = (size_t)std::max(64, std::atoi(e)) << 20;
+    if (const char* e = std::getenv("MI_NCC_CHUNK_MB")) budget = (size_t)std::max(1, std::atoi(e)) << 20;
     const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, budget / per_pair));
 
     MI_TRY(grow(ws.fbuf, 4 * pstride * chunk));

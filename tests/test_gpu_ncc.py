@@ -197,6 +197,15 @@ def test_grid_batch_recovers_jitter(dev):
         single = crossmips.PDAlgoMIPNCC.execute(tiles[r][c], tiles[rb][cb], 8, 8, 3, direction, ov)
         assert single.VHD_coords == d.VHD_coords and single.NCC_widths == d.NCC_widths
     assert reliable >= 0.75 * 2 * len(res)
+    # the same batch cut into chunks of a few pairs (device memory budget of 1 MB per chunk): identical records
+    import os
+    os.environ["MI_NCC_CHUNK_MB"] = "1"
+    try:
+        chunked = crossmips.compute_displacements(tiles, ov, ov, 8, 8, 3)
+    finally:
+        del os.environ["MI_NCC_CHUNK_MB"]
+    assert {k: (d.VHD_coords, d.NCC_widths, d.NCC_maxs) for k, d in chunked.items()} == \
+           {k: (d.VHD_coords, d.NCC_widths, d.NCC_maxs) for k, d in res.items()}
     # pair sharding across ranks: the union of the shards is the whole set, no overlap
     shards = [crossmips.compute_displacements(tiles, ov, ov, 8, 8, 3, rank=k, world_size=2) for k in range(2)]
     assert set(shards[0]) | set(shards[1]) == set(res) and not (set(shards[0]) & set(shards[1]))
