@@ -247,7 +247,15 @@ def main(argv=None):
             raise RuntimeError("block.p1 shape mismatch with block.nx, block.ny, block.nz")
         log.info("Resuming by loading block info ...")
     if block is None:
-        block = L.autosplit((sx, sy, sz), psf.shape[::-1], filt, bmax, args.numit)
+        try:
+            import psutil
+            ram = int(os.environ.get("MI_DECWRAP_RAM_BYTES", psutil.virtual_memory().available))
+        except Exception:
+            ram = int(os.environ.get("MI_DECWRAP_RAM_BYTES", 64 << 30))
+        out_bytes = 1 if (args.convert_to_8bit or (np.dtype(vol.dtype).itemsize == 1 and not args.convert_to_16bit)) else 2
+        n_wr = max(2, min(8, (os.cpu_count() or 4) // 2))
+        block = L.autosplit((sx, sy, sz), psf.shape[::-1], filt, bmax, args.numit, ram_available=ram, output_bytes=out_bytes,
+                            cores_in_flight=n_wr + 1 + len(args.gpu_indices) * max(1, args.gpu_workers_per_gpu))
         tmp = block_path.with_suffix(".json.tmp")
         with open(tmp, "w") as f:
             json.dump({"stack_info": stack_info,
@@ -359,24 +367,31 @@ def main(argv=None):
             stream.synchronize()
             arr = np.array(host.numpy())                                                   # the staging buffer is reused by the next block
         merge_min_max(lb, ub, rawmax)
-        # the brick is compressed and written behind the worker's back: LZ4 of a float32 core takes longer than its kernels
+        # the brick is compressed and written behind the worker's back: LZ4 of a float32 core takes longer than its kernels;
+        # at most `inflight` cores wait for a writer (back-pressure instead of a queue that could grow to the whole volume)
+        inflight.acquire()
         with lock:
             pending.append(writers.submit(save_brick, n, arr, lb, ub))
         log.info(f"block {n}/{num_blocks} done on GPU {g}: stats [{lb:.4g}, {ub:.4g}]")
 
     def save_brick(n, arr, lb, ub):
-        brick = brick_path(n)
-        with open(brick.with_suffix(".json"), "w") as f:                                   # the block's own clip range
-            json.dump({"lb": lb, "ub": ub}, f)
-        brickio.save_lz4(brick.with_suffix(".lz4.tmp"), arr)                               # LsDeconv.m:805-806
-        os.replace(brick.with_suffix(".lz4.tmp"), brick)
+        try:
+            brick = brick_path(n)
+            with open(brick.with_suffix(".json"), "w") as f:                               # the block's own clip range
+                json.dump({"lb": lb, "ub": ub}, f)
+            brickio.save_lz4(brick.with_suffix(".lz4.tmp"), arr)                           # LsDeconv.m:805-806
+            os.replace(brick.with_suffix(".lz4.tmp"), brick)
+        finally:
+            inflight.release()
 
     # ---- the deconvolution rounds (LsDeconv.m:618-660): stale claims and half-written bricks of an earlier run are removed,
     # the workers take what is missing from --start-block on; whatever is still missing afterwards (blocks below the start
     # block, claims of a process that died) is taken by another round from block 1
     start = max(1, min(int(args.start_block), num_blocks))
     pending = []
-    with ThreadPoolExecutor(max_workers=max(2, min(8, (os.cpu_count() or 4) // 2))) as writers:   # liblz4 runs outside the GIL
+    n_writers = max(2, min(8, (os.cpu_count() or 4) // 2))
+    inflight = threading.BoundedSemaphore(n_writers + 1)
+    with ThreadPoolExecutor(max_workers=n_writers) as writers:                             # liblz4 runs outside the GIL
         while True:
             missing = 0
             for n in range(1, num_blocks + 1):

@@ -90,35 +90,81 @@ def native_fft_shape(shape_xyz):
     return out
 
 
-def autosplit(stack_xyz, psf_size_xyz, filt: Filter, block_size_max: int, numit: int) -> Block:
-    """Largest block (core + 2*pad, 7-smooth for the FFT path) with fewer than ``block_size_max`` elements.
+def autosplit(stack_xyz, psf_size_xyz, filt: Filter, block_size_max: int, numit: int, ram_available: int | None = None,
+              output_bytes: int = 2, cores_in_flight: int = 4) -> Block:
+    """The block (core + 2*pad, an FFT-friendly shape for the FFT path) with fewer than ``block_size_max`` elements whose CORE is
+    largest (the reference's score, LsDeconv.m:365), square in xy.
 
-    Same ingredients as LsDeconv.m:308-385 -- pad = max(PSF extent, Gaussian pad) per side, FFT shapes rounded
-    to 7-smooth, square xy blocks, score = core volume -- without MATLAB's 2^31-element / 1290-per-side gpuArray
-    limits and host-RAM terms, which do not exist here."""
+    Same ingredients as LsDeconv.m:308-385 -- pad = max(PSF extent, Gaussian pad) per side, FFT shapes rounded to 7-smooth, square
+    xy blocks, score = core volume, and the host-memory terms: post-processing holds one z slab of bricks at the output type
+    (``output_bytes`` x stack_x x stack_y x block_z, at most half of ``ram_available``: :317-322) while ``cores_in_flight`` float32
+    cores wait for their writers (:359) -- without MATLAB's 2^31-element / 1290-per-side gpuArray limits.
+    ``ram_available`` None: no host-memory term (tests)."""
     pad = [1, 1, 1] if filt.destripe_sigma > 0 else [0, 0, 0]                                   # LsDeconv.m:339-340
     if numit > 0:
         pad = [max(a, b) for a, b in zip(pad, decon_pad_size(psf_size_xyz))]
     if any(s > 0 for s in filt.gaussian_sigma):
         pad = [max(a, b) for a, b in zip(pad, gaussian_pad_size(filt.gaussian_sigma, filt.gaussian_size))]
     sx, sy, sz = stack_xyz
-    best = None
-    z = sz
-    while z >= 1 and best is None:
-        xy = max(sx, sy)
-        while xy >= 1:
-            core = [min(xy, sx), min(xy, sy), z]
-            shape = [c + 2 * p for c, p in zip(core, pad)]
-            if filt.use_fft:
-                smooth, native = next_fast_len(shape), native_fft_shape(shape)
-                # prefer the native-pipeline shape unless it inflates the block by more than 30 % over the 7-smooth one
-                shape = native if np.prod(native) <= 1.3 * np.prod(smooth) else smooth
-            if shape[0] * shape[1] * shape[2] < block_size_max:
-                best = (core, shape)
-                break
-            xy = xy // 2 if xy > 64 else xy - 1
-        if best is None:
-            z = z // 2 if z > 16 else z - 1
+    z_max = sz
+    if ram_available is not None:
+        z_max = max(1, min(sz, int(0.5 * ram_available // (output_bytes * sx * sy))))
+
+    def shape_of(core):
+        shape = [c + 2 * p for c, p in zip(core, pad)]
+        if filt.use_fft:
+            smooth, native = next_fast_len(shape), native_fft_shape(shape)
+            # prefer the native-pipeline shape unless it inflates the block by more than 30 % over the 7-smooth one
+            shape = native if np.prod(native) <= 1.3 * np.prod(smooth) else smooth
+        return shape
+
+    def cost_per_core_voxel(core, shape):
+        """deconFFT blocks: transform cost of the block per voxel it contributes -- grid points x 1 (hand-written pipeline) or x 3.5
+        (rocFFT) over core voxels.  The reference's score is the core volume alone (LsDeconv.m:365); with two
+        transform routes of different speed the same intent -- least work per output voxel -- needs the route in it."""
+        if not filt.use_fft:
+            return 1.0
+        native = list(shape) == native_fft_shape(shape)
+        return float(np.prod(shape)) * (1.0 if native else 3.5) / float(np.prod(core))
+
+    def fits(xy, z):
+        core = [min(xy, sx), min(xy, sy), z]
+        shape = shape_of(core)
+        if shape[0] * shape[1] * shape[2] >= block_size_max:
+            return None
+        if ram_available is not None and output_bytes * sx * sy * z + core[0] * core[1] * z * cores_in_flight * 4 > ram_available:
+            return None
+        return core, shape
+
+    # candidate depths: every depth near the ends, a geometric ladder in between (the score is smooth in z)
+    zs = sorted({z_max} | {max(1, int(round(z_max * 0.85 ** i))) for i in range(60)} | set(range(1, min(z_max, 8) + 1)), reverse=True)
+    best, best_score = None, -1
+    for z in zs:
+        lo, hi = 1, max(sx, sy)                  # largest square xy that fits at this depth (monotone: bisection)
+        if fits(lo, z) is None:
+            continue
+        while lo < hi:
+            mid = (lo + hi + 1) // 2
+            if fits(mid, z) is not None:
+                lo = mid
+            else:
+                hi = mid - 1
+        # the largest xy of this depth, and -- FFT path -- the largest xy below it whose grid the hand-written pipeline takes
+        cands = [fits(lo, z)]
+        if filt.use_fft:
+            xy = lo
+            for _ in range(64):
+                c = fits(xy, z)
+                if c is not None and list(c[1]) == native_fft_shape(c[1]):
+                    cands.append(c)
+                    break
+                xy -= max(1, xy // 64)
+                if xy < 1:
+                    break
+        for core, shape in cands:
+            score = core[0] * core[1] * core[2] / cost_per_core_voxel(core, shape)
+            if score > best_score:
+                best, best_score = (core, shape), score
     if best is None:
         raise RuntimeError("autosplit: No block shape fits in memory. Try increasing block_size_max or reducing min_block.")
     core, shape = best

@@ -1,0 +1,62 @@
+"""decwrap on a volume that is larger than what its host-side buffers may hold: wall time, blocks, peak resident set.
+    python profiles/decwrap_scale_probe.py [nz ny nx] [block_size_max]
+Default: a 512 x 2048 x 2048 uint16 volume (4.3 GB) written as a memory-mapped *.npy under /tmp, deconFFT flavour, 6 iterations,
+blocks of at most 300 M elements (incl. pads), no whole-volume output copies (MI_DECWRAP_NPY=0): what is measured is the streaming
+pipeline -- box reads, device work, LZ4 bricks, slab-wise assembly + rescale."""
+import os
+import resource
+import shutil
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+
+shape = tuple(int(v) for v in sys.argv[1:4]) if len(sys.argv) >= 4 else (512, 2048, 2048)
+bmax = sys.argv[4] if len(sys.argv) >= 5 else "300000000"
+root = "/tmp/decwrap_scale"
+shutil.rmtree(root, ignore_errors=True)
+os.makedirs(root)
+t0 = time.perf_counter()
+vol = np.lib.format.open_memmap(os.path.join(root, "vol.npy"), mode="w+", dtype=np.uint16, shape=shape)
+rng = np.random.default_rng(1)
+for z in range(shape[0]):                      # sparse beads on a noisy background, slice by slice
+    sl = rng.integers(600, 700, size=shape[1:], dtype=np.uint16)
+    idx = rng.integers(0, sl.size, size=sl.size // 2000)
+    sl.reshape(-1)[idx] = rng.integers(5000, 60000, size=idx.size, dtype=np.uint16)
+    vol[z] = sl
+vol.flush()
+del vol
+t_gen = time.perf_counter() - t0
+rss0 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6
+# the memory-mapped input counts towards the resident set page by page (reclaimable page cache): what the pipeline itself holds is
+# the ANONYMOUS resident memory (staging buffers, cores waiting for a writer, the integer slab), sampled during the run
+import threading
+peak_anon = [0.0]
+stop = threading.Event()
+
+
+def sample():
+    while not stop.is_set():
+        with open("/proc/self/status") as f:
+            for line in f:
+                if line.startswith("RssAnon:"):
+                    peak_anon[0] = max(peak_anon[0], int(line.split()[1]) / 1e6)
+        stop.wait(0.1)
+
+
+threading.Thread(target=sample, daemon=True).start()
+os.environ["MI_DECWRAP_NPY"] = "0"
+from ipp_amd import decwrap  # noqa: E402
+t0 = time.perf_counter()
+rc = decwrap.main(["-i", os.path.join(root, "vol.npy"), "-dxy", "0.422", "-dz", "1.0", "-ex", "488", "-em", "525", "--use-fft", "-it", "6",
+                   "--block-size-max", bmax, "--gpu-indices", "1", "--gpu-workers-per-gpu", "2"])
+dt = time.perf_counter() - t0
+stop.set()
+rss = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6
+nvox = float(np.prod(shape))
+print(f"volume {shape[2]} x {shape[1]} x {shape[0]} uint16 = {nvox * 2 / 1e9:.1f} GB (generated in {t_gen:.0f} s), block-size-max {bmax}: rc {rc}, "
+      f"{dt:.1f} s wall = {nvox / dt / 1e6:.0f} Mvoxel/s end to end (6 RL iterations, default filters), peak resident set {rss:.1f} GB "
+      f"incl. the mapped input file (before the run {rss0:.1f} GB), peak ANONYMOUS resident memory {peak_anon[0]:.1f} GB "
+      f"(a float32 copy of the volume would be {nvox * 4 / 1e9:.1f} GB)", flush=True)
+shutil.rmtree(root, ignore_errors=True)

@@ -39,6 +39,17 @@ def test_pad_rules_and_autosplit():
     assert blk.nx * blk.x >= 300 and blk.nz * blk.z >= 100 and len(blk.p1) == blk.nx * blk.ny * blk.nz
     with pytest.raises(RuntimeError, match="No block shape fits"):
         L.autosplit((300, 300, 100), (9, 9, 19), f, block_size_max=10, numit=6)
+    # the reference's score (largest core, LsDeconv.m:365) and its host-memory terms (:317-322, 359): the z slab of bricks that
+    # post-processing assembles at the output type may take half of the available memory
+    g = L.Filter(use_fft=False)
+    free = L.autosplit((2048, 2048, 2048), (9, 9, 19), g, 300_000_000, 6)
+    tight = L.autosplit((2048, 2048, 2048), (9, 9, 19), g, 300_000_000, 6, ram_available=8 << 30, output_bytes=2)
+    assert tight.z <= (8 << 30) // 2 // (2 * 2048 * 2048) < free.z
+    assert tight.x * tight.y * tight.z <= free.x * free.y * free.z
+    for b in (free, tight):
+        assert (b.x + 2 * b.x_pad) * (b.y + 2 * b.y_pad) * (b.z + 2 * b.z_pad) < 300_000_000
+        # no other square-xy block of the candidate depths has a larger core
+        assert b.x == b.y and (b.x + 1 + 2 * b.x_pad) ** 2 * (b.z + 2 * b.z_pad) >= 300_000_000 or b.x == 2048
 
 
 def test_decwrap_cli_validation_and_dry_run(tmp_path, capsys):
