@@ -83,6 +83,7 @@ SIGNATURES = {
     "mi_rl_destroy": (_i, [_vp]),
     "mi_rl_engine": (_i, [_vp]),
     "mi_rl_separable": (_i, [_vp]),
+    "mi_rl_pair_layout": (_i, [_vp]),
     "mi_rl_device_bytes": (_sz, [_vp]),
     "mi_rl_forward_ratio": (_i, [_vp, _vp, _vp, _vp]),
     "mi_rl_adjoint_update": (_i, [_vp, _vp, _vp, _vp, _f, _vp]),

@@ -15,6 +15,7 @@ struct NativeDims {
     // planes [z_out_lo, z_out_hi) and rows < y_out_hi are ever read.  Whole grid when nothing is padded.
     int z_in_hi, z_out_lo, z_out_hi, y_out_hi;
     int dbg;          // timing experiments only: knocks out phases of the z pass (results are then wrong)
+    int paired;       // spectra around the z pass in the pair-interleaved layout (k_y_pair, k_z_pair_pipe)
 };
 
 // Padded mode: the caller's volume (extents n) sits at offset o inside the transform grid; the x passes apply the boundary
@@ -74,7 +75,7 @@ struct NativeFft {
     size_t spectrum_row_floats() const { return (size_t)2 * dims.nz * dims.hx; }
     int x_forward(hipStream_t s, const float* in);
     int middle(hipStream_t s, bool conj_otf);
-    int y_pass(hipStream_t s, bool inverse);
+    int y_pass(hipStream_t s, bool inverse, bool paired);
     int z_conv(hipStream_t s, bool conj_otf);
     int x_inverse(hipStream_t s, float* out, int epi_kind, const ConvEpilogue& epi, bool fuse_forward, const TileSelect* part = nullptr);
     bool pipe_ok() const;  // the fused x pass can run as the persistent pipelined kernel

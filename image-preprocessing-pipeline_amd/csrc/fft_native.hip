@@ -238,6 +238,7 @@ __host__ __device__ constexpr int axis_tw_entries(int n) {
 }
 constexpr int kLdsOneWg = 156 * 1024;  // one work-group per CU (160 KB LDS)
 constexpr int kLdsTwoWg = 78 * 1024;   // two work-groups per CU
+constexpr int kPairLines = 8;          // lines per block of the pair-interleaved z-side layout (8 A + 8 B lines = 128 bytes)
 // rows of an x tile / line pairs of a z tile: 16 (full 128-B lines in the transposed layouts) while tile + tables fit one
 // work-group per CU; columns of a y tile: two work-groups per CU
 __host__ __device__ constexpr int x_tile_rows(int hx) {
@@ -430,14 +431,14 @@ __device__ __forceinline__ void super_stage(float2* tile, int batch, int pitch, 
 // full transform of the tile's sequences as the chain of super-stages; twl: the axis' LDS tables.  The caller synchronises
 // before (tile and tables filled): with a work-group barrier, or -- PRIV, and the rows were filled by their owners -- not at
 // all.  On return the tile is consistent for the work-group (!PRIV) or for each row's owner (PRIV).
-template <int LOGN, bool INVERSE, int NT, int R3 = 1, int DONE = 0>
+template <int LOGN, bool INVERSE, int NT, int R3 = 1, int DONE = 0, int STOP = LOGN>
 __device__ __forceinline__ void lds_fft(float2* tile, int batch, int pitch, int hp, bool priv, const float2* twl) {
-    if constexpr (DONE < LOGN) {
+    if constexpr (DONE < STOP) {
         constexpr int s_lo = INVERSE ? DONE : seg_below(LOGN, LOGN - DONE);  // forward: top stages first; inverse: bottom first
         constexpr int r = INVERSE ? seg_r(LOGN, DONE) : LOGN - DONE - s_lo;
         super_stage<LOGN, r, s_lo, INVERSE, NT, R3>(tile, batch, pitch, hp, priv, twl + tw_off(LOGN, s_lo));
         stage_sync(priv);
-        lds_fft<LOGN, INVERSE, NT, R3, DONE + r>(tile, batch, pitch, hp, priv, twl);
+        lds_fft<LOGN, INVERSE, NT, R3, DONE + r, STOP>(tile, batch, pitch, hp, priv, twl);
     }
 }
 
@@ -699,6 +700,173 @@ __global__ __launch_bounds__(kThreadsY, 4) void k_y_pass(const float2* __restric
             const float2 a = tile[s0], b = tile[s0 ^ 1];
             if (!INVERSE || 2 * q < d.y_out_hi) reinterpret_cast<float4*>(dst + dest_col(c0 + c) * M)[q] = make_float4(a.x, a.y, b.x, b.y);
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- P2 / P4, pair-interleaved
+// The y passes on the pair-interleaved layout of the z side (NativeDims::paired): row (xk, z), xk <= Hx/2, holds 2 M samples,
+// for every block of 8 y positions the 8 lines of plane xk ("A") followed by their 8 mirror partners from plane Hx - xk ("B", in
+// partner order: B slot j is the line the z pass pairs with A slot j).  A work-group takes TC/2 z planes x {A, B} of one xk, so
+// that it reads and writes whole rows although each plane only owns every other 64 bytes.  Planes 0 and Hx/2 are their own
+// partners: their lines are stored twice (as A of their block and as B of the mirror block).
+template <int LY2, int R3, bool INVERSE>
+__global__ __launch_bounds__(kThreadsY, 4) void k_y_pair(const float2* __restrict__ src, float2* __restrict__ dst, NativeDims d,
+                                                      const float2* __restrict__ tw) {
+    extern __shared__ __attribute__((aligned(16))) float2 tile[];
+    constexpr int M = R3 << LY2, NW = kThreadsY / 64;
+    constexpr int pitch = row_pitch(M), quads = M / 2;
+    const int TC = d.tc, Hx = d.hx, L = d.nz;
+    const int zper = TC / 2, zblocks = L / zper, nxk = Hx / 2 + 1;
+    // work-groups in flight read neighbouring memory (reads wait, writes do not): forward, the planes of one z pair on the x
+    // side; inverse, consecutive rows of one xk on the z side
+    const int xk = INVERSE ? blockIdx.x / zblocks : blockIdx.x % nxk;
+    const int z0 = (INVERSE ? blockIdx.x - xk * zblocks : blockIdx.x / nxk) * zper;
+    if (!INVERSE) {
+        if (z0 >= d.z_in_hi) return;  // all-zero input planes of a padded grid: neither read nor produced
+    } else if (z0 >= d.z_out_hi || z0 + zper <= d.z_out_lo) {
+        return;                       // planes the crop drops
+    }
+    const int pxA = freq2pos(xk, d.lhx2, d.r3x), pxB = freq2pos(xk == 0 ? 0 : Hx - xk, d.lhx2, d.r3x);
+    const bool self = pxA == pxB;
+    // LDS row c of the tile: side c & 1, plane z0 + (c >> 1)
+    // x side ([z][px][py], whole columns): float4 q of column c = positions 2 q, 2 q + 1
+    auto x_item = [&](int i, int& c, int& q, size_t& g) {
+        c = i / quads;
+        q = i - c * quads;
+        g = (((size_t)(z0 + (c >> 1)) * Hx + ((c & 1) ? pxB : pxA)) * M) / 2 + q;
+    };
+    // z side, by float4 f of row (xk, z0 + zi): block f >> 3; f & 7 < 4: lines 2 (f & 3), + 1 of the block from the A column,
+    // else the partners of those two lines from the B column -- the mirrors of neighbouring positions are neighbours (they
+    // differ by M/2 in frequency), so both sides read or write one LDS slot pair
+    auto z_item = [&](int i, int& c, int& s0, size_t& g) {
+        const int zi = i / M, f = i - zi * M;
+        const int py = ((f >> 3) << 3) + 2 * (f & 3), side = (f >> 2) & 1;
+        c = 2 * zi + side;
+        s0 = c * pitch + phys(side ? mirror_pos(py, M, LY2, R3) : py);
+        g = ((size_t)xk * L + z0 + zi) * M + f;
+    };
+    const bool priv = (TC % NW) == 0;  // (the transform only: fill and drain cross the columns)
+    using TW = TwLds<LY2, R3>;
+    float2* twl = tile + TC * pitch;
+    TW::template fill<kThreadsY>(twl, tw);
+    const int n_items = TC * quads;
+    // fast path (power-of-two columns of at least 2 NT samples): item k of a lane is float4 tid + k NT of the tile on either
+    // side, so columns, rows and the high position bits are compile-time numbers and -- the swizzle being XOR-linear -- a slot
+    // is a lane constant XOR a compile-time constant.  x side: position 2 tid + (2 k NT mod M).  z side: the lane's block
+    // position py_l = 8 (tid >> 3) + 2 (tid & 3) plus f0 = k NT mod M; the mirror of f0 + py_l is (py_l ^ (NT - 1)) + [mirror
+    // of the high bits] unless f0 = 0, when it is the mirror of py_l inside the first NT positions.
+    constexpr int TCC = y_tile_cols(M);
+    constexpr bool FAST_OK = R3 == 1 && quads % kThreadsY == 0;
+    constexpr int NIT = FAST_OK ? TCC * quads / kThreadsY : 1;
+    const bool fast = FAST_OK && TC == TCC;
+    constexpr int WHI = FAST_OK ? LY2 - 9 : 0;  // position bits above the lane's 9 (kThreadsY = 512)
+    static_assert(kThreadsY == 512, "the fast path of k_y_pair counts on 512 lanes");
+    struct ZLane { int a, b0, b1, side; };
+    auto z_lane = [&]() {
+        const int tid = launder(threadIdx.x);
+        const int py_l = ((tid >> 3) << 3) + 2 * (tid & 3), side = (tid >> 2) & 1;
+        return ZLane{phys(py_l), phys(mirror_pos(py_l, M, LY2, R3)), phys(py_l ^ 511), side};
+    };
+    auto z_slot_fast = [&](const ZLane& zl, int k) {  // k: compile-time after unrolling
+        const int zi = (k * kThreadsY) / M, f0 = (k * kThreadsY) % M;
+        const int flo = (int)brev_n((unsigned)f0, LY2);                          // the low WHI frequency bits
+        const int mhi = flo ? (int)brev_n((unsigned)((1 << WHI) - flo), LY2) : 0;  // position bits of their negative
+        const int sa = zl.a ^ swz_c(f0), sb = flo ? (zl.b1 ^ swz_c(mhi)) : zl.b0;
+        return (2 * zi) * pitch + (zl.side ? pitch + sb : sa);
+    };
+    if (fast) {
+        if (INVERSE) {
+            const ZLane zl = z_lane();
+            const float4* rowp = reinterpret_cast<const float4*>(src) + ((size_t)xk * L + z0) * M + threadIdx.x;
+#pragma unroll
+            for (int k = 0; k < NIT; ++k) {
+                const float4 v = rowp[(size_t)k * kThreadsY];  // rows of the tile follow each other: (zi M + f0) = k NT
+                const int s0 = z_slot_fast(zl, k);
+                tile[s0] = make_float2(v.x, v.y);
+                tile[s0 ^ 1] = make_float2(v.z, v.w);
+            }
+        } else {
+            const int s_lane = phys(2 * (int)threadIdx.x);
+#pragma unroll
+            for (int k = 0; k < NIT; ++k) {
+                const int c = (k * kThreadsY) / quads, qk = (k * kThreadsY) % quads;
+                const size_t col = (((size_t)(z0 + (c >> 1)) * Hx + ((c & 1) ? pxB : pxA)) * M) / 2;  // scalar
+                const float4 v = reinterpret_cast<const float4*>(src)[col + qk + threadIdx.x];
+                const int s0 = c * pitch + (s_lane ^ swz_c(2 * qk));
+                tile[s0] = make_float2(v.x, v.y);
+                tile[s0 ^ 1] = make_float2(v.z, v.w);
+            }
+        }
+    } else {
+#pragma unroll MI_FFT_UNROLL
+    for (int i = threadIdx.x; i < n_items; i += kThreadsY) {
+        int c, s0;
+        size_t g;
+        if (INVERSE) {
+            z_item(i, c, s0, g);
+        } else {
+            int q;
+            x_item(i, c, q, g);
+            s0 = c * pitch + phys(2 * q);
+        }
+        const float4 v = reinterpret_cast<const float4*>(src)[g];
+        tile[s0] = make_float2(v.x, v.y);
+        tile[s0 ^ 1] = make_float2(v.z, v.w);
+    }
+    }
+    lds_barrier();
+    if constexpr (!INVERSE && R3 > 1) {
+        radix3_stage<R3, false, kThreadsY>(tile, TC, pitch, 1, priv, 1 << LY2, twl + TW::r3);
+        stage_sync(priv);
+    }
+    lds_fft<LY2, INVERSE, kThreadsY, R3>(tile, TC * R3, pitch, 1, priv, twl);
+    if constexpr (INVERSE && R3 > 1) {
+        radix3_stage<R3, true, kThreadsY>(tile, TC, pitch, 1, priv, 1 << LY2, twl + TW::r3);
+        stage_sync(priv);
+    }
+    if (priv) lds_barrier();
+    if (fast) {
+        if (INVERSE) {
+            const int s_lane = phys(2 * (int)threadIdx.x);
+#pragma unroll
+            for (int k = 0; k < NIT; ++k) {
+                const int c = (k * kThreadsY) / quads, qk = (k * kThreadsY) % quads;
+                const int z = z0 + (c >> 1);
+                // (a plane that is its own partner is written once, from its A copy)
+                if ((self && (c & 1)) || 2 * (qk + (int)threadIdx.x) >= d.y_out_hi || z < d.z_out_lo || z >= d.z_out_hi) continue;
+                const size_t col = (((size_t)z * Hx + ((c & 1) ? pxB : pxA)) * M) / 2;  // scalar
+                const int s0 = c * pitch + (s_lane ^ swz_c(2 * qk));
+                const float2 a = tile[s0], b = tile[s0 ^ 1];
+                reinterpret_cast<float4*>(dst)[col + qk + threadIdx.x] = make_float4(a.x, a.y, b.x, b.y);
+            }
+        } else {
+            const ZLane zl = z_lane();
+            float4* rowp = reinterpret_cast<float4*>(dst) + ((size_t)xk * L + z0) * M + threadIdx.x;
+#pragma unroll
+            for (int k = 0; k < NIT; ++k) {
+                const int s0 = z_slot_fast(zl, k);
+                const float2 a = tile[s0], b = tile[s0 ^ 1];
+                rowp[(size_t)k * kThreadsY] = make_float4(a.x, a.y, b.x, b.y);
+            }
+        }
+        return;
+    }
+#pragma unroll MI_FFT_UNROLL
+    for (int i = threadIdx.x; i < n_items; i += kThreadsY) {
+        int c, s0;
+        size_t g;
+        if (INVERSE) {
+            int q;
+            x_item(i, c, q, g);
+            const int z = z0 + (c >> 1);
+            // (a plane that is its own partner is written once, from its A copy)
+            if ((self && (c & 1)) || 2 * q >= d.y_out_hi || z < d.z_out_lo || z >= d.z_out_hi) continue;
+            s0 = c * pitch + phys(2 * q);
+        } else {
+            z_item(i, c, s0, g);
+        }
+        const float2 a = tile[s0], b = tile[s0 ^ 1];
+        reinterpret_cast<float4*>(dst)[g] = make_float4(a.x, a.y, b.x, b.y);
     }
 }
 
@@ -1068,6 +1236,176 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_z_conv_pipe(const floa
             }
         }
         lds_barrier();  // the tile is free for the next fill
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- P3, pair-interleaved layout
+// The spectra around the z pass as [xk][z][ty][side][TL]: the TL A lines of a tile and, right behind them, their TL mirror
+// partners (in partner order), so that a tile of only TL = 8 line pairs still moves whole 128-byte segments and two 8-wave
+// work-groups with a 64-KB tile each share a CU: one transforms while the other waits for HBM.
+template <int LZ2, int R3, bool REALG, int NT, int TL, bool TOPON = true>
+__global__ __launch_bounds__(NT, kWavesXZ) void k_z_pair_pipe(const float2* __restrict__ S, float2* __restrict__ T, const float4* __restrict__ G,
+                                                              NativeDims d, const float2* __restrict__ tw, int conj_otf, int ntiles, RealOtf ro) {
+    extern __shared__ __attribute__((aligned(16))) float2 tile[];
+    constexpr int L = R3 << LZ2, NW = NT / 64, hp = TL, pitch = row_pitch(L);
+    static_assert(TL == NW && L % 64 == 0 && R3 == 1, "one A line and its partner per wave");
+    constexpr int NPA = TL * L / NT;  // float4 (two neighbouring lines at one z) per lane and tile
+    constexpr int P = NT / TL;        // item k of a lane: position z0 + k * P
+    constexpr int NPG = TL * L / NT;  // point-wise items (mirror pairs) per lane
+    // the top super-stage of the chain (stages TOPS .. LZ2-1) works on elements z0 + k * 2^TOPS: exactly the items of a lane
+    constexpr int TOPS = seg_below(LZ2, LZ2), TOPR = LZ2 - TOPS;
+    constexpr bool TOPREG = TOPON && (1 << TOPS) == P && (1 << TOPR) == NPA;
+    const int Hx = d.hx, M = d.ny, ytiles = M / TL;
+    struct FView { int row, slot, z0; size_t off; };
+    auto f_view = [&]() {
+        const int tid = launder(threadIdx.x);
+        const int z0 = tid / TL, jq = tid - z0 * TL;  // float4 jq of the segment: lines 2 jq, 2 jq + 1 (rows TL.. = B side)
+        return FView{(2 * jq) * pitch, phys(z0) ^ rmask(2 * jq, hp), z0, (size_t)z0 * M + jq};
+    };
+    float4 pre[NPA];
+    auto load_S = [&](int t) {
+        const int plane = t / ytiles, ty = t - plane * ytiles;
+        const FView fv = f_view();
+        const float4* sp = reinterpret_cast<const float4*>(S) + (size_t)plane * L * M + (size_t)ty * TL + fv.off;
+#pragma unroll
+        for (int k = 0; k < NPA; ++k) pre[k] = (fv.z0 + k * P < d.z_in_hi) ? sp[(size_t)(k * P) * M] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    };
+    using TW = TwLds<LZ2, R3>;
+    float2* twl = tile + 2 * TL * pitch;
+    TW::template fill<NT>(twl, tw);
+    // REALG: the z ramp by POSITION, behind the twiddle tables (stride-1 look-ups in the point-wise step)
+    float2* phl = twl + TW::total;
+    if constexpr (REALG) {
+        for (int p = threadIdx.x; p < L; p += NT) phl[p] = ro.ph_z[pos2freq(p, LZ2, R3)];
+    }
+    int t = blockIdx.x;
+    if (t < ntiles) load_S(t);
+    for (; t < ntiles; t += gridDim.x) {
+        const int plane = t / ytiles, py0 = (t - plane * ytiles) * TL;
+        {
+            const FView fv = f_view();
+            if constexpr (TOPREG) {  // the top super-stage on the registers the loads arrived in
+                float2 v[NPA], u[NPA];
+#pragma unroll
+                for (int k = 0; k < NPA; ++k) { v[k] = make_float2(pre[k].x, pre[k].y); u[k] = make_float2(pre[k].z, pre[k].w); }
+                butterflies<TOPR, TOPS, false>(v, twl + tw_off(LZ2, TOPS), fv.z0);
+                butterflies<TOPR, TOPS, false>(u, twl + tw_off(LZ2, TOPS), fv.z0);
+#pragma unroll
+                for (int k = 0; k < NPA; ++k) {
+                    const int c = fv.row + (fv.slot ^ swz_c(k * P));
+                    tile[c] = v[k];
+                    tile[c + pitch] = u[k];
+                }
+            } else {
+#pragma unroll
+            for (int k = 0; k < NPA; ++k) {
+                const int c = fv.row + (fv.slot ^ swz_c(k * P));
+                tile[c] = make_float2(pre[k].x, pre[k].y);
+                tile[c + pitch] = make_float2(pre[k].z, pre[k].w);
+            }
+            }
+        }
+        const size_t g0 = ((size_t)plane * M + py0) * L;
+        float4 gv[REALG ? 1 : NPG];
+        float2 gr[REALG ? NPG : 1];
+        float2 ph_xy = make_float2(1.0f, 0.0f);
+        {
+            const int tid = launder(threadIdx.x);
+            const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+            if constexpr (REALG) {
+                ph_xy = cmul(ro.ph_x[plane], ro.ph_y[y_pos2freq(py0 + wv, d)]);
+            }
+            const size_t gl = g0 + (size_t)wv * L + (tid & 63);
+#pragma unroll
+            for (int k = 0; k < NPG; ++k) {
+                if constexpr (REALG) gr[k] = ro.g[gl + 64 * k];
+                else gv[k] = G[gl + 64 * k];
+            }
+        }
+        lds_barrier();
+        lds_fft<LZ2, false, NT, R3, TOPREG ? TOPR : 0>(tile, 2 * TL * R3, pitch, hp, true, twl);
+        float sw, cw;
+        sincospif(-2.0f * (float)plane / (float)(2 * Hx), &sw, &cw);  // exp(-2 pi i xk / Nx), Nx = 2 Hx
+        const float2 wx = make_float2(cw, sw);
+        {
+            const int tid = launder(threadIdx.x);
+            const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+            // item k: position lane + 64 k of the wave's A line and its mirror in the partner line.  The mirror of a position
+            // whose high bits 64 k are not zero is (lane ^ 63) + [mirror of the high bits alone], else the mirror of `lane` among
+            // the first 64 positions: lane constants XOR compile-time numbers, like every slot here
+            const int lane = tid & 63;
+            const int pA = phys(lane) ^ rmask(wv, hp), pB1 = phys(lane ^ 63) ^ rmask(TL + wv, hp);
+            const int pB0 = phys(mirror_pos(lane, L, LZ2, R3)) ^ rmask(TL + wv, hp);
+#pragma unroll
+            for (int k = 0; k < NPG; ++k) {
+                const int flo = (int)brev_n((unsigned)(64 * k), LZ2);
+                const int mhi = flo ? (int)brev_n((unsigned)((1 << (LZ2 - 6)) - flo), LZ2) : 0;
+                const int cA = wv * pitch + (pA ^ swz_c(64 * k));
+                const int cB = (TL + wv) * pitch + (flo ? (pB1 ^ swz_c(mhi)) : pB0);
+                const float2 a = tile[cA];
+                const float2 bc = cconj(tile[cB]);
+                const float2 E = make_float2(0.5f * (a.x + bc.x), 0.5f * (a.y + bc.y));
+                const float2 dlt = csub(a, bc);
+                const float2 O = make_float2(0.5f * dlt.y, -0.5f * dlt.x);
+                const float2 wO = cmul(wx, O);
+                const float2 Xa = cadd(E, wO), Xb = csub(E, wO);
+                float2 Ya, Yb;
+                if constexpr (REALG) {
+                    float2 Pq = cmul(ph_xy, phl[lane + 64 * k]);
+                    if (conj_otf) Pq.y = -Pq.y;
+                    const float2 XaP = cmul(Xa, Pq), XbP = cmul(Xb, Pq);
+                    Ya = make_float2(XaP.x * gr[k].x, XaP.y * gr[k].x);
+                    Yb = make_float2(XbP.x * gr[k].y, XbP.y * gr[k].y);
+                } else {
+                    float2 Ga = make_float2(gv[k].x, gv[k].y), Gb = make_float2(gv[k].z, gv[k].w);
+                    if (conj_otf) { Ga.y = -Ga.y; Gb.y = -Gb.y; }
+                    Ya = cmul(Xa, Ga);
+                    Yb = cmul(Xb, Gb);
+                }
+                const float2 E2 = make_float2(0.5f * (Ya.x + Yb.x), 0.5f * (Ya.y + Yb.y));
+                const float2 dY = csub(Ya, Yb);
+                const float2 O2 = cmulc(make_float2(0.5f * dY.x, 0.5f * dY.y), wx);
+                tile[cA] = make_float2(E2.x - O2.y, E2.y + O2.x);
+                tile[cB] = make_float2(E2.x + O2.y, O2.x - E2.y);
+            }
+        }
+        const int tn = t + gridDim.x;
+        if (tn < ntiles) load_S(tn);  // (requesting them right after the fill, a whole tile ahead, gains nothing: 4.72 vs 4.68 ms)
+        wave_lds_fence();
+        lds_fft<LZ2, true, NT, R3, 0, TOPREG ? TOPS : LZ2>(tile, 2 * TL * R3, pitch, hp, true, twl);
+        lds_barrier();
+        {
+            const FView fv = f_view();
+            float4* dp = reinterpret_cast<float4*>(T) + (size_t)plane * L * M + (size_t)(py0 / TL) * TL + fv.off;
+#pragma unroll
+            for (int k = 0; k < NPA; ++k) {
+                const int zk = fv.z0 + k * P;
+                if constexpr (!TOPREG) {
+                if (zk >= d.z_out_lo && zk < d.z_out_hi) {
+                    const int c = fv.row + (fv.slot ^ swz_c(k * P));
+                    const float2 a0 = tile[c], a1 = tile[c + pitch];
+                    dp[(size_t)(k * P) * M] = make_float4(a0.x, a0.y, a1.x, a1.y);
+                }
+                }
+            }
+            if constexpr (TOPREG) {
+                float2 v[NPA], u[NPA];
+#pragma unroll
+                for (int k = 0; k < NPA; ++k) {
+                    const int c = fv.row + (fv.slot ^ swz_c(k * P));
+                    v[k] = tile[c];
+                    u[k] = tile[c + pitch];
+                }
+                butterflies<TOPR, TOPS, true>(v, twl + tw_off(LZ2, TOPS), fv.z0);
+                butterflies<TOPR, TOPS, true>(u, twl + tw_off(LZ2, TOPS), fv.z0);
+#pragma unroll
+                for (int k = 0; k < NPA; ++k) {
+                    const int zk = fv.z0 + k * P;
+                    if (zk >= d.z_out_lo && zk < d.z_out_hi) dp[(size_t)(k * P) * M] = make_float4(v[k].x, v[k].y, u[k].x, u[k].y);
+                }
+            }
+        }
+        lds_barrier();
     }
 }
 
@@ -1503,9 +1841,16 @@ int NativeFft::init(hipStream_t s, const int F[3], bool explicit_adjoint) {
     MI_REQUIRE(lds_bytes(dims.ty, Hx) <= 160 * 1024 && lds_bytes(dims.tc, F[1]) <= 160 * 1024 &&
                    lds_bytes(2 * dims.tl, F[2]) <= 160 * 1024,
                "native FFT: transform too long for LDS");
+    // pair-interleaved z-side layout (k_y_pair / k_z_pair_pipe): z a power of two the paired z pass takes, whole blocks of
+    // kPairLines lines, an even number of columns per y tile; MI_FFT_NO_PAIR=1 keeps the plain layout (A/B measurements)
+    dims.paired = dims.r3z == 1 && dims.lz2 >= 6 && dims.lz2 <= 9 && F[1] % (2 * kPairLines) == 0 && dims.tc >= 2 && dims.tc % 2 == 0 &&
+                  F[2] % (dims.tc / 2) == 0 && dims.dbg == 0 && std::getenv("MI_FFT_NO_PAIR") == nullptr &&
+                  std::getenv("MI_FFT_NO_PIPE") == nullptr && std::getenv("MI_FFT_TL") == nullptr;
     n_cplx = (size_t)Hx * F[1] * F[2];
-    MI_TRY(S.alloc(sizeof(float2) * n_cplx));
-    MI_TRY(T.alloc(sizeof(float2) * n_cplx));
+    // (the two planes that are their own mirror partners are stored twice in the paired layout)
+    const size_t n_buf = n_cplx + (dims.paired ? (size_t)2 * F[1] * F[2] : 0);
+    MI_TRY(S.alloc(sizeof(float2) * n_buf));
+    MI_TRY(T.alloc(sizeof(float2) * n_buf));
     MI_TRY(G.alloc(sizeof(float4) * (size_t)(Hx / 2 + 1) * F[1] * F[2]));
     // twiddle tables exp(-2 pi i e / N) in double on the host, per axis: e < sub/2 for the power-of-two sub-transform
     // (sub = 2^l2), followed by the full circle e < n of the radix-3/9 stage when the axis has one
@@ -1609,9 +1954,9 @@ int NativeFft::x_forward(hipStream_t s, const float* in) {
     return rc;
 }
 
-int NativeFft::y_pass(hipStream_t s, bool inverse) {
+int NativeFft::y_pass(hipStream_t s, bool inverse, bool paired) {
     const int Hx = dims.hx, M = dims.ny, L = dims.nz;
-    const unsigned ycols = (unsigned)((size_t)L * Hx / dims.tc);
+    const unsigned ycols = paired ? (unsigned)((size_t)(Hx / 2 + 1) * (L / (dims.tc / 2))) : (unsigned)((size_t)L * Hx / dims.tc);
     const size_t yl = lds_bytes(dims.tc, M);
     const NativeDims d = dims;
     const float2* src = S.as<float2>();
@@ -1620,8 +1965,12 @@ int NativeFft::y_pass(hipStream_t s, bool inverse) {
     int rc = MI_ERR_INVALID;
 #define MI_Y(LG, R)                                                                                                            \
     case LG * 16 + R:                                                                                                          \
-        rc = inverse ? launch_lds(k_y_pass<LG, R, true>, ycols, kThreadsY, yl, s, "k_y_pass<inv>", src, dst, d, twy)            \
-                     : launch_lds(k_y_pass<LG, R, false>, ycols, kThreadsY, yl, s, "k_y_pass<fwd>", src, dst, d, twy);          \
+        if (paired)                                                                                                            \
+            rc = inverse ? launch_lds(k_y_pair<LG, R, true>, ycols, kThreadsY, yl, s, "k_y_pair<inv>", src, dst, d, twy)        \
+                         : launch_lds(k_y_pair<LG, R, false>, ycols, kThreadsY, yl, s, "k_y_pair<fwd>", src, dst, d, twy);      \
+        else                                                                                                                   \
+            rc = inverse ? launch_lds(k_y_pass<LG, R, true>, ycols, kThreadsY, yl, s, "k_y_pass<inv>", src, dst, d, twy)        \
+                         : launch_lds(k_y_pass<LG, R, false>, ycols, kThreadsY, yl, s, "k_y_pass<fwd>", src, dst, d, twy);      \
         break;
     switch (dims.ly2 * 16 + dims.r3) { MI_AXIS_CASES(MI_Y) default: return fail(MI_ERR_UNSUPPORTED, "native FFT: y length %d", M); }
 #undef MI_Y
@@ -1640,6 +1989,29 @@ int NativeFft::z_conv(hipStream_t s, bool conj_otf) {
     const float2* twz = tw_z;
     const int cj = (conj_otf && !have_adj) ? 1 : 0;
     int rc = MI_ERR_INVALID;
+    if (dims.paired) {
+        const int ntiles = (Hx / 2 + 1) * (M / kPairLines);
+        const size_t lds = lds_bytes(2 * kPairLines, L) + (real_otf ? sizeof(float2) * (size_t)L : 0);
+        const int per_cu = std::max(1, std::min(2, (int)(kLdsOneWg / lds)));  // 8 waves of 128 registers each: two fit a CU
+        const unsigned grid = (unsigned)std::min(ntiles, per_cu * n_cu);
+        RealOtf ro{};
+        if (real_otf) {
+            ro.g = adj_slot ? Gr_adj.as<float2>() : Gr.as<float2>();
+            ro.ph_x = ph.as<float2>();
+            ro.ph_y = ro.ph_x + (Hx / 2 + 1);
+            ro.ph_z = ro.ph_y + M;
+        }
+#define MI_ZQ(LG)                                                                                                                        \
+    case LG:                                                                                                                             \
+        rc = real_otf ? launch_lds(k_z_pair_pipe<LG, 1, true, 64 * kPairLines, kPairLines>, grid, 64 * kPairLines, lds, s,               \
+                                   "k_z_pair_pipe<real OTF>", Tp, Sp, Gp, d, twz, cj, ntiles, ro)                                       \
+                      : launch_lds(k_z_pair_pipe<LG, 1, false, 64 * kPairLines, kPairLines>, grid, 64 * kPairLines, lds, s,              \
+                                   "k_z_pair_pipe", Tp, Sp, Gp, d, twz, cj, ntiles, ro);                                                \
+        break;
+        switch (dims.lz2) { MI_ZQ(6) MI_ZQ(7) MI_ZQ(8) MI_ZQ(9) default: return fail(MI_ERR_UNSUPPORTED, "native FFT: paired z length %d", L); }
+#undef MI_ZQ
+        return rc;
+    }
     if (z_pipelined()) {
         const int ntiles = (int)ztiles;
         const unsigned grid = (unsigned)std::min(ntiles, n_cu);
@@ -1676,7 +2048,7 @@ int NativeFft::z_conv(hipStream_t s, bool conj_otf) {
 
 bool NativeFft::z_pipelined() const {
     static const bool no_pipe = std::getenv("MI_FFT_NO_PIPE") != nullptr;
-    return dims.dbg == 0 && !no_pipe && dims.tl == z_tile_lines(dims.nz);
+    return dims.paired || (dims.dbg == 0 && !no_pipe && dims.tl == z_tile_lines(dims.nz));
 }
 
 // Tries the real form of the OTF(s): `delta` = offset (x, y, z) of the PSF's centre sample from the grid origin.  Keeps the
@@ -1685,8 +2057,8 @@ bool NativeFft::z_pipelined() const {
 int NativeFft::try_real_otf(hipStream_t s, const int delta[3]) {
     const bool off = std::getenv("MI_FFT_COMPLEX_OTF") != nullptr;
     const int Hx = dims.hx, M = dims.ny, L = dims.nz;
-    bool even = false;
-#define MI_EV(LG, R) case LG * 16 + R: even = z_pipe_even(R << LG); break;
+    bool even = dims.paired != 0;
+#define MI_EV(LG, R) case LG * 16 + R: even = even || z_pipe_even(R << LG); break;
     switch (dims.lz2 * 16 + dims.r3z) { MI_Z_CASES(MI_EV) default: break; }
 #undef MI_EV
     if (off || !z_pipelined() || !even) return MI_OK;
@@ -1749,7 +2121,7 @@ int NativeFft::build_otf(hipStream_t s, const float* placed, bool adjoint_slot, 
 int NativeFft::spectrum(hipStream_t s, const float* vol, float4* Gp, float scale) {
     MI_REQUIRE(!pw.on, "native FFT: spectra are taken on the unpadded grid (before the pad window is set)");
     MI_TRY(x_forward(s, vol));
-    MI_TRY(y_pass(s, false));
+    MI_TRY(y_pass(s, false, false));  // (k_z_conv<build> reads the plain [px][z][py] layout)
     const int Hx = dims.hx, M = dims.ny, L = dims.nz;
     const unsigned ztiles = (unsigned)((size_t)(Hx / 2 + 1) * (M / dims.tl));
     const size_t zl = lds_bytes(2 * dims.tl, L);
@@ -1769,9 +2141,9 @@ int NativeFft::spectrum(hipStream_t s, const float* vol, float4* Gp, float scale
 
 // P2, P3, P4: S[z][px][py] -> T[z][px][py] (x still transformed), multiplied by the OTF or its conjugate
 int NativeFft::middle(hipStream_t s, bool conj_otf) {
-    MI_TRY(y_pass(s, false));
+    MI_TRY(y_pass(s, false, dims.paired != 0));
     MI_TRY(z_conv(s, conj_otf));
-    return y_pass(s, true);
+    return y_pass(s, true, dims.paired != 0);
 }
 
 // P5 (+ P1 of the next convolution when fuse_forward): T -> out (may be null when fused) [-> S]
@@ -1852,9 +2224,9 @@ int NativeFft::time_pass(hipStream_t s, int which, const float* bl, int reps, fl
             case 0: rc = x_forward(s, bl); break;
             case 4: rc = x_inverse(s, nullptr, EPI_RATIO, e, true); break;
             case 5: rc = x_inverse(s, const_cast<float*>(bl), EPI_UPDATE, e, true); break;
-            case 1: rc = y_pass(s, false); break;
+            case 1: rc = y_pass(s, false, dims.paired != 0); break;
             case 2: rc = z_conv(s, false); break;
-            default: rc = y_pass(s, true); break;
+            default: rc = y_pass(s, true, dims.paired != 0); break;
         }
     }
     (void)hipEventRecord(e1, s);

@@ -236,6 +236,9 @@ extern "C" size_t mi_rl_device_bytes(const mi_rl_ctx* ctx) {
 }
 
 extern "C" int mi_rl_separable(const mi_rl_ctx* ctx) { return ctx && ctx->separable ? 1 : 0; }
+extern "C" int mi_rl_pair_layout(const mi_rl_ctx* ctx) {
+    return ctx && ctx->engine == MI_ENGINE_FFT && ctx->fft && ctx->fft->native && ctx->fft->native->dims.paired ? 1 : 0;
+}
 
 static int ctx_conv(mi_rl_ctx* c, hipStream_t s, const float* in, bool adjoint, float* out, int epi_kind, const ConvEpilogue& epi) {
     if (c->engine == MI_ENGINE_DIRECT && c->separable) {

@@ -333,6 +333,11 @@ class RLContext:
         return bool(lib().mi_rl_separable(self._h))
 
     @property
+    def pair_layout(self) -> bool:
+        """The FFT engine keeps the spectra around its z pass pair-interleaved (``mi_rl_pair_layout``)."""
+        return bool(lib().mi_rl_pair_layout(self._h))
+
+    @property
     def otf_is_real(self) -> bool:
         return bool(lib().mi_rl_otf_is_real(self._h))
 

@@ -1,0 +1,91 @@
+// What the HBM system gives for the access pattern of the strided FFT passes, without any of their arithmetic: work-groups
+// (256 lanes, 8 per CU) copy tiles of NZ segments of SEG bytes that lie PITCH bytes apart, from `nstreams` places per tile
+// (the z pass: a line tile and its mirror partner).   build: hipcc --offload-arch=gfx950 -O3 -o profiles/build/strided_copy_probe profiles/strided_copy_probe.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+constexpr int NT = 256;
+// one work-group copies a quarter (NZ / 4 segments per stream) of a tile; 8 work-groups per CU overlap loads and stores
+template <int SEG, int NSTREAM, int NZ>
+__global__ __launch_bounds__(NT) void k_copy(const float4* __restrict__ src, float4* __restrict__ dst, size_t plane_f4, size_t pitch_f4,
+                                             int tiles_per_plane, int nplanes, int with_g, const float4* __restrict__ g, float* sink) {
+    constexpr int LPS = SEG / 16, ZPI = NT / LPS, K = NZ / 4 / ZPI;
+    const int t = blockIdx.x >> 2, zq = blockIdx.x & 3;
+    const int z0 = zq * (NZ / 4) + threadIdx.x / LPS, l = threadIdx.x % LPS;
+    const int plane = t / tiles_per_plane, yt = t - plane * tiles_per_plane;
+    float4 v[NSTREAM][K];
+    float acc = 0.0f;
+#pragma unroll
+    for (int st = 0; st < NSTREAM; ++st) {
+        const int p = st == 0 ? plane : (nplanes - 1 - plane), y = st == 0 ? yt : (tiles_per_plane - 1 - yt);
+        const float4* s = src + (size_t)p * plane_f4 + (size_t)y * LPS + (size_t)z0 * pitch_f4 + l;
+#pragma unroll
+        for (int k = 0; k < K; ++k) v[st][k] = s[(size_t)k * ZPI * pitch_f4];
+    }
+    if (with_g) {  // the OTF stream: contiguous, NSTREAM * NZ * SEG / 2 bytes per tile
+        const float4* gp = g + ((size_t)blockIdx.x * (NSTREAM * NZ * LPS / 8)) + threadIdx.x;
+#pragma unroll
+        for (int k = 0; k < NSTREAM * NZ * LPS / 8 / NT; ++k) { const float4 q = gp[k * NT]; acc += q.x + q.w; }
+    }
+#pragma unroll
+    for (int st = 0; st < NSTREAM; ++st) {
+        const int p = st == 0 ? plane : (nplanes - 1 - plane), y = st == 0 ? yt : (tiles_per_plane - 1 - yt);
+        float4* d = dst + (size_t)p * plane_f4 + (size_t)y * LPS + (size_t)z0 * pitch_f4 + l;
+#pragma unroll
+        for (int k = 0; k < K; ++k) d[(size_t)k * ZPI * pitch_f4] = v[st][k];
+    }
+    if (acc == 1.2345f) *sink = acc;
+}
+
+template <int SEG, int NSTREAM>
+void run(const char* what, float4* a, float4* b, float4* g, float* sink, size_t total_bytes, int with_g, int pad) {
+    constexpr int NZ = 512;
+    const size_t pitch = 16384 + (size_t)pad;         // bytes between the segments of a tile (the row of 2048 complex samples + padding)
+    const size_t plane = pitch * NZ;                  // one px plane
+    const int nplanes = (int)(total_bytes / plane) - 1;
+    const int tiles_per_plane = (int)(16384 / SEG);
+    const int ntiles = nplanes * tiles_per_plane / NSTREAM;  // NSTREAM streams cover the planes from both ends
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    float best = 1e9f;
+    for (int rep = 0; rep < 4; ++rep) {
+        CK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL((k_copy<SEG, NSTREAM, NZ>), dim3(ntiles * 4), dim3(NT), 0, 0, a, b, plane / 16, pitch / 16, tiles_per_plane, nplanes,
+                           with_g, g, sink);
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        if (rep > 0 && ms < best) best = ms;
+    }
+    const double bytes = 2.0 * total_bytes + (with_g ? total_bytes / 2.0 : 0.0);
+    printf("%-44s pad %4d  %6.3f ms  %5.2f TB/s\n", what, pad, best, bytes * (double)nplanes / (double)(nplanes + 1) / best / 1e9);
+    fflush(stdout);
+}
+
+int main() {
+    const size_t total = (size_t)1024 * 512 * 2048 * 8;  // the C3 spectrum: 8.6 GB
+    float4 *a, *b, *g;
+    float* sink;
+    CK(hipMalloc(&a, total));
+    CK(hipMalloc(&b, total));
+    CK(hipMalloc(&g, total / 2));
+    CK(hipMalloc(&sink, 4));
+    CK(hipMemset(a, 1, total));
+    CK(hipMemset(b, 0, total));
+    CK(hipMemset(g, 0, total / 2));
+    for (int with_g = 0; with_g < 2; ++with_g) {
+        printf(with_g ? "-- with the contiguous OTF stream (4.3 GB)\n" : "-- spectrum in + out only (17.2 GB)\n");
+        for (int pad : {0, 128, 256, 512, 1024, 2048}) {
+            run<128, 2>("2 streams x 128-B segments (z pass, plain)", a, b, g, sink, total, with_g, pad);
+            run<256, 1>("1 stream x 256-B segments", a, b, g, sink, total, with_g, pad);
+            run<64, 2>("2 streams x 64-B segments", a, b, g, sink, total, with_g, pad);
+        }
+    }
+    return 0;
+}
