@@ -2,7 +2,8 @@
 # Round profile (one GPU): kernel statistics, HBM traffic (PMC, separate passes) and SQ counters of the default bench (C3), and
 # kernel statistics + HBM traffic of the NCC batch (C5 grid).  Every profiler run is bounded (a run that has written its
 # results but does not exit is killed).
-# Run on the GPU box from the repo root:  bash profiles/collect.sh r02   -> files under gpurun_out/, to be copied into profiles/
+# Run on the GPU box from the repo root:  bash profiles/collect.sh r02 [rl]  -> files under gpurun_out/, to be copied into profiles/
+# (second argument "rl": only the RL bench part)
 tag=${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 T="timeout -k 5 300"
@@ -18,6 +19,7 @@ python3 profiles/pmc_summary.py gpurun_out/pmc_F gpurun_out/pmc_W gpurun_out/${t
 echo "bench pmc done"
 bash profiles/sq_pass.sh gpurun_out/${tag}_sq_counters.txt
 echo "bench sq done"
+if [ "$2" = "rl" ]; then rm -rf gpurun_out/pmc_F gpurun_out/pmc_W gpurun_out/prof_$tag; exit 0; fi
 $T rocprofv3 --kernel-trace --stats -d gpurun_out/prof_ncc_$tag -o $tag -- python3 $N > gpurun_out/prof_ncc_$tag.log 2>&1
 python3 profiles/summarize.py "$(db prof_ncc_$tag)" gpurun_out/${tag}_ncc_c5_kernel_stats.csv
 $T rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_NF -o pmc -- python3 $N > gpurun_out/pmc_NF.log 2>&1
