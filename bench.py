@@ -68,11 +68,14 @@ def pmc_traffic(pass_name, workload):
             continue
     if kern is None:
         return None
-    want = {"z_conv": ("k_z_conv_pipe<", ">"), "x_fused": ("k_x_fused_pipe<", ">"),
-            "y_forward": ("k_y_pass<", "false>"), "y_inverse": ("k_y_pass<", "true>")}[pass_name]
-    for name, v in kern.items():
-        if name.startswith(want[0]) and name.endswith(want[1]):
-            return round(v["hbm_bytes_per_launch"])
+    # (the pair-interleaved layout runs k_y_pair / k_z_pair_pipe, the plain one k_y_pass / k_z_conv_pipe)
+    want = {"z_conv": (("k_z_pair_pipe<", ">"), ("k_z_conv_pipe<", ">")), "x_fused": (("k_x_fused_pipe<", ">"),),
+            "y_forward": (("k_y_pair<", "false>"), ("k_y_pass<", "false>")),
+            "y_inverse": (("k_y_pair<", "true>"), ("k_y_pass<", "true>"))}[pass_name]
+    for pre, post in want:
+        for name, v in kern.items():
+            if name.startswith(pre) and name.endswith(post):
+                return round(v["hbm_bytes_per_launch"])
     return None
 
 
@@ -259,10 +262,12 @@ def main():
                 ach = algo_b * launch_vox / (times[dom] * 1e-3) / 1e9
                 roofline = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(dom, args.workload) if world == 1 else None,
-                            "kernel": {"z_conv": "k_z_conv_pipe (z-forward FFT + untangle*OTF + z-inverse FFT, one pass)",
+                            "kernel": {"z_conv": ("k_z_pair_pipe" if ctx.pair_layout else "k_z_conv_pipe") +
+                                                 " (z-forward FFT + untangle*OTF + z-inverse FFT, one pass)",
                                        "x_fused": "k_x_fused_pipe (x-inverse FFT + RL epilogue + x-forward FFT; mean of the "
                                                   "ratio and the update launch)",
-                                       "y_forward": "k_y_pass<fwd>", "y_inverse": "k_y_pass<inv>"}[dom],
+                                       "y_forward": "k_y_pair<fwd>" if ctx.pair_layout else "k_y_pass<fwd>",
+                                       "y_inverse": "k_y_pair<inv>" if ctx.pair_layout else "k_y_pass<inv>"}[dom],
                             "algorithmic_bytes_per_voxel_per_launch": algo_b, "voxels_per_launch": int(launch_vox),
                             "launch_ms": round(times[dom], 4), "launches_per_iteration": per_iter[dom],
                             "pass_ms": dict({k: round(v, 4) for k, v in times.items()},
