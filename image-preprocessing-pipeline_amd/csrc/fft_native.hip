@@ -1248,7 +1248,11 @@ __global__ __launch_bounds__(NT, kWavesXZ) void k_z_pair_pipe(const float2* __re
                                                               NativeDims d, const float2* __restrict__ tw, int conj_otf, int ntiles, RealOtf ro) {
     extern __shared__ __attribute__((aligned(16))) float2 tile[];
     constexpr int L = R3 << LZ2, NW = NT / 64, hp = TL, pitch = row_pitch(L);
-    static_assert(TL == NW && L % 64 == 0 && R3 == 1, "one A line and its partner per wave");
+    // WP: every wave owns one A line and its partner (rows wave, TL + wave), so the point-wise step is wave-private too;
+    // else (1024-point lines: 16 waves on 16 rows) a wave owns ONE row, the point-wise step of line `wave % TL` is shared by the
+    // owners of its two rows -- half of the positions each -- and sits between two work-group barriers
+    constexpr bool WP = TL == NW;
+    static_assert((WP || (NW == 2 * TL && L % 128 == 0)) && L % 64 == 0 && R3 == 1, "one or two waves per line pair");
     constexpr int NPA = TL * L / NT;  // float4 (two neighbouring lines at one z) per lane and tile
     constexpr int P = NT / TL;        // item k of a lane: position z0 + k * P
     constexpr int NPG = TL * L / NT;  // point-wise items (mirror pairs) per lane
@@ -1280,6 +1284,7 @@ __global__ __launch_bounds__(NT, kWavesXZ) void k_z_pair_pipe(const float2* __re
     }
     int t = blockIdx.x;
     if (t < ntiles) load_S(t);
+    lds_barrier();  // the tables: the first tile's top super-stage reads them before any other barrier
     for (; t < ntiles; t += gridDim.x) {
         const int plane = t / ytiles, py0 = (t - plane * ytiles) * TL;
         {
@@ -1312,10 +1317,11 @@ __global__ __launch_bounds__(NT, kWavesXZ) void k_z_pair_pipe(const float2* __re
         {
             const int tid = launder(threadIdx.x);
             const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+            const int line = WP ? wv : wv % TL, p0 = WP ? 0 : (wv / TL) * (L / 2);
             if constexpr (REALG) {
-                ph_xy = cmul(ro.ph_x[plane], ro.ph_y[y_pos2freq(py0 + wv, d)]);
+                ph_xy = cmul(ro.ph_x[plane], ro.ph_y[y_pos2freq(py0 + line, d)]);
             }
-            const size_t gl = g0 + (size_t)wv * L + (tid & 63);
+            const size_t gl = g0 + (size_t)line * L + p0 + (tid & 63);
 #pragma unroll
             for (int k = 0; k < NPG; ++k) {
                 if constexpr (REALG) gr[k] = ro.g[gl + 64 * k];
@@ -1324,6 +1330,7 @@ __global__ __launch_bounds__(NT, kWavesXZ) void k_z_pair_pipe(const float2* __re
         }
         lds_barrier();
         lds_fft<LZ2, false, NT, R3, TOPREG ? TOPR : 0>(tile, 2 * TL * R3, pitch, hp, true, twl);
+        if constexpr (!WP) lds_barrier();
         float sw, cw;
         sincospif(-2.0f * (float)plane / (float)(2 * Hx), &sw, &cw);  // exp(-2 pi i xk / Nx), Nx = 2 Hx
         const float2 wx = make_float2(cw, sw);
@@ -1334,14 +1341,16 @@ __global__ __launch_bounds__(NT, kWavesXZ) void k_z_pair_pipe(const float2* __re
             // whose high bits 64 k are not zero is (lane ^ 63) + [mirror of the high bits alone], else the mirror of `lane` among
             // the first 64 positions: lane constants XOR compile-time numbers, like every slot here
             const int lane = tid & 63;
-            const int pA = phys(lane) ^ rmask(wv, hp), pB1 = phys(lane ^ 63) ^ rmask(TL + wv, hp);
-            const int pB0 = phys(mirror_pos(lane, L, LZ2, R3)) ^ rmask(TL + wv, hp);
+            const int line = WP ? wv : wv % TL, p0 = WP ? 0 : (wv / TL) * (L / 2);  // (scalar)
+            const int pA = phys(lane) ^ rmask(line, hp), pB1 = phys(lane ^ 63) ^ rmask(TL + line, hp);
+            const int pB0 = phys(mirror_pos(lane, L, LZ2, R3)) ^ rmask(TL + line, hp);
 #pragma unroll
             for (int k = 0; k < NPG; ++k) {
-                const int flo = (int)brev_n((unsigned)(64 * k), LZ2);
+                const int hb = 64 * k + p0;  // the position bits above the lane's six
+                const int flo = (int)brev_n((unsigned)hb, LZ2);
                 const int mhi = flo ? (int)brev_n((unsigned)((1 << (LZ2 - 6)) - flo), LZ2) : 0;
-                const int cA = wv * pitch + (pA ^ swz_c(64 * k));
-                const int cB = (TL + wv) * pitch + (flo ? (pB1 ^ swz_c(mhi)) : pB0);
+                const int cA = line * pitch + (pA ^ swz_c(hb));
+                const int cB = (TL + line) * pitch + (flo ? (pB1 ^ swz_c(mhi)) : pB0);
                 const float2 a = tile[cA];
                 const float2 bc = cconj(tile[cB]);
                 const float2 E = make_float2(0.5f * (a.x + bc.x), 0.5f * (a.y + bc.y));
@@ -1351,7 +1360,7 @@ __global__ __launch_bounds__(NT, kWavesXZ) void k_z_pair_pipe(const float2* __re
                 const float2 Xa = cadd(E, wO), Xb = csub(E, wO);
                 float2 Ya, Yb;
                 if constexpr (REALG) {
-                    float2 Pq = cmul(ph_xy, phl[lane + 64 * k]);
+                    float2 Pq = cmul(ph_xy, phl[lane + hb]);
                     if (conj_otf) Pq.y = -Pq.y;
                     const float2 XaP = cmul(Xa, Pq), XbP = cmul(Xb, Pq);
                     Ya = make_float2(XaP.x * gr[k].x, XaP.y * gr[k].x);
@@ -1371,7 +1380,8 @@ __global__ __launch_bounds__(NT, kWavesXZ) void k_z_pair_pipe(const float2* __re
         }
         const int tn = t + gridDim.x;
         if (tn < ntiles) load_S(tn);  // (requesting them right after the fill, a whole tile ahead, gains nothing: 4.72 vs 4.68 ms)
-        wave_lds_fence();
+        if constexpr (WP) wave_lds_fence();
+        else lds_barrier();
         lds_fft<LZ2, true, NT, R3, 0, TOPREG ? TOPS : LZ2>(tile, 2 * TL * R3, pitch, hp, true, twl);
         lds_barrier();
         {
@@ -1843,7 +1853,7 @@ int NativeFft::init(hipStream_t s, const int F[3], bool explicit_adjoint) {
                "native FFT: transform too long for LDS");
     // pair-interleaved z-side layout (k_y_pair / k_z_pair_pipe): z a power of two the paired z pass takes, whole blocks of
     // kPairLines lines, an even number of columns per y tile; MI_FFT_NO_PAIR=1 keeps the plain layout (A/B measurements)
-    dims.paired = dims.r3z == 1 && dims.lz2 >= 6 && dims.lz2 <= 9 && F[1] % (2 * kPairLines) == 0 && dims.tc >= 2 && dims.tc % 2 == 0 &&
+    dims.paired = dims.r3z == 1 && dims.lz2 >= 6 && dims.lz2 <= 10 && F[1] % (2 * kPairLines) == 0 && dims.tc >= 2 && dims.tc % 2 == 0 &&
                   F[2] % (dims.tc / 2) == 0 && dims.dbg == 0 && std::getenv("MI_FFT_NO_PAIR") == nullptr &&
                   std::getenv("MI_FFT_NO_PIPE") == nullptr && std::getenv("MI_FFT_TL") == nullptr;
     n_cplx = (size_t)Hx * F[1] * F[2];
@@ -2008,7 +2018,16 @@ int NativeFft::z_conv(hipStream_t s, bool conj_otf) {
                       : launch_lds(k_z_pair_pipe<LG, 1, false, 64 * kPairLines, kPairLines>, grid, 64 * kPairLines, lds, s,              \
                                    "k_z_pair_pipe", Tp, Sp, Gp, d, twz, cj, ntiles, ro);                                                \
         break;
-        switch (dims.lz2) { MI_ZQ(6) MI_ZQ(7) MI_ZQ(8) MI_ZQ(9) default: return fail(MI_ERR_UNSUPPORTED, "native FFT: paired z length %d", L); }
+        switch (dims.lz2) {
+            MI_ZQ(6) MI_ZQ(7) MI_ZQ(8) MI_ZQ(9)
+            case 10:  // 128-KB tile: one work-group of 16 waves per CU, one line per wave
+                rc = real_otf ? launch_lds(k_z_pair_pipe<10, 1, true, 128 * kPairLines, kPairLines>, grid, 128 * kPairLines, lds, s,
+                                           "k_z_pair_pipe<1024, real OTF>", Tp, Sp, Gp, d, twz, cj, ntiles, ro)
+                              : launch_lds(k_z_pair_pipe<10, 1, false, 128 * kPairLines, kPairLines>, grid, 128 * kPairLines, lds, s,
+                                           "k_z_pair_pipe<1024>", Tp, Sp, Gp, d, twz, cj, ntiles, ro);
+                break;
+            default: return fail(MI_ERR_UNSUPPORTED, "native FFT: paired z length %d", L);
+        }
 #undef MI_ZQ
         return rc;
     }
