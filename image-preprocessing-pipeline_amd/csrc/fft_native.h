@@ -16,6 +16,8 @@ struct NativeDims {
     int z_in_hi, z_out_lo, z_out_hi, y_out_hi;
     int dbg;          // timing experiments only: knocks out phases of the z pass (results are then wrong)
     int paired;       // spectra around the z pass in the pair-interleaved layout (k_y_pair, k_z_pair_pipe)
+    int zpad;         // paired layout: float4 of padding behind every row (xk, z)
+    int xrow;         // x side: complex samples from one row (z, px) to the next (ny + padding)
 };
 
 // Padded mode: the caller's volume (extents n) sits at offset o inside the transform grid; the x passes apply the boundary
@@ -37,7 +39,8 @@ struct TileSelect {
 struct NativeFft {
     NativeDims dims{};
     PadWindow pw{};
-    DevBuf S, T, G, G_adj, tw;
+    DevBuf S, G, G_adj, tw;  // S: both spectrum arrays, S first
+    float2* t_spec = nullptr;  // the second spectrum array T (inside S's allocation)
     DevBuf Gr, Gr_adj, ph;  // real form of the OTF(s) + phase tables (symmetric PSFs), see try_real_otf
     bool real_otf = false;
     bool have_adj = false;  // adjoint = second OTF (G_adj) instead of conj(G)
@@ -61,7 +64,7 @@ struct NativeFft {
     // after build_otf: switch to the real OTF form when the PSF allows it (delta: centre offset from the grid origin)
     int try_real_otf(hipStream_t s, const int delta[3]);
     bool z_pipelined() const;
-    float* scratch() { return T.as<float>(); }  // F floats, free between convolutions
+    float* scratch() { return reinterpret_cast<float*>(t_spec); }  // F floats, free between convolutions
     // after the OTFs are built: volumes handed to conv / iterate have extents n (x, y, z) and are padded on the fly
     void set_window(const int n[3], const int o[3], const int rep[3], const int k[3]);
     bool can_fuse() const;  // consecutive convolutions may share their x passes (every padded axis follows the zero rule)
@@ -81,7 +84,7 @@ struct NativeFft {
     bool pipe_ok() const;  // the fused x pass can run as the persistent pipelined kernel
     bool splits() const;   // ... and a subset of its tiles (unpadded grids)
     TileSelect edge_tiles(int mode, int a0, int a1, int b0, int b1) const;
-    size_t device_bytes() const { return S.bytes + T.bytes + G.bytes + G_adj.bytes + Gr.bytes + Gr_adj.bytes + ph.bytes + tw.bytes; }
+    size_t device_bytes() const { return S.bytes + G.bytes + G_adj.bytes + Gr.bytes + Gr_adj.bytes + ph.bytes + tw.bytes; }
 };
 
 }  // namespace mi

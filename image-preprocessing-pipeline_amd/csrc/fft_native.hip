@@ -238,6 +238,9 @@ __host__ __device__ constexpr int axis_tw_entries(int n) {
 }
 constexpr int kLdsOneWg = 156 * 1024;  // one work-group per CU (160 KB LDS)
 constexpr int kLdsTwoWg = 78 * 1024;   // two work-groups per CU
+constexpr size_t kSpecGapBytes = 0;    // bytes between the end of S and the start of T (NativeFft::init)
+constexpr int kRowPadBytes = 4224;     // padding behind the rows of the spectrum arrays ...
+constexpr size_t kPadRowBytes = 8192;  // ... that are at least this long (NativeFft::init)
 constexpr int kPairLines = 8;          // lines per block of the pair-interleaved z-side layout (8 A + 8 B lines = 128 bytes)
 // rows of an x tile / line pairs of a z tile: 16 (full 128-B lines in the transposed layouts) while tile + tables fit one
 // work-group per CU; columns of a y tile: two work-groups per CU
@@ -552,8 +555,8 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_x_forward(const float*
     const int TY = d.ty, hp = TY / 2, pitch = row_pitch(Hx);
     const int ytiles = d.ny / TY;
     const int z = blockIdx.x / ytiles, y0 = (blockIdx.x % ytiles) * TY;
-    const int rowq = d.ny / 2;
-    float4* dst = reinterpret_cast<float4*>(S + ((size_t)z * Hx) * d.ny + y0);
+    const int rowq = d.xrow / 2;
+    float4* dst = reinterpret_cast<float4*>(S + ((size_t)z * Hx) * d.xrow + y0);
     if (pw.on) {
         // staged load with the boundary rule; a tile that lies entirely in the zero padding transforms to zeros
         const int sz = pad_src(pw, 2, z);
@@ -630,7 +633,9 @@ __global__ __launch_bounds__(kThreadsY, 4) void k_y_pass(const float2* __restric
         const int z_first = (int)(c0 % L);
         if (z_first >= d.z_out_hi || z_first + TC <= d.z_out_lo) return;
     }
-    const float4* base = reinterpret_cast<const float4*>(src + c0 * M);
+    // row pitches: the x side ([z][px][py]) may carry padding behind every row (NativeDims::xrow)
+    const size_t src_pitch = INVERSE ? (size_t)M : (size_t)d.xrow, dst_pitch = INVERSE ? (size_t)d.xrow : (size_t)M;
+    const float4* base = reinterpret_cast<const float4*>(src + c0 * src_pitch);
     // columns dealt to the waves when there are enough of them: then the fill, the transform and the drain of a column all
     // belong to one wave and the kernel has no work-group barrier besides the one behind the table fill
     const bool priv = (TC % NW) == 0;
@@ -655,7 +660,7 @@ __global__ __launch_bounds__(kThreadsY, 4) void k_y_pass(const float2* __restric
 #pragma unroll
         for (int k = 0; k < NIT; ++k) {
             const int c = (k * kThreadsY) / quads, qk = (k * kThreadsY) % quads;
-            const float4 v = base[(size_t)c * quads + qk + threadIdx.x];
+            const float4 v = base[(size_t)c * (src_pitch / 2) + qk + threadIdx.x];
             const int s0 = c * pitch + (s_lane ^ swz_c(2 * qk));
             tile[s0] = make_float2(v.x, v.y);
             tile[s0 ^ 1] = make_float2(v.z, v.w);
@@ -665,7 +670,7 @@ __global__ __launch_bounds__(kThreadsY, 4) void k_y_pass(const float2* __restric
         for (int i = first; i < n_items; i += step) {
             const int cl = i / quads, q = i - cl * quads;
             const int c = priv ? cl * NW + wave : cl;
-            const float4 v = base[(size_t)c * quads + q];
+            const float4 v = base[(size_t)c * (src_pitch / 2) + q];
             const int s0 = c * pitch + phys(2 * q);
             tile[s0] = make_float2(v.x, v.y);
             tile[s0 ^ 1] = make_float2(v.z, v.w);
@@ -688,7 +693,7 @@ __global__ __launch_bounds__(kThreadsY, 4) void k_y_pass(const float2* __restric
             const int c = (k * kThreadsY) / quads, qk = (k * kThreadsY) % quads;
             const int s0 = c * pitch + (s_lane ^ swz_c(2 * qk));
             const float2 a = tile[s0], b = tile[s0 ^ 1];
-            float4* dcol = reinterpret_cast<float4*>(dst + dest_col(c0 + c) * M);  // scalar
+            float4* dcol = reinterpret_cast<float4*>(dst + dest_col(c0 + c) * dst_pitch);  // scalar
             if (!INVERSE || 2 * (qk + (int)threadIdx.x) < d.y_out_hi) dcol[qk + threadIdx.x] = make_float4(a.x, a.y, b.x, b.y);
         }
     } else {
@@ -698,7 +703,7 @@ __global__ __launch_bounds__(kThreadsY, 4) void k_y_pass(const float2* __restric
             const int c = priv ? cl * NW + wave : cl;
             const int s0 = c * pitch + phys(2 * q);
             const float2 a = tile[s0], b = tile[s0 ^ 1];
-            if (!INVERSE || 2 * q < d.y_out_hi) reinterpret_cast<float4*>(dst + dest_col(c0 + c) * M)[q] = make_float4(a.x, a.y, b.x, b.y);
+            if (!INVERSE || 2 * q < d.y_out_hi) reinterpret_cast<float4*>(dst + dest_col(c0 + c) * dst_pitch)[q] = make_float4(a.x, a.y, b.x, b.y);
         }
     }
 }
@@ -733,7 +738,7 @@ __global__ __launch_bounds__(kThreadsY, 4) void k_y_pair(const float2* __restric
     auto x_item = [&](int i, int& c, int& q, size_t& g) {
         c = i / quads;
         q = i - c * quads;
-        g = (((size_t)(z0 + (c >> 1)) * Hx + ((c & 1) ? pxB : pxA)) * M) / 2 + q;
+        g = (((size_t)(z0 + (c >> 1)) * Hx + ((c & 1) ? pxB : pxA)) * d.xrow) / 2 + q;
     };
     // z side, by float4 f of row (xk, z0 + zi): block f >> 3; f & 7 < 4: lines 2 (f & 3), + 1 of the block from the A column,
     // else the partners of those two lines from the B column -- the mirrors of neighbouring positions are neighbours (they
@@ -743,7 +748,7 @@ __global__ __launch_bounds__(kThreadsY, 4) void k_y_pair(const float2* __restric
         const int py = ((f >> 3) << 3) + 2 * (f & 3), side = (f >> 2) & 1;
         c = 2 * zi + side;
         s0 = c * pitch + phys(side ? mirror_pos(py, M, LY2, R3) : py);
-        g = ((size_t)xk * L + z0 + zi) * M + f;
+        g = ((size_t)xk * L + z0 + zi) * (size_t)(M + d.zpad) + f;
     };
     const bool priv = (TC % NW) == 0;  // (the transform only: fill and drain cross the columns)
     using TW = TwLds<LY2, R3>;
@@ -777,10 +782,10 @@ __global__ __launch_bounds__(kThreadsY, 4) void k_y_pair(const float2* __restric
     if (fast) {
         if (INVERSE) {
             const ZLane zl = z_lane();
-            const float4* rowp = reinterpret_cast<const float4*>(src) + ((size_t)xk * L + z0) * M + threadIdx.x;
+            const float4* rowp = reinterpret_cast<const float4*>(src) + ((size_t)xk * L + z0) * (size_t)(M + d.zpad) + threadIdx.x;
 #pragma unroll
             for (int k = 0; k < NIT; ++k) {
-                const float4 v = rowp[(size_t)k * kThreadsY];  // rows of the tile follow each other: (zi M + f0) = k NT
+                const float4 v = rowp[(size_t)((k * kThreadsY) / M) * (M + d.zpad) + (k * kThreadsY) % M];
                 const int s0 = z_slot_fast(zl, k);
                 tile[s0] = make_float2(v.x, v.y);
                 tile[s0 ^ 1] = make_float2(v.z, v.w);
@@ -790,7 +795,7 @@ __global__ __launch_bounds__(kThreadsY, 4) void k_y_pair(const float2* __restric
 #pragma unroll
             for (int k = 0; k < NIT; ++k) {
                 const int c = (k * kThreadsY) / quads, qk = (k * kThreadsY) % quads;
-                const size_t col = (((size_t)(z0 + (c >> 1)) * Hx + ((c & 1) ? pxB : pxA)) * M) / 2;  // scalar
+                const size_t col = (((size_t)(z0 + (c >> 1)) * Hx + ((c & 1) ? pxB : pxA)) * d.xrow) / 2;  // scalar
                 const float4 v = reinterpret_cast<const float4*>(src)[col + qk + threadIdx.x];
                 const int s0 = c * pitch + (s_lane ^ swz_c(2 * qk));
                 tile[s0] = make_float2(v.x, v.y);
@@ -834,19 +839,19 @@ __global__ __launch_bounds__(kThreadsY, 4) void k_y_pair(const float2* __restric
                 const int z = z0 + (c >> 1);
                 // (a plane that is its own partner is written once, from its A copy)
                 if ((self && (c & 1)) || 2 * (qk + (int)threadIdx.x) >= d.y_out_hi || z < d.z_out_lo || z >= d.z_out_hi) continue;
-                const size_t col = (((size_t)z * Hx + ((c & 1) ? pxB : pxA)) * M) / 2;  // scalar
+                const size_t col = (((size_t)z * Hx + ((c & 1) ? pxB : pxA)) * d.xrow) / 2;  // scalar
                 const int s0 = c * pitch + (s_lane ^ swz_c(2 * qk));
                 const float2 a = tile[s0], b = tile[s0 ^ 1];
                 reinterpret_cast<float4*>(dst)[col + qk + threadIdx.x] = make_float4(a.x, a.y, b.x, b.y);
             }
         } else {
             const ZLane zl = z_lane();
-            float4* rowp = reinterpret_cast<float4*>(dst) + ((size_t)xk * L + z0) * M + threadIdx.x;
+            float4* rowp = reinterpret_cast<float4*>(dst) + ((size_t)xk * L + z0) * (size_t)(M + d.zpad) + threadIdx.x;
 #pragma unroll
             for (int k = 0; k < NIT; ++k) {
                 const int s0 = z_slot_fast(zl, k);
                 const float2 a = tile[s0], b = tile[s0 ^ 1];
-                rowp[(size_t)k * kThreadsY] = make_float4(a.x, a.y, b.x, b.y);
+                rowp[(size_t)((k * kThreadsY) / M) * (M + d.zpad) + (k * kThreadsY) % M] = make_float4(a.x, a.y, b.x, b.y);
             }
         }
         return;
@@ -1260,19 +1265,20 @@ __global__ __launch_bounds__(NT, kWavesXZ) void k_z_pair_pipe(const float2* __re
     constexpr int TOPS = seg_below(LZ2, LZ2), TOPR = LZ2 - TOPS;
     constexpr bool TOPREG = TOPON && (1 << TOPS) == P && (1 << TOPR) == NPA;
     const int Hx = d.hx, M = d.ny, ytiles = M / TL;
+    const size_t ZR = (size_t)(M + d.zpad);  // float4 per row (xk, z) of the paired layout
     struct FView { int row, slot, z0; size_t off; };
     auto f_view = [&]() {
         const int tid = launder(threadIdx.x);
         const int z0 = tid / TL, jq = tid - z0 * TL;  // float4 jq of the segment: lines 2 jq, 2 jq + 1 (rows TL.. = B side)
-        return FView{(2 * jq) * pitch, phys(z0) ^ rmask(2 * jq, hp), z0, (size_t)z0 * M + jq};
+        return FView{(2 * jq) * pitch, phys(z0) ^ rmask(2 * jq, hp), z0, (size_t)z0 * ZR + jq};
     };
     float4 pre[NPA];
     auto load_S = [&](int t) {
         const int plane = t / ytiles, ty = t - plane * ytiles;
         const FView fv = f_view();
-        const float4* sp = reinterpret_cast<const float4*>(S) + (size_t)plane * L * M + (size_t)ty * TL + fv.off;
+        const float4* sp = reinterpret_cast<const float4*>(S) + (size_t)plane * L * ZR + (size_t)ty * TL + fv.off;
 #pragma unroll
-        for (int k = 0; k < NPA; ++k) pre[k] = (fv.z0 + k * P < d.z_in_hi) ? sp[(size_t)(k * P) * M] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        for (int k = 0; k < NPA; ++k) pre[k] = (fv.z0 + k * P < d.z_in_hi) ? sp[(size_t)(k * P) * ZR] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     };
     using TW = TwLds<LZ2, R3>;
     float2* twl = tile + 2 * TL * pitch;
@@ -1386,7 +1392,7 @@ __global__ __launch_bounds__(NT, kWavesXZ) void k_z_pair_pipe(const float2* __re
         lds_barrier();
         {
             const FView fv = f_view();
-            float4* dp = reinterpret_cast<float4*>(T) + (size_t)plane * L * M + (size_t)(py0 / TL) * TL + fv.off;
+            float4* dp = reinterpret_cast<float4*>(T) + (size_t)plane * L * ZR + (size_t)(py0 / TL) * TL + fv.off;
 #pragma unroll
             for (int k = 0; k < NPA; ++k) {
                 const int zk = fv.z0 + k * P;
@@ -1394,7 +1400,7 @@ __global__ __launch_bounds__(NT, kWavesXZ) void k_z_pair_pipe(const float2* __re
                 if (zk >= d.z_out_lo && zk < d.z_out_hi) {
                     const int c = fv.row + (fv.slot ^ swz_c(k * P));
                     const float2 a0 = tile[c], a1 = tile[c + pitch];
-                    dp[(size_t)(k * P) * M] = make_float4(a0.x, a0.y, a1.x, a1.y);
+                    dp[(size_t)(k * P) * ZR] = make_float4(a0.x, a0.y, a1.x, a1.y);
                 }
                 }
             }
@@ -1411,7 +1417,7 @@ __global__ __launch_bounds__(NT, kWavesXZ) void k_z_pair_pipe(const float2* __re
 #pragma unroll
                 for (int k = 0; k < NPA; ++k) {
                     const int zk = fv.z0 + k * P;
-                    if (zk >= d.z_out_lo && zk < d.z_out_hi) dp[(size_t)(k * P) * M] = make_float4(v[k].x, v[k].y, u[k].x, u[k].y);
+                    if (zk >= d.z_out_lo && zk < d.z_out_hi) dp[(size_t)(k * P) * ZR] = make_float4(v[k].x, v[k].y, u[k].x, u[k].y);
                 }
             }
         }
@@ -1430,8 +1436,8 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_x_inverse(const float2
     const int TY = d.ty, hp = TY / 2, pitch = row_pitch(Hx);
     const int ytiles = d.ny / TY;
     const int z = blockIdx.x / ytiles, y0 = (blockIdx.x % ytiles) * TY;
-    const float4* src = reinterpret_cast<const float4*>(T + ((size_t)z * Hx) * d.ny + y0);
-    const int rowq = d.ny / 2;
+    const float4* src = reinterpret_cast<const float4*>(T + ((size_t)z * Hx) * d.xrow + y0);
+    const int rowq = d.xrow / 2;
     int oz = z;
     if (pw.on) {
         // rows outside the cropped result are never stored: a tile without any is skipped (fused: its part of the next
@@ -1441,7 +1447,7 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_x_inverse(const float2
         for (int r = 0; r < TY; ++r) live = live || pad_dst(pw, 1, y0 + r) >= 0;
         if (oz < 0 || !live) {
             if (FUSE && z < d.z_in_hi) {  // planes beyond are never read by the next y pass
-                float4* sdst = reinterpret_cast<float4*>(S_next + ((size_t)z * Hx) * d.ny + y0);
+                float4* sdst = reinterpret_cast<float4*>(S_next + ((size_t)z * Hx) * d.xrow + y0);
                 for (int i = threadIdx.x; i < hp * Hx; i += kThreadsXZ) {
                     const int px = i / hp, rp = i - px * hp;
                     sdst[(size_t)px * rowq + rp] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -1548,7 +1554,7 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_x_inverse(const float2
             lds_fft<LHX2, false, kThreadsXZ, R3>(tile, TY * R3, pitch, hp, priv, twl);
         }
         if (priv) lds_barrier();
-        float4* sdst = reinterpret_cast<float4*>(S_next + ((size_t)z * Hx) * d.ny + y0);
+        float4* sdst = reinterpret_cast<float4*>(S_next + ((size_t)z * Hx) * d.xrow + y0);
 #pragma unroll MI_FFT_UNROLL
         for (int i = threadIdx.x; i < hp * Hx; i += kThreadsXZ) {
             const int px = i / hp, rp = i - px * hp;
@@ -1578,7 +1584,7 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_x_fused_pipe(const flo
     // rows dealt to the waves: the inverse transform, the epilogue and the forward transform of a row all belong to its owner
     // and run without work-group barriers; only the transposed fill and drain are tile-wide
     constexpr bool PRIV = (TY % NW == 0) && (NQ % kThreadsXZ == 0) && (quads % 64 == 0);
-    const int ytiles = d.ny / TY, rowq = d.ny / 2;
+    const int ytiles = d.ny / TY, rowq = d.xrow / 2;
     // Lane constants of the two views (tile-invariant, a handful of registers).  The swizzle is XOR-linear, so the slot of
     // item j is the slot of item 0 XOR a compile-time constant: px0 < P and j * P (2 * lane < 128 and the multiples of 128 of
     // the row view) occupy disjoint bits.
@@ -1620,7 +1626,7 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_x_fused_pipe(const flo
         for (int u = blockIdx.x; u < d.z_in_hi * ytiles; u += gridDim.x) {  // every tile the next y pass reads ...
             const int z = u / ytiles, ty = u - z * ytiles;
             if (z < nzl && ty < nty) continue;                               // ... that the loop below does not produce
-            float4* sdst = reinterpret_cast<float4*>(S_next + ((size_t)z * Hx) * d.ny + ty * TY);
+            float4* sdst = reinterpret_cast<float4*>(S_next + ((size_t)z * Hx) * d.xrow + ty * TY);
             for (int i = threadIdx.x; i < hp * Hx; i += kThreadsXZ) {
                 const int px = i / hp, rp = i - px * hp;
                 sdst[(size_t)px * rowq + rp] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -1642,7 +1648,7 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_x_fused_pipe(const flo
         }
         y0 = ty * TY;
     };
-    auto tile_base = [&](int t) { int z, y0; tile_zy(t, z, y0); return ((size_t)z * Hx) * d.ny + y0; };
+    auto tile_base = [&](int t) { int z, y0; tile_zy(t, z, y0); return ((size_t)z * Hx) * d.xrow + y0; };
     auto load_T = [&](int t) {
         const TView tv = t_view();
         const float4* src = reinterpret_cast<const float4*>(T + tile_base(t)) + tv.off;
@@ -1858,9 +1864,24 @@ int NativeFft::init(hipStream_t s, const int F[3], bool explicit_adjoint) {
                   std::getenv("MI_FFT_NO_PIPE") == nullptr && std::getenv("MI_FFT_TL") == nullptr;
     n_cplx = (size_t)Hx * F[1] * F[2];
     // (the two planes that are their own mirror partners are stored twice in the paired layout)
-    const size_t n_buf = n_cplx + (dims.paired ? (size_t)2 * F[1] * F[2] : 0);
-    MI_TRY(S.alloc(sizeof(float2) * n_buf));
-    MI_TRY(T.alloc(sizeof(float2) * n_buf));
+    // Rows an exact power of two apart camp on few HBM channels: behind every row of the x side ([z][px][.]) and of the paired z
+    // side ([xk][z][.]) that is at least 8 KB long lie 4 KB + 128 B of padding.  C3 (profiles/zpad_probe.py): z pass 4.75 -> 4.2 ms
+    // with any odd multiple of 128 B behind the z rows (64-byte offsets break the 128-byte lines: 6.2 ms); with 4 KB + 128 B
+    // on both sides the y passes drop from 3.2-3.35 to 2.85-3.35 ms and the x pass from 5.1 / 6.0-7.2 to 4.75 / 5.7-6.8 ms.
+    const int pad_x = (size_t)F[1] * sizeof(float2) >= kPadRowBytes ? kRowPadBytes : 0;
+    const int pad_z = (size_t)F[1] * 2 * sizeof(float2) >= kPadRowBytes ? kRowPadBytes : 0;
+    dims.zpad = dims.paired ? pad_z / 16 : 0;
+    dims.xrow = F[1] + pad_x / 8;
+    if (const char* e = std::getenv("MI_FFT_ZPAD")) dims.zpad = dims.paired ? std::max(0, atoi(e)) : 0;   // float4 per row
+    if (const char* e = std::getenv("MI_FFT_XPAD")) dims.xrow = F[1] + 2 * std::max(0, atoi(e));          // float4 per row
+    const size_t n_x = (size_t)Hx * F[2] * dims.xrow;
+    const size_t n_buf = std::max(n_x, dims.paired ? (size_t)(Hx / 2 + 1) * F[2] * 2 * (size_t)(F[1] + dims.zpad) : n_cplx);
+    // one allocation for both arrays: their distance -- which decides how the strided streams of a pass that reads one and
+    // writes the other fall onto the HBM channels -- is then the same in every context instead of whatever the driver returns
+    size_t gap = kSpecGapBytes;
+    if (const char* e = std::getenv("MI_FFT_STGAP")) gap = (size_t)atoll(e) & ~(size_t)127;
+    MI_TRY(S.alloc(sizeof(float2) * 2 * n_buf + gap));
+    t_spec = S.as<float2>() + n_buf + gap / sizeof(float2);
     MI_TRY(G.alloc(sizeof(float4) * (size_t)(Hx / 2 + 1) * F[1] * F[2]));
     // twiddle tables exp(-2 pi i e / N) in double on the host, per axis: e < sub/2 for the power-of-two sub-transform
     // (sub = 2^l2), followed by the full circle e < n of the radix-3/9 stage when the axis has one
@@ -1970,7 +1991,7 @@ int NativeFft::y_pass(hipStream_t s, bool inverse, bool paired) {
     const size_t yl = lds_bytes(dims.tc, M);
     const NativeDims d = dims;
     const float2* src = S.as<float2>();
-    float2* dst = T.as<float2>();
+    float2* dst = t_spec;
     const float2* twy = tw_y;
     int rc = MI_ERR_INVALID;
 #define MI_Y(LG, R)                                                                                                            \
@@ -1992,7 +2013,7 @@ int NativeFft::z_conv(hipStream_t s, bool conj_otf) {
     const unsigned ztiles = (unsigned)((size_t)(Hx / 2 + 1) * (M / dims.tl));
     const size_t zl = lds_bytes(2 * dims.tl, L);
     const NativeDims d = dims;
-    const float2* Tp = T.as<float2>();
+    const float2* Tp = t_spec;
     float2* Sp = S.as<float2>();
     const bool adj_slot = conj_otf && have_adj;
     const float4* Gp = adj_slot ? G_adj.as<float4>() : G.as<float4>();
@@ -2145,7 +2166,7 @@ int NativeFft::spectrum(hipStream_t s, const float* vol, float4* Gp, float scale
     const unsigned ztiles = (unsigned)((size_t)(Hx / 2 + 1) * (M / dims.tl));
     const size_t zl = lds_bytes(2 * dims.tl, L);
     const NativeDims d = dims;
-    const float2* Tp = T.as<float2>();
+    const float2* Tp = t_spec;
     float2* Sp = S.as<float2>();
     const float2* twz = tw_z;
     int rc = MI_ERR_INVALID;
@@ -2171,7 +2192,7 @@ int NativeFft::x_inverse(hipStream_t s, float* out, int epi_kind, const ConvEpil
     const unsigned xtiles = (unsigned)((size_t)L * (M / dims.ty));
     const size_t xl = lds_bytes(dims.ty, Hx);
     const NativeDims d = dims;
-    const float2* Tp = T.as<float2>();
+    const float2* Tp = t_spec;
     float2* Sp = S.as<float2>();
     const float2* twx = tw_x;
     const int ek = epi_kind == EPI_TAPER_SHELL ? EPI_NONE : epi_kind;
@@ -2221,7 +2242,7 @@ int NativeFft::spectrum_rows(hipStream_t s, int y0, int rows, float2* buf, int d
     const size_t lines = (size_t)dims.nz * dims.hx, total = lines * (size_t)rows;
     size_t blocks = (total + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(k_spectrum_rows, dim3((unsigned)blocks), dim3(256), 0, s, S.as<float2>(), buf, lines, dims.ny, y0, rows, dir);
+    hipLaunchKernelGGL(k_spectrum_rows, dim3((unsigned)blocks), dim3(256), 0, s, S.as<float2>(), buf, lines, dims.xrow, y0, rows, dir);
     return launch_check("k_spectrum_rows");
 }
 
