@@ -238,7 +238,7 @@ __host__ __device__ constexpr int axis_tw_entries(int n) {
 }
 constexpr int kLdsOneWg = 156 * 1024;  // one work-group per CU (160 KB LDS)
 constexpr int kLdsTwoWg = 78 * 1024;   // two work-groups per CU
-constexpr size_t kSpecGapBytes = 0;    // bytes between the end of S and the start of T (NativeFft::init)
+constexpr size_t kSpecGapBytes = 4224;  // bytes between the end of S and the start of T (NativeFft::init)
 constexpr int kRowPadBytes = 4224;     // padding behind the rows of the spectrum arrays ...
 constexpr size_t kPadRowBytes = 8192;  // ... that are at least this long (NativeFft::init)
 constexpr int kPairLines = 8;          // lines per block of the pair-interleaved z-side layout (8 A + 8 B lines = 128 bytes)
@@ -1878,6 +1878,8 @@ int NativeFft::init(hipStream_t s, const int F[3], bool explicit_adjoint) {
     const size_t n_buf = std::max(n_x, dims.paired ? (size_t)(Hx / 2 + 1) * F[2] * 2 * (size_t)(F[1] + dims.zpad) : n_cplx);
     // one allocation for both arrays: their distance -- which decides how the strided streams of a pass that reads one and
     // writes the other fall onto the HBM channels -- is then the same in every context instead of whatever the driver returns
+    // (measuring the passes for six distances at plan time did not pay: in a process where the y passes run in their slow mode
+    // they do so for every distance tried)
     size_t gap = kSpecGapBytes;
     if (const char* e = std::getenv("MI_FFT_STGAP")) gap = (size_t)atoll(e) & ~(size_t)127;
     MI_TRY(S.alloc(sizeof(float2) * 2 * n_buf + gap));
