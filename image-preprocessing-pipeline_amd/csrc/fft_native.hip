@@ -233,6 +233,7 @@ struct TwLds {
 __host__ __device__ constexpr int axis_tw_entries(int n) {
     int r3 = 1, l2 = 0;
     while (n % 3 == 0) { n /= 3; r3 *= 3; }
+    while (n % 5 == 0) { n /= 5; r3 *= 5; }
     while ((1 << l2) < n) ++l2;
     return chain_entries(l2) + (r3 > 1 ? (1 << l2) : 0);
 }
@@ -459,6 +460,27 @@ __device__ __forceinline__ void dft3(float2& a, float2& b, float2& c) {
     c = csub(t2, t3);
 }
 
+// 5-point DFT in place (forward: exp(-2 pi i / 5); inverse: conjugate), in the usual sum / difference form
+template <bool INVERSE>
+__device__ __forceinline__ void dft5(float2 (&v)[5]) {
+    const float c1 = 0.30901699437494742f, c2 = -0.80901699437494742f;  // cos(2 pi / 5), cos(4 pi / 5)
+    const float s1 = 0.95105651629515357f, s2 = 0.58778525229247313f;   // sin(2 pi / 5), sin(4 pi / 5)
+    const float2 a1 = cadd(v[1], v[4]), a2 = cadd(v[2], v[3]), b1 = csub(v[1], v[4]), b2 = csub(v[2], v[3]);
+    const float2 x0 = v[0];
+    const float2 p1 = make_float2(x0.x + c1 * a1.x + c2 * a2.x, x0.y + c1 * a1.y + c2 * a2.y);
+    const float2 p2 = make_float2(x0.x + c2 * a1.x + c1 * a2.x, x0.y + c2 * a1.y + c1 * a2.y);
+    const float2 q1 = make_float2(s1 * b1.x + s2 * b2.x, s1 * b1.y + s2 * b2.y);
+    const float2 q2 = make_float2(s2 * b1.x - s1 * b2.x, s2 * b1.y - s1 * b2.y);
+    // forward: X[k] = p -+ i q ... with -i q = (q.y, -q.x); inverse: +i q = (-q.y, q.x)
+    const float2 iq1 = INVERSE ? make_float2(-q1.y, q1.x) : make_float2(q1.y, -q1.x);
+    const float2 iq2 = INVERSE ? make_float2(-q2.y, q2.x) : make_float2(q2.y, -q2.x);
+    v[0] = cadd(x0, cadd(a1, a2));
+    v[1] = cadd(p1, iq1);
+    v[4] = csub(p1, iq1);
+    v[2] = cadd(p2, iq2);
+    v[3] = csub(p2, iq2);
+}
+
 // radix-R3 stage of the y transform on `cols` LDS rows of length M = R3 * Msub: forward = DIF first stage
 // (DFT over n1 of x[n1 * Msub + n2], times W_M^(n2 k1), stored at k1 * Msub + n2); inverse = its exact reverse.
 // tw3[n2] = exp(-2 pi i n2 / M), n2 < Msub (LDS); the twiddles W_M^(n2 q), q < R3, are its powers.
@@ -489,6 +511,8 @@ __device__ __forceinline__ void radix3_stage(float2* tile, int cols, int pitch, 
         }
         if constexpr (R3 == 3) {
             dft3<INVERSE>(v[0], v[1], v[2]);
+        } else if constexpr (R3 == 5) {
+            dft5<INVERSE>(v);
         } else {  // 9 = 3 x 3: index n = 3 n1 + n2' , k = k1' + 3 k2'
             // DIF order for the forward transform, reversed for the inverse (which takes k-ordered input)
             if constexpr (!INVERSE) {
@@ -1794,13 +1818,13 @@ int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 // An axis length n = r3 * 2^l2 with r3 in {1, 3, 9}: powers of two from 8 to 4096, or 3 * / 9 * (32 .. 512).  (A radix-3/9
 // factor matters most on y, the axis the slab driver shards, where slab + halos is rarely a power of two; on x and z it
 // keeps zero-padded deconFFT shapes close to the 7-smooth ones.)
-static bool split_axis(int n, int* r3, int* l2) {
-    for (int r : {1, 3, 9}) {
-        if (n % r) continue;
+static bool split_axis(int n, int* r3, int* l2, bool five = false) {
+    for (int r : {1, 3, 5, 9}) {
+        if (n % r || (r == 5 && !five)) continue;
         const int m = n / r;
         if (!is_pow2(m)) continue;
         const int l = ilog2(m);
-        if (r == 1 ? (l >= 3 && l <= 12) : (l >= 5 && l <= 9)) { *r3 = r; *l2 = l; return true; }
+        if (r == 1 ? (l >= 3 && l <= 12) : (l >= 5 && l <= (r == 5 ? 8 : 9))) { *r3 = r; *l2 = l; return true; }
     }
     return false;
 }
@@ -1810,7 +1834,7 @@ static const int kMaxZ = 2304;  // 2 * TL >= 4 rows of the z pass must fit the L
 bool NativeFft::supported(const int F[3]) {
     // x: real length 2 * Hx, the transform runs on Hx complex points
     int r3, l2;
-    return F[0] % 2 == 0 && split_axis(F[0] / 2, &r3, &l2) && split_axis(F[1], &r3, &l2) && split_axis(F[2], &r3, &l2) && F[2] <= kMaxZ;
+    return F[0] % 2 == 0 && split_axis(F[0] / 2, &r3, &l2) && split_axis(F[1], &r3, &l2, true) && split_axis(F[2], &r3, &l2) && F[2] <= kMaxZ;
 }
 
 int NativeFft::good_size(int n, int axis) {
@@ -1820,7 +1844,7 @@ int NativeFft::good_size(int n, int axis) {
             if (split_axis(h, &r3, &l2)) return 2 * h;
     }
     for (int m = n < 8 ? 8 : n;; ++m)
-        if (split_axis(m, &r3, &l2)) return (axis == 2 && m > kMaxZ) ? 0 : m;
+        if (split_axis(m, &r3, &l2, axis == 1)) return (axis == 2 && m > kMaxZ) ? 0 : m;
 }
 
 // LDS of an axis kernel: the tile, then the twiddle tables (both chains and the radix-3/9 table: what the fused kernels of
@@ -1831,7 +1855,7 @@ int NativeFft::init(hipStream_t s, const int F[3], bool explicit_adjoint) {
     MI_REQUIRE(supported(F), "native FFT: unsupported shape %d x %d x %d", F[0], F[1], F[2]);
     const int Hx = F[0] / 2;
     split_axis(Hx, &dims.r3x, &dims.lhx2);
-    split_axis(F[1], &dims.r3, &dims.ly2);
+    split_axis(F[1], &dims.r3, &dims.ly2, true);  // (the y axis also takes 5 * 2^a: 320 rows of a slab rank instead of 384)
     split_axis(F[2], &dims.r3z, &dims.lz2);
     dims.hx = Hx;
     dims.ny = F[1];
@@ -1921,6 +1945,8 @@ int NativeFft::init(hipStream_t s, const int F[3], bool explicit_adjoint) {
 // key = l2 * 16 + r3
 #define MI_AXIS_CASES(M) M(3, 1) M(4, 1) M(5, 1) M(6, 1) M(7, 1) M(8, 1) M(9, 1) M(10, 1) M(11, 1) M(12, 1) \
     M(5, 3) M(6, 3) M(7, 3) M(8, 3) M(9, 3) M(5, 9) M(6, 9) M(7, 9) M(8, 9) M(9, 9)
+// y: also 5 * 2^a (only the y kernels are built for it)
+#define MI_Y_CASES(M) MI_AXIS_CASES(M) M(5, 5) M(6, 5) M(7, 5) M(8, 5)
 // z: lengths up to kMaxZ
 #define MI_Z_CASES(M) M(3, 1) M(4, 1) M(5, 1) M(6, 1) M(7, 1) M(8, 1) M(9, 1) M(10, 1) M(11, 1) \
     M(5, 3) M(6, 3) M(7, 3) M(8, 3) M(9, 3) M(5, 9) M(6, 9) M(7, 9) M(8, 9)
@@ -2005,7 +2031,7 @@ int NativeFft::y_pass(hipStream_t s, bool inverse, bool paired) {
             rc = inverse ? launch_lds(k_y_pass<LG, R, true>, ycols, kThreadsY, yl, s, "k_y_pass<inv>", src, dst, d, twy)        \
                          : launch_lds(k_y_pass<LG, R, false>, ycols, kThreadsY, yl, s, "k_y_pass<fwd>", src, dst, d, twy);      \
         break;
-    switch (dims.ly2 * 16 + dims.r3) { MI_AXIS_CASES(MI_Y) default: return fail(MI_ERR_UNSUPPORTED, "native FFT: y length %d", M); }
+    switch (dims.ly2 * 16 + dims.r3) { MI_Y_CASES(MI_Y) default: return fail(MI_ERR_UNSUPPORTED, "native FFT: y length %d", M); }
 #undef MI_Y
     return rc;
 }

@@ -103,7 +103,7 @@ class SlabRL:
         if self.world > 1 and any(b - a < self.h for a, b in slab_rows(gy, self.world)):
             raise ValueError(f"slab of {self.n_loc} rows is thinner than the halo ({self.h}); use fewer ranks")
         rows = self.n_loc + 2 * self.h
-        # local extent the FFT pipeline takes natively (2^a * {1,3,9}); the rows behind the upper halo stay zero
+        # local extent the FFT pipeline takes natively (2^a * {1,3,5,9} on this axis); the rows behind the upper halo stay zero
         self.rows = int(capi.lib().mi_fft_good_size(rows, 1)) if ops is None else rows
         bxz = BOUNDARY_CIRCULAR if flavour == "fft" else BOUNDARY_ZERO
         # y is "circular on the local extent": wrap-around only ever reaches halo / padding rows

@@ -234,7 +234,7 @@ int mi_decon_plan_destroy(mi_decon_plan* plan);
 int mi_engine_select(int nx, int ny, int nz, int kx, int ky, int kz, int boundary);
 
 /* smallest extent >= n that the hand-written FFT pipeline handles natively on `axis` (0 = x, 1 = y, 2 = z):
- * 2^a, 3 * 2^a or 9 * 2^a (x: twice such a number; z: at most 2304).  Returns 0 when there is none.  Other (7-smooth)
+ * 2^a, 3 * 2^a or 9 * 2^a (x: twice such a number; z: at most 2304; y also 5 * 2^a, a in 5..8).  Returns 0 when there is none.  Other (7-smooth)
  * shapes run through rocFFT; padded (zero / replicate boundary) convolutions pick such extents themselves. */
 int mi_fft_good_size(int n, int axis);
 /* next 7-smooth length >= n   [LsDeconv.m:405-419] */

@@ -15,6 +15,7 @@ pytestmark = pytest.mark.gpu
 SHAPES = [(8, 8, 16), (16, 32, 64), (32, 64, 128), (64, 16, 256), (8, 128, 32), (128, 8, 16), (16, 16, 1024),
           (8, 96, 32), (16, 288, 64), (8, 192, 16), (8, 576, 16), (16, 1152, 32),  # y = 3 * 2^a, 9 * 2^a: radix-3/9 stage
           (8, 16, 192), (16, 8, 576), (8, 32, 384), (8, 8, 1152),                  # x/2 = 3 * 2^a, 9 * 2^a
+          (8, 160, 16), (16, 320, 32), (8, 640, 16), (8, 1280, 16),                # y = 5 * 2^a (y only: the rows of a slab rank)
           (96, 16, 32), (288, 8, 16), (192, 16, 64), (576, 8, 16),                 # z = 3 * 2^a, 9 * 2^a
           (96, 96, 192), (288, 192, 576), (96, 288, 64)]                           # mixed
 
@@ -40,7 +41,8 @@ def test_circular_conv_native_vs_scipy_and_rocfft(dev, shape):
     assert _rel(got, ref) < 2e-5
 
 
-@pytest.mark.parametrize("shape", [(16, 32, 64), (32, 16, 128), (8, 64, 32), (8, 288, 32), (16, 96, 16), (96, 32, 192), (8, 96, 576)])
+@pytest.mark.parametrize("shape", [(16, 32, 64), (32, 16, 128), (8, 64, 32), (8, 288, 32), (16, 96, 16), (96, 32, 192), (8, 96, 576),
+                                   (16, 320, 32), (64, 160, 32)])
 @pytest.mark.parametrize("niter,lam,interval", [(4, 0.0, 0), (6, 0.05, 2), (7, 0.0, 3)])
 def test_decon_fft_native_matches_oracle(dev, shape, niter, lam, interval):
     from ipp_amd import decon

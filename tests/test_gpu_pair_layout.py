@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 # (z, y, x): z in 64..1024 (the paired z pass), y a multiple of 16 -- powers of two below and above the fast path of k_y_pair
 # (y >= 1024), 3 * 2^a and 9 * 2^a (generic path); x small
 SHAPES = [(64, 16, 32), (64, 96, 16), (128, 32, 64), (256, 64, 16), (512, 32, 16), (128, 288, 16), (64, 1024, 16), (64, 2048, 16),
-          (128, 4096, 16), (256, 1024, 16), (1024, 32, 16), (1024, 96, 32)]
+          (128, 4096, 16), (256, 1024, 16), (1024, 32, 16), (1024, 96, 32), (64, 160, 16), (128, 320, 32)]
 
 
 def _contexts(shape, psf, psf_inv, boundary, monkeypatch):
