@@ -82,17 +82,17 @@ def test_pair_enumeration_and_layers():
 
 
 def test_fft_good_size_per_axis():
-    """mi_fft_good_size: 2^a * {1,3,9} extents (x: twice such a number; z bounded by the LDS tile)."""
+    """mi_fft_good_size: 2^a * {1,3,9} extents (x: twice such a number; z bounded by the LDS tile; y also 5 * 2^a, a in 5..8)."""
     from ipp_amd import capi
     g = capi.lib().mi_fft_good_size
-    assert [g(n, 1) for n in (1, 8, 9, 33, 97, 130, 257, 289, 600, 1100)] == [8, 8, 16, 64, 128, 192, 288, 384, 768, 1152]
+    assert [g(n, 1) for n in (1, 8, 9, 33, 97, 130, 257, 289, 600, 1100, 1153)] == [8, 8, 16, 64, 128, 160, 288, 320, 640, 1152, 1280]
     assert [g(n, 0) for n in (10, 17, 70, 193, 200, 600, 2100)] == [16, 32, 128, 256, 256, 768, 2304]
     assert [g(n, 2) for n in (61, 100, 530, 2049, 2305)] == [64, 128, 576, 2304, 0]
     for axis in range(3):
         for n in range(1, 700, 7):
             m = g(n, axis)
             h = m // 2 if axis == 0 else m
-            assert m >= n and any(h % r == 0 and (h // r) & (h // r - 1) == 0 for r in (1, 3, 9))
+            assert m >= n and any(h % r == 0 and (h // r) & (h // r - 1) == 0 for r in ((1, 3, 5, 9) if axis == 1 else (1, 3, 9)))
 
 
 def _displ(coords, peaks, widths, inv=26, default=(0, 717, 0)):
