@@ -115,18 +115,28 @@ __global__ __launch_bounds__(256) void k_mips(const float* __restrict__ A, const
     float* xz = (second ? xz2 : xz1) + poff;
     (void)yz1; (void)yz2;  // written by k_mips_yz
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int j = blockIdx.x * 64 + lane;
+    // column blocks start on 256-byte boundaries of the TILE rows, not of the view (the first tile's view of a west-east pair
+    // starts at column 1741 of 2048: blocks laid out from there shared their first and last 128-byte lines with their neighbours,
+    // three lines fetched for two used); the first block is then the partial one
+    const int jshift = second ? 0 : (aj0 & 63);
+    const int j = (int)blockIdx.x * 64 + lane - jshift;
     const int i0 = blockIdx.y * MIP_ROWS;
     const int rows = min(MIP_ROWS, dimi_v - i0);
-    const bool live = j < dimj_v;
+    const bool live = j >= 0 && j < dimj_v;
     float best[MIP_ROWS];
 #pragma unroll
     for (int r = 0; r < MIP_ROWS; ++r) best[r] = 0.0f;
-    for (int k = wave; k < dimk; k += 4) {
+    // the wave's next slice is requested before the current one is reduced (32 instead of 16 loads per lane in flight: at 92
+    // registers only five waves fit a SIMD)
+    float v[MIP_ROWS], vn[MIP_ROWS];
+    auto load_slice = [&](int k, float (&dst)[MIP_ROWS]) {
         const float* p = vol + (size_t)k * slice + (size_t)i0 * pitch + j;
-        float v[MIP_ROWS];
 #pragma unroll
-        for (int r = 0; r < MIP_ROWS; ++r) v[r] = (live && r < rows) ? p[(size_t)r * pitch] : 0.0f;
+        for (int r = 0; r < MIP_ROWS; ++r) dst[r] = (live && r < rows) ? p[(size_t)r * pitch] : 0.0f;
+    };
+    if (wave < dimk) load_slice(wave, v);
+    for (int k = wave; k < dimk; k += 4) {
+        if (k + 4 < dimk) load_slice(k + 4, vn);
         float colmax = 0.0f;
 #pragma unroll
         for (int r = 0; r < MIP_ROWS; ++r) {
@@ -147,6 +157,8 @@ __global__ __launch_bounds__(256) void k_mips(const float* __restrict__ A, const
         // yz: the column maxima of this row band go to yz_tmp[tile][band][k][j] (unit-stride stores); k_mips_yz takes the
         // maximum over the bands -- 2.6 million atomics per pair on the yz MIPs cost more than the whole streaming pass
         if (live) yz_tmp[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * dimk + k) * dimj_v + j] = colmax;
+#pragma unroll
+        for (int r = 0; r < MIP_ROWS; ++r) v[r] = vn[r];
     }
     // xy: maximum over the four waves' slices
     if (wave > 0) {
@@ -191,12 +203,12 @@ __global__ __launch_bounds__(256) void k_mips_xz(const float* __restrict__ xz_tm
 // the six MIPs of `np` pairs (np == 1 and tab == nullptr: the pair A, B): k_mips + the reductions of its partial maxima.
 // `tmp` must hold mips_tmp_floats(...) floats per pair.
 inline size_t mips_tmp_floats(int dimk, int dimi_v, int dimj_v) {
-    const size_t bands = (dimi_v + MIP_ROWS - 1) / MIP_ROWS, cblocks = (dimj_v + 63) / 64;
+    const size_t bands = (dimi_v + MIP_ROWS - 1) / MIP_ROWS, cblocks = (dimj_v + 63) / 64 + 1;  // (+1: launch_mips aligns the blocks to the tile rows)
     return 2 * (bands * dimk * dimj_v + cblocks * (size_t)dimi_v * dimk);
 }
 int launch_mips(hipStream_t s, const float* A, const float* B, const float* const* tab, int np, size_t pstride, int dimk, int dimi_v, int dimj_v,
                 size_t slice, int pitch, int ai0, int aj0, float* xy1, float* xz1, float* yz1, float* xy2, float* xz2, float* yz2, float* tmp) {
-    const int bands = (dimi_v + MIP_ROWS - 1) / MIP_ROWS, cblocks = (dimj_v + 63) / 64;
+    const int bands = (dimi_v + MIP_ROWS - 1) / MIP_ROWS, cblocks = (dimj_v + (aj0 & 63) + 63) / 64;  // (see k_mips: aligned column blocks)
     float* yz_tmp = tmp;
     float* xz_tmp = tmp + 2 * (size_t)np * bands * dimk * dimj_v;
     const size_t lds = sizeof(float) * MIP_ROWS * (size_t)dimk;

@@ -68,6 +68,74 @@ void run(const char* what, float4* a, float4* b, float4* g, float* sink, size_t 
     fflush(stdout);
 }
 
+// read-only stream (what a reduction like the MIP pass of the NCC path can reach): UNR float4 per lane in flight
+template <int UNR>
+__global__ __launch_bounds__(256) void k_read(const float4* __restrict__ src, size_t n4, float* sink) {
+    float acc = 0.0f;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i + (UNR - 1) * stride < n4; i += UNR * stride) {
+        float4 v[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) v[u] = src[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) acc = fmaxf(acc, fmaxf(fmaxf(v[u].x, v[u].y), fmaxf(v[u].z, v[u].w)));
+    }
+    if (acc == 1.2345f) *sink = acc;
+}
+
+// the same with 4-byte loads (one float per lane and instruction, as a kernel that keeps a column per lane does)
+template <int UNR>
+__global__ __launch_bounds__(256) void k_read32(const float* __restrict__ src, size_t n, float* sink) {
+    float acc = 0.0f;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i + (UNR - 1) * stride < n; i += UNR * stride) {
+        float v[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) v[u] = src[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) acc = fmaxf(acc, v[u]);
+    }
+    if (acc == 1.2345f) *sink = acc;
+}
+
+template <int UNR>
+void run_read32(const float4* a, size_t bytes, int grid, float* sink) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    float best = 1e9f;
+    for (int rep = 0; rep < 4; ++rep) {
+        CK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL((k_read32<UNR>), dim3(grid), dim3(256), 0, 0, reinterpret_cast<const float*>(a), bytes / 4, sink);
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        if (rep > 0 && ms < best) best = ms;
+    }
+    printf("read only, %d floats (4-byte loads) per lane in flight, grid %5d: %6.3f ms  %5.2f TB/s\n", UNR, grid, best, (double)bytes / best / 1e9);
+    fflush(stdout);
+}
+
+template <int UNR>
+void run_read(const float4* a, size_t bytes, int grid, float* sink) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    float best = 1e9f;
+    for (int rep = 0; rep < 4; ++rep) {
+        CK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL((k_read<UNR>), dim3(grid), dim3(256), 0, 0, a, bytes / 16, sink);
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        if (rep > 0 && ms < best) best = ms;
+    }
+    printf("read only, %d float4 per lane in flight, grid %5d: %6.3f ms  %5.2f TB/s\n", UNR, grid, best, (double)bytes / best / 1e9);
+    fflush(stdout);
+}
+
 int main() {
     const size_t total = (size_t)1024 * 512 * 2048 * 8;  // the C3 spectrum: 8.6 GB
     float4 *a, *b, *g;
@@ -79,6 +147,16 @@ int main() {
     CK(hipMemset(a, 1, total));
     CK(hipMemset(b, 0, total));
     CK(hipMemset(g, 0, total / 2));
+    printf("-- read-only stream of 8.6 GB\n");
+    for (int grid : {8192, 32768, 131072}) {
+        run_read32<16>(a, total, grid, sink);
+        run_read32<32>(a, total, grid, sink);
+    }
+    for (int grid : {2048, 8192, 32768}) {
+        run_read<4>(a, total, grid, sink);
+        run_read<8>(a, total, grid, sink);
+        run_read<16>(a, total, grid, sink);
+    }
     for (int with_g = 0; with_g < 2; ++with_g) {
         printf(with_g ? "-- with the contiguous OTF stream (4.3 GB)\n" : "-- spectrum in + out only (17.2 GB)\n");
         for (int pad : {0, 128, 256, 512, 1024, 2048}) {
