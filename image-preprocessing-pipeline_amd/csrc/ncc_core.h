@@ -114,7 +114,8 @@ __global__ __launch_bounds__(256) void k_mips(const float* __restrict__ A, const
     float* xy = (second ? xy2 : xy1) + poff;
     float* xz = (second ? xz2 : xz1) + poff;
     (void)yz1; (void)yz2;  // written by k_mips_yz
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // (the wave index as a scalar: row addresses are then scalar bases + one per-lane offset instead of 16 address pairs)
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     // column blocks start on 256-byte boundaries of the TILE rows, not of the view (the first tile's view of a west-east pair
     // starts at column 1741 of 2048: blocks laid out from there shared their first and last 128-byte lines with their neighbours,
     // three lines fetched for two used); the first block is then the partial one
@@ -130,9 +131,9 @@ __global__ __launch_bounds__(256) void k_mips(const float* __restrict__ A, const
     // registers only five waves fit a SIMD)
     float v[MIP_ROWS], vn[MIP_ROWS];
     auto load_slice = [&](int k, float (&dst)[MIP_ROWS]) {
-        const float* p = vol + (size_t)k * slice + (size_t)i0 * pitch + j;
+        const float* p = vol + (size_t)k * slice + (size_t)i0 * pitch;  // wave-uniform
 #pragma unroll
-        for (int r = 0; r < MIP_ROWS; ++r) dst[r] = (live && r < rows) ? p[(size_t)r * pitch] : 0.0f;
+        for (int r = 0; r < MIP_ROWS; ++r) dst[r] = (live && r < rows) ? (p + (size_t)r * pitch)[j] : 0.0f;
     };
     if (wave < dimk) load_slice(wave, v);
     for (int k = wave; k < dimk; k += 4) {
