@@ -43,11 +43,14 @@ __device__ __forceinline__ cplx csub(cplx a, cplx b) { return make_double2(a.x -
 struct FftPlan {
     int N, nstages;
     int radix[14];
+    int twoff[14];  // start of stage s in the per-stage twiddle table (see fft_tables)
 };
 
 // In-place decimation-in-frequency transform of x[0 .. N) in LDS.  Natural order in, digit-reversed order out: with position
 // digits d_1 d_2 ... (most significant first, radices r_1 r_2 ...) the frequency is k = d_1 + r_1 (d_2 + r_2 (...)).
-// tw[n] = exp(-2 pi i n / N).
+// tw: per-stage tables -- stage s (radix r, q = L / r butterflies per group) holds exp(-2 pi i m t (N / L) / N) at
+// twoff[s] + (m - 1) q + t, m = 1 .. r - 1: the look-ups of consecutive lanes are consecutive entries (from the one table
+// exp(-2 pi i n / N) the middle stages touched up to 64 cache lines per load instruction).
 __device__ __forceinline__ int pos_of_freq(int k, const FftPlan& pl) {
     int p = 0, rem = pl.N;
     for (int s = 0; s < pl.nstages; ++s) {
@@ -64,7 +67,8 @@ __device__ void fft_dif(cplx* __restrict__ x, const FftPlan& pl, const cplx* __r
     int L = N;
     constexpr int BF = 2;  // butterflies per thread and step: their LDS reads and table loads are issued before any store
     for (int st = 0; st < pl.nstages; ++st) {
-        const int r = pl.radix[st], q = L / r, tstep = N / L, nb = N / r;
+        const int r = pl.radix[st], q = L / r, nb = N / r;
+        const cplx* stw = tw + pl.twoff[st];
         for (int i0 = threadIdx.x; i0 < nb; i0 += BF * blockDim.x) {
             cplx a[BF][4], w[BF][3];
             cplx* ptr[BF];
@@ -79,9 +83,9 @@ __device__ void fft_dif(cplx* __restrict__ x, const FftPlan& pl, const cplx* __r
                     a[u][1] = ptr[u][q];
                     if (r > 2) a[u][2] = ptr[u][2 * q];
                     if (r > 3) a[u][3] = ptr[u][3 * q];
-                    w[u][0] = tw[t * tstep];
-                    if (r > 2) w[u][1] = tw[2 * t * tstep];
-                    if (r > 3) w[u][2] = tw[3 * t * tstep];
+                    w[u][0] = stw[t];
+                    if (r > 2) w[u][1] = stw[q + t];
+                    if (r > 3) w[u][2] = stw[2 * q + t];
                 }
             }
 #pragma unroll
@@ -490,6 +494,12 @@ FftPlan make_fft_plan(int need) {
     while (a >= 2) { pl.radix[pl.nstages++] = 4; a -= 2; }
     if (a == 1) pl.radix[pl.nstages++] = 2;
     for (int b = 0; b < best_b; ++b) pl.radix[pl.nstages++] = 3;
+    int off = 0, L = pl.N;
+    for (int st = 0; st < pl.nstages; ++st) {
+        pl.twoff[st] = off;
+        L /= pl.radix[st];           // q of the stage
+        off += (pl.radix[st] - 1) * L;
+    }
     return pl;
 }
 
@@ -575,10 +585,25 @@ int fft_tables(int dev, const FftPlan& pl, hipStream_t s, FftTables* out) {
         tabs[NK + sl] = host_pos_of_freq((int)((N - (size_t)order[sl].second) % N), pl);
         tabs[2 * NK + sl] = order[sl].second;
     }
+    // per-stage tables: copies of the entries above, so every twiddle keeps its value
+    std::vector<double> hs;
+    {
+        size_t L = N;
+        for (int st = 0; st < pl.nstages; ++st) {
+            const size_t r = (size_t)pl.radix[st], q = L / r, tstep = N / L;
+            for (size_t m = 1; m < r; ++m)
+                for (size_t t = 0; t < q; ++t) {
+                    const size_t n = m * t * tstep;  // < N
+                    hs.push_back(h[2 * n]);
+                    hs.push_back(h[2 * n + 1]);
+                }
+            L = q;
+        }
+    }
     void *d = nullptr, *di = nullptr;
-    MI_HIP(hipMalloc(&d, sizeof(double) * 2 * N));
+    MI_HIP(hipMalloc(&d, sizeof(double) * hs.size()));
     MI_HIP(hipMalloc(&di, sizeof(int) * 3 * NK));
-    MI_HIP(hipMemcpyAsync(d, h.data(), sizeof(double) * 2 * N, hipMemcpyHostToDevice, s));
+    MI_HIP(hipMemcpyAsync(d, hs.data(), sizeof(double) * hs.size(), hipMemcpyHostToDevice, s));
     MI_HIP(hipMemcpyAsync(di, tabs.data(), sizeof(int) * 3 * NK, hipMemcpyHostToDevice, s));
     MI_HIP(hipStreamSynchronize(s));
     const int* ti = static_cast<const int*>(di);
