@@ -92,10 +92,10 @@ def host_cores():
     return n
 
 
-def cpu_baseline(vshape, kshape, seconds_budget=20.0):
+def cpu_baseline(vshape, kshape, seconds_budget=15.0):
     """The oracle's deconFFT loop (oracle/rl_oracle.py:decon_fft_f32 -- scipy.fft, float32 / complex64, every host core)
     on a bounded sub-volume of the same workload: 1/8 of the volume (every extent halved) when one iteration fits the
-    budget, else 1/64 (every extent quartered) for as many iterations as fit."""
+    budget, else 1/64 (every extent quartered); as many iterations as fit the budget, at most 8."""
     import numpy as np
     from oracle import rl_oracle
     cores = host_cores()
@@ -115,7 +115,8 @@ def cpu_baseline(vshape, kshape, seconds_budget=20.0):
     t_probe = run(probe, 1)
     scale = float(np.prod(target)) / float(np.prod(probe))
     shape = target if t_probe * scale * 1.15 <= seconds_budget else probe
-    iters = 1 if shape == target else max(1, min(8, int(seconds_budget / max(t_probe, 1e-3))))
+    t_iter = t_probe * (scale * 1.15 if shape == target else 1.0)           # expected seconds per iteration of the sample
+    iters = max(1, min(8, int(seconds_budget / max(t_iter, 1e-3))))         # about 10-20 s of CPU work, at most 8 iterations
     dt = run(shape, iters)
     return {"value": float(np.prod(shape)) * iters / dt / 1e9, "unit": "Gvoxel*iter/s", "cores": cores, "kind": "port",
             "OMP_NUM_THREADS": os.environ.get("OMP_NUM_THREADS"),
