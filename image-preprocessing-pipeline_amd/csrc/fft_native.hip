@@ -1290,7 +1290,7 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_z_conv_pipe(const floa
 // The spectra around the z pass as [xk][z][ty][side][TL]: the TL A lines of a tile and, right behind them, their TL mirror
 // partners (in partner order), so that a tile of only TL = 8 line pairs still moves whole 128-byte segments and two 8-wave
 // work-groups with a 64-KB tile each share a CU: one transforms while the other waits for HBM.
-template <int LZ2, int R3, bool REALG, int NT, int TL, bool TOPON = true>
+template <int LZ2, int R3, bool REALG, int NT, int TL, bool PHL = true, bool TOPON = true>
 __global__ __launch_bounds__(NT, kWavesXZ) void k_z_pair_pipe(const float2* __restrict__ S, float2* __restrict__ T, const float4* __restrict__ G,
                                                               NativeDims d, const float2* __restrict__ tw, int conj_otf, int ntiles, RealOtf ro) {
     extern __shared__ __attribute__((aligned(16))) float2 tile[];
@@ -1299,13 +1299,13 @@ __global__ __launch_bounds__(NT, kWavesXZ) void k_z_pair_pipe(const float2* __re
     // else (1024-point lines: 16 waves on 16 rows) a wave owns ONE row, the point-wise step of line `wave % TL` is shared by the
     // owners of its two rows -- half of the positions each -- and sits between two work-group barriers
     constexpr bool WP = TL == NW;
-    static_assert((WP || (NW == 2 * TL && L % 128 == 0)) && L % 64 == 0 && R3 == 1, "one or two waves per line pair");
+    static_assert((WP || (NW == 2 * TL && L % 128 == 0)) && L % 64 == 0 && (TL * L) % NT == 0, "one or two waves per line pair");
     constexpr int NPA = TL * L / NT;  // float4 (two neighbouring lines at one z) per lane and tile
     constexpr int P = NT / TL;        // item k of a lane: position z0 + k * P
     constexpr int NPG = TL * L / NT;  // point-wise items (mirror pairs) per lane
     // the top super-stage of the chain (stages TOPS .. LZ2-1) works on elements z0 + k * 2^TOPS: exactly the items of a lane
     constexpr int TOPS = seg_below(LZ2, LZ2), TOPR = LZ2 - TOPS;
-    constexpr bool TOPREG = TOPON && (1 << TOPS) == P && (1 << TOPR) == NPA;
+    constexpr bool TOPREG = TOPON && R3 == 1 && (1 << TOPS) == P && (1 << TOPR) == NPA;
     const int Hx = d.hx, M = d.ny, ytiles = M / TL;
     const size_t ZR = (size_t)(M + d.zpad);  // float4 per row (xk, z) of the paired layout
     struct FView { int row, slot, z0; size_t off; };
@@ -1325,9 +1325,10 @@ __global__ __launch_bounds__(NT, kWavesXZ) void k_z_pair_pipe(const float2* __re
     using TW = TwLds<LZ2, R3>;
     float2* twl = tile + 2 * TL * pitch;
     TW::template fill<NT>(twl, tw);
-    // REALG: the z ramp by POSITION, behind the twiddle tables (stride-1 look-ups in the point-wise step)
+    // REALG: the z ramp by POSITION, behind the twiddle tables (stride-1 look-ups in the point-wise step; PHL = false when that
+    // table would cost the second work-group of the CU: the ramp then comes from global memory, by frequency)
     float2* phl = twl + TW::total;
-    if constexpr (REALG) {
+    if constexpr (REALG && PHL) {
         for (int p = threadIdx.x; p < L; p += NT) phl[p] = ro.ph_z[pos2freq(p, LZ2, R3)];
     }
     int t = blockIdx.x;
@@ -1362,7 +1363,7 @@ __global__ __launch_bounds__(NT, kWavesXZ) void k_z_pair_pipe(const float2* __re
         float4 gv[REALG ? 1 : NPG];
         float2 gr[REALG ? NPG : 1];
         float2 ph_xy = make_float2(1.0f, 0.0f);
-        {
+        auto load_G = [&]() {
             const int tid = launder(threadIdx.x);
             const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
             const int line = WP ? wv : wv % TL, p0 = WP ? 0 : (wv / TL) * (L / 2);
@@ -1375,8 +1376,14 @@ __global__ __launch_bounds__(NT, kWavesXZ) void k_z_pair_pipe(const float2* __re
                 if constexpr (REALG) gr[k] = ro.g[gl + 64 * k];
                 else gv[k] = G[gl + 64 * k];
             }
-        }
+        };
+        if (R3 != 9) load_G();  // (radix-9 lines: requested behind the 9-point stage, which needs the registers)
         lds_barrier();
+        if constexpr (R3 > 1) {
+            radix3_stage<R3, false, NT>(tile, 2 * TL, pitch, hp, true, 1 << LZ2, twl + TW::r3);
+            wave_lds_fence();
+        }
+        if (R3 == 9) load_G();
         lds_fft<LZ2, false, NT, R3, TOPREG ? TOPR : 0>(tile, 2 * TL * R3, pitch, hp, true, twl);
         if constexpr (!WP) lds_barrier();
         float sw, cw;
@@ -1395,10 +1402,15 @@ __global__ __launch_bounds__(NT, kWavesXZ) void k_z_pair_pipe(const float2* __re
 #pragma unroll
             for (int k = 0; k < NPG; ++k) {
                 const int hb = 64 * k + p0;  // the position bits above the lane's six
-                const int flo = (int)brev_n((unsigned)hb, LZ2);
-                const int mhi = flo ? (int)brev_n((unsigned)((1 << (LZ2 - 6)) - flo), LZ2) : 0;
                 const int cA = line * pitch + (pA ^ swz_c(hb));
-                const int cB = (TL + line) * pitch + (flo ? (pB1 ^ swz_c(mhi)) : pB0);
+                int cB;
+                if constexpr (R3 == 1) {
+                    const int flo = (int)brev_n((unsigned)hb, LZ2);
+                    const int mhi = flo ? (int)brev_n((unsigned)((1 << (LZ2 - 6)) - flo), LZ2) : 0;
+                    cB = (TL + line) * pitch + (flo ? (pB1 ^ swz_c(mhi)) : pB0);
+                } else {  // (3 * 2^a, 9 * 2^a: the mirror map is not XOR-linear)
+                    cB = (TL + line) * pitch + (phys(mirror_pos(lane + hb, L, LZ2, R3)) ^ rmask(TL + line, hp));
+                }
                 const float2 a = tile[cA];
                 const float2 bc = cconj(tile[cB]);
                 const float2 E = make_float2(0.5f * (a.x + bc.x), 0.5f * (a.y + bc.y));
@@ -1408,7 +1420,7 @@ __global__ __launch_bounds__(NT, kWavesXZ) void k_z_pair_pipe(const float2* __re
                 const float2 Xa = cadd(E, wO), Xb = csub(E, wO);
                 float2 Ya, Yb;
                 if constexpr (REALG) {
-                    float2 Pq = cmul(ph_xy, phl[lane + hb]);
+                    float2 Pq = cmul(ph_xy, PHL ? phl[lane + hb] : ro.ph_z[pos2freq(lane + hb, LZ2, R3)]);
                     if (conj_otf) Pq.y = -Pq.y;
                     const float2 XaP = cmul(Xa, Pq), XbP = cmul(Xb, Pq);
                     Ya = make_float2(XaP.x * gr[k].x, XaP.y * gr[k].x);
@@ -1427,10 +1439,15 @@ __global__ __launch_bounds__(NT, kWavesXZ) void k_z_pair_pipe(const float2* __re
             }
         }
         const int tn = t + gridDim.x;
-        if (tn < ntiles) load_S(tn);  // (requesting them right after the fill, a whole tile ahead, gains nothing: 4.72 vs 4.68 ms)
+        if (R3 != 9 && tn < ntiles) load_S(tn);  // (requesting them right after the fill, a whole tile ahead, gains nothing: 4.72 vs 4.68 ms)
         if constexpr (WP) wave_lds_fence();
         else lds_barrier();
         lds_fft<LZ2, true, NT, R3, 0, TOPREG ? TOPS : LZ2>(tile, 2 * TL * R3, pitch, hp, true, twl);
+        if constexpr (R3 > 1) {
+            radix3_stage<R3, true, NT>(tile, 2 * TL, pitch, hp, true, 1 << LZ2, twl + TW::r3);
+            wave_lds_fence();
+        }
+        if (R3 == 9 && tn < ntiles) load_S(tn);
         lds_barrier();
         {
             const FView fv = f_view();
@@ -1901,7 +1918,9 @@ int NativeFft::init(hipStream_t s, const int F[3], bool explicit_adjoint) {
                "native FFT: transform too long for LDS");
     // pair-interleaved z-side layout (k_y_pair / k_z_pair_pipe): z a power of two the paired z pass takes, whole blocks of
     // kPairLines lines, an even number of columns per y tile; MI_FFT_NO_PAIR=1 keeps the plain layout (A/B measurements)
-    dims.paired = dims.r3z == 1 && dims.lz2 >= 6 && dims.lz2 <= 10 && F[1] % (2 * kPairLines) == 0 && dims.tc >= 2 && dims.tc % 2 == 0 &&
+    const bool z_pairs = dims.r3z == 1 ? (dims.lz2 >= 6 && dims.lz2 <= 10)
+                         : dims.r3z == 3 ? (dims.lz2 >= 6 && dims.lz2 <= 8) : (dims.r3z == 9 && dims.lz2 >= 6 && dims.lz2 <= 7);
+    dims.paired = z_pairs && F[1] % (2 * kPairLines) == 0 && dims.tc >= 2 && dims.tc % 2 == 0 &&
                   F[2] % (dims.tc / 2) == 0 && dims.dbg == 0 && std::getenv("MI_FFT_NO_PAIR") == nullptr &&
                   std::getenv("MI_FFT_NO_PIPE") == nullptr && std::getenv("MI_FFT_TL") == nullptr;
     n_cplx = (size_t)Hx * F[1] * F[2];
@@ -2068,7 +2087,8 @@ int NativeFft::z_conv(hipStream_t s, bool conj_otf) {
     int rc = MI_ERR_INVALID;
     if (dims.paired) {
         const int ntiles = (Hx / 2 + 1) * (M / kPairLines);
-        const size_t lds = lds_bytes(2 * kPairLines, L) + (real_otf ? sizeof(float2) * (size_t)L : 0);
+        const bool phl = !(dims.lz2 == 6 && dims.r3z == 9);  // (576-point lines: the LDS phase table would cost the second work-group)
+        const size_t lds = lds_bytes(2 * kPairLines, L) + (real_otf && phl ? sizeof(float2) * (size_t)L : 0);
         const int per_cu = std::max(1, std::min(2, (int)(kLdsOneWg / lds)));  // 8 waves of 128 registers each: two fit a CU
         const unsigned grid = (unsigned)std::min(ntiles, per_cu * n_cu);
         RealOtf ro{};
@@ -2078,21 +2098,18 @@ int NativeFft::z_conv(hipStream_t s, bool conj_otf) {
             ro.ph_y = ro.ph_x + (Hx / 2 + 1);
             ro.ph_z = ro.ph_y + M;
         }
-#define MI_ZQ(LG)                                                                                                                        \
-    case LG:                                                                                                                             \
-        rc = real_otf ? launch_lds(k_z_pair_pipe<LG, 1, true, 64 * kPairLines, kPairLines>, grid, 64 * kPairLines, lds, s,               \
-                                   "k_z_pair_pipe<real OTF>", Tp, Sp, Gp, d, twz, cj, ntiles, ro)                                       \
-                      : launch_lds(k_z_pair_pipe<LG, 1, false, 64 * kPairLines, kPairLines>, grid, 64 * kPairLines, lds, s,              \
-                                   "k_z_pair_pipe", Tp, Sp, Gp, d, twz, cj, ntiles, ro);                                                \
+#define MI_ZQ(LG, R, NTH, PH)                                                                                                            \
+    case LG * 16 + R:                                                                                                                    \
+        rc = real_otf ? launch_lds(k_z_pair_pipe<LG, R, true, NTH, kPairLines, PH>, grid, NTH, lds, s, "k_z_pair_pipe<real OTF>", Tp, Sp, Gp, \
+                                   d, twz, cj, ntiles, ro)                                                                              \
+                      : launch_lds(k_z_pair_pipe<LG, R, false, NTH, kPairLines, PH>, grid, NTH, lds, s, "k_z_pair_pipe", Tp, Sp, Gp, d, \
+                                   twz, cj, ntiles, ro);                                                                                \
         break;
-        switch (dims.lz2) {
-            MI_ZQ(6) MI_ZQ(7) MI_ZQ(8) MI_ZQ(9)
-            case 10:  // 128-KB tile: one work-group of 16 waves per CU, one line per wave
-                rc = real_otf ? launch_lds(k_z_pair_pipe<10, 1, true, 128 * kPairLines, kPairLines>, grid, 128 * kPairLines, lds, s,
-                                           "k_z_pair_pipe<1024, real OTF>", Tp, Sp, Gp, d, twz, cj, ntiles, ro)
-                              : launch_lds(k_z_pair_pipe<10, 1, false, 128 * kPairLines, kPairLines>, grid, 128 * kPairLines, lds, s,
-                                           "k_z_pair_pipe<1024>", Tp, Sp, Gp, d, twz, cj, ntiles, ro);
-                break;
+        // (lines of up to 576 points: 8 waves on a 64-KB tile, two work-groups per CU; longer ones: 16 waves, one line per wave)
+        switch (dims.lz2 * 16 + dims.r3z) {
+            MI_ZQ(6, 1, 512, true) MI_ZQ(7, 1, 512, true) MI_ZQ(8, 1, 512, true) MI_ZQ(9, 1, 512, true) MI_ZQ(10, 1, 1024, true)
+            MI_ZQ(6, 3, 512, true) MI_ZQ(7, 3, 512, true) MI_ZQ(8, 3, 1024, true)
+            MI_ZQ(6, 9, 512, false) MI_ZQ(7, 9, 1024, true)
             default: return fail(MI_ERR_UNSUPPORTED, "native FFT: paired z length %d", L);
         }
 #undef MI_ZQ

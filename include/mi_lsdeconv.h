@@ -121,7 +121,7 @@ int mi_rl_create_ex(int dev, void* stream, int nx, int ny, int nz, const float* 
  * MI_NO_SEPARABLE=1 disables the test. */
 int mi_rl_separable(const mi_rl_ctx* ctx);
 /* 1 when the FFT engine of the context keeps its spectra around the z pass in the pair-interleaved layout (every block of 8 lines
- * followed by its 8 mirror-partner lines; two 64-KB z tiles per CU): power-of-two z extents of 64..1024 on the hand-written
+ * followed by its 8 mirror-partner lines; two 64-KB z tiles per CU): z extents 2^a (64..1024), 3 * 2^a (192..768) or 9 * 2^a (576, 1152) on the hand-written
  * pipeline.  MI_FFT_NO_PAIR=1 keeps the plain layout [no reference counterpart: cuFFT owns its layouts]. */
 int mi_rl_pair_layout(const mi_rl_ctx* ctx);
 int mi_rl_destroy(mi_rl_ctx* ctx);

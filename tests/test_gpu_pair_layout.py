@@ -12,10 +12,11 @@ from tests.rl_util import assert_close, asymmetric_psf
 
 pytestmark = pytest.mark.gpu
 
-# (z, y, x): z in 64..1024 (the paired z pass), y a multiple of 16 -- powers of two below and above the fast path of k_y_pair
+# (z, y, x): z in 64..1152 (the paired z pass: 2^a, 3 * 2^a, 9 * 2^a), y a multiple of 16 -- powers of two below and above the fast path of k_y_pair
 # (y >= 1024), 3 * 2^a and 9 * 2^a (generic path); x small
 SHAPES = [(64, 16, 32), (64, 96, 16), (128, 32, 64), (256, 64, 16), (512, 32, 16), (128, 288, 16), (64, 1024, 16), (64, 2048, 16),
-          (128, 4096, 16), (256, 1024, 16), (1024, 32, 16), (1024, 96, 32), (64, 160, 16), (128, 320, 32)]
+          (128, 4096, 16), (256, 1024, 16), (1024, 32, 16), (1024, 96, 32), (64, 160, 16), (128, 320, 32),
+          (192, 32, 16), (384, 64, 16), (768, 32, 16), (576, 32, 16), (576, 96, 32), (1152, 16, 16)]   # z = 3 * 2^a, 9 * 2^a
 
 
 def _contexts(shape, psf, psf_inv, boundary, monkeypatch):
@@ -61,7 +62,7 @@ def test_paired_layout_equals_plain_layout_and_float64(dev, shape, symmetric, mo
     assert_close(adj_p, want_a, rel=2e-5, rel_l2=2e-6, pt_rel=2e-5)
 
 
-@pytest.mark.parametrize("shape", [(64, 32, 32), (128, 96, 16), (64, 1024, 16), (1024, 16, 32)])
+@pytest.mark.parametrize("shape", [(64, 32, 32), (128, 96, 16), (64, 1024, 16), (1024, 16, 32), (576, 32, 16), (384, 32, 32)])
 def test_paired_layout_fused_iterations_match_the_oracle(dev, shape, monkeypatch):
     from ipp_amd import capi
     psf = asymmetric_psf((5, 7, 5), seed=11)
