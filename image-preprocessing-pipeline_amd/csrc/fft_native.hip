@@ -1289,7 +1289,13 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_z_conv_pipe(const floa
 // ---------------------------------------------------------------------------------------------- P3, pair-interleaved layout
 // The spectra around the z pass as [xk][z][ty][side][TL]: the TL A lines of a tile and, right behind them, their TL mirror
 // partners (in partner order), so that a tile of only TL = 8 line pairs still moves whole 128-byte segments and two 8-wave
-// work-groups with a 64-KB tile each share a CU: one transforms while the other waits for HBM.
+// work-groups with a 64-KB tile each share a CU: one transforms while the other waits for HBM.  Replaces the same chain as
+// k_z_conv_pipe (decon.m:162-172: the z part of fftn, .* otf, the z part of ifftn); same OTF array, same point-wise step.
+//   NT = 512 (lines of up to 576 points): a wave owns one A line and its partner -- forward transform, point-wise step and
+//     inverse transform of the pair run inside the wave, the only work-group barriers surround the transposed fill and drain;
+//     for 2^a lines of 256 / 512 points the fill and the drain ARE the top super-stage (on the registers of the global access).
+//   NT = 1024 (768, 1024, 1152 points): a wave owns one line; the point-wise step sits between two barriers.
+//   Lines of 3 * 2^a / 9 * 2^a points carry the radix-3 / 9 stage in front (behind, inverse) of the power-of-two chain.
 template <int LZ2, int R3, bool REALG, int NT, int TL, bool PHL = true, bool TOPON = true>
 __global__ __launch_bounds__(NT, kWavesXZ) void k_z_pair_pipe(const float2* __restrict__ S, float2* __restrict__ T, const float4* __restrict__ G,
                                                               NativeDims d, const float2* __restrict__ tw, int conj_otf, int ntiles, RealOtf ro) {
