@@ -237,6 +237,9 @@ __host__ __device__ constexpr int axis_tw_entries(int n) {
     while ((1 << l2) < n) ++l2;
     return chain_entries(l2) + (r3 > 1 ? (1 << l2) : 0);
 }
+#ifndef MI_Y_TILE_CAP
+#define MI_Y_TILE_CAP 16
+#endif
 constexpr int kLdsOneWg = 156 * 1024;  // one work-group per CU (160 KB LDS)
 constexpr int kLdsTwoWg = 78 * 1024;   // two work-groups per CU
 constexpr size_t kSpecGapBytes = 4224;  // bytes between the end of S and the start of T (NativeFft::init)
@@ -256,7 +259,7 @@ __host__ __device__ constexpr int z_tile_lines(int nz) {
     return tl;
 }
 __host__ __device__ constexpr int y_tile_cols(int ny) {
-    int tc = 16;
+    int tc = MI_Y_TILE_CAP;
     while (tc > 1 && 8 * (tc * row_pitch(ny) + axis_tw_entries(ny)) > kLdsTwoWg) tc >>= 1;
     return tc;
 }
