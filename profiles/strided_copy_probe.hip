@@ -136,6 +136,49 @@ void run_read(const float4* a, size_t bytes, int grid, float* sink) {
     fflush(stdout);
 }
 
+// read-only, the shape of the MIP pass: a wave reads PIECE bytes of each of 16 rows (pitch 8 KB) of one slice (slices 16 MB apart,
+// 4 waves of a work-group on 4 slices, 8 slices per wave); work-groups tile the columns and the row bands of a 307-row strip
+template <int PIECE>
+__global__ __launch_bounds__(256) void k_read_rows(const float* __restrict__ src, int ncolblocks, int nbands, float* sink) {
+    constexpr int VEC = PIECE / 256;  // floats per lane
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tile = blockIdx.z, band = blockIdx.y, cb = blockIdx.x;
+    const float* base = src + (size_t)tile * (32u << 22) + (size_t)band * 16 * 2048 + (size_t)cb * (PIECE / 4) + lane * VEC;
+    float acc = 0.0f;
+    for (int k = wave; k < 32; k += 4) {
+        const float* p = base + (size_t)k * (1u << 22);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if constexpr (VEC == 1) acc = fmaxf(acc, p[r * 2048]);
+            else if constexpr (VEC == 2) { const float2 v = *reinterpret_cast<const float2*>(p + r * 2048); acc = fmaxf(acc, fmaxf(v.x, v.y)); }
+            else { const float4 v = *reinterpret_cast<const float4*>(p + r * 2048); acc = fmaxf(acc, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w))); }
+        }
+    }
+    if (acc == 1.2345f) *sink = acc;
+}
+
+template <int PIECE>
+void run_rows(const float4* a, float* sink) {
+    // 16 tiles of 2048 x 2048 x 32 floats (8.6 GB); the strip: 304 rows (19 bands) x all 2048 columns of every slice
+    const int ncb = 8192 / PIECE, nbands = 19, ntiles = 16;
+    const double bytes = (double)ntiles * 32 * nbands * 16 * 8192;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    float best = 1e9f;
+    for (int rep = 0; rep < 4; ++rep) {
+        CK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL((k_read_rows<PIECE>), dim3(ncb, nbands, ntiles), dim3(256), 0, 0, reinterpret_cast<const float*>(a), ncb, nbands, sink);
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        if (rep > 0 && ms < best) best = ms;
+    }
+    printf("MIP-shaped read, %4d-byte pieces per row and wave: %6.3f ms  %5.2f TB/s\n", PIECE, best, bytes / best / 1e9);
+    fflush(stdout);
+}
+
 int main() {
     const size_t total = (size_t)1024 * 512 * 2048 * 8;  // the C3 spectrum: 8.6 GB
     float4 *a, *b, *g;
@@ -147,6 +190,10 @@ int main() {
     CK(hipMemset(a, 1, total));
     CK(hipMemset(b, 0, total));
     CK(hipMemset(g, 0, total / 2));
+    printf("-- MIP-shaped read-only pass (N-S strips of 16 tiles)\n");
+    run_rows<256>(a, sink);
+    run_rows<512>(a, sink);
+    run_rows<1024>(a, sink);
     printf("-- read-only stream of 8.6 GB\n");
     for (int grid : {8192, 32768, 131072}) {
         run_read32<16>(a, total, grid, sink);
