@@ -69,7 +69,8 @@ def pmc_traffic(pass_name, workload):
     if kern is None:
         return None
     # (the pair-interleaved layout runs k_y_pair / k_z_pair_pipe, the plain one k_y_pass / k_z_conv_pipe)
-    want = {"z_conv": (("k_z_pair_pipe<", ">"), ("k_z_conv_pipe<", ">")), "x_fused": (("k_x_fused_pipe<", ">"),),
+    # (k_x_fused_pipe<.., 0> is the fused pass; modes 1 / 2 are the forward-only / inverse-only launches around a chain)
+    want = {"z_conv": (("k_z_pair_pipe<", ">"), ("k_z_conv_pipe<", ">")), "x_fused": (("k_x_fused_pipe<", ", 0>"), ("k_x_fused_pipe<", ">")),
             "y_forward": (("k_y_pair<", "false>"), ("k_y_pass<", "false>")),
             "y_inverse": (("k_y_pair<", "true>"), ("k_y_pass<", "true>"))}[pass_name]
     for pre, post in want:

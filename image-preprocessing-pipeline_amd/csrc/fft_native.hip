@@ -1638,7 +1638,10 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_x_inverse(const float2
 // the epilogue operand of the current tile is requested before the inverse transform and the next tile's spectrum before the
 // forward transform, both into registers (8 float4 each for a 16 x 1024 tile); stores drain behind.
 // Unpadded volumes only (the padded mode keeps k_x_inverse).
-template <int LHX2, int R3>
+// MODE 0: the fused pass.  MODE 1: forward only -- the rows of the real volume `e.a` are transformed into S_next (k_x_forward as a
+// persistent kernel: the next tile's rows travel during the transform and the store of the current one).  MODE 2: inverse only --
+// T -> epilogue (none / ratio / update) -> out, nothing is transformed forward (k_x_inverse without the regularised epilogues).
+template <int LHX2, int R3, int MODE = 0>
 __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_x_fused_pipe(const float2* __restrict__ T, float* __restrict__ out, ConvEpilogue e, NativeDims d,
                                                             const float2* __restrict__ tw, float2* __restrict__ S_next, int EPI, int ntiles,
                                                             TileSelect sel, PadWindow pw) {
@@ -1727,10 +1730,27 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_x_fused_pipe(const flo
     using TW = TwLds<LHX2, R3>;
     float2* twl = tile + TY * pitch;
     TW::template fill<kThreadsXZ>(twl, tw);
+    // MODE 1: the rows of a tile in the row view (float4 j of a lane as in r_item), requested one tile ahead into `pre`
+    auto load_rows = [&](int t) {
+        int z, y0;
+        tile_zy(t, z, y0);
+        const float4* src4 = reinterpret_cast<const float4*>(e.a) + ((size_t)z * d.ny + y0) * (size_t)quads;
+        const RView rv = r_view();
+#pragma unroll
+        for (int j = 0; j < NPF; ++j) {
+            int i, c, r, q;
+            r_item(rv, j, i, c, r, q);
+            if (NQ % kThreadsXZ == 0 || i < NQ) pre[j] = src4[i];
+        }
+    };
     int t = blockIdx.x;
-    if (t < ntiles) load_T(t);
+    if (t < ntiles) {
+        if constexpr (MODE == 1) load_rows(t);
+        else load_T(t);
+    }
+    if constexpr (MODE == 1) lds_barrier();  // the tables (the other modes meet a barrier before their first transform)
     for (; t < ntiles; t += gridDim.x) {
-        {
+        if constexpr (MODE != 1) {
             const TView tv = t_view();
 #pragma unroll
             for (int j = 0; j < NPF; ++j) {
@@ -1758,12 +1778,18 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_x_fused_pipe(const flo
                     int i, c, r, q;
                     r_item(rv, j, i, c, r, q);
                     if (NQ % kThreadsXZ == 0 || i < NQ) {
-                        const bool live = r < rows_live && q < data_quads;
+                        const bool live = r < rows_live && q < data_quads && !(MODE == 2 && EPI == EPI_NONE);  // (no operand then)
                         av[j] = live ? a4[g_index(i, r, q)] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                     }
                 }
             }
         };
+        if constexpr (MODE == 1) {
+#pragma unroll
+            for (int j = 0; j < NPF; ++j) av[j] = pre[j];
+            const int tnx = t + gridDim.x;
+            if (tnx < ntiles) load_rows(tnx);
+        } else {
         if (R3 != 9) load_a();  // (radix-9 rows: requested behind the 9-point stage, which needs the registers)
         lds_barrier();
         lds_fft<LHX2, true, kThreadsXZ, R3>(tile, TY * R3, pitch, hp, PRIV, twl);
@@ -1772,6 +1798,7 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_x_fused_pipe(const flo
             stage_sync(PRIV);
         }
         if (R3 == 9) load_a();
+        }
         float4* dst = reinterpret_cast<float4*>(out);
         const RView rv = r_view();
 #pragma unroll
@@ -1779,29 +1806,43 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_x_fused_pipe(const flo
             int i, s0, r, q;
             r_item(rv, j, i, s0, r, q);  // elements 2q and 2q + 1 are slot neighbours
             if (NQ % kThreadsXZ == 0 || i < NQ) {
-                const float2 c0 = tile[s0], c1 = tile[s0 ^ 1];
                 const float4 a = av[j];
+                if constexpr (MODE == 1) {  // the volume's rows, as they are
+                    tile[s0] = make_float2(a.x, a.y);
+                    tile[s0 ^ 1] = make_float2(a.z, a.w);
+                    continue;
+                }
+                const float2 c0 = tile[s0], c1 = tile[s0 ^ 1];
                 const bool live = r < rows_live && q < data_quads;
                 float4 o;
-                if (EPI == EPI_RATIO)
+                if (MODE == 2 && EPI == EPI_NONE)
+                    o = make_float4(c0.x, c0.y, c1.x, c1.y);
+                else if (EPI == EPI_RATIO)
                     o = make_float4(a.x * rcp_eps(c0.x), a.y * rcp_eps(c0.y), a.z * rcp_eps(c1.x), a.w * rcp_eps(c1.y));
                 else
                     o = make_float4(fabsf(a.x * c0.x), fabsf(a.y * c0.y), fabsf(a.z * c1.x), fabsf(a.w * c1.y));
                 if (!live) o = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // the zero padding of the next convolution's input
                 if (out != nullptr && live) dst[g_index(i, r, q)] = o;
-                tile[s0] = make_float2(o.x, o.y);
-                tile[s0 ^ 1] = make_float2(o.z, o.w);
+                if constexpr (MODE != 2) {
+                    tile[s0] = make_float2(o.x, o.y);
+                    tile[s0 ^ 1] = make_float2(o.z, o.w);
+                }
             }
         }
         // (radix-9 rows: the 9-point stage needs the registers, so the next tile is requested behind it)
         const int tn = t + gridDim.x;
-        if (R3 != 9 && tn < ntiles) load_T(tn);
+        if constexpr (MODE == 2) {  // nothing goes forward: the tile is free once everybody has read its rows
+            if (tn < ntiles) load_T(tn);
+            lds_barrier();
+            continue;
+        }
+        if (MODE == 0 && R3 != 9 && tn < ntiles) load_T(tn);
         stage_sync(PRIV);
         if constexpr (R3 > 1) {
             radix3_stage<R3, false, kThreadsXZ>(tile, TY, pitch, hp, PRIV, 1 << LHX2, twl + TW::r3);
             stage_sync(PRIV);
         }
-        if (R3 == 9 && tn < ntiles) load_T(tn);
+        if (MODE == 0 && R3 == 9 && tn < ntiles) load_T(tn);
         lds_fft<LHX2, false, kThreadsXZ, R3>(tile, TY * R3, pitch, hp, PRIV, twl);
         if (PRIV) lds_barrier();  // rows complete for everybody before the transposed drain
         const TView tv = t_view();
@@ -2047,6 +2088,18 @@ TileSelect NativeFft::edge_tiles(int mode, int a0, int a1, int b0, int b1) const
 int NativeFft::x_forward(hipStream_t s, const float* in) {
     const PadWindow pw = this->pw;
     const int Hx = dims.hx, M = dims.ny, L = dims.nz;
+    if (splits() && ((uintptr_t)in % 16) == 0 && std::getenv("MI_FFT_NO_XPIPE") == nullptr) {  // persistent kernel with prefetch (unpadded grids)
+        ConvEpilogue e;
+        e.a = in;
+        const int ntiles = L * (M / dims.ty);
+        const unsigned grid = (unsigned)std::min(ntiles, n_cu);
+        const NativeDims d = dims;
+        int rc = MI_ERR_INVALID;
+#define MI_XF(LG, R) case LG * 16 + R: rc = launch_lds(k_x_fused_pipe<LG, R, 1>, grid, kThreadsXZ, lds_bytes(dims.ty, Hx), s, "k_x_fused_pipe<forward>", (const float2*)nullptr, (float*)nullptr, e, d, tw_x, S.as<float2>(), (int)EPI_NONE, ntiles, TileSelect{}, pw); break;
+        switch (dims.lhx2 * 16 + dims.r3x) { MI_AXIS_CASES(MI_XF) default: return fail(MI_ERR_UNSUPPORTED, "native FFT: x length %d", 2 * Hx); }
+#undef MI_XF
+        return rc;
+    }
     const unsigned xtiles = (unsigned)((size_t)L * (M / dims.ty));
     const size_t xl = lds_bytes(dims.ty, Hx);
     const NativeDims d = dims;
@@ -2298,6 +2351,15 @@ int NativeFft::x_inverse(hipStream_t s, float* out, int epi_kind, const ConvEpil
         return rc;
     }
     MI_REQUIRE(!part || part->mode == 0, "native FFT: this kernel cannot run a subset of its tiles");
+    if (!fuse_forward && splits() && (ek == EPI_NONE || ek == EPI_RATIO || ek == EPI_UPDATE) && epi_kind != EPI_TAPER_SHELL && out != nullptr &&
+        ((uintptr_t)out % 16) == 0 && ((uintptr_t)epi.a % 16) == 0 && std::getenv("MI_FFT_NO_XPIPE") == nullptr) {
+        const int ntiles = L * (M / dims.ty);
+        const unsigned grid = (unsigned)std::min(ntiles, n_cu);
+#define MI_XO(LG, R) case LG * 16 + R: rc = launch_lds(k_x_fused_pipe<LG, R, 2>, grid, kThreadsXZ, xl, s, "k_x_fused_pipe<inverse>", Tp, out, epi, d, twx, (float2*)nullptr, ek, ntiles, TileSelect{}, w); break;
+        switch (dims.lhx2 * 16 + dims.r3x) { MI_AXIS_CASES(MI_XO) default: return fail(MI_ERR_UNSUPPORTED, "native FFT: x length %d", 2 * Hx); }
+#undef MI_XO
+        return rc;
+    }
 #define MI_XI(LG, R)                                                                                                               \
     case LG * 16 + R:                                                                                                              \
         rc = fuse_forward ? launch_lds(k_x_inverse<LG, R, true>, xtiles, kThreadsXZ, xl, s, "k_x_inverse<fused>", Tp, out, epi, d, twx, Sp, ek, w) \
