@@ -1692,7 +1692,7 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_x_fused_pipe(const flo
     // that is < ny, its quads q < nx / 4 hold data; everything else is padding (epilogue result 0).  Only the live tiles are
     // enumerated (mode 3); the tiles of live planes that lie entirely in the y padding are zero-filled first.
     const int data_quads = pw.on ? pw.n[0] / 4 : quads;
-    if (pw.on) {
+    if (pw.on && MODE != 2) {  // (the inverse-only mode writes no spectrum)
         const int nty = sel.n0, nzl = pw.n[2];
         for (int u = blockIdx.x; u < d.z_in_hi * ytiles; u += gridDim.x) {  // every tile the next y pass reads ...
             const int z = u / ytiles, ty = u - z * ytiles;
@@ -1734,13 +1734,19 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_x_fused_pipe(const flo
     auto load_rows = [&](int t) {
         int z, y0;
         tile_zy(t, z, y0);
-        const float4* src4 = reinterpret_cast<const float4*>(e.a) + ((size_t)z * d.ny + y0) * (size_t)quads;
+        // (padded grids: rows and quads beyond the caller's volume are zero, as in the epilogue below)
+        const size_t row0 = pw.on ? ((size_t)z * pw.n[1] + y0) * (size_t)data_quads : ((size_t)z * d.ny + y0) * (size_t)quads;
+        const int rows_live = pw.on ? pw.n[1] - y0 : TY;
+        const float4* src4 = reinterpret_cast<const float4*>(e.a);
         const RView rv = r_view();
 #pragma unroll
         for (int j = 0; j < NPF; ++j) {
             int i, c, r, q;
             r_item(rv, j, i, c, r, q);
-            if (NQ % kThreadsXZ == 0 || i < NQ) pre[j] = src4[i];
+            if (NQ % kThreadsXZ == 0 || i < NQ) {
+                const bool live = r < rows_live && q < data_quads;
+                pre[j] = live ? src4[pw.on ? row0 + (size_t)r * data_quads + q : row0 + i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
         }
     };
     int t = blockIdx.x;
@@ -2088,14 +2094,25 @@ TileSelect NativeFft::edge_tiles(int mode, int a0, int a1, int b0, int b1) const
 int NativeFft::x_forward(hipStream_t s, const float* in) {
     const PadWindow pw = this->pw;
     const int Hx = dims.hx, M = dims.ny, L = dims.nz;
-    if (splits() && ((uintptr_t)in % 16) == 0 && std::getenv("MI_FFT_NO_XPIPE") == nullptr) {  // persistent kernel with prefetch (unpadded grids)
+    // persistent kernel with prefetch: unpadded grids, and padded ones under the conditions of the fused pass (zero rule, data at
+    // the origin, whole float4 rows): only the tiles that hold rows of the volume are transformed, the others zero-filled
+    const bool pad_pipe = pw.on && can_fuse() && pipe_ok() && pw.o[0] == 0 && pw.o[1] == 0 && pw.o[2] == 0 && pw.n[0] % 4 == 0;
+    if ((splits() || pad_pipe) && ((uintptr_t)in % 16) == 0 && std::getenv("MI_FFT_NO_XPIPE") == nullptr) {
         ConvEpilogue e;
         e.a = in;
-        const int ntiles = L * (M / dims.ty);
+        TileSelect sel{};
+        int per = M / dims.ty, planes = L;
+        if (pad_pipe) {
+            sel.mode = 3;
+            sel.n0 = (pw.n[1] + dims.ty - 1) / dims.ty;
+            per = sel.n0;
+            planes = pw.n[2];
+        }
+        const int ntiles = planes * per;
         const unsigned grid = (unsigned)std::min(ntiles, n_cu);
         const NativeDims d = dims;
         int rc = MI_ERR_INVALID;
-#define MI_XF(LG, R) case LG * 16 + R: rc = launch_lds(k_x_fused_pipe<LG, R, 1>, grid, kThreadsXZ, lds_bytes(dims.ty, Hx), s, "k_x_fused_pipe<forward>", (const float2*)nullptr, (float*)nullptr, e, d, tw_x, S.as<float2>(), (int)EPI_NONE, ntiles, TileSelect{}, pw); break;
+#define MI_XF(LG, R) case LG * 16 + R: rc = launch_lds(k_x_fused_pipe<LG, R, 1>, grid, kThreadsXZ, lds_bytes(dims.ty, Hx), s, "k_x_fused_pipe<forward>", (const float2*)nullptr, (float*)nullptr, e, d, tw_x, S.as<float2>(), (int)EPI_NONE, ntiles, sel, pw); break;
         switch (dims.lhx2 * 16 + dims.r3x) { MI_AXIS_CASES(MI_XF) default: return fail(MI_ERR_UNSUPPORTED, "native FFT: x length %d", 2 * Hx); }
 #undef MI_XF
         return rc;
@@ -2351,11 +2368,20 @@ int NativeFft::x_inverse(hipStream_t s, float* out, int epi_kind, const ConvEpil
         return rc;
     }
     MI_REQUIRE(!part || part->mode == 0, "native FFT: this kernel cannot run a subset of its tiles");
-    if (!fuse_forward && splits() && (ek == EPI_NONE || ek == EPI_RATIO || ek == EPI_UPDATE) && epi_kind != EPI_TAPER_SHELL && out != nullptr &&
-        ((uintptr_t)out % 16) == 0 && ((uintptr_t)epi.a % 16) == 0 && std::getenv("MI_FFT_NO_XPIPE") == nullptr) {
-        const int ntiles = L * (M / dims.ty);
+    if (!fuse_forward && (splits() || pad_pipe) && (ek == EPI_NONE || ek == EPI_RATIO || ek == EPI_UPDATE) && epi_kind != EPI_TAPER_SHELL &&
+        out != nullptr && ((uintptr_t)out % 16) == 0 && ((uintptr_t)epi.a % 16) == 0 && std::getenv("MI_FFT_NO_XPIPE") == nullptr) {
+        TileSelect sel{};
+        int per = M / dims.ty, planes = L;
+        if (pad_pipe) {  // only the tiles that hold rows of the caller's volume
+            sel.mode = 3;
+            sel.n0 = (pw.n[1] + dims.ty - 1) / dims.ty;
+            per = sel.n0;
+            planes = pw.n[2];
+        }
+        const int ntiles = planes * per;
+        if (ntiles <= 0) return MI_OK;
         const unsigned grid = (unsigned)std::min(ntiles, n_cu);
-#define MI_XO(LG, R) case LG * 16 + R: rc = launch_lds(k_x_fused_pipe<LG, R, 2>, grid, kThreadsXZ, xl, s, "k_x_fused_pipe<inverse>", Tp, out, epi, d, twx, (float2*)nullptr, ek, ntiles, TileSelect{}, w); break;
+#define MI_XO(LG, R) case LG * 16 + R: rc = launch_lds(k_x_fused_pipe<LG, R, 2>, grid, kThreadsXZ, xl, s, "k_x_fused_pipe<inverse>", Tp, out, epi, d, twx, (float2*)nullptr, ek, ntiles, sel, w); break;
         switch (dims.lhx2 * 16 + dims.r3x) { MI_AXIS_CASES(MI_XO) default: return fail(MI_ERR_UNSUPPORTED, "native FFT: x length %d", 2 * Hx); }
 #undef MI_XO
         return rc;
