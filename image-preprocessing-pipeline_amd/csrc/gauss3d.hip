@@ -214,6 +214,10 @@ __global__ __launch_bounds__(GF_THREADS) void k_gauss3d_fused(const float* __res
     }
 }
 
+#ifndef MI_GAUSS_FUSED_LDS
+#define MI_GAUSS_FUSED_LDS (64 * 1024)
+#endif
+constexpr size_t kFusedLdsMax = MI_GAUSS_FUSED_LDS;
 size_t fused_lds_bytes(const int* k) {
     const int cq = (k[0] / 2 + 3) / 4, seg = 4 * (GF_TX / 4 + 2 * cq), rows_in = GF_TY + 2 * (k[1] / 2);
     return sizeof(float) * ((size_t)rows_in * seg + (size_t)rows_in * GF_TX + (size_t)k[2] * GF_TY * GF_TX);
@@ -236,7 +240,7 @@ int resolve_taps(const float* sigma, const int* ksize, int* k, Taps& tx, Taps& t
 // whether the single-pass kernel takes this filter on this volume (odd kernel sizes, rows of whole float4, the ring in 64 KB)
 bool gauss3d_fuses(int nx, const int* k) {
     const int cq = (k[0] / 2 + 3) / 4, patch = (GF_TY + 2 * (k[1] / 2)) * (GF_TX / 4 + 2 * cq);  // float4 of a staged patch
-    return (nx % 4) == 0 && (k[0] & 1) && (k[1] & 1) && (k[2] & 1) && fused_lds_bytes(k) <= 64 * 1024 && patch <= GF_NPRE * GF_THREADS;
+    return (nx % 4) == 0 && (k[0] & 1) && (k[1] & 1) && (k[2] & 1) && fused_lds_bytes(k) <= kFusedLdsMax && patch <= GF_NPRE * GF_THREADS;
 }
 
 // out-of-place: dst = G(src), one pass when gauss3d_fuses(); *fused tells the caller which route ran (the two-pass route needs
@@ -252,8 +256,10 @@ int gauss3d_to(hipStream_t s, float* src, float* dst, int nx, int ny, int nz, co
     if (*fused) {
         const int zchunk = k[2] <= 7 ? 128 : 256;
         const int total = ((nx + GF_TX - 1) / GF_TX) * ((ny + GF_TY - 1) / GF_TY) * ((nz + zchunk - 1) / zchunk);
-        hipLaunchKernelGGL(k_gauss3d_fused, dim3((total + 7) / 8 * 8), dim3(GF_THREADS), fused_lds_bytes(k), s, src, dst, nx, ny, nz, zchunk, tx,
-                           ty, tz);
+        const size_t lds = fused_lds_bytes(k);
+        if (lds > 64 * 1024)
+            MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gauss3d_fused), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_gauss3d_fused, dim3((total + 7) / 8 * 8), dim3(GF_THREADS), lds, s, src, dst, nx, ny, nz, zchunk, tx, ty, tz);
         return launch_check("k_gauss3d_fused");
     }
     // pass 1: src -> dst (x then y, each rounded to fp32 like the reference's separate passes); pass 2: dst -> src (z)
