@@ -93,20 +93,32 @@ __global__ __launch_bounds__(256) void k_gauss_z(const float* __restrict__ src, 
     const size_t col = (size_t)y * nx + x, pstride = (size_t)ny * nx;
     float* ring = lds + threadIdx.x;  // ring[slot * 256]
     int slot = 0;
-    for (int p = za - rz; p < zb + rz; ++p) {
-        ring[slot * 256] = src[col + (size_t)min(max(p, 0), nz - 1) * pstride];
-        const int zo = p - rz;
-        if (zo >= za) {
-            float acc = 0.0f;
-            int rs = slot + 1;
-            if (rs >= tz.n) rs -= tz.n;
-            for (int s = 0; s < tz.n; ++s) {
-                acc = fmaf(ring[rs * 256], tz.w[s], acc);
-                if (++rs >= tz.n) rs = 0;
+    constexpr int PF = 8;  // planes requested ahead of the walk (one load per step left the pass latency-bound at 2 TB/s)
+    float in[PF];
+    const int p_end = zb + rz;
+    auto fetch = [&](int p) { return src[col + (size_t)min(max(p, 0), nz - 1) * pstride]; };
+#pragma unroll
+    for (int u = 0; u < PF; ++u) in[u] = fetch(za - rz + u);  // (clamped: harmless beyond the end)
+    for (int p0 = za - rz; p0 < p_end; p0 += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int p = p0 + u;
+            if (p >= p_end) break;
+            ring[slot * 256] = in[u];
+            in[u] = fetch(p + PF);
+            const int zo = p - rz;
+            if (zo >= za) {
+                float acc = 0.0f;
+                int rs = slot + 1;
+                if (rs >= tz.n) rs -= tz.n;
+                for (int s = 0; s < tz.n; ++s) {
+                    acc = fmaf(ring[rs * 256], tz.w[s], acc);
+                    if (++rs >= tz.n) rs = 0;
+                }
+                dst[col + (size_t)zo * pstride] = acc;
             }
-            dst[col + (size_t)zo * pstride] = acc;
+            if (++slot >= tz.n) slot = 0;
         }
-        if (++slot >= tz.n) slot = 0;
     }
 }
 
