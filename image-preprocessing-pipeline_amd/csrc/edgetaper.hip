@@ -35,16 +35,22 @@ int matlab_round_half(int k) {  // round(k/2) with half away from zero, k > 0
     return (k + 1) / 2;
 }
 
+// one work-group per row (y, z): no 64-bit index arithmetic per voxel; rows on the plateau of both other axes only visit their
+// two tapered ends (x_lo, x_hi: first and one-past-last x with tx == 1)
 __global__ __launch_bounds__(256) void k_taper_blend(float* __restrict__ bl, const float* __restrict__ blur,
                                                       const float* __restrict__ tx, const float* __restrict__ ty,
-                                                      const float* __restrict__ tz, int nx, int ny, int nz) {
-    const size_t total = (size_t)nx * ny * nz;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int x = (int)(i % nx);
-        const size_t r = i / nx;
-        const int y = (int)(r % ny), z = (int)(r / ny);
-        const float m = (tx[x] * ty[y]) * tz[z];  // mask built x, then y, then z (edgetaper_3d.m:30-39)
-        if (m != 1.0f) bl[i] = m * bl[i] + (1.0f - m) * blur[i];
+                                                      const float* __restrict__ tz, int nx, int ny, int nz, int x_lo, int x_hi) {
+    const int y = blockIdx.x, z = blockIdx.y;
+    const float myz = ty[y], mz = tz[z];
+    const bool plateau = myz == 1.0f && mz == 1.0f;
+    const size_t row = ((size_t)z * ny + y) * (size_t)nx;
+    for (int x = threadIdx.x; x < nx; x += 256) {
+        if (plateau && x >= x_lo && x < x_hi) {  // skip to the upper end
+            x += ((x_hi - x + 255) / 256) * 256 - 256;
+            continue;
+        }
+        const float m = (tx[x] * myz) * mz;  // mask built x, then y, then z (edgetaper_3d.m:30-39)
+        if (m != 1.0f) bl[row + x] = m * bl[row + x] + (1.0f - m) * blur[row + x];
     }
 }
 
@@ -300,11 +306,12 @@ int edgetaper_async(hipStream_t s, float* bl, float* work, const float* psf, int
         MI_TRY(direct_prepare_psf(s, psf, kx, ky, kz, /*normalise=*/true, /*flip=*/true, kf, &kxp));
         MI_TRY(direct_conv_launch(s, bl, kf.as<float>(), work, nx, ny, nz, kx, ky, kz, kxp, MI_BOUNDARY_REPLICATE, EPI_TAPER_SHELL, epi));
     }
-    const size_t total = (size_t)nx * ny * nz;
-    size_t blocks = (total + 255) / 256;
-    if (blocks > 256 * 32) blocks = 256 * 32;
     const float* t = dtaper.as<float>();
-    hipLaunchKernelGGL(k_taper_blend, dim3((unsigned)blocks), dim3(256), 0, s, bl, work, t + off[0], t + off[1], t + off[2], nx, ny, nz);
+    int x_lo = 0, x_hi = nx;  // plateau of the x taper (host copy of the vectors: `taper`)
+    while (x_lo < nx && taper[0][x_lo] != 1.0f) ++x_lo;
+    while (x_hi > x_lo && taper[0][x_hi - 1] != 1.0f) --x_hi;
+    hipLaunchKernelGGL(k_taper_blend, dim3((unsigned)ny, (unsigned)nz), dim3(256), 0, s, bl, work, t + off[0], t + off[1], t + off[2], nx, ny, nz,
+                       x_lo, x_hi);
     MI_TRY(launch_check("k_taper_blend"));
     // host vector / DevBufs die at scope exit: the H2D copy source must outlive the copy
     MI_HIP(hipStreamSynchronize(s));
