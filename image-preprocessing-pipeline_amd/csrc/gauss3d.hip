@@ -112,7 +112,7 @@ constexpr int GZW_U = 8;  // output rows / planes per register-window chunk (k_g
 template <int N>
 __global__ __launch_bounds__(64 * GXY_WAVES) void k_gauss_xy_win(const float* __restrict__ src, float* __restrict__ dst, int nx, int ny, int nz,
                                                                   Taps tx, Taps ty) {
-    constexpr int R = N / 2, U = GZW_U, W = U + 2 * R, SEG = 64 + 2 * R, PF = 4;
+    constexpr int R = N / 2, U = GZW_U, W = U + 2 * R, SEG = 64 + 2 * R, PF = 16;
     __shared__ float rbs[GXY_WAVES][SEG];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float* rb = rbs[wave];
