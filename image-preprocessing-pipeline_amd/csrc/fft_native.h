@@ -18,6 +18,7 @@ struct NativeDims {
     int paired;       // spectra around the z pass in the pair-interleaved layout (k_y_pair, k_z_pair_pipe)
     int zpad;         // paired layout: float4 of padding behind every row (xk, z)
     int xrow;         // x side: complex samples from one row (z, px) to the next (ny + padding)
+    int xk0, xkn;     // paired layout: planes xk0 .. xk0 + xkn - 1 of a y / z launch (all of them, or one chunk of the blocked chain)
 };
 
 // Padded mode: the caller's volume (extents n) sits at offset o inside the transform grid; the x passes apply the boundary
@@ -49,6 +50,24 @@ struct NativeFft {
     const float2* tw_z = nullptr;
     size_t n_cplx = 0;
     int n_cu = 256;  // persistent kernels launch one work-group per CU
+    // x launches that run beside a halo exchange (part 2 of a sharded step): compute units left free for the collective's
+    // kernels, tiles handed out by a device counter instead of a fixed stride (mi_rl_set_overlap)
+    int overlap_free_cus = 0;
+    bool overlap_dynamic = false;
+    DevBuf ctr;
+    int persistent_grid(hipStream_t s, int ntiles, bool overlapped, unsigned* grid, int** ctr_out);
+    // Cache-blocked middle (y forward -> z * OTF -> y inverse on a chunk of `chunk_xk` plane pairs at a time, chunk after chunk):
+    // the intermediate spectra of a chunk live in a small buffer that stays in the 256-MiB Infinity Cache instead of crossing
+    // HBM twice per pass; the result returns to the rows of S it came from, and the x pass runs in place on S.
+    int chunk_xk = 0;              // 0: three full-volume passes through T
+    int chunk_streams = 1;         // chunks in flight (each on its own stream and buffer)
+    DevBuf Tc;
+    hipStream_t cstream[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t cev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    ~NativeFft();
+    int set_chunking(int xk_per_chunk, int streams);
+    int middle_chunked(hipStream_t s, bool conj_otf);
+    const float2* x_source() const { return chunk_xk > 0 ? S.as<float2>() : t_spec; }  // what the inverse x pass reads
 
     static bool supported(const int F[3]);
     // smallest supported extent >= n of axis 0 (x), 1 (y), 2 (z); 0 when there is none
@@ -78,8 +97,8 @@ struct NativeFft {
     size_t spectrum_row_floats() const { return (size_t)2 * dims.nz * dims.hx; }
     int x_forward(hipStream_t s, const float* in);
     int middle(hipStream_t s, bool conj_otf);
-    int y_pass(hipStream_t s, bool inverse, bool paired);
-    int z_conv(hipStream_t s, bool conj_otf);
+    int y_pass(hipStream_t s, bool inverse, bool paired, const float2* src = nullptr, float2* dst = nullptr, int xk0 = 0, int xkn = -1);
+    int z_conv(hipStream_t s, bool conj_otf, const float2* src = nullptr, float2* dst = nullptr, int xk0 = 0, int xkn = -1);
     int x_inverse(hipStream_t s, float* out, int epi_kind, const ConvEpilogue& epi, bool fuse_forward, const TileSelect* part = nullptr);
     bool pipe_ok() const;  // the fused x pass can run as the persistent pipelined kernel
     bool splits() const;   // ... and a subset of its tiles (unpadded grids)

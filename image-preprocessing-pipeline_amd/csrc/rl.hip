@@ -6,6 +6,7 @@
 // The numerator is the running estimate (no stored observation) and abs() follows the product,
 // exactly as the reference does.  The regularisation schedule, the Gaussian pre-smooth (5 taps on
 // the GPU path), the Tikhonov blend and the ||bl||_2 stop test follow decon.m:41-59,67-79,108-118.
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <new>
@@ -357,6 +358,77 @@ extern "C" int mi_rl_sharded_ratio(mi_rl_ctx* ctx, void* stream, const float* bl
 extern "C" int mi_rl_sharded_update(mi_rl_ctx* ctx, void* stream, float* bl, int more, int part, const int* edge_rows) {
     MI_REQUIRE(part == 0 || more, "mi_rl_sharded_update: a split step must produce the next input (more != 0)");
     return sharded_step(ctx, stream, bl, true, more, part, edge_rows);
+}
+
+extern "C" int mi_rl_set_overlap(mi_rl_ctx* ctx, int free_cus, int dynamic_tiles) {
+    NativeFft* nf = nullptr;
+    MI_TRY(sharded_native(ctx, &nf));
+    MI_REQUIRE(free_cus >= 0 && free_cus < nf->n_cu, "mi_rl_set_overlap: free_cus must be in [0, %d)", nf->n_cu);
+    nf->overlap_free_cus = free_cus;
+    nf->overlap_dynamic = dynamic_tiles != 0;
+    return MI_OK;
+}
+
+// A stand-in for a collective's kernels: `busy_wgs` small work-groups that hold their compute units for `ticks` of the 100-MHz
+// wall clock (and touch `buf` so that they are not optimised away)
+__global__ __launch_bounds__(256) void k_busy(long long ticks, int* __restrict__ buf) {
+    const long long t0 = wall_clock64();
+    int spins = 0;
+    while (wall_clock64() - t0 < ticks) {
+        __builtin_amdgcn_s_sleep(32);
+        ++spins;
+    }
+    if (threadIdx.x == 0 && buf) buf[blockIdx.x] = spins;
+}
+
+extern "C" int mi_rl_overlap_probe(mi_rl_ctx* ctx, void* stream, float* bl, const int* edge_rows, int busy_wgs, float busy_us, int reps,
+                                   float* out_ms) {
+    NativeFft* nf = nullptr;
+    MI_TRY(sharded_native(ctx, &nf));
+    MI_REQUIRE(bl && edge_rows && out_ms && reps > 0 && busy_wgs >= 0 && busy_wgs <= 1024 && busy_us >= 0.0f && busy_us <= 50000.0f,
+               "mi_rl_overlap_probe: bad arguments");
+    MI_REQUIRE(nf->splits(), "mi_rl_overlap_probe: this context cannot split the x pass");
+    hipStream_t s = as_stream(stream), side = nullptr;
+    const TileSelect sel = nf->edge_tiles(2, edge_rows[0], edge_rows[1], edge_rows[2], edge_rows[3]);
+    ConvEpilogue e;
+    e.a = bl;
+    DevBuf sink;
+    MI_TRY(sink.alloc(sizeof(int) * 1024));
+    MI_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+    hipEvent_t ev[4];
+    for (auto& x : ev) MI_HIP(hipEventCreate(&x));
+    int rc = MI_OK;
+    float sum_x = 0.0f, sum_all = 0.0f;
+    for (int r = -1; r < reps && rc == MI_OK; ++r) {  // r == -1: warm-up
+        (void)hipStreamSynchronize(s);
+        (void)hipEventRecord(ev[0], s);
+        if (busy_wgs > 0) {
+            (void)hipStreamWaitEvent(side, ev[0], 0);
+            hipLaunchKernelGGL(k_busy, dim3((unsigned)busy_wgs), dim3(256), 0, side, (long long)(busy_us * 100.0f), sink.as<int>());
+            rc = launch_check("k_busy");
+            (void)hipEventRecord(ev[3], side);
+            // the stand-in must be resident before the pass is launched, like a collective that was issued first
+            const auto t0 = std::chrono::steady_clock::now();
+            while (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() < 150.0) {}
+        }
+        (void)hipEventRecord(ev[1], s);
+        if (rc == MI_OK) rc = nf->x_inverse(s, nullptr, EPI_RATIO, e, true, &sel);
+        (void)hipEventRecord(ev[2], s);
+        if (busy_wgs > 0) (void)hipStreamWaitEvent(s, ev[3], 0);
+        (void)hipEventRecord(ev[3], s);
+        hipError_t he = hipEventSynchronize(ev[3]);
+        float a = 0.0f, b = 0.0f;
+        if (he == hipSuccess) he = hipEventElapsedTime(&a, ev[1], ev[2]);
+        if (he == hipSuccess) he = hipEventElapsedTime(&b, ev[0], ev[3]);
+        if (rc == MI_OK && he != hipSuccess) rc = fail(MI_ERR_HIP, "mi_rl_overlap_probe: %s", hipGetErrorString(he));
+        if (r >= 0) { sum_x += a; sum_all += b; }
+    }
+    (void)hipStreamSynchronize(side);
+    for (auto& x : ev) (void)hipEventDestroy(x);
+    (void)hipStreamDestroy(side);
+    out_ms[0] = sum_x / (float)reps;    // launch -> end of the x launch (part 2)
+    out_ms[1] = sum_all / (float)reps;  // stand-in issued -> both finished
+    return rc;
 }
 
 extern "C" int mi_rl_spectrum_rows(mi_rl_ctx* ctx, void* stream, int y0, int rows, float* buf, int dir) {

@@ -359,6 +359,18 @@ class RLContext:
         self._chk(bl)
         check(lib().mi_rl_sharded_update(self._h, _stream(bl), bl.data_ptr(), int(bool(more)), int(part), self._edges(edge_rows)))
 
+    def set_overlap(self, free_cus=0, dynamic_tiles=False):
+        """Launch geometry of the part-2 x launches that run beside a halo exchange (``mi_rl_set_overlap``)."""
+        check(lib().mi_rl_set_overlap(self._h, int(free_cus), int(bool(dynamic_tiles))))
+
+    def overlap_probe(self, bl, edge_rows, busy_wgs=8, busy_us=1000.0, reps=5):
+        """(ms of the part-2 x launch, ms until it and a stand-in for a collective's kernels have both finished)"""
+        self._chk(bl)
+        out = (C.c_float * 2)()
+        check(lib().mi_rl_overlap_probe(self._h, _stream(bl), bl.data_ptr(), self._edges(edge_rows), int(busy_wgs), float(busy_us),
+                                        int(reps), out))
+        return float(out[0]), float(out[1])
+
     def spectrum_pack(self, y0, rows):
         """Rows [y0, y0+rows) of the x-transformed input buffer as a contiguous float32 device tensor."""
         buf = torch.empty(int(rows) * int(lib().mi_rl_spectrum_row_floats(self._h)), dtype=torch.float32, device=self.device)

@@ -162,6 +162,21 @@ int mi_rl_sharded_ratio(mi_rl_ctx* ctx, void* stream, const float* bl, int part,
 int mi_rl_sharded_update(mi_rl_ctx* ctx, void* stream, float* bl, int more, int part, const int* edge_rows);
 int mi_rl_spectrum_rows(mi_rl_ctx* ctx, void* stream, int y0, int rows, float* buf, int dir);
 size_t mi_rl_spectrum_row_floats(mi_rl_ctx* ctx);
+/* How the "part 2" launches of a split step share the GPU with the halo exchange that is in flight beside them (the reference
+ * has no counterpart: its blocks never exchange anything, LsDeconv.m:643-654).  The x pass is a persistent kernel of one
+ * 16-wave work-group per compute unit; a collective's kernels need compute units too.  free_cus: work-groups NOT launched
+ * (grid = CUs - free_cus), so that many units stay available to the collective; dynamic_tiles != 0: tiles are handed out by a
+ * device counter (one atomicAdd per tile) instead of a fixed stride, so a work-group that starts late -- its unit was held by
+ * the collective -- takes fewer tiles instead of running its fixed share as the tail of the pass.  Default: 0, 0 (the single-GPU
+ * launch geometry).  A copy-engine transport (slab.py, transport="peer") needs neither. */
+int mi_rl_set_overlap(mi_rl_ctx* ctx, int free_cus, int dynamic_tiles);
+/* Measurement hook for the above on ONE GPU: launches `busy_wgs` stand-in work-groups (256 threads, holding their compute units
+ * for busy_us microseconds) on a second stream, then part 2 of a ratio step (the tiles outside edge_rows) on `stream` with the
+ * current overlap settings; out_ms[0] = HIP-event time of the x launch, out_ms[1] = from issuing the stand-in until both have
+ * finished; averages over `reps` (plus one warm-up).  busy_wgs = 0: the x launch alone.  S / T keep whatever the last step
+ * left in them.  Synchronises. */
+int mi_rl_overlap_probe(mi_rl_ctx* ctx, void* stream, float* bl, const int* edge_rows, int busy_wgs, float busy_us, int reps,
+                        float* out_ms);
 /* Measurement hook: average duration in ms of `reps` back-to-back launches of ONE pass of the native FFT pipeline,
  * taken with HIP events on `stream` (which: 0 x-forward, 1 y-forward, 2 z-forward*OTF*z-inverse, 3 y-inverse,
  * 4 fused x-inverse+ratio+x-forward, 5 fused x-inverse+update+x-forward -- this one OVERWRITES bl with values that mean
