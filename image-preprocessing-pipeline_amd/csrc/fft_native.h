@@ -53,8 +53,11 @@ struct NativeFft {
     // x launches that run beside a halo exchange (part 2 of a sharded step): compute units left free for the collective's
     // kernels, tiles handed out by a device counter instead of a fixed stride (mi_rl_set_overlap)
     int overlap_free_cus = 0;
-    bool overlap_dynamic = false;
+    bool overlap_dynamic = true;
+    bool x_dynamic = true;   // every other persistent x launch
     DevBuf ctr;
+    bool z_dynamic = true;   // the paired z pass takes its tiles from a counter too
+    int ctr_slot = 0;
     int persistent_grid(hipStream_t s, int ntiles, bool overlapped, unsigned* grid, int** ctr_out);
     // Cache-blocked middle (y forward -> z * OTF -> y inverse on a chunk of `chunk_xk` plane pairs at a time, chunk after chunk):
     // the intermediate spectra of a chunk live in a small buffer that stays in the 256-MiB Infinity Cache instead of crossing

@@ -1302,8 +1302,10 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_z_conv_pipe(const floa
 //   Lines of 3 * 2^a / 9 * 2^a points carry the radix-3 / 9 stage in front (behind, inverse) of the power-of-two chain.
 template <int LZ2, int R3, bool REALG, int NT, int TL, bool PHL = true, bool TOPON = true>
 __global__ __launch_bounds__(NT, kWavesXZ) void k_z_pair_pipe(const float2* __restrict__ S, float2* __restrict__ T, const float4* __restrict__ G,
-                                                              NativeDims d, const float2* __restrict__ tw, int conj_otf, int ntiles, RealOtf ro) {
+                                                              NativeDims d, const float2* __restrict__ tw, int conj_otf, int ntiles, RealOtf ro,
+                                                              int* __restrict__ tile_ctr) {
     extern __shared__ __attribute__((aligned(16))) float2 tile[];
+    __shared__ int s_next_tile;  // tiles from a device counter when tile_ctr != nullptr (see k_x_fused_pipe)
     constexpr int L = R3 << LZ2, NW = NT / 64, hp = TL, pitch = row_pitch(L);
     // WP: every wave owns one A line and its partner (rows wave, TL + wave), so the point-wise step is wave-private too;
     // else (1024-point lines: 16 waves on 16 rows) a wave owns ONE row, the point-wise step of line `wave % TL` is shared by the
@@ -1341,10 +1343,19 @@ __global__ __launch_bounds__(NT, kWavesXZ) void k_z_pair_pipe(const float2* __re
     if constexpr (REALG && PHL) {
         for (int p = threadIdx.x; p < L; p += NT) phl[p] = ro.ph_z[pos2freq(p, LZ2, R3)];
     }
-    int t = blockIdx.x;
+    const bool dyn = tile_ctr != nullptr;
+    int t = blockIdx.x, tn = t + (int)gridDim.x;
+    if (dyn) {
+        if (threadIdx.x == 0) s_next_tile = atomicAdd(tile_ctr, 2);
+        lds_barrier();
+        t = __builtin_amdgcn_readfirstlane(s_next_tile);
+        tn = t + 1;
+    }
     if (t < ntiles) load_S(t);
     lds_barrier();  // the tables: the first tile's top super-stage reads them before any other barrier
-    for (; t < ntiles; t += gridDim.x) {
+    for (; t < ntiles;) {
+        int fetched = 0;
+        if (dyn && threadIdx.x == 0) fetched = atomicAdd(tile_ctr, 1);  // the tile after the next one
         const int pl_ = t / ytiles, py0 = (t - pl_ * ytiles) * TL, plane = d.xk0 + pl_;
         {
             const FView fv = f_view();
@@ -1448,7 +1459,6 @@ __global__ __launch_bounds__(NT, kWavesXZ) void k_z_pair_pipe(const float2* __re
                 tile[cB] = make_float2(E2.x + O2.y, O2.x - E2.y);
             }
         }
-        const int tn = t + gridDim.x;
         if (R3 != 9 && tn < ntiles) load_S(tn);  // (requesting them right after the fill, a whole tile ahead, gains nothing: 4.72 vs 4.68 ms)
         if constexpr (WP) wave_lds_fence();
         else lds_barrier();
@@ -1490,7 +1500,10 @@ __global__ __launch_bounds__(NT, kWavesXZ) void k_z_pair_pipe(const float2* __re
                 }
             }
         }
+        if (dyn && threadIdx.x == 0) s_next_tile = fetched;
         lds_barrier();
+        t = tn;
+        tn = dyn ? __builtin_amdgcn_readfirstlane(s_next_tile) : tn + (int)gridDim.x;
     }
 }
 
@@ -2119,13 +2132,15 @@ TileSelect NativeFft::edge_tiles(int mode, int a0, int a1, int b0, int b1) const
 }
 
 // Grid of a persistent x launch and, when its tiles are handed out dynamically, the armed counter (see k_x_fused_pipe).
-// `overlapped`: the launch runs beside a halo exchange (part 2 of a sharded step) and follows the overlap settings: `free_cus`
-// compute units are left to the collective's kernels and the tiles come from the counter.  MI_X_DYN=1 / MI_X_FREE_CUS=<k> apply the
-// same to every launch (measurements).
+// Tiles come from the counter by default: compute units do not all run at the same speed, and the static stride left the
+// slowest one as the tail (C3: paired z pass 4.36 -> 3.94 ms, fused x pass 5.13 / 5.71 -> 5.06 / 5.61 ms; part 2 of a slab rank's
+// x pass at N = 8: 0.77 -> 0.66 ms; profiles/r03_overlap_probe.txt).  `overlapped`: the launch runs beside a halo exchange
+// (part 2 of a sharded step) and follows mi_rl_set_overlap: `free_cus` compute units are left to the collective's kernels.
+// MI_X_DYN=0|1 / MI_X_FREE_CUS=<k> override for every launch (A/B measurements).
 int NativeFft::persistent_grid(hipStream_t s, int ntiles, bool overlapped, unsigned* grid, int** ctr_out) {
     static const char* env_dyn = std::getenv("MI_X_DYN");
     static const char* env_free = std::getenv("MI_X_FREE_CUS");
-    const bool dyn = env_dyn ? atoi(env_dyn) != 0 : (overlapped && overlap_dynamic);
+    const bool dyn = env_dyn ? atoi(env_dyn) != 0 : (overlapped ? overlap_dynamic : x_dynamic);
     const int free_cus = env_free ? atoi(env_free) : (overlapped ? overlap_free_cus : 0);
     const int cus = std::max(1, n_cu - std::max(0, free_cus));
     *grid = (unsigned)std::min(ntiles, cus);
@@ -2229,6 +2244,15 @@ int NativeFft::z_conv(hipStream_t s, bool conj_otf, const float2* src_o, float2*
         const size_t lds = lds_bytes(2 * kPairLines, L) + (real_otf && phl ? sizeof(float2) * (size_t)L : 0);
         const int per_cu = std::max(1, std::min(2, (int)(kLdsOneWg / lds)));  // 8 waves of 128 registers each: two fit a CU
         const unsigned grid = (unsigned)std::min(ntiles, per_cu * n_cu);
+        int* ctr_p = nullptr;
+        {
+            static const char* env_dyn = std::getenv("MI_Z_DYN");
+            if (env_dyn ? atoi(env_dyn) != 0 : z_dynamic) {
+                if (!ctr.p) MI_TRY(ctr.alloc(256));
+                ctr_p = ctr.as<int>() + 16 + 4 * (ctr_slot & 7);
+                MI_HIP(hipMemsetAsync(ctr_p, 0, sizeof(int), s));
+            }
+        }
         RealOtf ro{};
         if (real_otf) {
             ro.g = adj_slot ? Gr_adj.as<float2>() : Gr.as<float2>();
@@ -2239,9 +2263,9 @@ int NativeFft::z_conv(hipStream_t s, bool conj_otf, const float2* src_o, float2*
 #define MI_ZQ(LG, R, NTH, PH)                                                                                                            \
     case LG * 16 + R:                                                                                                                    \
         rc = real_otf ? launch_lds(k_z_pair_pipe<LG, R, true, NTH, kPairLines, PH>, grid, NTH, lds, s, "k_z_pair_pipe<real OTF>", Tp, Sp, Gp, \
-                                   d, twz, cj, ntiles, ro)                                                                              \
+                                   d, twz, cj, ntiles, ro, ctr_p)                                                                       \
                       : launch_lds(k_z_pair_pipe<LG, R, false, NTH, kPairLines, PH>, grid, NTH, lds, s, "k_z_pair_pipe", Tp, Sp, Gp, d, \
-                                   twz, cj, ntiles, ro);                                                                                \
+                                   twz, cj, ntiles, ro, ctr_p);                                                                         \
         break;
         // (lines of up to 576 points: 8 waves on a 64-KB tile, two work-groups per CU; longer ones: 16 waves, one line per wave)
         switch (dims.lz2 * 16 + dims.r3z) {
@@ -2434,6 +2458,7 @@ int NativeFft::middle_chunked(hipStream_t s, bool conj_otf) {
         float2* virt = reinterpret_cast<float2*>(reinterpret_cast<uintptr_t>(Tc.as<float2>() + (size_t)slot * chunk_xk * plane) -
                                                  sizeof(float2) * plane * (size_t)xk0);
         MI_TRY(y_pass(cs, false, true, Sp, virt, xk0, n));
+        ctr_slot = slot;  // (chunks in flight count their z tiles separately)
         MI_TRY(z_conv(cs, conj_otf, virt, virt, xk0, n));
         MI_TRY(y_pass(cs, true, true, virt, Sp, xk0, n));
     }

@@ -372,13 +372,15 @@ extern "C" int mi_rl_set_overlap(mi_rl_ctx* ctx, int free_cus, int dynamic_tiles
 // A stand-in for a collective's kernels: `busy_wgs` small work-groups that hold their compute units for `ticks` of the 100-MHz
 // wall clock (and touch `buf` so that they are not optimised away)
 __global__ __launch_bounds__(256) void k_busy(long long ticks, int* __restrict__ buf) {
+    extern __shared__ int hold[];  // (dynamic LDS: what keeps a 140-KB work-group of the x pass off this compute unit)
+    hold[threadIdx.x] = (int)threadIdx.x;
     const long long t0 = wall_clock64();
     int spins = 0;
     while (wall_clock64() - t0 < ticks) {
         __builtin_amdgcn_s_sleep(32);
         ++spins;
     }
-    if (threadIdx.x == 0 && buf) buf[blockIdx.x] = spins;
+    if (threadIdx.x == 0 && buf) buf[blockIdx.x] = spins + hold[(spins + 1) & 255];
 }
 
 extern "C" int mi_rl_overlap_probe(mi_rl_ctx* ctx, void* stream, float* bl, const int* edge_rows, int busy_wgs, float busy_us, int reps,
@@ -404,7 +406,9 @@ extern "C" int mi_rl_overlap_probe(mi_rl_ctx* ctx, void* stream, float* bl, cons
         (void)hipEventRecord(ev[0], s);
         if (busy_wgs > 0) {
             (void)hipStreamWaitEvent(side, ev[0], 0);
-            hipLaunchKernelGGL(k_busy, dim3((unsigned)busy_wgs), dim3(256), 0, side, (long long)(busy_us * 100.0f), sink.as<int>());
+            // 48 KB of LDS per stand-in work-group: it cannot share a compute unit with a work-group of the x pass (~140 of 160 KB),
+            // like a collective's kernel with its staging buffers (a stand-in without LDS simply co-resides: measured, no effect)
+            hipLaunchKernelGGL(k_busy, dim3((unsigned)busy_wgs), dim3(256), 48 * 1024, side, (long long)(busy_us * 100.0f), sink.as<int>());
             rc = launch_check("k_busy");
             (void)hipEventRecord(ev[3], side);
             // the stand-in must be resident before the pass is launched, like a collective that was issued first

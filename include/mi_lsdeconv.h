@@ -167,8 +167,9 @@ size_t mi_rl_spectrum_row_floats(mi_rl_ctx* ctx);
  * 16-wave work-group per compute unit; a collective's kernels need compute units too.  free_cus: work-groups NOT launched
  * (grid = CUs - free_cus), so that many units stay available to the collective; dynamic_tiles != 0: tiles are handed out by a
  * device counter (one atomicAdd per tile) instead of a fixed stride, so a work-group that starts late -- its unit was held by
- * the collective -- takes fewer tiles instead of running its fixed share as the tail of the pass.  Default: 0, 0 (the single-GPU
- * launch geometry).  A copy-engine transport (slab.py, transport="peer") needs neither. */
+ * the collective -- takes fewer tiles, or none, instead of running a fixed share as the tail of the pass.  Default: 0, 1 (the
+ * single-GPU launch geometry; measured on one GPU with a stand-in collective: profiles/r03_overlap_probe.txt).  A copy-engine
+ * transport (slab.py, transport="peer") occupies no compute unit at all. */
 int mi_rl_set_overlap(mi_rl_ctx* ctx, int free_cus, int dynamic_tiles);
 /* Measurement hook for the above on ONE GPU: launches `busy_wgs` stand-in work-groups (256 threads, holding their compute units
  * for busy_us microseconds) on a second stream, then part 2 of a ratio step (the tiles outside edge_rows) on `stream` with the

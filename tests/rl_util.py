@@ -39,3 +39,24 @@ def asymmetric_psf(kshape, seed=0):
     p = p.astype(np.float32)
     assert not np.allclose(p, p[::-1, ::-1, ::-1], rtol=1e-2)
     return p
+
+
+def assert_close_device(got, want, rel=1e-4, rel_l2=1e-5, pt_rel=1e-4, pt_abs=1e-7, what=""):
+    """`assert_close` for torch tensors that stay on the device (volumes of several GB): the same three bounds, evaluated plane
+    by plane with float64 accumulators."""
+    import torch
+    assert got.shape == want.shape, (got.shape, want.shape)
+    wmax = max(float(want.abs().max()), 1e-30)
+    dmax, worst, d2, w2 = 0.0, 0.0, 0.0, 0.0
+    floor = pt_abs * max(1.0, wmax)
+    for z in range(got.shape[0]):
+        g, w = got[z].double(), want[z].double()
+        d = (g - w).abs()
+        dmax = max(dmax, float(d.max()))
+        worst = max(worst, float((d / (pt_rel * w.abs() + floor)).max()))
+        d2 += float((d * d).sum())
+        w2 += float((w * w).sum())
+    assert dmax <= rel * wmax, f"{what} max error {dmax / wmax:.3e} of the maximum"
+    l2 = (d2 / max(w2, 1e-300)) ** 0.5
+    assert l2 <= rel_l2, f"{what} relative L2 error {l2:.3e}"
+    assert worst <= 1.0, f"{what} point-wise error {worst:.3f} x the allowance"
