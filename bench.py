@@ -53,31 +53,29 @@ def make_volume(shape, device, seed=1234):
 
 
 def pmc_traffic(pass_name, workload):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r02_pmc_traffic.json:
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this same command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes).
-    Counters cannot be collected from inside the timed process, so the profile of the default workload is quoted."""
+    """(HBM bytes per launch of the dominant kernel, the file they come from): the committed PMC passes of this same command
+    (profiles/r03_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in two separate runs, FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes).  Counters cannot be collected from inside the timed process, so this is a CONSTANT of that
+    profile, quoted beside the live launch time -- `roofline.traffic_source` says so in the JSON line.  (None, None) when the
+    profile does not hold the kernel."""
     if workload != "c3":
-        return None
-    kern = None
-    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
-        try:
-            with open(os.path.join(ROOT, "profiles", name)) as f:
-                kern = json.load(f)["kernels"]
-            break
-        except OSError:
-            continue
-    if kern is None:
-        return None
+        return None, None
+    name = "r03_pmc_traffic.json"
+    try:
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            kern = json.load(f)["kernels"]
+    except (OSError, KeyError, ValueError):
+        return None, None
     # (the pair-interleaved layout runs k_y_pair / k_z_pair_pipe, the plain one k_y_pass / k_z_conv_pipe)
     # (k_x_fused_pipe<.., 0> is the fused pass; modes 1 / 2 are the forward-only / inverse-only launches around a chain)
     want = {"z_conv": (("k_z_pair_pipe<", ">"), ("k_z_conv_pipe<", ">")), "x_fused": (("k_x_fused_pipe<", ", 0>"), ("k_x_fused_pipe<", ">")),
             "y_forward": (("k_y_pair<", "false>"), ("k_y_pass<", "false>")),
             "y_inverse": (("k_y_pair<", "true>"), ("k_y_pass<", "true>"))}[pass_name]
     for pre, post in want:
-        for name, v in kern.items():
-            if name.startswith(pre) and name.endswith(post):
-                return round(v["hbm_bytes_per_launch"])
-    return None
+        for kname, v in kern.items():
+            if kname.startswith(pre) and kname.endswith(post):
+                return round(v["hbm_bytes_per_launch"]), "profiles/" + name
+    return None, None
 
 
 def host_cores():
@@ -127,6 +125,49 @@ def cpu_baseline(vshape, kshape, seconds_budget=15.0):
                       f"{kshape[2]}x{kshape[1]}x{kshape[0]} PSF, {dt:.1f} s"}
 
 
+def block_stages(vshape, psf_np, dev):
+    """what surrounds the iterations of one block, timed separately from the loop -- edgetaper_3d (decon.m:50,143)
+    and the host <-> device hand-over of the block (gpuArray / gather, LsDeconv.m:906-948) through pinned memory."""
+    import torch
+    from ipp_amd import decon
+    out = {}
+    n = vshape[0] * vshape[1] * vshape[2]
+    vol = make_volume(vshape, dev, seed=99)
+    psf_t = torch.from_numpy(psf_np).to(dev)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    try:
+        decon.edgetaper_3d(vol, psf_t)                 # first call builds the slab engines (a deconvolution plan keeps them)
+        torch.cuda.synchronize(dev)
+        ev0.record()
+        decon.edgetaper_3d(vol, psf_t)
+        ev1.record()
+        torch.cuda.synchronize(dev)
+        out["edgetaper_ms"] = round(ev0.elapsed_time(ev1), 3)
+    except Exception as e:
+        out["edgetaper_ms"] = None
+        sys.stderr.write(f"edgetaper timing unavailable: {e!r}\n")
+    try:
+        host = torch.empty(vshape, dtype=torch.float32, pin_memory=True)
+        host.fill_(0.5)
+        for key, fn in (("h2d_ms", lambda: vol.copy_(host, non_blocking=True)), ("d2h_ms", lambda: host.copy_(vol, non_blocking=True))):
+            fn()
+            torch.cuda.synchronize(dev)
+            ev0.record()
+            fn()
+            ev1.record()
+            torch.cuda.synchronize(dev)
+            out[key] = round(ev0.elapsed_time(ev1), 3)
+        out["pcie_GBps"] = round(4.0 * n / 1e9 / (0.5e-3 * (out["h2d_ms"] + out["d2h_ms"])), 1)
+        del host
+    except Exception as e:
+        out.setdefault("h2d_ms", None)
+        out.setdefault("d2h_ms", None)
+        sys.stderr.write(f"PCIe timing unavailable: {e!r}\n")
+    del vol
+    torch.cuda.empty_cache()
+    return out
+
+
 def launch_ranks(n, argv):
     """``python bench.py --gpus N`` from a plain shell: start the N ranks as a CHILD process tree (torch.distributed.run, one rank
     per GPU, rendezvous on 127.0.0.1), relay rank 0's JSON line and return the child's exit code.  Nothing in this process has
@@ -159,6 +200,7 @@ def main():
     ap.add_argument("--engine", default="auto", choices=["auto", "direct", "fft"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ncc", action="store_true")
+    ap.add_argument("--no-stages", action="store_true", help="skip the edge-taper / PCIe timings around the loop (N = 1)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the product path); gloo only to rehearse N > 1 on a one-GPU box")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: all ranks on cuda:0 (with --backend gloo)")
@@ -167,6 +209,11 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # not under a launcher: fan the ranks out as a child process tree before anything here touches the GPU
         raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+
+    ncc_workers = None
+    if args.gpus == 1 and not args.no_ncc and not args.no_cpu_baseline:
+        import bench_ncc
+        ncc_workers = bench_ncc.start_cpu_workers(host_cores())   # idle until the NCC CPU leg; started before the GPU is touched
 
     import torch
     from ipp_amd import capi, decon
@@ -262,8 +309,11 @@ def main():
                 dom = max(times, key=lambda k: times[k] * per_iter[k])
                 algo_b = {"z_conv": 10 if ctx.otf_is_real else 12, "y_forward": 8, "y_inverse": 8, "x_fused": 14}[dom]  # B/voxel/launch
                 ach = algo_b * launch_vox / (times[dom] * 1e-3) / 1e9
+                traffic, traffic_src = pmc_traffic(dom, args.workload) if world == 1 else (None, None)
                 roofline = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(dom, args.workload) if world == 1 else None,
+                            "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
+                            "traffic_source": (traffic_src + " (PMC passes of this command kept in the repository; not collected in this run)")
+                            if traffic_src else None,
                             "kernel": {"z_conv": ("k_z_pair_pipe" if ctx.pair_layout else "k_z_conv_pipe") +
                                                  " (z-forward FFT + untangle*OTF + z-inverse FFT, one pass)",
                                        "x_fused": "k_x_fused_pipe (x-inverse FFT + RL epilogue + x-forward FFT; mean of the "
@@ -274,6 +324,10 @@ def main():
                             "launch_ms": round(times[dom], 4), "launches_per_iteration": per_iter[dom],
                             "pass_ms": dict({k: round(v, 4) for k, v in times.items()},
                                             x_fused_ratio=round(t_ratio, 4), x_fused_update=round(t_update, 4))}
+                if args.workload == "c3" and world == 1:
+                    # the passes run in one of two speeds per allocation (physical page placement): which one this run got
+                    roofline["pass_mode"] = {"mode": "fast" if t_update < 5.95 else "slow", "x_fused_update_ms": round(t_update, 4),
+                                             "note": "update launch of the x pass: ~5.6 ms (fast) or ~6.3 ms (slow) per allocation"}
             except Exception as e:  # e.g. rocFFT fallback: no per-pass hook
                 roofline = None
                 sys.stderr.write(f"per-pass timing unavailable: {e!r}\n")
@@ -294,14 +348,34 @@ def main():
                        "engine": {1: "direct", 2: "fft"}.get(engine_used, str(engine_used)), "parallelism": parallelism},
             "roofline": roofline,
         }
+        if world == 1 and not args.no_stages:
+            ctx = bl = ratio = None                  # (the closures above see the rebinding: the context and its volume are freed)
+            torch.cuda.empty_cache()
+            capi.release_cached_memory()
+            out["block_stages"] = block_stages(vshape, psf_np, dev)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(vshape, kshape)
-        if not args.no_ncc and world == 1:
-            try:
-                import bench_ncc
-                out["ncc"] = bench_ncc.run(dev)
-            except Exception as e:  # the NCC leg must not hide the headline number
-                out["ncc"] = {"error": repr(e)}
+    ncc = None
+    if not args.no_ncc:
+        # second metric (BASELINE config 5).  N > 1: tile-row blocks, one block per rank (bench_ncc.py); every rank takes part
+        if world > 1:
+            step = drv = ctx = bl = None             # the slab context and its volume make room for the tile rows
+            torch.cuda.empty_cache()
+            capi.release_cached_memory()
+        try:
+            import bench_ncc
+            ncc = bench_ncc.run(dev, cpu_workers=ncc_workers, rank=rank, world=world, dist=dist,
+                                dist_device=(dev if args.backend == "nccl" else "cpu"))
+        except Exception as e:  # the NCC leg must not hide the headline number
+            ncc = {"error": repr(e)}
+            if world > 1:
+                raise
+        finally:
+            if ncc_workers:
+                bench_ncc.stop_cpu_workers(ncc_workers)
+    if rank == 0:
+        if ncc is not None:
+            out["ncc"] = ncc
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

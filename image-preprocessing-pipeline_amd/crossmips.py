@@ -273,28 +273,74 @@ def subvolume_layers(z_size: int, subvol_dim_D: int = S_SUBVOL_DIM_D_DEFAULT):
     return out
 
 
+def tile_row_blocks(n_rows: int, world_size: int, n_cols: int | None = None):
+    """Partition of a tile grid over ranks by ROW BLOCKS: rank q owns the rows [r0, r1) -- all their west-east pairs and the
+    north-south pairs (r, r + 1) for r in [r0, r1) -- and therefore keeps the rows [r0, min(r1 + 1, n_rows)) resident: every tile
+    is uploaded once, the first row behind a cut twice.  (The reference farms (pair, layer) jobs out over MPI ranks with
+    CUDA_VISIBLE_DEVICES = rank % num_gpus, each job re-reading its two stacks: Parastitcher.py:1367,1440-1560,
+    StackStitcher.cpp:223-374.)  Blocks are contiguous and balanced by PAIR count (a row costs n_cols - 1 west-east + n_cols
+    north-south pairs, the last row only the former): the cut that minimises the largest block.  Returns [(r0, r1)] per rank;
+    ranks beyond the rows get empty blocks."""
+    world_size = max(1, int(world_size))
+    n_cols = n_rows if n_cols is None else int(n_cols)
+    cost = [(n_cols - 1) + (n_cols if r + 1 < n_rows else 0) for r in range(n_rows)]
+    parts = min(world_size, n_rows)
+
+    def cuts(limit):                      # greedy: fewest blocks whose cost stays <= limit
+        out, r0, acc = [], 0, 0
+        for r, c in enumerate(cost):
+            if acc + c > limit and r > r0:
+                out.append((r0, r))
+                r0, acc = r, 0
+            acc += c
+        out.append((r0, n_rows))
+        return out
+
+    lo, hi = max(cost) if cost else 0, sum(cost)
+    while lo < hi:                        # smallest limit that needs at most `parts` blocks
+        mid = (lo + hi) // 2
+        if len(cuts(mid)) <= parts:
+            hi = mid
+        else:
+            lo = mid + 1
+    blocks = cuts(lo) if n_rows else []
+    return blocks + [(n_rows, n_rows)] * (world_size - len(blocks))
+
+
 def compute_displacements(tiles, overlap_V: int, overlap_H: int, displ_max_V=S_DISPL_SEARCH_RADIUS_DEF,
                           displ_max_H=S_DISPL_SEARCH_RADIUS_DEF, displ_max_D=S_DISPL_SEARCH_RADIUS_DEF,
-                          rank: int = 0, world_size: int = 1):
+                          rank: int = 0, world_size: int = 1, row_block=None):
     """Pairwise displacement computation over one z-layer of a tile grid (step 2 of the stitcher).
 
     ``tiles[r][c]`` are device-resident float32 (D, V, H) tensors of identical shape.  Pairs are independent
-    (StackStitcher.cpp:223-374; the reference farms them out over MPI ranks, Parastitcher.py:1440-1560): with
-    ``world_size`` > 1 this rank takes pairs ``rank::world_size`` -- no collective is involved.
+    (StackStitcher.cpp:223-374; the reference farms them out over MPI ranks, Parastitcher.py:1440-1560) -- no collective is
+    involved.  Two ways to share a grid among ranks: ``row_block = (r0, r1)`` (see ``tile_row_blocks``): this rank computes the
+    pairs that start in rows [r0, r1), and only the rows r0 .. min(r1, n_rows - 1) of ``tiles`` need to hold tensors (the others
+    may be None); or, with every tile resident on every rank, ``rank`` / ``world_size``: pairs ``rank::world_size``.
     Returns {(r, c, r_b, c_b, direction): DisplacementMIPNCC}."""
     capi.require_gpu()
     n_rows, n_cols = len(tiles), len(tiles[0])
     flat = [tiles[r][c] for r in range(n_rows) for c in range(n_cols)]
-    dev = flat[0].device
-    dim_D, dim_V, dim_H = (int(s) for s in flat[0].shape)
-    for t in flat:
-        if tuple(t.shape) != (dim_D, dim_V, dim_H) or t.dtype != torch.float32 or not t.is_contiguous() or t.device != dev:
-            raise ValueError("all tiles must be contiguous float32 tensors of one shape on one device")
-    pairs = list(enumerate_pairs(n_rows, n_cols))[rank::world_size]
+    pairs = list(enumerate_pairs(n_rows, n_cols))
+    if row_block is not None:
+        r0, r1 = int(row_block[0]), int(row_block[1])
+        pairs = [p for p in pairs if r0 <= p[0] < r1]
+    else:
+        pairs = pairs[rank::world_size]
     n = len(pairs)
     if n == 0:
         return {}
-    ptrs = (C.c_void_p * len(flat))(*[t.data_ptr() for t in flat])
+    used = sorted({r * n_cols + c for r, c, _, _, _ in pairs} | {rb * n_cols + cb for _, _, rb, cb, _ in pairs})
+    if any(flat[i] is None for i in used):
+        raise ValueError("a tile of a pair this rank computes is not resident (None)")
+    first = flat[used[0]]
+    dev = first.device
+    dim_D, dim_V, dim_H = (int(s) for s in first.shape)
+    for i in used:
+        t = flat[i]
+        if tuple(t.shape) != (dim_D, dim_V, dim_H) or t.dtype != torch.float32 or not t.is_contiguous() or t.device != dev:
+            raise ValueError("all tiles must be contiguous float32 tensors of one shape on one device")
+    ptrs = (C.c_void_p * len(flat))(*[(t.data_ptr() if t is not None else None) for t in flat])
     a_idx = (C.c_int * n)(*[r * n_cols + c for r, c, _, _, _ in pairs])
     b_idx = (C.c_int * n)(*[rb * n_cols + cb for _, _, rb, cb, _ in pairs])
     ni = (C.c_int * n)(*[dim_V - overlap_V if d == dir_vertical else 0 for *_, d in pairs])

@@ -152,14 +152,20 @@ def test_c4_shaped_slab_rank_edgetaper(dev):
     assert np.array_equal(core, vol_in[(2, 500, 288)][1000:3000])
 
 
-def test_ncc_full_size_pair_vs_oracle(dev):
+@pytest.mark.parametrize("direction", [1, 0], ids=["west_east", "north_south"])
+def test_ncc_full_size_pair_vs_oracle(dev, direction):
+    """One full-size C5 pair per direction (2048 x 2048 x 32 tiles, 307-px overlap, search (25, 25, 10)) against the C oracle: all
+    nine scalars of the record -- V, H and D offsets, the three peaks, the three widths -- and the mutated wRangeThr
+    (libcrossmips.cpp:275-277, 339-481)."""
     import bench_ncc
     from ipp_amd import crossmips
-    tiles, jit, step = bench_ncc.make_grid(dev, rows=1, cols=2, seed=4321)
-    d = crossmips.PDAlgoMIPNCC.execute(tiles[0][0], tiles[0][1], *bench_ncc.DISPL, 1, bench_ncc.OVERLAP)
-    want = N.pdalgo_execute(tiles[0][0].cpu().numpy(), tiles[0][1].cpu().numpy(), *bench_ncc.DISPL, 1, bench_ncc.OVERLAP,
-                            kind="oracle")
+    tiles, jit, step = bench_ncc.make_grid(dev, rows=2, cols=2, seed=4321)
+    a, b = tiles[0][0], (tiles[0][1] if direction == 1 else tiles[1][0])
+    d = crossmips.PDAlgoMIPNCC.execute(a, b, *bench_ncc.DISPL, direction, bench_ncc.OVERLAP)
+    want = N.pdalgo_execute(a.cpu().numpy(), b.cpu().numpy(), *bench_ncc.DISPL, direction, bench_ncc.OVERLAP, kind="oracle")
     assert d.VHD_coords == want["coord"] and d.NCC_widths == want["NCC_widths"] and d.wRangeThrs == want["wRangeThr"]
     assert np.allclose(np.array(d.NCC_maxs, np.float32), want["NCC_maxs"], atol=2e-6, equal_nan=True)
-    dj = jit[0, 1] - jit[0, 0]
-    assert d.VHD_coords[0] == int(dj[0]) and d.VHD_coords[1] == step + int(dj[1])
+    dj = jit[0, 1] - jit[0, 0] if direction == 1 else jit[1, 0] - jit[0, 0]
+    nominal = (0, step) if direction == 1 else (step, 0)
+    assert d.VHD_coords[0] == nominal[0] + int(dj[0]) and d.VHD_coords[1] == nominal[1] + int(dj[1])
+    assert d.VHD_coords[2] == int(dj[2])                 # the D offset of the jittered cut

@@ -210,6 +210,20 @@ def test_grid_batch_recovers_jitter(dev):
     shards = [crossmips.compute_displacements(tiles, ov, ov, 8, 8, 3, rank=k, world_size=2) for k in range(2)]
     assert set(shards[0]) | set(shards[1]) == set(res) and not (set(shards[0]) & set(shards[1]))
     assert 0.0 <= next(iter(res.values())).evalReliability(0) <= 1.0
+    # tile-row blocks (the N > 1 partition of bench.py): a rank holds only its rows and the first row behind its cut
+    n_rows, n_cols = len(tiles), len(tiles[0])
+    for world in (2, n_rows):
+        got = {}
+        for r0, r1 in crossmips.tile_row_blocks(n_rows, world, n_cols):
+            keep = set(range(r0, min(r1 + 1, n_rows)))
+            part = [[tiles[r][c] if r in keep else None for c in range(n_cols)] for r in range(n_rows)]
+            mine = crossmips.compute_displacements(part, ov, ov, 8, 8, 3, row_block=(r0, r1))
+            assert not (set(mine) & set(got))
+            got.update(mine)
+        assert {k: (d.VHD_coords, d.NCC_widths, d.NCC_maxs, d.wRangeThrs) for k, d in got.items()} == \
+               {k: (d.VHD_coords, d.NCC_widths, d.NCC_maxs, d.wRangeThrs) for k, d in res.items()}
+    with pytest.raises(ValueError, match="not resident"):
+        crossmips.compute_displacements([[None] * n_cols for _ in range(n_rows)], ov, ov, 8, 8, 3, row_block=(0, 1))
 
 
 # ------------------------------------------------------------------ cases that sit on a tie (tests/golden/make_ncc_tie_golden.py)

@@ -81,6 +81,30 @@ def test_pair_enumeration_and_layers():
     assert X.NCC_parms_t(40, 40, 40).wRangeThr_i == 29 and abs(p.widthThr - 0.8) < 1e-7 and p.maxIter == 2
 
 
+def test_tile_row_blocks_partition_pairs_once_and_balance():
+    """crossmips.tile_row_blocks: contiguous row blocks, every pair of the grid in exactly one block, the first row behind a cut is
+    the only row a second rank needs, largest block minimal for contiguous cuts (Parastitcher.py:1440-1560 farms jobs instead)."""
+    from ipp_amd import crossmips as X
+    for rows, cols, world in [(8, 8, 1), (8, 8, 2), (8, 8, 3), (8, 8, 8), (8, 8, 16), (5, 3, 2), (2, 7, 4), (1, 4, 3)]:
+        blocks = X.tile_row_blocks(rows, world, cols)
+        assert len(blocks) == world and blocks[0][0] == 0 and max(b[1] for b in blocks) == rows
+        assert all(a[1] == b[0] for a, b in zip(blocks, blocks[1:]) if b[0] < rows)
+        pairs = list(X.enumerate_pairs(rows, cols))
+        owned = [[p for p in pairs if r0 <= p[0] < r1] for r0, r1 in blocks]
+        assert sorted(sum(owned, [])) == sorted(pairs)
+        for (r0, r1), mine in zip(blocks, owned):
+            need = {p[0] for p in mine} | {p[2] for p in mine}
+            assert need <= set(range(r0, min(r1 + 1, rows)))
+        # no contiguous partition into the same number of blocks has a smaller largest block
+        import itertools
+        cost = [(cols - 1) + (cols if r + 1 < rows else 0) for r in range(rows)]
+        k = min(world, rows)
+        best = min(max(sum(cost[a:b]) for a, b in zip((0,) + cut, cut + (rows,)))
+                   for cut in itertools.combinations(range(1, rows), k - 1)) if rows else 0
+        assert max(len(m) for m in owned) == best
+    assert X.tile_row_blocks(8, 8, 8) == [(r, r + 1) for r in range(8)]
+
+
 def test_fft_good_size_per_axis():
     """mi_fft_good_size: 2^a * {1,3,9} extents (x: twice such a number; z bounded by the LDS tile; y also 5 * 2^a, a in 5..8)."""
     from ipp_amd import capi
