@@ -204,6 +204,9 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the product path); gloo only to rehearse N > 1 on a one-GPU box")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: all ranks on cuda:0 (with --backend gloo)")
+    ap.add_argument("--transport", default="rccl", choices=["rccl", "peer"],
+                    help="halo exchange at N > 1: grouped send/recv of the process group (RCCL), or hipMemcpyPeerAsync into the "
+                         "neighbour's buffers (copy engines; slab.PeerLink)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -253,10 +256,11 @@ def main():
     else:
         from ipp_amd import slab
         drv = slab.SlabRL(vshape, psf_np, rank=rank, world_size=world, device=dev, flavour="fft", engine=engine,
-                          seed=1234)
+                          seed=1234, transport=args.transport)
         step = drv.iterate
         run_steps = None
-        parallelism = f"y-slabs x{world}, RCCL halo exchange"
+        parallelism = (f"y-slabs x{world}, halo exchange: " +
+                       ("grouped send/recv (RCCL)" if args.transport == "rccl" else "hipMemcpyPeerAsync into the neighbour's buffers"))
         engine_used = drv.ctx.engine
         ctx, bl = drv.ctx, drv.bl                # rank-local context / slab (interior + halo rows) for the per-pass timing
 
@@ -356,6 +360,8 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(vshape, kshape)
     ncc = None
+    if world > 1:
+        drv.close()                                  # (the copy-engine link: mapped peer memory, interprocess events)
     if not args.no_ncc:
         # second metric (BASELINE config 5).  N > 1: tile-row blocks, one block per rank (bench_ncc.py); every rank takes part
         if world > 1:

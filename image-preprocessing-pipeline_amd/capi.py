@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmi_ipp.so")
 
 MI_OK = 0
+IPC_HANDLE_BYTES = 64  # MI_IPC_HANDLE_BYTES
 # mi_boundary / mi_engine (include/mi_lsdeconv.h)
 BOUNDARY_ZERO, BOUNDARY_REPLICATE, BOUNDARY_CIRCULAR = 0, 1, 2
 ENGINE_AUTO, ENGINE_DIRECT, ENGINE_FFT = 0, 1, 2
@@ -107,6 +108,18 @@ SIGNATURES = {
     "mi_fft_good_size": (_i, [_i, _i]),
     "mi_pack_rows": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "mi_unpack_rows": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "mi_peer_alloc": (_i, [_i, _sz, C.POINTER(_vp), C.c_char_p]),
+    "mi_peer_free": (_i, [_i, _vp]),
+    "mi_peer_open": (_i, [_i, C.c_char_p, C.POINTER(_vp)]),
+    "mi_peer_close": (_i, [_i, _vp]),
+    "mi_peer_event_create": (_i, [_i, C.POINTER(_vp), C.c_char_p]),
+    "mi_peer_event_open": (_i, [_i, C.c_char_p, C.POINTER(_vp)]),
+    "mi_peer_event_destroy": (_i, [_i, _vp]),
+    "mi_peer_event_record": (_i, [_i, _vp, _vp]),
+    "mi_peer_stream_wait": (_i, [_i, _vp, _vp]),
+    "mi_peer_stream_create": (_i, [_i, C.POINTER(_vp)]),
+    "mi_peer_stream_destroy": (_i, [_i, _vp]),
+    "mi_peer_copy": (_i, [_i, _vp, _vp, _i, _vp, _sz]),
     # mi_crossmips.h
     "mi_ncc_default_params": (None, [_i, _i, _i, C.POINTER(NccParams)]),
     "mi_ncc_mips": (_i, [_i, _vp, _vp, _vp] + [_i] * 10 + [C.POINTER(NccParams), C.POINTER(NccDescr)]),

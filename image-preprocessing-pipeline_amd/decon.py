@@ -371,11 +371,18 @@ class RLContext:
                                         int(reps), out))
         return float(out[0]), float(out[1])
 
-    def spectrum_pack(self, y0, rows):
-        """Rows [y0, y0+rows) of the x-transformed input buffer as a contiguous float32 device tensor."""
-        buf = torch.empty(int(rows) * int(lib().mi_rl_spectrum_row_floats(self._h)), dtype=torch.float32, device=self.device)
+    def spectrum_pack(self, y0, rows, out=None):
+        """Rows [y0, y0+rows) of the x-transformed input buffer as a contiguous float32 device tensor (``out``: written there)."""
+        n = int(rows) * int(lib().mi_rl_spectrum_row_floats(self._h))
+        buf = torch.empty(n, dtype=torch.float32, device=self.device) if out is None else out
+        if not (buf.is_cuda and buf.dtype == torch.float32 and buf.is_contiguous() and buf.numel() == n):
+            raise ValueError("spectrum_pack: `out` does not hold `rows` spectrum rows")
         check(lib().mi_rl_spectrum_rows(self._h, _stream(buf), int(y0), int(rows), buf.data_ptr(), 0))
         return buf
+
+    def spectrum_unpack_ptr(self, ptr, y0, rows):
+        """``spectrum_unpack`` from a raw device pointer (a receive buffer of the copy-engine transport)."""
+        check(lib().mi_rl_spectrum_rows(self._h, capi.current_stream_ptr(self.device), int(y0), int(rows), int(ptr), 1))
 
     def spectrum_unpack(self, buf, y0, rows):
         if buf is None:

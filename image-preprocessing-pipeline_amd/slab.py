@@ -25,6 +25,7 @@ data path; only the optional stop criterion all-reduces one double.
 """
 from __future__ import annotations
 
+import ctypes as C
 import math
 
 import numpy as np
@@ -76,6 +77,29 @@ class HipOps:
     def zero_rows(self, vol, y0, rows):
         vol[:, y0:y0 + rows, :].zero_()
 
+    # the copy-engine transport packs into its staging buffers and unpacks from raw receive pointers
+    def peer_backend(self):
+        return HipPeer(self.device)
+
+    def halo_floats(self, ctx, lshape, h):
+        return h * lshape[0] * lshape[2]               # h rows of an X x Z plane: real rows and x-transformed rows alike
+
+    def pack_spec_into(self, ctx, y0, rows, out):
+        ctx.spectrum_pack(y0, rows, out=out)
+
+    def unpack_spec_ptr(self, ctx, ptr, y0, rows):
+        ctx.spectrum_unpack_ptr(ptr, y0, rows)
+
+    def pack_into(self, vol, y0, rows, out):
+        nz, ny, nx = vol.shape
+        capi.check(capi.lib().mi_pack_rows(vol.device.index, capi.current_stream_ptr(vol.device), vol.data_ptr(), nx, ny, nz,
+                                           y0, rows, out.data_ptr()))
+
+    def unpack_ptr(self, ptr, vol, y0, rows):
+        nz, ny, nx = vol.shape
+        capi.check(capi.lib().mi_unpack_rows(vol.device.index, capi.current_stream_ptr(vol.device), int(ptr), nx, ny, nz, y0, rows,
+                                             vol.data_ptr()))
+
     # x-transformed rows of the fused pipeline (ctx.fuses)
     def pack_spec(self, ctx, y0, rows):
         return ctx.spectrum_pack(y0, rows)
@@ -84,12 +108,233 @@ class HipOps:
         ctx.spectrum_unpack(packed, y0, rows)
 
 
+class HipPeer:
+    """Device side of the copy-engine transport: HIP IPC memory / event handles, a copy stream and hipMemcpyPeerAsync, all through
+    the C ABI (include/mi_lsdeconv.h, "copy-engine transport")."""
+
+    def __init__(self, device):
+        capi.require_gpu()
+        self.dev = torch.device(device)
+        self.di = self.dev.index
+        self.L = capi.lib()
+        self.stream = C.c_void_p()
+        capi.check(self.L.mi_peer_stream_create(self.di, C.byref(self.stream)))
+        self._packed = torch.cuda.Event()
+
+    def ordinal(self):
+        return int(self.di)
+
+    def alloc(self, nbytes):
+        h, p = C.create_string_buffer(capi.IPC_HANDLE_BYTES), C.c_void_p()
+        capi.check(self.L.mi_peer_alloc(self.di, int(nbytes), C.byref(p), h))
+        return int(p.value), h.raw
+
+    def free(self, ptr):
+        self.L.mi_peer_free(self.di, C.c_void_p(ptr))
+
+    def open(self, handle):
+        q = C.c_void_p()
+        capi.check(self.L.mi_peer_open(self.di, handle, C.byref(q)))
+        return int(q.value)
+
+    def close(self, ptr):
+        self.L.mi_peer_close(self.di, C.c_void_p(ptr))
+
+    def offset(self, base, nbytes):
+        return base + int(nbytes)
+
+    def event(self):
+        e, h = C.c_void_p(), C.create_string_buffer(capi.IPC_HANDLE_BYTES)
+        capi.check(self.L.mi_peer_event_create(self.di, C.byref(e), h))
+        return e, h.raw
+
+    def event_open(self, handle):
+        e = C.c_void_p()
+        capi.check(self.L.mi_peer_event_open(self.di, handle, C.byref(e)))
+        return e
+
+    def event_destroy(self, ev):
+        self.L.mi_peer_event_destroy(self.di, ev)
+
+    def _s(self, copy_stream):
+        return self.stream if copy_stream else C.c_void_p(capi.current_stream_ptr(self.dev))
+
+    def record(self, ev, copy_stream):
+        capi.check(self.L.mi_peer_event_record(self.di, ev, self._s(copy_stream)))
+
+    def wait(self, ev, copy_stream):
+        capi.check(self.L.mi_peer_stream_wait(self.di, self._s(copy_stream), ev))
+
+    def copy_after_launch(self):
+        """The copy stream waits for what the launch stream holds so far (the pack kernels)."""
+        self._packed.record(torch.cuda.current_stream(self.dev))
+        capi.check(self.L.mi_peer_stream_wait(self.di, self.stream, C.c_void_p(self._packed.cuda_event)))
+
+    def copy(self, dst, dst_dev, src_tensor, nbytes):
+        capi.check(self.L.mi_peer_copy(self.di, self.stream, C.c_void_p(dst), int(dst_dev), src_tensor.data_ptr(), int(nbytes)))
+
+    def staging(self, nfloats):
+        return torch.empty(int(nfloats), dtype=torch.float32, device=self.dev)
+
+    def destroy(self):
+        torch.cuda.synchronize(self.dev)
+        self.L.mi_peer_stream_destroy(self.di, self.stream)
+
+
+class PeerLink:
+    """Copy-engine transport of the halo exchange ("peer"): every rank exports ONE device allocation that holds its receive buffers
+    (two sets, alternating between consecutive exchanges, x two halos) and interprocess events; a sender copies its packed rows
+    straight into the neighbour's buffer with ``hipMemcpyPeerAsync`` on a stream of its own -- executed by the SDMA engines, so the
+    persistent x pass that runs meanwhile keeps every compute unit -- and records an interprocess event the receiver's launch
+    stream waits for.  Record and wait of one exchange are ordered by a sequence number per directed edge in a small host
+    shared-memory file (an interprocess event only ever means "its latest record"); the receiver acknowledges a buffer set the
+    same way before the sender overwrites it two exchanges later.  Handles travel once, through ``all_gather_object``.
+
+    Directed edges of rank r: d = 0 "up" (its last interior rows -> lower halo of the next rank), d = 1 "down" (its first interior
+    rows -> upper halo of the previous rank); the receiving slot has the same index d.  ``backend``: HipPeer, or a host double
+    with the same methods (tests/slab_util.py) so that the protocol runs on CPU ranks."""
+
+    SETS = 2
+
+    def __init__(self, drv, nfloats, backend, group=None, timeout_s=120.0):
+        import mmap
+        import os
+        import tempfile
+
+        import torch.distributed as dist
+        self.drv, self.group, self.n, self.timeout = drv, group, 0, float(timeout_s)
+        self.be = backend
+        self.nfloats = int(nfloats)
+        self.nbytes = 4 * self.nfloats
+        self.recv_base, mem_handle = backend.alloc(2 * self.SETS * self.nbytes)
+        self.staging = [[backend.staging(self.nfloats) for _ in range(self.SETS)] for _ in range(2)]
+
+        def make_events():
+            pairs = [backend.event() for _ in range(2 * self.SETS)]
+            return [e for e, _ in pairs], [h for _, h in pairs]
+
+        self.ev_sent, hs_sent = make_events()          # [d * SETS + set]: my copy of edge d into the neighbour's set has been issued
+        self.ev_done, hs_done = make_events()          # [d * SETS + set]: I have consumed slot d, set
+        # host sequence numbers: [rank][d][0 = sent, 1 = consumed] uint64, one file for the job
+        name = [None]
+        if drv.rank == 0:
+            fd, path = tempfile.mkstemp(prefix="mi_halo_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+            os.ftruncate(fd, 8 * 4 * drv.world)
+            os.close(fd)
+            name[0] = path
+        dist.broadcast_object_list(name, src=0, group=group)
+        self.shm_path = name[0]
+        self._fd = os.open(self.shm_path, os.O_RDWR)
+        self._mm = mmap.mmap(self._fd, 8 * 4 * drv.world)
+        self.seq = np.frombuffer(self._mm, dtype=np.uint64).reshape(drv.world, 2, 2)
+        mine = {"mem": mem_handle, "sent": hs_sent, "done": hs_done, "dev": backend.ordinal()}
+        everyone = [None] * drv.world
+        dist.all_gather_object(everyone, mine, group=group)
+        lo, hi = drv.neighbours()
+        self.peer = {}                                  # d -> (rank, mapped base, device ordinal, opened ev_done of its slot d)
+        self.src = {}                                   # d -> (rank that fills my slot d, opened ev_sent of its edge d)
+        self._mapped = {}
+        for d, dst_rank, src_rank in ((0, hi, lo), (1, lo, hi)):
+            if dst_rank is not None:
+                info = everyone[dst_rank]
+                if dst_rank not in self._mapped:
+                    self._mapped[dst_rank] = backend.open(info["mem"])
+                evs = [backend.event_open(info["done"][d * self.SETS + st]) for st in range(self.SETS)]
+                self.peer[d] = (dst_rank, self._mapped[dst_rank], info["dev"], evs)
+            if src_rank is not None:
+                info = everyone[src_rank]
+                self.src[d] = (src_rank, [backend.event_open(info["sent"][d * self.SETS + st]) for st in range(self.SETS)])
+        dist.barrier(group=group)
+        if drv.rank == 0:
+            os.unlink(self.shm_path)                   # every rank holds it open; the name can go
+
+    def _slot(self, base, d, st):
+        return self.be.offset(base, (d * self.SETS + st) * self.nbytes)
+
+    def _host_wait(self, rank, d, field, n):
+        import time
+        t0 = time.monotonic()
+        while int(self.seq[rank, d, field]) < n:
+            if time.monotonic() - t0 > self.timeout:
+                raise TimeoutError(f"halo exchange {n}: rank {rank} did not {'issue its copy' if field == 0 else 'release its buffer'} "
+                                   f"within {self.timeout:.0f} s")
+
+    def begin(self):
+        """Next exchange: the staging buffers (edge 0, edge 1) to pack the rows into, on the launch stream."""
+        self.n += 1
+        st = self.n % self.SETS
+        out = []
+        for d in (0, 1):
+            if d in self.peer and self.n > self.SETS:   # the copy that read this staging buffer two exchanges ago must have run
+                self.be.wait(self.ev_sent[d * self.SETS + st], False)
+            out.append(self.staging[d][st] if d in self.peer else None)
+        return out
+
+    def send(self):
+        """The rows are packed (launch stream): copy them into the neighbours' buffers on the copy stream."""
+        st = self.n % self.SETS
+        if self.peer:
+            self.be.copy_after_launch()
+        for d in (0, 1):
+            if d not in self.peer:
+                continue
+            rank, base, pdev, ev_done = self.peer[d]
+            if self.n > self.SETS:                      # the neighbour has consumed what exchange n - SETS left in this set
+                self._host_wait(rank, d, 1, self.n - self.SETS)
+                self.be.wait(ev_done[st], True)
+            self.be.copy(self._slot(base, d, st), pdev, self.staging[d][st], self.nbytes)
+            self.be.record(self.ev_sent[d * self.SETS + st], True)
+            self.seq[self.drv.rank, d, 0] = self.n
+
+    def receive(self, d):
+        """The rows that arrived in slot d (None: global edge) as the backend's pointer; the launch stream waits for them."""
+        if d not in self.src:
+            return None
+        st = self.n % self.SETS
+        rank, ev_sent = self.src[d]
+        self._host_wait(rank, d, 0, self.n)
+        self.be.wait(ev_sent[st], False)
+        return self._slot(self.recv_base, d, st)
+
+    def release(self):
+        """The received rows have been unpacked (launch stream): the senders may overwrite this set."""
+        st = self.n % self.SETS
+        for d in self.src:
+            self.be.record(self.ev_done[d * self.SETS + st], False)
+            self.seq[self.drv.rank, d, 1] = self.n
+
+    def close(self):
+        import os
+        try:
+            for _, (_, _, _, evs) in self.peer.items():
+                for e in evs:
+                    self.be.event_destroy(e)
+            for _, (_, evs) in self.src.items():
+                for e in evs:
+                    self.be.event_destroy(e)
+            for q in self._mapped.values():
+                self.be.close(q)
+            for e in self.ev_sent + self.ev_done:
+                self.be.event_destroy(e)
+            self.be.destroy()
+            self.be.free(self.recv_base)
+            self.seq = None
+            self._mm.close()
+            os.close(self._fd)
+        except Exception:
+            pass
+        self.peer, self.src, self._mapped = {}, {}, {}
+
+
 class SlabRL:
     def __init__(self, global_shape_zyx, psf, rank=0, world_size=1, device=None, flavour="fft", engine=ENGINE_AUTO,
-                 volume=None, seed=None, ops=None, group=None):
+                 volume=None, seed=None, ops=None, group=None, transport="rccl"):
         if flavour not in ("fft", "spatial"):
             raise ValueError("flavour must be 'fft' (deconFFT) or 'spatial' (deconSpatial)")
+        if transport not in ("rccl", "peer"):
+            raise ValueError("transport must be 'rccl' (grouped send/recv of torch.distributed) or 'peer' (hipMemcpyPeerAsync)")
         self.rank, self.world, self.flavour, self.group = int(rank), int(world_size), flavour, group
+        self.transport, self.link = transport, None
         self.gshape = tuple(int(s) for s in global_shape_zyx)
         self.psf = np.ascontiguousarray(psf, dtype=np.float32)
         gz, gy, gx = self.gshape
@@ -178,6 +423,21 @@ class SlabRL:
             return None
         spec = vol is None
         lo_src, hi_src = self.neighbours()
+        if self.transport == "peer" and self.world > 1:
+            # copy engines: pack straight into the link's staging buffers, peer copies on the link's stream
+            h, n = self.h, self.n_loc
+            if self.link is None:
+                self.link = PeerLink(self, self.ops.halo_floats(self.ctx, self.lshape, h), self.ops.peer_backend(), self.group)
+            up, dn = self.link.begin()
+            for buf, y0 in ((up, n), (dn, h)):          # last h / first h interior rows
+                if buf is None:
+                    continue
+                if spec:
+                    self.ops.pack_spec_into(self.ctx, y0, h, buf)
+                else:
+                    self.ops.pack_into(vol, y0, h, buf)
+            self.link.send()
+            return ("peer", vol)
         send_up, send_dn = self.pack_spec_halos() if spec else self.pack_halos(vol)
         if self.world == 1:  # self-ring: my own rows wrap around
             return (vol, [], send_up if lo_src is not None else None, send_dn if hi_src is not None else None, False)
@@ -204,6 +464,21 @@ class SlabRL:
 
     def exchange_finish(self, state):
         if state is None:
+            return
+        if state[0] == "peer":
+            vol, h, n = state[1], self.h, self.n_loc
+            for d, y0 in ((0, 0), (1, h + n)):
+                ptr = self.link.receive(d)               # the launch stream waits for the neighbour's copy
+                if vol is None:
+                    if ptr is None:
+                        self.ops.unpack_spec(self.ctx, None, y0, h)   # global edge of the spatial flavour: zero rows
+                    else:
+                        self.ops.unpack_spec_ptr(self.ctx, ptr, y0, h)
+                elif ptr is None:
+                    self.ops.zero_rows(vol, y0, h)
+                else:
+                    self.ops.unpack_ptr(ptr, vol, y0, h)
+            self.link.release()
             return
         vol, reqs, recv_lo, recv_hi, staged = state[:5]
         for req in reqs:
@@ -266,6 +541,13 @@ class SlabRL:
                 if i > 1 and rel <= stop_criterion:
                     break
         return done
+
+    def close(self):
+        """Releases the copy-engine link (mapped peer memory, interprocess events); every rank calls it before the process group
+        goes away."""
+        if self.link is not None:
+            self.link.close()
+            self.link = None
 
     def interior(self):
         return self.bl[:, self.h:self.h + self.n_loc, :]

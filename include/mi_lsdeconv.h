@@ -262,6 +262,33 @@ int mi_next_fast_len(int n);
 int mi_pack_rows(int dev, void* stream, const float* vol, int nx, int ny, int nz, int y0, int rows, float* packed);
 int mi_unpack_rows(int dev, void* stream, const float* packed, int nx, int ny, int nz, int y0, int rows, float* vol);
 
+/* ---- copy-engine transport of the halo exchange (one process per GPU; no reference counterpart: LsDeconv.m:643-654 farms
+ * independent blocks out) ---------------------------------------------------------------------------------------------------
+ * Device buffers and events shared between the ranks of one node through HIP IPC handles (opaque MI_IPC_HANDLE_BYTES-byte
+ * blobs [host] that travel over any host channel), and hipMemcpyPeerAsync on a stream of the caller's choice: a peer copy is
+ * executed by the SDMA engines and takes no compute unit away from the persistent x pass it overlaps with, unlike the kernels
+ * of a grouped ncclSend/ncclRecv.  slab.py builds its "peer" transport from these (receive buffers exported once, two
+ * interprocess events per directed edge, a host-side sequence number in shared memory that orders record and wait). */
+#define MI_IPC_HANDLE_BYTES 64
+/* a device allocation of its own (hipMalloc, never a block of the library's pool) and its IPC handle */
+int mi_peer_alloc(int dev, size_t bytes, void** ptr, unsigned char* handle);
+int mi_peer_free(int dev, void* ptr);
+/* maps another process' allocation into this one (hipIpcOpenMemHandle, peer access enabled lazily) / unmaps it */
+int mi_peer_open(int dev, const unsigned char* handle, void** ptr);
+int mi_peer_close(int dev, void* ptr);
+/* interprocess event (hipEventInterprocess | hipEventDisableTiming) and its handle; the other process opens it */
+int mi_peer_event_create(int dev, void** event, unsigned char* handle);
+int mi_peer_event_open(int dev, const unsigned char* handle, void** event);
+int mi_peer_event_destroy(int dev, void* event);
+int mi_peer_event_record(int dev, void* event, void* stream);
+int mi_peer_stream_wait(int dev, void* stream, void* event);
+/* a non-blocking stream for the copies (torch's streams would do as well; this keeps the transport free of torch) */
+int mi_peer_stream_create(int dev, void** stream);
+int mi_peer_stream_destroy(int dev, void* stream);
+/* dst (a mapped peer pointer on device dst_dev, or any device pointer) <- src on `dev`, `bytes` bytes, in stream order:
+ * hipMemcpyPeerAsync; dst_dev outside the visible ordinals: hipMemcpyAsync on the mapped pointer */
+int mi_peer_copy(int dev, void* stream, void* dst, int dst_dev, const void* src, size_t bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -81,11 +81,114 @@ class NumpyCtx:
         bl.copy_(torch.from_numpy(np.abs(b * self._conv(ratio.numpy(), True)).astype(np.float32)))
 
 
+class ShmPeer:
+    """Host double of slab.HipPeer for CPU ranks: "device" allocations are shared-memory files, a handle is the file's path, a
+    pointer is (array, byte offset); copies are host memcpys that complete at once, so events have nothing to order -- what is
+    left to test is the link's own protocol: sequence numbers, alternating buffer sets, acknowledgements, teardown."""
+
+    def __init__(self):
+        self.files, self.events = [], 0
+
+    def ordinal(self):
+        return 0
+
+    def alloc(self, nbytes):
+        import os
+        import tempfile
+        fd, path = tempfile.mkstemp(prefix="mi_peer_test_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+        os.ftruncate(fd, int(nbytes))
+        os.close(fd)
+        arr = np.memmap(path, dtype=np.uint8, mode="r+")
+        arr[:] = 0xFF                                   # (NaN pattern: stale reads would show)
+        self.files.append(path)
+        return (arr, 0), path.encode()
+
+    def free(self, ptr):
+        import os
+        for f in self.files:
+            try:
+                os.unlink(f)
+            except OSError:
+                pass
+
+    def open(self, handle):
+        return (np.memmap(handle.decode(), dtype=np.uint8, mode="r+"), 0)
+
+    def close(self, ptr):
+        pass
+
+    def offset(self, base, nbytes):
+        return (base[0], base[1] + int(nbytes))
+
+    def event(self):
+        self.events += 1
+        return self.events, b"ev%d" % self.events
+
+    def event_open(self, handle):
+        return handle
+
+    def event_destroy(self, ev):
+        pass
+
+    def record(self, ev, copy_stream):
+        pass
+
+    def wait(self, ev, copy_stream):
+        pass
+
+    def copy_after_launch(self):
+        pass
+
+    def copy(self, dst, dst_dev, src_tensor, nbytes):
+        arr, off = dst
+        arr[off:off + nbytes] = src_tensor.numpy().view(np.uint8).reshape(-1)[:nbytes]
+
+    def staging(self, nfloats):
+        return torch.empty(int(nfloats), dtype=torch.float32)
+
+    def destroy(self):
+        pass
+
+
+def _ptr_tensor(ptr, nfloats):
+    arr, off = ptr
+    return torch.from_numpy(np.array(arr[off:off + 4 * nfloats]).view(np.float32))
+
+
 class NumpyOps:
     device = torch.device("cpu")
 
     def __init__(self, fuses=0):
         self.fuses = int(fuses)
+
+    def peer_backend(self):
+        return ShmPeer()
+
+    def halo_floats(self, ctx, lshape, h):
+        F = ctx.otf.shape                               # the double's spectra are complex128 on its padded grid
+        return max(lshape[0] * h * lshape[2], 4 * F[0] * h * F[2])
+
+    def pack_spec_into(self, ctx, y0, rows, out):
+        t = self._spec_f32(ctx, y0, rows)
+        out[:t.numel()].copy_(t)
+
+    @staticmethod
+    def _spec_f32(ctx, y0, rows):
+        # the double keeps float64 spectra; the link moves float32 words, so a complex128 row travels as four of them
+        return torch.from_numpy(np.ascontiguousarray(ctx.S[:, y0:y0 + rows, :]).view(np.float32).reshape(-1).copy())
+
+    def unpack_spec_ptr(self, ctx, ptr, y0, rows):
+        nz, _, nx = ctx.S.shape
+        t = _ptr_tensor(ptr, 4 * nz * rows * nx)
+        ctx.S[:, y0:y0 + rows, :] = t.numpy().view(np.complex128).reshape(nz, rows, nx)
+
+    def pack_into(self, vol, y0, rows, out):
+        t = vol[:, y0:y0 + rows, :].reshape(-1)
+        out[:t.numel()].copy_(t)
+
+    def unpack_ptr(self, ptr, vol, y0, rows):
+        nz, _, nx = vol.shape
+        vol[:, y0:y0 + rows, :] = _ptr_tensor(ptr, nz * rows * nx).reshape(nz, rows, nx)
 
     def make_ctx(self, lshape, psf, boundary_xyz, shift_xyz, engine, psf_inv=None):
         ctx = NumpyCtx(lshape, psf, boundary_xyz, shift_xyz, psf_inv)

@@ -1,0 +1,68 @@
+"""GPU: the copy-engine transport of the slab driver (slab.PeerLink on slab.HipPeer: HIP IPC memory and event handles,
+hipMemcpyPeerAsync on a stream of its own) with TWO processes that share the one GPU of the test box -- a rehearsal of the
+one-process-per-GPU layout: the handles cross a real process boundary, the copies land in the other process' buffers, the
+launch streams wait on interprocess events.  (Over xGMI the same calls address another device; that needs the 8-GPU node.)"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from oracle import rl_oracle as R
+from tests.rl_util import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, flavour, engine, vol, psf, niter, out):
+    import torch.distributed as dist
+    from ipp_amd import slab
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["MI_FFT_NATIVE_INFLATE"] = "100"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda", 0)
+        drv = slab.SlabRL(vol.shape, psf, rank=rank, world_size=world, device=dev, flavour=flavour, engine=engine, volume=vol,
+                          transport="peer")
+        drv.run(niter)
+        assert drv.link is not None and drv.link.n > drv.link.SETS
+        mine = drv.interior().cpu().contiguous()
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        info = (drv.sharded, drv.overlap, drv.link.n)
+        drv.close()
+        if rank == 0:
+            out.put((torch.cat(parts, dim=1).numpy(), info))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("flavour,engine", [("fft", 2), ("spatial", 2), ("fft", 1)],
+                         ids=["fused_overlapped_ring", "fused_zero_edges", "real_halos_direct_engine"])
+def test_two_processes_one_gpu_peer_copy_transport(dev, flavour, engine):
+    psf = R.gaussian_psf((5, 7, 5), (1.0, 1.5, 1.0))
+    vol = R.bead_volume((16, 128, 32), seed=33, psf=psf)
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = 29800 + (os.getpid() % 150) + (0 if flavour == "fft" else 1) + 2 * engine
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, flavour, engine, vol, psf, 4, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        got, (sharded, overlap, n_exchanges) = out.get(timeout=240)
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()
+    assert all(p.exitcode == 0 for p in procs)
+    want = (R.decon_fft(vol, psf, vol.shape, 4, skip_edgetaper=True) if flavour == "fft"
+            else R.decon_spatial(vol, psf, 4, skip_edgetaper=True))
+    assert_close(got, want)
+    assert sharded == (engine == 2)
+    assert n_exchanges == (2 * 4 + 1 if sharded else 2 * 4)
+    if engine == 2 and flavour == "fft" and not os.environ.get("MI_FFT_NO_PIPE"):
+        assert overlap                                  # edge tiles first, copies issued, remaining tiles, then the wait

@@ -20,18 +20,23 @@ def _rel(a, b):
     return float(np.abs(a.astype(np.float64) - b).max() / np.abs(b).max())
 
 
-def _worker(rank, world, port, flavour, vol, psf, niter, out, fuses=0):
+def _worker(rank, world, port, flavour, vol, psf, niter, out, fuses=0, transport="rccl"):
     import torch.distributed as dist
     from ipp_amd import slab
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        drv = slab.SlabRL(vol.shape, psf, rank=rank, world_size=world, flavour=flavour, volume=vol, ops=NumpyOps(fuses))
+        drv = slab.SlabRL(vol.shape, psf, rank=rank, world_size=world, flavour=flavour, volume=vol, ops=NumpyOps(fuses),
+                          transport=transport)
         assert drv.sharded == bool(fuses) and drv.overlap == (fuses == 2)
         n0 = drv.norm2()
         drv.run(niter)
+        if transport == "peer":
+            # exchanges so far (fused protocol: 1 + 2 per iteration; real-space protocol: 2 per iteration), both buffer sets used
+            assert drv.link is not None and drv.link.n == (2 * niter + 1 if fuses else 2 * niter) and drv.link.n > drv.link.SETS
         full = drv.gather()
+        drv.close()
         if rank == 0:
             out.put((full.numpy(), n0))
     finally:
@@ -39,15 +44,18 @@ def _worker(rank, world, port, flavour, vol, psf, niter, out, fuses=0):
 
 
 @pytest.mark.parametrize("flavour", ["fft", "spatial"])
+@pytest.mark.parametrize("transport", ["rccl", "peer"], ids=["send_recv", "peer_copy"])
 @pytest.mark.parametrize("fuses", [0, 1, 2], ids=["real_halos", "spectrum_halos", "spectrum_halos_overlapped"])
-def test_two_gloo_ranks_equal_unsharded_oracle(flavour, fuses):
+def test_two_gloo_ranks_equal_unsharded_oracle(flavour, fuses, transport):
     """Both halo protocols: real-space rows around forward_ratio / adjoint_update, and x-transformed rows around the fused
-    steps (the protocol of the native FFT pipeline)."""
+    steps (the protocol of the native FFT pipeline); both transports: grouped send / receive of the process group, and the
+    copy-engine link (buffers of the neighbour written directly, sequence numbers in shared memory; host double of the device
+    side: tests/slab_util.py:ShmPeer)."""
     vol, psf = _case()
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
-    port = 29600 + (os.getpid() % 200) + (0 if flavour == "fft" else 1) + 2 * fuses
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, flavour, vol, psf, 3, out, fuses)) for r in range(2)]
+    port = 29600 + (os.getpid() % 200) + (0 if flavour == "fft" else 1) + 2 * fuses + (6 if transport == "peer" else 0)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, flavour, vol, psf, 3, out, fuses, transport)) for r in range(2)]
     for p in procs:
         p.start()
     got, n0 = out.get(timeout=120)
