@@ -341,6 +341,11 @@ class RLContext:
     def otf_is_real(self) -> bool:
         return bool(lib().mi_rl_otf_is_real(self._h))
 
+    @property
+    def spectrum_row_floats(self) -> int:
+        """float32 words of one row (all z, all x frequencies) of the x-transformed input buffer."""
+        return int(lib().mi_rl_spectrum_row_floats(self._h))
+
     def sharded_begin(self, bl):
         self._chk(bl)
         check(lib().mi_rl_sharded_begin(self._h, _stream(bl), bl.data_ptr()))

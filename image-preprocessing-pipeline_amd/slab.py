@@ -82,16 +82,18 @@ class HipOps:
         return HipPeer(self.device)
 
     def halo_floats(self, ctx, lshape, h):
-        return h * lshape[0] * lshape[2]               # h rows of an X x Z plane: real rows and x-transformed rows alike
+        # h rows of an X x Z plane as real rows; as x-transformed rows of the context's (possibly zero-padded) transform grid
+        return max(h * lshape[0] * lshape[2], h * ctx.spectrum_row_floats if getattr(ctx, "fuses", 0) else 0)
 
     def pack_spec_into(self, ctx, y0, rows, out):
-        ctx.spectrum_pack(y0, rows, out=out)
+        ctx.spectrum_pack(y0, rows, out=out[:rows * ctx.spectrum_row_floats])
 
     def unpack_spec_ptr(self, ctx, ptr, y0, rows):
         ctx.spectrum_unpack_ptr(ptr, y0, rows)
 
     def pack_into(self, vol, y0, rows, out):
         nz, ny, nx = vol.shape
+        assert out.numel() >= nz * rows * nx
         capi.check(capi.lib().mi_pack_rows(vol.device.index, capi.current_stream_ptr(vol.device), vol.data_ptr(), nx, ny, nz,
                                            y0, rows, out.data_ptr()))
 

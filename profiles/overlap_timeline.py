@@ -15,7 +15,7 @@ with open(path) as f:
         name = r["Kernel_Name"]
         if "k_busy" in name or "k_x_fused_pipe" in name:
             rows.append(("busy" if "k_busy" in name else "x", int(r["Start_Timestamp"]), int(r["End_Timestamp"]),
-                         int(r.get("Workgroup_Size", 0) or 0), int(r.get("Grid_Size", 0) or 0)))
+                         int(r.get("Workgroup_Size_X", r.get("Workgroup_Size", 0)) or 0), int(r.get("Grid_Size_X", r.get("Grid_Size", 0)) or 0)))
 rows.sort(key=lambda r: r[1])
 # the probe's loop order (busy > 0 only; every variant = warm-up + one repetition, the repetition is printed)
 variants = [(b, us, dyn, free) for b, us in ((8, 300), (8, 1500), (32, 300), (32, 1500)) for dyn in (False, True) for free in (0, 8, 32)]
