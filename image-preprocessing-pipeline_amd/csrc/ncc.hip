@@ -149,31 +149,55 @@ extern "C" int mi_ncc_mips_batch(int dev, void* stream, int n_pairs, const float
             k.side = side[q]; k.ni = ni[q]; k.nj = nj[q]; k.p = params[q];
             groups[k].push_back(q);
         }
+        // every group's device stage is enqueued before the first one is waited for: the host rules of a group run while the next
+        // group's kernels do, and the tail of one group's lag chain overlaps the next group's MIP pass
+        struct InFlight {
+            const std::vector<int>* idx;
+            LagJob* job;
+            std::vector<const float*> pa, pb;
+            std::vector<mi_ncc_params> pp;
+        };
+        std::vector<InFlight> flights;
+        int rc = MI_OK;
         for (auto& kv : groups) {
             const std::vector<int>& idx = kv.second;
             const int q0 = idx[0], n = (int)idx.size();
             {   // the reference's parameter checks, on a copy
                 mi_ncc_params probe = params[q0];
                 PairPlan pl;
-                MI_TRY(plan_pair(dimk, dimi, dimj, 0, ni[q0], nj[q0], delayk, delayi, delayj, side[q0], &probe, pl));
+                rc = plan_pair(dimk, dimi, dimj, 0, ni[q0], nj[q0], delayk, delayi, delayj, side[q0], &probe, pl);
+                if (rc != MI_OK) break;
             }
             if (!ncc_lag_supported(dimk, dimi, dimj, ni[q0], nj[q0], delayk, delayi, delayj, side[q0], &params[q0])) {
                 todo.insert(todo.end(), idx.begin(), idx.end());
                 continue;
             }
-            std::vector<const float*> pa(n), pb(n);
-            std::vector<mi_ncc_params> pp(n);
+            flights.emplace_back();
+            InFlight& f = flights.back();
+            f.idx = &idx;
+            f.job = nullptr;
+            f.pa.resize(n); f.pb.resize(n); f.pp.resize(n);
+            for (int i = 0; i < n; ++i) { f.pa[i] = tiles[a_idx[idx[i]]]; f.pb[i] = tiles[b_idx[idx[i]]]; f.pp[i] = params[idx[i]]; }
+            rc = ncc_lag_enqueue(dev, user, n, f.pa.data(), f.pb.data(), dimk, dimi, dimj, ni[q0], nj[q0], delayk, delayi, delayj, side[q0],
+                                 f.pp.data(), &f.job);
+            if (rc != MI_OK) break;
+        }
+        for (InFlight& f : flights) {
+            if (rc != MI_OK) { ncc_lag_abandon(f.job); continue; }
+            const std::vector<int>& idx = *f.idx;
+            const int n = (int)idx.size();
             std::vector<mi_ncc_descr> po(n);
             std::vector<unsigned char> careful(n, 1);
-            for (int i = 0; i < n; ++i) { pa[i] = tiles[a_idx[idx[i]]]; pb[i] = tiles[b_idx[idx[i]]]; pp[i] = params[idx[i]]; }
-            MI_TRY(ncc_lag_group(dev, user, n, pa.data(), pb.data(), dimk, dimi, dimj, ni[q0], nj[q0], delayk, delayi, delayj, side[q0], pp.data(),
-                                 po.data(), careful.data()));
+            rc = ncc_lag_finish(f.job, f.pp.data(), po.data(), careful.data());
+            f.job = nullptr;
+            if (rc != MI_OK) continue;
             for (int i = 0; i < n; ++i) {
                 if (careful[i]) { todo.push_back(idx[i]); continue; }
-                params[idx[i]] = pp[i];
+                params[idx[i]] = f.pp[i];
                 out[idx[i]] = po[i];
             }
         }
+        if (rc != MI_OK) return rc;
         if (todo.empty()) return MI_OK;
         std::sort(todo.begin(), todo.end());
     } else {

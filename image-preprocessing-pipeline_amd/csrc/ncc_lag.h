@@ -10,7 +10,15 @@ namespace mi {
 float ncc_margin();
 // whether every plane of this geometry fits the lag transform (FFT length <= 8192, LDS)
 bool ncc_lag_supported(int dimk, int dimi, int dimj, int ni, int nj, int delayk, int delayi, int delayj, int side, const mi_ncc_params* p);
-// n pairs of one geometry; careful[q] != 0: pair q must be redone by the per-pair path, out[q] untouched.  One stream sync.
+// n pairs of one geometry in two steps, so that several groups can be in flight: enqueue the device stage (on streams of the job's
+// own, behind what `s` holds so far), then wait for it and run the host rules.  careful[q] != 0: pair q must be redone by the
+// per-pair path, out[q] untouched.  A job that is not finished must be abandoned.
+struct LagJob;
+int ncc_lag_enqueue(int dev, hipStream_t s, int n, const float* const* a_ptrs, const float* const* b_ptrs, int dimk, int dimi, int dimj, int ni,
+                    int nj, int delayk, int delayi, int delayj, int side, mi_ncc_params* params, LagJob** job);
+int ncc_lag_finish(LagJob* job, mi_ncc_params* params, mi_ncc_descr* out, unsigned char* careful);
+void ncc_lag_abandon(LagJob* job);
+// both steps at once
 int ncc_lag_group(int dev, hipStream_t s, int n, const float* const* a_ptrs, const float* const* b_ptrs, int dimk, int dimi, int dimj, int ni,
                   int nj, int delayk, int delayi, int delayj, int side, mi_ncc_params* params, mi_ncc_descr* out, unsigned char* careful);
 int ncc_lag_map(int dev, hipStream_t s, const float* mip1, const float* mip2, int dimu, int dimv, int delayu, int delayv, float* map);

@@ -618,6 +618,30 @@ struct LagWorkspace {
     int dev = -1;
     DevBuf fbuf, sat, mip_tmp, SF, ST, CH, cross, outw, outi, tab;
     PinnedBuf pin_tab, pin_w, pin_i;
+    // Two streams of its own: the MIP pass (k_mips: one HBM-bound streaming read of both overlap views) of piece i + 1 runs on
+    // `sm` while the table / lag-transform / refinement chain (fp64 and LDS work on a few MB) of piece i runs on `sl`.
+    hipStream_t sm = nullptr, sl = nullptr;
+    hipEvent_t ev_start = nullptr, ev_lag = nullptr;
+    std::vector<hipEvent_t> ev_mip;
+    ~LagWorkspace() {
+        if (sm) (void)hipStreamDestroy(sm);
+        if (sl) (void)hipStreamDestroy(sl);
+        if (ev_start) (void)hipEventDestroy(ev_start);
+        if (ev_lag) (void)hipEventDestroy(ev_lag);
+        for (hipEvent_t e : ev_mip) (void)hipEventDestroy(e);
+    }
+    int streams(size_t pieces) {
+        if (!sm) MI_HIP(hipStreamCreateWithFlags(&sm, hipStreamNonBlocking));
+        if (!sl) MI_HIP(hipStreamCreateWithFlags(&sl, hipStreamNonBlocking));
+        if (!ev_start) MI_HIP(hipEventCreateWithFlags(&ev_start, hipEventDisableTiming));
+        if (!ev_lag) MI_HIP(hipEventCreateWithFlags(&ev_lag, hipEventDisableTiming));
+        while (ev_mip.size() < pieces) {
+            hipEvent_t e = nullptr;
+            MI_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            ev_mip.push_back(e);
+        }
+        return MI_OK;
+    }
 };
 std::mutex& g_lag_mu = *new std::mutex;
 std::vector<std::unique_ptr<LagWorkspace>>& g_lag_ws = *new std::vector<std::unique_ptr<LagWorkspace>>;
@@ -744,23 +768,43 @@ bool ncc_lag_supported(int dimk, int dimi, int dimj, int ni, int nj, int delayk,
     return true;
 }
 
-// n pairs of ONE geometry (same side, nominal offsets and parameters): device stage of all of them, then the host rules.
-// careful[q] is set for pairs whose result was not taken here (see the header of this file); out[q] is then untouched.
-int ncc_lag_group(int dev, hipStream_t s, int n, const float* const* a_ptrs, const float* const* b_ptrs, int dimk, int dimi, int dimj, int ni,
-                  int nj, int delayk, int delayi, int delayj, int side, mi_ncc_params* params, mi_ncc_descr* out, unsigned char* careful) {
-    if (n <= 0) return MI_OK;
+// A group in flight: n pairs of ONE geometry (same side, nominal offsets and parameters) whose device stage has been enqueued.
+struct LagJob {
+    std::unique_ptr<LagWorkspace> ws;
     PairPlan pl;
+    LagPlane lp[3];
+    int n = 0, wcap = 1, ni = 0, nj = 0, side = 0;
+    float margin = 0.0f;
+    ~LagJob() {
+        if (ws) {
+            // (whatever the call that owned this job enqueued must not outlive the buffers' next user)
+            if (ws->sm) (void)hipStreamSynchronize(ws->sm);
+            if (ws->sl) (void)hipStreamSynchronize(ws->sl);
+            give_lag_ws(std::move(ws));
+        }
+    }
+};
+
+// Device stage of a group: enqueued behind the work `s` holds so far, on the workspace's two streams.  The pairs go through in
+// pieces (MI_NCC_PIECES, default 4 per group): the MIP pass of piece i + 1 overlaps the table / lag / refinement chain of piece i.
+int ncc_lag_enqueue(int dev, hipStream_t s, int n, const float* const* a_ptrs, const float* const* b_ptrs, int dimk, int dimi, int dimj, int ni,
+                    int nj, int delayk, int delayi, int delayj, int side, mi_ncc_params* params, LagJob** job_out) {
+    *job_out = nullptr;
+    if (n <= 0) return MI_OK;
+    std::unique_ptr<LagJob> job(new (std::nothrow) LagJob);
+    if (!job) return fail(MI_ERR_NOMEM, "mi_ncc_mips_batch: out of host memory");
+    PairPlan& pl = job->pl;
     for (int q = 0; q < n; ++q) MI_TRY(plan_pair(dimk, dimi, dimj, 0, ni, nj, delayk, delayi, delayj, side, &params[q], pl));
     const mi_ncc_params& P = params[0];
-    LagPlane lp[3];
+    LagPlane* lp = job->lp;
     for (int m = 0; m < 3; ++m) {
         lp[m] = plan_lag_plane(pl.g[m], P.maxIter);
         MI_REQUIRE(lp[m].ok, "mi_ncc_mips_batch: plane %d does not fit the lag transform", m);
     }
-    std::unique_ptr<LagWorkspace> wsp = take_lag_ws(dev);
-    if (!wsp) return fail(MI_ERR_NOMEM, "mi_ncc_mips_batch: out of host memory");
-    LagWorkspace& ws = *wsp;
-    struct Giver { std::unique_ptr<LagWorkspace>& p; ~Giver() { give_lag_ws(std::move(p)); } } giver{wsp};
+    job->ws = take_lag_ws(dev);
+    if (!job->ws) return fail(MI_ERR_NOMEM, "mi_ncc_mips_batch: out of host memory");
+    LagWorkspace& ws = *job->ws;
+    job->n = n; job->ni = ni; job->nj = nj; job->side = side;
 
     // per-pair footprint -> chunk size
     size_t sat_off[3], sstride = 0;
@@ -778,10 +822,14 @@ int ncc_lag_group(int dev, hipStream_t s, int n, const float* const* a_ptrs, con
         crs = std::max(crs, 8 * (size_t)(2 * lp[m].Eu + 1) * (2 * lp[m].Ev + 1));
         wcap = std::max(wcap, (2 * pl.g[m].wu + 1) * (2 * pl.g[m].wv + 1));
     }
+    job->wcap = wcap;
     const size_t per_pair = 4 * (pstride + tmp_floats) + 8 * sstride + spec + crs + 3 * 4 * (size_t)wcap + 64;
     size_t budget = (size_t)6 << 30;
     if (const char* e = std::getenv("MI_NCC_CHUNK_MB")) budget = (size_t)std::max(1, std::atoi(e)) << 20;
     const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, budget / per_pair));
+    int pieces = 4;
+    if (const char* e = std::getenv("MI_NCC_PIECES")) pieces = std::max(1, std::min(64, std::atoi(e)));
+    const int piece = std::max(1, (chunk + pieces - 1) / pieces);
 
     MI_TRY(grow(ws.fbuf, 4 * pstride * chunk));
     MI_TRY(grow(ws.sat, 8 * sstride * chunk));
@@ -793,38 +841,69 @@ int ncc_lag_group(int dev, hipStream_t s, int n, const float* const* a_ptrs, con
     MI_TRY(ws.pin_tab.reserve(sizeof(void*) * 2 * (size_t)n));
     MI_TRY(ws.pin_w.reserve(4 * (size_t)3 * wcap * n));
     MI_TRY(ws.pin_i.reserve(sizeof(int) * 3 * 4 * (size_t)n));
+    MI_TRY(ws.streams((size_t)(chunk + piece - 1) / piece));
     const float** htab = ws.pin_tab.as<const float*>();
     for (int q = 0; q < n; ++q) {
         MI_REQUIRE(a_ptrs[q] && b_ptrs[q], "mi_ncc_mips_batch: null tile");
         htab[2 * q] = a_ptrs[q];
         htab[2 * q + 1] = b_ptrs[q];
     }
-    const float margin = ncc_margin();
-    float* base = ws.fbuf.as<float>();
+    const float margin = job->margin = ncc_margin();
+    float* base0 = ws.fbuf.as<float>();
+    hipStream_t sm = ws.sm, sl = ws.sl;
+    MI_HIP(hipEventRecord(ws.ev_start, s));
+    MI_HIP(hipStreamWaitEvent(sm, ws.ev_start, 0));
+    MI_HIP(hipStreamWaitEvent(sl, ws.ev_start, 0));
     for (int c0 = 0; c0 < n; c0 += chunk) {
         const int nc = std::min(chunk, n - c0);
-        MI_HIP(hipMemcpyAsync(ws.tab.p, htab + 2 * c0, sizeof(void*) * 2 * nc, hipMemcpyHostToDevice, s));
-        MI_TRY(launch_mips(s, nullptr, nullptr, ws.tab.as<const float*>(), nc, pstride, pl.dimk, pl.dimi_v, pl.dimj_v, (size_t)dimi * dimj, dimj,
-                           pl.ai0, pl.aj0, base + pl.g[0].mip1, base + pl.g[1].mip1, base + pl.g[2].mip1, base + pl.g[0].mip2, base + pl.g[1].mip2,
-                           base + pl.g[2].mip2, ws.mip_tmp.as<float>()));
-        for (int m = 0; m < 3; ++m) {
-            const PlaneGeom& g = pl.g[m];
-            MI_TRY(prepare_plane_band(s, base + g.mip1, base + g.mip2, g, lp[m], base + g.ps1, base + g.ps2, ws.sat.as<double>() + sat_off[m], nc,
-                                      pstride, sstride));
-            MI_TRY(lag_cross(dev, s, lp[m], base + g.mip1, base + g.mip2, pstride, nc, ws));
-            const RefineGeom rg = refine_geom(g, lp[m], P.maxIter, sstride, sat_off[m], margin);
-            if (lp[m].lds_refine > 64 * 1024)
-                MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lag_refine), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp[m].lds_refine));
-            hipLaunchKernelGGL(k_lag_refine, dim3(nc), dim3(256), lp[m].lds_refine, s, rg, ws.sat.as<double>(), ws.cross.as<double>(), wcap,
-                               ws.outw.as<float>() + (size_t)m * chunk * wcap, ws.outi.as<int>() + (size_t)m * chunk * 4, (float*)nullptr);
-            MI_TRY(launch_check("k_lag_refine"));
-            MI_HIP(hipMemcpyAsync(ws.pin_w.as<float>() + ((size_t)m * n + c0) * wcap, ws.outw.as<float>() + (size_t)m * chunk * wcap,
-                                  4 * (size_t)nc * wcap, hipMemcpyDeviceToHost, s));
-            MI_HIP(hipMemcpyAsync(ws.pin_i.as<int>() + ((size_t)m * n + c0) * 4, ws.outi.as<int>() + (size_t)m * chunk * 4, sizeof(int) * 4 * nc,
-                                  hipMemcpyDeviceToHost, s));
+        if (c0 > 0) {  // the buffers of the previous chunk are free once its last lag chain has run
+            MI_HIP(hipEventRecord(ws.ev_lag, sl));
+            MI_HIP(hipStreamWaitEvent(sm, ws.ev_lag, 0));
+        }
+        for (int p0 = 0, pi = 0; p0 < nc; p0 += piece, ++pi) {
+            const int np = std::min(piece, nc - p0);
+            float* base = base0 + (size_t)p0 * pstride;
+            const float** dtab = ws.tab.as<const float*>() + 2 * (size_t)p0;
+            MI_HIP(hipMemcpyAsync(dtab, htab + 2 * (size_t)(c0 + p0), sizeof(void*) * 2 * np, hipMemcpyHostToDevice, sm));
+            MI_TRY(launch_mips(sm, nullptr, nullptr, dtab, np, pstride, pl.dimk, pl.dimi_v, pl.dimj_v, (size_t)dimi * dimj, dimj, pl.ai0, pl.aj0,
+                               base + pl.g[0].mip1, base + pl.g[1].mip1, base + pl.g[2].mip1, base + pl.g[0].mip2, base + pl.g[1].mip2,
+                               base + pl.g[2].mip2, ws.mip_tmp.as<float>() + (size_t)p0 * tmp_floats));
+            MI_HIP(hipEventRecord(ws.ev_mip[pi], sm));
+            MI_HIP(hipStreamWaitEvent(sl, ws.ev_mip[pi], 0));
+            double* sat_p = ws.sat.as<double>() + (size_t)p0 * sstride;
+            for (int m = 0; m < 3; ++m) {
+                const PlaneGeom& g = pl.g[m];
+                MI_TRY(prepare_plane_band(sl, base + g.mip1, base + g.mip2, g, lp[m], base + g.ps1, base + g.ps2, sat_p + sat_off[m], np, pstride,
+                                          sstride));
+                MI_TRY(lag_cross(dev, sl, lp[m], base + g.mip1, base + g.mip2, pstride, np, ws));
+                const RefineGeom rg = refine_geom(g, lp[m], P.maxIter, sstride, sat_off[m], margin);
+                if (lp[m].lds_refine > 64 * 1024)
+                    MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lag_refine), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)lp[m].lds_refine));
+                float* ow = ws.outw.as<float>() + ((size_t)m * chunk + p0) * wcap;
+                int* oi = ws.outi.as<int>() + ((size_t)m * chunk + p0) * 4;
+                hipLaunchKernelGGL(k_lag_refine, dim3(np), dim3(256), lp[m].lds_refine, sl, rg, sat_p, ws.cross.as<double>(), wcap, ow, oi,
+                                   (float*)nullptr);
+                MI_TRY(launch_check("k_lag_refine"));
+                MI_HIP(hipMemcpyAsync(ws.pin_w.as<float>() + ((size_t)m * n + c0 + p0) * wcap, ow, 4 * (size_t)np * wcap, hipMemcpyDeviceToHost, sl));
+                MI_HIP(hipMemcpyAsync(ws.pin_i.as<int>() + ((size_t)m * n + c0 + p0) * 4, oi, sizeof(int) * 4 * np, hipMemcpyDeviceToHost, sl));
+            }
         }
     }
-    MI_HIP(hipStreamSynchronize(s));
+    *job_out = job.release();
+    return MI_OK;
+}
+
+// Waits for the group's device stage, then the host rules.  careful[q] is set for pairs whose result was not taken here (see the
+// header of this file); out[q] is then untouched.  Destroys the job.
+int ncc_lag_finish(LagJob* job_in, mi_ncc_params* params, mi_ncc_descr* out, unsigned char* careful) {
+    std::unique_ptr<LagJob> job(job_in);
+    if (!job) return MI_OK;
+    LagWorkspace& ws = *job->ws;
+    const PairPlan& pl = job->pl;
+    const int n = job->n, wcap = job->wcap;
+    const float margin = job->margin;
+    MI_HIP(hipStreamSynchronize(ws.sl));   // (everything `sm` was given lies before the last event `sl` waited for)
 
     // compute_Alignment (compute_funcs.cu:1597-1609) on the returned windows
     for (int q = 0; q < n; ++q) {
@@ -850,13 +929,22 @@ int ncc_lag_group(int dev, hipStream_t s, int n, const float* const* a_ptrs, con
         combine_axis(Pq, &r, 0, du[0], peak[0], w1[0], du[1], peak[1], w1[1], &tight);  // V: xy rows, xz rows
         combine_axis(Pq, &r, 1, dv[0], peak[0], w2[0], du[2], peak[2], w1[2], &tight);  // H: xy cols, yz rows
         combine_axis(Pq, &r, 2, dv[1], peak[1], w2[1], dv[2], peak[2], w2[2], &tight);  // D: xz cols, yz cols
-        if (side == MI_NORTH_SOUTH) r.coord[0] += ni; else r.coord[1] += nj;           // libcrossmips.cpp:483-486
+        if (job->side == MI_NORTH_SOUTH) r.coord[0] += job->ni; else r.coord[1] += job->nj;  // libcrossmips.cpp:483-486
         if (redo || tight < margin) { careful[q] = 1; continue; }
         careful[q] = 0;
         out[q] = r;
         ncc_count(0, 1);
     }
     return MI_OK;
+}
+
+void ncc_lag_abandon(LagJob* job) { delete job; }
+
+int ncc_lag_group(int dev, hipStream_t s, int n, const float* const* a_ptrs, const float* const* b_ptrs, int dimk, int dimi, int dimj, int ni,
+                  int nj, int delayk, int delayi, int delayj, int side, mi_ncc_params* params, mi_ncc_descr* out, unsigned char* careful) {
+    LagJob* job = nullptr;
+    MI_TRY(ncc_lag_enqueue(dev, s, n, a_ptrs, b_ptrs, dimk, dimi, dimj, ni, nj, delayk, delayi, delayj, side, params, &job));
+    return ncc_lag_finish(job, params, out, careful);
 }
 
 // NCC map of one pair of MIPs through the lag transform (building block for the parity tests)
