@@ -999,9 +999,13 @@ int ncc_time_mips(int dev, hipStream_t s, int n, const float* const* a_ptrs, con
     const size_t lds = sizeof(float) * MIP_ROWS * (size_t)dimk;
     MI_REQUIRE(lds <= 32 * 1024, "mi_ncc_time_mips: stack too deep for the timed variant");
     float* xz_tmp = tmp.as<float>() + 2 * (size_t)n * bands * dimk * dimj_v;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    MI_HIP(hipEventCreate(&e0));
-    MI_HIP(hipEventCreate(&e1));
+    struct Events {  // (destroyed on every path out of this function)
+        hipEvent_t a = nullptr, b = nullptr;
+        ~Events() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+    } evs;
+    MI_HIP(hipEventCreate(&evs.a));
+    MI_HIP(hipEventCreate(&evs.b));
+    hipEvent_t e0 = evs.a, e1 = evs.b;
     for (int r = -1; r < reps; ++r) {  // r = -1: warm-up
         if (r == 0) MI_HIP(hipEventRecord(e0, s));
         hipLaunchKernelGGL(k_mips, dim3(cblocks, bands, 2 * n), dim3(256), lds, s, (const float*)nullptr, (const float*)nullptr, tab.as<const float*>(),
@@ -1012,8 +1016,6 @@ int ncc_time_mips(int dev, hipStream_t s, int n, const float* const* a_ptrs, con
     MI_HIP(hipEventSynchronize(e1));
     float total = 0.0f;
     MI_HIP(hipEventElapsedTime(&total, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     *ms = total / (float)reps;
     return launch_check("k_mips");
 }
