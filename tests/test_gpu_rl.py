@@ -213,8 +213,15 @@ def test_decon_fft_wiener_step_locked(dev, F_xyz, niter, interval):
     got = run(niter)[0].cpu().numpy()
     trace = []
     want = R.decon_fft_wiener(vol, psf, Fz, niter, 0.0, 0.0, interval, forced_psfs=starts, trace=trace)
-    assert _rel(got, want) < 5 * REL
+    # every oracle iteration started from the PSF the device used for it: the volume is held to the RL metric (1e-4 of the
+    # maximum, relative L2 1e-5, point-wise 1e-4) like every other loop
+    assert_close(got, want, what="step-locked Wiener volume:")
     assert len(trace) == niter - 1
+    # The PSF update itself stays at 2e-3 of its peak: otf_new = F{Y} conj(F{X}) / max(|F{X}|^2, eps) (decon.m:283-290) divides
+    # by the power spectrum of the current estimate, which is ~1e-10 of its DC value over most of the band -- there the quotient
+    # amplifies the fp32 rounding of the two transforms by orders of magnitude -- and the new PSF is the real part of its inverse
+    # transform cropped to the centre box, clamped and renormalised (decon.m:292-304): single-precision transforms on either side
+    # (the float64 oracle run with float32 transforms drifts from itself just the same) differ there by 1e-3 of the peak.
     for i, est in enumerate(trace, start=2):                               # the oracle's own update from the same state
         assert np.abs(starts[i] - est).max() <= 2e-3 * est.max(), i
 
