@@ -34,6 +34,16 @@ int normalised_psf(hipStream_t s, const float* ker, int n, DevBuf& out);
 int direct_conv_launch(hipStream_t s, const float* img, const float* kf, float* out, int nx, int ny, int nz, int kx, int ky,
                        int kz, int kxp, int boundary, int epi_kind, const ConvEpilogue& epi, const int* offs = nullptr,
                        const int* bnd3 = nullptr);
+// sep3d.hip: a rank-1 kernel a (x) b (x) c as ONE pass (8 B/voxel + epilogue operand) instead of three launches of the dense kernel.
+// taps[axis] in WINDOW order: out[i] = sum_t in[rule(i - offs[axis] + t)] * taps[axis].w[t], each 1-D result rounded to fp32.
+constexpr int kSepMaxTaps = 51;
+struct SepTaps {
+    float w[kSepMaxTaps];
+    int n;
+};
+bool sep3d_fits(int nx, const int* k, const int* offs);
+int sep3d_launch(hipStream_t s, const float* in, float* out, int nx, int ny, int nz, const SepTaps taps[3], const int* offs, const int* bnd3,
+                 int epi_kind, const ConvEpilogue& epi);
 int gauss3d_async(hipStream_t s, float* vol, float* work, int nx, int ny, int nz, const float* sigma, const int* ksize);
 // dst = G(src) in ONE pass when the filter fits the fused kernel (*fused = true); else the two-pass route, which uses dst as
 // its intermediate and leaves the result in src (*fused = false)

@@ -32,7 +32,9 @@ struct mi_rl_ctx {
     bool separable = false;
     DevBuf sep_fwd[3], sep_adj[3];  // 1-D tap tables per axis
     int sep_kxp[3] = {0, 0, 0};
-    DevBuf sep_t0, sep_t1;          // intermediate volumes (allocated with the first convolution)
+    DevBuf sep_t0, sep_t1;          // intermediate volumes of the three-launch route (allocated with its first convolution)
+    SepTaps sep_tf[3], sep_ta[3];   // the same taps in window order for the single-pass kernel (sep3d.hip)
+    bool sep_single = false;        // ... which takes this PSF (tap counts, LDS ring of kz planes, whole float4 rows)
     FftEngine* fft = nullptr;
     ~mi_rl_ctx() { delete fft; }
 };
@@ -48,12 +50,16 @@ bool factor_rank1(const std::vector<float>& p, int kx, int ky, int kz, std::vect
     if (!(std::fabs(p0) > 0.0) || kx * ky * kz == 1) return false;
     const int z0 = (int)(best / ((size_t)ky * kx)), y0 = (int)((best / kx) % ky), x0 = (int)(best % kx);
     auto at = [&](int z, int y, int x) { return (double)p[((size_t)z * ky + y) * kx + x]; };
-    double worst = 0.0;
+    // every sample within a few fp32 roundings of the product of its three line samples RELATIVE TO THE SAMPLE (four roundings:
+    // its own and those of the three line samples), with an absolute floor of 1e-9 of the peak for samples that underflow; the
+    // flux the rank-1 form takes from or adds to the PSF is then below 4e-7 of its own (an absolute bound of 4e-7 of the peak
+    // per sample allowed up to K * 4e-7 * peak)
     for (int z = 0; z < kz; ++z)
         for (int y = 0; y < ky; ++y)
-            for (int x = 0; x < kx; ++x)
-                worst = std::max(worst, std::fabs(at(z, y, x) - at(z, y0, x0) * at(z0, y, x0) * at(z0, y0, x) / (p0 * p0)));
-    if (worst > 4e-7 * std::fabs(p0)) return false;
+            for (int x = 0; x < kx; ++x) {
+                const double v = at(z, y, x), r = std::fabs(v - at(z, y0, x0) * at(z0, y, x0) * at(z0, y0, x) / (p0 * p0));
+                if (r > 4e-7 * std::fabs(v) + 1e-9 * std::fabs(p0)) return false;
+            }
     factors[0].resize(kx);
     factors[1].resize(ky);
     factors[2].resize(kz);
@@ -184,6 +190,22 @@ static int rl_create(int dev, void* stream, int nx, int ny, int nz, const float*
             // adjoint taps: flip(psf_inv); without psf_inv the transpose of the forward operator = the plain taps of psf
             if (rc == MI_OK) rc = psf_inv ? prepare_separable(s, fi, true, c->sep_adj, c->sep_kxp) : prepare_separable(s, ff, false, c->sep_adj, c->sep_kxp);
             c->separable = rc == MI_OK;
+            if (c->separable) {  // window-order taps: forward = the flipped lines; adjoint = flip(psf_inv), or the plain lines of psf
+                bool fits = true;
+                for (int d = 0; d < 3; ++d) {
+                    const std::vector<float>& fl = ff[d];
+                    const std::vector<float>& al = psf_inv ? fi[d] : ff[d];
+                    const int nt = (int)fl.size();
+                    fits = fits && nt <= kSepMaxTaps;
+                    if (!fits) break;
+                    c->sep_tf[d].n = c->sep_ta[d].n = nt;
+                    for (int t = 0; t < nt; ++t) {
+                        c->sep_tf[d].w[t] = fl[nt - 1 - t];
+                        c->sep_ta[d].w[t] = psf_inv ? al[nt - 1 - t] : al[t];
+                    }
+                }
+                c->sep_single = fits && !std::getenv("MI_NO_SEP_SINGLE") && sep3d_fits(nx, c->k, c->off_fwd) && sep3d_fits(nx, c->k, c->off_adj);
+            }
         }
     }
     if (rc == MI_OK && engine == MI_ENGINE_DIRECT) {
@@ -236,12 +258,16 @@ extern "C" size_t mi_rl_device_bytes(const mi_rl_ctx* ctx) {
     return ctx->kf_fwd.bytes + ctx->kf_adj.bytes + ctx->sep_t0.bytes + ctx->sep_t1.bytes + (ctx->fft ? ctx->fft->device_bytes() : 0);
 }
 
-extern "C" int mi_rl_separable(const mi_rl_ctx* ctx) { return ctx && ctx->separable ? 1 : 0; }
+extern "C" int mi_rl_separable(const mi_rl_ctx* ctx) { return ctx && ctx->separable ? (ctx->sep_single ? 2 : 1) : 0; }
 extern "C" int mi_rl_pair_layout(const mi_rl_ctx* ctx) {
     return ctx && ctx->engine == MI_ENGINE_FFT && ctx->fft && ctx->fft->native && ctx->fft->native->dims.paired ? 1 : 0;
 }
 
 static int ctx_conv(mi_rl_ctx* c, hipStream_t s, const float* in, bool adjoint, float* out, int epi_kind, const ConvEpilogue& epi) {
+    if (c->engine == MI_ENGINE_DIRECT && c->separable && c->sep_single && ((uintptr_t)in % 16) == 0 && ((uintptr_t)out % 16) == 0 &&
+        ((uintptr_t)epi.a % 16) == 0 && ((uintptr_t)epi.b % 16) == 0 && epi_kind != EPI_TAPER_SHELL)
+        return sep3d_launch(s, in, out, c->n[0], c->n[1], c->n[2], adjoint ? c->sep_ta : c->sep_tf, adjoint ? c->off_adj : c->off_fwd, c->bnd,
+                            epi_kind, epi);
     if (c->engine == MI_ENGINE_DIRECT && c->separable) {
         const size_t bytes = sizeof(float) * (size_t)c->n[0] * c->n[1] * c->n[2];
         if (!c->sep_t0.p) MI_TRY(c->sep_t0.alloc(bytes));

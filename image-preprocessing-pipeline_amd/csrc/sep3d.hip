@@ -1,0 +1,223 @@
+// Single-pass separable 3-D convolution with the RL epilogues (direct engine, rank-1 PSFs: BASELINE config 1's Gaussian and every
+// other outer-product PSF).
+//
+// The reference applies every PSF as the dense tap loop (conv3d_gpu.cu:68-99: kx * ky * kz taps per voxel, every tap a global
+// load; convn in decon.m:61,64).  A PSF that is an outer product a (x) b (x) c factors into three 1-D convolutions; run as three
+// launches they move 24 B/voxel.  Here they are ONE pass of 8 B/voxel (+ the epilogue operand): the structure of k_gauss3d_fused
+// (gauss3d.hip) with arbitrary taps, a window offset per axis (even extents, deconFFT's placement), one of the three boundary
+// rules per axis and the RL epilogues of the direct engine.  A work-group owns a 64 x 16 (x, y) tile and marches along z: the
+// boundary-resolved input patch of plane p + 1 travels into registers (16-byte loads where the patch lies inside the volume)
+// while plane p is filtered along x and y in LDS; the xy-filtered plane joins an LDS ring of the last kz planes, one z-filtered
+// plane leaves per step through the epilogue with 16-byte stores.  Every 1-D result is rounded to fp32, taps in window order.
+#include "conv3d_direct.h"
+
+namespace mi {
+namespace {
+
+constexpr int SF_TY = 16, SF_TX = 64, SF_THREADS = 256;
+constexpr size_t kSepLdsMax = 150 * 1024;
+
+// source index of grid coordinate i under a boundary rule (-1: the sample is zero)
+__device__ __forceinline__ int bnd_index(int i, int n, int rule) {
+    if (rule == MI_BOUNDARY_REPLICATE) return min(max(i, 0), n - 1);
+    if (rule == MI_BOUNDARY_CIRCULAR) {
+        i %= n;
+        return i < 0 ? i + n : i;
+    }
+    return (i < 0 || i >= n) ? -1 : i;
+}
+
+struct SepGeom {
+    int nx, ny, nz;
+    int cx, cy, cz;     // window start offsets: out[i] = sum_t in[i - c + t] w[t]
+    int bx, by, bz;     // boundary rule per axis
+    int zchunk;
+};
+
+template <int EPI, int NPRE>
+__global__ __launch_bounds__(SF_THREADS) void k_sep3d(const float* __restrict__ src, float* __restrict__ dst, ConvEpilogue epi, SepGeom g,
+                                                      SepTaps tx, SepTaps ty, SepTaps tz) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int nx = g.nx, ny = g.ny, nz = g.nz;
+    const int cql = (g.cx + 3) / 4, cqr = (tx.n - 1 - g.cx + 3) / 4;  // x halo in float4 units, left / right
+    const int segq = SF_TX / 4 + cql + cqr;                           // float4 per staged row
+    const int seg = 4 * segq, rows_in = SF_TY + ty.n - 1;
+    float* in = lds;                          // [rows_in][seg]
+    float* xf = in + rows_in * seg;           // [rows_in][64]
+    float* ring = xf + rows_in * SF_TX;       // [tz.n][16][64]
+    const int tid = threadIdx.x, xq = tid & 15, rsub = tid >> 4;
+    // XCD-aware tile order: a contiguous range of tiles per XCD keeps the halos of neighbouring tiles in one L2 (k_gauss3d_fused)
+    const int gx = (nx + SF_TX - 1) / SF_TX, gy = (ny + SF_TY - 1) / SF_TY, gz = (nz + g.zchunk - 1) / g.zchunk;
+    const int total = gx * gy * gz, per = (total + 7) / 8;
+    const int t = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (t >= total) return;
+    const int bz = t / (gx * gy), by = (t - bz * gx * gy) / gx, bx = t - bz * gx * gy - by * gx;
+    const int x0 = bx * SF_TX, y0 = by * SF_TY;
+    const int za = bz * g.zchunk, zb = min(za + g.zchunk, nz);
+    const int xoff = 4 * cql - g.cx;          // first tap of output x sits at staged column x + xoff
+    const int xs0 = x0 - 4 * cql;             // grid x of staged column 0
+    int slot = 0;
+    float4 pre[NPRE];
+    // the patch of walk position p (input plane p under the z rule), requested one plane ahead
+    auto fetch = [&](int p) {
+        const int zi = bnd_index(p, nz, g.bz);
+        const float* plane = src + (size_t)max(zi, 0) * ny * nx;
+#pragma unroll
+        for (int u = 0; u < NPRE; ++u) {
+            const int it = tid + u * SF_THREADS;
+            if (it < rows_in * segq) {
+                const int r = it / segq, q = it - r * segq;
+                const int yi = bnd_index(y0 - g.cy + r, ny, g.by);
+                const int x = xs0 + 4 * q;
+                float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (zi >= 0 && yi >= 0) {
+                    const float* row = plane + (size_t)yi * nx;
+                    if (x >= 0 && x + 3 < nx) {
+                        v = *reinterpret_cast<const float4*>(row + x);
+                    } else {
+                        const int i0 = bnd_index(x, nx, g.bx), i1 = bnd_index(x + 1, nx, g.bx), i2 = bnd_index(x + 2, nx, g.bx),
+                                  i3 = bnd_index(x + 3, nx, g.bx);
+                        v = make_float4(i0 >= 0 ? row[i0] : 0.0f, i1 >= 0 ? row[i1] : 0.0f, i2 >= 0 ? row[i2] : 0.0f, i3 >= 0 ? row[i3] : 0.0f);
+                    }
+                }
+                pre[u] = v;
+            }
+        }
+    };
+    const int p_first = za - g.cz, p_last = zb - 1 - g.cz + tz.n - 1;  // walk positions (grid z before the rule)
+    fetch(p_first);
+    for (int p = p_first; p <= p_last; ++p) {
+#pragma unroll
+        for (int u = 0; u < NPRE; ++u) {
+            const int it = tid + u * SF_THREADS;
+            if (it < rows_in * segq) {
+                const int r = it / segq, q = it - r * segq;
+                *reinterpret_cast<float4*>(in + r * seg + 4 * q) = pre[u];
+            }
+        }
+        __syncthreads();
+        if (p < p_last) fetch(p + 1);
+        for (int it = tid; it < rows_in * 16; it += SF_THREADS) {   // x filter: 4 outputs from kx + 3 staged samples
+            const int r = it >> 4, q = it & 15;
+            const float* a = in + r * seg + 4 * q + xoff;
+            float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f, o3 = 0.0f;
+            float v0 = a[0], v1 = a[1], v2 = a[2];
+            for (int k = 0; k < tx.n; ++k) {
+                const float v3 = a[k + 3], w = tx.w[k];
+                o0 = fmaf(v0, w, o0);
+                o1 = fmaf(v1, w, o1);
+                o2 = fmaf(v2, w, o2);
+                o3 = fmaf(v3, w, o3);
+                v0 = v1; v1 = v2; v2 = v3;
+            }
+            *reinterpret_cast<float4*>(xf + r * SF_TX + 4 * q) = make_float4(o0, o1, o2, o3);
+        }
+        __syncthreads();
+        {   // y filter of row rsub, columns 4 xq .. + 3 -> ring[slot]
+            float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            for (int k = 0; k < ty.n; ++k) {
+                const float4 v = *reinterpret_cast<const float4*>(xf + (rsub + k) * SF_TX + 4 * xq);
+                const float w = ty.w[k];
+                acc.x = fmaf(v.x, w, acc.x); acc.y = fmaf(v.y, w, acc.y); acc.z = fmaf(v.z, w, acc.z); acc.w = fmaf(v.w, w, acc.w);
+            }
+            *reinterpret_cast<float4*>(ring + ((size_t)slot * SF_TY + rsub) * SF_TX + 4 * xq) = acc;
+        }
+        const int zo = p + g.cz - (tz.n - 1);  // output plane whose window [zo - cz, zo - cz + kz - 1] is now complete
+        if (zo >= za) {
+            float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            int rs = slot + 1;  // slot of the window's first plane (kz slots back, wrapping)
+            if (rs >= tz.n) rs -= tz.n;
+            for (int k = 0; k < tz.n; ++k) {
+                const float4 v = *reinterpret_cast<const float4*>(ring + ((size_t)rs * SF_TY + rsub) * SF_TX + 4 * xq);
+                const float w = tz.w[k];
+                acc.x = fmaf(v.x, w, acc.x); acc.y = fmaf(v.y, w, acc.y); acc.z = fmaf(v.z, w, acc.z); acc.w = fmaf(v.w, w, acc.w);
+                if (++rs >= tz.n) rs = 0;
+            }
+            const int y = y0 + rsub, x = x0 + 4 * xq;
+            if (y < ny && x < nx) {
+                const size_t idx = ((size_t)zo * ny + y) * nx + x;
+                float4 o = acc;
+                if (EPI != EPI_NONE) {
+                    const float4 a = *reinterpret_cast<const float4*>(epi.a + idx);
+                    if (EPI == EPI_RATIO) {
+                        o = make_float4(a.x / fmaxf(acc.x, kEpsSingle), a.y / fmaxf(acc.y, kEpsSingle), a.z / fmaxf(acc.z, kEpsSingle),
+                                        a.w / fmaxf(acc.w, kEpsSingle));
+                    } else if (EPI == EPI_UPDATE) {
+                        o = make_float4(fabsf(a.x * acc.x), fabsf(a.y * acc.y), fabsf(a.z * acc.z), fabsf(a.w * acc.w));
+                    } else {
+                        const float4 b = *reinterpret_cast<const float4*>(epi.b + idx);
+                        const float l = epi.lambda, m = 1.0f - epi.lambda;
+                        o = make_float4(fabsf(a.x * acc.x * m + b.x * l), fabsf(a.y * acc.y * m + b.y * l), fabsf(a.z * acc.z * m + b.z * l),
+                                        fabsf(a.w * acc.w * m + b.w * l));
+                    }
+                }
+                *reinterpret_cast<float4*>(dst + idx) = o;
+            }
+        }
+        if (++slot >= tz.n) slot = 0;
+        // (the next plane's staging overwrites `in`, last read before the second barrier above; `xf` is rewritten only behind
+        // the next first barrier, which every thread reaches after its y filter)
+    }
+}
+
+size_t sep_lds_bytes(const int* k, const int* c) {
+    const int cql = (c[0] + 3) / 4, cqr = (k[0] - 1 - c[0] + 3) / 4, seg = 4 * (SF_TX / 4 + cql + cqr), rows_in = SF_TY + k[1] - 1;
+    return sizeof(float) * ((size_t)rows_in * seg + (size_t)rows_in * SF_TX + (size_t)k[2] * SF_TY * SF_TX);
+}
+int sep_patch_quads(const int* k, const int* c) {
+    const int cql = (c[0] + 3) / 4, cqr = (k[0] - 1 - c[0] + 3) / 4;
+    return (SF_TY + k[1] - 1) * (SF_TX / 4 + cql + cqr);
+}
+
+}  // namespace
+
+// whether the single-pass kernel takes this rank-1 convolution: rows of whole float4, tap counts within the argument block, the
+// plane ring within the LDS, the staged patch within the prefetch registers
+bool sep3d_fits(int nx, const int* k, const int* c) {
+    for (int a = 0; a < 3; ++a)
+        if (k[a] < 1 || k[a] > kSepMaxTaps || c[a] < 0 || c[a] >= k[a]) return false;
+    return (nx % 4) == 0 && sep_lds_bytes(k, c) <= kSepLdsMax && sep_patch_quads(k, c) <= 6 * SF_THREADS;
+}
+
+int sep3d_launch(hipStream_t s, const float* in, float* out, int nx, int ny, int nz, const SepTaps taps[3], const int* offs, const int* bnd3,
+                 int epi_kind, const ConvEpilogue& epi) {
+    const int k[3] = {taps[0].n, taps[1].n, taps[2].n};
+    MI_REQUIRE(sep3d_fits(nx, k, offs), "separable convolution: taps %d x %d x %d do not fit the single-pass kernel", k[0], k[1], k[2]);
+    MI_REQUIRE(in != out, "separable convolution: input and output must differ");
+    MI_REQUIRE(((uintptr_t)in % 16) == 0 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)epi.a % 16) == 0 && ((uintptr_t)epi.b % 16) == 0,
+               "separable convolution: buffers must be 16-byte aligned");
+    MI_REQUIRE(epi_kind == EPI_NONE || epi_kind == EPI_RATIO || epi_kind == EPI_UPDATE || epi_kind == EPI_UPDATE_REG,
+               "separable convolution: unknown epilogue %d", epi_kind);
+    MI_REQUIRE(epi_kind == EPI_NONE || epi.a, "separable convolution: the epilogue needs its operand");
+    MI_REQUIRE(epi_kind != EPI_UPDATE_REG || epi.b, "separable convolution: the regularised update needs its second operand");
+    SepGeom g{nx, ny, nz, offs[0], offs[1], offs[2], bnd3[0], bnd3[1], bnd3[2], 0};
+    // chunks along z: long enough that the kz - 1 planes of run-in are a small share, short enough to fill the device
+    const int tiles_xy = ((nx + SF_TX - 1) / SF_TX) * ((ny + SF_TY - 1) / SF_TY);
+    int zchunk = std::max(64, 8 * k[2]);
+    while (zchunk > 2 * k[2] && zchunk > 16 && (size_t)tiles_xy * ((nz + zchunk - 1) / zchunk) < 1024) zchunk /= 2;
+    g.zchunk = std::min(zchunk, nz);
+    const int total = tiles_xy * ((nz + g.zchunk - 1) / g.zchunk);
+    const size_t lds = sep_lds_bytes(k, offs);
+    const bool wide = sep_patch_quads(k, offs) > 3 * SF_THREADS;
+    const dim3 grid((unsigned)((total + 7) / 8 * 8));
+#define MI_SEP(E)                                                                                                                  \
+    case E:                                                                                                                        \
+        if (wide) {                                                                                                                \
+            if (lds > 64 * 1024)                                                                                                   \
+                MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sep3d<E, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            hipLaunchKernelGGL((k_sep3d<E, 6>), grid, dim3(SF_THREADS), lds, s, in, out, epi, g, taps[0], taps[1], taps[2]);       \
+        } else {                                                                                                                   \
+            if (lds > 64 * 1024)                                                                                                   \
+                MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sep3d<E, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            hipLaunchKernelGGL((k_sep3d<E, 3>), grid, dim3(SF_THREADS), lds, s, in, out, epi, g, taps[0], taps[1], taps[2]);       \
+        }                                                                                                                          \
+        break;
+    switch (epi_kind) {
+        MI_SEP(EPI_NONE) MI_SEP(EPI_RATIO) MI_SEP(EPI_UPDATE) MI_SEP(EPI_UPDATE_REG)
+        default: break;
+    }
+#undef MI_SEP
+    return launch_check("k_sep3d");
+}
+
+}  // namespace mi

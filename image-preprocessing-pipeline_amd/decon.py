@@ -333,6 +333,11 @@ class RLContext:
         return bool(lib().mi_rl_separable(self._h))
 
     @property
+    def separable_single_pass(self) -> bool:
+        """... and does so in one pass over the volume (``mi_rl_separable`` == 2)."""
+        return int(lib().mi_rl_separable(self._h)) == 2
+
+    @property
     def pair_layout(self) -> bool:
         """The FFT engine keeps the spectra around its z pass pair-interleaved (``mi_rl_pair_layout``)."""
         return bool(lib().mi_rl_pair_layout(self._h))

@@ -115,10 +115,12 @@ int mi_rl_create(int dev, void* stream, int nx, int ny, int nz, const float* psf
 int mi_rl_create_ex(int dev, void* stream, int nx, int ny, int nz, const float* psf, const float* psf_inv,
                     int kx, int ky, int kz, const int* boundary_xyz, const int* shift_xyz, int engine,
                     mi_rl_ctx** ctx);
-/* 1 when the context applies the PSF as three 1-D convolutions: the direct engine does so for PSFs (and explicit adjoint
- * kernels) that are an outer product of three lines to fp32 rounding, e.g. the Gaussian PSF of BASELINE config 1 --
- * kx + ky + kz instead of kx * ky * kz taps per voxel [no reference counterpart: conv3d_gpu.cu:68-99 always runs the dense loop].
- * MI_NO_SEPARABLE=1 disables the test. */
+/* > 0 when the context applies the PSF as three 1-D convolutions: the direct engine does so for PSFs (and explicit adjoint
+ * kernels) that are an outer product of three lines to fp32 rounding (every sample within 4e-7 of ITS value of the product of
+ * its line samples), e.g. the Gaussian PSF of BASELINE config 1 -- kx + ky + kz instead of kx * ky * kz taps per voxel [no
+ * reference counterpart: conv3d_gpu.cu:68-99 always runs the dense loop].  2: all three in ONE pass over the volume (sep3d.hip:
+ * 8 B/voxel; rows of whole float4, <= 51 taps per axis, a ring of kz xy-filtered planes in LDS); 1: three launches of the
+ * dense kernel with 1-D tap tables (24 B/voxel; MI_NO_SEP_SINGLE=1 forces it).  MI_NO_SEPARABLE=1 disables the test. */
 int mi_rl_separable(const mi_rl_ctx* ctx);
 /* 1 when the FFT engine of the context keeps its spectra around the z pass in the pair-interleaved layout (every block of 8 lines
  * followed by its 8 mirror-partner lines; two 64-KB z tiles per CU): z extents 2^a (64..1024), 3 * 2^a (192..768) or 9 * 2^a (576, 1152) on the hand-written

@@ -1,4 +1,4 @@
-"""Direct engine on a rank-1 (Gaussian) PSF: three 1-D passes (separable fast path) vs the dense tap loop vs the FFT engine.
+"""Direct engine on a rank-1 (Gaussian) PSF: single-pass separable kernel (sep3d.hip) vs three 1-D launches vs the dense tap loop vs the FFT engine.
     python profiles/separable_time.py            (BASELINE config 1 PSF 9 x 9 x 15 on a C2-sized volume, zero and circular boundary)"""
 import os
 import sys
@@ -39,9 +39,11 @@ def run(engine, boundary, env=None, iters=4):
 
 for bname, b in (("zero boundary (deconSpatial)", capi.BOUNDARY_ZERO), ("circular (deconFFT)", capi.BOUNDARY_CIRCULAR)):
     ms_sep, sep, a = run(capi.ENGINE_DIRECT, b)
+    ms_three, _, _ = run(capi.ENGINE_DIRECT, b, {"MI_NO_SEP_SINGLE": "1"})
     ms_dense, sep2, c = run(capi.ENGINE_DIRECT, b, {"MI_NO_SEPARABLE": "1"}, iters=1)
     ms_fft, _, d = run(capi.ENGINE_FFT, b)
     a1 = run(capi.ENGINE_DIRECT, b, iters=1)[2]
     err = float((a1 - c).abs().max() / c.abs().max())   # both after 2 iterations (1 warm-up + 1)
-    print(f"{bname}: direct separable {ms_sep:.2f} ms/iteration (separable={sep}), direct dense {ms_dense:.2f} (separable={sep2}), "
+    print(f"{bname}: direct separable, single pass {ms_sep:.2f} ms/iteration (separable={sep}), three launches {ms_three:.2f}, "
+          f"direct dense {ms_dense:.2f} (separable={sep2}), "
           f"FFT engine {ms_fft:.2f}; separable vs dense max rel diff {err:.2e}", flush=True)

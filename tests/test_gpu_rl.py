@@ -366,15 +366,22 @@ def test_separable_psf_takes_three_1d_passes(dev, boundary, kshape, monkeypatch)
     vol = R.bead_volume(shape, seed=5, psf=R.gaussian_psf((5, 5, 5), (1, 1, 1)))
     inv = R.flip3(psf) if boundary != 2 else None
 
+    single = []
+
     def run(p, pinv):
         ctx = decon.RLContext(shape, p, pinv, boundary=boundary, engine=1, device=dev)
         bl = _t(vol, dev)
         ratio = torch.empty_like(bl)
         ctx.iterate(bl, ratio, 3)
+        single.append(ctx.separable_single_pass)
         return bl.cpu().numpy(), ctx.separable
 
     got, sep = run(psf, inv)
-    assert sep
+    assert sep and single[-1]                    # one pass over the volume (sep3d.hip)
+    monkeypatch.setenv("MI_NO_SEP_SINGLE", "1")
+    three, sep3 = run(psf, inv)                  # three launches of the dense kernel with 1-D tap tables
+    monkeypatch.delenv("MI_NO_SEP_SINGLE")
+    assert sep3 and not single[-1] and _rel(got, three) < 5e-6
     monkeypatch.setenv("MI_NO_SEPARABLE", "1")
     dense, sep_off = run(psf, inv)
     monkeypatch.delenv("MI_NO_SEPARABLE")
@@ -385,3 +392,31 @@ def test_separable_psf_takes_three_1d_passes(dev, boundary, kshape, monkeypatch)
         assert_close(got, R.decon_fft(vol, psf, shape, 3, skip_edgetaper=True))
     _, sep_asym = run(asymmetric_psf(kshape, seed=1), R.flip3(asymmetric_psf(kshape, seed=1)) if boundary != 2 else None)
     assert not sep_asym
+
+
+@pytest.mark.parametrize("boundary", [0, 1, 2])
+def test_separable_single_pass_edges_and_regularised_update(dev, boundary):
+    """The single-pass separable kernel where its tiles are ragged: extents that are no multiples of the 64 x 16 tile, fewer planes
+    than taps along z, a z chunk boundary inside the volume, the regularised update epilogue (lambda > 0) -- against the dense
+    loop of the same engine and the oracle's whole deconSpatial / deconFFT run."""
+    from ipp_amd import decon
+    shape, kshape = (9, 23, 68), (11, 5, 7)
+    psf = R.gaussian_psf(kshape, (2.0, 1.0, 1.5))
+    vol = R.bead_volume(shape, seed=15, psf=R.gaussian_psf((3, 3, 3), (1, 1, 1)))
+    ctx = decon.RLContext(shape, psf, None, boundary=boundary, engine=1, device=dev)
+    assert ctx.separable_single_pass
+    if boundary == 1:
+        a = decon.conv3d_gpu(vol, psf)                                   # the dense kernel (conv3d_gpu.cu:68-99)
+        bl = _t(vol, dev)
+        ones = torch.ones_like(bl)
+        ctx.forward_ratio(bl, ones)                                      # ones <- bl ./ max(conv(bl), eps)
+        got = (bl / ones).cpu().numpy()
+        assert_close(got, R.conv3d_replicate(vol, psf), what="single-pass conv, replicate rule:")
+        assert _rel(got, a) < 5e-6
+        return
+    use_fft = boundary == 2
+    F = (shape[2], shape[1], shape[0])
+    want = (R.decon_fft(vol, psf, shape, 6, 0.05, 0.0, 2) if use_fft else R.decon_spatial(vol, psf, 6, 0.05, 0.0, 2))
+    got = decon.decon(_t(vol, dev), decon.make_psf_struct(psf) if not use_fft else psf, 6, 0.05, 0.0, 2, 1, use_fft, F if use_fft else None,
+                      False, engine=1).cpu().numpy()
+    assert_close(got, want)
