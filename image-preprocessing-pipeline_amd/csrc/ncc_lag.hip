@@ -618,22 +618,36 @@ struct LagWorkspace {
     int dev = -1;
     DevBuf fbuf, sat, mip_tmp, SF, ST, CH, cross, outw, outi, tab;
     PinnedBuf pin_tab, pin_w, pin_i;
-    // Two streams of its own: the MIP pass (k_mips: one HBM-bound streaming read of both overlap views) of piece i + 1 runs on
-    // `sm` while the table / lag-transform / refinement chain (fp64 and LDS work on a few MB) of piece i runs on `sl`.
+    // Two streams PER DEVICE, shared by every group in flight: the MIP pass (k_mips: one HBM-bound streaming read of both overlap
+    // views) of piece i + 1 runs on `sm` while the table / lag-transform / refinement chain (fp64 and LDS work on a few MB) of
+    // piece i runs on `sl`.  (A pair of streams per workspace mapped onto the same hardware queues in a way that put one
+    // group's MIP pass behind the other group's chain: 1.3 of 4.8 ms overlapped, profiles/r03_ncc_timeline.txt.)
     hipStream_t sm = nullptr, sl = nullptr;
-    hipEvent_t ev_start = nullptr, ev_lag = nullptr;
+    hipEvent_t ev_start = nullptr, ev_lag = nullptr, ev_done = nullptr;
     std::vector<hipEvent_t> ev_mip;
     ~LagWorkspace() {
-        if (sm) (void)hipStreamDestroy(sm);
-        if (sl) (void)hipStreamDestroy(sl);
         if (ev_start) (void)hipEventDestroy(ev_start);
         if (ev_lag) (void)hipEventDestroy(ev_lag);
+        if (ev_done) (void)hipEventDestroy(ev_done);
         for (hipEvent_t e : ev_mip) (void)hipEventDestroy(e);
     }
     int streams(size_t pieces) {
-        if (!sm) MI_HIP(hipStreamCreateWithFlags(&sm, hipStreamNonBlocking));
-        if (!sl) MI_HIP(hipStreamCreateWithFlags(&sl, hipStreamNonBlocking));
+        {
+            static std::mutex mu;
+            static std::map<int, std::pair<hipStream_t, hipStream_t>> per_dev;  // (never destroyed: the process' lifetime)
+            std::lock_guard<std::mutex> lock(mu);
+            auto it = per_dev.find(dev);
+            if (it == per_dev.end()) {
+                hipStream_t a = nullptr, b = nullptr;
+                MI_HIP(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
+                MI_HIP(hipStreamCreateWithFlags(&b, hipStreamNonBlocking));
+                it = per_dev.emplace(dev, std::make_pair(a, b)).first;
+            }
+            sm = it->second.first;
+            sl = it->second.second;
+        }
         if (!ev_start) MI_HIP(hipEventCreateWithFlags(&ev_start, hipEventDisableTiming));
+        if (!ev_done) MI_HIP(hipEventCreateWithFlags(&ev_done, hipEventDisableTiming));
         if (!ev_lag) MI_HIP(hipEventCreateWithFlags(&ev_lag, hipEventDisableTiming));
         while (ev_mip.size() < pieces) {
             hipEvent_t e = nullptr;
@@ -775,11 +789,12 @@ struct LagJob {
     LagPlane lp[3];
     int n = 0, wcap = 1, ni = 0, nj = 0, side = 0;
     float margin = 0.0f;
+    bool enqueued = false;  // ws->ev_done marks the end of this job's device stage
     ~LagJob() {
         if (ws) {
             // (whatever the call that owned this job enqueued must not outlive the buffers' next user)
-            if (ws->sm) (void)hipStreamSynchronize(ws->sm);
-            if (ws->sl) (void)hipStreamSynchronize(ws->sl);
+            if (enqueued && ws->ev_done) (void)hipEventSynchronize(ws->ev_done);
+            else if (ws->sl) { (void)hipStreamSynchronize(ws->sm); (void)hipStreamSynchronize(ws->sl); }
             give_lag_ws(std::move(ws));
         }
     }
@@ -890,6 +905,8 @@ int ncc_lag_enqueue(int dev, hipStream_t s, int n, const float* const* a_ptrs, c
             }
         }
     }
+    MI_HIP(hipEventRecord(ws.ev_done, sl));  // (everything `sm` was given lies before the last event `sl` waited for)
+    job->enqueued = true;
     *job_out = job.release();
     return MI_OK;
 }
@@ -903,7 +920,7 @@ int ncc_lag_finish(LagJob* job_in, mi_ncc_params* params, mi_ncc_descr* out, uns
     const PairPlan& pl = job->pl;
     const int n = job->n, wcap = job->wcap;
     const float margin = job->margin;
-    MI_HIP(hipStreamSynchronize(ws.sl));   // (everything `sm` was given lies before the last event `sl` waited for)
+    MI_HIP(hipEventSynchronize(ws.ev_done));
 
     // compute_Alignment (compute_funcs.cu:1597-1609) on the returned windows
     for (int q = 0; q < n; ++q) {

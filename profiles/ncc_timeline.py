@@ -5,13 +5,15 @@ lag / refinement chain did.
 import csv
 import glob
 import os
+import re
 import sys
 
 path = sorted(glob.glob(os.path.join(sys.argv[1], "**", "*kernel_trace.csv"), recursive=True))[0]
 rows = []
 with open(path) as f:
     for r in csv.DictReader(f):
-        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Queue_Id"], r["Kernel_Name"].split("(")[0][-40:]))
+        m = re.search(r"\b(k_[a-z0-9_]+)", r["Kernel_Name"])
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Queue_Id"], m.group(1) if m else r["Kernel_Name"][:40]))
 rows.sort()
 # batch calls are separated by idle gaps > 200 us
 calls, cur = [], [rows[0]]
