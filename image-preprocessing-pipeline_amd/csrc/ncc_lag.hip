@@ -616,36 +616,43 @@ int fft_tables(int dev, const FftPlan& pl, hipStream_t s, FftTables* out) {
 // device + pinned buffers of the batched pipeline, kept between calls (one set per concurrent caller and device)
 struct LagWorkspace {
     int dev = -1;
-    DevBuf fbuf, sat, mip_tmp, SF, ST, CH, cross, outw, outi, tab;
+    DevBuf fbuf, sat, mip_tmp, SF[3], ST[3], CH[3], cross[3], outw, outi, tab;  // (lag-transform scratch per plane: the planes' chains run side by side)
     PinnedBuf pin_tab, pin_w, pin_i;
     // Two streams PER DEVICE, shared by every group in flight: the MIP pass (k_mips: one HBM-bound streaming read of both overlap
     // views) of piece i + 1 runs on `sm` while the table / lag-transform / refinement chain (fp64 and LDS work on a few MB) of
     // piece i runs on `sl`.  (A pair of streams per workspace mapped onto the same hardware queues in a way that put one
     // group's MIP pass behind the other group's chain: 1.3 of 4.8 ms overlapped, profiles/r03_ncc_timeline.txt.)
-    hipStream_t sm = nullptr, sl = nullptr;
-    hipEvent_t ev_start = nullptr, ev_lag = nullptr, ev_done = nullptr;
+    hipStream_t sm = nullptr, sl[3] = {nullptr, nullptr, nullptr};  // (sl[m]: the chain of plane m; MI_NCC_CHAIN_STREAMS=1: one for all)
+    hipEvent_t ev_start = nullptr, ev_lag = nullptr, ev_done = nullptr, ev_plane[2] = {nullptr, nullptr};
     std::vector<hipEvent_t> ev_mip;
     ~LagWorkspace() {
         if (ev_start) (void)hipEventDestroy(ev_start);
         if (ev_lag) (void)hipEventDestroy(ev_lag);
         if (ev_done) (void)hipEventDestroy(ev_done);
+        for (hipEvent_t e : ev_plane)
+            if (e) (void)hipEventDestroy(e);
         for (hipEvent_t e : ev_mip) (void)hipEventDestroy(e);
     }
     int streams(size_t pieces) {
         {
             static std::mutex mu;
-            static std::map<int, std::pair<hipStream_t, hipStream_t>> per_dev;  // (never destroyed: the process' lifetime)
+            struct Four { hipStream_t s[4]; };
+            static std::map<int, Four> per_dev;  // (never destroyed: the process' lifetime)
             std::lock_guard<std::mutex> lock(mu);
             auto it = per_dev.find(dev);
             if (it == per_dev.end()) {
-                hipStream_t a = nullptr, b = nullptr;
-                MI_HIP(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
-                MI_HIP(hipStreamCreateWithFlags(&b, hipStreamNonBlocking));
-                it = per_dev.emplace(dev, std::make_pair(a, b)).first;
+                Four f{};
+                int chains = 3;
+                if (const char* e = std::getenv("MI_NCC_CHAIN_STREAMS")) chains = std::max(1, std::min(3, std::atoi(e)));
+                for (int i = 0; i < 1 + chains; ++i) MI_HIP(hipStreamCreateWithFlags(&f.s[i], hipStreamNonBlocking));
+                for (int i = 1 + chains; i < 4; ++i) f.s[i] = f.s[chains];
+                it = per_dev.emplace(dev, f).first;
             }
-            sm = it->second.first;
-            sl = it->second.second;
+            sm = it->second.s[0];
+            for (int m = 0; m < 3; ++m) sl[m] = it->second.s[1 + m];
         }
+        for (hipEvent_t& e : ev_plane)
+            if (!e) MI_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         if (!ev_start) MI_HIP(hipEventCreateWithFlags(&ev_start, hipEventDisableTiming));
         if (!ev_done) MI_HIP(hipEventCreateWithFlags(&ev_done, hipEventDisableTiming));
         if (!ev_lag) MI_HIP(hipEventCreateWithFlags(&ev_lag, hipEventDisableTiming));
@@ -684,29 +691,29 @@ void give_lag_ws(std::unique_ptr<LagWorkspace> r) {
 int grow(DevBuf& b, size_t bytes) { return b.bytes >= bytes ? MI_OK : b.alloc(bytes); }
 
 // cross terms of `np` pairs of one plane through the lag transform (MIPs at m1 / m2 + q * pstride) into ws.cross
-int lag_cross(int dev, hipStream_t s, const LagPlane& lp, const float* m1, const float* m2, size_t pstride, int np, LagWorkspace& ws) {
+int lag_cross(int dev, hipStream_t s, const LagPlane& lp, const float* m1, const float* m2, size_t pstride, int np, LagWorkspace& ws, int m = 0) {
     const int N = lp.fft.N, NK = N / 2 + 1, nlag = 2 * lp.Es + 1, nlp = (nlag + 3) / 4 * 4;
     FftTables ft;
     MI_TRY(fft_tables(dev, lp.fft, s, &ft));
     const cplx* tw = ft.tw;
-    MI_TRY(grow(ws.SF, sizeof(double) * 2 * (size_t)np * lp.n_short * NK));
-    MI_TRY(grow(ws.ST, sizeof(double) * 2 * (size_t)np * lp.n_short * NK));
-    MI_TRY(grow(ws.CH, sizeof(double) * 2 * (size_t)np * NK * nlp));
-    MI_TRY(grow(ws.cross, sizeof(double) * (size_t)np * (2 * lp.Eu + 1) * (2 * lp.Ev + 1)));
+    MI_TRY(grow(ws.SF[m], sizeof(double) * 2 * (size_t)np * lp.n_short * NK));
+    MI_TRY(grow(ws.ST[m], sizeof(double) * 2 * (size_t)np * lp.n_short * NK));
+    MI_TRY(grow(ws.CH[m], sizeof(double) * 2 * (size_t)np * NK * nlp));
+    MI_TRY(grow(ws.cross[m], sizeof(double) * (size_t)np * (2 * lp.Eu + 1) * (2 * lp.Ev + 1)));
     if (lp.lds_fft > 64 * 1024)
         MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lag_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp.lds_fft));
     hipLaunchKernelGGL(k_lag_fwd, dim3(lp.n_short, np), dim3(lp.fft_threads), lp.lds_fft, s, m1, m2, pstride, lp.n_long, lp.n_short, lp.ls, lp.ss, lp.fft, tw,
-                       ft.slot_pos, ft.slot_neg, ws.SF.as<cplx>(), ws.ST.as<cplx>());
+                       ft.slot_pos, ft.slot_neg, ws.SF[m].as<cplx>(), ws.ST[m].as<cplx>());
     MI_TRY(launch_check("k_lag_fwd"));
     if (lp.lds_mac > 64 * 1024)
         MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lag_mac), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp.lds_mac));
-    hipLaunchKernelGGL(k_lag_mac, dim3((NK + lp.KT - 1) / lp.KT, np), dim3(256), lp.lds_mac, s, ws.SF.as<cplx>(), ws.ST.as<cplx>(), lp.n_short, NK,
-                       lp.Es, lp.KT, lp.JP, lp.FW, lp.TW, ws.CH.as<cplx>());
+    hipLaunchKernelGGL(k_lag_mac, dim3((NK + lp.KT - 1) / lp.KT, np), dim3(256), lp.lds_mac, s, ws.SF[m].as<cplx>(), ws.ST[m].as<cplx>(), lp.n_short, NK,
+                       lp.Es, lp.KT, lp.JP, lp.FW, lp.TW, ws.CH[m].as<cplx>());
     MI_TRY(launch_check("k_lag_mac"));
     if (lp.lds_fft > 64 * 1024)
         MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lag_inv), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp.lds_fft));
-    hipLaunchKernelGGL(k_lag_inv, dim3((nlag + 1) / 2, np), dim3(lp.fft_threads), lp.lds_fft, s, ws.CH.as<cplx>(), NK, lp.fft, lp.Es, lp.El, lp.long_is_u ? 1 : 0,
-                       lp.Eu, lp.Ev, tw, ft.slot_freq, ws.cross.as<double>());
+    hipLaunchKernelGGL(k_lag_inv, dim3((nlag + 1) / 2, np), dim3(lp.fft_threads), lp.lds_fft, s, ws.CH[m].as<cplx>(), NK, lp.fft, lp.Es, lp.El, lp.long_is_u ? 1 : 0,
+                       lp.Eu, lp.Ev, tw, ft.slot_freq, ws.cross[m].as<double>());
     return launch_check("k_lag_inv");
 }
 
@@ -794,14 +801,20 @@ struct LagJob {
         if (ws) {
             // (whatever the call that owned this job enqueued must not outlive the buffers' next user)
             if (enqueued && ws->ev_done) (void)hipEventSynchronize(ws->ev_done);
-            else if (ws->sl) { (void)hipStreamSynchronize(ws->sm); (void)hipStreamSynchronize(ws->sl); }
+            else if (ws->sm) {
+                (void)hipStreamSynchronize(ws->sm);
+                for (hipStream_t st : ws->sl) (void)hipStreamSynchronize(st);
+            }
             give_lag_ws(std::move(ws));
         }
     }
 };
 
-// Device stage of a group: enqueued behind the work `s` holds so far, on the workspace's two streams.  The pairs go through in
-// pieces (MI_NCC_PIECES, default 4 per group): the MIP pass of piece i + 1 overlaps the table / lag / refinement chain of piece i.
+// Device stage of a group: enqueued behind the work `s` holds so far, on the device's MIP stream and its three chain streams.
+// What overlaps: the MIP pass of the NEXT group with the chains of this one, and the three planes' chains with each other.
+// (MI_NCC_PIECES > 1 cuts a group into pieces that are pipelined the same way; measured, it loses: the chain is a dozen
+// latency-bound launches whose cost hardly depends on the number of pairs, so pieces multiply it -- 9.3 / 10.2 / 12.3 ms per 112
+// pairs for 1 / 2 / 4 pieces.)
 int ncc_lag_enqueue(int dev, hipStream_t s, int n, const float* const* a_ptrs, const float* const* b_ptrs, int dimk, int dimi, int dimj, int ni,
                     int nj, int delayk, int delayi, int delayj, int side, mi_ncc_params* params, LagJob** job_out) {
     *job_out = nullptr;
@@ -842,7 +855,7 @@ int ncc_lag_enqueue(int dev, hipStream_t s, int n, const float* const* a_ptrs, c
     size_t budget = (size_t)6 << 30;
     if (const char* e = std::getenv("MI_NCC_CHUNK_MB")) budget = (size_t)std::max(1, std::atoi(e)) << 20;
     const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, budget / per_pair));
-    int pieces = 4;
+    int pieces = 1;
     if (const char* e = std::getenv("MI_NCC_PIECES")) pieces = std::max(1, std::min(64, std::atoi(e)));
     const int piece = std::max(1, (chunk + pieces - 1) / pieces);
 
@@ -865,15 +878,18 @@ int ncc_lag_enqueue(int dev, hipStream_t s, int n, const float* const* a_ptrs, c
     }
     const float margin = job->margin = ncc_margin();
     float* base0 = ws.fbuf.as<float>();
-    hipStream_t sm = ws.sm, sl = ws.sl;
+    hipStream_t sm = ws.sm;
     MI_HIP(hipEventRecord(ws.ev_start, s));
     MI_HIP(hipStreamWaitEvent(sm, ws.ev_start, 0));
-    MI_HIP(hipStreamWaitEvent(sl, ws.ev_start, 0));
+    for (int m = 0; m < 3; ++m)
+        if (m == 0 || ws.sl[m] != ws.sl[m - 1]) MI_HIP(hipStreamWaitEvent(ws.sl[m], ws.ev_start, 0));
     for (int c0 = 0; c0 < n; c0 += chunk) {
         const int nc = std::min(chunk, n - c0);
-        if (c0 > 0) {  // the buffers of the previous chunk are free once its last lag chain has run
-            MI_HIP(hipEventRecord(ws.ev_lag, sl));
-            MI_HIP(hipStreamWaitEvent(sm, ws.ev_lag, 0));
+        if (c0 > 0) {  // the buffers of the previous chunk are free once its chains have run
+            for (int m = 0; m < 3; ++m) {
+                MI_HIP(hipEventRecord(ws.ev_lag, ws.sl[m]));
+                MI_HIP(hipStreamWaitEvent(sm, ws.ev_lag, 0));
+            }
         }
         for (int p0 = 0, pi = 0; p0 < nc; p0 += piece, ++pi) {
             const int np = std::min(piece, nc - p0);
@@ -884,20 +900,23 @@ int ncc_lag_enqueue(int dev, hipStream_t s, int n, const float* const* a_ptrs, c
                                base + pl.g[0].mip1, base + pl.g[1].mip1, base + pl.g[2].mip1, base + pl.g[0].mip2, base + pl.g[1].mip2,
                                base + pl.g[2].mip2, ws.mip_tmp.as<float>() + (size_t)p0 * tmp_floats));
             MI_HIP(hipEventRecord(ws.ev_mip[pi], sm));
-            MI_HIP(hipStreamWaitEvent(sl, ws.ev_mip[pi], 0));
             double* sat_p = ws.sat.as<double>() + (size_t)p0 * sstride;
+            // the three planes' chains are independent (own MIPs, own tables, own lag-transform scratch): each is a dozen small
+            // dependent launches, so they run side by side on their own streams
             for (int m = 0; m < 3; ++m) {
+                hipStream_t sl = ws.sl[m];
+                if (m == 0 || sl != ws.sl[m - 1]) MI_HIP(hipStreamWaitEvent(sl, ws.ev_mip[pi], 0));
                 const PlaneGeom& g = pl.g[m];
                 MI_TRY(prepare_plane_band(sl, base + g.mip1, base + g.mip2, g, lp[m], base + g.ps1, base + g.ps2, sat_p + sat_off[m], np, pstride,
                                           sstride));
-                MI_TRY(lag_cross(dev, sl, lp[m], base + g.mip1, base + g.mip2, pstride, np, ws));
+                MI_TRY(lag_cross(dev, sl, lp[m], base + g.mip1, base + g.mip2, pstride, np, ws, m));
                 const RefineGeom rg = refine_geom(g, lp[m], P.maxIter, sstride, sat_off[m], margin);
                 if (lp[m].lds_refine > 64 * 1024)
                     MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lag_refine), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                (int)lp[m].lds_refine));
                 float* ow = ws.outw.as<float>() + ((size_t)m * chunk + p0) * wcap;
                 int* oi = ws.outi.as<int>() + ((size_t)m * chunk + p0) * 4;
-                hipLaunchKernelGGL(k_lag_refine, dim3(np), dim3(256), lp[m].lds_refine, sl, rg, sat_p, ws.cross.as<double>(), wcap, ow, oi,
+                hipLaunchKernelGGL(k_lag_refine, dim3(np), dim3(256), lp[m].lds_refine, sl, rg, sat_p, ws.cross[m].as<double>(), wcap, ow, oi,
                                    (float*)nullptr);
                 MI_TRY(launch_check("k_lag_refine"));
                 MI_HIP(hipMemcpyAsync(ws.pin_w.as<float>() + ((size_t)m * n + c0 + p0) * wcap, ow, 4 * (size_t)np * wcap, hipMemcpyDeviceToHost, sl));
@@ -905,6 +924,13 @@ int ncc_lag_enqueue(int dev, hipStream_t s, int n, const float* const* a_ptrs, c
             }
         }
     }
+    // the end of the job: plane 0's stream after the other two
+    for (int m = 1; m < 3; ++m) {
+        if (ws.sl[m] == ws.sl[0]) continue;
+        MI_HIP(hipEventRecord(ws.ev_plane[m - 1], ws.sl[m]));
+        MI_HIP(hipStreamWaitEvent(ws.sl[0], ws.ev_plane[m - 1], 0));
+    }
+    hipStream_t sl = ws.sl[0];
     MI_HIP(hipEventRecord(ws.ev_done, sl));  // (everything `sm` was given lies before the last event `sl` waited for)
     job->enqueued = true;
     *job_out = job.release();
@@ -987,7 +1013,7 @@ int ncc_lag_map(int dev, hipStream_t s, const float* mip1, const float* mip2, in
     const RefineGeom rg = refine_geom(g, lp, 0, L.total, 0, 0.0f);
     if (lp.lds_refine > 64 * 1024)
         MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lag_refine), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp.lds_refine));
-    hipLaunchKernelGGL(k_lag_refine, dim3(1), dim3(256), lp.lds_refine, s, rg, ws.sat.as<double>(), ws.cross.as<double>(), 1, ws.outw.as<float>(),
+    hipLaunchKernelGGL(k_lag_refine, dim3(1), dim3(256), lp.lds_refine, s, rg, ws.sat.as<double>(), ws.cross[0].as<double>(), 1, ws.outw.as<float>(),
                        ws.outi.as<int>(), map);
     MI_TRY(launch_check("k_lag_refine"));
     MI_HIP(hipStreamSynchronize(s));
