@@ -159,6 +159,8 @@ extern "C" int mi_ncc_mips_batch(int dev, void* stream, int n_pairs, const float
         };
         std::vector<InFlight> flights;
         int rc = MI_OK;
+        static const char* env_ser = std::getenv("MI_NCC_SERIAL_MIPS");
+        const bool serial_mips = env_ser ? std::atoi(env_ser) != 0 : true;
         for (auto& kv : groups) {
             const std::vector<int>& idx = kv.second;
             const int q0 = idx[0], n = (int)idx.size();
@@ -179,8 +181,19 @@ extern "C" int mi_ncc_mips_batch(int dev, void* stream, int n_pairs, const float
             f.pa.resize(n); f.pb.resize(n); f.pp.resize(n);
             for (int i = 0; i < n; ++i) { f.pa[i] = tiles[a_idx[idx[i]]]; f.pb[i] = tiles[b_idx[idx[i]]]; f.pp[i] = params[idx[i]]; }
             rc = ncc_lag_enqueue(dev, user, n, f.pa.data(), f.pb.data(), dimk, dimi, dimj, ni[q0], nj[q0], delayk, delayi, delayj, side[q0],
-                                 f.pp.data(), &f.job);
+                                 f.pp.data(), &f.job, serial_mips);
             if (rc != MI_OK) break;
+        }
+        if (rc == MI_OK && serial_mips && !flights.empty()) {
+            // every MIP pass first (one HBM-bound stream after the other), then every chain: a chain kernel that runs beside a MIP
+            // pass waits several times longer for each of its memory accesses, and the chains are latency-bound
+            hipEvent_t gate = nullptr;
+            hipStream_t sm = ncc_lag_mip_stream(flights.back().job);
+            if (hipEventCreateWithFlags(&gate, hipEventDisableTiming) != hipSuccess || hipEventRecord(gate, sm) != hipSuccess)
+                rc = fail(MI_ERR_HIP, "mi_ncc_mips_batch: event setup failed");
+            for (InFlight& f : flights)
+                if (rc == MI_OK) rc = ncc_lag_enqueue_chains(f.job, gate);
+            if (gate) (void)hipEventDestroy(gate);
         }
         for (InFlight& f : flights) {
             if (rc != MI_OK) { ncc_lag_abandon(f.job); continue; }

@@ -797,6 +797,10 @@ struct LagJob {
     int n = 0, wcap = 1, ni = 0, nj = 0, side = 0;
     float margin = 0.0f;
     bool enqueued = false;  // ws->ev_done marks the end of this job's device stage
+    // chains deferred (ncc_lag_enqueue_chains): what they need
+    bool chains_pending = false;
+    int dev = 0, chunk = 0, maxIter = 0;
+    size_t pstride = 0, sstride = 0, sat_off[3] = {0, 0, 0};
     ~LagJob() {
         if (ws) {
             // (whatever the call that owned this job enqueued must not outlive the buffers' next user)
@@ -815,8 +819,11 @@ struct LagJob {
 // (MI_NCC_PIECES > 1 cuts a group into pieces that are pipelined the same way; measured, it loses: the chain is a dozen
 // latency-bound launches whose cost hardly depends on the number of pairs, so pieces multiply it -- 9.3 / 10.2 / 12.3 ms per 112
 // pairs for 1 / 2 / 4 pieces.)
+static int enqueue_chains(LagJob& job, int c0, int p0, int np, int pi, hipEvent_t gate);
+static int close_job(LagJob& job);
+
 int ncc_lag_enqueue(int dev, hipStream_t s, int n, const float* const* a_ptrs, const float* const* b_ptrs, int dimk, int dimi, int dimj, int ni,
-                    int nj, int delayk, int delayi, int delayj, int side, mi_ncc_params* params, LagJob** job_out) {
+                    int nj, int delayk, int delayi, int delayj, int side, mi_ncc_params* params, LagJob** job_out, bool defer_chains) {
     *job_out = nullptr;
     if (n <= 0) return MI_OK;
     std::unique_ptr<LagJob> job(new (std::nothrow) LagJob);
@@ -876,7 +883,10 @@ int ncc_lag_enqueue(int dev, hipStream_t s, int n, const float* const* a_ptrs, c
         htab[2 * q] = a_ptrs[q];
         htab[2 * q + 1] = b_ptrs[q];
     }
-    const float margin = job->margin = ncc_margin();
+    job->margin = ncc_margin();
+    job->dev = dev; job->chunk = chunk; job->maxIter = P.maxIter; job->pstride = pstride; job->sstride = sstride;
+    for (int m = 0; m < 3; ++m) job->sat_off[m] = sat_off[m];
+    const bool defer = defer_chains && chunk >= n && piece >= chunk;  // (one chunk, one piece: nothing of the chains is needed earlier)
     float* base0 = ws.fbuf.as<float>();
     hipStream_t sm = ws.sm;
     MI_HIP(hipEventRecord(ws.ev_start, s));
@@ -900,48 +910,80 @@ int ncc_lag_enqueue(int dev, hipStream_t s, int n, const float* const* a_ptrs, c
                                base + pl.g[0].mip1, base + pl.g[1].mip1, base + pl.g[2].mip1, base + pl.g[0].mip2, base + pl.g[1].mip2,
                                base + pl.g[2].mip2, ws.mip_tmp.as<float>() + (size_t)p0 * tmp_floats));
             MI_HIP(hipEventRecord(ws.ev_mip[pi], sm));
-            double* sat_p = ws.sat.as<double>() + (size_t)p0 * sstride;
-            // the three planes' chains are independent (own MIPs, own tables, own lag-transform scratch): each is a dozen small
-            // dependent launches, so they run side by side on their own streams
-            for (int m = 0; m < 3; ++m) {
-                hipStream_t sl = ws.sl[m];
-                if (m == 0 || sl != ws.sl[m - 1]) MI_HIP(hipStreamWaitEvent(sl, ws.ev_mip[pi], 0));
-                const PlaneGeom& g = pl.g[m];
-                MI_TRY(prepare_plane_band(sl, base + g.mip1, base + g.mip2, g, lp[m], base + g.ps1, base + g.ps2, sat_p + sat_off[m], np, pstride,
-                                          sstride));
-                MI_TRY(lag_cross(dev, sl, lp[m], base + g.mip1, base + g.mip2, pstride, np, ws, m));
-                const RefineGeom rg = refine_geom(g, lp[m], P.maxIter, sstride, sat_off[m], margin);
-                if (lp[m].lds_refine > 64 * 1024)
-                    MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lag_refine), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               (int)lp[m].lds_refine));
-                float* ow = ws.outw.as<float>() + ((size_t)m * chunk + p0) * wcap;
-                int* oi = ws.outi.as<int>() + ((size_t)m * chunk + p0) * 4;
-                hipLaunchKernelGGL(k_lag_refine, dim3(np), dim3(256), lp[m].lds_refine, sl, rg, sat_p, ws.cross[m].as<double>(), wcap, ow, oi,
-                                   (float*)nullptr);
-                MI_TRY(launch_check("k_lag_refine"));
-                MI_HIP(hipMemcpyAsync(ws.pin_w.as<float>() + ((size_t)m * n + c0 + p0) * wcap, ow, 4 * (size_t)np * wcap, hipMemcpyDeviceToHost, sl));
-                MI_HIP(hipMemcpyAsync(ws.pin_i.as<int>() + ((size_t)m * n + c0 + p0) * 4, oi, sizeof(int) * 4 * np, hipMemcpyDeviceToHost, sl));
-            }
+            if (defer) continue;
+            MI_TRY(enqueue_chains(*job, c0, p0, np, pi, ws.ev_mip[pi]));
         }
     }
-    // the end of the job: plane 0's stream after the other two
+    job->chains_pending = defer;
+    if (!defer) MI_TRY(close_job(*job));
+    *job_out = job.release();
+    return MI_OK;
+}
+
+// the table / lag-transform / refinement chains of the pairs [p0, p0 + np) of a chunk, one plane per chain stream, behind `gate`
+static int enqueue_chains(LagJob& job, int c0, int p0, int np, int pi, hipEvent_t gate) {
+    (void)pi;
+    LagWorkspace& ws = *job.ws;
+    const PairPlan& pl = job.pl;
+    const LagPlane* lp = job.lp;
+    const int n = job.n, wcap = job.wcap, chunk = job.chunk;
+    const size_t pstride = job.pstride, sstride = job.sstride;
+    float* base = ws.fbuf.as<float>() + (size_t)p0 * pstride;
+    double* sat_p = ws.sat.as<double>() + (size_t)p0 * sstride;
+    // the three planes' chains are independent (own MIPs, own tables, own lag-transform scratch): each is a dozen small
+    // dependent launches, so they run side by side on their own streams
+    for (int m = 0; m < 3; ++m) {
+        hipStream_t sl = ws.sl[m];
+        if (m == 0 || sl != ws.sl[m - 1]) MI_HIP(hipStreamWaitEvent(sl, gate, 0));
+        const PlaneGeom& g = pl.g[m];
+        MI_TRY(prepare_plane_band(sl, base + g.mip1, base + g.mip2, g, lp[m], base + g.ps1, base + g.ps2, sat_p + job.sat_off[m], np, pstride,
+                                  sstride));
+        MI_TRY(lag_cross(job.dev, sl, lp[m], base + g.mip1, base + g.mip2, pstride, np, ws, m));
+        const RefineGeom rg = refine_geom(g, lp[m], job.maxIter, sstride, job.sat_off[m], job.margin);
+        if (lp[m].lds_refine > 64 * 1024)
+            MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lag_refine), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lp[m].lds_refine));
+        float* ow = ws.outw.as<float>() + ((size_t)m * chunk + p0) * wcap;
+        int* oi = ws.outi.as<int>() + ((size_t)m * chunk + p0) * 4;
+        hipLaunchKernelGGL(k_lag_refine, dim3(np), dim3(256), lp[m].lds_refine, sl, rg, sat_p, ws.cross[m].as<double>(), wcap, ow, oi,
+                           (float*)nullptr);
+        MI_TRY(launch_check("k_lag_refine"));
+        MI_HIP(hipMemcpyAsync(ws.pin_w.as<float>() + ((size_t)m * n + c0 + p0) * wcap, ow, 4 * (size_t)np * wcap, hipMemcpyDeviceToHost, sl));
+        MI_HIP(hipMemcpyAsync(ws.pin_i.as<int>() + ((size_t)m * n + c0 + p0) * 4, oi, sizeof(int) * 4 * np, hipMemcpyDeviceToHost, sl));
+    }
+    return MI_OK;
+}
+
+// the end of the job: plane 0's stream after the other two
+static int close_job(LagJob& job) {
+    LagWorkspace& ws = *job.ws;
     for (int m = 1; m < 3; ++m) {
         if (ws.sl[m] == ws.sl[0]) continue;
         MI_HIP(hipEventRecord(ws.ev_plane[m - 1], ws.sl[m]));
         MI_HIP(hipStreamWaitEvent(ws.sl[0], ws.ev_plane[m - 1], 0));
     }
-    hipStream_t sl = ws.sl[0];
-    MI_HIP(hipEventRecord(ws.ev_done, sl));  // (everything `sm` was given lies before the last event `sl` waited for)
-    job->enqueued = true;
-    *job_out = job.release();
+    MI_HIP(hipEventRecord(ws.ev_done, ws.sl[0]));  // (everything `sm` was given lies before the last event a chain waited for)
+    job.enqueued = true;
     return MI_OK;
 }
+
+// the chains of a job whose enqueue deferred them, behind `gate` (an event on the device's MIP stream: the batch records it
+// after the LAST group's MIP pass, so that no chain kernel competes with a MIP pass for the memory system)
+int ncc_lag_enqueue_chains(LagJob* job, hipEvent_t gate) {
+    if (!job || !job->chains_pending) return MI_OK;
+    MI_TRY(enqueue_chains(*job, 0, 0, job->n, 0, gate ? gate : job->ws->ev_mip[0]));
+    job->chains_pending = false;
+    return close_job(*job);
+}
+
+hipStream_t ncc_lag_mip_stream(LagJob* job) { return job ? job->ws->sm : nullptr; }
 
 // Waits for the group's device stage, then the host rules.  careful[q] is set for pairs whose result was not taken here (see the
 // header of this file); out[q] is then untouched.  Destroys the job.
 int ncc_lag_finish(LagJob* job_in, mi_ncc_params* params, mi_ncc_descr* out, unsigned char* careful) {
     std::unique_ptr<LagJob> job(job_in);
     if (!job) return MI_OK;
+    if (job->chains_pending) MI_TRY(ncc_lag_enqueue_chains(job.get(), nullptr));
     LagWorkspace& ws = *job->ws;
     const PairPlan& pl = job->pl;
     const int n = job->n, wcap = job->wcap;
@@ -986,7 +1028,7 @@ void ncc_lag_abandon(LagJob* job) { delete job; }
 int ncc_lag_group(int dev, hipStream_t s, int n, const float* const* a_ptrs, const float* const* b_ptrs, int dimk, int dimi, int dimj, int ni,
                   int nj, int delayk, int delayi, int delayj, int side, mi_ncc_params* params, mi_ncc_descr* out, unsigned char* careful) {
     LagJob* job = nullptr;
-    MI_TRY(ncc_lag_enqueue(dev, s, n, a_ptrs, b_ptrs, dimk, dimi, dimj, ni, nj, delayk, delayi, delayj, side, params, &job));
+    MI_TRY(ncc_lag_enqueue(dev, s, n, a_ptrs, b_ptrs, dimk, dimi, dimj, ni, nj, delayk, delayi, delayj, side, params, &job, false));
     return ncc_lag_finish(job, params, out, careful);
 }
 
