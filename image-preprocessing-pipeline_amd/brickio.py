@@ -57,10 +57,13 @@ def _lib():
     return _lz4
 
 
-def save_lz4(filename, array, chunk_size=CHUNK_SIZE):
+def save_lz4(filename, array, chunk_size=CHUNK_SIZE, pool=None):
     """``save_lz4_mex(filename, array)``: the header is written twice -- a placeholder first, the final one with the chunk sizes
     at the end (save_lz4_mex.c:131-175); the file appears under its name only when complete (callers write ``*.tmp`` and rename,
-    LsDeconv.m:805-806)."""
+    LsDeconv.m:805-806).  ``chunk_size``: the reference compresses chunks of 1 GiB one after the other; the format records every
+    chunk's sizes in its header and both of its loaders walk that table (load_lz4_mex.c:135-165, load_slab_lz4.cpp:100-130), so
+    smaller chunks read back the same -- and ``pool`` (a ``concurrent.futures`` executor) compresses them side by side: liblz4
+    runs outside the GIL.  The array's memory is read in place (no copy for contiguous input)."""
     a = np.ascontiguousarray(array)
     if a.dtype not in _CODES:
         raise TypeError("save_lz4_mex:BadType: Only double, single, and uint16 arrays are supported.")
@@ -76,17 +79,36 @@ def save_lz4(filename, array, chunk_size=CHUNK_SIZE):
     h["dims"][:a.ndim] = a.shape[::-1]                                   # MATLAB order: fastest axis first
     h["total_uncompressed"], h["chunk_size"], h["num_chunks"] = total, chunk_size, n_chunks
     lib = _lib()
+    bound = lib.LZ4_compressBound(int(min(chunk_size, max(total, 1))))
+
+    def compress(i, dst):
+        src = raw[i * chunk_size:(i + 1) * chunk_size]
+        n = lib.LZ4_compress_default(src.ctypes.data, dst.ctypes.data, int(src.size), int(dst.size))
+        if n <= 0:
+            raise RuntimeError(f"save_lz4_mex:CompressionFailed: chunk {i}")
+        return int(src.size), n
+
     with open(filename, "wb") as f:
         f.write(h.tobytes())
-        bound = lib.LZ4_compressBound(int(min(chunk_size, max(total, 1))))
-        dst = np.empty(bound, np.uint8)
-        for i in range(n_chunks):
-            src = raw[i * chunk_size:(i + 1) * chunk_size]
-            n = lib.LZ4_compress_default(src.ctypes.data, dst.ctypes.data, int(src.size), int(bound))
-            if n <= 0:
-                raise RuntimeError(f"save_lz4_mex:CompressionFailed: chunk {i}")
-            f.write(dst[:n].tobytes())
-            h["chunk_uncomp"][i], h["chunk_comp"][i] = src.size, n
+        if pool is None or n_chunks <= 1:
+            dst = np.empty(bound, np.uint8)
+            for i in range(n_chunks):
+                usize, n = compress(i, dst)
+                f.write(memoryview(dst)[:n])
+                h["chunk_uncomp"][i], h["chunk_comp"][i] = usize, n
+        else:
+            # a window of chunks in flight: compressed side by side, written in order
+            window = max(2, min(n_chunks, getattr(pool, "_max_workers", 4) + 1))
+            bufs = [np.empty(bound, np.uint8) for _ in range(window)]
+            futs = {}
+            nxt = 0
+            for i in range(n_chunks):
+                while nxt < n_chunks and nxt < i + window:
+                    futs[nxt] = pool.submit(compress, nxt, bufs[nxt % window])
+                    nxt += 1
+                usize, n = futs.pop(i).result()
+                f.write(memoryview(bufs[i % window])[:n])
+                h["chunk_uncomp"][i], h["chunk_comp"][i] = usize, n
         f.seek(0)
         f.write(h.tobytes())
 
@@ -102,8 +124,10 @@ def read_header(f):
     return h
 
 
-def load_lz4(filename):
-    """``load_lz4_mex(filename)`` -> array in (Z, Y, X) order (the reverse of the stored MATLAB dims)."""
+def load_lz4(filename, pool=None, out=None):
+    """``load_lz4_mex(filename)`` -> array in (Z, Y, X) order (the reverse of the stored MATLAB dims).  ``pool``: the chunks are
+    decompressed side by side; ``out``: a writable uint8 buffer of at least the uncompressed size (e.g. pinned memory) that
+    receives the bytes instead of a fresh array."""
     lib = _lib()
     with open(filename, "rb") as f:
         try:
@@ -112,19 +136,39 @@ def load_lz4(filename):
             raise ValueError(f"{filename}: {e}") from None
         dt = np.dtype(_DTYPES[int(h["dtype"])])
         total = int(h["total_uncompressed"])
-        out = np.empty(total, np.uint8)
-        off = 0
-        for i in range(int(h["num_chunks"])):
-            clen, ulen = int(h["chunk_comp"][i]), int(h["chunk_uncomp"][i])
-            comp = np.frombuffer(f.read(clen), np.uint8)
-            if comp.size != clen:
-                raise ValueError(f"{filename}: chunk: I/O error")
-            n = lib.LZ4_decompress_safe(comp.ctypes.data, out[off:].ctypes.data, clen, ulen) if ulen else 0
-            if n != ulen:
-                raise ValueError(f"{filename}: LZ4 error")
-            off += ulen
-        if off != total:
+        nch = int(h["num_chunks"])
+        clens = [int(h["chunk_comp"][i]) for i in range(nch)]
+        ulens = [int(h["chunk_uncomp"][i]) for i in range(nch)]
+        if sum(ulens) != total:
             raise ValueError(f"{filename}: size mismatch")
+        if out is None:
+            out = np.empty(total, np.uint8)
+        else:
+            out = np.asarray(out).reshape(-1).view(np.uint8)
+            if out.size < total or not out.flags.writeable:
+                raise ValueError("load_lz4: `out` is too small or read-only")
+            out = out[:total]
+        comp = np.empty(sum(clens), np.uint8)
+        if f.readinto(memoryview(comp)) != comp.size:
+            raise ValueError(f"{filename}: chunk: I/O error")
+
+    def expand(i, coff, uoff):
+        clen, ulen = clens[i], ulens[i]
+        n = lib.LZ4_decompress_safe(comp[coff:].ctypes.data, out[uoff:].ctypes.data, clen, ulen) if ulen else 0
+        if n != ulen:
+            raise ValueError(f"{filename}: LZ4 error")
+
+    jobs, coff, uoff = [], 0, 0
+    for i in range(nch):
+        jobs.append((i, coff, uoff))
+        coff += clens[i]
+        uoff += ulens[i]
+    if pool is None or nch <= 1:
+        for jb in jobs:
+            expand(*jb)
+    else:
+        for fu in [pool.submit(expand, *jb) for jb in jobs]:
+            fu.result()
     dims = [int(v) for v in h["dims"][:int(h["ndims"])]][::-1]
     return out.view(dt).reshape(dims)
 

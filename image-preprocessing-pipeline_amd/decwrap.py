@@ -221,6 +221,16 @@ def main(argv=None):
     import time
     from concurrent.futures import ThreadPoolExecutor
     from ipp_amd import brickio
+    # LZ4 runs as chunk jobs on one pool for the whole run (bricks are written -- and later read -- as 32-MiB chunks, which the
+    # brick format allows: every chunk's sizes are in the header, save_lz4_mex.c:56-67): a single core compresses side by side
+    # on every host core instead of on one, and the few writer threads only put the chunks into their file in order
+    try:
+        n_cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n_cores = os.cpu_count() or 4
+    n_writers = max(2, min(4, n_cores // 4))
+    codec = ThreadPoolExecutor(max_workers=max(2, n_cores - 1))
+    brick_chunk = int(os.environ.get("MI_DECWRAP_BRICK_CHUNK", 32 << 20))
     cache = Path(args.cache_drive) if args.cache_drive else out_dir / "cache"
     if not args.resume and args.start_block == 1:
         if cache.exists():
@@ -253,9 +263,8 @@ def main(argv=None):
         except Exception:
             ram = int(os.environ.get("MI_DECWRAP_RAM_BYTES", 64 << 30))
         out_bytes = 1 if (args.convert_to_8bit or (np.dtype(vol.dtype).itemsize == 1 and not args.convert_to_16bit)) else 2
-        n_wr = max(2, min(8, (os.cpu_count() or 4) // 2))
         block = L.autosplit((sx, sy, sz), psf.shape[::-1], filt, bmax, args.numit, ram_available=ram, output_bytes=out_bytes,
-                            cores_in_flight=n_wr + 1 + len(args.gpu_indices) * max(1, args.gpu_workers_per_gpu))
+                            cores_in_flight=n_writers + len(args.gpu_indices) * max(1, args.gpu_workers_per_gpu))
         tmp = block_path.with_suffix(".json.tmp")
         with open(tmp, "w") as f:
             json.dump({"stack_info": stack_info,
@@ -320,17 +329,75 @@ def main(argv=None):
     # never take the same block (LsDeconv.m:696-706); the result reaches the cache as bl_<n>.lz4.tmp + rename (:805-806).
     workers = [g for g in args.gpu_indices for _ in range(max(1, args.gpu_workers_per_gpu))]
 
+    import socket
+    me = f"{socket.gethostname()}:{os.getpid()}"
+
     def claim(n):
+        """creates the (empty) brick file; who holds the claim is noted beside it, for the reaper of another round or process"""
         try:
             os.close(os.open(brick_path(n), os.O_CREAT | os.O_EXCL | os.O_WRONLY))
-            return True
         except FileExistsError:
             return False
+        try:
+            with open(brick_path(n).with_suffix(".claim"), "w") as f:
+                f.write(me)
+        except OSError:
+            pass
+        return True
+
+    stale_s = float(os.environ.get("MI_DECWRAP_STALE_S", 1800))
+
+    def claim_is_dead(n):
+        """an incomplete brick may be removed when nobody can be working on it: it is this process' own leftover, its owner is a
+        process of this host that no longer exists, or it has not been touched for MI_DECWRAP_STALE_S seconds (default 30 min: far
+        beyond a block's run time) -- a live claim of another machine on a shared cache folder is left alone"""
+        try:
+            owner = brick_path(n).with_suffix(".claim").read_text().strip()
+        except OSError:
+            owner = ""
+        host, _, pid = owner.rpartition(":")
+        if owner == me:
+            return True
+        if host == socket.gethostname() and pid.isdigit():
+            try:
+                os.kill(int(pid), 0)
+            except ProcessLookupError:
+                return True
+            except PermissionError:
+                pass
+        newest = 0.0
+        for q in (brick_path(n), brick_path(n).with_suffix(".lz4.tmp"), brick_path(n).with_suffix(".claim")):
+            try:
+                newest = max(newest, q.stat().st_mtime)
+            except OSError:
+                pass
+        # (no owner note: the claimant died between its two steps, or the file was placed by hand -- a minute is enough)
+        return time.time() - newest > (60.0 if owner == "" else stale_s)
+
+    # Pinned host buffers of one core each, shared by the workers (D2H target), the brick writers (LZ4 source) and, later, the brick
+    # readers of the assembly (LZ4 target, H2D source): a core goes device -> pinned buffer -> compressed chunks -> file without
+    # another copy on the host.  The pool is the back-pressure too: a worker waits for a buffer when the writers are behind.
+    import queue
+    core_max = int(block.x) * int(block.y) * int(block.z)
+    n_stage = len(workers) + n_writers
+    stage_free, stage_made = queue.Queue(), [0]
+
+    def stage_get():
+        with lock:
+            make = stage_made[0] < n_stage
+            if make:
+                stage_made[0] += 1
+        if make and stage_free.empty():
+            return torch.empty(core_max, dtype=torch.float32, pin_memory=True)
+        if make:
+            with lock:
+                stage_made[0] -= 1
+        return stage_free.get()
 
     def run(worker_id, first_block):
         g = workers[worker_id]
         stream = torch.cuda.Stream(device=g - 1)
-        staging = {}  # pinned host buffers by core shape: D2H at PCIe rate instead of page-faulting a fresh pageable array
+        staging = {}  # the worker's pinned upload buffer (load_block_device)
         # blocks of equal shape share the RL context and the taper's FFT engine (MI_NO_DECON_PLAN: rebuild them per block)
         plan = None if os.environ.get("MI_NO_DECON_PLAN") else D.DeconPlan(g)
         try:
@@ -360,38 +427,38 @@ def main(argv=None):
             core = t[pad[2]:t.shape[0] - pad[2] or None, pad[1]:t.shape[1] - pad[1] or None, pad[0]:t.shape[2] - pad[0] or None]
             core = core.contiguous()                                                       # strip pads, LsDeconv.m:750-752
             assert tuple(core.shape) == core_shape(n), "[remove padding]: Output block size mismatch!"
-            if tuple(core.shape) not in staging:
-                staging[tuple(core.shape)] = torch.empty(core.shape, dtype=torch.float32, pin_memory=True)
-            host = staging[tuple(core.shape)]
-            host.copy_(core, non_blocking=True)
+            host = stage_get()                                                             # (waits while the writers are behind)
+            view = host[:core.numel()].view(core.shape)
+            view.copy_(core, non_blocking=True)
             stream.synchronize()
-            arr = np.array(host.numpy())                                                   # the staging buffer is reused by the next block
         merge_min_max(lb, ub, rawmax)
-        # the brick is compressed and written behind the worker's back: LZ4 of a float32 core takes longer than its kernels;
-        # at most `inflight` cores wait for a writer (back-pressure instead of a queue that could grow to the whole volume)
-        inflight.acquire()
+        # the brick is compressed and written behind the worker's back, straight from the pinned buffer, its chunks side by side
+        # on the codec pool; the buffer returns to the pool when the file is complete
         with lock:
-            pending.append(writers.submit(save_brick, n, arr, lb, ub))
+            pending.append(writers.submit(save_brick, n, view.numpy(), host, lb, ub))
         log.info(f"block {n}/{num_blocks} done on GPU {g}: stats [{lb:.4g}, {ub:.4g}]")
 
-    def save_brick(n, arr, lb, ub):
+    def save_brick(n, arr, host, lb, ub):
         try:
             brick = brick_path(n)
             with open(brick.with_suffix(".json"), "w") as f:                               # the block's own clip range
                 json.dump({"lb": lb, "ub": ub}, f)
-            brickio.save_lz4(brick.with_suffix(".lz4.tmp"), arr)                           # LsDeconv.m:805-806
-            os.replace(brick.with_suffix(".lz4.tmp"), brick)
+            brickio.save_lz4(brick.with_suffix(".lz4.tmp"), arr, chunk_size=brick_chunk, pool=codec)   # LsDeconv.m:805-806
+            try:
+                os.replace(brick.with_suffix(".lz4.tmp"), brick)
+            except FileNotFoundError:
+                # another process that shares the cache folder reaped this claim (it looked stale to it): the block is redone by
+                # whoever claims it next -- the same race exists in LsDeconv.m:621-640 -- and nothing of this run is lost but time
+                log.warning(f"block {n}: the claim was removed by another process while its brick was being written; skipped")
         finally:
-            inflight.release()
+            stage_free.put(host)
 
     # ---- the deconvolution rounds (LsDeconv.m:618-660): stale claims and half-written bricks of an earlier run are removed,
     # the workers take what is missing from --start-block on; whatever is still missing afterwards (blocks below the start
     # block, claims of a process that died) is taken by another round from block 1
     start = max(1, min(int(args.start_block), num_blocks))
     pending = []
-    n_writers = max(2, min(8, (os.cpu_count() or 4) // 2))
-    inflight = threading.BoundedSemaphore(n_writers + 1)
-    with ThreadPoolExecutor(max_workers=n_writers) as writers:                             # liblz4 runs outside the GIL
+    with ThreadPoolExecutor(max_workers=n_writers) as writers:                             # one brick file each; liblz4 runs outside the GIL
         while True:
             missing = 0
             for n in range(1, num_blocks + 1):
@@ -400,8 +467,8 @@ def main(argv=None):
                         log.info(f"block {n}/{num_blocks} taken from the cache")
                     continue
                 missing += 1
-                if n >= start:
-                    for q in (brick_path(n), brick_path(n).with_suffix(".lz4.tmp")):
+                if n >= start and claim_is_dead(n):
+                    for q in (brick_path(n), brick_path(n).with_suffix(".lz4.tmp"), brick_path(n).with_suffix(".claim")):
                         try:
                             q.unlink()
                         except FileNotFoundError:
@@ -413,12 +480,15 @@ def main(argv=None):
                     f.result()                                                             # re-raises a worker's exception
             for f in pending:
                 f.result()
+            if not pending and start == 1:
+                time.sleep(2.0)                                                            # the missing blocks are live claims of another process
             pending.clear()
             if start > 1 and all(brick_complete(n) for n in range(start, num_blocks + 1)):
                 break                                                                      # a helper machine is done with its share
             start = 1
     if int(args.start_block) != 1:
         log.info("--start-block > 1: the blocks are in the cache; the process started with --start-block 1 assembles the output")
+        codec.shutdown(wait=True)
         return 0                                                                           # LsDeconv.m:579-583, 667-670
 
     # ---- postprocess_save (LsDeconv.m:950-1111): clip range over all blocks, target scale, then one z slab of bricks at a time:
@@ -447,22 +517,53 @@ def main(argv=None):
     dev = torch.device("cuda", args.gpu_indices[0] - 1)
     per_slab = block.nx * block.ny
     n_tif = 0
+    out_dtype = np.uint8 if bits == 8 else np.uint16
+    slab_buf = None                      # one integer slab, reused by every z slab of bricks (fresh pages cost seconds per slab)
+    q_host = [torch.empty(core_max, dtype=torch.uint8 if bits == 8 else torch.uint16, pin_memory=True) for _ in range(2)]
+
+    def read_brick(n):
+        """brick -> a pinned core buffer (chunks decompressed side by side on the codec pool)"""
+        host = stage_get()
+        try:
+            core = brickio.load_lz4(brick_path(n), pool=codec, out=host.numpy())
+        except BaseException:
+            stage_free.put(host)
+            raise
+        if core.shape != core_shape(n):
+            stage_free.put(host)
+            raise RuntimeError(f"brick {brick_path(n)} has shape {core.shape}, block {n} needs {core_shape(n)}")
+        return host, core
+
     for iz in range(block.nz):
-        ids = range(iz * per_slab + 1, (iz + 1) * per_slab + 1)
+        ids = list(range(iz * per_slab + 1, (iz + 1) * per_slab + 1))
         z1, z2 = int(block.p1[ids[0] - 1][2]), int(block.p2[ids[0] - 1][2])
         if tiff_out and all((out_dir / f"img_{z:06d}.tif").exists() for z in range(z1, z2 + 1)) and not want_npy:
             continue                                                                       # resume: this slab's slices exist (:1037-1054)
-        slab = np.empty((z2 - z1 + 1, sy, sx), np.uint8 if bits == 8 else np.uint16)
-        for n in ids:
-            p1, p2 = block.p1[n - 1], block.p2[n - 1]
-            core = brickio.load_lz4(brick_path(n))
-            if core.shape != core_shape(n):
-                raise RuntimeError(f"brick {brick_path(n)} has shape {core.shape}, block {n} needs {core_shape(n)}")
-            box = (slice(int(p1[2]) - z1, int(p2[2]) - z1 + 1), slice(int(p1[1]) - 1, int(p2[1])), slice(int(p1[0]) - 1, int(p2[0])))
-            if npy_f is not None:
-                npy_f[int(p1[2]) - 1:int(p2[2]), box[1], box[2]] = core
-            q = D.rescale_block(torch.from_numpy(np.ascontiguousarray(core, dtype=np.float32)).to(dev), scal, args.signal_amp, lo, hi)
-            slab[box] = q.cpu().numpy()
+        if slab_buf is None:
+            slab_buf = np.empty((int(block.z), sy, sx), out_dtype)
+        slab = slab_buf[:z2 - z1 + 1]
+        with ThreadPoolExecutor(max_workers=2) as readers:                                 # bricks are read ahead of the device
+            ahead = max(1, min(2, n_stage - 1))
+            futs = {k: readers.submit(read_brick, ids[k]) for k in range(min(ahead, len(ids)))}
+            for k, n in enumerate(ids):
+                host, core = futs.pop(k).result()
+                if k + ahead < len(ids):
+                    futs[k + ahead] = readers.submit(read_brick, ids[k + ahead])
+                p1, p2 = block.p1[n - 1], block.p2[n - 1]
+                box = (slice(int(p1[2]) - z1, int(p2[2]) - z1 + 1), slice(int(p1[1]) - 1, int(p2[1])), slice(int(p1[0]) - 1, int(p2[0])))
+                if npy_f is not None:
+                    npy_f[int(p1[2]) - 1:int(p2[2]), box[1], box[2]] = core
+                # rescale on the device (load_slab_lz4.cpp:134-157): pinned core up, pinned integers down
+                qh = q_host[k & 1][:core.size].view(core.shape)
+                with torch.cuda.device(dev):
+                    d_core = host[:core.size].view(core.shape).to(dev, non_blocking=True)       # (the pinned tensor itself: a true async copy)
+                    q = D.rescale_block(d_core, scal, args.signal_amp, lo, hi)
+                    qh.copy_(q, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record()
+                ev.synchronize()
+                stage_free.put(host)
+                slab[box] = qh.numpy()
         if args.flip:
             slab = np.ascontiguousarray(slab[:, ::-1])                                     # R = flip(R, 2): the y axis (LsDeconv.m:1097-1099)
         if npy_i is not None:
@@ -475,6 +576,7 @@ def main(argv=None):
     del npy_f, npy_i
     if tiff_out:
         log.info(f"wrote {n_tif} TIFF slices to {out_dir}")
+    codec.shutdown(wait=True)
     shutil.rmtree(cache, ignore_errors=True)                                               # LsDeconv.m:286-296
     log.info(f"wrote {out_dir} (scale {scal:g}, clip [{lo:.4g}, {hi:.4g}])")
     return 0

@@ -93,3 +93,29 @@ def test_lazy_tiff_volume_reads_boxes(tmp_path):
     for box in [(slice(0, 9), slice(0, 20), slice(0, 23)), (slice(2, 5), slice(3, 17), slice(1, 8)), (slice(8, 9), slice(19, 20), slice(0, 23))]:
         assert np.array_equal(lazy[box], vol[box])
     assert len(lazy._cache) <= 3
+
+
+def test_parallel_chunks_round_trip_and_out_buffer(tmp_path):
+    """Bricks written as small chunks on a thread pool (decwrap's writers) are byte-identical to the same chunks written one after
+    the other, read back by either route, and land in a caller's buffer when one is given (save_lz4_mex.c:131-175,
+    load_lz4_mex.c:135-165: the chunk table of the header drives the loaders)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from ipp_amd import brickio
+    rng = np.random.default_rng(3)
+    a = (rng.random((7, 33, 65)) * np.linspace(0, 1, 65)).astype(np.float32)
+    a[2:4] = 0.0                                                         # a compressible stretch
+    with ThreadPoolExecutor(4) as pool:
+        brickio.save_lz4(tmp_path / "par.lz4", a, chunk_size=4096, pool=pool)
+        brickio.save_lz4(tmp_path / "ser.lz4", a, chunk_size=4096)
+        assert (tmp_path / "par.lz4").read_bytes() == (tmp_path / "ser.lz4").read_bytes()
+        with open(tmp_path / "par.lz4", "rb") as f:
+            h = brickio.read_header(f)
+        assert int(h["num_chunks"]) == -(-a.nbytes // 4096) and int(h["chunk_size"]) == 4096
+        b = brickio.load_lz4(tmp_path / "par.lz4", pool=pool)
+        buf = np.full(a.nbytes + 64, 0xAB, np.uint8)
+        c = brickio.load_lz4(tmp_path / "par.lz4", pool=pool, out=buf)
+    assert np.array_equal(a, b) and np.array_equal(a, c) and b.dtype == np.float32 and c.shape == a.shape
+    assert np.shares_memory(c, buf) and np.all(buf[a.nbytes:] == 0xAB)
+    import pytest
+    with pytest.raises(ValueError, match="too small"):
+        brickio.load_lz4(tmp_path / "par.lz4", out=np.empty(16, np.uint8))
