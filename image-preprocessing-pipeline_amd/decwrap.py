@@ -418,19 +418,34 @@ def main(argv=None):
             smooth, native = L.next_fast_len(bl_xyz), L.native_fft_shape(bl_xyz)
             fshape = native if np.prod(native) <= 1.3 * np.prod(smooth) else smooth
         blk = L.Block(block.x, block.y, block.z, block.nx, block.ny, block.nz, *pad, fft_shape=fshape)
+        t_a = time.perf_counter()
         with torch.cuda.device(g - 1), torch.cuda.stream(stream):
             # load_block on the device: the raw samples cross PCIe, conversion and symmetric padding happen there
+            ev0 = torch.cuda.Event(enable_timing=True)
+            ev1 = torch.cuda.Event(enable_timing=True)
             bl = L.load_block_device(vol, p1, p2, pad, torch.device("cuda", g - 1), staging)
+            t_b = time.perf_counter()
+            ev0.record()
             rawmax = None if int_input else float(bl.max())                               # LsDeconv.m:717-721
             t, lb, ub = L.process_block(bl, blk, psf_struct, args.numit, args.lambda_damping, args.stop_criterion, filt,
                                         args.clipval, g, plan=plan)
             core = t[pad[2]:t.shape[0] - pad[2] or None, pad[1]:t.shape[1] - pad[1] or None, pad[0]:t.shape[2] - pad[0] or None]
             core = core.contiguous()                                                       # strip pads, LsDeconv.m:750-752
             assert tuple(core.shape) == core_shape(n), "[remove padding]: Output block size mismatch!"
+            ev1.record()
+            t_c = time.perf_counter()
             host = stage_get()                                                             # (waits while the writers are behind)
+            t_d = time.perf_counter()
             view = host[:core.numel()].view(core.shape)
             view.copy_(core, non_blocking=True)
             stream.synchronize()
+        t_e = time.perf_counter()
+        with lock:                                                                         # where a block's time goes (summary at the end)
+            timing["blocks"] += 1
+            timing["box_read_s"] += t_b - t_a
+            timing["device_ms"] += ev0.elapsed_time(ev1)
+            timing["wait_buffer_s"] += t_d - t_c
+            timing["d2h_s"] += t_e - t_d
         merge_min_max(lb, ub, rawmax)
         # the brick is compressed and written behind the worker's back, straight from the pinned buffer, its chunks side by side
         # on the codec pool; the buffer returns to the pool when the file is complete
@@ -458,6 +473,8 @@ def main(argv=None):
     # block, claims of a process that died) is taken by another round from block 1
     start = max(1, min(int(args.start_block), num_blocks))
     pending = []
+    timing = {"blocks": 0, "box_read_s": 0.0, "device_ms": 0.0, "wait_buffer_s": 0.0, "d2h_s": 0.0}
+    t_blocks0 = time.perf_counter()
     with ThreadPoolExecutor(max_workers=n_writers) as writers:                             # one brick file each; liblz4 runs outside the GIL
         while True:
             missing = 0
@@ -486,6 +503,13 @@ def main(argv=None):
             if start > 1 and all(brick_complete(n) for n in range(start, num_blocks + 1)):
                 break                                                                      # a helper machine is done with its share
             start = 1
+    t_blocks = time.perf_counter() - t_blocks0
+    if timing["blocks"]:
+        log.info(f"{timing['blocks']} blocks in {t_blocks:.1f} s: device work {timing['device_ms'] / 1e3:.1f} s "
+                 f"({timing['device_ms'] / 1e3 / max(t_blocks, 1e-9) * 100:.0f} % of that time), box reads {timing['box_read_s']:.1f} s, "
+                 f"D2H of the cores {timing['d2h_s']:.1f} s, waiting for a free core buffer {timing['wait_buffer_s']:.1f} s "
+                 f"(summed over {len(workers)} workers)")
+    main.last_timing = dict(timing, blocks_wall_s=t_blocks)
     if int(args.start_block) != 1:
         log.info("--start-block > 1: the blocks are in the cache; the process started with --start-block 1 assembles the output")
         codec.shutdown(wait=True)
@@ -577,6 +601,7 @@ def main(argv=None):
     if tiff_out:
         log.info(f"wrote {n_tif} TIFF slices to {out_dir}")
     codec.shutdown(wait=True)
+    main.last_timing["assembly_wall_s"] = time.perf_counter() - t_blocks0 - t_blocks
     shutil.rmtree(cache, ignore_errors=True)                                               # LsDeconv.m:286-296
     log.info(f"wrote {out_dir} (scale {scal:g}, clip [{lo:.4g}, {hi:.4g}])")
     return 0
