@@ -394,6 +394,21 @@ def main(argv=None):
                 stage_made[0] -= 1
         return stage_free.get()
 
+    def stage_warm():
+        """pins the pool's buffers while the first blocks are being read and deconvolved (pinning ~1 GB takes a few tenths of a second)"""
+        try:
+            while True:
+                with lock:
+                    if stage_made[0] >= n_stage:
+                        return
+                    stage_made[0] += 1
+                stage_free.put(torch.empty(core_max, dtype=torch.float32, pin_memory=True))
+        except Exception:                                                                  # (the lazy path reports what is wrong)
+            with lock:
+                stage_made[0] -= 1
+
+    threading.Thread(target=stage_warm, daemon=True).start()
+
     def run(worker_id, first_block):
         g = workers[worker_id]
         stream = torch.cuda.Stream(device=g - 1)
@@ -566,7 +581,9 @@ def main(argv=None):
         if slab_buf is None:
             slab_buf = np.empty((int(block.z), sy, sx), out_dtype)
         slab = slab_buf[:z2 - z1 + 1]
-        with ThreadPoolExecutor(max_workers=2) as readers:                                 # bricks are read ahead of the device
+        with ThreadPoolExecutor(max_workers=2) as readers, ThreadPoolExecutor(max_workers=2) as copiers:
+            # bricks are read ahead of the device; the integer cores are copied into the slab behind it
+            placed = [None, None]
             ahead = max(1, min(2, n_stage - 1))
             futs = {k: readers.submit(read_brick, ids[k]) for k in range(min(ahead, len(ids)))}
             for k, n in enumerate(ids):
@@ -578,6 +595,8 @@ def main(argv=None):
                 if npy_f is not None:
                     npy_f[int(p1[2]) - 1:int(p2[2]), box[1], box[2]] = core
                 # rescale on the device (load_slab_lz4.cpp:134-157): pinned core up, pinned integers down
+                if placed[k & 1] is not None:
+                    placed[k & 1].result()                                                 # this integer buffer's last core is in the slab
                 qh = q_host[k & 1][:core.size].view(core.shape)
                 with torch.cuda.device(dev):
                     d_core = host[:core.size].view(core.shape).to(dev, non_blocking=True)       # (the pinned tensor itself: a true async copy)
@@ -587,7 +606,10 @@ def main(argv=None):
                     ev.record()
                 ev.synchronize()
                 stage_free.put(host)
-                slab[box] = qh.numpy()
+                placed[k & 1] = copiers.submit(slab.__setitem__, box, qh.numpy())
+            for fu in placed:
+                if fu is not None:
+                    fu.result()
         if args.flip:
             slab = np.ascontiguousarray(slab[:, ::-1])                                     # R = flip(R, 2): the y axis (LsDeconv.m:1097-1099)
         if npy_i is not None:

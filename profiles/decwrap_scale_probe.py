@@ -14,6 +14,7 @@ import numpy as np  # noqa: E402
 
 shape = tuple(int(v) for v in sys.argv[1:4]) if len(sys.argv) >= 4 else (512, 2048, 2048)
 bmax = sys.argv[4] if len(sys.argv) >= 5 else "300000000"
+nworkers = os.environ.get("PROBE_WORKERS", "2")
 root = "/tmp/decwrap_scale"
 shutil.rmtree(root, ignore_errors=True)
 os.makedirs(root)
@@ -50,7 +51,7 @@ os.environ["MI_DECWRAP_NPY"] = "0"
 from ipp_amd import decwrap  # noqa: E402
 t0 = time.perf_counter()
 rc = decwrap.main(["-i", os.path.join(root, "vol.npy"), "-dxy", "0.422", "-dz", "1.0", "-ex", "488", "-em", "525", "--use-fft", "-it", "6",
-                   "--block-size-max", bmax, "--gpu-indices", "1", "--gpu-workers-per-gpu", "2"])
+                   "--block-size-max", bmax, "--gpu-indices", "1", "--gpu-workers-per-gpu", nworkers])
 dt = time.perf_counter() - t0
 stop.set()
 rss = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6
@@ -60,7 +61,7 @@ if tm:
           f"device-busy; box reads {tm['box_read_s']:.1f} s, D2H {tm['d2h_s']:.1f} s, waiting for a core buffer {tm['wait_buffer_s']:.1f} s, summed over "
           f"the workers), assembly phase {tm.get('assembly_wall_s', 0.0):.1f} s", flush=True)
 nvox = float(np.prod(shape))
-print(f"volume {shape[2]} x {shape[1]} x {shape[0]} uint16 = {nvox * 2 / 1e9:.1f} GB (generated in {t_gen:.0f} s), block-size-max {bmax}: rc {rc}, "
+print(f"{nworkers} workers per GPU; volume {shape[2]} x {shape[1]} x {shape[0]} uint16 = {nvox * 2 / 1e9:.1f} GB (generated in {t_gen:.0f} s), block-size-max {bmax}: rc {rc}, "
       f"{dt:.1f} s wall = {nvox / dt / 1e6:.0f} Mvoxel/s end to end (6 RL iterations, default filters), peak resident set {rss:.1f} GB "
       f"incl. the mapped input file (before the run {rss0:.1f} GB), peak ANONYMOUS resident memory {peak_anon[0]:.1f} GB "
       f"(a float32 copy of the volume would be {nvox * 4 / 1e9:.1f} GB)", flush=True)
