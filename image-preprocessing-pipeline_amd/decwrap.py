@@ -177,6 +177,8 @@ def open_volume(path: Path):
 
 
 def main(argv=None):
+    import time as _time
+    t_main0 = _time.perf_counter()
     gpus = get_all_gpu_indices()
     args = build_parser(gpus).parse_args(argv)
     validate_args(args)
@@ -205,8 +207,10 @@ def main(argv=None):
     vol = open_volume(args.input)
     sz, sy, sx = vol.shape
     dz = args.dz if args.dz else args.dxy
+    t_psf0 = _time.perf_counter()
     psf = P.LsMakePSF(args.dxy * 1000.0, dz * 1000.0, args.na, args.rf, float(args.lambda_ex), float(args.lambda_em),
                       float(args.fcyl), args.slitwidth)                                    # LsDeconv.m:160 (nm units)
+    log.info(f"imports + device {t_psf0 - t_main0:.1f} s, LsMakePSF {_time.perf_counter() - t_psf0:.1f} s")
     psf_struct = D.make_psf_struct(psf)
     log.info(f"PSF size (x y z): {psf.shape[::-1]}")
     filt = L.Filter(tuple(args.gaussian_sigma), tuple(args.gaussian_filter_size), 0.0, args.destripe_sigma,
@@ -490,6 +494,7 @@ def main(argv=None):
     pending = []
     timing = {"blocks": 0, "box_read_s": 0.0, "device_ms": 0.0, "wait_buffer_s": 0.0, "d2h_s": 0.0}
     t_blocks0 = time.perf_counter()
+    log.info(f"set-up (imports, device, PSF, block grid, cache folder): {t_blocks0 - t_main0:.1f} s")
     with ThreadPoolExecutor(max_workers=n_writers) as writers:                             # one brick file each; liblz4 runs outside the GIL
         while True:
             missing = 0
