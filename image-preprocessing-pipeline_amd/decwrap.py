@@ -233,7 +233,10 @@ def main(argv=None):
     except AttributeError:
         n_cores = os.cpu_count() or 4
     n_writers = max(2, min(4, n_cores // 4))
-    codec = ThreadPoolExecutor(max_workers=max(2, n_cores - 1))
+    # (the GPU workers, which launch the kernels, and the brick writers need cores of their own: with every core compressing, the
+    # device sat idle half of the time)
+    n_busy = len(args.gpu_indices) * max(1, args.gpu_workers_per_gpu) + n_writers // 2
+    codec = ThreadPoolExecutor(max_workers=int(os.environ.get("MI_DECWRAP_CODEC_THREADS", max(2, n_cores - n_busy))))
     brick_chunk = int(os.environ.get("MI_DECWRAP_BRICK_CHUNK", 32 << 20))
     cache = Path(args.cache_drive) if args.cache_drive else out_dir / "cache"
     if not args.resume and args.start_block == 1:
