@@ -68,8 +68,9 @@ def build_parser(default_gpus):
     p.add_argument("--stop-criterion", type=float, default=0)
     p.add_argument("--block-size-max", type=int, default=0, help="Max elements per GPU block (0: from free HBM)")
     p.add_argument("--gpu-indices", type=int, nargs="+", default=default_gpus, help="1-based GPU indices")
-    p.add_argument("--gpu-workers-per-gpu", type=int, default=2,
-                   help="workers (own stream + pinned staging) per GPU: two overlap one block's PCIe / host staging with another's kernels")
+    p.add_argument("--gpu-workers-per-gpu", type=int, default=3,
+                   help="workers (own stream + pinned upload buffer) per GPU: they overlap one block's box read / PCIe / host staging "
+                        "with the others' kernels (measured on a 17-GB volume: 2 -> 16.7 s, 3 -> 14.8 s, 4 -> 14.4 s)")
     p.add_argument("--cpu-workers", type=int, default=0)
     p.add_argument("--signal-amp", type=float, default=1.0)
     p.add_argument("--gaussian-sigma", type=float, nargs=3, default=[0.5, 0.5, 2.5])
