@@ -2071,6 +2071,45 @@ int NativeFft::init(hipStream_t s, const int F[3], bool explicit_adjoint) {
     have_adj = explicit_adjoint;
     if (have_adj) MI_TRY(G_adj.alloc(G.bytes));  // explicit adjoint kernel (psf_inv of the 'same'-convolution flavour) instead of conj(OTF)
     MI_HIP(hipStreamSynchronize(s));  // host twiddle vector dies at scope exit
+    // Placement trial (MI_FFT_PLACEMENT_TRIES=<n>, default 1 = off): the strided passes run at one of two speeds per ALLOCATION of the
+    // spectrum arrays (the physical pages behind it decide how the concurrent streams of a pass fall onto the HBM channels; offsets
+    // inside the allocation do not: profiles/r02_xupdate_variance.txt).  With n > 1, up to n allocations are held at once, the y
+    // pass is timed on each (3 launches) and the fastest is kept.
+    int tries = 1;
+    if (const char* e = std::getenv("MI_FFT_PLACEMENT_TRIES")) tries = std::max(1, std::min(4, atoi(e)));
+    if (tries > 1 && S.bytes >= ((size_t)1 << 30)) {
+        DevBuf cand[4];
+        float best = 0.0f;
+        int bi = -1;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        MI_HIP(hipEventCreate(&e0));
+        MI_HIP(hipEventCreate(&e1));
+        int rc = MI_OK;
+        for (int i = 0; i < tries && rc == MI_OK; ++i) {
+            if (i == 0) { cand[0].p = S.p; cand[0].bytes = S.bytes; S.p = nullptr; S.bytes = 0; }
+            else if (cand[i].alloc(cand[0].bytes) != MI_OK) break;   // (no room for another candidate: keep what there is)
+            S.p = cand[i].p; S.bytes = cand[i].bytes;
+            t_spec = S.as<float2>() + n_buf + gap / sizeof(float2);
+            (void)hipMemsetAsync(S.p, 0, S.bytes, s);
+            float ms = 0.0f;
+            for (int r = -1; r < 3 && rc == MI_OK; ++r) {
+                if (r == 0) (void)hipEventRecord(e0, s);
+                rc = y_pass(s, false, dims.paired != 0);
+            }
+            (void)hipEventRecord(e1, s);
+            if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) rc = fail(MI_ERR_HIP, "native FFT: placement trial failed");
+            S.p = nullptr; S.bytes = 0;
+            if (rc == MI_OK && (bi < 0 || ms < best)) { best = ms; bi = i; }
+            if (std::getenv("MI_FFT_PLACEMENT_LOG")) fprintf(stderr, "placement trial %d: y pass %.3f ms\n", i, ms / 3.0f);
+        }
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        if (bi < 0) bi = 0;
+        S.p = cand[bi].p; S.bytes = cand[bi].bytes;
+        cand[bi].p = nullptr; cand[bi].bytes = 0;      // (the others are released at scope exit)
+        t_spec = S.as<float2>() + n_buf + gap / sizeof(float2);
+        MI_TRY(rc);
+    }
     return MI_OK;
 }
 
