@@ -244,8 +244,13 @@ def main():
     n_vox_global = vshape[0] * vshape[1] * vshape[2]
 
     if world == 1:
-        bl = make_volume(vshape, dev)
-        ctx = decon.RLContext(vshape, psf_np, None, boundary=capi.BOUNDARY_CIRCULAR, engine=engine, device=dev)
+        if os.environ.get("MI_BENCH_VOLUME_FIRST"):
+            bl = make_volume(vshape, dev)
+            ctx = decon.RLContext(vshape, psf_np, None, boundary=capi.BOUNDARY_CIRCULAR, engine=engine, device=dev)
+        else:
+            # the context first: its spectrum arrays (21.6 GB in one allocation) are mapped while device memory is still one piece
+            ctx = decon.RLContext(vshape, psf_np, None, boundary=capi.BOUNDARY_CIRCULAR, engine=engine, device=dev)
+            bl = make_volume(vshape, dev)
         ratio = None if ctx.fuses else torch.empty_like(bl)   # scratch only for engines that cannot fuse an iteration
 
         def step():

@@ -1,7 +1,7 @@
 #!/bin/bash
 # does keeping the fastest of several allocations of the spectrum arrays remove the two pass speeds?  (bench --no-ncc --no-cpu-baseline)
 B="bench.py --steps 20 --warmup 5 --no-ncc --no-cpu-baseline --no-stages"
-for t in 1 3 1 3 1 3 1 3; do
+for t in ${TRIES:-1 3 1 3 1 3 1 3}; do
   MI_FFT_PLACEMENT_LOG=1 MI_FFT_PLACEMENT_TRIES=$t python3 $B 2> gpurun_out/place.err | python3 -c "
 import sys, json
 for l in sys.stdin:
