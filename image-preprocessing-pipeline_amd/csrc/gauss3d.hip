@@ -9,6 +9,8 @@
 // along y with an LDS ring of x-filtered rows, z a second walk with a per-lane ring landing back in
 // `vol`.  Taps travel in the kernel argument block.
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 
 #include "mi_internal.h"
 #include "mi_lsdeconv.h"
@@ -244,9 +246,11 @@ __global__ __launch_bounds__(256) void k_gauss_z(const float* __restrict__ src, 
 // planes and emits one z-filtered plane with 16-byte stores.  A thread owns four neighbouring x of one row from the y filter
 // on (its ring entries are private: no barrier between the y and z filters).  Used when the ring fits (kz <= 12 or so: the
 // sigma = 0.5 regularisation step of the RL loop, 5 taps per axis); larger z kernels take the two-pass kernels above.
-constexpr int GF_TY = 16, GF_TX = 64, GF_THREADS = 256, GF_NPRE = 3;
-__global__ __launch_bounds__(GF_THREADS) void k_gauss3d_fused(const float* __restrict__ src, float* __restrict__ dst, int nx, int ny, int nz,
+constexpr int GF_NPRE = 3;
+template <int GF_TX, int GF_TY>
+__global__ __launch_bounds__((GF_TX / 4) * GF_TY) void k_gauss3d_fused(const float* __restrict__ src, float* __restrict__ dst, int nx, int ny, int nz,
                                                               int zchunk, Taps tx, Taps ty, Taps tz) {
+    constexpr int GF_XQ = GF_TX / 4, GF_THREADS = GF_XQ * GF_TY;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int rx = tx.n / 2, ry = ty.n / 2, rz = tz.n / 2;
     const int cq = (rx + 3) / 4;              // x halo in float4 units per side
@@ -255,7 +259,7 @@ __global__ __launch_bounds__(GF_THREADS) void k_gauss3d_fused(const float* __res
     float* in = lds;                          // [rows_in][seg]
     float* xf = in + rows_in * seg;           // [rows_in][64]
     float* ring = xf + rows_in * GF_TX;       // [tz.n][16][64]
-    const int tid = threadIdx.x, xq = tid & 15, rsub = tid >> 4;
+    const int tid = threadIdx.x, xq = tid % GF_XQ, rsub = tid / GF_XQ;
     // XCD-aware tile order: work-groups are dealt round-robin over the 8 XCDs, so linear id L goes to XCD L % 8; giving every XCD
     // a contiguous range of tiles (x fastest, then y, then z chunk) keeps the x / y halos of neighbouring tiles in ONE L2
     const int gx = (nx + GF_TX - 1) / GF_TX, gy = (ny + GF_TY - 1) / GF_TY, gz = (nz + zchunk - 1) / zchunk;
@@ -297,8 +301,8 @@ __global__ __launch_bounds__(GF_THREADS) void k_gauss3d_fused(const float* __res
         }
         __syncthreads();
         if (p + 1 < zb + rz) fetch(p + 1);
-        for (int it = tid; it < rows_in * 16; it += GF_THREADS) {   // x filter: 4 outputs from kx + 3 staged samples
-            const int r = it >> 4, q = it & 15;
+        for (int it = tid; it < rows_in * GF_XQ; it += GF_THREADS) {   // x filter: 4 outputs from kx + 3 staged samples
+            const int r = it / GF_XQ, q = it % GF_XQ;
             const float* a = in + r * seg + 4 * q + xoff;
             float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f, o3 = 0.0f;
             float v0 = a[0], v1 = a[1], v2 = a[2];
@@ -346,7 +350,22 @@ __global__ __launch_bounds__(GF_THREADS) void k_gauss3d_fused(const float* __res
 #define MI_GAUSS_FUSED_LDS (64 * 1024)
 #endif
 constexpr size_t kFusedLdsMax = MI_GAUSS_FUSED_LDS;
+// tile of the single-pass kernel: 64 x 16 (x, y) by default; MI_GAUSS_TILE=<tx>x<ty> picks another built one (measurements)
+void fused_tile(int* tx, int* ty) {
+    static int sx = 0, sy = 0;
+    if (!sx) {
+        int a = 64, b = 16;
+        if (const char* e = std::getenv("MI_GAUSS_TILE")) {
+            int u = 0, v = 0;
+            if (sscanf(e, "%dx%d", &u, &v) == 2 && ((u == 64 && (v == 16 || v == 32)) || (u == 128 && (v == 8 || v == 16)))) { a = u; b = v; }
+        }
+        sx = a; sy = b;
+    }
+    *tx = sx; *ty = sy;
+}
 size_t fused_lds_bytes(const int* k) {
+    int GF_TX, GF_TY;
+    fused_tile(&GF_TX, &GF_TY);
     const int cq = (k[0] / 2 + 3) / 4, seg = 4 * (GF_TX / 4 + 2 * cq), rows_in = GF_TY + 2 * (k[1] / 2);
     return sizeof(float) * ((size_t)rows_in * seg + (size_t)rows_in * GF_TX + (size_t)k[2] * GF_TY * GF_TX);
 }
@@ -367,8 +386,10 @@ int resolve_taps(const float* sigma, const int* ksize, int* k, Taps& tx, Taps& t
 
 // whether the single-pass kernel takes this filter on this volume (odd kernel sizes, rows of whole float4, the ring in 64 KB)
 bool gauss3d_fuses(int nx, const int* k) {
+    int GF_TX, GF_TY;
+    fused_tile(&GF_TX, &GF_TY);
     const int cq = (k[0] / 2 + 3) / 4, patch = (GF_TY + 2 * (k[1] / 2)) * (GF_TX / 4 + 2 * cq);  // float4 of a staged patch
-    return (nx % 4) == 0 && (k[0] & 1) && (k[1] & 1) && (k[2] & 1) && fused_lds_bytes(k) <= kFusedLdsMax && patch <= GF_NPRE * GF_THREADS;
+    return (nx % 4) == 0 && (k[0] & 1) && (k[1] & 1) && (k[2] & 1) && fused_lds_bytes(k) <= kFusedLdsMax && patch <= GF_NPRE * (GF_TX / 4) * GF_TY;
 }
 
 // out-of-place: dst = G(src), one pass when gauss3d_fuses(); *fused tells the caller which route ran (the two-pass route needs
@@ -382,12 +403,21 @@ int gauss3d_to(hipStream_t s, float* src, float* dst, int nx, int ny, int nz, co
     MI_TRY(resolve_taps(sigma, ksize, k, tx, ty, tz));
     *fused = gauss3d_fuses(nx, k);
     if (*fused) {
-        const int zchunk = k[2] <= 7 ? 128 : 256;
+        int GF_TX, GF_TY;
+        fused_tile(&GF_TX, &GF_TY);
+        int zchunk = k[2] <= 7 ? 128 : 256;
+        if (const char* e = std::getenv("MI_GAUSS_ZCHUNK")) zchunk = std::max(2 * k[2], atoi(e));
         const int total = ((nx + GF_TX - 1) / GF_TX) * ((ny + GF_TY - 1) / GF_TY) * ((nz + zchunk - 1) / zchunk);
         const size_t lds = fused_lds_bytes(k);
-        if (lds > 64 * 1024)
-            MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gauss3d_fused), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_gauss3d_fused, dim3((total + 7) / 8 * 8), dim3(GF_THREADS), lds, s, src, dst, nx, ny, nz, zchunk, tx, ty, tz);
+        const dim3 grid((total + 7) / 8 * 8), block((GF_TX / 4) * GF_TY);
+#define MI_GF(TXV, TYV)                                                                                                                 \
+    if (GF_TX == TXV && GF_TY == TYV) {                                                                                                 \
+        if (lds > 64 * 1024)                                                                                                            \
+            MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gauss3d_fused<TXV, TYV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((k_gauss3d_fused<TXV, TYV>), grid, block, lds, s, src, dst, nx, ny, nz, zchunk, tx, ty, tz);                  \
+    }
+        MI_GF(64, 16) MI_GF(64, 32) MI_GF(128, 8) MI_GF(128, 16)
+#undef MI_GF
         return launch_check("k_gauss3d_fused");
     }
     // pass 1: src -> dst (x then y, each rounded to fp32 like the reference's separate passes); pass 2: dst -> src (z)
