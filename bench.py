@@ -31,7 +31,12 @@ HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec (MI355X_MICROARCH.md, chip-l
 ALGO_BYTES_PER_VOXEL_ITER = 48  # RL FFT path, SURVEY.md section 8d / DESIGN.md
 
 
-def make_psf(kshape):
+def make_psf(kshape, gaussian=False):
+    if gaussian:  # BASELINE config 1: a Gaussian PSF (an outer product of three lines: the direct engine's single-pass separable kernel)
+        import numpy as np
+        ax = [np.exp(-0.5 * ((np.arange(k) - (k - 1) / 2.0) / max((k - 1) / 6.0, 0.5)) ** 2) for k in kshape]
+        p = ax[0][:, None, None] * ax[1][None, :, None] * ax[2][None, None, :]
+        return (p / p.sum()).astype(np.float32)
     from ipp_amd import psf as P
     base, _ = P.generate_psf(lambda_em=525.0, lambda_ex=488.0, numerical_aperture=0.4, dxy=100.0, dz=250.0,
                              refractive_index=1.42, f_cylinder_lens=240.0, slit_width=12.0)
@@ -91,14 +96,14 @@ def host_cores():
     return n
 
 
-def cpu_baseline(vshape, kshape, seconds_budget=15.0):
+def cpu_baseline(vshape, kshape, seconds_budget=15.0, gaussian=False):
     """The oracle's deconFFT loop (oracle/rl_oracle.py:decon_fft_f32 -- scipy.fft, float32 / complex64, every host core)
     on a bounded sub-volume of the same workload: 1/8 of the volume (every extent halved) when one iteration fits the
     budget, else 1/64 (every extent quartered); as many iterations as fit the budget, at most 8."""
     import numpy as np
     from oracle import rl_oracle
     cores = host_cores()
-    psf = make_psf(kshape)
+    psf = make_psf(kshape, gaussian)
     rng = np.random.default_rng(1234)
 
     def run(shape, iters):
@@ -239,7 +244,7 @@ def main():
             dist.init_process_group(backend="gloo", rank=rank, world_size=world)
 
     vshape, kshape = WORKLOADS[args.workload]
-    psf_np = make_psf(kshape)
+    psf_np = make_psf(kshape, gaussian=args.workload == "c1")
     engine = {"auto": capi.ENGINE_AUTO, "direct": capi.ENGINE_DIRECT, "fft": capi.ENGINE_FFT}[args.engine]
     n_vox_global = vshape[0] * vshape[1] * vshape[2]
 
@@ -363,7 +368,7 @@ def main():
             capi.release_cached_memory()
             out["block_stages"] = block_stages(vshape, psf_np, dev)
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(vshape, kshape)
+            out["cpu_baseline"] = cpu_baseline(vshape, kshape, gaussian=args.workload == "c1")
     ncc = None
     if world > 1:
         drv.close()                                  # (the copy-engine link: mapped peer memory, interprocess events)
