@@ -149,6 +149,15 @@ def autosplit(stack_xyz, psf_size_xyz, filt: Filter, block_size_max: int, numit:
                 lo = mid
             else:
                 hi = mid - 1
+        if filt.use_fft:
+            # the padded volume is not monotone in xy -- shape_of moves between the native and the 7-smooth grid by its 1.3x rule,
+            # and both grids are staircases -- so the bisection can stop below a larger xy that fits.  The two grids of one core differ
+            # by at most 1.3x in volume, i.e. 1.14x per xy side: nothing beyond that fits
+            top = min(max(sx, sy), int(1.15 * (lo + 2 * max(pad))) + 8)
+            for xy in range(top, lo, -1):
+                if fits(xy, z) is not None:
+                    lo = xy
+                    break
         # the largest xy of this depth, and -- FFT path -- the largest xy below it whose grid the hand-written pipeline takes
         cands = [fits(lo, z)]
         if filt.use_fft:
@@ -156,6 +165,12 @@ def autosplit(stack_xyz, psf_size_xyz, filt: Filter, block_size_max: int, numit:
             for _ in range(64):
                 c = fits(xy, z)
                 if c is not None and list(c[1]) == native_fft_shape(c[1]):
+                    # (the walk down takes steps of xy / 64: the largest side of this native grid lies within the last step)
+                    for up in range(xy + 1, min(lo, xy + max(1, xy // 64) + 1) + 1):
+                        c2 = fits(up, z)
+                        if c2 is None or list(c2[1]) != native_fft_shape(c2[1]):
+                            break
+                        c = c2
                     cands.append(c)
                     break
                 xy -= max(1, xy // 64)

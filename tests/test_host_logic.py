@@ -52,6 +52,33 @@ def test_pad_rules_and_autosplit():
         assert b.x == b.y and (b.x + 1 + 2 * b.x_pad) ** 2 * (b.z + 2 * b.z_pad) >= 300_000_000 or b.x == 2048
 
 
+def test_autosplit_fft_blocks_are_the_largest_that_fit():
+    """use_fft: the padded volume is not monotone in the xy side (native vs 7-smooth grid, both staircases), so the block must be
+    found by more than a bisection: for the depth autosplit chose, no larger square core fits (brute force over every side), and
+    the chosen block's score (core voxels per unit of transform cost) is not beaten by any candidate of the other depths it
+    looked at [LsDeconv.m:308-385: largest core under block_size_max]."""
+    from ipp_amd import lsdeconv as L
+    f = L.Filter(use_fft=True)
+    for stack, bmax in (((700, 700, 300), 40_000_000), ((1500, 900, 120), 90_000_000), ((400, 400, 400), 9_000_000)):
+        blk = L.autosplit(stack, (9, 9, 19), f, bmax, 6)
+        pad = (blk.x_pad, blk.y_pad, blk.z_pad)
+
+        def grid(core):
+            shape = [c + 2 * p for c, p in zip(core, pad)]
+            smooth, native = L.next_fast_len(shape), L.native_fft_shape(shape)
+            return native if np.prod(native) <= 1.3 * np.prod(smooth) else smooth
+
+        assert list(blk.fft_shape) == grid((blk.x, blk.y, blk.z)) and np.prod(blk.fft_shape) < bmax
+        side = max(blk.x, blk.y)
+        larger = [xy for xy in range(side + 1, max(stack[0], stack[1]) + 1)
+                  if np.prod(grid((min(xy, stack[0]), min(xy, stack[1]), blk.z))) < bmax]
+        # a larger side may fit only on a grid the hand-written pipeline does not take (autosplit prefers the native one by cost)
+        for xy in larger:
+            g = grid((min(xy, stack[0]), min(xy, stack[1]), blk.z))
+            assert g != L.native_fft_shape(g) or list(blk.fft_shape) != L.native_fft_shape(list(blk.fft_shape)) or \
+                min(xy, stack[0]) * min(xy, stack[1]) <= blk.x * blk.y, (stack, xy)
+
+
 def test_decwrap_cli_validation_and_dry_run(tmp_path, capsys):
     from ipp_amd import decwrap
     np.save(tmp_path / "vol.npy", np.zeros((4, 4, 4), np.uint16))
