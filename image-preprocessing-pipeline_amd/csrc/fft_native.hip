@@ -2077,6 +2077,7 @@ int NativeFft::init(hipStream_t s, const int F[3], bool explicit_adjoint) {
     // pass is timed on each (3 launches) and the fastest is kept.
     int tries = 1;
     if (const char* e = std::getenv("MI_FFT_PLACEMENT_TRIES")) tries = std::max(1, std::min(4, atoi(e)));
+    if (std::getenv("MI_FFT_PLACEMENT_LOG")) fprintf(stderr, "spectrum arrays at %p (%zu bytes), OTF at %p\n", S.p, S.bytes, G.p);
     if (tries > 1 && S.bytes >= ((size_t)1 << 30)) {
         DevBuf cand[4];
         float best = 0.0f;

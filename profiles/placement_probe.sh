@@ -9,5 +9,5 @@ for l in sys.stdin:
         d = json.loads(l); r = d['roofline']; p = r['pass_ms']
         print('tries $t: %.2f ms/iteration  y %.2f/%.2f z %.2f x %.2f/%.2f  %s' % (d['ms_per_step'], p['y_forward'], p['y_inverse'], p['z_conv'], p['x_fused_ratio'], p['x_fused_update'], r.get('pass_mode', {}).get('mode')))
 "
-  grep "placement trial" gpurun_out/place.err | tr '\n' ' '; echo
+  grep "placement trial\|spectrum arrays" gpurun_out/place.err | tr '\n' ' '; echo
 done

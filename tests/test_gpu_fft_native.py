@@ -259,3 +259,58 @@ def test_random_shapes_fft_engine_equals_direct_engine(dev, shape, kshape, bound
     fft.iterate(a, ratio, 3)
     direct.iterate(b, ratio, 3)
     assert _rel(a.cpu().numpy(), b.cpu().numpy().astype(np.float64)) < 1e-4
+
+
+@pytest.mark.parametrize("shape", [(64, 64, 128), (128, 32, 64), (192, 48, 64)])
+def test_tile_hand_out_and_blocked_middle_are_bit_identical(dev, shape, monkeypatch):
+    """How the persistent kernels get their tiles (device counter -- the default -- or the fixed stride) and whether the middle of a
+    convolution runs as three full passes or chunk by chunk on a small buffer (MI_FFT_CHUNK, several chunks in flight) changes the
+    ORDER of the work only: the results of fused iterations are identical bit for bit."""
+    from ipp_amd import capi, decon
+    psf = R.gaussian_psf((5, 7, 5), (1.0, 1.5, 1.0))
+    vol = torch.from_numpy(R.bead_volume(shape, seed=23, psf=psf)).to(dev)
+
+    def run():
+        ctx = decon.RLContext(shape, psf, None, boundary=capi.BOUNDARY_CIRCULAR, engine=capi.ENGINE_FFT, device=dev)
+        assert ctx.fuses and ctx.pair_layout
+        bl = vol.clone()
+        ctx.iterate(bl, None, 3)
+        return bl
+
+    ref = run()
+    for env in ({"MI_X_DYN": "0", "MI_Z_DYN": "0"}, {"MI_FFT_CHUNK": "3,1"}, {"MI_FFT_CHUNK": "2,3"}, {"MI_FFT_CHUNK": "1000,2"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        got = run()
+        for k in env:
+            monkeypatch.delenv(k)
+        assert torch.equal(got, ref), env
+
+
+def test_overlap_settings_and_probe(dev):
+    """mi_rl_set_overlap / mi_rl_overlap_probe: part 2 of a split step with compute units left free, with and without the device
+    counter, beside a stand-in collective -- every setting leaves the arithmetic alone (the sharded step equals the whole step)."""
+    from ipp_amd import capi, decon
+    psf = R.gaussian_psf((5, 7, 5), (1.0, 1.5, 1.0))
+    shape = (16, 128, 64)
+    ctx = decon.RLContext(shape, psf, None, boundary=capi.BOUNDARY_CIRCULAR, engine=capi.ENGINE_FFT, device=dev)
+    assert ctx.fuses == 2
+    vol = torch.from_numpy(R.bead_volume(shape, seed=29, psf=psf)).to(dev)
+    edges = (16, 32, 96, 112)
+    whole = vol.clone()
+    ctx.sharded_begin(whole)
+    ctx.sharded_ratio(whole)
+    ctx.sharded_update(whole, True)
+    for free, dyn in ((0, True), (0, False), (8, True), (200, False)):
+        ctx.set_overlap(free, dyn)
+        bl = vol.clone()
+        ctx.sharded_begin(bl)
+        ctx.sharded_ratio(bl, 1, edges)
+        ctx.sharded_ratio(bl, 2, edges)
+        ctx.sharded_update(bl, True, 1, edges)
+        ctx.sharded_update(bl, True, 2, edges)
+        assert torch.equal(bl, whole), (free, dyn)
+    x_ms, all_ms = ctx.overlap_probe(vol.clone(), edges, busy_wgs=4, busy_us=200.0, reps=2)
+    assert 0.0 < x_ms < 50.0 and all_ms >= 0.19
+    with pytest.raises(capi.MiError, match="free_cus"):
+        ctx.set_overlap(100000, True)
