@@ -261,7 +261,7 @@ def test_random_shapes_fft_engine_equals_direct_engine(dev, shape, kshape, bound
     assert _rel(a.cpu().numpy(), b.cpu().numpy().astype(np.float64)) < 1e-4
 
 
-@pytest.mark.parametrize("shape", [(64, 64, 128), (128, 32, 64), (192, 48, 64)])
+@pytest.mark.parametrize("shape", [(64, 64, 128), (128, 32, 64), (192, 96, 64)])
 def test_tile_hand_out_and_blocked_middle_are_bit_identical(dev, shape, monkeypatch):
     """How the persistent kernels get their tiles (device counter -- the default -- or the fixed stride) and whether the middle of a
     convolution runs as three full passes or chunk by chunk on a small buffer (MI_FFT_CHUNK, several chunks in flight) changes the
