@@ -348,6 +348,7 @@ __global__ __launch_bounds__(256) void k_mip_partial(const float* __restrict__ m
 
 // global mean c0 of each of the two MIPs of a plane (blockIdx.x = 0 / 1) from the slices' sums (fixed order) and the table of
 // its float tile sums
+constexpr int kMeanLdsEntries = 4096;  // 32 KB of doubles: tile-sum tables of planes up to e.g. 2048 x 2016 pixels
 __global__ __launch_bounds__(1024) void k_mip_mean(const double* __restrict__ part, size_t pstride, size_t sstride, int dimu, int dimv,
                                                    const float* __restrict__ ps1, const float* __restrict__ ps2, double* __restrict__ c0a,
                                                    double* __restrict__ c0b, double* __restrict__ ts1, double* __restrict__ ts2) {
@@ -363,18 +364,26 @@ __global__ __launch_bounds__(1024) void k_mip_mean(const double* __restrict__ pa
     }
     const int ph = dimu / TILE, pw = dimv / TILE;
     if (ps && ph * pw > 0) {
-        // (ph+1) x (pw+1) inclusive table; a few hundred entries: one lane per row, then one per column
-        const int w1 = pw + 1;
-        for (int i = threadIdx.x; i < (ph + 1) * w1; i += 1024) ts[i] = 0.0;
+        // (ph+1) x (pw+1) inclusive table; a few hundred entries: one lane per row, then one per column.  The two running sums
+        // are chains of dependent read-modify-writes: through global memory they cost ~1.5 us per step (64 steps: 0.1 ms for a
+        // kernel that does nothing else), so the table is built in LDS when it fits and written out once
+        const int w1 = pw + 1, n = (ph + 1) * w1;
+        __shared__ double tl[kMeanLdsEntries];
+        double* t = n <= kMeanLdsEntries ? tl : ts;
+        for (int i = threadIdx.x; i < n; i += 1024) t[i] = 0.0;
         __syncthreads();
         for (int r = threadIdx.x; r < ph; r += 1024) {
             double run = 0.0;
-            for (int c = 0; c < pw; ++c) { run += (double)ps[r * pw + c]; ts[(r + 1) * w1 + c + 1] = run; }
+            for (int c = 0; c < pw; ++c) { run += (double)ps[r * pw + c]; t[(r + 1) * w1 + c + 1] = run; }
         }
         __syncthreads();
         for (int c = threadIdx.x; c < pw; c += 1024) {
             double run = 0.0;
-            for (int r = 0; r < ph; ++r) { run += ts[(r + 1) * w1 + c + 1]; ts[(r + 1) * w1 + c + 1] = run; }
+            for (int r = 0; r < ph; ++r) { run += t[(r + 1) * w1 + c + 1]; t[(r + 1) * w1 + c + 1] = run; }
+        }
+        if (t != ts) {
+            __syncthreads();
+            for (int i = threadIdx.x; i < n; i += 1024) ts[i] = tl[i];
         }
     }
 }

@@ -623,12 +623,14 @@ struct LagWorkspace {
     // piece i runs on `sl`.  (A pair of streams per workspace mapped onto the same hardware queues in a way that put one
     // group's MIP pass behind the other group's chain: 1.3 of 4.8 ms overlapped, profiles/r03_ncc_timeline.txt.)
     hipStream_t sm = nullptr, sl[3] = {nullptr, nullptr, nullptr};  // (sl[m]: the chain of plane m; MI_NCC_CHAIN_STREAMS=1: one for all)
-    hipEvent_t ev_start = nullptr, ev_lag = nullptr, ev_done = nullptr, ev_plane[2] = {nullptr, nullptr};
+    hipStream_t sx = nullptr;  // the lag transform of the xy plane, beside that plane's tables (MI_NCC_SPLIT_XY=0: behind them)
+    hipEvent_t ev_start = nullptr, ev_lag = nullptr, ev_done = nullptr, ev_plane[2] = {nullptr, nullptr}, ev_x = nullptr;
     std::vector<hipEvent_t> ev_mip;
     ~LagWorkspace() {
         if (ev_start) (void)hipEventDestroy(ev_start);
         if (ev_lag) (void)hipEventDestroy(ev_lag);
         if (ev_done) (void)hipEventDestroy(ev_done);
+        if (ev_x) (void)hipEventDestroy(ev_x);
         for (hipEvent_t e : ev_plane)
             if (e) (void)hipEventDestroy(e);
         for (hipEvent_t e : ev_mip) (void)hipEventDestroy(e);
@@ -636,7 +638,7 @@ struct LagWorkspace {
     int streams(size_t pieces) {
         {
             static std::mutex mu;
-            struct Four { hipStream_t s[4]; };
+            struct Four { hipStream_t s[5]; };
             static std::map<int, Four> per_dev;  // (never destroyed: the process' lifetime)
             std::lock_guard<std::mutex> lock(mu);
             auto it = per_dev.find(dev);
@@ -646,11 +648,16 @@ struct LagWorkspace {
                 if (const char* e = std::getenv("MI_NCC_CHAIN_STREAMS")) chains = std::max(1, std::min(3, std::atoi(e)));
                 for (int i = 0; i < 1 + chains; ++i) MI_HIP(hipStreamCreateWithFlags(&f.s[i], hipStreamNonBlocking));
                 for (int i = 1 + chains; i < 4; ++i) f.s[i] = f.s[chains];
+                f.s[4] = f.s[1];
+                const char* sp = std::getenv("MI_NCC_SPLIT_XY");
+                if (chains == 3 && !(sp && std::atoi(sp) == 0)) MI_HIP(hipStreamCreateWithFlags(&f.s[4], hipStreamNonBlocking));
                 it = per_dev.emplace(dev, f).first;
             }
             sm = it->second.s[0];
             for (int m = 0; m < 3; ++m) sl[m] = it->second.s[1 + m];
+            sx = it->second.s[4];
         }
+        if (!ev_x) MI_HIP(hipEventCreateWithFlags(&ev_x, hipEventDisableTiming));
         for (hipEvent_t& e : ev_plane)
             if (!e) MI_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         if (!ev_start) MI_HIP(hipEventCreateWithFlags(&ev_start, hipEventDisableTiming));
@@ -808,6 +815,7 @@ struct LagJob {
             else if (ws->sm) {
                 (void)hipStreamSynchronize(ws->sm);
                 for (hipStream_t st : ws->sl) (void)hipStreamSynchronize(st);
+                if (ws->sx) (void)hipStreamSynchronize(ws->sx);
             }
             give_lag_ws(std::move(ws));
         }
@@ -936,9 +944,17 @@ static int enqueue_chains(LagJob& job, int c0, int p0, int np, int pi, hipEvent_
         hipStream_t sl = ws.sl[m];
         if (m == 0 || sl != ws.sl[m - 1]) MI_HIP(hipStreamWaitEvent(sl, gate, 0));
         const PlaneGeom& g = pl.g[m];
+        // the tables (tile sums, means, banded summed-area tables) and the lag transform of a plane read the same MIPs and meet
+        // only in the refinement: for the xy plane, whose chain is the longest, they run on two streams
+        hipStream_t sxm = (m == 0 && ws.sx != sl) ? ws.sx : sl;
+        if (sxm != sl) MI_HIP(hipStreamWaitEvent(sxm, gate, 0));
         MI_TRY(prepare_plane_band(sl, base + g.mip1, base + g.mip2, g, lp[m], base + g.ps1, base + g.ps2, sat_p + job.sat_off[m], np, pstride,
                                   sstride));
-        MI_TRY(lag_cross(job.dev, sl, lp[m], base + g.mip1, base + g.mip2, pstride, np, ws, m));
+        MI_TRY(lag_cross(job.dev, sxm, lp[m], base + g.mip1, base + g.mip2, pstride, np, ws, m));
+        if (sxm != sl) {
+            MI_HIP(hipEventRecord(ws.ev_x, sxm));
+            MI_HIP(hipStreamWaitEvent(sl, ws.ev_x, 0));
+        }
         const RefineGeom rg = refine_geom(g, lp[m], job.maxIter, sstride, job.sat_off[m], job.margin);
         if (lp[m].lds_refine > 64 * 1024)
             MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lag_refine), hipFuncAttributeMaxDynamicSharedMemorySize,
