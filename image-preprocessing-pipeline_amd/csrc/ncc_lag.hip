@@ -623,7 +623,8 @@ struct LagWorkspace {
     // piece i runs on `sl`.  (A pair of streams per workspace mapped onto the same hardware queues in a way that put one
     // group's MIP pass behind the other group's chain: 1.3 of 4.8 ms overlapped, profiles/r03_ncc_timeline.txt.)
     hipStream_t sm = nullptr, sl[3] = {nullptr, nullptr, nullptr};  // (sl[m]: the chain of plane m; MI_NCC_CHAIN_STREAMS=1: one for all)
-    hipStream_t sx = nullptr;  // the lag transform of the xy plane, beside that plane's tables (MI_NCC_SPLIT_XY=0: behind them)
+    hipStream_t sx = nullptr;  // MI_NCC_SPLIT_XY=1: the lag transform of the xy plane beside that plane's tables (default: behind them;
+                               // measured equal -- the runtime maps the extra stream onto the hardware queue of the tables)
     hipEvent_t ev_start = nullptr, ev_lag = nullptr, ev_done = nullptr, ev_plane[2] = {nullptr, nullptr}, ev_x = nullptr;
     std::vector<hipEvent_t> ev_mip;
     ~LagWorkspace() {
@@ -650,7 +651,7 @@ struct LagWorkspace {
                 for (int i = 1 + chains; i < 4; ++i) f.s[i] = f.s[chains];
                 f.s[4] = f.s[1];
                 const char* sp = std::getenv("MI_NCC_SPLIT_XY");
-                if (chains == 3 && !(sp && std::atoi(sp) == 0)) MI_HIP(hipStreamCreateWithFlags(&f.s[4], hipStreamNonBlocking));
+                if (chains == 3 && sp && std::atoi(sp) != 0) MI_HIP(hipStreamCreateWithFlags(&f.s[4], hipStreamNonBlocking));
                 it = per_dev.emplace(dev, f).first;
             }
             sm = it->second.s[0];
