@@ -209,6 +209,9 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the product path); gloo only to rehearse N > 1 on a one-GPU box")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: all ranks on cuda:0 (with --backend gloo)")
+    ap.add_argument("--zchunks", type=int, default=1,
+                    help="halo rows travel in this many z chunks (slab.SlabRL zchunks: sent per chunk of planes as their x tiles finish, "
+                         "the next y-forward pass starts per chunk as its rows land)")
     ap.add_argument("--transport", default="rccl", choices=["rccl", "peer"],
                     help="halo exchange at N > 1: grouped send/recv of the process group (RCCL), or hipMemcpyPeerAsync into the "
                          "neighbour's buffers (copy engines; slab.PeerLink)")
@@ -266,11 +269,12 @@ def main():
     else:
         from ipp_amd import slab
         drv = slab.SlabRL(vshape, psf_np, rank=rank, world_size=world, device=dev, flavour="fft", engine=engine,
-                          seed=1234, transport=args.transport)
+                          seed=1234, transport=args.transport, zchunks=args.zchunks)
         step = drv.iterate
         run_steps = None
         parallelism = (f"y-slabs x{world}, halo exchange: " +
-                       ("grouped send/recv (RCCL)" if args.transport == "rccl" else "hipMemcpyPeerAsync into the neighbour's buffers"))
+                       ("grouped send/recv (RCCL)" if args.transport == "rccl" else "hipMemcpyPeerAsync into the neighbour's buffers") +
+                       (f", {len(drv.zb)} z chunks" if drv.zb is not None else ""))
         engine_used = drv.ctx.engine
         ctx, bl = drv.ctx, drv.bl                # rank-local context / slab (interior + halo rows) for the per-pass timing
 

@@ -75,6 +75,9 @@ SIGNATURES = {
     "mi_rl_sharded_update": (_i, [_vp, _vp, _vp, _i, _i, C.POINTER(C.c_int)]),
     "mi_rl_spectrum_rows": (_i, [_vp, _vp, _i, _i, _vp, _i]),
     "mi_rl_spectrum_row_floats": (_sz, [_vp]),
+    "mi_rl_sharded_stage": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, C.POINTER(C.c_int)]),
+    "mi_rl_spectrum_rows_z": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i]),
+    "mi_rl_z_granule": (_i, [_vp]),
     "mi_rl_set_overlap": (_i, [_vp, _i, _i]),
     "mi_rl_overlap_probe": (_i, [_vp, _vp, _vp, _ip, _i, _f, _i, C.POINTER(C.c_float)]),
     "mi_prctile": (_i, [_i, _vp, _vp, _sz, C.POINTER(C.c_double), _i, C.POINTER(C.c_float)]),

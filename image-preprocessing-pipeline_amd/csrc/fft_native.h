@@ -1,5 +1,6 @@
 // Internal interface of the hand-written FFT convolution pipeline (fft_native.hip).
 #pragma once
+#include <algorithm>
 #include "conv3d_direct.h"
 
 namespace mi {
@@ -19,6 +20,7 @@ struct NativeDims {
     int zpad;         // paired layout: float4 of padding behind every row (xk, z)
     int xrow;         // x side: complex samples from one row (z, px) to the next (ny + padding)
     int xk0, xkn;     // paired layout: planes xk0 .. xk0 + xkn - 1 of a y / z launch (all of them, or one chunk of the blocked chain)
+    int yz0;          // forward y pass: first z plane of the launch (a z chunk of the sharded step; multiple of the planes per work-group)
 };
 
 // Padded mode: the caller's volume (extents n) sits at offset o inside the transform grid; the x passes apply the boundary
@@ -35,6 +37,7 @@ struct PadWindow {
 // Subset of the y tiles of the fused x pass: mode 0 all, 1 only the tiles [lo0, lo0+n0) and [lo1, lo1+n1), 2 all the others
 struct TileSelect {
     int mode = 0, lo0 = 0, n0 = 0, lo1 = 0, n1 = 0;
+    int z0 = 0, nz = 0;  // only the planes [z0, z0 + nz) (nz = 0: all): the z-chunked halo exchange runs the edge tiles chunk by chunk
 };
 
 struct NativeFft {
@@ -96,7 +99,11 @@ struct NativeFft {
     int iterate(hipStream_t s, float* bl, int n_iters);
     int time_pass(hipStream_t s, int which, const float* bl, int reps, float* avg_ms);
     // rows [y0, y0 + rows) of S (the x-transformed input of the next convolution): dir 0 pack into buf, 1 unpack from buf, 2 zero
-    int spectrum_rows(hipStream_t s, int y0, int rows, float2* buf, int dir);
+    // (z0, nzc: only the planes [z0, z0 + nzc), which keep their place in the packed buffer; nzc = 0: all)
+    int spectrum_rows(hipStream_t s, int y0, int rows, float2* buf, int dir, int z0 = 0, int nzc = 0);
+    // forward y pass of the planes [z0, z0 + nzc) only (both layouts); z0 and nzc multiples of y_z_granule()
+    int y_forward_planes(hipStream_t s, int z0, int nzc);
+    int y_z_granule() const { return dims.paired ? std::max(1, dims.tc / 2) : 1; }
     size_t spectrum_row_floats() const { return (size_t)2 * dims.nz * dims.hx; }
     int x_forward(hipStream_t s, const float* in);
     int middle(hipStream_t s, bool conj_otf);

@@ -651,7 +651,7 @@ __global__ __launch_bounds__(kThreadsY, 4) void k_y_pass(const float2* __restric
     constexpr int pitch = row_pitch(M), quads = M / 2;
     constexpr int TCC = y_tile_cols(M);  // the tile height the host normally picks: compile-time item decomposition
     const int TC = d.tc, Hx = d.hx, L = d.nz;
-    const size_t c0 = (size_t)blockIdx.x * TC;
+    const size_t c0 = (size_t)blockIdx.x * TC + (INVERSE ? (size_t)0 : (size_t)d.yz0 * Hx);  // (forward: columns (z, px), z slowest)
     // padded grids: forward, the columns of all-zero input planes are neither read nor produced (the z pass knows they are
     // zero); inverse, only the planes that survive the crop are transformed
     if (!INVERSE) {
@@ -753,7 +753,7 @@ __global__ __launch_bounds__(kThreadsY, 4) void k_y_pair(const float2* __restric
     // side; inverse, consecutive rows of one xk on the z side
     const int xkl = INVERSE ? blockIdx.x / zblocks : blockIdx.x % nxk;
     const int xk = d.xk0 + xkl;
-    const int z0 = (INVERSE ? blockIdx.x - xkl * zblocks : blockIdx.x / nxk) * zper;
+    const int z0 = (INVERSE ? blockIdx.x - xkl * zblocks : blockIdx.x / nxk) * zper + (INVERSE ? 0 : d.yz0);
     if (!INVERSE) {
         if (z0 >= d.z_in_hi) return;  // all-zero input planes of a padded grid: neither read nor produced
     } else if (z0 >= d.z_out_hi || z0 + zper <= d.z_out_lo) {
@@ -1730,8 +1730,9 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_x_fused_pipe(const flo
     // sends the edge rows off while the rest of the pass runs)
     auto tile_zy = [&](int t, int& z, int& y0) {
         const int per = sel.mode == 0 ? ytiles : (sel.mode == 1 ? sel.n0 + sel.n1 : sel.mode == 3 ? sel.n0 : ytiles - sel.n0 - sel.n1);
-        z = t / per;
-        int ty = t - z * per;
+        const int zl = t / per;
+        z = sel.z0 + zl;
+        int ty = t - zl * per;
         if (sel.mode == 1) {
             ty = ty < sel.n0 ? sel.lo0 + ty : sel.lo1 + (ty - sel.n0);
         } else if (sel.mode == 2) {
@@ -1998,6 +1999,7 @@ int NativeFft::init(hipStream_t s, const int F[3], bool explicit_adjoint) {
     dims.y_out_hi = F[1];
     dims.xk0 = 0;
     dims.xkn = Hx / 2 + 1;
+    dims.yz0 = 0;
     dims.dbg = 0;
     if (const char* e = std::getenv("MI_FFT_ZDBG")) dims.dbg = atoi(e);  // phase knock-out for timing experiments
     // tuning overrides (experiments only): MI_FFT_TY / MI_FFT_TC / MI_FFT_TL
@@ -2541,6 +2543,10 @@ int NativeFft::x_inverse(hipStream_t s, float* out, int epi_kind, const ConvEpil
         } else if (part && part->mode != 0) {
             sel = *part;
             per = sel.mode == 1 ? sel.n0 + sel.n1 : per - sel.n0 - sel.n1;
+            if (sel.nz > 0) {
+                MI_REQUIRE(sel.z0 >= 0 && sel.z0 + sel.nz <= L, "native FFT: plane range [%d, %d) outside [0, %d)", sel.z0, sel.z0 + sel.nz, L);
+                planes = sel.nz;
+            }
         }
         const int ntiles = planes * per;
         if (ntiles <= 0) return MI_OK;
@@ -2583,14 +2589,46 @@ int NativeFft::x_inverse(hipStream_t s, float* out, int epi_kind, const ConvEpil
     return rc;
 }
 
-int NativeFft::spectrum_rows(hipStream_t s, int y0, int rows, float2* buf, int dir) {
+int NativeFft::spectrum_rows(hipStream_t s, int y0, int rows, float2* buf, int dir, int z0, int nzc) {
     MI_REQUIRE(y0 >= 0 && rows > 0 && y0 + rows <= dims.ny, "spectrum rows [%d, %d) outside [0, %d)", y0, y0 + rows, dims.ny);
     MI_REQUIRE(dir == 2 || buf, "spectrum rows: null buffer");
-    const size_t lines = (size_t)dims.nz * dims.hx, total = lines * (size_t)rows;
+    if (nzc <= 0) { z0 = 0; nzc = dims.nz; }
+    MI_REQUIRE(z0 >= 0 && z0 + nzc <= dims.nz, "spectrum rows: planes [%d, %d) outside [0, %d)", z0, z0 + nzc, dims.nz);
+    // lines (z, px) of the chunk: they keep their place in S and in the packed buffer [z * Hx + px][rows]
+    const size_t line0 = (size_t)z0 * dims.hx, lines = (size_t)nzc * dims.hx, total = lines * (size_t)rows;
     size_t blocks = (total + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(k_spectrum_rows, dim3((unsigned)blocks), dim3(256), 0, s, S.as<float2>(), buf, lines, dims.xrow, y0, rows, dir);
+    hipLaunchKernelGGL(k_spectrum_rows, dim3((unsigned)blocks), dim3(256), 0, s, S.as<float2>() + line0 * dims.xrow,
+                       buf ? buf + line0 * (size_t)rows : buf, lines, dims.xrow, y0, rows, dir);
     return launch_check("k_spectrum_rows");
+}
+
+// forward y pass of a range of z planes (the z-chunked halo exchange: a chunk's columns are transformed as soon as its halo rows
+// have landed, while the later chunks still travel)
+int NativeFft::y_forward_planes(hipStream_t s, int z0, int nzc) {
+    const int Hx = dims.hx, M = dims.ny, L = dims.nz, gran = y_z_granule();
+    MI_REQUIRE(chunk_xk == 0, "native FFT: the blocked middle and the z-chunked y pass exclude each other");
+    MI_REQUIRE(z0 >= 0 && nzc > 0 && z0 + nzc <= L && z0 % gran == 0 && (nzc % gran == 0 || z0 + nzc == L),
+               "native FFT: plane range [%d, %d) must be cut at multiples of %d", z0, z0 + nzc, gran);
+    const bool paired = dims.paired != 0;
+    if (!paired) MI_REQUIRE(((size_t)nzc * Hx) % dims.tc == 0 && ((size_t)z0 * Hx) % dims.tc == 0, "native FFT: plane range does not hold whole y tiles");
+    const unsigned ycols = paired ? (unsigned)((size_t)(Hx / 2 + 1) * ((nzc + gran - 1) / gran)) : (unsigned)((size_t)nzc * Hx / dims.tc);
+    const size_t yl = lds_bytes(dims.tc, M);
+    NativeDims d = dims;
+    d.yz0 = z0;
+    d.z_in_hi = std::min(dims.z_in_hi, z0 + nzc);   // (work-groups of the last, partial granule stop here)
+    const float2* src = S.as<float2>();
+    float2* dst = t_spec;
+    const float2* twy = tw_y;
+    int rc = MI_ERR_INVALID;
+#define MI_YZ(LG, R)                                                                                                     \
+    case LG * 16 + R:                                                                                                    \
+        rc = paired ? launch_lds(k_y_pair<LG, R, false>, ycols, kThreadsY, yl, s, "k_y_pair<fwd>", src, dst, d, twy)      \
+                    : launch_lds(k_y_pass<LG, R, false>, ycols, kThreadsY, yl, s, "k_y_pass<fwd>", src, dst, d, twy);     \
+        break;
+    switch (dims.ly2 * 16 + dims.r3) { MI_Y_CASES(MI_YZ) default: return fail(MI_ERR_UNSUPPORTED, "native FFT: y length %d", M); }
+#undef MI_YZ
+    return rc;
 }
 
 // Average duration (ms) of one launch of a single pass, measured with HIP events on `s` (bench.py's roofline leg).

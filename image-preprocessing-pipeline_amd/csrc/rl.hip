@@ -468,6 +468,49 @@ extern "C" int mi_rl_spectrum_rows(mi_rl_ctx* ctx, void* stream, int y0, int row
     return nf->spectrum_rows(as_stream(stream), y0, rows, reinterpret_cast<float2*>(buf), dir);
 }
 
+extern "C" int mi_rl_spectrum_rows_z(mi_rl_ctx* ctx, void* stream, int y0, int rows, int z0, int z1, float* buf, int dir) {
+    NativeFft* nf = nullptr;
+    MI_TRY(sharded_native(ctx, &nf));
+    MI_REQUIRE(dir >= 0 && dir <= 2, "mi_rl_spectrum_rows_z: dir must be 0 (pack), 1 (unpack) or 2 (zero)");
+    MI_REQUIRE(z0 >= 0 && z0 < z1 && z1 <= ctx->n[2], "mi_rl_spectrum_rows_z: planes [%d, %d) outside [0, %d)", z0, z1, ctx->n[2]);
+    return nf->spectrum_rows(as_stream(stream), y0, rows, reinterpret_cast<float2*>(buf), dir, z0, z1 - z0);
+}
+
+extern "C" int mi_rl_z_granule(mi_rl_ctx* ctx) {
+    NativeFft* nf = nullptr;
+    if (sharded_native(ctx, &nf) != MI_OK || !nf->splits()) return 0;
+    return nf->y_z_granule();
+}
+
+// The sharded step cut into the stages of the z-chunked halo exchange (see include/mi_lsdeconv.h)
+extern "C" int mi_rl_sharded_stage(mi_rl_ctx* ctx, void* stream, float* bl, int update, int stage, int z0, int z1, const int* edges) {
+    NativeFft* nf = nullptr;
+    MI_TRY(sharded_native(ctx, &nf));
+    MI_REQUIRE(stage >= 0 && stage <= 3, "mi_rl_sharded_stage: stage must be 0 .. 3");
+    MI_REQUIRE(nf->splits(), "mi_rl_sharded_stage: this context cannot split the x pass (mi_rl_fuses() != 2)");
+    hipStream_t s = as_stream(stream);
+    if (stage == 0) {
+        MI_REQUIRE(z0 >= 0 && z0 < z1 && z1 <= ctx->n[2], "mi_rl_sharded_stage: planes [%d, %d) outside [0, %d)", z0, z1, ctx->n[2]);
+        return nf->y_forward_planes(s, z0, z1 - z0);
+    }
+    if (stage == 1) {
+        MI_TRY(nf->z_conv(s, update != 0));
+        return nf->y_pass(s, true, nf->dims.paired != 0);
+    }
+    MI_REQUIRE(bl, "mi_rl_sharded_stage: null pointer");
+    MI_REQUIRE(edges && edges[0] >= 0 && edges[0] < edges[1] && edges[1] <= edges[2] && edges[2] < edges[3] && edges[3] <= ctx->n[1],
+               "mi_rl_sharded_stage: edge row ranges must be ordered and inside the volume");
+    TileSelect sel = nf->edge_tiles(stage == 2 ? 1 : 2, edges[0], edges[1], edges[2], edges[3]);
+    if (stage == 2) {
+        MI_REQUIRE(z0 >= 0 && z0 < z1 && z1 <= ctx->n[2], "mi_rl_sharded_stage: planes [%d, %d) outside [0, %d)", z0, z1, ctx->n[2]);
+        sel.z0 = z0;
+        sel.nz = z1 - z0;
+    }
+    ConvEpilogue e;
+    e.a = bl;
+    return update ? nf->x_inverse(s, bl, EPI_UPDATE, e, true, &sel) : nf->x_inverse(s, nullptr, EPI_RATIO, e, true, &sel);
+}
+
 extern "C" size_t mi_rl_spectrum_row_floats(mi_rl_ctx* ctx) {
     return mi_rl_fuses(ctx) ? ctx->fft->native->spectrum_row_floats() : 0;
 }

@@ -381,6 +381,25 @@ class RLContext:
                                         int(reps), out))
         return float(out[0]), float(out[1])
 
+    @property
+    def z_granule(self) -> int:
+        """z chunks of the staged sharded step must be cut at multiples of this (0: the context cannot run it)."""
+        return int(lib().mi_rl_z_granule(self._h))
+
+    def sharded_stage(self, bl, update, stage, z0=0, z1=0, edge_rows=None):
+        """One stage of a half-step of the z-chunked exchange (``mi_rl_sharded_stage``): 0 y-forward of the planes [z0, z1),
+        1 z pass + y-inverse, 2 edge tiles of the planes [z0, z1), 3 all other tiles."""
+        self._chk(bl)
+        check(lib().mi_rl_sharded_stage(self._h, _stream(bl), bl.data_ptr(), int(bool(update)), int(stage), int(z0), int(z1),
+                                        self._edges(edge_rows)))
+
+    def spectrum_rows_z(self, buf, y0, rows, z0, z1, direction):
+        """Pack (0) / unpack (1) / zero (2) the rows [y0, y0 + rows) of the planes [z0, z1); ``buf`` is the WHOLE packed buffer (a
+        float32 device tensor or a raw device pointer), of which the chunk keeps its place."""
+        ptr = None if buf is None else (buf.data_ptr() if isinstance(buf, torch.Tensor) else int(buf))
+        check(lib().mi_rl_spectrum_rows_z(self._h, capi.current_stream_ptr(self.device), int(y0), int(rows), int(z0), int(z1), ptr,
+                                          int(direction)))
+
     def spectrum_pack(self, y0, rows, out=None):
         """Rows [y0, y0+rows) of the x-transformed input buffer as a contiguous float32 device tensor (``out``: written there)."""
         n = int(rows) * int(lib().mi_rl_spectrum_row_floats(self._h))

@@ -91,6 +91,27 @@ class HipOps:
     def unpack_spec_ptr(self, ctx, ptr, y0, rows):
         ctx.spectrum_unpack_ptr(ptr, y0, rows)
 
+    # z-chunked exchange of the fused pipeline: a chunk of planes keeps its place in the packed buffer
+    def spec_planes(self, ctx, lshape):
+        return int(lshape[0])
+
+    def spec_granule(self, ctx):
+        return int(ctx.z_granule)
+
+    def spec_chunk_span(self, ctx, h, z0, z1, nz):
+        per_plane = h * ctx.spectrum_row_floats // nz
+        return z0 * per_plane, (z1 - z0) * per_plane
+
+    def pack_spec_chunk(self, ctx, y0, rows, z0, z1, out_full):
+        ctx.spectrum_rows_z(out_full, y0, rows, z0, z1, 0)
+
+    def unpack_spec_chunk(self, ctx, src_full, y0, rows, z0, z1):
+        """``src_full``: the whole packed buffer (tensor or raw device pointer), or None for zero rows"""
+        ctx.spectrum_rows_z(src_full, y0, rows, z0, z1, 2 if src_full is None else 1)
+
+    def stage(self, ctx, bl, update, stage, z0=0, z1=0, edge_rows=None):
+        ctx.sharded_stage(bl, update, stage, z0, z1, edge_rows)
+
     def pack_into(self, vol, y0, rows, out):
         nz, ny, nx = vol.shape
         assert out.numel() >= nz * rows * nx
@@ -198,7 +219,7 @@ class PeerLink:
 
     SETS = 2
 
-    def __init__(self, drv, nfloats, backend, group=None, timeout_s=120.0):
+    def __init__(self, drv, nfloats, backend, group=None, timeout_s=120.0, chunks=1):
         import mmap
         import os
         import tempfile
@@ -208,15 +229,17 @@ class PeerLink:
         self.be = backend
         self.nfloats = int(nfloats)
         self.nbytes = 4 * self.nfloats
+        self.C = max(1, int(chunks))   # an exchange may travel in C chunks (z chunks of the halo rows), each with its own event
         self.recv_base, mem_handle = backend.alloc(2 * self.SETS * self.nbytes)
         self.staging = [[backend.staging(self.nfloats) for _ in range(self.SETS)] for _ in range(2)]
 
-        def make_events():
-            pairs = [backend.event() for _ in range(2 * self.SETS)]
+        def make_events(per):
+            pairs = [backend.event() for _ in range(2 * self.SETS * per)]
             return [e for e, _ in pairs], [h for _, h in pairs]
 
-        self.ev_sent, hs_sent = make_events()          # [d * SETS + set]: my copy of edge d into the neighbour's set has been issued
-        self.ev_done, hs_done = make_events()          # [d * SETS + set]: I have consumed slot d, set
+        # [(d * SETS + set) * C + chunk]: my copy of that chunk of edge d into the neighbour's set has been issued
+        self.ev_sent, hs_sent = make_events(self.C)
+        self.ev_done, hs_done = make_events(1)         # [d * SETS + set]: I have consumed slot d, set
         # host sequence numbers: [rank][d][0 = sent, 1 = consumed] uint64, one file for the job
         name = [None]
         if drv.rank == 0:
@@ -245,7 +268,8 @@ class PeerLink:
                 self.peer[d] = (dst_rank, self._mapped[dst_rank], info["dev"], evs)
             if src_rank is not None:
                 info = everyone[src_rank]
-                self.src[d] = (src_rank, [backend.event_open(info["sent"][d * self.SETS + st]) for st in range(self.SETS)])
+                self.src[d] = (src_rank, [backend.event_open(info["sent"][(d * self.SETS + st) * self.C + k])
+                                          for st in range(self.SETS) for k in range(self.C)])
         dist.barrier(group=group)
         if drv.rank == 0:
             os.unlink(self.shm_path)                   # every rank holds it open; the name can go
@@ -267,35 +291,40 @@ class PeerLink:
         st = self.n % self.SETS
         out = []
         for d in (0, 1):
-            if d in self.peer and self.n > self.SETS:   # the copy that read this staging buffer two exchanges ago must have run
-                self.be.wait(self.ev_sent[d * self.SETS + st], False)
+            if d in self.peer and self.n > self.SETS:   # the copies that read this staging buffer two exchanges ago must have run
+                self.be.wait(self.ev_sent[(d * self.SETS + st) * self.C + self.C - 1], False)
             out.append(self.staging[d][st] if d in self.peer else None)
         return out
 
-    def send(self):
-        """The rows are packed (launch stream): copy them into the neighbours' buffers on the copy stream."""
+    def send(self, k=0, first_float=0, nfloats=None):
+        """Chunk k of the rows is packed (launch stream): copy it into the neighbours' buffers on the copy stream.  The chunk is the
+        float range [first_float, first_float + nfloats) of the staging buffer and lands at the same place of the receive buffer
+        (default: the whole buffer as the only chunk)."""
         st = self.n % self.SETS
+        nfloats = self.nfloats - first_float if nfloats is None else int(nfloats)
         if self.peer:
             self.be.copy_after_launch()
         for d in (0, 1):
             if d not in self.peer:
                 continue
             rank, base, pdev, ev_done = self.peer[d]
-            if self.n > self.SETS:                      # the neighbour has consumed what exchange n - SETS left in this set
+            if k == 0 and self.n > self.SETS:           # the neighbour has consumed what exchange n - SETS left in this set
                 self._host_wait(rank, d, 1, self.n - self.SETS)
                 self.be.wait(ev_done[st], True)
-            self.be.copy(self._slot(base, d, st), pdev, self.staging[d][st], self.nbytes)
-            self.be.record(self.ev_sent[d * self.SETS + st], True)
-            self.seq[self.drv.rank, d, 0] = self.n
+            self.be.copy(self.be.offset(self._slot(base, d, st), 4 * first_float), pdev,
+                         self.staging[d][st][first_float:first_float + nfloats], 4 * nfloats)
+            self.be.record(self.ev_sent[(d * self.SETS + st) * self.C + k], True)
+            self.seq[self.drv.rank, d, 0] = (self.n - 1) * self.C + k + 1
 
-    def receive(self, d):
-        """The rows that arrived in slot d (None: global edge) as the backend's pointer; the launch stream waits for them."""
+    def receive(self, d, k=0):
+        """The rows that arrived in slot d (None: global edge) as the backend's pointer TO THE WHOLE SLOT; the launch stream waits
+        for chunk k of them."""
         if d not in self.src:
             return None
         st = self.n % self.SETS
         rank, ev_sent = self.src[d]
-        self._host_wait(rank, d, 0, self.n)
-        self.be.wait(ev_sent[st], False)
+        self._host_wait(rank, d, 0, (self.n - 1) * self.C + k + 1)
+        self.be.wait(ev_sent[st * self.C + k], False)
         return self._slot(self.recv_base, d, st)
 
     def release(self):
@@ -330,7 +359,7 @@ class PeerLink:
 
 class SlabRL:
     def __init__(self, global_shape_zyx, psf, rank=0, world_size=1, device=None, flavour="fft", engine=ENGINE_AUTO,
-                 volume=None, seed=None, ops=None, group=None, transport="rccl"):
+                 volume=None, seed=None, ops=None, group=None, transport="rccl", zchunks=1):
         if flavour not in ("fft", "spatial"):
             raise ValueError("flavour must be 'fft' (deconFFT) or 'spatial' (deconSpatial)")
         if transport not in ("rccl", "peer"):
@@ -371,6 +400,19 @@ class SlabRL:
         self.edge_rows = (self.h, 2 * self.h, self.n_loc, self.n_loc + self.h)
         self.overlap = (int(getattr(self.ctx, "fuses", 0)) == 2 and self.h > 0 and self.n_loc >= 2 * self.h)
         self.ratio = None if self.sharded else torch.zeros(self.lshape, dtype=torch.float32, device=self.device)
+        # z-chunked exchange (fused pipeline with a split x pass): the halo rows travel in `zchunks` chunks of planes; a chunk is
+        # sent as soon as the x tiles of its planes have run and the next step's y-forward pass starts on a chunk as soon as ITS
+        # halos have landed -- the exchange hides behind almost the whole x pass and the y pass instead of the rest of the x pass
+        self.zb, self._pending = None, None
+        if int(zchunks) > 1 and self.overlap:
+            g = self.ops.spec_granule(self.ctx)
+            nzp = self.ops.spec_planes(self.ctx, self.lshape)
+            if g > 0 and nzp >= 2 * g:
+                c = min(int(zchunks), nzp // g)
+                per = -(-nzp // c)
+                per = -(-per // g) * g
+                self.zb = [(z, min(z + per, nzp)) for z in range(0, nzp, per)]
+                self.nzp = nzp
         if volume is not None:
             v = volume[:, self.y0:self.y1, :]
             v = torch.from_numpy(np.ascontiguousarray(v)) if isinstance(v, np.ndarray) else v
@@ -502,6 +544,8 @@ class SlabRL:
     # ------------------------------------------------------------------ iteration
     def iterate(self):
         """One RL iteration (decon.m:61-79 / 162-186, lambda = 0) on the sharded volume."""
+        if self.sharded and self.zb is not None:
+            return self._iterate_zchunked()
         if self.sharded:
             if not self._begun:                  # x-forward of the start volume; later iterations get it from the update
                 self.ctx.sharded_begin(self.bl)
@@ -529,6 +573,119 @@ class SlabRL:
         self.exchange(self.ratio)
         self.ctx.adjoint_update(self.ratio, self.bl)
 
+    # ------------------------------------------------------------------ z-chunked exchange (fused pipeline)
+    def _zx_begin(self):
+        """Buffers of the next exchange: (kind, send_up, send_dn, recv_lo, recv_hi, per-chunk requests, staged)."""
+        h = self.h
+        lo_src, hi_src = self.neighbours()
+        nfl = self.ops.halo_floats(self.ctx, self.lshape, h)
+        if self.world > 1 and self.transport == "peer":
+            if self.link is None:
+                self.link = PeerLink(self, nfl, self.ops.peer_backend(), self.group, chunks=len(self.zb))
+            up, dn = self.link.begin()
+            return {"kind": "peer", "up": up, "dn": dn}
+        mk = lambda: torch.empty(nfl, dtype=torch.float32, device=self.device)   # noqa: E731
+        st = {"kind": "self" if self.world == 1 else "rccl", "up": mk() if hi_src is not None else None,
+              "dn": mk() if lo_src is not None else None, "reqs": [None] * len(self.zb), "keep": []}
+        if st["kind"] == "rccl":
+            import torch.distributed as dist
+            st["staged"] = self.device.type == "cuda" and dist.get_backend(self.group) == "gloo"
+            host = "cpu" if st["staged"] else self.device
+            st["recv_lo"] = torch.empty(nfl, dtype=torch.float32, device=host) if lo_src is not None else None
+            st["recv_hi"] = torch.empty(nfl, dtype=torch.float32, device=host) if hi_src is not None else None
+        return st
+
+    def _zx_send(self, st, k):
+        """Pack chunk k of the edge rows and send it off."""
+        import torch.distributed as dist
+        h, n = self.h, self.n_loc
+        z0, z1 = self.zb[k]
+        off, cnt = self.ops.spec_chunk_span(self.ctx, h, z0, z1, self.nzp)
+        for buf, y0 in ((st["up"], n), (st["dn"], h)):
+            if buf is not None:
+                self.ops.pack_spec_chunk(self.ctx, y0, h, z0, z1, buf)
+        if st["kind"] == "peer":
+            self.link.send(k, off, cnt)
+            return
+        if st["kind"] == "self":
+            return
+        lo_src, hi_src = self.neighbours()
+        up = st["up"][off:off + cnt] if st["up"] is not None else None
+        dn = st["dn"][off:off + cnt] if st["dn"] is not None else None
+        if st["staged"]:
+            up, dn = (up.cpu() if up is not None else None), (dn.cpu() if dn is not None else None)
+        ops = []
+        if hi_src is not None:
+            ops.append(dist.P2POp(dist.isend, up, hi_src, self.group, 1))
+        if lo_src is not None:
+            ops.append(dist.P2POp(dist.isend, dn, lo_src, self.group, 2))
+        if lo_src is not None:
+            ops.append(dist.P2POp(dist.irecv, st["recv_lo"][off:off + cnt], lo_src, self.group, 1))
+        if hi_src is not None:
+            ops.append(dist.P2POp(dist.irecv, st["recv_hi"][off:off + cnt], hi_src, self.group, 2))
+        st["reqs"][k] = dist.batch_isend_irecv(ops)
+        st["keep"].append((up, dn))                      # the send slices stay alive until the wait
+
+    def _zx_recv(self, st, k):
+        """Wait for chunk k of the halo rows and unpack it (the launch stream waits; the host only where the transport needs it)."""
+        h, n = self.h, self.n_loc
+        z0, z1 = self.zb[k]
+        if st["kind"] == "peer":
+            for d, y0 in ((0, 0), (1, h + n)):
+                self.ops.unpack_spec_chunk(self.ctx, self.link.receive(d, k), y0, h, z0, z1)
+            return
+        if st["kind"] == "self":                         # self-ring: my own rows wrap around
+            lo_src, hi_src = self.neighbours()
+            self.ops.unpack_spec_chunk(self.ctx, st["up"] if lo_src is not None else None, 0, h, z0, z1)
+            self.ops.unpack_spec_chunk(self.ctx, st["dn"] if hi_src is not None else None, h + n, h, z0, z1)
+            return
+        for req in st["reqs"][k]:
+            req.wait()
+        off, cnt = self.ops.spec_chunk_span(self.ctx, h, z0, z1, self.nzp)
+        for key, y0 in (("recv_lo", 0), ("recv_hi", h + n)):
+            src = st[key]
+            if src is not None and st["staged"]:
+                dev = st.setdefault(key + "_dev", torch.empty(src.numel(), dtype=torch.float32, device=self.device))
+                dev[off:off + cnt].copy_(src[off:off + cnt])
+                src = dev
+            self.ops.unpack_spec_chunk(self.ctx, src, y0, h, z0, z1)
+
+    def _zx_done(self, st):
+        if st["kind"] == "peer":
+            self.link.release()
+
+    def drain(self):
+        """Completes the exchange the last half-step left in flight (z-chunked mode): every rank calls it after its last iteration
+        -- ``run`` and ``close`` do -- so that no transfer or acknowledgement is left dangling."""
+        if self._pending is not None:
+            for k in range(len(self.zb)):
+                self._zx_recv(self._pending, k)
+            self._zx_done(self._pending)
+            self._pending = None                         # (the halo rows are in place: a later iterate goes on from here)
+
+    def _iterate_zchunked(self):
+        e, K = self.edge_rows, range(len(self.zb))
+        if not self._begun:                              # x-forward of the start volume, its halo rows chunk by chunk
+            self.ctx.sharded_begin(self.bl)
+            st = self._zx_begin()
+            for k in K:
+                self._zx_send(st, k)
+            self._pending, self._begun = st, True
+        for update in (False, True):
+            for k in K:                                  # y-forward on every chunk whose halo rows have landed
+                if self._pending is not None:
+                    self._zx_recv(self._pending, k)
+                self.ops.stage(self.ctx, self.bl, update, 0, *self.zb[k])
+            if self._pending is not None:
+                self._zx_done(self._pending)
+            self.ops.stage(self.ctx, self.bl, update, 1)                     # z pass + y-inverse
+            st = self._zx_begin()
+            for k in K:                                  # edge tiles of a chunk, then that chunk is on its way
+                self.ops.stage(self.ctx, self.bl, update, 2, *self.zb[k], e)
+                self._zx_send(st, k)
+            self.ops.stage(self.ctx, self.bl, update, 3, 0, 0, e)            # everything else runs while the halos travel
+            self._pending = st
+
     def run(self, niter, stop_criterion=0.0):
         """``niter`` iterations with the reference's stop test on the GLOBAL norm (decon.m:108-118)."""
         prev = self.norm2() if stop_criterion > 0 else 0.0
@@ -542,11 +699,13 @@ class SlabRL:
                 prev = cur
                 if i > 1 and rel <= stop_criterion:
                     break
+        self.drain()
         return done
 
     def close(self):
         """Releases the copy-engine link (mapped peer memory, interprocess events); every rank calls it before the process group
         goes away."""
+        self.drain()
         if self.link is not None:
             self.link.close()
             self.link = None

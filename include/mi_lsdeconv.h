@@ -164,6 +164,22 @@ int mi_rl_sharded_ratio(mi_rl_ctx* ctx, void* stream, const float* bl, int part,
 int mi_rl_sharded_update(mi_rl_ctx* ctx, void* stream, float* bl, int more, int part, const int* edge_rows);
 int mi_rl_spectrum_rows(mi_rl_ctx* ctx, void* stream, int y0, int rows, float* buf, int dir);
 size_t mi_rl_spectrum_row_floats(mi_rl_ctx* ctx);
+/* The same steps cut along z, for a halo exchange that travels in z chunks (slab.py: zchunks > 1).  The x transform of a row
+ * depends on nothing else and the y transform of a column (z, px) only on the rows of its own plane, so a rank can (a) send the
+ * edge rows of the planes [z0, z1) as soon as the x tiles of those planes have run and (b) start the next step's y-forward pass
+ * on a chunk of planes as soon as THAT chunk's halo rows have landed, while later chunks still travel: the window of an exchange
+ * grows from the rest of the x pass to almost the whole x pass plus the y pass.  One half-step (update = 0: ratio, 1: update):
+ *     stage 0, per chunk   y-forward of the planes [z0, z1)             (their halo rows must have been unpacked)
+ *     stage 1              z pass (OTF or its conjugate) + y-inverse     (all planes)
+ *     stage 2, per chunk   x pass, the tiles that hold rows of edge_rows, planes [z0, z1)  [then pack + send that chunk]
+ *     stage 3              x pass, all other tiles
+ * Results are identical to part 0 / 1 / 2 of mi_rl_sharded_ratio / _update.  Chunk boundaries must be multiples of
+ * mi_rl_z_granule(ctx) (0: the context cannot run chunked).  mi_rl_spectrum_rows_z is mi_rl_spectrum_rows restricted to the planes
+ * [z0, z1); the chunk keeps its place in the packed buffer ([z * nx/2 + px][rows] complex), i.e. it is the contiguous range that
+ * starts z0 * rows * (row_floats / nz) floats into it. */
+int mi_rl_sharded_stage(mi_rl_ctx* ctx, void* stream, float* bl, int update, int stage, int z0, int z1, const int* edge_rows);
+int mi_rl_spectrum_rows_z(mi_rl_ctx* ctx, void* stream, int y0, int rows, int z0, int z1, float* buf, int dir);
+int mi_rl_z_granule(mi_rl_ctx* ctx);
 /* How the "part 2" launches of a split step share the GPU with the halo exchange that is in flight beside them (the reference
  * has no counterpart: its blocks never exchange anything, LsDeconv.m:643-654).  The x pass is a persistent kernel of one
  * 16-wave work-group per compute unit; a collective's kernels need compute units too.  free_cus: work-groups NOT launched

@@ -65,6 +65,42 @@ class NumpyCtx:
         if more:
             self._to_S(bl.numpy())
 
+    # ---- the staged step of the z-chunked exchange (mi_rl_sharded_stage).  What each stage READS is what the real kernels read at
+    # that point: stage 0 snapshots the planes it transforms (a chunk whose halo rows arrive later would be wrong), stages 2 / 3
+    # reveal the new spectrum rows only where the real x pass has written them
+    z_granule = 1
+    _Sin = _Snew = None
+
+    def sharded_stage(self, bl, update, stage, z0=0, z1=0, edge_rows=None):
+        if stage == 0:
+            if self._Sin is None:
+                self._Sin = np.full_like(self.S, np.nan)
+            self._Sin[z0:z1] = self.S[z0:z1]
+            return
+        if stage == 1:
+            assert not np.isnan(self._Sin).any(), "a chunk of planes was never transformed"
+            o = self.otf_adj if update else self.otf
+            c = np.real(np.fft.ifftn(np.fft.fft2(self._Sin, axes=(0, 1)) * o))
+            sl = tuple(slice(q, q + n) for q, n in zip(self.pad, self.n))
+            self._c, self._Sin, self._Snew = c[sl].astype(np.float32), None, None
+            return
+        if self._Snew is None:                          # the epilogue + forward x transform of the whole slab, revealed piecewise
+            b = bl.numpy()
+            if update:
+                bl.copy_(torch.from_numpy(np.abs(b * self._c).astype(np.float32)))
+                new = bl.numpy()
+            else:
+                new = (b / np.maximum(self._c, np.float32(2.0 ** -23))).astype(np.float32)
+            self._Snew = np.fft.fft(np.pad(new.astype(np.float64), [(q, q) for q in self.pad]), axis=2)
+        a0, a1, b0, b1 = edge_rows
+        edge = np.zeros(self.S.shape[1], bool)
+        edge[a0:a1] = True
+        edge[b0:b1] = True
+        if stage == 2:
+            self.S[z0:z1, edge, :] = self._Snew[z0:z1, edge, :]
+        else:
+            self.S[:, ~edge, :] = self._Snew[:, ~edge, :]
+
     def spectrum_pack(self, y0, rows):
         assert self.pad[1] == 0  # y is circular on the local extent
         return torch.view_as_real(torch.from_numpy(np.ascontiguousarray(self.S[:, y0:y0 + rows, :]))).contiguous()
@@ -164,6 +200,36 @@ class NumpyOps:
     def peer_backend(self):
         return ShmPeer()
 
+    # z-chunked exchange: the double's packed rows are [z][rows][x] complex128 = four float32 words per sample
+    def spec_planes(self, ctx, lshape):
+        return int(ctx.otf.shape[0])
+
+    def spec_granule(self, ctx):
+        return 1
+
+    def spec_chunk_span(self, ctx, h, z0, z1, nz):
+        per_plane = 4 * h * ctx.otf.shape[2]
+        return z0 * per_plane, (z1 - z0) * per_plane
+
+    def pack_spec_chunk(self, ctx, y0, rows, z0, z1, out_full):
+        off, cnt = self.spec_chunk_span(ctx, rows, z0, z1, 0)
+        out_full[off:off + cnt].copy_(torch.from_numpy(np.ascontiguousarray(ctx.S[z0:z1, y0:y0 + rows, :]).view(np.float32).reshape(-1).copy()))
+
+    def unpack_spec_chunk(self, ctx, src_full, y0, rows, z0, z1):
+        if src_full is None:
+            ctx.S[z0:z1, y0:y0 + rows, :] = 0
+            return
+        off, cnt = self.spec_chunk_span(ctx, rows, z0, z1, 0)
+        if isinstance(src_full, tuple):                 # a receive slot of the ShmPeer double: (array, byte offset)
+            arr, boff = src_full
+            words = np.array(arr[boff + 4 * off:boff + 4 * (off + cnt)]).view(np.float32)
+        else:
+            words = src_full[off:off + cnt].numpy()
+        ctx.S[z0:z1, y0:y0 + rows, :] = np.ascontiguousarray(words).view(np.complex128).reshape(z1 - z0, rows, ctx.S.shape[2])
+
+    def stage(self, ctx, bl, update, stage, z0=0, z1=0, edge_rows=None):
+        ctx.sharded_stage(bl, update, stage, z0, z1, edge_rows)
+
     def halo_floats(self, ctx, lshape, h):
         F = ctx.otf.shape                               # the double's spectra are complex128 on its padded grid
         return max(lshape[0] * h * lshape[2], 4 * F[0] * h * F[2])
@@ -209,6 +275,55 @@ class NumpyOps:
 
     def zero_rows(self, vol, y0, rows):
         vol[:, y0:y0 + rows, :] = 0
+
+
+def lockstep_iterate_zchunked(slabs, niter):
+    """All slabs of one volume in one process, z-chunked protocol: the same order of stages, packs and unpacks as
+    SlabRL._iterate_zchunked on separate ranks -- the halo rows of a half-step are delivered chunk by chunk at the START of the
+    next one, each chunk right before its planes are transformed along y."""
+    s0 = slabs[0]
+    assert all(s.zb is not None and s.zb == s0.zb for s in slabs)
+    h = s0.h
+    K = range(len(s0.zb))
+
+    def new_bufs():
+        return [[(torch.empty(s.ops.halo_floats(s.ctx, s.lshape, h), dtype=torch.float32, device=s.device)) for _ in range(2)] for s in slabs]
+
+    def pack_chunk(bufs, k):
+        for s, (up, dn) in zip(slabs, bufs):
+            z0, z1 = s.zb[k]
+            s.ops.pack_spec_chunk(s.ctx, s.n_loc, h, z0, z1, up)      # last h interior rows -> the next slab's lower halo
+            s.ops.pack_spec_chunk(s.ctx, h, h, z0, z1, dn)            # first h interior rows -> the previous slab's upper halo
+
+    def deliver_chunk(bufs, k):
+        for s in slabs:
+            lo, hi = s.neighbours()
+            z0, z1 = s.zb[k]
+            s.ops.unpack_spec_chunk(s.ctx, bufs[lo][0] if lo is not None else None, 0, h, z0, z1)
+            s.ops.unpack_spec_chunk(s.ctx, bufs[hi][1] if hi is not None else None, h + s.n_loc, h, z0, z1)
+
+    for s in slabs:
+        s.ctx.sharded_begin(s.bl)
+    pending = new_bufs()
+    for k in K:
+        pack_chunk(pending, k)
+    for _ in range(niter):
+        for update in (False, True):
+            for k in K:
+                deliver_chunk(pending, k)
+                for s in slabs:
+                    s.ops.stage(s.ctx, s.bl, update, 0, *s.zb[k])
+            for s in slabs:
+                s.ops.stage(s.ctx, s.bl, update, 1)
+            nxt = new_bufs()
+            for k in K:
+                for s in slabs:
+                    s.ops.stage(s.ctx, s.bl, update, 2, *s.zb[k], s.edge_rows)
+                pack_chunk(nxt, k)
+            for s in slabs:
+                s.ops.stage(s.ctx, s.bl, update, 3, 0, 0, s.edge_rows)
+            pending = nxt
+    return torch.cat([s.interior() for s in slabs], dim=1)
 
 
 def lockstep_iterate(slabs, niter):

@@ -15,7 +15,7 @@ from tests.rl_util import assert_close
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, flavour, engine, vol, psf, niter, out):
+def _worker(rank, world, port, flavour, engine, vol, psf, niter, out, zchunks=1):
     import torch.distributed as dist
     from ipp_amd import slab
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -26,7 +26,8 @@ def _worker(rank, world, port, flavour, engine, vol, psf, niter, out):
     try:
         dev = torch.device("cuda", 0)
         drv = slab.SlabRL(vol.shape, psf, rank=rank, world_size=world, device=dev, flavour=flavour, engine=engine, volume=vol,
-                          transport="peer")
+                          transport="peer", zchunks=zchunks)
+        assert (drv.zb is not None) == (zchunks > 1 and drv.overlap)
         drv.run(niter)
         assert drv.link is not None and drv.link.n > drv.link.SETS
         mine = drv.interior().cpu().contiguous()
@@ -40,15 +41,15 @@ def _worker(rank, world, port, flavour, engine, vol, psf, niter, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("flavour,engine", [("fft", 2), ("spatial", 2), ("fft", 1)],
-                         ids=["fused_overlapped_ring", "fused_zero_edges", "real_halos_direct_engine"])
-def test_two_processes_one_gpu_peer_copy_transport(dev, flavour, engine):
+@pytest.mark.parametrize("flavour,engine,zchunks", [("fft", 2, 1), ("spatial", 2, 1), ("fft", 1, 1), ("fft", 2, 4)],
+                         ids=["fused_overlapped_ring", "fused_zero_edges", "real_halos_direct_engine", "fused_ring_z_chunked"])
+def test_two_processes_one_gpu_peer_copy_transport(dev, flavour, engine, zchunks):
     psf = R.gaussian_psf((5, 7, 5), (1.0, 1.5, 1.0))
     vol = R.bead_volume((16, 128, 32), seed=33, psf=psf)
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
-    port = 29800 + (os.getpid() % 150) + (0 if flavour == "fft" else 1) + 2 * engine
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, flavour, engine, vol, psf, 4, out)) for r in range(2)]
+    port = 29800 + (os.getpid() % 150) + (0 if flavour == "fft" else 1) + 2 * engine + 5 * zchunks
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, flavour, engine, vol, psf, 4, out, zchunks)) for r in range(2)]
     for p in procs:
         p.start()
     try:
