@@ -651,7 +651,7 @@ struct LagWorkspace {
                 for (int i = 1 + chains; i < 4; ++i) f.s[i] = f.s[chains];
                 f.s[4] = f.s[1];
                 const char* sp = std::getenv("MI_NCC_SPLIT_XY");
-                if (chains == 3 && sp && std::atoi(sp) != 0) MI_HIP(hipStreamCreateWithFlags(&f.s[4], hipStreamNonBlocking));
+                if (chains >= 2 && sp && std::atoi(sp) != 0) MI_HIP(hipStreamCreateWithFlags(&f.s[4], hipStreamNonBlocking));
                 it = per_dev.emplace(dev, f).first;
             }
             sm = it->second.s[0];
