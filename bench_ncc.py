@@ -206,7 +206,7 @@ def cpu_baseline(tiles, res, workers):
             "pairs_compared": {"north_south": sum(1 for p in recs if p[4] == 0), "west_east": sum(1 for p in recs if p[4] == 1)}}
 
 
-def run(dev, repeats=3, cpu_workers=None, rank=0, world=1, dist=None, dist_device=None):
+def run(dev, repeats=10, cpu_workers=None, rank=0, world=1, dist=None, dist_device=None):
     import torch
     from ipp_amd import crossmips
     blocks = crossmips.tile_row_blocks(GRID, world, GRID)

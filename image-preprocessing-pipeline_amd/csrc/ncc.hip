@@ -160,7 +160,7 @@ extern "C" int mi_ncc_mips_batch(int dev, void* stream, int n_pairs, const float
         std::vector<InFlight> flights;
         int rc = MI_OK;
         static const char* env_ser = std::getenv("MI_NCC_SERIAL_MIPS");
-        const bool serial_mips = env_ser ? std::atoi(env_ser) != 0 : true;
+        const bool serial_mips = env_ser ? std::atoi(env_ser) != 0 : false;
         for (auto& kv : groups) {
             const std::vector<int>& idx = kv.second;
             const int q0 = idx[0], n = (int)idx.size();
@@ -185,8 +185,10 @@ extern "C" int mi_ncc_mips_batch(int dev, void* stream, int n_pairs, const float
             if (rc != MI_OK) break;
         }
         if (rc == MI_OK && serial_mips && !flights.empty()) {
-            // every MIP pass first (one HBM-bound stream after the other), then every chain: a chain kernel that runs beside a MIP
-            // pass waits several times longer for each of its memory accesses, and the chains are latency-bound
+            // MI_NCC_SERIAL_MIPS=1: every MIP pass first (one HBM-bound stream after the other), then every chain -- a chain kernel
+            // that runs beside a MIP pass waits several times longer for each of its memory accesses, and the chains are latency-
+            // bound; measured, both orders end within a few per cent of each other (profiles/r03_ncc_timeline.txt), the default lets
+            // the next group's MIP pass run beside this group's chains
             hipEvent_t gate = nullptr;
             hipStream_t sm = ncc_lag_mip_stream(flights.back().job);
             if (hipEventCreateWithFlags(&gate, hipEventDisableTiming) != hipSuccess || hipEventRecord(gate, sm) != hipSuccess)
