@@ -306,6 +306,35 @@ def test_entry_points_in_a_fresh_process(dev, tmp_path):
     assert (tmp_path / "xml_displcomp.xml").exists()
 
 
+@pytest.mark.parametrize("extra", [[], ["--transport", "peer", "--zchunks", "2"]], ids=["send_recv", "peer_copy_z_chunked"])
+def test_bench_two_ranks_on_one_gpu_prints_the_contract_line(dev, extra):
+    """``python bench.py --gpus 2`` from a plain shell: it fans its two ranks out itself (gloo rendezvous on 127.0.0.1, both ranks on
+    the one GPU of the test box -- a rehearsal of the driver's N > 1 launch), runs the slab-sharded RL loop and the NCC leg on tile-row
+    blocks, and rank 0 prints ONE JSON line with the contract's keys, ``roofline`` and ``ncc`` at N = 2."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MI_NCC_GRID="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu", "--workload", "c2",
+                        "--steps", "3", "--warmup", "1"] + extra, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "roofline"):
+        assert key in d, key
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["value"] > 0 and d["scaling"] == "strong" and d["dtype"] == "f32"
+    assert "workload" in d["config"] and "y-slabs x2" in d["config"]["parallelism"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and 0 < rf["frac"] < 1 and rf["traffic"] is None
+    ncc = d["ncc"]
+    assert ncc["n_gpus"] == 2 and ncc["value"] > 0 and ncc["pairs_with_exact_VH_offsets"] == "4/4"
+    assert ncc["partition"]["row_blocks"] == [[0, 1], [1, 2]] and "roofline" in ncc and "cpu_baseline" not in d
+
+
 @pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.float32])
 def test_load_block_on_the_device_is_bit_identical(dev, dtype):
     """mi_load_block (conversion like im2single + padarray 'symmetric' on the device) against lsdeconv.load_block on the host:
