@@ -29,6 +29,8 @@ void ncc_count(int which, long long n);
 namespace {
 
 constexpr int TILE = 32;  // TILE_SIDE, compute_funcs.h:66
+constexpr int MIP_KPW = 8;    // slices per wave whose column maxima stay in registers (stacks of up to 32 slices)
+constexpr int MIP_NB = 4;     // row bands per work-group in that case
 constexpr int MIP_ROWS = 16;
 constexpr int NCC_THREADS = 256;
 
@@ -121,9 +123,19 @@ __global__ __launch_bounds__(256) void k_mips(const float* __restrict__ A, const
     // three lines fetched for two used); the first block is then the partial one
     const int jshift = second ? 0 : (aj0 & 63);
     const int j = (int)blockIdx.x * 64 + lane - jshift;
-    const int i0 = blockIdx.y * MIP_ROWS;
-    const int rows = min(MIP_ROWS, dimi_v - i0);
     const bool live = j >= 0 && j < dimj_v;
+    // A work-group walks MIP_NB consecutive row bands (stacks of up to 4 * MIP_KPW slices): the column maxima of the slices a wave
+    // owns stay in its registers across the bands and go to yz_tmp ONCE per band group -- a quarter of the partial maxima that
+    // k_mips_yz has to read back.  Deeper stacks write them per band (nb = 1 below).
+    const bool keep = dimk <= 4 * MIP_KPW;
+    const int nb = keep ? MIP_NB : 1;
+    float colacc[MIP_KPW];
+#pragma unroll
+    for (int q = 0; q < MIP_KPW; ++q) colacc[q] = 0.0f;
+    for (int b = 0; b < nb; ++b) {
+    const int i0 = ((int)blockIdx.y * nb + b) * MIP_ROWS;
+    if (i0 >= dimi_v) break;  // (uniform)
+    const int rows = min(MIP_ROWS, dimi_v - i0);
     float best[MIP_ROWS];
 #pragma unroll
     for (int r = 0; r < MIP_ROWS; ++r) best[r] = 0.0f;
@@ -136,7 +148,9 @@ __global__ __launch_bounds__(256) void k_mips(const float* __restrict__ A, const
         for (int r = 0; r < MIP_ROWS; ++r) dst[r] = (live && r < rows) ? (p + (size_t)r * pitch)[j] : 0.0f;
     };
     if (wave < dimk) load_slice(wave, v);
-    for (int k = wave; k < dimk; k += 4) {
+    if (b > 0) __syncthreads();  // (comb / xzp of the previous band have been read)
+    // one slice of the wave: returns its column maximum
+    auto slice_step = [&](int k) {
         if (k + 4 < dimk) load_slice(k + 4, vn);
         float colmax = 0.0f;
 #pragma unroll
@@ -155,11 +169,23 @@ __global__ __launch_bounds__(256) void k_mips(const float* __restrict__ A, const
                 else if (r < rows) atomic_max_nonneg(&xz[(size_t)(i0 + r) * dimk + k], rowmax);
             }
         }
-        // yz: the column maxima of this row band go to yz_tmp[tile][band][k][j] (unit-stride stores); k_mips_yz takes the
-        // maximum over the bands -- 2.6 million atomics per pair on the yz MIPs cost more than the whole streaming pass
-        if (live) yz_tmp[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * dimk + k) * dimj_v + j] = colmax;
 #pragma unroll
         for (int r = 0; r < MIP_ROWS; ++r) v[r] = vn[r];
+        return colmax;
+    };
+    // yz: the column maxima of this band (group) go to yz_tmp[tile][group][k][j] (unit-stride stores); k_mips_yz takes the maximum
+    // over the groups -- 2.6 million atomics per pair on the yz MIPs cost more than the whole streaming pass
+    if (keep) {
+#pragma unroll
+        for (int q = 0; q < MIP_KPW; ++q) {
+            const int k = wave + 4 * q;
+            if (k < dimk) colacc[q] = fmaxf(colacc[q], slice_step(k));
+        }
+    } else {
+        for (int k = wave; k < dimk; k += 4) {
+            const float colmax = slice_step(k);
+            if (live) yz_tmp[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * dimk + k) * dimj_v + j] = colmax;
+        }
     }
     // xy: maximum over the four waves' slices
     if (wave > 0) {
@@ -175,6 +201,14 @@ __global__ __launch_bounds__(256) void k_mips(const float* __restrict__ A, const
     if (xz_tmp) {  // rows * dimk contiguous floats
         float* dst = xz_tmp + (((size_t)blockIdx.z * gridDim.x + blockIdx.x) * dimi_v + i0) * dimk;
         for (int e = threadIdx.x; e < rows * dimk; e += 256) dst[e] = xzp[e];
+    }
+    }
+    if (keep && live) {
+#pragma unroll
+        for (int q = 0; q < MIP_KPW; ++q) {
+            const int k = wave + 4 * q;
+            if (k < dimk) yz_tmp[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * dimk + k) * dimj_v + j] = colacc[q];
+        }
     }
 }
 
@@ -203,13 +237,19 @@ __global__ __launch_bounds__(256) void k_mips_xz(const float* __restrict__ xz_tm
 
 // the six MIPs of `np` pairs (np == 1 and tab == nullptr: the pair A, B): k_mips + the reductions of its partial maxima.
 // `tmp` must hold mips_tmp_floats(...) floats per pair.
+// row bands per work-group of k_mips (see there) and the number of band groups of a view
+inline int mips_band_group(int dimk) { return dimk <= 4 * MIP_KPW ? MIP_NB : 1; }
+inline int mips_groups(int dimk, int dimi_v) {
+    const int per = MIP_ROWS * mips_band_group(dimk);
+    return (dimi_v + per - 1) / per;
+}
 inline size_t mips_tmp_floats(int dimk, int dimi_v, int dimj_v) {
-    const size_t bands = (dimi_v + MIP_ROWS - 1) / MIP_ROWS, cblocks = (dimj_v + 63) / 64 + 1;  // (+1: launch_mips aligns the blocks to the tile rows)
+    const size_t bands = (size_t)mips_groups(dimk, dimi_v), cblocks = (dimj_v + 63) / 64 + 1;  // (+1: launch_mips aligns the blocks to the tile rows)
     return 2 * (bands * dimk * dimj_v + cblocks * (size_t)dimi_v * dimk);
 }
 int launch_mips(hipStream_t s, const float* A, const float* B, const float* const* tab, int np, size_t pstride, int dimk, int dimi_v, int dimj_v,
                 size_t slice, int pitch, int ai0, int aj0, float* xy1, float* xz1, float* yz1, float* xy2, float* xz2, float* yz2, float* tmp) {
-    const int bands = (dimi_v + MIP_ROWS - 1) / MIP_ROWS, cblocks = (dimj_v + (aj0 & 63) + 63) / 64;  // (see k_mips: aligned column blocks)
+    const int bands = mips_groups(dimk, dimi_v), cblocks = (dimj_v + (aj0 & 63) + 63) / 64;  // (see k_mips: band groups, aligned column blocks)
     float* yz_tmp = tmp;
     float* xz_tmp = tmp + 2 * (size_t)np * bands * dimk * dimj_v;
     const size_t lds = sizeof(float) * MIP_ROWS * (size_t)dimk;

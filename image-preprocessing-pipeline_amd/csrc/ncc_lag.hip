@@ -1097,7 +1097,7 @@ int ncc_time_mips(int dev, hipStream_t s, int n, const float* const* a_ptrs, con
     MI_HIP(hipMemcpyAsync(tab.p, h.data(), sizeof(void*) * 2 * n, hipMemcpyHostToDevice, s));
     MI_HIP(hipStreamSynchronize(s));
     float* o = out.as<float>();
-    const int bands = (dimi_v + MIP_ROWS - 1) / MIP_ROWS, cblocks = (dimj_v + 63) / 64;
+    const int bands = mips_groups(dimk, dimi_v), cblocks = (dimj_v + 63) / 64;
     const size_t lds = sizeof(float) * MIP_ROWS * (size_t)dimk;
     MI_REQUIRE(lds <= 32 * 1024, "mi_ncc_time_mips: stack too deep for the timed variant");
     float* xz_tmp = tmp.as<float>() + 2 * (size_t)n * bands * dimk * dimj_v;
