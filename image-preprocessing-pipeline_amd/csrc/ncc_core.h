@@ -129,12 +129,18 @@ __global__ __launch_bounds__(256) void k_mips(const float* __restrict__ A, const
     // k_mips_yz has to read back.  Deeper stacks write them per band (nb = 1 below).
     const bool keep = dimk <= 4 * MIP_KPW;
     const int nb = keep ? MIP_NB : 1;
-    float colacc[MIP_KPW];
+    // (in LDS, one column per lane and slice of the wave: as registers behind an unrolled slice loop they took the kernel from 73 to
+    // 130 VGPRs, three waves per SIMD instead of six)
+    __shared__ float cacc[4][MIP_KPW][64];
+    float* colacc = &cacc[wave][0][lane];
+    if (keep) {
 #pragma unroll
-    for (int q = 0; q < MIP_KPW; ++q) colacc[q] = 0.0f;
+        for (int q = 0; q < MIP_KPW; ++q) colacc[q * 64] = 0.0f;
+    }
+#pragma unroll 1
     for (int b = 0; b < nb; ++b) {
-    const int i0 = ((int)blockIdx.y * nb + b) * MIP_ROWS;
-    if (i0 >= dimi_v) break;  // (uniform)
+    const int i0 = __builtin_amdgcn_readfirstlane(((int)blockIdx.y * nb + b) * MIP_ROWS);  // (scalar: so are the row addresses)
+    if (i0 >= dimi_v) break;
     const int rows = min(MIP_ROWS, dimi_v - i0);
     float best[MIP_ROWS];
 #pragma unroll
@@ -176,12 +182,10 @@ __global__ __launch_bounds__(256) void k_mips(const float* __restrict__ A, const
     // yz: the column maxima of this band (group) go to yz_tmp[tile][group][k][j] (unit-stride stores); k_mips_yz takes the maximum
     // over the groups -- 2.6 million atomics per pair on the yz MIPs cost more than the whole streaming pass
     if (keep) {
-#pragma unroll
-        for (int q = 0; q < MIP_KPW; ++q) {
-            const int k = wave + 4 * q;
-            if (k < dimk) colacc[q] = fmaxf(colacc[q], slice_step(k));
-        }
+#pragma unroll 1
+        for (int k = wave, q = 0; k < dimk; k += 4, ++q) colacc[q * 64] = fmaxf(colacc[q * 64], slice_step(k));
     } else {
+#pragma unroll 1
         for (int k = wave; k < dimk; k += 4) {
             const float colmax = slice_step(k);
             if (live) yz_tmp[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * dimk + k) * dimj_v + j] = colmax;
@@ -207,7 +211,7 @@ __global__ __launch_bounds__(256) void k_mips(const float* __restrict__ A, const
 #pragma unroll
         for (int q = 0; q < MIP_KPW; ++q) {
             const int k = wave + 4 * q;
-            if (k < dimk) yz_tmp[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * dimk + k) * dimj_v + j] = colacc[q];
+            if (k < dimk) yz_tmp[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * dimk + k) * dimj_v + j] = colacc[q * 64];
         }
     }
 }
