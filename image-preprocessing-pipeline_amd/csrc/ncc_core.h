@@ -129,8 +129,10 @@ __global__ __launch_bounds__(256) void k_mips(const float* __restrict__ A, const
     // k_mips_yz has to read back.  Deeper stacks write them per band (nb = 1 below).
     const bool keep = dimk <= 4 * MIP_KPW;
     const int nb = keep ? MIP_NB : 1;
-    // (in LDS, one column per lane and slice of the wave: as registers behind an unrolled slice loop they took the kernel from 73 to
-    // 130 VGPRs, three waves per SIMD instead of six)
+    // (in LDS, one column per lane and slice of the wave.  With the band loop around it the kernel needs 128 VGPRs -- the 16 scalar
+    // row bases of two slices in flight now overflow the scalar registers and spill into vector ones -- i.e. four waves per SIMD
+    // instead of six; forcing five or six spills to scratch, lane offsets instead of scalar bases cost 185 VGPRs.  Measured it
+    // still wins: MIP phase of 112 C5 pairs 4.6 -> 4.15 ms, 12.0-12.4 -> 12.9-13.0 k pairs/s)
     __shared__ float cacc[4][MIP_KPW][64];
     float* colacc = &cacc[wave][0][lane];
     if (keep) {
