@@ -241,7 +241,17 @@ int edgetaper_async(hipStream_t s, float* bl, float* work, const float* psf, int
     const double nf = (double)F[0] * F[1] * F[2];
     shell = 1.0 - shell;
     const double taps = (double)kx * ky * kz, nvox = (double)nx * ny * nz;
-    const double t_direct = shell * nvox * 2.0 * taps / 50e12;
+    // (the direct engine skips whole 128 x 16 x 2 tiles on the plateau: a tile that the shell only touches is computed in full, so
+    // for blocks a few tiles wide most of the volume counts -- 512 columns with a 9-sample taper: half of them)
+    double inner_tiles = 1.0;
+    {
+        const int tile[3] = {128, 16, 2};
+        for (int d = 0; d < 3; ++d) {
+            const int t0 = (epi.plat_lo[d] + tile[d] - 1) / tile[d], t1 = epi.plat_hi[d] / tile[d], nt = (n[d] + tile[d] - 1) / tile[d];
+            inner_tiles *= (double)std::max(0, t1 - t0) / nt;
+        }
+    }
+    const double t_direct = (1.0 - inner_tiles) * nvox * 2.0 * taps / 50e12;
     const double t_fft = native_grid ? nf * 25e-12 + 0.02 : nf * 220.0 / 4e12 + 2.5;
     const bool odd = (kx & 1) && (ky & 1) && (kz & 1);
     bool use_fft = odd && t_fft < t_direct;
