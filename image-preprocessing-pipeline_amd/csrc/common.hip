@@ -3,6 +3,8 @@
 #include <map>
 #include <mutex>
 
+#include <cstdlib>
+
 #include "mi_internal.h"
 #include "mi_lsdeconv.h"
 
@@ -86,7 +88,19 @@ int pool_alloc(size_t n, void** out) {
             return MI_OK;
         }
     }
-    hipError_t e = hipMalloc(out, n);
+    // Large blocks are asked for as PHYSICALLY CONTIGUOUS memory first (MI_CONTIG_MIN_MB, default 1024; 0 = never): the strided
+    // passes of the FFT pipeline run at one of two speeds depending on the pages behind the spectrum arrays, and a process that
+    // starts on a device whose memory earlier processes have churned gets the slow ones from a plain hipMalloc
+    static const size_t contig_min = [] {
+        const char* e = std::getenv("MI_CONTIG_MIN_MB");
+        return (size_t)(e ? std::max(0, atoi(e)) : 1024) << 20;
+    }();
+    hipError_t e = hipErrorOutOfMemory;
+    if (contig_min > 0 && n >= contig_min) {
+        e = hipExtMallocWithFlags(out, n, hipDeviceMallocContiguous);
+        if (e != hipSuccess) (void)hipGetLastError();
+    }
+    if (e != hipSuccess) e = hipMalloc(out, n);
     if (e != hipSuccess && P.enabled) {  // give the cached blocks back and try once more
         (void)hipGetLastError();
         std::lock_guard<std::mutex> g(P.mu);
