@@ -88,12 +88,14 @@ int pool_alloc(size_t n, void** out) {
             return MI_OK;
         }
     }
-    // Large blocks are asked for as PHYSICALLY CONTIGUOUS memory first (MI_CONTIG_MIN_MB, default 1024; 0 = never): the strided
-    // passes of the FFT pipeline run at one of two speeds depending on the pages behind the spectrum arrays, and a process that
-    // starts on a device whose memory earlier processes have churned gets the slow ones from a plain hipMalloc
+    // MI_CONTIG_MIN_MB=<n> (default 0 = never): blocks of at least n MB are asked for as PHYSICALLY CONTIGUOUS memory first.
+    // An experiment that answered a question of rounds 2 / 3: the strided passes of the FFT pipeline run at one of two speeds
+    // depending on the pages behind the spectrum arrays (y passes 2.93 or 3.35 ms on C3).  With contiguous memory they ALWAYS run
+    // at the slow speed, whatever the row paddings and the distance between the two arrays (profiles/r03_placement.txt): the
+    // fast speed belongs to allocations whose pages the driver scattered, which a library cannot ask for.
     static const size_t contig_min = [] {
         const char* e = std::getenv("MI_CONTIG_MIN_MB");
-        return (size_t)(e ? std::max(0, atoi(e)) : 1024) << 20;
+        return (size_t)(e ? std::max(0, atoi(e)) : 0) << 20;
     }();
     hipError_t e = hipErrorOutOfMemory;
     if (contig_min > 0 && n >= contig_min) {
