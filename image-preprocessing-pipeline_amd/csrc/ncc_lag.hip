@@ -62,10 +62,11 @@ __device__ __forceinline__ int pos_of_freq(int k, const FftPlan& pl) {
     return p;
 }
 
-__device__ void fft_dif(cplx* __restrict__ x, const FftPlan& pl, const cplx* __restrict__ tw) {
+// BF = butterflies per thread and step: their LDS reads and table loads are issued before any store
+template <int BF>
+__device__ __forceinline__ void fft_dif(cplx* __restrict__ x, const FftPlan& pl, const cplx* __restrict__ tw) {
     const int N = pl.N;
     int L = N;
-    constexpr int BF = 2;  // butterflies per thread and step: their LDS reads and table loads are issued before any store
     for (int st = 0; st < pl.nstages; ++st) {
         const int r = pl.radix[st], q = L / r, nb = N / r;
         const cplx* stw = tw + pl.twoff[st];
@@ -119,7 +120,8 @@ __device__ void fft_dif(cplx* __restrict__ x, const FftPlan& pl, const cplx* __r
 }
 
 // forward lag transform of short-axis line j (blockIdx.x) of pair blockIdx.y: element i of the line = m[i * ls + j * ss]
-__global__ __launch_bounds__(512) void k_lag_fwd(const float* __restrict__ m1, const float* __restrict__ m2, size_t pstride, int n_long, int n_short,
+template <int TH, int BF>
+__global__ __launch_bounds__(TH) void k_lag_fwd(const float* __restrict__ m1, const float* __restrict__ m2, size_t pstride, int n_long, int n_short,
                                                  int ls, int ss, FftPlan pl, const cplx* __restrict__ tw, const int* __restrict__ slot_pos,
                                                  const int* __restrict__ slot_neg, cplx* __restrict__ SF, cplx* __restrict__ ST) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lag_lds[];
@@ -130,7 +132,7 @@ __global__ __launch_bounds__(512) void k_lag_fwd(const float* __restrict__ m1, c
     for (int i = threadIdx.x; i < N; i += blockDim.x)
         x[i] = i < n_long ? make_double2((double)a[(size_t)i * ls], (double)b[(size_t)i * ls]) : make_double2(0.0, 0.0);
     __syncthreads();
-    fft_dif(x, pl, tw);
+    fft_dif<BF>(x, pl, tw);
     cplx* of = SF + ((size_t)blockIdx.y * n_short + j) * NK;
     cplx* ot = ST + ((size_t)blockIdx.y * n_short + j) * NK;
     // The N/2 + 1 frequencies 0 .. N/2 of a real signal's spectrum are kept in POSITION order ("slots": slot_pos ascending; slot_neg =
@@ -144,72 +146,132 @@ __global__ __launch_bounds__(512) void k_lag_fwd(const float* __restrict__ m1, c
     }
 }
 
-// per frequency: C_s[k] = sum_j F_{j+s}[k] conj(T_j[k]),  s = -Es .. Es.  A work-group takes KT frequencies; a thread one
-// frequency, four neighbouring lags and one of JP parts of the j range (sliding registers: two LDS reads feed 16 FMAs).
+// per frequency: C_s[k] = sum_j F_{j+s}[k] conj(T_j[k]),  s = -Es .. Es.  A TILE is KT frequencies of one pair; a thread takes one
+// frequency, LB neighbouring lags and one of JP parts of the j range.  The LB samples of F a step needs sit in a ring of registers
+// (two 16-byte LDS reads feed 4 LB FMAs; LB steps bring every sample back to its slot).
+// The work-groups are persistent (tile blockIdx.x, + gridDim.x, ...) and carry the NEXT tile's spectra in registers (PF elements
+// of F and of T per thread, requested right after the current tile reached LDS): work-groups of one CU start together and stay in
+// step, so without this every fill phase -- 39 KB per tile on the xy plane of config 5 -- was a phase in which the CU computed
+// nothing (600 -> 4xx us for that plane: profiles/r03_lag_shapes.txt).
+template <int LB, int PF>
 __global__ __launch_bounds__(256) void k_lag_mac(const cplx* __restrict__ SF, const cplx* __restrict__ ST, int n_short, int NK, int Es, int KT, int JP,
-                                                 int FW, int TW, cplx* __restrict__ CH) {
+                                                 int FW, int TW, int nlp, int tiles_per_pair, int ntiles, cplx* __restrict__ CH) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lag_lds[];
     cplx* Fs = reinterpret_cast<cplx*>(lag_lds);  // KT rows of FW: PAD zeros | n_short samples | zeros
     cplx* Ts = Fs + (size_t)KT * FW;              // KT rows of TW
-    const int PAD = Es + 3, k0 = blockIdx.x * KT, nk = min(KT, NK - k0);
-    const size_t pbase = (size_t)blockIdx.y * n_short;
+    cplx* red = Ts + (size_t)KT * TW;             // [jp - 1][vb][kl][LB]: the partial sums of the parts jp > 0
+    const int PAD = Es + LB - 1;
     for (int e = threadIdx.x; e < KT * FW; e += blockDim.x) Fs[e] = make_double2(0.0, 0.0);
-    __syncthreads();
-    for (int e = threadIdx.x; e < n_short * KT; e += blockDim.x) {  // kl fastest: 16 * KT contiguous bytes per line j
-        const int x = e / KT, kl = e - x * KT;
-        if (kl < nk) {
-            Fs[(size_t)kl * FW + PAD + x] = SF[(pbase + x) * NK + k0 + kl];
-            Ts[(size_t)kl * TW + x] = ST[(pbase + x) * NK + k0 + kl];
-        }
-    }
-    __syncthreads();
-    const int nlag = 2 * Es + 1, nvb = (nlag + 3) / 4, nlp = nvb * 4;
+    const int nvb = nlp / LB;
     const int jlen = (n_short + JP - 1) / JP;
-    cplx acc[4];
     const int item = threadIdx.x;  // (jp, vb, kl), kl fastest
     const int kl = item % KT, vb = (item / KT) % nvb, jp = item / (KT * nvb);
-    const bool live = jp < JP && kl < nk;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) acc[q] = make_double2(0.0, 0.0);
-    if (live) {
-        const int v0 = -Es + 4 * vb, jb = jp * jlen, je = min(n_short, jb + jlen);
-        const cplx* fr = Fs + (size_t)kl * FW + PAD + v0;
-        const cplx* tr = Ts + (size_t)kl * TW;
-        cplx f0 = fr[jb], f1 = fr[jb + 1], f2 = fr[jb + 2];
-        for (int j = jb; j < je; ++j) {
-            const cplx f3 = fr[j + 3], t = tr[j];
-            acc[0].x = fma(f0.x, t.x, fma(f0.y, t.y, acc[0].x)); acc[0].y = fma(f0.y, t.x, fma(-f0.x, t.y, acc[0].y));
-            acc[1].x = fma(f1.x, t.x, fma(f1.y, t.y, acc[1].x)); acc[1].y = fma(f1.y, t.x, fma(-f1.x, t.y, acc[1].y));
-            acc[2].x = fma(f2.x, t.x, fma(f2.y, t.y, acc[2].x)); acc[2].y = fma(f2.y, t.x, fma(-f2.x, t.y, acc[2].y));
-            acc[3].x = fma(f3.x, t.x, fma(f3.y, t.y, acc[3].x)); acc[3].y = fma(f3.y, t.x, fma(-f3.x, t.y, acc[3].y));
-            f0 = f1; f1 = f2; f2 = f3;
+    const int v0 = -Es + LB * vb, jb = jp * jlen, je = min(n_short, jb + jlen);
+    const cplx* fr = Fs + (size_t)kl * FW + PAD + v0;
+    const cplx* tr = Ts + (size_t)kl * TW;
+    const int nelem = n_short * KT;  // elements of a tile, kl fastest: 16 * KT contiguous bytes per line j
+
+    int tile = blockIdx.x;
+    __syncthreads();
+    if (tile < ntiles) {  // the first tile goes to LDS directly
+        const int pair = tile / tiles_per_pair, k0 = (tile - pair * tiles_per_pair) * KT, nk = min(KT, NK - k0);
+        const size_t pbase = (size_t)pair * n_short;
+        for (int e = threadIdx.x; e < nelem; e += 256) {
+            const int x = e / KT, l = e - x * KT;
+            if (l < nk) {
+                Fs[(size_t)l * FW + PAD + x] = SF[(pbase + x) * NK + k0 + l];
+                Ts[(size_t)l * TW + x] = ST[(pbase + x) * NK + k0 + l];
+            }
         }
     }
-    // the JP parts of a (kl, vb) are added in a fixed order through LDS (the spectra are no longer needed)
-    __syncthreads();
-    cplx* red = Fs;  // [jp][vb][kl][4]
-    if (live && jp > 0) {
+    while (tile < ntiles) {
+        const int pair = tile / tiles_per_pair, k0 = (tile - pair * tiles_per_pair) * KT, nk = min(KT, NK - k0);
+        __syncthreads();  // the tile is in LDS
+        const int next = tile + gridDim.x;
+        const bool has_next = next < ntiles;
+        const int npair = next / tiles_per_pair, nk0 = (next - npair * tiles_per_pair) * KT, nnk = min(KT, NK - nk0);
+        cplx pf[PF], pt[PF];
+        if (has_next) {
+            const size_t pbase = (size_t)npair * n_short;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) red[(((size_t)(jp - 1) * nvb + vb) * KT + kl) * 4 + q] = acc[q];
-    }
-    __syncthreads();
-    if (live && jp == 0) {
-        for (int p = 1; p < JP; ++p)
+            for (int i = 0; i < PF; ++i) {
+                const int e = threadIdx.x + i * 256;
+                const int x = e / KT, l = e - x * KT;
+                const bool ok = e < nelem && l < nnk;
+                pf[i] = ok ? SF[(pbase + x) * NK + nk0 + l] : make_double2(0.0, 0.0);
+                pt[i] = ok ? ST[(pbase + x) * NK + nk0 + l] : make_double2(0.0, 0.0);
+            }
+        }
+
+        const bool live = jp < JP && kl < nk;
+        cplx acc[LB];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc[q] = cadd(acc[q], red[(((size_t)(p - 1) * nvb + vb) * KT + kl) * 4 + q]);
-        cplx* dst = CH + ((size_t)blockIdx.y * NK + k0 + kl) * nlp + 4 * vb;
+        for (int q = 0; q < LB; ++q) acc[q] = make_double2(0.0, 0.0);
+        if (live) {
+            const cplx* fp = fr + jb;
+            const cplx* tp = tr + jb;
+            cplx f[LB];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) dst[q] = acc[q];
+            for (int q = 0; q < LB - 1; ++q) f[q] = fp[q];
+            auto steps = [&](int rem) {  // LB steps; rem < LB: only the first rem count (the others see t = 0)
+#pragma unroll
+                for (int jj = 0; jj < LB; ++jj) {
+                    f[(jj + LB - 1) % LB] = fp[jj + LB - 1];  // (zeros past the row: FW leaves room for a whole trip)
+                    cplx t = tp[jj];
+                    if (jj >= rem) t = make_double2(0.0, 0.0);  // (the next part's samples, or what lies past the row)
+#pragma unroll
+                    for (int q = 0; q < LB; ++q) {
+                        const cplx fv = f[(jj + q) % LB];
+                        acc[q].x = fma(fv.x, t.x, fma(fv.y, t.y, acc[q].x));
+                        acc[q].y = fma(fv.y, t.x, fma(-fv.x, t.y, acc[q].y));
+                    }
+                }
+            };
+            const int trips = (je - jb) / LB;
+            for (int it = 0; it < trips; ++it) {
+                steps(LB);
+                fp += LB;
+                tp += LB;
+            }
+            if (je - jb > trips * LB) steps(je - jb - trips * LB);
+        }
+        // the JP parts of a (kl, vb) are added in a fixed order
+        if (live && jp > 0) {
+#pragma unroll
+            for (int q = 0; q < LB; ++q) red[(((size_t)(jp - 1) * nvb + vb) * KT + kl) * LB + q] = acc[q];
+        }
+        __syncthreads();  // (also: every read of this tile's spectra is done)
+        if (live && jp == 0) {
+            for (int p = 1; p < JP; ++p)
+#pragma unroll
+                for (int q = 0; q < LB; ++q) acc[q] = cadd(acc[q], red[(((size_t)(p - 1) * nvb + vb) * KT + kl) * LB + q]);
+            cplx* dst = CH + ((size_t)pair * NK + k0 + kl) * nlp + LB * vb;
+#pragma unroll
+            for (int q = 0; q < LB; ++q) dst[q] = acc[q];
+        }
+        if (has_next) {  // (every read of this tile's spectra lies before the barrier above; `red` is its own region)
+#pragma unroll
+            for (int i = 0; i < PF; ++i) {
+                const int e = threadIdx.x + i * 256;
+                const int x = e / KT, l = e - x * KT;
+                if (e < nelem && l < nnk) {
+                    Fs[(size_t)l * FW + PAD + x] = pf[i];
+                    Ts[(size_t)l * TW + x] = pt[i];
+                }
+            }
+        }
+        tile = next;
     }
 }
 
 // inverse lag transform of two short-axis lags (2 * blockIdx.x, + 1) of pair blockIdx.y: c_a[n] + i c_b[n] = FFT(conj C_a + i conj C_b) / N
 // (both c real); the long-axis lags [-El, El] go to cross[(u + Eu) * (2 Ev + 1) + (v + Ev)]
-__global__ __launch_bounds__(512) void k_lag_inv(const cplx* __restrict__ CH, int NK, FftPlan pl, int Es, int El, int long_is_u, int Eu, int Ev,
+template <int TH, int BF>
+__global__ __launch_bounds__(TH) void k_lag_inv(const cplx* __restrict__ CH, int NK, int nlp, FftPlan pl, int Es, int El, int long_is_u, int Eu, int Ev,
                                                  const cplx* __restrict__ tw, const int* __restrict__ slot_freq, double* __restrict__ cross) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lag_lds[];
     cplx* x = reinterpret_cast<cplx*>(lag_lds);
-    const int N = pl.N, nlag = 2 * Es + 1, nlp = (nlag + 3) / 4 * 4;
+    const int N = pl.N, nlag = 2 * Es + 1;
     const int sa = 2 * blockIdx.x, sb = sa + 1;
     const bool has_b = sb < nlag;
     const cplx* src = CH + (size_t)blockIdx.y * NK * nlp;
@@ -221,7 +283,7 @@ __global__ __launch_bounds__(512) void k_lag_inv(const cplx* __restrict__ CH, in
         if (k > 0 && k < N / 2) x[N - k] = make_double2(xa.x - xb.y, xa.y + xb.x);   // Xa + i Xb  (= conj X[N-k] terms)
     }
     __syncthreads();
-    fft_dif(x, pl, tw);
+    fft_dif<BF>(x, pl, tw);
     const double inv = 1.0 / (double)N;
     const int W = 2 * Ev + 1;
     double* out = cross + (size_t)blockIdx.y * (2 * Eu + 1) * W;
@@ -473,7 +535,7 @@ struct LagPlane {
     bool long_is_u;
     int n_long, n_short, ls, ss, El, Es, Eu, Ev;
     FftPlan fft;
-    int KT, JP, FW, TW, fft_threads;
+    int KT, JP, FW, TW, LB, nlp, fft_threads;
     size_t lds_fft, lds_mac, lds_refine;
     bool ok;
 };
@@ -531,22 +593,26 @@ LagPlane plan_lag_plane(const PlaneGeom& g, int maxIter) {
     p.Ev = p.long_is_u ? p.Es : p.El;
     p.fft = make_fft_plan(p.n_long + p.El);
     p.lds_fft = sizeof(double) * 2 * (size_t)p.fft.N;
-    const int PAD = p.Es + 3;
-    p.FW = (p.n_short + 2 * PAD + 15) / 16 * 16 + 1;  // rows one 16-byte slot apart in the banks
-    p.TW = (p.n_short + 15) / 16 * 16 + 1;
+    const int nlag = 2 * p.Es + 1;
+    p.LB = 4;  // lags per thread of the correlation kernel (8 was measured: twice the registers, bank conflicts, no faster)
+    p.nlp = (nlag + p.LB - 1) / p.LB * p.LB;
+    const int PAD = p.Es + p.LB - 1;
+    // odd row lengths (in 16-byte slots): the KT rows a wave touches at once start in different banks, and a lag block is four slots
+    p.FW = (p.n_short + 2 * PAD + p.LB) | 1;
+    p.TW = (p.n_short + p.LB) | 1;
     const size_t row = sizeof(double) * 2 * (size_t)(p.FW + p.TW);
     // four frequencies per work-group: with rows one 16-byte slot apart and lanes ordered (frequency fastest, then lag block) the
     // 16-byte LDS reads of a wave are conflict-free; the j range is cut into JP parts so that all 256 threads have an item
     p.KT = (int)std::min<size_t>(4, (48 * 1024) / row);
     if (p.KT < 1) p.KT = 1;
-    const int nvb = (2 * p.Es + 1 + 3) / 4;
-    while (p.KT > 1 && p.KT * nvb > 256) --p.KT;
+    const int nvb = p.nlp / p.LB;
+    while (p.KT > 1 && (p.KT * nvb > 256 || p.n_short * p.KT > 6 * 256)) --p.KT;
     p.JP = std::max(1, std::min(8, 256 / (p.KT * nvb)));
     p.fft_threads = p.fft.N >= 2048 ? 512 : 256;
-    p.lds_mac = std::max(row * p.KT, sizeof(double) * 2 * 4 * (size_t)p.JP * nvb * p.KT);
+    p.lds_mac = row * p.KT + sizeof(double) * 2 * p.LB * (size_t)(p.JP - 1) * nvb * p.KT;  // (xy plane of config 5: 52 KB, three per CU)
     const int Hm = 2 * g.delayu + 1, Wm = 2 * g.delayv + 1, H = 2 * g.wu + 1, W = 2 * g.wv + 1;
     p.lds_refine = sizeof(float) * ((size_t)Hm * Wm + 2 * (size_t)H * W);
-    p.ok = p.fft.N <= 8192 && p.lds_mac <= 150 * 1024 && nvb <= 256 && p.lds_refine <= 120 * 1024;
+    p.ok = p.fft.N <= 8192 && p.lds_mac <= 150 * 1024 && nvb <= 256 && p.n_short * p.KT <= 6 * 256 && p.lds_refine <= 120 * 1024;
     return p;
 }
 
@@ -626,6 +692,8 @@ struct LagWorkspace {
     hipStream_t sx = nullptr;  // MI_NCC_SPLIT_XY=1: the lag transform of the xy plane beside that plane's tables (default: behind them;
                                // measured equal -- the runtime maps the extra stream onto the hardware queue of the tables)
     hipEvent_t ev_start = nullptr, ev_lag = nullptr, ev_done = nullptr, ev_plane[2] = {nullptr, nullptr}, ev_x = nullptr;
+    hipEvent_t ev_head_tab = nullptr;
+    hipEvent_t ev_head = nullptr;  // per DEVICE like the streams (not owned): "the memory-bound head of the latest xy chain has run"
     std::vector<hipEvent_t> ev_mip;
     ~LagWorkspace() {
         if (ev_start) (void)hipEventDestroy(ev_start);
@@ -639,7 +707,7 @@ struct LagWorkspace {
     int streams(size_t pieces) {
         {
             static std::mutex mu;
-            struct Four { hipStream_t s[5]; };
+            struct Four { hipStream_t s[5]; hipEvent_t head, head_tab; };
             static std::map<int, Four> per_dev;  // (never destroyed: the process' lifetime)
             std::lock_guard<std::mutex> lock(mu);
             auto it = per_dev.find(dev);
@@ -652,11 +720,15 @@ struct LagWorkspace {
                 f.s[4] = f.s[1];
                 const char* sp = std::getenv("MI_NCC_SPLIT_XY");
                 if (chains >= 2 && sp && std::atoi(sp) != 0) MI_HIP(hipStreamCreateWithFlags(&f.s[4], hipStreamNonBlocking));
+                MI_HIP(hipEventCreateWithFlags(&f.head, hipEventDisableTiming));
+                MI_HIP(hipEventCreateWithFlags(&f.head_tab, hipEventDisableTiming));
                 it = per_dev.emplace(dev, f).first;
             }
             sm = it->second.s[0];
             for (int m = 0; m < 3; ++m) sl[m] = it->second.s[1 + m];
             sx = it->second.s[4];
+            ev_head = it->second.head;
+            ev_head_tab = it->second.head_tab;
         }
         if (!ev_x) MI_HIP(hipEventCreateWithFlags(&ev_x, hipEventDisableTiming));
         for (hipEvent_t& e : ev_plane)
@@ -698,9 +770,43 @@ void give_lag_ws(std::unique_ptr<LagWorkspace> r) {
 
 int grow(DevBuf& b, size_t bytes) { return b.bytes >= bytes ? MI_OK : b.alloc(bytes); }
 
+// The work-group shapes of the two transform kernels: threads and butterflies per thread and step.
+using FwdFn = void (*)(const float*, const float*, size_t, int, int, int, int, FftPlan, const cplx*, const int*, const int*, cplx*, cplx*);
+using InvFn = void (*)(const cplx*, int, int, FftPlan, int, int, int, int, int, const cplx*, const int*, double*);
+struct FftShape {
+    int threads, bf;
+    FwdFn fwd_fn;
+    InvFn inv_fn;
+    const void *fwd, *inv;
+};
+template <int TH, int BF>
+FftShape make_shape() {
+    FftShape s{TH, BF, k_lag_fwd<TH, BF>, k_lag_inv<TH, BF>, nullptr, nullptr};
+    s.fwd = reinterpret_cast<const void*>(s.fwd_fn);
+    s.inv = reinterpret_cast<const void*>(s.inv_fn);
+    return s;
+}
+const FftShape& fft_shape(const LagPlane& lp) {
+    static const FftShape shapes[] = {make_shape<512, 2>(), make_shape<512, 1>(), make_shape<256, 2>(), make_shape<256, 1>(), make_shape<256, 3>(),
+                                      make_shape<192, 3>(), make_shape<384, 3>(), make_shape<128, 3>(), make_shape<128, 5>()};
+    static const int forced = [] {  // MI_NCC_FFT_SHAPE=<threads>,<butterflies>: measurement aid
+        const char* e = std::getenv("MI_NCC_FFT_SHAPE");
+        int t = 0, b = 0;
+        if (!e || sscanf(e, "%d,%d", &t, &b) != 2) return -1;
+        for (size_t i = 0; i < sizeof(shapes) / sizeof(shapes[0]); ++i)
+            if (shapes[i].threads == t && shapes[i].bf == b) return (int)i;
+        return -1;
+    }();
+    if (forced >= 0) return shapes[forced];
+    // one butterfly per thread and step keeps the kernels under 64 registers: four work-groups of 512 per CU instead of two
+    // (forward transform of the xy plane 765 -> 500 us: profiles/r03_lag_shapes.txt)
+    return lp.fft_threads == 512 ? shapes[1] : shapes[3];
+}
+
 // cross terms of `np` pairs of one plane through the lag transform (MIPs at m1 / m2 + q * pstride) into ws.cross
-int lag_cross(int dev, hipStream_t s, const LagPlane& lp, const float* m1, const float* m2, size_t pstride, int np, LagWorkspace& ws, int m = 0) {
-    const int N = lp.fft.N, NK = N / 2 + 1, nlag = 2 * lp.Es + 1, nlp = (nlag + 3) / 4 * 4;
+int lag_cross(int dev, hipStream_t s, const LagPlane& lp, const float* m1, const float* m2, size_t pstride, int np, LagWorkspace& ws, int m = 0,
+              hipEvent_t after_fwd = nullptr) {
+    const int N = lp.fft.N, NK = N / 2 + 1, nlag = 2 * lp.Es + 1, nlp = lp.nlp;
     FftTables ft;
     MI_TRY(fft_tables(dev, lp.fft, s, &ft));
     const cplx* tw = ft.tw;
@@ -708,20 +814,31 @@ int lag_cross(int dev, hipStream_t s, const LagPlane& lp, const float* m1, const
     MI_TRY(grow(ws.ST[m], sizeof(double) * 2 * (size_t)np * lp.n_short * NK));
     MI_TRY(grow(ws.CH[m], sizeof(double) * 2 * (size_t)np * NK * nlp));
     MI_TRY(grow(ws.cross[m], sizeof(double) * (size_t)np * (2 * lp.Eu + 1) * (2 * lp.Ev + 1)));
-    if (lp.lds_fft > 64 * 1024)
-        MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lag_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp.lds_fft));
-    hipLaunchKernelGGL(k_lag_fwd, dim3(lp.n_short, np), dim3(lp.fft_threads), lp.lds_fft, s, m1, m2, pstride, lp.n_long, lp.n_short, lp.ls, lp.ss, lp.fft, tw,
-                       ft.slot_pos, ft.slot_neg, ws.SF[m].as<cplx>(), ws.ST[m].as<cplx>());
+    const FftShape& sh = fft_shape(lp);
+    if (lp.lds_fft > 64 * 1024) MI_HIP(hipFuncSetAttribute(sh.fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp.lds_fft));
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(sh.fwd_fn), dim3(lp.n_short, np), dim3(sh.threads), lp.lds_fft, s, m1, m2, pstride, lp.n_long, lp.n_short, lp.ls,
+                       lp.ss, lp.fft, tw, ft.slot_pos, ft.slot_neg, ws.SF[m].as<cplx>(), ws.ST[m].as<cplx>());
     MI_TRY(launch_check("k_lag_fwd"));
-    if (lp.lds_mac > 64 * 1024)
-        MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lag_mac), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp.lds_mac));
-    hipLaunchKernelGGL(k_lag_mac, dim3((NK + lp.KT - 1) / lp.KT, np), dim3(256), lp.lds_mac, s, ws.SF[m].as<cplx>(), ws.ST[m].as<cplx>(), lp.n_short, NK,
-                       lp.Es, lp.KT, lp.JP, lp.FW, lp.TW, ws.CH[m].as<cplx>());
+    if (after_fwd) MI_HIP(hipEventRecord(after_fwd, s));
+    {
+        using MacFn = void (*)(const cplx*, const cplx*, int, int, int, int, int, int, int, int, int, int, cplx*);
+        static const MacFn macs[] = {k_lag_mac<4, 1>, k_lag_mac<4, 2>, k_lag_mac<4, 3>, k_lag_mac<4, 4>, k_lag_mac<4, 5>, k_lag_mac<4, 6>};
+        const int pfn = (lp.n_short * lp.KT + 255) / 256;  // (plan_lag_plane keeps it within the table)
+        MacFn mac = macs[pfn - 1];
+        const int tiles_per_pair = (NK + lp.KT - 1) / lp.KT, ntiles = tiles_per_pair * np;
+        int cus = 256, per_cu = 1;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (lp.lds_mac > 64 * 1024)
+            MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mac), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp.lds_mac));
+        per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / std::max<size_t>(lp.lds_mac, 1)));
+        const int grid = std::min(ntiles, cus * per_cu);
+        hipLaunchKernelGGL(mac, dim3(grid), dim3(256), lp.lds_mac, s, ws.SF[m].as<cplx>(), ws.ST[m].as<cplx>(), lp.n_short, NK, lp.Es, lp.KT, lp.JP,
+                           lp.FW, lp.TW, nlp, tiles_per_pair, ntiles, ws.CH[m].as<cplx>());
+    }
     MI_TRY(launch_check("k_lag_mac"));
-    if (lp.lds_fft > 64 * 1024)
-        MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lag_inv), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp.lds_fft));
-    hipLaunchKernelGGL(k_lag_inv, dim3((nlag + 1) / 2, np), dim3(lp.fft_threads), lp.lds_fft, s, ws.CH[m].as<cplx>(), NK, lp.fft, lp.Es, lp.El, lp.long_is_u ? 1 : 0,
-                       lp.Eu, lp.Ev, tw, ft.slot_freq, ws.cross[m].as<double>());
+    if (lp.lds_fft > 64 * 1024) MI_HIP(hipFuncSetAttribute(sh.inv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp.lds_fft));
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(sh.inv_fn), dim3((nlag + 1) / 2, np), dim3(sh.threads), lp.lds_fft, s, ws.CH[m].as<cplx>(), NK, nlp, lp.fft, lp.Es, lp.El,
+                       lp.long_is_u ? 1 : 0, lp.Eu, lp.Ev, tw, ft.slot_freq, ws.cross[m].as<double>());
     return launch_check("k_lag_inv");
 }
 
@@ -831,6 +948,24 @@ struct LagJob {
 static int enqueue_chains(LagJob& job, int c0, int p0, int np, int pi, hipEvent_t gate);
 static int close_job(LagJob& job);
 
+// MI_NCC_GATE (default 1): a group's MIP pass starts only when the previous group's xy chain is past its tables and its forward lag
+// transform.  Those are bound by memory latency and run three times longer beside a MIP pass (which they slow down in turn); what
+// is left of the chain -- the fp64 correlation, the inverse transform, the refinement -- is compute-bound and shares the device well.
+static bool xy_tables_aside() {
+    static const bool on = [] {
+        const char* e = std::getenv("MI_NCC_XY_TABLES_ASIDE");
+        return e ? std::atoi(e) != 0 : true;
+    }();
+    return on;
+}
+static bool mip_gate() {
+    static const bool on = [] {
+        const char* e = std::getenv("MI_NCC_GATE");
+        return e ? std::atoi(e) != 0 : true;
+    }();
+    return on;
+}
+
 int ncc_lag_enqueue(int dev, hipStream_t s, int n, const float* const* a_ptrs, const float* const* b_ptrs, int dimk, int dimi, int dimj, int ni,
                     int nj, int delayk, int delayi, int delayj, int side, mi_ncc_params* params, LagJob** job_out, bool defer_chains) {
     *job_out = nullptr;
@@ -861,7 +996,7 @@ int ncc_lag_enqueue(int dev, hipStream_t s, int n, const float* const* a_ptrs, c
     size_t spec = 0, crs = 0;
     int wcap = 1;
     for (int m = 0; m < 3; ++m) {
-        const size_t NK = (size_t)lp[m].fft.N / 2 + 1, nlp = (2 * lp[m].Es + 1 + 3) / 4 * 4;
+        const size_t NK = (size_t)lp[m].fft.N / 2 + 1, nlp = (size_t)lp[m].nlp;
         spec = std::max(spec, 16 * (2 * (size_t)lp[m].n_short * NK + NK * nlp));
         crs = std::max(crs, 8 * (size_t)(2 * lp[m].Eu + 1) * (2 * lp[m].Ev + 1));
         wcap = std::max(wcap, (2 * pl.g[m].wu + 1) * (2 * pl.g[m].wv + 1));
@@ -902,6 +1037,10 @@ int ncc_lag_enqueue(int dev, hipStream_t s, int n, const float* const* a_ptrs, c
     MI_HIP(hipStreamWaitEvent(sm, ws.ev_start, 0));
     for (int m = 0; m < 3; ++m)
         if (m == 0 || ws.sl[m] != ws.sl[m - 1]) MI_HIP(hipStreamWaitEvent(ws.sl[m], ws.ev_start, 0));
+    if (mip_gate()) {  // (never recorded yet: no wait)
+        MI_HIP(hipStreamWaitEvent(sm, ws.ev_head, 0));
+        MI_HIP(hipStreamWaitEvent(sm, ws.ev_head_tab, 0));
+    }
     for (int c0 = 0; c0 < n; c0 += chunk) {
         const int nc = std::min(chunk, n - c0);
         if (c0 > 0) {  // the buffers of the previous chunk are free once its chains have run
@@ -946,12 +1085,22 @@ static int enqueue_chains(LagJob& job, int c0, int p0, int np, int pi, hipEvent_
         if (m == 0 || sl != ws.sl[m - 1]) MI_HIP(hipStreamWaitEvent(sl, gate, 0));
         const PlaneGeom& g = pl.g[m];
         // the tables (tile sums, means, banded summed-area tables) and the lag transform of a plane read the same MIPs and meet
-        // only in the refinement: for the xy plane, whose chain is the longest, they run on two streams
-        hipStream_t sxm = (m == 0 && ws.sx != sl) ? ws.sx : sl;
+        // only in the refinement.  For the xy plane, whose chain is the longest, the tables go to the stream of the xz plane (ahead
+        // of its chain): half a dozen small launches that fit beside the transform and the correlation.  (The device offers this
+        // process three hardware queues besides the default stream's: the MIP stream, the xy chain, everything else.)
+        const bool aside = m == 0 && xy_tables_aside() && ws.sl[1] != sl;
+        hipStream_t st = aside ? ws.sl[1] : sl;
+        hipStream_t sxm = (m == 0 && !aside && ws.sx != sl) ? ws.sx : sl;
+        if (st != sl) MI_HIP(hipStreamWaitEvent(st, gate, 0));
         if (sxm != sl) MI_HIP(hipStreamWaitEvent(sxm, gate, 0));
-        MI_TRY(prepare_plane_band(sl, base + g.mip1, base + g.mip2, g, lp[m], base + g.ps1, base + g.ps2, sat_p + job.sat_off[m], np, pstride,
+        MI_TRY(prepare_plane_band(st, base + g.mip1, base + g.mip2, g, lp[m], base + g.ps1, base + g.ps2, sat_p + job.sat_off[m], np, pstride,
                                   sstride));
-        MI_TRY(lag_cross(job.dev, sxm, lp[m], base + g.mip1, base + g.mip2, pstride, np, ws, m));
+        if (st != sl) {
+            MI_HIP(hipEventRecord(ws.ev_x, st));
+            if (mip_gate()) MI_HIP(hipEventRecord(ws.ev_head_tab, st));
+        }
+        MI_TRY(lag_cross(job.dev, sxm, lp[m], base + g.mip1, base + g.mip2, pstride, np, ws, m, m == 0 && sxm == sl && mip_gate() ? ws.ev_head : nullptr));
+        if (st != sl) MI_HIP(hipStreamWaitEvent(sl, ws.ev_x, 0));
         if (sxm != sl) {
             MI_HIP(hipEventRecord(ws.ev_x, sxm));
             MI_HIP(hipStreamWaitEvent(sl, ws.ev_x, 0));
