@@ -104,11 +104,11 @@ __global__ __launch_bounds__(256) void k_mips(const float* __restrict__ A, const
                                                size_t pstride, int dimk, int dimi_v, int dimj_v,
                                                size_t slice, int pitch, int ai0, int aj0, float* __restrict__ xy1, float* __restrict__ xz1,
                                                float* __restrict__ yz1, float* __restrict__ xy2, float* __restrict__ xz2,
-                                               float* __restrict__ yz2, float* __restrict__ yz_tmp, float* __restrict__ xz_tmp) {
+                                               float* __restrict__ yz2, float* __restrict__ yz_tmp, float* __restrict__ xz_tmp, int knock) {
+    // (knock: measurement aid, MI_NCC_MIPS_KNOCK -- 1: no xz maxima, 2: no yz maxima, 4: no xy store)
     // a work-group owns a 16-row x 64-column patch of the view; its four waves share the slices (wave w: k = w, w + 4, ...),
     // so a patch keeps four times as many loads in flight as one wave walking all slices
-    __shared__ float comb[3][MIP_ROWS][64];
-    extern __shared__ float xzp[];  // [MIP_ROWS][dimk] row maxima of this patch (xz_tmp != nullptr)
+    extern __shared__ float xzp[];  // [band][MIP_ROWS][dimk] row maxima of the work-group's patches (xz_tmp != nullptr)
     const bool second = blockIdx.z & 1;
     const size_t poff = (size_t)(blockIdx.z >> 1) * pstride;
     const float* vol = tab ? tab[blockIdx.z] : (second ? B : A);
@@ -125,89 +125,96 @@ __global__ __launch_bounds__(256) void k_mips(const float* __restrict__ A, const
     const int j = (int)blockIdx.x * 64 + lane - jshift;
     const bool live = j >= 0 && j < dimj_v;
     // A work-group walks MIP_NB consecutive row bands (stacks of up to 4 * MIP_KPW slices): the column maxima of the slices a wave
-    // owns stay in its registers across the bands and go to yz_tmp ONCE per band group -- a quarter of the partial maxima that
-    // k_mips_yz has to read back.  Deeper stacks write them per band (nb = 1 below).
+    // owns stay with it across the bands (in LDS, one column per lane and slice of the wave) and go to yz_tmp ONCE per band group
+    // -- a quarter of the partial maxima that k_mips_yz has to read back.  Deeper stacks write them per band (nb = 1 below).
+    // NOTHING is stored to memory before the last slice has been requested: loads and stores of a wave return in order, so a
+    // store in the middle of the stream -- the xy rows of a band, its xz maxima -- held up the loads requested behind it until
+    // its acknowledgement came back, and the other three waves at the next barrier (switching the xy store off saved 11 % of
+    // the pass although it is 3 % of its bytes: profiles/r03_mips_knock.txt).  The xy maxima of a band are merged across the
+    // waves with LDS atomics, the xz maxima of all bands wait in LDS: the band loop has no barrier left.
     const bool keep = dimk <= 4 * MIP_KPW;
     const int nb = keep ? MIP_NB : 1;
-    // (in LDS, one column per lane and slice of the wave.  With the band loop around it the kernel needs 128 VGPRs -- the 16 scalar
-    // row bases of two slices in flight now overflow the scalar registers and spill into vector ones -- i.e. four waves per SIMD
-    // instead of six; forcing five or six spills to scratch, lane offsets instead of scalar bases cost 185 VGPRs.  Measured it
-    // still wins: MIP phase of 112 C5 pairs 4.6 -> 4.15 ms, 12.0-12.4 -> 12.9-13.0 k pairs/s)
+    __shared__ float xyb[MIP_NB][MIP_ROWS][64];
     __shared__ float cacc[4][MIP_KPW][64];
     float* colacc = &cacc[wave][0][lane];
     if (keep) {
 #pragma unroll
         for (int q = 0; q < MIP_KPW; ++q) colacc[q * 64] = 0.0f;
     }
-#pragma unroll 1
-    for (int b = 0; b < nb; ++b) {
-    const int i0 = __builtin_amdgcn_readfirstlane(((int)blockIdx.y * nb + b) * MIP_ROWS);  // (scalar: so are the row addresses)
-    if (i0 >= dimi_v) break;
-    const int rows = min(MIP_ROWS, dimi_v - i0);
-    float best[MIP_ROWS];
-#pragma unroll
-    for (int r = 0; r < MIP_ROWS; ++r) best[r] = 0.0f;
-    // the wave's next slice is requested before the current one is reduced (32 instead of 16 loads per lane in flight: at 92
-    // registers only five waves fit a SIMD)
+    for (int e = threadIdx.x; e < MIP_NB * MIP_ROWS * 64; e += 256) (&xyb[0][0][0])[e] = 0.0f;
+    const int ib0 = __builtin_amdgcn_readfirstlane((int)blockIdx.y * nb * MIP_ROWS);
+    const int nbv = min(nb, (dimi_v - ib0 + MIP_ROWS - 1) / MIP_ROWS);  // bands of this work-group inside the view (>= 1)
+    // the wave's slices of all its bands form one sequence: the next slice -- of this band or the first of the next -- is requested
+    // before the current one is reduced
     float v[MIP_ROWS], vn[MIP_ROWS];
-    auto load_slice = [&](int k, float (&dst)[MIP_ROWS]) {
+    auto load_slice = [&](int bb, int k, float (&dst)[MIP_ROWS]) {
+        const int i0 = ib0 + bb * MIP_ROWS, rows = min(MIP_ROWS, dimi_v - i0);
         const float* p = vol + (size_t)k * slice + (size_t)i0 * pitch;  // wave-uniform
 #pragma unroll
         for (int r = 0; r < MIP_ROWS; ++r) dst[r] = (live && r < rows) ? (p + (size_t)r * pitch)[j] : 0.0f;
     };
-    if (wave < dimk) load_slice(wave, v);
-    if (b > 0) __syncthreads();  // (comb / xzp of the previous band have been read)
-    // one slice of the wave: returns its column maximum
-    auto slice_step = [&](int k) {
-        if (k + 4 < dimk) load_slice(k + 4, vn);
-        float colmax = 0.0f;
+    if (wave < dimk) load_slice(0, wave, v);
+    __syncthreads();  // (xyb is zero)
+#pragma unroll 1
+    for (int b = 0; b < nbv; ++b) {
+        const int i0 = ib0 + b * MIP_ROWS;  // (scalar: so are the row addresses)
+        const int rows = min(MIP_ROWS, dimi_v - i0);
+        float best[MIP_ROWS];
 #pragma unroll
-        for (int r = 0; r < MIP_ROWS; ++r) {
-            best[r] = fmaxf(best[r], v[r]);
-            colmax = fmaxf(colmax, v[r]);
-        }
-        // xz: the 16 row maxima over the 64 columns of the patch, per patch through LDS into xz_tmp[tile][column block][i][k]
-        // (k_mips_xz takes the maximum over the column blocks); as atomics on the MIP they were 655 thousand single-lane
-        // atomics per C5 pair, as 16 separate wave reductions 96 DPP steps per slice
-        {
-            const float rowmax = rows_max16(v, lane);
-            const int r = row_of_lane(lane);
-            if (lane < 16) {
-                if (xz_tmp) xzp[r * dimk + k] = rowmax;
-                else if (r < rows) atomic_max_nonneg(&xz[(size_t)(i0 + r) * dimk + k], rowmax);
+        for (int r = 0; r < MIP_ROWS; ++r) best[r] = 0.0f;
+        // one slice of the wave: returns its column maximum
+        auto slice_step = [&](int k) {
+            const bool wrap = k + 4 >= dimk;  // (wave-uniform)
+            const int kn = __builtin_amdgcn_readfirstlane(wrap ? wave : k + 4), bn = __builtin_amdgcn_readfirstlane(wrap ? b + 1 : b);
+            if (bn < nbv) load_slice(bn, kn, vn);
+            float colmax = 0.0f;
+#pragma unroll
+            for (int r = 0; r < MIP_ROWS; ++r) {
+                best[r] = fmaxf(best[r], v[r]);
+                colmax = fmaxf(colmax, v[r]);
+            }
+            // xz: the 16 row maxima over the 64 columns of the patch, per patch through LDS into xz_tmp[tile][column block][i][k]
+            // (k_mips_xz takes the maximum over the column blocks); as atomics on the MIP they were 655 thousand single-lane
+            // atomics per C5 pair, as 16 separate wave reductions 96 DPP steps per slice
+            if (!(knock & 1)) {
+                const float rowmax = rows_max16(v, lane);
+                const int r = row_of_lane(lane);
+                if (lane < 16) {
+                    if (xz_tmp) xzp[(b * MIP_ROWS + r) * dimk + k] = rowmax;
+                    else if (r < rows) atomic_max_nonneg(&xz[(size_t)(i0 + r) * dimk + k], rowmax);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < MIP_ROWS; ++r) v[r] = vn[r];
+            return (knock & 2) ? 0.0f : colmax;
+        };
+        // yz: the column maxima of this band (group) go to yz_tmp[tile][group][k][j] (unit-stride stores); k_mips_yz takes the
+        // maximum over the groups -- 2.6 million atomics per pair on the yz MIPs cost more than the whole streaming pass
+        if (keep) {
+#pragma unroll 1
+            for (int k = wave, q = 0; k < dimk; k += 4, ++q) colacc[q * 64] = fmaxf(colacc[q * 64], slice_step(k));
+        } else {
+#pragma unroll 1
+            for (int k = wave; k < dimk; k += 4) {
+                const float colmax = slice_step(k);
+                if (live) yz_tmp[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * dimk + k) * dimj_v + j] = colmax;
             }
         }
+        // xy: maximum over the four waves' slices
 #pragma unroll
-        for (int r = 0; r < MIP_ROWS; ++r) v[r] = vn[r];
-        return colmax;
-    };
-    // yz: the column maxima of this band (group) go to yz_tmp[tile][group][k][j] (unit-stride stores); k_mips_yz takes the maximum
-    // over the groups -- 2.6 million atomics per pair on the yz MIPs cost more than the whole streaming pass
-    if (keep) {
-#pragma unroll 1
-        for (int k = wave, q = 0; k < dimk; k += 4, ++q) colacc[q * 64] = fmaxf(colacc[q * 64], slice_step(k));
-    } else {
-#pragma unroll 1
-        for (int k = wave; k < dimk; k += 4) {
-            const float colmax = slice_step(k);
-            if (live) yz_tmp[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * dimk + k) * dimj_v + j] = colmax;
-        }
-    }
-    // xy: maximum over the four waves' slices
-    if (wave > 0) {
-#pragma unroll
-        for (int r = 0; r < MIP_ROWS; ++r) comb[wave - 1][r][lane] = best[r];
+        for (int r = 0; r < MIP_ROWS; ++r) atomic_max_nonneg(&xyb[b][r][lane], best[r]);
     }
     __syncthreads();
-    if (wave == 0 && live) {
+    if (wave < nbv && live && !(knock & 4)) {  // wave b stores band b
+        const int i0 = ib0 + wave * MIP_ROWS, rows = min(MIP_ROWS, dimi_v - i0);
 #pragma unroll
         for (int r = 0; r < MIP_ROWS; ++r)
-            if (r < rows) xy[(size_t)(i0 + r) * dimj_v + j] = fmaxf(fmaxf(best[r], comb[0][r][lane]), fmaxf(comb[1][r][lane], comb[2][r][lane]));
+            if (r < rows) xy[(size_t)(i0 + r) * dimj_v + j] = xyb[wave][r][lane];
     }
-    if (xz_tmp) {  // rows * dimk contiguous floats
-        float* dst = xz_tmp + (((size_t)blockIdx.z * gridDim.x + blockIdx.x) * dimi_v + i0) * dimk;
-        for (int e = threadIdx.x; e < rows * dimk; e += 256) dst[e] = xzp[e];
-    }
+    if (xz_tmp) {  // the rows of all bands * dimk: contiguous floats
+        float* dst = xz_tmp + (((size_t)blockIdx.z * gridDim.x + blockIdx.x) * dimi_v + ib0) * dimk;
+        const int total = min(nbv * MIP_ROWS, dimi_v - ib0) * dimk;
+        for (int e = threadIdx.x; e < total; e += 256) dst[e] = xzp[e];
     }
     if (keep && live) {
 #pragma unroll
@@ -258,15 +265,19 @@ int launch_mips(hipStream_t s, const float* A, const float* B, const float* cons
     const int bands = mips_groups(dimk, dimi_v), cblocks = (dimj_v + (aj0 & 63) + 63) / 64;  // (see k_mips: band groups, aligned column blocks)
     float* yz_tmp = tmp;
     float* xz_tmp = tmp + 2 * (size_t)np * bands * dimk * dimj_v;
-    const size_t lds = sizeof(float) * MIP_ROWS * (size_t)dimk;
+    const size_t lds = sizeof(float) * MIP_ROWS * (size_t)dimk * mips_band_group(dimk);  // (k_mips: xzp)
     const bool via_lds = lds <= 32 * 1024;
     if (!via_lds) {  // very deep stacks: the xz MIPs are merged with atomicMax and must start at 0 (libcrossmips.cpp:319-337)
         MI_HIP(hipMemset2DAsync(xz1, sizeof(float) * (pstride ? pstride : 1), 0, sizeof(float) * (size_t)dimi_v * dimk, np, s));
         MI_HIP(hipMemset2DAsync(xz2, sizeof(float) * (pstride ? pstride : 1), 0, sizeof(float) * (size_t)dimi_v * dimk, np, s));
     }
     dim3 grid(cblocks, bands, 2 * np);
+    static const int knock = [] {
+        const char* e = std::getenv("MI_NCC_MIPS_KNOCK");
+        return e ? std::atoi(e) : 0;
+    }();
     hipLaunchKernelGGL(k_mips, grid, dim3(256), via_lds ? lds : 0, s, A, B, tab, pstride, dimk, dimi_v, dimj_v, slice, pitch, ai0, aj0, xy1, xz1, yz1,
-                       xy2, xz2, yz2, yz_tmp, via_lds ? xz_tmp : (float*)nullptr);
+                       xy2, xz2, yz2, yz_tmp, via_lds ? xz_tmp : (float*)nullptr, knock);
     MI_TRY(launch_check("k_mips"));
     hipLaunchKernelGGL(k_mips_yz, dim3((dimk * dimj_v + 255) / 256, 2 * np), dim3(256), 0, s, yz_tmp, pstride, bands, dimk, dimj_v, yz1, yz2);
     MI_TRY(launch_check("k_mips_yz"));

@@ -1247,7 +1247,7 @@ int ncc_time_mips(int dev, hipStream_t s, int n, const float* const* a_ptrs, con
     MI_HIP(hipStreamSynchronize(s));
     float* o = out.as<float>();
     const int bands = mips_groups(dimk, dimi_v), cblocks = (dimj_v + 63) / 64;
-    const size_t lds = sizeof(float) * MIP_ROWS * (size_t)dimk;
+    const size_t lds = sizeof(float) * MIP_ROWS * (size_t)dimk * mips_band_group(dimk);
     MI_REQUIRE(lds <= 32 * 1024, "mi_ncc_time_mips: stack too deep for the timed variant");
     float* xz_tmp = tmp.as<float>() + 2 * (size_t)n * bands * dimk * dimj_v;
     struct Events {  // (destroyed on every path out of this function)
@@ -1257,11 +1257,13 @@ int ncc_time_mips(int dev, hipStream_t s, int n, const float* const* a_ptrs, con
     MI_HIP(hipEventCreate(&evs.a));
     MI_HIP(hipEventCreate(&evs.b));
     hipEvent_t e0 = evs.a, e1 = evs.b;
+    const char* ke = std::getenv("MI_NCC_MIPS_KNOCK");  // (measurement aid, see k_mips)
+    const int knock = ke ? std::atoi(ke) : 0;
     for (int r = -1; r < reps; ++r) {  // r = -1: warm-up
         if (r == 0) MI_HIP(hipEventRecord(e0, s));
         hipLaunchKernelGGL(k_mips, dim3(cblocks, bands, 2 * n), dim3(256), lds, s, (const float*)nullptr, (const float*)nullptr, tab.as<const float*>(),
                            pstride, dimk, dimi_v, dimj_v, (size_t)dimi * dimj, dimj, side == MI_NORTH_SOUTH ? ni : 0, side == MI_WEST_EAST ? nj : 0, o,
-                           o + xy, o + xy + xz, o + xy + xz + yz, o + 2 * xy + xz + yz, o + 2 * xy + 2 * xz + yz, tmp.as<float>(), xz_tmp);
+                           o + xy, o + xy + xz, o + xy + xz + yz, o + 2 * xy + xz + yz, o + 2 * xy + 2 * xz + yz, tmp.as<float>(), xz_tmp, knock);
     }
     MI_HIP(hipEventRecord(e1, s));
     MI_HIP(hipEventSynchronize(e1));
