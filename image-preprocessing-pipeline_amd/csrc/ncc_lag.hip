@@ -122,19 +122,23 @@ __device__ __forceinline__ void fft_dif(cplx* __restrict__ x, const FftPlan& pl,
 // forward lag transform of short-axis line j (blockIdx.x) of pair blockIdx.y: element i of the line = m[i * ls + j * ss]
 template <int TH, int BF>
 __global__ __launch_bounds__(TH) void k_lag_fwd(const float* __restrict__ m1, const float* __restrict__ m2, size_t pstride, int n_long, int n_short,
-                                                 int ls, int ss, FftPlan pl, const cplx* __restrict__ tw, const int* __restrict__ slot_pos,
+                                                 int ls, int ss, int nkp, FftPlan pl, const cplx* __restrict__ tw, const int* __restrict__ slot_pos,
                                                  const int* __restrict__ slot_neg, cplx* __restrict__ SF, cplx* __restrict__ ST) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lag_lds[];
     cplx* x = reinterpret_cast<cplx*>(lag_lds);
-    const int N = pl.N, NK = N / 2 + 1, j = blockIdx.x;
+    // gridDim.x = 8 * ceil(n_short / 8): work-groups b, b + 8, ... run on one XCD and take NEIGHBOURING lines j -- with the long
+    // axis strided in memory (west-east pairs) 32 neighbouring lines share every 128-byte line they read, and spread over the
+    // eight L2s each of them fetched it again (0.81 GB fetched for 0.28 GB of MIPs)
+    const int N = pl.N, NK = N / 2 + 1, j = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+    if (j >= n_short) return;
     const float* a = m1 + (size_t)blockIdx.y * pstride + (size_t)j * ss;
     const float* b = m2 + (size_t)blockIdx.y * pstride + (size_t)j * ss;
     for (int i = threadIdx.x; i < N; i += blockDim.x)
         x[i] = i < n_long ? make_double2((double)a[(size_t)i * ls], (double)b[(size_t)i * ls]) : make_double2(0.0, 0.0);
     __syncthreads();
     fft_dif<BF>(x, pl, tw);
-    cplx* of = SF + ((size_t)blockIdx.y * n_short + j) * NK;
-    cplx* ot = ST + ((size_t)blockIdx.y * n_short + j) * NK;
+    cplx* of = SF + ((size_t)blockIdx.y * n_short + j) * nkp;  // (rows of nkp >= NK spectra: whole 128-byte lines per eight)
+    cplx* ot = ST + ((size_t)blockIdx.y * n_short + j) * nkp;
     // The N/2 + 1 frequencies 0 .. N/2 of a real signal's spectrum are kept in POSITION order ("slots": slot_pos ascending; slot_neg =
     // position of the mirror frequency N - k): the untangling pass then reads LDS in nearly contiguous order -- in frequency
     // order consecutive lanes sit N/4 elements apart, a 16-way bank conflict -- and the per-frequency correlation does not care
@@ -155,7 +159,7 @@ __global__ __launch_bounds__(TH) void k_lag_fwd(const float* __restrict__ m1, co
 // nothing (600 -> 4xx us for that plane: profiles/r03_lag_shapes.txt).
 template <int LB, int PF>
 __global__ __launch_bounds__(256) void k_lag_mac(const cplx* __restrict__ SF, const cplx* __restrict__ ST, int n_short, int NK, int Es, int KT, int JP,
-                                                 int FW, int TW, int nlp, int tiles_per_pair, int ntiles, cplx* __restrict__ CH) {
+                                                 int FW, int TW, int nlp, int nkp, int tiles_per_pair, int ntiles, cplx* __restrict__ CH) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lag_lds[];
     cplx* Fs = reinterpret_cast<cplx*>(lag_lds);  // KT rows of FW: PAD zeros | n_short samples | zeros
     cplx* Ts = Fs + (size_t)KT * FW;              // KT rows of TW
@@ -171,25 +175,39 @@ __global__ __launch_bounds__(256) void k_lag_mac(const cplx* __restrict__ SF, co
     const cplx* tr = Ts + (size_t)kl * TW;
     const int nelem = n_short * KT;  // elements of a tile, kl fastest: 16 * KT contiguous bytes per line j
 
-    int tile = blockIdx.x;
+    // Slot b of the persistent sequence (blockIdx.x, + gridDim.x, ...; both multiples of 16) -> tile: the two tiles that share the
+    // 128-byte lines of the spectra (k0 = 8 m and 8 m + 4; tiles_per_pair is even) go to work-groups b and b + 8, which run on ONE
+    // XCD at about the same time -- taken in order they sat on different XCDs and every L2 fetched whole lines for half of
+    // each (1.75 GB fetched for 0.63 GB of spectra).  Tiles past the end and the padding tile of a pair are empty (nk <= 0).
+    auto decode = [&](int b, int& pair, int& k0, int& nk) {
+        const int tile = (b & ~15) | ((b & 7) << 1) | ((b >> 3) & 1);
+        pair = tile / tiles_per_pair;
+        k0 = (tile - pair * tiles_per_pair) * KT;
+        nk = tile < ntiles ? min(KT, NK - k0) : 0;
+    };
+    const int nslots = (ntiles + 15) & ~15;
+    int slot = blockIdx.x;
     __syncthreads();
-    if (tile < ntiles) {  // the first tile goes to LDS directly
-        const int pair = tile / tiles_per_pair, k0 = (tile - pair * tiles_per_pair) * KT, nk = min(KT, NK - k0);
+    if (slot < nslots) {  // the first tile goes to LDS directly
+        int pair, k0, nk;
+        decode(slot, pair, k0, nk);
         const size_t pbase = (size_t)pair * n_short;
         for (int e = threadIdx.x; e < nelem; e += 256) {
             const int x = e / KT, l = e - x * KT;
             if (l < nk) {
-                Fs[(size_t)l * FW + PAD + x] = SF[(pbase + x) * NK + k0 + l];
-                Ts[(size_t)l * TW + x] = ST[(pbase + x) * NK + k0 + l];
+                Fs[(size_t)l * FW + PAD + x] = SF[(pbase + x) * nkp + k0 + l];
+                Ts[(size_t)l * TW + x] = ST[(pbase + x) * nkp + k0 + l];
             }
         }
     }
-    while (tile < ntiles) {
-        const int pair = tile / tiles_per_pair, k0 = (tile - pair * tiles_per_pair) * KT, nk = min(KT, NK - k0);
+    while (slot < nslots) {
+        int pair, k0, nk;
+        decode(slot, pair, k0, nk);
         __syncthreads();  // the tile is in LDS
-        const int next = tile + gridDim.x;
-        const bool has_next = next < ntiles;
-        const int npair = next / tiles_per_pair, nk0 = (next - npair * tiles_per_pair) * KT, nnk = min(KT, NK - nk0);
+        const int next = slot + gridDim.x;
+        const bool has_next = next < nslots;
+        int npair = 0, nk0 = 0, nnk = 0;
+        if (has_next) decode(next, npair, nk0, nnk);
         cplx pf[PF], pt[PF];
         if (has_next) {
             const size_t pbase = (size_t)npair * n_short;
@@ -198,8 +216,8 @@ __global__ __launch_bounds__(256) void k_lag_mac(const cplx* __restrict__ SF, co
                 const int e = threadIdx.x + i * 256;
                 const int x = e / KT, l = e - x * KT;
                 const bool ok = e < nelem && l < nnk;
-                pf[i] = ok ? SF[(pbase + x) * NK + nk0 + l] : make_double2(0.0, 0.0);
-                pt[i] = ok ? ST[(pbase + x) * NK + nk0 + l] : make_double2(0.0, 0.0);
+                pf[i] = ok ? SF[(pbase + x) * nkp + nk0 + l] : make_double2(0.0, 0.0);
+                pt[i] = ok ? ST[(pbase + x) * nkp + nk0 + l] : make_double2(0.0, 0.0);
             }
         }
 
@@ -260,7 +278,7 @@ __global__ __launch_bounds__(256) void k_lag_mac(const cplx* __restrict__ SF, co
                 }
             }
         }
-        tile = next;
+        slot = next;
     }
 }
 
@@ -771,7 +789,7 @@ void give_lag_ws(std::unique_ptr<LagWorkspace> r) {
 int grow(DevBuf& b, size_t bytes) { return b.bytes >= bytes ? MI_OK : b.alloc(bytes); }
 
 // The work-group shapes of the two transform kernels: threads and butterflies per thread and step.
-using FwdFn = void (*)(const float*, const float*, size_t, int, int, int, int, FftPlan, const cplx*, const int*, const int*, cplx*, cplx*);
+using FwdFn = void (*)(const float*, const float*, size_t, int, int, int, int, int, FftPlan, const cplx*, const int*, const int*, cplx*, cplx*);
 using InvFn = void (*)(const cplx*, int, int, FftPlan, int, int, int, int, int, const cplx*, const int*, double*);
 struct FftShape {
     int threads, bf;
@@ -806,34 +824,34 @@ const FftShape& fft_shape(const LagPlane& lp) {
 // cross terms of `np` pairs of one plane through the lag transform (MIPs at m1 / m2 + q * pstride) into ws.cross
 int lag_cross(int dev, hipStream_t s, const LagPlane& lp, const float* m1, const float* m2, size_t pstride, int np, LagWorkspace& ws, int m = 0,
               hipEvent_t after_fwd = nullptr) {
-    const int N = lp.fft.N, NK = N / 2 + 1, nlag = 2 * lp.Es + 1, nlp = lp.nlp;
+    const int N = lp.fft.N, NK = N / 2 + 1, nlag = 2 * lp.Es + 1, nlp = lp.nlp, NKP = (NK + 7) & ~7;
     FftTables ft;
     MI_TRY(fft_tables(dev, lp.fft, s, &ft));
     const cplx* tw = ft.tw;
-    MI_TRY(grow(ws.SF[m], sizeof(double) * 2 * (size_t)np * lp.n_short * NK));
-    MI_TRY(grow(ws.ST[m], sizeof(double) * 2 * (size_t)np * lp.n_short * NK));
+    MI_TRY(grow(ws.SF[m], sizeof(double) * 2 * (size_t)np * lp.n_short * NKP));
+    MI_TRY(grow(ws.ST[m], sizeof(double) * 2 * (size_t)np * lp.n_short * NKP));
     MI_TRY(grow(ws.CH[m], sizeof(double) * 2 * (size_t)np * NK * nlp));
     MI_TRY(grow(ws.cross[m], sizeof(double) * (size_t)np * (2 * lp.Eu + 1) * (2 * lp.Ev + 1)));
     const FftShape& sh = fft_shape(lp);
     if (lp.lds_fft > 64 * 1024) MI_HIP(hipFuncSetAttribute(sh.fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp.lds_fft));
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(sh.fwd_fn), dim3(lp.n_short, np), dim3(sh.threads), lp.lds_fft, s, m1, m2, pstride, lp.n_long, lp.n_short, lp.ls,
-                       lp.ss, lp.fft, tw, ft.slot_pos, ft.slot_neg, ws.SF[m].as<cplx>(), ws.ST[m].as<cplx>());
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(sh.fwd_fn), dim3(8 * ((lp.n_short + 7) / 8), np), dim3(sh.threads), lp.lds_fft, s, m1, m2, pstride, lp.n_long,
+                       lp.n_short, lp.ls, lp.ss, NKP, lp.fft, tw, ft.slot_pos, ft.slot_neg, ws.SF[m].as<cplx>(), ws.ST[m].as<cplx>());
     MI_TRY(launch_check("k_lag_fwd"));
     if (after_fwd) MI_HIP(hipEventRecord(after_fwd, s));
     {
-        using MacFn = void (*)(const cplx*, const cplx*, int, int, int, int, int, int, int, int, int, int, cplx*);
+        using MacFn = void (*)(const cplx*, const cplx*, int, int, int, int, int, int, int, int, int, int, int, cplx*);
         static const MacFn macs[] = {k_lag_mac<4, 1>, k_lag_mac<4, 2>, k_lag_mac<4, 3>, k_lag_mac<4, 4>, k_lag_mac<4, 5>, k_lag_mac<4, 6>};
         const int pfn = (lp.n_short * lp.KT + 255) / 256;  // (plan_lag_plane keeps it within the table)
         MacFn mac = macs[pfn - 1];
-        const int tiles_per_pair = (NK + lp.KT - 1) / lp.KT, ntiles = tiles_per_pair * np;
+        const int tiles_per_pair = ((NK + lp.KT - 1) / lp.KT + 1) & ~1, ntiles = tiles_per_pair * np;  // (even: see k_lag_mac)
         int cus = 256, per_cu = 1;
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         if (lp.lds_mac > 64 * 1024)
             MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mac), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp.lds_mac));
         per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / std::max<size_t>(lp.lds_mac, 1)));
-        const int grid = std::min(ntiles, cus * per_cu);
+        const int grid = std::max(16, std::min((ntiles + 15) & ~15, (cus * per_cu) & ~15));
         hipLaunchKernelGGL(mac, dim3(grid), dim3(256), lp.lds_mac, s, ws.SF[m].as<cplx>(), ws.ST[m].as<cplx>(), lp.n_short, NK, lp.Es, lp.KT, lp.JP,
-                           lp.FW, lp.TW, nlp, tiles_per_pair, ntiles, ws.CH[m].as<cplx>());
+                           lp.FW, lp.TW, nlp, NKP, tiles_per_pair, ntiles, ws.CH[m].as<cplx>());
     }
     MI_TRY(launch_check("k_lag_mac"));
     if (lp.lds_fft > 64 * 1024) MI_HIP(hipFuncSetAttribute(sh.inv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp.lds_fft));
@@ -997,7 +1015,7 @@ int ncc_lag_enqueue(int dev, hipStream_t s, int n, const float* const* a_ptrs, c
     int wcap = 1;
     for (int m = 0; m < 3; ++m) {
         const size_t NK = (size_t)lp[m].fft.N / 2 + 1, nlp = (size_t)lp[m].nlp;
-        spec = std::max(spec, 16 * (2 * (size_t)lp[m].n_short * NK + NK * nlp));
+        spec = std::max(spec, 16 * (2 * (size_t)lp[m].n_short * ((NK + 7) & ~(size_t)7) + NK * nlp));
         crs = std::max(crs, 8 * (size_t)(2 * lp[m].Eu + 1) * (2 * lp[m].Ev + 1));
         wcap = std::max(wcap, (2 * pl.g[m].wu + 1) * (2 * pl.g[m].wv + 1));
     }
