@@ -261,7 +261,8 @@ inline size_t mips_tmp_floats(int dimk, int dimi_v, int dimj_v) {
     return 2 * (bands * dimk * dimj_v + cblocks * (size_t)dimi_v * dimk);
 }
 int launch_mips(hipStream_t s, const float* A, const float* B, const float* const* tab, int np, size_t pstride, int dimk, int dimi_v, int dimj_v,
-                size_t slice, int pitch, int ai0, int aj0, float* xy1, float* xz1, float* yz1, float* xy2, float* xz2, float* yz2, float* tmp) {
+                size_t slice, int pitch, int ai0, int aj0, float* xy1, float* xz1, float* yz1, float* xy2, float* xz2, float* yz2, float* tmp,
+                hipEvent_t xy_done = nullptr) {  // recorded when the xy MIPs are final (k_mips), before the reductions of the other two
     const int bands = mips_groups(dimk, dimi_v), cblocks = (dimj_v + (aj0 & 63) + 63) / 64;  // (see k_mips: band groups, aligned column blocks)
     float* yz_tmp = tmp;
     float* xz_tmp = tmp + 2 * (size_t)np * bands * dimk * dimj_v;
@@ -279,6 +280,7 @@ int launch_mips(hipStream_t s, const float* A, const float* B, const float* cons
     hipLaunchKernelGGL(k_mips, grid, dim3(256), via_lds ? lds : 0, s, A, B, tab, pstride, dimk, dimi_v, dimj_v, slice, pitch, ai0, aj0, xy1, xz1, yz1,
                        xy2, xz2, yz2, yz_tmp, via_lds ? xz_tmp : (float*)nullptr, knock);
     MI_TRY(launch_check("k_mips"));
+    if (xy_done) MI_HIP(hipEventRecord(xy_done, s));
     hipLaunchKernelGGL(k_mips_yz, dim3((dimk * dimj_v + 255) / 256, 2 * np), dim3(256), 0, s, yz_tmp, pstride, bands, dimk, dimj_v, yz1, yz2);
     MI_TRY(launch_check("k_mips_yz"));
     if (via_lds) {

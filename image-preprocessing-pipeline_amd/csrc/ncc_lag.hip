@@ -712,7 +712,7 @@ struct LagWorkspace {
     hipEvent_t ev_start = nullptr, ev_lag = nullptr, ev_done = nullptr, ev_plane[2] = {nullptr, nullptr}, ev_x = nullptr;
     hipEvent_t ev_head_tab = nullptr;
     hipEvent_t ev_head = nullptr;  // per DEVICE like the streams (not owned): "the memory-bound head of the latest xy chain has run"
-    std::vector<hipEvent_t> ev_mip;
+    std::vector<hipEvent_t> ev_mip, ev_mip_xy;  // per piece: all six MIPs of its pairs final / the xy MIPs final
     ~LagWorkspace() {
         if (ev_start) (void)hipEventDestroy(ev_start);
         if (ev_lag) (void)hipEventDestroy(ev_lag);
@@ -721,6 +721,7 @@ struct LagWorkspace {
         for (hipEvent_t e : ev_plane)
             if (e) (void)hipEventDestroy(e);
         for (hipEvent_t e : ev_mip) (void)hipEventDestroy(e);
+        for (hipEvent_t e : ev_mip_xy) (void)hipEventDestroy(e);
     }
     int streams(size_t pieces) {
         {
@@ -758,6 +759,9 @@ struct LagWorkspace {
             hipEvent_t e = nullptr;
             MI_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             ev_mip.push_back(e);
+            hipEvent_t e2 = nullptr;
+            MI_HIP(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
+            ev_mip_xy.push_back(e2);
         }
         return MI_OK;
     }
@@ -963,7 +967,7 @@ struct LagJob {
 // (MI_NCC_PIECES > 1 cuts a group into pieces that are pipelined the same way; measured, it loses: the chain is a dozen
 // latency-bound launches whose cost hardly depends on the number of pairs, so pieces multiply it -- 9.3 / 10.2 / 12.3 ms per 112
 // pairs for 1 / 2 / 4 pieces.)
-static int enqueue_chains(LagJob& job, int c0, int p0, int np, int pi, hipEvent_t gate);
+static int enqueue_chains(LagJob& job, int c0, int p0, int np, int pi, hipEvent_t gate, hipEvent_t gate_xy = nullptr);
 static int close_job(LagJob& job);
 
 // MI_NCC_GATE (default 1): a group's MIP pass starts only when the previous group's xy chain is past its tables and its forward lag
@@ -1074,10 +1078,10 @@ int ncc_lag_enqueue(int dev, hipStream_t s, int n, const float* const* a_ptrs, c
             MI_HIP(hipMemcpyAsync(dtab, htab + 2 * (size_t)(c0 + p0), sizeof(void*) * 2 * np, hipMemcpyHostToDevice, sm));
             MI_TRY(launch_mips(sm, nullptr, nullptr, dtab, np, pstride, pl.dimk, pl.dimi_v, pl.dimj_v, (size_t)dimi * dimj, dimj, pl.ai0, pl.aj0,
                                base + pl.g[0].mip1, base + pl.g[1].mip1, base + pl.g[2].mip1, base + pl.g[0].mip2, base + pl.g[1].mip2,
-                               base + pl.g[2].mip2, ws.mip_tmp.as<float>() + (size_t)p0 * tmp_floats));
+                               base + pl.g[2].mip2, ws.mip_tmp.as<float>() + (size_t)p0 * tmp_floats, ws.ev_mip_xy[pi]));
             MI_HIP(hipEventRecord(ws.ev_mip[pi], sm));
             if (defer) continue;
-            MI_TRY(enqueue_chains(*job, c0, p0, np, pi, ws.ev_mip[pi]));
+            MI_TRY(enqueue_chains(*job, c0, p0, np, pi, ws.ev_mip[pi], ws.ev_mip_xy[pi]));
         }
     }
     job->chains_pending = defer;
@@ -1087,8 +1091,10 @@ int ncc_lag_enqueue(int dev, hipStream_t s, int n, const float* const* a_ptrs, c
 }
 
 // the table / lag-transform / refinement chains of the pairs [p0, p0 + np) of a chunk, one plane per chain stream, behind `gate`
-static int enqueue_chains(LagJob& job, int c0, int p0, int np, int pi, hipEvent_t gate) {
+// (gate_xy: an earlier event that the xy plane's chain may start behind -- its MIPs come straight out of k_mips)
+static int enqueue_chains(LagJob& job, int c0, int p0, int np, int pi, hipEvent_t gate, hipEvent_t gate_xy) {
     (void)pi;
+    if (!gate_xy) gate_xy = gate;
     LagWorkspace& ws = *job.ws;
     const PairPlan& pl = job.pl;
     const LagPlane* lp = job.lp;
@@ -1100,7 +1106,8 @@ static int enqueue_chains(LagJob& job, int c0, int p0, int np, int pi, hipEvent_
     // dependent launches, so they run side by side on their own streams
     for (int m = 0; m < 3; ++m) {
         hipStream_t sl = ws.sl[m];
-        if (m == 0 || sl != ws.sl[m - 1]) MI_HIP(hipStreamWaitEvent(sl, gate, 0));
+        hipEvent_t gm = m == 0 ? gate_xy : gate;
+        if (m == 0 || sl != ws.sl[m - 1]) MI_HIP(hipStreamWaitEvent(sl, gm, 0));
         const PlaneGeom& g = pl.g[m];
         // the tables (tile sums, means, banded summed-area tables) and the lag transform of a plane read the same MIPs and meet
         // only in the refinement.  For the xy plane, whose chain is the longest, the tables go to the stream of the xz plane (ahead
@@ -1109,8 +1116,8 @@ static int enqueue_chains(LagJob& job, int c0, int p0, int np, int pi, hipEvent_
         const bool aside = m == 0 && xy_tables_aside() && ws.sl[1] != sl;
         hipStream_t st = aside ? ws.sl[1] : sl;
         hipStream_t sxm = (m == 0 && !aside && ws.sx != sl) ? ws.sx : sl;
-        if (st != sl) MI_HIP(hipStreamWaitEvent(st, gate, 0));
-        if (sxm != sl) MI_HIP(hipStreamWaitEvent(sxm, gate, 0));
+        if (st != sl) MI_HIP(hipStreamWaitEvent(st, gm, 0));
+        if (sxm != sl) MI_HIP(hipStreamWaitEvent(sxm, gm, 0));
         MI_TRY(prepare_plane_band(st, base + g.mip1, base + g.mip2, g, lp[m], base + g.ps1, base + g.ps2, sat_p + job.sat_off[m], np, pstride,
                                   sstride));
         if (st != sl) {
