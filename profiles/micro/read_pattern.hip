@@ -6,9 +6,9 @@
 #include <cstdio>
 #include <cstdlib>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
-constexpr int DK = 32, DI = 2048, DJ = 2048, OV = 307, ROWS = 16, NB = 4;
+constexpr int DK = 32, DI = 2048, DJ = 2048, OV = 307, ROWS = 16;
 
-template <int VEC, int DEPTH, int LDSKB>
+template <int VEC, int DEPTH, int LDSKB, int NB>
 __global__ __launch_bounds__(256) void k_read(const float* __restrict__ vol, int i_lo, int n_i, int j_lo, int n_j, float* __restrict__ out) {
     __shared__ float pad[LDSKB * 256 + 1];  // (occupancy: LDSKB = 32 -> four work-groups per CU like k_mips)
     if (LDSKB > 0) pad[threadIdx.x] = 0.0f;
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void k_read(const float* __restrict__ vol, int
     if (acc == 12345.0f) out[0] = acc + pad[threadIdx.x];  // (keeps the loads alive)
 }
 
-template <int VEC, int DEPTH, int LDSKB = 0>
+template <int VEC, int DEPTH, int LDSKB = 0, int NB = 4>
 void run(const char* name, const float* vol, int tiles, bool west_east, float* out) {
     const int i_lo = west_east ? 0 : DI - OV, n_i = west_east ? DI : OV, j_lo = west_east ? DJ - OV : 0, n_j = west_east ? OV : DJ;
     const int jal = j_lo & ~(64 * VEC - 1);
@@ -62,7 +62,7 @@ void run(const char* name, const float* vol, int tiles, bool west_east, float* o
     float best = 1e9f;
     for (int rep = 0; rep < 4; ++rep) {
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL((k_read<VEC, DEPTH, LDSKB>), dim3(cblocks, bands, tiles), dim3(256), 0, 0, vol, i_lo, n_i, j_lo, n_j, out);
+        hipLaunchKernelGGL((k_read<VEC, DEPTH, LDSKB, NB>), dim3(cblocks, bands, tiles), dim3(256), 0, 0, vol, i_lo, n_i, j_lo, n_j, out);
         CK(hipEventRecord(e1));
         CK(hipEventSynchronize(e1));
         float ms = 0;
@@ -70,7 +70,7 @@ void run(const char* name, const float* vol, int tiles, bool west_east, float* o
         if (rep > 0 && ms < best) best = ms;
     }
     const double bytes = (double)tiles * DK * n_i * n_j * 4;
-    printf("%-34s %s: %.3f ms, %.0f GB/s of the view's bytes\n", name, west_east ? "west-east  " : "north-south", best, bytes / best / 1e6);
+    printf("%-42s %s: %.3f ms, %.0f GB/s of the view's bytes\n", name, west_east ? "west-east  " : "north-south", best, bytes / best / 1e6);
 }
 
 int main() {
@@ -85,6 +85,10 @@ int main() {
         run<1, 2, 32>("float per lane, 2 slices, 4 WG/CU", vol, tiles, we, out);
         run<1, 1, 32>("float per lane, 1 slice, 4 WG/CU", vol, tiles, we, out);
         run<1, 2, 48>("float per lane, 2 slices, 3 WG/CU", vol, tiles, we, out);
+        run<1, 2, 32, 1>("float, 2 slices, 4 WG/CU, 1 band per WG", vol, tiles, we, out);
+        run<1, 2, 32, 2>("float, 2 slices, 4 WG/CU, 2 bands", vol, tiles, we, out);
+        run<1, 2, 32, 8>("float, 2 slices, 4 WG/CU, 8 bands", vol, tiles, we, out);
+        run<1, 2, 32, 32>("float, 2 slices, 4 WG/CU, 32 bands", vol, tiles, we, out);
         run<2, 2>("float2 per lane, 2 slices", vol, tiles, we, out);
         run<4, 1>("float4 per lane, 1 slice", vol, tiles, we, out);
         run<4, 2>("float4 per lane, 2 slices", vol, tiles, we, out);
