@@ -208,8 +208,8 @@ __global__ __launch_bounds__(256) void k_lag_mac(const cplx* __restrict__ SF, co
         const bool has_next = next < nslots;
         int npair = 0, nk0 = 0, nnk = 0;
         if (has_next) decode(next, npair, nk0, nnk);
-        cplx pf[PF], pt[PF];
-        if (has_next) {
+        cplx pf[PF > 0 ? PF : 1], pt[PF > 0 ? PF : 1];  // (PF = 0: rows too long for the registers -- the next tile is fetched behind this one)
+        if (PF > 0 && has_next) {
             const size_t pbase = (size_t)npair * n_short;
 #pragma unroll
             for (int i = 0; i < PF; ++i) {
@@ -267,7 +267,17 @@ __global__ __launch_bounds__(256) void k_lag_mac(const cplx* __restrict__ SF, co
 #pragma unroll
             for (int q = 0; q < LB; ++q) dst[q] = acc[q];
         }
-        if (has_next) {  // (every read of this tile's spectra lies before the barrier above; `red` is its own region)
+        if (PF == 0 && has_next) {
+            const size_t pbase = (size_t)npair * n_short;
+            for (int e = threadIdx.x; e < nelem; e += 256) {
+                const int x = e / KT, l = e - x * KT;
+                if (l < nnk) {
+                    Fs[(size_t)l * FW + PAD + x] = SF[(pbase + x) * nkp + nk0 + l];
+                    Ts[(size_t)l * TW + x] = ST[(pbase + x) * nkp + nk0 + l];
+                }
+            }
+        }
+        if (PF > 0 && has_next) {  // (every read of this tile's spectra lies before the barrier above; `red` is its own region)
 #pragma unroll
             for (int i = 0; i < PF; ++i) {
                 const int e = threadIdx.x + i * 256;
@@ -624,13 +634,13 @@ LagPlane plan_lag_plane(const PlaneGeom& g, int maxIter) {
     p.KT = (int)std::min<size_t>(4, (48 * 1024) / row);
     if (p.KT < 1) p.KT = 1;
     const int nvb = p.nlp / p.LB;
-    while (p.KT > 1 && (p.KT * nvb > 256 || p.n_short * p.KT > 6 * 256)) --p.KT;
+    while (p.KT > 1 && p.KT * nvb > 256) --p.KT;
     p.JP = std::max(1, std::min(8, 256 / (p.KT * nvb)));
     p.fft_threads = p.fft.N >= 2048 ? 512 : 256;
     p.lds_mac = row * p.KT + sizeof(double) * 2 * p.LB * (size_t)(p.JP - 1) * nvb * p.KT;  // (xy plane of config 5: 52 KB, three per CU)
     const int Hm = 2 * g.delayu + 1, Wm = 2 * g.delayv + 1, H = 2 * g.wu + 1, W = 2 * g.wv + 1;
     p.lds_refine = sizeof(float) * ((size_t)Hm * Wm + 2 * (size_t)H * W);
-    p.ok = p.fft.N <= 8192 && p.lds_mac <= 150 * 1024 && nvb <= 256 && p.n_short * p.KT <= 6 * 256 && p.lds_refine <= 120 * 1024;
+    p.ok = p.fft.N <= 8192 && p.lds_mac <= 150 * 1024 && nvb <= 256 && p.lds_refine <= 120 * 1024;
     return p;
 }
 
@@ -844,9 +854,9 @@ int lag_cross(int dev, hipStream_t s, const LagPlane& lp, const float* m1, const
     if (after_fwd) MI_HIP(hipEventRecord(after_fwd, s));
     {
         using MacFn = void (*)(const cplx*, const cplx*, int, int, int, int, int, int, int, int, int, int, int, cplx*);
-        static const MacFn macs[] = {k_lag_mac<4, 1>, k_lag_mac<4, 2>, k_lag_mac<4, 3>, k_lag_mac<4, 4>, k_lag_mac<4, 5>, k_lag_mac<4, 6>};
-        const int pfn = (lp.n_short * lp.KT + 255) / 256;  // (plan_lag_plane keeps it within the table)
-        MacFn mac = macs[pfn - 1];
+        static const MacFn macs[] = {k_lag_mac<4, 0>, k_lag_mac<4, 1>, k_lag_mac<4, 2>, k_lag_mac<4, 3>, k_lag_mac<4, 4>, k_lag_mac<4, 5>, k_lag_mac<4, 6>};
+        const int pfn = (lp.n_short * lp.KT + 255) / 256;  // float4 pairs per thread of a tile; beyond the table: no register prefetch
+        MacFn mac = macs[pfn <= 6 ? pfn : 0];
         const int tiles_per_pair = ((NK + lp.KT - 1) / lp.KT + 1) & ~1, ntiles = tiles_per_pair * np;  // (even: see k_lag_mac)
         int cus = 256, per_cu = 1;
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);

@@ -143,6 +143,20 @@ def test_wide_search_and_wide_mips_vs_oracle(dev):
             assert np.allclose(mp.cpu().numpy(), want["maps"][m], rtol=0, atol=2e-6, equal_nan=True), (side, m)
 
 
+def test_overlap_wider_than_the_prefetch_registers_vs_oracle(dev):
+    """An xy plane whose SHORT axis is 1650 samples: a tile of the correlation kernel (ncc_lag.hip:k_lag_mac) no longer fits the registers
+    that carry the next tile's spectra, so the kernel variant that fetches the next tile behind the current one runs (and one
+    frequency per work-group instead of four)."""
+    from ipp_amd import crossmips
+    for side, shape, ov, shift in ((0, (8, 1700, 1800), 1650, (2, -3, 0)), (1, (8, 1800, 1700), 1650, (-4, 1, 1))):
+        A, B = N.tile_pair(shape, ov, side, shift, seed=900 + side)
+        want = N.pdalgo_execute(A, B, 8, 8, 2, side, ov, kind="oracle")
+        got = crossmips.PDAlgoMIPNCC.execute(torch.from_numpy(A).to(dev), torch.from_numpy(B).to(dev), 8, 8, 2, side, ov)
+        assert got.VHD_coords == want["coord"] and got.NCC_widths == want["NCC_widths"], (side, got.VHD_coords, want["coord"])
+        assert got.wRangeThrs == want["wRangeThr"]
+        assert np.allclose(np.array(got.NCC_maxs, np.float32), want["NCC_maxs"], atol=2e-6, equal_nan=True)
+
+
 def test_host_pointer_entry_and_errors(dev):
     import ctypes as C
     from ipp_amd import capi, crossmips
