@@ -100,7 +100,11 @@ __device__ __forceinline__ float rows_max16(const float (&v)[MIP_ROWS], int lane
 
 // view(k,i,j) = vol[k*slice + (i+i0)*pitch + (j+j0)]; blockIdx.z = 2 * pair + (0: A, 1: B).  A batch hands the tile pointers
 // over as a device table (tab[2 * pair + which]); every output array of pair q sits q * pstride floats behind pair 0's.
-__global__ __launch_bounds__(256) void k_mips(const float* __restrict__ A, const float* __restrict__ B, const float* const* __restrict__ tab,
+// FAST: stacks of up to 4 * MIP_KPW slices whose xz maxima go through LDS (every C5-like stack): no conditional memory operation is left
+// in the slice loop -- with one the compiler cannot count the loads in flight and waits for all of them (`s_waitcnt vmcnt(0)`)
+// before it reduces a slice, i.e. the next slice never travelled while the current one was reduced.
+template <bool FAST>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_mips(const float* __restrict__ A, const float* __restrict__ B, const float* const* __restrict__ tab,
                                                size_t pstride, int dimk, int dimi_v, int dimj_v,
                                                size_t slice, int pitch, int ai0, int aj0, float* __restrict__ xy1, float* __restrict__ xz1,
                                                float* __restrict__ yz1, float* __restrict__ xy2, float* __restrict__ xz2,
@@ -132,7 +136,7 @@ __global__ __launch_bounds__(256) void k_mips(const float* __restrict__ A, const
     // its acknowledgement came back, and the other three waves at the next barrier (switching the xy store off saved 11 % of
     // the pass although it is 3 % of its bytes: profiles/r03_mips_knock.txt).  The xy maxima of a band are merged across the
     // waves with LDS atomics, the xz maxima of all bands wait in LDS: the band loop has no barrier left.
-    const bool keep = dimk <= 4 * MIP_KPW;
+    const bool keep = FAST || dimk <= 4 * MIP_KPW;
     const int nb = keep ? MIP_NB : 1;
     __shared__ float xyb[MIP_NB][MIP_ROWS][64];
     __shared__ float cacc[4][MIP_KPW][64];
@@ -147,11 +151,20 @@ __global__ __launch_bounds__(256) void k_mips(const float* __restrict__ A, const
     // the wave's slices of all its bands form one sequence: the next slice -- of this band or the first of the next -- is requested
     // before the current one is reduced
     float v[MIP_ROWS], vn[MIP_ROWS];
+    // Every load is unconditional: lanes outside the view read its nearest column, rows past the last band its last row -- a
+    // maximum does not change when a sample is taken twice (the partial results of such lanes are never stored).  Predicated
+    // loads cost a branch around each of the 16 rows of a slice (`s_cbranch_execz`), in the inner loop of a memory-bound pass.
+    const int jc = min(max(j, 0), dimj_v - 1);
     auto load_slice = [&](int bb, int k, float (&dst)[MIP_ROWS]) {
-        const int i0 = ib0 + bb * MIP_ROWS, rows = min(MIP_ROWS, dimi_v - i0);
-        const float* p = vol + (size_t)k * slice + (size_t)i0 * pitch;  // wave-uniform
+        const int i0 = ib0 + bb * MIP_ROWS, last = min(MIP_ROWS, dimi_v - i0) - 1;
+        // (a GLOBAL pointer, said explicitly: the tile pointer comes out of a table in memory, and what the compiler cannot prove
+        // global it reads with FLAT loads -- which count against the LDS counter as well and are waited for with vmcnt(0).
+        // Measured on one box, same run: 1.87 / 1.81 ms with global loads and counted waits, 1.90 / 1.82 ms with FLAT loads -- the
+        // pass is not bound by what a wave keeps in flight (three or four waves per SIMD are the optimum, five or two are slower))
+        typedef const float __attribute__((address_space(1))) gfloat;
+        gfloat* p = (gfloat*)(vol + (size_t)k * slice + (size_t)i0 * pitch);  // wave-uniform
 #pragma unroll
-        for (int r = 0; r < MIP_ROWS; ++r) dst[r] = (live && r < rows) ? (p + (size_t)r * pitch)[j] : 0.0f;
+        for (int r = 0; r < MIP_ROWS; ++r) dst[r] = (p + (size_t)min(r, last) * pitch)[jc];
     };
     if (wave < dimk) load_slice(0, wave, v);
     __syncthreads();  // (xyb is zero)
@@ -162,43 +175,52 @@ __global__ __launch_bounds__(256) void k_mips(const float* __restrict__ A, const
         float best[MIP_ROWS];
 #pragma unroll
         for (int r = 0; r < MIP_ROWS; ++r) best[r] = 0.0f;
-        // one slice of the wave: returns its column maximum
-        auto slice_step = [&](int k) {
+        // one slice of the wave, held in `cur`; the wave's next one is requested into `nxt` first.  Returns the column maximum.
+        // (The two buffers swap roles from slice to slice -- the loops below take two slices per trip.  With one loop body and a
+        // copy nxt -> cur at its end the compiler had to wait for the slice it had just requested: `s_waitcnt vmcnt(0)` in every
+        // step, no load in flight while a slice was reduced.)
+        auto slice_step = [&](int k, float (&cur)[MIP_ROWS], float (&nxt)[MIP_ROWS]) {
             const bool wrap = k + 4 >= dimk;  // (wave-uniform)
             const int kn = __builtin_amdgcn_readfirstlane(wrap ? wave : k + 4), bn = __builtin_amdgcn_readfirstlane(wrap ? b + 1 : b);
-            if (bn < nbv) load_slice(bn, kn, vn);
+            // (behind the work-group's last slice there is nothing to fetch: the first slice of its last band is read once more --
+            // one slice in 128 -- so that the number of loads in flight is the same in every step)
+            if (FAST) load_slice(min(bn, nbv - 1), kn, nxt);
+            else if (bn < nbv) load_slice(bn, kn, nxt);
             float colmax = 0.0f;
 #pragma unroll
             for (int r = 0; r < MIP_ROWS; ++r) {
-                best[r] = fmaxf(best[r], v[r]);
-                colmax = fmaxf(colmax, v[r]);
+                best[r] = fmaxf(best[r], cur[r]);
+                colmax = fmaxf(colmax, cur[r]);
             }
             // xz: the 16 row maxima over the 64 columns of the patch, per patch through LDS into xz_tmp[tile][column block][i][k]
             // (k_mips_xz takes the maximum over the column blocks); as atomics on the MIP they were 655 thousand single-lane
             // atomics per C5 pair, as 16 separate wave reductions 96 DPP steps per slice
             if (!(knock & 1)) {
-                const float rowmax = rows_max16(v, lane);
+                const float rowmax = rows_max16(cur, lane);
                 const int r = row_of_lane(lane);
                 if (lane < 16) {
-                    if (xz_tmp) xzp[(b * MIP_ROWS + r) * dimk + k] = rowmax;
+                    if (FAST || xz_tmp) xzp[(b * MIP_ROWS + r) * dimk + k] = rowmax;
                     else if (r < rows) atomic_max_nonneg(&xz[(size_t)(i0 + r) * dimk + k], rowmax);
                 }
             }
-#pragma unroll
-            for (int r = 0; r < MIP_ROWS; ++r) v[r] = vn[r];
             return (knock & 2) ? 0.0f : colmax;
         };
         // yz: the column maxima of this band (group) go to yz_tmp[tile][group][k][j] (unit-stride stores); k_mips_yz takes the
         // maximum over the groups -- 2.6 million atomics per pair on the yz MIPs cost more than the whole streaming pass
-        if (keep) {
+        auto yz_out = [&](int k, int q, float colmax) {
+            if (FAST || keep) colacc[q * 64] = fmaxf(colacc[q * 64], colmax);
+            else if (live) yz_tmp[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * dimk + k) * dimj_v + j] = colmax;
+        };
+        int k = wave, q = 0;
 #pragma unroll 1
-            for (int k = wave, q = 0; k < dimk; k += 4, ++q) colacc[q * 64] = fmaxf(colacc[q * 64], slice_step(k));
-        } else {
-#pragma unroll 1
-            for (int k = wave; k < dimk; k += 4) {
-                const float colmax = slice_step(k);
-                if (live) yz_tmp[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * dimk + k) * dimj_v + j] = colmax;
-            }
+        for (; k + 4 < dimk; k += 8, q += 2) {
+            yz_out(k, q, slice_step(k, v, vn));
+            yz_out(k + 4, q + 1, slice_step(k + 4, vn, v));
+        }
+        if (k < dimk) {  // an odd number of slices: the next band's first slice has arrived in the other buffer
+            yz_out(k, q, slice_step(k, v, vn));
+#pragma unroll
+            for (int r = 0; r < MIP_ROWS; ++r) v[r] = vn[r];
         }
         // xy: maximum over the four waves' slices
 #pragma unroll
@@ -277,7 +299,7 @@ int launch_mips(hipStream_t s, const float* A, const float* B, const float* cons
         const char* e = std::getenv("MI_NCC_MIPS_KNOCK");
         return e ? std::atoi(e) : 0;
     }();
-    hipLaunchKernelGGL(k_mips, grid, dim3(256), via_lds ? lds : 0, s, A, B, tab, pstride, dimk, dimi_v, dimj_v, slice, pitch, ai0, aj0, xy1, xz1, yz1,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(via_lds && dimk <= 4 * MIP_KPW ? k_mips<true> : k_mips<false>), grid, dim3(256), via_lds ? lds : 0, s, A, B, tab, pstride, dimk, dimi_v, dimj_v, slice, pitch, ai0, aj0, xy1, xz1, yz1,
                        xy2, xz2, yz2, yz_tmp, via_lds ? xz_tmp : (float*)nullptr, knock);
     MI_TRY(launch_check("k_mips"));
     if (xy_done) MI_HIP(hipEventRecord(xy_done, s));

@@ -1296,7 +1296,7 @@ int ncc_time_mips(int dev, hipStream_t s, int n, const float* const* a_ptrs, con
     const int knock = ke ? std::atoi(ke) : 0;
     for (int r = -1; r < reps; ++r) {  // r = -1: warm-up
         if (r == 0) MI_HIP(hipEventRecord(e0, s));
-        hipLaunchKernelGGL(k_mips, dim3(cblocks, bands, 2 * n), dim3(256), lds, s, (const float*)nullptr, (const float*)nullptr, tab.as<const float*>(),
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(dimk <= 4 * MIP_KPW ? k_mips<true> : k_mips<false>), dim3(cblocks, bands, 2 * n), dim3(256), lds, s, (const float*)nullptr, (const float*)nullptr, tab.as<const float*>(),
                            pstride, dimk, dimi_v, dimj_v, (size_t)dimi * dimj, dimj, side == MI_NORTH_SOUTH ? ni : 0, side == MI_WEST_EAST ? nj : 0, o,
                            o + xy, o + xy + xz, o + xy + xz + yz, o + 2 * xy + xz + yz, o + 2 * xy + 2 * xz + yz, tmp.as<float>(), xz_tmp, knock);
     }
