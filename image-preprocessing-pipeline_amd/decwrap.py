@@ -219,7 +219,22 @@ def main(argv=None):
     gpu = args.gpu_indices[0]
     # workers that share a device share its memory (decwrap.py:133-169 divides by the workers per GPU as well)
     per_dev = max(1, args.gpu_workers_per_gpu) * max(1, args.gpu_indices.count(gpu))
-    bmax = args.block_size_max or L.estimate_block_size_max(gpu - 1, n_real=3, n_complex=2 if args.use_fft else 0) // per_dev
+    # Finished cores stay in device memory until the assembly needs them (288 GB of HBM hold a 30-Gvoxel result in float32): the
+    # assembly then rescales them where they are instead of reading its bricks back, decompressing them and sending them up again.
+    # MI_DECWRAP_RESIDENT=0 switches that off; MI_DECWRAP_BRICKS=0 additionally writes no brick for a core that stays resident (no
+    # D2H of the float32 core, no LZ4, no file: the run cannot be resumed).  Memory: with an explicit --block-size-max whatever the
+    # workers' blocks leave free; otherwise the result's share of this device is set aside first, if that is at most half of it.
+    n_work_vols = 3 + 2 * (2 if args.use_fft else 0)
+    free0 = torch.cuda.mem_get_info(gpu - 1)[0]
+    keep_resident = os.environ.get("MI_DECWRAP_RESIDENT", "1") != "0" and int(args.start_block) == 1
+    keep_bricks = os.environ.get("MI_DECWRAP_BRICKS", "1") != "0" or not keep_resident
+    res_share = sz * sy * sx * 4 // len(set(args.gpu_indices)) + (1 << 30)
+    if args.block_size_max:
+        bmax = args.block_size_max
+        res_budget = max(0, free0 - (3 << 30) - per_dev * bmax * 4 * n_work_vols) if keep_resident else 0
+    else:
+        res_budget = res_share if (keep_resident and res_share <= free0 // 2) else 0
+        bmax = max(1, (free0 - (3 << 30) - res_budget) // 4 // n_work_vols) // per_dev
 
     import shutil
     import threading
@@ -291,8 +306,13 @@ def main(argv=None):
     def brick_path(n):
         return cache / f"bl_{n}.lz4"
 
+    resident = {}                                   # block number -> its float32 core on the device that computed it
+    res_used = {g: 0 for g in set(args.gpu_indices)}
+
     def brick_complete(n):
-        """a finished brick of this block: non-empty, readable header, float32, the block's core shape"""
+        """a finished brick of this block: non-empty, readable header, float32, the block's core shape (or its core is resident)"""
+        if n in resident:
+            return True
         p = brick_path(n)
         try:
             if p.stat().st_size == 0:
@@ -417,6 +437,27 @@ def main(argv=None):
 
     threading.Thread(target=stage_warm, daemon=True).start()
 
+    # The assembly's host buffers -- one integer z slab of the whole stack (fresh pages: a second per 4 GB) and two pinned integer
+    # cores -- are made while the blocks are being deconvolved, when the output type is already known (integer input: the scale
+    # follows from the input type, LsDeconv.m:1009-1024); the device used to sit idle for 1.5 s between the two phases.
+    prep = {}
+
+    def prepare_assembly():
+        try:
+            scal0 = L.output_scale(float(np.iinfo(vol.dtype).max), args.convert_to_8bit, args.convert_to_16bit)
+            dt = np.uint8 if scal0 <= 255 else np.uint16
+            q = [torch.empty(core_max, dtype=torch.uint8 if dt == np.uint8 else torch.uint16, pin_memory=True) for _ in range(2)]
+            slab0 = np.empty((int(block.z), sy, sx), dt)
+            slab0.fill(0)                                                                  # (touches every page)
+            prep.update(dtype=dt, q_host=q, slab=slab0)
+        except Exception as e:                                                             # (the assembly then makes its own)
+            log.debug(f"assembly buffers not prepared ahead: {e}")
+
+    prep_thread = None
+    if int_input and int(args.start_block) == 1:
+        prep_thread = threading.Thread(target=prepare_assembly, daemon=True)
+        prep_thread.start()
+
     def run(worker_id, first_block):
         g = workers[worker_id]
         stream = torch.cuda.Stream(device=g - 1)
@@ -425,7 +466,7 @@ def main(argv=None):
         plan = None if os.environ.get("MI_NO_DECON_PLAN") else D.DeconPlan(g)
         try:
             for n in range(first_block, num_blocks + 1):
-                if not claim(n):
+                if n in resident or not claim(n):
                     continue                                                               # finished or being worked on elsewhere
                 run_block(n, g, stream, staging, plan)
         finally:
@@ -457,11 +498,21 @@ def main(argv=None):
             assert tuple(core.shape) == core_shape(n), "[remove padding]: Output block size mismatch!"
             ev1.record()
             t_c = time.perf_counter()
-            host = stage_get()                                                             # (waits while the writers are behind)
+            nbytes = core.numel() * 4
+            with lock:
+                stays = res_used[g] + nbytes <= res_budget
+                if stays:
+                    res_used[g] += nbytes
+            host = None
+            if keep_bricks or not stays:
+                host = stage_get()                                                         # (waits while the writers are behind)
             t_d = time.perf_counter()
-            view = host[:core.numel()].view(core.shape)
-            view.copy_(core, non_blocking=True)
+            if host is not None:
+                view = host[:core.numel()].view(core.shape)
+                view.copy_(core, non_blocking=True)
             stream.synchronize()
+            if stays:
+                resident[n] = core                                                         # (complete: the stream has been waited for)
         t_e = time.perf_counter()
         with lock:                                                                         # where a block's time goes (summary at the end)
             timing["blocks"] += 1
@@ -472,9 +523,16 @@ def main(argv=None):
         merge_min_max(lb, ub, rawmax)
         # the brick is compressed and written behind the worker's back, straight from the pinned buffer, its chunks side by side
         # on the codec pool; the buffer returns to the pool when the file is complete
-        with lock:
-            pending.append(writers.submit(save_brick, n, view.numpy(), host, lb, ub))
-        log.info(f"block {n}/{num_blocks} done on GPU {g}: stats [{lb:.4g}, {ub:.4g}]")
+        if host is not None:
+            with lock:
+                pending.append(writers.submit(save_brick, n, view.numpy(), host, lb, ub))
+        else:
+            try:
+                brick_path(n).unlink()                                                     # the claim: nothing will be written
+                brick_path(n).with_suffix(".claim").unlink()
+            except OSError:
+                pass
+        log.info(f"block {n}/{num_blocks} done on GPU {g}: stats [{lb:.4g}, {ub:.4g}]" + ("" if host is not None else " (kept on the device only)"))
 
     def save_brick(n, arr, host, lb, ub):
         try:
@@ -567,7 +625,14 @@ def main(argv=None):
     n_tif = 0
     out_dtype = np.uint8 if bits == 8 else np.uint16
     slab_buf = None                      # one integer slab, reused by every z slab of bricks (fresh pages cost seconds per slab)
-    q_host = [torch.empty(core_max, dtype=torch.uint8 if bits == 8 else torch.uint16, pin_memory=True) for _ in range(2)]
+    if prep_thread is not None:
+        prep_thread.join()
+    if prep.get("dtype") == out_dtype:
+        slab_buf, q_host = prep["slab"], prep["q_host"]
+    else:
+        q_host = [torch.empty(core_max, dtype=torch.uint8 if bits == 8 else torch.uint16, pin_memory=True) for _ in range(2)]
+    prep.clear()
+    n_resident = [0]
 
     def read_brick(n):
         """brick -> a pinned core buffer (chunks decompressed side by side on the codec pool)"""
@@ -594,27 +659,41 @@ def main(argv=None):
             # bricks are read ahead of the device; the integer cores are copied into the slab behind it
             placed = [None, None]
             ahead = max(1, min(2, n_stage - 1))
-            futs = {k: readers.submit(read_brick, ids[k]) for k in range(min(ahead, len(ids)))}
+            from_disk = [k for k, n in enumerate(ids) if n not in resident]               # (the others wait on their device)
+            futs = {k: readers.submit(read_brick, ids[k]) for k in from_disk[:ahead]}
+            nxt = ahead
             for k, n in enumerate(ids):
-                host, core = futs.pop(k).result()
-                if k + ahead < len(ids):
-                    futs[k + ahead] = readers.submit(read_brick, ids[k + ahead])
+                host = None
+                if n in resident:
+                    d_core = resident.pop(n)
+                    shape, size = tuple(d_core.shape), d_core.numel()
+                    n_resident[0] += 1
+                else:
+                    host, core = futs.pop(k).result()
+                    if nxt < len(from_disk):
+                        futs[from_disk[nxt]] = readers.submit(read_brick, ids[from_disk[nxt]])
+                        nxt += 1
+                    shape, size = core.shape, core.size
                 p1, p2 = block.p1[n - 1], block.p2[n - 1]
                 box = (slice(int(p1[2]) - z1, int(p2[2]) - z1 + 1), slice(int(p1[1]) - 1, int(p2[1])), slice(int(p1[0]) - 1, int(p2[0])))
                 if npy_f is not None:
-                    npy_f[int(p1[2]) - 1:int(p2[2]), box[1], box[2]] = core
-                # rescale on the device (load_slab_lz4.cpp:134-157): pinned core up, pinned integers down
+                    npy_f[int(p1[2]) - 1:int(p2[2]), box[1], box[2]] = core if host is not None else d_core.cpu().numpy()
+                # rescale on the device (load_slab_lz4.cpp:134-157): a resident core where it is, a brick's via a pinned buffer;
+                # pinned integers down
                 if placed[k & 1] is not None:
                     placed[k & 1].result()                                                 # this integer buffer's last core is in the slab
-                qh = q_host[k & 1][:core.size].view(core.shape)
-                with torch.cuda.device(dev):
-                    d_core = host[:core.size].view(core.shape).to(dev, non_blocking=True)       # (the pinned tensor itself: a true async copy)
+                qh = q_host[k & 1][:size].view(shape)
+                with torch.cuda.device(dev if host is not None else d_core.device):
+                    if host is not None:
+                        d_core = host[:size].view(shape).to(dev, non_blocking=True)          # (the pinned tensor itself: a true async copy)
                     q = D.rescale_block(d_core, scal, args.signal_amp, lo, hi)
                     qh.copy_(q, non_blocking=True)
                     ev = torch.cuda.Event()
                     ev.record()
                 ev.synchronize()
-                stage_free.put(host)
+                del d_core
+                if host is not None:
+                    stage_free.put(host)
                 placed[k & 1] = copiers.submit(slab.__setitem__, box, qh.numpy())
             for fu in placed:
                 if fu is not None:
@@ -633,6 +712,8 @@ def main(argv=None):
         log.info(f"wrote {n_tif} TIFF slices to {out_dir}")
     codec.shutdown(wait=True)
     main.last_timing["assembly_wall_s"] = time.perf_counter() - t_blocks0 - t_blocks
+    main.last_timing["cores_from_device"] = n_resident[0]
+    log.info(f"assembly: {n_resident[0]} of {num_blocks} cores came straight from device memory, the others from their bricks")
     shutil.rmtree(cache, ignore_errors=True)                                               # LsDeconv.m:286-296
     log.info(f"wrote {out_dir} (scale {scal:g}, clip [{lo:.4g}, {hi:.4g}])")
     return 0

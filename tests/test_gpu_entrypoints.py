@@ -188,6 +188,33 @@ def test_decwrap_block_parallel_workers_equal_sequential(dev, tmp_path):
     assert float(np.abs(outs[0][0]).max()) > 0
 
 
+def test_decwrap_resident_cores_equal_the_brick_route(dev, tmp_path, monkeypatch):
+    """The assembly takes finished cores straight from device memory (default), from their LZ4 bricks (MI_DECWRAP_RESIDENT=0,
+    the reference's route: LsDeconv.m:799-806, load_slab_lz4.cpp), or -- MI_DECWRAP_BRICKS=0 -- from device memory with no brick
+    written at all: three identical stacks; the last mode leaves no brick behind and reports every core as resident."""
+    from ipp_amd import decwrap
+    rng = np.random.default_rng(12)
+    vol16 = (rng.random((24, 40, 44)) * 3000 + 200).astype(np.uint16)
+    outs = []
+    for k, env in enumerate(({}, {"MI_DECWRAP_RESIDENT": "0"}, {"MI_DECWRAP_BRICKS": "0"})):
+        for name in ("MI_DECWRAP_RESIDENT", "MI_DECWRAP_BRICKS"):
+            monkeypatch.delenv(name, raising=False)
+        for name, v in env.items():
+            monkeypatch.setenv(name, v)
+        d = tmp_path / f"m{k}"
+        d.mkdir()
+        np.save(d / "vol.npy", vol16)
+        rc = decwrap.main(["-i", str(d / "vol.npy"), "-dxy", "0.422", "-dz", "1.0", "-ex", "488", "-em", "525", "-it", "3",
+                           "--gaussian-sigma", "0", "0", "0", "--block-size-max", "60000", "--gpu-indices", "1",
+                           "--gpu-workers-per-gpu", "2"])
+        assert rc == 0
+        outs.append((np.load(d / "deconvolved" / "deconvolved.npy"), np.load(d / "deconvolved" / "deconvolved_16bit.npy")))
+        n_dev = decwrap.main.last_timing["cores_from_device"]
+        assert (n_dev == 0) if env.get("MI_DECWRAP_RESIDENT") == "0" else (n_dev > 1), (env, n_dev)
+    for o in outs[1:]:
+        assert np.array_equal(outs[0][0], o[0]) and np.array_equal(outs[0][1], o[1])
+
+
 def test_device_memory_pool_reuses_and_releases(dev):
     """Scratch memory a call releases stays in the library's per-device pool and is handed out again; it goes back to the driver
     on request (mi_release_cached_memory)."""
