@@ -331,8 +331,20 @@ def main(argv=None):
     int_input = np.issubdtype(np.dtype(vol.dtype), np.integer)
     state = {"deconvmin": float("inf"), "deconvmax": 0.0, "rawmax": float(np.iinfo(vol.dtype).max) if int_input else float("-inf")}
 
+    mm_written = [0.0]
+
     def merge_min_max(lb=None, ub=None, rawmax=None):
         with lock:
+            if lb is not None:
+                state["deconvmin"], state["deconvmax"] = min(state["deconvmin"], lb), max(state["deconvmax"], ub)
+            if rawmax is not None:
+                state["rawmax"] = max(state["rawmax"], rawmax)
+            # the file is what other processes on a shared cache folder see: refreshed at most once a second while blocks finish
+            # (half a dozen file operations per block were a fifth of a block's time on an overlay file system), always at the end
+            now = time.monotonic()
+            if lb is not None and now - mm_written[0] < 1.0:
+                return
+            mm_written[0] = now
             if mm_path.exists():                                                           # another process may have updated it
                 try:
                     with open(mm_path) as f:
@@ -360,8 +372,17 @@ def main(argv=None):
     import socket
     me = f"{socket.gethostname()}:{os.getpid()}"
 
+    claimed_here = set()
+
     def claim(n):
-        """creates the (empty) brick file; who holds the claim is noted beside it, for the reaper of another round or process"""
+        """creates the (empty) brick file; who holds the claim is noted beside it, for the reaper of another round or process.
+        (Without bricks nobody else can share this run: the workers of this process settle the blocks among themselves.)"""
+        if not keep_bricks:
+            with lock:
+                if n in claimed_here:
+                    return False
+                claimed_here.add(n)
+            return True
         try:
             os.close(os.open(brick_path(n), os.O_CREAT | os.O_EXCL | os.O_WRONLY))
         except FileExistsError:
@@ -516,6 +537,7 @@ def main(argv=None):
         t_e = time.perf_counter()
         with lock:                                                                         # where a block's time goes (summary at the end)
             timing["blocks"] += 1
+            timing["host_in_device_s"] = timing.get("host_in_device_s", 0.0) + t_c - t_b
             timing["box_read_s"] += t_b - t_a
             timing["device_ms"] += ev0.elapsed_time(ev1)
             timing["wait_buffer_s"] += t_d - t_c
@@ -524,14 +546,13 @@ def main(argv=None):
         # the brick is compressed and written behind the worker's back, straight from the pinned buffer, its chunks side by side
         # on the codec pool; the buffer returns to the pool when the file is complete
         if host is not None:
+            if not keep_bricks:                                                            # (a core that found no room on the device)
+                try:
+                    os.close(os.open(brick_path(n), os.O_CREAT | os.O_WRONLY))
+                except OSError:
+                    pass
             with lock:
                 pending.append(writers.submit(save_brick, n, view.numpy(), host, lb, ub))
-        else:
-            try:
-                brick_path(n).unlink()                                                     # the claim: nothing will be written
-                brick_path(n).with_suffix(".claim").unlink()
-            except OSError:
-                pass
         log.info(f"block {n}/{num_blocks} done on GPU {g}: stats [{lb:.4g}, {ub:.4g}]" + ("" if host is not None else " (kept on the device only)"))
 
     def save_brick(n, arr, host, lb, ub):
