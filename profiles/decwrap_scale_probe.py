@@ -47,6 +47,33 @@ def sample():
 
 
 threading.Thread(target=sample, daemon=True).start()
+
+# PROBE_SAMPLE=1: where the host threads are -- every 5 ms the innermost frames of all threads (a poor man's sampling profiler)
+stacks = {}
+
+
+def sample_stacks():
+    import collections
+    me = threading.get_ident()
+    while not stop.is_set():
+        for tid, fr in sys._current_frames().items():
+            if tid == me:
+                continue
+            chain = []
+            f = fr
+            while f is not None:
+                chain.append(f"{os.path.basename(f.f_code.co_filename)}:{f.f_lineno}:{f.f_code.co_name}")
+                f = f.f_back
+            if not any(":run_block" in c for c in chain):
+                continue                                   # only the block workers
+            own = [c for c in chain if c.startswith(("decwrap.py", "lsdeconv.py", "decon.py", "capi.py", "brickio.py"))]
+            key = " < ".join(own[:3])
+            stacks[key] = stacks.get(key, 0) + 1
+        stop.wait(0.005)
+
+
+if os.environ.get("PROBE_SAMPLE"):
+    threading.Thread(target=sample_stacks, daemon=True).start()
 os.environ["MI_DECWRAP_NPY"] = "0"
 from ipp_amd import decwrap  # noqa: E402
 t0 = time.perf_counter()
@@ -65,4 +92,8 @@ print(f"{nworkers} workers per GPU; volume {shape[2]} x {shape[1]} x {shape[0]} 
       f"{dt:.1f} s wall = {nvox / dt / 1e6:.0f} Mvoxel/s end to end (6 RL iterations, default filters), peak resident set {rss:.1f} GB "
       f"incl. the mapped input file (before the run {rss0:.1f} GB), peak ANONYMOUS resident memory {peak_anon[0]:.1f} GB "
       f"(a float32 copy of the volume would be {nvox * 4 / 1e9:.1f} GB)", flush=True)
+if stacks:
+    tot = sum(stacks.values())
+    for k, v in sorted(stacks.items(), key=lambda kv: -kv[1])[:40]:
+        print(f"  {100.0 * v / tot:5.1f} %  {k}")
 shutil.rmtree(root, ignore_errors=True)
