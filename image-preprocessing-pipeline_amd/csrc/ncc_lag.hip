@@ -72,18 +72,19 @@ __device__ __forceinline__ void fft_dif(cplx* __restrict__ x, const FftPlan& pl,
         const cplx* stw = tw + pl.twoff[st];
         for (int i0 = threadIdx.x; i0 < nb; i0 += BF * blockDim.x) {
             cplx a[BF][4], w[BF][3];
-            cplx* ptr[BF];
+            int off[BF];  // (offsets, not pointers: a pointer that may be null is no longer known to point into LDS -> FLAT accesses)
+            bool live[BF];
 #pragma unroll
             for (int u = 0; u < BF; ++u) {
                 const int idx = i0 + u * blockDim.x;
-                const bool ok = idx < nb;
+                live[u] = idx < nb;
                 const int g = idx / q, t = idx - g * q;
-                ptr[u] = ok ? x + g * L + t : nullptr;
-                if (ok) {
-                    a[u][0] = ptr[u][0];
-                    a[u][1] = ptr[u][q];
-                    if (r > 2) a[u][2] = ptr[u][2 * q];
-                    if (r > 3) a[u][3] = ptr[u][3 * q];
+                off[u] = g * L + t;
+                if (live[u]) {
+                    a[u][0] = x[off[u]];
+                    a[u][1] = x[off[u] + q];
+                    if (r > 2) a[u][2] = x[off[u] + 2 * q];
+                    if (r > 3) a[u][3] = x[off[u] + 3 * q];
                     w[u][0] = stw[t];
                     if (r > 2) w[u][1] = stw[q + t];
                     if (r > 3) w[u][2] = stw[2 * q + t];
@@ -91,26 +92,27 @@ __device__ __forceinline__ void fft_dif(cplx* __restrict__ x, const FftPlan& pl,
             }
 #pragma unroll
             for (int u = 0; u < BF; ++u) {
-                if (!ptr[u]) continue;
+                if (!live[u]) continue;
+                cplx* pu = x + off[u];
                 if (r == 4) {
                     const cplx s02 = cadd(a[u][0], a[u][2]), d02 = csub(a[u][0], a[u][2]), s13 = cadd(a[u][1], a[u][3]), d13 = csub(a[u][1], a[u][3]);
                     const cplx y1 = make_double2(d02.x + d13.y, d02.y - d13.x);  // d02 - i d13
                     const cplx y3 = make_double2(d02.x - d13.y, d02.y + d13.x);  // d02 + i d13
-                    ptr[u][0] = cadd(s02, s13);
-                    ptr[u][q] = cmul(y1, w[u][0]);
-                    ptr[u][2 * q] = cmul(csub(s02, s13), w[u][1]);
-                    ptr[u][3 * q] = cmul(y3, w[u][2]);
+                    pu[0] = cadd(s02, s13);
+                    pu[q] = cmul(y1, w[u][0]);
+                    pu[2 * q] = cmul(csub(s02, s13), w[u][1]);
+                    pu[3 * q] = cmul(y3, w[u][2]);
                 } else if (r == 3) {
                     const cplx t1 = cadd(a[u][1], a[u][2]), dd = csub(a[u][1], a[u][2]);
                     const cplx t2 = make_double2(a[u][0].x - 0.5 * t1.x, a[u][0].y - 0.5 * t1.y);
                     const double h = 0.86602540378443864676;  // sqrt(3) / 2
                     const cplx sv = make_double2(h * dd.x, h * dd.y);
-                    ptr[u][0] = cadd(a[u][0], t1);
-                    ptr[u][q] = cmul(make_double2(t2.x + sv.y, t2.y - sv.x), w[u][0]);      // t2 - i sv
-                    ptr[u][2 * q] = cmul(make_double2(t2.x - sv.y, t2.y + sv.x), w[u][1]);  // t2 + i sv
+                    pu[0] = cadd(a[u][0], t1);
+                    pu[q] = cmul(make_double2(t2.x + sv.y, t2.y - sv.x), w[u][0]);      // t2 - i sv
+                    pu[2 * q] = cmul(make_double2(t2.x - sv.y, t2.y + sv.x), w[u][1]);  // t2 + i sv
                 } else {
-                    ptr[u][0] = cadd(a[u][0], a[u][1]);
-                    ptr[u][q] = cmul(csub(a[u][0], a[u][1]), w[u][0]);
+                    pu[0] = cadd(a[u][0], a[u][1]);
+                    pu[q] = cmul(csub(a[u][0], a[u][1]), w[u][0]);
                 }
             }
         }
