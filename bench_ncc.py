@@ -258,9 +258,52 @@ def run(dev, repeats=10, cpu_workers=None, rank=0, world=1, dist=None, dist_devi
                             "row_blocks": [list(b) for b in blocks], "pairs_on_rank0": n_mine,
                             "tiles_resident_on_rank0": sum(t is not None for row in tiles for t in row)}
         roof["note"] = "k_mips launches of rank 0's pairs"
+    if world == 1:
+        out["u16_tiles"] = u16_leg(dev, tiles, jit, step, repeats)
     if cpu_workers and world == 1:
         out["cpu_baseline"] = cpu_baseline(tiles, res, cpu_workers)
     return out
+
+
+def u16_leg(dev, tiles, jit, step, repeats):
+    """Secondary line, NOT the metric (BASELINE config 5 is defined on float32 tiles): the same grid with the tiles kept as 16-bit
+    samples, as the reference's TIFF tiles are stored (it divides them by 65535 when it loads them, tiff2D.cpp:606-610) --
+    mi_ncc_mips_batch_u16 reads those in its MIP pass and returns the records of the converted tiles bit for bit."""
+    import ctypes as C
+    import torch
+    from ipp_amd import capi, crossmips
+    t16 = [[(t * 65535.0).round_().clamp_(0, 65535).to(torch.uint16) for t in row] for row in tiles]
+    res = crossmips.compute_displacements(t16, OVERLAP, OVERLAP, *DISPL)
+    ok = 0
+    for (r, c, rb, cb, direction), d in res.items():
+        dj = jit[rb, cb] - jit[r, c]
+        nominal = [step if direction == 0 else 0, step if direction == 1 else 0]
+        ok += all(d.VHD_coords[ax] == nominal[ax] + int(dj[ax]) for ax in range(2))
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(repeats):
+        crossmips.compute_displacements(t16, OVERLAP, OVERLAP, *DISPL)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    n = len(res)
+    flat = [t for row in t16 for t in row]
+    Cc = len(t16[0])
+    dk, di, dj_ = (int(v) for v in flat[0].shape)
+    ptrs = (C.c_void_p * len(flat))(*[t.data_ptr() for t in flat])
+    launches = {}
+    for side, name in ((1, "west_east"), (0, "north_south")):
+        mine = [p for p in res.keys() if p[4] == side]
+        a_idx = (C.c_int * len(mine))(*[r * Cc + c for r, c, _, _, _ in mine])
+        b_idx = (C.c_int * len(mine))(*[rb * Cc + cb for _, _, rb, cb, _ in mine])
+        ni, nj = (di - OVERLAP if side == 0 else 0), (dj_ - OVERLAP if side == 1 else 0)
+        ms = C.c_float()
+        capi.check(capi.lib().mi_ncc_time_mips_u16(dev.index, capi.current_stream_ptr(dev), len(mine), ptrs, 65535.0, a_idx, b_idx, dk, di, dj_, ni,
+                                                   nj, side, 5, C.byref(ms)))
+        nbytes = len(mine) * 2.0 * dk * (di - ni) * (dj_ - nj) * 2
+        launches[name] = {"pairs_per_launch": len(mine), "launch_ms": round(ms.value, 4), "GBps": round(nbytes / (ms.value * 1e-3) / 1e9, 1)}
+    return {"value": round(n * repeats / dt, 3), "unit": "pairs/s", "pairs_with_exact_VH_offsets": f"{ok}/{n}",
+            "kernel": "k_mips_u16 (two 16-bit columns per lane, packed maxima)", "bytes_per_sample": 2, "launches": launches,
+            "note": "tiles stored as uint16 samples = round(float tile * 65535); not the headline metric"}
 
 
 if __name__ == "__main__":

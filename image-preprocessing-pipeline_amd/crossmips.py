@@ -309,10 +309,13 @@ def tile_row_blocks(n_rows: int, world_size: int, n_cols: int | None = None):
 
 def compute_displacements(tiles, overlap_V: int, overlap_H: int, displ_max_V=S_DISPL_SEARCH_RADIUS_DEF,
                           displ_max_H=S_DISPL_SEARCH_RADIUS_DEF, displ_max_D=S_DISPL_SEARCH_RADIUS_DEF,
-                          rank: int = 0, world_size: int = 1, row_block=None):
+                          rank: int = 0, world_size: int = 1, row_block=None, sample_scale: float = 65535.0):
     """Pairwise displacement computation over one z-layer of a tile grid (step 2 of the stitcher).
 
-    ``tiles[r][c]`` are device-resident float32 (D, V, H) tensors of identical shape.  Pairs are independent
+    ``tiles[r][c]`` are device-resident float32 (D, V, H) tensors of identical shape -- or uint16 tensors holding the samples the
+    reference would have divided by ``sample_scale`` when it loaded the tiles (65535; 255 for 8-bit samples widened to 16 bits:
+    tiff2D.cpp:606-610): the records are identical, the MIP pass reads half the bytes (``mi_ncc_mips_batch_u16``; needs an even H and
+    at most 32 slices).  Pairs are independent
     (StackStitcher.cpp:223-374; the reference farms them out over MPI ranks, Parastitcher.py:1440-1560) -- no collective is
     involved.  Two ways to share a grid among ranks: ``row_block = (r0, r1)`` (see ``tile_row_blocks``): this rank computes the
     pairs that start in rows [r0, r1), and only the rows r0 .. min(r1, n_rows - 1) of ``tiles`` need to hold tensors (the others
@@ -338,8 +341,11 @@ def compute_displacements(tiles, overlap_V: int, overlap_H: int, displ_max_V=S_D
     dim_D, dim_V, dim_H = (int(s) for s in first.shape)
     for i in used:
         t = flat[i]
-        if tuple(t.shape) != (dim_D, dim_V, dim_H) or t.dtype != torch.float32 or not t.is_contiguous() or t.device != dev:
-            raise ValueError("all tiles must be contiguous float32 tensors of one shape on one device")
+        if tuple(t.shape) != (dim_D, dim_V, dim_H) or t.dtype != first.dtype or not t.is_contiguous() or t.device != dev:
+            raise ValueError("all tiles must be contiguous float32 (or uint16) tensors of one shape on one device")
+    if first.dtype not in (torch.float32, torch.uint16):
+        raise TypeError("stacks must be float32 (iom::real_t) or uint16 samples")
+    as_u16 = first.dtype == torch.uint16
     ptrs = (C.c_void_p * len(flat))(*[(t.data_ptr() if t is not None else None) for t in flat])
     a_idx = (C.c_int * n)(*[r * n_cols + c for r, c, _, _, _ in pairs])
     b_idx = (C.c_int * n)(*[rb * n_cols + cb for _, _, rb, cb, _ in pairs])
@@ -353,8 +359,12 @@ def compute_displacements(tiles, overlap_V: int, overlap_H: int, displ_max_V=S_D
     for q in range(n):                       # one parameter block per pair (the callee clamps wRangeThr_* in place)
         C.memmove(C.byref(params[q]), C.byref(p0), C.sizeof(NccParams))
     out = (NccDescr * n)()
-    check(lib().mi_ncc_mips_batch(dev.index, capi.current_stream_ptr(dev), n, ptrs, a_idx, b_idx, dim_D, dim_V, dim_H,
-                                  ni, nj, displ_max_D, displ_max_V, displ_max_H, side, params, out))
+    if as_u16:
+        check(lib().mi_ncc_mips_batch_u16(dev.index, capi.current_stream_ptr(dev), n, ptrs, float(sample_scale), a_idx, b_idx, dim_D, dim_V,
+                                          dim_H, ni, nj, displ_max_D, displ_max_V, displ_max_H, side, params, out))
+    else:
+        check(lib().mi_ncc_mips_batch(dev.index, capi.current_stream_ptr(dev), n, ptrs, a_idx, b_idx, dim_D, dim_V, dim_H,
+                                      ni, nj, displ_max_D, displ_max_V, displ_max_H, side, params, out))
     # the records of all pairs at once: NccDescr = 3 ints, 3 floats, 3 ints; evalReliability (DisplacementMIPNCC.cpp:130-147)
     # vectorised with the same float / double steps as the per-record method
     raw = np.frombuffer(out, dtype=np.int32).reshape(n, 9)

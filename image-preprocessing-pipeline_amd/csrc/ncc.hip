@@ -122,9 +122,35 @@ extern "C" int mi_ncc_mips_host(int dev, void* stream, const float* A, const flo
     return rc;
 }
 
+static int ncc_batch(int dev, void* stream, int n_pairs, const float* const* tiles, const int* a_idx, const int* b_idx, int dimk, int dimi,
+                     int dimj, const int* ni, const int* nj, int delayk, int delayi, int delayj, const int* side, mi_ncc_params* params,
+                     mi_ncc_descr* out, TileFmt fmt);
+
 extern "C" int mi_ncc_mips_batch(int dev, void* stream, int n_pairs, const float* const* tiles, const int* a_idx, const int* b_idx,
                                  int dimk, int dimi, int dimj, const int* ni, const int* nj, int delayk, int delayi, int delayj,
                                  const int* side, mi_ncc_params* params, mi_ncc_descr* out) {
+    return ncc_batch(dev, stream, n_pairs, tiles, a_idx, b_idx, dimk, dimi, dimj, ni, nj, delayk, delayi, delayj, side, params, out, TileFmt());
+}
+
+// The same batch on tiles kept as the 16-bit samples they were loaded from: tile value = sample / scale (65535, or 255 for 8-bit
+// samples widened to 16 bits: tiff2D.cpp:606-610); every result is identical to mi_ncc_mips_batch on the converted tiles.
+// Needs dimj even and dimk <= 32 (MI_ERR_UNSUPPORTED otherwise: convert the tiles and use the float entry).
+extern "C" int mi_ncc_mips_batch_u16(int dev, void* stream, int n_pairs, const unsigned short* const* tiles, float scale, const int* a_idx,
+                                     const int* b_idx, int dimk, int dimi, int dimj, const int* ni, const int* nj, int delayk, int delayi, int delayj,
+                                     const int* side, mi_ncc_params* params, mi_ncc_descr* out) {
+    if (!(scale > 0.0f)) return fail(MI_ERR_INVALID, "mi_ncc_mips_batch_u16: scale must be positive");
+    if (!mips_u16_ok(dimk, dimj, (size_t)dimi * dimj))
+        return fail(MI_ERR_UNSUPPORTED, "mi_ncc_mips_batch_u16: 16-bit tiles need an even row length and at most %d slices", 4 * MIP_KPW);
+    TileFmt fmt;
+    fmt.u16 = true;
+    fmt.scale = scale;
+    return ncc_batch(dev, stream, n_pairs, reinterpret_cast<const float* const*>(tiles), a_idx, b_idx, dimk, dimi, dimj, ni, nj, delayk, delayi, delayj,
+                     side, params, out, fmt);
+}
+
+static int ncc_batch(int dev, void* stream, int n_pairs, const float* const* tiles, const int* a_idx, const int* b_idx, int dimk, int dimi,
+                     int dimj, const int* ni, const int* nj, int delayk, int delayi, int delayj, const int* side, mi_ncc_params* params,
+                     mi_ncc_descr* out, TileFmt fmt) {
     MI_TRY(use_device(dev));
     MI_REQUIRE(n_pairs >= 0, "mi_ncc_mips_batch: negative pair count");
     if (n_pairs == 0) return MI_OK;
@@ -181,7 +207,7 @@ extern "C" int mi_ncc_mips_batch(int dev, void* stream, int n_pairs, const float
             f.pa.resize(n); f.pb.resize(n); f.pp.resize(n);
             for (int i = 0; i < n; ++i) { f.pa[i] = tiles[a_idx[idx[i]]]; f.pb[i] = tiles[b_idx[idx[i]]]; f.pp[i] = params[idx[i]]; }
             rc = ncc_lag_enqueue(dev, user, n, f.pa.data(), f.pb.data(), dimk, dimi, dimj, ni[q0], nj[q0], delayk, delayi, delayj, side[q0],
-                                 f.pp.data(), &f.job, serial_mips);
+                                 f.pp.data(), &f.job, serial_mips, fmt);
             if (rc != MI_OK) break;
         }
         if (rc == MI_OK && serial_mips && !flights.empty()) {
@@ -249,7 +275,7 @@ extern "C" int mi_ncc_mips_batch(int dev, void* stream, int n_pairs, const float
                 const int q = todo[qi];
                 Slot& sl = slot[k & 1];
                 rc = plan_pair(dimk, dimi, dimj, 0, ni[q], nj[q], delayk, delayi, delayj, side[q], &params[q], sl.pl);
-                if (rc == MI_OK) rc = pair_enqueue(sl.s, tiles[a_idx[q]], tiles[b_idx[q]], dimi, dimj, sl.pl, sl.ws);
+                if (rc == MI_OK) rc = pair_enqueue(sl.s, tiles[a_idx[q]], tiles[b_idx[q]], dimi, dimj, sl.pl, sl.ws, fmt);
             }
             const int fi = qi - NT;
             if (fi >= 0 && fi < n_todo && rc == MI_OK) {
@@ -305,6 +331,21 @@ extern "C" int mi_ncc_time_mips(int dev, void* stream, int n_pairs, const float*
     std::vector<const float*> pa(n_pairs), pb(n_pairs);
     for (int q = 0; q < n_pairs; ++q) { pa[q] = tiles[a_idx[q]]; pb[q] = tiles[b_idx[q]]; }
     return ncc_time_mips(dev, as_stream(stream), n_pairs, pa.data(), pb.data(), dimk, dimi, dimj, ni, nj, side, reps, ms_per_launch);
+}
+
+extern "C" int mi_ncc_time_mips_u16(int dev, void* stream, int n_pairs, const unsigned short* const* tiles, float scale, const int* a_idx,
+                                    const int* b_idx, int dimk, int dimi, int dimj, int ni, int nj, int side, int reps, float* ms_per_launch) {
+    MI_TRY(use_device(dev));
+    MI_REQUIRE(n_pairs > 0 && tiles && a_idx && b_idx && scale > 0.0f, "mi_ncc_time_mips_u16: invalid arguments");
+    std::vector<const float*> pa(n_pairs), pb(n_pairs);
+    for (int q = 0; q < n_pairs; ++q) {
+        pa[q] = reinterpret_cast<const float*>(tiles[a_idx[q]]);
+        pb[q] = reinterpret_cast<const float*>(tiles[b_idx[q]]);
+    }
+    TileFmt fmt;
+    fmt.u16 = true;
+    fmt.scale = scale;
+    return ncc_time_mips(dev, as_stream(stream), n_pairs, pa.data(), pb.data(), dimk, dimi, dimj, ni, nj, side, reps, ms_per_launch, fmt);
 }
 
 extern "C" int mi_ncc_compute_map_lag(int dev, void* stream, const float* mip1, const float* mip2, int dimu, int dimv, int delayu, int delayv,

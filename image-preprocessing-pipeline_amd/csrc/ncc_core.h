@@ -24,6 +24,15 @@ namespace mi {
 // cumulative counters behind mi_ncc_stats (defined in ncc.hip): pairs finished by the batched pipeline, pairs finished by the
 // per-pair (careful) path, entries recomputed in the two-pass form
 void ncc_count(int which, long long n);
+// Sample format of the tiles: float (iom::real_t, the reference's) or the 16-bit integers they were loaded from (k_mips_u16), with
+// the divisor that turns those into the reference's floats.  Tile pointers travel as `const float*` either way.
+#ifndef MI_TILE_FMT_DEFINED
+#define MI_TILE_FMT_DEFINED
+struct TileFmt {
+    bool u16 = false;
+    float scale = 65535.0f;
+};
+#endif
 }
 
 namespace {
@@ -247,6 +256,158 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
 }
 
+// ---- 16-bit tiles.  TeraStitcher turns the 8 / 16-bit samples of its TIFF tiles into floats in [0, 1] when it loads them (value /
+// 255 or / 65535, tiff2D.cpp:606-610) and compute_3_MIPs reads those; the division is monotonic, so the MIPs of the floats are the
+// divided MIPs of the integers, bit for bit.  k_mips_u16 reads the tiles as they are stored -- half the bytes of the pass that
+// dominates a batch -- and a lane takes TWO neighbouring columns as one packed 32-bit value: running maxima, column maxima and the
+// transpose reduction of the row maxima work on both halves at once (v_pk_max_u16), i.e. the same instructions as for one float
+// column move twice the voxels.  Only the results are divided (IEEE division: what numpy's float32 division gives the host mirror).
+typedef unsigned short mi_u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk_max_u16(unsigned a, unsigned b) {
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(mi_u16x2, a), __builtin_bit_cast(mi_u16x2, b)));
+}
+// rows_max16 for packed pairs: returns, in every lane, the packed maxima of row row_of_lane(lane) over the 64 lanes
+__device__ __forceinline__ unsigned rows_max16_pk(const unsigned (&v)[MIP_ROWS], int lane) {
+    unsigned w[8];
+    {
+        const bool up = lane & 1;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const unsigned mine = up ? v[i + 8] : v[i], send = up ? v[i] : v[i + 8];
+            w[i] = pk_max_u16(mine, (unsigned)__builtin_amdgcn_update_dpp(0, (int)send, 0xB1, 0xf, 0xf, false));
+        }
+    }
+    {
+        const bool up = lane & 2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned mine = up ? w[i + 4] : w[i], send = up ? w[i] : w[i + 4];
+            w[i] = pk_max_u16(mine, (unsigned)__builtin_amdgcn_update_dpp(0, (int)send, 0x4E, 0xf, 0xf, false));
+        }
+    }
+    {
+        const bool up = lane & 4;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const unsigned mine = up ? w[i + 2] : w[i], send = up ? w[i] : w[i + 2];
+            w[i] = pk_max_u16(mine, (unsigned)__shfl_xor((int)send, 4, 64));
+        }
+    }
+    {
+        const bool up = lane & 8;
+        const unsigned mine = up ? w[1] : w[0], send = up ? w[0] : w[1];
+        w[0] = pk_max_u16(mine, (unsigned)__shfl_xor((int)send, 8, 64));
+    }
+    w[0] = pk_max_u16(w[0], (unsigned)__shfl_xor((int)w[0], 16, 64));
+    w[0] = pk_max_u16(w[0], (unsigned)__shfl_xor((int)w[0], 32, 64));
+    return w[0];
+}
+
+// The views as in k_mips (grid z = 2 * pair + tile, tab / A / B, ai0 / aj0 of the first tile); a work-group owns 16 rows x 128
+// columns per band, column pairs aligned to the TILE rows (dimj and slice even: 32-bit loads).  Stacks of up to 4 * MIP_KPW slices.
+// `scale`: 65535 (255 for 8-bit samples widened to 16 bits).
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_mips_u16(
+    const unsigned short* __restrict__ A, const unsigned short* __restrict__ B, const unsigned short* const* __restrict__ tab, size_t pstride, int dimk,
+    int dimi_v, int dimj_v, size_t slice, int pitch, int ai0, int aj0, float scale, float* __restrict__ xy1, float* __restrict__ xy2,
+    float* __restrict__ yz_tmp, float* __restrict__ xz_tmp) {
+    extern __shared__ float xzp[];                    // [band][MIP_ROWS][dimk] row maxima, already divided
+    __shared__ unsigned xyb[MIP_NB][MIP_ROWS][128];   // xy maxima of the bands, one word per column (merged with LDS atomics)
+    __shared__ unsigned cacc[4][MIP_KPW][64];         // packed column maxima of the wave's slices
+    const bool second = blockIdx.z & 1;
+    const size_t poff = (size_t)(blockIdx.z >> 1) * pstride;
+    const unsigned short* vol = tab ? tab[blockIdx.z] : (second ? B : A);
+    if (!second) vol += (size_t)ai0 * pitch;
+    float* xy = (second ? xy2 : xy1) + poff;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int a0 = second ? 0 : aj0, alast = a0 + dimj_v - 1;    // first / last tile column of the view
+    const int cj = (a0 & ~127) + (int)blockIdx.x * 128 + 2 * lane;  // tile column of the lane's pair (even)
+    const int jv0 = cj - a0, jv1 = jv0 + 1;
+    const bool valid0 = jv0 >= 0 && jv0 < dimj_v, valid1 = jv1 >= 0 && jv1 < dimj_v;
+    // every load is unconditional (see k_mips): a pair outside the view reads the nearest pair inside, a pair that straddles the
+    // view's edge takes its inside column twice (byte permute with a lane-constant selector)
+    const int cc = min(max(cj, a0 & ~1), alast & ~1);
+    const unsigned sel = cc < a0 ? 0x03020302u : (cc + 1 > alast ? 0x01000100u : 0x03020100u);
+    unsigned* colacc = &cacc[wave][0][lane];
+#pragma unroll
+    for (int q = 0; q < MIP_KPW; ++q) colacc[q * 64] = 0u;
+    for (int e = threadIdx.x; e < MIP_NB * MIP_ROWS * 128; e += 256) (&xyb[0][0][0])[e] = 0u;
+    const int ib0 = __builtin_amdgcn_readfirstlane((int)blockIdx.y * MIP_NB * MIP_ROWS);
+    const int nbv = min(MIP_NB, (dimi_v - ib0 + MIP_ROWS - 1) / MIP_ROWS);
+    unsigned v[MIP_ROWS], vn[MIP_ROWS];
+    auto load_slice = [&](int bb, int k, unsigned (&dst)[MIP_ROWS]) {
+        const int i0 = ib0 + bb * MIP_ROWS, last = min(MIP_ROWS, dimi_v - i0) - 1;
+        typedef const unsigned __attribute__((address_space(1))) gword;
+        const unsigned short* p = vol + (size_t)k * slice + (size_t)i0 * pitch;  // wave-uniform
+#pragma unroll
+        for (int r = 0; r < MIP_ROWS; ++r) dst[r] = *(gword*)(p + (size_t)min(r, last) * pitch + cc);
+    };
+    if (wave < dimk) load_slice(0, wave, v);
+    __syncthreads();  // (xyb is zero)
+#pragma unroll 1
+    for (int b = 0; b < nbv; ++b) {
+        unsigned best[MIP_ROWS];
+#pragma unroll
+        for (int r = 0; r < MIP_ROWS; ++r) best[r] = 0u;
+        auto slice_step = [&](int k, unsigned (&cur)[MIP_ROWS], unsigned (&nxt)[MIP_ROWS]) {
+            const bool wrap = k + 4 >= dimk;  // (wave-uniform)
+            const int kn = __builtin_amdgcn_readfirstlane(wrap ? wave : k + 4), bn = __builtin_amdgcn_readfirstlane(wrap ? b + 1 : b);
+            load_slice(min(bn, nbv - 1), kn, nxt);
+            unsigned colmax = 0u;
+#pragma unroll
+            for (int r = 0; r < MIP_ROWS; ++r) {
+                cur[r] = __builtin_amdgcn_perm(cur[r], cur[r], sel);
+                best[r] = pk_max_u16(best[r], cur[r]);
+                colmax = pk_max_u16(colmax, cur[r]);
+            }
+            const unsigned rm = rows_max16_pk(cur, lane);
+            if (lane < 16) xzp[(b * MIP_ROWS + row_of_lane(lane)) * dimk + k] = (float)max(rm & 0xffffu, rm >> 16) / scale;
+            return colmax;
+        };
+        int k = wave, q = 0;
+#pragma unroll 1
+        for (; k + 4 < dimk; k += 8, q += 2) {
+            colacc[q * 64] = pk_max_u16(colacc[q * 64], slice_step(k, v, vn));
+            colacc[(q + 1) * 64] = pk_max_u16(colacc[(q + 1) * 64], slice_step(k + 4, vn, v));
+        }
+        if (k < dimk) {
+            colacc[q * 64] = pk_max_u16(colacc[q * 64], slice_step(k, v, vn));
+#pragma unroll
+            for (int r = 0; r < MIP_ROWS; ++r) v[r] = vn[r];
+        }
+#pragma unroll
+        for (int r = 0; r < MIP_ROWS; ++r) {
+            atomicMax(&xyb[b][r][2 * lane], best[r] & 0xffffu);
+            atomicMax(&xyb[b][r][2 * lane + 1], best[r] >> 16);
+        }
+    }
+    __syncthreads();
+    if (wave < nbv) {  // wave b stores band b
+        const int i0 = ib0 + wave * MIP_ROWS, rows = min(MIP_ROWS, dimi_v - i0);
+#pragma unroll
+        for (int r = 0; r < MIP_ROWS; ++r) {
+            if (r < rows) {
+                if (valid0) xy[(size_t)(i0 + r) * dimj_v + jv0] = (float)xyb[wave][r][2 * lane] / scale;
+                if (valid1) xy[(size_t)(i0 + r) * dimj_v + jv1] = (float)xyb[wave][r][2 * lane + 1] / scale;
+            }
+        }
+    }
+    {   // the rows of all bands * dimk: contiguous floats
+        float* dst = xz_tmp + (((size_t)blockIdx.z * gridDim.x + blockIdx.x) * dimi_v + ib0) * dimk;
+        const int total = min(nbv * MIP_ROWS, dimi_v - ib0) * dimk;
+        for (int e = threadIdx.x; e < total; e += 256) dst[e] = xzp[e];
+    }
+#pragma unroll
+    for (int q = 0; q < MIP_KPW; ++q) {
+        const int k = wave + 4 * q;
+        if (k < dimk) {
+            const unsigned c = colacc[q * 64];
+            float* row = yz_tmp + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * dimk + k) * dimj_v;
+            if (valid0) row[jv0] = (float)(c & 0xffffu) / scale;
+            if (valid1) row[jv1] = (float)(c >> 16) / scale;
+        }
+    }
+}
+
 // yz[j][k] = max over the row bands of yz_tmp[tile][band][k][j]; one lane per (k, j), tile = blockIdx.y = 2 * pair + which
 __global__ __launch_bounds__(256) void k_mips_yz(const float* __restrict__ yz_tmp, size_t pstride, int bands, int dimk, int dimj_v,
                                                   float* __restrict__ yz1, float* __restrict__ yz2) {
@@ -282,12 +443,29 @@ inline size_t mips_tmp_floats(int dimk, int dimi_v, int dimj_v) {
     const size_t bands = (size_t)mips_groups(dimk, dimi_v), cblocks = (dimj_v + 63) / 64 + 1;  // (+1: launch_mips aligns the blocks to the tile rows)
     return 2 * (bands * dimk * dimj_v + cblocks * (size_t)dimi_v * dimk);
 }
+inline bool mips_u16_ok(int dimk, int pitch, size_t slice) { return dimk <= 4 * MIP_KPW && pitch % 2 == 0 && slice % 2 == 0; }
+
 int launch_mips(hipStream_t s, const float* A, const float* B, const float* const* tab, int np, size_t pstride, int dimk, int dimi_v, int dimj_v,
                 size_t slice, int pitch, int ai0, int aj0, float* xy1, float* xz1, float* yz1, float* xy2, float* xz2, float* yz2, float* tmp,
-                hipEvent_t xy_done = nullptr) {  // recorded when the xy MIPs are final (k_mips), before the reductions of the other two
-    const int bands = mips_groups(dimk, dimi_v), cblocks = (dimj_v + (aj0 & 63) + 63) / 64;  // (see k_mips: band groups, aligned column blocks)
+                hipEvent_t xy_done = nullptr,  // recorded when the xy MIPs are final (k_mips), before the reductions of the other two
+                TileFmt fmt = TileFmt()) {
+    const int bands = mips_groups(dimk, dimi_v);
+    const int cblocks = fmt.u16 ? (dimj_v + (aj0 & 127) + 127) / 128 : (dimj_v + (aj0 & 63) + 63) / 64;  // (band groups, aligned column blocks)
     float* yz_tmp = tmp;
     float* xz_tmp = tmp + 2 * (size_t)np * bands * dimk * dimj_v;
+    if (fmt.u16) {
+        MI_REQUIRE(mips_u16_ok(dimk, pitch, slice), "16-bit tiles: stacks of up to %d slices with an even row length", 4 * MIP_KPW);
+        hipLaunchKernelGGL(k_mips_u16, dim3(cblocks, bands, 2 * np), dim3(256), sizeof(float) * MIP_ROWS * (size_t)dimk * MIP_NB, s,
+                           reinterpret_cast<const unsigned short*>(A), reinterpret_cast<const unsigned short*>(B),
+                           reinterpret_cast<const unsigned short* const*>(tab), pstride, dimk, dimi_v, dimj_v, slice, pitch, ai0, aj0, fmt.scale, xy1, xy2,
+                           yz_tmp, xz_tmp);
+        MI_TRY(launch_check("k_mips_u16"));
+        if (xy_done) MI_HIP(hipEventRecord(xy_done, s));
+        hipLaunchKernelGGL(k_mips_yz, dim3((dimk * dimj_v + 255) / 256, 2 * np), dim3(256), 0, s, yz_tmp, pstride, bands, dimk, dimj_v, yz1, yz2);
+        MI_TRY(launch_check("k_mips_yz"));
+        hipLaunchKernelGGL(k_mips_xz, dim3((dimk * dimi_v + 255) / 256, 2 * np), dim3(256), 0, s, xz_tmp, pstride, cblocks, dimk, dimi_v, xz1, xz2);
+        return launch_check("k_mips_xz");
+    }
     const size_t lds = sizeof(float) * MIP_ROWS * (size_t)dimk * mips_band_group(dimk);  // (k_mips: xzp)
     const bool via_lds = lds <= 32 * 1024;
     if (!via_lds) {  // very deep stacks: the xz MIPs are merged with atomicMax and must start at 0 (libcrossmips.cpp:319-337)
@@ -1201,7 +1379,7 @@ int plan_pair(int dimk, int dimi, int dimj, int nk, int ni, int nj, int delayk, 
 }
 
 // stage 1 of a pair: everything up to the D2H copy of the three NCC maps is enqueued on `s`, nothing is waited for
-int pair_enqueue(hipStream_t s, const float* A, const float* B, int dimi, int dimj, const PairPlan& pl, Workspace& ws) {
+int pair_enqueue(hipStream_t s, const float* A, const float* B, int dimi, int dimj, const PairPlan& pl, Workspace& ws, TileFmt fmt = TileFmt()) {
     const size_t need = pl.total_floats + pl.res_floats;
     if (ws.buf.bytes < sizeof(float) * need) MI_TRY(ws.buf.alloc(sizeof(float) * need));
     ws.floats = pl.total_floats;
@@ -1215,7 +1393,7 @@ int pair_enqueue(hipStream_t s, const float* A, const float* B, int dimi, int di
     }
     MI_TRY(launch_mips(s, A, B, nullptr, 1, 0, pl.dimk, pl.dimi_v, pl.dimj_v, (size_t)dimi * dimj, dimj, pl.ai0, pl.aj0, base + pl.g[0].mip1,
                        base + pl.g[1].mip1, base + pl.g[2].mip1, base + pl.g[0].mip2, base + pl.g[1].mip2, base + pl.g[2].mip2,
-                       ws.mip_tmp.as<float>()));
+                       ws.mip_tmp.as<float>(), nullptr, fmt));
     if (ws.sat.bytes < sizeof(double) * pl.sat_doubles) MI_TRY(ws.sat.alloc(sizeof(double) * pl.sat_doubles));
     for (int m = 0; m < 3; ++m) {
         const PlaneGeom& g = pl.g[m];

@@ -6,6 +6,14 @@
 
 namespace mi {
 
+#ifndef MI_TILE_FMT_DEFINED
+#define MI_TILE_FMT_DEFINED
+struct TileFmt {  // (see ncc_core.h)
+    bool u16 = false;
+    float scale = 65535.0f;
+};
+#endif
+
 // resolution below which a decision is not taken on lag-transform / summed-area-table values (MI_NCC_MARGIN, default 4e-6)
 float ncc_margin();
 // whether every plane of this geometry fits the lag transform (FFT length <= 8192, LDS)
@@ -17,17 +25,19 @@ struct LagJob;
 // defer_chains: only the MIP pass is enqueued; the caller enqueues the chains of all its jobs afterwards (ncc_lag_enqueue_chains)
 // behind an event it records on the MIP stream after the last job's MIP pass
 int ncc_lag_enqueue(int dev, hipStream_t s, int n, const float* const* a_ptrs, const float* const* b_ptrs, int dimk, int dimi, int dimj, int ni,
-                    int nj, int delayk, int delayi, int delayj, int side, mi_ncc_params* params, LagJob** job, bool defer_chains = false);
+                    int nj, int delayk, int delayi, int delayj, int side, mi_ncc_params* params, LagJob** job, bool defer_chains = false,
+                    TileFmt fmt = TileFmt());
 int ncc_lag_enqueue_chains(LagJob* job, hipEvent_t gate);
 hipStream_t ncc_lag_mip_stream(LagJob* job);
 int ncc_lag_finish(LagJob* job, mi_ncc_params* params, mi_ncc_descr* out, unsigned char* careful);
 void ncc_lag_abandon(LagJob* job);
 // both steps at once
 int ncc_lag_group(int dev, hipStream_t s, int n, const float* const* a_ptrs, const float* const* b_ptrs, int dimk, int dimi, int dimj, int ni,
-                  int nj, int delayk, int delayi, int delayj, int side, mi_ncc_params* params, mi_ncc_descr* out, unsigned char* careful);
+                  int nj, int delayk, int delayi, int delayj, int side, mi_ncc_params* params, mi_ncc_descr* out, unsigned char* careful,
+                  TileFmt fmt = TileFmt());
 int ncc_lag_map(int dev, hipStream_t s, const float* mip1, const float* mip2, int dimu, int dimv, int delayu, int delayv, float* map);
 int ncc_time_mips(int dev, hipStream_t s, int n, const float* const* a_ptrs, const float* const* b_ptrs, int dimk, int dimi, int dimj, int ni, int nj,
-                  int side, int reps, float* ms);
+                  int side, int reps, float* ms, TileFmt fmt = TileFmt());
 void ncc_lag_drop_cached(int dev);
 
 }  // namespace mi

@@ -1001,7 +1001,7 @@ static bool mip_gate() {
 }
 
 int ncc_lag_enqueue(int dev, hipStream_t s, int n, const float* const* a_ptrs, const float* const* b_ptrs, int dimk, int dimi, int dimj, int ni,
-                    int nj, int delayk, int delayi, int delayj, int side, mi_ncc_params* params, LagJob** job_out, bool defer_chains) {
+                    int nj, int delayk, int delayi, int delayj, int side, mi_ncc_params* params, LagJob** job_out, bool defer_chains, TileFmt fmt) {
     *job_out = nullptr;
     if (n <= 0) return MI_OK;
     std::unique_ptr<LagJob> job(new (std::nothrow) LagJob);
@@ -1090,7 +1090,7 @@ int ncc_lag_enqueue(int dev, hipStream_t s, int n, const float* const* a_ptrs, c
             MI_HIP(hipMemcpyAsync(dtab, htab + 2 * (size_t)(c0 + p0), sizeof(void*) * 2 * np, hipMemcpyHostToDevice, sm));
             MI_TRY(launch_mips(sm, nullptr, nullptr, dtab, np, pstride, pl.dimk, pl.dimi_v, pl.dimj_v, (size_t)dimi * dimj, dimj, pl.ai0, pl.aj0,
                                base + pl.g[0].mip1, base + pl.g[1].mip1, base + pl.g[2].mip1, base + pl.g[0].mip2, base + pl.g[1].mip2,
-                               base + pl.g[2].mip2, ws.mip_tmp.as<float>() + (size_t)p0 * tmp_floats, ws.ev_mip_xy[pi]));
+                               base + pl.g[2].mip2, ws.mip_tmp.as<float>() + (size_t)p0 * tmp_floats, ws.ev_mip_xy[pi], fmt));
             MI_HIP(hipEventRecord(ws.ev_mip[pi], sm));
             if (defer) continue;
             MI_TRY(enqueue_chains(*job, c0, p0, np, pi, ws.ev_mip[pi], ws.ev_mip_xy[pi]));
@@ -1229,9 +1229,9 @@ int ncc_lag_finish(LagJob* job_in, mi_ncc_params* params, mi_ncc_descr* out, uns
 void ncc_lag_abandon(LagJob* job) { delete job; }
 
 int ncc_lag_group(int dev, hipStream_t s, int n, const float* const* a_ptrs, const float* const* b_ptrs, int dimk, int dimi, int dimj, int ni,
-                  int nj, int delayk, int delayi, int delayj, int side, mi_ncc_params* params, mi_ncc_descr* out, unsigned char* careful) {
+                  int nj, int delayk, int delayi, int delayj, int side, mi_ncc_params* params, mi_ncc_descr* out, unsigned char* careful, TileFmt fmt) {
     LagJob* job = nullptr;
-    MI_TRY(ncc_lag_enqueue(dev, s, n, a_ptrs, b_ptrs, dimk, dimi, dimj, ni, nj, delayk, delayi, delayj, side, params, &job, false));
+    MI_TRY(ncc_lag_enqueue(dev, s, n, a_ptrs, b_ptrs, dimk, dimi, dimj, ni, nj, delayk, delayi, delayj, side, params, &job, false, fmt));
     return ncc_lag_finish(job, params, out, careful);
 }
 
@@ -1267,8 +1267,10 @@ int ncc_lag_map(int dev, hipStream_t s, const float* mip1, const float* mip2, in
 
 // average duration of ONE k_mips launch over n pairs (HIP events on `s` around `reps` launches; bench.py's roofline hook)
 int ncc_time_mips(int dev, hipStream_t s, int n, const float* const* a_ptrs, const float* const* b_ptrs, int dimk, int dimi, int dimj, int ni, int nj,
-                  int side, int reps, float* ms) {
+                  int side, int reps, float* ms, TileFmt fmt) {
     MI_REQUIRE(n > 0 && reps > 0 && ms && a_ptrs && b_ptrs, "mi_ncc_time_mips: invalid arguments");
+    MI_REQUIRE(!fmt.u16 || mips_u16_ok(dimk, dimj, (size_t)dimi * dimj), "mi_ncc_time_mips: 16-bit tiles need an even row length and at most %d slices",
+               4 * MIP_KPW);
     MI_REQUIRE(side == MI_NORTH_SOUTH || side == MI_WEST_EAST, "CrossMIPs: unexpected alignment configuration");
     const int dimi_v = side == MI_NORTH_SOUTH ? dimi - ni : dimi, dimj_v = side == MI_WEST_EAST ? dimj - nj : dimj;
     MI_REQUIRE(dimi_v > 0 && dimj_v > 0 && dimk > 0, "mi_ncc_time_mips: empty view");
@@ -1298,6 +1300,13 @@ int ncc_time_mips(int dev, hipStream_t s, int n, const float* const* a_ptrs, con
     const int knock = ke ? std::atoi(ke) : 0;
     for (int r = -1; r < reps; ++r) {  // r = -1: warm-up
         if (r == 0) MI_HIP(hipEventRecord(e0, s));
+        if (fmt.u16) {
+            const int aj0 = side == MI_WEST_EAST ? nj : 0;
+            hipLaunchKernelGGL(k_mips_u16, dim3((dimj_v + (aj0 & 127) + 127) / 128, bands, 2 * n), dim3(256), lds, s, (const unsigned short*)nullptr,
+                               (const unsigned short*)nullptr, tab.as<const unsigned short*>(), pstride, dimk, dimi_v, dimj_v, (size_t)dimi * dimj, dimj,
+                               side == MI_NORTH_SOUTH ? ni : 0, aj0, fmt.scale, o, o + xy + xz + yz, tmp.as<float>(), xz_tmp);
+            continue;
+        }
         hipLaunchKernelGGL(HIP_KERNEL_NAME(dimk <= 4 * MIP_KPW ? k_mips<true> : k_mips<false>), dim3(cblocks, bands, 2 * n), dim3(256), lds, s, (const float*)nullptr, (const float*)nullptr, tab.as<const float*>(),
                            pstride, dimk, dimi_v, dimj_v, (size_t)dimi * dimj, dimj, side == MI_NORTH_SOUTH ? ni : 0, side == MI_WEST_EAST ? nj : 0, o,
                            o + xy, o + xy + xz, o + xy + xz + yz, o + 2 * xy + xz + yz, o + 2 * xy + 2 * xz + yz, tmp.as<float>(), xz_tmp, knock);

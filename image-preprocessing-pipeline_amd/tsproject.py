@@ -266,6 +266,15 @@ class Project:
         d_raw.record_stream(torch.cuda.current_stream(device))
         return dst
 
+    def loadImageStackSamplesDevice(self, stk: Stack, z0: int, z1: int, device):
+        """The same slices as the 16-bit SAMPLES on the device (8-bit tiles widened) and the divisor that turns them into the
+        reference's floats (tiff2D.cpp:606-610): what ``crossmips.compute_displacements`` takes instead of float32 tiles -- half the
+        bytes across PCIe, in device memory and in the MIP pass, identical records."""
+        import torch
+        raw = self._read_slices(stk, z0, z1)
+        scale = 255.0 if raw.dtype == np.uint8 else 65535.0
+        return torch.from_numpy(np.ascontiguousarray(raw, dtype=np.uint16)).to(device), scale
+
     # ---- displacement bookkeeping
     def insertDisplacement(self, stk_A: Stack, stk_B: Stack, d: DisplacementMIPNCC):
         for k in range(3):
@@ -349,9 +358,18 @@ class Project:
             za, zb = z0 + a, z0 + b - 1
             complete = [[s.isComplete(za, zb) for s in row] for row in self.STACKS]
             if all(all(r) for r in complete):
-                tiles = [[self.loadImageStackDevice(s, za, zb, dev) for s in row] for row in self.STACKS]
-                res = crossmips.compute_displacements(tiles, overlap_V, overlap_H, displ_max_V, displ_max_H, displ_max_D,
-                                                      rank=rank, world_size=world_size)
+                # integer tiles stay integers on the device when the 16-bit MIP kernel takes the geometry (MI_NCC_FLOAT_TILES=1:
+                # always convert to float32 first, the reference's in-memory form)
+                as_samples = zb - za + 1 <= 32 and self.getStacksWidth() % 2 == 0 and not os.environ.get("MI_NCC_FLOAT_TILES")
+                loaded = [[self.loadImageStackSamplesDevice(s, za, zb, dev) for s in row] for row in self.STACKS] if as_samples else None
+                if loaded is not None and len({sc for row in loaded for _, sc in row}) == 1:
+                    tiles, scale = [[t for t, _ in row] for row in loaded], loaded[0][0][1]
+                    res = crossmips.compute_displacements(tiles, overlap_V, overlap_H, displ_max_V, displ_max_H, displ_max_D,
+                                                          rank=rank, world_size=world_size, sample_scale=scale)
+                else:
+                    tiles = [[self.loadImageStackDevice(s, za, zb, dev) for s in row] for row in self.STACKS]
+                    res = crossmips.compute_displacements(tiles, overlap_V, overlap_H, displ_max_V, displ_max_H, displ_max_D,
+                                                          rank=rank, world_size=world_size)
             else:   # sparse layer: pair by pair over the tiles that exist
                 res, q = {}, 0
                 for (r, c, rb, cb, direction) in crossmips.enumerate_pairs(self.N_ROWS, self.N_COLS):

@@ -157,6 +157,44 @@ def test_overlap_wider_than_the_prefetch_registers_vs_oracle(dev):
         assert np.allclose(np.array(got.NCC_maxs, np.float32), want["NCC_maxs"], atol=2e-6, equal_nan=True)
 
 
+@pytest.mark.parametrize("tile,ov,scale", [((30, 130, 150), 41, 65535.0), ((32, 96, 256), 64, 65535.0), ((9, 70, 258), 35, 255.0),
+                                           ((26, 200, 132), 57, 65535.0)])
+def test_u16_tiles_give_the_records_of_the_converted_tiles(dev, tile, ov, scale, monkeypatch):
+    """Tiles kept as the 16-bit samples they were loaded from (mi_ncc_mips_batch_u16: packed 16-bit MIP kernel, two columns per
+    lane) against the same tiles converted like the reference converts them (sample / 65535 or / 255, tiff2D.cpp:606-610): every
+    field of every record identical -- odd and even view origins, odd view widths, partial last bands, stacks that are no
+    multiple of four slices -- through the batched pipeline and through the per-pair path."""
+    from ipp_amd import crossmips
+    rng = np.random.default_rng(5)
+    R_, C_ = 2, 3
+    step_v, step_h = tile[1] - ov, tile[2] - ov
+    field = N.bead_field((tile[0] + 6, R_ * step_v + ov + 12, C_ * step_h + ov + 12), seed=21, density=1 / 250)
+    top = 255 if scale == 255.0 else 65535
+    q = np.clip(np.rint(field / max(float(field.max()), 1e-6) * top), 0, top).astype(np.uint16)
+    tiles16 = [[None] * C_ for _ in range(R_)]
+    for r in range(R_):
+        for c in range(C_):
+            v, h, d = (int(x) for x in rng.integers(-2, 3, size=3))
+            z0, y0, x0 = 3 + max(-1, min(1, d)), 6 + r * step_v + v, 6 + c * step_h + h
+            tiles16[r][c] = torch.from_numpy(np.ascontiguousarray(q[z0:z0 + tile[0], y0:y0 + tile[1], x0:x0 + tile[2]])).to(dev)
+    # (numpy's float32 division is the reference's `(real_t) sample / 65535.0f`; torch divides by multiplying with the reciprocal)
+    tilesf = [[torch.from_numpy(t.cpu().numpy().astype(np.float32) / np.float32(scale)).to(dev) for t in row] for row in tiles16]
+    for direct in ("0", "1"):
+        monkeypatch.setenv("MI_NCC_DIRECT", direct)
+        want = crossmips.compute_displacements(tilesf, ov, ov, 7, 7, 2)
+        got = crossmips.compute_displacements(tiles16, ov, ov, 7, 7, 2, sample_scale=scale)
+        assert got.keys() == want.keys() and len(got) == 2 * R_ * C_ - R_ - C_
+        for k in want:
+            a, b = got[k], want[k]
+            assert a.VHD_coords == b.VHD_coords and a.NCC_widths == b.NCC_widths and a.wRangeThrs == b.wRangeThrs, (direct, k)
+            assert np.array_equal(np.array(a.NCC_maxs, np.float32).view(np.uint32), np.array(b.NCC_maxs, np.float32).view(np.uint32)), (direct, k)
+    monkeypatch.delenv("MI_NCC_DIRECT")
+    # what the 16-bit kernel does not take is refused, not approximated: an odd row length
+    odd = [[t[:, :, :-1].contiguous() for t in row] for row in tiles16]
+    with pytest.raises(Exception):
+        crossmips.compute_displacements(odd, ov, ov - 1, 7, 7, 2, sample_scale=scale)
+
+
 def test_host_pointer_entry_and_errors(dev):
     import ctypes as C
     from ipp_amd import capi, crossmips
