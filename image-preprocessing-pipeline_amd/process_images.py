@@ -83,11 +83,34 @@ def load_tiles(folder: Path):
         row = []
         for c in range(cols):
             a = np.load(grid[(r, c)])
+            if a.dtype in (np.uint8, np.uint16):
+                row.append(np.ascontiguousarray(a))          # (kept as samples: see sample_scale / to_device below)
+                continue
             if np.issubdtype(a.dtype, np.integer):
                 a = a.astype(np.float32) / np.float32(np.iinfo(a.dtype).max)
             row.append(np.ascontiguousarray(a, dtype=np.float32))
         tiles.append(row)
     return tiles
+
+
+def layer_to_device(host_tiles, z0, z1, dev):
+    """One z layer of the grid on the device (loadImageStack(z0, z1)): float32 in [0, 1] like the reference's stacks (sample / 255 or
+    / 65535, tiff2D.cpp:606-610) -- or, when all tiles are 8 / 16-bit samples and the 16-bit MIP kernel takes the geometry, the
+    samples themselves as uint16 and the divisor (identical records, half the bytes).  Returns (tiles, sample_scale or None)."""
+    import numpy as np
+    import torch
+    kinds = {t.dtype for row in host_tiles for t in row}
+    width = host_tiles[0][0].shape[2]
+    if len(kinds) == 1 and next(iter(kinds)) in (np.dtype(np.uint8), np.dtype(np.uint16)) and z1 - z0 <= 32 and width % 2 == 0 \
+            and not os.environ.get("MI_NCC_FLOAT_TILES"):
+        scale = 255.0 if next(iter(kinds)) == np.dtype(np.uint8) else 65535.0
+        return [[torch.from_numpy(np.ascontiguousarray(t[z0:z1], dtype=np.uint16)).to(dev) for t in row] for row in host_tiles], scale
+
+    def as_float(t):
+        if t.dtype in (np.uint8, np.uint16):
+            return t[z0:z1].astype(np.float32) / np.float32(np.iinfo(t.dtype).max)
+        return t[z0:z1]
+    return [[torch.from_numpy(np.ascontiguousarray(as_float(t))).to(dev) for t in row] for row in host_tiles], None
 
 
 def read_pairs(path):
@@ -234,8 +257,9 @@ def main(argv=None):
     root = ET.Element("TeraStitcher", step="2", threshold=str(args.threshold), sV=str(args.sV), sH=str(args.sH), sD=str(args.sD),
                       subvoldim=str(args.subvoldim))
     for layer, (z0, z1) in enumerate(crossmips.subvolume_layers(dim_D, args.subvoldim)):
-        tiles = [[torch.from_numpy(t[z0:z1]).to(dev) for t in row] for row in host_tiles]   # loadImageStack(z0, z1)
-        res = crossmips.compute_displacements(tiles, args.oV, args.oH, args.sV, args.sH, args.sD, rank=rank, world_size=world)
+        tiles, scale = layer_to_device(host_tiles, z0, z1, dev)                              # loadImageStack(z0, z1)
+        res = crossmips.compute_displacements(tiles, args.oV, args.oH, args.sV, args.sH, args.sD, rank=rank, world_size=world,
+                                              **({} if scale is None else {"sample_scale": scale}))
         for (r, c, rb, cb, direction), d in sorted(res.items()):
             pair = ET.SubElement(root, "Pair", layer=str(layer), z0=str(z0), z1=str(z1), rowA=str(r), colA=str(c), rowB=str(rb),
                                  colB=str(cb), direction="NORTH_SOUTH" if direction == crossmips.dir_vertical else "WEST_EAST")
