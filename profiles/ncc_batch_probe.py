@@ -16,6 +16,9 @@ from ipp_amd.capi import NccDescr, NccParams, check, lib  # noqa: E402
 dev = torch.device("cuda", 0)
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 tiles, jit, step = bench_ncc.make_grid(dev)
+U16 = bool(os.environ.get("PROBE_U16"))   # the grid stored as 16-bit samples (mi_ncc_mips_batch_u16)
+if U16:
+    tiles = [[(t * 65535.0).round_().clamp_(0, 65535).to(torch.uint16) for t in row] for row in tiles]
 R, Cc = len(tiles), len(tiles[0])
 flat = [tiles[r][c] for r in range(R) for c in range(Cc)]
 pairs = list(crossmips.enumerate_pairs(R, Cc))
@@ -35,6 +38,10 @@ def raw():
     for q in range(n):
         lib().mi_ncc_default_params(*bench_ncc.DISPL, C.byref(params[q]))
     out = (NccDescr * n)()
+    if U16:
+        check(lib().mi_ncc_mips_batch_u16(dev.index, capi.current_stream_ptr(dev), n, ptrs, 65535.0, a_idx, b_idx, dim_D, dim_V, dim_H, ni, nj,
+                                          bench_ncc.DISPL[2], bench_ncc.DISPL[0], bench_ncc.DISPL[1], side, params, out))
+        return out
     check(lib().mi_ncc_mips_batch(dev.index, capi.current_stream_ptr(dev), n, ptrs, a_idx, b_idx, dim_D, dim_V, dim_H, ni, nj,
                                   bench_ncc.DISPL[2], bench_ncc.DISPL[0], bench_ncc.DISPL[1], side, params, out))
     return out
