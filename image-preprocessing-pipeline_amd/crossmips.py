@@ -346,6 +346,13 @@ def compute_displacements(tiles, overlap_V: int, overlap_H: int, displ_max_V=S_D
     if first.dtype not in (torch.float32, torch.uint16):
         raise TypeError("stacks must be float32 (iom::real_t) or uint16 samples")
     as_u16 = first.dtype == torch.uint16
+    if as_u16 and (dim_H % 2 or dim_D > 32):
+        # what the 16-bit MIP kernel does not take is converted the way the reference converts it when it loads a stack: a true
+        # float32 division, element by element (dividing by a Python scalar, torch multiplies by the reciprocal: 1 ulp off in places)
+        div = torch.full((), float(sample_scale), dtype=torch.float32, device=dev)
+        conv = {i: torch.div(flat[i].to(torch.float32), div) for i in used}
+        flat = [conv.get(i) for i in range(len(flat))]
+        as_u16 = False
     ptrs = (C.c_void_p * len(flat))(*[(t.data_ptr() if t is not None else None) for t in flat])
     a_idx = (C.c_int * n)(*[r * n_cols + c for r, c, _, _, _ in pairs])
     b_idx = (C.c_int * n)(*[rb * n_cols + cb for _, _, rb, cb, _ in pairs])

@@ -189,10 +189,23 @@ def test_u16_tiles_give_the_records_of_the_converted_tiles(dev, tile, ov, scale,
             assert a.VHD_coords == b.VHD_coords and a.NCC_widths == b.NCC_widths and a.wRangeThrs == b.wRangeThrs, (direct, k)
             assert np.array_equal(np.array(a.NCC_maxs, np.float32).view(np.uint32), np.array(b.NCC_maxs, np.float32).view(np.uint32)), (direct, k)
     monkeypatch.delenv("MI_NCC_DIRECT")
-    # what the 16-bit kernel does not take is refused, not approximated: an odd row length
-    odd = [[t[:, :, :-1].contiguous() for t in row] for row in tiles16]
-    with pytest.raises(Exception):
-        crossmips.compute_displacements(odd, ov, ov - 1, 7, 7, 2, sample_scale=scale)
+    # what the 16-bit kernel does not take (an odd row length) is converted on the device like the reference converts it: same records
+    odd16 = [[t[:, :, :-1].contiguous() for t in row] for row in tiles16]
+    oddf = [[t[:, :, :-1].contiguous() for t in row] for row in tilesf]
+    want = crossmips.compute_displacements(oddf, ov, ov - 1, 7, 7, 2)
+    got = crossmips.compute_displacements(odd16, ov, ov - 1, 7, 7, 2, sample_scale=scale)
+    for k in want:
+        assert got[k].VHD_coords == want[k].VHD_coords and got[k].NCC_widths == want[k].NCC_widths
+        assert np.array_equal(np.array(got[k].NCC_maxs, np.float32).view(np.uint32), np.array(want[k].NCC_maxs, np.float32).view(np.uint32))
+    # the C entry itself refuses such tiles
+    import ctypes as C
+    from ipp_amd import capi
+    z = (C.c_int * 1)(0)
+    one = (C.c_void_p * 1)(odd16[0][0].data_ptr())
+    p = (capi.NccParams * 1)()
+    o = (capi.NccDescr * 1)()
+    rc = capi.lib().mi_ncc_mips_batch_u16(dev.index, None, 1, one, 65535.0, z, z, *[int(v) for v in odd16[0][0].shape], z, z, 2, 7, 7, z, p, o)
+    assert rc != 0
 
 
 def test_host_pointer_entry_and_errors(dev):
