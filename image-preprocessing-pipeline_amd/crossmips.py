@@ -314,8 +314,8 @@ def compute_displacements(tiles, overlap_V: int, overlap_H: int, displ_max_V=S_D
 
     ``tiles[r][c]`` are device-resident float32 (D, V, H) tensors of identical shape -- or uint16 tensors holding the samples the
     reference would have divided by ``sample_scale`` when it loaded the tiles (65535; 255 for 8-bit samples widened to 16 bits:
-    tiff2D.cpp:606-610): the records are identical, the MIP pass reads half the bytes (``mi_ncc_mips_batch_u16``; needs an even H and
-    at most 32 slices).  Pairs are independent
+    tiff2D.cpp:606-610): the records are identical, the MIP pass reads half the bytes (``mi_ncc_mips_batch_u16``; tiles with an odd H or
+    more than 32 slices are converted on the device first).  Pairs are independent
     (StackStitcher.cpp:223-374; the reference farms them out over MPI ranks, Parastitcher.py:1440-1560) -- no collective is
     involved.  Two ways to share a grid among ranks: ``row_block = (r0, r1)`` (see ``tile_row_blocks``): this rank computes the
     pairs that start in rows [r0, r1), and only the rows r0 .. min(r1, n_rows - 1) of ``tiles`` need to hold tensors (the others
