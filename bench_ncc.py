@@ -97,10 +97,11 @@ def mips_roofline(dev, tiles, pairs):
     for name in ("r03_ncc_pmc_traffic.json", "r02_ncc_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
-                traffic = round(json.load(f)["kernels"]["k_mips"]["hbm_bytes_per_launch"])
+                ks = json.load(f)["kernels"]
+                traffic = round(ks[next(k for k in ("k_mips<true>", "k_mips") if k in ks)]["hbm_bytes_per_launch"])
             source = "profiles/" + name
             break
-        except (OSError, KeyError, ValueError):
+        except (OSError, KeyError, ValueError, StopIteration):
             continue
     if not (len(pairs) == 112 and launches == 2):
         traffic, source = None, None
