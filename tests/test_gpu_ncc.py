@@ -208,6 +208,33 @@ def test_u16_tiles_give_the_records_of_the_converted_tiles(dev, tile, ov, scale,
     assert rc != 0
 
 
+def test_u16_tiles_random_geometries(dev):
+    """Random stack depths (1 .. 32 slices, also fewer than the four waves of a work-group), tile sizes, overlaps and search ranges:
+    the 16-bit route equals the float route on every field (MI_TEST_SWEEP trials, default 10)."""
+    import os
+    from ipp_amd import crossmips
+    rng = np.random.default_rng(int(os.environ.get("MI_TEST_SWEEP_SEED", "77")))
+    for trial in range(int(os.environ.get("MI_TEST_SWEEP", "10"))):
+        D = int(rng.choice([1, 2, 3, 5, 8, 13, 26, 31, 32]))
+        V, H = int(rng.integers(40, 220)), 2 * int(rng.integers(20, 160))
+        ov_v, ov_h = int(rng.integers(26, min(V, 90))), int(rng.integers(26, min(H, 90)))
+        sv, sh, sd = int(rng.integers(2, 9)), int(rng.integers(2, 9)), int(rng.integers(0, 3))
+        grid = [[None, None], [None, None]]
+        for r in range(2):
+            for c in range(2):
+                a = N.bead_field((D, V, H), seed=500 + 17 * trial + 2 * r + c, density=1 / 200)
+                grid[r][c] = np.clip(np.rint(a / max(float(a.max()), 1e-6) * 65535), 0, 65535).astype(np.uint16)
+        t16 = [[torch.from_numpy(t).to(dev) for t in row] for row in grid]
+        tf = [[torch.from_numpy(t.astype(np.float32) / np.float32(65535.0)).to(dev) for t in row] for row in grid]
+        want = crossmips.compute_displacements(tf, ov_v, ov_h, sv, sh, sd)
+        got = crossmips.compute_displacements(t16, ov_v, ov_h, sv, sh, sd)
+        case = (trial, (D, V, H), (ov_v, ov_h), (sv, sh, sd))
+        for k in want:
+            a, b = got[k], want[k]
+            assert a.VHD_coords == b.VHD_coords and a.NCC_widths == b.NCC_widths and a.wRangeThrs == b.wRangeThrs, (case, k)
+            assert np.array_equal(np.array(a.NCC_maxs, np.float32).view(np.uint32), np.array(b.NCC_maxs, np.float32).view(np.uint32)), (case, k)
+
+
 def test_host_pointer_entry_and_errors(dev):
     import ctypes as C
     from ipp_amd import capi, crossmips
