@@ -260,20 +260,23 @@ def run(dev, repeats=10, cpu_workers=None, rank=0, world=1, dist=None, dist_devi
                             "tiles_resident_on_rank0": sum(t is not None for row in tiles for t in row)}
         roof["note"] = "k_mips launches of rank 0's pairs"
     if world == 1:
-        out["u16_tiles"] = u16_leg(dev, tiles, jit, step, repeats)
+        out["u16_tiles"] = int_leg(dev, tiles, jit, step, repeats, 16)
+        out["u8_tiles"] = int_leg(dev, tiles, jit, step, repeats, 8)
     if cpu_workers and world == 1:
         out["cpu_baseline"] = cpu_baseline(tiles, res, cpu_workers)
     return out
 
 
-def u16_leg(dev, tiles, jit, step, repeats):
-    """Secondary line, NOT the metric (BASELINE config 5 is defined on float32 tiles): the same grid with the tiles kept as 16-bit
-    samples, as the reference's TIFF tiles are stored (it divides them by 65535 when it loads them, tiff2D.cpp:606-610) --
-    mi_ncc_mips_batch_u16 reads those in its MIP pass and returns the records of the converted tiles bit for bit."""
+def int_leg(dev, tiles, jit, step, repeats, bits):
+    """Secondary lines, NOT the metric (BASELINE config 5 is defined on float32 tiles): the same grid with the tiles kept as 16-bit
+    (8-bit) samples, as the reference's TIFF tiles are stored (it divides them by 65535 (255) when it loads them,
+    tiff2D.cpp:606-610) -- mi_ncc_mips_batch_u16 (_u8) reads those in its MIP pass and returns the records of the converted tiles
+    bit for bit."""
     import ctypes as C
     import torch
     from ipp_amd import capi, crossmips
-    t16 = [[(t * 65535.0).round_().clamp_(0, 65535).to(torch.uint16) for t in row] for row in tiles]
+    top = float((1 << bits) - 1)
+    t16 = [[(t * top).round_().clamp_(0, top).to(torch.uint16 if bits == 16 else torch.uint8) for t in row] for row in tiles]
     res = crossmips.compute_displacements(t16, OVERLAP, OVERLAP, *DISPL)
     ok = 0
     for (r, c, rb, cb, direction), d in res.items():
@@ -298,13 +301,13 @@ def u16_leg(dev, tiles, jit, step, repeats):
         b_idx = (C.c_int * len(mine))(*[rb * Cc + cb for _, _, rb, cb, _ in mine])
         ni, nj = (di - OVERLAP if side == 0 else 0), (dj_ - OVERLAP if side == 1 else 0)
         ms = C.c_float()
-        capi.check(capi.lib().mi_ncc_time_mips_u16(dev.index, capi.current_stream_ptr(dev), len(mine), ptrs, 65535.0, a_idx, b_idx, dk, di, dj_, ni,
-                                                   nj, side, 5, C.byref(ms)))
-        nbytes = len(mine) * 2.0 * dk * (di - ni) * (dj_ - nj) * 2
+        timer = capi.lib().mi_ncc_time_mips_u16 if bits == 16 else capi.lib().mi_ncc_time_mips_u8
+        capi.check(timer(dev.index, capi.current_stream_ptr(dev), len(mine), ptrs, top, a_idx, b_idx, dk, di, dj_, ni, nj, side, 5, C.byref(ms)))
+        nbytes = len(mine) * 2.0 * dk * (di - ni) * (dj_ - nj) * (bits // 8)
         launches[name] = {"pairs_per_launch": len(mine), "launch_ms": round(ms.value, 4), "GBps": round(nbytes / (ms.value * 1e-3) / 1e9, 1)}
     return {"value": round(n * repeats / dt, 3), "unit": "pairs/s", "pairs_with_exact_VH_offsets": f"{ok}/{n}",
-            "kernel": "k_mips_u16 (two 16-bit columns per lane, packed maxima)", "bytes_per_sample": 2, "launches": launches,
-            "note": "tiles stored as uint16 samples = round(float tile * 65535); not the headline metric"}
+            "kernel": f"k_mips_int<{bits // 8}> ({32 // bits} columns per lane, packed 16-bit maxima)", "bytes_per_sample": bits // 8, "launches": launches,
+            "note": f"tiles stored as uint{bits} samples = round(float tile * {int(top)}); not the headline metric"}
 
 
 if __name__ == "__main__":

@@ -131,7 +131,10 @@ SIGNATURES = {
                                C.POINTER(NccParams), C.POINTER(NccDescr)]),
     "mi_ncc_mips_batch_u16": (_i, [_i, _vp, _i, C.POINTER(_vp), C.c_float, _ip, _ip, _i, _i, _i, _ip, _ip, _i, _i, _i, _ip,
                                    C.POINTER(NccParams), C.POINTER(NccDescr)]),
+    "mi_ncc_mips_batch_u8": (_i, [_i, _vp, _i, C.POINTER(_vp), C.c_float, _ip, _ip, _i, _i, _i, _ip, _ip, _i, _i, _i, _ip,
+                                  C.POINTER(NccParams), C.POINTER(NccDescr)]),
     "mi_ncc_time_mips": (_i, [_i, _vp, _i, C.POINTER(_vp), _ip, _ip, _i, _i, _i, _i, _i, _i, _i, C.POINTER(C.c_float)]),
+    "mi_ncc_time_mips_u8": (_i, [_i, _vp, _i, C.POINTER(_vp), C.c_float, _ip, _ip, _i, _i, _i, _i, _i, _i, _i, C.POINTER(C.c_float)]),
     "mi_ncc_time_mips_u16": (_i, [_i, _vp, _i, C.POINTER(_vp), C.c_float, _ip, _ip, _i, _i, _i, _i, _i, _i, _i, C.POINTER(C.c_float)]),
     "mi_ncc_stats": (None, [C.POINTER(C.c_longlong), _i]),
     "mi_ncc_compute_mips": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i] + [_vp] * 6),

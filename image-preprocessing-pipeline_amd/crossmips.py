@@ -309,13 +309,13 @@ def tile_row_blocks(n_rows: int, world_size: int, n_cols: int | None = None):
 
 def compute_displacements(tiles, overlap_V: int, overlap_H: int, displ_max_V=S_DISPL_SEARCH_RADIUS_DEF,
                           displ_max_H=S_DISPL_SEARCH_RADIUS_DEF, displ_max_D=S_DISPL_SEARCH_RADIUS_DEF,
-                          rank: int = 0, world_size: int = 1, row_block=None, sample_scale: float = 65535.0):
+                          rank: int = 0, world_size: int = 1, row_block=None, sample_scale=None):
     """Pairwise displacement computation over one z-layer of a tile grid (step 2 of the stitcher).
 
-    ``tiles[r][c]`` are device-resident float32 (D, V, H) tensors of identical shape -- or uint16 tensors holding the samples the
-    reference would have divided by ``sample_scale`` when it loaded the tiles (65535; 255 for 8-bit samples widened to 16 bits:
-    tiff2D.cpp:606-610): the records are identical, the MIP pass reads half the bytes (``mi_ncc_mips_batch_u16``; tiles with an odd H or
-    more than 32 slices are converted on the device first).  Pairs are independent
+    ``tiles[r][c]`` are device-resident float32 (D, V, H) tensors of identical shape -- or uint16 / uint8 tensors holding the samples
+    the reference would have divided by ``sample_scale`` when it loaded the tiles (default 65535 / 255: tiff2D.cpp:606-610): the
+    records are identical, the MIP pass reads half / a quarter of the bytes (``mi_ncc_mips_batch_u16`` / ``_u8``; tiles whose rows are
+    no whole 32-bit words or that have more than 32 slices are converted on the device first).  Pairs are independent
     (StackStitcher.cpp:223-374; the reference farms them out over MPI ranks, Parastitcher.py:1440-1560) -- no collective is
     involved.  Two ways to share a grid among ranks: ``row_block = (r0, r1)`` (see ``tile_row_blocks``): this rank computes the
     pairs that start in rows [r0, r1), and only the rows r0 .. min(r1, n_rows - 1) of ``tiles`` need to hold tensors (the others
@@ -343,16 +343,18 @@ def compute_displacements(tiles, overlap_V: int, overlap_H: int, displ_max_V=S_D
         t = flat[i]
         if tuple(t.shape) != (dim_D, dim_V, dim_H) or t.dtype != first.dtype or not t.is_contiguous() or t.device != dev:
             raise ValueError("all tiles must be contiguous float32 (or uint16) tensors of one shape on one device")
-    if first.dtype not in (torch.float32, torch.uint16):
-        raise TypeError("stacks must be float32 (iom::real_t) or uint16 samples")
-    as_u16 = first.dtype == torch.uint16
-    if as_u16 and (dim_H % 2 or dim_D > 32):
-        # what the 16-bit MIP kernel does not take is converted the way the reference converts it when it loads a stack: a true
+    if first.dtype not in (torch.float32, torch.uint16, torch.uint8):
+        raise TypeError("stacks must be float32 (iom::real_t) or uint16 / uint8 samples")
+    as_int = {torch.uint16: 2, torch.uint8: 1}.get(first.dtype, 0)
+    if as_int and sample_scale is None:
+        sample_scale = 65535.0 if as_int == 2 else 255.0
+    if as_int and (dim_H % (4 // as_int) or dim_D > 32):
+        # what the integer MIP kernels do not take is converted the way the reference converts it when it loads a stack: a true
         # float32 division, element by element (dividing by a Python scalar, torch multiplies by the reciprocal: 1 ulp off in places)
         div = torch.full((), float(sample_scale), dtype=torch.float32, device=dev)
         conv = {i: torch.div(flat[i].to(torch.float32), div) for i in used}
         flat = [conv.get(i) for i in range(len(flat))]
-        as_u16 = False
+        as_int = 0
     ptrs = (C.c_void_p * len(flat))(*[(t.data_ptr() if t is not None else None) for t in flat])
     a_idx = (C.c_int * n)(*[r * n_cols + c for r, c, _, _, _ in pairs])
     b_idx = (C.c_int * n)(*[rb * n_cols + cb for _, _, rb, cb, _ in pairs])
@@ -366,8 +368,8 @@ def compute_displacements(tiles, overlap_V: int, overlap_H: int, displ_max_V=S_D
     for q in range(n):                       # one parameter block per pair (the callee clamps wRangeThr_* in place)
         C.memmove(C.byref(params[q]), C.byref(p0), C.sizeof(NccParams))
     out = (NccDescr * n)()
-    if as_u16:
-        check(lib().mi_ncc_mips_batch_u16(dev.index, capi.current_stream_ptr(dev), n, ptrs, float(sample_scale), a_idx, b_idx, dim_D, dim_V,
+    if as_int:
+        check((lib().mi_ncc_mips_batch_u16 if as_int == 2 else lib().mi_ncc_mips_batch_u8)(dev.index, capi.current_stream_ptr(dev), n, ptrs, float(sample_scale), a_idx, b_idx, dim_D, dim_V,
                                           dim_H, ni, nj, displ_max_D, displ_max_V, displ_max_H, side, params, out))
     else:
         check(lib().mi_ncc_mips_batch(dev.index, capi.current_stream_ptr(dev), n, ptrs, a_idx, b_idx, dim_D, dim_V, dim_H,

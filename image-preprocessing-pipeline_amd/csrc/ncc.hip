@@ -132,20 +132,32 @@ extern "C" int mi_ncc_mips_batch(int dev, void* stream, int n_pairs, const float
     return ncc_batch(dev, stream, n_pairs, tiles, a_idx, b_idx, dimk, dimi, dimj, ni, nj, delayk, delayi, delayj, side, params, out, TileFmt());
 }
 
-// The same batch on tiles kept as the 16-bit samples they were loaded from: tile value = sample / scale (65535, or 255 for 8-bit
-// samples widened to 16 bits: tiff2D.cpp:606-610); every result is identical to mi_ncc_mips_batch on the converted tiles.
-// Needs dimj even and dimk <= 32 (MI_ERR_UNSUPPORTED otherwise: convert the tiles and use the float entry).
-extern "C" int mi_ncc_mips_batch_u16(int dev, void* stream, int n_pairs, const unsigned short* const* tiles, float scale, const int* a_idx,
-                                     const int* b_idx, int dimk, int dimi, int dimj, const int* ni, const int* nj, int delayk, int delayi, int delayj,
-                                     const int* side, mi_ncc_params* params, mi_ncc_descr* out) {
-    if (!(scale > 0.0f)) return fail(MI_ERR_INVALID, "mi_ncc_mips_batch_u16: scale must be positive");
-    if (!mips_u16_ok(dimk, dimj, (size_t)dimi * dimj))
-        return fail(MI_ERR_UNSUPPORTED, "mi_ncc_mips_batch_u16: 16-bit tiles need an even row length and at most %d slices", 4 * MIP_KPW);
+// The same batch on tiles kept as the integer samples they were loaded from: tile value = sample / scale (65535 for 16-bit, 255 for
+// 8-bit samples: tiff2D.cpp:606-610); every result is identical to mi_ncc_mips_batch on the converted tiles.  Needs rows of whole
+// 32-bit words (dimj even / a multiple of 4) and dimk <= 32 (MI_ERR_UNSUPPORTED otherwise: convert the tiles, use the float entry).
+static int ncc_batch_int(const char* who, int bytes, int dev, void* stream, int n_pairs, const void* const* tiles, float scale, const int* a_idx,
+                         const int* b_idx, int dimk, int dimi, int dimj, const int* ni, const int* nj, int delayk, int delayi, int delayj,
+                         const int* side, mi_ncc_params* params, mi_ncc_descr* out) {
+    if (!(scale > 0.0f)) return fail(MI_ERR_INVALID, "%s: scale must be positive", who);
+    if (!mips_int_ok(bytes, dimk, dimj, (size_t)dimi * dimj))
+        return fail(MI_ERR_UNSUPPORTED, "%s: integer tiles need rows of whole 32-bit words and at most %d slices", who, 4 * MIP_KPW);
     TileFmt fmt;
-    fmt.u16 = true;
+    fmt.bytes = bytes;
     fmt.scale = scale;
     return ncc_batch(dev, stream, n_pairs, reinterpret_cast<const float* const*>(tiles), a_idx, b_idx, dimk, dimi, dimj, ni, nj, delayk, delayi, delayj,
                      side, params, out, fmt);
+}
+extern "C" int mi_ncc_mips_batch_u16(int dev, void* stream, int n_pairs, const unsigned short* const* tiles, float scale, const int* a_idx,
+                                     const int* b_idx, int dimk, int dimi, int dimj, const int* ni, const int* nj, int delayk, int delayi, int delayj,
+                                     const int* side, mi_ncc_params* params, mi_ncc_descr* out) {
+    return ncc_batch_int("mi_ncc_mips_batch_u16", 2, dev, stream, n_pairs, reinterpret_cast<const void* const*>(tiles), scale, a_idx, b_idx, dimk, dimi,
+                         dimj, ni, nj, delayk, delayi, delayj, side, params, out);
+}
+extern "C" int mi_ncc_mips_batch_u8(int dev, void* stream, int n_pairs, const unsigned char* const* tiles, float scale, const int* a_idx,
+                                    const int* b_idx, int dimk, int dimi, int dimj, const int* ni, const int* nj, int delayk, int delayi, int delayj,
+                                    const int* side, mi_ncc_params* params, mi_ncc_descr* out) {
+    return ncc_batch_int("mi_ncc_mips_batch_u8", 1, dev, stream, n_pairs, reinterpret_cast<const void* const*>(tiles), scale, a_idx, b_idx, dimk, dimi,
+                         dimj, ni, nj, delayk, delayi, delayj, side, params, out);
 }
 
 static int ncc_batch(int dev, void* stream, int n_pairs, const float* const* tiles, const int* a_idx, const int* b_idx, int dimk, int dimi,
@@ -333,19 +345,29 @@ extern "C" int mi_ncc_time_mips(int dev, void* stream, int n_pairs, const float*
     return ncc_time_mips(dev, as_stream(stream), n_pairs, pa.data(), pb.data(), dimk, dimi, dimj, ni, nj, side, reps, ms_per_launch);
 }
 
-extern "C" int mi_ncc_time_mips_u16(int dev, void* stream, int n_pairs, const unsigned short* const* tiles, float scale, const int* a_idx,
-                                    const int* b_idx, int dimk, int dimi, int dimj, int ni, int nj, int side, int reps, float* ms_per_launch) {
+static int time_mips_int(int bytes, int dev, void* stream, int n_pairs, const void* const* tiles, float scale, const int* a_idx, const int* b_idx,
+                         int dimk, int dimi, int dimj, int ni, int nj, int side, int reps, float* ms_per_launch) {
     MI_TRY(use_device(dev));
-    MI_REQUIRE(n_pairs > 0 && tiles && a_idx && b_idx && scale > 0.0f, "mi_ncc_time_mips_u16: invalid arguments");
+    MI_REQUIRE(n_pairs > 0 && tiles && a_idx && b_idx && scale > 0.0f, "mi_ncc_time_mips_u%d: invalid arguments", 8 * bytes);
     std::vector<const float*> pa(n_pairs), pb(n_pairs);
     for (int q = 0; q < n_pairs; ++q) {
         pa[q] = reinterpret_cast<const float*>(tiles[a_idx[q]]);
         pb[q] = reinterpret_cast<const float*>(tiles[b_idx[q]]);
     }
     TileFmt fmt;
-    fmt.u16 = true;
+    fmt.bytes = bytes;
     fmt.scale = scale;
     return ncc_time_mips(dev, as_stream(stream), n_pairs, pa.data(), pb.data(), dimk, dimi, dimj, ni, nj, side, reps, ms_per_launch, fmt);
+}
+extern "C" int mi_ncc_time_mips_u16(int dev, void* stream, int n_pairs, const unsigned short* const* tiles, float scale, const int* a_idx,
+                                    const int* b_idx, int dimk, int dimi, int dimj, int ni, int nj, int side, int reps, float* ms_per_launch) {
+    return time_mips_int(2, dev, stream, n_pairs, reinterpret_cast<const void* const*>(tiles), scale, a_idx, b_idx, dimk, dimi, dimj, ni, nj, side, reps,
+                         ms_per_launch);
+}
+extern "C" int mi_ncc_time_mips_u8(int dev, void* stream, int n_pairs, const unsigned char* const* tiles, float scale, const int* a_idx,
+                                   const int* b_idx, int dimk, int dimi, int dimj, int ni, int nj, int side, int reps, float* ms_per_launch) {
+    return time_mips_int(1, dev, stream, n_pairs, reinterpret_cast<const void* const*>(tiles), scale, a_idx, b_idx, dimk, dimi, dimj, ni, nj, side, reps,
+                         ms_per_launch);
 }
 
 extern "C" int mi_ncc_compute_map_lag(int dev, void* stream, const float* mip1, const float* mip2, int dimu, int dimv, int delayu, int delayv,

@@ -24,12 +24,12 @@ namespace mi {
 // cumulative counters behind mi_ncc_stats (defined in ncc.hip): pairs finished by the batched pipeline, pairs finished by the
 // per-pair (careful) path, entries recomputed in the two-pass form
 void ncc_count(int which, long long n);
-// Sample format of the tiles: float (iom::real_t, the reference's) or the 16-bit integers they were loaded from (k_mips_u16), with
+// Sample format of the tiles: float (iom::real_t, the reference's) or the 8 / 16-bit integers they were loaded from (k_mips_int), with
 // the divisor that turns those into the reference's floats.  Tile pointers travel as `const float*` either way.
 #ifndef MI_TILE_FMT_DEFINED
 #define MI_TILE_FMT_DEFINED
 struct TileFmt {
-    bool u16 = false;
+    int bytes = 4;  // 4: float; 2 / 1: the integer samples the tiles were loaded from
     float scale = 65535.0f;
 };
 #endif
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 
 // ---- 16-bit tiles.  TeraStitcher turns the 8 / 16-bit samples of its TIFF tiles into floats in [0, 1] when it loads them (value /
 // 255 or / 65535, tiff2D.cpp:606-610) and compute_3_MIPs reads those; the division is monotonic, so the MIPs of the floats are the
-// divided MIPs of the integers, bit for bit.  k_mips_u16 reads the tiles as they are stored -- half the bytes of the pass that
+// divided MIPs of the integers, bit for bit.  k_mips_int reads the tiles as they are stored -- half or a quarter of the bytes of the pass that
 // dominates a batch -- and a lane takes TWO neighbouring columns as one packed 32-bit value: running maxima, column maxima and the
 // transpose reduction of the row maxima work on both halves at once (v_pk_max_u16), i.e. the same instructions as for one float
 // column move twice the voxels.  Only the results are divided (IEEE division: what numpy's float32 division gives the host mirror).
@@ -303,91 +303,137 @@ __device__ __forceinline__ unsigned rows_max16_pk(const unsigned (&v)[MIP_ROWS],
     return w[0];
 }
 
-// The views as in k_mips (grid z = 2 * pair + tile, tab / A / B, ai0 / aj0 of the first tile); a work-group owns 16 rows x 128
-// columns per band, column pairs aligned to the TILE rows (dimj and slice even: 32-bit loads).  Stacks of up to 4 * MIP_KPW slices.
-// `scale`: 65535 (255 for 8-bit samples widened to 16 bits).
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_mips_u16(
-    const unsigned short* __restrict__ A, const unsigned short* __restrict__ B, const unsigned short* const* __restrict__ tab, size_t pstride, int dimk,
+// The views as in k_mips (grid z = 2 * pair + tile, tab / A / B, ai0 / aj0 of the first tile).  BYTES = 2: a lane's word holds two
+// columns, a work-group owns 16 rows x 128 columns per band and walks MIP_NB bands.  BYTES = 1: four columns per word, taken apart
+// into two packed pairs (even / odd bytes) that go through the same packed instructions -- 16 rows x 256 columns per band, half
+// as many bands per work-group (the xy maxima of its bands wait in LDS, one word per column).  Words are aligned to the TILE rows
+// (dimj and the slice size a multiple of 4 / BYTES samples: 32-bit loads).  Stacks of up to 4 * MIP_KPW slices.
+// `scale`: 65535 for 16-bit, 255 for 8-bit samples (tiff2D.cpp:606-610).
+template <int BYTES>
+struct IntTiles {
+    static constexpr int P = BYTES == 2 ? 1 : 2;  // packed pairs per word
+    static constexpr int C = 2 * P;               // columns per lane
+    static constexpr int NB = MIP_NB / P;         // row bands per work-group
+    static constexpr int W = 64 * C;              // columns per work-group
+};
+template <int BYTES>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_mips_int(
+    const unsigned char* __restrict__ A, const unsigned char* __restrict__ B, const unsigned char* const* __restrict__ tab, size_t pstride, int dimk,
     int dimi_v, int dimj_v, size_t slice, int pitch, int ai0, int aj0, float scale, float* __restrict__ xy1, float* __restrict__ xy2,
     float* __restrict__ yz_tmp, float* __restrict__ xz_tmp) {
-    extern __shared__ float xzp[];                    // [band][MIP_ROWS][dimk] row maxima, already divided
-    __shared__ unsigned xyb[MIP_NB][MIP_ROWS][128];   // xy maxima of the bands, one word per column (merged with LDS atomics)
-    __shared__ unsigned cacc[4][MIP_KPW][64];         // packed column maxima of the wave's slices
+    using G = IntTiles<BYTES>;
+    constexpr int P = G::P, C = G::C, NB = G::NB;
+    extern __shared__ float xzp[];                     // [band][MIP_ROWS][dimk] row maxima, already divided
+    __shared__ unsigned xyb[NB][MIP_ROWS][64 * C];     // xy maxima of the bands, one word per column (merged with LDS atomics)
+    __shared__ unsigned cacc[4][MIP_KPW][P][64];       // packed column maxima of the wave's slices
     const bool second = blockIdx.z & 1;
     const size_t poff = (size_t)(blockIdx.z >> 1) * pstride;
-    const unsigned short* vol = tab ? tab[blockIdx.z] : (second ? B : A);
-    if (!second) vol += (size_t)ai0 * pitch;
+    const unsigned char* vol = tab ? tab[blockIdx.z] : (second ? B : A);
+    if (!second) vol += (size_t)ai0 * pitch * BYTES;
     float* xy = (second ? xy2 : xy1) + poff;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int a0 = second ? 0 : aj0, alast = a0 + dimj_v - 1;    // first / last tile column of the view
-    const int cj = (a0 & ~127) + (int)blockIdx.x * 128 + 2 * lane;  // tile column of the lane's pair (even)
-    const int jv0 = cj - a0, jv1 = jv0 + 1;
-    const bool valid0 = jv0 >= 0 && jv0 < dimj_v, valid1 = jv1 >= 0 && jv1 < dimj_v;
-    // every load is unconditional (see k_mips): a pair outside the view reads the nearest pair inside, a pair that straddles the
-    // view's edge takes its inside column twice (byte permute with a lane-constant selector)
-    const int cc = min(max(cj, a0 & ~1), alast & ~1);
-    const unsigned sel = cc < a0 ? 0x03020302u : (cc + 1 > alast ? 0x01000100u : 0x03020100u);
-    unsigned* colacc = &cacc[wave][0][lane];
+    const int a0 = second ? 0 : aj0, alast = a0 + dimj_v - 1;          // first / last tile column of the view
+    const int cj = (a0 & ~(G::W - 1)) + (int)blockIdx.x * G::W + C * lane;  // tile column of the lane's word
+    const int jv0 = cj - a0;                                             // view column of its first sample
+    // every load is unconditional (see k_mips): a word outside the view reads the nearest word inside, a word that straddles the
+    // view's edge takes its nearest inside sample in place of the outside ones (byte permute with a lane-constant selector)
+    const int cc = min(max(cj, a0 & ~(C - 1)), alast & ~(C - 1));
+    unsigned sel;
+    if (BYTES == 2) {
+        sel = cc < a0 ? 0x03020302u : (cc + 1 > alast ? 0x01000100u : 0x03020100u);
+    } else {
+        const int f = max(0, a0 - cc), l = min(3, alast - cc);
+        sel = 0;
 #pragma unroll
-    for (int q = 0; q < MIP_KPW; ++q) colacc[q * 64] = 0u;
-    for (int e = threadIdx.x; e < MIP_NB * MIP_ROWS * 128; e += 256) (&xyb[0][0][0])[e] = 0u;
-    const int ib0 = __builtin_amdgcn_readfirstlane((int)blockIdx.y * MIP_NB * MIP_ROWS);
-    const int nbv = min(MIP_NB, (dimi_v - ib0 + MIP_ROWS - 1) / MIP_ROWS);
+        for (int bb = 0; bb < 4; ++bb) sel |= (unsigned)min(max(bb, f), l) << (8 * bb);
+    }
+    // column c of the lane's word sits in half h of packed pair p
+    auto col_of = [](int p, int h) { return BYTES == 2 ? h : 2 * h + p; };
+    unsigned* colacc = &cacc[wave][0][0][lane];  // [q][p]: q * P * 64 + p * 64
+#pragma unroll
+    for (int q = 0; q < MIP_KPW * P; ++q) colacc[q * 64] = 0u;
+    for (int e = threadIdx.x; e < NB * MIP_ROWS * 64 * C; e += 256) (&xyb[0][0][0])[e] = 0u;
+    const int ib0 = __builtin_amdgcn_readfirstlane((int)blockIdx.y * NB * MIP_ROWS);
+    const int nbv = min(NB, (dimi_v - ib0 + MIP_ROWS - 1) / MIP_ROWS);
     unsigned v[MIP_ROWS], vn[MIP_ROWS];
     auto load_slice = [&](int bb, int k, unsigned (&dst)[MIP_ROWS]) {
         const int i0 = ib0 + bb * MIP_ROWS, last = min(MIP_ROWS, dimi_v - i0) - 1;
         typedef const unsigned __attribute__((address_space(1))) gword;
-        const unsigned short* p = vol + (size_t)k * slice + (size_t)i0 * pitch;  // wave-uniform
+        const unsigned char* p = vol + ((size_t)k * slice + (size_t)i0 * pitch + cc) * BYTES;  // (+ cc: per lane)
 #pragma unroll
-        for (int r = 0; r < MIP_ROWS; ++r) dst[r] = *(gword*)(p + (size_t)min(r, last) * pitch + cc);
+        for (int r = 0; r < MIP_ROWS; ++r) dst[r] = *(gword*)(p + (size_t)min(r, last) * pitch * BYTES);
     };
     if (wave < dimk) load_slice(0, wave, v);
     __syncthreads();  // (xyb is zero)
 #pragma unroll 1
     for (int b = 0; b < nbv; ++b) {
-        unsigned best[MIP_ROWS];
+        unsigned best[P][MIP_ROWS];
 #pragma unroll
-        for (int r = 0; r < MIP_ROWS; ++r) best[r] = 0u;
-        auto slice_step = [&](int k, unsigned (&cur)[MIP_ROWS], unsigned (&nxt)[MIP_ROWS]) {
+        for (int p = 0; p < P; ++p)
+#pragma unroll
+            for (int r = 0; r < MIP_ROWS; ++r) best[p][r] = 0u;
+        // one slice: the packed column maxima of its pairs go to colacc[q]
+        auto slice_step = [&](int k, int q, unsigned (&cur)[MIP_ROWS], unsigned (&nxt)[MIP_ROWS]) {
             const bool wrap = k + 4 >= dimk;  // (wave-uniform)
             const int kn = __builtin_amdgcn_readfirstlane(wrap ? wave : k + 4), bn = __builtin_amdgcn_readfirstlane(wrap ? b + 1 : b);
             load_slice(min(bn, nbv - 1), kn, nxt);
-            unsigned colmax = 0u;
+            unsigned colmax[P];
+#pragma unroll
+            for (int p = 0; p < P; ++p) colmax[p] = 0u;
 #pragma unroll
             for (int r = 0; r < MIP_ROWS; ++r) {
-                cur[r] = __builtin_amdgcn_perm(cur[r], cur[r], sel);
-                best[r] = pk_max_u16(best[r], cur[r]);
-                colmax = pk_max_u16(colmax, cur[r]);
+                const unsigned w = __builtin_amdgcn_perm(cur[r], cur[r], sel);
+                if (BYTES == 2) {
+                    best[0][r] = pk_max_u16(best[0][r], w);
+                    colmax[0] = pk_max_u16(colmax[0], w);
+                    cur[r] = w;
+                } else {
+                    const unsigned e = w & 0x00ff00ffu, o = (w >> 8) & 0x00ff00ffu;
+                    best[0][r] = pk_max_u16(best[0][r], e);
+                    best[P - 1][r] = pk_max_u16(best[P - 1][r], o);
+                    colmax[0] = pk_max_u16(colmax[0], e);
+                    colmax[P - 1] = pk_max_u16(colmax[P - 1], o);
+                    cur[r] = pk_max_u16(e, o);  // (the row maximum does not care which column)
+                }
             }
             const unsigned rm = rows_max16_pk(cur, lane);
             if (lane < 16) xzp[(b * MIP_ROWS + row_of_lane(lane)) * dimk + k] = (float)max(rm & 0xffffu, rm >> 16) / scale;
-            return colmax;
+#pragma unroll
+            for (int p = 0; p < P; ++p) colacc[(q * P + p) * 64] = pk_max_u16(colacc[(q * P + p) * 64], colmax[p]);
         };
         int k = wave, q = 0;
 #pragma unroll 1
         for (; k + 4 < dimk; k += 8, q += 2) {
-            colacc[q * 64] = pk_max_u16(colacc[q * 64], slice_step(k, v, vn));
-            colacc[(q + 1) * 64] = pk_max_u16(colacc[(q + 1) * 64], slice_step(k + 4, vn, v));
+            slice_step(k, q, v, vn);
+            slice_step(k + 4, q + 1, vn, v);
         }
         if (k < dimk) {
-            colacc[q * 64] = pk_max_u16(colacc[q * 64], slice_step(k, v, vn));
+            slice_step(k, q, v, vn);
 #pragma unroll
             for (int r = 0; r < MIP_ROWS; ++r) v[r] = vn[r];
         }
 #pragma unroll
-        for (int r = 0; r < MIP_ROWS; ++r) {
-            atomicMax(&xyb[b][r][2 * lane], best[r] & 0xffffu);
-            atomicMax(&xyb[b][r][2 * lane + 1], best[r] >> 16);
-        }
+        for (int r = 0; r < MIP_ROWS; ++r)
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                atomicMax(&xyb[b][r][C * lane + col_of(p, 0)], best[p][r] & 0xffffu);
+                atomicMax(&xyb[b][r][C * lane + col_of(p, 1)], best[p][r] >> 16);
+            }
     }
     __syncthreads();
-    if (wave < nbv) {  // wave b stores band b
-        const int i0 = ib0 + wave * MIP_ROWS, rows = min(MIP_ROWS, dimi_v - i0);
+    {   // 4 / NB waves share a band's rows
+        constexpr int WPB = 4 / NB, RPW = MIP_ROWS / WPB;
+        const int bnd = wave % NB, r0 = (wave / NB) * RPW;
+        if (bnd < nbv) {
+            const int i0 = ib0 + bnd * MIP_ROWS, rows = min(MIP_ROWS, dimi_v - i0);
 #pragma unroll
-        for (int r = 0; r < MIP_ROWS; ++r) {
-            if (r < rows) {
-                if (valid0) xy[(size_t)(i0 + r) * dimj_v + jv0] = (float)xyb[wave][r][2 * lane] / scale;
-                if (valid1) xy[(size_t)(i0 + r) * dimj_v + jv1] = (float)xyb[wave][r][2 * lane + 1] / scale;
+            for (int rr = 0; rr < RPW; ++rr) {
+                const int r = r0 + rr;
+                if (r < rows) {
+#pragma unroll
+                    for (int c = 0; c < C; ++c)
+                        if (jv0 + c >= 0 && jv0 + c < dimj_v) xy[(size_t)(i0 + r) * dimj_v + jv0 + c] = (float)xyb[bnd][r][C * lane + c] / scale;
+                }
             }
         }
     }
@@ -400,10 +446,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
     for (int q = 0; q < MIP_KPW; ++q) {
         const int k = wave + 4 * q;
         if (k < dimk) {
-            const unsigned c = colacc[q * 64];
             float* row = yz_tmp + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * dimk + k) * dimj_v;
-            if (valid0) row[jv0] = (float)(c & 0xffffu) / scale;
-            if (valid1) row[jv1] = (float)(c >> 16) / scale;
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                const unsigned c = colacc[(q * P + p) * 64];
+                const int j0 = jv0 + col_of(p, 0), j1 = jv0 + col_of(p, 1);
+                if (j0 >= 0 && j0 < dimj_v) row[j0] = (float)(c & 0xffffu) / scale;
+                if (j1 >= 0 && j1 < dimj_v) row[j1] = (float)(c >> 16) / scale;
+            }
         }
     }
 }
@@ -440,26 +490,41 @@ inline int mips_groups(int dimk, int dimi_v) {
     return (dimi_v + per - 1) / per;
 }
 inline size_t mips_tmp_floats(int dimk, int dimi_v, int dimj_v) {
-    const size_t bands = (size_t)mips_groups(dimk, dimi_v), cblocks = (dimj_v + 63) / 64 + 1;  // (+1: launch_mips aligns the blocks to the tile rows)
+    // (an upper bound over the sample formats: the 8-bit kernel walks two bands per group, the float kernel has the narrowest column
+    // blocks; +1: launch_mips aligns the blocks to the tile rows)
+    const size_t bands = std::max<size_t>(mips_groups(dimk, dimi_v), (dimi_v + 2 * MIP_ROWS - 1) / (2 * MIP_ROWS)), cblocks = (dimj_v + 63) / 64 + 1;
     return 2 * (bands * dimk * dimj_v + cblocks * (size_t)dimi_v * dimk);
 }
-inline bool mips_u16_ok(int dimk, int pitch, size_t slice) { return dimk <= 4 * MIP_KPW && pitch % 2 == 0 && slice % 2 == 0; }
+inline bool mips_int_ok(int bytes, int dimk, int pitch, size_t slice) {
+    const int per = 4 / bytes;  // samples per 32-bit word
+    return (bytes == 1 || bytes == 2) && dimk <= 4 * MIP_KPW && pitch % per == 0 && slice % per == 0;
+}
+// launch geometry of the MIP kernel of a sample format: row bands per work-group, columns per work-group
+inline int mips_fmt_bands(int bytes, int dimk) { return bytes == 4 ? mips_band_group(dimk) : (bytes == 2 ? IntTiles<2>::NB : IntTiles<1>::NB); }
+inline int mips_fmt_width(int bytes) { return bytes == 4 ? 64 : (bytes == 2 ? IntTiles<2>::W : IntTiles<1>::W); }
 
 int launch_mips(hipStream_t s, const float* A, const float* B, const float* const* tab, int np, size_t pstride, int dimk, int dimi_v, int dimj_v,
                 size_t slice, int pitch, int ai0, int aj0, float* xy1, float* xz1, float* yz1, float* xy2, float* xz2, float* yz2, float* tmp,
                 hipEvent_t xy_done = nullptr,  // recorded when the xy MIPs are final (k_mips), before the reductions of the other two
                 TileFmt fmt = TileFmt()) {
-    const int bands = mips_groups(dimk, dimi_v);
-    const int cblocks = fmt.u16 ? (dimj_v + (aj0 & 127) + 127) / 128 : (dimj_v + (aj0 & 63) + 63) / 64;  // (band groups, aligned column blocks)
+    const int nb = mips_fmt_bands(fmt.bytes, dimk), wcol = mips_fmt_width(fmt.bytes);
+    const int bands = (dimi_v + MIP_ROWS * nb - 1) / (MIP_ROWS * nb);
+    const int cblocks = (dimj_v + (aj0 & (wcol - 1)) + wcol - 1) / wcol;  // (band groups, column blocks aligned to the tile rows)
     float* yz_tmp = tmp;
     float* xz_tmp = tmp + 2 * (size_t)np * bands * dimk * dimj_v;
-    if (fmt.u16) {
-        MI_REQUIRE(mips_u16_ok(dimk, pitch, slice), "16-bit tiles: stacks of up to %d slices with an even row length", 4 * MIP_KPW);
-        hipLaunchKernelGGL(k_mips_u16, dim3(cblocks, bands, 2 * np), dim3(256), sizeof(float) * MIP_ROWS * (size_t)dimk * MIP_NB, s,
-                           reinterpret_cast<const unsigned short*>(A), reinterpret_cast<const unsigned short*>(B),
-                           reinterpret_cast<const unsigned short* const*>(tab), pstride, dimk, dimi_v, dimj_v, slice, pitch, ai0, aj0, fmt.scale, xy1, xy2,
-                           yz_tmp, xz_tmp);
-        MI_TRY(launch_check("k_mips_u16"));
+    if (fmt.bytes != 4) {
+        MI_REQUIRE(mips_int_ok(fmt.bytes, dimk, pitch, slice), "integer tiles: stacks of up to %d slices, rows of whole 32-bit words", 4 * MIP_KPW);
+        const size_t lds = sizeof(float) * MIP_ROWS * (size_t)dimk * nb;
+        const unsigned char* a8 = reinterpret_cast<const unsigned char*>(A);
+        const unsigned char* b8 = reinterpret_cast<const unsigned char*>(B);
+        const unsigned char* const* t8 = reinterpret_cast<const unsigned char* const*>(tab);
+        if (fmt.bytes == 2)
+            hipLaunchKernelGGL(k_mips_int<2>, dim3(cblocks, bands, 2 * np), dim3(256), lds, s, a8, b8, t8, pstride, dimk, dimi_v, dimj_v, slice, pitch,
+                               ai0, aj0, fmt.scale, xy1, xy2, yz_tmp, xz_tmp);
+        else
+            hipLaunchKernelGGL(k_mips_int<1>, dim3(cblocks, bands, 2 * np), dim3(256), lds, s, a8, b8, t8, pstride, dimk, dimi_v, dimj_v, slice, pitch,
+                               ai0, aj0, fmt.scale, xy1, xy2, yz_tmp, xz_tmp);
+        MI_TRY(launch_check("k_mips_int"));
         if (xy_done) MI_HIP(hipEventRecord(xy_done, s));
         hipLaunchKernelGGL(k_mips_yz, dim3((dimk * dimj_v + 255) / 256, 2 * np), dim3(256), 0, s, yz_tmp, pstride, bands, dimk, dimj_v, yz1, yz2);
         MI_TRY(launch_check("k_mips_yz"));

@@ -9,7 +9,7 @@ namespace mi {
 #ifndef MI_TILE_FMT_DEFINED
 #define MI_TILE_FMT_DEFINED
 struct TileFmt {  // (see ncc_core.h)
-    bool u16 = false;
+    int bytes = 4;
     float scale = 65535.0f;
 };
 #endif

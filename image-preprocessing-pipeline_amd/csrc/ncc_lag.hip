@@ -1277,9 +1277,8 @@ int ncc_lag_map(int dev, hipStream_t s, const float* mip1, const float* mip2, in
 int ncc_time_mips(int dev, hipStream_t s, int n, const float* const* a_ptrs, const float* const* b_ptrs, int dimk, int dimi, int dimj, int ni, int nj,
                   int side, int reps, float* ms, TileFmt fmt) {
     MI_REQUIRE(n > 0 && reps > 0 && ms && a_ptrs && b_ptrs, "mi_ncc_time_mips: invalid arguments");
-    MI_REQUIRE(!fmt.u16 || mips_u16_ok(dimk, dimj, (size_t)dimi * dimj), "mi_ncc_time_mips: 16-bit tiles need an even row length and at most %d slices",
-               4 * MIP_KPW);
-    MI_REQUIRE(side == MI_NORTH_SOUTH || side == MI_WEST_EAST, "CrossMIPs: unexpected alignment configuration");
+    MI_REQUIRE(fmt.bytes == 4 || mips_int_ok(fmt.bytes, dimk, dimj, (size_t)dimi * dimj),
+               "mi_ncc_time_mips: integer tiles need rows of whole 32-bit words and at most %d slices", 4 * MIP_KPW);
     const int dimi_v = side == MI_NORTH_SOUTH ? dimi - ni : dimi, dimj_v = side == MI_WEST_EAST ? dimj - nj : dimj;
     MI_REQUIRE(dimi_v > 0 && dimj_v > 0 && dimk > 0, "mi_ncc_time_mips: empty view");
     const size_t xy = (size_t)dimi_v * dimj_v, xz = (size_t)dimi_v * dimk, yz = (size_t)dimj_v * dimk;
@@ -1293,8 +1292,9 @@ int ncc_time_mips(int dev, hipStream_t s, int n, const float* const* a_ptrs, con
     MI_HIP(hipMemcpyAsync(tab.p, h.data(), sizeof(void*) * 2 * n, hipMemcpyHostToDevice, s));
     MI_HIP(hipStreamSynchronize(s));
     float* o = out.as<float>();
-    const int bands = mips_groups(dimk, dimi_v), cblocks = (dimj_v + 63) / 64;
-    const size_t lds = sizeof(float) * MIP_ROWS * (size_t)dimk * mips_band_group(dimk);
+    const int nb = mips_fmt_bands(fmt.bytes, dimk);
+    const int bands = (dimi_v + MIP_ROWS * nb - 1) / (MIP_ROWS * nb), cblocks = (dimj_v + 63) / 64;
+    const size_t lds = sizeof(float) * MIP_ROWS * (size_t)dimk * nb;
     MI_REQUIRE(lds <= 32 * 1024, "mi_ncc_time_mips: stack too deep for the timed variant");
     float* xz_tmp = tmp.as<float>() + 2 * (size_t)n * bands * dimk * dimj_v;
     struct Events {  // (destroyed on every path out of this function)
@@ -1308,11 +1308,18 @@ int ncc_time_mips(int dev, hipStream_t s, int n, const float* const* a_ptrs, con
     const int knock = ke ? std::atoi(ke) : 0;
     for (int r = -1; r < reps; ++r) {  // r = -1: warm-up
         if (r == 0) MI_HIP(hipEventRecord(e0, s));
-        if (fmt.u16) {
-            const int aj0 = side == MI_WEST_EAST ? nj : 0;
-            hipLaunchKernelGGL(k_mips_u16, dim3((dimj_v + (aj0 & 127) + 127) / 128, bands, 2 * n), dim3(256), lds, s, (const unsigned short*)nullptr,
-                               (const unsigned short*)nullptr, tab.as<const unsigned short*>(), pstride, dimk, dimi_v, dimj_v, (size_t)dimi * dimj, dimj,
-                               side == MI_NORTH_SOUTH ? ni : 0, aj0, fmt.scale, o, o + xy + xz + yz, tmp.as<float>(), xz_tmp);
+        if (fmt.bytes != 4) {
+            const int aj0 = side == MI_WEST_EAST ? nj : 0, wcol = mips_fmt_width(fmt.bytes);
+            const dim3 grid((dimj_v + (aj0 & (wcol - 1)) + wcol - 1) / wcol, bands, 2 * n);
+            const unsigned char* const* t8 = tab.as<const unsigned char*>();
+            if (fmt.bytes == 2)
+                hipLaunchKernelGGL(k_mips_int<2>, grid, dim3(256), lds, s, (const unsigned char*)nullptr, (const unsigned char*)nullptr, t8, pstride, dimk,
+                                   dimi_v, dimj_v, (size_t)dimi * dimj, dimj, side == MI_NORTH_SOUTH ? ni : 0, aj0, fmt.scale, o, o + xy + xz + yz,
+                                   tmp.as<float>(), xz_tmp);
+            else
+                hipLaunchKernelGGL(k_mips_int<1>, grid, dim3(256), lds, s, (const unsigned char*)nullptr, (const unsigned char*)nullptr, t8, pstride, dimk,
+                                   dimi_v, dimj_v, (size_t)dimi * dimj, dimj, side == MI_NORTH_SOUTH ? ni : 0, aj0, fmt.scale, o, o + xy + xz + yz,
+                                   tmp.as<float>(), xz_tmp);
             continue;
         }
         hipLaunchKernelGGL(HIP_KERNEL_NAME(dimk <= 4 * MIP_KPW ? k_mips<true> : k_mips<false>), dim3(cblocks, bands, 2 * n), dim3(256), lds, s, (const float*)nullptr, (const float*)nullptr, tab.as<const float*>(),

@@ -103,8 +103,11 @@ def layer_to_device(host_tiles, z0, z1, dev):
     width = host_tiles[0][0].shape[2]
     if len(kinds) == 1 and next(iter(kinds)) in (np.dtype(np.uint8), np.dtype(np.uint16)) and z1 - z0 <= 32 and width % 2 == 0 \
             and not os.environ.get("MI_NCC_FLOAT_TILES"):
-        scale = 255.0 if next(iter(kinds)) == np.dtype(np.uint8) else 65535.0
-        return [[torch.from_numpy(np.ascontiguousarray(t[z0:z1], dtype=np.uint16)).to(dev) for t in row] for row in host_tiles], scale
+        kind = next(iter(kinds))
+        scale = 255.0 if kind == np.dtype(np.uint8) else 65535.0
+        if kind == np.dtype(np.uint8) and width % 4:
+            kind = np.dtype(np.uint16)                  # (rows that are no whole 32-bit words: widened, the 16-bit kernel takes them)
+        return [[torch.from_numpy(np.ascontiguousarray(t[z0:z1], dtype=kind)).to(dev) for t in row] for row in host_tiles], scale
 
     def as_float(t):
         if t.dtype in (np.uint8, np.uint16):

@@ -267,13 +267,16 @@ class Project:
         return dst
 
     def loadImageStackSamplesDevice(self, stk: Stack, z0: int, z1: int, device):
-        """The same slices as the 16-bit SAMPLES on the device (8-bit tiles widened) and the divisor that turns them into the
-        reference's floats (tiff2D.cpp:606-610): what ``crossmips.compute_displacements`` takes instead of float32 tiles -- half the
-        bytes across PCIe, in device memory and in the MIP pass, identical records."""
+        """The same slices as the integer SAMPLES on the device and the divisor that turns them into the reference's floats
+        (tiff2D.cpp:606-610): what ``crossmips.compute_displacements`` takes instead of float32 tiles -- a half / a quarter of the
+        bytes across PCIe, in device memory and in the MIP pass, identical records.  8-bit tiles whose rows are no whole 32-bit
+        words are widened to 16 bits (the 16-bit kernel needs an even width only)."""
         import torch
         raw = self._read_slices(stk, z0, z1)
         scale = 255.0 if raw.dtype == np.uint8 else 65535.0
-        return torch.from_numpy(np.ascontiguousarray(raw, dtype=np.uint16)).to(device), scale
+        if raw.dtype == np.uint8 and raw.shape[2] % 4:
+            raw = raw.astype(np.uint16)
+        return torch.from_numpy(np.ascontiguousarray(raw)).to(device), scale
 
     # ---- displacement bookkeeping
     def insertDisplacement(self, stk_A: Stack, stk_B: Stack, d: DisplacementMIPNCC):

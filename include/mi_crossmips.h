@@ -71,7 +71,7 @@ int mi_ncc_mips_batch(int dev, void* stream, int n_pairs, const float* const* ti
                       const int* ni, const int* nj, int delayk, int delayi, int delayj, const int* side,
                       mi_ncc_params* params, mi_ncc_descr* out);
 
-/* The same batch on tiles kept as the 16-bit samples they were loaded from.  The reference turns the samples of its TIFF tiles into
+/* The same batch on tiles kept as the integer samples they were loaded from (16-bit; mi_ncc_mips_batch_u8: 8-bit).  The reference turns the samples of its TIFF tiles into
  * iom::real_t in [0, 1] when it loads them (value / 255 or / 65535, iomanager tiff2D.cpp:606-610) and compute_3_MIPs
  * (compute_funcs.cu:502-521) reads those floats; the division is monotonic, so the MIPs of the floats are the divided MIPs of the
  * integers and everything downstream is unchanged: every field of every result equals mi_ncc_mips_batch on the converted tiles.
@@ -81,6 +81,10 @@ int mi_ncc_mips_batch_u16(int dev, void* stream, int n_pairs, const unsigned sho
                           const int* a_idx, const int* b_idx, int dimk, int dimi, int dimj,
                           const int* ni, const int* nj, int delayk, int delayi, int delayj, const int* side,
                           mi_ncc_params* params, mi_ncc_descr* out);
+int mi_ncc_mips_batch_u8(int dev, void* stream, int n_pairs, const unsigned char* const* tiles, float scale,
+                         const int* a_idx, const int* b_idx, int dimk, int dimi, int dimj,
+                         const int* ni, const int* nj, int delayk, int delayi, int delayj, const int* side,
+                         mi_ncc_params* params, mi_ncc_descr* out);
 
 /* Cumulative counters of this process: out3[0] pairs finished by the batched pipeline, out3[1] pairs finished by the per-pair
  * path (geometries the lag transform does not take, MI_NCC_DIRECT=1, and pairs handed back because a decision was inside the
@@ -93,9 +97,11 @@ void mi_ncc_stats(long long* out3, int reset);
  * n_pairs pairs of one geometry, HIP events on `stream` around `reps` launches.  Synchronises. */
 int mi_ncc_time_mips(int dev, void* stream, int n_pairs, const float* const* tiles, const int* a_idx, const int* b_idx,
                      int dimk, int dimi, int dimj, int ni, int nj, int side, int reps, float* ms_per_launch);
-/* ... of the 16-bit MIP kernel (2 bytes per sample) */
+/* ... of the integer MIP kernels (2 bytes / 1 byte per sample) */
 int mi_ncc_time_mips_u16(int dev, void* stream, int n_pairs, const unsigned short* const* tiles, float scale, const int* a_idx,
                          const int* b_idx, int dimk, int dimi, int dimj, int ni, int nj, int side, int reps, float* ms_per_launch);
+int mi_ncc_time_mips_u8(int dev, void* stream, int n_pairs, const unsigned char* const* tiles, float scale, const int* a_idx,
+                        const int* b_idx, int dimk, int dimi, int dimj, int ni, int nj, int side, int reps, float* ms_per_launch);
 
 /* ---- building blocks (exposed for parity tests against the reference's exported helpers) ------ */
 

@@ -158,7 +158,7 @@ def test_overlap_wider_than_the_prefetch_registers_vs_oracle(dev):
 
 
 @pytest.mark.parametrize("tile,ov,scale", [((30, 130, 150), 41, 65535.0), ((32, 96, 256), 64, 65535.0), ((9, 70, 258), 35, 255.0),
-                                           ((26, 200, 132), 57, 65535.0)])
+                                           ((26, 200, 132), 57, 65535.0), ((31, 90, 268), 75, 255.0), ((12, 300, 96), 33, 255.0)])
 def test_u16_tiles_give_the_records_of_the_converted_tiles(dev, tile, ov, scale, monkeypatch):
     """Tiles kept as the 16-bit samples they were loaded from (mi_ncc_mips_batch_u16: packed 16-bit MIP kernel, two columns per
     lane) against the same tiles converted like the reference converts them (sample / 65535 or / 255, tiff2D.cpp:606-610): every
@@ -188,6 +188,13 @@ def test_u16_tiles_give_the_records_of_the_converted_tiles(dev, tile, ov, scale,
             a, b = got[k], want[k]
             assert a.VHD_coords == b.VHD_coords and a.NCC_widths == b.NCC_widths and a.wRangeThrs == b.wRangeThrs, (direct, k)
             assert np.array_equal(np.array(a.NCC_maxs, np.float32).view(np.uint32), np.array(b.NCC_maxs, np.float32).view(np.uint32)), (direct, k)
+        if scale == 255.0:   # ... and the same samples as 8-bit tensors (four columns per lane)
+            tiles8 = [[t.to(torch.uint8) for t in row] for row in tiles16]
+            got8 = crossmips.compute_displacements(tiles8, ov, ov, 7, 7, 2)
+            for k in want:
+                a, b = got8[k], want[k]
+                assert a.VHD_coords == b.VHD_coords and a.NCC_widths == b.NCC_widths and a.wRangeThrs == b.wRangeThrs, (direct, k)
+                assert np.array_equal(np.array(a.NCC_maxs, np.float32).view(np.uint32), np.array(b.NCC_maxs, np.float32).view(np.uint32)), (direct, k)
     monkeypatch.delenv("MI_NCC_DIRECT")
     # what the 16-bit kernel does not take (an odd row length) is converted on the device like the reference converts it: same records
     odd16 = [[t[:, :, :-1].contiguous() for t in row] for row in tiles16]
@@ -224,8 +231,12 @@ def test_u16_tiles_random_geometries(dev):
             for c in range(2):
                 a = N.bead_field((D, V, H), seed=500 + 17 * trial + 2 * r + c, density=1 / 200)
                 grid[r][c] = np.clip(np.rint(a / max(float(a.max()), 1e-6) * 65535), 0, 65535).astype(np.uint16)
+        top = 65535.0
+        if trial % 2:   # 8-bit samples (rows of whole words when H is a multiple of 4, converted on the device otherwise)
+            grid = [[(t >> 8).astype(np.uint8) for t in row] for row in grid]
+            top = 255.0
         t16 = [[torch.from_numpy(t).to(dev) for t in row] for row in grid]
-        tf = [[torch.from_numpy(t.astype(np.float32) / np.float32(65535.0)).to(dev) for t in row] for row in grid]
+        tf = [[torch.from_numpy(t.astype(np.float32) / np.float32(top)).to(dev) for t in row] for row in grid]
         want = crossmips.compute_displacements(tf, ov_v, ov_h, sv, sh, sd)
         got = crossmips.compute_displacements(t16, ov_v, ov_h, sv, sh, sd)
         case = (trial, (D, V, H), (ov_v, ov_h), (sv, sh, sd))
