@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmi_ipp.so")
+# MI_IPP_PROBES=1 (profiles/ only): the build with the experiment switches compiled in (make -C csrc probes)
+LIB_PATH = os.path.join(_HERE, "libmi_ipp_probes.so" if os.environ.get("MI_IPP_PROBES") == "1" else "libmi_ipp.so")
 
 MI_OK = 0
 IPC_HANDLE_BYTES = 64  # MI_IPC_HANDLE_BYTES

@@ -1,0 +1,453 @@
+// fp64 complex FFT of length N = R1 * 2^a (R1 = 1, 3 or 9) held in LDS, built for the lag transforms of the batched MIP-NCC
+// pipeline (ncc_lag.hip; the cross terms of compute_NCC, compute_funcs.cu:1163-1292, for every shift at once).
+//
+// Why it looks like this (gfx950, MI355X_MICROARCH.md "LDS"): a 16-byte LDS store costs 13 cycles per wave instruction against 4
+// for a 16-byte read, so a transform is bound by the number of times its points travel THROUGH LDS, not by its arithmetic.
+//   * Few, wide stages: a thread owns a whole radix-16 / 9 / 8 butterfly in registers (64 VGPRs of data), so 2304 = 9 * 16 * 16
+//     points make three LDS round trips instead of the six of a radix-4 / 3 cascade.
+//   * The odd factor goes FIRST (decimation in frequency): after it the transform is R1 independent power-of-two transforms, and
+//     every index that follows is a bit field -- which is what makes the next point possible.
+//   * LDS image: element p lives at p ^ fold(p), fold = a GF(2)-linear map of the bits >= 3 of p into its low four bits, searched
+//     on the host (fft64_search_swizzle) so that every access of every stage is conflict-free under BOTH bank rules of 16-byte
+//     accesses: ds_read_b128 serves 4 groups of 16 lanes (lane sets {0-3,12-15,20-27}, ... = fixed lane bit 5 and fixed parity of
+//     lane bits 2..4) over 64 banks, ds_write_b128 8 groups of 8 contiguous lanes over 32 banks.  Because the map is linear and the
+//     fields of p = (sub-transform | group | m | t) do not overlap, phys(p) = phys(base) ^ phys(m * q): one fold per butterfly, the
+//     R element offsets are wave-uniform constants from the plan.
+//   * The first stage of a transform can take its inputs straight from global memory and the last stage of an inverse can store
+//     straight to it (the callers do): two LDS passes fewer.
+// Inverse transforms run the same stages backwards on conjugated data (twiddle first, then the same butterfly): the forward
+// pass leaves digit-reversed order, the backward pass takes it -- no reordering pass in between.
+//
+// Everything index-related is host-callable: tests/test_fft64_host.py compiles this header with g++ and checks the transforms
+// against a direct DFT and counts bank conflicts with the two rules above.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <vector>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define F64_HD __host__ __device__ __forceinline__
+typedef double2 f64c;
+#else
+#define F64_HD inline
+struct f64c { double x, y; };
+#endif
+
+namespace fft64 {
+
+constexpr int MAX_STAGES = 5;  // one odd stage + four power-of-two stages (N <= 9 * 2^16)
+
+struct Plan {
+    int N, R1, a, nst;
+    int radix[MAX_STAGES];
+    int lq[MAX_STAGES];     // log2 of the butterfly stride q of a power-of-two stage (odd stage: q = 2^a)
+    int lr[MAX_STAGES];     // log2 of its radix (odd stage: 0)
+    int twoff[MAX_STAGES];  // start of the stage's twiddle table: entry (m - 1) * q + t = exp(-2 pi i m t / (q * radix))
+    unsigned fmask[4];      // bit j of fold(p) = parity(p & fmask[j])
+    int pm[MAX_STAGES][16]; // phys(m * q): XOR offsets of the butterfly's elements
+    int lslot[MAX_STAGES];  // log2 of the butterfly slots per transform when a work-group runs several transforms side by side:
+                            // max(32, N / radix rounded up to 2^k) -- lane bit 5 and up then select the transform, never a lane group
+    int tw_total;
+};
+
+F64_HD f64c mk(double x, double y) {
+    f64c r;
+    r.x = x;
+    r.y = y;
+    return r;
+}
+F64_HD f64c cadd(f64c a, f64c b) { return mk(a.x + b.x, a.y + b.y); }
+F64_HD f64c csub(f64c a, f64c b) { return mk(a.x - b.x, a.y - b.y); }
+F64_HD f64c cmul(f64c a, f64c b) { return mk(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+F64_HD f64c cconj(f64c a) { return mk(a.x, -a.y); }
+F64_HD f64c mul_mi(f64c a) { return mk(a.y, -a.x); }  // a * (-i)
+F64_HD f64c mul_pi(f64c a) { return mk(-a.y, a.x); }  // a * (+i)
+
+F64_HD int popc32(unsigned v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __popc(v);
+#else
+    return __builtin_popcount(v);
+#endif
+}
+F64_HD int fold(const Plan& pl, unsigned p) {
+    return (popc32(p & pl.fmask[0]) & 1) | ((popc32(p & pl.fmask[1]) & 1) << 1) | ((popc32(p & pl.fmask[2]) & 1) << 2) |
+           ((popc32(p & pl.fmask[3]) & 1) << 3);
+}
+F64_HD int phys(const Plan& pl, int p) { return p ^ fold(pl, (unsigned)p); }
+
+// ---------------------------------------------------------------------------------------------------- butterflies (forward)
+template <int R> struct Dft;
+template <> struct Dft<2> {
+    static F64_HD void run(f64c* v) {
+        const f64c a = v[0], b = v[1];
+        v[0] = cadd(a, b);
+        v[1] = csub(a, b);
+    }
+};
+F64_HD void dft3(f64c& a, f64c& b, f64c& c) {
+    const f64c t1 = cadd(b, c), dd = csub(b, c);
+    const f64c t2 = mk(a.x - 0.5 * t1.x, a.y - 0.5 * t1.y);
+    const double h = 0.86602540378443864676;  // sqrt(3) / 2
+    const f64c sv = mk(h * dd.x, h * dd.y);
+    a = cadd(a, t1);
+    b = mk(t2.x + sv.y, t2.y - sv.x);  // t2 - i sv
+    c = mk(t2.x - sv.y, t2.y + sv.x);  // t2 + i sv
+}
+F64_HD void dft4(f64c& a, f64c& b, f64c& c, f64c& d) {
+    const f64c s02 = cadd(a, c), d02 = csub(a, c), s13 = cadd(b, d), d13 = csub(b, d);
+    a = cadd(s02, s13);
+    b = mk(d02.x + d13.y, d02.y - d13.x);  // d02 - i d13
+    c = csub(s02, s13);
+    d = mk(d02.x - d13.y, d02.y + d13.x);  // d02 + i d13
+}
+template <> struct Dft<3> {
+    static F64_HD void run(f64c* v) { dft3(v[0], v[1], v[2]); }
+};
+template <> struct Dft<4> {
+    static F64_HD void run(f64c* v) { dft4(v[0], v[1], v[2], v[3]); }
+};
+// n = j + 2 n1, k = m1 + 4 m2
+template <> struct Dft<8> {
+    static F64_HD void run(f64c* v) {
+        const double c = 0.70710678118654752440;
+        dft4(v[0], v[2], v[4], v[6]);  // u_0[m1] at v[2 m1]
+        dft4(v[1], v[3], v[5], v[7]);  // u_1[m1] at v[2 m1 + 1]
+        const f64c u1 = mk(c * (v[3].x + v[3].y), c * (v[3].y - v[3].x));   // * w8
+        const f64c u2 = mul_mi(v[5]);                                      // * w8^2 = -i
+        const f64c u3 = mk(c * (v[7].y - v[7].x), -c * (v[7].x + v[7].y));  // * w8^3
+        const f64c a0 = v[0], a1 = v[2], a2 = v[4], a3 = v[6], b0 = v[1];
+        v[0] = cadd(a0, b0); v[4] = csub(a0, b0);
+        v[1] = cadd(a1, u1); v[5] = csub(a1, u1);
+        v[2] = cadd(a2, u2); v[6] = csub(a2, u2);
+        v[3] = cadd(a3, u3); v[7] = csub(a3, u3);
+    }
+};
+// n = j + 3 n1, k = m1 + 3 m2
+template <> struct Dft<9> {
+    static F64_HD void run(f64c* v) {
+        dft3(v[0], v[3], v[6]);  // u_0[m1] at v[3 m1]
+        dft3(v[1], v[4], v[7]);  // u_1[m1] at v[3 m1 + 1]
+        dft3(v[2], v[5], v[8]);  // u_2[m1] at v[3 m1 + 2]
+        const f64c w1 = mk(0.76604444311897803520, -0.64278760968653932632);   // exp(-2 pi i / 9)
+        const f64c w2 = mk(0.17364817766693034885, -0.98480775301220805937);   // ^2
+        const f64c w4 = mk(-0.93969262078590838405, -0.34202014332566873304);  // ^4
+        v[4] = cmul(v[4], w1);  // u_1[1]
+        v[7] = cmul(v[7], w2);  // u_1[2]
+        v[5] = cmul(v[5], w2);  // u_2[1]
+        v[8] = cmul(v[8], w4);  // u_2[2]
+        // y[m1 + 3 m2] = dft3 over j of u_j[m1]: in place on (v[3 m1], v[3 m1 + 1], v[3 m1 + 2]) -> m2 = 0, 1, 2
+        dft3(v[0], v[1], v[2]);
+        dft3(v[3], v[4], v[5]);
+        dft3(v[6], v[7], v[8]);
+        // now v[3 m1 + m2] holds y[m1 + 3 m2]: transpose to natural order
+        f64c t;
+        t = v[1]; v[1] = v[3]; v[3] = t;
+        t = v[2]; v[2] = v[6]; v[6] = t;
+        t = v[5]; v[5] = v[7]; v[7] = t;
+    }
+};
+// n = j + 4 n1, k = m1 + 4 m2
+template <> struct Dft<16> {
+    static F64_HD void run(f64c* v) {
+        const double C = 0.92387953251128675613, S = 0.38268343236508977173, c = 0.70710678118654752440;
+        dft4(v[0], v[4], v[8], v[12]);   // u_0[m1] at v[4 m1]
+        dft4(v[1], v[5], v[9], v[13]);   // u_1[m1] at v[4 m1 + 1]
+        dft4(v[2], v[6], v[10], v[14]);  // u_2
+        dft4(v[3], v[7], v[11], v[15]);  // u_3
+        // u_j[m1] *= w16^(j m1)
+        v[5] = cmul(v[5], mk(C, -S));                                    // j=1 m1=1: w^1
+        v[9] = mk(c * (v[9].x + v[9].y), c * (v[9].y - v[9].x));         // j=1 m1=2: w^2
+        v[13] = cmul(v[13], mk(S, -C));                                  // j=1 m1=3: w^3
+        v[6] = mk(c * (v[6].x + v[6].y), c * (v[6].y - v[6].x));         // j=2 m1=1: w^2
+        v[10] = mul_mi(v[10]);                                           // j=2 m1=2: w^4
+        v[14] = mk(c * (v[14].y - v[14].x), -c * (v[14].x + v[14].y));   // j=2 m1=3: w^6
+        v[7] = cmul(v[7], mk(S, -C));                                    // j=3 m1=1: w^3
+        v[11] = mk(c * (v[11].y - v[11].x), -c * (v[11].x + v[11].y));   // j=3 m1=2: w^6
+        v[15] = cmul(v[15], mk(-C, S));                                  // j=3 m1=3: w^9
+        dft4(v[0], v[1], v[2], v[3]);      // m1 = 0: y[0 + 4 m2] at v[m2]
+        dft4(v[4], v[5], v[6], v[7]);      // m1 = 1: y[1 + 4 m2] at v[4 + m2]
+        dft4(v[8], v[9], v[10], v[11]);
+        dft4(v[12], v[13], v[14], v[15]);
+        // v[4 m1 + m2] holds y[m1 + 4 m2]: transpose
+        f64c t;
+        t = v[1]; v[1] = v[4]; v[4] = t;
+        t = v[2]; v[2] = v[8]; v[8] = t;
+        t = v[3]; v[3] = v[12]; v[12] = t;
+        t = v[6]; v[6] = v[9]; v[9] = t;
+        t = v[7]; v[7] = v[13]; v[13] = t;
+        t = v[11]; v[11] = v[14]; v[14] = t;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------- stage index math
+// butterfly idx of stage st -> its base point p0 (the m = 0 element) and t (twiddle index); element m sits at phys(p0) ^ pm[st][m]
+F64_HD int stage_base(const Plan& pl, int st, int idx, int* t_out) {
+    if (pl.lr[st] == 0) {  // the odd stage: q = 2^a, one group
+        *t_out = idx;
+        return idx;
+    }
+    const int lq = pl.lq[st], lr = pl.lr[st], per = pl.a - lr;  // butterflies per sub-transform = 2^per
+    const int sub = idx >> per, r = idx & ((1 << per) - 1);
+    const int g = r >> lq, t = r & ((1 << lq) - 1);
+    *t_out = t;
+    return (sub << pl.a) | (g << (lq + lr)) | t;
+}
+F64_HD int stage_count(const Plan& pl, int st) { return pl.N / pl.radix[st]; }
+
+// One butterfly.  Forward (decimation in frequency): y = DFT_R(x), y_m *= w^(m t).  Backward: x_m *= w^(m t) first, then the same
+// DFT (run on conjugated data this is the inverse of the forward stage, see the header).
+template <int R, bool BACK>
+F64_HD void butterfly(f64c* v, const f64c* __restrict__ stw, int q, int t) {
+    if (BACK && q > 1) {
+#pragma unroll
+        for (int m = 1; m < R; ++m) v[m] = cmul(v[m], stw[(m - 1) * q + t]);
+    }
+    Dft<R>::run(v);
+    if (!BACK && q > 1) {
+#pragma unroll
+        for (int m = 1; m < R; ++m) v[m] = cmul(v[m], stw[(m - 1) * q + t]);
+    }
+}
+
+// one butterfly of stage st on the LDS image x
+template <int R, bool BACK>
+F64_HD void butterfly_lds(f64c* x, const Plan& pl, int st, const f64c* __restrict__ stw, int q, int idx) {
+    int t;
+    const int base = phys(pl, stage_base(pl, st, idx, &t));
+    f64c v[R];
+#pragma unroll
+    for (int m = 0; m < R; ++m) v[m] = x[base ^ pl.pm[st][m]];
+    butterfly<R, BACK>(v, stw, q, t);
+#pragma unroll
+    for (int m = 0; m < R; ++m) x[base ^ pl.pm[st][m]] = v[m];
+}
+
+// a whole stage on `narr` LDS images `stride` elements apart (work items first, first + step, ...: item = transform * slots + butterfly)
+template <int R, bool BACK>
+F64_HD void stage_lds(f64c* x, int stride, int narr, const Plan& pl, int st, const f64c* __restrict__ tw, int first, int step) {
+    const int nb = pl.N / R, q = pl.lr[st] == 0 ? (1 << pl.a) : (1 << pl.lq[st]), ls = pl.lslot[st];
+    const f64c* stw = tw + pl.twoff[st];
+    for (int e = first; e < (narr << ls); e += step) {
+        const int f = e >> ls, idx = e & ((1 << ls) - 1);
+        if (idx < nb) butterfly_lds<R, BACK>(x + (size_t)f * stride, pl, st, stw, q, idx);
+    }
+}
+template <bool BACK>
+F64_HD void stage_any(f64c* x, int stride, int narr, const Plan& pl, int st, const f64c* __restrict__ tw, int first, int step) {
+    switch (pl.radix[st]) {
+        case 16: stage_lds<16, BACK>(x, stride, narr, pl, st, tw, first, step); break;
+        case 9: stage_lds<9, BACK>(x, stride, narr, pl, st, tw, first, step); break;
+        case 8: stage_lds<8, BACK>(x, stride, narr, pl, st, tw, first, step); break;
+        case 4: stage_lds<4, BACK>(x, stride, narr, pl, st, tw, first, step); break;
+        case 3: stage_lds<3, BACK>(x, stride, narr, pl, st, tw, first, step); break;
+        default: stage_lds<2, BACK>(x, stride, narr, pl, st, tw, first, step); break;
+    }
+}
+
+// twiddles of the stages after the first: few (15 * 16 entries for 2304 = 9 * 16 * 16) and needed in the middle of LDS-bound
+// stages, where a global load would be waited for on the spot -- the kernels keep a copy behind their LDS images
+F64_HD int lds_twiddles(const Plan& pl) { return pl.nst > 1 ? pl.tw_total - pl.twoff[1] : 0; }
+
+// position (logical, before the swizzle) of frequency k after the forward pass: digits of k, least significant first, are the
+// m of the stages in order
+F64_HD int pos_of_freq(const Plan& pl, int k) {
+    int p = 0, rem = pl.N;
+    for (int s = 0; s < pl.nst; ++s) {
+        const int r = pl.radix[s];
+        rem /= r;
+        p += (k % r) * rem;
+        k /= r;
+    }
+    return p;
+}
+
+// ---------------------------------------------------------------------------------------------------- host: plan + swizzle
+// conflict cycles of one 64-lane access whose lane l touches element e[l] (e < 0: lane idle): reads by the ds_read_b128 rule,
+// writes by the ds_write_b128 rule
+inline int conflicts_b128(const int e[64], bool write) {
+    int extra = 0;
+    if (!write) {
+        for (int half = 0; half < 2; ++half)
+            for (int par = 0; par < 2; ++par) {
+                int cnt[16] = {0};
+                int seen[16][16];
+                for (int l = half * 32; l < half * 32 + 32; ++l) {
+                    const int p = ((l >> 2) ^ (l >> 3) ^ (l >> 4)) & 1;
+                    if (p != par || e[l] < 0) continue;
+                    const int bank = e[l] & 15;  // 16-byte elements over 64 dword banks
+                    bool dup = false;
+                    for (int k = 0; k < cnt[bank]; ++k) dup = dup || seen[bank][k] == e[l];
+                    if (!dup) seen[bank][cnt[bank]++] = e[l];
+                }
+                int worst = 1;
+                for (int b = 0; b < 16; ++b) worst = cnt[b] > worst ? cnt[b] : worst;
+                extra += worst - 1;
+            }
+    } else {
+        for (int g = 0; g < 8; ++g) {
+            int cnt[8] = {0};
+            for (int l = 8 * g; l < 8 * g + 8; ++l)
+                if (e[l] >= 0) ++cnt[e[l] & 7];  // 32 dword banks
+            int worst = 1;
+            for (int b = 0; b < 8; ++b) worst = cnt[b] > worst ? cnt[b] : worst;
+            extra += worst - 1;
+        }
+    }
+    return extra;
+}
+
+// all stage accesses of the first wave of every stage (the map is affine in the lane bits, so later waves behave alike)
+inline int swizzle_cost(const Plan& pl) {
+    int cost = 0;
+    for (int st = 0; st < pl.nst; ++st) {
+        const int nb = stage_count(pl, st);
+        for (int m = 0; m < pl.radix[st]; ++m) {
+            int e[64];
+            for (int l = 0; l < 64; ++l) {
+                if (l >= nb) { e[l] = -1; continue; }
+                int t;
+                e[l] = phys(pl, stage_base(pl, st, l, &t)) ^ pl.pm[st][m];
+            }
+            cost += conflicts_b128(e, false) + conflicts_b128(e, true);
+        }
+    }
+    return cost;
+}
+
+inline void set_pm(Plan& pl) {
+    for (int st = 0; st < pl.nst; ++st) {
+        const int q = pl.lr[st] == 0 ? (1 << pl.a) : (1 << pl.lq[st]);
+        for (int m = 0; m < 16; ++m) pl.pm[st][m] = m < pl.radix[st] ? phys(pl, m * q) : 0;
+    }
+}
+
+// columns S[i] (4 bits; bit 3 of p folds into bits 0..2 only) -> masks
+inline void set_columns(Plan& pl, const int S[20]) {
+    for (int j = 0; j < 4; ++j) pl.fmask[j] = 0;
+    for (int i = 3; i < pl.a + 4 && i < 20; ++i)
+        for (int j = 0; j < 4; ++j)
+            if ((S[i] >> j) & 1) pl.fmask[j] |= 1u << i;
+    set_pm(pl);
+}
+
+// coordinate descent over the columns from a few deterministic starts; returns the cost reached (0 = conflict-free)
+inline int search_swizzle(Plan& pl) {
+    const int top = pl.a + 4 < 20 ? pl.a + 4 : 20;
+    int best_cost = 1 << 30, bestS[20] = {0};
+    uint64_t rng = 0x9E3779B97F4A7C15ull ^ (uint64_t)pl.N;
+    auto next = [&]() {
+        rng ^= rng << 13;
+        rng ^= rng >> 7;
+        rng ^= rng << 17;
+        return (unsigned)(rng >> 11);
+    };
+    for (int start = 0; start < 64 && best_cost > 0; ++start) {
+        int S[20] = {0};
+        for (int i = 3; i < top; ++i) {
+            if (start == 0) S[i] = i >= 4 ? 1 << ((i - 4) & 3) : 0;  // p ^ (p >> 4): the classic fold
+            else S[i] = (int)(next() & (i == 3 ? 7u : 15u));
+        }
+        set_columns(pl, S);
+        int cost = swizzle_cost(pl);
+        bool moved = true;
+        while (cost > 0 && moved) {
+            moved = false;
+            for (int i = 3; i < top && cost > 0; ++i) {
+                const int keep = S[i];
+                int bv = keep, bc = cost;
+                for (int v = 0; v < (i == 3 ? 8 : 16); ++v) {
+                    if (v == keep) continue;
+                    S[i] = v;
+                    set_columns(pl, S);
+                    const int c = swizzle_cost(pl);
+                    if (c < bc) { bc = c; bv = v; }
+                }
+                S[i] = bv;
+                if (bv != keep) { cost = bc; moved = true; }
+            }
+            set_columns(pl, S);
+        }
+        if (cost < best_cost) {
+            best_cost = cost;
+            for (int i = 0; i < 20; ++i) bestS[i] = S[i];
+        }
+    }
+    set_columns(pl, bestS);
+    return best_cost;
+}
+
+// smallest N = 2^a * {1, 3, 9} >= need with a >= amin
+inline Plan make_plan(int need, int amin = 2) {
+    long best = 0;
+    int best_a = 0, best_r = 1;
+    for (int r1 = 1; r1 <= 9; r1 *= 3) {
+        long n = r1;
+        int a = 0;
+        while (a < amin || n < need) { n *= 2; ++a; }
+        if (best == 0 || n < best) { best = n; best_a = a; best_r = r1; }
+    }
+    Plan pl{};
+    pl.N = (int)best;
+    pl.R1 = best_r;
+    pl.a = best_a;
+    if (best_r > 1) {
+        pl.radix[pl.nst] = best_r;
+        pl.lq[pl.nst] = best_a;
+        pl.lr[pl.nst] = 0;
+        ++pl.nst;
+    }
+    // the power-of-two part in ceil(a / 4) stages of nearly equal size, the larger ones first
+    const int ns = (best_a + 3) / 4;
+    int left = best_a;
+    for (int s = 0; s < ns; ++s) {
+        const int lr = (left + (ns - s) - 1) / (ns - s);
+        left -= lr;
+        pl.radix[pl.nst] = 1 << lr;
+        pl.lr[pl.nst] = lr;
+        pl.lq[pl.nst] = left;
+        ++pl.nst;
+    }
+    int off = 0;
+    for (int st = 0; st < pl.nst; ++st) {
+        const int q = pl.lr[st] == 0 ? (1 << pl.a) : (1 << pl.lq[st]);
+        pl.twoff[st] = off;
+        off += q > 1 ? (pl.radix[st] - 1) * q : 0;
+    }
+    pl.tw_total = off;
+    for (int st = 0; st < pl.nst; ++st) {
+        int l = 5;
+        while ((1 << l) < pl.N / pl.radix[st]) ++l;
+        pl.lslot[st] = l;
+    }
+    search_swizzle(pl);
+    return pl;
+}
+
+// the stages' twiddle tables (interleaved re, im), exact to the rounding of cosl / sinl
+inline std::vector<double> make_twiddles(const Plan& pl) {
+    std::vector<double> h(2 * (size_t)(pl.tw_total > 0 ? pl.tw_total : 1));
+    const long double tau = 2.0L * 3.14159265358979323846264338327950288L;
+    for (int st = 0; st < pl.nst; ++st) {
+        const int q = pl.lr[st] == 0 ? (1 << pl.a) : (1 << pl.lq[st]), R = pl.radix[st];
+        if (q <= 1) continue;
+        const long L = (long)q * R;
+        for (int m = 1; m < R; ++m)
+            for (int t = 0; t < q; ++t) {
+                const long n = ((long)m * t) % L;
+                double c = (double)cosl(tau * (long double)n / (long double)L), s = (double)-sinl(tau * (long double)n / (long double)L);
+                if (4 * n == L) { c = 0.0; s = -1.0; }
+                if (2 * n == L) { c = -1.0; s = 0.0; }
+                if (4 * n == 3 * L) { c = 0.0; s = 1.0; }
+                if (n == 0) { c = 1.0; s = 0.0; }
+                const size_t e = (size_t)pl.twoff[st] + (size_t)(m - 1) * q + t;
+                h[2 * e] = c;
+                h[2 * e + 1] = s;
+            }
+    }
+    return h;
+}
+
+}  // namespace fft64

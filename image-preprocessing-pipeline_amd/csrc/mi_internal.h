@@ -4,6 +4,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 
 #include "mi_common.h"
@@ -52,6 +53,14 @@ inline int use_device(int dev) {
     MI_HIP(hipSetDevice(dev));
     return MI_OK;
 }
+
+// Experiment switches (phase knock-outs, tile shapes, stream layouts: everything profiles/ varies) exist only in probe builds
+// (`make EXTRA=-DMI_PROBES`): the product library does not contain their names and reads none of them.
+#ifdef MI_PROBES
+#define MI_PROBE_ENV(name) std::getenv(name)
+#else
+#define MI_PROBE_ENV(name) (static_cast<const char*>(nullptr))
+#endif
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 

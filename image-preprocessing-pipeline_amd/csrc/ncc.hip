@@ -197,7 +197,7 @@ static int ncc_batch(int dev, void* stream, int n_pairs, const float* const* til
         };
         std::vector<InFlight> flights;
         int rc = MI_OK;
-        static const char* env_ser = std::getenv("MI_NCC_SERIAL_MIPS");
+        static const char* env_ser = MI_PROBE_ENV("MI_NCC_SERIAL_MIPS");
         const bool serial_mips = env_ser ? std::atoi(env_ser) != 0 : false;
         for (auto& kv : groups) {
             const std::vector<int>& idx = kv.second;

@@ -27,105 +27,57 @@
 #include <cfloat>
 #include <map>
 
+#include "fft64_lds.h"
 #include "ncc_core.h"
 #include "ncc_lag.h"
 
 namespace {
 
 typedef double2 cplx;
+using fft64::Plan;
 
 __device__ __forceinline__ cplx cmul(cplx a, cplx b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 __device__ __forceinline__ cplx cadd(cplx a, cplx b) { return make_double2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ cplx csub(cplx a, cplx b) { return make_double2(a.x - b.x, a.y - b.y); }
 
-// Transform length N = 2^a * 3^b (b <= 2): the radices of the decimation-in-frequency stages, in order (4s, then a 2, then 3s).
-// 2048-row MIPs with 75 lags need N >= 2123: 2304 = 4^4 * 9 instead of 4096 cuts every lag kernel by 44 %.
-struct FftPlan {
-    int N, nstages;
-    int radix[14];
-    int twoff[14];  // start of stage s in the per-stage twiddle table (see fft_tables)
-};
-
-// In-place decimation-in-frequency transform of x[0 .. N) in LDS.  Natural order in, digit-reversed order out: with position
-// digits d_1 d_2 ... (most significant first, radices r_1 r_2 ...) the frequency is k = d_1 + r_1 (d_2 + r_2 (...)).
-// tw: per-stage tables -- stage s (radix r, q = L / r butterflies per group) holds exp(-2 pi i m t (N / L) / N) at
-// twoff[s] + (m - 1) q + t, m = 1 .. r - 1: the look-ups of consecutive lanes are consecutive entries (from the one table
-// exp(-2 pi i n / N) the middle stages touched up to 64 cache lines per load instruction).
-__device__ __forceinline__ int pos_of_freq(int k, const FftPlan& pl) {
-    int p = 0, rem = pl.N;
-    for (int s = 0; s < pl.nstages; ++s) {
-        const int r = pl.radix[s];
-        rem /= r;
-        p += (k % r) * rem;
-        k /= r;
-    }
-    return p;
-}
-
-// BF = butterflies per thread and step: their LDS reads and table loads are issued before any store
-template <int BF>
-__device__ __forceinline__ void fft_dif(cplx* __restrict__ x, const FftPlan& pl, const cplx* __restrict__ tw) {
-    const int N = pl.N;
-    int L = N;
-    for (int st = 0; st < pl.nstages; ++st) {
-        const int r = pl.radix[st], q = L / r, nb = N / r;
-        const cplx* stw = tw + pl.twoff[st];
-        for (int i0 = threadIdx.x; i0 < nb; i0 += BF * blockDim.x) {
-            cplx a[BF][4], w[BF][3];
-            int off[BF];  // (offsets, not pointers: a pointer that may be null is no longer known to point into LDS -> FLAT accesses)
-            bool live[BF];
+// The transforms are those of fft64_lds.h: length N = 2^a * {1, 3, 9} (2048-row MIPs with 75 lags need N >= 2123: 2304 = 9 * 16 * 16),
+// a thread owns a whole radix-16 / 9 / 8 butterfly, three LDS round trips for 2304 points under a conflict-free XOR image.
+// First stage of a forward transform whose inputs come from load(i), i = logical index, instead of LDS (no fill pass).
+template <int R, class Load>
+__device__ __forceinline__ void first_stage_from(cplx* x, const Plan& pl, const cplx* __restrict__ tw, int first, int step, Load load) {
+    const int nb = pl.N / R, q = pl.lr[0] == 0 ? (1 << pl.a) : (1 << pl.lq[0]);
+    const cplx* stw = tw + pl.twoff[0];
+    for (int t = first; t < nb; t += step) {
+        cplx v[R];
 #pragma unroll
-            for (int u = 0; u < BF; ++u) {
-                const int idx = i0 + u * blockDim.x;
-                live[u] = idx < nb;
-                const int g = idx / q, t = idx - g * q;
-                off[u] = g * L + t;
-                if (live[u]) {
-                    a[u][0] = x[off[u]];
-                    a[u][1] = x[off[u] + q];
-                    if (r > 2) a[u][2] = x[off[u] + 2 * q];
-                    if (r > 3) a[u][3] = x[off[u] + 3 * q];
-                    w[u][0] = stw[t];
-                    if (r > 2) w[u][1] = stw[q + t];
-                    if (r > 3) w[u][2] = stw[2 * q + t];
-                }
-            }
+        for (int m = 0; m < R; ++m) v[m] = load(t + m * q);
+        fft64::butterfly<R, false>(v, stw, q, t);
+        const int base = fft64::phys(pl, t);
 #pragma unroll
-            for (int u = 0; u < BF; ++u) {
-                if (!live[u]) continue;
-                cplx* pu = x + off[u];
-                if (r == 4) {
-                    const cplx s02 = cadd(a[u][0], a[u][2]), d02 = csub(a[u][0], a[u][2]), s13 = cadd(a[u][1], a[u][3]), d13 = csub(a[u][1], a[u][3]);
-                    const cplx y1 = make_double2(d02.x + d13.y, d02.y - d13.x);  // d02 - i d13
-                    const cplx y3 = make_double2(d02.x - d13.y, d02.y + d13.x);  // d02 + i d13
-                    pu[0] = cadd(s02, s13);
-                    pu[q] = cmul(y1, w[u][0]);
-                    pu[2 * q] = cmul(csub(s02, s13), w[u][1]);
-                    pu[3 * q] = cmul(y3, w[u][2]);
-                } else if (r == 3) {
-                    const cplx t1 = cadd(a[u][1], a[u][2]), dd = csub(a[u][1], a[u][2]);
-                    const cplx t2 = make_double2(a[u][0].x - 0.5 * t1.x, a[u][0].y - 0.5 * t1.y);
-                    const double h = 0.86602540378443864676;  // sqrt(3) / 2
-                    const cplx sv = make_double2(h * dd.x, h * dd.y);
-                    pu[0] = cadd(a[u][0], t1);
-                    pu[q] = cmul(make_double2(t2.x + sv.y, t2.y - sv.x), w[u][0]);      // t2 - i sv
-                    pu[2 * q] = cmul(make_double2(t2.x - sv.y, t2.y + sv.x), w[u][1]);  // t2 + i sv
-                } else {
-                    pu[0] = cadd(a[u][0], a[u][1]);
-                    pu[q] = cmul(csub(a[u][0], a[u][1]), w[u][0]);
-                }
-            }
-        }
-        __syncthreads();
-        L = q;
+        for (int m = 0; m < R; ++m) x[base ^ pl.pm[0][m]] = v[m];
     }
 }
+template <class Load>
+__device__ __forceinline__ void first_stage_any(cplx* x, const Plan& pl, const cplx* __restrict__ tw, int first, int step, Load load) {
+    switch (pl.radix[0]) {
+        case 16: first_stage_from<16>(x, pl, tw, first, step, load); break;
+        case 9: first_stage_from<9>(x, pl, tw, first, step, load); break;
+        case 8: first_stage_from<8>(x, pl, tw, first, step, load); break;
+        case 4: first_stage_from<4>(x, pl, tw, first, step, load); break;
+        case 3: first_stage_from<3>(x, pl, tw, first, step, load); break;
+        default: first_stage_from<2>(x, pl, tw, first, step, load); break;
+    }
+}
+
+// Spectra of a plane: SP[((pair * ntile + tile) * n_short + j) * 2 KT + {0: F, 1: T} * KT + l] -- the KT frequency slots of a tile,
+// for line j, F then T: one 128-byte line when KT = 4.  The forward transform of line j stores whole lines; the correlation
+// kernels read a tile (all j of KT slots) as ONE contiguous block.
 
 // forward lag transform of short-axis line j (blockIdx.x) of pair blockIdx.y: element i of the line = m[i * ls + j * ss]
-template <int TH, int BF>
+template <int TH>
 __global__ __launch_bounds__(TH) void k_lag_fwd(const float* __restrict__ m1, const float* __restrict__ m2, size_t pstride, int n_long, int n_short,
-                                                 int ls, int ss, int nkp, FftPlan pl, const cplx* __restrict__ tw, const int* __restrict__ slot_pos,
-                                                 const int* __restrict__ slot_neg, cplx* __restrict__ SF, cplx* __restrict__ ST) {
+                                                 int ls, int ss, int KT, int ntile, Plan pl, const cplx* __restrict__ tw,
+                                                 const int* __restrict__ slot_pos, const int* __restrict__ slot_neg, cplx* __restrict__ SP) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lag_lds[];
     cplx* x = reinterpret_cast<cplx*>(lag_lds);
     // gridDim.x = 8 * ceil(n_short / 8): work-groups b, b + 8, ... run on one XCD and take NEIGHBOURING lines j -- with the long
@@ -135,20 +87,138 @@ __global__ __launch_bounds__(TH) void k_lag_fwd(const float* __restrict__ m1, co
     if (j >= n_short) return;
     const float* a = m1 + (size_t)blockIdx.y * pstride + (size_t)j * ss;
     const float* b = m2 + (size_t)blockIdx.y * pstride + (size_t)j * ss;
-    for (int i = threadIdx.x; i < N; i += blockDim.x)
-        x[i] = i < n_long ? make_double2((double)a[(size_t)i * ls], (double)b[(size_t)i * ls]) : make_double2(0.0, 0.0);
+    // f in the real, t in the imaginary part; the zero padding never exists in memory
+    // (unconditional loads through a clamped index: a load inside a predicated block is waited for on the spot, and the nine
+    // inputs of a butterfly then arrive one memory latency after the other)
+    cplx* twl = x + N;  // the later stages' twiddles (fft64::lds_twiddles)
+    for (int e = threadIdx.x; e < fft64::lds_twiddles(pl); e += TH) twl[e] = tw[pl.twoff[1] + e];
+    const cplx* tws = twl - (pl.nst > 1 ? pl.twoff[1] : 0);
+    first_stage_any(x, pl, tw, threadIdx.x, TH, [&](int i) {
+        const size_t o = (size_t)min(i, n_long - 1) * ls;
+        const float fa = a[o], fb = b[o];
+        return make_double2(i < n_long ? (double)fa : 0.0, i < n_long ? (double)fb : 0.0);
+    });
     __syncthreads();
-    fft_dif<BF>(x, pl, tw);
-    cplx* of = SF + ((size_t)blockIdx.y * n_short + j) * nkp;  // (rows of nkp >= NK spectra: whole 128-byte lines per eight)
-    cplx* ot = ST + ((size_t)blockIdx.y * n_short + j) * nkp;
-    // The N/2 + 1 frequencies 0 .. N/2 of a real signal's spectrum are kept in POSITION order ("slots": slot_pos ascending; slot_neg =
-    // position of the mirror frequency N - k): the untangling pass then reads LDS in nearly contiguous order -- in frequency
-    // order consecutive lanes sit N/4 elements apart, a 16-way bank conflict -- and the per-frequency correlation does not care
-    // about the order of its frequencies.
-    for (int sl = threadIdx.x; sl < NK; sl += blockDim.x) {
+    for (int st = 1; st < pl.nst; ++st) {
+        fft64::stage_any<false>(x, 0, 1, pl, st, tws, threadIdx.x, TH);
+        __syncthreads();
+    }
+    // The N/2 + 1 frequencies 0 .. N/2 of a real signal's spectrum are kept in POSITION order ("slots": slot_pos = LDS slot of the
+    // frequency, ascending in logical position; slot_neg = slot of the mirror frequency N - k): the untangling pass reads LDS
+    // nearly contiguously, and the per-frequency correlation does not care about the order of its frequencies.
+    cplx* row = SP + ((size_t)blockIdx.y * ntile * n_short + j) * 2 * KT;
+    const size_t tstride = (size_t)n_short * 2 * KT;
+    for (int sl = threadIdx.x; sl < NK; sl += TH) {
         const cplx zk = x[slot_pos[sl]], zn = x[slot_neg[sl]];
-        of[sl] = make_double2(0.5 * (zk.x + zn.x), 0.5 * (zk.y - zn.y));   // (Z[k] + conj Z[N-k]) / 2
-        ot[sl] = make_double2(0.5 * (zk.y + zn.y), -0.5 * (zk.x - zn.x));  // (Z[k] - conj Z[N-k]) / (2 i)
+        const int tile = sl / KT, l = sl - tile * KT;
+        cplx* o = row + (size_t)tile * tstride + l;
+        o[0] = make_double2(0.5 * (zk.x + zn.x), 0.5 * (zk.y - zn.y));    // (Z[k] + conj Z[N-k]) / 2
+        o[KT] = make_double2(0.5 * (zk.y + zn.y), -0.5 * (zk.x - zn.x));  // (Z[k] - conj Z[N-k]) / (2 i)
+    }
+}
+
+// Correlation along the short axis through a second transform (planes whose short axis is long enough to pay for it): per
+// frequency slot k,  C_s[k] = sum_j F_{j+s}[k] conj(T_j[k])  is the inverse transform of  F^[m] conj(T^[m])  on a zero-padded circle
+// of M >= n_short + Es points.  A work-group takes the KT slots of a tile: 2 KT transforms of M points side by side in LDS (images
+// M + 1 elements apart, so the 2 KT elements a wave writes for one t land in different banks), first stage straight from the
+// tile in global memory, point-wise product in digit-reversed order, backward pass on KT images, last stage straight to CH.
+// 3 x 5 M log2 M flops per slot instead of 8 n_short (2 Es + 1): config 5's xy plane 5 x fewer, and LDS-bound instead of fp64-bound.
+template <int R>
+__device__ __forceinline__ void corr_first(cplx* arr, int AS, int KT2, const cplx* __restrict__ src, int n_short, const Plan& pl,
+                                           const cplx* __restrict__ tw, int first, int step) {
+    const int nb = pl.N / R, q = pl.lr[0] == 0 ? (1 << pl.a) : (1 << pl.lq[0]);
+    const cplx* stw = tw + pl.twoff[0];
+    for (int e = first; e < nb * KT2; e += step) {
+        const int t = e / KT2, f = e - t * KT2;  // f fastest: a wave reads whole 128-byte lines of the tile
+        cplx v[R];
+#pragma unroll
+        for (int m = 0; m < R; ++m) {
+            const int i = t + m * q;  // (clamped index + select: see k_lag_fwd)
+            const cplx g = src[(size_t)min(i, n_short - 1) * KT2 + f];
+            v[m] = make_double2(i < n_short ? g.x : 0.0, i < n_short ? g.y : 0.0);
+        }
+        fft64::butterfly<R, false>(v, stw, q, t);
+        cplx* x = arr + (size_t)f * AS;
+        const int base = fft64::phys(pl, t);
+#pragma unroll
+        for (int m = 0; m < R; ++m) x[base ^ pl.pm[0][m]] = v[m];
+    }
+}
+template <int R>
+__device__ __forceinline__ void corr_last(const cplx* arr, int AS, int nk, const Plan& pl, const cplx* __restrict__ tw, int Es, int nlp,
+                                          cplx* __restrict__ dst, int first, int step) {
+    const int nb = pl.N / R, q = pl.lr[0] == 0 ? (1 << pl.a) : (1 << pl.lq[0]), ls = pl.lslot[0], M = pl.N;
+    const cplx* stw = tw + pl.twoff[0];
+    const double inv = 1.0 / (double)M;
+    for (int e = first; e < (nk << ls); e += step) {
+        const int l = e >> ls, t = e & ((1 << ls) - 1);
+        if (t >= nb) continue;
+        bool need = false;
+#pragma unroll
+        for (int m = 0; m < R; ++m) need = need || t + m * q <= Es || t + m * q >= M - Es;
+        if (!need) continue;
+        const cplx* x = arr + (size_t)l * AS;
+        const int base = fft64::phys(pl, t);
+        cplx v[R];
+#pragma unroll
+        for (int m = 0; m < R; ++m) v[m] = x[base ^ pl.pm[0][m]];
+        fft64::butterfly<R, true>(v, stw, q, t);
+        cplx* o = dst + (size_t)l * nlp;
+#pragma unroll
+        for (int m = 0; m < R; ++m) {
+            const int pos = t + m * q;  // lag s >= 0 at s, s < 0 at M + s
+            if (pos <= Es) o[pos + Es] = make_double2(v[m].x * inv, -v[m].y * inv);
+            else if (pos >= M - Es) o[pos - M + Es] = make_double2(v[m].x * inv, -v[m].y * inv);
+        }
+    }
+}
+template <int TH>
+__global__ __launch_bounds__(TH) void k_lag_corr(const cplx* __restrict__ SP, int n_short, int NK, int Es, int KT, int nlp, int tiles_per_pair, Plan pl,
+                                                  const cplx* __restrict__ tw, cplx* __restrict__ CH) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lag_lds[];
+    cplx* arr = reinterpret_cast<cplx*>(lag_lds);
+    const int tile = blockIdx.x, pair = blockIdx.y, KT2 = 2 * KT, M = pl.N, AS = M + 1;
+    const int k0 = tile * KT, nk = min(KT, NK - k0);
+    if (nk <= 0) return;
+    const cplx* src = SP + ((size_t)pair * tiles_per_pair + tile) * n_short * KT2;
+    cplx* twl = arr + (size_t)KT2 * AS;
+    for (int e = threadIdx.x; e < fft64::lds_twiddles(pl); e += TH) twl[e] = tw[pl.twoff[1] + e];
+    const cplx* tws = twl - (pl.nst > 1 ? pl.twoff[1] : 0);
+    switch (pl.radix[0]) {
+        case 16: corr_first<16>(arr, AS, KT2, src, n_short, pl, tw, threadIdx.x, TH); break;
+        case 9: corr_first<9>(arr, AS, KT2, src, n_short, pl, tw, threadIdx.x, TH); break;
+        case 8: corr_first<8>(arr, AS, KT2, src, n_short, pl, tw, threadIdx.x, TH); break;
+        case 4: corr_first<4>(arr, AS, KT2, src, n_short, pl, tw, threadIdx.x, TH); break;
+        case 3: corr_first<3>(arr, AS, KT2, src, n_short, pl, tw, threadIdx.x, TH); break;
+        default: corr_first<2>(arr, AS, KT2, src, n_short, pl, tw, threadIdx.x, TH); break;
+    }
+    __syncthreads();
+    for (int st = 1; st < pl.nst; ++st) {
+        fft64::stage_any<false>(arr, AS, KT2, pl, st, tws, threadIdx.x, TH);
+        __syncthreads();
+    }
+    // conj(F^ conj(T^)) = conj(F^) T^, position by position (both spectra sit in the same digit-reversed, swizzled order), into F's image
+    for (int l = 0; l < nk; ++l) {
+        cplx* F = arr + (size_t)l * AS;
+        const cplx* T = arr + (size_t)(KT + l) * AS;
+        for (int p = threadIdx.x; p < M; p += TH) {
+            const cplx f = F[p], t = T[p];
+            F[p] = make_double2(f.x * t.x + f.y * t.y, f.x * t.y - f.y * t.x);
+        }
+    }
+    __syncthreads();
+    for (int st = pl.nst - 1; st >= 1; --st) {
+        fft64::stage_any<true>(arr, AS, nk, pl, st, tws, threadIdx.x, TH);
+        __syncthreads();
+    }
+    cplx* dst = CH + ((size_t)pair * NK + k0) * nlp;
+    switch (pl.radix[0]) {
+        case 16: corr_last<16>(arr, AS, nk, pl, tw, Es, nlp, dst, threadIdx.x, TH); break;
+        case 9: corr_last<9>(arr, AS, nk, pl, tw, Es, nlp, dst, threadIdx.x, TH); break;
+        case 8: corr_last<8>(arr, AS, nk, pl, tw, Es, nlp, dst, threadIdx.x, TH); break;
+        case 4: corr_last<4>(arr, AS, nk, pl, tw, Es, nlp, dst, threadIdx.x, TH); break;
+        case 3: corr_last<3>(arr, AS, nk, pl, tw, Es, nlp, dst, threadIdx.x, TH); break;
+        default: corr_last<2>(arr, AS, nk, pl, tw, Es, nlp, dst, threadIdx.x, TH); break;
     }
 }
 
@@ -160,8 +230,8 @@ __global__ __launch_bounds__(TH) void k_lag_fwd(const float* __restrict__ m1, co
 // step, so without this every fill phase -- 39 KB per tile on the xy plane of config 5 -- was a phase in which the CU computed
 // nothing (600 -> 4xx us for that plane: profiles/r03_lag_shapes.txt).
 template <int LB, int PF>
-__global__ __launch_bounds__(256) void k_lag_mac(const cplx* __restrict__ SF, const cplx* __restrict__ ST, int n_short, int NK, int Es, int KT, int JP,
-                                                 int FW, int TW, int nlp, int nkp, int tiles_per_pair, int ntiles, cplx* __restrict__ CH) {
+__global__ __launch_bounds__(256) void k_lag_mac(const cplx* __restrict__ SP, int n_short, int NK, int Es, int KT, int JP, int FW, int TW, int nlp,
+                                                 int tiles_per_pair, int ntiles, cplx* __restrict__ CH) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lag_lds[];
     cplx* Fs = reinterpret_cast<cplx*>(lag_lds);  // KT rows of FW: PAD zeros | n_short samples | zeros
     cplx* Ts = Fs + (size_t)KT * FW;              // KT rows of TW
@@ -176,14 +246,13 @@ __global__ __launch_bounds__(256) void k_lag_mac(const cplx* __restrict__ SF, co
     const cplx* fr = Fs + (size_t)kl * FW + PAD + v0;
     const cplx* tr = Ts + (size_t)kl * TW;
     const int nelem = n_short * KT;  // elements of a tile, kl fastest: 16 * KT contiguous bytes per line j
+    const size_t tsz = (size_t)n_short * 2 * KT;  // a tile of SP: [j][F | T][KT]
 
-    // Slot b of the persistent sequence (blockIdx.x, + gridDim.x, ...; both multiples of 16) -> tile: the two tiles that share the
-    // 128-byte lines of the spectra (k0 = 8 m and 8 m + 4; tiles_per_pair is even) go to work-groups b and b + 8, which run on ONE
-    // XCD at about the same time -- taken in order they sat on different XCDs and every L2 fetched whole lines for half of
-    // each (1.75 GB fetched for 0.63 GB of spectra).  Tiles past the end and the padding tile of a pair are empty (nk <= 0).
-    auto decode = [&](int b, int& pair, int& k0, int& nk) {
-        const int tile = (b & ~15) | ((b & 7) << 1) | ((b >> 3) & 1);
-        pair = tile / tiles_per_pair;
+    // Slot b of the persistent sequence (blockIdx.x, + gridDim.x, ...; both multiples of 16) -> tile (neighbouring tiles on one
+    // XCD).  Tiles past the end and the padding tile of a pair are empty (nk <= 0).
+    auto decode = [&](int b, int& tile, int& k0, int& nk) {
+        tile = (b & ~15) | ((b & 7) << 1) | ((b >> 3) & 1);
+        const int pair = tile / tiles_per_pair;
         k0 = (tile - pair * tiles_per_pair) * KT;
         nk = tile < ntiles ? min(KT, NK - k0) : 0;
     };
@@ -191,35 +260,36 @@ __global__ __launch_bounds__(256) void k_lag_mac(const cplx* __restrict__ SF, co
     int slot = blockIdx.x;
     __syncthreads();
     if (slot < nslots) {  // the first tile goes to LDS directly
-        int pair, k0, nk;
-        decode(slot, pair, k0, nk);
-        const size_t pbase = (size_t)pair * n_short;
+        int tile, k0, nk;
+        decode(slot, tile, k0, nk);
+        const cplx* src = SP + (size_t)tile * tsz;
         for (int e = threadIdx.x; e < nelem; e += 256) {
             const int x = e / KT, l = e - x * KT;
             if (l < nk) {
-                Fs[(size_t)l * FW + PAD + x] = SF[(pbase + x) * nkp + k0 + l];
-                Ts[(size_t)l * TW + x] = ST[(pbase + x) * nkp + k0 + l];
+                Fs[(size_t)l * FW + PAD + x] = src[(size_t)x * 2 * KT + l];
+                Ts[(size_t)l * TW + x] = src[(size_t)x * 2 * KT + KT + l];
             }
         }
     }
     while (slot < nslots) {
-        int pair, k0, nk;
-        decode(slot, pair, k0, nk);
+        int tile, k0, nk;
+        decode(slot, tile, k0, nk);
+        const int pair = tile / tiles_per_pair;
         __syncthreads();  // the tile is in LDS
         const int next = slot + gridDim.x;
         const bool has_next = next < nslots;
-        int npair = 0, nk0 = 0, nnk = 0;
-        if (has_next) decode(next, npair, nk0, nnk);
+        int ntile_ = 0, nk0 = 0, nnk = 0;
+        if (has_next) decode(next, ntile_, nk0, nnk);
+        const cplx* nsrc = SP + (size_t)ntile_ * tsz;
         cplx pf[PF > 0 ? PF : 1], pt[PF > 0 ? PF : 1];  // (PF = 0: rows too long for the registers -- the next tile is fetched behind this one)
         if (PF > 0 && has_next) {
-            const size_t pbase = (size_t)npair * n_short;
 #pragma unroll
             for (int i = 0; i < PF; ++i) {
                 const int e = threadIdx.x + i * 256;
                 const int x = e / KT, l = e - x * KT;
                 const bool ok = e < nelem && l < nnk;
-                pf[i] = ok ? SF[(pbase + x) * nkp + nk0 + l] : make_double2(0.0, 0.0);
-                pt[i] = ok ? ST[(pbase + x) * nkp + nk0 + l] : make_double2(0.0, 0.0);
+                pf[i] = ok ? nsrc[(size_t)x * 2 * KT + l] : make_double2(0.0, 0.0);
+                pt[i] = ok ? nsrc[(size_t)x * 2 * KT + KT + l] : make_double2(0.0, 0.0);
             }
         }
 
@@ -270,12 +340,11 @@ __global__ __launch_bounds__(256) void k_lag_mac(const cplx* __restrict__ SF, co
             for (int q = 0; q < LB; ++q) dst[q] = acc[q];
         }
         if (PF == 0 && has_next) {
-            const size_t pbase = (size_t)npair * n_short;
             for (int e = threadIdx.x; e < nelem; e += 256) {
                 const int x = e / KT, l = e - x * KT;
                 if (l < nnk) {
-                    Fs[(size_t)l * FW + PAD + x] = SF[(pbase + x) * nkp + nk0 + l];
-                    Ts[(size_t)l * TW + x] = ST[(pbase + x) * nkp + nk0 + l];
+                    Fs[(size_t)l * FW + PAD + x] = nsrc[(size_t)x * 2 * KT + l];
+                    Ts[(size_t)l * TW + x] = nsrc[(size_t)x * 2 * KT + KT + l];
                 }
             }
         }
@@ -294,32 +363,45 @@ __global__ __launch_bounds__(256) void k_lag_mac(const cplx* __restrict__ SF, co
     }
 }
 
-// inverse lag transform of two short-axis lags (2 * blockIdx.x, + 1) of pair blockIdx.y: c_a[n] + i c_b[n] = FFT(conj C_a + i conj C_b) / N
-// (both c real); the long-axis lags [-El, El] go to cross[(u + Eu) * (2 Ev + 1) + (v + Ev)]
-template <int TH, int BF>
-__global__ __launch_bounds__(TH) void k_lag_inv(const cplx* __restrict__ CH, int NK, int nlp, FftPlan pl, int Es, int El, int long_is_u, int Eu, int Ev,
-                                                 const cplx* __restrict__ tw, const int* __restrict__ slot_freq, double* __restrict__ cross) {
+// inverse lag transform of two short-axis lags (sa, sa + 1) of a pair: c_a[n] + i c_b[n] = FFT(conj C_a + i conj C_b) / N (both c
+// real); the long-axis lags [-El, El] go to cross[(u + Eu) * (2 Ev + 1) + (v + Ev)].  The first stage gathers its inputs from CH
+// (slot of frequency k: freq_slot[k]).  Work-groups b, b + 8, ... share an XCD and take the lag pairs of ONE pair after another: its
+// block of CH (2 MB on config 5, read as 32-byte pieces of 1.6-KB rows) is then fetched once into that L2.
+template <int TH>
+__global__ __launch_bounds__(TH) void k_lag_inv(const cplx* __restrict__ CH, int NK, int nlp, Plan pl, int Es, int El, int long_is_u, int Eu, int Ev,
+                                                 const cplx* __restrict__ tw, const int* __restrict__ freq_slot, int np, int lagpairs,
+                                                 double* __restrict__ cross) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lag_lds[];
     cplx* x = reinterpret_cast<cplx*>(lag_lds);
     const int N = pl.N, nlag = 2 * Es + 1;
-    const int sa = 2 * blockIdx.x, sb = sa + 1;
+    const int slot = (int)(blockIdx.x >> 3), pair = 8 * (slot / lagpairs) + (int)(blockIdx.x & 7);
+    if (pair >= np) return;
+    const int sa = 2 * (slot % lagpairs), sb = sa + 1;
     const bool has_b = sb < nlag;
-    const cplx* src = CH + (size_t)blockIdx.y * NK * nlp;
-    for (int sl = threadIdx.x; sl < NK; sl += blockDim.x) {
-        const int k = slot_freq[sl];
+    const cplx* src = CH + (size_t)pair * NK * nlp;
+    cplx* twl = x + N;
+    for (int e = threadIdx.x; e < fft64::lds_twiddles(pl); e += TH) twl[e] = tw[pl.twoff[1] + e];
+    const cplx* tws = twl - (pl.nst > 1 ? pl.twoff[1] : 0);
+    first_stage_any(x, pl, tw, threadIdx.x, TH, [&](int kk) {
+        const bool low = 2 * kk <= N;
+        const int sl = freq_slot[low ? kk : N - kk];
         const cplx xa = src[(size_t)sl * nlp + sa];
-        const cplx xb = has_b ? src[(size_t)sl * nlp + sb] : make_double2(0.0, 0.0);
-        x[k] = make_double2(xa.x + xb.y, -xa.y + xb.x);                              // conj(Xa) + i conj(Xb)
-        if (k > 0 && k < N / 2) x[N - k] = make_double2(xa.x - xb.y, xa.y + xb.x);   // Xa + i Xb  (= conj X[N-k] terms)
-    }
+        cplx xb = src[(size_t)sl * nlp + (has_b ? sb : sa)];
+        if (!has_b) xb = make_double2(0.0, 0.0);
+        return low ? make_double2(xa.x + xb.y, -xa.y + xb.x)   // conj(Xa) + i conj(Xb)
+                   : make_double2(xa.x - xb.y, xa.y + xb.x);   // Xa + i Xb  (= conj X[N-k] terms)
+    });
     __syncthreads();
-    fft_dif<BF>(x, pl, tw);
+    for (int st = 1; st < pl.nst; ++st) {
+        fft64::stage_any<false>(x, 0, 1, pl, st, tws, threadIdx.x, TH);
+        __syncthreads();
+    }
     const double inv = 1.0 / (double)N;
     const int W = 2 * Ev + 1;
-    double* out = cross + (size_t)blockIdx.y * (2 * Eu + 1) * W;
-    for (int e = threadIdx.x; e < 2 * El + 1; e += blockDim.x) {
+    double* out = cross + (size_t)pair * (2 * Eu + 1) * W;
+    for (int e = threadIdx.x; e < 2 * El + 1; e += TH) {
         const int l = e - El;
-        const cplx v = x[pos_of_freq((l + N) % N, pl)];
+        const cplx v = x[fft64::phys(pl, fft64::pos_of_freq(pl, (l + N) % N))];
         if (long_is_u) {
             out[(size_t)(l + Eu) * W + (sa - Es + Ev)] = v.x * inv;
             if (has_b) out[(size_t)(l + Eu) * W + (sb - Es + Ev)] = v.y * inv;
@@ -332,39 +414,150 @@ __global__ __launch_bounds__(TH) void k_lag_inv(const cplx* __restrict__ CH, int
 
 // ------------------------------------------------------------------------------------------------ banded summed-area tables
 // (BandView, ncc_core.h).  Logical coordinates: a = long axis, b = short axis, element (a, b) = m[a * ls + b * ss].
-constexpr int BAND_CH = 128;  // rows per chunk of the column sums
+// Everything the refinement needs besides the cross terms, for the three planes of every pair of a group in TWO launches of
+// small independent work-groups (round 3: six launches per plane -- tile sums, pixel sums, means, chunk sums, band columns, band
+// rows -- 36 dependent launches per call of two groups, 1.3 ms of kernel time for 0.7 GB of reads):
+//   k_plane_sums   float tile sums in the reference's order (seq_cpu_compute_partial_sums, compute_funcs.cu:474-500), and the
+//                  column sums of every SEGMENT of rows: the kept rows in pieces of BAND_RC, the rows no window statistic reads
+//                  (a in [B, n_long - B): most of a MIP) in chunks of BAND_CH;
+//   k_band_tables  per (pair, plane, MIP) one work-group per PIECE of kept rows (its start = the segment sums before it, its rows
+//                  walked by a thread per column, the prefix along b by wave scans in registers) and one for the tile-sum table.
+// (One work-group per MIP with the pieces in sequence was built first: 0.2 ms alone, 0.9 ms beside the transform kernels, which
+// left its 1024-thread work-groups waiting for whole compute units.)
+// The tables hold sums of g = f - c0 and g^2.  c0 only has to lie near the mean (it keeps the sums small; every use of the tables
+// adds it back exactly): it is the mean of 64 evenly spaced samples, which every wave that needs it takes itself -- the exact mean
+// of round 3 cost a reduction over the whole MIP and a launch boundary before anything else could start.
+constexpr int BAND_CH = 128;  // rows per chunk of the skipped rows
+constexpr int BAND_RC = 16;   // kept rows per piece
+struct TabPlane {
+    int dimu, dimv, tiled, nt, pw;                       // MIP extents, full 32 x 32 tiles
+    int n_long, n_short, ls, ss, B, rows, long_contig;   // band geometry (BandLayout)
+    int ppb, nbands, nch, nseg, units;                   // pieces per band, bands, chunks of skipped rows, segments, waves of sums per MIP
+    size_t mip1, mip2, ps1, ps2;                         // float offsets inside a pair's block of the MIP buffer
+    size_t sat_off, tab, ts;                             // double offsets / sizes inside a pair's block of the table buffer
+};
+struct TabGeom {
+    TabPlane p[3];
+    int nplanes;
+    size_t pstride, sstride;
+};
 
-// chunk column sums of (f - c0) and (f - c0)^2: T[((2 z + {0,1}) * nch + chunk) * n_short + b], z = blockIdx.z = 2 * pair + MIP.
-// LONG_CONTIG = false: rows a are n_short apart in memory, a wave owns 64 neighbouring columns b (coalesced rows);
-// LONG_CONTIG = true : the long axis is the contiguous one, a wave owns ONE b and strides along a.
-template <bool LONG_CONTIG>
-__global__ __launch_bounds__(64) void k_band_chunksum(const float* __restrict__ m1, const float* __restrict__ m2, size_t pstride, size_t sstride,
-                                                      const double* __restrict__ c0a, int n_long, int n_short, int ls, int ss, int nch,
-                                                      double* __restrict__ T) {
-    const int z = blockIdx.z, pair = z >> 1, which = z & 1, ca = blockIdx.y;
-    const float* m = (which ? m2 : m1) + (size_t)pair * pstride;
-    const double cm = c0a[(size_t)pair * sstride + which];
-    double* Tp = T + (size_t)pair * sstride + ((size_t)(2 * which) * nch + ca) * n_short;
-    double* Tq = Tp + (size_t)nch * n_short;
-    const int a0 = ca * BAND_CH, a1 = min(n_long, a0 + BAND_CH);
-    double p = 0.0, q = 0.0;
-    if (!LONG_CONTIG) {
-        const int b = blockIdx.x * 64 + threadIdx.x;
-        if (b >= n_short) return;
-        const float* col = m + (size_t)b * ss;
-#pragma unroll 4
-        for (int a = a0; a < a1; ++a) {
-            const double g = (double)col[(size_t)a * ls] - cm;
-            p += g;
-            q += g * g;
-        }
-        Tp[b] = p;
-        Tq[b] = q;
+struct __attribute__((packed, aligned(4))) F4u { float v[4]; };  // four floats at a 4-byte aligned address (rows of odd width)
+
+// mean of 64 evenly spaced samples of a MIP of n pixels, the same bits in every lane of every wave that asks
+__device__ __forceinline__ double sample_c0(const float* __restrict__ m, size_t n) {
+    const int lane = threadIdx.x & 63;
+    double v = (double)m[(size_t)lane * n / 64];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v * (1.0 / 64.0);
+}
+
+// inclusive prefix sum over the 64 lanes of a wave, in the VALU: four shifts inside the rows of 16 lanes, then the totals of
+// rows 0 / 2 into rows 1 / 3 and of rows 0-1 into rows 2-3 (DPP moves of the two halves of the double; lanes without a source
+// add 0).  (__shfl_up goes through the LDS crossbar: 12 dependent trips per scan, and a piece of the tables takes 32 scans.)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_take(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double wave_scan_dpp(double v) {
+    v += dpp_take<0x111, 0xf>(v);  // row_shr:1
+    v += dpp_take<0x112, 0xf>(v);  // row_shr:2
+    v += dpp_take<0x114, 0xf>(v);  // row_shr:4
+    v += dpp_take<0x118, 0xf>(v);  // row_shr:8
+    v += dpp_take<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+    v += dpp_take<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
+// rows [a0, a1) of segment s: pieces of the lower band | chunks of the skipped rows | pieces of the upper band
+__device__ __forceinline__ void seg_rows(const TabPlane& T, int s, int* a0, int* a1) {
+    const bool full = T.nbands == 1;
+    if (s < T.ppb) {
+        *a0 = s * BAND_RC;
+        *a1 = min(*a0 + BAND_RC, full ? T.n_long : T.B);
+    } else if (s < T.ppb + T.nch) {
+        const int skipped = T.n_long - 2 * T.B, ch = T.long_contig ? skipped : BAND_CH;
+        *a0 = T.B + (s - T.ppb) * ch;
+        *a1 = min(*a0 + ch, T.n_long - T.B);
     } else {
-        const int b = blockIdx.x;
-        const float* row = m + (size_t)b * ss;
-        for (int a = a0 + threadIdx.x; a < a1; a += 64) {
-            const double g = (double)row[(size_t)a * ls] - cm;
+        *a0 = T.n_long - T.B + (s - T.ppb - T.nch) * BAND_RC;
+        *a1 = min(*a0 + BAND_RC, T.n_long);
+    }
+}
+
+// blockIdx.z = pair, blockIdx.y = 2 * plane + MIP.  blockIdx.x in [0, tb): tile sums (below).  blockIdx.x in [tb, ...): column
+// sums of the segments, a wave per unit: (segment, strip of 64 columns) with a lane per column, or -- the skipped rows of a MIP
+// whose long axis is the contiguous one -- (column b) with the lanes along a.  T[((2 MIP + {p, q}) * nseg + segment) * n_short + b].
+__global__ __launch_bounds__(256) void k_plane_sums(TabGeom G, float* __restrict__ fbuf, double* __restrict__ sat, int tb, int knock) {
+    const int plane = blockIdx.y >> 1, which = blockIdx.y & 1;
+    if (knock && (((int)blockIdx.x < tb) ? (knock & 1) : (knock & 2))) return;  // (probe builds only: MI_NCC_TAB_KNOCK)
+    const TabPlane& T = G.p[plane];
+    float* base = fbuf + (size_t)blockIdx.z * G.pstride;
+    const float* m = base + (which ? T.mip2 : T.mip1);
+    if ((int)blockIdx.x < tb) {
+        // a wave per (row of tiles ti, block of up to 64 tiles along the row): the 32 image rows of the band arrive as coalesced
+        // 16-byte loads (the next row requested while the current one is added), cross LDS once -- tile t at 36 t floats, so
+        // that the 16-byte reads of 16 lanes fall into different banks -- and lane t adds the 32 samples of its tile's row in
+        // order into a FLOAT running sum like the reference does, bit-identical by construction
+        __shared__ __attribute__((aligned(16))) float tl[4][64 * 36];
+        const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        const int tjb = (T.pw + 63) / 64, unit = (int)blockIdx.x * 4 + wv;
+        if (!T.tiled || unit >= (T.dimu / TILE) * tjb) return;
+        const int ti = unit / tjb, tj0 = (unit - ti * tjb) * 64, ntw = min(64, T.pw - tj0), width = T.dimv, nf4 = 8 * ntw;
+        const float* p = m + (size_t)ti * TILE * width + tj0 * TILE;
+        float* my = tl[wv];
+        F4u cur[8], nxt[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int f = min(lane + 64 * k, nf4 - 1);
+            cur[k] = *reinterpret_cast<const F4u*>(p + 4 * f);
+        }
+        float s = 0.0f;
+        for (int i = 0; i < TILE; ++i) {
+            const float* pn = p + (size_t)min(i + 1, TILE - 1) * width;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int f = min(lane + 64 * k, nf4 - 1);
+                nxt[k] = *reinterpret_cast<const F4u*>(pn + 4 * f);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int f = lane + 64 * k;
+                if (f < nf4) *reinterpret_cast<float4*>(my + 36 * (f >> 3) + 4 * (f & 7)) = make_float4(cur[k].v[0], cur[k].v[1], cur[k].v[2], cur[k].v[3]);
+            }
+            __builtin_amdgcn_wave_barrier();  // (one wave: its LDS operations execute in order)
+            if (lane < ntw) {
+                float4 r[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) r[k] = *reinterpret_cast<const float4*>(my + 36 * lane + 4 * k);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { s += r[k].x; s += r[k].y; s += r[k].z; s += r[k].w; }
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = 0; k < 8; ++k) cur[k] = nxt[k];
+        }
+        if (lane < ntw) (base + (which ? T.ps2 : T.ps1))[ti * T.pw + tj0 + lane] = s;
+        return;
+    }
+    const int unit = ((int)blockIdx.x - tb) * 4 + (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (unit >= T.units) return;
+    const int n_short = T.n_short, ls = T.ls, ss = T.ss, strips = (n_short + 63) / 64, nbseg = T.nbands * T.ppb;
+    const double cm = sample_c0(m, (size_t)T.dimu * T.dimv);
+    double* Tp = sat + (size_t)blockIdx.z * G.sstride + T.sat_off + 2 + 4 * T.tab + 2 * T.ts + (size_t)(2 * which) * T.nseg * n_short;
+    double* Tq = Tp + (size_t)T.nseg * n_short;
+    double p = 0.0, q = 0.0;
+    int a0, a1;
+    if (T.long_contig && unit >= nbseg * strips) {  // one column over all skipped rows, the lanes along a
+        const int b = unit - nbseg * strips;
+        seg_rows(T, T.ppb, &a0, &a1);
+        const float* col = m + (size_t)b * ss;
+#pragma unroll 8
+        for (int a = a0 + lane; a < a1; a += 64) {
+            const double g = (double)col[(size_t)a * ls] - cm;
             p += g;
             q += g * g;
         }
@@ -372,63 +565,152 @@ __global__ __launch_bounds__(64) void k_band_chunksum(const float* __restrict__ 
             p += __shfl_down(p, off, 64);
             q += __shfl_down(q, off, 64);
         }
-        if (threadIdx.x == 0) { Tp[b] = p; Tq[b] = q; }
+        if (lane == 0) { Tp[(size_t)T.ppb * n_short + b] = p; Tq[(size_t)T.ppb * n_short + b] = q; }
+        return;
     }
-}
-
-// column running sums at the band rows: tab[row(a)][b + 1] = sum_{a' < a} g[a'][b]  (P and Q of one MIP); blockIdx.y = band
-// (0: rows [0, B], 1: rows [n_long - B, n_long]), a lane owns one column b
-__global__ __launch_bounds__(64) void k_band_cols(const float* __restrict__ m1, const float* __restrict__ m2, size_t pstride, size_t sstride,
-                                                  const double* __restrict__ c0a, int n_long, int n_short, int ls, int ss, int nch, int B, size_t tab,
-                                                  const double* __restrict__ T, double* __restrict__ P1) {
-    const int z = blockIdx.z, pair = z >> 1, which = z & 1, band = blockIdx.y;
-    const int b = blockIdx.x * 64 + threadIdx.x;
+    int sg, strip;
+    if (unit < nbseg * strips) {
+        const int si = unit / strips;
+        strip = unit - si * strips;
+        sg = si < T.ppb ? si : T.ppb + T.nch + (si - T.ppb);
+    } else {
+        const int c = (unit - nbseg * strips) / strips;
+        strip = unit - nbseg * strips - c * strips;
+        sg = T.ppb + c;
+    }
+    const int b = strip * 64 + lane;
     if (b >= n_short) return;
-    const bool full = B >= n_long;
-    if (full && band == 1) return;
-    const float* col = (which ? m2 : m1) + (size_t)pair * pstride + (size_t)b * ss;
-    const double cm = c0a[(size_t)pair * sstride + which];
-    double* P = P1 + (size_t)pair * sstride + (size_t)(2 * which) * tab;  // P1 | Q1 | P2 | Q2
-    double* Q = P + tab;
-    const int w1 = n_short + 1;
-    auto rowof = [&](int a) { return (full || a <= B) ? a : a - (n_long - B) + B + 1; };
-    double p = 0.0, q = 0.0;
-    int a = 0;
-    if (band == 1) {  // everything below the band: whole chunks from their sums, the rest row by row
-        const int a_start = n_long - B, cs = a_start / BAND_CH;
-        const double* Tp = T + (size_t)pair * sstride + (size_t)(2 * which) * nch * n_short;
-        const double* Tq = Tp + (size_t)nch * n_short;
-        for (int c = 0; c < cs; ++c) { p += Tp[(size_t)c * n_short + b]; q += Tq[(size_t)c * n_short + b]; }
-        for (a = cs * BAND_CH; a < a_start; ++a) {
-            const double g = (double)col[(size_t)a * ls] - cm;
-            p += g;
-            q += g * g;
-        }
-    }
-    const int a_end = band == 0 ? min(n_long, full ? n_long : B) : n_long;
-    P[(size_t)rowof(a) * w1 + b + 1] = p;
-    Q[(size_t)rowof(a) * w1 + b + 1] = q;
-    for (; a < a_end; ++a) {
+    seg_rows(T, sg, &a0, &a1);
+    const float* col = m + (size_t)b * ss;
+#pragma unroll 16
+    for (int a = a0; a < a1; ++a) {
         const double g = (double)col[(size_t)a * ls] - cm;
         p += g;
         q += g * g;
-        P[(size_t)rowof(a + 1) * w1 + b + 1] = p;
-        Q[(size_t)rowof(a + 1) * w1 + b + 1] = q;
     }
+    Tp[(size_t)sg * n_short + b] = p;
+    Tq[(size_t)sg * n_short + b] = q;
 }
 
-// prefix along b of every kept row, in place; column 0 = 0.  One wave per (row, table); blockIdx.y = table (P1, Q1, P2, Q2)
-__global__ __launch_bounds__(64) void k_band_rows(size_t sstride, int n_short, size_t tab, double* __restrict__ P1) {
-    double* S = P1 + (size_t)blockIdx.z * sstride + (size_t)blockIdx.y * tab + (size_t)blockIdx.x * (n_short + 1);
-    const int lane = threadIdx.x;
-    double carry = 0.0;
-    if (lane == 0) S[0] = 0.0;
-    for (int b0 = 0; b0 < n_short; b0 += 64) {
-        const int b = b0 + lane;
-        const double v = b < n_short ? S[b + 1] : 0.0;
-        const double sc = wave_inclusive_scan(v) + carry;
-        if (b < n_short) S[b + 1] = sc;
-        carry = __shfl(sc, 63, 64);
+// blockIdx.z = pair, blockIdx.y = 2 * plane + MIP, blockIdx.x = piece of BAND_RC kept rows, or (the last one) the tile-sum table.
+// A piece: the thread of column b adds the segment sums that lie before the piece (in order), walks down its rows (running sums of
+// g and g^2, all samples requested together); emitted row e then holds, per column, the sum over a' < a(e), and the prefix along b
+// is a wave scan over the lanes = columns, the waves' totals meeting in LDS; columns beyond 256 in further rounds with a carry.
+__global__ __launch_bounds__(256) void k_band_tables(TabGeom G, const float* __restrict__ fbuf, double* __restrict__ sat) {
+    const int plane = blockIdx.y >> 1, which = blockIdx.y & 1, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const TabPlane& T = G.p[plane];
+    const int npieces = T.nbands * T.ppb, pc = blockIdx.x;
+    if (pc > npieces) return;
+    const float* base = fbuf + (size_t)blockIdx.z * G.pstride;
+    const float* m = base + (which ? T.mip2 : T.mip1);
+    double* S = sat + (size_t)blockIdx.z * G.sstride + T.sat_off;
+    const double cm = sample_c0(m, (size_t)T.dimu * T.dimv);
+    if (pc == npieces) {  // c0 and the (ph + 1) x (pw + 1) inclusive table of the tile sums, one wave
+        if (wave != 0) return;
+        if (lane == 0) S[which] = cm;
+        const int ph = T.dimu / TILE, pw = T.dimv / TILE;
+        if (!T.tiled || ph * pw == 0) return;
+        const float* ps = base + (which ? T.ps2 : T.ps1);
+        double* ts = S + 2 + 4 * T.tab + which * T.ts;
+        const int tw1 = pw + 1;
+        for (int i = lane; i < tw1; i += 64) ts[i] = 0.0;
+        for (int r = lane; r <= ph; r += 64) ts[(size_t)r * tw1] = 0.0;
+        // The lanes run along the longer side of the tile grid, the shorter side is walked in sequence (its samples requested
+        // eight steps at a time): cumulative sums along the lanes by a wave scan, along the walk in the lanes' registers.
+        const bool lanes_cols = pw >= ph;
+        const int nl = lanes_cols ? pw : ph, nsq = lanes_cols ? ph : pw;         // lanes' extent, steps
+        const int lstep = lanes_cols ? 1 : pw, sstep = lanes_cols ? pw : 1;      // strides in ps
+        const int olstep = lanes_cols ? 1 : tw1, osstep = lanes_cols ? tw1 : 1;  // strides in ts (entry (r + 1, c + 1))
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};  // (tile grids of up to 256 along the lanes: MIPs of up to 8192 pixels)
+        for (int q0 = 0; q0 < nsq; q0 += 8) {
+            float v[8][4];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) {
+                    const int l = min(kb * 64 + lane, nl - 1), q = min(q0 + u, nsq - 1);
+                    v[u][kb] = kb * 64 < nl ? ps[(size_t)q * sstep + (size_t)l * lstep] : 0.0f;
+                }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (q0 + u >= nsq) break;
+                double carry_l = 0.0;
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) {
+                    if (kb * 64 >= nl) break;
+                    const int l = kb * 64 + lane;
+                    const double sc = wave_scan_dpp(l < nl ? (double)v[u][kb] : 0.0) + carry_l;
+                    carry_l = __shfl(sc, 63, 64);
+                    acc[kb] += sc;
+                    if (l < nl) ts[(size_t)(q0 + u + 1) * osstep + (size_t)(l + 1) * olstep] = acc[kb];
+                }
+            }
+        }
+        return;
+    }
+    __shared__ double tot[2][BAND_RC][4];    // the waves' row totals (p, q)
+    __shared__ double carry[2][BAND_RC];     // totals of the column rounds before this one
+    const int n_long = T.n_long, n_short = T.n_short, ls = T.ls, ss = T.ss, B = T.B, w1 = n_short + 1;
+    const bool full = T.nbands == 1;
+    const int band = pc / T.ppb, k = pc - band * T.ppb, per_band = full ? n_long + 1 : B + 1;
+    const int e0 = band * per_band + k * BAND_RC, ne = min(BAND_RC, per_band - k * BAND_RC);
+    const int a_first = band == 0 ? k * BAND_RC : n_long - B + k * BAND_RC;
+    const int nstart = band == 0 ? k : T.ppb + T.nch + k;
+    double* P = S + 2 + (size_t)(2 * which) * T.tab;
+    double* Q = P + T.tab;
+    const double* Tp = S + 2 + 4 * T.tab + 2 * T.ts + (size_t)(2 * which) * T.nseg * n_short;
+    const double* Tq = Tp + (size_t)T.nseg * n_short;
+    if (tid < 2 * BAND_RC) carry[tid / BAND_RC][tid % BAND_RC] = 0.0;
+    __syncthreads();
+    for (int b0 = 0; b0 < n_short; b0 += 256) {
+        const int b = b0 + tid, bc = min(b, n_short - 1);
+        const float* col = m + (size_t)bc * ss;
+        float v[BAND_RC];
+#pragma unroll
+        for (int r = 0; r < BAND_RC; ++r) v[r] = col[(size_t)min(a_first + r, n_long - 1) * ls];
+        double rp = 0.0, rq = 0.0;
+        for (int s0 = 0; s0 < nstart; s0 += 8) {  // (requested together, added in order)
+            double tp[8], tq[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const size_t o = (size_t)min(s0 + c, nstart - 1) * n_short + bc;
+                tp[c] = Tp[o];
+                tq[c] = Tq[o];
+            }
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                if (s0 + c < nstart) { rp += tp[c]; rq += tq[c]; }
+        }
+        if (b >= n_short) { rp = 0.0; rq = 0.0; }
+        double ep[BAND_RC], eq[BAND_RC];
+#pragma unroll
+        for (int r = 0; r < BAND_RC; ++r) {
+            ep[r] = wave_scan_dpp(rp);
+            eq[r] = wave_scan_dpp(rq);
+            if (lane == 63) { tot[0][r][wave] = ep[r]; tot[1][r][wave] = eq[r]; }
+            if (b < n_short && a_first + r < n_long) {
+                const double g = (double)v[r] - cm;
+                rp += g;
+                rq += g * g;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < BAND_RC; ++r) {
+            double op = carry[0][r], oq = carry[1][r];
+            for (int w = 0; w < wave; ++w) { op += tot[0][r][w]; oq += tot[1][r][w]; }
+            if (r < ne && b < n_short) {
+                P[(size_t)(e0 + r) * w1 + b + 1] = ep[r] + op;
+                Q[(size_t)(e0 + r) * w1 + b + 1] = eq[r] + oq;
+            }
+        }
+        if (b0 == 0 && tid < ne) { P[(size_t)(e0 + tid) * w1] = 0.0; Q[(size_t)(e0 + tid) * w1] = 0.0; }
+        __syncthreads();
+        if (tid < 2 * BAND_RC) {
+            const int t = tid / BAND_RC, r = tid % BAND_RC;
+            carry[t][r] += tot[t][r][0] + tot[t][r][1] + tot[t][r][2] + tot[t][r][3];
+        }
+        __syncthreads();
     }
 }
 
@@ -485,8 +767,17 @@ __device__ int block_argmax(const float* __restrict__ arr, int len, float* red_v
 // one work-group per pair: the NCC map of a plane from the cross table + summed-area tables (compute_NCC, :1163-1292), then
 // compute_Neighborhood (:1324-1592) entirely on the device.  Returns the final window, du, dv, failed and flags
 // (1: an entry outside the transformed lag range was needed, 2: an argmax was decided by less than `margin`).
-__global__ __launch_bounds__(256) void k_lag_refine(RefineGeom g, const double* __restrict__ sat_base, const double* __restrict__ cross, int wcap,
-                                                    float* __restrict__ out_win, int* __restrict__ out_int, float* __restrict__ out_map) {
+struct RefineAll {
+    RefineGeom g[3];
+    const double* cross[3];
+    int chunk;  // pairs per plane in the output arrays: window of (plane, pair) at out_win + (plane * chunk + pair) * wcap
+};
+__global__ __launch_bounds__(256) void k_lag_refine(RefineAll A, const double* __restrict__ sat_base, int wcap, float* __restrict__ out_win,
+                                                    int* __restrict__ out_int, float* __restrict__ out_map) {
+    const RefineGeom& g = A.g[blockIdx.y];
+    const double* cross = A.cross[blockIdx.y];
+    out_win += (size_t)blockIdx.y * A.chunk * wcap;
+    out_int += (size_t)blockIdx.y * A.chunk * 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char lag_lds[];
     __shared__ float red_v[256];
     __shared__ int red_i[256];
@@ -564,46 +855,22 @@ __global__ __launch_bounds__(256) void k_lag_refine(RefineGeom g, const double* 
 struct LagPlane {
     bool long_is_u;
     int n_long, n_short, ls, ss, El, Es, Eu, Ev;
-    FftPlan fft;
+    Plan fft;    // along the long axis
+    Plan cfft;   // along the short axis (use_corr)
+    bool use_corr;
     int KT, JP, FW, TW, LB, nlp, fft_threads;
-    size_t lds_fft, lds_mac, lds_refine;
+    size_t lds_fft, lds_mac, lds_corr, lds_refine;
     bool ok;
 };
 
-// smallest N = 2^a * {1, 3, 9} >= need (a >= 2), as radix-4 stages, then a radix-2 stage, then the radix-3 stages
-FftPlan make_fft_plan(int need) {
-    long best = 0;
-    int best_a = 0, best_b = 0;
-    for (int b = 0; b <= 2; ++b) {
-        long n = b == 0 ? 1 : (b == 1 ? 3 : 9);
-        int a = 0;
-        while (a < 2 || n < need) { n *= 2; ++a; }
-        if (best == 0 || n < best) { best = n; best_a = a; best_b = b; }
-    }
-    FftPlan pl{};
-    pl.N = (int)best;
-    int a = best_a;
-    while (a >= 2) { pl.radix[pl.nstages++] = 4; a -= 2; }
-    if (a == 1) pl.radix[pl.nstages++] = 2;
-    for (int b = 0; b < best_b; ++b) pl.radix[pl.nstages++] = 3;
-    int off = 0, L = pl.N;
-    for (int st = 0; st < pl.nstages; ++st) {
-        pl.twoff[st] = off;
-        L /= pl.radix[st];           // q of the stage
-        off += (pl.radix[st] - 1) * L;
-    }
-    return pl;
-}
-
-int host_pos_of_freq(int k, const FftPlan& pl) {
-    int p = 0, rem = pl.N;
-    for (int s = 0; s < pl.nstages; ++s) {
-        const int r = pl.radix[s];
-        rem /= r;
-        p += (k % r) * rem;
-        k /= r;
-    }
-    return p;
+// make_plan searches the LDS image of a length: once per length and process
+const Plan& plan_for(int need) {
+    static std::mutex& mu = *new std::mutex;
+    static std::map<int, Plan>& plans = *new std::map<int, Plan>;  // keyed by the request; several requests may share a length
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = plans.find(need);
+    if (it == plans.end()) it = plans.emplace(need, fft64::make_plan(need)).first;
+    return it->second;
 }
 
 LagPlane plan_lag_plane(const PlaneGeom& g, int maxIter) {
@@ -621,80 +888,71 @@ LagPlane plan_lag_plane(const PlaneGeom& g, int maxIter) {
     p.Es = ds + (maxIter > 0 ? wsh : 0);
     p.Eu = p.long_is_u ? p.El : p.Es;
     p.Ev = p.long_is_u ? p.Es : p.El;
-    p.fft = make_fft_plan(p.n_long + p.El);
-    p.lds_fft = sizeof(double) * 2 * (size_t)p.fft.N;
+    p.ok = p.n_long + p.El <= 8192;
+    if (!p.ok) return p;
+    p.fft = plan_for(p.n_long + p.El);
+    p.lds_fft = sizeof(double) * 2 * ((size_t)p.fft.N + fft64::lds_twiddles(p.fft));
     const int nlag = 2 * p.Es + 1;
-    p.LB = 4;  // lags per thread of the correlation kernel (8 was measured: twice the registers, bank conflicts, no faster)
+    p.LB = 4;  // lags per thread of the direct correlation kernel (8 was measured: twice the registers, bank conflicts, no faster)
     p.nlp = (nlag + p.LB - 1) / p.LB * p.LB;
-    const int PAD = p.Es + p.LB - 1;
-    // odd row lengths (in 16-byte slots): the KT rows a wave touches at once start in different banks, and a lag block is four slots
-    p.FW = (p.n_short + 2 * PAD + p.LB) | 1;
-    p.TW = (p.n_short + p.LB) | 1;
-    const size_t row = sizeof(double) * 2 * (size_t)(p.FW + p.TW);
-    // four frequencies per work-group: with rows one 16-byte slot apart and lanes ordered (frequency fastest, then lag block) the
-    // 16-byte LDS reads of a wave are conflict-free; the j range is cut into JP parts so that all 256 threads have an item
-    p.KT = (int)std::min<size_t>(4, (48 * 1024) / row);
-    if (p.KT < 1) p.KT = 1;
-    const int nvb = p.nlp / p.LB;
-    while (p.KT > 1 && p.KT * nvb > 256) --p.KT;
-    p.JP = std::max(1, std::min(8, 256 / (p.KT * nvb)));
-    p.fft_threads = p.fft.N >= 2048 ? 512 : 256;
-    p.lds_mac = row * p.KT + sizeof(double) * 2 * p.LB * (size_t)(p.JP - 1) * nvb * p.KT;  // (xy plane of config 5: 52 KB, three per CU)
+    // Short axes of 64 lines and more are correlated through a second transform (k_lag_corr), the others lag by lag (k_lag_mac):
+    // 32-line planes (the xz / yz MIPs of thin stacks) have too few samples per frequency to fill a transform's work-group.
+    p.use_corr = p.n_short >= 64;
+    if (p.use_corr) {
+        p.cfft = plan_for(p.n_short + p.Es);
+        const size_t img = sizeof(double) * 2 * ((size_t)p.cfft.N + 1);
+        p.KT = (int)std::max<size_t>(1, std::min<size_t>(4, (48 * 1024) / (2 * img)));
+        p.lds_corr = 2 * (size_t)p.KT * img + sizeof(double) * 2 * (size_t)fft64::lds_twiddles(p.cfft);
+        p.JP = 1; p.FW = p.TW = 0;
+        p.lds_mac = 0;
+        p.ok = p.lds_corr <= 150 * 1024;
+    } else {
+        const int PAD = p.Es + p.LB - 1;
+        // odd row lengths (in 16-byte slots): the KT rows a wave touches at once start in different banks, and a lag block is four slots
+        p.FW = (p.n_short + 2 * PAD + p.LB) | 1;
+        p.TW = (p.n_short + p.LB) | 1;
+        const size_t row = sizeof(double) * 2 * (size_t)(p.FW + p.TW);
+        // four frequencies per work-group: with rows one 16-byte slot apart and lanes ordered (frequency fastest, then lag block) the
+        // 16-byte LDS reads of a wave are conflict-free; the j range is cut into JP parts so that all 256 threads have an item
+        p.KT = (int)std::min<size_t>(4, (48 * 1024) / row);
+        if (p.KT < 1) p.KT = 1;
+        const int nvb = p.nlp / p.LB;
+        while (p.KT > 1 && p.KT * nvb > 256) --p.KT;
+        p.JP = std::max(1, std::min(8, 256 / (p.KT * nvb)));
+        p.lds_mac = row * p.KT + sizeof(double) * 2 * p.LB * (size_t)(p.JP - 1) * nvb * p.KT;
+        p.ok = p.lds_mac <= 150 * 1024 && nvb <= 256;
+    }
+    p.fft_threads = p.fft.N >= 1024 ? 256 : 128;
     const int Hm = 2 * g.delayu + 1, Wm = 2 * g.delayv + 1, H = 2 * g.wu + 1, W = 2 * g.wv + 1;
     p.lds_refine = sizeof(float) * ((size_t)Hm * Wm + 2 * (size_t)H * W);
-    p.ok = p.fft.N <= 8192 && p.lds_mac <= 150 * 1024 && nvb <= 256 && p.lds_refine <= 120 * 1024;
+    p.ok = p.ok && p.fft.N <= 8192 && p.lds_refine <= 120 * 1024;
     return p;
 }
 
-// Per (device, N), kept for the life of the process: exp(-2 pi i n / N) in fp64, and the slot tables of the half spectrum
-// (position of slot s in ascending order, position of its mirror frequency, its frequency).
+// Per (device, N), kept for the life of the process: the stages' twiddle tables in fp64 and the slot tables of the half spectrum
+// (LDS slot of the s-th frequency in ascending logical position, LDS slot of its mirror frequency, slot of a frequency).
 struct FftTables {
     const cplx* tw;
-    const int *slot_pos, *slot_neg, *slot_freq;
+    const int *slot_pos, *slot_neg, *freq_slot;
 };
 struct TwiddleKey { int dev, n; bool operator<(const TwiddleKey& o) const { return dev != o.dev ? dev < o.dev : n < o.n; } };
 std::mutex& g_tw_mu = *new std::mutex;
 std::map<TwiddleKey, FftTables>& g_tw = *new std::map<TwiddleKey, FftTables>;
 
-int fft_tables(int dev, const FftPlan& pl, hipStream_t s, FftTables* out) {
+int fft_tables(int dev, const Plan& pl, hipStream_t s, FftTables* out) {
     std::lock_guard<std::mutex> lock(g_tw_mu);
     auto it = g_tw.find(TwiddleKey{dev, pl.N});
     if (it != g_tw.end()) { *out = it->second; return MI_OK; }
     const size_t N = (size_t)pl.N, NK = N / 2 + 1;
-    std::vector<double> h(2 * N);
-    const long double step = 2.0L * 3.14159265358979323846264338327950288L / (long double)N;
-    for (size_t n = 0; n < N; ++n) {
-        h[2 * n] = (double)cosl(step * (long double)n);
-        h[2 * n + 1] = (double)-sinl(step * (long double)n);
-    }
-    if (N % 4 == 0) {  // exact at the quarter points
-        h[2 * (N / 4)] = 0.0; h[2 * (N / 4) + 1] = -1.0;
-        h[2 * (N / 2)] = -1.0; h[2 * (N / 2) + 1] = 0.0;
-        h[2 * (3 * N / 4)] = 0.0; h[2 * (3 * N / 4) + 1] = 1.0;
-    }
-    std::vector<std::pair<int, int>> order(NK);  // (position, frequency)
-    for (size_t k = 0; k < NK; ++k) order[k] = {host_pos_of_freq((int)k, pl), (int)k};
+    const std::vector<double> hs = fft64::make_twiddles(pl);
+    std::vector<std::pair<int, int>> order(NK);  // (logical position, frequency)
+    for (size_t k = 0; k < NK; ++k) order[k] = {fft64::pos_of_freq(pl, (int)k), (int)k};
     std::sort(order.begin(), order.end());
     std::vector<int> tabs(3 * NK);
     for (size_t sl = 0; sl < NK; ++sl) {
-        tabs[sl] = order[sl].first;
-        tabs[NK + sl] = host_pos_of_freq((int)((N - (size_t)order[sl].second) % N), pl);
-        tabs[2 * NK + sl] = order[sl].second;
-    }
-    // per-stage tables: copies of the entries above, so every twiddle keeps its value
-    std::vector<double> hs;
-    {
-        size_t L = N;
-        for (int st = 0; st < pl.nstages; ++st) {
-            const size_t r = (size_t)pl.radix[st], q = L / r, tstep = N / L;
-            for (size_t m = 1; m < r; ++m)
-                for (size_t t = 0; t < q; ++t) {
-                    const size_t n = m * t * tstep;  // < N
-                    hs.push_back(h[2 * n]);
-                    hs.push_back(h[2 * n + 1]);
-                }
-            L = q;
-        }
+        tabs[sl] = fft64::phys(pl, order[sl].first);
+        tabs[NK + sl] = fft64::phys(pl, fft64::pos_of_freq(pl, (int)((N - (size_t)order[sl].second) % N)));
+        tabs[2 * NK + (size_t)order[sl].second] = (int)sl;
     }
     void *d = nullptr, *di = nullptr;
     MI_HIP(hipMalloc(&d, sizeof(double) * hs.size()));
@@ -712,67 +970,54 @@ int fft_tables(int dev, const FftPlan& pl, hipStream_t s, FftTables* out) {
 // device + pinned buffers of the batched pipeline, kept between calls (one set per concurrent caller and device)
 struct LagWorkspace {
     int dev = -1;
-    DevBuf fbuf, sat, mip_tmp, SF[3], ST[3], CH[3], cross[3], outw, outi, tab;  // (lag-transform scratch per plane: the planes' chains run side by side)
+    DevBuf fbuf, sat, mip_tmp, SP[3], CH[3], cross[3], outw, outi, tab;  // (lag-transform scratch per plane: the planes' chains run side by side)
     PinnedBuf pin_tab, pin_w, pin_i;
-    // Two streams PER DEVICE, shared by every group in flight: the MIP pass (k_mips: one HBM-bound streaming read of both overlap
-    // views) of piece i + 1 runs on `sm` while the table / lag-transform / refinement chain (fp64 and LDS work on a few MB) of
-    // piece i runs on `sl`.  (A pair of streams per workspace mapped onto the same hardware queues in a way that put one
-    // group's MIP pass behind the other group's chain: 1.3 of 4.8 ms overlapped, profiles/r03_ncc_timeline.txt.)
-    hipStream_t sm = nullptr, sl[3] = {nullptr, nullptr, nullptr};  // (sl[m]: the chain of plane m; MI_NCC_CHAIN_STREAMS=1: one for all)
-    hipStream_t sx = nullptr;  // MI_NCC_SPLIT_XY=1: the lag transform of the xy plane beside that plane's tables (default: behind them;
-                               // measured equal -- the runtime maps the extra stream onto the hardware queue of the tables)
-    hipEvent_t ev_start = nullptr, ev_lag = nullptr, ev_done = nullptr, ev_plane[2] = {nullptr, nullptr}, ev_x = nullptr;
+    // Three streams PER DEVICE, shared by every group in flight: `sm` the MIP pass (k_mips: one HBM-bound streaming read of both
+    // overlap views), `sa` the lag transform of the xy plane and the refinement of all planes, `sb` the tables of all planes and
+    // the lag transforms of the two thin planes.  (A set of streams per workspace mapped onto the same hardware queues in a way
+    // that put one group's MIP pass behind the other group's chain: profiles/r03_ncc_timeline.txt.)
+    hipStream_t sm = nullptr, sa = nullptr, sb = nullptr;
+    hipEvent_t ev_start = nullptr, ev_lag = nullptr, ev_done = nullptr, ev_side = nullptr;
     hipEvent_t ev_head_tab = nullptr;
     hipEvent_t ev_head = nullptr;  // per DEVICE like the streams (not owned): "the memory-bound head of the latest xy chain has run"
     std::vector<hipEvent_t> ev_mip, ev_mip_xy;  // per piece: all six MIPs of its pairs final / the xy MIPs final
-    // The end of a job's device stage: ev_done on the xy plane's stream and one event on each of the other two.  The HOST waits for the
-    // three; the xy stream does not wait for the others -- the streams belong to the device, and the next group's xy chain sat
-    // behind that wait until this group's xz and yz chains had finished (0.35 ms of a 112-pair call: profiles/r03_ncc_timeline.txt).
     int wait_done() {
         MI_HIP(hipEventSynchronize(ev_done));
-        for (int m = 1; m < 3; ++m)
-            if (sl[m] != sl[0]) MI_HIP(hipEventSynchronize(ev_plane[m - 1]));
         return MI_OK;
     }
     ~LagWorkspace() {
         if (ev_start) (void)hipEventDestroy(ev_start);
         if (ev_lag) (void)hipEventDestroy(ev_lag);
         if (ev_done) (void)hipEventDestroy(ev_done);
-        if (ev_x) (void)hipEventDestroy(ev_x);
-        for (hipEvent_t e : ev_plane)
-            if (e) (void)hipEventDestroy(e);
+        if (ev_side) (void)hipEventDestroy(ev_side);
         for (hipEvent_t e : ev_mip) (void)hipEventDestroy(e);
         for (hipEvent_t e : ev_mip_xy) (void)hipEventDestroy(e);
     }
     int streams(size_t pieces) {
         {
             static std::mutex mu;
-            struct Four { hipStream_t s[5]; hipEvent_t head, head_tab; };
-            static std::map<int, Four> per_dev;  // (never destroyed: the process' lifetime)
+            struct PerDev { hipStream_t s[3]; hipEvent_t head, head_tab; };
+            static std::map<int, PerDev> per_dev;  // (never destroyed: the process' lifetime)
             std::lock_guard<std::mutex> lock(mu);
             auto it = per_dev.find(dev);
             if (it == per_dev.end()) {
-                Four f{};
-                int chains = 3;
-                if (const char* e = std::getenv("MI_NCC_CHAIN_STREAMS")) chains = std::max(1, std::min(3, std::atoi(e)));
+                PerDev f{};
+                int chains = 2;
+                if (const char* e = MI_PROBE_ENV("MI_NCC_CHAIN_STREAMS")) chains = std::max(1, std::min(2, std::atoi(e)));
+                // (stream priorities were measured: no effect on a call, profiles/r04_ncc_notes.txt)
                 for (int i = 0; i < 1 + chains; ++i) MI_HIP(hipStreamCreateWithFlags(&f.s[i], hipStreamNonBlocking));
-                for (int i = 1 + chains; i < 4; ++i) f.s[i] = f.s[chains];
-                f.s[4] = f.s[1];
-                const char* sp = std::getenv("MI_NCC_SPLIT_XY");
-                if (chains >= 2 && sp && std::atoi(sp) != 0) MI_HIP(hipStreamCreateWithFlags(&f.s[4], hipStreamNonBlocking));
+                for (int i = 1 + chains; i < 3; ++i) f.s[i] = f.s[chains];
                 MI_HIP(hipEventCreateWithFlags(&f.head, hipEventDisableTiming));
                 MI_HIP(hipEventCreateWithFlags(&f.head_tab, hipEventDisableTiming));
                 it = per_dev.emplace(dev, f).first;
             }
             sm = it->second.s[0];
-            for (int m = 0; m < 3; ++m) sl[m] = it->second.s[1 + m];
-            sx = it->second.s[4];
+            sa = it->second.s[1];
+            sb = it->second.s[2];
             ev_head = it->second.head;
             ev_head_tab = it->second.head_tab;
         }
-        if (!ev_x) MI_HIP(hipEventCreateWithFlags(&ev_x, hipEventDisableTiming));
-        for (hipEvent_t& e : ev_plane)
-            if (!e) MI_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        if (!ev_side) MI_HIP(hipEventCreateWithFlags(&ev_side, hipEventDisableTiming));
         if (!ev_start) MI_HIP(hipEventCreateWithFlags(&ev_start, hipEventDisableTiming));
         if (!ev_done) MI_HIP(hipEventCreateWithFlags(&ev_done, hipEventDisableTiming));
         if (!ev_lag) MI_HIP(hipEventCreateWithFlags(&ev_lag, hipEventDisableTiming));
@@ -813,123 +1058,107 @@ void give_lag_ws(std::unique_ptr<LagWorkspace> r) {
 
 int grow(DevBuf& b, size_t bytes) { return b.bytes >= bytes ? MI_OK : b.alloc(bytes); }
 
-// The work-group shapes of the two transform kernels: threads and butterflies per thread and step.
-using FwdFn = void (*)(const float*, const float*, size_t, int, int, int, int, int, FftPlan, const cplx*, const int*, const int*, cplx*, cplx*);
-using InvFn = void (*)(const cplx*, int, int, FftPlan, int, int, int, int, int, const cplx*, const int*, double*);
-struct FftShape {
-    int threads, bf;
-    FwdFn fwd_fn;
-    InvFn inv_fn;
-    const void *fwd, *inv;
-};
-template <int TH, int BF>
-FftShape make_shape() {
-    FftShape s{TH, BF, k_lag_fwd<TH, BF>, k_lag_inv<TH, BF>, nullptr, nullptr};
-    s.fwd = reinterpret_cast<const void*>(s.fwd_fn);
-    s.inv = reinterpret_cast<const void*>(s.inv_fn);
-    return s;
-}
-const FftShape& fft_shape(const LagPlane& lp) {
-    static const FftShape shapes[] = {make_shape<512, 2>(), make_shape<512, 1>(), make_shape<256, 2>(), make_shape<256, 1>(), make_shape<256, 3>(),
-                                      make_shape<192, 3>(), make_shape<384, 3>(), make_shape<128, 3>(), make_shape<128, 5>()};
-    static const int forced = [] {  // MI_NCC_FFT_SHAPE=<threads>,<butterflies>: measurement aid
-        const char* e = std::getenv("MI_NCC_FFT_SHAPE");
-        int t = 0, b = 0;
-        if (!e || sscanf(e, "%d,%d", &t, &b) != 2) return -1;
-        for (size_t i = 0; i < sizeof(shapes) / sizeof(shapes[0]); ++i)
-            if (shapes[i].threads == t && shapes[i].bf == b) return (int)i;
-        return -1;
-    }();
-    if (forced >= 0) return shapes[forced];
-    // one butterfly per thread and step keeps the kernels under 64 registers: four work-groups of 512 per CU instead of two
-    // (forward transform of the xy plane 765 -> 500 us: profiles/r03_lag_shapes.txt)
-    return lp.fft_threads == 512 ? shapes[1] : shapes[3];
-}
-
 // cross terms of `np` pairs of one plane through the lag transform (MIPs at m1 / m2 + q * pstride) into ws.cross
 int lag_cross(int dev, hipStream_t s, const LagPlane& lp, const float* m1, const float* m2, size_t pstride, int np, LagWorkspace& ws, int m = 0,
               hipEvent_t after_fwd = nullptr) {
-    const int N = lp.fft.N, NK = N / 2 + 1, nlag = 2 * lp.Es + 1, nlp = lp.nlp, NKP = (NK + 7) & ~7;
+    const int N = lp.fft.N, NK = N / 2 + 1, nlag = 2 * lp.Es + 1, nlp = lp.nlp;
+    const int tiles_per_pair = ((NK + lp.KT - 1) / lp.KT + 1) & ~1, ntiles = tiles_per_pair * np;  // (even: see k_lag_mac)
     FftTables ft;
     MI_TRY(fft_tables(dev, lp.fft, s, &ft));
-    const cplx* tw = ft.tw;
-    MI_TRY(grow(ws.SF[m], sizeof(double) * 2 * (size_t)np * lp.n_short * NKP));
-    MI_TRY(grow(ws.ST[m], sizeof(double) * 2 * (size_t)np * lp.n_short * NKP));
+    MI_TRY(grow(ws.SP[m], sizeof(double) * 2 * (size_t)ntiles * lp.n_short * 2 * lp.KT));
     MI_TRY(grow(ws.CH[m], sizeof(double) * 2 * (size_t)np * NK * nlp));
     MI_TRY(grow(ws.cross[m], sizeof(double) * (size_t)np * (2 * lp.Eu + 1) * (2 * lp.Ev + 1)));
-    const FftShape& sh = fft_shape(lp);
-    if (lp.lds_fft > 64 * 1024) MI_HIP(hipFuncSetAttribute(sh.fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp.lds_fft));
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(sh.fwd_fn), dim3(8 * ((lp.n_short + 7) / 8), np), dim3(sh.threads), lp.lds_fft, s, m1, m2, pstride, lp.n_long,
-                       lp.n_short, lp.ls, lp.ss, NKP, lp.fft, tw, ft.slot_pos, ft.slot_neg, ws.SF[m].as<cplx>(), ws.ST[m].as<cplx>());
-    MI_TRY(launch_check("k_lag_fwd"));
-    if (after_fwd) MI_HIP(hipEventRecord(after_fwd, s));
+    const bool big = lp.fft_threads == 256;
     {
-        using MacFn = void (*)(const cplx*, const cplx*, int, int, int, int, int, int, int, int, int, int, int, cplx*);
+        auto fwd = big ? k_lag_fwd<256> : k_lag_fwd<128>;
+        if (lp.lds_fft > 64 * 1024)
+            MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp.lds_fft));
+        hipLaunchKernelGGL(fwd, dim3(8 * ((lp.n_short + 7) / 8), np), dim3(lp.fft_threads), lp.lds_fft, s, m1, m2, pstride, lp.n_long, lp.n_short, lp.ls,
+                           lp.ss, lp.KT, tiles_per_pair, lp.fft, ft.tw, ft.slot_pos, ft.slot_neg, ws.SP[m].as<cplx>());
+        MI_TRY(launch_check("k_lag_fwd"));
+    }
+    if (after_fwd) MI_HIP(hipEventRecord(after_fwd, s));
+    if (lp.use_corr) {
+        FftTables ct;
+        MI_TRY(fft_tables(dev, lp.cfft, s, &ct));
+        if (lp.lds_corr > 64 * 1024)
+            MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lag_corr<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp.lds_corr));
+        hipLaunchKernelGGL(k_lag_corr<256>, dim3(tiles_per_pair, np), dim3(256), lp.lds_corr, s, ws.SP[m].as<cplx>(), lp.n_short, NK, lp.Es, lp.KT, nlp,
+                           tiles_per_pair, lp.cfft, ct.tw, ws.CH[m].as<cplx>());
+        MI_TRY(launch_check("k_lag_corr"));
+    } else {
+        using MacFn = void (*)(const cplx*, int, int, int, int, int, int, int, int, int, int, cplx*);
         static const MacFn macs[] = {k_lag_mac<4, 0>, k_lag_mac<4, 1>, k_lag_mac<4, 2>, k_lag_mac<4, 3>, k_lag_mac<4, 4>, k_lag_mac<4, 5>, k_lag_mac<4, 6>};
         const int pfn = (lp.n_short * lp.KT + 255) / 256;  // float4 pairs per thread of a tile; beyond the table: no register prefetch
         MacFn mac = macs[pfn <= 6 ? pfn : 0];
-        const int tiles_per_pair = ((NK + lp.KT - 1) / lp.KT + 1) & ~1, ntiles = tiles_per_pair * np;  // (even: see k_lag_mac)
         int cus = 256, per_cu = 1;
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         if (lp.lds_mac > 64 * 1024)
             MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mac), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp.lds_mac));
         per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / std::max<size_t>(lp.lds_mac, 1)));
         const int grid = std::max(16, std::min((ntiles + 15) & ~15, (cus * per_cu) & ~15));
-        hipLaunchKernelGGL(mac, dim3(grid), dim3(256), lp.lds_mac, s, ws.SF[m].as<cplx>(), ws.ST[m].as<cplx>(), lp.n_short, NK, lp.Es, lp.KT, lp.JP,
-                           lp.FW, lp.TW, nlp, NKP, tiles_per_pair, ntiles, ws.CH[m].as<cplx>());
+        hipLaunchKernelGGL(mac, dim3(grid), dim3(256), lp.lds_mac, s, ws.SP[m].as<cplx>(), lp.n_short, NK, lp.Es, lp.KT, lp.JP, lp.FW, lp.TW, nlp,
+                           tiles_per_pair, ntiles, ws.CH[m].as<cplx>());
+        MI_TRY(launch_check("k_lag_mac"));
     }
-    MI_TRY(launch_check("k_lag_mac"));
-    if (lp.lds_fft > 64 * 1024) MI_HIP(hipFuncSetAttribute(sh.inv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp.lds_fft));
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(sh.inv_fn), dim3((nlag + 1) / 2, np), dim3(sh.threads), lp.lds_fft, s, ws.CH[m].as<cplx>(), NK, nlp, lp.fft, lp.Es, lp.El,
-                       lp.long_is_u ? 1 : 0, lp.Eu, lp.Ev, tw, ft.slot_freq, ws.cross[m].as<double>());
+    {
+        auto inv = big ? k_lag_inv<256> : k_lag_inv<128>;
+        if (lp.lds_fft > 64 * 1024)
+            MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(inv), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp.lds_fft));
+        const int lagpairs = (nlag + 1) / 2;
+        hipLaunchKernelGGL(inv, dim3(8 * ((np + 7) / 8) * lagpairs), dim3(lp.fft_threads), lp.lds_fft, s, ws.CH[m].as<cplx>(), NK, nlp, lp.fft, lp.Es,
+                           lp.El, lp.long_is_u ? 1 : 0, lp.Eu, lp.Ev, ft.tw, ft.freq_slot, np, lagpairs, ws.cross[m].as<double>());
+    }
     return launch_check("k_lag_inv");
 }
 
-// layout of one plane's banded tables (doubles): c0a, c0b | P1 | Q1 | P2 | Q2 | TS1 | TS2 | partial pixel sums | chunk column sums
+// layout of one plane's banded tables (doubles): c0a, c0b | P1 | Q1 | P2 | Q2 | TS1 | TS2 | column sums of the row segments
 struct BandLayout {
-    int B, rows, nch;
+    int B, rows, ppb, nbands, nch, nseg;
     size_t tab, ts, total;
     BandLayout(const PlaneGeom& g, const LagPlane& lp) {
         B = lp.El + TILE;                                   // rows read: within E (+ 31 for the tile-aligned ones) of either end
         if (2 * (B + 1) >= lp.n_long + 1) B = lp.n_long;    // no gain: keep every row
-        rows = B >= lp.n_long ? lp.n_long + 1 : 2 * (B + 1);
-        nch = (lp.n_long + BAND_CH - 1) / BAND_CH;
+        const bool full = B >= lp.n_long;
+        rows = full ? lp.n_long + 1 : 2 * (B + 1);
+        nbands = full ? 1 : 2;
+        ppb = ((full ? lp.n_long + 1 : B + 1) + BAND_RC - 1) / BAND_RC;
+        const int skipped = full ? 0 : lp.n_long - 2 * B;
+        nch = lp.ls == 1 ? (skipped > 0 ? 1 : 0) : (skipped + BAND_CH - 1) / BAND_CH;  // (long axis contiguous: one sum per column)
+        nseg = ppb + nch + (nbands == 2 ? ppb : 0);
         tab = (size_t)rows * (lp.n_short + 1);
         ts = (size_t)(g.dimu / TILE + 1) * (g.dimv / TILE + 1);
-        total = 2 + 4 * tab + 2 * ts + 2 * MEAN_PARTS + 4 * (size_t)nch * lp.n_short;
+        total = 2 + 4 * tab + 2 * ts + 4 * (size_t)nseg * lp.n_short;
     }
 };
 
-// float tile sums (reference order), global means and the banded tables of both MIPs of a plane, `np` pairs at once
-int prepare_plane_band(hipStream_t s, const float* m1, const float* m2, const PlaneGeom& g, const LagPlane& lp, float* ps1, float* ps2, double* sat,
-                       int np, size_t pstride, size_t sstride) {
+TabPlane tab_plane(const PlaneGeom& g, const LagPlane& lp, size_t sat_off) {
     const BandLayout L(g, lp);
-    double *c0a = sat, *c0b = sat + 1, *P1 = sat + 2, *T1 = P1 + 4 * L.tab, *T2 = T1 + L.ts, *part = T2 + L.ts, *chunks = part + 2 * MEAN_PARTS;
-    if (g.tiled) {
-        const int nt = (g.dimu / TILE) * (g.dimv / TILE);
-        hipLaunchKernelGGL(k_tile_sums, dim3(nt, 2, np), dim3(64), 0, s, m1, m2, pstride, g.dimu, g.dimv, ps1, ps2);
-        MI_TRY(launch_check("k_tile_sums"));
+    TabPlane t{};
+    t.dimu = g.dimu; t.dimv = g.dimv; t.tiled = g.tiled ? 1 : 0;
+    t.pw = g.dimv / TILE; t.nt = (g.dimu / TILE) * t.pw;
+    t.n_long = lp.n_long; t.n_short = lp.n_short; t.ls = lp.ls; t.ss = lp.ss; t.B = L.B; t.rows = L.rows; t.long_contig = lp.ls == 1 ? 1 : 0;
+    t.ppb = L.ppb; t.nbands = L.nbands; t.nch = L.nch; t.nseg = L.nseg;
+    const int strips = (lp.n_short + 63) / 64;
+    t.units = L.nbands * L.ppb * strips + (t.long_contig ? (L.nch ? lp.n_short : 0) : L.nch * strips);
+    t.mip1 = g.mip1; t.mip2 = g.mip2; t.ps1 = g.ps1; t.ps2 = g.ps2;
+    t.sat_off = sat_off; t.tab = L.tab; t.ts = L.ts;
+    return t;
+}
+
+// float tile sums (reference order), shift constants and the banded tables of both MIPs of `nplanes` planes, `np` pairs at once
+int prepare_tables(hipStream_t s, const TabGeom& G, float* fbuf, double* sat, int np) {
+    int tb = 1, ub = 0, pieces = 0;
+    for (int m = 0; m < G.nplanes; ++m) {
+        tb = std::max(tb, ((G.p[m].dimu / TILE) * ((G.p[m].pw + 63) / 64) + 3) / 4);
+        ub = std::max(ub, (G.p[m].units + 3) / 4);
+        pieces = std::max(pieces, G.p[m].nbands * G.p[m].ppb);
     }
-    hipLaunchKernelGGL(k_mip_partial, dim3(MEAN_PARTS, 2, np), dim3(256), 0, s, m1, m2, pstride, sstride, (size_t)g.dimu * g.dimv, part);
-    MI_TRY(launch_check("k_mip_partial"));
-    hipLaunchKernelGGL(k_mip_mean, dim3(2, 1, np), dim3(1024), 0, s, part, pstride, sstride, g.dimu, g.dimv, g.tiled ? ps1 : nullptr,
-                       g.tiled ? ps2 : nullptr, c0a, c0b, T1, T2);
-    MI_TRY(launch_check("k_mip_mean"));
-    const int cblocks = (lp.n_short + 63) / 64;
-    if (L.B < lp.n_long) {  // the lower band starts from the chunk sums
-        if (lp.long_is_u)
-            hipLaunchKernelGGL(k_band_chunksum<false>, dim3(cblocks, L.nch, 2 * np), dim3(64), 0, s, m1, m2, pstride, sstride, c0a, lp.n_long, lp.n_short,
-                               lp.ls, lp.ss, L.nch, chunks);
-        else
-            hipLaunchKernelGGL(k_band_chunksum<true>, dim3(lp.n_short, L.nch, 2 * np), dim3(64), 0, s, m1, m2, pstride, sstride, c0a, lp.n_long, lp.n_short,
-                               lp.ls, lp.ss, L.nch, chunks);
-        MI_TRY(launch_check("k_band_chunksum"));
-    }
-    hipLaunchKernelGGL(k_band_cols, dim3(cblocks, 2, 2 * np), dim3(64), 0, s, m1, m2, pstride, sstride, c0a, lp.n_long, lp.n_short, lp.ls, lp.ss, L.nch,
-                       L.B, L.tab, chunks, P1);
-    MI_TRY(launch_check("k_band_cols"));
-    hipLaunchKernelGGL(k_band_rows, dim3(L.rows, 4, np), dim3(64), 0, s, sstride, lp.n_short, L.tab, P1);
-    return launch_check("k_band_rows");
+    static const int knock = [] { const char* e = MI_PROBE_ENV("MI_NCC_TAB_KNOCK"); return e ? std::atoi(e) : 0; }();
+    hipLaunchKernelGGL(k_plane_sums, dim3(tb + ub, 2 * G.nplanes, np), dim3(256), 0, s, G, fbuf, sat, tb, knock);
+    MI_TRY(launch_check("k_plane_sums"));
+    hipLaunchKernelGGL(k_band_tables, dim3(pieces + 1, 2 * G.nplanes, np), dim3(256), 0, s, G, fbuf, sat);
+    return launch_check("k_band_tables");
 }
 
 RefineGeom refine_geom(const PlaneGeom& g, const LagPlane& lp, int maxIter, size_t sstride, size_t sat_off, float margin) {
@@ -975,35 +1204,26 @@ struct LagJob {
             if (enqueued && ws->ev_done) (void)ws->wait_done();
             else if (ws->sm) {
                 (void)hipStreamSynchronize(ws->sm);
-                for (hipStream_t st : ws->sl) (void)hipStreamSynchronize(st);
-                if (ws->sx) (void)hipStreamSynchronize(ws->sx);
+                (void)hipStreamSynchronize(ws->sa);
+                (void)hipStreamSynchronize(ws->sb);
             }
             give_lag_ws(std::move(ws));
         }
     }
 };
 
-// Device stage of a group: enqueued behind the work `s` holds so far, on the device's MIP stream and its three chain streams.
-// What overlaps: the MIP pass of the NEXT group with the chains of this one, and the three planes' chains with each other.
-// (MI_NCC_PIECES > 1 cuts a group into pieces that are pipelined the same way; measured, it loses: the chain is a dozen
-// latency-bound launches whose cost hardly depends on the number of pairs, so pieces multiply it -- 9.3 / 10.2 / 12.3 ms per 112
-// pairs for 1 / 2 / 4 pieces.)
+// Device stage of a group: enqueued behind the work `s` holds so far, on the device's MIP stream and its two chain streams.
+// What overlaps: the MIP pass of the NEXT group with the chains of this one, and the xy plane's lag transform with the tables and
+// the thin planes' transforms.
 static int enqueue_chains(LagJob& job, int c0, int p0, int np, int pi, hipEvent_t gate, hipEvent_t gate_xy = nullptr);
 static int close_job(LagJob& job);
 
-// MI_NCC_GATE (default 1): a group's MIP pass starts only when the previous group's xy chain is past its tables and its forward lag
-// transform.  Those are bound by memory latency and run three times longer beside a MIP pass (which they slow down in turn); what
-// is left of the chain -- the fp64 correlation, the inverse transform, the refinement -- is compute-bound and shares the device well.
-static bool xy_tables_aside() {
-    static const bool on = [] {
-        const char* e = std::getenv("MI_NCC_XY_TABLES_ASIDE");
-        return e ? std::atoi(e) != 0 : true;
-    }();
-    return on;
-}
+// A group's MIP pass starts only when the previous group's chain is past its tables and its xy forward transform: those are bound
+// by memory latency and run several times longer beside a MIP pass (which they slow down in turn); what is left of the chain --
+// the correlation, the inverse transform, the refinement -- shares the device well (profiles/r03_ncc_timeline.txt).
 static bool mip_gate() {
     static const bool on = [] {
-        const char* e = std::getenv("MI_NCC_GATE");
+        const char* e = MI_PROBE_ENV("MI_NCC_GATE");
         return e ? std::atoi(e) != 0 : true;
     }();
     return on;
@@ -1039,9 +1259,9 @@ int ncc_lag_enqueue(int dev, hipStream_t s, int n, const float* const* a_ptrs, c
     size_t spec = 0, crs = 0;
     int wcap = 1;
     for (int m = 0; m < 3; ++m) {
-        const size_t NK = (size_t)lp[m].fft.N / 2 + 1, nlp = (size_t)lp[m].nlp;
-        spec = std::max(spec, 16 * (2 * (size_t)lp[m].n_short * ((NK + 7) & ~(size_t)7) + NK * nlp));
-        crs = std::max(crs, 8 * (size_t)(2 * lp[m].Eu + 1) * (2 * lp[m].Ev + 1));
+        const size_t NK = (size_t)lp[m].fft.N / 2 + 1, nlp = (size_t)lp[m].nlp, kt = (size_t)lp[m].KT;
+        spec += 16 * (2 * (size_t)lp[m].n_short * kt * (((NK + kt - 1) / kt + 1) & ~(size_t)1) + NK * nlp);
+        crs += 8 * (size_t)(2 * lp[m].Eu + 1) * (2 * lp[m].Ev + 1);
         wcap = std::max(wcap, (2 * pl.g[m].wu + 1) * (2 * pl.g[m].wv + 1));
     }
     job->wcap = wcap;
@@ -1049,9 +1269,7 @@ int ncc_lag_enqueue(int dev, hipStream_t s, int n, const float* const* a_ptrs, c
     size_t budget = (size_t)6 << 30;
     if (const char* e = std::getenv("MI_NCC_CHUNK_MB")) budget = (size_t)std::max(1, std::atoi(e)) << 20;
     const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, budget / per_pair));
-    int pieces = 1;
-    if (const char* e = std::getenv("MI_NCC_PIECES")) pieces = std::max(1, std::min(64, std::atoi(e)));
-    const int piece = std::max(1, (chunk + pieces - 1) / pieces);
+    const int piece = chunk;
 
     MI_TRY(grow(ws.fbuf, 4 * pstride * chunk));
     MI_TRY(grow(ws.sat, 8 * sstride * chunk));
@@ -1073,24 +1291,22 @@ int ncc_lag_enqueue(int dev, hipStream_t s, int n, const float* const* a_ptrs, c
     job->margin = ncc_margin();
     job->dev = dev; job->chunk = chunk; job->maxIter = P.maxIter; job->pstride = pstride; job->sstride = sstride;
     for (int m = 0; m < 3; ++m) job->sat_off[m] = sat_off[m];
-    const bool defer = defer_chains && chunk >= n && piece >= chunk;  // (one chunk, one piece: nothing of the chains is needed earlier)
+    const bool defer = defer_chains && chunk >= n;  // (one chunk: nothing of the chains is needed earlier)
     float* base0 = ws.fbuf.as<float>();
     hipStream_t sm = ws.sm;
     MI_HIP(hipEventRecord(ws.ev_start, s));
     MI_HIP(hipStreamWaitEvent(sm, ws.ev_start, 0));
-    for (int m = 0; m < 3; ++m)
-        if (m == 0 || ws.sl[m] != ws.sl[m - 1]) MI_HIP(hipStreamWaitEvent(ws.sl[m], ws.ev_start, 0));
+    MI_HIP(hipStreamWaitEvent(ws.sa, ws.ev_start, 0));
+    if (ws.sb != ws.sa) MI_HIP(hipStreamWaitEvent(ws.sb, ws.ev_start, 0));
     if (mip_gate()) {  // (never recorded yet: no wait)
         MI_HIP(hipStreamWaitEvent(sm, ws.ev_head, 0));
         MI_HIP(hipStreamWaitEvent(sm, ws.ev_head_tab, 0));
     }
     for (int c0 = 0; c0 < n; c0 += chunk) {
         const int nc = std::min(chunk, n - c0);
-        if (c0 > 0) {  // the buffers of the previous chunk are free once its chains have run
-            for (int m = 0; m < 3; ++m) {
-                MI_HIP(hipEventRecord(ws.ev_lag, ws.sl[m]));
-                MI_HIP(hipStreamWaitEvent(sm, ws.ev_lag, 0));
-            }
+        if (c0 > 0) {  // the buffers of the previous chunk are free once its chains have run (the refinement on `sa` is their end)
+            MI_HIP(hipEventRecord(ws.ev_lag, ws.sa));
+            MI_HIP(hipStreamWaitEvent(sm, ws.ev_lag, 0));
         }
         for (int p0 = 0, pi = 0; p0 < nc; p0 += piece, ++pi) {
             const int np = std::min(piece, nc - p0);
@@ -1111,8 +1327,8 @@ int ncc_lag_enqueue(int dev, hipStream_t s, int n, const float* const* a_ptrs, c
     return MI_OK;
 }
 
-// the table / lag-transform / refinement chains of the pairs [p0, p0 + np) of a chunk, one plane per chain stream, behind `gate`
-// (gate_xy: an earlier event that the xy plane's chain may start behind -- its MIPs come straight out of k_mips)
+// the table / lag-transform / refinement chain of the pairs [p0, p0 + np) of a chunk behind `gate` (gate_xy: an earlier event
+// that the xy plane's transform may start behind -- its MIPs come straight out of k_mips)
 static int enqueue_chains(LagJob& job, int c0, int p0, int np, int pi, hipEvent_t gate, hipEvent_t gate_xy) {
     (void)pi;
     if (!gate_xy) gate_xy = gate;
@@ -1123,57 +1339,55 @@ static int enqueue_chains(LagJob& job, int c0, int p0, int np, int pi, hipEvent_
     const size_t pstride = job.pstride, sstride = job.sstride;
     float* base = ws.fbuf.as<float>() + (size_t)p0 * pstride;
     double* sat_p = ws.sat.as<double>() + (size_t)p0 * sstride;
-    // the three planes' chains are independent (own MIPs, own tables, own lag-transform scratch): each is a dozen small
-    // dependent launches, so they run side by side on their own streams
+    hipStream_t sa = ws.sa, sb = ws.sb;
+    // `sb`: the tables of the three planes (two launches), then the lag transforms of the thin planes
+    MI_HIP(hipStreamWaitEvent(sb, gate, 0));
+    TabGeom G{};
+    G.nplanes = 3; G.pstride = pstride; G.sstride = sstride;
+    for (int m = 0; m < 3; ++m) G.p[m] = tab_plane(pl.g[m], lp[m], job.sat_off[m]);
+    MI_TRY(prepare_tables(sb, G, base, sat_p, np));
+    if (mip_gate()) MI_HIP(hipEventRecord(ws.ev_head_tab, sb));
+    for (int m = 1; m < 3; ++m) MI_TRY(lag_cross(job.dev, sb, lp[m], base + pl.g[m].mip1, base + pl.g[m].mip2, pstride, np, ws, m));
+    // `sa`: the xy plane's lag transform
+    if (sa != sb) MI_HIP(hipStreamWaitEvent(sa, gate_xy, 0));
+    MI_TRY(lag_cross(job.dev, sa, lp[0], base + pl.g[0].mip1, base + pl.g[0].mip2, pstride, np, ws, 0, mip_gate() ? ws.ev_head : nullptr));
+    if (sa != sb) {
+        MI_HIP(hipEventRecord(ws.ev_side, sb));
+        MI_HIP(hipStreamWaitEvent(sa, ws.ev_side, 0));
+    }
+    // the refinement of the three planes: one launch, one work-group per (pair, plane)
+    RefineAll R{};
+    size_t lds_refine = 0;
     for (int m = 0; m < 3; ++m) {
-        hipStream_t sl = ws.sl[m];
-        hipEvent_t gm = m == 0 ? gate_xy : gate;
-        if (m == 0 || sl != ws.sl[m - 1]) MI_HIP(hipStreamWaitEvent(sl, gm, 0));
-        const PlaneGeom& g = pl.g[m];
-        // the tables (tile sums, means, banded summed-area tables) and the lag transform of a plane read the same MIPs and meet
-        // only in the refinement.  For the xy plane, whose chain is the longest, the tables go to the stream of the xz plane (ahead
-        // of its chain): half a dozen small launches that fit beside the transform and the correlation.  (The device offers this
-        // process three hardware queues besides the default stream's: the MIP stream, the xy chain, everything else.)
-        const bool aside = m == 0 && xy_tables_aside() && ws.sl[1] != sl;
-        hipStream_t st = aside ? ws.sl[1] : sl;
-        hipStream_t sxm = (m == 0 && !aside && ws.sx != sl) ? ws.sx : sl;
-        if (st != sl) MI_HIP(hipStreamWaitEvent(st, gm, 0));
-        if (sxm != sl) MI_HIP(hipStreamWaitEvent(sxm, gm, 0));
-        MI_TRY(prepare_plane_band(st, base + g.mip1, base + g.mip2, g, lp[m], base + g.ps1, base + g.ps2, sat_p + job.sat_off[m], np, pstride,
-                                  sstride));
-        if (st != sl) {
-            MI_HIP(hipEventRecord(ws.ev_x, st));
-            if (mip_gate()) MI_HIP(hipEventRecord(ws.ev_head_tab, st));
+        R.g[m] = refine_geom(pl.g[m], lp[m], job.maxIter, sstride, job.sat_off[m], job.margin);
+        R.cross[m] = ws.cross[m].as<double>();
+        lds_refine = std::max(lds_refine, lp[m].lds_refine);
+    }
+    R.chunk = chunk;
+    if (lds_refine > 64 * 1024)
+        MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lag_refine), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_refine));
+    float* ow = ws.outw.as<float>() + (size_t)p0 * wcap;
+    int* oi = ws.outi.as<int>() + (size_t)p0 * 4;
+    hipLaunchKernelGGL(k_lag_refine, dim3(np, 3), dim3(256), lds_refine, sa, R, sat_p, wcap, ow, oi, (float*)nullptr);
+    MI_TRY(launch_check("k_lag_refine"));
+    if (np == chunk && chunk == n) {  // the whole job at once: the three planes' results are one block on either side
+        MI_HIP(hipMemcpyAsync(ws.pin_w.as<float>(), ws.outw.as<float>(), 4 * (size_t)3 * n * wcap, hipMemcpyDeviceToHost, sa));
+        MI_HIP(hipMemcpyAsync(ws.pin_i.as<int>(), ws.outi.as<int>(), sizeof(int) * 4 * 3 * (size_t)n, hipMemcpyDeviceToHost, sa));
+    } else {
+        for (int m = 0; m < 3; ++m) {
+            MI_HIP(hipMemcpyAsync(ws.pin_w.as<float>() + ((size_t)m * n + c0 + p0) * wcap, ow + (size_t)m * chunk * wcap, 4 * (size_t)np * wcap,
+                                  hipMemcpyDeviceToHost, sa));
+            MI_HIP(hipMemcpyAsync(ws.pin_i.as<int>() + ((size_t)m * n + c0 + p0) * 4, oi + (size_t)m * chunk * 4, sizeof(int) * 4 * np,
+                                  hipMemcpyDeviceToHost, sa));
         }
-        MI_TRY(lag_cross(job.dev, sxm, lp[m], base + g.mip1, base + g.mip2, pstride, np, ws, m, m == 0 && sxm == sl && mip_gate() ? ws.ev_head : nullptr));
-        if (st != sl) MI_HIP(hipStreamWaitEvent(sl, ws.ev_x, 0));
-        if (sxm != sl) {
-            MI_HIP(hipEventRecord(ws.ev_x, sxm));
-            MI_HIP(hipStreamWaitEvent(sl, ws.ev_x, 0));
-        }
-        const RefineGeom rg = refine_geom(g, lp[m], job.maxIter, sstride, job.sat_off[m], job.margin);
-        if (lp[m].lds_refine > 64 * 1024)
-            MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lag_refine), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lp[m].lds_refine));
-        float* ow = ws.outw.as<float>() + ((size_t)m * chunk + p0) * wcap;
-        int* oi = ws.outi.as<int>() + ((size_t)m * chunk + p0) * 4;
-        hipLaunchKernelGGL(k_lag_refine, dim3(np), dim3(256), lp[m].lds_refine, sl, rg, sat_p, ws.cross[m].as<double>(), wcap, ow, oi,
-                           (float*)nullptr);
-        MI_TRY(launch_check("k_lag_refine"));
-        MI_HIP(hipMemcpyAsync(ws.pin_w.as<float>() + ((size_t)m * n + c0 + p0) * wcap, ow, 4 * (size_t)np * wcap, hipMemcpyDeviceToHost, sl));
-        MI_HIP(hipMemcpyAsync(ws.pin_i.as<int>() + ((size_t)m * n + c0 + p0) * 4, oi, sizeof(int) * 4 * np, hipMemcpyDeviceToHost, sl));
     }
     return MI_OK;
 }
 
-// the end of the job: an event on each plane's stream (LagWorkspace::wait_done)
+// the end of the job: an event behind the refinement and its copies
 static int close_job(LagJob& job) {
     LagWorkspace& ws = *job.ws;
-    for (int m = 1; m < 3; ++m) {
-        if (ws.sl[m] == ws.sl[0]) continue;
-        MI_HIP(hipEventRecord(ws.ev_plane[m - 1], ws.sl[m]));
-    }
-    MI_HIP(hipEventRecord(ws.ev_done, ws.sl[0]));  // (everything `sm` was given lies before the last event a chain waited for)
+    MI_HIP(hipEventRecord(ws.ev_done, ws.sa));  // (everything `sm` and `sb` were given lies before an event `sa` waited for)
     job.enqueued = true;
     return MI_OK;
 }
@@ -1254,20 +1468,29 @@ int ncc_lag_map(int dev, hipStream_t s, const float* mip1, const float* mip2, in
     if (!wsp) return fail(MI_ERR_NOMEM, "compute_NCC_map: out of host memory");
     LagWorkspace& ws = *wsp;
     struct Giver { std::unique_ptr<LagWorkspace>& p; ~Giver() { give_lag_ws(std::move(p)); } } giver{wsp};
-    const int nt = (dimu / TILE) * (dimv / TILE);
+    const size_t nt = (size_t)(dimu / TILE) * (dimv / TILE), npx = ((size_t)dimu * dimv + 3) / 4 * 4;
     const BandLayout L(g, lp);
-    DevBuf ps;
-    MI_TRY(ps.alloc(sizeof(float) * 2 * (size_t)(nt > 0 ? nt : 1)));
+    // the kernels address a pair's arrays as offsets into ONE block: mip1 | mip2 | tile sums 1 | tile sums 2
+    g.mip1 = 0; g.mip2 = npx; g.ps1 = 2 * npx; g.ps2 = 2 * npx + nt;
+    MI_TRY(grow(ws.fbuf, 4 * (2 * npx + 2 * nt + 4)));
     MI_TRY(grow(ws.sat, 8 * L.total));
     MI_TRY(grow(ws.outw, 4 * 4));
     MI_TRY(grow(ws.outi, sizeof(int) * 4));
-    MI_TRY(prepare_plane_band(s, mip1, mip2, g, lp, ps.as<float>(), ps.as<float>() + (nt > 0 ? nt : 0), ws.sat.as<double>(), 1, 0, L.total));
-    MI_TRY(lag_cross(dev, s, lp, mip1, mip2, 0, 1, ws));
-    const RefineGeom rg = refine_geom(g, lp, 0, L.total, 0, 0.0f);
+    float* base = ws.fbuf.as<float>();
+    MI_HIP(hipMemcpyAsync(base, mip1, 4 * (size_t)dimu * dimv, hipMemcpyDeviceToDevice, s));
+    MI_HIP(hipMemcpyAsync(base + npx, mip2, 4 * (size_t)dimu * dimv, hipMemcpyDeviceToDevice, s));
+    TabGeom G{};
+    G.nplanes = 1; G.pstride = 0; G.sstride = L.total;
+    G.p[0] = tab_plane(g, lp, 0);
+    MI_TRY(prepare_tables(s, G, base, ws.sat.as<double>(), 1));
+    MI_TRY(lag_cross(dev, s, lp, base, base + npx, 0, 1, ws));
+    RefineAll R{};
+    R.g[0] = refine_geom(g, lp, 0, L.total, 0, 0.0f);
+    R.cross[0] = ws.cross[0].as<double>();
+    R.chunk = 1;
     if (lp.lds_refine > 64 * 1024)
         MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lag_refine), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp.lds_refine));
-    hipLaunchKernelGGL(k_lag_refine, dim3(1), dim3(256), lp.lds_refine, s, rg, ws.sat.as<double>(), ws.cross[0].as<double>(), 1, ws.outw.as<float>(),
-                       ws.outi.as<int>(), map);
+    hipLaunchKernelGGL(k_lag_refine, dim3(1, 1), dim3(256), lp.lds_refine, s, R, ws.sat.as<double>(), 1, ws.outw.as<float>(), ws.outi.as<int>(), map);
     MI_TRY(launch_check("k_lag_refine"));
     MI_HIP(hipStreamSynchronize(s));
     return MI_OK;
@@ -1304,7 +1527,7 @@ int ncc_time_mips(int dev, hipStream_t s, int n, const float* const* a_ptrs, con
     MI_HIP(hipEventCreate(&evs.a));
     MI_HIP(hipEventCreate(&evs.b));
     hipEvent_t e0 = evs.a, e1 = evs.b;
-    const char* ke = std::getenv("MI_NCC_MIPS_KNOCK");  // (measurement aid, see k_mips)
+    const char* ke = MI_PROBE_ENV("MI_NCC_MIPS_KNOCK");  // (measurement aid, see k_mips)
     const int knock = ke ? std::atoi(ke) : 0;
     for (int r = -1; r < reps; ++r) {  // r = -1: warm-up
         if (r == 0) MI_HIP(hipEventRecord(e0, s));
