@@ -61,8 +61,10 @@ template <class Load>
 __device__ __forceinline__ void first_stage_any(cplx* x, const Plan& pl, const cplx* __restrict__ tw, int first, int step, Load load) {
     switch (pl.radix[0]) {
         case 16: first_stage_from<16>(x, pl, tw, first, step, load); break;
+        case 12: first_stage_from<12>(x, pl, tw, first, step, load); break;
         case 9: first_stage_from<9>(x, pl, tw, first, step, load); break;
         case 8: first_stage_from<8>(x, pl, tw, first, step, load); break;
+        case 6: first_stage_from<6>(x, pl, tw, first, step, load); break;
         case 4: first_stage_from<4>(x, pl, tw, first, step, load); break;
         case 3: first_stage_from<3>(x, pl, tw, first, step, load); break;
         default: first_stage_from<2>(x, pl, tw, first, step, load); break;
@@ -76,10 +78,12 @@ __device__ __forceinline__ void first_stage_any(cplx* x, const Plan& pl, const c
 // forward lag transform of short-axis line j (blockIdx.x) of pair blockIdx.y: element i of the line = m[i * ls + j * ss]
 template <int TH>
 __global__ __launch_bounds__(TH) void k_lag_fwd(const float* __restrict__ m1, const float* __restrict__ m2, size_t pstride, int n_long, int n_short,
-                                                 int ls, int ss, int KT, int ntile, Plan pl, const cplx* __restrict__ tw,
+                                                 int ls, int ss, int KT, int ntile, const Plan* __restrict__ plp, const cplx* __restrict__ tw,
                                                  const int* __restrict__ slot_pos, const int* __restrict__ slot_neg, cplx* __restrict__ SP) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lag_lds[];
     cplx* x = reinterpret_cast<cplx*>(lag_lds);
+    const Plan& pl = *plp;  // (in device memory, not a by-value argument: the stage loops index its tables with the stage number, and a
+                            // by-value struct indexed that way is copied to scratch memory first)
     // gridDim.x = 8 * ceil(n_short / 8): work-groups b, b + 8, ... run on one XCD and take NEIGHBOURING lines j -- with the long
     // axis strided in memory (west-east pairs) 32 neighbouring lines share every 128-byte line they read, and spread over the
     // eight L2s each of them fetched it again (0.81 GB fetched for 0.28 GB of MIPs)
@@ -123,18 +127,18 @@ __global__ __launch_bounds__(TH) void k_lag_fwd(const float* __restrict__ m1, co
 // M + 1 elements apart, so the 2 KT elements a wave writes for one t land in different banks), first stage straight from the
 // tile in global memory, point-wise product in digit-reversed order, backward pass on KT images, last stage straight to CH.
 // 3 x 5 M log2 M flops per slot instead of 8 n_short (2 Es + 1): config 5's xy plane 5 x fewer, and LDS-bound instead of fp64-bound.
-template <int R>
-__device__ __forceinline__ void corr_first(cplx* arr, int AS, int KT2, const cplx* __restrict__ src, int n_short, const Plan& pl,
+template <int R, int KT2>
+__device__ __forceinline__ void corr_first(cplx* arr, int AS, const cplx* __restrict__ src, int n_short, const Plan& pl,
                                            const cplx* __restrict__ tw, int first, int step) {
     const int nb = pl.N / R, q = pl.lr[0] == 0 ? (1 << pl.a) : (1 << pl.lq[0]);
     const cplx* stw = tw + pl.twoff[0];
     for (int e = first; e < nb * KT2; e += step) {
-        const int t = e / KT2, f = e - t * KT2;  // f fastest: a wave reads whole 128-byte lines of the tile
+        const int t = e / KT2, f = e % KT2;  // f fastest: a wave reads whole 128-byte lines of the tile
         cplx v[R];
 #pragma unroll
         for (int m = 0; m < R; ++m) {
-            const int i = t + m * q;  // (clamped index + select: see k_lag_fwd)
-            const cplx g = src[(size_t)min(i, n_short - 1) * KT2 + f];
+            const int i = t + m * q;  // (clamped index + select: see k_lag_fwd; a tile is a few thousand elements: 32-bit offsets)
+            const cplx g = src[min(i, n_short - 1) * KT2 + f];
             v[m] = make_double2(i < n_short ? g.x : 0.0, i < n_short ? g.y : 0.0);
         }
         fft64::butterfly<R, false>(v, stw, q, t);
@@ -172,12 +176,14 @@ __device__ __forceinline__ void corr_last(const cplx* arr, int AS, int nk, const
         }
     }
 }
-template <int TH>
-__global__ __launch_bounds__(TH) void k_lag_corr(const cplx* __restrict__ SP, int n_short, int NK, int Es, int KT, int nlp, int tiles_per_pair, Plan pl,
+template <int TH, int KT>
+__global__ __launch_bounds__(TH) void k_lag_corr(const cplx* __restrict__ SP, int n_short, int NK, int Es, int nlp, int tiles_per_pair, const Plan* __restrict__ plp,
                                                   const cplx* __restrict__ tw, cplx* __restrict__ CH) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lag_lds[];
     cplx* arr = reinterpret_cast<cplx*>(lag_lds);
-    const int tile = blockIdx.x, pair = blockIdx.y, KT2 = 2 * KT, M = pl.N, AS = M + 1;
+    const Plan& pl = *plp;
+    constexpr int KT2 = 2 * KT;
+    const int tile = blockIdx.x, pair = blockIdx.y, M = pl.N, AS = M + 1;
     const int k0 = tile * KT, nk = min(KT, NK - k0);
     if (nk <= 0) return;
     const cplx* src = SP + ((size_t)pair * tiles_per_pair + tile) * n_short * KT2;
@@ -185,12 +191,14 @@ __global__ __launch_bounds__(TH) void k_lag_corr(const cplx* __restrict__ SP, in
     for (int e = threadIdx.x; e < fft64::lds_twiddles(pl); e += TH) twl[e] = tw[pl.twoff[1] + e];
     const cplx* tws = twl - (pl.nst > 1 ? pl.twoff[1] : 0);
     switch (pl.radix[0]) {
-        case 16: corr_first<16>(arr, AS, KT2, src, n_short, pl, tw, threadIdx.x, TH); break;
-        case 9: corr_first<9>(arr, AS, KT2, src, n_short, pl, tw, threadIdx.x, TH); break;
-        case 8: corr_first<8>(arr, AS, KT2, src, n_short, pl, tw, threadIdx.x, TH); break;
-        case 4: corr_first<4>(arr, AS, KT2, src, n_short, pl, tw, threadIdx.x, TH); break;
-        case 3: corr_first<3>(arr, AS, KT2, src, n_short, pl, tw, threadIdx.x, TH); break;
-        default: corr_first<2>(arr, AS, KT2, src, n_short, pl, tw, threadIdx.x, TH); break;
+        case 16: corr_first<16, KT2>(arr, AS, src, n_short, pl, tw, threadIdx.x, TH); break;
+        case 12: corr_first<12, KT2>(arr, AS, src, n_short, pl, tw, threadIdx.x, TH); break;
+        case 9: corr_first<9, KT2>(arr, AS, src, n_short, pl, tw, threadIdx.x, TH); break;
+        case 8: corr_first<8, KT2>(arr, AS, src, n_short, pl, tw, threadIdx.x, TH); break;
+        case 6: corr_first<6, KT2>(arr, AS, src, n_short, pl, tw, threadIdx.x, TH); break;
+        case 4: corr_first<4, KT2>(arr, AS, src, n_short, pl, tw, threadIdx.x, TH); break;
+        case 3: corr_first<3, KT2>(arr, AS, src, n_short, pl, tw, threadIdx.x, TH); break;
+        default: corr_first<2, KT2>(arr, AS, src, n_short, pl, tw, threadIdx.x, TH); break;
     }
     __syncthreads();
     for (int st = 1; st < pl.nst; ++st) {
@@ -214,8 +222,10 @@ __global__ __launch_bounds__(TH) void k_lag_corr(const cplx* __restrict__ SP, in
     cplx* dst = CH + ((size_t)pair * NK + k0) * nlp;
     switch (pl.radix[0]) {
         case 16: corr_last<16>(arr, AS, nk, pl, tw, Es, nlp, dst, threadIdx.x, TH); break;
+        case 12: corr_last<12>(arr, AS, nk, pl, tw, Es, nlp, dst, threadIdx.x, TH); break;
         case 9: corr_last<9>(arr, AS, nk, pl, tw, Es, nlp, dst, threadIdx.x, TH); break;
         case 8: corr_last<8>(arr, AS, nk, pl, tw, Es, nlp, dst, threadIdx.x, TH); break;
+        case 6: corr_last<6>(arr, AS, nk, pl, tw, Es, nlp, dst, threadIdx.x, TH); break;
         case 4: corr_last<4>(arr, AS, nk, pl, tw, Es, nlp, dst, threadIdx.x, TH); break;
         case 3: corr_last<3>(arr, AS, nk, pl, tw, Es, nlp, dst, threadIdx.x, TH); break;
         default: corr_last<2>(arr, AS, nk, pl, tw, Es, nlp, dst, threadIdx.x, TH); break;
@@ -368,11 +378,12 @@ __global__ __launch_bounds__(256) void k_lag_mac(const cplx* __restrict__ SP, in
 // (slot of frequency k: freq_slot[k]).  Work-groups b, b + 8, ... share an XCD and take the lag pairs of ONE pair after another: its
 // block of CH (2 MB on config 5, read as 32-byte pieces of 1.6-KB rows) is then fetched once into that L2.
 template <int TH>
-__global__ __launch_bounds__(TH) void k_lag_inv(const cplx* __restrict__ CH, int NK, int nlp, Plan pl, int Es, int El, int long_is_u, int Eu, int Ev,
+__global__ __launch_bounds__(TH) void k_lag_inv(const cplx* __restrict__ CH, int NK, int nlp, const Plan* __restrict__ plp, int Es, int El, int long_is_u, int Eu, int Ev,
                                                  const cplx* __restrict__ tw, const int* __restrict__ freq_slot, int np, int lagpairs,
                                                  double* __restrict__ cross) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lag_lds[];
     cplx* x = reinterpret_cast<cplx*>(lag_lds);
+    const Plan& pl = *plp;
     const int N = pl.N, nlag = 2 * Es + 1;
     const int slot = (int)(blockIdx.x >> 3), pair = 8 * (slot / lagpairs) + (int)(blockIdx.x & 7);
     if (pair >= np) return;
@@ -901,7 +912,7 @@ LagPlane plan_lag_plane(const PlaneGeom& g, int maxIter) {
     if (p.use_corr) {
         p.cfft = plan_for(p.n_short + p.Es);
         const size_t img = sizeof(double) * 2 * ((size_t)p.cfft.N + 1);
-        p.KT = (int)std::max<size_t>(1, std::min<size_t>(4, (48 * 1024) / (2 * img)));
+        p.KT = 2 * img * 4 <= 52 * 1024 ? 4 : (2 * img * 2 <= 80 * 1024 ? 2 : 1);  // (three work-groups per CU where the images allow)
         p.lds_corr = 2 * (size_t)p.KT * img + sizeof(double) * 2 * (size_t)fft64::lds_twiddles(p.cfft);
         p.JP = 1; p.FW = p.TW = 0;
         p.lds_mac = 0;
@@ -934,6 +945,7 @@ LagPlane plan_lag_plane(const PlaneGeom& g, int maxIter) {
 struct FftTables {
     const cplx* tw;
     const int *slot_pos, *slot_neg, *freq_slot;
+    const Plan* plan;  // the plan itself, for the kernels
 };
 struct TwiddleKey { int dev, n; bool operator<(const TwiddleKey& o) const { return dev != o.dev ? dev < o.dev : n < o.n; } };
 std::mutex& g_tw_mu = *new std::mutex;
@@ -954,14 +966,16 @@ int fft_tables(int dev, const Plan& pl, hipStream_t s, FftTables* out) {
         tabs[NK + sl] = fft64::phys(pl, fft64::pos_of_freq(pl, (int)((N - (size_t)order[sl].second) % N)));
         tabs[2 * NK + (size_t)order[sl].second] = (int)sl;
     }
-    void *d = nullptr, *di = nullptr;
+    void *d = nullptr, *di = nullptr, *dp = nullptr;
     MI_HIP(hipMalloc(&d, sizeof(double) * hs.size()));
     MI_HIP(hipMalloc(&di, sizeof(int) * 3 * NK));
+    MI_HIP(hipMalloc(&dp, sizeof(Plan)));
     MI_HIP(hipMemcpyAsync(d, hs.data(), sizeof(double) * hs.size(), hipMemcpyHostToDevice, s));
     MI_HIP(hipMemcpyAsync(di, tabs.data(), sizeof(int) * 3 * NK, hipMemcpyHostToDevice, s));
+    MI_HIP(hipMemcpyAsync(dp, &pl, sizeof(Plan), hipMemcpyHostToDevice, s));
     MI_HIP(hipStreamSynchronize(s));
     const int* ti = static_cast<const int*>(di);
-    FftTables t{static_cast<const cplx*>(d), ti, ti + NK, ti + 2 * NK};
+    FftTables t{static_cast<const cplx*>(d), ti, ti + NK, ti + 2 * NK, static_cast<const Plan*>(dp)};
     g_tw[TwiddleKey{dev, pl.N}] = t;
     *out = t;
     return MI_OK;
@@ -1074,17 +1088,18 @@ int lag_cross(int dev, hipStream_t s, const LagPlane& lp, const float* m1, const
         if (lp.lds_fft > 64 * 1024)
             MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp.lds_fft));
         hipLaunchKernelGGL(fwd, dim3(8 * ((lp.n_short + 7) / 8), np), dim3(lp.fft_threads), lp.lds_fft, s, m1, m2, pstride, lp.n_long, lp.n_short, lp.ls,
-                           lp.ss, lp.KT, tiles_per_pair, lp.fft, ft.tw, ft.slot_pos, ft.slot_neg, ws.SP[m].as<cplx>());
+                           lp.ss, lp.KT, tiles_per_pair, ft.plan, ft.tw, ft.slot_pos, ft.slot_neg, ws.SP[m].as<cplx>());
         MI_TRY(launch_check("k_lag_fwd"));
     }
     if (after_fwd) MI_HIP(hipEventRecord(after_fwd, s));
     if (lp.use_corr) {
         FftTables ct;
         MI_TRY(fft_tables(dev, lp.cfft, s, &ct));
+        auto corr = lp.KT == 4 ? k_lag_corr<256, 4> : (lp.KT == 2 ? k_lag_corr<256, 2> : k_lag_corr<256, 1>);
         if (lp.lds_corr > 64 * 1024)
-            MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lag_corr<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp.lds_corr));
-        hipLaunchKernelGGL(k_lag_corr<256>, dim3(tiles_per_pair, np), dim3(256), lp.lds_corr, s, ws.SP[m].as<cplx>(), lp.n_short, NK, lp.Es, lp.KT, nlp,
-                           tiles_per_pair, lp.cfft, ct.tw, ws.CH[m].as<cplx>());
+            MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(corr), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp.lds_corr));
+        hipLaunchKernelGGL(corr, dim3(tiles_per_pair, np), dim3(256), lp.lds_corr, s, ws.SP[m].as<cplx>(), lp.n_short, NK, lp.Es, nlp, tiles_per_pair,
+                           ct.plan, ct.tw, ws.CH[m].as<cplx>());
         MI_TRY(launch_check("k_lag_corr"));
     } else {
         using MacFn = void (*)(const cplx*, int, int, int, int, int, int, int, int, int, int, cplx*);
@@ -1106,7 +1121,7 @@ int lag_cross(int dev, hipStream_t s, const LagPlane& lp, const float* m1, const
         if (lp.lds_fft > 64 * 1024)
             MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(inv), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp.lds_fft));
         const int lagpairs = (nlag + 1) / 2;
-        hipLaunchKernelGGL(inv, dim3(8 * ((np + 7) / 8) * lagpairs), dim3(lp.fft_threads), lp.lds_fft, s, ws.CH[m].as<cplx>(), NK, nlp, lp.fft, lp.Es,
+        hipLaunchKernelGGL(inv, dim3(8 * ((np + 7) / 8) * lagpairs), dim3(lp.fft_threads), lp.lds_fft, s, ws.CH[m].as<cplx>(), NK, nlp, ft.plan, lp.Es,
                            lp.El, lp.long_is_u ? 1 : 0, lp.Eu, lp.Ev, ft.tw, ft.freq_slot, np, lagpairs, ws.cross[m].as<double>());
     }
     return launch_check("k_lag_inv");
