@@ -173,6 +173,58 @@ def block_stages(vshape, psf_np, dev):
     return out
 
 
+def secondary_rows(vshape, kshape, psf_np, dev, gaussian, steps):
+    """SURVEY.md 8(d)'s second row and the reference's own configuration of BASELINE config 2, both through `decon` (the entry
+    decwrap.py calls per block, with a deconvolution plan as its workers keep one; edge taper skipped: the loop alone, like the
+    headline).
+      defaults    the headline workload with decwrap.py's defaults (decwrap.py:294-321): 6 iterations, regularize_interval = 3
+                  (the 5-tap Gaussian of decon.m:157-161 before iteration 3), lambda = 0, deconFFT semantics;
+      c2_spatial  BASELINE config 2 (1024 x 1024 x 256, 15 x 15 x 31 PSF) in decon.m's spatial flavour (zero boundary, psf.inv =
+                  flipped PSF, decon.m:41-124), 20 iterations -- whatever engine mi_engine_select picks for it."""
+    import torch
+    from ipp_amd import decon
+    out = {}
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def timed(shape, psf, niter, reps, reg, **kw):
+        bl = make_volume(shape, dev, seed=4321)
+        with decon.DeconPlan(dev) as plan:
+            decon.decon(bl, psf, niter, 0.0, 0.0, reg, plan=plan, skip_edgetaper=True, **kw)   # builds the plan
+            torch.cuda.synchronize(dev)
+            ev0.record()
+            for _ in range(reps):
+                decon.decon(bl, psf, niter, 0.0, 0.0, reg, plan=plan, skip_edgetaper=True, **kw)
+            ev1.record()
+            torch.cuda.synchronize(dev)
+        del bl
+        return ev0.elapsed_time(ev1) / (niter * reps)
+
+    try:
+        reps = max(1, steps // 6)
+        ms = timed(vshape, psf_np, 6, reps, 3, use_fft=True, fft_shape=[vshape[2], vshape[1], vshape[0]])
+        n = vshape[0] * vshape[1] * vshape[2]
+        out["defaults"] = {"ms_per_step": round(ms, 4), "value": round(n / (ms * 1e-3) / 1e9, 4), "unit": "Gvoxel*iter/s",
+                           "config": "decwrap.py defaults on the headline workload: 6 iterations per call, regularize_interval=3 "
+                                     "(Gaussian before iteration 3), lambda=0, deconFFT semantics; device time of "
+                                     f"{reps} call(s) of decon() on a kept plan, edge taper skipped"}
+    except Exception as e:
+        out["defaults"] = {"error": repr(e)}
+    torch.cuda.empty_cache()
+    try:
+        c2v, c2k = WORKLOADS["c2"]
+        psf2 = make_psf(c2k)
+        ms = timed(c2v, psf2, 20, 2, 0, use_fft=False)
+        n = c2v[0] * c2v[1] * c2v[2]
+        out["c2_spatial"] = {"ms_per_step": round(ms, 4), "value": round(n / (ms * 1e-3) / 1e9, 4), "unit": "Gvoxel*iter/s",
+                             "engine": {1: "direct", 2: "fft"}.get(decon.engine_select(c2v, c2k), "?"),
+                             "config": f"c2: {c2v[2]}x{c2v[1]}x{c2v[0]} volume, {c2k[2]}x{c2k[1]}x{c2k[0]} PSF, decon.m spatial flavour "
+                                       "(zero boundary, psf.inv = flipped PSF), 20 iterations per call, 2 calls on a kept plan"}
+    except Exception as e:
+        out["c2_spatial"] = {"error": repr(e)}
+    torch.cuda.empty_cache()
+    return out
+
+
 def launch_ranks(n, argv):
     """``python bench.py --gpus N`` from a plain shell: start the N ranks as a CHILD process tree (torch.distributed.run, one rank
     per GPU, rendezvous on 127.0.0.1), relay rank 0's JSON line and return the child's exit code.  Nothing in this process has
@@ -240,11 +292,16 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        try:   # a rank that never arrives must end the run with a message, not hang it
+            tmo = datetime.timedelta(seconds=int(os.environ.get("MI_BENCH_RENDEZVOUS_S", "180")))
+            if args.backend == "nccl":
+                dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev, timeout=tmo)
+            else:
+                dist.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=tmo)
+        except Exception as e:
+            raise SystemExit(f"bench.py: rank {rank} of {world}: rendezvous over {args.backend} failed: {e!r}")
 
     vshape, kshape = WORKLOADS[args.workload]
     psf_np = make_psf(kshape, gaussian=args.workload == "c1")
@@ -268,12 +325,20 @@ def main():
         engine_used = ctx.engine
     else:
         from ipp_amd import slab
-        drv = slab.SlabRL(vshape, psf_np, rank=rank, world_size=world, device=dev, flavour="fft", engine=engine,
-                          seed=1234, transport=args.transport, zchunks=args.zchunks)
+        try:
+            drv = slab.SlabRL(vshape, psf_np, rank=rank, world_size=world, device=dev, flavour="fft", engine=engine,
+                              seed=1234, transport=args.transport, zchunks=args.zchunks)
+        except (TimeoutError, RuntimeError) as e:   # e.g. the peer transport's handle exchange timing out
+            raise SystemExit(f"bench.py: rank {rank} of {world}: setting up the {args.transport} halo exchange failed: {e!r}")
         step = drv.iterate
         run_steps = None
-        parallelism = (f"y-slabs x{world}, halo exchange: " +
-                       ("grouped send/recv (RCCL)" if args.transport == "rccl" else "hipMemcpyPeerAsync into the neighbour's buffers") +
+        pg_world = dist.get_world_size()
+        if pg_world != world:
+            raise SystemExit(f"process group has {pg_world} ranks, expected {world}")
+        parallelism = (f"y-slabs x{pg_world}, process group backend {dist.get_backend()}, halo exchange: " +
+                       ((("grouped send/recv (RCCL over xGMI)" if args.backend == "nccl" else
+                          "grouped send/recv through gloo (host staging: a REHEARSAL of the N > 1 path, not an RCCL result)")
+                         if args.transport == "rccl" else "hipMemcpyPeerAsync into the neighbour's buffers")) +
                        (f", {len(drv.zb)} z chunks" if drv.zb is not None else ""))
         engine_used = drv.ctx.engine
         ctx, bl = drv.ctx, drv.bl                # rank-local context / slab (interior + halo rows) for the per-pass timing
@@ -371,6 +436,9 @@ def main():
             torch.cuda.empty_cache()
             capi.release_cached_memory()
             out["block_stages"] = block_stages(vshape, psf_np, dev)
+            capi.release_cached_memory()
+            out.update(secondary_rows(vshape, kshape, psf_np, dev, args.workload == "c1", args.steps))
+            capi.release_cached_memory()
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(vshape, kshape, gaussian=args.workload == "c1")
     ncc = None

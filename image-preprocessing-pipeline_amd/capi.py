@@ -20,6 +20,9 @@ ENGINE_AUTO, ENGINE_DIRECT, ENGINE_FFT = 0, 1, 2
 NORTH_SOUTH, WEST_EAST = 0, 1
 
 
+MI_ERR_NOMEM = -4  # include/mi_common.h
+
+
 class MiError(RuntimeError):
     """A C-ABI call returned a negative mi_status; the message is mi_last_error()."""
 

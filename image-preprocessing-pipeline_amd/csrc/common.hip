@@ -88,21 +88,7 @@ int pool_alloc(size_t n, void** out) {
             return MI_OK;
         }
     }
-    // MI_CONTIG_MIN_MB=<n> (default 0 = never): blocks of at least n MB are asked for as PHYSICALLY CONTIGUOUS memory first.
-    // An experiment that answered a question of rounds 2 / 3: the strided passes of the FFT pipeline run at one of two speeds
-    // depending on the pages behind the spectrum arrays (y passes 2.93 or 3.35 ms on C3).  With contiguous memory they ALWAYS run
-    // at the slow speed, whatever the row paddings and the distance between the two arrays (profiles/r03_placement.txt): the
-    // fast speed belongs to allocations whose pages the driver scattered, which a library cannot ask for.
-    static const size_t contig_min = [] {
-        const char* e = std::getenv("MI_CONTIG_MIN_MB");
-        return (size_t)(e ? std::max(0, atoi(e)) : 0) << 20;
-    }();
-    hipError_t e = hipErrorOutOfMemory;
-    if (contig_min > 0 && n >= contig_min) {
-        e = hipExtMallocWithFlags(out, n, hipDeviceMallocContiguous);
-        if (e != hipSuccess) (void)hipGetLastError();
-    }
-    if (e != hipSuccess) e = hipMalloc(out, n);
+    hipError_t e = hipMalloc(out, n);
     if (e != hipSuccess && P.enabled) {  // give the cached blocks back and try once more
         (void)hipGetLastError();
         std::lock_guard<std::mutex> g(P.mu);

@@ -1,5 +1,6 @@
 // Internal interface of the hand-written FFT convolution pipeline (fft_native.hip).
 #pragma once
+#include <vector>
 #include <algorithm>
 #include "conv3d_direct.h"
 
@@ -40,6 +41,17 @@ struct TileSelect {
     int z0 = 0, nz = 0;  // only the planes [z0, z0 + nz) (nz = 0: all): the z-chunked halo exchange runs the edge tiles chunk by chunk
 };
 
+// a device address range backed by physical chunks that were created one by one and mapped in a chosen order (HIP virtual memory)
+struct VmmRange {
+    void* va = nullptr;
+    size_t bytes = 0, chunk = 0;
+    bool mapped = false;
+    std::vector<hipMemGenericAllocationHandle_t> h;
+    int alloc(size_t n, size_t chunk_bytes, int order);
+    void release();
+    ~VmmRange() { release(); }
+};
+
 struct NativeFft {
     NativeDims dims{};
     PadWindow pw{};
@@ -62,18 +74,8 @@ struct NativeFft {
     bool z_dynamic = true;   // the paired z pass takes its tiles from a counter too
     int ctr_slot = 0;
     int persistent_grid(hipStream_t s, int ntiles, bool overlapped, unsigned* grid, int** ctr_out);
-    // Cache-blocked middle (y forward -> z * OTF -> y inverse on a chunk of `chunk_xk` plane pairs at a time, chunk after chunk):
-    // the intermediate spectra of a chunk live in a small buffer that stays in the 256-MiB Infinity Cache instead of crossing
-    // HBM twice per pass; the result returns to the rows of S it came from, and the x pass runs in place on S.
-    int chunk_xk = 0;              // 0: three full-volume passes through T
-    int chunk_streams = 1;         // chunks in flight (each on its own stream and buffer)
-    DevBuf Tc;
-    hipStream_t cstream[4] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t cev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    VmmRange vmm;  // probe builds, MI_FFT_VMM: the spectrum arrays as a range mapped chunk by chunk
     ~NativeFft();
-    int set_chunking(int xk_per_chunk, int streams);
-    int middle_chunked(hipStream_t s, bool conj_otf);
-    const float2* x_source() const { return chunk_xk > 0 ? S.as<float2>() : t_spec; }  // what the inverse x pass reads
 
     static bool supported(const int F[3]);
     // smallest supported extent >= n of axis 0 (x), 1 (y), 2 (z); 0 when there is none

@@ -2001,11 +2001,11 @@ int NativeFft::init(hipStream_t s, const int F[3], bool explicit_adjoint) {
     dims.xkn = Hx / 2 + 1;
     dims.yz0 = 0;
     dims.dbg = 0;
-    if (const char* e = std::getenv("MI_FFT_ZDBG")) dims.dbg = atoi(e);  // phase knock-out for timing experiments
+    if (const char* e = MI_PROBE_ENV("MI_FFT_ZDBG")) dims.dbg = atoi(e);  // phase knock-out for timing experiments
     // tuning overrides (experiments only): MI_FFT_TY / MI_FFT_TC / MI_FFT_TL
-    if (const char* e = std::getenv("MI_FFT_TY")) dims.ty = std::max(2, std::min(atoi(e), F[1]));
-    if (const char* e = std::getenv("MI_FFT_TC")) dims.tc = std::max(1, atoi(e));
-    if (const char* e = std::getenv("MI_FFT_TL")) dims.tl = std::max(2, std::min(atoi(e), F[1]));
+    if (const char* e = MI_PROBE_ENV("MI_FFT_TY")) dims.ty = std::max(2, std::min(atoi(e), F[1]));
+    if (const char* e = MI_PROBE_ENV("MI_FFT_TC")) dims.tc = std::max(1, atoi(e));
+    if (const char* e = MI_PROBE_ENV("MI_FFT_TL")) dims.tl = std::max(2, std::min(atoi(e), F[1]));
     while ((size_t)F[2] * Hx % dims.tc) dims.tc >>= 1;
     // tiles are whole float4 groups of rows / lines and must divide y; z tiles of TL positions must map onto aligned
     // mirror blocks, which holds for TL <= 2^ly2 (positions inside one power-of-two sub-block mirror inside one)
@@ -2020,7 +2020,7 @@ int NativeFft::init(hipStream_t s, const int F[3], bool explicit_adjoint) {
                          : dims.r3z == 3 ? (dims.lz2 >= 6 && dims.lz2 <= 8) : (dims.r3z == 9 && dims.lz2 >= 6 && dims.lz2 <= 7);
     dims.paired = z_pairs && F[1] % (2 * kPairLines) == 0 && dims.tc >= 2 && dims.tc % 2 == 0 &&
                   F[2] % (dims.tc / 2) == 0 && dims.dbg == 0 && std::getenv("MI_FFT_NO_PAIR") == nullptr &&
-                  std::getenv("MI_FFT_NO_PIPE") == nullptr && std::getenv("MI_FFT_TL") == nullptr;
+                  std::getenv("MI_FFT_NO_PIPE") == nullptr && MI_PROBE_ENV("MI_FFT_TL") == nullptr;
     n_cplx = (size_t)Hx * F[1] * F[2];
     // (the two planes that are their own mirror partners are stored twice in the paired layout)
     // Rows an exact power of two apart camp on few HBM channels: behind every row of the x side ([z][px][.]) and of the paired z
@@ -2031,8 +2031,8 @@ int NativeFft::init(hipStream_t s, const int F[3], bool explicit_adjoint) {
     const int pad_z = (size_t)F[1] * 2 * sizeof(float2) >= kPadRowBytes ? kRowPadBytes : 0;
     dims.zpad = dims.paired ? pad_z / 16 : 0;
     dims.xrow = F[1] + pad_x / 8;
-    if (const char* e = std::getenv("MI_FFT_ZPAD")) dims.zpad = dims.paired ? std::max(0, atoi(e)) : 0;   // float4 per row
-    if (const char* e = std::getenv("MI_FFT_XPAD")) dims.xrow = F[1] + 2 * std::max(0, atoi(e));          // float4 per row
+    if (const char* e = MI_PROBE_ENV("MI_FFT_ZPAD")) dims.zpad = dims.paired ? std::max(0, atoi(e)) : 0;   // float4 per row
+    if (const char* e = MI_PROBE_ENV("MI_FFT_XPAD")) dims.xrow = F[1] + 2 * std::max(0, atoi(e));          // float4 per row
     const size_t n_x = (size_t)Hx * F[2] * dims.xrow;
     const size_t n_buf = std::max(n_x, dims.paired ? (size_t)(Hx / 2 + 1) * F[2] * 2 * (size_t)(F[1] + dims.zpad) : n_cplx);
     // one allocation for both arrays: their distance -- which decides how the strided streams of a pass that reads one and
@@ -2040,8 +2040,22 @@ int NativeFft::init(hipStream_t s, const int F[3], bool explicit_adjoint) {
     // (measuring the passes for six distances at plan time did not pay: in a process where the y passes run in their slow mode
     // they do so for every distance tried)
     size_t gap = kSpecGapBytes;
-    if (const char* e = std::getenv("MI_FFT_STGAP")) gap = (size_t)atoll(e) & ~(size_t)127;
-    MI_TRY(S.alloc(sizeof(float2) * 2 * n_buf + gap));
+    if (const char* e = MI_PROBE_ENV("MI_FFT_STGAP")) gap = (size_t)atoll(e) & ~(size_t)127;
+    // Probe builds: MI_FFT_VMM=<order>[,<chunk MB>] backs the spectrum arrays with the virtual-memory API instead of one
+    // hipMalloc -- physical chunks created one by one and mapped into a reserved range in a chosen ORDER (0 as created, 1 reversed,
+    // 2 bit-reversed, 3 shuffled) -- to see whether the library can choose how physical memory meets the power-of-two row pitch
+    // (profiles/r04_placement_vmm.txt).
+    int vmm_order = -1, vmm_chunk_mb = 0;
+    if (const char* e = MI_PROBE_ENV("MI_FFT_VMM")) {
+        if (sscanf(e, "%d,%d", &vmm_order, &vmm_chunk_mb) < 1) vmm_order = -1;
+    }
+    if (vmm_order >= 0) {
+        MI_TRY(vmm.alloc(sizeof(float2) * 2 * n_buf + gap, (size_t)std::max(0, vmm_chunk_mb) << 20, vmm_order));
+        S.p = vmm.va;  // (not the pool's: handed back by ~NativeFft)
+        S.bytes = sizeof(float2) * 2 * n_buf + gap;
+    } else {
+        MI_TRY(S.alloc(sizeof(float2) * 2 * n_buf + gap));
+    }
     t_spec = S.as<float2>() + n_buf + gap / sizeof(float2);
     MI_TRY(G.alloc(sizeof(float4) * (size_t)(Hx / 2 + 1) * F[1] * F[2]));
     // twiddle tables exp(-2 pi i e / N) in double on the host, per axis: e < sub/2 for the power-of-two sub-transform
@@ -2073,46 +2087,6 @@ int NativeFft::init(hipStream_t s, const int F[3], bool explicit_adjoint) {
     have_adj = explicit_adjoint;
     if (have_adj) MI_TRY(G_adj.alloc(G.bytes));  // explicit adjoint kernel (psf_inv of the 'same'-convolution flavour) instead of conj(OTF)
     MI_HIP(hipStreamSynchronize(s));  // host twiddle vector dies at scope exit
-    // Placement trial (MI_FFT_PLACEMENT_TRIES=<n>, default 1 = off): the strided passes run at one of two speeds per ALLOCATION of the
-    // spectrum arrays (the physical pages behind it decide how the concurrent streams of a pass fall onto the HBM channels; offsets
-    // inside the allocation do not: profiles/r02_xupdate_variance.txt).  With n > 1, up to n allocations are held at once, the y
-    // pass is timed on each (3 launches) and the fastest is kept.
-    int tries = 1;
-    if (const char* e = std::getenv("MI_FFT_PLACEMENT_TRIES")) tries = std::max(1, std::min(4, atoi(e)));
-    if (std::getenv("MI_FFT_PLACEMENT_LOG")) fprintf(stderr, "spectrum arrays at %p (%zu bytes), OTF at %p\n", S.p, S.bytes, G.p);
-    if (tries > 1 && S.bytes >= ((size_t)1 << 30)) {
-        DevBuf cand[4];
-        float best = 0.0f;
-        int bi = -1;
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        MI_HIP(hipEventCreate(&e0));
-        MI_HIP(hipEventCreate(&e1));
-        int rc = MI_OK;
-        for (int i = 0; i < tries && rc == MI_OK; ++i) {
-            if (i == 0) { cand[0].p = S.p; cand[0].bytes = S.bytes; S.p = nullptr; S.bytes = 0; }
-            else if (cand[i].alloc(cand[0].bytes) != MI_OK) break;   // (no room for another candidate: keep what there is)
-            S.p = cand[i].p; S.bytes = cand[i].bytes;
-            t_spec = S.as<float2>() + n_buf + gap / sizeof(float2);
-            (void)hipMemsetAsync(S.p, 0, S.bytes, s);
-            float ms = 0.0f;
-            for (int r = -1; r < 3 && rc == MI_OK; ++r) {
-                if (r == 0) (void)hipEventRecord(e0, s);
-                rc = y_pass(s, false, dims.paired != 0);
-            }
-            (void)hipEventRecord(e1, s);
-            if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) rc = fail(MI_ERR_HIP, "native FFT: placement trial failed");
-            S.p = nullptr; S.bytes = 0;
-            if (rc == MI_OK && (bi < 0 || ms < best)) { best = ms; bi = i; }
-            if (std::getenv("MI_FFT_PLACEMENT_LOG")) fprintf(stderr, "placement trial %d: y pass %.3f ms\n", i, ms / 3.0f);
-        }
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
-        if (bi < 0) bi = 0;
-        S.p = cand[bi].p; S.bytes = cand[bi].bytes;
-        cand[bi].p = nullptr; cand[bi].bytes = 0;      // (the others are released at scope exit)
-        t_spec = S.as<float2>() + n_buf + gap / sizeof(float2);
-        MI_TRY(rc);
-    }
     return MI_OK;
 }
 
@@ -2181,7 +2155,7 @@ TileSelect NativeFft::edge_tiles(int mode, int a0, int a1, int b0, int b1) const
 // MI_X_DYN=0|1 / MI_X_FREE_CUS=<k> override for every launch (A/B measurements).
 int NativeFft::persistent_grid(hipStream_t s, int ntiles, bool overlapped, unsigned* grid, int** ctr_out) {
     static const char* env_dyn = std::getenv("MI_X_DYN");
-    static const char* env_free = std::getenv("MI_X_FREE_CUS");
+    static const char* env_free = MI_PROBE_ENV("MI_X_FREE_CUS");
     const bool dyn = env_dyn ? atoi(env_dyn) != 0 : (overlapped ? overlap_dynamic : x_dynamic);
     const int free_cus = env_free ? atoi(env_free) : (overlapped ? overlap_free_cus : 0);
     const int cus = std::max(1, n_cu - std::max(0, free_cus));
@@ -2448,69 +2422,85 @@ int NativeFft::spectrum(hipStream_t s, const float* vol, float4* Gp, float scale
 
 // P2, P3, P4: S[z][px][py] -> T[z][px][py] (x still transformed), multiplied by the OTF or its conjugate
 int NativeFft::middle(hipStream_t s, bool conj_otf) {
-    if (chunk_xk > 0) return middle_chunked(s, conj_otf);
     MI_TRY(y_pass(s, false, dims.paired != 0));
     MI_TRY(z_conv(s, conj_otf));
     return y_pass(s, true, dims.paired != 0);
 }
 
 NativeFft::~NativeFft() {
-    for (auto& st : cstream)
-        if (st) (void)hipStreamDestroy(st);
-    for (auto& ev : cev)
-        if (ev) (void)hipEventDestroy(ev);
+    if (vmm.va) {  // the spectrum arrays are a mapped range, not a pool block
+        S.p = nullptr;
+        S.bytes = 0;
+        vmm.release();
+    }
 }
 
-// Switches the cache-blocked middle on (xk_per_chunk > 0) or off.  Needs the paired layout on an unpadded grid.
-int NativeFft::set_chunking(int xk_per_chunk, int streams) {
-    if (xk_per_chunk <= 0) {
-        chunk_xk = 0;
-        Tc.release();
-        return MI_OK;
-    }
-    MI_REQUIRE(dims.paired && !pw.on, "native FFT: the blocked middle needs the pair-interleaved layout on an unpadded grid");
-    streams = std::max(1, std::min(streams, 4));
-    const int nxk = dims.hx / 2 + 1;
-    xk_per_chunk = std::min(xk_per_chunk, nxk);
-    const size_t plane = (size_t)dims.nz * 2 * (size_t)(dims.ny + dims.zpad);  // float2 per plane pair
-    MI_TRY(Tc.alloc(sizeof(float2) * plane * (size_t)xk_per_chunk * (size_t)streams));
-    for (int i = 0; i < streams; ++i)
-        if (!cstream[i]) MI_HIP(hipStreamCreateWithFlags(&cstream[i], hipStreamNonBlocking));
-    for (auto& ev : cev)
-        if (!ev) MI_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    chunk_xk = xk_per_chunk;
-    chunk_streams = streams;
-    return MI_OK;
-}
-
-// S (x side) -> [chunk: y forward -> Tc; z * OTF in place; y inverse -> the rows of S the chunk came from], chunk after chunk.
-// Chunk c runs on stream c mod chunk_streams with its own slice of Tc; kernels address plane xk of the virtual array
-// Tc_slice - xk0 * plane, so every chunk lands on the same cache-resident bytes.
-int NativeFft::middle_chunked(hipStream_t s, bool conj_otf) {
-    const int nxk = dims.hx / 2 + 1;
-    const size_t plane = (size_t)dims.nz * 2 * (size_t)(dims.ny + dims.zpad);
-    float2* Sp = S.as<float2>();
-    const bool fan = chunk_streams > 1;
-    if (fan) MI_HIP(hipEventRecord(cev[4], s));
-    for (int c = 0, xk0 = 0; xk0 < nxk; ++c, xk0 += chunk_xk) {
-        const int n = std::min(chunk_xk, nxk - xk0), slot = c % chunk_streams;
-        hipStream_t cs = fan ? cstream[slot] : s;
-        if (fan && c < chunk_streams) MI_HIP(hipStreamWaitEvent(cs, cev[4], 0));
-        // (pointer arithmetic on integers: the virtual base lies outside the allocation)
-        float2* virt = reinterpret_cast<float2*>(reinterpret_cast<uintptr_t>(Tc.as<float2>() + (size_t)slot * chunk_xk * plane) -
-                                                 sizeof(float2) * plane * (size_t)xk0);
-        MI_TRY(y_pass(cs, false, true, Sp, virt, xk0, n));
-        ctr_slot = slot;  // (chunks in flight count their z tiles separately)
-        MI_TRY(z_conv(cs, conj_otf, virt, virt, xk0, n));
-        MI_TRY(y_pass(cs, true, true, virt, Sp, xk0, n));
-    }
-    if (fan) {
-        for (int i = 0; i < chunk_streams; ++i) {
-            MI_HIP(hipEventRecord(cev[i], cstream[i]));
-            MI_HIP(hipStreamWaitEvent(s, cev[i], 0));
+int VmmRange::alloc(size_t n, size_t chunk_bytes, int order) {
+    release();
+    int dev = 0;
+    MI_HIP(hipGetDevice(&dev));
+    hipMemAllocationProp prop{};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = dev;
+    size_t gran = 0;
+    MI_HIP(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
+    if (gran == 0) gran = (size_t)2 << 20;
+    chunk = std::max(gran, (chunk_bytes + gran - 1) / gran * gran);
+    const size_t nchunks = (n + chunk - 1) / chunk;
+    bytes = nchunks * chunk;
+    MI_HIP(hipMemAddressReserve(&va, bytes, 0, nullptr, 0));
+    h.assign(nchunks, hipMemGenericAllocationHandle_t{});
+    for (size_t i = 0; i < nchunks; ++i) {
+        hipError_t e = hipMemCreate(&h[i], chunk, &prop, 0);
+        if (e != hipSuccess) {
+            h.resize(i);
+            release();
+            return fail(MI_ERR_NOMEM, "hipMemCreate(%zu bytes) failed: %s", chunk, hipGetErrorString(e));
         }
     }
+    // physical chunk perm[i] backs slot i of the range
+    std::vector<size_t> perm(nchunks);
+    for (size_t i = 0; i < nchunks; ++i) perm[i] = i;
+    if (order == 1) std::reverse(perm.begin(), perm.end());
+    if (order == 2) {  // bit-reversed positions (of the next power of two), the gaps closed
+        size_t bits = 0;
+        while (((size_t)1 << bits) < nchunks) ++bits;
+        std::vector<std::pair<size_t, size_t>> key(nchunks);
+        for (size_t i = 0; i < nchunks; ++i) {
+            size_t r = 0;
+            for (size_t b = 0; b < bits; ++b) r |= ((i >> b) & 1) << (bits - 1 - b);
+            key[i] = {r, i};
+        }
+        std::sort(key.begin(), key.end());
+        for (size_t i = 0; i < nchunks; ++i) perm[i] = key[i].second;
+    }
+    if (order == 3) {
+        unsigned long long rng = 0x9E3779B97F4A7C15ull;
+        for (size_t i = nchunks; i > 1; --i) {
+            rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17;
+            std::swap(perm[i - 1], perm[(size_t)(rng % i)]);
+        }
+    }
+    hipMemAccessDesc acc{};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    for (size_t i = 0; i < nchunks; ++i) MI_HIP(hipMemMap(static_cast<char*>(va) + i * chunk, chunk, 0, h[perm[i]], 0));
+    MI_HIP(hipMemSetAccess(va, bytes, &acc, 1));
+    mapped = true;
     return MI_OK;
+}
+
+void VmmRange::release() {
+    if (va) {
+        if (mapped) (void)hipMemUnmap(va, bytes);
+        for (auto& hh : h) (void)hipMemRelease(hh);
+        (void)hipMemAddressFree(va, bytes);
+    }
+    h.clear();
+    va = nullptr;
+    bytes = 0;
+    mapped = false;
 }
 
 // P5 (+ P1 of the next convolution when fuse_forward): T -> out (may be null when fused) [-> S]
@@ -2519,7 +2509,7 @@ int NativeFft::x_inverse(hipStream_t s, float* out, int epi_kind, const ConvEpil
     const unsigned xtiles = (unsigned)((size_t)L * (M / dims.ty));
     const size_t xl = lds_bytes(dims.ty, Hx);
     const NativeDims d = dims;
-    const float2* Tp = x_source();
+    const float2* Tp = t_spec;
     float2* Sp = S.as<float2>();
     const float2* twx = tw_x;
     const int ek = epi_kind == EPI_TAPER_SHELL ? EPI_NONE : epi_kind;
@@ -2607,7 +2597,6 @@ int NativeFft::spectrum_rows(hipStream_t s, int y0, int rows, float2* buf, int d
 // have landed, while the later chunks still travel)
 int NativeFft::y_forward_planes(hipStream_t s, int z0, int nzc) {
     const int Hx = dims.hx, M = dims.ny, L = dims.nz, gran = y_z_granule();
-    MI_REQUIRE(chunk_xk == 0, "native FFT: the blocked middle and the z-chunked y pass exclude each other");
     MI_REQUIRE(z0 >= 0 && nzc > 0 && z0 + nzc <= L && z0 % gran == 0 && (nzc % gran == 0 || z0 + nzc == L),
                "native FFT: plane range [%d, %d) must be cut at multiples of %d", z0, z0 + nzc, gran);
     const bool paired = dims.paired != 0;
@@ -2650,9 +2639,9 @@ int NativeFft::time_pass(hipStream_t s, int which, const float* bl, int reps, fl
             case 4: rc = x_inverse(s, nullptr, EPI_RATIO, e, true); break;
             case 5: rc = x_inverse(s, const_cast<float*>(bl), EPI_UPDATE, e, true); break;
             // (blocked middle: the whole chain is quoted as pass 1, passes 2 and 3 do not exist on their own)
-            case 1: rc = chunk_xk > 0 ? middle_chunked(s, false) : y_pass(s, false, dims.paired != 0); break;
-            case 2: rc = chunk_xk > 0 ? MI_OK : z_conv(s, false); break;
-            default: rc = chunk_xk > 0 ? MI_OK : y_pass(s, true, dims.paired != 0); break;
+            case 1: rc = y_pass(s, false, dims.paired != 0); break;
+            case 2: rc = z_conv(s, false); break;
+            default: rc = y_pass(s, true, dims.paired != 0); break;
         }
     }
     (void)hipEventRecord(e1, s);

@@ -298,11 +298,6 @@ int FftEngine::init(hipStream_t s, const int n[3], const int k[3], const int bnd
             }
             native->set_window(nn, oo, rep, kk);
         }
-        // cache-blocked middle (profiles/chunk_probe.py): MI_FFT_CHUNK=<plane pairs per chunk>[,<chunks in flight>]
-        if (const char* e = std::getenv("MI_FFT_CHUNK")) {
-            int c = 0, st = 1;
-            if (sscanf(e, "%d,%d", &c, &st) >= 1 && c > 0 && !padded && native->dims.paired) MI_TRY(native->set_chunking(c, st));
-        }
         return MI_OK;
     }
     const size_t lengths[3] = {(size_t)F[0], (size_t)F[1], (size_t)F[2]};  // rocFFT: fastest dimension first

@@ -8,6 +8,7 @@
 // no copy back is needed), else TWO passes of 16 B/voxel in all: x and y fused in a kernel whose waves walk
 // along y with an LDS ring of x-filtered rows, z a second walk with a per-lane ring landing back in
 // `vol`.  Taps travel in the kernel argument block.
+#include <utility>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -346,22 +347,150 @@ __global__ __launch_bounds__((GF_TX / 4) * GF_TY) void k_gauss3d_fused(const flo
     }
 }
 
+// The same single pass with nothing shared between waves (round 4): a WAVE owns a 64 x 8 (x, y) tile and marches along z.  Its
+// clamped input patch ((8 + 2 ry) rows, requested a plane ahead with 16-byte loads) goes through its own slice of LDS, is filtered
+// along x there (a lane takes 4 outputs of a row at a time), then along y by the lane that owns four neighbouring x of two rows
+// (r and r + 4), and the z window -- the last KZ xy-filtered values of those 8 voxels -- never leaves the lane's registers.
+// No work-group barrier (k_gauss3d_fused has two per plane, and five 4-wave work-groups per CU standing at them were its bound),
+// no LDS ring (a float4 written and KZ read per plane and lane), 6.6 KB of LDS per wave: 24 waves per CU.
+// Filters of the RL loop's regularisation step: kx, ky <= 7, kz = KZ in {3, 5, 7}; everything else takes the kernels above.
+constexpr int GW_ROWS = 8, GW_MAXR = 3, GW_SEG = 64 + 8, GW_RIN = GW_ROWS + 2 * GW_MAXR, GW_NPRE = 4;
+constexpr int GW_WAVE_FLOATS = GW_RIN * GW_SEG + GW_RIN * 64;
+template <int KZ>
+__global__ __launch_bounds__(256) void k_gauss3d_wave(const float* __restrict__ src, float* __restrict__ dst, int nx, int ny, int nz, int zchunk,
+                                                       Taps tx, Taps ty, Taps tz) {
+    __shared__ __attribute__((aligned(16))) float lds_all[4 * GW_WAVE_FLOATS];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float* in = lds_all + wave * GW_WAVE_FLOATS;   // [rows_in][GW_SEG]: the staged patch, one float4 of halo on either side
+    float* xf = in + GW_RIN * GW_SEG;              // [rows_in][64]: after the x filter
+    const int rx = tx.n / 2, ry = ty.n / 2, rows_in = GW_ROWS + 2 * ry;
+    constexpr int rz = KZ / 2, segq = GW_SEG / 4;
+    // tiles as in k_gauss3d_fused: a work-group's four waves take the four 8-row strips of a 64 x 32 tile, contiguous tile ranges per XCD
+    const int gx = (nx + 63) / 64, gy = (ny + 31) / 32, gz = (nz + zchunk - 1) / zchunk;
+    const int total = gx * gy * gz, per = (total + 7) / 8;
+    const int t = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (t >= total) return;
+    const int bz = t / (gx * gy), by = (t - bz * gx * gy) / gx, bx = t - bz * gx * gy - by * gx;
+    const int x0 = bx * 64, y0 = by * 32 + wave * GW_ROWS;
+    if (y0 >= ny) return;
+    const int za = bz * zchunk, zb = min(za + zchunk, nz);
+    const int xoff = 4 - rx;                       // first tap of output x sits at staged column x + xoff
+    const int xq = lane & 15, rs = lane >> 4;      // y / z filters: columns 4 xq .. + 3 of rows rs and rs + 4
+    // the patches of the next TWO planes travel while a plane is filtered (one plane ahead left the march latency-bound: a plane is
+    // filtered in less than a memory round trip); the lane's pieces of a patch do not depend on the plane: offsets once
+    float4 preA[GW_NPRE], preB[GW_NPRE];
+    int poff[GW_NPRE];
+    bool inside = true;
+#pragma unroll
+    for (int u = 0; u < GW_NPRE; ++u) {
+        const int it = min(lane + 64 * u, rows_in * segq - 1);   // (lanes past the patch repeat its last piece: no predicated load)
+        const int r = it / segq, q = it - r * segq, x = x0 - 4 + 4 * q;
+        poff[u] = min(max(y0 - ry + r, 0), ny - 1) * nx + x;
+        inside = inside && x >= 0 && x + 3 < nx;
+    }
+    const bool all_inside = __all(inside) && (size_t)ny * nx < ((size_t)1 << 31);   // (wave-uniform: one code path per wave)
+    auto fetch = [&](int p, float4 (&pre)[GW_NPRE]) {
+        const float* plane = src + (size_t)min(max(p, 0), nz - 1) * ny * nx;
+        if (all_inside) {
+#pragma unroll
+            for (int u = 0; u < GW_NPRE; ++u) pre[u] = *reinterpret_cast<const float4*>(plane + poff[u]);
+            return;
+        }
+#pragma unroll
+        for (int u = 0; u < GW_NPRE; ++u) {
+            const int it = min(lane + 64 * u, rows_in * segq - 1);
+            const int r = it / segq, q = it - r * segq;
+            const float* row = plane + (size_t)min(max(y0 - ry + r, 0), ny - 1) * nx;
+            const int x = x0 - 4 + 4 * q;
+            pre[u] = make_float4(row[min(max(x, 0), nx - 1)], row[min(max(x + 1, 0), nx - 1)], row[min(max(x + 2, 0), nx - 1)],
+                                 row[min(max(x + 3, 0), nx - 1)]);
+        }
+    };
+    float4 win[KZ][2];  // the z window of the lane's 8 voxels, oldest first
+#pragma unroll
+    for (int i = 0; i < KZ; ++i) win[i][0] = win[i][1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    fetch(za - rz, preA);
+    fetch(za - rz + 1, preB);
+    auto plane_step = [&](int p, float4 (&pre)[GW_NPRE]) {
+#pragma unroll
+        for (int u = 0; u < GW_NPRE; ++u) {
+            const int it = lane + 64 * u;
+            if (it < rows_in * segq) {
+                const int r = it / segq, q = it - r * segq;
+                *reinterpret_cast<float4*>(in + r * GW_SEG + 4 * q) = pre[u];
+            }
+        }
+        wave_fence();
+        fetch(p + 2, pre);   // (clamped planes past the chunk: harmless)
+        for (int it = lane; it < rows_in * 16; it += 64) {   // x filter: 4 outputs from kx + 3 staged samples
+            const int r = it >> 4, q = it & 15;
+            const float* a = in + r * GW_SEG + 4 * q + xoff;
+            float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f, o3 = 0.0f;
+            float v0 = a[0], v1 = a[1], v2 = a[2];
+            for (int k = 0; k < tx.n; ++k) {
+                const float v3 = a[k + 3], w = tx.w[k];
+                o0 = fmaf(v0, w, o0);
+                o1 = fmaf(v1, w, o1);
+                o2 = fmaf(v2, w, o2);
+                o3 = fmaf(v3, w, o3);
+                v0 = v1; v1 = v2; v2 = v3;
+            }
+            *reinterpret_cast<float4*>(xf + r * 64 + 4 * q) = make_float4(o0, o1, o2, o3);
+        }
+        wave_fence();
+#pragma unroll
+        for (int i = 0; i + 1 < KZ; ++i) { win[i][0] = win[i + 1][0]; win[i][1] = win[i + 1][1]; }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {   // y filter of rows rs and rs + 4
+            float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            for (int k = 0; k < ty.n; ++k) {
+                const float4 v = *reinterpret_cast<const float4*>(xf + (rs + 4 * h + k) * 64 + 4 * xq);
+                const float w = ty.w[k];
+                acc.x = fmaf(v.x, w, acc.x); acc.y = fmaf(v.y, w, acc.y); acc.z = fmaf(v.z, w, acc.z); acc.w = fmaf(v.w, w, acc.w);
+            }
+            win[KZ - 1][h] = acc;
+        }
+        wave_fence();   // (the next plane's staging overwrites `in` and `xf`)
+        const int zo = p - rz;  // output plane whose window [zo - rz, zo + rz] is now complete
+        if (zo >= za) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+                for (int k = 0; k < KZ; ++k) {
+                    const float4 v = win[k][h];
+                    const float w = tz.w[k];
+                    acc.x = fmaf(v.x, w, acc.x); acc.y = fmaf(v.y, w, acc.y); acc.z = fmaf(v.z, w, acc.z); acc.w = fmaf(v.w, w, acc.w);
+                }
+                const int y = y0 + rs + 4 * h, x = x0 + 4 * xq;
+                if (y < ny && x < nx) *reinterpret_cast<float4*>(dst + ((size_t)zo * ny + y) * nx + x) = acc;
+            }
+        }
+    };
+    for (int p = za - rz; p < zb + rz; p += 2) {
+        plane_step(p, preA);
+        if (p + 1 < zb + rz) plane_step(p + 1, preB);
+    }
+}
+
 #ifndef MI_GAUSS_FUSED_LDS
 #define MI_GAUSS_FUSED_LDS (64 * 1024)
 #endif
 constexpr size_t kFusedLdsMax = MI_GAUSS_FUSED_LDS;
 // tile of the single-pass kernel: 64 x 16 (x, y) by default; MI_GAUSS_TILE=<tx>x<ty> picks another built one (measurements)
 void fused_tile(int* tx, int* ty) {
-    static int sx = 0, sy = 0;
-    if (!sx) {
+    // (a function-local static with an initialiser: set once, under the language's own lock -- worker threads of one process call
+    // this concurrently, and two lazily assigned ints could be seen half-set)
+    static const std::pair<int, int> tile = [] {
         int a = 64, b = 16;
-        if (const char* e = std::getenv("MI_GAUSS_TILE")) {
+        if (const char* e = MI_PROBE_ENV("MI_GAUSS_TILE")) {
             int u = 0, v = 0;
             if (sscanf(e, "%dx%d", &u, &v) == 2 && ((u == 64 && (v == 16 || v == 32)) || (u == 128 && (v == 8 || v == 16)))) { a = u; b = v; }
         }
-        sx = a; sy = b;
-    }
-    *tx = sx; *ty = sy;
+        return std::make_pair(a, b);
+    }();
+    *tx = tile.first;
+    *ty = tile.second;
 }
 size_t fused_lds_bytes(const int* k) {
     int GF_TX, GF_TY;
@@ -402,11 +531,21 @@ int gauss3d_to(hipStream_t s, float* src, float* dst, int nx, int ny, int nz, co
     Taps tx, ty, tz;
     MI_TRY(resolve_taps(sigma, ksize, k, tx, ty, tz));
     *fused = gauss3d_fuses(nx, k);
+    static const bool no_wave = MI_PROBE_ENV("MI_GAUSS_NO_WAVE") != nullptr;  // (probe builds: A/B against the work-group kernel)
+    if (*fused && !no_wave && k[0] <= 2 * GW_MAXR + 1 && k[1] <= 2 * GW_MAXR + 1 && (k[2] == 3 || k[2] == 5 || k[2] == 7)) {
+        const int zchunk = 128;
+        const int total = ((nx + 63) / 64) * ((ny + 31) / 32) * ((nz + zchunk - 1) / zchunk);
+        const dim3 grid((total + 7) / 8 * 8), block(256);
+        if (k[2] == 3) hipLaunchKernelGGL(k_gauss3d_wave<3>, grid, block, 0, s, src, dst, nx, ny, nz, zchunk, tx, ty, tz);
+        else if (k[2] == 5) hipLaunchKernelGGL(k_gauss3d_wave<5>, grid, block, 0, s, src, dst, nx, ny, nz, zchunk, tx, ty, tz);
+        else hipLaunchKernelGGL(k_gauss3d_wave<7>, grid, block, 0, s, src, dst, nx, ny, nz, zchunk, tx, ty, tz);
+        return launch_check("k_gauss3d_wave");
+    }
     if (*fused) {
         int GF_TX, GF_TY;
         fused_tile(&GF_TX, &GF_TY);
         int zchunk = k[2] <= 7 ? 128 : 256;
-        if (const char* e = std::getenv("MI_GAUSS_ZCHUNK")) zchunk = std::max(2 * k[2], atoi(e));
+        if (const char* e = MI_PROBE_ENV("MI_GAUSS_ZCHUNK")) zchunk = std::max(2 * k[2], atoi(e));
         const int total = ((nx + GF_TX - 1) / GF_TX) * ((ny + GF_TY - 1) / GF_TY) * ((nz + zchunk - 1) / zchunk);
         const size_t lds = fused_lds_bytes(k);
         const dim3 grid((total + 7) / 8 * 8), block((GF_TX / 4) * GF_TY);
@@ -415,9 +554,12 @@ int gauss3d_to(hipStream_t s, float* src, float* dst, int nx, int ny, int nz, co
         if (lds > 64 * 1024)                                                                                                            \
             MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gauss3d_fused<TXV, TYV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL((k_gauss3d_fused<TXV, TYV>), grid, block, lds, s, src, dst, nx, ny, nz, zchunk, tx, ty, tz);                  \
+        launched = true;                                                                                                                 \
     }
+        bool launched = false;
         MI_GF(64, 16) MI_GF(64, 32) MI_GF(128, 8) MI_GF(128, 16)
 #undef MI_GF
+        if (!launched) return fail(MI_ERR_INVALID, "gauss3d_gpu: no single-pass kernel for a %d x %d tile", GF_TX, GF_TY);
         return launch_check("k_gauss3d_fused");
     }
     // pass 1: src -> dst (x then y, each rounded to fp32 like the reference's separate passes); pass 2: dst -> src (z)

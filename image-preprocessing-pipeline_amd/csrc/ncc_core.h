@@ -539,7 +539,7 @@ int launch_mips(hipStream_t s, const float* A, const float* B, const float* cons
     }
     dim3 grid(cblocks, bands, 2 * np);
     static const int knock = [] {
-        const char* e = std::getenv("MI_NCC_MIPS_KNOCK");
+        const char* e = MI_PROBE_ENV("MI_NCC_MIPS_KNOCK");
         return e ? std::atoi(e) : 0;
     }();
     hipLaunchKernelGGL(HIP_KERNEL_NAME(via_lds && dimk <= 4 * MIP_KPW ? k_mips<true> : k_mips<false>), grid, dim3(256), via_lds ? lds : 0, s, A, B, tab, pstride, dimk, dimi_v, dimj_v, slice, pitch, ai0, aj0, xy1, xz1, yz1,

@@ -22,11 +22,13 @@ bool ncc_lag_supported(int dimk, int dimi, int dimj, int ni, int nj, int delayk,
 // own, behind what `s` holds so far), then wait for it and run the host rules.  careful[q] != 0: pair q must be redone by the
 // per-pair path, out[q] untouched.  A job that is not finished must be abandoned.
 struct LagJob;
+// groups_in_flight: how many groups the caller keeps enqueued at once -- they share the device-memory budget of a chunk
+// (MI_NCC_CHUNK_MB); concurrent callers on one device share its three streams and serialise on them.
 // defer_chains: only the MIP pass is enqueued; the caller enqueues the chains of all its jobs afterwards (ncc_lag_enqueue_chains)
 // behind an event it records on the MIP stream after the last job's MIP pass
 int ncc_lag_enqueue(int dev, hipStream_t s, int n, const float* const* a_ptrs, const float* const* b_ptrs, int dimk, int dimi, int dimj, int ni,
                     int nj, int delayk, int delayi, int delayj, int side, mi_ncc_params* params, LagJob** job, bool defer_chains = false,
-                    TileFmt fmt = TileFmt());
+                    TileFmt fmt = TileFmt(), int groups_in_flight = 1);
 int ncc_lag_enqueue_chains(LagJob* job, hipEvent_t gate);
 hipStream_t ncc_lag_mip_stream(LagJob* job);
 int ncc_lag_finish(LagJob* job, mi_ncc_params* params, mi_ncc_descr* out, unsigned char* careful);

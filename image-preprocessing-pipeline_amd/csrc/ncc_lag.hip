@@ -1245,7 +1245,8 @@ static bool mip_gate() {
 }
 
 int ncc_lag_enqueue(int dev, hipStream_t s, int n, const float* const* a_ptrs, const float* const* b_ptrs, int dimk, int dimi, int dimj, int ni,
-                    int nj, int delayk, int delayi, int delayj, int side, mi_ncc_params* params, LagJob** job_out, bool defer_chains, TileFmt fmt) {
+                    int nj, int delayk, int delayi, int delayj, int side, mi_ncc_params* params, LagJob** job_out, bool defer_chains, TileFmt fmt,
+                    int groups_in_flight) {
     *job_out = nullptr;
     if (n <= 0) return MI_OK;
     std::unique_ptr<LagJob> job(new (std::nothrow) LagJob);
@@ -1281,7 +1282,8 @@ int ncc_lag_enqueue(int dev, hipStream_t s, int n, const float* const* a_ptrs, c
     }
     job->wcap = wcap;
     const size_t per_pair = 4 * (pstride + tmp_floats) + 8 * sstride + spec + crs + 3 * 4 * (size_t)wcap + 64;
-    size_t budget = (size_t)6 << 30;
+    // (every group of a batch is enqueued before the first is waited for, each with a workspace of its own: they share the budget)
+    size_t budget = std::max((size_t)1 << 30, ((size_t)6 << 30) / (size_t)std::max(1, groups_in_flight));
     if (const char* e = std::getenv("MI_NCC_CHUNK_MB")) budget = (size_t)std::max(1, std::atoi(e)) << 20;
     const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, budget / per_pair));
     const int piece = chunk;
@@ -1468,7 +1470,7 @@ void ncc_lag_abandon(LagJob* job) { delete job; }
 int ncc_lag_group(int dev, hipStream_t s, int n, const float* const* a_ptrs, const float* const* b_ptrs, int dimk, int dimi, int dimj, int ni,
                   int nj, int delayk, int delayi, int delayj, int side, mi_ncc_params* params, mi_ncc_descr* out, unsigned char* careful, TileFmt fmt) {
     LagJob* job = nullptr;
-    MI_TRY(ncc_lag_enqueue(dev, s, n, a_ptrs, b_ptrs, dimk, dimi, dimj, ni, nj, delayk, delayi, delayj, side, params, &job, false, fmt));
+    MI_TRY(ncc_lag_enqueue(dev, s, n, a_ptrs, b_ptrs, dimk, dimi, dimj, ni, nj, delayk, delayi, delayj, side, params, &job, false, fmt, 1));
     return ncc_lag_finish(job, params, out, careful);
 }
 
@@ -1515,6 +1517,7 @@ int ncc_lag_map(int dev, hipStream_t s, const float* mip1, const float* mip2, in
 int ncc_time_mips(int dev, hipStream_t s, int n, const float* const* a_ptrs, const float* const* b_ptrs, int dimk, int dimi, int dimj, int ni, int nj,
                   int side, int reps, float* ms, TileFmt fmt) {
     MI_REQUIRE(n > 0 && reps > 0 && ms && a_ptrs && b_ptrs, "mi_ncc_time_mips: invalid arguments");
+    MI_REQUIRE(side == MI_NORTH_SOUTH || side == MI_WEST_EAST, "CrossMIPs: unexpected alignment configuration");
     MI_REQUIRE(fmt.bytes == 4 || mips_int_ok(fmt.bytes, dimk, dimj, (size_t)dimi * dimj),
                "mi_ncc_time_mips: integer tiles need rows of whole 32-bit words and at most %d slices", 4 * MIP_KPW);
     const int dimi_v = side == MI_NORTH_SOUTH ? dimi - ni : dimi, dimj_v = side == MI_WEST_EAST ? dimj - nj : dimj;

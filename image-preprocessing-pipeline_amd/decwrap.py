@@ -231,7 +231,9 @@ def main(argv=None):
     res_share = sz * sy * sx * 4 // len(set(args.gpu_indices)) + (1 << 30)
     if args.block_size_max:
         bmax = args.block_size_max
-        res_budget = max(0, free0 - (3 << 30) - per_dev * bmax * 4 * n_work_vols) if keep_resident else 0
+        # (at most half of the free memory: the workers' real allocations -- transform grids 1.3 x the block, taper engines, plan
+        # buffers -- are larger than the estimate below, and resident cores must never be what makes them fail)
+        res_budget = min(free0 // 2, max(0, free0 - (3 << 30) - per_dev * bmax * 4 * n_work_vols)) if keep_resident else 0
     else:
         res_budget = res_share if (keep_resident and res_share <= free0 // 2) else 0
         bmax = max(1, (free0 - (3 << 30) - res_budget) // 4 // n_work_vols) // per_dev
@@ -307,6 +309,7 @@ def main(argv=None):
         return cache / f"bl_{n}.lz4"
 
     resident = {}                                   # block number -> its float32 core on the device that computed it
+    resident_dev = {}                               # block number -> that device
     res_used = {g: 0 for g in set(args.gpu_indices)}
 
     def brick_complete(n):
@@ -479,6 +482,26 @@ def main(argv=None):
         prep_thread = threading.Thread(target=prepare_assembly, daemon=True)
         prep_thread.start()
 
+    def evict_resident(g):
+        """Allocation failure on GPU g: its resident cores are given up (a core without a brick is written first), the budget of
+        every device drops to zero, cached blocks go back to the driver."""
+        nonlocal res_budget
+        with lock:
+            res_budget = 0
+            mine = [n for n, gg in resident_dev.items() if gg == g and n in resident]
+        log.warning(f"GPU {g}: out of device memory; {len(mine)} resident core(s) go back to their bricks")
+        for n in mine:
+            core = resident.pop(n)
+            if not brick_complete(n):
+                arr = core.cpu().numpy()
+                brickio.save_lz4(brick_path(n).with_suffix(".lz4.tmp"), arr, chunk_size=brick_chunk, pool=codec)
+                os.replace(brick_path(n).with_suffix(".lz4.tmp"), brick_path(n))
+            del core
+        with lock:
+            res_used[g] = 0
+        torch.cuda.empty_cache()
+        capi.release_cached_memory()
+
     def run(worker_id, first_block):
         g = workers[worker_id]
         stream = torch.cuda.Stream(device=g - 1)
@@ -512,8 +535,18 @@ def main(argv=None):
             t_b = time.perf_counter()
             ev0.record()
             rawmax = None if int_input else float(bl.max())                               # LsDeconv.m:717-721
-            t, lb, ub = L.process_block(bl, blk, psf_struct, args.numit, args.lambda_damping, args.stop_criterion, filt,
-                                        args.clipval, g, plan=plan)
+            try:
+                t, lb, ub = L.process_block(bl, blk, psf_struct, args.numit, args.lambda_damping, args.stop_criterion, filt,
+                                            args.clipval, g, plan=plan)
+            except (torch.cuda.OutOfMemoryError, capi.MiError) as e:
+                if isinstance(e, capi.MiError) and e.code != capi.MI_ERR_NOMEM:
+                    raise
+                # the device is full: the resident cores go back to being bricks (they are copies of what the cache folder holds,
+                # or are written now), nothing more is kept on the device, and the block is tried once more
+                evict_resident(g)
+                bl = L.load_block_device(vol, p1, p2, pad, torch.device("cuda", g - 1), staging)
+                t, lb, ub = L.process_block(bl, blk, psf_struct, args.numit, args.lambda_damping, args.stop_criterion, filt,
+                                            args.clipval, g, plan=plan)
             core = t[pad[2]:t.shape[0] - pad[2] or None, pad[1]:t.shape[1] - pad[1] or None, pad[0]:t.shape[2] - pad[0] or None]
             core = core.contiguous()                                                       # strip pads, LsDeconv.m:750-752
             assert tuple(core.shape) == core_shape(n), "[remove padding]: Output block size mismatch!"
@@ -531,9 +564,12 @@ def main(argv=None):
             if host is not None:
                 view = host[:core.numel()].view(core.shape)
                 view.copy_(core, non_blocking=True)
+            if stays and core.untyped_storage().nbytes() > nbytes:
+                core = core.clone()            # a block padded along z only: `core` is a VIEW that would keep the whole padded block alive
             stream.synchronize()
             if stays:
                 resident[n] = core                                                         # (complete: the stream has been waited for)
+                resident_dev[n] = g
         t_e = time.perf_counter()
         with lock:                                                                         # where a block's time goes (summary at the end)
             timing["blocks"] += 1
@@ -613,6 +649,7 @@ def main(argv=None):
                  f"D2H of the cores {timing['d2h_s']:.1f} s, waiting for a free core buffer {timing['wait_buffer_s']:.1f} s "
                  f"(summed over {len(workers)} workers)")
     main.last_timing = dict(timing, blocks_wall_s=t_blocks)
+    merge_min_max()                                                                        # (helpers too: rawmax of their last blocks)
     if int(args.start_block) != 1:
         log.info("--start-block > 1: the blocks are in the cache; the process started with --start-block 1 assembles the output")
         codec.shutdown(wait=True)

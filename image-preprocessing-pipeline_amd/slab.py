@@ -147,6 +147,29 @@ class HipPeer:
     def ordinal(self):
         return int(self.di)
 
+    def identity(self):
+        """What names this device in EVERY process of the job: its UUID (a rank that masks its devices sees its GPU as ordinal 0)."""
+        pr = torch.cuda.get_device_properties(self.dev)
+        u = getattr(pr, "uuid", None)
+        if u is not None:
+            return ("uuid", str(u))
+        bus = [getattr(pr, k, None) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id")]
+        return ("pci", tuple(bus)) if all(b is not None for b in bus) else ("ordinal", int(self.di))
+
+    def resolve(self, ident):
+        """The ordinal under which THIS process sees the device `ident` names; -1 when it does not (mi_peer_copy then leaves the
+        mapped pointer to the runtime instead of naming a device)."""
+        kind, val = ident
+        if kind == "ordinal":
+            return int(val)
+        for i in range(torch.cuda.device_count()):
+            pr = torch.cuda.get_device_properties(i)
+            if kind == "uuid" and str(getattr(pr, "uuid", None)) == val:
+                return i
+            if kind == "pci" and tuple(getattr(pr, k, None) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id")) == tuple(val):
+                return i
+        return -1
+
     def alloc(self, nbytes):
         h, p = C.create_string_buffer(capi.IPC_HANDLE_BYTES), C.c_void_p()
         capi.check(self.L.mi_peer_alloc(self.di, int(nbytes), C.byref(p), h))
@@ -252,7 +275,8 @@ class PeerLink:
         self._fd = os.open(self.shm_path, os.O_RDWR)
         self._mm = mmap.mmap(self._fd, 8 * 4 * drv.world)
         self.seq = np.frombuffer(self._mm, dtype=np.uint64).reshape(drv.world, 2, 2)
-        mine = {"mem": mem_handle, "sent": hs_sent, "done": hs_done, "dev": backend.ordinal()}
+        mine = {"mem": mem_handle, "sent": hs_sent, "done": hs_done,
+                "dev": backend.identity() if hasattr(backend, "identity") else ("ordinal", backend.ordinal())}
         everyone = [None] * drv.world
         dist.all_gather_object(everyone, mine, group=group)
         lo, hi = drv.neighbours()
@@ -265,7 +289,8 @@ class PeerLink:
                 if dst_rank not in self._mapped:
                     self._mapped[dst_rank] = backend.open(info["mem"])
                 evs = [backend.event_open(info["done"][d * self.SETS + st]) for st in range(self.SETS)]
-                self.peer[d] = (dst_rank, self._mapped[dst_rank], info["dev"], evs)
+                pdev = backend.resolve(info["dev"]) if hasattr(backend, "resolve") else int(info["dev"][1])
+                self.peer[d] = (dst_rank, self._mapped[dst_rank], pdev, evs)
             if src_rank is not None:
                 info = everyone[src_rank]
                 self.src[d] = (src_rank, [backend.event_open(info["sent"][(d * self.SETS + st) * self.C + k])
@@ -281,6 +306,7 @@ class PeerLink:
         import time
         t0 = time.monotonic()
         while int(self.seq[rank, d, field]) < n:
+            time.sleep(20e-6)                          # (the neighbour is at most one enqueue away: no need to burn the core)
             if time.monotonic() - t0 > self.timeout:
                 raise TimeoutError(f"halo exchange {n}: rank {rank} did not {'issue its copy' if field == 0 else 'release its buffer'} "
                                    f"within {self.timeout:.0f} s")
@@ -336,6 +362,7 @@ class PeerLink:
 
     def close(self):
         import os
+        import sys
         try:
             for _, (_, _, _, evs) in self.peer.items():
                 for e in evs:
@@ -345,6 +372,13 @@ class PeerLink:
                     self.be.event_destroy(e)
             for q in self._mapped.values():
                 self.be.close(q)
+            # nobody frees the buffer it exported before every neighbour has closed its mapping of it
+            try:
+                import torch.distributed as dist
+                if dist.is_initialized():
+                    dist.barrier(group=self.group)
+            except Exception as e:
+                sys.stderr.write(f"PeerLink.close: no barrier before the buffers are freed ({e!r})\n")
             for e in self.ev_sent + self.ev_done:
                 self.be.event_destroy(e)
             self.be.destroy()
@@ -352,8 +386,8 @@ class PeerLink:
             self.seq = None
             self._mm.close()
             os.close(self._fd)
-        except Exception:
-            pass
+        except Exception as e:
+            sys.stderr.write(f"PeerLink.close: {e!r}\n")
         self.peer, self.src, self._mapped = {}, {}, {}
 
 

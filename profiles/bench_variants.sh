@@ -1,6 +1,6 @@
 B="bench.py --steps 20 --warmup 5 --no-ncc --no-cpu-baseline"
 for rep in 1 2; do
-for v in "" "MI_X_DYN=1" "MI_X_DYN=1 MI_Z_DYN=1" "MI_X_DYN=1 MI_Z_DYN=1 MI_FFT_CHUNK=4,2"; do
+for v in "" "MI_X_DYN=1" "MI_X_DYN=1 MI_Z_DYN=1"; do
   echo "== $v" >> gpurun_out/r3_b2.txt
   env $v python3 $B 2>/dev/null | python3 -c "
 import sys, json

@@ -1,0 +1,118 @@
+"""Is a slab rank host-bound?    The HOST cost of enqueueing one sharded RL iteration -- the Python step
+sequence of slab.SlabRL.iterate: edge tiles, pack, send, remaining tiles, wait, unpack, y, z, y, twice per iteration -- against the
+DEVICE time of the same iteration, on the rank-local shapes of the 8-GPU runs:
+
+    C3 at N = 8   global 2048 x 2048 x 512, 31 x 31 x 61 PSF  -> rank 2048 x 288 x 512   (256 rows + 2 x 15 halo rows -> 288)
+    C4 at N = 8   global 4096 x 4096 x 1024, 63 x 63 x 127 PSF -> rank 4096 x 576 x 1024 (512 rows + 2 x 31 -> 576)
+
+One GPU suffices: a self-ring (one process whose slab is its own neighbour: every kernel and every pack / unpack of a rank, no
+transport) and two processes on one GPU with the copy-engine transport (slab.PeerLink: IPC handles, peer copies, interprocess events,
+sequence numbers).  "enqueue" = wall time of K iterations issued back to back WITHOUT a synchronisation, per iteration (the launch
+queues take them all); "device" = the same K iterations timed to their end.  A rank is host-bound when enqueue >= device.
+
+    python profiles/slab_host_cost.py > gpurun_out/r04_slab_host_cost.txt
+"""
+import os
+import sys
+import time
+
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+RANKS = {  # name: (slab of ONE rank as a global shape (z, y, x) for a ring of `world` such slabs, psf (z, y, x))
+    "C3 at N=8": ((512, 256, 2048), (61, 31, 31)),
+    "C4 at N=8": ((1024, 512, 4096), (127, 63, 63)),
+}
+K = 12
+
+
+def measure(drv, dev):
+    for _ in range(3):
+        drv.iterate()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(K):
+        drv.iterate()
+    t_enq = (time.perf_counter() - t0) / K * 1e3
+    torch.cuda.synchronize(dev)
+    t_all = (time.perf_counter() - t0) / K * 1e3
+    # device time alone: the queue is full when the clock starts only if the host is ahead; time K more with events
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(K):
+        drv.iterate()
+    ev1.record()
+    torch.cuda.synchronize(dev)
+    return t_enq, t_all, ev0.elapsed_time(ev1) / K
+
+
+def self_ring(name, zchunks):
+    import bench
+    from ipp_amd import slab
+    dev = torch.device("cuda", 0)
+    shape, kshape = RANKS[name]
+    psf = bench.make_psf(kshape)
+    drv = slab.SlabRL(shape, psf, rank=0, world_size=1, device=dev, flavour="fft", engine=2, seed=1, zchunks=zchunks)
+    t_enq, t_all, t_dev = measure(drv, dev)
+    print(f"{name}  self-ring        zchunks {zchunks}: local {drv.lshape[2]} x {drv.lshape[1]} x {drv.lshape[0]}, fused {drv.sharded}, "
+          f"split x pass {drv.overlap}:  enqueue {t_enq:6.3f} ms / iteration, device {t_dev:6.3f} ms, wall {t_all:6.3f} ms "
+          f"-> host share {t_enq / t_dev:.2f}", flush=True)
+    drv.close()
+    del drv
+    torch.cuda.empty_cache()
+
+
+def _peer_worker(rank, world, port, name, zchunks, out):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    import bench
+    from ipp_amd import slab
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda", 0)
+        shape, kshape = RANKS[name]
+        gshape = (shape[0], shape[1] * world, shape[2])  # two slabs of the rank's size
+        psf = bench.make_psf(kshape)
+        drv = slab.SlabRL(gshape, psf, rank=rank, world_size=world, device=dev, flavour="fft", engine=2, seed=1, transport="peer",
+                          zchunks=zchunks)
+        res = measure(drv, dev)
+        dist.barrier()
+        drv.close()
+        if rank == 0:
+            out.put((res, tuple(drv.lshape)))
+    finally:
+        dist.destroy_process_group()
+
+
+def two_processes(name, zchunks):
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = 29650 + (os.getpid() % 100) + zchunks
+    procs = [ctx.Process(target=_peer_worker, args=(r, 2, port, name, zchunks, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        (t_enq, t_all, t_dev), lshape = out.get(timeout=600)
+    finally:
+        for p in procs:
+            p.join(timeout=120)
+            if p.is_alive():
+                p.kill()
+    print(f"{name}  2 procs, 1 GPU   zchunks {zchunks}: local {lshape[2]} x {lshape[1]} x {lshape[0]}, copy-engine transport:  enqueue "
+          f"{t_enq:6.3f} ms / iteration per rank, device (BOTH ranks share the GPU) {t_dev:6.3f} ms, wall {t_all:6.3f} ms "
+          f"-> host share of ONE rank's device time {t_enq / (t_dev / 2):.2f}", flush=True)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or list(RANKS)
+    for name in which:
+        for zc in (1, 4):
+            self_ring(name, zc)
+    for zc in (1, 4):
+        two_processes("C3 at N=8", zc)

@@ -47,3 +47,21 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in text.replace("test oracle", ""), f"{f} mentions the oracle"
+
+
+def test_product_library_contains_no_experiment_switch():
+    """Experiment switches (phase knock-outs, tile shapes, stream layouts, placement probes: MI_PROBE_ENV in csrc/) exist only in
+    the probe build (make -C csrc probes -> libmi_ipp_probes.so); the product library must not even contain their names."""
+    import __graft_entry__ as g
+    g.build()
+    csrc = os.path.join(ROOT, "image-preprocessing-pipeline_amd", "csrc")
+    names = set()
+    for f in glob.glob(os.path.join(csrc, "*.h*")):
+        names |= set(re.findall(r'MI_PROBE_ENV\("([A-Z0-9_]+)"\)', open(f).read()))
+    assert len(names) >= 10
+    blob = open(os.path.join(ROOT, "image-preprocessing-pipeline_amd", "libmi_ipp.so"), "rb").read()
+    found = sorted(n for n in names if n.encode() in blob)
+    assert not found, f"libmi_ipp.so contains experiment switches: {found}"
+    # routes that were measured and rejected are gone altogether
+    for gone in ("MI_FFT_CHUNK", "MI_CONTIG_MIN_MB", "MI_NCC_SPLIT_XY", "MI_NCC_PIECES", "MI_FFT_PLACEMENT_TRIES", "MI_NCC_XY_TABLES_ASIDE"):
+        assert gone.encode() not in blob, gone
