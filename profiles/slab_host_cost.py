@@ -8,7 +8,9 @@ DEVICE time of the same iteration, on the rank-local shapes of the 8-GPU runs:
 One GPU suffices: a self-ring (one process whose slab is its own neighbour: every kernel and every pack / unpack of a rank, no
 transport) and two processes on one GPU with the copy-engine transport (slab.PeerLink: IPC handles, peer copies, interprocess events,
 sequence numbers).  "enqueue" = wall time of K iterations issued back to back WITHOUT a synchronisation, per iteration (the launch
-queues take them all); "device" = the same K iterations timed to their end.  A rank is host-bound when enqueue >= device.
+queues take them all); "CPU" = the thread's CPU time over the same loop (with a neighbour, the issue loop waits for the neighbour's
+sequence numbers -- sleeping -- so its wall time follows the device; the CPU time is what the host works); "device" = the same K
+iterations timed to their end.  A rank is host-bound when its host work approaches its device time.
 
     python profiles/slab_host_cost.py > gpurun_out/r04_slab_host_cost.txt
 """
@@ -33,10 +35,11 @@ def measure(drv, dev):
     for _ in range(3):
         drv.iterate()
     torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
+    t0, c0 = time.perf_counter(), time.thread_time()
     for _ in range(K):
         drv.iterate()
     t_enq = (time.perf_counter() - t0) / K * 1e3
+    t_cpu = (time.thread_time() - c0) / K * 1e3   # CPU time of this thread: what the host WORKS per iteration (waits for a neighbour sleep)
     torch.cuda.synchronize(dev)
     t_all = (time.perf_counter() - t0) / K * 1e3
     # device time alone: the queue is full when the clock starts only if the host is ahead; time K more with events
@@ -46,7 +49,7 @@ def measure(drv, dev):
         drv.iterate()
     ev1.record()
     torch.cuda.synchronize(dev)
-    return t_enq, t_all, ev0.elapsed_time(ev1) / K
+    return t_enq, t_all, ev0.elapsed_time(ev1) / K, t_cpu
 
 
 def self_ring(name, zchunks):
@@ -56,9 +59,9 @@ def self_ring(name, zchunks):
     shape, kshape = RANKS[name]
     psf = bench.make_psf(kshape)
     drv = slab.SlabRL(shape, psf, rank=0, world_size=1, device=dev, flavour="fft", engine=2, seed=1, zchunks=zchunks)
-    t_enq, t_all, t_dev = measure(drv, dev)
+    t_enq, t_all, t_dev, t_cpu = measure(drv, dev)
     print(f"{name}  self-ring        zchunks {zchunks}: local {drv.lshape[2]} x {drv.lshape[1]} x {drv.lshape[0]}, fused {drv.sharded}, "
-          f"split x pass {drv.overlap}:  enqueue {t_enq:6.3f} ms / iteration, device {t_dev:6.3f} ms, wall {t_all:6.3f} ms "
+          f"split x pass {drv.overlap}:  enqueue {t_enq:6.3f} ms / iteration (CPU {t_cpu:6.3f} ms), device {t_dev:6.3f} ms, wall {t_all:6.3f} ms "
           f"-> host share {t_enq / t_dev:.2f}", flush=True)
     drv.close()
     del drv
@@ -86,6 +89,10 @@ def _peer_worker(rank, world, port, name, zchunks, out):
         drv.close()
         if rank == 0:
             out.put((res, tuple(drv.lshape)))
+    except Exception as e:   # (the parent must hear about it: the other rank would wait for this one until its time-out)
+        import traceback
+        out.put(("error", f"rank {rank}: {e!r}\n{traceback.format_exc()}"))
+        os._exit(1)
     finally:
         dist.destroy_process_group()
 
@@ -98,15 +105,19 @@ def two_processes(name, zchunks):
     for p in procs:
         p.start()
     try:
-        (t_enq, t_all, t_dev), lshape = out.get(timeout=600)
+        got = out.get(timeout=240)
+        if got[0] == "error":
+            raise RuntimeError(got[1])
+        (t_enq, t_all, t_dev, t_cpu), lshape = got
     finally:
         for p in procs:
-            p.join(timeout=120)
+            p.join(timeout=20)
             if p.is_alive():
                 p.kill()
-    print(f"{name}  2 procs, 1 GPU   zchunks {zchunks}: local {lshape[2]} x {lshape[1]} x {lshape[0]}, copy-engine transport:  enqueue "
-          f"{t_enq:6.3f} ms / iteration per rank, device (BOTH ranks share the GPU) {t_dev:6.3f} ms, wall {t_all:6.3f} ms "
-          f"-> host share of ONE rank's device time {t_enq / (t_dev / 2):.2f}", flush=True)
+    print(f"{name}  2 procs, 1 GPU   zchunks {zchunks}: local {lshape[2]} x {lshape[1]} x {lshape[0]}, copy-engine transport:  issue loop "
+          f"{t_enq:6.3f} ms / iteration per rank (it WAITS for the neighbour's sequence numbers: two ranks share one GPU), of which CPU "
+          f"{t_cpu:6.3f} ms; device (BOTH ranks) {t_dev:6.3f} ms, wall {t_all:6.3f} ms "
+          f"-> host work / ONE rank's device time {t_cpu / (t_dev / 2):.2f}", flush=True)
 
 
 if __name__ == "__main__":
