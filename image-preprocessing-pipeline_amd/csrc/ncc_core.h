@@ -117,7 +117,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                                                size_t pstride, int dimk, int dimi_v, int dimj_v,
                                                size_t slice, int pitch, int ai0, int aj0, float* __restrict__ xy1, float* __restrict__ xz1,
                                                float* __restrict__ yz1, float* __restrict__ xy2, float* __restrict__ xz2,
-                                               float* __restrict__ yz2, float* __restrict__ yz_tmp, float* __restrict__ xz_tmp, int knock) {
+                                               float* __restrict__ yz2, float* __restrict__ yz_tmp, float* __restrict__ xz_tmp, int knock,
+                                               float* __restrict__ xyT, size_t tstride) {
+    // xyT (batched pipeline, views whose rows are the long axis): a second, TRANSPOSED copy of the xy MIP -- [j][i], MIP `second` of
+    // pair q at xyT + (2 q + second) * tstride -- so that the lag transform along i reads contiguous lines (as a strided gather
+    // it took 0.46 instead of 0.24 ms per 56 pairs: every lane of a load another 128-byte line)
     // (knock: measurement aid, MI_NCC_MIPS_KNOCK -- 1: no xz maxima, 2: no yz maxima, 4: no xy store)
     // a work-group owns a 16-row x 64-column patch of the view; its four waves share the slices (wave w: k = w, w + 4, ...),
     // so a patch keeps four times as many loads in flight as one wave walking all slices
@@ -242,6 +246,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         for (int r = 0; r < MIP_ROWS; ++r)
             if (r < rows) xy[(size_t)(i0 + r) * dimj_v + j] = xyb[wave][r][lane];
     }
+    if (xyT) {  // column c of the patch = 16 nbv consecutive floats of line j of the transposed copy: the lanes run along i
+        float* t = xyT + (size_t)blockIdx.z * tstride;
+        const int i = ib0 + lane;
+        if (lane < nbv * MIP_ROWS && i < dimi_v)
+            for (int c = wave; c < 64; c += 4) {
+                const int jc_ = (int)blockIdx.x * 64 + c - jshift;
+                if (jc_ >= 0 && jc_ < dimj_v) t[(size_t)jc_ * dimi_v + i] = xyb[lane >> 4][lane & 15][c];
+            }
+    }
     if (xz_tmp) {  // the rows of all bands * dimk: contiguous floats
         float* dst = xz_tmp + (((size_t)blockIdx.z * gridDim.x + blockIdx.x) * dimi_v + ib0) * dimk;
         const int total = min(nbv * MIP_ROWS, dimi_v - ib0) * dimk;
@@ -320,7 +333,7 @@ template <int BYTES>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_mips_int(
     const unsigned char* __restrict__ A, const unsigned char* __restrict__ B, const unsigned char* const* __restrict__ tab, size_t pstride, int dimk,
     int dimi_v, int dimj_v, size_t slice, int pitch, int ai0, int aj0, float scale, float* __restrict__ xy1, float* __restrict__ xy2,
-    float* __restrict__ yz_tmp, float* __restrict__ xz_tmp) {
+    float* __restrict__ yz_tmp, float* __restrict__ xz_tmp, float* __restrict__ xyT, size_t tstride) {
     using G = IntTiles<BYTES>;
     constexpr int P = G::P, C = G::C, NB = G::NB;
     extern __shared__ float xzp[];                     // [band][MIP_ROWS][dimk] row maxima, already divided
@@ -437,6 +450,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
             }
         }
     }
+    if (xyT) {  // the transposed copy (see k_mips): lanes along i, a wave per column
+        float* t = xyT + (size_t)blockIdx.z * tstride;
+        const int i = ib0 + lane, jv_first = (a0 & ~(G::W - 1)) + (int)blockIdx.x * G::W - a0;  // view column of the work-group's word 0, sample 0
+        if (lane < nbv * MIP_ROWS && i < dimi_v)
+            for (int c = wave; c < G::W; c += 4) {
+                const int jv = jv_first + c;
+                if (jv >= 0 && jv < dimj_v) t[(size_t)jv * dimi_v + i] = (float)xyb[lane >> 4][lane & 15][c] / scale;
+            }
+    }
     {   // the rows of all bands * dimk: contiguous floats
         float* dst = xz_tmp + (((size_t)blockIdx.z * gridDim.x + blockIdx.x) * dimi_v + ib0) * dimk;
         const int total = min(nbv * MIP_ROWS, dimi_v - ib0) * dimk;
@@ -506,7 +528,7 @@ inline int mips_fmt_width(int bytes) { return bytes == 4 ? 64 : (bytes == 2 ? In
 int launch_mips(hipStream_t s, const float* A, const float* B, const float* const* tab, int np, size_t pstride, int dimk, int dimi_v, int dimj_v,
                 size_t slice, int pitch, int ai0, int aj0, float* xy1, float* xz1, float* yz1, float* xy2, float* xz2, float* yz2, float* tmp,
                 hipEvent_t xy_done = nullptr,  // recorded when the xy MIPs are final (k_mips), before the reductions of the other two
-                TileFmt fmt = TileFmt()) {
+                TileFmt fmt = TileFmt(), float* xyT = nullptr, size_t tstride = 0) {
     const int nb = mips_fmt_bands(fmt.bytes, dimk), wcol = mips_fmt_width(fmt.bytes);
     const int bands = (dimi_v + MIP_ROWS * nb - 1) / (MIP_ROWS * nb);
     const int cblocks = (dimj_v + (aj0 & (wcol - 1)) + wcol - 1) / wcol;  // (band groups, column blocks aligned to the tile rows)
@@ -520,10 +542,10 @@ int launch_mips(hipStream_t s, const float* A, const float* B, const float* cons
         const unsigned char* const* t8 = reinterpret_cast<const unsigned char* const*>(tab);
         if (fmt.bytes == 2)
             hipLaunchKernelGGL(k_mips_int<2>, dim3(cblocks, bands, 2 * np), dim3(256), lds, s, a8, b8, t8, pstride, dimk, dimi_v, dimj_v, slice, pitch,
-                               ai0, aj0, fmt.scale, xy1, xy2, yz_tmp, xz_tmp);
+                               ai0, aj0, fmt.scale, xy1, xy2, yz_tmp, xz_tmp, xyT, tstride);
         else
             hipLaunchKernelGGL(k_mips_int<1>, dim3(cblocks, bands, 2 * np), dim3(256), lds, s, a8, b8, t8, pstride, dimk, dimi_v, dimj_v, slice, pitch,
-                               ai0, aj0, fmt.scale, xy1, xy2, yz_tmp, xz_tmp);
+                               ai0, aj0, fmt.scale, xy1, xy2, yz_tmp, xz_tmp, xyT, tstride);
         MI_TRY(launch_check("k_mips_int"));
         if (xy_done) MI_HIP(hipEventRecord(xy_done, s));
         hipLaunchKernelGGL(k_mips_yz, dim3((dimk * dimj_v + 255) / 256, 2 * np), dim3(256), 0, s, yz_tmp, pstride, bands, dimk, dimj_v, yz1, yz2);
@@ -543,7 +565,7 @@ int launch_mips(hipStream_t s, const float* A, const float* B, const float* cons
         return e ? std::atoi(e) : 0;
     }();
     hipLaunchKernelGGL(HIP_KERNEL_NAME(via_lds && dimk <= 4 * MIP_KPW ? k_mips<true> : k_mips<false>), grid, dim3(256), via_lds ? lds : 0, s, A, B, tab, pstride, dimk, dimi_v, dimj_v, slice, pitch, ai0, aj0, xy1, xz1, yz1,
-                       xy2, xz2, yz2, yz_tmp, via_lds ? xz_tmp : (float*)nullptr, knock);
+                       xy2, xz2, yz2, yz_tmp, via_lds ? xz_tmp : (float*)nullptr, knock, xyT, tstride);
     MI_TRY(launch_check("k_mips"));
     if (xy_done) MI_HIP(hipEventRecord(xy_done, s));
     hipLaunchKernelGGL(k_mips_yz, dim3((dimk * dimj_v + 255) / 256, 2 * np), dim3(256), 0, s, yz_tmp, pstride, bands, dimk, dimj_v, yz1, yz2);

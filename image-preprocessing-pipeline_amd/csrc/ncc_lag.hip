@@ -957,14 +957,77 @@ int fft_tables(int dev, const Plan& pl, hipStream_t s, FftTables* out) {
     if (it != g_tw.end()) { *out = it->second; return MI_OK; }
     const size_t N = (size_t)pl.N, NK = N / 2 + 1;
     const std::vector<double> hs = fft64::make_twiddles(pl);
-    std::vector<std::pair<int, int>> order(NK);  // (logical position, frequency)
-    for (size_t k = 0; k < NK; ++k) order[k] = {fft64::pos_of_freq(pl, (int)k), (int)k};
-    std::sort(order.begin(), order.end());
+    // Which frequency sits in which slot is free (the correlation kernels do not care, the inverse transform looks slots up), so the
+    // order is chosen for the untangling pass of k_lag_fwd: lane l of a wave reads Z[k] and Z[N - k] of slot 64 w + l with 16-byte
+    // LDS reads, which are served in four groups of 16 lanes over 16 bank quads -- every group gets 16 frequencies whose Z[k] fall
+    // into 16 different quads AND whose Z[N - k] do.  Frequencies are bucketed by the two quads; a group is a perfect matching
+    // between the quads of the first read and those of the second (Kuhn's augmenting paths on a 16 x 16 graph), fullest buckets
+    // first; what cannot be matched at the end fills the last slots.  (In position order the first read was 2-way, the second up
+    // to 4-way conflicted: SQ_LDS_BANK_CONFLICT 14 % of the LDS cycles of the transform.)
+    std::vector<int> p1(NK), p2(NK);
+    std::vector<std::vector<int>> bucket(256);
+    for (size_t k = 0; k < NK; ++k) {
+        p1[k] = fft64::phys(pl, fft64::pos_of_freq(pl, (int)k));
+        p2[k] = fft64::phys(pl, fft64::pos_of_freq(pl, (int)((N - k) % N)));
+        bucket[(size_t)(p1[k] & 15) * 16 + (size_t)(p2[k] & 15)].push_back((int)k);
+    }
+    static const int lanes_of_group[4][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
+                                               {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31},
+                                               {32, 33, 34, 35, 44, 45, 46, 47, 52, 53, 54, 55, 56, 57, 58, 59},
+                                               {36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63}};
+    std::vector<int> slot_freq(NK, -1);
+    size_t placed = 0;
+    for (size_t w = 0; w * 64 < NK && placed < NK; ++w)
+        for (int g = 0; g < 4 && placed < NK; ++g) {
+            int match_of_b2[16];
+            for (int& m : match_of_b2) m = -1;
+            // Kuhn: first-read quads in turn, their edges tried in the order of bucket size
+            for (int a = 0; a < 16; ++a) {
+                bool seen[16] = {false};
+                struct Rec {
+                    static bool go(int a_, const std::vector<std::vector<int>>& bk, int* mb, bool* sn) {
+                        int ord[16];
+                        for (int i = 0; i < 16; ++i) ord[i] = i;
+                        std::sort(ord, ord + 16, [&](int x, int y) { return bk[(size_t)a_ * 16 + x].size() > bk[(size_t)a_ * 16 + y].size(); });
+                        for (int oi = 0; oi < 16; ++oi) {
+                            const int b = ord[oi];
+                            if (bk[(size_t)a_ * 16 + b].empty() || sn[b]) continue;
+                            sn[b] = true;
+                            if (mb[b] < 0 || go(mb[b], bk, mb, sn)) { mb[b] = a_; return true; }
+                        }
+                        return false;
+                    }
+                };
+                (void)Rec::go(a, bucket, match_of_b2, seen);
+            }
+            int li = 0;
+            bool used_lane[16] = {false};
+            for (int b = 0; b < 16; ++b) {
+                if (match_of_b2[b] < 0) continue;
+                std::vector<int>& bk = bucket[(size_t)match_of_b2[b] * 16 + b];
+                const size_t sl = w * 64 + (size_t)lanes_of_group[g][li];
+                if (sl >= NK) continue;  // (the last, partial wave)
+                slot_freq[sl] = bk.back();
+                bk.pop_back();
+                used_lane[li++] = true;
+                ++placed;
+            }
+            (void)used_lane;
+            // lanes the matching left empty are filled at the end
+        }
+    {
+        std::vector<int> rest;
+        for (auto& bk : bucket) rest.insert(rest.end(), bk.begin(), bk.end());
+        size_t ri = 0;
+        for (size_t sl = 0; sl < NK; ++sl)
+            if (slot_freq[sl] < 0) slot_freq[sl] = rest[ri++];
+    }
     std::vector<int> tabs(3 * NK);
     for (size_t sl = 0; sl < NK; ++sl) {
-        tabs[sl] = fft64::phys(pl, order[sl].first);
-        tabs[NK + sl] = fft64::phys(pl, fft64::pos_of_freq(pl, (int)((N - (size_t)order[sl].second) % N)));
-        tabs[2 * NK + (size_t)order[sl].second] = (int)sl;
+        const size_t k = (size_t)slot_freq[sl];
+        tabs[sl] = p1[k];
+        tabs[NK + sl] = p2[k];
+        tabs[2 * NK + k] = (int)sl;
     }
     void *d = nullptr, *di = nullptr, *dp = nullptr;
     MI_HIP(hipMalloc(&d, sizeof(double) * hs.size()));
@@ -984,7 +1047,7 @@ int fft_tables(int dev, const Plan& pl, hipStream_t s, FftTables* out) {
 // device + pinned buffers of the batched pipeline, kept between calls (one set per concurrent caller and device)
 struct LagWorkspace {
     int dev = -1;
-    DevBuf fbuf, sat, mip_tmp, SP[3], CH[3], cross[3], outw, outi, tab;  // (lag-transform scratch per plane: the planes' chains run side by side)
+    DevBuf fbuf, sat, mip_tmp, xyT, SP[3], CH[3], cross[3], outw, outi, tab;  // (lag-transform scratch per plane: the planes' chains run side by side)
     PinnedBuf pin_tab, pin_w, pin_i;
     // Three streams PER DEVICE, shared by every group in flight: `sm` the MIP pass (k_mips: one HBM-bound streaming read of both
     // overlap views), `sa` the lag transform of the xy plane and the refinement of all planes, `sb` the tables of all planes and
@@ -1212,7 +1275,7 @@ struct LagJob {
     // chains deferred (ncc_lag_enqueue_chains): what they need
     bool chains_pending = false;
     int dev = 0, chunk = 0, maxIter = 0;
-    size_t pstride = 0, sstride = 0, sat_off[3] = {0, 0, 0};
+    size_t pstride = 0, sstride = 0, sat_off[3] = {0, 0, 0}, tstride = 0;
     ~LagJob() {
         if (ws) {
             // (whatever the call that owned this job enqueued must not outlive the buffers' next user)
@@ -1291,6 +1354,10 @@ int ncc_lag_enqueue(int dev, hipStream_t s, int n, const float* const* a_ptrs, c
     MI_TRY(grow(ws.fbuf, 4 * pstride * chunk));
     MI_TRY(grow(ws.sat, 8 * sstride * chunk));
     MI_TRY(grow(ws.mip_tmp, 4 * tmp_floats * chunk));
+    // xy MIPs whose long axis is the row index (west-east views) are also kept transposed, for the lag transform
+    const size_t tstride = lp[0].ls == 1 ? 0 : ((size_t)pl.g[0].dimu * pl.g[0].dimv + 3) / 4 * 4;
+    job->tstride = tstride;
+    if (tstride) MI_TRY(grow(ws.xyT, 4 * 2 * tstride * chunk));
     MI_TRY(grow(ws.outw, 4 * (size_t)3 * wcap * chunk));
     MI_TRY(grow(ws.outi, sizeof(int) * 3 * 4 * chunk));
     MI_TRY(grow(ws.tab, sizeof(void*) * 2 * chunk));
@@ -1332,7 +1399,8 @@ int ncc_lag_enqueue(int dev, hipStream_t s, int n, const float* const* a_ptrs, c
             MI_HIP(hipMemcpyAsync(dtab, htab + 2 * (size_t)(c0 + p0), sizeof(void*) * 2 * np, hipMemcpyHostToDevice, sm));
             MI_TRY(launch_mips(sm, nullptr, nullptr, dtab, np, pstride, pl.dimk, pl.dimi_v, pl.dimj_v, (size_t)dimi * dimj, dimj, pl.ai0, pl.aj0,
                                base + pl.g[0].mip1, base + pl.g[1].mip1, base + pl.g[2].mip1, base + pl.g[0].mip2, base + pl.g[1].mip2,
-                               base + pl.g[2].mip2, ws.mip_tmp.as<float>() + (size_t)p0 * tmp_floats, ws.ev_mip_xy[pi], fmt));
+                               base + pl.g[2].mip2, ws.mip_tmp.as<float>() + (size_t)p0 * tmp_floats, ws.ev_mip_xy[pi], fmt,
+                               tstride ? ws.xyT.as<float>() + 2 * tstride * (size_t)p0 : nullptr, tstride));
             MI_HIP(hipEventRecord(ws.ev_mip[pi], sm));
             if (defer) continue;
             MI_TRY(enqueue_chains(*job, c0, p0, np, pi, ws.ev_mip[pi], ws.ev_mip_xy[pi]));
@@ -1367,7 +1435,15 @@ static int enqueue_chains(LagJob& job, int c0, int p0, int np, int pi, hipEvent_
     for (int m = 1; m < 3; ++m) MI_TRY(lag_cross(job.dev, sb, lp[m], base + pl.g[m].mip1, base + pl.g[m].mip2, pstride, np, ws, m));
     // `sa`: the xy plane's lag transform
     if (sa != sb) MI_HIP(hipStreamWaitEvent(sa, gate_xy, 0));
-    MI_TRY(lag_cross(job.dev, sa, lp[0], base + pl.g[0].mip1, base + pl.g[0].mip2, pstride, np, ws, 0, mip_gate() ? ws.ev_head : nullptr));
+    if (job.tstride) {  // the transposed copies: line j of MIP 1 / 2 of pair q at xyT + (2 q) / (2 q + 1) * tstride + j * dimu
+        LagPlane lt = lp[0];
+        lt.ls = 1;
+        lt.ss = lp[0].n_long;
+        const float* t1 = ws.xyT.as<float>() + 2 * job.tstride * (size_t)p0;
+        MI_TRY(lag_cross(job.dev, sa, lt, t1, t1 + job.tstride, 2 * job.tstride, np, ws, 0, mip_gate() ? ws.ev_head : nullptr));
+    } else {
+        MI_TRY(lag_cross(job.dev, sa, lp[0], base + pl.g[0].mip1, base + pl.g[0].mip2, pstride, np, ws, 0, mip_gate() ? ws.ev_head : nullptr));
+    }
     if (sa != sb) {
         MI_HIP(hipEventRecord(ws.ev_side, sb));
         MI_HIP(hipStreamWaitEvent(sa, ws.ev_side, 0));
@@ -1556,16 +1632,17 @@ int ncc_time_mips(int dev, hipStream_t s, int n, const float* const* a_ptrs, con
             if (fmt.bytes == 2)
                 hipLaunchKernelGGL(k_mips_int<2>, grid, dim3(256), lds, s, (const unsigned char*)nullptr, (const unsigned char*)nullptr, t8, pstride, dimk,
                                    dimi_v, dimj_v, (size_t)dimi * dimj, dimj, side == MI_NORTH_SOUTH ? ni : 0, aj0, fmt.scale, o, o + xy + xz + yz,
-                                   tmp.as<float>(), xz_tmp);
+                                   tmp.as<float>(), xz_tmp, (float*)nullptr, (size_t)0);
             else
                 hipLaunchKernelGGL(k_mips_int<1>, grid, dim3(256), lds, s, (const unsigned char*)nullptr, (const unsigned char*)nullptr, t8, pstride, dimk,
                                    dimi_v, dimj_v, (size_t)dimi * dimj, dimj, side == MI_NORTH_SOUTH ? ni : 0, aj0, fmt.scale, o, o + xy + xz + yz,
-                                   tmp.as<float>(), xz_tmp);
+                                   tmp.as<float>(), xz_tmp, (float*)nullptr, (size_t)0);
             continue;
         }
         hipLaunchKernelGGL(HIP_KERNEL_NAME(dimk <= 4 * MIP_KPW ? k_mips<true> : k_mips<false>), dim3(cblocks, bands, 2 * n), dim3(256), lds, s, (const float*)nullptr, (const float*)nullptr, tab.as<const float*>(),
                            pstride, dimk, dimi_v, dimj_v, (size_t)dimi * dimj, dimj, side == MI_NORTH_SOUTH ? ni : 0, side == MI_WEST_EAST ? nj : 0, o,
-                           o + xy, o + xy + xz, o + xy + xz + yz, o + 2 * xy + xz + yz, o + 2 * xy + 2 * xz + yz, tmp.as<float>(), xz_tmp, knock);
+                           o + xy, o + xy + xz, o + xy + xz + yz, o + 2 * xy + xz + yz, o + 2 * xy + 2 * xz + yz, tmp.as<float>(), xz_tmp, knock, (float*)nullptr,
+                           (size_t)0);
     }
     MI_HIP(hipEventRecord(e1, s));
     MI_HIP(hipEventSynchronize(e1));
