@@ -59,13 +59,13 @@ def make_volume(shape, device, seed=1234):
 
 def pmc_traffic(pass_name, workload):
     """(HBM bytes per launch of the dominant kernel, the file they come from): the committed PMC passes of this same command
-    (profiles/r03_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in two separate runs, FETCH_SIZE doubled as
+    (profiles/r04_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in two separate runs, FETCH_SIZE doubled as
     MI355X_MICROARCH.md prescribes).  Counters cannot be collected from inside the timed process, so this is a CONSTANT of that
     profile, quoted beside the live launch time -- `roofline.traffic_source` says so in the JSON line.  (None, None) when the
     profile does not hold the kernel."""
     if workload != "c3":
         return None, None
-    name = "r03_pmc_traffic.json"
+    name = "r04_pmc_traffic.json"
     try:
         with open(os.path.join(ROOT, "profiles", name)) as f:
             kern = json.load(f)["kernels"]

@@ -94,7 +94,7 @@ def mips_roofline(dev, tiles, pairs):
     # HBM bytes per launch from the committed PMC passes (profiles/collect.sh: FETCH_SIZE x 2 + WRITE_SIZE, 56 pairs per launch);
     # a constant of that profile, not a measurement of this run -- only quoted for the launch geometry it was taken on
     traffic, source = None, None
-    for name in ("r03_ncc_pmc_traffic.json", "r02_ncc_pmc_traffic.json"):
+    for name in ("r04_ncc_pmc_traffic.json", "r03_ncc_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 ks = json.load(f)["kernels"]
