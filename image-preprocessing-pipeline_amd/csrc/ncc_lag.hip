@@ -1349,6 +1349,8 @@ int ncc_lag_enqueue(int dev, hipStream_t s, int n, const float* const* a_ptrs, c
     size_t budget = std::max((size_t)1 << 30, ((size_t)6 << 30) / (size_t)std::max(1, groups_in_flight));
     if (const char* e = std::getenv("MI_NCC_CHUNK_MB")) budget = (size_t)std::max(1, std::atoi(e)) << 20;
     const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, budget / per_pair));
+    // (pieces of a chunk -- the MIP pass of piece i + 1 beside the chain of piece i -- were measured again on the round-4 chain: 6.6 / 6.9 /
+    // 7.1 / 7.2 ms per 112 pairs for 1 / 2 / 3 / 4 pieces, uint16 tiles 4.6 / 5.6 / 5.9 / 6.0: more launches, more contention)
     const int piece = chunk;
 
     MI_TRY(grow(ws.fbuf, 4 * pstride * chunk));
@@ -1375,7 +1377,7 @@ int ncc_lag_enqueue(int dev, hipStream_t s, int n, const float* const* a_ptrs, c
     job->margin = ncc_margin();
     job->dev = dev; job->chunk = chunk; job->maxIter = P.maxIter; job->pstride = pstride; job->sstride = sstride;
     for (int m = 0; m < 3; ++m) job->sat_off[m] = sat_off[m];
-    const bool defer = defer_chains && chunk >= n;  // (one chunk: nothing of the chains is needed earlier)
+    const bool defer = defer_chains && chunk >= n && piece >= chunk;  // (one chunk, one piece: nothing of the chains is needed earlier)
     float* base0 = ws.fbuf.as<float>();
     hipStream_t sm = ws.sm;
     MI_HIP(hipEventRecord(ws.ev_start, s));
