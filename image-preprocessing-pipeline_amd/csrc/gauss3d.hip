@@ -347,82 +347,80 @@ __global__ __launch_bounds__((GF_TX / 4) * GF_TY) void k_gauss3d_fused(const flo
     }
 }
 
-// The same single pass with nothing shared between waves (round 4): a WAVE owns a 64 x 8 (x, y) tile and marches along z.  Its
-// clamped input patch ((8 + 2 ry) rows, requested a plane ahead with 16-byte loads) goes through its own slice of LDS, is filtered
-// along x there (a lane takes 4 outputs of a row at a time), then along y by the lane that owns four neighbouring x of two rows
-// (r and r + 4), and the z window -- the last KZ xy-filtered values of those 8 voxels -- never leaves the lane's registers.
-// No work-group barrier (k_gauss3d_fused has two per plane, and five 4-wave work-groups per CU standing at them were its bound),
-// no LDS ring (a float4 written and KZ read per plane and lane), 6.6 KB of LDS per wave: 24 waves per CU.
+// The single pass, round 4 (k_gauss3d_wave).  A work-group owns a 64 x 32 (x, y) tile and marches along z; its four waves SHARE the
+// staged input patch ((32 + 2 ry) rows: every input row is fetched 1.125 x 1.125 times -- with a patch per wave of 8 rows it was
+// 1.5 x 1.125, PMC: 17.2 GB fetched for an 8.6-GB volume, and the pass ran at the HBM rate of THAT traffic) and nothing else: a wave
+// filters the 8 + 2 ry rows it needs along x into its own slice of LDS, then along y in the lane that owns four neighbouring x of
+// rows r and r + 4, and the z window -- the last KZ xy-filtered values of those 8 voxels -- never leaves the lane's registers (no
+// LDS ring: k_gauss3d_fused writes a float4 and reads KZ per plane and lane).  ONE work-group barrier per plane, a whole plane away
+// from where its data is needed: the patch is double-buffered, plane p + 2 is requested into registers while plane p is filtered,
+// written to the other buffer one step later, used one step after that.
 // Filters of the RL loop's regularisation step: kx, ky <= 7, kz = KZ in {3, 5, 7}; everything else takes the kernels above.
-constexpr int GW_ROWS = 8, GW_MAXR = 3, GW_SEG = 64 + 8, GW_RIN = GW_ROWS + 2 * GW_MAXR, GW_NPRE = 4;
-constexpr int GW_WAVE_FLOATS = GW_RIN * GW_SEG + GW_RIN * 64;
+constexpr int GW_ROWS = 8, GW_MAXR = 3, GW_SEG = 64 + 8, GW_WGROWS = 32, GW_RIN = GW_WGROWS + 2 * GW_MAXR, GW_NPRE = 3;
+constexpr int GW_XF = (GW_ROWS + 2 * GW_MAXR) * 64;  // a wave's x-filtered rows
 template <int KZ>
 __global__ __launch_bounds__(256) void k_gauss3d_wave(const float* __restrict__ src, float* __restrict__ dst, int nx, int ny, int nz, int zchunk,
                                                        Taps tx, Taps ty, Taps tz) {
-    __shared__ __attribute__((aligned(16))) float lds_all[4 * GW_WAVE_FLOATS];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    float* in = lds_all + wave * GW_WAVE_FLOATS;   // [rows_in][GW_SEG]: the staged patch, one float4 of halo on either side
-    float* xf = in + GW_RIN * GW_SEG;              // [rows_in][64]: after the x filter
-    const int rx = tx.n / 2, ry = ty.n / 2, rows_in = GW_ROWS + 2 * ry;
+    __shared__ __attribute__((aligned(16))) float in2[2][GW_RIN * GW_SEG];   // the staged patch of two planes
+    __shared__ __attribute__((aligned(16))) float xf_all[4 * GW_XF];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    float* xf = xf_all + wave * GW_XF;             // [rows of the wave][64]: after the x filter
+    const int rx = tx.n / 2, ry = ty.n / 2, rows_in = GW_WGROWS + 2 * ry, rows_w = GW_ROWS + 2 * ry;
     constexpr int rz = KZ / 2, segq = GW_SEG / 4;
-    // tiles as in k_gauss3d_fused: a work-group's four waves take the four 8-row strips of a 64 x 32 tile, contiguous tile ranges per XCD
-    const int gx = (nx + 63) / 64, gy = (ny + 31) / 32, gz = (nz + zchunk - 1) / zchunk;
+    // tiles as in k_gauss3d_fused: contiguous tile ranges per XCD
+    const int gx = (nx + 63) / 64, gy = (ny + GW_WGROWS - 1) / GW_WGROWS, gz = (nz + zchunk - 1) / zchunk;
     const int total = gx * gy * gz, per = (total + 7) / 8;
     const int t = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
     if (t >= total) return;
     const int bz = t / (gx * gy), by = (t - bz * gx * gy) / gx, bx = t - bz * gx * gy - by * gx;
-    const int x0 = bx * 64, y0 = by * 32 + wave * GW_ROWS;
-    if (y0 >= ny) return;
+    const int x0 = bx * 64, y0 = by * GW_WGROWS;
     const int za = bz * zchunk, zb = min(za + zchunk, nz);
     const int xoff = 4 - rx;                       // first tap of output x sits at staged column x + xoff
-    const int xq = lane & 15, rs = lane >> 4;      // y / z filters: columns 4 xq .. + 3 of rows rs and rs + 4
-    // the patches of the next TWO planes travel while a plane is filtered (one plane ahead left the march latency-bound: a plane is
-    // filtered in less than a memory round trip); the lane's pieces of a patch do not depend on the plane: offsets once
-    float4 preA[GW_NPRE], preB[GW_NPRE];
-    int poff[GW_NPRE];
-    bool inside = true;
+    const int xq = lane & 15, rs = lane >> 4;      // y / z filters: columns 4 xq .. + 3 of rows rs and rs + 4 of the wave's 8
+    // a staged float4 lies wholly inside a row or wholly outside it (x0 and nx are multiples of 4): outside, it is the row's first
+    // / last sample four times (replicate rule) -- the nearest inside float4 is loaded and one of its ends splatted
+    float4 pre[GW_NPRE];
+    int poff[GW_NPRE], pedge[GW_NPRE];
 #pragma unroll
     for (int u = 0; u < GW_NPRE; ++u) {
-        const int it = min(lane + 64 * u, rows_in * segq - 1);   // (lanes past the patch repeat its last piece: no predicated load)
+        const int it = min(tid + 256 * u, rows_in * segq - 1);   // (threads past the patch repeat its last piece: no predicated load)
         const int r = it / segq, q = it - r * segq, x = x0 - 4 + 4 * q;
-        poff[u] = min(max(y0 - ry + r, 0), ny - 1) * nx + x;
-        inside = inside && x >= 0 && x + 3 < nx;
+        poff[u] = min(max(y0 - ry + r, 0), ny - 1) * nx + min(max(x, 0), nx - 4);
+        pedge[u] = x < 0 ? -1 : (x >= nx ? 1 : 0);
     }
-    const bool all_inside = __all(inside) && (size_t)ny * nx < ((size_t)1 << 31);   // (wave-uniform: one code path per wave)
-    auto fetch = [&](int p, float4 (&pre)[GW_NPRE]) {
+    auto fetch = [&](int p) {
         const float* plane = src + (size_t)min(max(p, 0), nz - 1) * ny * nx;
-        if (all_inside) {
-#pragma unroll
-            for (int u = 0; u < GW_NPRE; ++u) pre[u] = *reinterpret_cast<const float4*>(plane + poff[u]);
-            return;
-        }
 #pragma unroll
         for (int u = 0; u < GW_NPRE; ++u) {
-            const int it = min(lane + 64 * u, rows_in * segq - 1);
-            const int r = it / segq, q = it - r * segq;
-            const float* row = plane + (size_t)min(max(y0 - ry + r, 0), ny - 1) * nx;
-            const int x = x0 - 4 + 4 * q;
-            pre[u] = make_float4(row[min(max(x, 0), nx - 1)], row[min(max(x + 1, 0), nx - 1)], row[min(max(x + 2, 0), nx - 1)],
-                                 row[min(max(x + 3, 0), nx - 1)]);
+            float4 v = *reinterpret_cast<const float4*>(plane + poff[u]);
+            if (pedge[u] < 0) v = make_float4(v.x, v.x, v.x, v.x);
+            if (pedge[u] > 0) v = make_float4(v.w, v.w, v.w, v.w);
+            pre[u] = v;
+        }
+    };
+    auto stage = [&](float* buf) {
+#pragma unroll
+        for (int u = 0; u < GW_NPRE; ++u) {
+            const int it = tid + 256 * u;
+            if (it < rows_in * segq) {
+                const int r = it / segq, q = it - r * segq;
+                *reinterpret_cast<float4*>(buf + r * GW_SEG + 4 * q) = pre[u];
+            }
         }
     };
     float4 win[KZ][2];  // the z window of the lane's 8 voxels, oldest first
 #pragma unroll
     for (int i = 0; i < KZ; ++i) win[i][0] = win[i][1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    fetch(za - rz, preA);
-    fetch(za - rz + 1, preB);
-    auto plane_step = [&](int p, float4 (&pre)[GW_NPRE]) {
-#pragma unroll
-        for (int u = 0; u < GW_NPRE; ++u) {
-            const int it = lane + 64 * u;
-            if (it < rows_in * segq) {
-                const int r = it / segq, q = it - r * segq;
-                *reinterpret_cast<float4*>(in + r * GW_SEG + 4 * q) = pre[u];
-            }
-        }
-        wave_fence();
-        fetch(p + 2, pre);   // (clamped planes past the chunk: harmless)
-        for (int it = lane; it < rows_in * 16; it += 64) {   // x filter: 4 outputs from kx + 3 staged samples
+    const int p0 = za - rz, p1 = zb + rz;
+    fetch(p0);
+    stage(in2[0]);
+    fetch(p0 + 1);
+    __syncthreads();
+    for (int p = p0; p < p1; ++p) {
+        const float* in = in2[(p - p0) & 1] + wave * GW_ROWS * GW_SEG;   // the wave's rows of plane p
+        stage(in2[(p - p0 + 1) & 1]);                                      // plane p + 1 (requested one step ago)
+        fetch(p + 2);                                                      // (clamped planes past the chunk: harmless)
+        for (int it = lane; it < rows_w * 16; it += 64) {   // x filter: 4 outputs from kx + 3 staged samples
             const int r = it >> 4, q = it & 15;
             const float* a = in + r * GW_SEG + 4 * q + xoff;
             float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f, o3 = 0.0f;
@@ -450,7 +448,6 @@ __global__ __launch_bounds__(256) void k_gauss3d_wave(const float* __restrict__ 
             }
             win[KZ - 1][h] = acc;
         }
-        wave_fence();   // (the next plane's staging overwrites `in` and `xf`)
         const int zo = p - rz;  // output plane whose window [zo - rz, zo + rz] is now complete
         if (zo >= za) {
 #pragma unroll
@@ -462,14 +459,11 @@ __global__ __launch_bounds__(256) void k_gauss3d_wave(const float* __restrict__ 
                     const float w = tz.w[k];
                     acc.x = fmaf(v.x, w, acc.x); acc.y = fmaf(v.y, w, acc.y); acc.z = fmaf(v.z, w, acc.z); acc.w = fmaf(v.w, w, acc.w);
                 }
-                const int y = y0 + rs + 4 * h, x = x0 + 4 * xq;
+                const int y = y0 + wave * GW_ROWS + rs + 4 * h, x = x0 + 4 * xq;
                 if (y < ny && x < nx) *reinterpret_cast<float4*>(dst + ((size_t)zo * ny + y) * nx + x) = acc;
             }
         }
-    };
-    for (int p = za - rz; p < zb + rz; p += 2) {
-        plane_step(p, preA);
-        if (p + 1 < zb + rz) plane_step(p + 1, preB);
+        __syncthreads();   // plane p + 1 is staged for everybody; nobody reads plane p's buffer any more (it is written next step)
     }
 }
 
@@ -532,7 +526,8 @@ int gauss3d_to(hipStream_t s, float* src, float* dst, int nx, int ny, int nz, co
     MI_TRY(resolve_taps(sigma, ksize, k, tx, ty, tz));
     *fused = gauss3d_fuses(nx, k);
     static const bool no_wave = MI_PROBE_ENV("MI_GAUSS_NO_WAVE") != nullptr;  // (probe builds: A/B against the work-group kernel)
-    if (*fused && !no_wave && k[0] <= 2 * GW_MAXR + 1 && k[1] <= 2 * GW_MAXR + 1 && (k[2] == 3 || k[2] == 5 || k[2] == 7)) {
+    if (*fused && !no_wave && k[0] <= 2 * GW_MAXR + 1 && k[1] <= 2 * GW_MAXR + 1 && (k[2] == 3 || k[2] == 5 || k[2] == 7) &&
+        (size_t)ny * nx < ((size_t)1 << 31)) {  // (patch offsets inside a plane are 32-bit)
         const int zchunk = 128;
         const int total = ((nx + 63) / 64) * ((ny + 31) / 32) * ((nz + zchunk - 1) / zchunk);
         const dim3 grid((total + 7) / 8 * 8), block(256);

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(TH) void k_lag_fwd(const float* __restrict__ m1, co
 // tile in global memory, point-wise product in digit-reversed order, backward pass on KT images, last stage straight to CH.
 // 3 x 5 M log2 M flops per slot instead of 8 n_short (2 Es + 1): config 5's xy plane 5 x fewer, and LDS-bound instead of fp64-bound.
 template <int R, int KT2>
-__device__ __forceinline__ void corr_first(cplx* arr, int AS, const cplx* __restrict__ src, int n_short, const Plan& pl,
+__device__ __forceinline__ void corr_first(cplx* arr, int AS, const cplx* __restrict__ src, int n_short, int nk, const Plan& pl,
                                            const cplx* __restrict__ tw, int first, int step) {
     const int nb = pl.N / R, q = pl.lr[0] == 0 ? (1 << pl.a) : (1 << pl.lq[0]);
     const cplx* stw = tw + pl.twoff[0];
@@ -139,7 +139,8 @@ __device__ __forceinline__ void corr_first(cplx* arr, int AS, const cplx* __rest
         for (int m = 0; m < R; ++m) {
             const int i = t + m * q;  // (clamped index + select: see k_lag_fwd; a tile is a few thousand elements: 32-bit offsets)
             const cplx g = src[min(i, n_short - 1) * KT2 + f];
-            v[m] = make_double2(i < n_short ? g.x : 0.0, i < n_short ? g.y : 0.0);
+            const bool on = i < n_short && (f % (KT2 / 2)) < nk;   // (slots past the spectrum's end in the last tile were never written)
+            v[m] = make_double2(on ? g.x : 0.0, on ? g.y : 0.0);
         }
         fft64::butterfly<R, false>(v, stw, q, t);
         cplx* x = arr + (size_t)f * AS;
@@ -191,14 +192,14 @@ __global__ __launch_bounds__(TH) void k_lag_corr(const cplx* __restrict__ SP, in
     for (int e = threadIdx.x; e < fft64::lds_twiddles(pl); e += TH) twl[e] = tw[pl.twoff[1] + e];
     const cplx* tws = twl - (pl.nst > 1 ? pl.twoff[1] : 0);
     switch (pl.radix[0]) {
-        case 16: corr_first<16, KT2>(arr, AS, src, n_short, pl, tw, threadIdx.x, TH); break;
-        case 12: corr_first<12, KT2>(arr, AS, src, n_short, pl, tw, threadIdx.x, TH); break;
-        case 9: corr_first<9, KT2>(arr, AS, src, n_short, pl, tw, threadIdx.x, TH); break;
-        case 8: corr_first<8, KT2>(arr, AS, src, n_short, pl, tw, threadIdx.x, TH); break;
-        case 6: corr_first<6, KT2>(arr, AS, src, n_short, pl, tw, threadIdx.x, TH); break;
-        case 4: corr_first<4, KT2>(arr, AS, src, n_short, pl, tw, threadIdx.x, TH); break;
-        case 3: corr_first<3, KT2>(arr, AS, src, n_short, pl, tw, threadIdx.x, TH); break;
-        default: corr_first<2, KT2>(arr, AS, src, n_short, pl, tw, threadIdx.x, TH); break;
+        case 16: corr_first<16, KT2>(arr, AS, src, n_short, nk, pl, tw, threadIdx.x, TH); break;
+        case 12: corr_first<12, KT2>(arr, AS, src, n_short, nk, pl, tw, threadIdx.x, TH); break;
+        case 9: corr_first<9, KT2>(arr, AS, src, n_short, nk, pl, tw, threadIdx.x, TH); break;
+        case 8: corr_first<8, KT2>(arr, AS, src, n_short, nk, pl, tw, threadIdx.x, TH); break;
+        case 6: corr_first<6, KT2>(arr, AS, src, n_short, nk, pl, tw, threadIdx.x, TH); break;
+        case 4: corr_first<4, KT2>(arr, AS, src, n_short, nk, pl, tw, threadIdx.x, TH); break;
+        case 3: corr_first<3, KT2>(arr, AS, src, n_short, nk, pl, tw, threadIdx.x, TH); break;
+        default: corr_first<2, KT2>(arr, AS, src, n_short, nk, pl, tw, threadIdx.x, TH); break;
     }
     __syncthreads();
     for (int st = 1; st < pl.nst; ++st) {

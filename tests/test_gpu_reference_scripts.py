@@ -169,7 +169,7 @@ def test_decon_fft_script_one_fused_step(dev, sz, lam):
     # PSF in its upper half puts psf(1,1,1) on the grid's origin for even grids: exactly fftn(psf, sz)
     big = np.zeros(tuple(2 * k for k in psf.shape), np.float32)
     big[psf.shape[0]:, psf.shape[1]:, psf.shape[2]:] = psf
-    otf = np.fft.fftn(psf.astype(np.float64), s=shape)
+    otf = np.fft.fftn(psf.astype(np.float64), s=shape, axes=(0, 1, 2))
     assert np.abs(R.otf_from_psf(big, shape) - otf).max() < 1e-12
     b64 = bl.astype(np.float64)
     buf = np.real(np.fft.ifftn(np.fft.fftn(b64) * otf)).astype(np.float32)
