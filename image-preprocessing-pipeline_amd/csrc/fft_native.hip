@@ -1459,7 +1459,11 @@ __global__ __launch_bounds__(NT, kWavesXZ) void k_z_pair_pipe(const float2* __re
                 tile[cB] = make_float2(E2.x + O2.y, O2.x - E2.y);
             }
         }
-        if (R3 != 9 && tn < ntiles) load_S(tn);  // (requesting them right after the fill, a whole tile ahead, gains nothing: 4.72 vs 4.68 ms)
+        // (requesting them right after the fill, a whole tile ahead, gains nothing with two work-groups per CU: 4.72 vs 4.68 ms; with
+        // the one 1024-thread work-group of 1024-point lines it LOSES -- 6.28 against 5.90 ms on 1024 x 576 x 4096, A / B in one
+        // process, the loads unconditional and behind the OTF loads so that every wait stays counted; a 512-thread variant with a
+        // line pair per wave measured 6.00: round 4, profiles/zpass_ab.py)
+        if (R3 != 9 && tn < ntiles) load_S(tn);
         if constexpr (WP) wave_lds_fence();
         else lds_barrier();
         lds_fft<LZ2, true, NT, R3, 0, TOPREG ? TOPS : LZ2>(tile, 2 * TL * R3, pitch, hp, true, twl);
