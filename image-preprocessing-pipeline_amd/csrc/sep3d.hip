@@ -160,9 +160,174 @@ __global__ __launch_bounds__(SF_THREADS) void k_sep3d(const float* __restrict__ 
     }
 }
 
+// The same pass with the z window in REGISTERS (kz <= KZB taps): instead of a ring of the last kz xy-filtered planes in LDS -- 64 KB
+// for 16 taps, 124 KB for 31: one work-group per CU, and kz 16-byte LDS reads per four outputs -- every thread keeps the kz partial
+// sums of the output planes its four voxels are still collecting (acc[j]: output plane zo + j, zo the oldest one open).  An xy-filtered
+// plane adds its term to all of them (tap kz - 1 - j), the oldest sum is complete and leaves through the epilogue, the others move
+// down one slot.  The terms of an output arrive in window order, each one fmaf onto the sum so far -- the arithmetic of the ring
+// version, bit for bit.  The register shifts cost VALU slots the pass has to spare; the LDS holds the patch and its x-filtered rows
+// only (17 KB for 15 x 15 taps), so several work-groups share a CU and their barriers interleave.
+template <int EPI, int NPRE, int KZB>
+__global__ __launch_bounds__(SF_THREADS) void k_sep3d_acc(const float* __restrict__ src, float* __restrict__ dst, ConvEpilogue epi, SepGeom g,
+                                                          SepTaps tx, SepTaps ty, SepTaps tzr) {
+    // tzr: the z taps REVERSED and zero-filled up to KZB (compile-time indices: they live in scalar registers)
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int nx = g.nx, ny = g.ny, nz = g.nz;
+    const int cql = (g.cx + 3) / 4, cqr = (tx.n - 1 - g.cx + 3) / 4;
+    const int segq = SF_TX / 4 + cql + cqr;
+    const int seg = 4 * segq, rows_in = SF_TY + ty.n - 1;
+    const int xoff = 4 * cql - g.cx;          // first tap of output x sits at staged column x + xoff
+    // The 1-D filters read LDS in 16-byte pieces, a whole piece of taps per trip, the next trip's operands requested before the
+    // current one's products: with one tap per trip, its weight fetched from the argument block, every trip waited for an LDS
+    // and a scalar-memory round trip (5 ms per iteration on a C2-sized volume with 9 x 9 x 15 taps, 1.3 TB/s).  The tap lists are
+    // zero-filled to whole pieces (a zero weight leaves a sum as it is); what a zero weight multiplies is finite: staged samples
+    // of a neighbouring row, or LDS that was cleared once.
+    const int kyp = (ty.n + 3) & ~3, rows_pad = SF_TY + kyp - 1;     // y taps in fours; the rows the last four may touch
+    const int nxc = (xoff + tx.n + 3 + 3) / 4;                        // 16-byte pieces of a row that four outputs draw on
+    float* in = lds;                          // [rows_in][seg]
+    float* xf = in + rows_in * seg;           // [rows_pad][64]  (rows >= rows_in stay zero)
+    float* wx = xf + rows_pad * SF_TX;        // [4 nxc + 4]: wx[m] = tap m - 3 - xoff (0 outside the window)
+    float* wy = wx + 4 * nxc + 4;             // [kyp]
+    const int tid = threadIdx.x, xq = tid & 15, rsub = tid >> 4;
+    const int gx = (nx + SF_TX - 1) / SF_TX, gy = (ny + SF_TY - 1) / SF_TY, gz = (nz + g.zchunk - 1) / g.zchunk;
+    const int total = gx * gy * gz, per = (total + 7) / 8;
+    const int t = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (t >= total) return;
+    for (int i = tid; i < rows_pad * SF_TX; i += SF_THREADS) xf[i] = 0.0f;
+    for (int m = tid; m < 4 * nxc + 4; m += SF_THREADS) {
+        const int k = m - 3 - xoff;
+        wx[m] = (k >= 0 && k < tx.n) ? tx.w[k] : 0.0f;
+    }
+    for (int k = tid; k < kyp; k += SF_THREADS) wy[k] = k < ty.n ? ty.w[k] : 0.0f;
+    const int bz = t / (gx * gy), by = (t - bz * gx * gy) / gx, bx = t - bz * gx * gy - by * gx;
+    const int x0 = bx * SF_TX, y0 = by * SF_TY;
+    const int za = bz * g.zchunk, zb = min(za + g.zchunk, nz);
+    const int xs0 = x0 - 4 * cql;
+    const int kz = tzr.n;
+    float4 pre[NPRE];
+    auto fetch = [&](int p) {
+        const int zi = bnd_index(p, nz, g.bz);
+        const float* plane = src + (size_t)max(zi, 0) * ny * nx;
+#pragma unroll
+        for (int u = 0; u < NPRE; ++u) {
+            const int it = tid + u * SF_THREADS;
+            if (it < rows_in * segq) {
+                const int r = it / segq, q = it - r * segq;
+                const int yi = bnd_index(y0 - g.cy + r, ny, g.by);
+                const int x = xs0 + 4 * q;
+                float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (zi >= 0 && yi >= 0) {
+                    const float* row = plane + (size_t)yi * nx;
+                    if (x >= 0 && x + 3 < nx) {
+                        v = *reinterpret_cast<const float4*>(row + x);
+                    } else {
+                        const int i0 = bnd_index(x, nx, g.bx), i1 = bnd_index(x + 1, nx, g.bx), i2 = bnd_index(x + 2, nx, g.bx),
+                                  i3 = bnd_index(x + 3, nx, g.bx);
+                        v = make_float4(i0 >= 0 ? row[i0] : 0.0f, i1 >= 0 ? row[i1] : 0.0f, i2 >= 0 ? row[i2] : 0.0f, i3 >= 0 ? row[i3] : 0.0f);
+                    }
+                }
+                pre[u] = v;
+            }
+        }
+    };
+    float4 acc[KZB];
+#pragma unroll
+    for (int j = 0; j < KZB; ++j) acc[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const int p_first = za - g.cz, p_last = zb - 1 - g.cz + kz - 1;
+    fetch(p_first);
+    for (int p = p_first; p <= p_last; ++p) {
+#pragma unroll
+        for (int u = 0; u < NPRE; ++u) {
+            const int it = tid + u * SF_THREADS;
+            if (it < rows_in * segq) {
+                const int r = it / segq, q = it - r * segq;
+                *reinterpret_cast<float4*>(in + r * seg + 4 * q) = pre[u];
+            }
+        }
+        __syncthreads();
+        if (p < p_last) fetch(p + 1);
+        // x filter: sample j = 4 c + e of the piece row is term j - xoff - i of output i; wx is laid out so that its weight is
+        // wx[4 c + e - i + 3].  The terms of an output arrive in window order.
+        for (int it = tid; it < rows_in * 16; it += SF_THREADS) {
+            const int r = it >> 4, q = it & 15;
+            const float4* a = reinterpret_cast<const float4*>(in + r * seg + 4 * q);
+            const float4* wq = reinterpret_cast<const float4*>(wx);
+            float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f, o3 = 0.0f;
+            float4 d = a[0], wa = wq[0], wb = wq[1];
+            for (int c = 0; c < nxc; ++c) {
+                const float4 dn = a[c + 1 < nxc ? c + 1 : c], wan = wb, wbn = wq[c + 2];   // (wx ends with a spare piece)
+                o0 = fmaf(d.x, wa.w, o0); o0 = fmaf(d.y, wb.x, o0); o0 = fmaf(d.z, wb.y, o0); o0 = fmaf(d.w, wb.z, o0);
+                o1 = fmaf(d.x, wa.z, o1); o1 = fmaf(d.y, wa.w, o1); o1 = fmaf(d.z, wb.x, o1); o1 = fmaf(d.w, wb.y, o1);
+                o2 = fmaf(d.x, wa.y, o2); o2 = fmaf(d.y, wa.z, o2); o2 = fmaf(d.z, wa.w, o2); o2 = fmaf(d.w, wb.x, o2);
+                o3 = fmaf(d.x, wa.x, o3); o3 = fmaf(d.y, wa.y, o3); o3 = fmaf(d.z, wa.z, o3); o3 = fmaf(d.w, wa.w, o3);
+                d = dn; wa = wan; wb = wbn;
+            }
+            *reinterpret_cast<float4*>(xf + r * SF_TX + 4 * q) = make_float4(o0, o1, o2, o3);
+        }
+        __syncthreads();
+        float4 yv = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        {   // y filter, four taps per trip
+            const float* col = xf + rsub * SF_TX + 4 * xq;
+            const float4* wq = reinterpret_cast<const float4*>(wy);
+            auto row4 = [&](int k) { return *reinterpret_cast<const float4*>(col + k * SF_TX); };
+            float4 v0 = row4(0), v1 = row4(1), v2 = row4(2), v3 = row4(3), w = wq[0];
+            for (int k = 0; k < kyp; k += 4) {
+                const int kn = k + 4 < kyp ? k + 4 : k;
+                const float4 n0 = row4(kn), n1 = row4(kn + 1), n2 = row4(kn + 2), n3 = row4(kn + 3), wn = wq[kn >> 2];
+                yv.x = fmaf(v0.x, w.x, yv.x); yv.y = fmaf(v0.y, w.x, yv.y); yv.z = fmaf(v0.z, w.x, yv.z); yv.w = fmaf(v0.w, w.x, yv.w);
+                yv.x = fmaf(v1.x, w.y, yv.x); yv.y = fmaf(v1.y, w.y, yv.y); yv.z = fmaf(v1.z, w.y, yv.z); yv.w = fmaf(v1.w, w.y, yv.w);
+                yv.x = fmaf(v2.x, w.z, yv.x); yv.y = fmaf(v2.y, w.z, yv.y); yv.z = fmaf(v2.z, w.z, yv.z); yv.w = fmaf(v2.w, w.z, yv.w);
+                yv.x = fmaf(v3.x, w.w, yv.x); yv.y = fmaf(v3.y, w.w, yv.y); yv.z = fmaf(v3.z, w.w, yv.z); yv.w = fmaf(v3.w, w.w, yv.w);
+                v0 = n0; v1 = n1; v2 = n2; v3 = n3; w = wn;
+            }
+        }
+        // plane p is term kz - 1 - j of the output plane behind acc[j] (tzr[j]; zero for j >= kz, where the sums stay zero)
+#pragma unroll
+        for (int j = 0; j < KZB; ++j) {
+            const float w = tzr.w[j];
+            acc[j].x = fmaf(yv.x, w, acc[j].x); acc[j].y = fmaf(yv.y, w, acc[j].y);
+            acc[j].z = fmaf(yv.z, w, acc[j].z); acc[j].w = fmaf(yv.w, w, acc[j].w);
+        }
+        const int zo = p + g.cz - (kz - 1);
+        if (zo >= za) {
+            const float4 a0 = acc[0];
+            const int y = y0 + rsub, x = x0 + 4 * xq;
+            if (y < ny && x < nx) {
+                const size_t idx = ((size_t)zo * ny + y) * nx + x;
+                float4 o = a0;
+                if (EPI != EPI_NONE) {
+                    const float4 a = *reinterpret_cast<const float4*>(epi.a + idx);
+                    if (EPI == EPI_RATIO) {
+                        o = make_float4(a.x / fmaxf(a0.x, kEpsSingle), a.y / fmaxf(a0.y, kEpsSingle), a.z / fmaxf(a0.z, kEpsSingle),
+                                        a.w / fmaxf(a0.w, kEpsSingle));
+                    } else if (EPI == EPI_UPDATE) {
+                        o = make_float4(fabsf(a.x * a0.x), fabsf(a.y * a0.y), fabsf(a.z * a0.z), fabsf(a.w * a0.w));
+                    } else {
+                        const float4 b = *reinterpret_cast<const float4*>(epi.b + idx);
+                        const float l = epi.lambda, m = 1.0f - epi.lambda;
+                        o = make_float4(fabsf(a.x * a0.x * m + b.x * l), fabsf(a.y * a0.y * m + b.y * l), fabsf(a.z * a0.z * m + b.z * l),
+                                        fabsf(a.w * a0.w * m + b.w * l));
+                    }
+                }
+                *reinterpret_cast<float4*>(dst + idx) = o;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j + 1 < KZB; ++j) acc[j] = acc[j + 1];
+        acc[KZB - 1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        // (`in` is rewritten behind the second barrier above, `xf` behind the next first barrier, which every thread reaches after
+        // its y filter)
+    }
+}
+
 size_t sep_lds_bytes(const int* k, const int* c) {
     const int cql = (c[0] + 3) / 4, cqr = (k[0] - 1 - c[0] + 3) / 4, seg = 4 * (SF_TX / 4 + cql + cqr), rows_in = SF_TY + k[1] - 1;
     return sizeof(float) * ((size_t)rows_in * seg + (size_t)rows_in * SF_TX + (size_t)k[2] * SF_TY * SF_TX);
+}
+size_t sep_lds_bytes_acc(const int* k, const int* c) {  // k_sep3d_acc: the patch and its x-filtered rows
+    const int cql = (c[0] + 3) / 4, cqr = (k[0] - 1 - c[0] + 3) / 4, seg = 4 * (SF_TX / 4 + cql + cqr), rows_in = SF_TY + k[1] - 1;
+    const int kyp = (k[1] + 3) & ~3, rows_pad = SF_TY + kyp - 1, nxc = (4 * cql - c[0] + k[0] + 3 + 3) / 4;
+    return sizeof(float) * ((size_t)rows_in * seg + (size_t)rows_pad * SF_TX + 4 * nxc + 4 + kyp);
 }
 int sep_patch_quads(const int* k, const int* c) {
     const int cql = (c[0] + 3) / 4, cqr = (k[0] - 1 - c[0] + 3) / 4;
@@ -176,7 +341,8 @@ int sep_patch_quads(const int* k, const int* c) {
 bool sep3d_fits(int nx, const int* k, const int* c) {
     for (int a = 0; a < 3; ++a)
         if (k[a] < 1 || k[a] > kSepMaxTaps || c[a] < 0 || c[a] >= k[a]) return false;
-    return (nx % 4) == 0 && sep_lds_bytes(k, c) <= kSepLdsMax && sep_patch_quads(k, c) <= 6 * SF_THREADS;
+    return (nx % 4) == 0 && (k[2] <= 32 ? sep_lds_bytes_acc(k, c) <= 64 * 1024 : sep_lds_bytes(k, c) <= kSepLdsMax) &&
+           sep_patch_quads(k, c) <= 6 * SF_THREADS;
 }
 
 int sep3d_launch(hipStream_t s, const float* in, float* out, int nx, int ny, int nz, const SepTaps taps[3], const int* offs, const int* bnd3,
@@ -197,9 +363,35 @@ int sep3d_launch(hipStream_t s, const float* in, float* out, int nx, int ny, int
     while (zchunk > 2 * k[2] && zchunk > 16 && (size_t)tiles_xy * ((nz + zchunk - 1) / zchunk) < 1024) zchunk /= 2;
     g.zchunk = std::min(zchunk, nz);
     const int total = tiles_xy * ((nz + g.zchunk - 1) / g.zchunk);
-    const size_t lds = sep_lds_bytes(k, offs);
     const bool wide = sep_patch_quads(k, offs) > 3 * SF_THREADS;
     const dim3 grid((unsigned)((total + 7) / 8 * 8));
+    if (k[2] <= 32 && !MI_PROBE_ENV("MI_SEP_RING")) {  // z window in registers (k_sep3d_acc); MI_SEP_RING=1 (probes build): the LDS-ring kernel
+        const size_t lds_a = sep_lds_bytes_acc(k, offs);
+        SepTaps tzr{};
+        tzr.n = k[2];
+        for (int j = 0; j < k[2]; ++j) tzr.w[j] = taps[2].w[k[2] - 1 - j];
+#define MI_SEPA3(E, NP, KB) hipLaunchKernelGGL((k_sep3d_acc<E, NP, KB>), grid, dim3(SF_THREADS), lds_a, s, in, out, epi, g, taps[0], taps[1], tzr)
+#define MI_SEPA2(E, NP)                                                                     \
+    do {                                                                                    \
+        if (k[2] <= 8) MI_SEPA3(E, NP, 8);                                                  \
+        else if (k[2] <= 16) MI_SEPA3(E, NP, 16);                                           \
+        else MI_SEPA3(E, NP, 32);                                                           \
+    } while (0)
+#define MI_SEPA(E)                                                                          \
+    case E:                                                                                 \
+        if (wide) MI_SEPA2(E, 6);                                                           \
+        else MI_SEPA2(E, 3);                                                                \
+        break;
+        switch (epi_kind) {
+            MI_SEPA(EPI_NONE) MI_SEPA(EPI_RATIO) MI_SEPA(EPI_UPDATE) MI_SEPA(EPI_UPDATE_REG)
+            default: break;
+        }
+#undef MI_SEPA
+#undef MI_SEPA2
+#undef MI_SEPA3
+        return launch_check("k_sep3d_acc");
+    }
+    const size_t lds = sep_lds_bytes(k, offs);
 #define MI_SEP(E)                                                                                                                  \
     case E:                                                                                                                        \
         if (wide) {                                                                                                                \
