@@ -204,48 +204,73 @@ __global__ __launch_bounds__(SF_THREADS) void k_sep3d_acc(const float* __restric
     const int za = bz * g.zchunk, zb = min(za + g.zchunk, nz);
     const int xs0 = x0 - 4 * cql;
     const int kz = tzr.n;
-    float4 pre[NPRE];
-    auto fetch = [&](int p) {
-        const int zi = bnd_index(p, nz, g.bz);
-        const float* plane = src + (size_t)max(zi, 0) * ny * nx;
+    // ---- the march.  Two patches are under way at any time (planes p + 1 and p + 2 while plane p is filtered: with one, a step
+    // waited most of a memory round trip for its patch), and the epilogue operand of the NEXT step's output is requested before
+    // them -- loads and stores of a wave retire in order, so an operand requested behind the patches could only be used once they
+    // had landed.  For the waits to be counted no memory operation may sit in a branch: every load is unconditional -- an item
+    // past the patch reads the last item again, a sample the boundary rule replaces comes from the nearest quad inside the
+    // volume -- and the rule is applied when the registers are copied to LDS (item constants: the quad's offset inside a plane
+    // with the rule in its two low bits -- 1: zero, 2 / 3: the quad's first / last sample four times; nx is a multiple of 4, so a
+    // quad lies inside the row or outside, never across its end).
+    const int n_items = rows_in * segq;
+    int item_om[NPRE];
 #pragma unroll
-        for (int u = 0; u < NPRE; ++u) {
-            const int it = tid + u * SF_THREADS;
-            if (it < rows_in * segq) {
-                const int r = it / segq, q = it - r * segq;
-                const int yi = bnd_index(y0 - g.cy + r, ny, g.by);
-                const int x = xs0 + 4 * q;
-                float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                if (zi >= 0 && yi >= 0) {
-                    const float* row = plane + (size_t)yi * nx;
-                    if (x >= 0 && x + 3 < nx) {
-                        v = *reinterpret_cast<const float4*>(row + x);
-                    } else {
-                        const int i0 = bnd_index(x, nx, g.bx), i1 = bnd_index(x + 1, nx, g.bx), i2 = bnd_index(x + 2, nx, g.bx),
-                                  i3 = bnd_index(x + 3, nx, g.bx);
-                        v = make_float4(i0 >= 0 ? row[i0] : 0.0f, i1 >= 0 ? row[i1] : 0.0f, i2 >= 0 ? row[i2] : 0.0f, i3 >= 0 ? row[i3] : 0.0f);
-                    }
-                }
-                pre[u] = v;
+    for (int u = 0; u < NPRE; ++u) {
+        const int it = min(tid + u * SF_THREADS, n_items - 1);
+        const int r = it / segq, q = it - r * segq;
+        const int yi = bnd_index(y0 - g.cy + r, ny, g.by);
+        const int x = xs0 + 4 * q;
+        int xi = x, mode = yi < 0 ? 1 : 0;
+        if (x < 0 || x >= nx) {
+            if (g.bx == MI_BOUNDARY_CIRCULAR) {
+                xi = x % nx;
+                if (xi < 0) xi += nx;
+            } else {
+                xi = x < 0 ? 0 : nx - 4;
+                if (mode == 0) mode = g.bx == MI_BOUNDARY_REPLICATE ? (x < 0 ? 2 : 3) : 1;
             }
         }
+        item_om[u] = (max(yi, 0) * nx + xi) | mode;   // (a plane has fewer than 2^31 samples: sep3d_launch)
+    }
+    auto fetch = [&](int p, float4 (&buf)[NPRE]) {
+        const int zi = bnd_index(p, nz, g.bz);
+        const float* plane = src + (size_t)max(zi, 0) * ny * nx;   // (a plane the z rule zeroes is read and dropped)
+#pragma unroll
+        for (int u = 0; u < NPRE; ++u) buf[u] = *reinterpret_cast<const float4*>(plane + (item_om[u] & ~3));
+    };
+    auto stage = [&](int p, const float4 (&buf)[NPRE]) {
+        const bool zero_plane = bnd_index(p, nz, g.bz) < 0;
+#pragma unroll
+        for (int u = 0; u < NPRE; ++u) {
+            const int it = tid + u * SF_THREADS, mode = item_om[u] & 3;
+            float4 v = buf[u];
+            if (mode == 2) v = make_float4(v.x, v.x, v.x, v.x);
+            if (mode == 3) v = make_float4(v.w, v.w, v.w, v.w);
+            if (mode == 1 || zero_plane) v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (it < n_items) *reinterpret_cast<float4*>(in + 4 * it) = v;   // (item it = row it / segq, quad it % segq: rows are seg floats)
+        }
+    };
+    // the lane's output voxels: row y0 + rsub, x0 + 4 xq .. + 3 (clamped for the operand loads; stores are guarded)
+    const int oy = y0 + rsub, ox = x0 + 4 * xq;
+    const bool o_live = oy < ny && ox < nx;
+    const size_t o_base = (size_t)min(oy, ny - 1) * nx + min(ox, nx - 4);
+    const size_t plane_sz = (size_t)ny * nx;
+    auto operand = [&](const float* arr, int zo) {  // the epilogue operand of output plane zo (clamped into the chunk)
+        return *reinterpret_cast<const float4*>(arr + (size_t)min(max(zo, za), zb - 1) * plane_sz + o_base);
     };
     float4 acc[KZB];
 #pragma unroll
     for (int j = 0; j < KZB; ++j) acc[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     const int p_first = za - g.cz, p_last = zb - 1 - g.cz + kz - 1;
-    fetch(p_first);
-    for (int p = p_first; p <= p_last; ++p) {
-#pragma unroll
-        for (int u = 0; u < NPRE; ++u) {
-            const int it = tid + u * SF_THREADS;
-            if (it < rows_in * segq) {
-                const int r = it / segq, q = it - r * segq;
-                *reinterpret_cast<float4*>(in + r * seg + 4 * q) = pre[u];
-            }
-        }
+    const int zshift = g.cz - (kz - 1);   // output plane completed by walk position p: p + zshift
+    // one step: plane p (in `buf`) is staged, the operand of the next step's output and the patch of plane p + 2 are requested
+    // (into the operand registers of the next step and into `buf` itself), the plane is filtered, the oldest sum leaves
+    auto step = [&](int p, float4 (&buf)[NPRE], const float4& a_cur, const float4& b_cur, float4& a_nxt, float4& b_nxt) {
+        stage(p, buf);
         __syncthreads();
-        if (p < p_last) fetch(p + 1);
+        if (EPI != EPI_NONE) a_nxt = operand(epi.a, p + 1 + zshift);
+        if (EPI == EPI_UPDATE_REG) b_nxt = operand(epi.b, p + 1 + zshift);
+        fetch(min(p + 2, p_last), buf);
         // x filter: sample j = 4 c + e of the piece row is term j - xoff - i of output i; wx is laid out so that its weight is
         // wx[4 c + e - i + 3].  The terms of an output arrive in window order.
         for (int it = tid; it < rows_in * 16; it += SF_THREADS) {
@@ -266,19 +291,17 @@ __global__ __launch_bounds__(SF_THREADS) void k_sep3d_acc(const float* __restric
         }
         __syncthreads();
         float4 yv = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        {   // y filter, four taps per trip
+        {   // y filter, four taps per trip (their rows requested together, no second set: the other waves of the SIMD fill the gap)
             const float* col = xf + rsub * SF_TX + 4 * xq;
             const float4* wq = reinterpret_cast<const float4*>(wy);
-            auto row4 = [&](int k) { return *reinterpret_cast<const float4*>(col + k * SF_TX); };
-            float4 v0 = row4(0), v1 = row4(1), v2 = row4(2), v3 = row4(3), w = wq[0];
             for (int k = 0; k < kyp; k += 4) {
-                const int kn = k + 4 < kyp ? k + 4 : k;
-                const float4 n0 = row4(kn), n1 = row4(kn + 1), n2 = row4(kn + 2), n3 = row4(kn + 3), wn = wq[kn >> 2];
+                const float4 v0 = *reinterpret_cast<const float4*>(col + k * SF_TX), v1 = *reinterpret_cast<const float4*>(col + (k + 1) * SF_TX),
+                             v2 = *reinterpret_cast<const float4*>(col + (k + 2) * SF_TX), v3 = *reinterpret_cast<const float4*>(col + (k + 3) * SF_TX),
+                             w = wq[k >> 2];
                 yv.x = fmaf(v0.x, w.x, yv.x); yv.y = fmaf(v0.y, w.x, yv.y); yv.z = fmaf(v0.z, w.x, yv.z); yv.w = fmaf(v0.w, w.x, yv.w);
                 yv.x = fmaf(v1.x, w.y, yv.x); yv.y = fmaf(v1.y, w.y, yv.y); yv.z = fmaf(v1.z, w.y, yv.z); yv.w = fmaf(v1.w, w.y, yv.w);
                 yv.x = fmaf(v2.x, w.z, yv.x); yv.y = fmaf(v2.y, w.z, yv.y); yv.z = fmaf(v2.z, w.z, yv.z); yv.w = fmaf(v2.w, w.z, yv.w);
                 yv.x = fmaf(v3.x, w.w, yv.x); yv.y = fmaf(v3.y, w.w, yv.y); yv.z = fmaf(v3.z, w.w, yv.z); yv.w = fmaf(v3.w, w.w, yv.w);
-                v0 = n0; v1 = n1; v2 = n2; v3 = n3; w = wn;
             }
         }
         // plane p is term kz - 1 - j of the output plane behind acc[j] (tzr[j]; zero for j >= kz, where the sums stay zero)
@@ -288,35 +311,46 @@ __global__ __launch_bounds__(SF_THREADS) void k_sep3d_acc(const float* __restric
             acc[j].x = fmaf(yv.x, w, acc[j].x); acc[j].y = fmaf(yv.y, w, acc[j].y);
             acc[j].z = fmaf(yv.z, w, acc[j].z); acc[j].w = fmaf(yv.w, w, acc[j].w);
         }
-        const int zo = p + g.cz - (kz - 1);
-        if (zo >= za) {
+        const int zo = p + zshift;
+        if (zo >= za && zo < zb && o_live) {
             const float4 a0 = acc[0];
-            const int y = y0 + rsub, x = x0 + 4 * xq;
-            if (y < ny && x < nx) {
-                const size_t idx = ((size_t)zo * ny + y) * nx + x;
-                float4 o = a0;
-                if (EPI != EPI_NONE) {
-                    const float4 a = *reinterpret_cast<const float4*>(epi.a + idx);
-                    if (EPI == EPI_RATIO) {
-                        o = make_float4(a.x / fmaxf(a0.x, kEpsSingle), a.y / fmaxf(a0.y, kEpsSingle), a.z / fmaxf(a0.z, kEpsSingle),
-                                        a.w / fmaxf(a0.w, kEpsSingle));
-                    } else if (EPI == EPI_UPDATE) {
-                        o = make_float4(fabsf(a.x * a0.x), fabsf(a.y * a0.y), fabsf(a.z * a0.z), fabsf(a.w * a0.w));
-                    } else {
-                        const float4 b = *reinterpret_cast<const float4*>(epi.b + idx);
-                        const float l = epi.lambda, m = 1.0f - epi.lambda;
-                        o = make_float4(fabsf(a.x * a0.x * m + b.x * l), fabsf(a.y * a0.y * m + b.y * l), fabsf(a.z * a0.z * m + b.z * l),
-                                        fabsf(a.w * a0.w * m + b.w * l));
-                    }
+            const size_t idx = (size_t)zo * plane_sz + (size_t)oy * nx + ox;
+            float4 o = a0;
+            if (EPI != EPI_NONE) {
+                const float4 a = a_cur;
+                if (EPI == EPI_RATIO) {
+                    o = make_float4(a.x / fmaxf(a0.x, kEpsSingle), a.y / fmaxf(a0.y, kEpsSingle), a.z / fmaxf(a0.z, kEpsSingle),
+                                    a.w / fmaxf(a0.w, kEpsSingle));
+                } else if (EPI == EPI_UPDATE) {
+                    o = make_float4(fabsf(a.x * a0.x), fabsf(a.y * a0.y), fabsf(a.z * a0.z), fabsf(a.w * a0.w));
+                } else {
+                    const float4 b = b_cur;
+                    const float l = epi.lambda, m = 1.0f - epi.lambda;
+                    o = make_float4(fabsf(a.x * a0.x * m + b.x * l), fabsf(a.y * a0.y * m + b.y * l), fabsf(a.z * a0.z * m + b.z * l),
+                                    fabsf(a.w * a0.w * m + b.w * l));
                 }
-                *reinterpret_cast<float4*>(dst + idx) = o;
             }
+            *reinterpret_cast<float4*>(dst + idx) = o;
         }
 #pragma unroll
         for (int j = 0; j + 1 < KZB; ++j) acc[j] = acc[j + 1];
         acc[KZB - 1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         // (`in` is rewritten behind the second barrier above, `xf` behind the next first barrier, which every thread reaches after
         // its y filter)
+    };
+    float4 bufX[NPRE], bufY[NPRE];
+    float4 aX = make_float4(0.0f, 0.0f, 0.0f, 0.0f), aY = aX, bX = aX, bY = aX;
+    if (EPI != EPI_NONE) aX = operand(epi.a, p_first + zshift);
+    if (EPI == EPI_UPDATE_REG) bX = operand(epi.b, p_first + zshift);
+    fetch(p_first, bufX);
+    fetch(min(p_first + 1, p_last), bufY);
+    // (two steps per trip: the register sets swap roles from step to step, and a copy from one to the other would wait for the
+    // loads under way)
+    // (an odd number of planes: the last step runs on the last plane once more and stores nothing -- a second step in a branch
+    // would make the compiler wait for every load at the top of each trip, not knowing how many are under way)
+    for (int p = p_first; p <= p_last; p += 2) {
+        step(p, bufX, aX, bX, aY, bY);
+        step(p + 1, bufY, aY, bY, aX, bX);
     }
 }
 
@@ -365,7 +399,7 @@ int sep3d_launch(hipStream_t s, const float* in, float* out, int nx, int ny, int
     const int total = tiles_xy * ((nz + g.zchunk - 1) / g.zchunk);
     const bool wide = sep_patch_quads(k, offs) > 3 * SF_THREADS;
     const dim3 grid((unsigned)((total + 7) / 8 * 8));
-    if (k[2] <= 32 && !MI_PROBE_ENV("MI_SEP_RING")) {  // z window in registers (k_sep3d_acc); MI_SEP_RING=1 (probes build): the LDS-ring kernel
+    if (k[2] <= 32 && (size_t)ny * nx < ((size_t)1 << 31) && !MI_PROBE_ENV("MI_SEP_RING")) {  // z window in registers (k_sep3d_acc); MI_SEP_RING=1 (probes build): the LDS-ring kernel
         const size_t lds_a = sep_lds_bytes_acc(k, offs);
         SepTaps tzr{};
         tzr.n = k[2];
