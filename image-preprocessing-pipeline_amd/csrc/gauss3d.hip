@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 
+#include "conv3d_direct.h"
 #include "mi_internal.h"
 #include "mi_lsdeconv.h"
 
@@ -525,6 +526,24 @@ int gauss3d_to(hipStream_t s, float* src, float* dst, int nx, int ny, int nz, co
     Taps tx, ty, tz;
     MI_TRY(resolve_taps(sigma, ksize, k, tx, ty, tz));
     *fused = gauss3d_fuses(nx, k);
+#ifdef MI_PROBES
+    // (probe builds) the filter as a separable convolution with the replicate rule (sep3d.hip: k_sep3d_acc).  Bit-identical to the
+    // kernels below; measured on a C3-sized volume incl. the copy back (profiles/gauss_time.py): 5 taps 8.6 against 8.4 ms,
+    // 13 x 13 x 25 taps 16.6 against 7.8 ms for the two passes below -- so the Gaussian keeps its own kernels.
+    if (MI_PROBE_ENV("MI_GAUSS_VIA_SEP")) {
+        const int offs[3] = {k[0] / 2, k[1] / 2, k[2] / 2}, bnd[3] = {MI_BOUNDARY_REPLICATE, MI_BOUNDARY_REPLICATE, MI_BOUNDARY_REPLICATE};
+        if ((k[0] & 1) && (k[1] & 1) && (k[2] & 1) && sep3d_fits(nx, k, offs)) {
+            SepTaps t[3];
+            const Taps* g3[3] = {&tx, &ty, &tz};
+            for (int a = 0; a < 3; ++a) {
+                t[a].n = k[a];
+                for (int i = 0; i < k[a]; ++i) t[a].w[i] = g3[a]->w[i];
+            }
+            *fused = true;
+            return sep3d_launch(s, src, dst, nx, ny, nz, t, offs, bnd, EPI_NONE, ConvEpilogue{});
+        }
+    }
+#endif
     static const bool no_wave = MI_PROBE_ENV("MI_GAUSS_NO_WAVE") != nullptr;  // (probe builds: A/B against the work-group kernel)
     if (*fused && !no_wave && k[0] <= 2 * GW_MAXR + 1 && k[1] <= 2 * GW_MAXR + 1 && (k[2] == 3 || k[2] == 5 || k[2] == 7) &&
         (size_t)ny * nx < ((size_t)1 << 31)) {  // (patch offsets inside a plane are 32-bit)
