@@ -13,6 +13,7 @@ CUDA tensors stay on the device, numpy arrays are uploaded.  All arithmetic runs
 from __future__ import annotations
 
 import ctypes as C
+import functools
 import math
 from dataclasses import dataclass, field
 
@@ -307,6 +308,30 @@ def tile_row_blocks(n_rows: int, world_size: int, n_cols: int | None = None):
     return blocks + [(n_rows, n_rows)] * (world_size - len(blocks))
 
 
+@functools.lru_cache(maxsize=64)
+def _pair_list(n_rows, n_cols, row_block, rank, world_size):
+    """The pairs one rank computes and the tiles they touch (see compute_displacements)."""
+    pairs = list(enumerate_pairs(n_rows, n_cols))
+    if row_block is not None:
+        pairs = [p for p in pairs if row_block[0] <= p[0] < row_block[1]]
+    else:
+        pairs = pairs[rank::world_size]
+    used = sorted({r * n_cols + c for r, c, _, _, _ in pairs} | {rb * n_cols + cb for _, _, rb, cb, _ in pairs})
+    return tuple(pairs), tuple(used)
+
+
+@functools.lru_cache(maxsize=64)
+def _pair_arrays(n_rows, n_cols, row_block, rank, world_size, ni_v, nj_h):
+    """ctypes arrays of that pair list: tile indices, the extents a pair drops (ni for vertical, nj for horizontal pairs), sides."""
+    pairs, _ = _pair_list(n_rows, n_cols, row_block, rank, world_size)
+    n = len(pairs)
+    ni_l = [ni_v if d == dir_vertical else 0 for *_, d in pairs]
+    nj_l = [nj_h if d == dir_horizontal else 0 for *_, d in pairs]
+    return ((C.c_int * n)(*[r * n_cols + c for r, c, _, _, _ in pairs]), (C.c_int * n)(*[rb * n_cols + cb for _, _, rb, cb, _ in pairs]),
+            (C.c_int * n)(*ni_l), (C.c_int * n)(*nj_l), (C.c_int * n)(*[d for *_, d in pairs]),
+            tuple((a, b, 0) for a, b in zip(ni_l, nj_l)))
+
+
 def compute_displacements(tiles, overlap_V: int, overlap_H: int, displ_max_V=S_DISPL_SEARCH_RADIUS_DEF,
                           displ_max_H=S_DISPL_SEARCH_RADIUS_DEF, displ_max_D=S_DISPL_SEARCH_RADIUS_DEF,
                           rank: int = 0, world_size: int = 1, row_block=None, sample_scale=None):
@@ -324,16 +349,10 @@ def compute_displacements(tiles, overlap_V: int, overlap_H: int, displ_max_V=S_D
     capi.require_gpu()
     n_rows, n_cols = len(tiles), len(tiles[0])
     flat = [tiles[r][c] for r in range(n_rows) for c in range(n_cols)]
-    pairs = list(enumerate_pairs(n_rows, n_cols))
-    if row_block is not None:
-        r0, r1 = int(row_block[0]), int(row_block[1])
-        pairs = [p for p in pairs if r0 <= p[0] < r1]
-    else:
-        pairs = pairs[rank::world_size]
+    pairs, used = _pair_list(n_rows, n_cols, None if row_block is None else (int(row_block[0]), int(row_block[1])), int(rank), int(world_size))
     n = len(pairs)
     if n == 0:
         return {}
-    used = sorted({r * n_cols + c for r, c, _, _, _ in pairs} | {rb * n_cols + cb for _, _, rb, cb, _ in pairs})
     if any(flat[i] is None for i in used):
         raise ValueError("a tile of a pair this rank computes is not resident (None)")
     first = flat[used[0]]
@@ -356,17 +375,13 @@ def compute_displacements(tiles, overlap_V: int, overlap_H: int, displ_max_V=S_D
         flat = [conv.get(i) for i in range(len(flat))]
         as_int = 0
     ptrs = (C.c_void_p * len(flat))(*[(t.data_ptr() if t is not None else None) for t in flat])
-    a_idx = (C.c_int * n)(*[r * n_cols + c for r, c, _, _, _ in pairs])
-    b_idx = (C.c_int * n)(*[rb * n_cols + cb for _, _, rb, cb, _ in pairs])
-    ni = (C.c_int * n)(*[dim_V - overlap_V if d == dir_vertical else 0 for *_, d in pairs])
-    nj = (C.c_int * n)(*[dim_H - overlap_H if d == dir_horizontal else 0 for *_, d in pairs])
-    side = (C.c_int * n)(*[d for *_, d in pairs])
+    # (index and extent arrays of the pair list: built once per grid shape -- the callee only reads them)
+    a_idx, b_idx, ni, nj, side, ninj = _pair_arrays(n_rows, n_cols, None if row_block is None else (int(row_block[0]), int(row_block[1])),
+                                                    int(rank), int(world_size), dim_V - overlap_V, dim_H - overlap_H)
     p0 = NccParams()
     lib().mi_ncc_default_params(displ_max_V, displ_max_H, displ_max_D, C.byref(p0))
     inf_w = p0.INF_W
-    params = (NccParams * n)()
-    for q in range(n):                       # one parameter block per pair (the callee clamps wRangeThr_* in place)
-        C.memmove(C.byref(params[q]), C.byref(p0), C.sizeof(NccParams))
+    params = (NccParams * n).from_buffer_copy(bytes(p0) * n)   # one parameter block per pair (the callee clamps wRangeThr_* in place)
     out = (NccDescr * n)()
     if as_int:
         check((lib().mi_ncc_mips_batch_u16 if as_int == 2 else lib().mi_ncc_mips_batch_u8)(dev.index, capi.current_stream_ptr(dev), n, ptrs, float(sample_scale), a_idx, b_idx, dim_D, dim_V,
@@ -393,9 +408,12 @@ def compute_displacements(tiles, overlap_V: int, overlap_H: int, displ_max_V=S_D
     gc.disable()    # a few thousand small containers: the cyclic collector's passes over a torch-sized heap cost 0.1 ms per record
     try:
         cl, pl, wl, tl, rl = coords.tolist(), peaks.astype(np.float64).tolist(), widths.tolist(), thr.tolist(), rel.astype(np.float64).tolist()
+        new = object.__new__   # (the dataclass constructor with its default factories costs 4 us per record; 112 records a call)
         for q, key in enumerate(pairs):
-            res[key] = DisplacementMIPNCC(cl[q], pl[q], wl[q], list(delays), tl[q], [inf_w] * 3,
-                                          [int(ni[q]), int(nj[q]), 0], rl[q])                       # vmVirtualVolume.cpp:279-306
+            d = new(DisplacementMIPNCC)
+            d.__dict__ = {"VHD_coords": cl[q], "NCC_maxs": pl[q], "NCC_widths": wl[q], "delays": list(delays), "wRangeThrs": tl[q],
+                          "invWidths": [inf_w] * 3, "VHD_def_coords": list(ninj[q]), "rel_factors": rl[q], "extra": {}}   # vmVirtualVolume.cpp:279-306
+            res[key] = d
     finally:
         if gc_on:
             gc.enable()
