@@ -394,6 +394,37 @@ def test_separable_psf_takes_three_1d_passes(dev, boundary, kshape, monkeypatch)
     assert not sep_asym
 
 
+@pytest.mark.parametrize("boundary", [0, 2])
+@pytest.mark.parametrize("kshape", [(19, 5, 7), (5, 33, 9), (35, 3, 5), (32, 4, 3)])
+def test_separable_single_pass_variants(dev, boundary, kshape, monkeypatch):
+    """Every build of the single-pass separable kernel (sep3d.hip): z windows of 17 - 32 taps in registers (19; 32 with an even
+    window offset), the patch of a long y kernel in six register quads per thread (33 rows of taps), the LDS-ring kernel that
+    keeps z windows beyond 32 taps (35) -- against the three-launch route and the dense loop of the same engine, and (first case)
+    the oracle's loop."""
+    from ipp_amd import decon
+    shape = (44, 50, 72)
+    psf = R.gaussian_psf(kshape, (kshape[0] / 5.0, kshape[1] / 5.0, kshape[2] / 5.0))
+    psf = (psf * np.linspace(0.8, 1.2, kshape[0])[:, None, None]).astype(np.float32)       # rank 1, not symmetric along z
+    vol = R.bead_volume(shape, seed=25, psf=R.gaussian_psf((3, 3, 3), (1, 1, 1)))
+    inv = R.flip3(psf) if boundary != 2 else None
+
+    def run(iters=2):
+        ctx = decon.RLContext(shape, psf, inv, boundary=boundary, engine=1, device=dev)
+        bl = _t(vol, dev)
+        ctx.iterate(bl, torch.empty_like(bl), iters)
+        return bl.cpu().numpy(), ctx.separable_single_pass
+
+    got, single = run()
+    assert single
+    monkeypatch.setenv("MI_NO_SEP_SINGLE", "1")
+    three, single3 = run()
+    monkeypatch.delenv("MI_NO_SEP_SINGLE")
+    assert not single3 and _rel(got, three) < 5e-6
+    if kshape == (19, 5, 7):
+        want = R.decon_fft(vol, psf, shape, 2, skip_edgetaper=True) if boundary == 2 else R.decon_spatial(vol, psf, 2, skip_edgetaper=True)
+        assert_close(got, want)
+
+
 @pytest.mark.parametrize("boundary", [0, 1, 2])
 def test_separable_single_pass_edges_and_regularised_update(dev, boundary):
     """The single-pass separable kernel where its tiles are ragged: extents that are no multiples of the 64 x 16 tile, fewer planes
