@@ -357,24 +357,29 @@ __global__ __launch_bounds__((GF_TX / 4) * GF_TY) void k_gauss3d_fused(const flo
 // from where its data is needed: the patch is double-buffered, plane p + 2 is requested into registers while plane p is filtered,
 // written to the other buffer one step later, used one step after that.
 // Filters of the RL loop's regularisation step: kx, ky <= 7, kz = KZ in {3, 5, 7}; everything else takes the kernels above.
-constexpr int GW_ROWS = 8, GW_MAXR = 3, GW_SEG = 64 + 8, GW_WGROWS = 32, GW_RIN = GW_WGROWS + 2 * GW_MAXR, GW_NPRE = 3;
+constexpr int GW_ROWS = 8, GW_MAXR = 3, GW_WGROWS = 32, GW_RIN = GW_WGROWS + 2 * GW_MAXR, GW_NPRE = 3;
+// WX: the tile is 64 WX columns wide (WX waves side by side on each group of 8 rows, 256 WX threads): the x halo of a tile costs two
+// 128-byte lines per row whatever its width -- 2 on 2 lines of payload for 64 columns, 2 on 4 for 128 (C3 volume: 4.2 -> 3.9 ms;
+// 256 columns with 1024 threads: 4.0)
 constexpr int GW_XF = (GW_ROWS + 2 * GW_MAXR) * 64;  // a wave's x-filtered rows
-template <int KZ>
-__global__ __launch_bounds__(256) void k_gauss3d_wave(const float* __restrict__ src, float* __restrict__ dst, int nx, int ny, int nz, int zchunk,
+template <int KZ, int WX>
+__global__ __launch_bounds__(256 * WX) void k_gauss3d_wave(const float* __restrict__ src, float* __restrict__ dst, int nx, int ny, int nz, int zchunk,
                                                        Taps tx, Taps ty, Taps tz) {
+    constexpr int GW_TX = 64 * WX, GW_SEG = GW_TX + 8, NT = 256 * WX;
     __shared__ __attribute__((aligned(16))) float in2[2][GW_RIN * GW_SEG];   // the staged patch of two planes
-    __shared__ __attribute__((aligned(16))) float xf_all[4 * GW_XF];
+    __shared__ __attribute__((aligned(16))) float xf_all[4 * WX * GW_XF];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wx = wave % WX, wy = wave / WX;   // the wave's 64 columns and its 8 rows inside the tile
     float* xf = xf_all + wave * GW_XF;             // [rows of the wave][64]: after the x filter
     const int rx = tx.n / 2, ry = ty.n / 2, rows_in = GW_WGROWS + 2 * ry, rows_w = GW_ROWS + 2 * ry;
     constexpr int rz = KZ / 2, segq = GW_SEG / 4;
     // tiles as in k_gauss3d_fused: contiguous tile ranges per XCD
-    const int gx = (nx + 63) / 64, gy = (ny + GW_WGROWS - 1) / GW_WGROWS, gz = (nz + zchunk - 1) / zchunk;
+    const int gx = (nx + GW_TX - 1) / GW_TX, gy = (ny + GW_WGROWS - 1) / GW_WGROWS, gz = (nz + zchunk - 1) / zchunk;
     const int total = gx * gy * gz, per = (total + 7) / 8;
     const int t = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
     if (t >= total) return;
     const int bz = t / (gx * gy), by = (t - bz * gx * gy) / gx, bx = t - bz * gx * gy - by * gx;
-    const int x0 = bx * 64, y0 = by * GW_WGROWS;
+    const int x0 = bx * GW_TX, y0 = by * GW_WGROWS;
     const int za = bz * zchunk, zb = min(za + zchunk, nz);
     const int xoff = 4 - rx;                       // first tap of output x sits at staged column x + xoff
     const int xq = lane & 15, rs = lane >> 4;      // y / z filters: columns 4 xq .. + 3 of rows rs and rs + 4 of the wave's 8
@@ -384,7 +389,7 @@ __global__ __launch_bounds__(256) void k_gauss3d_wave(const float* __restrict__ 
     int poff[GW_NPRE], pedge[GW_NPRE];
 #pragma unroll
     for (int u = 0; u < GW_NPRE; ++u) {
-        const int it = min(tid + 256 * u, rows_in * segq - 1);   // (threads past the patch repeat its last piece: no predicated load)
+        const int it = min(tid + NT * u, rows_in * segq - 1);   // (threads past the patch repeat its last piece: no predicated load)
         const int r = it / segq, q = it - r * segq, x = x0 - 4 + 4 * q;
         poff[u] = min(max(y0 - ry + r, 0), ny - 1) * nx + min(max(x, 0), nx - 4);
         pedge[u] = x < 0 ? -1 : (x >= nx ? 1 : 0);
@@ -402,7 +407,7 @@ __global__ __launch_bounds__(256) void k_gauss3d_wave(const float* __restrict__ 
     auto stage = [&](float* buf) {
 #pragma unroll
         for (int u = 0; u < GW_NPRE; ++u) {
-            const int it = tid + 256 * u;
+            const int it = tid + NT * u;
             if (it < rows_in * segq) {
                 const int r = it / segq, q = it - r * segq;
                 *reinterpret_cast<float4*>(buf + r * GW_SEG + 4 * q) = pre[u];
@@ -418,7 +423,7 @@ __global__ __launch_bounds__(256) void k_gauss3d_wave(const float* __restrict__ 
     fetch(p0 + 1);
     __syncthreads();
     for (int p = p0; p < p1; ++p) {
-        const float* in = in2[(p - p0) & 1] + wave * GW_ROWS * GW_SEG;   // the wave's rows of plane p
+        const float* in = in2[(p - p0) & 1] + wy * GW_ROWS * GW_SEG + 64 * wx;   // the wave's rows and columns of plane p
         stage(in2[(p - p0 + 1) & 1]);                                      // plane p + 1 (requested one step ago)
         fetch(p + 2);                                                      // (clamped planes past the chunk: harmless)
         for (int it = lane; it < rows_w * 16; it += 64) {   // x filter: 4 outputs from kx + 3 staged samples
@@ -460,7 +465,7 @@ __global__ __launch_bounds__(256) void k_gauss3d_wave(const float* __restrict__ 
                     const float w = tz.w[k];
                     acc.x = fmaf(v.x, w, acc.x); acc.y = fmaf(v.y, w, acc.y); acc.z = fmaf(v.z, w, acc.z); acc.w = fmaf(v.w, w, acc.w);
                 }
-                const int y = y0 + wave * GW_ROWS + rs + 4 * h, x = x0 + 4 * xq;
+                const int y = y0 + wy * GW_ROWS + rs + 4 * h, x = x0 + 64 * wx + 4 * xq;
                 if (y < ny && x < nx) *reinterpret_cast<float4*>(dst + ((size_t)zo * ny + y) * nx + x) = acc;
             }
         }
@@ -548,11 +553,17 @@ int gauss3d_to(hipStream_t s, float* src, float* dst, int nx, int ny, int nz, co
     if (*fused && !no_wave && k[0] <= 2 * GW_MAXR + 1 && k[1] <= 2 * GW_MAXR + 1 && (k[2] == 3 || k[2] == 5 || k[2] == 7) &&
         (size_t)ny * nx < ((size_t)1 << 31)) {  // (patch offsets inside a plane are 32-bit)
         const int zchunk = 128;
-        const int total = ((nx + 63) / 64) * ((ny + 31) / 32) * ((nz + zchunk - 1) / zchunk);
-        const dim3 grid((total + 7) / 8 * 8), block(256);
-        if (k[2] == 3) hipLaunchKernelGGL(k_gauss3d_wave<3>, grid, block, 0, s, src, dst, nx, ny, nz, zchunk, tx, ty, tz);
-        else if (k[2] == 5) hipLaunchKernelGGL(k_gauss3d_wave<5>, grid, block, 0, s, src, dst, nx, ny, nz, zchunk, tx, ty, tz);
-        else hipLaunchKernelGGL(k_gauss3d_wave<7>, grid, block, 0, s, src, dst, nx, ny, nz, zchunk, tx, ty, tz);
+        int wx = nx >= 512 ? 2 : 1;   // tiles of 128 columns where a row has enough of them
+        if (const char* e = MI_PROBE_ENV("MI_GAUSS_WX")) wx = atoi(e) == 2 ? 2 : 1;
+        const int total = ((nx + 64 * wx - 1) / (64 * wx)) * ((ny + 31) / 32) * ((nz + zchunk - 1) / zchunk);
+        const dim3 grid((total + 7) / 8 * 8), block(256 * wx);
+#define MI_GW(KZV, WXV) hipLaunchKernelGGL((k_gauss3d_wave<KZV, WXV>), grid, block, 0, s, src, dst, nx, ny, nz, zchunk, tx, ty, tz)
+        if (wx == 2) {
+            if (k[2] == 3) MI_GW(3, 2); else if (k[2] == 5) MI_GW(5, 2); else MI_GW(7, 2);
+        } else {
+            if (k[2] == 3) MI_GW(3, 1); else if (k[2] == 5) MI_GW(5, 1); else MI_GW(7, 1);
+        }
+#undef MI_GW
         return launch_check("k_gauss3d_wave");
     }
     if (*fused) {

@@ -33,8 +33,10 @@ for name, sig, ks in [("reg step sigma=0.5 (5 taps)", 0.5, None), ("pre-filter s
     ms = run(sig, ks, ref)
     line = f"{name}: {ms:.2f} ms  ({x0.numel() * 8 / ms / 1e6:.0f} GB/s on the 8 B/voxel ideal)"
     if os.environ.get("MI_IPP_PROBES") == "1":
-        os.environ["MI_GAUSS_VIA_SEP"] = "1"
-        ms2 = run(sig, ks, alt)
-        del os.environ["MI_GAUSS_VIA_SEP"]
-        line += f"; as a separable convolution (k_sep3d_acc + copy back) {ms2:.2f} ms, max |difference| {float((ref - alt).abs().max()):.1e}"
+        for var, val, what in (("MI_GAUSS_WX", "1", "tiles of 64 columns"), ("MI_GAUSS_WX", "2", "tiles of 128 columns"),
+                               ("MI_GAUSS_VIA_SEP", "1", "as a separable convolution (k_sep3d_acc)")):
+            os.environ[var] = val
+            ms2 = run(sig, ks, alt)
+            del os.environ[var]
+            line += f"; {what} {ms2:.2f} ms (max |difference| {float((ref - alt).abs().max()):.1e})"
     print(line, flush=True)
