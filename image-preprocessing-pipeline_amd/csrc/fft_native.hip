@@ -167,12 +167,16 @@ __device__ __forceinline__ constexpr float s16(int k) {
 
 // ------------------------------------------------------------------------------------------------ super-stage chains
 // The log2(N) radix-2 stages of a transform are cut, bottom-up, into super-stages of 3 stages (8 points per lane in
-// registers; a remainder of 4 becomes 2 + 2, a remainder of 1 or 2 sits at the top): seg_r(logn, s) is the length of the
+// registers; a remainder of 4 becomes 2 + 2 -- one stage of 16 points for 1024-point transforms --, a remainder of 1 or 2 sits at the top): seg_r(logn, s) is the length of the
 // super-stage that starts at stage s.  The same cut serves both directions (forward walks it top-down, inverse bottom-up),
 // and all its (S_LO, LR) pairs below stage 5 are among the conflict-free patterns of the swizzle.
 __host__ __device__ constexpr int seg_r(int logn, int s) {
     const int rem = logn - s;
     if (logn == 4) return s == 0 ? 3 : 1;
+    // 1024 points as 8 x 8 x 16 -- three LDS round trips instead of the four of 8 x 8 x 4 x 4 (round 4; C3: ratio launch of the x
+    // pass 5.07 -> 4.76 ms, the z pass of 1024-point lines 6.15 -> 5.71 ms, the y passes of C2 0.426 -> 0.416 ms).  The sixteen-point
+    // butterfly reads its fifteen twiddles where it uses them (butterflies): held together they spilled.
+    if (logn == 10 && rem == 4) return 4;
     return rem >= 5 ? 3 : rem == 4 ? 2 : rem;  // rem in {1, 2, 3}: all of it
 }
 // start of the super-stage that ends at stage `top` (exclusive)
@@ -326,19 +330,19 @@ __host__ __device__ constexpr int bit_rev(int j, int bits) {
 template <int LR, int S_LO, bool INVERSE>
 __device__ __forceinline__ void butterflies(float2 (&v)[1 << LR], const float2* twl, int m) {
     constexpr int R = 1 << LR, NP = tw_powers(S_LO, LR);
-    float2 w[R];
+    float2 w[NP == R - 1 ? 1 : R];
+    // (all powers in the table: each is read where it is used -- sixteen points per lane and their fifteen twiddles at once do not
+    // fit the 128 registers of the strided passes)
+    auto tw_of = [&](int j) { return twl[((bit_rev(j, LR) - 1) << S_LO) + m]; };
     if constexpr (S_LO > 0) {
-        if constexpr (NP == R - 1) {
-#pragma unroll
-            for (int p = 1; p < R; ++p) w[p] = twl[((p - 1) << S_LO) + m];
-        } else {
+        if constexpr (NP != R - 1) {
             w[1] = twl[m];
 #pragma unroll
             for (int p = 2; p < R; ++p) w[p] = (p & 1) ? cmul(w[p - 1], w[1]) : cmul(w[p / 2], w[p / 2]);
         }
         if constexpr (INVERSE) {
 #pragma unroll
-            for (int j = 1; j < R; ++j) v[j] = cmulc(v[j], w[bit_rev(j, LR)]);
+            for (int j = 1; j < R; ++j) v[j] = cmulc(v[j], NP == R - 1 ? tw_of(j) : w[NP == R - 1 ? 0 : bit_rev(j, LR)]);
         }
     }
 #pragma unroll
@@ -362,7 +366,7 @@ __device__ __forceinline__ void butterflies(float2 (&v)[1 << LR], const float2* 
     }
     if constexpr (S_LO > 0 && !INVERSE) {
 #pragma unroll
-        for (int j = 1; j < R; ++j) v[j] = cmul(v[j], w[bit_rev(j, LR)]);
+        for (int j = 1; j < R; ++j) v[j] = cmul(v[j], NP == R - 1 ? tw_of(j) : w[NP == R - 1 ? 0 : bit_rev(j, LR)]);
     }
 }
 
@@ -1836,9 +1840,19 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_x_fused_pipe(const flo
             for (int j = 0; j < NPF; ++j) av[j] = pre[j];
             if (tn < ntiles) load_rows(tn);
         } else {
-        if (R3 != 9) load_a();  // (radix-9 rows: requested behind the 9-point stage, which needs the registers)
+        // (the inverse-only launch with a sixteen-point top stage: the operand is requested in front of that stage -- held across
+        // the whole transform it does not fit the 128 registers beside the stage's sixteen points)
+        constexpr int TOP_LO = seg_below(LHX2, LHX2);
+        constexpr bool LATE_A = MODE == 2 && R3 == 1 && LHX2 - TOP_LO == 4;
+        if (R3 != 9 && !LATE_A) load_a();  // (radix-9 rows: requested behind the 9-point stage, which needs the registers)
         lds_barrier();
-        lds_fft<LHX2, true, kThreadsXZ, R3>(tile, TY * R3, pitch, hp, PRIV, twl);
+        if constexpr (LATE_A) {
+            lds_fft<LHX2, true, kThreadsXZ, R3, 0, TOP_LO>(tile, TY * R3, pitch, hp, PRIV, twl);
+            load_a();
+            lds_fft<LHX2, true, kThreadsXZ, R3, TOP_LO, LHX2>(tile, TY * R3, pitch, hp, PRIV, twl);
+        } else {
+            lds_fft<LHX2, true, kThreadsXZ, R3>(tile, TY * R3, pitch, hp, PRIV, twl);
+        }
         if constexpr (R3 > 1) {
             radix3_stage<R3, true, kThreadsXZ>(tile, TY, pitch, hp, PRIV, 1 << LHX2, twl + TW::r3);
             stage_sync(PRIV);
