@@ -177,6 +177,8 @@ __host__ __device__ constexpr int seg_r(int logn, int s) {
     // pass 5.07 -> 4.76 ms, the z pass of 1024-point lines 6.15 -> 5.71 ms, the y passes of C2 0.426 -> 0.416 ms).  The sixteen-point
     // butterfly reads its fifteen twiddles where it uses them (butterflies): held together they spilled.
     if (logn == 10 && rem == 4) return 4;
+    // (2048 points as 16 x 16 x 8 instead of 8 x 8 x 8 x 4: y passes of C3 3.34 against 3.38 ms forward, equal inverse, in the
+    // placement where they run at 5.1 TB/s -- not kept)
     return rem >= 5 ? 3 : rem == 4 ? 2 : rem;  // rem in {1, 2, 3}: all of it
 }
 // start of the super-stage that ends at stage `top` (exclusive)
@@ -1196,14 +1198,23 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_z_conv_pipe(const floa
                 }
             }
         };
-        if (R3 != 9) load_G();  // (radix-9 lines: requested behind the 9-point stage, which needs the registers)
+        // (a sixteen-point top stage -- the FIRST of the forward transform -- and the OTF registers do not fit 128 registers together:
+        // the OTF is then requested behind that stage)
+        constexpr bool LATE_G = R3 == 1 && LZ2 - seg_below(LZ2, LZ2) == 4;
+        if (R3 != 9 && !LATE_G) load_G();  // (radix-9 lines: requested behind the 9-point stage, which needs the registers)
         lds_barrier();
         if constexpr (R3 > 1) {
             radix3_stage<R3, false, kThreadsXZ>(tile, 2 * TL, pitch, hp, PRIV, 1 << LZ2, twl + TW::r3);
             stage_sync(PRIV);
         }
         if (R3 == 9) load_G();
-        lds_fft<LZ2, false, kThreadsXZ, R3>(tile, 2 * TL * R3, pitch, hp, PRIV, twl);
+        if constexpr (LATE_G) {
+            lds_fft<LZ2, false, kThreadsXZ, R3, 0, 4>(tile, 2 * TL * R3, pitch, hp, PRIV, twl);
+            load_G();
+            lds_fft<LZ2, false, kThreadsXZ, R3, 4, LZ2>(tile, 2 * TL * R3, pitch, hp, PRIV, twl);
+        } else {
+            lds_fft<LZ2, false, kThreadsXZ, R3>(tile, 2 * TL * R3, pitch, hp, PRIV, twl);
+        }
         if (PRIV && !WP) lds_barrier();  // the point-wise step pairs rows of different owners
         float sw, cw;
         sincospif(-2.0f * (float)w.plane / (float)(2 * Hx), &sw, &cw);  // exp(-2 pi i xk / Nx), Nx = 2 Hx
@@ -1402,14 +1413,22 @@ __global__ __launch_bounds__(NT, kWavesXZ) void k_z_pair_pipe(const float2* __re
                 else gv[k] = G[gl + 64 * k];
             }
         };
-        if (R3 != 9) load_G();  // (radix-9 lines: requested behind the 9-point stage, which needs the registers)
+        // (complex OTF and a sixteen-point top stage, the first of the forward transform: see k_z_conv_pipe)
+        constexpr bool LATE_G = !REALG && R3 == 1 && !TOPREG && LZ2 - seg_below(LZ2, LZ2) == 4;
+        if (R3 != 9 && !LATE_G) load_G();  // (radix-9 lines: requested behind the 9-point stage, which needs the registers)
         lds_barrier();
         if constexpr (R3 > 1) {
             radix3_stage<R3, false, NT>(tile, 2 * TL, pitch, hp, true, 1 << LZ2, twl + TW::r3);
             wave_lds_fence();
         }
         if (R3 == 9) load_G();
-        lds_fft<LZ2, false, NT, R3, TOPREG ? TOPR : 0>(tile, 2 * TL * R3, pitch, hp, true, twl);
+        if constexpr (LATE_G) {
+            lds_fft<LZ2, false, NT, R3, 0, 4>(tile, 2 * TL * R3, pitch, hp, true, twl);
+            load_G();
+            lds_fft<LZ2, false, NT, R3, 4, LZ2>(tile, 2 * TL * R3, pitch, hp, true, twl);
+        } else {
+            lds_fft<LZ2, false, NT, R3, TOPREG ? TOPR : 0>(tile, 2 * TL * R3, pitch, hp, true, twl);
+        }
         if constexpr (!WP) lds_barrier();
         float sw, cw;
         sincospif(-2.0f * (float)plane / (float)(2 * Hx), &sw, &cw);  // exp(-2 pi i xk / Nx), Nx = 2 Hx

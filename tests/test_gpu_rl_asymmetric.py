@@ -62,7 +62,10 @@ def test_decon_spatial_asymmetric_psf_and_explicit_inv(dev, engine, kshape, inv,
 
 # ------------------------------------------------------------------ fused mi_rl_iterate and the half-steps
 @pytest.mark.parametrize("kshape", KSHAPES)
-@pytest.mark.parametrize("shape", [(16, 32, 64), (8, 96, 32), (96, 16, 192)])
+@pytest.mark.parametrize("shape", [(16, 32, 64), (8, 96, 32), (96, 16, 192),
+                                   # 1024-point transforms (three LDS round trips with a 16-point stage) on each axis: z in the paired
+                                   # and (8 rows) in the plain layout -- both with the complex OTF requested behind that stage --, y, x
+                                   (1024, 16, 32), (1024, 8, 32), (16, 1024, 32), (8, 16, 2048)])
 def test_fused_iterate_asymmetric_psf(dev, shape, kshape):
     from ipp_amd import capi, decon
     psf = asymmetric_psf(kshape, seed=5)
