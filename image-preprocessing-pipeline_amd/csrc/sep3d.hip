@@ -426,6 +426,7 @@ int sep3d_launch(hipStream_t s, const float* in, float* out, int nx, int ny, int
         return launch_check("k_sep3d_acc");
     }
     const size_t lds = sep_lds_bytes(k, offs);
+    MI_REQUIRE(lds <= kSepLdsMax, "separable convolution: the plane ring of %d taps does not fit the LDS (planes of 2^31 samples and more take the ring kernel)", k[2]);
 #define MI_SEP(E)                                                                                                                  \
     case E:                                                                                                                        \
         if (wide) {                                                                                                                \
