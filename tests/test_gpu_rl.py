@@ -73,7 +73,8 @@ def test_conv3d_errors(dev):
 
 
 # ------------------------------------------------------------------ gauss3d_gpu (R8)
-@pytest.mark.parametrize("shape", [(32, 64, 32), (20, 33, 47), (37, 70, 130), (530, 12, 68)])
+@pytest.mark.parametrize("shape", [(32, 64, 32), (20, 33, 47), (37, 70, 130), (530, 12, 68),
+                                   (9, 37, 520), (6, 70, 1156)])   # rows of >= 512 samples: 128-column tiles of the single pass, ragged in x and y
 @pytest.mark.parametrize("sigma,ksize", [(2.5, None), ([1.5, 1.5, 2.5], [9, 11, 15]), ([0.5, 0.5, 2.5], None),
                                          (0.25, 3), (8, 51), ([0.5, 0.5, 2.5], [13, 13, 25])])
 def test_gauss3d_gpu_matches_oracle(dev, shape, sigma, ksize):
