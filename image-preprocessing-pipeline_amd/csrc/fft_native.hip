@@ -1313,10 +1313,11 @@ __global__ __launch_bounds__(kThreadsXZ, kWavesXZ) void k_z_conv_pipe(const floa
 //   NT = 512 (lines of up to 576 points): a wave owns one A line and its partner -- forward transform, point-wise step and
 //     inverse transform of the pair run inside the wave, the only work-group barriers surround the transposed fill and drain;
 //     for 2^a lines of 256 / 512 points the fill and the drain ARE the top super-stage (on the registers of the global access).
-//   NT = 1024 (768, 1024, 1152 points): a wave owns one line; the point-wise step sits between two barriers.
+//   NT = 1024 (768, 1152 points): a wave owns one line; the point-wise step sits between two barriers.  (1024-point lines run on
+//     NT = 512 with 246 registers: see the launch.)
 //   Lines of 3 * 2^a / 9 * 2^a points carry the radix-3 / 9 stage in front (behind, inverse) of the power-of-two chain.
 template <int LZ2, int R3, bool REALG, int NT, int TL, bool PHL = true, bool TOPON = true>
-__global__ __launch_bounds__(NT, kWavesXZ) void k_z_pair_pipe(const float2* __restrict__ S, float2* __restrict__ T, const float4* __restrict__ G,
+__global__ __launch_bounds__(NT, (NT == 512 && (R3 << LZ2) > 576) ? 2 : kWavesXZ) void k_z_pair_pipe(const float2* __restrict__ S, float2* __restrict__ T, const float4* __restrict__ G,
                                                               NativeDims d, const float2* __restrict__ tw, int conj_otf, int ntiles, RealOtf ro,
                                                               int* __restrict__ tile_ctr) {
     extern __shared__ __attribute__((aligned(16))) float2 tile[];
@@ -1485,7 +1486,8 @@ __global__ __launch_bounds__(NT, kWavesXZ) void k_z_pair_pipe(const float2* __re
         // (requesting them right after the fill, a whole tile ahead, gains nothing with two work-groups per CU: 4.72 vs 4.68 ms; with
         // the one 1024-thread work-group of 1024-point lines it LOSES -- 6.28 against 5.90 ms on 1024 x 576 x 4096, A / B in one
         // process, the loads unconditional and behind the OTF loads so that every wait stays counted; a 512-thread variant with a
-        // line pair per wave measured 6.00: round 4, profiles/zpass_ab.py)
+        // line pair per wave measured 6.00 with the 4 x 4 top stages -- with the 16-point top stage on the registers of the global
+        // access it became the kept form, see the launch: round 4, profiles/zpass_ab.py)
         if (R3 != 9 && tn < ntiles) load_S(tn);
         if constexpr (WP) wave_lds_fence();
         else lds_barrier();
@@ -2320,9 +2322,12 @@ int NativeFft::z_conv(hipStream_t s, bool conj_otf, const float2* src_o, float2*
                       : launch_lds(k_z_pair_pipe<LG, R, false, NTH, kPairLines, PH>, grid, NTH, lds, s, "k_z_pair_pipe", Tp, Sp, Gp, d, \
                                    twz, cj, ntiles, ro, ctr_p);                                                                         \
         break;
-        // (lines of up to 576 points: 8 waves on a 64-KB tile, two work-groups per CU; longer ones: 16 waves, one line per wave)
+        // (lines of up to 576 points: 8 waves on a 64-KB tile, two work-groups per CU; 768 and 1152 points: 16 waves, one line per wave;
+        // 1024 points: 8 waves again, a line pair per wave -- with the 16-point top stage a lane's 16 float4 are exactly that stage's
+        // points of two lines, so it runs on the registers of the global access like the 512-point pass (246 registers, one
+        // work-group per CU): 5.60 -> 5.11 ms on 1024 x 576 x 4096 against the 16-wave form, A / B in one process)
         switch (dims.lz2 * 16 + dims.r3z) {
-            MI_ZQ(6, 1, 512, true) MI_ZQ(7, 1, 512, true) MI_ZQ(8, 1, 512, true) MI_ZQ(9, 1, 512, true) MI_ZQ(10, 1, 1024, true)
+            MI_ZQ(6, 1, 512, true) MI_ZQ(7, 1, 512, true) MI_ZQ(8, 1, 512, true) MI_ZQ(9, 1, 512, true) MI_ZQ(10, 1, 512, true)
             MI_ZQ(6, 3, 512, true) MI_ZQ(7, 3, 512, true) MI_ZQ(8, 3, 1024, true)
             MI_ZQ(6, 9, 512, false) MI_ZQ(7, 9, 1024, true)
             default: return fail(MI_ERR_UNSUPPORTED, "native FFT: paired z length %d", L);
