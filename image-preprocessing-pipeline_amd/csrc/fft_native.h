@@ -65,6 +65,8 @@ struct NativeFft {
     const float2* tw_z = nullptr;
     size_t n_cplx = 0;
     int n_cu = 256;  // persistent kernels launch one work-group per CU
+    std::vector<float> placement_ms;  // forward y pass on each candidate placement of the spectrum arrays (init)
+    int placement_kept = -1;
     // x launches that run beside a halo exchange (part 2 of a sharded step): compute units left free for the collective's
     // kernels, tiles handed out by a device counter instead of a fixed stride (mi_rl_set_overlap)
     int overlap_free_cus = 0;

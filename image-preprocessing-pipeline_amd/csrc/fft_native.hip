@@ -2126,6 +2126,63 @@ int NativeFft::init(hipStream_t s, const int F[3], bool explicit_adjoint) {
     have_adj = explicit_adjoint;
     if (have_adj) MI_TRY(G_adj.alloc(G.bytes));  // explicit adjoint kernel (psf_inv of the 'same'-convolution flavour) instead of conj(OTF)
     MI_HIP(hipStreamSynchronize(s));  // host twiddle vector dies at scope exit
+    // ---- where the spectrum arrays lie.  The strided passes run at one of two speeds depending on the PHYSICAL memory behind the
+    // arrays (y passes of C3 2.96 or 3.36 ms, the update launch of the x pass 5.5 or 6.3), and which one a plain allocation gets
+    // changes from region to region of the device memory: eight contexts created one after the other and all kept alive ran fast,
+    // fast, fast, slow, slow, slow, fast, slow (profiles/r04_hold_contexts.txt).  Releasing and allocating again returns the same
+    // memory (round 3's placement trials); so large arrays are placed by trial WITHOUT release: up to MI_FFT_PLACEMENT_TRIES (4)
+    // candidates are allocated side by side, a forward y pass is timed on each (the contents do not matter), the fastest stays.
+    // Costs a few passes and, for a moment, the memory of the rejected candidates; only arrays of 8 GB and more (one GPU, large
+    // volumes: block and slab-rank plans are smaller and several of them share a device).
+    if (vmm_order < 0 && S.bytes >= ((size_t)8 << 30)) {
+        int tries = 4;
+        if (const char* e = std::getenv("MI_FFT_PLACEMENT_TRIES")) tries = std::max(1, std::min(8, atoi(e)));
+        size_t free_b = 0, total_b = 0;
+        MI_HIP(hipMemGetInfo(&free_b, &total_b));
+        const size_t bytes = S.bytes, keep = (size_t)24 << 30;   // (what the caller still allocates: volumes, scratch)
+        while (tries > 1 && (size_t)(tries - 1) * bytes + keep > free_b) --tries;
+        if (tries > 1) {
+            hipEvent_t e0, e1;
+            MI_HIP(hipEventCreate(&e0));
+            MI_HIP(hipEventCreate(&e1));
+            std::vector<void*> cand{S.p};
+            std::vector<float> ms;
+            int rc = MI_OK;
+            for (int i = 0; i < tries && rc == MI_OK; ++i) {
+                if (i > 0) {
+                    void* q = nullptr;
+                    if (hipMalloc(&q, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
+                    cand.push_back(q);
+                }
+                S.p = cand[i];
+                t_spec = S.as<float2>() + n_buf + gap / sizeof(float2);
+                float t = 0.0f;
+                for (int rep = 0; rep < 2 && rc == MI_OK; ++rep) {   // (the second run counts)
+                    (void)hipEventRecord(e0, s);
+                    rc = y_pass(s, false, dims.paired != 0);
+                    (void)hipEventRecord(e1, s);
+                    if (rc == MI_OK && hipEventSynchronize(e1) != hipSuccess) rc = fail(MI_ERR_HIP, "native FFT: placement trial failed");
+                    if (rc == MI_OK) (void)hipEventElapsedTime(&t, e0, e1);
+                }
+                ms.push_back(t);
+            }
+            size_t best = 0;
+            for (size_t i = 1; i < ms.size(); ++i)
+                if (ms[i] < ms[best]) best = i;
+            for (size_t i = 0; i < cand.size(); ++i)
+                if (i != best || rc != MI_OK) {
+                    (void)hipFree(cand[i]);   // (straight back to the driver, also the first one, which the pool handed out)
+                }
+            (void)hipEventDestroy(e0);
+            (void)hipEventDestroy(e1);
+            if (rc != MI_OK) { S.p = nullptr; S.bytes = 0; return rc; }
+            S.p = cand[best];
+            S.bytes = bytes;
+            t_spec = S.as<float2>() + n_buf + gap / sizeof(float2);
+            placement_ms = ms;
+            placement_kept = (int)best;
+        }
+    }
     return MI_OK;
 }
 
