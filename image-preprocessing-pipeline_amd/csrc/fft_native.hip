@@ -2130,21 +2130,27 @@ int NativeFft::init(hipStream_t s, const int F[3], bool explicit_adjoint) {
     // arrays (y passes of C3 2.96 or 3.36 ms, the update launch of the x pass 5.5 or 6.3), and which one a plain allocation gets
     // changes from region to region of the device memory: eight contexts created one after the other and all kept alive ran fast,
     // fast, fast, slow, slow, slow, fast, slow (profiles/r04_hold_contexts.txt).  Releasing and allocating again returns the same
-    // memory (round 3's placement trials); so large arrays are placed by trial WITHOUT release: up to MI_FFT_PLACEMENT_TRIES (4)
-    // candidates are allocated side by side, a forward y pass is timed on each (the contents do not matter), the fastest stays.
+    // memory (round 3's placement trials); so large arrays are placed by trial WITHOUT release: up to MI_FFT_PLACEMENT_TRIES (8)
+    // candidates are allocated side by side, a forward y pass and an update launch of the x pass are timed on each (the contents do
+    // not matter), the candidate with the smallest 4 y + update stays.
     // Costs a few passes and, for a moment, the memory of the rejected candidates; only arrays of 8 GB and more (one GPU, large
     // volumes: block and slab-rank plans are smaller and several of them share a device).
     if (vmm_order < 0 && S.bytes >= ((size_t)8 << 30)) {
-        int tries = 4;
-        if (const char* e = std::getenv("MI_FFT_PLACEMENT_TRIES")) tries = std::max(1, std::min(8, atoi(e)));
+        int tries = 8;
+        if (const char* e = std::getenv("MI_FFT_PLACEMENT_TRIES")) tries = std::max(1, std::min(10, atoi(e)));
         size_t free_b = 0, total_b = 0;
         MI_HIP(hipMemGetInfo(&free_b, &total_b));
-        const size_t bytes = S.bytes, keep = (size_t)24 << 30;   // (what the caller still allocates: volumes, scratch)
+        const size_t vol_bytes = sizeof(float) * 2 * (size_t)Hx * F[1] * F[2];
+        const size_t bytes = S.bytes, keep = ((size_t)24 << 30) + vol_bytes;   // (what the caller still allocates: volumes, scratch)
         while (tries > 1 && (size_t)(tries - 1) * bytes + keep > free_b) --tries;
         if (tries > 1) {
             hipEvent_t e0, e1;
             MI_HIP(hipEventCreate(&e0));
             MI_HIP(hipEventCreate(&e1));
+            // (a stand-in for the caller's volume: the update launch of the x pass has two speeds of its own, and they follow the
+            // spectrum arrays, not the volume -- the same context runs it equally fast on two different volumes)
+            void* xtmp = nullptr;
+            if (hipMalloc(&xtmp, vol_bytes) != hipSuccess) { (void)hipGetLastError(); xtmp = nullptr; }
             std::vector<void*> cand{S.p};
             std::vector<float> ms;
             int rc = MI_OK;
@@ -2156,7 +2162,7 @@ int NativeFft::init(hipStream_t s, const int F[3], bool explicit_adjoint) {
                 }
                 S.p = cand[i];
                 t_spec = S.as<float2>() + n_buf + gap / sizeof(float2);
-                float t = 0.0f;
+                float t = 0.0f, tx = 0.0f;
                 for (int rep = 0; rep < 2 && rc == MI_OK; ++rep) {   // (the second run counts)
                     (void)hipEventRecord(e0, s);
                     rc = y_pass(s, false, dims.paired != 0);
@@ -2164,7 +2170,16 @@ int NativeFft::init(hipStream_t s, const int F[3], bool explicit_adjoint) {
                     if (rc == MI_OK && hipEventSynchronize(e1) != hipSuccess) rc = fail(MI_ERR_HIP, "native FFT: placement trial failed");
                     if (rc == MI_OK) (void)hipEventElapsedTime(&t, e0, e1);
                 }
-                ms.push_back(t);
+                for (int rep = 0; rep < 2 && rc == MI_OK && xtmp; ++rep) {
+                    ConvEpilogue ep;
+                    ep.a = static_cast<const float*>(xtmp);
+                    (void)hipEventRecord(e0, s);
+                    rc = x_inverse(s, static_cast<float*>(xtmp), EPI_UPDATE, ep, true);
+                    (void)hipEventRecord(e1, s);
+                    if (rc == MI_OK && hipEventSynchronize(e1) != hipSuccess) rc = fail(MI_ERR_HIP, "native FFT: placement trial failed");
+                    if (rc == MI_OK) (void)hipEventElapsedTime(&tx, e0, e1);
+                }
+                ms.push_back(4.0f * t + tx);   // (an iteration runs four y passes and one update launch)
             }
             size_t best = 0;
             for (size_t i = 1; i < ms.size(); ++i)
@@ -2175,12 +2190,18 @@ int NativeFft::init(hipStream_t s, const int F[3], bool explicit_adjoint) {
                 }
             (void)hipEventDestroy(e0);
             (void)hipEventDestroy(e1);
+            if (xtmp) (void)hipFree(xtmp);
             if (rc != MI_OK) { S.p = nullptr; S.bytes = 0; return rc; }
             S.p = cand[best];
             S.bytes = bytes;
             t_spec = S.as<float2>() + n_buf + gap / sizeof(float2);
             placement_ms = ms;
             placement_kept = (int)best;
+            if (std::getenv("MI_FFT_PLACEMENT_LOG")) {   // (diagnostics on stderr: the cost 4 y + update of every candidate, the kept one)
+                std::fprintf(stderr, "native FFT: placement of %.1f GB,", (double)bytes / 1e9);
+                for (size_t i = 0; i < ms.size(); ++i) std::fprintf(stderr, " %s%.2f%s", i == best ? "[" : "", (double)ms[i], i == best ? "]" : "");
+                std::fprintf(stderr, " ms (%d of %d candidates allocated)\n", (int)cand.size(), tries);
+            }
         }
     }
     return MI_OK;
