@@ -2133,9 +2133,14 @@ int NativeFft::init(hipStream_t s, const int F[3], bool explicit_adjoint) {
     // memory (round 3's placement trials); so large arrays are placed by trial WITHOUT release: up to MI_FFT_PLACEMENT_TRIES (8)
     // candidates are allocated side by side, a forward y pass and an update launch of the x pass are timed on each (the contents do
     // not matter), the candidate with the smallest 4 y + update stays.
-    // Costs a few passes and, for a moment, the memory of the rejected candidates; only arrays of 8 GB and more (one GPU, large
-    // volumes: block and slab-rank plans are smaller and several of them share a device).
-    if (vmm_order < 0 && S.bytes >= ((size_t)8 << 30)) {
+    // Costs a few passes and, for a moment, the memory of the rejected candidates (as many as the free memory allows beside 24 GB
+    // for the caller); arrays of MI_FFT_PLACEMENT_MIN_MB (6144) and more -- the first large allocation of a fresh process is
+    // regularly the slowest candidate: slab ranks of C3 at N = 2 / 4 12.4 -> 10.1, 5.6 -> 4.9 ms of 4 y + update (N = 8, 2.4 GB: 2.81 -> 2.68;
+    // smaller plans are not tried: decwrap creates its block plans, 3-4 GB each, on several workers per device while others
+    // compute, and every released candidate is a device-wide synchronisation).
+    size_t place_min = (size_t)6 << 30;
+    if (const char* e = std::getenv("MI_FFT_PLACEMENT_MIN_MB")) place_min = (size_t)std::max(0LL, atoll(e)) << 20;
+    if (vmm_order < 0 && S.bytes >= place_min) {
         int tries = 8;
         if (const char* e = std::getenv("MI_FFT_PLACEMENT_TRIES")) tries = std::max(1, std::min(10, atoi(e)));
         size_t free_b = 0, total_b = 0;
