@@ -313,3 +313,32 @@ def test_overlap_settings_and_probe(dev):
     assert 0.0 < x_ms < 50.0 and all_ms >= 0.19
     with pytest.raises(capi.MiError, match="free_cus"):
         ctx.set_overlap(100000, True)
+
+
+def test_placement_trials_keep_one_candidate_and_the_result(dev, monkeypatch, capfd):
+    """Spectrum arrays placed by trial (fft_native.hip, NativeFft::init: several candidates allocated side by side, the one whose
+    passes run fastest stays, the others go back): forced onto a small shape, the context computes what a plain allocation computes,
+    bit for bit, and the log names the candidates."""
+    from ipp_amd import capi, decon
+    shape, kshape = (32, 64, 128), (7, 5, 9)
+    rng = np.random.default_rng(3)
+    vol = (rng.random(shape, dtype=np.float32) + 0.1)
+    psf = R.gaussian_psf(kshape, (1.5, 1.0, 2.0))
+
+    def run():
+        ctx = decon.RLContext(shape, psf, None, boundary=capi.BOUNDARY_CIRCULAR, engine=capi.ENGINE_FFT, device=dev)
+        bl = torch.from_numpy(vol).to(dev)
+        ctx.iterate(bl, None, 3)
+        return bl.cpu().numpy()
+
+    monkeypatch.setenv("MI_FFT_PLACEMENT_TRIES", "1")
+    plain = run()
+    monkeypatch.setenv("MI_FFT_PLACEMENT_TRIES", "3")
+    monkeypatch.setenv("MI_FFT_PLACEMENT_MIN_MB", "0")
+    monkeypatch.setenv("MI_FFT_PLACEMENT_LOG", "1")
+    capfd.readouterr()
+    placed = run()
+    err = capfd.readouterr().err
+    assert "3 of 3 candidates allocated" in err and "[" in err, err
+    assert np.array_equal(plain, placed)
+    assert_close(placed, R.decon_fft(vol, psf, shape, 3, skip_edgetaper=True))
