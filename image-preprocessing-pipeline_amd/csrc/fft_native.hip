@@ -2129,20 +2129,20 @@ int NativeFft::init(hipStream_t s, const int F[3], bool explicit_adjoint) {
     // ---- where the spectrum arrays lie.  The strided passes run at one of two speeds depending on the PHYSICAL memory behind the
     // arrays (y passes of C3 2.96 or 3.36 ms, the update launch of the x pass 5.5 or 6.3), and which one a plain allocation gets
     // changes from region to region of the device memory: eight contexts created one after the other and all kept alive ran fast,
-    // fast, fast, slow, slow, slow, fast, slow (profiles/r04_hold_contexts.txt).  Releasing and allocating again returns the same
-    // memory (round 3's placement trials); so large arrays are placed by trial WITHOUT release: up to MI_FFT_PLACEMENT_TRIES (8)
+    // fast, fast, slow, slow, slow, fast, slow (profiles/r04_hold_contexts.txt).  Round 3 had tried three candidates on the y pass
+    // alone (a fast one in one process of four: too few); large arrays are now placed by trial without release: up to MI_FFT_PLACE_CANDIDATES (8)
     // candidates are allocated side by side, a forward y pass and an update launch of the x pass are timed on each (the contents do
     // not matter), the candidate with the smallest 4 y + update stays.
     // Costs a few passes and, for a moment, the memory of the rejected candidates (as many as the free memory allows beside 24 GB
-    // for the caller); arrays of MI_FFT_PLACEMENT_MIN_MB (6144) and more -- the first large allocation of a fresh process is
+    // for the caller); arrays of MI_FFT_PLACE_MIN_MB (6144) and more -- the first large allocation of a fresh process is
     // regularly the slowest candidate: slab ranks of C3 at N = 2 / 4 12.4 -> 10.1, 5.6 -> 4.9 ms of 4 y + update (N = 8, 2.4 GB: 2.81 -> 2.68;
     // smaller plans are not tried: decwrap creates its block plans, 3-4 GB each, on several workers per device while others
     // compute, and every released candidate is a device-wide synchronisation).
     size_t place_min = (size_t)6 << 30;
-    if (const char* e = std::getenv("MI_FFT_PLACEMENT_MIN_MB")) place_min = (size_t)std::max(0LL, atoll(e)) << 20;
+    if (const char* e = std::getenv("MI_FFT_PLACE_MIN_MB")) place_min = (size_t)std::max(0LL, atoll(e)) << 20;
     if (vmm_order < 0 && S.bytes >= place_min) {
         int tries = 8;
-        if (const char* e = std::getenv("MI_FFT_PLACEMENT_TRIES")) tries = std::max(1, std::min(10, atoi(e)));
+        if (const char* e = std::getenv("MI_FFT_PLACE_CANDIDATES")) tries = std::max(1, std::min(10, atoi(e)));
         size_t free_b = 0, total_b = 0;
         MI_HIP(hipMemGetInfo(&free_b, &total_b));
         const size_t vol_bytes = sizeof(float) * 2 * (size_t)Hx * F[1] * F[2];
@@ -2202,7 +2202,7 @@ int NativeFft::init(hipStream_t s, const int F[3], bool explicit_adjoint) {
             t_spec = S.as<float2>() + n_buf + gap / sizeof(float2);
             placement_ms = ms;
             placement_kept = (int)best;
-            if (std::getenv("MI_FFT_PLACEMENT_LOG")) {   // (diagnostics on stderr: the cost 4 y + update of every candidate, the kept one)
+            if (std::getenv("MI_FFT_PLACE_LOG")) {   // (diagnostics on stderr: the cost 4 y + update of every candidate, the kept one)
                 std::fprintf(stderr, "native FFT: placement of %.1f GB,", (double)bytes / 1e9);
                 for (size_t i = 0; i < ms.size(); ++i) std::fprintf(stderr, " %s%.2f%s", i == best ? "[" : "", (double)ms[i], i == best ? "]" : "");
                 std::fprintf(stderr, " ms (%d of %d candidates allocated)\n", (int)cand.size(), tries);

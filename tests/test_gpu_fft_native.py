@@ -331,11 +331,11 @@ def test_placement_trials_keep_one_candidate_and_the_result(dev, monkeypatch, ca
         ctx.iterate(bl, None, 3)
         return bl.cpu().numpy()
 
-    monkeypatch.setenv("MI_FFT_PLACEMENT_TRIES", "1")
+    monkeypatch.setenv("MI_FFT_PLACE_CANDIDATES", "1")
     plain = run()
-    monkeypatch.setenv("MI_FFT_PLACEMENT_TRIES", "3")
-    monkeypatch.setenv("MI_FFT_PLACEMENT_MIN_MB", "0")
-    monkeypatch.setenv("MI_FFT_PLACEMENT_LOG", "1")
+    monkeypatch.setenv("MI_FFT_PLACE_CANDIDATES", "3")
+    monkeypatch.setenv("MI_FFT_PLACE_MIN_MB", "0")
+    monkeypatch.setenv("MI_FFT_PLACE_LOG", "1")
     capfd.readouterr()
     placed = run()
     err = capfd.readouterr().err
