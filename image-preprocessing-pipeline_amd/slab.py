@@ -425,6 +425,10 @@ class SlabRL:
         inv = None
         if flavour == "spatial" and any(k % 2 == 0 for k in self.psf.shape):
             inv = np.ascontiguousarray(self.psf[::-1, ::-1, ::-1])
+        # a rank has its device to itself (one process per GPU): also the smaller spectrum arrays of many ranks are placed by trial
+        # (fft_native.hip, NativeFft::init; the library's own limit of 6 GB keeps decwrap's concurrent block plans out)
+        import os
+        os.environ.setdefault("MI_FFT_PLACE_MIN_MB", "1024")
         self.ctx = self.ops.make_ctx(self.lshape, self.psf, boundary_xyz, shift_xyz, engine, inv)
         self.bl = torch.zeros(self.lshape, dtype=torch.float32, device=self.device)
         # fused pipeline: halos travel as x-transformed rows, no ratio volume exists
