@@ -411,6 +411,12 @@ def main():
                     # the passes run in one of two speeds per allocation (physical page placement): which one this run got
                     roofline["pass_mode"] = {"mode": "fast" if t_update < 5.95 else "slow", "x_fused_update_ms": round(t_update, 4),
                                              "note": "update launch of the x pass: ~5.6 ms (fast) or ~6.3 ms (slow) per allocation"}
+                    try:   # how the library placed the spectrum arrays (candidates' cost 4 y + update in ms, the kept one)
+                        cand, kept = ctx.fft_placement()
+                        roofline["placement"] = {"candidates_ms": cand, "kept": kept,
+                                                 "note": "plan-time trial: candidates allocated side by side, the fastest kept (DESIGN.md 5)"}
+                    except Exception:
+                        pass
             except Exception as e:  # e.g. rocFFT fallback: no per-pass hook
                 roofline = None
                 sys.stderr.write(f"per-pass timing unavailable: {e!r}\n")

@@ -523,6 +523,18 @@ extern "C" int mi_rl_time_pass(mi_rl_ctx* ctx, void* stream, int which, const fl
     return ctx->fft->native->time_pass(as_stream(stream), which, bl, reps, avg_ms);
 }
 
+extern "C" int mi_rl_fft_placement(mi_rl_ctx* ctx, float* cost_ms, int cap, int* n, int* kept) {
+    MI_REQUIRE(ctx && n && kept && (cost_ms || cap <= 0), "mi_rl_fft_placement: null pointer");
+    *n = 0;
+    *kept = -1;
+    if (!(ctx->engine == MI_ENGINE_FFT && ctx->fft && ctx->fft->native)) return MI_OK;
+    const auto& ms = ctx->fft->native->placement_ms;
+    *n = (int)ms.size();
+    *kept = ctx->fft->native->placement_kept;
+    for (int i = 0; i < *n && i < cap; ++i) cost_ms[i] = ms[i];
+    return MI_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 extern "C" int mi_conv3d(int dev, void* stream, const float* img, const float* ker, float* out, int nx, int ny, int nz, int kx, int ky,
                          int kz, int boundary, int engine) {

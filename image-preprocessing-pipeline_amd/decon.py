@@ -432,6 +432,14 @@ class RLContext:
         check(lib().mi_rl_time_pass(self._h, _stream(bl), self.PASSES[which], bl.data_ptr(), int(reps), C.byref(ms)))
         return float(ms.value)
 
+    def fft_placement(self):
+        """(costs in ms of the candidate placements of the spectrum arrays, index of the kept one): mi_rl_fft_placement.
+        ([], -1) for a plain allocation."""
+        cost = (C.c_float * 16)()
+        n, kept = C.c_int(), C.c_int()
+        check(lib().mi_rl_fft_placement(self._h, cost, 16, C.byref(n), C.byref(kept)))
+        return [round(float(cost[i]), 3) for i in range(min(n.value, 16))], int(kept.value)
+
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
             lib().mi_rl_destroy(self._h)

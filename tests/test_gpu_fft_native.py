@@ -325,8 +325,11 @@ def test_placement_trials_keep_one_candidate_and_the_result(dev, monkeypatch, ca
     vol = (rng.random(shape, dtype=np.float32) + 0.1)
     psf = R.gaussian_psf(kshape, (1.5, 1.0, 2.0))
 
+    record = []
+
     def run():
         ctx = decon.RLContext(shape, psf, None, boundary=capi.BOUNDARY_CIRCULAR, engine=capi.ENGINE_FFT, device=dev)
+        record.append(ctx.fft_placement())            # mi_rl_fft_placement
         bl = torch.from_numpy(vol).to(dev)
         ctx.iterate(bl, None, 3)
         return bl.cpu().numpy()
@@ -340,5 +343,7 @@ def test_placement_trials_keep_one_candidate_and_the_result(dev, monkeypatch, ca
     placed = run()
     err = capfd.readouterr().err
     assert "3 of 3 candidates allocated" in err and "[" in err, err
+    assert record[0] == ([], -1) and len(record[1][0]) == 3 and 0 <= record[1][1] < 3
+    assert record[1][0][record[1][1]] == min(record[1][0])
     assert np.array_equal(plain, placed)
     assert_close(placed, R.decon_fft(vol, psf, shape, 3, skip_edgetaper=True))
