@@ -99,6 +99,8 @@ SIGNATURES = {
     "mi_rl_adjoint_update": (_i, [_vp, _vp, _vp, _vp, _f, _vp]),
     "mi_rl_iterate": (_i, [_vp, _vp, _vp, _vp, _i]),
     "mi_rl_time_pass": (_i, [_vp, _vp, _i, _vp, _i, C.POINTER(C.c_float)]),
+    "mi_rl_fft_spectrum_bytes": (_sz, [_vp]),
+    "mi_rl_time_between": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, C.POINTER(C.c_float)]),
     "mi_rl_fft_placement": (_i, [_vp, C.POINTER(C.c_float), _i, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "mi_rl_reg_term": (_i, [_i, _vp, _vp, _vp, _i, _i, _i]),
     "mi_rl_spatial": (_i, [_i, _vp, _vp, _vp, _vp] + [_i] * 6 + [C.POINTER(RlOptions), _ip]),

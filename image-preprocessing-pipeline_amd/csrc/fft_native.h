@@ -56,7 +56,8 @@ struct NativeFft {
     NativeDims dims{};
     PadWindow pw{};
     DevBuf S, G, G_adj, tw;  // S: both spectrum arrays, S first
-    float2* t_spec = nullptr;  // the second spectrum array T (inside S's allocation)
+    float2* t_spec = nullptr;  // the second spectrum array T (inside S's allocation, or T2 when the arrays were placed by trial)
+    DevBuf T2;
     DevBuf Gr, Gr_adj, ph;  // real form of the OTF(s) + phase tables (symmetric PSFs), see try_real_otf
     bool real_otf = false;
     bool have_adj = false;  // adjoint = second OTF (G_adj) instead of conj(G)
@@ -102,6 +103,9 @@ struct NativeFft {
     // n fused RL iterations on bl in place (lambda = 0, no regularisation step in between)
     int iterate(hipStream_t s, float* bl, int n_iters);
     int time_pass(hipStream_t s, int which, const float* bl, int reps, float* avg_ms);
+    size_t spectrum_bytes() const { return spec_bytes; }   // one of the two spectrum arrays
+    int time_between(hipStream_t s, int which, const float2* src, float2* dst, float* bl, int reps, float* avg_ms);
+    size_t spec_bytes = 0;
     // rows [y0, y0 + rows) of S (the x-transformed input of the next convolution): dir 0 pack into buf, 1 unpack from buf, 2 zero
     // (z0, nzc: only the planes [z0, z0 + nzc), which keep their place in the packed buffer; nzc = 0: all)
     int spectrum_rows(hipStream_t s, int y0, int rows, float2* buf, int dir, int z0 = 0, int nzc = 0);
@@ -117,7 +121,7 @@ struct NativeFft {
     bool pipe_ok() const;  // the fused x pass can run as the persistent pipelined kernel
     bool splits() const;   // ... and a subset of its tiles (unpadded grids)
     TileSelect edge_tiles(int mode, int a0, int a1, int b0, int b1) const;
-    size_t device_bytes() const { return S.bytes + G.bytes + G_adj.bytes + Gr.bytes + Gr_adj.bytes + ph.bytes + tw.bytes; }
+    size_t device_bytes() const { return S.bytes + T2.bytes + G.bytes + G_adj.bytes + Gr.bytes + Gr_adj.bytes + ph.bytes + tw.bytes; }
 };
 
 }  // namespace mi

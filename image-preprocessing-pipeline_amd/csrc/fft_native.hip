@@ -2096,6 +2096,7 @@ int NativeFft::init(hipStream_t s, const int F[3], bool explicit_adjoint) {
         MI_TRY(S.alloc(sizeof(float2) * 2 * n_buf + gap));
     }
     t_spec = S.as<float2>() + n_buf + gap / sizeof(float2);
+    spec_bytes = sizeof(float2) * n_buf;
     MI_TRY(G.alloc(sizeof(float4) * (size_t)(Hx / 2 + 1) * F[1] * F[2]));
     // twiddle tables exp(-2 pi i e / N) in double on the host, per axis: e < sub/2 for the power-of-two sub-transform
     // (sub = 2^l2), followed by the full circle e < n of the radix-3/9 stage when the axis has one
@@ -2126,86 +2127,100 @@ int NativeFft::init(hipStream_t s, const int F[3], bool explicit_adjoint) {
     have_adj = explicit_adjoint;
     if (have_adj) MI_TRY(G_adj.alloc(G.bytes));  // explicit adjoint kernel (psf_inv of the 'same'-convolution flavour) instead of conj(OTF)
     MI_HIP(hipStreamSynchronize(s));  // host twiddle vector dies at scope exit
-    // ---- where the spectrum arrays lie.  The strided passes run at one of two speeds depending on the PHYSICAL memory behind the
-    // arrays (y passes of C3 2.96 or 3.36 ms, the update launch of the x pass 5.5 or 6.3), and which one a plain allocation gets
-    // changes from region to region of the device memory: eight contexts created one after the other and all kept alive ran fast,
-    // fast, fast, slow, slow, slow, fast, slow (profiles/r04_hold_contexts.txt).  Round 3 had tried three candidates on the y pass
-    // alone (a fast one in one process of four: too few); large arrays are now placed by trial without release: up to MI_FFT_PLACE_CANDIDATES (8)
-    // candidates are allocated side by side, a forward y pass and an update launch of the x pass are timed on each (the contents do
-    // not matter), the candidate with the smallest 4 y + update stays.
-    // Costs a few passes and, for a moment, the memory of the rejected candidates (as many as the free memory allows beside 24 GB
-    // for the caller); arrays of MI_FFT_PLACE_MIN_MB (6144) and more -- the first large allocation of a fresh process is
-    // regularly the slowest candidate: slab ranks of C3 at N = 2 / 4 12.4 -> 10.1, 5.6 -> 4.9 ms of 4 y + update (N = 8, 2.4 GB: 2.81 -> 2.68;
-    // smaller plans are not tried: decwrap creates its block plans, 3-4 GB each, on several workers per device while others
-    // compute, and every released candidate is a device-wide synchronisation).
+    // ---- where the spectrum arrays lie.  A strided pass runs at one of two speeds depending on the PHYSICAL memory behind the array
+    // it reads and the array it writes: K buffers of one array's size allocated side by side fall into groups (runs of ~32 GB on one
+    // box: the size of an HBM stack), and the forward y pass of C3 takes 3.10 ms between two buffers of one group, 2.98 ms across
+    // groups; the update launch of the x pass takes 6.1 instead of 5.5 ms when the array it writes shares a group with the volume
+    // (profiles/r04_spectrum_halves.txt).  Two arrays carved out of ONE allocation -- rounds 1-3 -- mostly share a group: the slow
+    // placement of those rounds, and what a fresh process' first allocation regularly gets.  So large arrays are placed by trial:
+    // up to MI_FFT_PLACE_CANDIDATES (6) buffers are allocated side by side (as many as the free memory allows beside 24 GB for the
+    // caller), the passes are timed on every ordered pair (S read by the four y passes, T read by the two z and the two x passes of
+    // an iteration: cost = 4 y(S -> T) + 3 update(T -> S), on a stand-in volume, contents do not matter), the best pair stays, the
+    // rest goes back to the driver.  ~0.5 s and, for a moment, the candidates' memory at plan creation; arrays of
+    // MI_FFT_PLACE_MIN_MB (6144, both together) and more -- smaller plans are not tried: decwrap creates its block plans, 3-4 GB
+    // each, on several workers per device while others compute, and every released candidate is a device-wide synchronisation
+    // (slab.SlabRL lowers the limit for its rank, which has its device to itself).
     size_t place_min = (size_t)6 << 30;
     if (const char* e = std::getenv("MI_FFT_PLACE_MIN_MB")) place_min = (size_t)std::max(0LL, atoll(e)) << 20;
     if (vmm_order < 0 && S.bytes >= place_min) {
-        int tries = 8;
-        if (const char* e = std::getenv("MI_FFT_PLACE_CANDIDATES")) tries = std::max(1, std::min(10, atoi(e)));
+        int tries = 6;
+        if (const char* e = std::getenv("MI_FFT_PLACE_CANDIDATES")) tries = std::max(1, std::min(8, atoi(e)));
         size_t free_b = 0, total_b = 0;
         MI_HIP(hipMemGetInfo(&free_b, &total_b));
         const size_t vol_bytes = sizeof(float) * 2 * (size_t)Hx * F[1] * F[2];
-        const size_t bytes = S.bytes, keep = ((size_t)24 << 30) + vol_bytes;   // (what the caller still allocates: volumes, scratch)
-        while (tries > 1 && (size_t)(tries - 1) * bytes + keep > free_b) --tries;
+        const size_t half = sizeof(float2) * n_buf, keep = ((size_t)24 << 30) + vol_bytes;
+        while (tries > 1 && (size_t)tries * half + keep > free_b) --tries;
         if (tries > 1) {
             hipEvent_t e0, e1;
             MI_HIP(hipEventCreate(&e0));
             MI_HIP(hipEventCreate(&e1));
-            // (a stand-in for the caller's volume: the update launch of the x pass has two speeds of its own, and they follow the
-            // spectrum arrays, not the volume -- the same context runs it equally fast on two different volumes)
+            (void)hipFree(S.p);   // (the single allocation made above makes room for the candidates)
+            S.p = nullptr;
+            const size_t block_bytes = S.bytes;
+            S.bytes = 0;
+            t_spec = nullptr;
             void* xtmp = nullptr;
             if (hipMalloc(&xtmp, vol_bytes) != hipSuccess) { (void)hipGetLastError(); xtmp = nullptr; }
-            std::vector<void*> cand{S.p};
-            std::vector<float> ms;
-            int rc = MI_OK;
-            for (int i = 0; i < tries && rc == MI_OK; ++i) {
-                if (i > 0) {
-                    void* q = nullptr;
-                    if (hipMalloc(&q, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
-                    cand.push_back(q);
-                }
-                S.p = cand[i];
-                t_spec = S.as<float2>() + n_buf + gap / sizeof(float2);
-                float t = 0.0f, tx = 0.0f;
-                for (int rep = 0; rep < 2 && rc == MI_OK; ++rep) {   // (the second run counts)
-                    (void)hipEventRecord(e0, s);
-                    rc = y_pass(s, false, dims.paired != 0);
-                    (void)hipEventRecord(e1, s);
-                    if (rc == MI_OK && hipEventSynchronize(e1) != hipSuccess) rc = fail(MI_ERR_HIP, "native FFT: placement trial failed");
-                    if (rc == MI_OK) (void)hipEventElapsedTime(&t, e0, e1);
-                }
-                for (int rep = 0; rep < 2 && rc == MI_OK && xtmp; ++rep) {
-                    ConvEpilogue ep;
-                    ep.a = static_cast<const float*>(xtmp);
-                    (void)hipEventRecord(e0, s);
-                    rc = x_inverse(s, static_cast<float*>(xtmp), EPI_UPDATE, ep, true);
-                    (void)hipEventRecord(e1, s);
-                    if (rc == MI_OK && hipEventSynchronize(e1) != hipSuccess) rc = fail(MI_ERR_HIP, "native FFT: placement trial failed");
-                    if (rc == MI_OK) (void)hipEventElapsedTime(&tx, e0, e1);
-                }
-                ms.push_back(4.0f * t + tx);   // (an iteration runs four y passes and one update launch)
+            std::vector<void*> cand;
+            for (int i = 0; i < tries; ++i) {
+                void* q = nullptr;
+                if (hipMalloc(&q, half) != hipSuccess) { (void)hipGetLastError(); break; }
+                cand.push_back(q);
             }
-            size_t best = 0;
-            for (size_t i = 1; i < ms.size(); ++i)
-                if (ms[i] < ms[best]) best = i;
-            for (size_t i = 0; i < cand.size(); ++i)
-                if (i != best || rc != MI_OK) {
-                    (void)hipFree(cand[i]);   // (straight back to the driver, also the first one, which the pool handed out)
+            const int K = (int)cand.size();
+            int rc = MI_OK, bi = -1, bj = -1, kept_idx = -1;
+            float best = 0.0f;
+            std::vector<float> ms;
+            auto timed = [&](auto&& launch, float* out) {   // (two launches, the second counts)
+                for (int rep = 0; rep < 2 && rc == MI_OK; ++rep) {
+                    (void)hipEventRecord(e0, s);
+                    rc = launch();
+                    (void)hipEventRecord(e1, s);
+                    if (rc == MI_OK && hipEventSynchronize(e1) != hipSuccess) rc = fail(MI_ERR_HIP, "native FFT: placement trial failed");
+                    if (rc == MI_OK) (void)hipEventElapsedTime(out, e0, e1);
+                }
+            };
+            for (int i = 0; i < K && rc == MI_OK; ++i)
+                for (int j = 0; j < K && rc == MI_OK; ++j) {
+                    if (i == j) continue;
+                    S.p = cand[i];
+                    t_spec = static_cast<float2*>(cand[j]);
+                    float ty = 0.0f, tx = 0.0f;
+                    timed([&] { return y_pass(s, false, dims.paired != 0); }, &ty);
+                    if (xtmp) {
+                        ConvEpilogue ep;
+                        ep.a = static_cast<const float*>(xtmp);
+                        timed([&] { return x_inverse(s, static_cast<float*>(xtmp), EPI_UPDATE, ep, true); }, &tx);
+                    }
+                    const float cost = 4.0f * ty + 3.0f * tx;
+                    if (bi < 0 || cost < best) { best = cost; bi = i; bj = j; kept_idx = (int)ms.size(); }
+                    ms.push_back(cost);
                 }
             (void)hipEventDestroy(e0);
             (void)hipEventDestroy(e1);
             if (xtmp) (void)hipFree(xtmp);
-            if (rc != MI_OK) { S.p = nullptr; S.bytes = 0; return rc; }
-            S.p = cand[best];
-            S.bytes = bytes;
-            t_spec = S.as<float2>() + n_buf + gap / sizeof(float2);
-            placement_ms = ms;
-            placement_kept = (int)best;
-            if (std::getenv("MI_FFT_PLACE_LOG")) {   // (diagnostics on stderr: the cost 4 y + update of every candidate, the kept one)
-                std::fprintf(stderr, "native FFT: placement of %.1f GB,", (double)bytes / 1e9);
-                for (size_t i = 0; i < ms.size(); ++i) std::fprintf(stderr, " %s%.2f%s", i == best ? "[" : "", (double)ms[i], i == best ? "]" : "");
-                std::fprintf(stderr, " ms (%d of %d candidates allocated)\n", (int)cand.size(), tries);
+            for (int i = 0; i < K; ++i)
+                if (rc != MI_OK || bi < 0 || (i != bi && i != bj)) (void)hipFree(cand[i]);
+            S.p = nullptr;
+            t_spec = nullptr;
+            if (rc != MI_OK) return rc;
+            if (bi < 0) {   // (fewer than two candidates: back to the single allocation)
+                MI_TRY(S.alloc(block_bytes));
+                t_spec = S.as<float2>() + n_buf + gap / sizeof(float2);
+            } else {
+                S.p = cand[bi];
+                S.bytes = half;
+                T2.p = cand[bj];
+                T2.bytes = half;
+                t_spec = T2.as<float2>();
+                placement_ms = ms;
+                placement_kept = kept_idx;   // (index in the list of ordered pairs (i, j), i != j, i slowest)
+                if (std::getenv("MI_FFT_PLACE_LOG")) {   // (diagnostics on stderr)
+                    float worst = best;
+                    for (float v : ms) worst = std::max(worst, v);
+                    std::fprintf(stderr, "native FFT: 2 x %.1f GB placed on buffers %d (S) and %d (T) of %d: 4 y + 3 update %.2f ms (pairs from %.2f to %.2f)\n",
+                                 (double)half / 1e9, bi, bj, K, (double)best, (double)best, (double)worst);
+                }
             }
         }
     }
@@ -2776,6 +2791,38 @@ int NativeFft::time_pass(hipStream_t s, int which, const float* bl, int reps, fl
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     if (rc == MI_OK && he != hipSuccess) rc = fail(MI_ERR_HIP, "time_pass: %s", hipGetErrorString(he));
+    *avg_ms = ms / (float)reps;
+    return rc;
+}
+
+int NativeFft::time_between(hipStream_t s, int which, const float2* src, float2* dst, float* bl, int reps, float* avg_ms) {
+    hipEvent_t e0, e1;
+    MI_HIP(hipEventCreate(&e0));
+    MI_HIP(hipEventCreate(&e1));
+    int rc = MI_OK;
+    void* const s_own = S.p;
+    float2* const t_own = t_spec;
+    ConvEpilogue ep;
+    ep.a = bl;
+    for (int r = -1; r < reps && rc == MI_OK; ++r) {
+        if (r == 0) (void)hipEventRecord(e0, s);
+        if (which == 0) {
+            rc = y_pass(s, false, dims.paired != 0, src, dst);
+        } else {   // the update launch reads T and writes S: the two buffers stand in for them
+            t_spec = const_cast<float2*>(src);
+            S.p = dst;
+            rc = x_inverse(s, bl, EPI_UPDATE, ep, true);
+            S.p = s_own;
+            t_spec = t_own;
+        }
+    }
+    (void)hipEventRecord(e1, s);
+    hipError_t he = hipEventSynchronize(e1);
+    float ms = 0.0f;
+    if (he == hipSuccess) he = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc == MI_OK && he != hipSuccess) rc = fail(MI_ERR_HIP, "time_between: %s", hipGetErrorString(he));
     *avg_ms = ms / (float)reps;
     return rc;
 }

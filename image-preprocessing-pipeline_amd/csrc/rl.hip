@@ -523,6 +523,19 @@ extern "C" int mi_rl_time_pass(mi_rl_ctx* ctx, void* stream, int which, const fl
     return ctx->fft->native->time_pass(as_stream(stream), which, bl, reps, avg_ms);
 }
 
+extern "C" size_t mi_rl_fft_spectrum_bytes(mi_rl_ctx* ctx) {
+    if (!(ctx && ctx->engine == MI_ENGINE_FFT && ctx->fft && ctx->fft->native)) return 0;
+    return ctx->fft->native->spectrum_bytes();
+}
+
+extern "C" int mi_rl_time_between(mi_rl_ctx* ctx, void* stream, int which, const void* src, void* dst, float* bl, int reps, float* avg_ms) {
+    MI_REQUIRE(ctx && src && dst && avg_ms && reps > 0 && (which == 0 || (which == 1 && bl)), "mi_rl_time_between: bad arguments");
+    MI_TRY(use_device(ctx->dev));
+    if (!(ctx->engine == MI_ENGINE_FFT && ctx->fft->native && !ctx->fft->padded))
+        return fail(MI_ERR_UNSUPPORTED, "mi_rl_time_between: only the unpadded native FFT pipeline");
+    return ctx->fft->native->time_between(as_stream(stream), which, static_cast<const float2*>(src), static_cast<float2*>(dst), bl, reps, avg_ms);
+}
+
 extern "C" int mi_rl_fft_placement(mi_rl_ctx* ctx, float* cost_ms, int cap, int* n, int* kept) {
     MI_REQUIRE(ctx && n && kept && (cost_ms || cap <= 0), "mi_rl_fft_placement: null pointer");
     *n = 0;

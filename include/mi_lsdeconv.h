@@ -201,6 +201,14 @@ int mi_rl_overlap_probe(mi_rl_ctx* ctx, void* stream, float* bl, const int* edge
  * 4 fused x-inverse+ratio+x-forward, 5 fused x-inverse+update+x-forward -- this one OVERWRITES bl with values that mean
  * nothing).  MI_ERR_UNSUPPORTED for other engines.  Synchronises. */
 int mi_rl_time_pass(mi_rl_ctx* ctx, void* stream, int which, const float* bl, int reps, float* avg_ms);
+/* Measurement hook: one pass of the native FFT pipeline between two caller-given spectrum buffers (device buffers of
+ * mi_rl_fft_spectrum_bytes(ctx) bytes each, contents arbitrary) instead of the context's own arrays -- which 0: the forward
+ * y pass reading `src`, writing `dst`; which 1: the update launch of the fused x pass reading `src` (in the role of T),
+ * writing `dst` (in the role of S) and reading / writing the volume `bl` (overwritten with values that mean nothing).
+ * Average ms of `reps` launches (profiles/spectrum_halves_probe.py: a buffer's memory region decides how fast it is read
+ * and how fast it is written, independently of its partner).  Synchronises. */
+size_t mi_rl_fft_spectrum_bytes(mi_rl_ctx* ctx);
+int mi_rl_time_between(mi_rl_ctx* ctx, void* stream, int which, const void* src, void* dst, float* bl, int reps, float* avg_ms);
 /* Measurement hook: how the spectrum arrays of the native FFT pipeline were placed when the context was created (candidates
  * allocated side by side, "4 y passes + update launch" timed on each, the fastest kept: csrc/fft_native.hip, NativeFft::init).
  * Writes up to `cap` candidate costs in ms to cost_ms, the number of candidates to *n (0: a plain allocation) and the index

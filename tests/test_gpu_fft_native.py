@@ -316,9 +316,9 @@ def test_overlap_settings_and_probe(dev):
 
 
 def test_placement_trials_keep_one_candidate_and_the_result(dev, monkeypatch, capfd):
-    """Spectrum arrays placed by trial (fft_native.hip, NativeFft::init: several candidates allocated side by side, the one whose
-    passes run fastest stays, the others go back): forced onto a small shape, the context computes what a plain allocation computes,
-    bit for bit, and the log names the candidates."""
+    """Spectrum arrays placed by trial (fft_native.hip, NativeFft::init: several buffers allocated side by side, the ordered pair on
+    which the passes run fastest becomes (S, T), the others go back): forced onto a small shape, the context computes what a plain
+    allocation computes, bit for bit, and the log and mi_rl_fft_placement name the pairs."""
     from ipp_amd import capi, decon
     shape, kshape = (32, 64, 128), (7, 5, 9)
     rng = np.random.default_rng(3)
@@ -342,8 +342,8 @@ def test_placement_trials_keep_one_candidate_and_the_result(dev, monkeypatch, ca
     capfd.readouterr()
     placed = run()
     err = capfd.readouterr().err
-    assert "3 of 3 candidates allocated" in err and "[" in err, err
-    assert record[0] == ([], -1) and len(record[1][0]) == 3 and 0 <= record[1][1] < 3
+    assert "(T) of 3" in err and "placed on buffers" in err, err
+    assert record[0] == ([], -1) and len(record[1][0]) == 6 and 0 <= record[1][1] < 6      # the ordered pairs of three buffers
     assert record[1][0][record[1][1]] == min(record[1][0])
     assert np.array_equal(plain, placed)
     assert_close(placed, R.decon_fft(vol, psf, shape, 3, skip_edgetaper=True))
