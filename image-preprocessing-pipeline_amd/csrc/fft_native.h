@@ -57,7 +57,7 @@ struct NativeFft {
     PadWindow pw{};
     DevBuf S, G, G_adj, tw;  // S: both spectrum arrays, S first
     float2* t_spec = nullptr;  // the second spectrum array T (inside S's allocation, or T2 when the arrays were placed by trial)
-    DevBuf T2;
+    DevBuf T2, S_alt;  // S_alt: a second buffer for S, kept until the caller's volume is known (settle_s)
     DevBuf Gr, Gr_adj, ph;  // real form of the OTF(s) + phase tables (symmetric PSFs), see try_real_otf
     bool real_otf = false;
     bool have_adj = false;  // adjoint = second OTF (G_adj) instead of conj(G)
@@ -104,6 +104,10 @@ struct NativeFft {
     int iterate(hipStream_t s, float* bl, int n_iters);
     int time_pass(hipStream_t s, int which, const float* bl, int reps, float* avg_ms);
     size_t spectrum_bytes() const { return spec_bytes; }   // one of the two spectrum arrays
+    void settle_before_update();
+    int settle_decide(hipStream_t s);
+    int alt_phase = 0;                 // 0 / 1: the next timed update launch writes the first / second S buffer; 2: decide; 3: settled
+    hipEvent_t alt_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     int time_between(hipStream_t s, int which, const float2* src, float2* dst, float* bl, int reps, float* avg_ms);
     size_t spec_bytes = 0;
     // rows [y0, y0 + rows) of S (the x-transformed input of the next convolution): dir 0 pack into buf, 1 unpack from buf, 2 zero
@@ -121,7 +125,7 @@ struct NativeFft {
     bool pipe_ok() const;  // the fused x pass can run as the persistent pipelined kernel
     bool splits() const;   // ... and a subset of its tiles (unpadded grids)
     TileSelect edge_tiles(int mode, int a0, int a1, int b0, int b1) const;
-    size_t device_bytes() const { return S.bytes + T2.bytes + G.bytes + G_adj.bytes + Gr.bytes + Gr_adj.bytes + ph.bytes + tw.bytes; }
+    size_t device_bytes() const { return S.bytes + T2.bytes + S_alt.bytes + G.bytes + G_adj.bytes + Gr.bytes + Gr_adj.bytes + ph.bytes + tw.bytes; }
 };
 
 }  // namespace mi

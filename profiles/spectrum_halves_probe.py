@@ -47,3 +47,4 @@ def table(which, what):
 
 table(0, "forward y pass")
 table(1, "update launch of the x pass")
+table(2, "forward x pass (reads the volume, writes buffer j; i unused)")
