@@ -414,7 +414,7 @@ def main():
                     try:   # how the library placed the spectrum arrays (candidates' cost 4 y + update in ms, the kept one)
                         cand, kept = ctx.fft_placement()
                         roofline["placement"] = {"candidates_ms": cand, "kept": kept,
-                                                 "note": "plan-time trial: candidates allocated side by side, the fastest kept (DESIGN.md 5)"}
+                                                 "note": "plan-time trial: buffers allocated side by side, cost 4 y + 3 update of every ordered pair (S, T), the cheapest kept (DESIGN.md 5)"}
                     except Exception:
                         pass
             except Exception as e:  # e.g. rocFFT fallback: no per-pass hook

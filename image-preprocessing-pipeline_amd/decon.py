@@ -433,12 +433,13 @@ class RLContext:
         return float(ms.value)
 
     def fft_placement(self):
-        """(costs in ms of the candidate placements of the spectrum arrays, index of the kept one): mi_rl_fft_placement.
+        """(costs in ms of the candidate placements of the spectrum arrays -- the ordered pairs (S, T) of the buffers tried --, index of
+        the kept one): mi_rl_fft_placement.
         ([], -1) for a plain allocation."""
-        cost = (C.c_float * 16)()
+        cost = (C.c_float * 64)()           # (ordered pairs of up to eight buffers)
         n, kept = C.c_int(), C.c_int()
-        check(lib().mi_rl_fft_placement(self._h, cost, 16, C.byref(n), C.byref(kept)))
-        return [round(float(cost[i]), 3) for i in range(min(n.value, 16))], int(kept.value)
+        check(lib().mi_rl_fft_placement(self._h, cost, 64, C.byref(n), C.byref(kept)))
+        return [round(float(cost[i]), 3) for i in range(min(n.value, 64))], int(kept.value)
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:

@@ -212,8 +212,8 @@ size_t mi_rl_fft_spectrum_bytes(mi_rl_ctx* ctx);
 int mi_rl_time_between(mi_rl_ctx* ctx, void* stream, int which, const void* src, void* dst, float* bl, int reps, float* avg_ms);
 /* Measurement hook: how the spectrum arrays of the native FFT pipeline were placed when the context was created (candidates
  * allocated side by side, "4 y passes + update launch" timed on each, the fastest kept: csrc/fft_native.hip, NativeFft::init).
- * Writes up to `cap` candidate costs in ms to cost_ms, the number of candidates to *n (0: a plain allocation) and the index
- * of the kept one to *kept.  No reference counterpart (the reference allocates inside MATLAB's gpuArray). */
+ * Writes up to `cap` candidate costs in ms to cost_ms -- one per ordered pair (S, T) of the buffers tried, S slowest --, their
+ * number to *n (0: a plain allocation) and the index of the kept pair to *kept.  No reference counterpart (the reference allocates inside MATLAB's gpuArray). */
 int mi_rl_fft_placement(mi_rl_ctx* ctx, float* cost_ms, int cap, int* n, int* kept);
 /* reg = convn(bl, R, 'same'), R = ones(3,3,3)/26 with centre 0   [decon.m:42,70] */
 int mi_rl_reg_term(int dev, void* stream, const float* bl, float* reg, int nx, int ny, int nz);
