@@ -2257,6 +2257,13 @@ static int launch_lds(K kernel, unsigned grid, int threads, size_t lds, hipStrea
 
 void NativeFft::set_window(const int n[3], const int o[3], const int rep[3], const int k[3]) {
     pw.on = 1;
+    if (S_alt.p && alt_phase < 3) {   // (padded grids do not settle S on their update launches: the second buffer is not needed)
+        if (alt_phase == 1 || alt_phase == 2) { /* nothing to undo: S.p is whichever buffer the last launch wrote */ }
+        (void)hipFree(S_alt.p);
+        S_alt.p = nullptr;
+        S_alt.bytes = 0;
+        alt_phase = 3;
+    }
     for (int a = 0; a < 3; ++a) {
         pw.n[a] = n[a];
         pw.o[a] = o[a];
