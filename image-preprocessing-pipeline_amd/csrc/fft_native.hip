@@ -2203,9 +2203,11 @@ int NativeFft::init(hipStream_t s, const int F[3], bool explicit_adjoint) {
             // a second buffer for S stays until the first call that brings the caller's volume: the update launch is slow when S
             // shares a region with THAT volume, which nothing here can know (NativeFft::iterate settles it: settle_s)
             int bk = -1;
-            if (rc == MI_OK && bi >= 0 && half >= ((size_t)8 << 30))
+            size_t alt_min = (size_t)8 << 30;   // (MI_FFT_PLACE_ALT_MIN_MB: the smallest array that keeps a second buffer for S)
+            if (const char* e = std::getenv("MI_FFT_PLACE_ALT_MIN_MB")) alt_min = (size_t)std::max(0LL, atoll(e)) << 20;
+            if (rc == MI_OK && bi >= 0 && half >= alt_min)
                 for (int k = 0; k < K; ++k)
-                    if (k != bi && k != bj && tyv[(size_t)k * K + bj] <= 1.03f * tyv[(size_t)bi * K + bj] &&
+                    if (k != bi && k != bj && tyv[(size_t)k * K + bj] <= 1.03f * tyv[(size_t)bi * K + bj] + 0.02f &&
                         (bk < 0 || tyv[(size_t)k * K + bj] < tyv[(size_t)bk * K + bj]))
                         bk = k;
             for (int i = 0; i < K; ++i)

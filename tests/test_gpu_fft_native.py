@@ -327,11 +327,12 @@ def test_placement_trials_keep_one_candidate_and_the_result(dev, monkeypatch, ca
 
     record = []
 
-    def run():
+    def run(calls=(3,)):
         ctx = decon.RLContext(shape, psf, None, boundary=capi.BOUNDARY_CIRCULAR, engine=capi.ENGINE_FFT, device=dev)
         record.append(ctx.fft_placement())            # mi_rl_fft_placement
         bl = torch.from_numpy(vol).to(dev)
-        ctx.iterate(bl, None, 3)
+        for n in calls:
+            ctx.iterate(bl, None, n)
         return bl.cpu().numpy()
 
     monkeypatch.setenv("MI_FFT_PLACE_CANDIDATES", "1")
@@ -347,3 +348,14 @@ def test_placement_trials_keep_one_candidate_and_the_result(dev, monkeypatch, ca
     assert record[1][0][record[1][1]] == min(record[1][0])
     assert np.array_equal(plain, placed)
     assert_close(placed, R.decon_fft(vol, psf, shape, 3, skip_edgetaper=True))
+    # a second buffer for S, settled on the loop's own update launches: inside one call of five iterations, and across calls of two
+    monkeypatch.setenv("MI_FFT_PLACE_ALT_MIN_MB", "0")
+    monkeypatch.setenv("MI_FFT_PLACE_CANDIDATES", "1")
+    plain5 = run((5,))
+    monkeypatch.setenv("MI_FFT_PLACE_CANDIDATES", "4")
+    capfd.readouterr()
+    one_call = run((5,))
+    assert "S settled on the" in capfd.readouterr().err
+    across = run((2, 2, 1))
+    assert "S settled on the" in capfd.readouterr().err
+    assert np.array_equal(plain5, one_call) and np.array_equal(plain5, across)
