@@ -2833,6 +2833,14 @@ int NativeFft::time_between(hipStream_t s, int which, const float2* src, float2*
             S.p = dst;
             rc = x_forward(s, bl);
             S.p = s_own;
+        } else if (which == 3) {   // the z pass reads T (and the OTF), writes S
+            rc = z_conv(s, false, src, dst);
+        } else if (which == 4) {   // the z pass on the context's own arrays with `src` standing in for the (real) OTF
+            void* const g_own = Gr.p;
+            if (!g_own) { rc = fail(MI_ERR_UNSUPPORTED, "time_between: no real OTF"); break; }
+            Gr.p = const_cast<float2*>(src);
+            rc = z_conv(s, false);
+            Gr.p = g_own;
         } else {   // the update launch reads T and writes S: the two buffers stand in for them
             t_spec = const_cast<float2*>(src);
             S.p = dst;

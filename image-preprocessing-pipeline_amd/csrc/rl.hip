@@ -529,7 +529,7 @@ extern "C" size_t mi_rl_fft_spectrum_bytes(mi_rl_ctx* ctx) {
 }
 
 extern "C" int mi_rl_time_between(mi_rl_ctx* ctx, void* stream, int which, const void* src, void* dst, float* bl, int reps, float* avg_ms) {
-    MI_REQUIRE(ctx && src && dst && avg_ms && reps > 0 && (which == 0 || ((which == 1 || which == 2) && bl)), "mi_rl_time_between: bad arguments");
+    MI_REQUIRE(ctx && src && dst && avg_ms && reps > 0 && (which == 0 || which == 3 || which == 4 || ((which == 1 || which == 2) && bl)), "mi_rl_time_between: bad arguments");
     MI_TRY(use_device(ctx->dev));
     if (!(ctx->engine == MI_ENGINE_FFT && ctx->fft->native && !ctx->fft->padded))
         return fail(MI_ERR_UNSUPPORTED, "mi_rl_time_between: only the unpadded native FFT pipeline");

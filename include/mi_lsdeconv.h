@@ -205,7 +205,8 @@ int mi_rl_time_pass(mi_rl_ctx* ctx, void* stream, int which, const float* bl, in
  * mi_rl_fft_spectrum_bytes(ctx) bytes each, contents arbitrary) instead of the context's own arrays -- which 0: the forward
  * y pass reading `src`, writing `dst`; which 1: the update launch of the fused x pass reading `src` (in the role of T),
  * writing `dst` (in the role of S) and reading / writing the volume `bl` (overwritten with values that mean nothing);
- * which 2: the forward x pass reading the volume `bl`, writing `dst` (`src` unused).
+ * which 2: the forward x pass reading the volume `bl`, writing `dst` (`src` unused); which 3: the z pass reading `src`, writing
+ * `dst`; which 4: the z pass on the context's own arrays with `src` in the place of the real OTF (`dst` unused).
  * Average ms of `reps` launches (profiles/spectrum_halves_probe.py: a buffer's memory region decides how fast it is read
  * and how fast it is written, independently of its partner).  Synchronises. */
 size_t mi_rl_fft_spectrum_bytes(mi_rl_ctx* ctx);

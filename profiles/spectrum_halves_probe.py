@@ -47,4 +47,5 @@ def table(which, what):
 
 table(0, "forward y pass")
 table(1, "update launch of the x pass")
-table(2, "forward x pass (reads the volume, writes buffer j; i unused)")
+table(3, "z pass")
+table(4, "z pass on the context's own arrays, buffer i in the place of the OTF (j unused)")
