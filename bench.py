@@ -26,6 +26,7 @@ WORKLOADS = {  # name: (volume (z,y,x), psf (z,y,x))
     "c1": ((64, 256, 256), (15, 9, 9)),
     "c2": ((256, 1024, 1024), (31, 15, 15)),
     "c3": ((512, 2048, 2048), (61, 31, 31)),
+    "c4": ((1024, 4096, 4096), (127, 63, 63)),   # whole on ONE device: 241 GB of the 288 (--workload c4, or the c4_single row at N = 1)
 }
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec (MI355X_MICROARCH.md, chip-level parameters)
 ALGO_BYTES_PER_VOXEL_ITER = 48  # RL FFT path, SURVEY.md section 8d / DESIGN.md

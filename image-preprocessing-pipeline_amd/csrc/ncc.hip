@@ -219,7 +219,7 @@ static int ncc_batch(int dev, void* stream, int n_pairs, const float* const* til
             f.pa.resize(n); f.pb.resize(n); f.pp.resize(n);
             for (int i = 0; i < n; ++i) { f.pa[i] = tiles[a_idx[idx[i]]]; f.pb[i] = tiles[b_idx[idx[i]]]; f.pp[i] = params[idx[i]]; }
             rc = ncc_lag_enqueue(dev, user, n, f.pa.data(), f.pb.data(), dimk, dimi, dimj, ni[q0], nj[q0], delayk, delayi, delayj, side[q0],
-                                 f.pp.data(), &f.job, serial_mips, fmt, (int)groups.size());
+                                 f.pp.data(), &f.job, serial_mips, fmt, (int)groups.size(), flights.size() > 1 && !serial_mips);
             if (rc != MI_OK) break;
         }
         if (rc == MI_OK && serial_mips && !flights.empty()) {

@@ -269,6 +269,151 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
 }
 
+// ---- k_mips5: the float pass for stacks of up to 4 * MIP_KPW slices (every C5-like stack), round-5 form of k_mips<true>.  Same
+// patches, same slice pipeline (a work-group owns 16 rows x 64 columns x MIP_NB bands, its four waves share the slices, the next
+// slice is requested before the current one is reduced, nothing is stored before the last load).  What changed:
+//  * addressing: BUFFER loads -- the slice's first row is the descriptor base (wave-uniform, five scalar instructions per slice), the 16
+//    row offsets of the wave's band wait in SGPRs (recomputed when the band changes, once per 8 slices) and go into the instruction's
+//    scalar offset, the lane's column into its vector offset.  k_mips<true> rebuilt 16 64-bit row addresses per slice: 92 scalar
+//    instructions per slice against 155 vector ones (profiles/r04_ncc_sq_counters.txt).
+//  * no partial maxima in memory: the column maxima (yz) and row maxima (xz) a work-group has gathered in LDS are merged into the
+//    MIPs themselves with integer atomic maxima (non-negative floats order like their bit patterns), 256 contiguous bytes per wave
+//    instruction, ONCE per work-group -- 0.29 GB per 56-pair launch were written as yz_tmp / xz_tmp and read back by k_mips_yz /
+//    k_mips_xz.  The MIPs must be zero when the pass starts (k_mips_zero).
+//  * LDS images without bank conflicts: the row maxima at a stride of 33 words (16 lanes stored at a stride of dimk = 32 words: one
+//    bank), the xy rows and column maxima at 65 (the transposed copy read them at a stride of 64 words: one bank for 64 lanes).
+constexpr int MIP5_XS = 4 * MIP_KPW + 1;  // words per row of the xz image
+__global__ __launch_bounds__(256) void k_mips_zero(size_t pstride, size_t n_xz, size_t n_yz, float* __restrict__ xz1, float* __restrict__ yz1,
+                                                   float* __restrict__ xz2, float* __restrict__ yz2) {
+    const size_t poff = (size_t)(blockIdx.y >> 1) * pstride;
+    float* xz = ((blockIdx.y & 1) ? xz2 : xz1) + poff;
+    float* yz = ((blockIdx.y & 1) ? yz2 : yz1) + poff;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n_xz + n_yz; e += (size_t)gridDim.x * 256) {
+        if (e < n_xz) xz[e] = 0.0f;
+        else yz[e - n_xz] = 0.0f;
+    }
+}
+
+template <int WPE>  // waves per SIMD = work-groups per compute unit
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_mips5(
+    const float* __restrict__ A, const float* __restrict__ B, const float* const* __restrict__ tab, size_t pstride, int dimk, int dimi_v, int dimj_v,
+    size_t slice, int pitch, int ai0, int aj0, float* __restrict__ xy1, float* __restrict__ xz1, float* __restrict__ yz1, float* __restrict__ xy2,
+    float* __restrict__ xz2, float* __restrict__ yz2, int knock, float* __restrict__ xyT, size_t tstride) {
+    __shared__ float xyb[MIP_NB][MIP_ROWS][65];        // xy maxima of the bands (merged across the waves with LDS atomics)
+    __shared__ float cacc[4][MIP_KPW][65];             // column maxima of the wave's slices over all bands: slice k = wave + 4 q
+    __shared__ float xzp[MIP_NB * MIP_ROWS][MIP5_XS];  // row maxima over the patch's 64 columns
+    const bool second = blockIdx.z & 1;
+    const size_t poff = (size_t)(blockIdx.z >> 1) * pstride;
+    const float* vol = tab ? tab[blockIdx.z] : (second ? B : A);
+    if (!second) vol += (size_t)ai0 * pitch + aj0;
+    float* xy = (second ? xy2 : xy1) + poff;
+    float* xz = (second ? xz2 : xz1) + poff;
+    float* yz = (second ? yz2 : yz1) + poff;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int jshift = second ? 0 : (aj0 & 63);  // column blocks start on 256-byte boundaries of the TILE rows (see k_mips)
+    const int j = (int)blockIdx.x * 64 + lane - jshift;
+    const bool live = j >= 0 && j < dimj_v;
+    float* colacc = &cacc[wave][0][lane];
+#pragma unroll
+    for (int q = 0; q < MIP_KPW; ++q) colacc[q * 65] = 0.0f;
+    for (int e = threadIdx.x; e < MIP_NB * MIP_ROWS * 65; e += 256) (&xyb[0][0][0])[e] = 0.0f;
+    const int ib0 = __builtin_amdgcn_readfirstlane((int)blockIdx.y * MIP_NB * MIP_ROWS);
+    const int nbv = min(MIP_NB, (dimi_v - ib0 + MIP_ROWS - 1) / MIP_ROWS);  // bands of this work-group inside the view (>= 1)
+    float v[MIP_ROWS], vn[MIP_ROWS];
+    // every load is unconditional (see k_mips): lanes outside the view read its nearest column, rows past the last band its last row
+    const int voff = 4 * min(max(j, 0), dimj_v - 1);
+    const int pitch4 = 4 * pitch;
+    int ro[MIP_ROWS];  // byte offsets of the 16 rows of the band being REQUESTED from the first row of its slice (scalars)
+    auto set_band = [&](int bb) {
+        const int last = min(MIP_ROWS, dimi_v - (ib0 + bb * MIP_ROWS)) - 1;
+#pragma unroll
+        for (int r = 0; r < MIP_ROWS; ++r) ro[r] = __builtin_amdgcn_readfirstlane(min(r, last) * pitch4);
+    };
+    auto load_slice = [&](int bb, int k, float (&dst)[MIP_ROWS]) {
+        const float* p = vol + (size_t)k * slice + (size_t)(ib0 + bb * MIP_ROWS) * pitch;  // wave-uniform
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+        for (int r = 0; r < MIP_ROWS; ++r) dst[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, ro[r], 0));
+    };
+    set_band(0);
+    if (wave < dimk) load_slice(0, wave, v);
+    __syncthreads();  // (the LDS images are zero)
+#pragma unroll 1
+    for (int b = 0; b < nbv; ++b) {
+        float best[MIP_ROWS];
+#pragma unroll
+        for (int r = 0; r < MIP_ROWS; ++r) best[r] = 0.0f;
+        auto slice_step = [&](int k, int q, float (&cur)[MIP_ROWS], float (&nxt)[MIP_ROWS]) {
+            const bool wrap = k + 4 >= dimk;  // (wave-uniform)
+            const int kn = __builtin_amdgcn_readfirstlane(wrap ? wave : k + 4);
+            // (behind the work-group's last slice there is nothing to fetch: the first slice of its last band is read once more --
+            // one slice in 128 -- so that the number of loads in flight is the same in every step)
+            const int bn = __builtin_amdgcn_readfirstlane(wrap ? min(b + 1, nbv - 1) : b);
+            if (wrap) set_band(bn);
+            load_slice(bn, kn, nxt);
+            float colmax = 0.0f;
+#pragma unroll
+            for (int r = 0; r < MIP_ROWS; ++r) {
+                best[r] = fmaxf(best[r], cur[r]);
+                colmax = fmaxf(colmax, cur[r]);
+            }
+            if (!(knock & 1)) {
+                const float rowmax = rows_max16(cur, lane);
+                if (lane < 16) xzp[b * MIP_ROWS + row_of_lane(lane)][k] = rowmax;
+            }
+            if (!(knock & 2)) colacc[q * 65] = fmaxf(colacc[q * 65], colmax);
+        };
+        int k = wave, q = 0;
+#pragma unroll 1
+        for (; k + 4 < dimk; k += 8, q += 2) {
+            slice_step(k, q, v, vn);
+            slice_step(k + 4, q + 1, vn, v);
+        }
+        if (k < dimk) {  // an odd number of slices: the next band's first slice has arrived in the other buffer
+            slice_step(k, q, v, vn);
+#pragma unroll
+            for (int r = 0; r < MIP_ROWS; ++r) v[r] = vn[r];
+        }
+        // xy: maximum over the four waves' slices
+#pragma unroll
+        for (int r = 0; r < MIP_ROWS; ++r) atomic_max_nonneg(&xyb[b][r][lane], best[r]);
+    }
+    __syncthreads();
+    if (wave < nbv && live && !(knock & 4)) {  // wave b stores band b
+        const int i0 = ib0 + wave * MIP_ROWS, rows = min(MIP_ROWS, dimi_v - i0);
+#pragma unroll
+        for (int r = 0; r < MIP_ROWS; ++r)
+            if (r < rows) xy[(size_t)(i0 + r) * dimj_v + j] = xyb[wave][r][lane];
+    }
+    if (xyT) {  // column c of the patch = 16 nbv consecutive floats of line j of the transposed copy: the lanes run along i
+        float* t = xyT + (size_t)blockIdx.z * tstride;
+        const int i = ib0 + lane;
+        if (lane < nbv * MIP_ROWS && i < dimi_v)
+            for (int c = wave; c < 64; c += 4) {
+                const int jc_ = (int)blockIdx.x * 64 + c - jshift;
+                if (jc_ >= 0 && jc_ < dimj_v) t[(size_t)jc_ * dimi_v + i] = xyb[lane >> 4][lane & 15][c];
+            }
+    }
+    // xz[i][k] and yz[j][k]: a half-wave takes the dimk slices of one row / column -- 128 contiguous bytes of the MIP when dimk = 32
+    {
+        const int k = threadIdx.x & 31;
+        const int rows = min(nbv * MIP_ROWS, dimi_v - ib0);
+        if (k < dimk && !(knock & 8)) {
+#pragma unroll
+            for (int it = 0; it < MIP_NB * MIP_ROWS / 8; ++it) {
+                const int r = (threadIdx.x >> 5) + 8 * it;
+                if (r < rows) atomic_max_nonneg(&xz[(size_t)(ib0 + r) * dimk + k], xzp[r][k]);
+            }
+            const float* ck = &cacc[k & 3][k >> 2][0];
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int c = (threadIdx.x >> 5) + 8 * it, jc_ = (int)blockIdx.x * 64 + c - jshift;
+                if (jc_ >= 0 && jc_ < dimj_v) atomic_max_nonneg(&yz[(size_t)jc_ * dimk + k], ck[c]);
+            }
+        }
+    }
+}
+
 // ---- 16-bit tiles.  TeraStitcher turns the 8 / 16-bit samples of its TIFF tiles into floats in [0, 1] when it loads them (value /
 // 255 or / 65535, tiff2D.cpp:606-610) and compute_3_MIPs reads those; the division is monotonic, so the MIPs of the floats are the
 // divided MIPs of the integers, bit for bit.  k_mips_int reads the tiles as they are stored -- half or a quarter of the bytes of the pass that
@@ -332,18 +477,24 @@ struct IntTiles {
 template <int BYTES>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_mips_int(
     const unsigned char* __restrict__ A, const unsigned char* __restrict__ B, const unsigned char* const* __restrict__ tab, size_t pstride, int dimk,
-    int dimi_v, int dimj_v, size_t slice, int pitch, int ai0, int aj0, float scale, float* __restrict__ xy1, float* __restrict__ xy2,
-    float* __restrict__ yz_tmp, float* __restrict__ xz_tmp, float* __restrict__ xyT, size_t tstride) {
+    int dimi_v, int dimj_v, size_t slice, int pitch, int ai0, int aj0, float scale, float* __restrict__ xy1, float* __restrict__ xz1,
+    float* __restrict__ yz1, float* __restrict__ xy2, float* __restrict__ xz2, float* __restrict__ yz2, float* __restrict__ xyT, size_t tstride) {
+    // (round 5, as k_mips5: buffer loads with the band's row offsets in SGPRs; row and column maxima merged into the zeroed MIPs with
+    // atomic maxima of the DIVIDED values -- the division is monotonic --, LDS images at odd strides)
     using G = IntTiles<BYTES>;
     constexpr int P = G::P, C = G::C, NB = G::NB;
-    extern __shared__ float xzp[];                     // [band][MIP_ROWS][dimk] row maxima, already divided
-    __shared__ unsigned xyb[NB][MIP_ROWS][64 * C];     // xy maxima of the bands, one word per column (merged with LDS atomics)
-    __shared__ unsigned cacc[4][MIP_KPW][P][64];       // packed column maxima of the wave's slices
+    constexpr int XW = 64 * C + 1;                     // words per row of the xy image
+    constexpr int CS = P * 64 + 1;                     // words per (wave, q) row of the column maxima
+    __shared__ float xzp[NB * MIP_ROWS][MIP5_XS];      // row maxima, already divided
+    __shared__ unsigned xyb[NB][MIP_ROWS][XW];         // xy maxima of the bands, one word per column (merged with LDS atomics)
+    __shared__ unsigned cacc[4 * MIP_KPW][CS];         // packed column maxima of the wave's slices: row wave * MIP_KPW + q, word p * 64 + lane
     const bool second = blockIdx.z & 1;
     const size_t poff = (size_t)(blockIdx.z >> 1) * pstride;
     const unsigned char* vol = tab ? tab[blockIdx.z] : (second ? B : A);
     if (!second) vol += (size_t)ai0 * pitch * BYTES;
     float* xy = (second ? xy2 : xy1) + poff;
+    float* xz = (second ? xz2 : xz1) + poff;
+    float* yz = (second ? yz2 : yz1) + poff;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int a0 = second ? 0 : aj0, alast = a0 + dimj_v - 1;          // first / last tile column of the view
     const int cj = (a0 & ~(G::W - 1)) + (int)blockIdx.x * G::W + C * lane;  // tile column of the lane's word
@@ -362,22 +513,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
     }
     // column c of the lane's word sits in half h of packed pair p
     auto col_of = [](int p, int h) { return BYTES == 2 ? h : 2 * h + p; };
-    unsigned* colacc = &cacc[wave][0][0][lane];  // [q][p]: q * P * 64 + p * 64
+    unsigned* colacc = &cacc[wave * MIP_KPW][lane];  // [q][p]: q * CS + p * 64
 #pragma unroll
-    for (int q = 0; q < MIP_KPW * P; ++q) colacc[q * 64] = 0u;
-    for (int e = threadIdx.x; e < NB * MIP_ROWS * 64 * C; e += 256) (&xyb[0][0][0])[e] = 0u;
+    for (int q = 0; q < MIP_KPW; ++q)
+#pragma unroll
+        for (int p = 0; p < P; ++p) colacc[q * CS + p * 64] = 0u;
+    for (int e = threadIdx.x; e < NB * MIP_ROWS * XW; e += 256) (&xyb[0][0][0])[e] = 0u;
     const int ib0 = __builtin_amdgcn_readfirstlane((int)blockIdx.y * NB * MIP_ROWS);
     const int nbv = min(NB, (dimi_v - ib0 + MIP_ROWS - 1) / MIP_ROWS);
     unsigned v[MIP_ROWS], vn[MIP_ROWS];
-    auto load_slice = [&](int bb, int k, unsigned (&dst)[MIP_ROWS]) {
-        const int i0 = ib0 + bb * MIP_ROWS, last = min(MIP_ROWS, dimi_v - i0) - 1;
-        typedef const unsigned __attribute__((address_space(1))) gword;
-        const unsigned char* p = vol + ((size_t)k * slice + (size_t)i0 * pitch + cc) * BYTES;  // (+ cc: per lane)
+    const int voff = cc * BYTES, pitchb = pitch * BYTES;
+    int ro[MIP_ROWS];  // byte offsets of the 16 rows of the band being requested from the first row of its slice (scalars)
+    auto set_band = [&](int bb) {
+        const int last = min(MIP_ROWS, dimi_v - (ib0 + bb * MIP_ROWS)) - 1;
 #pragma unroll
-        for (int r = 0; r < MIP_ROWS; ++r) dst[r] = *(gword*)(p + (size_t)min(r, last) * pitch * BYTES);
+        for (int r = 0; r < MIP_ROWS; ++r) ro[r] = __builtin_amdgcn_readfirstlane(min(r, last) * pitchb);
     };
+    auto load_slice = [&](int bb, int k, unsigned (&dst)[MIP_ROWS]) {
+        const unsigned char* p = vol + ((size_t)k * slice + (size_t)(ib0 + bb * MIP_ROWS) * pitch) * BYTES;  // wave-uniform
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(p), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+        for (int r = 0; r < MIP_ROWS; ++r) dst[r] = __builtin_amdgcn_raw_buffer_load_b32(rs, voff, ro[r], 0);
+    };
+    set_band(0);
     if (wave < dimk) load_slice(0, wave, v);
-    __syncthreads();  // (xyb is zero)
+    __syncthreads();  // (the LDS images are zero)
 #pragma unroll 1
     for (int b = 0; b < nbv; ++b) {
         unsigned best[P][MIP_ROWS];
@@ -388,8 +548,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
         // one slice: the packed column maxima of its pairs go to colacc[q]
         auto slice_step = [&](int k, int q, unsigned (&cur)[MIP_ROWS], unsigned (&nxt)[MIP_ROWS]) {
             const bool wrap = k + 4 >= dimk;  // (wave-uniform)
-            const int kn = __builtin_amdgcn_readfirstlane(wrap ? wave : k + 4), bn = __builtin_amdgcn_readfirstlane(wrap ? b + 1 : b);
-            load_slice(min(bn, nbv - 1), kn, nxt);
+            const int kn = __builtin_amdgcn_readfirstlane(wrap ? wave : k + 4);
+            const int bn = __builtin_amdgcn_readfirstlane(wrap ? min(b + 1, nbv - 1) : b);
+            if (wrap) set_band(bn);
+            load_slice(bn, kn, nxt);
             unsigned colmax[P];
 #pragma unroll
             for (int p = 0; p < P; ++p) colmax[p] = 0u;
@@ -410,9 +572,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
                 }
             }
             const unsigned rm = rows_max16_pk(cur, lane);
-            if (lane < 16) xzp[(b * MIP_ROWS + row_of_lane(lane)) * dimk + k] = (float)max(rm & 0xffffu, rm >> 16) / scale;
+            if (lane < 16) xzp[b * MIP_ROWS + row_of_lane(lane)][k] = (float)max(rm & 0xffffu, rm >> 16) / scale;
 #pragma unroll
-            for (int p = 0; p < P; ++p) colacc[(q * P + p) * 64] = pk_max_u16(colacc[(q * P + p) * 64], colmax[p]);
+            for (int p = 0; p < P; ++p) colacc[q * CS + p * 64] = pk_max_u16(colacc[q * CS + p * 64], colmax[p]);
         };
         int k = wave, q = 0;
 #pragma unroll 1
@@ -450,31 +612,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
             }
         }
     }
+    const int jv_first = (a0 & ~(G::W - 1)) + (int)blockIdx.x * G::W - a0;  // view column of the work-group's word 0, sample 0
     if (xyT) {  // the transposed copy (see k_mips): lanes along i, a wave per column
         float* t = xyT + (size_t)blockIdx.z * tstride;
-        const int i = ib0 + lane, jv_first = (a0 & ~(G::W - 1)) + (int)blockIdx.x * G::W - a0;  // view column of the work-group's word 0, sample 0
+        const int i = ib0 + lane;
         if (lane < nbv * MIP_ROWS && i < dimi_v)
             for (int c = wave; c < G::W; c += 4) {
                 const int jv = jv_first + c;
                 if (jv >= 0 && jv < dimj_v) t[(size_t)jv * dimi_v + i] = (float)xyb[lane >> 4][lane & 15][c] / scale;
             }
     }
-    {   // the rows of all bands * dimk: contiguous floats
-        float* dst = xz_tmp + (((size_t)blockIdx.z * gridDim.x + blockIdx.x) * dimi_v + ib0) * dimk;
-        const int total = min(nbv * MIP_ROWS, dimi_v - ib0) * dimk;
-        for (int e = threadIdx.x; e < total; e += 256) dst[e] = xzp[e];
-    }
-#pragma unroll
-    for (int q = 0; q < MIP_KPW; ++q) {
-        const int k = wave + 4 * q;
+    {   // xz[i][k] and yz[j][k]: a half-wave takes the dimk slices of one row / column (see k_mips5)
+        const int k = threadIdx.x & 31;
+        const int rows = min(nbv * MIP_ROWS, dimi_v - ib0);
         if (k < dimk) {
-            float* row = yz_tmp + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * dimk + k) * dimj_v;
 #pragma unroll
-            for (int p = 0; p < P; ++p) {
-                const unsigned c = colacc[(q * P + p) * 64];
-                const int j0 = jv0 + col_of(p, 0), j1 = jv0 + col_of(p, 1);
-                if (j0 >= 0 && j0 < dimj_v) row[j0] = (float)(c & 0xffffu) / scale;
-                if (j1 >= 0 && j1 < dimj_v) row[j1] = (float)(c >> 16) / scale;
+            for (int it = 0; it < NB * MIP_ROWS / 8; ++it) {
+                const int r = (threadIdx.x >> 5) + 8 * it;
+                if (r < rows) atomic_max_nonneg(&xz[(size_t)(ib0 + r) * dimk + k], xzp[r][k]);
+            }
+            const unsigned* ck = &cacc[(k & 3) * MIP_KPW + (k >> 2)][0];
+#pragma unroll 4
+            for (int it = 0; it < G::W / 8; ++it) {
+                const int c = (threadIdx.x >> 5) + 8 * it;   // column of the work-group: word c / C, sample c % C of it
+                const int l = c / C, cs = c % C;
+                const int p = BYTES == 2 ? 0 : (cs & 1), h = BYTES == 2 ? cs : (cs >> 1);
+                const unsigned wv = ck[p * 64 + l];
+                const int jv = jv_first + c;
+                if (jv >= 0 && jv < dimj_v) atomic_max_nonneg(&yz[(size_t)jv * dimk + k], (float)(h ? (wv >> 16) : (wv & 0xffffu)) / scale);
             }
         }
     }
@@ -517,6 +682,8 @@ inline size_t mips_tmp_floats(int dimk, int dimi_v, int dimj_v) {
     const size_t bands = std::max<size_t>(mips_groups(dimk, dimi_v), (dimi_v + 2 * MIP_ROWS - 1) / (2 * MIP_ROWS)), cblocks = (dimj_v + 63) / 64 + 1;
     return 2 * (bands * dimk * dimj_v + cblocks * (size_t)dimi_v * dimk);
 }
+// k_mips5: stacks whose xz maxima fit its LDS image, row offsets that fit the buffer instructions' 32-bit offsets
+inline bool mips5_ok(int dimk, int pitch) { return dimk <= 4 * MIP_KPW && pitch < (1 << 24); }
 inline bool mips_int_ok(int bytes, int dimk, int pitch, size_t slice) {
     const int per = 4 / bytes;  // samples per 32-bit word
     return (bytes == 1 || bytes == 2) && dimk <= 4 * MIP_KPW && pitch % per == 0 && slice % per == 0;
@@ -525,45 +692,67 @@ inline bool mips_int_ok(int bytes, int dimk, int pitch, size_t slice) {
 inline int mips_fmt_bands(int bytes, int dimk) { return bytes == 4 ? mips_band_group(dimk) : (bytes == 2 ? IntTiles<2>::NB : IntTiles<1>::NB); }
 inline int mips_fmt_width(int bytes) { return bytes == 4 ? 64 : (bytes == 2 ? IntTiles<2>::W : IntTiles<1>::W); }
 
+// `beside_chain`: a lag chain of an earlier group runs while this pass does -- the pass then keeps three work-groups per compute
+// unit instead of four (a quarter of the LDS and of the registers stay free for the chain's work-groups, which otherwise wait for
+// whole work-groups of the pass to retire: profiles/r05_ncc_wpe.txt)
 int launch_mips(hipStream_t s, const float* A, const float* B, const float* const* tab, int np, size_t pstride, int dimk, int dimi_v, int dimj_v,
                 size_t slice, int pitch, int ai0, int aj0, float* xy1, float* xz1, float* yz1, float* xy2, float* xz2, float* yz2, float* tmp,
-                hipEvent_t xy_done = nullptr,  // recorded when the xy MIPs are final (k_mips), before the reductions of the other two
-                TileFmt fmt = TileFmt(), float* xyT = nullptr, size_t tstride = 0) {
+                hipEvent_t xy_done = nullptr,  // recorded when the MIPs of k_mips5 / k_mips_int are final (deep stacks: the xy MIPs)
+                TileFmt fmt = TileFmt(), float* xyT = nullptr, size_t tstride = 0, bool beside_chain = false) {
     const int nb = mips_fmt_bands(fmt.bytes, dimk), wcol = mips_fmt_width(fmt.bytes);
     const int bands = (dimi_v + MIP_ROWS * nb - 1) / (MIP_ROWS * nb);
     const int cblocks = (dimj_v + (aj0 & (wcol - 1)) + wcol - 1) / wcol;  // (band groups, column blocks aligned to the tile rows)
-    float* yz_tmp = tmp;
-    float* xz_tmp = tmp + 2 * (size_t)np * bands * dimk * dimj_v;
+    const dim3 grid(cblocks, bands, 2 * np);
+    const size_t n_xz = (size_t)dimi_v * dimk, n_yz = (size_t)dimj_v * dimk;
+    auto zero_mips = [&]() {  // the passes that merge their row / column maxima into the MIPs with atomic maxima start from zero
+        hipLaunchKernelGGL(k_mips_zero, dim3((unsigned)std::min<size_t>((n_xz + n_yz + 255) / 256, 64), 2 * np), dim3(256), 0, s, pstride, n_xz, n_yz, xz1,
+                           yz1, xz2, yz2);
+        return launch_check("k_mips_zero");
+    };
     if (fmt.bytes != 4) {
         MI_REQUIRE(mips_int_ok(fmt.bytes, dimk, pitch, slice), "integer tiles: stacks of up to %d slices, rows of whole 32-bit words", 4 * MIP_KPW);
-        const size_t lds = sizeof(float) * MIP_ROWS * (size_t)dimk * nb;
         const unsigned char* a8 = reinterpret_cast<const unsigned char*>(A);
         const unsigned char* b8 = reinterpret_cast<const unsigned char*>(B);
         const unsigned char* const* t8 = reinterpret_cast<const unsigned char* const*>(tab);
+        MI_TRY(zero_mips());
         if (fmt.bytes == 2)
-            hipLaunchKernelGGL(k_mips_int<2>, dim3(cblocks, bands, 2 * np), dim3(256), lds, s, a8, b8, t8, pstride, dimk, dimi_v, dimj_v, slice, pitch,
-                               ai0, aj0, fmt.scale, xy1, xy2, yz_tmp, xz_tmp, xyT, tstride);
+            hipLaunchKernelGGL(k_mips_int<2>, grid, dim3(256), 0, s, a8, b8, t8, pstride, dimk, dimi_v, dimj_v, slice, pitch, ai0, aj0, fmt.scale, xy1, xz1,
+                               yz1, xy2, xz2, yz2, xyT, tstride);
         else
-            hipLaunchKernelGGL(k_mips_int<1>, dim3(cblocks, bands, 2 * np), dim3(256), lds, s, a8, b8, t8, pstride, dimk, dimi_v, dimj_v, slice, pitch,
-                               ai0, aj0, fmt.scale, xy1, xy2, yz_tmp, xz_tmp, xyT, tstride);
+            hipLaunchKernelGGL(k_mips_int<1>, grid, dim3(256), 0, s, a8, b8, t8, pstride, dimk, dimi_v, dimj_v, slice, pitch, ai0, aj0, fmt.scale, xy1, xz1,
+                               yz1, xy2, xz2, yz2, xyT, tstride);
         MI_TRY(launch_check("k_mips_int"));
         if (xy_done) MI_HIP(hipEventRecord(xy_done, s));
-        hipLaunchKernelGGL(k_mips_yz, dim3((dimk * dimj_v + 255) / 256, 2 * np), dim3(256), 0, s, yz_tmp, pstride, bands, dimk, dimj_v, yz1, yz2);
-        MI_TRY(launch_check("k_mips_yz"));
-        hipLaunchKernelGGL(k_mips_xz, dim3((dimk * dimi_v + 255) / 256, 2 * np), dim3(256), 0, s, xz_tmp, pstride, cblocks, dimk, dimi_v, xz1, xz2);
-        return launch_check("k_mips_xz");
+        return MI_OK;
     }
+    static const int knock = [] {
+        const char* e = MI_PROBE_ENV("MI_NCC_MIPS_KNOCK");
+        return e ? std::atoi(e) : 0;
+    }();
+    static const bool old_pass = [] { const char* e = MI_PROBE_ENV("MI_NCC_MIPS_OLD"); return e && std::atoi(e) != 0; }();  // (probe builds: A/B)
+    if (mips5_ok(dimk, pitch) && !old_pass) {
+        static const int wpe_env = [] { const char* e = MI_PROBE_ENV("MI_NCC_MIPS_WPE"); return e ? std::atoi(e) : 0; }();
+        const int wpe = wpe_env ? wpe_env : (beside_chain ? 3 : 4);
+        MI_TRY(zero_mips());
+        if (wpe == 3)
+            hipLaunchKernelGGL(k_mips5<3>, grid, dim3(256), 0, s, A, B, tab, pstride, dimk, dimi_v, dimj_v, slice, pitch, ai0, aj0, xy1, xz1, yz1, xy2, xz2, yz2,
+                               knock, xyT, tstride);
+        else
+            hipLaunchKernelGGL(k_mips5<4>, grid, dim3(256), 0, s, A, B, tab, pstride, dimk, dimi_v, dimj_v, slice, pitch, ai0, aj0, xy1, xz1, yz1, xy2, xz2, yz2,
+                               knock, xyT, tstride);
+        MI_TRY(launch_check("k_mips5"));
+        if (xy_done) MI_HIP(hipEventRecord(xy_done, s));
+        return MI_OK;
+    }
+    // deeper stacks (or rows too long for 32-bit offsets): the round-3 pass with its partial maxima and their reductions
+    float* yz_tmp = tmp;
+    float* xz_tmp = tmp + 2 * (size_t)np * bands * dimk * dimj_v;
     const size_t lds = sizeof(float) * MIP_ROWS * (size_t)dimk * mips_band_group(dimk);  // (k_mips: xzp)
     const bool via_lds = lds <= 32 * 1024;
     if (!via_lds) {  // very deep stacks: the xz MIPs are merged with atomicMax and must start at 0 (libcrossmips.cpp:319-337)
         MI_HIP(hipMemset2DAsync(xz1, sizeof(float) * (pstride ? pstride : 1), 0, sizeof(float) * (size_t)dimi_v * dimk, np, s));
         MI_HIP(hipMemset2DAsync(xz2, sizeof(float) * (pstride ? pstride : 1), 0, sizeof(float) * (size_t)dimi_v * dimk, np, s));
     }
-    dim3 grid(cblocks, bands, 2 * np);
-    static const int knock = [] {
-        const char* e = MI_PROBE_ENV("MI_NCC_MIPS_KNOCK");
-        return e ? std::atoi(e) : 0;
-    }();
     hipLaunchKernelGGL(HIP_KERNEL_NAME(via_lds && dimk <= 4 * MIP_KPW ? k_mips<true> : k_mips<false>), grid, dim3(256), via_lds ? lds : 0, s, A, B, tab, pstride, dimk, dimi_v, dimj_v, slice, pitch, ai0, aj0, xy1, xz1, yz1,
                        xy2, xz2, yz2, yz_tmp, via_lds ? xz_tmp : (float*)nullptr, knock, xyT, tstride);
     MI_TRY(launch_check("k_mips"));

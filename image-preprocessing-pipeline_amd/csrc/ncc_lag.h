@@ -28,7 +28,8 @@ struct LagJob;
 // behind an event it records on the MIP stream after the last job's MIP pass
 int ncc_lag_enqueue(int dev, hipStream_t s, int n, const float* const* a_ptrs, const float* const* b_ptrs, int dimk, int dimi, int dimj, int ni,
                     int nj, int delayk, int delayi, int delayj, int side, mi_ncc_params* params, LagJob** job, bool defer_chains = false,
-                    TileFmt fmt = TileFmt(), int groups_in_flight = 1);
+                    TileFmt fmt = TileFmt(), int groups_in_flight = 1, bool chain_beside = false);
+// (chain_beside: an earlier group's chain is still running when this group's MIP pass starts -- launch_mips)
 int ncc_lag_enqueue_chains(LagJob* job, hipEvent_t gate);
 hipStream_t ncc_lag_mip_stream(LagJob* job);
 int ncc_lag_finish(LagJob* job, mi_ncc_params* params, mi_ncc_descr* out, unsigned char* careful);

@@ -1297,20 +1297,22 @@ struct LagJob {
 static int enqueue_chains(LagJob& job, int c0, int p0, int np, int pi, hipEvent_t gate, hipEvent_t gate_xy = nullptr);
 static int close_job(LagJob& job);
 
-// A group's MIP pass starts only when the previous group's chain is past its tables and its xy forward transform: those are bound
-// by memory latency and run several times longer beside a MIP pass (which they slow down in turn); what is left of the chain --
-// the correlation, the inverse transform, the refinement -- shares the device well (profiles/r03_ncc_timeline.txt).
+// MI_NCC_GATE=1 (probe builds): a group's MIP pass starts only when the previous group's chain is past its tables and its xy forward
+// transform.  Rounds 3-4 ran that way -- those kernels are bound by memory latency and waited for whole work-groups of the pass to
+// retire before they found a compute unit (profiles/r03_ncc_timeline.txt).  Since round 5 a pass that runs beside a chain keeps three
+// work-groups per compute unit (launch_mips), the chain's work-groups are resident next to them, and the gate costs more than it
+// saves: 6.12 against 6.27 ms per 112 pairs (profiles/r05_ncc_wpe.txt).
 static bool mip_gate() {
     static const bool on = [] {
         const char* e = MI_PROBE_ENV("MI_NCC_GATE");
-        return e ? std::atoi(e) != 0 : true;
+        return e ? std::atoi(e) != 0 : false;
     }();
     return on;
 }
 
 int ncc_lag_enqueue(int dev, hipStream_t s, int n, const float* const* a_ptrs, const float* const* b_ptrs, int dimk, int dimi, int dimj, int ni,
                     int nj, int delayk, int delayi, int delayj, int side, mi_ncc_params* params, LagJob** job_out, bool defer_chains, TileFmt fmt,
-                    int groups_in_flight) {
+                    int groups_in_flight, bool chain_beside) {
     *job_out = nullptr;
     if (n <= 0) return MI_OK;
     std::unique_ptr<LagJob> job(new (std::nothrow) LagJob);
@@ -1403,7 +1405,7 @@ int ncc_lag_enqueue(int dev, hipStream_t s, int n, const float* const* a_ptrs, c
             MI_TRY(launch_mips(sm, nullptr, nullptr, dtab, np, pstride, pl.dimk, pl.dimi_v, pl.dimj_v, (size_t)dimi * dimj, dimj, pl.ai0, pl.aj0,
                                base + pl.g[0].mip1, base + pl.g[1].mip1, base + pl.g[2].mip1, base + pl.g[0].mip2, base + pl.g[1].mip2,
                                base + pl.g[2].mip2, ws.mip_tmp.as<float>() + (size_t)p0 * tmp_floats, ws.ev_mip_xy[pi], fmt,
-                               tstride ? ws.xyT.as<float>() + 2 * tstride * (size_t)p0 : nullptr, tstride));
+                               tstride ? ws.xyT.as<float>() + 2 * tstride * (size_t)p0 : nullptr, tstride, chain_beside || c0 > 0 || p0 > 0));
             MI_HIP(hipEventRecord(ws.ev_mip[pi], sm));
             if (defer) continue;
             MI_TRY(enqueue_chains(*job, c0, p0, np, pi, ws.ev_mip[pi], ws.ev_mip_xy[pi]));
@@ -1549,7 +1551,7 @@ void ncc_lag_abandon(LagJob* job) { delete job; }
 int ncc_lag_group(int dev, hipStream_t s, int n, const float* const* a_ptrs, const float* const* b_ptrs, int dimk, int dimi, int dimj, int ni,
                   int nj, int delayk, int delayi, int delayj, int side, mi_ncc_params* params, mi_ncc_descr* out, unsigned char* careful, TileFmt fmt) {
     LagJob* job = nullptr;
-    MI_TRY(ncc_lag_enqueue(dev, s, n, a_ptrs, b_ptrs, dimk, dimi, dimj, ni, nj, delayk, delayi, delayj, side, params, &job, false, fmt, 1));
+    MI_TRY(ncc_lag_enqueue(dev, s, n, a_ptrs, b_ptrs, dimk, dimi, dimj, ni, nj, delayk, delayi, delayj, side, params, &job, false, fmt, 1, false));
     return ncc_lag_finish(job, params, out, careful);
 }
 
@@ -1626,20 +1628,30 @@ int ncc_time_mips(int dev, hipStream_t s, int n, const float* const* a_ptrs, con
     hipEvent_t e0 = evs.a, e1 = evs.b;
     const char* ke = MI_PROBE_ENV("MI_NCC_MIPS_KNOCK");  // (measurement aid, see k_mips)
     const int knock = ke ? std::atoi(ke) : 0;
+    const char* oe = MI_PROBE_ENV("MI_NCC_MIPS_OLD");
+    const bool old_pass = oe && std::atoi(oe) != 0;
     for (int r = -1; r < reps; ++r) {  // r = -1: warm-up
         if (r == 0) MI_HIP(hipEventRecord(e0, s));
         if (fmt.bytes != 4) {
             const int aj0 = side == MI_WEST_EAST ? nj : 0, wcol = mips_fmt_width(fmt.bytes);
             const dim3 grid((dimj_v + (aj0 & (wcol - 1)) + wcol - 1) / wcol, bands, 2 * n);
             const unsigned char* const* t8 = tab.as<const unsigned char*>();
+            float* o2 = o + xy + xz + yz;   // (the maxima merge into whatever the MIPs hold: the timed launches need no zeroing)
             if (fmt.bytes == 2)
-                hipLaunchKernelGGL(k_mips_int<2>, grid, dim3(256), lds, s, (const unsigned char*)nullptr, (const unsigned char*)nullptr, t8, pstride, dimk,
-                                   dimi_v, dimj_v, (size_t)dimi * dimj, dimj, side == MI_NORTH_SOUTH ? ni : 0, aj0, fmt.scale, o, o + xy + xz + yz,
-                                   tmp.as<float>(), xz_tmp, (float*)nullptr, (size_t)0);
+                hipLaunchKernelGGL(k_mips_int<2>, grid, dim3(256), 0, s, (const unsigned char*)nullptr, (const unsigned char*)nullptr, t8, pstride, dimk,
+                                   dimi_v, dimj_v, (size_t)dimi * dimj, dimj, side == MI_NORTH_SOUTH ? ni : 0, aj0, fmt.scale, o, o + xy, o + xy + xz, o2,
+                                   o2 + xy, o2 + xy + xz, (float*)nullptr, (size_t)0);
             else
-                hipLaunchKernelGGL(k_mips_int<1>, grid, dim3(256), lds, s, (const unsigned char*)nullptr, (const unsigned char*)nullptr, t8, pstride, dimk,
-                                   dimi_v, dimj_v, (size_t)dimi * dimj, dimj, side == MI_NORTH_SOUTH ? ni : 0, aj0, fmt.scale, o, o + xy + xz + yz,
-                                   tmp.as<float>(), xz_tmp, (float*)nullptr, (size_t)0);
+                hipLaunchKernelGGL(k_mips_int<1>, grid, dim3(256), 0, s, (const unsigned char*)nullptr, (const unsigned char*)nullptr, t8, pstride, dimk,
+                                   dimi_v, dimj_v, (size_t)dimi * dimj, dimj, side == MI_NORTH_SOUTH ? ni : 0, aj0, fmt.scale, o, o + xy, o + xy + xz, o2,
+                                   o2 + xy, o2 + xy + xz, (float*)nullptr, (size_t)0);
+            continue;
+        }
+        if (mips5_ok(dimk, dimj) && !old_pass) {  // (its maxima merge into whatever the MIPs hold: the timed launches need no zeroing)
+            const char* we = MI_PROBE_ENV("MI_NCC_MIPS_WPE");
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(we && std::atoi(we) == 3 ? k_mips5<3> : k_mips5<4>), dim3(cblocks, bands, 2 * n), dim3(256), 0, s, (const float*)nullptr, (const float*)nullptr, tab.as<const float*>(), pstride,
+                               dimk, dimi_v, dimj_v, (size_t)dimi * dimj, dimj, side == MI_NORTH_SOUTH ? ni : 0, side == MI_WEST_EAST ? nj : 0, o, o + xy,
+                               o + xy + xz, o + xy + xz + yz, o + 2 * xy + xz + yz, o + 2 * xy + 2 * xz + yz, knock, (float*)nullptr, (size_t)0);
             continue;
         }
         hipLaunchKernelGGL(HIP_KERNEL_NAME(dimk <= 4 * MIP_KPW ? k_mips<true> : k_mips<false>), dim3(cblocks, bands, 2 * n), dim3(256), lds, s, (const float*)nullptr, (const float*)nullptr, tab.as<const float*>(),

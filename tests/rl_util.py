@@ -60,3 +60,26 @@ def assert_close_device(got, want, rel=1e-4, rel_l2=1e-5, pt_rel=1e-4, pt_abs=1e
     l2 = (d2 / max(w2, 1e-300)) ** 0.5
     assert l2 <= rel_l2, f"{what} relative L2 error {l2:.3e}"
     assert worst <= 1.0, f"{what} point-wise error {worst:.3f} x the allowance"
+
+
+def delta_on_ones_closed_form(psf, shifts, amp, d):
+    """One RL iteration (decon.m:162-186, circular) on bl = 1 + amp * delta_p, evaluated at y = p + d in float64.  With P(u) =
+    psf[u + shift] (sample j lands on offset j - shift, decon.m:131-133), sum(P) = 1:  conv = 1 + amp P(x - p), ratio = bl / conv,
+    a(y) = sum_x ratio(x) P(x - y) = 1 - sum_u g(u) P(u - d) + [amp / (1 + amp P(0))] P(-d),  g = amp P / (1 + amp P);
+    the iteration returns |bl(y) a(y)|."""
+    P = psf.astype(np.float64)
+    g = amp * P / (1.0 + amp * P)
+    k = P.shape
+    acc = 0.0
+    lo = [max(0, dd) for dd in d]                        # j (index of g) with j - d inside the PSF
+    hi = [min(kk, kk + dd) for kk, dd in zip(k, d)]
+    if all(h > l for l, h in zip(lo, hi)):
+        gs = g[lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]]
+        ps = P[lo[0] - d[0]:hi[0] - d[0], lo[1] - d[1]:hi[1] - d[1], lo[2] - d[2]:hi[2] - d[2]]
+        acc = float((gs * ps).sum())
+    jm = [s - dd for s, dd in zip(shifts, d)]            # P(-d) = psf[shift - d]
+    pm = float(P[jm[0], jm[1], jm[2]]) if all(0 <= j < kk for j, kk in zip(jm, k)) else 0.0
+    p0 = float(P[shifts[0], shifts[1], shifts[2]])
+    a = 1.0 - acc + amp / (1.0 + amp * p0) * pm
+    bl = 1.0 + (amp if tuple(d) == (0, 0, 0) else 0.0)
+    return abs(bl * a)

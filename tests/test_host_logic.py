@@ -225,3 +225,22 @@ def test_displacement_xml_round_trip_and_threshold_grid(tmp_path):
     del grid[(1, 0, 1, 1)]
     with pytest.raises(ValueError, match="one and only displacement"):
         crossmips.threshold_displacements(grid, 2, 2, 0.65)
+
+
+def test_delta_on_ones_closed_form_matches_the_oracle():
+    """The closed form the full-size config-4 test checks the device against (tests/rl_util.py) IS one deconFFT iteration of the
+    oracle (decon.m:162-186) on 1 + amp * delta -- at an impulse next to the wrap-around of every axis, with an unsymmetric PSF."""
+    from tests.rl_util import delta_on_ones_closed_form
+    rng = np.random.default_rng(0)
+    psf = rng.random((9, 7, 5)).astype(np.float32)
+    psf /= psf.sum()
+    shape = (32, 48, 40)
+    shifts = [n // 2 - (n - k) // 2 for n, k in zip(shape, psf.shape)]
+    amp = 10.0 / float(psf[tuple(shifts)])
+    vol = np.ones(shape, np.float32)
+    p = (30, 46, 39)
+    vol[p] = 1 + amp
+    out = R.decon(vol, psf, 1, 0.0, 0.0, 0, use_fft=True, fft_shape_zyx=shape, skip_edgetaper=True)
+    for d in [(0, 0, 0), (1, 0, 0), (0, -1, 0), (3, -2, 1), (-4, 3, -2), (8, 6, 4), (-8, -6, -4), (5, 0, 0), (9, 0, 0), (0, 20, 0)]:
+        y = tuple((a + b) % n for a, b, n in zip(p, d, shape))
+        assert out[y] == pytest.approx(delta_on_ones_closed_form(psf, shifts, amp, d), rel=2e-6), d
