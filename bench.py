@@ -226,6 +226,44 @@ def secondary_rows(vshape, kshape, psf_np, dev, gaussian, steps):
     return out
 
 
+def c4_single(dev, steps=3):
+    """BASELINE config 4 WHOLE on one device (4096 x 4096 x 1024 voxels, 63 x 63 x 127 PSF, deconFFT semantics): 17.2 G voxels, 258 GB of
+    the 288 -- the volume, two spectrum arrays, the real OTF.  The reference cannot hold such a block at all (2^31 - 1 elements,
+    LsDeconv.m:308-385).  Device time of `steps` fused iterations after one warm-up iteration."""
+    import torch
+    from ipp_amd import capi, decon
+    free_b, total_b = torch.cuda.mem_get_info(dev)
+    if free_b < 265e9:
+        return {"skipped": f"needs about 258 GB on the device: {free_b / 1e9:.1f} GB free of {total_b / 1e9:.1f} GB"}
+    vshape, kshape = WORKLOADS["c4"]
+    ctx = decon.RLContext(vshape, make_psf(kshape), None, boundary=capi.BOUNDARY_CIRCULAR, engine=capi.ENGINE_FFT, device=dev)
+    bl = make_volume(vshape, dev)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ctx.iterate(bl, None, 1)
+    torch.cuda.synchronize(dev)
+    ev0.record()
+    ctx.iterate(bl, None, steps)
+    ev1.record()
+    torch.cuda.synchronize(dev)
+    ms = ev0.elapsed_time(ev1) / steps
+    n = vshape[0] * vshape[1] * vshape[2]
+    out = {"ms_per_step": round(ms, 3), "value": round(n / (ms * 1e-3) / 1e9, 4), "unit": "Gvoxel*iter/s", "steps": steps,
+           "device_bytes_context": int(ctx.device_bytes), "device_bytes_volume": 4 * n,
+           "iteration": {"algorithmic_bytes_per_voxel_iter": ALGO_BYTES_PER_VOXEL_ITER,
+                         "achieved_GBps": round(ALGO_BYTES_PER_VOXEL_ITER * n / (ms * 1e-3) / 1e9, 1),
+                         "frac": round(ALGO_BYTES_PER_VOXEL_ITER * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+           "config": f"c4 whole on one device: {vshape[2]}x{vshape[1]}x{vshape[0]} fp32 volume, {kshape[2]}x{kshape[1]}x{kshape[0]} PSF, "
+                     "deconFFT semantics, lambda=0, fused iterations (mi_rl_iterate)"}
+    try:
+        out["pass_ms"] = {k: round(ctx.time_pass(k, bl, reps=2), 3) for k in ("y_forward", "z_conv", "y_inverse", "x_fused")}
+    except Exception as e:
+        out["pass_ms"] = {"error": repr(e)}
+    del ctx, bl
+    torch.cuda.empty_cache()
+    capi.release_cached_memory()
+    return out
+
+
 def launch_ranks(n, argv):
     """``python bench.py --gpus N`` from a plain shell: start the N ranks as a CHILD process tree (torch.distributed.run, one rank
     per GPU, rendezvous on 127.0.0.1), relay rank 0's JSON line and return the child's exit code.  Nothing in this process has
@@ -446,6 +484,13 @@ def main():
             capi.release_cached_memory()
             out.update(secondary_rows(vshape, kshape, psf_np, dev, args.workload == "c1", args.steps))
             capi.release_cached_memory()
+            if args.workload == "c3":
+                try:
+                    out["c4_single"] = c4_single(dev)
+                except Exception as e:
+                    out["c4_single"] = {"error": repr(e)}
+                    torch.cuda.empty_cache()
+                    capi.release_cached_memory()
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(vshape, kshape, gaussian=args.workload == "c1")
     ncc = None

@@ -109,6 +109,15 @@ void pool_free(void* p, size_t n) {
         (void)hipFree(p);
         return;
     }
+    {   // so do blocks of more than an eighth of the device: the pool exists for the working sets of decwrap's blocks (tens of GB in
+        // pieces of a few GB), and a 69-GB array kept here -- the complex OTF of BASELINE config 4 on one device, released once its
+        // real form exists -- is memory the caller's own allocator never gets to see (its failures do not trim this pool)
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && n > total_b / 8) {
+            (void)hipFree(p);
+            return;
+        }
+    }
     // hipFree waits for the device before it releases memory; a cached block may be handed out to another stream, so the same
     // guarantee is kept here
     int cur = 0, dev = 0;

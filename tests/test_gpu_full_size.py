@@ -62,24 +62,29 @@ def test_rl_full_size_properties(dev, workload):
         assert float((a - b).abs().max()) <= 1e-4 * float(a.abs().max())
 
 
+def _sum64(t, planes=32):
+    """float64 sum of a float32 volume in slabs of `planes` z planes (torch casts the whole operand first: 137 GB for config 4)"""
+    return float(sum(torch.sum(t[z:z + planes], dtype=torch.float64) for z in range(0, t.shape[0], planes)))
+
+
 def test_rl_config4_whole_on_one_gpu(dev):
     """BASELINE config 4 WHOLE on one device: 4096 x 4096 x 1024 voxels (17.2 G: linear voxel indices past 2^32), 63 x 63 x 127 PSF,
     deconFFT semantics.  The reference caps a block at 2^31 - 1 elements (LsDeconv.m:308-385); nothing here does.  Device memory:
-    volume 68.7 GB + two spectrum arrays 2 x 68.7 GB + real OTF 34.4 GB = 241 GB of the 288 -- so only the fused iteration runs (the
-    two half-steps need a fourth array), and it is checked (i) against the closed form of one iteration on 1 + amp * delta for two
+    volume 68.7 GB + two spectrum arrays 2 x 77.6 GB (rows of 32 KB + 4 KB + 128 B of padding against channel camping) + real OTF
+    34.4 GB = 258 GB of the 288 -- so only the fused iteration runs (the two half-steps need a fourth array), and it is checked (i) against the closed form of one iteration on 1 + amp * delta for two
     impulses, one of them at a linear index above 2^32 and next to the wrap-around of x and y: forward placement (decon.m:131-133),
     mirrored adjoint, both through 64-bit addressing; (ii) by flux conservation and non-negativity over two more iterations on the
     bead volume of the bench."""
     import bench
     from ipp_amd import capi, decon
     free_b, total_b = torch.cuda.mem_get_info(dev)
-    if free_b < 250e9:
-        pytest.skip(f"config 4 whole needs about 241 GB on the device: {free_b / 1e9:.1f} GB free of {total_b / 1e9:.1f} GB")
+    if free_b < 265e9:
+        pytest.skip(f"config 4 whole needs about 258 GB on the device: {free_b / 1e9:.1f} GB free of {total_b / 1e9:.1f} GB")
     shape, kshape = bench.WORKLOADS["c4"]
     psf = bench.make_psf(kshape)
     ctx = decon.RLContext(shape, psf, None, boundary=capi.BOUNDARY_CIRCULAR, engine=capi.ENGINE_FFT, device=dev)
     assert ctx.engine == capi.ENGINE_FFT and ctx.fuses
-    assert ctx.device_bytes < 180e9, ctx.device_bytes   # 2 spectrum arrays + the real OTF; no trial candidates, no spare array
+    assert ctx.device_bytes < 195e9, ctx.device_bytes   # 2 spectrum arrays + the real OTF; no trial candidates, no spare array
     shifts = [n // 2 - (n - k) // 2 for n, k in zip(shape, psf.shape)]
     amp = 10.0 / float(psf[shifts[0], shifts[1], shifts[2]])
     bl = torch.ones(shape, device=dev)
@@ -98,7 +103,7 @@ def test_rl_config4_whole_on_one_gpu(dev):
             assert float(bl[y]) == pytest.approx(want, rel=2e-4), (p, d)
     assert float(bl[512, 2048, 2048]) == pytest.approx(1.0, rel=1e-5)      # far from both impulses nothing moves
     n = float(bl.numel())
-    assert abs(float(torch.sum(bl, dtype=torch.float64)) - (n + 2 * amp)) / n < 1e-5   # flux of the iteration (sum(psf) = 1)
+    assert abs(_sum64(bl) - (n + 2 * amp)) / n < 1e-5   # flux of the iteration (sum(psf) = 1)
     # the bench's bead volume, generated into the same array
     g = torch.Generator(device=dev).manual_seed(1234)
     bl.uniform_(0.01, 0.02, generator=g)
@@ -106,10 +111,10 @@ def test_rl_config4_whole_on_one_gpu(dev):
     idx = torch.randint(0, bl.numel(), (nb,), generator=g, device=dev)
     bl.view(-1).index_put_((idx,), torch.empty(nb, device=dev).uniform_(0.2, 1.0, generator=g), accumulate=True)
     del idx
-    s0 = float(torch.sum(bl, dtype=torch.float64))
+    s0 = _sum64(bl)
     ctx.iterate(bl, None, 2)
     assert float(bl.min()) >= 0.0 and np.isfinite(float(bl.max()))
-    assert abs(float(torch.sum(bl, dtype=torch.float64)) - s0) / s0 < 1e-4
+    assert abs(_sum64(bl) - s0) / s0 < 1e-4
     del bl, ctx
     torch.cuda.empty_cache()
     capi.release_cached_memory()
