@@ -118,18 +118,15 @@ SIGNATURES = {
     "mi_fft_good_size": (_i, [_i, _i]),
     "mi_pack_rows": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "mi_unpack_rows": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
-    "mi_peer_alloc": (_i, [_i, _sz, C.POINTER(_vp), C.c_char_p]),
-    "mi_peer_free": (_i, [_i, _vp]),
-    "mi_peer_open": (_i, [_i, C.c_char_p, C.POINTER(_vp)]),
-    "mi_peer_close": (_i, [_i, _vp]),
-    "mi_peer_event_create": (_i, [_i, C.POINTER(_vp), C.c_char_p]),
-    "mi_peer_event_open": (_i, [_i, C.c_char_p, C.POINTER(_vp)]),
-    "mi_peer_event_destroy": (_i, [_i, _vp]),
-    "mi_peer_event_record": (_i, [_i, _vp, _vp]),
-    "mi_peer_stream_wait": (_i, [_i, _vp, _vp]),
-    "mi_peer_stream_create": (_i, [_i, C.POINTER(_vp)]),
-    "mi_peer_stream_destroy": (_i, [_i, _vp]),
-    "mi_peer_copy": (_i, [_i, _vp, _vp, _i, _vp, _sz]),
+    "mi_peer_link_create": (_i, [_i, _sz, C.POINTER(_vp), C.c_char_p, C.c_char_p]),
+    "mi_peer_link_connect": (_i, [_vp, _i, C.c_char_p, C.c_char_p, _i]),
+    "mi_peer_link_begin": (_i, [_vp, _vp, C.c_uint, _i]),
+    "mi_peer_link_send": (_i, [_vp, _vp, C.c_uint, _i, _i, _sz, _sz, _vp, _vp]),
+    "mi_peer_link_recv": (_i, [_vp, _vp, C.c_uint, _i, _i, _i, C.POINTER(_vp)]),
+    "mi_peer_exchange": (_i, [_vp, _vp, C.c_uint, _i, _vp, _vp, C.POINTER(_vp), C.POINTER(_vp)]),
+    "mi_peer_link_status": (_i, [_vp, C.POINTER(_i)]),
+    "mi_peer_link_disconnect": (_i, [_vp]),
+    "mi_peer_link_destroy": (_i, [_vp]),
     # mi_crossmips.h
     "mi_ncc_default_params": (None, [_i, _i, _i, C.POINTER(NccParams)]),
     "mi_ncc_mips": (_i, [_i, _vp, _vp, _vp] + [_i] * 10 + [C.POINTER(NccParams), C.POINTER(NccDescr)]),

@@ -132,20 +132,16 @@ class HipOps:
 
 
 class HipPeer:
-    """Device side of the copy-engine transport: HIP IPC memory / event handles, a copy stream and hipMemcpyPeerAsync, all through
-    the C ABI (include/mi_lsdeconv.h, "copy-engine transport")."""
+    """Device side of the copy-engine transport: one ``mi_peer_link`` of the C ABI (include/mi_lsdeconv.h, "copy-engine transport")
+    -- receive slots and a page of flag words exported through HIP IPC memory handles, a copy stream, hipMemcpyPeerAsync, one-lane
+    kernels that write / wait for sequence numbers.  One C call per step of an exchange."""
 
     def __init__(self, device):
         capi.require_gpu()
         self.dev = torch.device(device)
         self.di = self.dev.index
         self.L = capi.lib()
-        self.stream = C.c_void_p()
-        capi.check(self.L.mi_peer_stream_create(self.di, C.byref(self.stream)))
-        self._packed = torch.cuda.Event()
-
-    def ordinal(self):
-        return int(self.di)
+        self.link = C.c_void_p()
 
     def identity(self):
         """What names this device in EVERY process of the job: its UUID (a rank that masks its devices sees its GPU as ordinal 0)."""
@@ -157,8 +153,8 @@ class HipPeer:
         return ("pci", tuple(bus)) if all(b is not None for b in bus) else ("ordinal", int(self.di))
 
     def resolve(self, ident):
-        """The ordinal under which THIS process sees the device `ident` names; -1 when it does not (mi_peer_copy then leaves the
-        mapped pointer to the runtime instead of naming a device)."""
+        """The ordinal under which THIS process sees the device `ident` names; -1 when it does not (the runtime then resolves the
+        mapped pointer instead of a named device)."""
         kind, val = ident
         if kind == "ordinal":
             return int(val)
@@ -170,225 +166,149 @@ class HipPeer:
                 return i
         return -1
 
-    def alloc(self, nbytes):
-        h, p = C.create_string_buffer(capi.IPC_HANDLE_BYTES), C.c_void_p()
-        capi.check(self.L.mi_peer_alloc(self.di, int(nbytes), C.byref(p), h))
-        return int(p.value), h.raw
+    def _s(self):
+        return C.c_void_p(capi.current_stream_ptr(self.dev))
 
-    def free(self, ptr):
-        self.L.mi_peer_free(self.di, C.c_void_p(ptr))
+    def create(self, nbytes):
+        """-> the handles (payload, flag page) the neighbours connect with"""
+        hp, hf = C.create_string_buffer(capi.IPC_HANDLE_BYTES), C.create_string_buffer(capi.IPC_HANDLE_BYTES)
+        capi.check(self.L.mi_peer_link_create(self.di, int(nbytes), C.byref(self.link), hp, hf))
+        return hp.raw, hf.raw
 
-    def open(self, handle):
-        q = C.c_void_p()
-        capi.check(self.L.mi_peer_open(self.di, handle, C.byref(q)))
-        return int(q.value)
-
-    def close(self, ptr):
-        self.L.mi_peer_close(self.di, C.c_void_p(ptr))
-
-    def offset(self, base, nbytes):
-        return base + int(nbytes)
-
-    def event(self):
-        e, h = C.c_void_p(), C.create_string_buffer(capi.IPC_HANDLE_BYTES)
-        capi.check(self.L.mi_peer_event_create(self.di, C.byref(e), h))
-        return e, h.raw
-
-    def event_open(self, handle):
-        e = C.c_void_p()
-        capi.check(self.L.mi_peer_event_open(self.di, handle, C.byref(e)))
-        return e
-
-    def event_destroy(self, ev):
-        self.L.mi_peer_event_destroy(self.di, ev)
-
-    def _s(self, copy_stream):
-        return self.stream if copy_stream else C.c_void_p(capi.current_stream_ptr(self.dev))
-
-    def record(self, ev, copy_stream):
-        capi.check(self.L.mi_peer_event_record(self.di, ev, self._s(copy_stream)))
-
-    def wait(self, ev, copy_stream):
-        capi.check(self.L.mi_peer_stream_wait(self.di, self._s(copy_stream), ev))
-
-    def copy_after_launch(self):
-        """The copy stream waits for what the launch stream holds so far (the pack kernels)."""
-        self._packed.record(torch.cuda.current_stream(self.dev))
-        capi.check(self.L.mi_peer_stream_wait(self.di, self.stream, C.c_void_p(self._packed.cuda_event)))
-
-    def copy(self, dst, dst_dev, src_tensor, nbytes):
-        capi.check(self.L.mi_peer_copy(self.di, self.stream, C.c_void_p(dst), int(dst_dev), src_tensor.data_ptr(), int(nbytes)))
+    def connect(self, d, handles, ident):
+        capi.check(self.L.mi_peer_link_connect(self.link, int(d), handles[0], handles[1], self.resolve(ident)))
 
     def staging(self, nfloats):
         return torch.empty(int(nfloats), dtype=torch.float32, device=self.dev)
 
+    def begin(self, n, src_mask):
+        capi.check(self.L.mi_peer_link_begin(self.link, self._s(), int(n), int(src_mask)))
+
+    def send(self, n, k, chunks, first_byte, nbytes, up, dn):
+        capi.check(self.L.mi_peer_link_send(self.link, self._s(), int(n), int(k), int(chunks), int(first_byte), int(nbytes),
+                                            up.data_ptr() if up is not None else None, dn.data_ptr() if dn is not None else None))
+
+    def recv(self, n, k, chunks, d):
+        q = C.c_void_p()
+        capi.check(self.L.mi_peer_link_recv(self.link, self._s(), int(n), int(k), int(chunks), int(d), C.byref(q)))
+        return int(q.value)
+
+    def exchange(self, n, src_mask, up, dn):
+        """One exchange of one chunk in ONE call: both sends, then the waits.  -> (slot 0 or None, slot 1 or None)"""
+        lo, hi = C.c_void_p(), C.c_void_p()
+        capi.check(self.L.mi_peer_exchange(self.link, self._s(), int(n), int(src_mask), up.data_ptr() if up is not None else None,
+                                           dn.data_ptr() if dn is not None else None, C.byref(lo), C.byref(hi)))
+        return (int(lo.value) if lo.value else None), (int(hi.value) if hi.value else None)
+
+    def timed_out(self):
+        v = C.c_int()
+        capi.check(self.L.mi_peer_link_status(self.link, C.byref(v)))
+        return int(v.value)
+
+    def disconnect(self):
+        if self.link:
+            self.L.mi_peer_link_disconnect(self.link)
+
     def destroy(self):
-        torch.cuda.synchronize(self.dev)
-        self.L.mi_peer_stream_destroy(self.di, self.stream)
+        if self.link:
+            self.L.mi_peer_link_destroy(self.link)
+            self.link = C.c_void_p()
 
 
 class PeerLink:
-    """Copy-engine transport of the halo exchange ("peer"): every rank exports ONE device allocation that holds its receive buffers
-    (two sets, alternating between consecutive exchanges, x two halos) and interprocess events; a sender copies its packed rows
-    straight into the neighbour's buffer with ``hipMemcpyPeerAsync`` on a stream of its own -- executed by the SDMA engines, so the
-    persistent x pass that runs meanwhile keeps every compute unit -- and records an interprocess event the receiver's launch
-    stream waits for.  Record and wait of one exchange are ordered by a sequence number per directed edge in a small host
-    shared-memory file (an interprocess event only ever means "its latest record"); the receiver acknowledges a buffer set the
-    same way before the sender overwrites it two exchanges later.  Handles travel once, through ``all_gather_object``.
+    """Copy-engine transport of the halo exchange ("peer").  Every rank exports its receive slots (two directions x two sets that
+    alternate between consecutive exchanges) and a page of flag words; a sender copies its packed rows straight into the
+    neighbour's slot on a stream of its own -- SDMA engines, so the persistent x pass that runs meanwhile keeps every compute
+    unit -- and then writes the sequence number of what it has delivered into the neighbour's arrival word; the receiver's launch
+    stream waits until that word has reached the number it needs.  The receiver acknowledges exchange n when exchange n + 1 begins
+    (a word of the sender's page), and the sender's copy stream waits for that before it overwrites the set at exchange n + 2.
+    Nothing is handed over on the host after the handles have travelled once (``all_gather_object``); a wait names a VALUE, so a
+    repeated or early wait is harmless (round 4 used interprocess events and host sequence numbers: csrc/peer.hip).
 
-    Directed edges of rank r: d = 0 "up" (its last interior rows -> lower halo of the next rank), d = 1 "down" (its first interior
-    rows -> upper halo of the previous rank); the receiving slot has the same index d.  ``backend``: HipPeer, or a host double
-    with the same methods (tests/slab_util.py) so that the protocol runs on CPU ranks."""
+    Directed edges of rank r: d = 0 "up" (its last interior rows -> slot 0 of the next rank), d = 1 "down" (its first interior
+    rows -> slot 1 of the previous rank).  ``backend``: HipPeer, or a host double with the same methods (tests/slab_util.py) so
+    that the protocol runs on CPU ranks."""
 
     SETS = 2
 
     def __init__(self, drv, nfloats, backend, group=None, timeout_s=120.0, chunks=1):
-        import mmap
-        import os
-        import tempfile
-
         import torch.distributed as dist
-        self.drv, self.group, self.n, self.timeout = drv, group, 0, float(timeout_s)
+        self.drv, self.group, self.n = drv, group, 0
         self.be = backend
         self.nfloats = int(nfloats)
         self.nbytes = 4 * self.nfloats
-        self.C = max(1, int(chunks))   # an exchange may travel in C chunks (z chunks of the halo rows), each with its own event
-        self.recv_base, mem_handle = backend.alloc(2 * self.SETS * self.nbytes)
+        self.C = max(1, int(chunks))   # an exchange may travel in C chunks (z chunks of the halo rows)
+        handles = backend.create(self.nbytes)
         self.staging = [[backend.staging(self.nfloats) for _ in range(self.SETS)] for _ in range(2)]
-
-        def make_events(per):
-            pairs = [backend.event() for _ in range(2 * self.SETS * per)]
-            return [e for e, _ in pairs], [h for _, h in pairs]
-
-        # [(d * SETS + set) * C + chunk]: my copy of that chunk of edge d into the neighbour's set has been issued
-        self.ev_sent, hs_sent = make_events(self.C)
-        self.ev_done, hs_done = make_events(1)         # [d * SETS + set]: I have consumed slot d, set
-        # host sequence numbers: [rank][d][0 = sent, 1 = consumed] uint64, one file for the job
-        name = [None]
-        if drv.rank == 0:
-            fd, path = tempfile.mkstemp(prefix="mi_halo_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
-            os.ftruncate(fd, 8 * 4 * drv.world)
-            os.close(fd)
-            name[0] = path
-        dist.broadcast_object_list(name, src=0, group=group)
-        self.shm_path = name[0]
-        self._fd = os.open(self.shm_path, os.O_RDWR)
-        self._mm = mmap.mmap(self._fd, 8 * 4 * drv.world)
-        self.seq = np.frombuffer(self._mm, dtype=np.uint64).reshape(drv.world, 2, 2)
-        mine = {"mem": mem_handle, "sent": hs_sent, "done": hs_done,
-                "dev": backend.identity() if hasattr(backend, "identity") else ("ordinal", backend.ordinal())}
+        mine = {"handles": handles, "dev": backend.identity()}
         everyone = [None] * drv.world
         dist.all_gather_object(everyone, mine, group=group)
         lo, hi = drv.neighbours()
-        self.peer = {}                                  # d -> (rank, mapped base, device ordinal, opened ev_done of its slot d)
-        self.src = {}                                   # d -> (rank that fills my slot d, opened ev_sent of its edge d)
-        self._mapped = {}
-        for d, dst_rank, src_rank in ((0, hi, lo), (1, lo, hi)):
+        self.has_dst = {0: hi is not None, 1: lo is not None}     # edge d has a receiver
+        self.src_mask = (1 if lo is not None else 0) | (2 if hi is not None else 0)   # slot d has a sender
+        for d, dst_rank in ((0, hi), (1, lo)):
             if dst_rank is not None:
-                info = everyone[dst_rank]
-                if dst_rank not in self._mapped:
-                    self._mapped[dst_rank] = backend.open(info["mem"])
-                evs = [backend.event_open(info["done"][d * self.SETS + st]) for st in range(self.SETS)]
-                pdev = backend.resolve(info["dev"]) if hasattr(backend, "resolve") else int(info["dev"][1])
-                self.peer[d] = (dst_rank, self._mapped[dst_rank], pdev, evs)
-            if src_rank is not None:
-                info = everyone[src_rank]
-                self.src[d] = (src_rank, [backend.event_open(info["sent"][(d * self.SETS + st) * self.C + k])
-                                          for st in range(self.SETS) for k in range(self.C)])
+                backend.connect(d, everyone[dst_rank]["handles"], everyone[dst_rank]["dev"])
+        self._slots = (None, None)
         dist.barrier(group=group)
-        if drv.rank == 0:
-            os.unlink(self.shm_path)                   # every rank holds it open; the name can go
-
-    def _slot(self, base, d, st):
-        return self.be.offset(base, (d * self.SETS + st) * self.nbytes)
-
-    def _host_wait(self, rank, d, field, n):
-        import time
-        t0 = time.monotonic()
-        while int(self.seq[rank, d, field]) < n:
-            time.sleep(20e-6)                          # (the neighbour is at most one enqueue away: no need to burn the core)
-            if time.monotonic() - t0 > self.timeout:
-                raise TimeoutError(f"halo exchange {n}: rank {rank} did not {'issue its copy' if field == 0 else 'release its buffer'} "
-                                   f"within {self.timeout:.0f} s")
 
     def begin(self):
         """Next exchange: the staging buffers (edge 0, edge 1) to pack the rows into, on the launch stream."""
         self.n += 1
         st = self.n % self.SETS
-        out = []
-        for d in (0, 1):
-            if d in self.peer and self.n > self.SETS:   # the copies that read this staging buffer two exchanges ago must have run
-                self.be.wait(self.ev_sent[(d * self.SETS + st) * self.C + self.C - 1], False)
-            out.append(self.staging[d][st] if d in self.peer else None)
-        return out
+        self.be.begin(self.n, self.src_mask)
+        self._slots = (None, None)
+        return [self.staging[d][st] if self.has_dst[d] else None for d in (0, 1)]
 
     def send(self, k=0, first_float=0, nfloats=None):
-        """Chunk k of the rows is packed (launch stream): copy it into the neighbours' buffers on the copy stream.  The chunk is the
-        float range [first_float, first_float + nfloats) of the staging buffer and lands at the same place of the receive buffer
-        (default: the whole buffer as the only chunk)."""
+        """Chunk k of the rows is packed (launch stream): copy it into the neighbours' slots on the copy stream.  The chunk is the
+        float range [first_float, first_float + nfloats) of the staging buffer and lands at the same place of the receive slot."""
         st = self.n % self.SETS
         nfloats = self.nfloats - first_float if nfloats is None else int(nfloats)
-        if self.peer:
-            self.be.copy_after_launch()
-        for d in (0, 1):
-            if d not in self.peer:
-                continue
-            rank, base, pdev, ev_done = self.peer[d]
-            if k == 0 and self.n > self.SETS:           # the neighbour has consumed what exchange n - SETS left in this set
-                self._host_wait(rank, d, 1, self.n - self.SETS)
-                self.be.wait(ev_done[st], True)
-            self.be.copy(self.be.offset(self._slot(base, d, st), 4 * first_float), pdev,
-                         self.staging[d][st][first_float:first_float + nfloats], 4 * nfloats)
-            self.be.record(self.ev_sent[(d * self.SETS + st) * self.C + k], True)
-            self.seq[self.drv.rank, d, 0] = (self.n - 1) * self.C + k + 1
+        self.be.send(self.n, k, self.C, 4 * first_float, 4 * nfloats, self.staging[0][st] if self.has_dst[0] else None,
+                     self.staging[1][st] if self.has_dst[1] else None)
+
+    def exchange(self):
+        """send() of the whole buffer and receive() of both slots in one call of the backend (C == 1)."""
+        st = self.n % self.SETS
+        self._slots = self.be.exchange(self.n, self.src_mask, self.staging[0][st] if self.has_dst[0] else None,
+                                       self.staging[1][st] if self.has_dst[1] else None)
 
     def receive(self, d, k=0):
         """The rows that arrived in slot d (None: global edge) as the backend's pointer TO THE WHOLE SLOT; the launch stream waits
         for chunk k of them."""
-        if d not in self.src:
+        if not (self.src_mask >> d & 1):
             return None
-        st = self.n % self.SETS
-        rank, ev_sent = self.src[d]
-        self._host_wait(rank, d, 0, (self.n - 1) * self.C + k + 1)
-        self.be.wait(ev_sent[st * self.C + k], False)
-        return self._slot(self.recv_base, d, st)
+        if self.C == 1 and self._slots[d] is not None:   # exchange() has enqueued the wait already
+            return self._slots[d]
+        return self.be.recv(self.n, k, self.C, d)
 
     def release(self):
-        """The received rows have been unpacked (launch stream): the senders may overwrite this set."""
-        st = self.n % self.SETS
-        for d in self.src:
-            self.be.record(self.ev_done[d * self.SETS + st], False)
-            self.seq[self.drv.rank, d, 1] = self.n
+        """(kept for the callers' sequence: the acknowledgement of an exchange is written when the next one begins)"""
+
+    def check(self):
+        """Raises when a wait of this link ended by its timeout (synchronises with the device)."""
+        t = self.be.timed_out()
+        if t:
+            raise TimeoutError(f"halo exchange: {t} wait(s) of rank {self.drv.rank} for a neighbour ended by the timeout (MI_PEER_TIMEOUT_S)")
 
     def close(self):
-        import os
         import sys
         try:
-            for _, (_, _, _, evs) in self.peer.items():
-                for e in evs:
-                    self.be.event_destroy(e)
-            for _, (_, evs) in self.src.items():
-                for e in evs:
-                    self.be.event_destroy(e)
-            for q in self._mapped.values():
-                self.be.close(q)
-            # nobody frees the buffer it exported before every neighbour has closed its mapping of it
+            t = self.be.timed_out()
+            self.be.disconnect()
+            # nobody frees what it exported before every neighbour has unmapped it
             try:
                 import torch.distributed as dist
                 if dist.is_initialized():
                     dist.barrier(group=self.group)
             except Exception as e:
                 sys.stderr.write(f"PeerLink.close: no barrier before the buffers are freed ({e!r})\n")
-            for e in self.ev_sent + self.ev_done:
-                self.be.event_destroy(e)
             self.be.destroy()
-            self.be.free(self.recv_base)
-            self.seq = None
-            self._mm.close()
-            os.close(self._fd)
+            if t:
+                sys.stderr.write(f"PeerLink.close: {t} wait(s) for a neighbour had ended by the timeout\n")
         except Exception as e:
             sys.stderr.write(f"PeerLink.close: {e!r}\n")
-        self.peer, self.src, self._mapped = {}, {}, {}
 
 
 class SlabRL:
@@ -498,7 +418,7 @@ class SlabRL:
         self.ops.unpack_spec(self.ctx, recv_lo, 0, h)          # None = global edge of the spatial flavour -> zero rows
         self.ops.unpack_spec(self.ctx, recv_hi, h + n, h)
 
-    def exchange_start(self, vol=None):
+    def exchange_start(self, vol=None, finish_now=False):
         """Pack the rows the neighbours need and issue the sends / receives; returns the state ``exchange_finish`` needs.
         ``vol`` None: the rows of the context's x-transformed input buffer (fused pipeline)."""
         if self.h == 0:
@@ -518,7 +438,10 @@ class SlabRL:
                     self.ops.pack_spec_into(self.ctx, y0, h, buf)
                 else:
                     self.ops.pack_into(vol, y0, h, buf)
-            self.link.send()
+            if finish_now:
+                self.link.exchange()                     # nothing runs between start and finish: sends and waits in ONE call of the C ABI
+            else:
+                self.link.send()                         # (the waits follow the x tiles that run beside the copies: exchange_finish)
             return ("peer", vol)
         send_up, send_dn = self.pack_spec_halos() if spec else self.pack_halos(vol)
         if self.world == 1:  # self-ring: my own rows wrap around
@@ -577,7 +500,7 @@ class SlabRL:
         """Refresh the 2*h halo rows from the neighbouring slabs (ring for the circular flavour, zeros at the global
         edges for the spatial one): of ``vol`` in real space, or -- ``vol`` None, fused pipeline -- of the context's
         x-transformed input buffer."""
-        self.exchange_finish(self.exchange_start(vol))
+        self.exchange_finish(self.exchange_start(vol, finish_now=True))
 
     # ------------------------------------------------------------------ iteration
     def iterate(self):
@@ -738,11 +661,13 @@ class SlabRL:
                 if i > 1 and rel <= stop_criterion:
                     break
         self.drain()
+        if self.link is not None:
+            self.link.check()                            # a neighbour that never delivered: an error, not silence
         return done
 
     def close(self):
-        """Releases the copy-engine link (mapped peer memory, interprocess events); every rank calls it before the process group
-        goes away."""
+        """Releases the copy-engine link (mapped peer memory, its own exported buffers); every rank calls it before the process
+        group goes away."""
         self.drain()
         if self.link is not None:
             self.link.close()

@@ -297,30 +297,48 @@ int mi_unpack_rows(int dev, void* stream, const float* packed, int nx, int ny, i
 
 /* ---- copy-engine transport of the halo exchange (one process per GPU; no reference counterpart: LsDeconv.m:643-654 farms
  * independent blocks out) ---------------------------------------------------------------------------------------------------
- * Device buffers and events shared between the ranks of one node through HIP IPC handles (opaque MI_IPC_HANDLE_BYTES-byte
- * blobs [host] that travel over any host channel), and hipMemcpyPeerAsync on a stream of the caller's choice: a peer copy is
- * executed by the SDMA engines and takes no compute unit away from the persistent x pass it overlaps with, unlike the kernels
- * of a grouped ncclSend/ncclRecv.  slab.py builds its "peer" transport from these (receive buffers exported once, two
- * interprocess events per directed edge, a host-side sequence number in shared memory that orders record and wait). */
+ * A LINK is a rank's side of the ring of slabs: a device allocation with its receive slots (2 directions x 2 alternating sets)
+ * and a page of flag words in fine-grained device memory, both exported through HIP IPC memory handles (opaque
+ * MI_IPC_HANDLE_BYTES-byte blobs [host] that travel once over any host channel), a copy stream, and the mapped memory of its
+ * (at most two) neighbours.  A sender copies its packed rows into the neighbour's slot with hipMemcpyPeerAsync -- executed by the
+ * SDMA engines, which take no compute unit away from the persistent x pass it overlaps with, unlike the kernels of a grouped
+ * ncclSend/ncclRecv -- and then writes the sequence number (exchange - 1) * chunks + chunk + 1 into the neighbour's arrival word;
+ * the receiver's launch stream waits in a one-lane kernel until that word has reached the number it needs.  A receiver
+ * acknowledges exchange n when exchange n + 1 begins (its unpack kernels lie before that point of its launch stream) by writing
+ * n into the sender's acknowledgement word, which the sender's copy stream waits for before it overwrites the set at exchange
+ * n + 2.  No interprocess events, no host-side hand-shake: a wait names a value, so an early, late or repeated wait is the same
+ * comparison (csrc/peer.hip has the reasons).  Every wait gives up after MI_PEER_TIMEOUT_S seconds (default 120) and counts
+ * itself in the link's status word.
+ * Directed edges of a rank: d = 0 "up" (its last interior rows -> slot 0 of the next rank), d = 1 "down" (its first interior rows
+ * -> slot 1 of the previous rank).  Exchanges are numbered n = 1, 2, ... by the caller, the same on every rank. */
 #define MI_IPC_HANDLE_BYTES 64
-/* a device allocation of its own (hipMalloc, never a block of the library's pool) and its IPC handle */
-int mi_peer_alloc(int dev, size_t bytes, void** ptr, unsigned char* handle);
-int mi_peer_free(int dev, void* ptr);
-/* maps another process' allocation into this one (hipIpcOpenMemHandle, peer access enabled lazily) / unmaps it */
-int mi_peer_open(int dev, const unsigned char* handle, void** ptr);
-int mi_peer_close(int dev, void* ptr);
-/* interprocess event (hipEventInterprocess | hipEventDisableTiming) and its handle; the other process opens it */
-int mi_peer_event_create(int dev, void** event, unsigned char* handle);
-int mi_peer_event_open(int dev, const unsigned char* handle, void** event);
-int mi_peer_event_destroy(int dev, void* event);
-int mi_peer_event_record(int dev, void* event, void* stream);
-int mi_peer_stream_wait(int dev, void* stream, void* event);
-/* a non-blocking stream for the copies (torch's streams would do as well; this keeps the transport free of torch) */
-int mi_peer_stream_create(int dev, void** stream);
-int mi_peer_stream_destroy(int dev, void* stream);
-/* dst (a mapped peer pointer on device dst_dev, or any device pointer) <- src on `dev`, `bytes` bytes, in stream order:
- * hipMemcpyPeerAsync; dst_dev outside the visible ordinals: hipMemcpyAsync on the mapped pointer */
-int mi_peer_copy(int dev, void* stream, void* dst, int dst_dev, const void* src, size_t bytes);
+typedef struct mi_peer_link mi_peer_link;
+/* slot_bytes: packed halo rows of one direction.  payload_handle, flag_handle [host, MI_IPC_HANDLE_BYTES each]: what the
+ * neighbours need to connect. */
+int mi_peer_link_create(int dev, size_t slot_bytes, mi_peer_link** link, unsigned char* payload_handle, unsigned char* flag_handle);
+/* the rank that receives edge d (and fills slot 1 - d): its handles, and the ordinal under which THIS process sees its device
+ * (-1: not visible under an ordinal -- the runtime resolves the mapped pointer).  An edge without a neighbour is not connected. */
+int mi_peer_link_connect(mi_peer_link* link, int d, const unsigned char* payload_handle, const unsigned char* flag_handle, int peer_dev);
+/* exchange n begins, BEFORE its rows are packed (launch stream): acknowledges exchange n - 1 to the senders of the slots in
+ * src_mask (bit d: slot d has a sender), and makes the launch stream wait for the copies that read the staging buffers of this
+ * set two exchanges ago. */
+int mi_peer_link_begin(mi_peer_link* link, void* launch_stream, unsigned n, int src_mask);
+/* chunk k of `chunks` of exchange n has been packed on the launch stream into src_up / src_dn [device; the caller's staging
+ * buffers of this exchange's set, NULL for an edge without neighbour]: bytes [first_byte, first_byte + bytes) of both go to the
+ * same place of the neighbours' slots on the copy stream, followed by the arrival number. */
+int mi_peer_link_send(mi_peer_link* link, void* launch_stream, unsigned n, int k, int chunks, size_t first_byte, size_t bytes,
+                      const void* src_up, const void* src_dn);
+/* the launch stream waits for chunk k of slot d of exchange n; *slot [device]: the WHOLE slot */
+int mi_peer_link_recv(mi_peer_link* link, void* launch_stream, unsigned n, int k, int chunks, int d, void** slot);
+/* one exchange in one call (one chunk): send of both edges, then the waits for the slots in src_mask (*slot_lo = slot 0,
+ * *slot_hi = slot 1; NULL where there is no sender).  The caller packs before it, unpacks after it. */
+int mi_peer_exchange(mi_peer_link* link, void* launch_stream, unsigned n, int src_mask, const void* src_up, const void* src_dn,
+                     void** slot_lo, void** slot_hi);
+/* waits of this link that ended by their timeout so far (synchronises with the device) */
+int mi_peer_link_status(mi_peer_link* link, int* timed_out);
+/* teardown in two steps: every rank unmaps its neighbours (disconnect) before any rank frees what it exported (destroy) */
+int mi_peer_link_disconnect(mi_peer_link* link);
+int mi_peer_link_destroy(mi_peer_link* link);
 
 #ifdef __cplusplus
 }

@@ -6,13 +6,13 @@ DEVICE time of the same iteration, on the rank-local shapes of the 8-GPU runs:
     C4 at N = 8   global 4096 x 4096 x 1024, 63 x 63 x 127 PSF -> rank 4096 x 576 x 1024 (512 rows + 2 x 31 -> 576)
 
 One GPU suffices: a self-ring (one process whose slab is its own neighbour: every kernel and every pack / unpack of a rank, no
-transport) and two processes on one GPU with the copy-engine transport (slab.PeerLink: IPC handles, peer copies, interprocess events,
-sequence numbers).  "enqueue" = wall time of K iterations issued back to back WITHOUT a synchronisation, per iteration (the launch
-queues take them all); "CPU" = the thread's CPU time over the same loop (with a neighbour, the issue loop waits for the neighbour's
-sequence numbers -- sleeping -- so its wall time follows the device; the CPU time is what the host works); "device" = the same K
-iterations timed to their end.  A rank is host-bound when its host work approaches its device time.
+transport) and two processes on one GPU with the copy-engine transport (slab.PeerLink on one mi_peer_link: IPC memory handles, peer
+copies, sequence numbers in flag words; round 4: interprocess events and host sequence numbers).  "enqueue" = wall time of K iterations
+issued back to back WITHOUT a synchronisation, per iteration (the launch queues take them all; since round 5 the issue loop never waits
+for the neighbour on the host); "CPU" = the thread's CPU time over the same loop; "device" = the same K iterations timed to their end.
+A rank is host-bound when its host work approaches its device time.
 
-    python profiles/slab_host_cost.py > gpurun_out/r04_slab_host_cost.txt
+    python profiles/slab_host_cost.py > gpurun_out/r05_slab_host_cost.txt
 """
 import os
 import sys
@@ -49,7 +49,17 @@ def measure(drv, dev):
         drv.iterate()
     ev1.record()
     torch.cuda.synchronize(dev)
-    return t_enq, t_all, ev0.elapsed_time(ev1) / K, t_cpu
+    t_dev = ev0.elapsed_time(ev1) / K
+    # the same issue sequence with an idle device in front of it (one iteration, then a synchronisation): what the host needs per
+    # iteration when nothing pushes back -- K iterations ahead of the device the runtime makes the caller wait inside
+    # hipMemcpyPeerAsync for its in-flight copies (1 ms per call, profiles/r05_slab_host_cost.txt), which is the device's pace, not host work
+    t_idle = 0.0
+    for _ in range(K):
+        t0 = time.perf_counter()
+        drv.iterate()
+        t_idle += time.perf_counter() - t0
+        torch.cuda.synchronize(dev)
+    return t_enq, t_all, t_dev, t_cpu, t_idle / K * 1e3
 
 
 def self_ring(name, zchunks):
@@ -59,10 +69,10 @@ def self_ring(name, zchunks):
     shape, kshape = RANKS[name]
     psf = bench.make_psf(kshape)
     drv = slab.SlabRL(shape, psf, rank=0, world_size=1, device=dev, flavour="fft", engine=2, seed=1, zchunks=zchunks)
-    t_enq, t_all, t_dev, t_cpu = measure(drv, dev)
+    t_enq, t_all, t_dev, t_cpu, t_idle = measure(drv, dev)
     print(f"{name}  self-ring        zchunks {zchunks}: local {drv.lshape[2]} x {drv.lshape[1]} x {drv.lshape[0]}, fused {drv.sharded}, "
           f"split x pass {drv.overlap}:  enqueue {t_enq:6.3f} ms / iteration (CPU {t_cpu:6.3f} ms), device {t_dev:6.3f} ms, wall {t_all:6.3f} ms "
-          f"-> host share {t_enq / t_dev:.2f}", flush=True)
+          f"-> host share {t_enq / t_dev:.2f}; issued to an idle device {t_idle:6.3f} ms", flush=True)
     drv.close()
     del drv
     torch.cuda.empty_cache()
@@ -84,7 +94,31 @@ def _peer_worker(rank, world, port, name, zchunks, out):
         psf = bench.make_psf(kshape)
         drv = slab.SlabRL(gshape, psf, rank=rank, world_size=world, device=dev, flavour="fft", engine=2, seed=1, transport="peer",
                           zchunks=zchunks)
+        # host time inside each call of the link's backend (one C call each), summed over the measured iterations
+        acc = {}
+        be = drv.link.be if drv.link is not None else None
+        if be is None:   # (the link is made by the first exchange)
+            drv.iterate()
+            be = drv.link.be
+
+        def timed(name):
+            fn = getattr(be, name)
+
+            def wrapper(*a, **kw):
+                t0 = time.perf_counter()
+                r = fn(*a, **kw)
+                c = acc.setdefault(name, [0, 0.0])
+                c[0] += 1
+                c[1] += time.perf_counter() - t0
+                return r
+            setattr(be, name, wrapper)
+        for nm in ("begin", "send", "recv", "exchange"):
+            timed(nm)
         res = measure(drv, dev)
+        if rank == 0:
+            iters = 3 + 2 * K
+            print("    host time inside the link's C calls, rank 0: " + ", ".join(
+                f"{nm} {c[0] / iters:.1f} calls / iteration x {c[1] / c[0] * 1e6:.0f} us" for nm, c in sorted(acc.items())), flush=True)
         dist.barrier()
         drv.close()
         if rank == 0:
@@ -108,16 +142,17 @@ def two_processes(name, zchunks):
         got = out.get(timeout=240)
         if got[0] == "error":
             raise RuntimeError(got[1])
-        (t_enq, t_all, t_dev, t_cpu), lshape = got
+        (t_enq, t_all, t_dev, t_cpu, t_idle), lshape = got
     finally:
         for p in procs:
             p.join(timeout=20)
             if p.is_alive():
                 p.kill()
     print(f"{name}  2 procs, 1 GPU   zchunks {zchunks}: local {lshape[2]} x {lshape[1]} x {lshape[0]}, copy-engine transport:  issue loop "
-          f"{t_enq:6.3f} ms / iteration per rank (it WAITS for the neighbour's sequence numbers: two ranks share one GPU), of which CPU "
+          f"{t_enq:6.3f} ms / iteration per rank, of which CPU "
           f"{t_cpu:6.3f} ms; device (BOTH ranks) {t_dev:6.3f} ms, wall {t_all:6.3f} ms "
-          f"-> host work / ONE rank's device time {t_cpu / (t_dev / 2):.2f}", flush=True)
+          f"-> host work / ONE rank's device time {t_cpu / (t_dev / 2):.2f}; issued to an idle device {t_idle:6.3f} ms / iteration "
+          f"-> {t_idle / (t_dev / 2):.2f} of one rank's device time", flush=True)
 
 
 if __name__ == "__main__":

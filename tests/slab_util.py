@@ -118,72 +118,99 @@ class NumpyCtx:
 
 
 class ShmPeer:
-    """Host double of slab.HipPeer for CPU ranks: "device" allocations are shared-memory files, a handle is the file's path, a
-    pointer is (array, byte offset); copies are host memcpys that complete at once, so events have nothing to order -- what is
-    left to test is the link's own protocol: sequence numbers, alternating buffer sets, acknowledgements, teardown."""
+    """Host double of slab.HipPeer for CPU ranks, same protocol (csrc/peer.hip): the exported "device" allocations are shared-memory
+    files (a handle is the file's path, a slot pointer is (array, byte offset)), copies are host memcpys, the flag words are uint32
+    in a second file -- a sender writes the sequence number behind its copy, a receiver polls for `word >= sequence` (on the host,
+    bounded by a timeout), acknowledgements travel the same way.  What this tests is the link's protocol: sequence numbers,
+    alternating buffer sets, acknowledgements before a set is overwritten, waits that are early, late or repeated, teardown."""
 
-    def __init__(self):
-        self.files, self.events = [], 0
+    ARR, ACK = 0, 2
 
-    def ordinal(self):
-        return 0
+    def __init__(self, timeout_s=60.0):
+        self.timeout = float(timeout_s)
+        self.files, self.peers, self.dst, self.timeouts = [], [], {}, 0
 
-    def alloc(self, nbytes):
+    def identity(self):
+        return ("ordinal", 0)
+
+    def _file(self, nbytes, fill):
         import os
         import tempfile
         fd, path = tempfile.mkstemp(prefix="mi_peer_test_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
         os.ftruncate(fd, int(nbytes))
         os.close(fd)
         arr = np.memmap(path, dtype=np.uint8, mode="r+")
-        arr[:] = 0xFF                                   # (NaN pattern: stale reads would show)
+        arr[:] = fill
         self.files.append(path)
-        return (arr, 0), path.encode()
+        return arr, path.encode()
 
-    def free(self, ptr):
+    def create(self, nbytes):
+        self.slot = (int(nbytes) + 255) & ~255
+        self.payload, hp = self._file(4 * self.slot, 0xFF)          # (NaN pattern: stale reads would show)
+        fl, hf = self._file(4096, 0)
+        self.flags = fl.view(np.uint32)
+        return hp, hf
+
+    def connect(self, d, handles, ident):
+        for i, (hp, _, _) in enumerate(self.peers):
+            if hp == handles[0]:
+                self.dst[d] = i
+                return
+        self.peers.append((handles[0], np.memmap(handles[0].decode(), dtype=np.uint8, mode="r+"),
+                           np.memmap(handles[1].decode(), dtype=np.uint8, mode="r+").view(np.uint32)))
+        self.dst[d] = len(self.peers) - 1
+
+    def staging(self, nfloats):
+        return torch.empty(int(nfloats), dtype=torch.float32)
+
+    def _wait(self, word, want):
+        import time
+        t0 = time.monotonic()
+        while int(self.flags[word]) < want:
+            time.sleep(20e-6)
+            if time.monotonic() - t0 > self.timeout:
+                self.timeouts += 1
+                return
+
+    def begin(self, n, src_mask):
+        for d in (0, 1):
+            if n > 1 and (src_mask >> d & 1) and (1 - d) in self.dst:
+                self.peers[self.dst[1 - d]][2][self.ACK + d] = n - 1
+
+    def send(self, n, k, chunks, first_byte, nbytes, up, dn):
+        st = n & 1
+        for d, src in ((0, up), (1, dn)):
+            if d not in self.dst:
+                continue
+            _, pay, fl = self.peers[self.dst[d]]
+            if k == 0 and n > 2:
+                self._wait(self.ACK + d, n - 2)
+            off = (2 * d + st) * self.slot + first_byte
+            pay[off:off + nbytes] = src.numpy().view(np.uint8).reshape(-1)[first_byte:first_byte + nbytes]
+            fl[self.ARR + d] = (n - 1) * chunks + k + 1
+
+    def recv(self, n, k, chunks, d):
+        self._wait(self.ARR + d, (n - 1) * chunks + k + 1)
+        return (self.payload, (2 * d + (n & 1)) * self.slot)
+
+    def exchange(self, n, src_mask, up, dn):
+        self.send(n, 0, 1, 0, 4 * (up if up is not None else dn).numel(), up, dn)
+        return tuple(self.recv(n, 0, 1, d) if (src_mask >> d & 1) else None for d in (0, 1))
+
+    def timed_out(self):
+        return self.timeouts
+
+    def disconnect(self):
+        self.peers, self.dst = [], {}
+
+    def destroy(self):
         import os
         for f in self.files:
             try:
                 os.unlink(f)
             except OSError:
                 pass
-
-    def open(self, handle):
-        return (np.memmap(handle.decode(), dtype=np.uint8, mode="r+"), 0)
-
-    def close(self, ptr):
-        pass
-
-    def offset(self, base, nbytes):
-        return (base[0], base[1] + int(nbytes))
-
-    def event(self):
-        self.events += 1
-        return self.events, b"ev%d" % self.events
-
-    def event_open(self, handle):
-        return handle
-
-    def event_destroy(self, ev):
-        pass
-
-    def record(self, ev, copy_stream):
-        pass
-
-    def wait(self, ev, copy_stream):
-        pass
-
-    def copy_after_launch(self):
-        pass
-
-    def copy(self, dst, dst_dev, src_tensor, nbytes):
-        arr, off = dst
-        arr[off:off + nbytes] = src_tensor.numpy().view(np.uint8).reshape(-1)[:nbytes]
-
-    def staging(self, nfloats):
-        return torch.empty(int(nfloats), dtype=torch.float32)
-
-    def destroy(self):
-        pass
+        self.files = []
 
 
 def _ptr_tensor(ptr, nfloats):
