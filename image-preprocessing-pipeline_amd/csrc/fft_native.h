@@ -106,6 +106,9 @@ struct NativeFft {
     size_t spectrum_bytes() const { return spec_bytes; }   // one of the two spectrum arrays
     void settle_before_update();
     int settle_decide(hipStream_t s);
+    // the spare buffer for S goes back to the driver (every consumer of S other than iterate() calls this first: the sharded steps of
+    // the slab driver, single convolutions -- a C4-shaped rank carried 9.7 GB of it for the whole run)
+    int release_spare();
     int alt_phase = 0;                 // 0 / 1: the next timed update launch writes the first / second S buffer; 2: decide; 3: settled
     hipEvent_t alt_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     int time_between(hipStream_t s, int which, const float2* src, float2* dst, float* bl, int reps, float* avg_ms);

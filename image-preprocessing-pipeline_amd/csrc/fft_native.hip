@@ -26,6 +26,7 @@
 // kept conflict-free, short and overlapped.
 #include <cmath>
 #include <cstdlib>
+#include <mutex>
 #include <vector>
 
 #include "fft_native.h"
@@ -2145,15 +2146,27 @@ int NativeFft::init(hipStream_t s, const int F[3], bool explicit_adjoint) {
     if (vmm_order < 0 && S.bytes >= place_min) {
         int tries = 6;
         if (const char* e = std::getenv("MI_FFT_PLACE_CANDIDATES")) tries = std::max(1, std::min(8, atoi(e)));
+        // one trial at a time per device (plans created concurrently -- decwrap's workers with a large --block-size-max -- would each
+        // hold their candidates and push each other out of memory); what the pool keeps cached goes back to the driver first: the
+        // candidates are allocated behind the pool's back and get none of its trim-on-failure
+        static std::mutex trial_mu[16];
+        int dev_id = 0;
+        MI_HIP(hipGetDevice(&dev_id));
+        std::lock_guard<std::mutex> trial_lock(trial_mu[dev_id & 15]);
+        (void)mi_release_cached_memory(dev_id);
         size_t free_b = 0, total_b = 0;
         MI_HIP(hipMemGetInfo(&free_b, &total_b));
         const size_t vol_bytes = sizeof(float) * 2 * (size_t)Hx * F[1] * F[2];
         const size_t half = sizeof(float2) * n_buf, keep = ((size_t)24 << 30) + vol_bytes;
         while (tries > 1 && (size_t)tries * half + keep > free_b) --tries;
         if (tries > 1) {
-            hipEvent_t e0, e1;
-            MI_HIP(hipEventCreate(&e0));
-            MI_HIP(hipEventCreate(&e1));
+            struct TrialEvents {   // (destroyed on every path out of the trial)
+                hipEvent_t a = nullptr, b = nullptr;
+                ~TrialEvents() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+            } tev;
+            MI_HIP(hipEventCreate(&tev.a));
+            MI_HIP(hipEventCreate(&tev.b));
+            const hipEvent_t e0 = tev.a, e1 = tev.b;
             (void)hipFree(S.p);   // (the single allocation made above makes room for the candidates)
             S.p = nullptr;
             const size_t block_bytes = S.bytes;
@@ -2197,8 +2210,6 @@ int NativeFft::init(hipStream_t s, const int F[3], bool explicit_adjoint) {
                     if (bi < 0 || cost < best) { best = cost; bi = i; bj = j; kept_idx = (int)ms.size(); }
                     ms.push_back(cost);
                 }
-            (void)hipEventDestroy(e0);
-            (void)hipEventDestroy(e1);
             if (xtmp) (void)hipFree(xtmp);
             // a second buffer for S stays until the first call that brings the caller's volume: the update launch is slow when S
             // shares a region with THAT volume, which nothing here can know (NativeFft::iterate settles it: settle_s)
@@ -2872,6 +2883,7 @@ int NativeFft::conv(hipStream_t s, const float* in, bool conj_otf, float* out, i
         MI_TRY(check_aligned(epi.a, "epilogue operand"));
         MI_TRY(check_aligned(epi.b, "epilogue operand"));
     }
+    MI_TRY(release_spare());
     MI_TRY(x_forward(s, in));
     MI_TRY(middle(s, conj_otf));
     return x_inverse(s, out, epi_kind, epi, false);
@@ -2906,6 +2918,19 @@ int NativeFft::settle_decide(hipStream_t s) {
     S_alt.bytes = 0;
     alt_phase = 3;
     return he == hipSuccess ? MI_OK : fail(MI_ERR_HIP, "native FFT: settling S: %s", hipGetErrorString(he));
+}
+
+int NativeFft::release_spare() {
+    if (!S_alt.p || alt_phase >= 3) return MI_OK;
+    if (alt_phase == 2) return settle_decide(nullptr);   // (both update launches have been timed: keep the faster buffer)
+    // phase 0 / 1: S.p is the first buffer, the second was never (or not yet) written by a launch whose output is still needed
+    for (auto& e : alt_ev)
+        if (e) { (void)hipEventDestroy(e); e = nullptr; }
+    (void)hipFree(S_alt.p);   // (waits for the device)
+    S_alt.p = nullptr;
+    S_alt.bytes = 0;
+    alt_phase = 3;
+    return MI_OK;
 }
 
 int NativeFft::iterate(hipStream_t s, float* bl, int n_iters) {

@@ -338,7 +338,7 @@ static int sharded_native(mi_rl_ctx* ctx, NativeFft** out) {
     if (!(ctx->engine == MI_ENGINE_FFT && ctx->fft->native && ctx->fft->native->can_fuse()))
         return fail(MI_ERR_UNSUPPORTED, "mi_rl_sharded: only the native FFT pipeline fuses consecutive convolutions");
     *out = ctx->fft->native;
-    return MI_OK;
+    return ctx->fft->native->release_spare();   // (only the fused loop of mi_rl_iterate settles the spare S array: here it would stay for good)
 }
 
 extern "C" int mi_rl_fuses(mi_rl_ctx* ctx) {

@@ -177,6 +177,31 @@ def open_volume(path: Path):
     raise RuntimeError(f"no *.npy / *.tif slices in {path}")
 
 
+def evict_cores(g, resident, resident_dev, brick_future, lock, evict_lock, brick_complete, write_brick):
+    """The cores of device ``g`` leave ``resident`` (block -> core); a core whose brick is not complete is written first
+    (``write_brick(n, core)``).  Safe with several workers per device that run out of memory together: evictions of one device take
+    turns (``evict_lock``) and the second finds nothing left; a core is popped under ``lock`` (a block is evicted once); a block whose
+    brick is still being written by the writer pool (``brick_future[n]``) is waited for, never written a second time -- two writers
+    of one ``bl_n.lz4.tmp`` would interleave.  Returns the number of cores evicted."""
+    done = 0
+    with evict_lock:
+        with lock:
+            mine = [n for n, gg in resident_dev.items() if gg == g and n in resident]
+        for n in mine:
+            with lock:
+                core = resident.pop(n, None)
+                fut = brick_future.get(n)
+            if core is None:
+                continue
+            if fut is not None:
+                fut.result()
+            if not brick_complete(n):
+                write_brick(n, core)
+            del core
+            done += 1
+    return done
+
+
 def main(argv=None):
     import time as _time
     t_main0 = _time.perf_counter()
@@ -244,6 +269,7 @@ def main(argv=None):
     # D2H of the float32 core, no LZ4, no file: the run cannot be resumed).  Memory: with an explicit --block-size-max whatever the
     # workers' blocks leave free; otherwise the result's share of this device is set aside first, if that is at most half of it.
     n_work_vols = 3 + 2 * (2 if args.use_fft else 0)
+    _warm_thread.join(timeout=120.0)      # its allocations on this device are gone before the free memory sizes the block grid
     free0 = torch.cuda.mem_get_info(gpu - 1)[0]
     keep_resident = os.environ.get("MI_DECWRAP_RESIDENT", "1") != "0" and int(args.start_block) == 1
     keep_bricks = os.environ.get("MI_DECWRAP_BRICKS", "1") != "0" or not keep_resident
@@ -501,21 +527,25 @@ def main(argv=None):
         prep_thread = threading.Thread(target=prepare_assembly, daemon=True)
         prep_thread.start()
 
+    evict_locks = {g: threading.Lock() for g in set(workers)}   # one eviction at a time per device (several workers share one)
+    brick_future = {}                                            # block -> the writer's future of its brick (save_brick)
+
+    def write_evicted(n, core):
+        arr = core.cpu().numpy()
+        brickio.save_lz4(brick_path(n).with_suffix(".lz4.tmp"), arr, chunk_size=brick_chunk, pool=codec)
+        try:
+            os.replace(brick_path(n).with_suffix(".lz4.tmp"), brick_path(n))
+        except FileNotFoundError:       # (the claim was reaped by another process meanwhile: save_brick has the same race)
+            log.warning(f"block {n}: the claim was removed by another process while its brick was being written; skipped")
+
     def evict_resident(g):
         """Allocation failure on GPU g: its resident cores are given up (a core without a brick is written first), the budget of
         every device drops to zero, cached blocks go back to the driver."""
         nonlocal res_budget
         with lock:
             res_budget = 0
-            mine = [n for n, gg in resident_dev.items() if gg == g and n in resident]
-        log.warning(f"GPU {g}: out of device memory; {len(mine)} resident core(s) go back to their bricks")
-        for n in mine:
-            core = resident.pop(n)
-            if not brick_complete(n):
-                arr = core.cpu().numpy()
-                brickio.save_lz4(brick_path(n).with_suffix(".lz4.tmp"), arr, chunk_size=brick_chunk, pool=codec)
-                os.replace(brick_path(n).with_suffix(".lz4.tmp"), brick_path(n))
-            del core
+        k = evict_cores(g, resident, resident_dev, brick_future, lock, evict_locks[g], brick_complete, write_evicted)
+        log.warning(f"GPU {g}: out of device memory; {k} resident core(s) went back to their bricks")
         with lock:
             res_used[g] = 0
         torch.cuda.empty_cache()
@@ -554,14 +584,19 @@ def main(argv=None):
             t_b = time.perf_counter()
             ev0.record()
             rawmax = None if int_input else float(bl.max())                               # LsDeconv.m:717-721
+            out_of_memory = False
             try:
                 t, lb, ub = L.process_block(bl, blk, psf_struct, args.numit, args.lambda_damping, args.stop_criterion, filt,
                                             args.clipval, g, plan=plan)
             except (torch.cuda.OutOfMemoryError, capi.MiError) as e:
                 if isinstance(e, capi.MiError) and e.code != capi.MI_ERR_NOMEM:
                     raise
+                out_of_memory = True               # (recovery happens OUTSIDE the handler: the exception's traceback keeps the failed
+                #                                    attempt's frames -- and their tensors -- alive for as long as it is being handled)
+            if out_of_memory:
                 # the device is full: the resident cores go back to being bricks (they are copies of what the cache folder holds,
                 # or are written now), nothing more is kept on the device, and the block is tried once more
+                bl = t = None
                 evict_resident(g)
                 bl = L.load_block_device(vol, p1, p2, pad, torch.device("cuda", g - 1), staging)
                 t, lb, ub = L.process_block(bl, blk, psf_struct, args.numit, args.lambda_damping, args.stop_criterion, filt,
@@ -607,7 +642,9 @@ def main(argv=None):
                 except OSError:
                     pass
             with lock:
-                pending.append(writers.submit(save_brick, n, view.numpy(), host, lb, ub))
+                fut = writers.submit(save_brick, n, view.numpy(), host, lb, ub)
+                pending.append(fut)
+                brick_future[n] = fut
         log.info(f"block {n}/{num_blocks} done on GPU {g}: stats [{lb:.4g}, {ub:.4g}]" + ("" if host is not None else " (kept on the device only)"))
 
     def save_brick(n, arr, host, lb, ub):

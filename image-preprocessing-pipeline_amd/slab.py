@@ -347,9 +347,17 @@ class SlabRL:
             inv = np.ascontiguousarray(self.psf[::-1, ::-1, ::-1])
         # a rank has its device to itself (one process per GPU): also the smaller spectrum arrays of many ranks are placed by trial
         # (fft_native.hip, NativeFft::init; the library's own limit of 6 GB keeps decwrap's concurrent block plans out)
+        # -- for THIS plan only: the variable is read at plan creation and put back at once, later plans of the process (decon blocks,
+        # other tests) keep the library's limit
         import os
-        os.environ.setdefault("MI_FFT_PLACE_MIN_MB", "1024")
-        self.ctx = self.ops.make_ctx(self.lshape, self.psf, boundary_xyz, shift_xyz, engine, inv)
+        prev = os.environ.get("MI_FFT_PLACE_MIN_MB")
+        if prev is None:
+            os.environ["MI_FFT_PLACE_MIN_MB"] = "1024"
+        try:
+            self.ctx = self.ops.make_ctx(self.lshape, self.psf, boundary_xyz, shift_xyz, engine, inv)
+        finally:
+            if prev is None:
+                os.environ.pop("MI_FFT_PLACE_MIN_MB", None)
         self.bl = torch.zeros(self.lshape, dtype=torch.float32, device=self.device)
         # fused pipeline: halos travel as x-transformed rows, no ratio volume exists
         self.sharded = bool(getattr(self.ctx, "fuses", 0))

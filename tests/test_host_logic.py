@@ -244,3 +244,56 @@ def test_delta_on_ones_closed_form_matches_the_oracle():
     for d in [(0, 0, 0), (1, 0, 0), (0, -1, 0), (3, -2, 1), (-4, 3, -2), (8, 6, 4), (-8, -6, -4), (5, 0, 0), (9, 0, 0), (0, 20, 0)]:
         y = tuple((a + b) % n for a, b, n in zip(p, d, shape))
         assert out[y] == pytest.approx(delta_on_ones_closed_form(psf, shifts, amp, d), rel=2e-6), d
+
+
+def test_evict_cores_from_two_workers_of_one_device():
+    """decwrap's out-of-memory recovery with several workers per device: two workers evict at once while the writer pool
+    still holds one block's brick -- every core leaves once, no brick is written twice or by two writers, nobody raises."""
+    import threading
+    import time
+    from concurrent.futures import ThreadPoolExecutor
+    from ipp_amd import decwrap
+    lock, evict_lock = threading.Lock(), threading.Lock()
+    resident = {n: object() for n in range(1, 9)}
+    resident_dev = {n: (1 if n <= 6 else 2) for n in resident}
+    complete, writing, written = set(), set(), []
+
+    def slow_writer(n):                      # the writer pool's save_brick of block 3
+        with lock:
+            assert n not in writing
+            writing.add(n)
+        time.sleep(0.3)
+        with lock:
+            writing.discard(n)
+            complete.add(n)
+            written.append(n)
+
+    def write_brick(n, core):
+        with lock:
+            assert n not in writing and n not in complete
+            writing.add(n)
+        time.sleep(0.02)
+        with lock:
+            writing.discard(n)
+            complete.add(n)
+            written.append(n)
+
+    with ThreadPoolExecutor(2) as pool:
+        futures = {3: pool.submit(slow_writer, 3)}
+        complete.add(5)                       # a brick that was finished long ago
+        errors, counts = [], []
+
+        def worker():
+            try:
+                counts.append(decwrap.evict_cores(1, resident, resident_dev, futures, lock, evict_lock, lambda n: n in complete, write_brick))
+            except Exception as e:            # noqa: BLE001
+                errors.append(e)
+        ts = [threading.Thread(target=worker) for _ in range(2)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+    assert not errors, errors
+    assert sorted(counts) == [0, 6]
+    assert sorted(resident) == [7, 8]                       # the other device's cores stay
+    assert sorted(written) == [1, 2, 3, 4, 6]               # 3 by the writer pool (waited for), 5 was complete, none twice
