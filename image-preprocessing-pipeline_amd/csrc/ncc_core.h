@@ -692,9 +692,11 @@ inline bool mips_int_ok(int bytes, int dimk, int pitch, size_t slice) {
 inline int mips_fmt_bands(int bytes, int dimk) { return bytes == 4 ? mips_band_group(dimk) : (bytes == 2 ? IntTiles<2>::NB : IntTiles<1>::NB); }
 inline int mips_fmt_width(int bytes) { return bytes == 4 ? 64 : (bytes == 2 ? IntTiles<2>::W : IntTiles<1>::W); }
 
-// `beside_chain`: a lag chain of an earlier group runs while this pass does -- the pass then keeps three work-groups per compute
-// unit instead of four (a quarter of the LDS and of the registers stay free for the chain's work-groups, which otherwise wait for
-// whole work-groups of the pass to retire: profiles/r05_ncc_wpe.txt)
+// `beside_chain`: a lag chain of an earlier group runs while this pass does -- the pass then keeps TWO work-groups per compute
+// unit instead of four (half of the LDS and of the registers stay free for the chain's work-groups, which otherwise wait for whole
+// work-groups of the pass to retire and see none of the memory system: beside a pass at four the xy forward transform of 56 pairs
+// took 2.3 ms instead of 0.24 -- profiles/r05_ncc_timeline_default.txt, r05_ncc_wpe.txt, r05_ncc_sched.txt: 5.8-5.9 ms per 112
+// pairs at two, 6.1-6.3 at three, 6.3 at one)
 int launch_mips(hipStream_t s, const float* A, const float* B, const float* const* tab, int np, size_t pstride, int dimk, int dimi_v, int dimj_v,
                 size_t slice, int pitch, int ai0, int aj0, float* xy1, float* xz1, float* yz1, float* xy2, float* xz2, float* yz2, float* tmp,
                 hipEvent_t xy_done = nullptr,  // recorded when the MIPs of k_mips5 / k_mips_int are final (deep stacks: the xy MIPs)
@@ -732,9 +734,16 @@ int launch_mips(hipStream_t s, const float* A, const float* B, const float* cons
     static const bool old_pass = [] { const char* e = MI_PROBE_ENV("MI_NCC_MIPS_OLD"); return e && std::atoi(e) != 0; }();  // (probe builds: A/B)
     if (mips5_ok(dimk, pitch) && !old_pass) {
         static const int wpe_env = [] { const char* e = MI_PROBE_ENV("MI_NCC_MIPS_WPE"); return e ? std::atoi(e) : 0; }();
-        const int wpe = wpe_env ? wpe_env : (beside_chain ? 3 : 4);
+        static const int wpe_beside = [] { const char* e = MI_PROBE_ENV("MI_NCC_MIPS_WPE_BESIDE"); return e ? std::atoi(e) : 0; }();
+        const int wpe = beside_chain ? (wpe_beside ? wpe_beside : (wpe_env ? wpe_env : 2)) : (wpe_env ? wpe_env : 4);
         MI_TRY(zero_mips());
-        if (wpe == 3)
+        if (wpe == 1)
+            hipLaunchKernelGGL(k_mips5<1>, grid, dim3(256), 0, s, A, B, tab, pstride, dimk, dimi_v, dimj_v, slice, pitch, ai0, aj0, xy1, xz1, yz1, xy2, xz2, yz2,
+                               knock, xyT, tstride);
+        else if (wpe == 2)
+            hipLaunchKernelGGL(k_mips5<2>, grid, dim3(256), 0, s, A, B, tab, pstride, dimk, dimi_v, dimj_v, slice, pitch, ai0, aj0, xy1, xz1, yz1, xy2, xz2, yz2,
+                               knock, xyT, tstride);
+        else if (wpe == 3)
             hipLaunchKernelGGL(k_mips5<3>, grid, dim3(256), 0, s, A, B, tab, pstride, dimk, dimi_v, dimj_v, slice, pitch, ai0, aj0, xy1, xz1, yz1, xy2, xz2, yz2,
                                knock, xyT, tstride);
         else

@@ -1299,9 +1299,9 @@ static int close_job(LagJob& job);
 
 // MI_NCC_GATE=1 (probe builds): a group's MIP pass starts only when the previous group's chain is past its tables and its xy forward
 // transform.  Rounds 3-4 ran that way -- those kernels are bound by memory latency and waited for whole work-groups of the pass to
-// retire before they found a compute unit (profiles/r03_ncc_timeline.txt).  Since round 5 a pass that runs beside a chain keeps three
+// retire before they found a compute unit (profiles/r03_ncc_timeline.txt).  Since round 5 a pass that runs beside a chain keeps two
 // work-groups per compute unit (launch_mips), the chain's work-groups are resident next to them, and the gate costs more than it
-// saves: 6.12 against 6.27 ms per 112 pairs (profiles/r05_ncc_wpe.txt).
+// saves: 5.96 against 6.07 ms per 112 pairs (profiles/r05_ncc_sched.txt).
 static bool mip_gate() {
     static const bool on = [] {
         const char* e = MI_PROBE_ENV("MI_NCC_GATE");
@@ -1354,7 +1354,10 @@ int ncc_lag_enqueue(int dev, hipStream_t s, int n, const float* const* a_ptrs, c
     const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, budget / per_pair));
     // (pieces of a chunk -- the MIP pass of piece i + 1 beside the chain of piece i -- were measured again on the round-4 chain: 6.6 / 6.9 /
     // 7.1 / 7.2 ms per 112 pairs for 1 / 2 / 3 / 4 pieces, uint16 tiles 4.6 / 5.6 / 5.9 / 6.0: more launches, more contention)
-    const int piece = chunk;
+    int piece = chunk;
+    if (const char* e = MI_PROBE_ENV("MI_NCC_PIECES")) piece = std::max(1, (chunk + std::max(1, std::atoi(e)) - 1) / std::max(1, std::atoi(e)));
+    if (const char* e = MI_PROBE_ENV("MI_NCC_PIECES_BESIDE"))
+        if (chain_beside) piece = std::max(1, (chunk + std::max(1, std::atoi(e)) - 1) / std::max(1, std::atoi(e)));
 
     MI_TRY(grow(ws.fbuf, 4 * pstride * chunk));
     MI_TRY(grow(ws.sat, 8 * sstride * chunk));
