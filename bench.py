@@ -26,7 +26,7 @@ WORKLOADS = {  # name: (volume (z,y,x), psf (z,y,x))
     "c1": ((64, 256, 256), (15, 9, 9)),
     "c2": ((256, 1024, 1024), (31, 15, 15)),
     "c3": ((512, 2048, 2048), (61, 31, 31)),
-    "c4": ((1024, 4096, 4096), (127, 63, 63)),   # whole on ONE device: 241 GB of the 288 (--workload c4, or the c4_single row at N = 1)
+    "c4": ((1024, 4096, 4096), (127, 63, 63)),   # whole on ONE device: 258 GB of the 288 (--workload c4, or the c4_single row at N = 1)
 }
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec (MI355X_MICROARCH.md, chip-level parameters)
 ALGO_BYTES_PER_VOXEL_ITER = 48  # RL FFT path, SURVEY.md section 8d / DESIGN.md
@@ -60,17 +60,21 @@ def make_volume(shape, device, seed=1234):
 
 def pmc_traffic(pass_name, workload):
     """(HBM bytes per launch of the dominant kernel, the file they come from): the committed PMC passes of this same command
-    (profiles/r04_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in two separate runs, FETCH_SIZE doubled as
+    (profiles/r05_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in two separate runs, FETCH_SIZE doubled as
     MI355X_MICROARCH.md prescribes).  Counters cannot be collected from inside the timed process, so this is a CONSTANT of that
     profile, quoted beside the live launch time -- `roofline.traffic_source` says so in the JSON line.  (None, None) when the
     profile does not hold the kernel."""
     if workload != "c3":
         return None, None
-    name = "r04_pmc_traffic.json"
-    try:
-        with open(os.path.join(ROOT, "profiles", name)) as f:
-            kern = json.load(f)["kernels"]
-    except (OSError, KeyError, ValueError):
+    kern, name = None, None
+    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                kern = json.load(f)["kernels"]
+            break
+        except (OSError, KeyError, ValueError):
+            continue
+    if kern is None:
         return None, None
     # (the pair-interleaved layout runs k_y_pair / k_z_pair_pipe, the plain one k_y_pass / k_z_conv_pipe)
     # (k_x_fused_pipe<.., 0> is the fused pass; modes 1 / 2 are the forward-only / inverse-only launches around a chain)

@@ -94,18 +94,18 @@ def mips_roofline(dev, tiles, pairs):
     # HBM bytes per launch from the committed PMC passes (profiles/collect.sh: FETCH_SIZE x 2 + WRITE_SIZE, 56 pairs per launch);
     # a constant of that profile, not a measurement of this run -- only quoted for the launch geometry it was taken on
     traffic, source = None, None
-    for name in ("r04_ncc_pmc_traffic.json", "r03_ncc_pmc_traffic.json"):
+    for name in ("r05_ncc_pmc_traffic.json", "r04_ncc_pmc_traffic.json", "r03_ncc_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 ks = json.load(f)["kernels"]
-                traffic = round(ks[next(k for k in ("k_mips<true>", "k_mips") if k in ks)]["hbm_bytes_per_launch"])
+                traffic = round(ks[next(k for k in ("k_mips5<4>", "k_mips<true>", "k_mips") if k in ks)]["hbm_bytes_per_launch"])
             source = "profiles/" + name
             break
         except (OSError, KeyError, ValueError, StopIteration):
             continue
     if not (len(pairs) == 112 and launches == 2):
         traffic, source = None, None
-    return {"bound": "hbm", "kernel": "k_mips (six MIPs of every pair of a group in one streaming pass)", "achieved": round(ach, 1),
+    return {"bound": "hbm", "kernel": "k_mips5 (six MIPs of every pair of a group in one streaming pass)", "achieved": round(ach, 1),
             "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": traffic, "traffic_source": source,
             "algorithmic_bytes_per_launch": int(tot_bytes / max(launches, 1)), "algorithmic_bytes_per_pair": int(2 * dk * (di - 0) * OVERLAP * 4),
             "launches": out}
