@@ -250,6 +250,9 @@ def main(argv=None):
             log.debug(f"warm-up skipped: {e!r}")
 
     import threading as _threading
+    # (the free memory that sizes the block grid is read BEFORE the warm-up allocates anything on this device: the grid, and with it
+    # the shapes a resumed cache folder must match, does not depend on how far the thread has got)
+    free0 = torch.cuda.mem_get_info(args.gpu_indices[0] - 1)[0]
     _warm_thread = _threading.Thread(target=_warm, daemon=True)
     _warm_thread.start()
     t_psf0 = _time.perf_counter()
@@ -269,8 +272,6 @@ def main(argv=None):
     # D2H of the float32 core, no LZ4, no file: the run cannot be resumed).  Memory: with an explicit --block-size-max whatever the
     # workers' blocks leave free; otherwise the result's share of this device is set aside first, if that is at most half of it.
     n_work_vols = 3 + 2 * (2 if args.use_fft else 0)
-    _warm_thread.join(timeout=120.0)      # its allocations on this device are gone before the free memory sizes the block grid
-    free0 = torch.cuda.mem_get_info(gpu - 1)[0]
     keep_resident = os.environ.get("MI_DECWRAP_RESIDENT", "1") != "0" and int(args.start_block) == 1
     keep_bricks = os.environ.get("MI_DECWRAP_BRICKS", "1") != "0" or not keep_resident
     res_share = sz * sy * sx * 4 // len(set(args.gpu_indices)) + (1 << 30)
@@ -687,6 +688,7 @@ def main(argv=None):
                             pass
             if missing == 0:
                 break
+            _warm_thread.join(timeout=120.0)       # (its plan is closed before the workers make their first allocations)
             with ThreadPoolExecutor(max_workers=len(workers)) as pool:
                 for f in [pool.submit(run, w, min(num_blocks, start + w)) for w in range(len(workers))]:
                     f.result()                                                             # re-raises a worker's exception
