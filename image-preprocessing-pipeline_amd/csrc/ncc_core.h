@@ -298,26 +298,45 @@ template <int WPE>  // waves per SIMD = work-groups per compute unit
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_mips5(
     const float* __restrict__ A, const float* __restrict__ B, const float* const* __restrict__ tab, size_t pstride, int dimk, int dimi_v, int dimj_v,
     size_t slice, int pitch, int ai0, int aj0, float* __restrict__ xy1, float* __restrict__ xz1, float* __restrict__ yz1, float* __restrict__ xy2,
-    float* __restrict__ xz2, float* __restrict__ yz2, int knock, float* __restrict__ xyT, size_t tstride) {
+    float* __restrict__ xz2, float* __restrict__ yz2, int knock, float* __restrict__ xyT, size_t tstride, int cblocks, int groups, int nviews, int remap) {
+    // Patch of this work-group: column block bx, band group by, view bz, from a one-dimensional grid.  remap: work-groups b, b + 8,
+    // b + 16, ... -- they run on one XCD and start together -- take the `cblocks` column blocks of ONE group of rows: their xy rows
+    // are pieces of the same lines and of the same DRAM pages, and what one L2 collects it writes back as whole runs.
+    int bx, by, bz;
+    {
+        const int id = (int)blockIdx.x;
+        int rg;
+        if (remap) {
+            const int s_ = id >> 3;
+            bx = s_ % cblocks;
+            rg = (s_ / cblocks) * 8 + (id & 7);
+        } else {
+            bx = id % cblocks;
+            rg = id / cblocks;
+        }
+        by = rg % groups;
+        bz = rg / groups;
+        if (bz >= nviews) return;   // (the grid is padded to whole groups of 8 row groups)
+    }
     __shared__ float xyb[MIP_NB][MIP_ROWS][65];        // xy maxima of the bands (merged across the waves with LDS atomics)
     __shared__ float cacc[4][MIP_KPW][65];             // column maxima of the wave's slices over all bands: slice k = wave + 4 q
     __shared__ float xzp[MIP_NB * MIP_ROWS][MIP5_XS];  // row maxima over the patch's 64 columns
-    const bool second = blockIdx.z & 1;
-    const size_t poff = (size_t)(blockIdx.z >> 1) * pstride;
-    const float* vol = tab ? tab[blockIdx.z] : (second ? B : A);
+    const bool second = bz & 1;
+    const size_t poff = (size_t)(bz >> 1) * pstride;
+    const float* vol = tab ? tab[bz] : (second ? B : A);
     if (!second) vol += (size_t)ai0 * pitch + aj0;
     float* xy = (second ? xy2 : xy1) + poff;
     float* xz = (second ? xz2 : xz1) + poff;
     float* yz = (second ? yz2 : yz1) + poff;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int jshift = second ? 0 : (aj0 & 63);  // column blocks start on 256-byte boundaries of the TILE rows (see k_mips)
-    const int j = (int)blockIdx.x * 64 + lane - jshift;
+    const int j = bx * 64 + lane - jshift;
     const bool live = j >= 0 && j < dimj_v;
     float* colacc = &cacc[wave][0][lane];
 #pragma unroll
     for (int q = 0; q < MIP_KPW; ++q) colacc[q * 65] = 0.0f;
     for (int e = threadIdx.x; e < MIP_NB * MIP_ROWS * 65; e += 256) (&xyb[0][0][0])[e] = 0.0f;
-    const int ib0 = __builtin_amdgcn_readfirstlane((int)blockIdx.y * MIP_NB * MIP_ROWS);
+    const int ib0 = __builtin_amdgcn_readfirstlane(by * MIP_NB * MIP_ROWS);
     const int nbv = min(MIP_NB, (dimi_v - ib0 + MIP_ROWS - 1) / MIP_ROWS);  // bands of this work-group inside the view (>= 1)
     float v[MIP_ROWS], vn[MIP_ROWS];
     // every load is unconditional (see k_mips): lanes outside the view read its nearest column, rows past the last band its last row
@@ -386,11 +405,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
             if (r < rows) xy[(size_t)(i0 + r) * dimj_v + j] = xyb[wave][r][lane];
     }
     if (xyT) {  // column c of the patch = 16 nbv consecutive floats of line j of the transposed copy: the lanes run along i
-        float* t = xyT + (size_t)blockIdx.z * tstride;
+        float* t = xyT + (size_t)bz * tstride;
         const int i = ib0 + lane;
         if (lane < nbv * MIP_ROWS && i < dimi_v)
             for (int c = wave; c < 64; c += 4) {
-                const int jc_ = (int)blockIdx.x * 64 + c - jshift;
+                const int jc_ = bx * 64 + c - jshift;
                 if (jc_ >= 0 && jc_ < dimj_v) t[(size_t)jc_ * dimi_v + i] = xyb[lane >> 4][lane & 15][c];
             }
     }
@@ -407,7 +426,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
             const float* ck = &cacc[k & 3][k >> 2][0];
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
-                const int c = (threadIdx.x >> 5) + 8 * it, jc_ = (int)blockIdx.x * 64 + c - jshift;
+                const int c = (threadIdx.x >> 5) + 8 * it, jc_ = bx * 64 + c - jshift;
                 if (jc_ >= 0 && jc_ < dimj_v) atomic_max_nonneg(&yz[(size_t)jc_ * dimk + k], ck[c]);
             }
         }
@@ -478,7 +497,17 @@ template <int BYTES>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_mips_int(
     const unsigned char* __restrict__ A, const unsigned char* __restrict__ B, const unsigned char* const* __restrict__ tab, size_t pstride, int dimk,
     int dimi_v, int dimj_v, size_t slice, int pitch, int ai0, int aj0, float scale, float* __restrict__ xy1, float* __restrict__ xz1,
-    float* __restrict__ yz1, float* __restrict__ xy2, float* __restrict__ xz2, float* __restrict__ yz2, float* __restrict__ xyT, size_t tstride) {
+    float* __restrict__ yz1, float* __restrict__ xy2, float* __restrict__ xz2, float* __restrict__ yz2, float* __restrict__ xyT, size_t tstride,
+    int cblocks, int groups, int nviews) {
+    int bx, by, bz;   // column block, band group, view: the column blocks of one group of rows on ONE XCD (see k_mips5)
+    {
+        const int id = (int)blockIdx.x, s_ = id >> 3;
+        bx = s_ % cblocks;
+        const int rg = (s_ / cblocks) * 8 + (id & 7);
+        by = rg % groups;
+        bz = rg / groups;
+        if (bz >= nviews) return;   // (the grid is padded to whole groups of 8 row groups)
+    }
     // (round 5, as k_mips5: buffer loads with the band's row offsets in SGPRs; row and column maxima merged into the zeroed MIPs with
     // atomic maxima of the DIVIDED values -- the division is monotonic --, LDS images at odd strides)
     using G = IntTiles<BYTES>;
@@ -488,16 +517,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
     __shared__ float xzp[NB * MIP_ROWS][MIP5_XS];      // row maxima, already divided
     __shared__ unsigned xyb[NB][MIP_ROWS][XW];         // xy maxima of the bands, one word per column (merged with LDS atomics)
     __shared__ unsigned cacc[4 * MIP_KPW][CS];         // packed column maxima of the wave's slices: row wave * MIP_KPW + q, word p * 64 + lane
-    const bool second = blockIdx.z & 1;
-    const size_t poff = (size_t)(blockIdx.z >> 1) * pstride;
-    const unsigned char* vol = tab ? tab[blockIdx.z] : (second ? B : A);
+    const bool second = bz & 1;
+    const size_t poff = (size_t)(bz >> 1) * pstride;
+    const unsigned char* vol = tab ? tab[bz] : (second ? B : A);
     if (!second) vol += (size_t)ai0 * pitch * BYTES;
     float* xy = (second ? xy2 : xy1) + poff;
     float* xz = (second ? xz2 : xz1) + poff;
     float* yz = (second ? yz2 : yz1) + poff;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int a0 = second ? 0 : aj0, alast = a0 + dimj_v - 1;          // first / last tile column of the view
-    const int cj = (a0 & ~(G::W - 1)) + (int)blockIdx.x * G::W + C * lane;  // tile column of the lane's word
+    const int cj = (a0 & ~(G::W - 1)) + bx * G::W + C * lane;  // tile column of the lane's word
     const int jv0 = cj - a0;                                             // view column of its first sample
     // every load is unconditional (see k_mips): a word outside the view reads the nearest word inside, a word that straddles the
     // view's edge takes its nearest inside sample in place of the outside ones (byte permute with a lane-constant selector)
@@ -519,7 +548,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
 #pragma unroll
         for (int p = 0; p < P; ++p) colacc[q * CS + p * 64] = 0u;
     for (int e = threadIdx.x; e < NB * MIP_ROWS * XW; e += 256) (&xyb[0][0][0])[e] = 0u;
-    const int ib0 = __builtin_amdgcn_readfirstlane((int)blockIdx.y * NB * MIP_ROWS);
+    const int ib0 = __builtin_amdgcn_readfirstlane(by * NB * MIP_ROWS);
     const int nbv = min(NB, (dimi_v - ib0 + MIP_ROWS - 1) / MIP_ROWS);
     unsigned v[MIP_ROWS], vn[MIP_ROWS];
     const int voff = cc * BYTES, pitchb = pitch * BYTES;
@@ -612,9 +641,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
             }
         }
     }
-    const int jv_first = (a0 & ~(G::W - 1)) + (int)blockIdx.x * G::W - a0;  // view column of the work-group's word 0, sample 0
+    const int jv_first = (a0 & ~(G::W - 1)) + bx * G::W - a0;  // view column of the work-group's word 0, sample 0
     if (xyT) {  // the transposed copy (see k_mips): lanes along i, a wave per column
-        float* t = xyT + (size_t)blockIdx.z * tstride;
+        float* t = xyT + (size_t)bz * tstride;
         const int i = ib0 + lane;
         if (lane < nbv * MIP_ROWS && i < dimi_v)
             for (int c = wave; c < G::W; c += 4) {
@@ -704,7 +733,7 @@ int launch_mips(hipStream_t s, const float* A, const float* B, const float* cons
     const int nb = mips_fmt_bands(fmt.bytes, dimk), wcol = mips_fmt_width(fmt.bytes);
     const int bands = (dimi_v + MIP_ROWS * nb - 1) / (MIP_ROWS * nb);
     const int cblocks = (dimj_v + (aj0 & (wcol - 1)) + wcol - 1) / wcol;  // (band groups, column blocks aligned to the tile rows)
-    const dim3 grid(cblocks, bands, 2 * np);
+    const dim3 grid(cblocks, bands, 2 * np);   // (the deep-stack pass; k_mips5 and k_mips_int enumerate the same patches from a one-dimensional grid)
     const size_t n_xz = (size_t)dimi_v * dimk, n_yz = (size_t)dimj_v * dimk;
     auto zero_mips = [&]() {  // the passes that merge their row / column maxima into the MIPs with atomic maxima start from zero
         hipLaunchKernelGGL(k_mips_zero, dim3((unsigned)std::min<size_t>((n_xz + n_yz + 255) / 256, 64), 2 * np), dim3(256), 0, s, pstride, n_xz, n_yz, xz1,
@@ -717,12 +746,13 @@ int launch_mips(hipStream_t s, const float* A, const float* B, const float* cons
         const unsigned char* b8 = reinterpret_cast<const unsigned char*>(B);
         const unsigned char* const* t8 = reinterpret_cast<const unsigned char* const*>(tab);
         MI_TRY(zero_mips());
+        const dim3 grid_i((unsigned)((bands * 2 * np + 7) / 8 * 8 * cblocks));
         if (fmt.bytes == 2)
-            hipLaunchKernelGGL(k_mips_int<2>, grid, dim3(256), 0, s, a8, b8, t8, pstride, dimk, dimi_v, dimj_v, slice, pitch, ai0, aj0, fmt.scale, xy1, xz1,
-                               yz1, xy2, xz2, yz2, xyT, tstride);
+            hipLaunchKernelGGL(k_mips_int<2>, grid_i, dim3(256), 0, s, a8, b8, t8, pstride, dimk, dimi_v, dimj_v, slice, pitch, ai0, aj0, fmt.scale, xy1,
+                               xz1, yz1, xy2, xz2, yz2, xyT, tstride, cblocks, bands, 2 * np);
         else
-            hipLaunchKernelGGL(k_mips_int<1>, grid, dim3(256), 0, s, a8, b8, t8, pstride, dimk, dimi_v, dimj_v, slice, pitch, ai0, aj0, fmt.scale, xy1, xz1,
-                               yz1, xy2, xz2, yz2, xyT, tstride);
+            hipLaunchKernelGGL(k_mips_int<1>, grid_i, dim3(256), 0, s, a8, b8, t8, pstride, dimk, dimi_v, dimj_v, slice, pitch, ai0, aj0, fmt.scale, xy1,
+                               xz1, yz1, xy2, xz2, yz2, xyT, tstride, cblocks, bands, 2 * np);
         MI_TRY(launch_check("k_mips_int"));
         if (xy_done) MI_HIP(hipEventRecord(xy_done, s));
         return MI_OK;
@@ -737,18 +767,17 @@ int launch_mips(hipStream_t s, const float* A, const float* B, const float* cons
         static const int wpe_beside = [] { const char* e = MI_PROBE_ENV("MI_NCC_MIPS_WPE_BESIDE"); return e ? std::atoi(e) : 0; }();
         const int wpe = beside_chain ? (wpe_beside ? wpe_beside : (wpe_env ? wpe_env : 2)) : (wpe_env ? wpe_env : 4);
         MI_TRY(zero_mips());
-        if (wpe == 1)
-            hipLaunchKernelGGL(k_mips5<1>, grid, dim3(256), 0, s, A, B, tab, pstride, dimk, dimi_v, dimj_v, slice, pitch, ai0, aj0, xy1, xz1, yz1, xy2, xz2, yz2,
-                               knock, xyT, tstride);
-        else if (wpe == 2)
-            hipLaunchKernelGGL(k_mips5<2>, grid, dim3(256), 0, s, A, B, tab, pstride, dimk, dimi_v, dimj_v, slice, pitch, ai0, aj0, xy1, xz1, yz1, xy2, xz2, yz2,
-                               knock, xyT, tstride);
-        else if (wpe == 3)
-            hipLaunchKernelGGL(k_mips5<3>, grid, dim3(256), 0, s, A, B, tab, pstride, dimk, dimi_v, dimj_v, slice, pitch, ai0, aj0, xy1, xz1, yz1, xy2, xz2, yz2,
-                               knock, xyT, tstride);
-        else
-            hipLaunchKernelGGL(k_mips5<4>, grid, dim3(256), 0, s, A, B, tab, pstride, dimk, dimi_v, dimj_v, slice, pitch, ai0, aj0, xy1, xz1, yz1, xy2, xz2, yz2,
-                               knock, xyT, tstride);
+        static const int remap = [] { const char* e = MI_PROBE_ENV("MI_NCC_MIPS_NOREMAP"); return e && std::atoi(e) != 0 ? 0 : 1; }();
+        const int row_groups = bands * 2 * np;
+        const dim3 grid1((unsigned)((row_groups + 7) / 8 * 8 * cblocks));
+#define MI_LAUNCH_MIPS5(W)                                                                                                                        \
+    hipLaunchKernelGGL(k_mips5<W>, grid1, dim3(256), 0, s, A, B, tab, pstride, dimk, dimi_v, dimj_v, slice, pitch, ai0, aj0, xy1, xz1, yz1, xy2, xz2, yz2, \
+                       knock, xyT, tstride, cblocks, bands, 2 * np, remap)
+        if (wpe == 1) MI_LAUNCH_MIPS5(1);
+        else if (wpe == 2) MI_LAUNCH_MIPS5(2);
+        else if (wpe == 3) MI_LAUNCH_MIPS5(3);
+        else MI_LAUNCH_MIPS5(4);
+#undef MI_LAUNCH_MIPS5
         MI_TRY(launch_check("k_mips5"));
         if (xy_done) MI_HIP(hipEventRecord(xy_done, s));
         return MI_OK;

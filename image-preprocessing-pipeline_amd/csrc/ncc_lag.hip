@@ -1618,7 +1618,7 @@ int ncc_time_mips(int dev, hipStream_t s, int n, const float* const* a_ptrs, con
     MI_HIP(hipStreamSynchronize(s));
     float* o = out.as<float>();
     const int nb = mips_fmt_bands(fmt.bytes, dimk);
-    const int bands = (dimi_v + MIP_ROWS * nb - 1) / (MIP_ROWS * nb), cblocks = (dimj_v + 63) / 64;
+    const int bands = (dimi_v + MIP_ROWS * nb - 1) / (MIP_ROWS * nb), cblocks = (dimj_v + ((side == MI_WEST_EAST ? nj : 0) & 63) + 63) / 64;
     const size_t lds = sizeof(float) * MIP_ROWS * (size_t)dimk * nb;
     MI_REQUIRE(lds <= 32 * 1024, "mi_ncc_time_mips: stack too deep for the timed variant");
     float* xz_tmp = tmp.as<float>() + 2 * (size_t)n * bands * dimk * dimj_v;
@@ -1637,24 +1637,28 @@ int ncc_time_mips(int dev, hipStream_t s, int n, const float* const* a_ptrs, con
         if (r == 0) MI_HIP(hipEventRecord(e0, s));
         if (fmt.bytes != 4) {
             const int aj0 = side == MI_WEST_EAST ? nj : 0, wcol = mips_fmt_width(fmt.bytes);
-            const dim3 grid((dimj_v + (aj0 & (wcol - 1)) + wcol - 1) / wcol, bands, 2 * n);
+            const int cb = (dimj_v + (aj0 & (wcol - 1)) + wcol - 1) / wcol;
+            const dim3 grid((unsigned)((bands * 2 * n + 7) / 8 * 8 * cb));
             const unsigned char* const* t8 = tab.as<const unsigned char*>();
             float* o2 = o + xy + xz + yz;   // (the maxima merge into whatever the MIPs hold: the timed launches need no zeroing)
             if (fmt.bytes == 2)
                 hipLaunchKernelGGL(k_mips_int<2>, grid, dim3(256), 0, s, (const unsigned char*)nullptr, (const unsigned char*)nullptr, t8, pstride, dimk,
                                    dimi_v, dimj_v, (size_t)dimi * dimj, dimj, side == MI_NORTH_SOUTH ? ni : 0, aj0, fmt.scale, o, o + xy, o + xy + xz, o2,
-                                   o2 + xy, o2 + xy + xz, (float*)nullptr, (size_t)0);
+                                   o2 + xy, o2 + xy + xz, (float*)nullptr, (size_t)0, cb, bands, 2 * n);
             else
                 hipLaunchKernelGGL(k_mips_int<1>, grid, dim3(256), 0, s, (const unsigned char*)nullptr, (const unsigned char*)nullptr, t8, pstride, dimk,
                                    dimi_v, dimj_v, (size_t)dimi * dimj, dimj, side == MI_NORTH_SOUTH ? ni : 0, aj0, fmt.scale, o, o + xy, o + xy + xz, o2,
-                                   o2 + xy, o2 + xy + xz, (float*)nullptr, (size_t)0);
+                                   o2 + xy, o2 + xy + xz, (float*)nullptr, (size_t)0, cb, bands, 2 * n);
             continue;
         }
         if (mips5_ok(dimk, dimj) && !old_pass) {  // (its maxima merge into whatever the MIPs hold: the timed launches need no zeroing)
             const char* we = MI_PROBE_ENV("MI_NCC_MIPS_WPE");
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(we && std::atoi(we) == 3 ? k_mips5<3> : k_mips5<4>), dim3(cblocks, bands, 2 * n), dim3(256), 0, s, (const float*)nullptr, (const float*)nullptr, tab.as<const float*>(), pstride,
-                               dimk, dimi_v, dimj_v, (size_t)dimi * dimj, dimj, side == MI_NORTH_SOUTH ? ni : 0, side == MI_WEST_EAST ? nj : 0, o, o + xy,
-                               o + xy + xz, o + xy + xz + yz, o + 2 * xy + xz + yz, o + 2 * xy + 2 * xz + yz, knock, (float*)nullptr, (size_t)0);
+            const char* nr = MI_PROBE_ENV("MI_NCC_MIPS_NOREMAP");
+            const int row_groups = bands * 2 * n, remap = nr && std::atoi(nr) != 0 ? 0 : 1;
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(we && std::atoi(we) == 3 ? k_mips5<3> : k_mips5<4>), dim3((unsigned)((row_groups + 7) / 8 * 8 * cblocks)), dim3(256), 0, s,
+                               (const float*)nullptr, (const float*)nullptr, tab.as<const float*>(), pstride, dimk, dimi_v, dimj_v, (size_t)dimi * dimj, dimj,
+                               side == MI_NORTH_SOUTH ? ni : 0, side == MI_WEST_EAST ? nj : 0, o, o + xy, o + xy + xz, o + xy + xz + yz, o + 2 * xy + xz + yz,
+                               o + 2 * xy + 2 * xz + yz, knock, (float*)nullptr, (size_t)0, cblocks, bands, 2 * n, remap);
             continue;
         }
         hipLaunchKernelGGL(HIP_KERNEL_NAME(dimk <= 4 * MIP_KPW ? k_mips<true> : k_mips<false>), dim3(cblocks, bands, 2 * n), dim3(256), lds, s, (const float*)nullptr, (const float*)nullptr, tab.as<const float*>(),
