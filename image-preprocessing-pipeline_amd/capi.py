@@ -131,6 +131,9 @@ SIGNATURES = {
     "mi_ncc_default_params": (None, [_i, _i, _i, C.POINTER(NccParams)]),
     "mi_ncc_mips": (_i, [_i, _vp, _vp, _vp] + [_i] * 10 + [C.POINTER(NccParams), C.POINTER(NccDescr)]),
     "mi_ncc_mips_host": (_i, [_i, _vp, _vp, _vp] + [_i] * 10 + [C.POINTER(NccParams), C.POINTER(NccDescr)]),
+    "mi_ncc_mips_batch_begin": (_i, [_i, _vp, _i, C.POINTER(_vp), _i, _f, _ip, _ip, _i, _i, _i, _ip, _ip, _i, _i, _i, _ip, C.POINTER(NccParams),
+                                     C.POINTER(_vp)]),
+    "mi_ncc_mips_batch_end": (_i, [_vp, C.POINTER(NccParams), C.POINTER(NccDescr)]),
     "mi_ncc_mips_batch": (_i, [_i, _vp, _i, C.POINTER(_vp), _ip, _ip, _i, _i, _i, _ip, _ip, _i, _i, _i, _ip,
                                C.POINTER(NccParams), C.POINTER(NccDescr)]),
     "mi_ncc_mips_batch_u16": (_i, [_i, _vp, _i, C.POINTER(_vp), C.c_float, _ip, _ip, _i, _i, _i, _ip, _ip, _i, _i, _i, _ip,

@@ -332,10 +332,15 @@ def _pair_arrays(n_rows, n_cols, row_block, rank, world_size, ni_v, nj_h):
             tuple((a, b, 0) for a, b in zip(ni_l, nj_l)))
 
 
-def compute_displacements(tiles, overlap_V: int, overlap_H: int, displ_max_V=S_DISPL_SEARCH_RADIUS_DEF,
+def compute_displacements_begin(tiles, overlap_V: int, overlap_H: int, displ_max_V=S_DISPL_SEARCH_RADIUS_DEF,
                           displ_max_H=S_DISPL_SEARCH_RADIUS_DEF, displ_max_D=S_DISPL_SEARCH_RADIUS_DEF,
                           rank: int = 0, world_size: int = 1, row_block=None, sample_scale=None):
-    """Pairwise displacement computation over one z-layer of a tile grid (step 2 of the stitcher).
+    """``compute_displacements`` in two halves (``mi_ncc_mips_batch_begin`` / ``_end``): enqueues the device stage of the layer's pairs
+    and returns a ``PendingDisplacements``; its ``result()`` waits, runs the host rules and returns the dictionary.  A caller that
+    walks the z layers of a grid begins layer l + 1 before it takes the result of layer l (``compute_displacements_layers``): the
+    next layer's first MIP pass then runs beside this layer's last lag chain.  The tiles must stay unchanged until ``result()``.
+
+    Pairwise displacement computation over one z-layer of a tile grid (step 2 of the stitcher).
 
     ``tiles[r][c]`` are device-resident float32 (D, V, H) tensors of identical shape -- or uint16 / uint8 tensors holding the samples
     the reference would have divided by ``sample_scale`` when it loaded the tiles (default 65535 / 255: tiff2D.cpp:606-610): the
@@ -352,7 +357,7 @@ def compute_displacements(tiles, overlap_V: int, overlap_H: int, displ_max_V=S_D
     pairs, used = _pair_list(n_rows, n_cols, None if row_block is None else (int(row_block[0]), int(row_block[1])), int(rank), int(world_size))
     n = len(pairs)
     if n == 0:
-        return {}
+        return PendingDisplacements(None)
     if any(flat[i] is None for i in used):
         raise ValueError("a tile of a pair this rank computes is not resident (None)")
     first = flat[used[0]]
@@ -382,42 +387,90 @@ def compute_displacements(tiles, overlap_V: int, overlap_H: int, displ_max_V=S_D
     lib().mi_ncc_default_params(displ_max_V, displ_max_H, displ_max_D, C.byref(p0))
     inf_w = p0.INF_W
     params = (NccParams * n).from_buffer_copy(bytes(p0) * n)   # one parameter block per pair (the callee clamps wRangeThr_* in place)
-    out = (NccDescr * n)()
-    if as_int:
-        check((lib().mi_ncc_mips_batch_u16 if as_int == 2 else lib().mi_ncc_mips_batch_u8)(dev.index, capi.current_stream_ptr(dev), n, ptrs, float(sample_scale), a_idx, b_idx, dim_D, dim_V,
-                                          dim_H, ni, nj, displ_max_D, displ_max_V, displ_max_H, side, params, out))
-    else:
-        check(lib().mi_ncc_mips_batch(dev.index, capi.current_stream_ptr(dev), n, ptrs, a_idx, b_idx, dim_D, dim_V, dim_H,
-                                      ni, nj, displ_max_D, displ_max_V, displ_max_H, side, params, out))
-    # the records of all pairs at once: NccDescr = 3 ints, 3 floats, 3 ints; evalReliability (DisplacementMIPNCC.cpp:130-147)
-    # vectorised with the same float / double steps as the per-record method
-    raw = np.frombuffer(out, dtype=np.int32).reshape(n, 9)
-    coords, widths = raw[:, 0:3], raw[:, 6:9]
-    peaks = raw[:, 3:6].copy().view(np.float32)
-    f = np.float32
-    wn = (f(100.0) - (widths.astype(f) * f(100.0) / f(inf_w))) / f(100.0)
-    with np.errstate(invalid="ignore"):
-        rel = np.sqrt(S_NCC_WIDTH_WEIGHT * wn.astype(np.float64) ** 2 + S_NCC_PEAK_WEIGHT * peaks.astype(np.float64) ** 2).astype(f)
-    praw = np.frombuffer(params, dtype=np.int32).reshape(n, C.sizeof(NccParams) // 4)
-    o_i = NccParams.wRangeThr_i.offset // 4
-    thr = praw[:, o_i:o_i + 3]
-    delays = [displ_max_V, displ_max_H, displ_max_D]
-    res = {}
-    import gc
-    gc_on = gc.isenabled()
-    gc.disable()    # a few thousand small containers: the cyclic collector's passes over a torch-sized heap cost 0.1 ms per record
-    try:
-        cl, pl, wl, tl, rl = coords.tolist(), peaks.astype(np.float64).tolist(), widths.tolist(), thr.tolist(), rel.astype(np.float64).tolist()
-        new = object.__new__   # (the dataclass constructor with its default factories costs 4 us per record; 112 records a call)
-        for q, key in enumerate(pairs):
-            d = new(DisplacementMIPNCC)
-            d.__dict__ = {"VHD_coords": cl[q], "NCC_maxs": pl[q], "NCC_widths": wl[q], "delays": list(delays), "wRangeThrs": tl[q],
-                          "invWidths": [inf_w] * 3, "VHD_def_coords": list(ninj[q]), "rel_factors": rl[q], "extra": {}}   # vmVirtualVolume.cpp:279-306
-            res[key] = d
-    finally:
-        if gc_on:
-            gc.enable()
-    return res
+    job = C.c_void_p()
+    check(lib().mi_ncc_mips_batch_begin(dev.index, capi.current_stream_ptr(dev), n, ptrs, {0: 4, 2: 2, 1: 1}[as_int], float(sample_scale or 1.0), a_idx, b_idx,
+                                        dim_D, dim_V, dim_H, ni, nj, displ_max_D, displ_max_V, displ_max_H, side, params, C.byref(job)))
+    return PendingDisplacements(job, n=n, pairs=pairs, params=params, keep=(flat, ptrs, a_idx, b_idx, ni, nj, side), inf_w=inf_w, ninj=ninj,
+                                delays=[displ_max_V, displ_max_H, displ_max_D])
+
+
+class PendingDisplacements:
+    """A layer's batch under way on the device (``compute_displacements_begin``)."""
+
+    def __init__(self, job, **kw):
+        self.job = job
+        self.__dict__.update(kw)
+        self._res = {} if job is None else None
+
+    def __del__(self):                      # a batch nobody asked the result of is still ended: its device stage holds buffers
+        try:
+            if self._res is None and self.job is not None and self.job.value:
+                lib().mi_ncc_mips_batch_end(self.job, None, (NccDescr * self.n)())
+        except Exception:
+            pass
+
+    def result(self):
+        if self._res is None:
+            self._res = self._finish()
+        return self._res
+
+    def _finish(self):
+        n, pairs, params, inf_w, ninj, delays = self.n, self.pairs, self.params, self.inf_w, self.ninj, self.delays
+        out = (NccDescr * n)()
+        job, self.job = self.job, None
+        check(lib().mi_ncc_mips_batch_end(job, params, out))
+        self.keep = None
+        # the records of all pairs at once: NccDescr = 3 ints, 3 floats, 3 ints; evalReliability (DisplacementMIPNCC.cpp:130-147)
+        # vectorised with the same float / double steps as the per-record method
+        raw = np.frombuffer(out, dtype=np.int32).reshape(n, 9)
+        coords, widths = raw[:, 0:3], raw[:, 6:9]
+        peaks = raw[:, 3:6].copy().view(np.float32)
+        f = np.float32
+        wn = (f(100.0) - (widths.astype(f) * f(100.0) / f(inf_w))) / f(100.0)
+        with np.errstate(invalid="ignore"):
+            rel = np.sqrt(S_NCC_WIDTH_WEIGHT * wn.astype(np.float64) ** 2 + S_NCC_PEAK_WEIGHT * peaks.astype(np.float64) ** 2).astype(f)
+        praw = np.frombuffer(params, dtype=np.int32).reshape(n, C.sizeof(NccParams) // 4)
+        o_i = NccParams.wRangeThr_i.offset // 4
+        thr = praw[:, o_i:o_i + 3]
+        res = {}
+        import gc
+        gc_on = gc.isenabled()
+        gc.disable()    # a few thousand small containers: the cyclic collector's passes over a torch-sized heap cost 0.1 ms per record
+        try:
+            cl, pl, wl, tl, rl = coords.tolist(), peaks.astype(np.float64).tolist(), widths.tolist(), thr.tolist(), rel.astype(np.float64).tolist()
+            new = object.__new__   # (the dataclass constructor with its default factories costs 4 us per record; 112 records a call)
+            for q, key in enumerate(pairs):
+                d = new(DisplacementMIPNCC)
+                d.__dict__ = {"VHD_coords": cl[q], "NCC_maxs": pl[q], "NCC_widths": wl[q], "delays": list(delays), "wRangeThrs": tl[q],
+                              "invWidths": [inf_w] * 3, "VHD_def_coords": list(ninj[q]), "rel_factors": rl[q], "extra": {}}   # vmVirtualVolume.cpp:279-306
+                res[key] = d
+        finally:
+            if gc_on:
+                gc.enable()
+        return res
+
+
+def compute_displacements(tiles, overlap_V: int, overlap_H: int, displ_max_V=S_DISPL_SEARCH_RADIUS_DEF,
+                          displ_max_H=S_DISPL_SEARCH_RADIUS_DEF, displ_max_D=S_DISPL_SEARCH_RADIUS_DEF,
+                          rank: int = 0, world_size: int = 1, row_block=None, sample_scale=None):
+    """Pairwise displacement computation over one z-layer of a tile grid (step 2 of the stitcher): ``compute_displacements_begin``
+    and its result at once.  Returns {(r, c, r_b, c_b, direction): DisplacementMIPNCC}."""
+    return compute_displacements_begin(tiles, overlap_V, overlap_H, displ_max_V, displ_max_H, displ_max_D, rank, world_size, row_block,
+                                       sample_scale).result()
+
+
+def compute_displacements_layers(layers, overlap_V: int, overlap_H: int, *args, **kw):
+    """The layers of a grid one after the other (``layers``: an iterable of tile grids, one per z layer: StackStitcher.cpp:223-374),
+    one batch ahead: the device stage of layer l + 1 is enqueued before the host takes the result of layer l.  Yields the
+    dictionaries of ``compute_displacements`` in order."""
+    prev = None
+    for tiles in layers:
+        cur = compute_displacements_begin(tiles, overlap_V, overlap_H, *args, **kw)
+        if prev is not None:
+            yield prev.result()
+        prev = cur
+    if prev is not None:
+        yield prev.result()
 
 
 def compute_mips(A, B, ni, nj, side):

@@ -160,103 +160,133 @@ extern "C" int mi_ncc_mips_batch_u8(int dev, void* stream, int n_pairs, const un
                          dimj, ni, nj, delayk, delayi, delayj, side, params, out);
 }
 
-static int ncc_batch(int dev, void* stream, int n_pairs, const float* const* tiles, const int* a_idx, const int* b_idx, int dimk, int dimi,
-                     int dimj, const int* ni, const int* nj, int delayk, int delayi, int delayj, const int* side, mi_ncc_params* params,
-                     mi_ncc_descr* out, TileFmt fmt) {
-    MI_TRY(use_device(dev));
-    MI_REQUIRE(n_pairs >= 0, "mi_ncc_mips_batch: negative pair count");
-    if (n_pairs == 0) return MI_OK;
-    MI_REQUIRE(tiles && a_idx && b_idx && ni && nj && side && params && out, "mi_ncc_mips_batch: null pointer");
-    hipStream_t user = as_stream(stream);
-    for (int q = 0; q < n_pairs; ++q)
-        MI_REQUIRE(tiles[a_idx[q]] && tiles[b_idx[q]], "mi_ncc_mips_batch: null tile for pair %d", q);
+// A batch in two halves: begin enqueues the device stage of every group (and returns), end waits for it, runs the host rules and
+// the per-pair path of whatever the batched pipeline handed back.  A caller that walks the z layers of a grid (StackStitcher.cpp:
+// 223-374) begins layer l + 1 before it ends layer l: the device's streams are per DEVICE (ncc_lag.hip), so the first MIP pass of the
+// next batch runs beside the last chain of this one -- the only chain of a call that otherwise has nothing to hide behind.
+struct mi_ncc_batch_job {
+    int dev = 0;
+    hipStream_t user = nullptr;
+    TileFmt fmt;
+    int n_pairs = 0, dimk = 0, dimi = 0, dimj = 0, delayk = 0, delayi = 0, delayj = 0;
+    std::vector<const float*> ta, tb;                 // the tiles of pair q (the caller keeps them alive until end)
+    std::vector<int> ni, nj, side;
+    std::vector<mi_ncc_params> params;                // in-out parameter blocks, working copies
+    struct InFlight {
+        std::vector<int> idx;
+        LagJob* job = nullptr;
+        std::vector<const float*> pa, pb;
+        std::vector<mi_ncc_params> pp;
+    };
+    std::vector<InFlight> flights;
+    std::vector<int> todo;                            // pairs for the per-pair path
+    bool counted = false;
+    ~mi_ncc_batch_job() {
+        for (InFlight& f : flights)
+            if (f.job) ncc_lag_abandon(f.job);
+    }
+};
+static std::atomic<int> g_batches_in_flight[16];     // per device: batches begun and not yet ended
+
+static int ncc_batch_begin(mi_ncc_batch_job& J) {
+    MI_TRY(use_device(J.dev));
+    const int n_pairs = J.n_pairs, dimk = J.dimk, dimi = J.dimi, dimj = J.dimj;
     // Batched pipeline (ncc_lag.hip): pairs of equal geometry (side, nominal offsets, parameters) go through the device together,
     // one synchronisation per group.  Pairs it hands back (a decision inside the resolution of its values, a move outside the
-    // transformed lags) and geometries it does not take continue on the per-pair path below.
-    std::vector<int> todo;
-    if (!force_direct()) {
-        struct Key {
-            int side, ni, nj;
-            mi_ncc_params p;
-            bool operator<(const Key& o) const { return std::memcmp(this, &o, sizeof(Key)) < 0; }
-        };
-        std::map<Key, std::vector<int>> groups;
-        for (int q = 0; q < n_pairs; ++q) {
-            Key k;
-            std::memset(&k, 0, sizeof k);
-            k.side = side[q]; k.ni = ni[q]; k.nj = nj[q]; k.p = params[q];
-            groups[k].push_back(q);
-        }
-        // every group's device stage is enqueued before the first one is waited for: the host rules of a group run while the next
-        // group's kernels do, and the tail of one group's lag chain overlaps the next group's MIP pass
-        struct InFlight {
-            const std::vector<int>* idx;
-            LagJob* job;
-            std::vector<const float*> pa, pb;
-            std::vector<mi_ncc_params> pp;
-        };
-        std::vector<InFlight> flights;
-        int rc = MI_OK;
-        static const char* env_ser = MI_PROBE_ENV("MI_NCC_SERIAL_MIPS");
-        const bool serial_mips = env_ser ? std::atoi(env_ser) != 0 : false;
-        for (auto& kv : groups) {
-            const std::vector<int>& idx = kv.second;
-            const int q0 = idx[0], n = (int)idx.size();
-            {   // the reference's parameter checks, on a copy
-                mi_ncc_params probe = params[q0];
-                PairPlan pl;
-                rc = plan_pair(dimk, dimi, dimj, 0, ni[q0], nj[q0], delayk, delayi, delayj, side[q0], &probe, pl);
-                if (rc != MI_OK) break;
-            }
-            if (!ncc_lag_supported(dimk, dimi, dimj, ni[q0], nj[q0], delayk, delayi, delayj, side[q0], &params[q0])) {
-                todo.insert(todo.end(), idx.begin(), idx.end());
-                continue;
-            }
-            flights.emplace_back();
-            InFlight& f = flights.back();
-            f.idx = &idx;
-            f.job = nullptr;
-            f.pa.resize(n); f.pb.resize(n); f.pp.resize(n);
-            for (int i = 0; i < n; ++i) { f.pa[i] = tiles[a_idx[idx[i]]]; f.pb[i] = tiles[b_idx[idx[i]]]; f.pp[i] = params[idx[i]]; }
-            rc = ncc_lag_enqueue(dev, user, n, f.pa.data(), f.pb.data(), dimk, dimi, dimj, ni[q0], nj[q0], delayk, delayi, delayj, side[q0],
-                                 f.pp.data(), &f.job, serial_mips, fmt, (int)groups.size(), flights.size() > 1 && !serial_mips);
-            if (rc != MI_OK) break;
-        }
-        if (rc == MI_OK && serial_mips && !flights.empty()) {
-            // MI_NCC_SERIAL_MIPS=1: every MIP pass first (one HBM-bound stream after the other), then every chain -- a chain kernel
-            // that runs beside a MIP pass waits several times longer for each of its memory accesses, and the chains are latency-
-            // bound; measured, both orders end within a few per cent of each other (profiles/r03_ncc_timeline.txt), the default lets
-            // the next group's MIP pass run beside this group's chains
-            hipEvent_t gate = nullptr;
-            hipStream_t sm = ncc_lag_mip_stream(flights.back().job);
-            if (hipEventCreateWithFlags(&gate, hipEventDisableTiming) != hipSuccess || hipEventRecord(gate, sm) != hipSuccess)
-                rc = fail(MI_ERR_HIP, "mi_ncc_mips_batch: event setup failed");
-            for (InFlight& f : flights)
-                if (rc == MI_OK) rc = ncc_lag_enqueue_chains(f.job, gate);
-            if (gate) (void)hipEventDestroy(gate);
-        }
-        for (InFlight& f : flights) {
-            if (rc != MI_OK) { ncc_lag_abandon(f.job); continue; }
-            const std::vector<int>& idx = *f.idx;
-            const int n = (int)idx.size();
-            std::vector<mi_ncc_descr> po(n);
-            std::vector<unsigned char> careful(n, 1);
-            rc = ncc_lag_finish(f.job, f.pp.data(), po.data(), careful.data());
-            f.job = nullptr;
-            if (rc != MI_OK) continue;
-            for (int i = 0; i < n; ++i) {
-                if (careful[i]) { todo.push_back(idx[i]); continue; }
-                params[idx[i]] = f.pp[i];
-                out[idx[i]] = po[i];
-            }
-        }
-        if (rc != MI_OK) return rc;
-        if (todo.empty()) return MI_OK;
-        std::sort(todo.begin(), todo.end());
-    } else {
-        for (int q = 0; q < n_pairs; ++q) todo.push_back(q);
+    // transformed lags) and geometries it does not take continue on the per-pair path (ncc_batch_end).
+    if (force_direct()) {
+        for (int q = 0; q < n_pairs; ++q) J.todo.push_back(q);
+        return MI_OK;
     }
+    struct Key {
+        int side, ni, nj;
+        mi_ncc_params p;
+        bool operator<(const Key& o) const { return std::memcmp(this, &o, sizeof(Key)) < 0; }
+    };
+    std::map<Key, std::vector<int>> groups;
+    for (int q = 0; q < n_pairs; ++q) {
+        Key k;
+        std::memset(&k, 0, sizeof k);
+        k.side = J.side[q]; k.ni = J.ni[q]; k.nj = J.nj[q]; k.p = J.params[q];
+        groups[k].push_back(q);
+    }
+    // every group's device stage is enqueued before the first one is waited for: the host rules of a group run while the next
+    // group's kernels do, and the tail of one group's lag chain overlaps the next group's MIP pass
+    static const char* env_ser = MI_PROBE_ENV("MI_NCC_SERIAL_MIPS");
+    const bool serial_mips = env_ser ? std::atoi(env_ser) != 0 : false;
+    const bool earlier_batch = g_batches_in_flight[J.dev & 15].fetch_add(1) > 0;   // (its last chain is still under way)
+    J.counted = true;
+    J.flights.reserve(groups.size());
+    for (auto& kv : groups) {
+        const std::vector<int>& idx = kv.second;
+        const int q0 = idx[0], n = (int)idx.size();
+        {   // the reference's parameter checks, on a copy
+            mi_ncc_params probe = J.params[q0];
+            PairPlan pl;
+            MI_TRY(plan_pair(dimk, dimi, dimj, 0, J.ni[q0], J.nj[q0], J.delayk, J.delayi, J.delayj, J.side[q0], &probe, pl));
+        }
+        if (!ncc_lag_supported(dimk, dimi, dimj, J.ni[q0], J.nj[q0], J.delayk, J.delayi, J.delayj, J.side[q0], &J.params[q0])) {
+            J.todo.insert(J.todo.end(), idx.begin(), idx.end());
+            continue;
+        }
+        J.flights.emplace_back();
+        mi_ncc_batch_job::InFlight& f = J.flights.back();
+        f.idx = idx;
+        f.pa.resize(n); f.pb.resize(n); f.pp.resize(n);
+        for (int i = 0; i < n; ++i) { f.pa[i] = J.ta[idx[i]]; f.pb[i] = J.tb[idx[i]]; f.pp[i] = J.params[idx[i]]; }
+        MI_TRY(ncc_lag_enqueue(J.dev, J.user, n, f.pa.data(), f.pb.data(), dimk, dimi, dimj, J.ni[q0], J.nj[q0], J.delayk, J.delayi, J.delayj, J.side[q0],
+                               f.pp.data(), &f.job, serial_mips, J.fmt, (int)groups.size(), (J.flights.size() > 1 || earlier_batch) && !serial_mips));
+    }
+    if (serial_mips && !J.flights.empty()) {
+        // MI_NCC_SERIAL_MIPS=1 (probe builds): every MIP pass first (one HBM-bound stream after the other), then every chain
+        hipEvent_t gate = nullptr;
+        hipStream_t sm = ncc_lag_mip_stream(J.flights.back().job);
+        int rc = MI_OK;
+        if (hipEventCreateWithFlags(&gate, hipEventDisableTiming) != hipSuccess || hipEventRecord(gate, sm) != hipSuccess)
+            rc = fail(MI_ERR_HIP, "mi_ncc_mips_batch: event setup failed");
+        for (mi_ncc_batch_job::InFlight& f : J.flights)
+            if (rc == MI_OK) rc = ncc_lag_enqueue_chains(f.job, gate);
+        if (gate) (void)hipEventDestroy(gate);
+        MI_TRY(rc);
+    }
+    return MI_OK;
+}
+
+static int ncc_batch_end(mi_ncc_batch_job& J, mi_ncc_params* params, mi_ncc_descr* out) {
+    MI_TRY(use_device(J.dev));
+    const int dev = J.dev, dimk = J.dimk, dimi = J.dimi, dimj = J.dimj, delayk = J.delayk, delayi = J.delayi, delayj = J.delayj;
+    const TileFmt fmt = J.fmt;
+    hipStream_t user = J.user;
+    std::vector<int>& todo = J.todo;
+    int rc = MI_OK;
+    for (mi_ncc_batch_job::InFlight& f : J.flights) {
+        if (rc != MI_OK) { ncc_lag_abandon(f.job); f.job = nullptr; continue; }
+        const int n = (int)f.idx.size();
+        std::vector<mi_ncc_descr> po(n);
+        std::vector<unsigned char> careful(n, 1);
+        rc = ncc_lag_finish(f.job, f.pp.data(), po.data(), careful.data());
+        f.job = nullptr;
+        if (rc != MI_OK) continue;
+        for (int i = 0; i < n; ++i) {
+            if (careful[i]) { todo.push_back(f.idx[i]); continue; }
+            J.params[f.idx[i]] = f.pp[i];
+            out[f.idx[i]] = po[i];
+        }
+    }
+    if (rc != MI_OK) return rc;
+    std::sort(todo.begin(), todo.end());
+    const int* ni = J.ni.data();
+    const int* nj = J.nj.data();
+    const int* side = J.side.data();
+    mi_ncc_params* wparams = J.params.data();
+    auto tile_a = [&](int q) { return J.ta[q]; };
+    auto tile_b = [&](int q) { return J.tb[q]; };
     const int n_todo = (int)todo.size();
+    if (n_todo == 0) {
+        if (params)
+            for (int q = 0; q < J.n_pairs; ++q) params[q] = J.params[q];
+        return MI_OK;
+    }
     // Per-pair path.  The host side of a pair (argmax, neighbourhood refinement with its small launches and stream syncs, widths,
     // alignment) is a serial latency chain of about a millisecond, and few of a pair's kernels fill the device on their own: NT
     // host threads, each with its own stream and workspace, take every NT-th pair; within a thread the next pair's kernels are
@@ -286,14 +316,14 @@ static int ncc_batch(int dev, void* stream, int n_pairs, const float* const* til
             if (qi < n_todo) {
                 const int q = todo[qi];
                 Slot& sl = slot[k & 1];
-                rc = plan_pair(dimk, dimi, dimj, 0, ni[q], nj[q], delayk, delayi, delayj, side[q], &params[q], sl.pl);
-                if (rc == MI_OK) rc = pair_enqueue(sl.s, tiles[a_idx[q]], tiles[b_idx[q]], dimi, dimj, sl.pl, sl.ws, fmt);
+                rc = plan_pair(dimk, dimi, dimj, 0, ni[q], nj[q], delayk, delayi, delayj, side[q], &wparams[q], sl.pl);
+                if (rc == MI_OK) rc = pair_enqueue(sl.s, tile_a(q), tile_b(q), dimi, dimj, sl.pl, sl.ws, fmt);
             }
             const int fi = qi - NT;
             if (fi >= 0 && fi < n_todo && rc == MI_OK) {
                 const int f = todo[fi];
                 Slot& pr = slot[(k - 1) & 1];
-                rc = pair_finish(pr.s, ni[f], nj[f], side[f], &params[f], pr.pl, pr.ws, &out[f]);
+                rc = pair_finish(pr.s, ni[f], nj[f], side[f], &wparams[f], pr.pl, pr.ws, &out[f]);
                 ncc_count(1, 1);
             }
             if (qi >= n_todo) break;
@@ -317,7 +347,90 @@ static int ncc_batch(int dev, void* stream, int n_pairs, const float* const* til
     (void)hipEventDestroy(ev);
     for (int t = 0; t < NT; ++t)
         if (rcs[t] != MI_OK) return fail(rcs[t], "%s", msgs[t].c_str());
+    if (params)
+        for (int q = 0; q < J.n_pairs; ++q) params[q] = J.params[q];
     return MI_OK;
+}
+
+static int ncc_batch_make(int dev, void* stream, int n_pairs, const float* const* tiles, const int* a_idx, const int* b_idx, int dimk, int dimi, int dimj,
+                          const int* ni, const int* nj, int delayk, int delayi, int delayj, const int* side, const mi_ncc_params* params, TileFmt fmt,
+                          std::unique_ptr<mi_ncc_batch_job>& out) {
+    MI_TRY(use_device(dev));
+    MI_REQUIRE(n_pairs >= 0, "mi_ncc_mips_batch: negative pair count");
+    MI_REQUIRE(n_pairs == 0 || (tiles && a_idx && b_idx && ni && nj && side && params), "mi_ncc_mips_batch: null pointer");
+    out.reset(new (std::nothrow) mi_ncc_batch_job);
+    if (!out) return fail(MI_ERR_NOMEM, "mi_ncc_mips_batch: out of host memory");
+    mi_ncc_batch_job& J = *out;
+    J.dev = dev; J.user = as_stream(stream); J.fmt = fmt; J.n_pairs = n_pairs;
+    J.dimk = dimk; J.dimi = dimi; J.dimj = dimj; J.delayk = delayk; J.delayi = delayi; J.delayj = delayj;
+    J.ta.resize(n_pairs); J.tb.resize(n_pairs);
+    for (int q = 0; q < n_pairs; ++q) {
+        MI_REQUIRE(tiles[a_idx[q]] && tiles[b_idx[q]], "mi_ncc_mips_batch: null tile for pair %d", q);
+        J.ta[q] = tiles[a_idx[q]];
+        J.tb[q] = tiles[b_idx[q]];
+    }
+    J.ni.assign(ni, ni + n_pairs); J.nj.assign(nj, nj + n_pairs); J.side.assign(side, side + n_pairs);
+    J.params.assign(params, params + n_pairs);
+    return MI_OK;
+}
+
+static int ncc_batch_finish(mi_ncc_batch_job* job, mi_ncc_params* params, mi_ncc_descr* out) {
+    std::unique_ptr<mi_ncc_batch_job> J(job);
+    int rc = MI_OK;
+    if (J->n_pairs > 0) {
+        if (!out) rc = fail(MI_ERR_INVALID, "mi_ncc_mips_batch_end: null pointer");
+        else rc = ncc_batch_end(*J, params, out);
+    }
+    if (J->counted) g_batches_in_flight[J->dev & 15].fetch_sub(1);
+    return rc;
+}
+
+static int ncc_batch(int dev, void* stream, int n_pairs, const float* const* tiles, const int* a_idx, const int* b_idx, int dimk, int dimi,
+                     int dimj, const int* ni, const int* nj, int delayk, int delayi, int delayj, const int* side, mi_ncc_params* params,
+                     mi_ncc_descr* out, TileFmt fmt) {
+    MI_REQUIRE(n_pairs <= 0 || out, "mi_ncc_mips_batch: null pointer");
+    std::unique_ptr<mi_ncc_batch_job> J;
+    MI_TRY(ncc_batch_make(dev, stream, n_pairs, tiles, a_idx, b_idx, dimk, dimi, dimj, ni, nj, delayk, delayi, delayj, side, params, fmt, J));
+    if (n_pairs == 0) return MI_OK;
+    int rc = ncc_batch_begin(*J);
+    if (rc != MI_OK) {
+        if (J->counted) g_batches_in_flight[dev & 15].fetch_sub(1);
+        return rc;
+    }
+    return ncc_batch_finish(J.release(), params, out);
+}
+
+extern "C" int mi_ncc_mips_batch_begin(int dev, void* stream, int n_pairs, const void* const* tiles, int sample_bytes, float scale, const int* a_idx,
+                                       const int* b_idx, int dimk, int dimi, int dimj, const int* ni, const int* nj, int delayk, int delayi, int delayj,
+                                       const int* side, const mi_ncc_params* params, mi_ncc_batch_job** job) {
+    MI_REQUIRE(job, "mi_ncc_mips_batch_begin: null pointer");
+    *job = nullptr;
+    MI_REQUIRE(sample_bytes == 4 || sample_bytes == 2 || sample_bytes == 1, "mi_ncc_mips_batch_begin: samples of 4 (float), 2 or 1 bytes");
+    TileFmt fmt;
+    if (sample_bytes != 4) {
+        if (!(scale > 0.0f)) return fail(MI_ERR_INVALID, "mi_ncc_mips_batch_begin: scale must be positive");
+        if (!mips_int_ok(sample_bytes, dimk, dimj, (size_t)dimi * dimj))
+            return fail(MI_ERR_UNSUPPORTED, "mi_ncc_mips_batch_begin: integer tiles need rows of whole 32-bit words and at most %d slices", 4 * MIP_KPW);
+        fmt.bytes = sample_bytes;
+        fmt.scale = scale;
+    }
+    std::unique_ptr<mi_ncc_batch_job> J;
+    MI_TRY(ncc_batch_make(dev, stream, n_pairs, reinterpret_cast<const float* const*>(tiles), a_idx, b_idx, dimk, dimi, dimj, ni, nj, delayk, delayi,
+                          delayj, side, params, fmt, J));
+    if (n_pairs > 0) {
+        int rc = ncc_batch_begin(*J);
+        if (rc != MI_OK) {
+            if (J->counted) g_batches_in_flight[dev & 15].fetch_sub(1);
+            return rc;
+        }
+    }
+    *job = J.release();
+    return MI_OK;
+}
+
+extern "C" int mi_ncc_mips_batch_end(mi_ncc_batch_job* job, mi_ncc_params* params, mi_ncc_descr* out) {
+    if (!job) return MI_OK;
+    return ncc_batch_finish(job, params, out);
 }
 
 extern "C" int mi_ncc_compute_mips(int dev, void* stream, const float* A, const float* B, int dimk, int dimi, int dimj, int ni, int nj,

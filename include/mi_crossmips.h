@@ -86,6 +86,20 @@ int mi_ncc_mips_batch_u8(int dev, void* stream, int n_pairs, const unsigned char
                          const int* ni, const int* nj, int delayk, int delayi, int delayj, const int* side,
                          mi_ncc_params* params, mi_ncc_descr* out);
 
+/* A batch in two halves, for callers that walk the z layers of a grid (StackStitcher.cpp:223-374 computes the same pairs layer
+ * after layer): _begin copies the arguments, enqueues the device stage of every group and returns; _end waits for it, runs the
+ * host rules (and the per-pair path of whatever the batched pipeline hands back), fills params [in-out blocks, may be NULL] and
+ * out, and destroys the job.  Beginning layer l + 1 before ending layer l lets the first MIP pass of the next batch run beside
+ * the last lag chain of this one -- the one chain of a batch that has nothing to hide behind.  sample_bytes: 4 (float tiles),
+ * 2 or 1 (integer samples, tile value = sample / scale: see mi_ncc_mips_batch_u16).  The tiles stay alive and unchanged until
+ * _end; jobs are ended in the order they were begun.  mi_ncc_mips_batch == _begin + _end. */
+typedef struct mi_ncc_batch_job mi_ncc_batch_job;
+int mi_ncc_mips_batch_begin(int dev, void* stream, int n_pairs, const void* const* tiles, int sample_bytes, float scale,
+                            const int* a_idx, const int* b_idx, int dimk, int dimi, int dimj,
+                            const int* ni, const int* nj, int delayk, int delayi, int delayj, const int* side,
+                            const mi_ncc_params* params, mi_ncc_batch_job** job);
+int mi_ncc_mips_batch_end(mi_ncc_batch_job* job, mi_ncc_params* params, mi_ncc_descr* out);
+
 /* Cumulative counters of this process: out3[0] pairs finished by the batched pipeline, out3[1] pairs finished by the per-pair
  * path (geometries the lag transform does not take, MI_NCC_DIRECT=1, and pairs handed back because a decision was inside the
  * resolution of the map values), out3[2] map entries recomputed in the reference's two-pass fp64 form

@@ -373,3 +373,37 @@ def test_tie_cases_are_decided_like_the_reference(dev, name, direct, monkeypatch
         for lag in (False, True):
             got = crossmips.compute_NCC_map(mips[m], mips[m + 3], du, dv, lag=lag).cpu().numpy()
             assert np.array_equal(np.isnan(got), np.isnan(want)) and _ulps(got, want) <= MAX_ULPS, (nm, lag)
+
+
+def test_layers_one_batch_ahead_equal_layer_by_layer(dev):
+    """``compute_displacements_layers`` (mi_ncc_mips_batch_begin / _end: layer l + 1 enqueued before layer l is finished, the next
+    layer's first MIP pass beside this layer's last lag chain) returns, layer by layer, exactly the records of one synchronous
+    call per layer (StackStitcher.cpp:223-374 walks the layers in turn) -- float and 16-bit tiles, a layer without pairs and a
+    pending batch that is dropped unfinished included."""
+    from ipp_amd import crossmips
+    rng = np.random.default_rng(5)
+    tile, ov, R_, C_, L = (24, 128, 192), 40, 2, 3, 4
+    field = N.bead_field((L * tile[0] + 8, R_ * (tile[1] - ov) + ov + 16, C_ * (tile[2] - ov) + ov + 16), seed=21, density=1 / 300)
+    layers = []
+    for layer in range(L):
+        jit = rng.integers(-3, 4, size=(R_, C_, 2))
+        grid = [[None] * C_ for _ in range(R_)]
+        for r in range(R_):
+            for c in range(C_):
+                z0, y0, x0 = 4 + layer * tile[0], 8 + r * (tile[1] - ov) + jit[r, c, 0], 8 + c * (tile[2] - ov) + jit[r, c, 1]
+                grid[r][c] = torch.from_numpy(np.ascontiguousarray(field[z0:z0 + tile[0], y0:y0 + tile[1], x0:x0 + tile[2]])).to(dev)
+        layers.append(grid)
+    for as_u16 in (False, True):
+        ls = [[[(t * 65535.0).round().clamp(0, 65535).to(torch.uint16) for t in row] for row in g] for g in layers] if as_u16 else layers
+        want = [crossmips.compute_displacements(g, ov, ov, 8, 8, 3) for g in ls]
+        got = list(crossmips.compute_displacements_layers(ls, ov, ov, 8, 8, 3))
+        assert len(got) == L
+        for w, g in zip(want, got):
+            assert w.keys() == g.keys() and len(w) == 2 * R_ * C_ - R_ - C_
+            for k in w:
+                assert w[k].VHD_coords == g[k].VHD_coords and w[k].NCC_widths == g[k].NCC_widths and w[k].wRangeThrs == g[k].wRangeThrs
+                assert np.array_equal(np.array(w[k].NCC_maxs, np.float32), np.array(g[k].NCC_maxs, np.float32), equal_nan=True)
+    assert list(crossmips.compute_displacements_layers([[[layers[0][0][0]]]], ov, ov, 8, 8, 3)) == [{}]   # one tile: no pair
+    pending = crossmips.compute_displacements_begin(layers[0], ov, ov, 8, 8, 3)                          # never asked for its result
+    del pending
+    assert crossmips.compute_displacements(layers[1], ov, ov, 8, 8, 3).keys() == want[1].keys()
