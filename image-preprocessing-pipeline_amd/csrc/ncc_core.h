@@ -706,8 +706,10 @@ inline int mips_groups(int dimk, int dimi_v) {
     return (dimi_v + per - 1) / per;
 }
 inline size_t mips_tmp_floats(int dimk, int dimi_v, int dimj_v) {
-    // (an upper bound over the sample formats: the 8-bit kernel walks two bands per group, the float kernel has the narrowest column
-    // blocks; +1: launch_mips aligns the blocks to the tile rows)
+    // (only the pass for stacks deeper than 4 * MIP_KPW slices still writes partial maxima: k_mips5 and k_mips_int merge theirs into the
+    // MIPs.  A few floats all the same, so that a buffer exists.  Rows too long for k_mips5's 32-bit offsets -- 2^24 samples -- do not occur
+    // with stacks this shallow in any caller's tiles; launch_mips refuses them.)
+    if (dimk <= 4 * MIP_KPW) return 16;
     const size_t bands = std::max<size_t>(mips_groups(dimk, dimi_v), (dimi_v + 2 * MIP_ROWS - 1) / (2 * MIP_ROWS)), cblocks = (dimj_v + 63) / 64 + 1;
     return 2 * (bands * dimk * dimj_v + cblocks * (size_t)dimi_v * dimk);
 }
@@ -761,8 +763,7 @@ int launch_mips(hipStream_t s, const float* A, const float* B, const float* cons
         const char* e = MI_PROBE_ENV("MI_NCC_MIPS_KNOCK");
         return e ? std::atoi(e) : 0;
     }();
-    static const bool old_pass = [] { const char* e = MI_PROBE_ENV("MI_NCC_MIPS_OLD"); return e && std::atoi(e) != 0; }();  // (probe builds: A/B)
-    if (mips5_ok(dimk, pitch) && !old_pass) {
+    if (mips5_ok(dimk, pitch)) {
         static const int wpe_env = [] { const char* e = MI_PROBE_ENV("MI_NCC_MIPS_WPE"); return e ? std::atoi(e) : 0; }();
         static const int wpe_beside = [] { const char* e = MI_PROBE_ENV("MI_NCC_MIPS_WPE_BESIDE"); return e ? std::atoi(e) : 0; }();
         const int wpe = beside_chain ? (wpe_beside ? wpe_beside : (wpe_env ? wpe_env : 2)) : (wpe_env ? wpe_env : 4);
@@ -782,7 +783,8 @@ int launch_mips(hipStream_t s, const float* A, const float* B, const float* cons
         if (xy_done) MI_HIP(hipEventRecord(xy_done, s));
         return MI_OK;
     }
-    // deeper stacks (or rows too long for 32-bit offsets): the round-3 pass with its partial maxima and their reductions
+    MI_REQUIRE(dimk > 4 * MIP_KPW, "compute_3_MIPs: rows of %d samples are too long for the MIP pass", pitch);
+    // deeper stacks: the round-3 pass with its partial maxima and their reductions
     float* yz_tmp = tmp;
     float* xz_tmp = tmp + 2 * (size_t)np * bands * dimk * dimj_v;
     const size_t lds = sizeof(float) * MIP_ROWS * (size_t)dimk * mips_band_group(dimk);  // (k_mips: xzp)
@@ -791,7 +793,7 @@ int launch_mips(hipStream_t s, const float* A, const float* B, const float* cons
         MI_HIP(hipMemset2DAsync(xz1, sizeof(float) * (pstride ? pstride : 1), 0, sizeof(float) * (size_t)dimi_v * dimk, np, s));
         MI_HIP(hipMemset2DAsync(xz2, sizeof(float) * (pstride ? pstride : 1), 0, sizeof(float) * (size_t)dimi_v * dimk, np, s));
     }
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(via_lds && dimk <= 4 * MIP_KPW ? k_mips<true> : k_mips<false>), grid, dim3(256), via_lds ? lds : 0, s, A, B, tab, pstride, dimk, dimi_v, dimj_v, slice, pitch, ai0, aj0, xy1, xz1, yz1,
+    hipLaunchKernelGGL(k_mips<false>, grid, dim3(256), via_lds ? lds : 0, s, A, B, tab, pstride, dimk, dimi_v, dimj_v, slice, pitch, ai0, aj0, xy1, xz1, yz1,
                        xy2, xz2, yz2, yz_tmp, via_lds ? xz_tmp : (float*)nullptr, knock, xyT, tstride);
     MI_TRY(launch_check("k_mips"));
     if (xy_done) MI_HIP(hipEventRecord(xy_done, s));

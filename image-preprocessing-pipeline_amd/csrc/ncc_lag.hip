@@ -1606,6 +1606,7 @@ int ncc_time_mips(int dev, hipStream_t s, int n, const float* const* a_ptrs, con
                "mi_ncc_time_mips: integer tiles need rows of whole 32-bit words and at most %d slices", 4 * MIP_KPW);
     const int dimi_v = side == MI_NORTH_SOUTH ? dimi - ni : dimi, dimj_v = side == MI_WEST_EAST ? dimj - nj : dimj;
     MI_REQUIRE(dimi_v > 0 && dimj_v > 0 && dimk > 0, "mi_ncc_time_mips: empty view");
+    MI_REQUIRE(fmt.bytes != 4 || dimk > 4 * MIP_KPW || mips5_ok(dimk, dimj), "mi_ncc_time_mips: rows of %d samples are too long for the MIP pass", dimj);
     const size_t xy = (size_t)dimi_v * dimj_v, xz = (size_t)dimi_v * dimk, yz = (size_t)dimj_v * dimk;
     const size_t pstride = (2 * (xy + xz + yz) + 3) / 4 * 4, tmpf = mips_tmp_floats(dimk, dimi_v, dimj_v);
     DevBuf out, tmp, tab;
@@ -1631,8 +1632,6 @@ int ncc_time_mips(int dev, hipStream_t s, int n, const float* const* a_ptrs, con
     hipEvent_t e0 = evs.a, e1 = evs.b;
     const char* ke = MI_PROBE_ENV("MI_NCC_MIPS_KNOCK");  // (measurement aid, see k_mips)
     const int knock = ke ? std::atoi(ke) : 0;
-    const char* oe = MI_PROBE_ENV("MI_NCC_MIPS_OLD");
-    const bool old_pass = oe && std::atoi(oe) != 0;
     for (int r = -1; r < reps; ++r) {  // r = -1: warm-up
         if (r == 0) MI_HIP(hipEventRecord(e0, s));
         if (fmt.bytes != 4) {
@@ -1651,7 +1650,7 @@ int ncc_time_mips(int dev, hipStream_t s, int n, const float* const* a_ptrs, con
                                    o2 + xy, o2 + xy + xz, (float*)nullptr, (size_t)0, cb, bands, 2 * n);
             continue;
         }
-        if (mips5_ok(dimk, dimj) && !old_pass) {  // (its maxima merge into whatever the MIPs hold: the timed launches need no zeroing)
+        if (mips5_ok(dimk, dimj)) {  // (its maxima merge into whatever the MIPs hold: the timed launches need no zeroing)
             const char* we = MI_PROBE_ENV("MI_NCC_MIPS_WPE");
             const char* nr = MI_PROBE_ENV("MI_NCC_MIPS_NOREMAP");
             const int row_groups = bands * 2 * n, remap = nr && std::atoi(nr) != 0 ? 0 : 1;
@@ -1661,7 +1660,7 @@ int ncc_time_mips(int dev, hipStream_t s, int n, const float* const* a_ptrs, con
                                o + 2 * xy + 2 * xz + yz, knock, (float*)nullptr, (size_t)0, cblocks, bands, 2 * n, remap);
             continue;
         }
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(dimk <= 4 * MIP_KPW ? k_mips<true> : k_mips<false>), dim3(cblocks, bands, 2 * n), dim3(256), lds, s, (const float*)nullptr, (const float*)nullptr, tab.as<const float*>(),
+        hipLaunchKernelGGL(k_mips<false>, dim3(cblocks, bands, 2 * n), dim3(256), lds, s, (const float*)nullptr, (const float*)nullptr, tab.as<const float*>(),
                            pstride, dimk, dimi_v, dimj_v, (size_t)dimi * dimj, dimj, side == MI_NORTH_SOUTH ? ni : 0, side == MI_WEST_EAST ? nj : 0, o,
                            o + xy, o + xy + xz, o + xy + xz + yz, o + 2 * xy + xz + yz, o + 2 * xy + 2 * xz + yz, tmp.as<float>(), xz_tmp, knock, (float*)nullptr,
                            (size_t)0);
