@@ -231,7 +231,7 @@ class PeerLink:
 
     SETS = 2
 
-    def __init__(self, drv, nfloats, backend, group=None, timeout_s=120.0, chunks=1):
+    def __init__(self, drv, nfloats, backend, group=None, chunks=1):
         import torch.distributed as dist
         self.drv, self.group, self.n = drv, group, 0
         self.be = backend
