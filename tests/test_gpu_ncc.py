@@ -407,3 +407,30 @@ def test_layers_one_batch_ahead_equal_layer_by_layer(dev):
     pending = crossmips.compute_displacements_begin(layers[0], ov, ov, 8, 8, 3)                          # never asked for its result
     del pending
     assert crossmips.compute_displacements(layers[1], ov, ov, 8, 8, 3).keys() == want[1].keys()
+
+
+def test_mips_shape_sweep_is_exact(dev):
+    """compute_3_MIPs (compute_funcs.cu:502-521) on views whose extents sit on and around every boundary of the MIP pass: stacks of
+    1 .. 33 slices (k_mips5 takes up to 32 -- a wave owns slices w, w + 4, ...; the deep-stack pass beyond), views of 1 .. 130 rows
+    (bands of 16, groups of 4 bands) and columns (blocks of 64 aligned to the TILE rows, so the first block of a west-east view is
+    partial), both sides.  The six MIPs must equal numpy's maxima bit for bit (a maximum has no rounding)."""
+    from ipp_amd import crossmips
+    rng = np.random.default_rng(123)
+    cases = []
+    for dimk in (1, 2, 3, 4, 5, 8, 31, 32, 33):
+        cases.append((dimk, 70, 200, 1, 77))            # west-east: 123 columns from column 77 (first block partial), 70 rows
+        cases.append((dimk, 70, 200, 0, 40))            # north-south: 30 rows, 200 columns
+    for rows, cols in ((1, 1), (15, 63), (16, 64), (17, 65), (64, 128), (65, 129), (130, 3)):
+        cases.append((6, rows + 9, cols + 13, 1, 13))   # views of rows + 9 x cols rows / columns
+        cases.append((6, rows + 9, cols + 13, 0, 9))
+    for dimk, dimi, dimj, side, off in cases:
+        A = rng.random((dimk, dimi, dimj), dtype=np.float32)
+        B = rng.random((dimk, dimi, dimj), dtype=np.float32)
+        ni, nj = (off, 0) if side == 0 else (0, off)
+        got = [m.cpu().numpy() for m in crossmips.compute_mips(torch.from_numpy(A).to(dev), torch.from_numpy(B).to(dev), ni, nj, side)]
+        va = A[:, ni:, nj:]                              # libcrossmips.cpp:296-317: the first stack's view starts at (ni, nj) ...
+        vb = B[:, :dimi - ni, :dimj - nj]               # ... the second's at the origin, both of the overlap's extent
+        for k, v in ((0, va), (3, vb)):
+            assert np.array_equal(got[k], v.max(axis=0)), (dimk, dimi, dimj, side, "xy")
+            assert np.array_equal(got[k + 1], v.max(axis=2).T), (dimk, dimi, dimj, side, "xz")
+            assert np.array_equal(got[k + 2], v.max(axis=1).T), (dimk, dimi, dimj, side, "yz")

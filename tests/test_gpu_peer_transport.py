@@ -78,3 +78,36 @@ def test_two_processes_one_gpu_peer_copy_transport(dev, flavour, engine, zchunks
     assert n_exchanges == (2 * 4 + 1 if sharded else 2 * 4)
     if engine == 2 and flavour == "fft" and not os.environ.get("MI_FFT_NO_PIPE"):
         assert overlap                                  # edge tiles first, copies issued, remaining tiles, then the wait
+
+
+def test_a_wait_nobody_answers_ends_by_its_timeout(dev, monkeypatch):
+    """A neighbour that never delivers (a rank that died) leaves an error behind, not a hung device: the one-lane wait kernel gives up
+    after MI_PEER_TIMEOUT_S, counts itself in the link's status word, and the stream goes on."""
+    import ctypes as C
+    import time
+    from ipp_amd import capi
+    monkeypatch.setenv("MI_PEER_TIMEOUT_S", "1")
+    L = capi.lib()
+    link, hp, hf = C.c_void_p(), C.create_string_buffer(capi.IPC_HANDLE_BYTES), C.create_string_buffer(capi.IPC_HANDLE_BYTES)
+    capi.check(L.mi_peer_link_create(dev.index, 4096, C.byref(link), hp, hf))
+    try:
+        assert any(hp.raw) and any(hf.raw)
+        t = C.c_int(-1)
+        capi.check(L.mi_peer_link_status(link, C.byref(t)))
+        assert t.value == 0
+        slot = C.c_void_p()
+        s = C.c_void_p(capi.current_stream_ptr(dev))
+        t0 = time.perf_counter()
+        capi.check(L.mi_peer_link_recv(link, s, 1, 0, 1, 0, C.byref(slot)))      # exchange 1 of a slot nobody fills
+        after = torch.ones(8, device=dev) * 2                                      # work behind the wait on the same stream
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        assert 0.9 < dt < 10.0 and slot.value and float(after.sum()) == 16.0
+        capi.check(L.mi_peer_link_status(link, C.byref(t)))
+        assert t.value == 1
+        # invalid arguments are refused before anything is enqueued
+        assert L.mi_peer_link_recv(link, s, 0, 0, 1, 0, C.byref(slot)) == capi.MI_ERR_INVALID
+        assert L.mi_peer_link_send(link, s, 1, 2, 2, 0, 16, None, None) == capi.MI_ERR_INVALID
+        assert L.mi_peer_link_send(link, s, 1, 0, 1, 4000, 200, None, None) == capi.MI_ERR_INVALID   # beyond the slot
+    finally:
+        L.mi_peer_link_destroy(link)
