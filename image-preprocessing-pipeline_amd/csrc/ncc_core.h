@@ -109,10 +109,8 @@ __device__ __forceinline__ float rows_max16(const float (&v)[MIP_ROWS], int lane
 
 // view(k,i,j) = vol[k*slice + (i+i0)*pitch + (j+j0)]; blockIdx.z = 2 * pair + (0: A, 1: B).  A batch hands the tile pointers
 // over as a device table (tab[2 * pair + which]); every output array of pair q sits q * pstride floats behind pair 0's.
-// FAST: stacks of up to 4 * MIP_KPW slices whose xz maxima go through LDS (every C5-like stack): no conditional memory operation is left
-// in the slice loop -- with one the compiler cannot count the loads in flight and waits for all of them (`s_waitcnt vmcnt(0)`)
-// before it reduces a slice, i.e. the next slice never travelled while the current one was reduced.
-template <bool FAST>
+// Since round 5 this is the pass for stacks DEEPER than 4 * MIP_KPW slices only (k_mips5 below takes the others): partial row / column
+// maxima per band and column block in `yz_tmp` / `xz_tmp`, reduced by k_mips_yz / k_mips_xz.
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_mips(const float* __restrict__ A, const float* __restrict__ B, const float* const* __restrict__ tab,
                                                size_t pstride, int dimk, int dimi_v, int dimj_v,
                                                size_t slice, int pitch, int ai0, int aj0, float* __restrict__ xy1, float* __restrict__ xz1,
@@ -149,7 +147,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     // its acknowledgement came back, and the other three waves at the next barrier (switching the xy store off saved 11 % of
     // the pass although it is 3 % of its bytes: profiles/r03_mips_knock.txt).  The xy maxima of a band are merged across the
     // waves with LDS atomics, the xz maxima of all bands wait in LDS: the band loop has no barrier left.
-    const bool keep = FAST || dimk <= 4 * MIP_KPW;
+    const bool keep = dimk <= 4 * MIP_KPW;
     const int nb = keep ? MIP_NB : 1;
     __shared__ float xyb[MIP_NB][MIP_ROWS][64];
     __shared__ float cacc[4][MIP_KPW][64];
@@ -197,8 +195,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             const int kn = __builtin_amdgcn_readfirstlane(wrap ? wave : k + 4), bn = __builtin_amdgcn_readfirstlane(wrap ? b + 1 : b);
             // (behind the work-group's last slice there is nothing to fetch: the first slice of its last band is read once more --
             // one slice in 128 -- so that the number of loads in flight is the same in every step)
-            if (FAST) load_slice(min(bn, nbv - 1), kn, nxt);
-            else if (bn < nbv) load_slice(bn, kn, nxt);
+            if (bn < nbv) load_slice(bn, kn, nxt);
             float colmax = 0.0f;
 #pragma unroll
             for (int r = 0; r < MIP_ROWS; ++r) {
@@ -212,7 +209,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 const float rowmax = rows_max16(cur, lane);
                 const int r = row_of_lane(lane);
                 if (lane < 16) {
-                    if (FAST || xz_tmp) xzp[(b * MIP_ROWS + r) * dimk + k] = rowmax;
+                    if (xz_tmp) xzp[(b * MIP_ROWS + r) * dimk + k] = rowmax;
                     else if (r < rows) atomic_max_nonneg(&xz[(size_t)(i0 + r) * dimk + k], rowmax);
                 }
             }
@@ -221,7 +218,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         // yz: the column maxima of this band (group) go to yz_tmp[tile][group][k][j] (unit-stride stores); k_mips_yz takes the
         // maximum over the groups -- 2.6 million atomics per pair on the yz MIPs cost more than the whole streaming pass
         auto yz_out = [&](int k, int q, float colmax) {
-            if (FAST || keep) colacc[q * 64] = fmaxf(colacc[q * 64], colmax);
+            if (keep) colacc[q * 64] = fmaxf(colacc[q * 64], colmax);
             else if (live) yz_tmp[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * dimk + k) * dimj_v + j] = colmax;
         };
         int k = wave, q = 0;
@@ -793,7 +790,7 @@ int launch_mips(hipStream_t s, const float* A, const float* B, const float* cons
         MI_HIP(hipMemset2DAsync(xz1, sizeof(float) * (pstride ? pstride : 1), 0, sizeof(float) * (size_t)dimi_v * dimk, np, s));
         MI_HIP(hipMemset2DAsync(xz2, sizeof(float) * (pstride ? pstride : 1), 0, sizeof(float) * (size_t)dimi_v * dimk, np, s));
     }
-    hipLaunchKernelGGL(k_mips<false>, grid, dim3(256), via_lds ? lds : 0, s, A, B, tab, pstride, dimk, dimi_v, dimj_v, slice, pitch, ai0, aj0, xy1, xz1, yz1,
+    hipLaunchKernelGGL(k_mips, grid, dim3(256), via_lds ? lds : 0, s, A, B, tab, pstride, dimk, dimi_v, dimj_v, slice, pitch, ai0, aj0, xy1, xz1, yz1,
                        xy2, xz2, yz2, yz_tmp, via_lds ? xz_tmp : (float*)nullptr, knock, xyT, tstride);
     MI_TRY(launch_check("k_mips"));
     if (xy_done) MI_HIP(hipEventRecord(xy_done, s));

@@ -1660,7 +1660,7 @@ int ncc_time_mips(int dev, hipStream_t s, int n, const float* const* a_ptrs, con
                                o + 2 * xy + 2 * xz + yz, knock, (float*)nullptr, (size_t)0, cblocks, bands, 2 * n, remap);
             continue;
         }
-        hipLaunchKernelGGL(k_mips<false>, dim3(cblocks, bands, 2 * n), dim3(256), lds, s, (const float*)nullptr, (const float*)nullptr, tab.as<const float*>(),
+        hipLaunchKernelGGL(k_mips, dim3(cblocks, bands, 2 * n), dim3(256), lds, s, (const float*)nullptr, (const float*)nullptr, tab.as<const float*>(),
                            pstride, dimk, dimi_v, dimj_v, (size_t)dimi * dimj, dimj, side == MI_NORTH_SOUTH ? ni : 0, side == MI_WEST_EAST ? nj : 0, o,
                            o + xy, o + xy + xz, o + xy + xz + yz, o + 2 * xy + xz + yz, o + 2 * xy + 2 * xz + yz, tmp.as<float>(), xz_tmp, knock, (float*)nullptr,
                            (size_t)0);
