@@ -40,6 +40,10 @@ namespace {
 constexpr int kThreadsXZ = 1024;  // strided passes: one ~140-KB work-group of 16 waves per CU
 constexpr int kWavesXZ = 4;       // waves per SIMD the register budget is sized for (128 VGPRs)
 constexpr int kThreadsY = 512;    // contiguous pass: two work-groups per CU
+#ifndef MI_YCUT
+#define MI_YCUT 1
+#endif
+constexpr int kYCut = MI_YCUT;    // super-stage cut of the y kernels (seg_r); -DMI_YCUT=0: the round-4 cut, for A/B builds
 
 // ------------------------------------------------------------------------------------------------ LDS image
 // Element i (8 B) of a row sits at slot i ^ G(bits 4..7 of i) ^ rmask(row).  DS traffic is banked per instruction
@@ -171,21 +175,25 @@ __device__ __forceinline__ constexpr float s16(int k) {
 // registers; a remainder of 4 becomes 2 + 2 -- one stage of 16 points for 1024-point transforms --, a remainder of 1 or 2 sits at the top): seg_r(logn, s) is the length of the
 // super-stage that starts at stage s.  The same cut serves both directions (forward walks it top-down, inverse bottom-up),
 // and all its (S_LO, LR) pairs below stage 5 are among the conflict-free patterns of the swizzle.
-__host__ __device__ constexpr int seg_r(int logn, int s) {
+__host__ __device__ constexpr int seg_r(int logn, int s, int cut = 0) {
     const int rem = logn - s;
     if (logn == 4) return s == 0 ? 3 : 1;
     // 1024 points as 8 x 8 x 16 -- three LDS round trips instead of the four of 8 x 8 x 4 x 4 (round 4; C3: ratio launch of the x
     // pass 5.07 -> 4.76 ms, the z pass of 1024-point lines 6.15 -> 5.71 ms, the y passes of C2 0.426 -> 0.416 ms).  The sixteen-point
     // butterfly reads its fifteen twiddles where it uses them (butterflies): held together they spilled.
     if (logn == 10 && rem == 4) return 4;
-    // (2048 points as 16 x 16 x 8 instead of 8 x 8 x 8 x 4: y passes of C3 3.34 against 3.38 ms forward, equal inverse, in the
-    // placement where they run at 5.1 TB/s -- not kept)
+    // cut 1 (the y kernels: 512 threads, 256 registers to spend): 2048 points as 16 x 16 x 8 and 4096 as 16 x 16 x 16 -- three round
+    // trips instead of four (round 5; C3: y passes 3.06 / 3.10 -> 2.99 / 2.93 ms).  The x kernels keep 8 x 8 x 8 x 4 for 2048 points:
+    // at their 128 registers the sixteen-point butterflies cost more than the round trip (C4-shaped rank: x pass 7.0 / 7.9 ms
+    // against 7.7 / 8.6 with 16 x 16 x 8 and 9.5 / 10.6 with 8 x 16 x 16, profiles/r05_fft_cut_2048.txt).
+    if (cut == 1 && logn == 11) return s < 8 ? 4 : 3;
+    if (cut == 1 && logn == 12) return 4;
     return rem >= 5 ? 3 : rem == 4 ? 2 : rem;  // rem in {1, 2, 3}: all of it
 }
 // start of the super-stage that ends at stage `top` (exclusive)
-__host__ __device__ constexpr int seg_below(int logn, int top) {
+__host__ __device__ constexpr int seg_below(int logn, int top, int cut = 0) {
     int s = 0;
-    while (s + seg_r(logn, s) < top) s += seg_r(logn, s);
+    while (s + seg_r(logn, s, cut) < top) s += seg_r(logn, s, cut);
     return s;
 }
 // LDS twiddle tables: every super-stage with S_LO > 0 owns a packed table of 2^S_LO entries, exp(-2 pi i m / 2^(S_LO+LR))
@@ -194,42 +202,42 @@ __host__ __device__ constexpr int seg_below(int logn, int top) {
 // Powers kept per lane-twiddle index: all R - 1 of them while the table stays small (stage <= 6), else only the first (the
 // others are derived by multiplications).
 __host__ __device__ constexpr int tw_powers(int s, int r) { return s <= 6 ? (1 << r) - 1 : 1; }
-__host__ __device__ constexpr int tw_off(int logn, int s) {
+__host__ __device__ constexpr int tw_off(int logn, int s, int cut = 0) {
     int off = 0, t = 0;
     while (t < s) {
-        if (t > 0) off += tw_powers(t, seg_r(logn, t)) << t;
-        t += seg_r(logn, t);
+        if (t > 0) off += tw_powers(t, seg_r(logn, t, cut)) << t;
+        t += seg_r(logn, t, cut);
     }
     return off;
 }
-__host__ __device__ constexpr int chain_entries(int logn) { return tw_off(logn, logn); }
+__host__ __device__ constexpr int chain_entries(int logn, int cut = 0) { return tw_off(logn, logn, cut); }
 // gather the tables from the global table tw[e] = exp(-2 pi i e / 2^LOGN), e < 2^(LOGN-1): entry [p - 1][m] of the super-stage
 // at S is exp(-2 pi i m p / 2^(S+r)), the p-th power of the lane twiddle of group element m
-template <int LOGN, int NT, int S = 0>
+template <int LOGN, int NT, int S = 0, int CUT = 0>
 __device__ __forceinline__ void fill_chain_tw(float2* twl, const float2* __restrict__ tw) {
     if constexpr (S < LOGN) {
-        constexpr int r = seg_r(LOGN, S);
+        constexpr int r = seg_r(LOGN, S, CUT);
         if constexpr (S > 0) {
             constexpr int np = tw_powers(S, r);
             for (int i = threadIdx.x; i < (np << S); i += NT) {
                 const int p = (i >> S) + 1, m = i & ((1 << S) - 1);
                 const int e = (m * p) << (LOGN - S - r);  // < 2^LOGN
                 const float2 t = tw[e & ((1 << (LOGN - 1)) - 1)];
-                twl[tw_off(LOGN, S) + i] = (e >> (LOGN - 1)) ? make_float2(-t.x, -t.y) : t;  // exp(-i(x + pi)) = -exp(-ix)
+                twl[tw_off(LOGN, S, CUT) + i] = (e >> (LOGN - 1)) ? make_float2(-t.x, -t.y) : t;  // exp(-i(x + pi)) = -exp(-ix)
             }
         }
-        fill_chain_tw<LOGN, NT, S + r>(twl, tw);
+        fill_chain_tw<LOGN, NT, S + r, CUT>(twl, tw);
     }
 }
 // LDS layout behind the tile of an axis kernel: [chain tables][radix-3/9 table: exp(-2 pi i n2 / N), n2 < 2^L2]
-template <int L2, int R3>
+template <int L2, int R3, int CUT = 0>
 struct TwLds {
-    static constexpr int r3 = chain_entries(L2);
+    static constexpr int r3 = chain_entries(L2, CUT);
     static constexpr int total = r3 + (R3 > 1 ? (1 << L2) : 0);
     // tw: global table of the axis ([sub/2 power-of-two part][full circle of N when R3 > 1])
     template <int NT>
     static __device__ __forceinline__ void fill(float2* twl, const float2* __restrict__ tw) {
-        fill_chain_tw<L2, NT>(twl, tw);
+        fill_chain_tw<L2, NT, 0, CUT>(twl, tw);
         if constexpr (R3 > 1) {
             const float2* twM = tw + (1 << L2) / 2;
             for (int n2 = threadIdx.x; n2 < (1 << L2); n2 += NT) twl[r3 + n2] = twM[n2];
@@ -445,14 +453,14 @@ __device__ __forceinline__ void super_stage(float2* tile, int batch, int pitch, 
 // full transform of the tile's sequences as the chain of super-stages; twl: the axis' LDS tables.  The caller synchronises
 // before (tile and tables filled): with a work-group barrier, or -- PRIV, and the rows were filled by their owners -- not at
 // all.  On return the tile is consistent for the work-group (!PRIV) or for each row's owner (PRIV).
-template <int LOGN, bool INVERSE, int NT, int R3 = 1, int DONE = 0, int STOP = LOGN>
+template <int LOGN, bool INVERSE, int NT, int R3 = 1, int DONE = 0, int STOP = LOGN, int CUT = 0>
 __device__ __forceinline__ void lds_fft(float2* tile, int batch, int pitch, int hp, bool priv, const float2* twl) {
     if constexpr (DONE < STOP) {
-        constexpr int s_lo = INVERSE ? DONE : seg_below(LOGN, LOGN - DONE);  // forward: top stages first; inverse: bottom first
-        constexpr int r = INVERSE ? seg_r(LOGN, DONE) : LOGN - DONE - s_lo;
-        super_stage<LOGN, r, s_lo, INVERSE, NT, R3>(tile, batch, pitch, hp, priv, twl + tw_off(LOGN, s_lo));
+        constexpr int s_lo = INVERSE ? DONE : seg_below(LOGN, LOGN - DONE, CUT);  // forward: top stages first; inverse: bottom first
+        constexpr int r = INVERSE ? seg_r(LOGN, DONE, CUT) : LOGN - DONE - s_lo;
+        super_stage<LOGN, r, s_lo, INVERSE, NT, R3>(tile, batch, pitch, hp, priv, twl + tw_off(LOGN, s_lo, CUT));
         stage_sync(priv);
-        lds_fft<LOGN, INVERSE, NT, R3, DONE + r, STOP>(tile, batch, pitch, hp, priv, twl);
+        lds_fft<LOGN, INVERSE, NT, R3, DONE + r, STOP, CUT>(tile, batch, pitch, hp, priv, twl);
     }
 }
 
@@ -673,7 +681,7 @@ __global__ __launch_bounds__(kThreadsY, 4) void k_y_pass(const float2* __restric
     // columns dealt to the waves when there are enough of them: then the fill, the transform and the drain of a column all
     // belong to one wave and the kernel has no work-group barrier besides the one behind the table fill
     const bool priv = (TC % NW) == 0;
-    using TW = TwLds<LY2, R3>;
+    using TW = TwLds<LY2, R3, kYCut>;
     float2* twl = tile + TC * pitch;
     TW::template fill<kThreadsY>(twl, tw);
     // destination of source column sc: forward [z][px] -> [px][z], inverse [px][z] -> [z][px]
@@ -715,7 +723,7 @@ __global__ __launch_bounds__(kThreadsY, 4) void k_y_pass(const float2* __restric
         radix3_stage<R3, false, kThreadsY>(tile, TC, pitch, 1, priv, 1 << LY2, twl + TW::r3);
         stage_sync(priv);
     }
-    lds_fft<LY2, INVERSE, kThreadsY, R3>(tile, TC * R3, pitch, 1, priv, twl);
+    lds_fft<LY2, INVERSE, kThreadsY, R3, 0, LY2, kYCut>(tile, TC * R3, pitch, 1, priv, twl);
     if constexpr (INVERSE && R3 > 1) {
         radix3_stage<R3, true, kThreadsY>(tile, TC, pitch, 1, priv, 1 << LY2, twl + TW::r3);
         stage_sync(priv);
@@ -802,7 +810,7 @@ __global__ __launch_bounds__(kThreadsY, 4) void k_y_pair(const float2* __restric
         }
     };
     const bool priv = (TC % NW) == 0;  // (the transform only: fill and drain cross the columns)
-    using TW = TwLds<LY2, R3>;
+    using TW = TwLds<LY2, R3, kYCut>;
     float2* twl = tile + TC * pitch;
     TW::template fill<kThreadsY>(twl, tw);
     const int n_items = TC * quads;
@@ -876,7 +884,7 @@ __global__ __launch_bounds__(kThreadsY, 4) void k_y_pair(const float2* __restric
         radix3_stage<R3, false, kThreadsY>(tile, TC, pitch, 1, priv, 1 << LY2, twl + TW::r3);
         stage_sync(priv);
     }
-    lds_fft<LY2, INVERSE, kThreadsY, R3>(tile, TC * R3, pitch, 1, priv, twl);
+    lds_fft<LY2, INVERSE, kThreadsY, R3, 0, LY2, kYCut>(tile, TC * R3, pitch, 1, priv, twl);
     if constexpr (INVERSE && R3 > 1) {
         radix3_stage<R3, true, kThreadsY>(tile, TC, pitch, 1, priv, 1 << LY2, twl + TW::r3);
         stage_sync(priv);
