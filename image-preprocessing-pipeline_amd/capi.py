@@ -35,7 +35,7 @@ class RlOptions(C.Structure):
     """mi_rl_options (include/mi_lsdeconv.h)."""
     _fields_ = [("niter", C.c_int), ("lambda_", C.c_float), ("stop_criterion", C.c_float),
                 ("regularize_interval", C.c_int), ("engine", C.c_int), ("skip_edgetaper", C.c_int),
-                ("gauss_taps", C.c_int)]
+                ("gauss_taps", C.c_int), ("psf_grid", C.c_int * 3)]
 
 
 class NccParams(C.Structure):

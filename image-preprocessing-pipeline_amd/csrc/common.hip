@@ -126,7 +126,9 @@ void pool_free(void* p, size_t n) {
     hipPointerAttribute_t attr{};
     if (hipPointerGetAttributes(&attr, p) == hipSuccess) dev = attr.device;
     if (dev != cur) (void)hipSetDevice(dev);
+    MI_SPAN_BEGIN(spw, "pool_free: device-wide wait");
     (void)hipDeviceSynchronize();
+    MI_SPAN_END(spw);
     if (dev != cur) (void)hipSetDevice(cur);
     std::lock_guard<std::mutex> g(P.mu);
     P.free_blocks.insert({{dev, n}, p});
@@ -420,3 +422,40 @@ extern "C" int mi_rl_reg_term(int dev, void* stream, const float* bl, float* reg
     hipLaunchKernelGGL(k_reg_term, dim3(stream_grid((size_t)nx * ny * nz)), dim3(kThreads), 0, as_stream(stream), bl, reg, nx, ny, nz);
     return launch_check("k_reg_term");
 }
+
+// ------------------------------------------------------------------------------------------------ host-time spans (probe builds only)
+#ifdef MI_PROBES
+#include <chrono>
+namespace mi {
+namespace {
+struct SpanTable {
+    std::mutex m;
+    std::map<std::string, std::pair<double, long>> t;
+};
+SpanTable& span_table() {
+    static SpanTable* t = new SpanTable;  // (never destroyed: worker threads may still add at exit)
+    return *t;
+}
+}  // namespace
+double probe_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+void probe_span_add(const char* label, double seconds) {
+    SpanTable& T = span_table();
+    std::lock_guard<std::mutex> g(T.m);
+    auto& e = T.t[label];
+    e.first += seconds;
+    e.second += 1;
+}
+}  // namespace mi
+// the table as text ("label calls seconds\n" per line), cleared by the call; returns the number of bytes written
+extern "C" int mi_probe_host_spans(char* buf, int cap) {
+    mi::SpanTable& T = mi::span_table();
+    std::lock_guard<std::mutex> g(T.m);
+    int n = 0;
+    for (auto& kv : T.t) {
+        if (n >= cap) break;
+        n += std::snprintf(buf + n, (size_t)(cap - n), "%-40s %7ld %10.4f\n", kv.first.c_str(), kv.second.second, kv.second.first);
+    }
+    T.t.clear();
+    return n < cap ? n : cap;
+}
+#endif

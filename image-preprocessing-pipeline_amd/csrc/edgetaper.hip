@@ -158,16 +158,20 @@ int edgetaper_slabs(hipStream_t s, const float* bl, float* work, const float* ps
         const int* F = sp.F[d];
         const size_t G = (size_t)F[0] * F[1] * F[2];
         if (gin.bytes < sizeof(float) * G) {
+            MI_SPAN_BEGIN(spa, "edgetaper: slab buffers (wait + alloc)");
             MI_HIP(hipStreamSynchronize(s));
             MI_TRY(gin.alloc(sizeof(float) * G));
             MI_TRY(gout.alloc(sizeof(float) * G));
+            MI_SPAN_END(spa);
         }
         FftEngine local, *fe = &local;
         if (keep) {
             if (!keep->slab[d]) {
                 keep->slab[d] = new (std::nothrow) FftEngine;
                 if (!keep->slab[d]) return fail(MI_ERR_NOMEM, "edgetaper_3d: out of host memory");
+                MI_SPAN_BEGIN(spi, "edgetaper: slab engine init (a new shape)");
                 int rc = keep->slab[d]->init(s, F, k, circ, shift, psf_norm, nullptr, false);
+                MI_SPAN_END(spi);
                 if (rc != MI_OK) { delete keep->slab[d]; keep->slab[d] = nullptr; return rc; }
             }
             fe = keep->slab[d];
@@ -223,6 +227,7 @@ int edgetaper_async(hipStream_t s, float* bl, float* work, const float* psf, int
         tot += n[d];
     }
     DevBuf dtaper, kf;
+    MI_SPAN_BEGIN(spb, "edgetaper: blur (engine build, enqueue, waits)");
     MI_TRY(dtaper.alloc(sizeof(float) * tot));
     std::vector<float> host(tot);
     for (int d = 0; d < 3; ++d) std::copy(taper[d].begin(), taper[d].end(), host.begin() + off[d]);
@@ -316,6 +321,8 @@ int edgetaper_async(hipStream_t s, float* bl, float* work, const float* psf, int
         MI_TRY(direct_prepare_psf(s, psf, kx, ky, kz, /*normalise=*/true, /*flip=*/true, kf, &kxp));
         MI_TRY(direct_conv_launch(s, bl, kf.as<float>(), work, nx, ny, nz, kx, ky, kz, kxp, MI_BOUNDARY_REPLICATE, EPI_TAPER_SHELL, epi));
     }
+    MI_SPAN_END(spb);
+    MI_SPAN_BEGIN(spw, "edgetaper: blend + final wait");
     const float* t = dtaper.as<float>();
     int x_lo = 0, x_hi = nx;  // plateau of the x taper (host copy of the vectors: `taper`)
     while (x_lo < nx && taper[0][x_lo] != 1.0f) ++x_lo;
@@ -325,6 +332,7 @@ int edgetaper_async(hipStream_t s, float* bl, float* work, const float* psf, int
     MI_TRY(launch_check("k_taper_blend"));
     // host vector / DevBufs die at scope exit: the H2D copy source must outlive the copy
     MI_HIP(hipStreamSynchronize(s));
+    MI_SPAN_END(spw);
     return MI_OK;
 }
 

@@ -193,6 +193,11 @@ bool choose_fft_lengths(const int need[3], const int bnd[3], int F[3]) {
     return use_native;
 }
 
+// (rocFFT plans are destroyed with their engine, not kept for the next engine of the same lengths -- creating the pair takes 0.7 s at
+// decwrap's block sizes -- because live rocFFT plans are not independent of each other in ROCm 7.2: with the plans of a
+// 256 x 16 x 64 grid alive, a new engine on 32 x 128 x 8 returns values 6 % off (profiles/r05_rocfft_coexistence.txt; alone it is
+// exact).  A table of idle plans turned that into a failure of consecutive calls; callers keep away from the rocFFT route instead:
+// lsdeconv.block_fft_shape.)
 FftEngine::~FftEngine() {
     delete native;
     if (info) rocfft_execution_info_destroy(info);
@@ -274,7 +279,10 @@ int FftEngine::init(hipStream_t s, const int n[3], const int k[3], const int bnd
         // the hand-written pipeline transforms the placed PSF itself: no rocFFT plan, no half-spectrum buffers
         native = new (std::nothrow) NativeFft;
         if (!native) return fail(MI_ERR_NOMEM, "FFT engine: out of host memory");
+        MI_SPAN_BEGIN(sp0, "FftEngine: native init");
         MI_TRY(native->init(s, F, have_adj));
+        MI_SPAN_END(sp0);
+        MI_SPAN_BEGIN(sp1, "FftEngine: native OTF (enqueue)");
         // 1/(Fx Fy Fz) of the unnormalised inverse transform, times 2 for the half-length complex packing of x
         const float nscale = 2.0f / (float)((double)F[0] * F[1] * F[2]);
         for (int slot = 0; slot < (have_adj ? 2 : 1); ++slot) {
@@ -282,11 +290,14 @@ int FftEngine::init(hipStream_t s, const int n[3], const int k[3], const int bnd
                                ax[1].k, ax[2].k, ax[0].F, ax[1].F, ax[2].F, ax[0].shift, ax[1].shift, ax[2].shift));
             MI_TRY(native->build_otf(s, native->scratch(), slot == 1, nscale));
         }
+        MI_SPAN_END(sp1);
         // PSFs of odd extents that are mirror-symmetric about their centre sample (every LsMakePSF PSF) have a real OTF up to the
         // phase ramp of the centre's offset from the grid origin: sample j sits at j - shift, the centre at (k-1)/2 - shift
         if (fixed_psf && (ax[0].k & 1) && (ax[1].k & 1) && (ax[2].k & 1)) {
             const int delta[3] = {(ax[0].k - 1) / 2 - ax[0].shift, (ax[1].k - 1) / 2 - ax[1].shift, (ax[2].k - 1) / 2 - ax[2].shift};
+            MI_SPAN_BEGIN(sp2, "FftEngine: native real-OTF test");
             MI_TRY(native->try_real_otf(s, delta));
+            MI_SPAN_END(sp2);
         }
         if (padded) {  // the x passes pad and crop on the fly: no staging volume
             int nn[3], oo[3], rep[3], kk[3];
@@ -301,12 +312,16 @@ int FftEngine::init(hipStream_t s, const int n[3], const int k[3], const int bnd
         return MI_OK;
     }
     const size_t lengths[3] = {(size_t)F[0], (size_t)F[1], (size_t)F[2]};  // rocFFT: fastest dimension first
+    MI_SPAN_BEGIN(sp3, "FftEngine: rocFFT plans");
     MI_TRY(make_plans(s, lengths, &fwd, &inv, &info, work));
+    MI_SPAN_END(sp3);
+    MI_SPAN_BEGIN(sp4, "FftEngine: rocFFT buffers + OTF (enqueue)");
     MI_TRY(real.alloc(sizeof(float) * n_real));
     MI_TRY(spec.alloc(sizeof(float) * 2 * n_spec));
     MI_TRY(otf.alloc(sizeof(float) * 2 * n_spec));
     const float scale = 1.0f / (float)((double)F[0] * F[1] * F[2]);
     MI_TRY(build_otf(s, fwd, info, psf, ax, real.as<float>(), otf.as<float>(), scale));
+    MI_SPAN_END(sp4);
     if (have_adj) {
         MI_TRY(otf_adj.alloc(sizeof(float) * 2 * n_spec));
         MI_TRY(build_otf(s, fwd, info, psf_inv, ax, real.as<float>(), otf_adj.as<float>(), scale));

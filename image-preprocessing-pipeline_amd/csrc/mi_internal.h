@@ -61,6 +61,17 @@ inline int use_device(int dev) {
 #else
 #define MI_PROBE_ENV(name) (static_cast<const char*>(nullptr))
 #endif
+// Host-time spans of a probe build: MI_SPAN_BEGIN(v, "label") ... MI_SPAN_END(v) adds the wall time between the two to the label's sum
+// (all threads; common.hip keeps the table, mi_probe_host_spans prints it).  Nothing in the product build.
+#ifdef MI_PROBES
+double probe_now();
+void probe_span_add(const char* label, double seconds);
+#define MI_SPAN_BEGIN(v, label) const char* v##_label = (label); const double v##_t0 = ::mi::probe_now()
+#define MI_SPAN_END(v) ::mi::probe_span_add(v##_label, ::mi::probe_now() - v##_t0)
+#else
+#define MI_SPAN_BEGIN(v, label) do { } while (0)
+#define MI_SPAN_END(v) do { } while (0)
+#endif
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 

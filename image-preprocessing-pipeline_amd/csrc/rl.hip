@@ -220,7 +220,9 @@ static int rl_create(int dev, void* stream, int nx, int ny, int nz, const float*
         if (rc == MI_OK) rc = c->fft->init(s, n, k, c->bnd, shift, psf, psf_inv, true, fixed_psf);
     }
     if (rc == MI_OK) {
+        MI_SPAN_BEGIN(spw, "rl_create: final wait for the stream");
         hipError_t e = hipStreamSynchronize(s);
+        MI_SPAN_END(spw);
         if (e != hipSuccess) rc = fail(MI_ERR_HIP, "mi_rl_create: %s", hipGetErrorString(e));
     }
     if (rc != MI_OK) {
@@ -661,6 +663,7 @@ int check_options(const mi_rl_options* o) {
     MI_REQUIRE(o->niter >= 0, "decon: niter must be >= 0");
     MI_REQUIRE(o->lambda >= 0.0f && o->lambda < 1.0f, "decon: lambda must be in [0,1)");
     MI_REQUIRE(o->gauss_taps == 0 || o->gauss_taps == 3 || o->gauss_taps == 5, "decon: gauss_taps must be 0, 3 or 5");
+    MI_REQUIRE(o->psf_grid[0] >= 0 && o->psf_grid[1] >= 0 && o->psf_grid[2] >= 0, "decon: psf_grid extents must be >= 0");
     return MI_OK;
 }
 
@@ -725,33 +728,59 @@ static int rl_fft_impl(int dev, void* stream, float* bl, const float* psf, int n
     const bool need_reg = opt->lambda > 0.0f && opt->regularize_interval > 0 && opt->regularize_interval < opt->niter;
     const bool reg_sched = opt->regularize_interval > 0 && opt->regularize_interval < opt->niter;
     DevBuf ratio, reg, scratch, blF;
+    MI_SPAN_BEGIN(sp0, "deconFFT: allocations");
     if (need_reg) MI_TRY(reg.alloc(sizeof(float) * NF));
     MI_TRY(scratch.alloc(sizeof(double)));
+    if (!opt->skip_edgetaper) MI_TRY(ratio.alloc(sizeof(float) * NF));
+    MI_SPAN_END(sp0);
     if (!opt->skip_edgetaper) {  // decon.m:143
-        MI_TRY(ratio.alloc(sizeof(float) * NF));
+        MI_SPAN_BEGIN(sp1, "deconFFT: edgetaper (ends with a wait)");
         MI_TRY(edgetaper_async(s, bl, ratio.as<float>(), psf, nx, ny, nz, kx, ky, kz, keep_taper));
+        MI_SPAN_END(sp1);
     }
     float* work_bl = bl;
     if (padded) {  // decon.m:144
+        MI_SPAN_BEGIN(sp2, "deconFFT: padded copy (alloc + enqueue)");
         MI_TRY(blF.alloc(sizeof(float) * NF));
         MI_TRY(mi_pad_center(dev, stream, bl, nx, ny, nz, blF.as<float>(), fx, fy, fz));
         work_bl = blF.as<float>();
+        MI_SPAN_END(sp2);
     }
     double delta_prev = 0.0;
     if (opt->stop_criterion > 0.0f) MI_TRY(host_norm(s, work_bl, NF, scratch.as<double>(), &delta_prev));  // decon.m:145-147
     mi_rl_ctx* ctx = keep_ctx ? *keep_ctx : nullptr;
     const int engine = opt->engine == MI_ENGINE_DIRECT ? MI_ENGINE_DIRECT : MI_ENGINE_FFT;
-    if (!ctx) MI_TRY(mi_rl_create(dev, stream, fx, fy, fz, psf, nullptr, kx, ky, kz, MI_BOUNDARY_CIRCULAR, engine, &ctx));
+    if (!ctx) {
+        MI_SPAN_BEGIN(sp3, "deconFFT: mi_rl_create (a new shape)");
+        // where the PSF's samples land on the circular grid: ifftshift(zero-pad-centre(psf)) on the grid opt->psf_grid names
+        // (default: the FFT shape; see mi_rl_options)
+        const int circ[3] = {MI_BOUNDARY_CIRCULAR, MI_BOUNDARY_CIRCULAR, MI_BOUNDARY_CIRCULAR};
+        const int F[3] = {fx, fy, fz}, K[3] = {kx, ky, kz};
+        int shift[3];
+        for (int d = 0; d < 3; ++d) {
+            const int g = opt->psf_grid[d] > 0 ? opt->psf_grid[d] : F[d];
+            MI_REQUIRE(g >= K[d], "deconFFT: psf_grid extent %d smaller than the PSF extent %d on axis %d", g, K[d], d);
+            shift[d] = g / 2 - (g - K[d]) / 2;
+        }
+        MI_TRY(mi_rl_create_ex(dev, stream, fx, fy, fz, psf, nullptr, kx, ky, kz, circ, shift, engine, &ctx));
+        MI_SPAN_END(sp3);
+    }
     if (keep_ctx) *keep_ctx = ctx;
+    MI_SPAN_BEGIN(sp4, "deconFFT: wait + release of the taper's work");
     if (reg_sched || !mi_rl_fuses(ctx)) {  // (see rl_spatial_impl)
         if (!ratio.p) MI_TRY(ratio.alloc(sizeof(float) * NF));
     } else {
         MI_HIP(hipStreamSynchronize(s));
         ratio.release();
     }
+    MI_SPAN_END(sp4);
+    MI_SPAN_BEGIN(sp5, "deconFFT: rl_iterate (enqueue)");
     int rc = rl_iterate(ctx, s, work_bl, ratio.as<float>(), reg.as<float>(), scratch.as<double>(), fx, fy, fz, *opt, delta_prev, iters_done);
     if (rc == MI_OK && padded) rc = mi_crop_center(dev, stream, work_bl, fx, fy, fz, bl, nx, ny, nz);  // decon.m:203
+    MI_SPAN_END(sp5);
+    MI_SPAN_BEGIN(sp6, "deconFFT: final wait for the stream");
     hipError_t e = hipStreamSynchronize(s);
+    MI_SPAN_END(sp6);
     if (!keep_ctx) mi_rl_destroy(ctx);
     if (rc == MI_OK && e != hipSuccess) rc = fail(MI_ERR_HIP, "deconFFT: %s", hipGetErrorString(e));
     return rc;
@@ -926,7 +955,7 @@ extern "C" int mi_decon(int dev, void* stream, float* bl, const float* psf, cons
 // engine change.  One plan per worker thread (it is not re-entrant).
 struct mi_decon_plan {
     int dev = 0;
-    int key[12] = {0};          // nx ny nz kx ky kz use_fft fx fy fz engine has_inv
+    int key[15] = {0};          // nx ny nz kx ky kz use_fft fx fy fz engine has_inv psf_grid[3]
     std::vector<float> psf, psf_inv;
     mi_rl_ctx* ctx = nullptr;
     TaperKeep* taper = nullptr;
@@ -967,23 +996,28 @@ extern "C" int mi_decon_plan_run(mi_decon_plan* plan, void* stream, float* bl, c
     MI_REQUIRE(kx > 0 && ky > 0 && kz > 0, "decon: psf must be 3D and non-empty");
     int f[3] = {nx, ny, nz};
     if (use_fft && fft_shape_xyz) { f[0] = fft_shape_xyz[0]; f[1] = fft_shape_xyz[1]; f[2] = fft_shape_xyz[2]; }
-    const int key[12] = {nx, ny, nz, kx, ky, kz, use_fft ? 1 : 0, f[0], f[1], f[2], opt->engine, (!use_fft && psf_inv) ? 1 : 0};
+    const int key[15] = {nx, ny, nz, kx, ky, kz, use_fft ? 1 : 0, f[0], f[1], f[2], opt->engine, (!use_fft && psf_inv) ? 1 : 0,
+                         use_fft ? opt->psf_grid[0] : 0, use_fft ? opt->psf_grid[1] : 0, use_fft ? opt->psf_grid[2] : 0};
     // the PSFs are small: compare their values with the ones the kept objects were built from
     hipStream_t s = as_stream(stream);
     const size_t nk = (size_t)kx * ky * kz;
     std::vector<float> h(nk), hi;
+    MI_SPAN_BEGIN(sp0, "plan_run: psf fetch + wait for the stream");
     MI_HIP(hipMemcpyAsync(h.data(), psf, sizeof(float) * nk, hipMemcpyDeviceToHost, s));
     if (key[11]) {
         hi.resize(nk);
         MI_HIP(hipMemcpyAsync(hi.data(), psf_inv, sizeof(float) * nk, hipMemcpyDeviceToHost, s));
     }
     MI_HIP(hipStreamSynchronize(s));
+    MI_SPAN_END(sp0);
     if (std::memcmp(key, plan->key, sizeof(key)) != 0 || h != plan->psf || hi != plan->psf_inv) {
+        MI_SPAN_BEGIN(sp1, "plan_run: drop of the kept objects");
         MI_HIP(hipStreamSynchronize(s));
         plan->drop();
         std::memcpy(plan->key, key, sizeof(key));
         plan->psf.swap(h);
         plan->psf_inv.swap(hi);
+        MI_SPAN_END(sp1);
     }
     int rc = use_fft ? rl_fft_impl(dev, stream, bl, psf, nx, ny, nz, kx, ky, kz, f[0], f[1], f[2], opt, iters_done, &plan->ctx, &plan->taper)
                      : rl_spatial_impl(dev, stream, bl, psf, psf_inv, nx, ny, nz, kx, ky, kz, opt, iters_done, &plan->ctx, &plan->taper);

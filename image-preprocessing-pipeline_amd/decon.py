@@ -485,7 +485,7 @@ class DeconPlan:
 
 def decon(bl, psf, niter, lambda_=0.0, stop_criterion=0.0, regularize_interval=0, device_id=None, use_fft=False,
           fft_shape=None, adaptive_psf=False, *, engine=ENGINE_AUTO, skip_edgetaper=False, gauss_taps=0,
-          return_iters=False, return_psf=False, plan=None):
+          return_iters=False, return_psf=False, plan=None, psf_grid=None):
     """``bl = decon(bl, psf, niter, lambda, stop_criterion, regularize_interval, device_id, use_fft, fft_shape,
     adaptive_psf)`` (decon.m:1-23).  ``adaptive_psf`` with ``use_fft`` runs ``deconFFT_Wiener`` (decon.m:206-321), whose
     ``fft_shape`` must be made of extents the hand-written FFT takes (``fft_good_size``); ``return_psf`` then also hands
@@ -494,7 +494,9 @@ def decon(bl, psf, niter, lambda_=0.0, stop_criterion=0.0, regularize_interval=0
     ``psf`` is the reference's struct with fields ``psf`` and ``inv`` (anything with those attributes / keys), or
     a bare array (``inv`` is then the flipped PSF).  ``fft_shape`` is [x y z].  A CUDA tensor ``bl`` is updated
     in place and returned; a numpy ``bl`` is uploaded and gathered.  Keyword-only extras select the convolution
-    engine and let a caller that already tapered the block skip the taper (used by the benchmark)."""
+    engine and let a caller that already tapered the block skip the taper (used by the benchmark).  ``psf_grid`` [x y z]
+    (deconFFT): the grid whose parity decides where the PSF's centre sample lands (``mi_rl_options.psf_grid``; default: ``fft_shape``,
+    the reference's rule) -- for a caller that enlarges the reference's ``next_fast_len`` grid and wants the reference's placement."""
     if adaptive_psf and not use_fft:
         raise ValueError("--adaptive-psf requires --use-fft")  # decwrap.py:216-217
     dev = _device(device_id if device_id is not None else
@@ -519,6 +521,10 @@ def decon(bl, psf, niter, lambda_=0.0, stop_criterion=0.0, regularize_interval=0
     kx, ky, kz = _xyz(p.shape)
     opt = RlOptions(int(niter), float(lambda_), float(stop_criterion), int(regularize_interval), int(engine),
                     1 if skip_edgetaper else 0, int(gauss_taps))
+    if psf_grid is not None:
+        if not use_fft or adaptive_psf:
+            raise ValueError("decon: psf_grid applies to deconFFT only")
+        opt.psf_grid[:] = [int(v) for v in psf_grid]
     done = C.c_int(0)
     fs = None
     if use_fft:

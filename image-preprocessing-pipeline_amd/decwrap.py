@@ -571,11 +571,11 @@ def main(argv=None):
     def run_block(n, g, stream, staging, plan):
         p1, p2 = block.p1[n - 1], block.p2[n - 1]
         bl_xyz = tuple(int(b) - int(a) + 1 + 2 * int(q) for a, b, q in zip(p1, p2, pad))   # padded block, [x y z]
-        fshape = None
+        fshape = ref_grid = None
         if args.use_fft:
-            smooth, native = L.next_fast_len(bl_xyz), L.native_fft_shape(bl_xyz)
-            fshape = native if np.prod(native) <= 1.3 * np.prod(smooth) else smooth
-        blk = L.Block(block.x, block.y, block.z, block.nx, block.ny, block.nz, *pad, fft_shape=fshape)
+            fshape = L.block_fft_shape(bl_xyz, block.fft_shape)
+            ref_grid = tuple(L.next_fast_len(bl_xyz))                                      # LsDeconv.m:405-419: the reference's grid
+        blk = L.Block(block.x, block.y, block.z, block.nx, block.ny, block.nz, *pad, fft_shape=fshape, psf_grid=ref_grid)
         t_a = time.perf_counter()
         with torch.cuda.device(g - 1), torch.cuda.stream(stream):
             # load_block on the device: the raw samples cross PCIe, conversion and symmetric padding happen there

@@ -34,6 +34,7 @@ class Block:
     y_pad: int = 0
     z_pad: int = 0
     fft_shape: tuple | None = None  # [x y z]
+    psf_grid: tuple | None = None   # [x y z]: the reference's grid when fft_shape was enlarged past it (decon(..., psf_grid=))
     p1: np.ndarray = field(default=None, repr=False)
     p2: np.ndarray = field(default=None, repr=False)
 
@@ -88,6 +89,22 @@ def native_fft_shape(shape_xyz):
         g = int(capi.lib().mi_fft_good_size(int(n), axis))
         out.append(g if g > 0 else D.next_fast_len(int(n)))
     return out
+
+
+def block_fft_shape(bl_xyz, main_fft_shape=None):
+    """FFT shape of ONE padded block (decwrap's run_block): the grid the hand-written pipeline takes whenever that costs less than the
+    7-smooth grid through rocFFT -- 1 against 3.5 per grid point (``cost_per_core_voxel``), and a rocFFT plan of a new shape takes
+    0.7 s to create where the pipeline's set-up takes 10 ms (profiles/r05_decwrap_spans.txt) -- i.e. up to the 2.2x inflation the
+    library itself accepts (``MI_FFT_NATIVE_INFLATE``), as long as the grid stays inside the main block's (``main_fft_shape``: the one
+    ``autosplit`` sized against --block-size-max; remainder blocks are smaller on every axis, so is their native grid).  The native
+    extents are all even, the 7-smooth ones need not be: the caller hands the 7-smooth grid to ``decon`` as ``psf_grid`` so that the
+    PSF lands where the reference's grid puts it (``mi_rl_options.psf_grid``)."""
+    smooth, native = next_fast_len(bl_xyz), native_fft_shape(bl_xyz)
+    ratio = float(np.prod(native)) / float(np.prod(smooth))
+    if ratio <= 1.3:
+        return native
+    inside = main_fft_shape is None or all(int(a) <= int(b) for a, b in zip(native, main_fft_shape))
+    return native if (ratio <= 2.2 and inside) else smooth
 
 
 def autosplit(stack_xyz, psf_size_xyz, filt: Filter, block_size_max: int, numit: int, ram_available: int | None = None,
@@ -304,8 +321,9 @@ def process_block(bl, block: Block, psf, niter, lambda_, stop_criterion, filt: F
             capi.check(capi.lib().mi_subtract_dark(dev.index, capi.current_stream_ptr(dev), t.data_ptr(), t.data_ptr(),
                                                    t.numel(), float(filt.dark)))                # :924-927
     if niter > 0 and float(t.max()) > 2.0 ** -23:                                               # :929
+        grid = block.psf_grid if (filt.use_fft and not filt.adaptive_psf) else None
         D.decon(t, psf, niter, lambda_, stop_criterion, filt.regularize_interval, gpu, filt.use_fft,
-                block.fft_shape if filt.use_fft else None, filt.adaptive_psf, plan=plan)
+                block.fft_shape if filt.use_fft else None, filt.adaptive_psf, plan=plan, psf_grid=grid)
     if filt.destripe_sigma > 0:
         D.filter_subband_3d_z(t, filt.destripe_sigma, 0, "db9")                                 # :934-936
     lb, ub = deconvolved_stats(t, clipval)

@@ -229,6 +229,15 @@ typedef struct {
     int engine;              /* mi_engine */
     int skip_edgetaper;      /* 0: like decon.m:50/143; 1: caller tapered already (bench times the loop only) */
     int gauss_taps;          /* 0: gauss3d_gpu(bl,0.5) default 5 taps (GPU path); 3: imgaussfilt3 CPU flavour */
+    int psf_grid[3];         /* deconFFT only, [x y z]; 0 = the FFT shape itself (the reference).  ifftshift(zero-pad-centre(psf))
+                              * (decon.m:131-133, otf_gpu.cu:36-67,121-123) puts the centre sample of an odd PSF at index 0 of a grid
+                              * of odd extent and at index -1 of a grid of even extent: where the PSF lands depends on the parity of
+                              * fft_shape, and the result with it (the ratio bl ./ conv(bl) is taken one sample off).  A caller that
+                              * runs a block on a larger grid than the reference's next_fast_len one (decwrap.py: an extent the
+                              * hand-written transform takes) names the reference's extent here; the PSF is then placed where THAT
+                              * grid would have put it (shift = g/2 - (g-k)/2 per axis) and the result differs from the
+                              * reference grid's by the effect of the wider zero margin only.  Ignored by deconSpatial and
+                              * deconFFT_Wiener. */
 } mi_rl_options;
 
 /* bl = deconSpatial(bl, psf, psf_inv, ...)   [decon.m:26-124]  in place; iters_done [host] may be NULL.

@@ -226,21 +226,31 @@ def unpad_block(bl, pre, post):
     return np.ascontiguousarray(bl[sl])
 
 
-def otf_from_psf(psf, fft_shape_zyx):
-    """``fftn(ifftshift(zero-pad-centre(psf)))`` (decon.m:131-133; otf_gpu.cu:36-67)."""
-    p, _, _ = pad_block_to_fft_shape(psf.astype(np.float32), fft_shape_zyx)
-    return np.fft.fftn(np.fft.ifftshift(p).astype(np.float64))
+def otf_from_psf(psf, fft_shape_zyx, psf_grid_zyx=None):
+    """``fftn(ifftshift(zero-pad-centre(psf)))`` (decon.m:131-133; otf_gpu.cu:36-67).
+
+    ``psf_grid_zyx`` (no reference counterpart: ``mi_rl_options.psf_grid``): the PSF is placed on the ``fft_shape`` grid where
+    ``ifftshift(zero-pad-centre(.))`` on a grid of THOSE extents puts it -- sample j of an axis at circular index
+    j - (g // 2 - (g - k) // 2), which is what the two reference steps amount to (pre = floor((g - k) / 2) samples in front, then
+    a rotation by floor(g / 2))."""
+    if psf_grid_zyx is None:
+        p, _, _ = pad_block_to_fft_shape(psf.astype(np.float32), fft_shape_zyx)
+        return np.fft.fftn(np.fft.ifftshift(p).astype(np.float64))
+    p = np.zeros(tuple(fft_shape_zyx), np.float32)
+    idx = [(np.arange(k) - (g // 2 - (g - k) // 2)) % f for k, g, f in zip(psf.shape, psf_grid_zyx, fft_shape_zyx)]
+    p[np.ix_(*idx)] = psf.astype(np.float32)
+    return np.fft.fftn(p.astype(np.float64))
 
 
 def decon_fft(bl, psf, fft_shape_zyx, niter, lam=0.0, stop_criterion=0.0, regularize_interval=0,
-              gauss_flavour="gpu", return_iters=False, skip_edgetaper=False):
+              gauss_flavour="gpu", return_iters=False, skip_edgetaper=False, psf_grid_zyx=None):
     """``deconFFT`` (decon.m:127-204): circular convolution on ``fft_shape``; float64
     transforms rounded to float32 at each ``real(ifftn(..))`` like the single-precision
     reference buffers."""
     bl = bl.astype(np.float32)
     psf = psf.astype(np.float32)
     lam = np.float32(lam)
-    otf = otf_from_psf(psf, fft_shape_zyx)
+    otf = otf_from_psf(psf, fft_shape_zyx, psf_grid_zyx)
     R = _reg_kernel()
     if not skip_edgetaper:
         bl = edgetaper_3d(bl, psf)

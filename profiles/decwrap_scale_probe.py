@@ -76,6 +76,35 @@ if os.environ.get("PROBE_SAMPLE"):
     threading.Thread(target=sample_stacks, daemon=True).start()
 os.environ["MI_DECWRAP_NPY"] = "0"
 from ipp_amd import decwrap  # noqa: E402
+
+# PROBE_SPANS=1: host wall time per stage of a block, summed over the workers (Python calls here; with MI_IPP_PROBES=1 the library's
+# own spans -- MI_SPAN_BEGIN/END, probe build only -- are printed after the run)
+py_spans = {}
+if os.environ.get("PROBE_SPANS"):
+    from ipp_amd import decon as _D, lsdeconv as _L
+    span_lock = threading.Lock()
+
+    def timed(mod, name, label=None):
+        fn = getattr(mod, name)
+
+        def wrapper(*a, **k):
+            t = time.perf_counter()
+            try:
+                return fn(*a, **k)
+            finally:
+                dt_ = time.perf_counter() - t
+                with span_lock:
+                    e = py_spans.setdefault(label or name, [0, 0.0])
+                    e[0] += 1
+                    e[1] += dt_
+        setattr(mod, name, wrapper)
+
+    timed(_L, "load_block_device")
+    timed(_L, "process_block")
+    timed(_L, "deconvolved_stats")
+    timed(_D, "gauss3d_gpu")
+    timed(_D, "decon")
+    timed(_D, "rescale_block")
 t0 = time.perf_counter()
 rc = decwrap.main(["-i", os.path.join(root, "vol.npy"), "-dxy", "0.422", "-dz", "1.0", "-ex", "488", "-em", "525", "--use-fft", "-it", "6",
                    "--block-size-max", bmax, "--gpu-indices", "1", "--gpu-workers-per-gpu", nworkers])
@@ -92,6 +121,18 @@ print(f"{nworkers} workers per GPU; volume {shape[2]} x {shape[1]} x {shape[0]} 
       f"{dt:.1f} s wall = {nvox / dt / 1e6:.0f} Mvoxel/s end to end (6 RL iterations, default filters), peak resident set {rss:.1f} GB "
       f"incl. the mapped input file (before the run {rss0:.1f} GB), peak ANONYMOUS resident memory {peak_anon[0]:.1f} GB "
       f"(a float32 copy of the volume would be {nvox * 4 / 1e9:.1f} GB)", flush=True)
+if py_spans:
+    print("  host wall time per stage, summed over the workers (calls, seconds):")
+    for k, (c, v) in sorted(py_spans.items(), key=lambda kv: -kv[1][1]):
+        print(f"    {k:40s} {c:7d} {v:10.3f}")
+    import ctypes
+    from ipp_amd import capi
+    lib = capi.lib()
+    if hasattr(lib, "mi_probe_host_spans"):
+        buf = ctypes.create_string_buffer(1 << 16)
+        n = lib.mi_probe_host_spans(buf, len(buf))
+        print("  spans inside the library (label, calls, seconds):")
+        print("    " + buf.raw[:n].decode().replace("\n", "\n    "))
 if stacks:
     tot = sum(stacks.values())
     for k, v in sorted(stacks.items(), key=lambda kv: -kv[1])[:40]:

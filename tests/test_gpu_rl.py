@@ -261,6 +261,47 @@ def test_decon_fft_semantics_on_direct_engine(dev):
     assert_close(b, R.decon_fft(vol, psf, vol.shape, 4))
 
 
+@pytest.mark.parametrize("engine,rocfft", [(0, False), (1, False), (2, False), (2, True)], ids=["auto", "direct", "native_fft", "rocfft"])
+def test_decon_fft_psf_placed_by_a_named_grid(dev, engine, rocfft, monkeypatch):
+    """mi_rl_options.psf_grid: a block on a larger grid than the reference's next_fast_len one, the PSF placed where the reference's
+    grid puts it (odd 7-smooth extents: centre at index 0; the even extents of the hand-written transform alone: index -1).  Every
+    engine against the oracle's restatement of the same rule, and -- the point of the option -- close to the reference grid's
+    result where the default placement is far from it."""
+    from ipp_amd import decon
+    monkeypatch.setenv("MI_FFT_NATIVE_INFLATE", "100")
+    if rocfft:
+        monkeypatch.setenv("MI_FFT_ROCFFT", "1")
+    vol, psf = _case((24, 26, 28), (7, 5, 5), (1.5, 1.0, 1.0), 3)
+    ref_grid, big = (29, 27, 25), (32, 32, 32)                                       # [x y z]
+    want = R.decon_fft(vol, psf, big[::-1], 4, regularize_interval=2, psf_grid_zyx=ref_grid[::-1])
+    got = decon.decon(_t(vol, dev), psf, 4, 0.0, 0.0, 2, 1, True, big, False, engine=engine, psf_grid=ref_grid).cpu().numpy()
+    assert_close(got, want)
+    plain = decon.decon(_t(vol, dev), psf, 4, 0.0, 0.0, 2, 1, True, big, False, engine=engine).cpu().numpy()
+    assert_close(plain, R.decon_fft(vol, psf, big[::-1], 4, regularize_interval=2))
+    on_ref = R.decon_fft(vol, psf, ref_grid[::-1], 4, regularize_interval=2)
+    core = (slice(7, -7), slice(5, -5), slice(5, -5))
+    assert np.abs(got[core] - on_ref[core]).max() < 0.03 * on_ref[core].max() < np.abs(plain[core] - on_ref[core]).max()
+    # naming the FFT shape itself is the default; the option belongs to deconFFT
+    same = decon.decon(_t(vol, dev), psf, 4, 0.0, 0.0, 2, 1, True, big, False, engine=engine, psf_grid=big).cpu().numpy()
+    assert np.array_equal(same, plain)
+    with pytest.raises(ValueError, match="deconFFT only"):
+        decon.decon(_t(vol, dev), psf, 1, 0.0, 0.0, 0, 1, False, None, False, psf_grid=big)
+
+
+def test_decon_plan_is_keyed_by_the_psf_grid(dev, monkeypatch):
+    from ipp_amd import decon
+    monkeypatch.setenv("MI_FFT_NATIVE_INFLATE", "100")
+    vol, psf = _case((24, 26, 28), (7, 5, 5), (1.5, 1.0, 1.0), 5)
+    big = (32, 32, 32)
+    plan = decon.DeconPlan(1)
+    try:
+        for grid in ((29, 27, 25), None, (29, 27, 25), (30, 27, 26)):
+            got = decon.decon(_t(vol, dev), psf, 3, 0.0, 0.0, 0, 1, True, big, False, plan=plan, psf_grid=grid).cpu().numpy()
+            assert_close(got, R.decon_fft(vol, psf, big[::-1], 3, psf_grid_zyx=None if grid is None else grid[::-1]))
+    finally:
+        plan.close()
+
+
 def test_decon_stop_criterion_and_numpy_roundtrip(dev):
     from ipp_amd import decon
     vol, psf = _case((12, 16, 16), (5, 5, 5), (1, 1, 1), 4)

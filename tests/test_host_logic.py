@@ -79,6 +79,21 @@ def test_autosplit_fft_blocks_are_the_largest_that_fit():
                 min(xy, stack[0]) * min(xy, stack[1]) <= blk.x * blk.y, (stack, xy)
 
 
+def test_block_fft_shape_of_remainder_blocks():
+    """decwrap's per-block grid: the hand-written pipeline's extents up to 2.2x the 7-smooth grid (a rocFFT plan per new shape costs
+    0.7 s, its transforms 3.5x per point), never beyond the main block's grid; the reference's grid travels as psf_grid."""
+    from ipp_amd import lsdeconv as L
+    main = (512, 512, 1024)
+    assert L.block_fft_shape((512, 512, 959), main) == [512, 512, 1024]
+    assert L.block_fft_shape((130, 512, 959), main) == [192, 512, 1024]        # 1.52x the 7-smooth [135, 512, 960]
+    assert L.block_fft_shape((130, 130, 280), main) == [192, 160, 288]         # 1.73x
+    assert L.block_fft_shape((130, 130, 280), (160, 160, 288)) == [135, 135, 280]   # would leave the main block's grid
+    s, n = L.next_fast_len((66, 66, 66)), L.native_fft_shape((66, 66, 66))
+    assert np.prod(n) > 2.2 * np.prod(s) and L.block_fft_shape((66, 66, 66)) == s
+    blk = L.Block(10, 10, 10, 1, 1, 1, fft_shape=(192, 160, 288), psf_grid=(135, 135, 280))
+    assert blk.psf_grid == (135, 135, 280)
+
+
 def test_decwrap_cli_validation_and_dry_run(tmp_path, capsys):
     from ipp_amd import decwrap
     np.save(tmp_path / "vol.npy", np.zeros((4, 4, 4), np.uint16))

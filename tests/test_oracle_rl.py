@@ -95,6 +95,29 @@ def test_otf_matches_reference_definition():
     assert abs(otf[0, 0, 0] - psf.sum()) < 1e-6
 
 
+def test_otf_placement_named_by_another_grid():
+    # mi_rl_options.psf_grid: the grid whose parity places the PSF.  Naming the FFT shape itself is the reference's two steps
+    # exactly; an even grid named on an odd one moves an odd PSF by one sample (decon.m:131-133 on an even extent), and only that
+    psf = R.gaussian_psf((7, 5, 5), (1.5, 1.0, 1.0))
+    for F in ((16, 12, 10), (15, 13, 11), (16, 13, 10)):
+        assert np.array_equal(R.otf_from_psf(psf, F), R.otf_from_psf(psf, F, F))
+    F, G = (15, 13, 11), (16, 14, 12)
+    a = np.real(np.fft.ifftn(R.otf_from_psf(psf, F, G)))
+    b = np.real(np.fft.ifftn(R.otf_from_psf(psf, F)))
+    assert np.abs(a - np.roll(b, (-1, -1, -1), (0, 1, 2))).max() < 1e-12 and np.abs(a - b).max() > 1e-3
+    # the same placement on two grids: the spectra agree wherever both sample the same frequency (here: the z axis doubled)
+    F2 = (30, 13, 11)
+    c = R.otf_from_psf(psf, F2, F)
+    assert np.abs(c[::2] - R.otf_from_psf(psf, F)).max() < 1e-12
+    # a block on a larger grid with the smaller grid's placement: the same deconvolution up to the wider zero margin
+    vol = R.bead_volume((24, 26, 28), seed=3, psf=psf)
+    ref = R.decon_fft(vol, psf, (25, 27, 29), 3)
+    same = R.decon_fft(vol, psf, (32, 32, 32), 3, psf_grid_zyx=(25, 27, 29))
+    off = R.decon_fft(vol, psf, (32, 32, 32), 3)
+    core = (slice(7, -7), slice(5, -5), slice(5, -5))
+    assert np.abs(same[core] - ref[core]).max() < 0.02 * ref[core].max() < np.abs(off[core] - ref[core]).max()
+
+
 def test_fft_step_equals_composition_of_fft_convs():
     # mex_incubator/deconFFT_test.m:15,81-87: one fused RL step vs explicit FFT convolutions < 2e-4
     rng = np.random.default_rng(5)
