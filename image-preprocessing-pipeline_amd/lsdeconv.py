@@ -94,17 +94,18 @@ def native_fft_shape(shape_xyz):
 def block_fft_shape(bl_xyz, main_fft_shape=None):
     """FFT shape of ONE padded block (decwrap's run_block): the grid the hand-written pipeline takes whenever that costs less than the
     7-smooth grid through rocFFT -- 1 against 3.5 per grid point (``cost_per_core_voxel``), and a rocFFT plan of a new shape takes
-    0.7 s to create where the pipeline's set-up takes 10 ms (profiles/r05_decwrap_spans.txt) -- i.e. up to the 2.2x inflation the
-    library itself accepts (``MI_FFT_NATIVE_INFLATE``), as long as the grid stays inside the main block's (``main_fft_shape``: the one
-    ``autosplit`` sized against --block-size-max; remainder blocks are smaller on every axis, so is their native grid).  The native
+    0.7 s to create where the pipeline's set-up takes 10 ms (profiles/r05_decwrap_spans.txt) -- i.e. up to 3.4x the 7-smooth grid's
+    volume when the grid stays inside the main block's (``main_fft_shape``: the one ``autosplit`` sized against --block-size-max, so
+    memory is not in question; remainder blocks are smaller on every axis, so is their native grid), up to 1.3x otherwise.  It also keeps
+    blocks of different shapes away from rocFFT plans that are alive at the same time (profiles/r05_rocfft_coexistence.txt).  The native
     extents are all even, the 7-smooth ones need not be: the caller hands the 7-smooth grid to ``decon`` as ``psf_grid`` so that the
     PSF lands where the reference's grid puts it (``mi_rl_options.psf_grid``)."""
     smooth, native = next_fast_len(bl_xyz), native_fft_shape(bl_xyz)
     ratio = float(np.prod(native)) / float(np.prod(smooth))
     if ratio <= 1.3:
         return native
-    inside = main_fft_shape is None or all(int(a) <= int(b) for a, b in zip(native, main_fft_shape))
-    return native if (ratio <= 2.2 and inside) else smooth
+    inside = main_fft_shape is not None and all(int(a) <= int(b) for a, b in zip(native, main_fft_shape))
+    return native if (ratio <= 3.4 and inside) else smooth
 
 
 def autosplit(stack_xyz, psf_size_xyz, filt: Filter, block_size_max: int, numit: int, ram_available: int | None = None,

@@ -80,8 +80,9 @@ def test_autosplit_fft_blocks_are_the_largest_that_fit():
 
 
 def test_block_fft_shape_of_remainder_blocks():
-    """decwrap's per-block grid: the hand-written pipeline's extents up to 2.2x the 7-smooth grid (a rocFFT plan per new shape costs
-    0.7 s, its transforms 3.5x per point), never beyond the main block's grid; the reference's grid travels as psf_grid."""
+    """decwrap's per-block grid: the hand-written pipeline's extents up to 3.4x the 7-smooth grid inside the main block's grid (a
+    rocFFT plan per new shape costs 0.7 s, its transforms 3.5x per point), up to 1.3x without one; the reference's grid travels as
+    psf_grid."""
     from ipp_amd import lsdeconv as L
     main = (512, 512, 1024)
     assert L.block_fft_shape((512, 512, 959), main) == [512, 512, 1024]
@@ -89,7 +90,9 @@ def test_block_fft_shape_of_remainder_blocks():
     assert L.block_fft_shape((130, 130, 280), main) == [192, 160, 288]         # 1.73x
     assert L.block_fft_shape((130, 130, 280), (160, 160, 288)) == [135, 135, 280]   # would leave the main block's grid
     s, n = L.next_fast_len((66, 66, 66)), L.native_fft_shape((66, 66, 66))
-    assert np.prod(n) > 2.2 * np.prod(s) and L.block_fft_shape((66, 66, 66)) == s
+    assert 3.4 < np.prod(n) / np.prod(s) < 3.5 and L.block_fft_shape((66, 66, 66), main) == s      # beyond the break-even
+    assert L.block_fft_shape((130, 66, 66), main) == [192, 96, 96]                                 # 2.67x, inside the main grid
+    assert L.block_fft_shape((130, 66, 66)) == [135, 70, 70]                                       # no main grid: the 1.3x rule
     blk = L.Block(10, 10, 10, 1, 1, 1, fft_shape=(192, 160, 288), psf_grid=(135, 135, 280))
     assert blk.psf_grid == (135, 135, 280)
 
