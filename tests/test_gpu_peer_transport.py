@@ -80,6 +80,31 @@ def test_two_processes_one_gpu_peer_copy_transport(dev, flavour, engine, zchunks
         assert overlap                                  # edge tiles first, copies issued, remaining tiles, then the wait
 
 
+@pytest.mark.parametrize("world,zchunks", [(4, 1), (3, 2)], ids=["four_ranks", "three_ranks_z_chunked"])
+def test_more_processes_one_gpu_peer_copy_ring(dev, world, zchunks):
+    """The ring with inner ranks (two neighbours each, both directions in flight) and an odd rank count: `world` processes on the one
+    GPU of the test box (at most 6 may use it), equal slabs of 32 / 42 rows, the fused overlapped iteration, result against the
+    whole-volume oracle."""
+    psf = R.gaussian_psf((5, 7, 5), (1.0, 1.5, 1.0))
+    vol = R.bead_volume((16, 128 if world == 4 else 126, 32), seed=35, psf=psf)
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = 29960 + (os.getpid() % 30) + world
+    procs = [ctx.Process(target=_worker, args=(r, world, port, "fft", 2, vol, psf, 3, out, zchunks)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        got, (sharded, overlap, n_exchanges) = out.get(timeout=180)
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.kill()
+    assert all(p.exitcode == 0 for p in procs)
+    assert_close(got, R.decon_fft(vol, psf, vol.shape, 3, skip_edgetaper=True))
+    assert sharded and n_exchanges == 2 * 3 + 1
+
+
 def test_a_wait_nobody_answers_ends_by_its_timeout(dev, monkeypatch):
     """A neighbour that never delivers (a rank that died) leaves an error behind, not a hung device: the one-lane wait kernel gives up
     after MI_PEER_TIMEOUT_S, counts itself in the link's status word, and the stream goes on."""
