@@ -24,6 +24,7 @@ import json
 import logging
 import os
 import sys
+from concurrent.futures import CancelledError
 from pathlib import Path
 
 logging.basicConfig(level=logging.INFO, format="%(message)s")
@@ -194,7 +195,10 @@ def evict_cores(g, resident, resident_dev, brick_future, lock, evict_lock, brick
             if core is None:
                 continue
             if fut is not None:
-                fut.result()
+                try:
+                    fut.result()
+                except CancelledError:     # (a brick that was to be written behind the workers and never begun)
+                    pass
             if not brick_complete(n):
                 write_brick(n, core)
             del core
@@ -268,12 +272,24 @@ def main(argv=None):
     per_dev = max(1, args.gpu_workers_per_gpu) * max(1, args.gpu_indices.count(gpu))
     # Finished cores stay in device memory until the assembly needs them (288 GB of HBM hold a 30-Gvoxel result in float32): the
     # assembly then rescales them where they are instead of reading its bricks back, decompressing them and sending them up again.
-    # MI_DECWRAP_RESIDENT=0 switches that off; MI_DECWRAP_BRICKS=0 additionally writes no brick for a core that stays resident (no
-    # D2H of the float32 core, no LZ4, no file: the run cannot be resumed).  Memory: with an explicit --block-size-max whatever the
-    # workers' blocks leave free; otherwise the result's share of this device is set aside first, if that is at most half of it.
+    # MI_DECWRAP_RESIDENT=0 switches that off.  The bricks of RESIDENT cores are only there for a resumed run, and writing 64 GB of
+    # float32 into the cache folder took as long as computing it (workers done after 5.7 s with, 2.8 s without: r05_decwrap_scale.txt):
+    # MI_DECWRAP_BRICKS=trail (default) writes them BEHIND the workers -- a core stays on its device, a writer thread
+    # (MI_DECWRAP_TRAIL_THREADS, default one) fetches it when it has a free buffer, and whatever is not begun when the last block is
+    # done is not written at all: the output is assembled from the resident cores and the cache folder goes away with a complete run;
+    # an interrupted run resumes from the bricks it has and recomputes the rest.  This only concerns results that fit into device
+    # memory, i.e. runs of seconds to a few minutes; cores that find no room on the device get their brick before their worker goes on,
+    # as do all blocks of a helper process (--start-block > 1).  MI_DECWRAP_BRICKS=1: every brick is complete before its worker goes on (the reference's
+    # order, LsDeconv.m:799-806); =0: no brick for a core that stays resident (no D2H of the float32 core, no LZ4, no file: the run
+    # cannot be resumed).  Memory: with an explicit --block-size-max whatever the workers' blocks leave free; otherwise the result's
+    # share of this device is set aside first, if that is at most half of it.
     n_work_vols = 3 + 2 * (2 if args.use_fft else 0)
     keep_resident = os.environ.get("MI_DECWRAP_RESIDENT", "1") != "0" and int(args.start_block) == 1
-    keep_bricks = os.environ.get("MI_DECWRAP_BRICKS", "1") != "0" or not keep_resident
+    bricks_mode = os.environ.get("MI_DECWRAP_BRICKS", "trail")
+    if bricks_mode not in ("0", "1", "trail"):
+        raise ValueError("MI_DECWRAP_BRICKS must be 0, 1 or trail")
+    keep_bricks = bricks_mode != "0" or not keep_resident
+    trail_bricks = bricks_mode == "trail" and keep_resident
     res_share = sz * sy * sx * 4 // len(set(args.gpu_indices)) + (1 << 30)
     if args.block_size_max:
         bmax = args.block_size_max
@@ -529,7 +545,41 @@ def main(argv=None):
         prep_thread.start()
 
     evict_locks = {g: threading.Lock() for g in set(workers)}   # one eviction at a time per device (several workers share one)
-    brick_future = {}                                            # block -> the writer's future of its brick (save_brick)
+    brick_future = {}                                            # block -> the writer's future of its brick (save_brick / trail_brick)
+    stop_trailing = threading.Event()                            # the last block is done: no further brick of a resident core is begun
+    trailing = []                                                # futures of trail_brick
+    trail_local = threading.local()
+
+    def trail_brick(n, lb, ub):
+        """MI_DECWRAP_BRICKS=trail: the brick of a core that stays on its device, fetched by a writer thread when it has a pinned buffer
+        to spare.  True: written.  (evict_cores waits for this future before it decides whether the core still needs a brick.)"""
+        if stop_trailing.is_set():
+            return False
+        with lock:
+            core = resident.get(n)
+        if core is None:                                                                   # (evicted meanwhile: evict_cores wrote it)
+            return False
+        host = stage_get()
+        try:
+            if stop_trailing.is_set():
+                stage_free.put(host)
+                return False
+            with torch.cuda.device(core.device):
+                st = getattr(trail_local, "stream", None)
+                if st is None or st.device != core.device:
+                    st = trail_local.stream = torch.cuda.Stream(device=core.device)
+                view = host[:core.numel()].view(core.shape)
+                with torch.cuda.stream(st):
+                    view.copy_(core, non_blocking=True)
+                st.synchronize()
+        except BaseException:
+            stage_free.put(host)
+            raise
+        del core
+        save_brick(n, view.numpy(), host, lb, ub)                                          # (hands the buffer back)
+        with lock:
+            timing["bricks_trailed"] += 1
+        return True
 
     def write_evicted(n, core):
         arr = core.cpu().numpy()
@@ -564,6 +614,8 @@ def main(argv=None):
                     continue                                                               # finished or being worked on elsewhere
                 run_block(n, g, stream, staging, plan)
         finally:
+            with lock:
+                timing["worker_end_s"].append(time.perf_counter() - t_blocks0)
             if plan is not None:
                 with torch.cuda.device(g - 1):
                     plan.close()
@@ -613,7 +665,8 @@ def main(argv=None):
                 if stays:
                     res_used[g] += nbytes
             host = None
-            if keep_bricks or not stays:
+            behind = trail_bricks and stays                                                # its brick is written behind the workers
+            if (keep_bricks and not behind) or not stays:
                 host = stage_get()                                                         # (waits while the writers are behind)
             t_d = time.perf_counter()
             if host is not None:
@@ -646,6 +699,11 @@ def main(argv=None):
                 fut = writers.submit(save_brick, n, view.numpy(), host, lb, ub)
                 pending.append(fut)
                 brick_future[n] = fut
+        elif behind:
+            with lock:
+                fut = trailers.submit(trail_brick, n, lb, ub)
+                trailing.append(fut)
+                brick_future[n] = fut
         log.info(f"block {n}/{num_blocks} done on GPU {g}: stats [{lb:.4g}, {ub:.4g}]" + ("" if host is not None else " (kept on the device only)"))
 
     def save_brick(n, arr, host, lb, ub):
@@ -668,7 +726,12 @@ def main(argv=None):
     # block, claims of a process that died) is taken by another round from block 1
     start = max(1, min(int(args.start_block), num_blocks))
     pending = []
-    timing = {"blocks": 0, "box_read_s": 0.0, "device_ms": 0.0, "wait_buffer_s": 0.0, "d2h_s": 0.0}
+    timing = {"blocks": 0, "box_read_s": 0.0, "device_ms": 0.0, "wait_buffer_s": 0.0, "d2h_s": 0.0, "worker_end_s": [], "flush_s": 0.0,
+              "bricks_trailed": 0, "bricks_not_written": 0}
+    # (trail_brick; ended before the assembly.  ONE writer by default: four of them wrote 59 of 75 bricks of the 17-GB probe and the
+    # workers took 5.5 s, as long as with every brick complete; one writes 12 and the workers take 3.1 s -- 2.7 s without any brick:
+    # what slows the workers is the host's memory traffic of the writers, not waiting for them)
+    trailers = ThreadPoolExecutor(max_workers=max(1, int(os.environ.get("MI_DECWRAP_TRAIL_THREADS", max(1, n_writers // 4)))))
     t_blocks0 = time.perf_counter()
     log.info(f"set-up (imports, device, PSF, block grid, cache folder): {t_blocks0 - t_main0:.1f} s")
     with ThreadPoolExecutor(max_workers=n_writers) as writers:                             # one brick file each; liblz4 runs outside the GIL
@@ -689,23 +752,37 @@ def main(argv=None):
             if missing == 0:
                 break
             _warm_thread.join(timeout=120.0)       # (its plan is closed before the workers make their first allocations)
+            done_before = timing["blocks"]
             with ThreadPoolExecutor(max_workers=len(workers)) as pool:
                 for f in [pool.submit(run, w, min(num_blocks, start + w)) for w in range(len(workers))]:
                     f.result()                                                             # re-raises a worker's exception
+            t_f = time.perf_counter()
             for f in pending:
                 f.result()
-            if not pending and start == 1:
+            timing["flush_s"] += time.perf_counter() - t_f
+            if timing["blocks"] == done_before and start == 1:
                 time.sleep(2.0)                                                            # the missing blocks are live claims of another process
             pending.clear()
             if start > 1 and all(brick_complete(n) for n in range(start, num_blocks + 1)):
                 break                                                                      # a helper machine is done with its share
             start = 1
+    # bricks of resident cores that no writer has begun are not written (trail_brick); the ones in flight finish
+    stop_trailing.set()
+    trailers.shutdown(wait=True, cancel_futures=True)
+    for f in trailing:
+        if not f.cancelled():
+            f.result()                                                                     # (re-raises a writer's exception)
+    timing["bricks_not_written"] = len(trailing) - timing["bricks_trailed"]
+    trailing.clear()
     t_blocks = time.perf_counter() - t_blocks0
     if timing["blocks"]:
         log.info(f"{timing['blocks']} blocks in {t_blocks:.1f} s: device work {timing['device_ms'] / 1e3:.1f} s "
                  f"({timing['device_ms'] / 1e3 / max(t_blocks, 1e-9) * 100:.0f} % of that time), box reads {timing['box_read_s']:.1f} s, "
                  f"D2H of the cores {timing['d2h_s']:.1f} s, waiting for a free core buffer {timing['wait_buffer_s']:.1f} s "
-                 f"(summed over {len(workers)} workers)")
+                 f"(summed over {len(workers)} workers); the workers ended after "
+                 f"{', '.join(f'{v:.1f}' for v in sorted(timing['worker_end_s']))} s, the last bricks were written {timing['flush_s']:.1f} s later"
+                 + (f"; bricks behind the workers: {timing['bricks_trailed']} written, {timing['bricks_not_written']} not begun when the last "
+                    f"block was done" if trail_bricks else ""))
     main.last_timing = dict(timing, blocks_wall_s=t_blocks)
     merge_min_max()                                                                        # (helpers too: rawmax of their last blocks)
     if int(args.start_block) != 1:

@@ -189,14 +189,15 @@ def test_decwrap_block_parallel_workers_equal_sequential(dev, tmp_path):
 
 
 def test_decwrap_resident_cores_equal_the_brick_route(dev, tmp_path, monkeypatch):
-    """The assembly takes finished cores straight from device memory (default), from their LZ4 bricks (MI_DECWRAP_RESIDENT=0,
-    the reference's route: LsDeconv.m:799-806, load_slab_lz4.cpp), or -- MI_DECWRAP_BRICKS=0 -- from device memory with no brick
-    written at all: three identical stacks; the last mode leaves no brick behind and reports every core as resident."""
+    """The assembly takes finished cores straight from device memory (default; their bricks are written behind the workers as far as
+    the writers get: MI_DECWRAP_BRICKS=trail), from their LZ4 bricks (MI_DECWRAP_RESIDENT=0, the reference's route:
+    LsDeconv.m:799-806, load_slab_lz4.cpp), from device memory with every brick complete before its worker goes on
+    (MI_DECWRAP_BRICKS=1), or -- MI_DECWRAP_BRICKS=0 -- with no brick written at all: four identical stacks."""
     from ipp_amd import decwrap
     rng = np.random.default_rng(12)
     vol16 = (rng.random((24, 40, 44)) * 3000 + 200).astype(np.uint16)
     outs = []
-    for k, env in enumerate(({}, {"MI_DECWRAP_RESIDENT": "0"}, {"MI_DECWRAP_BRICKS": "0"})):
+    for k, env in enumerate(({}, {"MI_DECWRAP_RESIDENT": "0"}, {"MI_DECWRAP_BRICKS": "0"}, {"MI_DECWRAP_BRICKS": "1"})):
         for name in ("MI_DECWRAP_RESIDENT", "MI_DECWRAP_BRICKS"):
             monkeypatch.delenv(name, raising=False)
         for name, v in env.items():
@@ -209,8 +210,13 @@ def test_decwrap_resident_cores_equal_the_brick_route(dev, tmp_path, monkeypatch
                            "--gpu-workers-per-gpu", "2"])
         assert rc == 0
         outs.append((np.load(d / "deconvolved" / "deconvolved.npy"), np.load(d / "deconvolved" / "deconvolved_16bit.npy")))
-        n_dev = decwrap.main.last_timing["cores_from_device"]
+        tm = decwrap.main.last_timing
+        n_dev = tm["cores_from_device"]
         assert (n_dev == 0) if env.get("MI_DECWRAP_RESIDENT") == "0" else (n_dev > 1), (env, n_dev)
+        if not env:      # every resident core's brick was either written behind the workers or never begun
+            assert tm["bricks_trailed"] + tm["bricks_not_written"] == n_dev and tm["bricks_trailed"] >= 0
+        else:
+            assert tm["bricks_trailed"] == 0 and tm["bricks_not_written"] == 0
     for o in outs[1:]:
         assert np.array_equal(outs[0][0], o[0]) and np.array_equal(outs[0][1], o[1])
 
