@@ -268,6 +268,7 @@ int edgetaper_async(hipStream_t s, float* bl, float* work, const float* psf, int
         use_fft = odd && f[0] == 'f';
         use_slabs = odd && sp.ok && f[0] == 's';
     }
+    MI_SPAN_BEGIN(spr, use_slabs ? "edgetaper route: slabs" : use_fft ? "edgetaper route: whole-block FFT" : "edgetaper route: direct shell");
     if (use_slabs) {
         TaperKeep local_keep;
         TaperKeep* kp = nullptr;
@@ -321,6 +322,7 @@ int edgetaper_async(hipStream_t s, float* bl, float* work, const float* psf, int
         MI_TRY(direct_prepare_psf(s, psf, kx, ky, kz, /*normalise=*/true, /*flip=*/true, kf, &kxp));
         MI_TRY(direct_conv_launch(s, bl, kf.as<float>(), work, nx, ny, nz, kx, ky, kz, kxp, MI_BOUNDARY_REPLICATE, EPI_TAPER_SHELL, epi));
     }
+    MI_SPAN_END(spr);
     MI_SPAN_END(spb);
     MI_SPAN_BEGIN(spw, "edgetaper: blend + final wait");
     const float* t = dtaper.as<float>();
