@@ -20,7 +20,7 @@ ENGINE_AUTO, ENGINE_DIRECT, ENGINE_FFT = 0, 1, 2
 NORTH_SOUTH, WEST_EAST = 0, 1
 
 
-MI_ERR_INVALID, MI_ERR_HIP, MI_ERR_NOMEM, MI_ERR_UNSUPPORTED = -1, -2, -4, -5  # include/mi_common.h
+MI_ERR_INVALID, MI_ERR_HIP, MI_ERR_FFT, MI_ERR_NOMEM, MI_ERR_UNSUPPORTED = -1, -2, -3, -4, -5  # include/mi_common.h
 
 
 class MiError(RuntimeError):

@@ -9,7 +9,10 @@
 //     placement has for even fft_shape;
 //   * convn(...,'same') / conv3d_gpu semantics for large PSFs: the volume is staged into a padded
 //     buffer (zeros or clamped samples) large enough that circular wrap never reaches the output.
+#include <algorithm>
+#include <cmath>
 #include <mutex>
+#include <vector>
 
 #include <cstdlib>
 
@@ -196,8 +199,8 @@ bool choose_fft_lengths(const int need[3], const int bnd[3], int F[3]) {
 // (rocFFT plans are destroyed with their engine, not kept for the next engine of the same lengths -- creating the pair takes 0.7 s at
 // decwrap's block sizes -- because live rocFFT plans are not independent of each other in ROCm 7.2: with the plans of a
 // 256 x 16 x 64 grid alive, a new engine on 32 x 128 x 8 returns values 6 % off (profiles/r05_rocfft_coexistence.txt; alone it is
-// exact).  A table of idle plans turned that into a failure of consecutive calls; callers keep away from the rocFFT route instead:
-// lsdeconv.block_fft_shape.)
+// exact).  A table of idle plans turned that into a failure of consecutive calls; callers keep away from the rocFFT route instead
+// (lsdeconv.block_fft_shape), and an engine on it checks its transforms at creation: verify_rocfft_engine.)
 FftEngine::~FftEngine() {
     delete native;
     if (info) rocfft_execution_info_destroy(info);
@@ -224,6 +227,93 @@ static int make_plans(hipStream_t s, const size_t lengths[3], rocfft_plan* fwd, 
         MI_FFT(rocfft_execution_info_set_work_buffer(*info, work.p, w));
     }
     MI_FFT(rocfft_execution_info_set_stream(*info, s));
+    return MI_OK;
+}
+
+// Does the rocFFT plan pair transform?  Live rocFFT plans are not independent of each other in ROCm 7.2 (a new plan can return
+// values several per cent off while certain other plans exist: profiles/r05_rocfft_coexistence.txt), and nothing in this library
+// can prevent that -- so every engine on the rocFFT route proves itself once, at creation, on the data it has anyway:
+//   forward: a few bins of the OTF it has just built against the direct sum over the PSF's samples (k^3 terms per bin, on the host);
+//   inverse: the inverse transform of that OTF must give back the placed PSF (read at a few of its samples and at empty positions).
+// A wrong transform fails the creation with MI_ERR_FFT instead of deconvolving with it.  Cost: one inverse transform, a few
+// 8-byte reads and a synchronisation per engine; rocFFT plan creation itself takes tens to hundreds of milliseconds.
+static int verify_rocfft_engine(hipStream_t s, FftEngine& e, const float* psf, const float* otf_dev, float scale) {
+    const AxisPlan* ax = e.ax;
+    const int kx = ax[0].k, ky = ax[1].k, kz = ax[2].k, Fx = ax[0].F, Fy = ax[1].F, Fz = ax[2].F, Hx = Fx / 2 + 1;
+    const size_t nk = (size_t)kx * ky * kz;
+    std::vector<float> hp(nk);
+    MI_HIP(hipMemcpyAsync(hp.data(), psf, sizeof(float) * nk, hipMemcpyDeviceToHost, s));
+    constexpr int NB = 6;
+    int bins[NB][3];
+    float2 got[NB];
+    unsigned lcg = 12345u + (unsigned)Fx * 31u + (unsigned)Fy * 17u + (unsigned)Fz;
+    auto next = [&](int m) { lcg = lcg * 1664525u + 1013904223u; return (int)((lcg >> 8) % (unsigned)m); };
+    for (int b = 0; b < NB; ++b) {
+        bins[b][0] = next(Hx);
+        bins[b][1] = next(Fy);
+        bins[b][2] = next(Fz);
+        const size_t idx = ((size_t)bins[b][2] * Fy + bins[b][1]) * Hx + bins[b][0];
+        MI_HIP(hipMemcpyAsync(&got[b], reinterpret_cast<const float2*>(otf_dev) + idx, sizeof(float2), hipMemcpyDeviceToHost, s));
+    }
+    // inverse: spec <- OTF (the real inverse may overwrite its input), real <- inv(spec)
+    MI_HIP(hipMemcpyAsync(e.spec.p, otf_dev, sizeof(float2) * e.n_spec, hipMemcpyDeviceToDevice, s));
+    void* iin[1] = {e.spec.p};
+    void* iout[1] = {e.real.p};
+    MI_FFT(rocfft_execute(e.inv, iin, iout, e.info));
+    constexpr int NS = 8;
+    size_t pos[NS];
+    int tap[NS];   // index into the PSF, or -1: a position no sample lands on
+    float back[NS];
+    auto placed = [&](int jx, int jy, int jz) {
+        const int x = ((jx - ax[0].shift) % Fx + Fx) % Fx, y = ((jy - ax[1].shift) % Fy + Fy) % Fy, z = ((jz - ax[2].shift) % Fz + Fz) % Fz;
+        return ((size_t)z * Fy + y) * Fx + x;
+    };
+    for (int q = 0; q < NS; ++q) {
+        if (q < 6) {
+            const int jx = q == 0 ? kx / 2 : next(kx), jy = q == 0 ? ky / 2 : next(ky), jz = q == 0 ? kz / 2 : next(kz);
+            tap[q] = (jz * ky + jy) * kx + jx;
+            pos[q] = placed(jx, jy, jz);
+        } else {   // the position half a grid away from the centre sample: empty whenever F > 2 k - 1, else checked as what it holds
+            const int x = (((kx / 2 - ax[0].shift) + Fx / 2) % Fx + Fx) % Fx, y = (((ky / 2 - ax[1].shift) + (q == 6 ? Fy / 2 : 0)) % Fy + Fy) % Fy,
+                      z = (((kz / 2 - ax[2].shift) + (q == 7 ? Fz / 2 : 0)) % Fz + Fz) % Fz;
+            pos[q] = ((size_t)z * Fy + y) * Fx + x;
+            tap[q] = -1;
+            for (size_t i = 0; i < nk && tap[q] < 0; ++i) {
+                const int jx = (int)(i % kx), r = (int)(i / kx), jy = r % ky, jz = r / ky;
+                if (placed(jx, jy, jz) == pos[q]) tap[q] = (int)i;
+            }
+        }
+        MI_HIP(hipMemcpyAsync(&back[q], e.real.as<float>() + pos[q], sizeof(float), hipMemcpyDeviceToHost, s));
+    }
+    MI_HIP(hipStreamSynchronize(s));
+    double sum_abs = 0.0, max_abs = 0.0;
+    for (float v : hp) { sum_abs += std::fabs((double)v); max_abs = std::max(max_abs, std::fabs((double)v)); }
+    const double two_pi = 6.283185307179586476925286766559;
+    for (int b = 0; b < NB; ++b) {
+        double re = 0.0, im = 0.0;
+        for (size_t i = 0; i < nk; ++i) {
+            const int jx = (int)(i % kx), r = (int)(i / kx), jy = r % ky, jz = r / ky;
+            const double ph = -two_pi * ((double)bins[b][0] * (jx - ax[0].shift) / Fx + (double)bins[b][1] * (jy - ax[1].shift) / Fy +
+                                         (double)bins[b][2] * (jz - ax[2].shift) / Fz);
+            re += hp[i] * std::cos(ph);
+            im += hp[i] * std::sin(ph);
+        }
+        const double err = std::hypot(got[b].x - re * scale, got[b].y - im * scale);
+        if (!(err <= 2e-4 * sum_abs * scale + 1e-30))
+            return fail(MI_ERR_FFT, "rocFFT forward transform of the %d x %d x %d grid is wrong: OTF bin (%d, %d, %d) is (%g, %g), the PSF's direct sum gives (%g, %g) "
+                        "-- live rocFFT plans of other lengths can do this (profiles/r05_rocfft_coexistence.txt): destroy the other FFT contexts of this "
+                        "process, or choose a shape the hand-written pipeline takes (mi_fft_good_size)",
+                        Fx, Fy, Fz, bins[b][0], bins[b][1], bins[b][2], (double)got[b].x, (double)got[b].y, re * scale, im * scale);
+    }
+    const double n_all = (double)Fx * Fy * Fz * scale;   // the inverse is unnormalised: real = N * scale * placed PSF
+    for (int q = 0; q < NS; ++q) {
+        const double want = tap[q] >= 0 ? (double)hp[(size_t)tap[q]] * n_all : 0.0;
+        if (!(std::fabs((double)back[q] - want) <= 2e-4 * sum_abs * n_all + 1e-30))
+            return fail(MI_ERR_FFT, "rocFFT inverse transform of the %d x %d x %d grid is wrong: sample %d of the placed PSF comes back as %g instead of %g "
+                        "-- live rocFFT plans of other lengths can do this (profiles/r05_rocfft_coexistence.txt): destroy the other FFT contexts of this "
+                        "process, or choose a shape the hand-written pipeline takes (mi_fft_good_size)", Fx, Fy, Fz, q, (double)back[q], want);
+    }
+    (void)max_abs;
     return MI_OK;
 }
 
@@ -322,6 +412,7 @@ int FftEngine::init(hipStream_t s, const int n[3], const int k[3], const int bnd
     const float scale = 1.0f / (float)((double)F[0] * F[1] * F[2]);
     MI_TRY(build_otf(s, fwd, info, psf, ax, real.as<float>(), otf.as<float>(), scale));
     MI_SPAN_END(sp4);
+    if (!std::getenv("MI_FFT_NO_VERIFY")) MI_TRY(verify_rocfft_engine(s, *this, psf, otf.as<float>(), scale));
     if (have_adj) {
         MI_TRY(otf_adj.alloc(sizeof(float) * 2 * n_spec));
         MI_TRY(build_otf(s, fwd, info, psf_inv, ax, real.as<float>(), otf_adj.as<float>(), scale));

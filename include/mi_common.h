@@ -28,7 +28,7 @@ typedef enum {
     MI_OK = 0,
     MI_ERR_INVALID = -1,     /* bad argument (the reference's mexErrMsgIdAndTxt / iom::exception cases) */
     MI_ERR_HIP = -2,         /* a HIP runtime call failed */
-    MI_ERR_FFT = -3,         /* a rocFFT call failed */
+    MI_ERR_FFT = -3,         /* a rocFFT call failed, or a rocFFT plan did not transform (every engine on that route checks itself once) */
     MI_ERR_NOMEM = -4,       /* workspace too small / allocation failed */
     MI_ERR_UNSUPPORTED = -5  /* valid in the reference but not built here (e.g. NCC `enhance`) */
 } mi_status;

@@ -54,6 +54,47 @@ def test_decon_fft_native_matches_oracle(dev, shape, niter, lam, interval):
     assert_close(got, want)
 
 
+def test_rocfft_engine_never_silently_wrong_beside_another_plan(dev, monkeypatch):
+    """Live rocFFT plans are not independent in ROCm 7.2: beside the plans of a 256 x 16 x 64 grid a new engine on 32 x 128 x 8 transforms
+    wrongly (profiles/r05_rocfft_coexistence.txt).  Every engine on the rocFFT route checks its own transforms at creation (a few OTF
+    bins against the PSF's direct sum, the inverse against the placed PSF): the context is either refused with MI_ERR_FFT or right."""
+    import gc
+    from ipp_amd import capi, decon
+    monkeypatch.setenv("MI_FFT_ROCFFT", "1")
+    rng = np.random.default_rng(1)
+    ker = rng.random((3, 5, 7), dtype=np.float32)
+    img = rng.random((8, 128, 32), dtype=np.float32) + 0.5
+
+    def conv(ctx):
+        a = torch.from_numpy(img).to(dev)
+        r = torch.empty_like(a)
+        ctx.forward_ratio(a, r)
+        return (a / r).cpu().numpy()
+
+    def make(shape):
+        return decon.RLContext(shape, ker, None, boundary=capi.BOUNDARY_CIRCULAR, engine=capi.ENGINE_FFT, device=dev)
+
+    alone = make(img.shape)
+    want = conv(alone)
+    alone.close()
+    del alone
+    gc.collect()
+    other = make((64, 16, 256))
+    try:
+        beside = make(img.shape)
+    except capi.MiError as e:
+        assert e.code == capi.MI_ERR_FFT and "rocFFT" in str(e) and "r05_rocfft_coexistence" in str(e)
+    else:
+        assert _rel(conv(beside), want) < 2e-5
+        beside.close()
+    other.close()
+    del other
+    gc.collect()
+    again = make(img.shape)                       # with the other plans gone the same shape is served, and right
+    assert _rel(conv(again), want) < 2e-5
+    again.close()
+
+
 def test_adjoint_is_exact_transpose(dev):
     """<conv(a), b> == <a, conv_adj(b)> for the circular operator pair (forward = OTF, adjoint = conj OTF)."""
     from ipp_amd import capi, decon
