@@ -207,6 +207,7 @@ int edgetaper_slabs(hipStream_t s, const float* bl, float* work, const float* ps
 int edgetaper_async(hipStream_t s, float* bl, float* work, const float* psf, int nx, int ny, int nz, int kx, int ky, int kz,
                     TaperKeep** keep) {
     MI_REQUIRE(bl && work && psf && bl != work, "edgetaper_3d: null or aliased buffers");
+    NoPlacementTrial as_they_come;   // (the blur's engines run once per block: fft_native.h)
     MI_REQUIRE(nx > 0 && ny > 0 && nz > 0 && kx > 0 && ky > 0 && kz > 0, "edgetaper_3d: bl and psf must be 3D");
     const int n[3] = {nx, ny, nz}, k[3] = {kx, ky, kz};
     std::vector<float> taper[3];

@@ -52,6 +52,18 @@ struct VmmRange {
     ~VmmRange() { release(); }
 };
 
+// While one of these exists on a thread, the contexts that thread creates take their spectrum arrays as they come instead of placing
+// them by trial (NativeFft::init): the whole-loop entry points (mi_decon, mi_decon_plan_run, mi_rl_fft) run a handful of iterations per
+// context, the trial costs 0.5 s, holds six candidates of the arrays, is serialised per device and trims the pool -- with five
+// decwrap workers on blocks of 1024^3 it made 27 blocks take 14.5 s (profiles/r05_decwrap_scale.txt).  Contexts made with
+// mi_rl_create (a bench, a slab rank: thousands of iterations on one placement) are placed by trial as before.
+struct NoPlacementTrial {
+    NoPlacementTrial();
+    ~NoPlacementTrial();
+    NoPlacementTrial(const NoPlacementTrial&) = delete;
+    NoPlacementTrial& operator=(const NoPlacementTrial&) = delete;
+};
+
 struct NativeFft {
     NativeDims dims{};
     PadWindow pw{};

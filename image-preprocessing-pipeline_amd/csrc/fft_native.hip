@@ -2029,6 +2029,12 @@ int NativeFft::good_size(int n, int axis) {
 // the axis use, an upper bound for the others; see TwLds)
 static size_t lds_bytes(int rows, int n) { return sizeof(float2) * ((size_t)rows * row_pitch(n) + axis_tw_entries(n)); }
 
+namespace {
+thread_local int tl_no_placement_trial = 0;
+}
+NoPlacementTrial::NoPlacementTrial() { ++tl_no_placement_trial; }
+NoPlacementTrial::~NoPlacementTrial() { --tl_no_placement_trial; }
+
 int NativeFft::init(hipStream_t s, const int F[3], bool explicit_adjoint) {
     MI_REQUIRE(supported(F), "native FFT: unsupported shape %d x %d x %d", F[0], F[1], F[2]);
     const int Hx = F[0] / 2;
@@ -2151,7 +2157,7 @@ int NativeFft::init(hipStream_t s, const int F[3], bool explicit_adjoint) {
     // (slab.SlabRL lowers the limit for its rank, which has its device to itself).
     size_t place_min = (size_t)6 << 30;
     if (const char* e = std::getenv("MI_FFT_PLACE_MIN_MB")) place_min = (size_t)std::max(0LL, atoll(e)) << 20;
-    if (vmm_order < 0 && S.bytes >= place_min) {
+    if (vmm_order < 0 && S.bytes >= place_min && tl_no_placement_trial == 0) {
         int tries = 6;
         if (const char* e = std::getenv("MI_FFT_PLACE_CANDIDATES")) tries = std::max(1, std::min(8, atoi(e)));
         // one trial at a time per device (plans created concurrently -- decwrap's workers with a large --block-size-max -- would each

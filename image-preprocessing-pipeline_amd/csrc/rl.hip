@@ -692,7 +692,10 @@ static int rl_spatial_impl(int dev, void* stream, float* bl, const float* psf, c
         MI_TRY(edgetaper_async(s, bl, ratio.as<float>(), psf, nx, ny, nz, kx, ky, kz, keep_taper));
     }
     mi_rl_ctx* ctx = keep_ctx ? *keep_ctx : nullptr;
-    if (!ctx) MI_TRY(mi_rl_create(dev, stream, nx, ny, nz, psf, psf_inv, kx, ky, kz, MI_BOUNDARY_ZERO, opt->engine, &ctx));
+    if (!ctx) {
+        NoPlacementTrial as_they_come;   // (a handful of iterations per context: see fft_native.h)
+        MI_TRY(mi_rl_create(dev, stream, nx, ny, nz, psf, psf_inv, kx, ky, kz, MI_BOUNDARY_ZERO, opt->engine, &ctx));
+    }
     if (keep_ctx) *keep_ctx = ctx;
     if (reg_sched || !mi_rl_fuses(ctx)) {
         if (!ratio.p) MI_TRY(ratio.alloc(sizeof(float) * N));
@@ -752,6 +755,7 @@ static int rl_fft_impl(int dev, void* stream, float* bl, const float* psf, int n
     const int engine = opt->engine == MI_ENGINE_DIRECT ? MI_ENGINE_DIRECT : MI_ENGINE_FFT;
     if (!ctx) {
         MI_SPAN_BEGIN(sp3, "deconFFT: mi_rl_create (a new shape)");
+        NoPlacementTrial as_they_come;   // (a handful of iterations per context: see fft_native.h)
         // where the PSF's samples land on the circular grid: ifftshift(zero-pad-centre(psf)) on the grid opt->psf_grid names
         // (default: the FFT shape; see mi_rl_options)
         const int circ[3] = {MI_BOUNDARY_CIRCULAR, MI_BOUNDARY_CIRCULAR, MI_BOUNDARY_CIRCULAR};
@@ -875,7 +879,10 @@ extern "C" int mi_rl_fft_wiener(int dev, void* stream, float* bl, float* psf, in
     if (opt->stop_criterion > 0.0f) MI_TRY(host_norm(s, work_bl, NF, scratch.as<double>(), &delta_prev));  // decon.m:215
     mi_rl_ctx* ctx = nullptr;
     const int b[3] = {MI_BOUNDARY_CIRCULAR, MI_BOUNDARY_CIRCULAR, MI_BOUNDARY_CIRCULAR};
-    MI_TRY(rl_create(dev, stream, fx, fy, fz, psf, nullptr, kx, ky, kz, b, nullptr, MI_ENGINE_FFT, /*fixed_psf=*/false, &ctx));
+    {
+        NoPlacementTrial as_they_come;
+        MI_TRY(rl_create(dev, stream, fx, fy, fz, psf, nullptr, kx, ky, kz, b, nullptr, MI_ENGINE_FFT, /*fixed_psf=*/false, &ctx));
+    }
     struct Guard { mi_rl_ctx* c; hipStream_t s; ~Guard() { (void)hipStreamSynchronize(s); mi_rl_destroy(c); } } guard{ctx, s};
     FftEngine* fe = ctx->fft;
     MI_REQUIRE(fe->native, "deconFFT_Wiener: the hand-written FFT pipeline refused fft_shape [%d %d %d]", fx, fy, fz);

@@ -299,6 +299,12 @@ def main(argv=None):
     else:
         res_budget = res_share if (keep_resident and res_share <= free0 // 2) else 0
         bmax = max(1, (free0 - (3 << 30) - res_budget) // 4 // n_work_vols) // per_dev
+        # ... which is what fits, not what is fast: the workers form a pipeline (box read, upload, kernels, download) that fills and
+        # drains once per run, and the last blocks leave workers idle.  At least a dozen blocks per worker, blocks of 3e8 elements or
+        # more (smaller ones pay the pads twice over): the 17-GB probe takes 5.7 s with 3e8, 5.9 s with 1.5e8, 6.8 s with 6e8 and
+        # 17.6 s with the 1.2e9 the memory rule alone would allow (profiles/r05_decwrap_scale.txt)
+        n_workers_all = max(1, len(args.gpu_indices) * max(1, args.gpu_workers_per_gpu))
+        bmax = min(bmax, max(300_000_000, int(1.25 * sz * sy * sx) // (12 * n_workers_all)))
 
     import shutil
     import threading

@@ -1,5 +1,5 @@
 """decwrap on a volume that is larger than what its host-side buffers may hold: wall time, blocks, peak resident set.
-    python profiles/decwrap_scale_probe.py [nz ny nx] [block_size_max]
+    python profiles/decwrap_scale_probe.py [nz ny nx] [block_size_max | auto]     (auto: decwrap's own choice)
 Default: a 512 x 2048 x 2048 uint16 volume (4.3 GB) written as a memory-mapped *.npy under /tmp, deconFFT flavour, 6 iterations,
 blocks of at most 300 M elements (incl. pads), no whole-volume output copies (MI_DECWRAP_NPY=0): what is measured is the streaming
 pipeline -- box reads, device work, LZ4 bricks, slab-wise assembly + rescale."""
@@ -106,8 +106,8 @@ if os.environ.get("PROBE_SPANS"):
     timed(_D, "decon")
     timed(_D, "rescale_block")
 t0 = time.perf_counter()
-rc = decwrap.main(["-i", os.path.join(root, "vol.npy"), "-dxy", "0.422", "-dz", "1.0", "-ex", "488", "-em", "525", "--use-fft", "-it", "6",
-                   "--block-size-max", bmax, "--gpu-indices", "1", "--gpu-workers-per-gpu", nworkers])
+rc = decwrap.main(["-i", os.path.join(root, "vol.npy"), "-dxy", "0.422", "-dz", "1.0", "-ex", "488", "-em", "525", "--use-fft", "-it", "6"]
+                  + ([] if bmax == "auto" else ["--block-size-max", bmax]) + ["--gpu-indices", "1", "--gpu-workers-per-gpu", nworkers])
 dt = time.perf_counter() - t0
 stop.set()
 rss = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6
