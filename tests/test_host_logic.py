@@ -315,3 +315,44 @@ def test_evict_cores_from_two_workers_of_one_device():
     assert sorted(counts) == [0, 6]
     assert sorted(resident) == [7, 8]                       # the other device's cores stay
     assert sorted(written) == [1, 2, 3, 4, 6]               # 3 by the writer pool (waited for), 5 was complete, none twice
+
+
+def test_evict_cores_with_bricks_that_trail_behind_the_workers():
+    """MI_DECWRAP_BRICKS=trail: the brick of a resident core is a job of a one-thread pool that may not have begun, may be running, or
+    may have been cancelled when the core is evicted -- a cancelled or never-written brick is written by the eviction, a finished one
+    is left alone."""
+    import threading
+    import time
+    from concurrent.futures import ThreadPoolExecutor
+    from ipp_amd import decwrap
+    lock, evict_lock = threading.Lock(), threading.Lock()
+    resident = {n: object() for n in range(1, 5)}
+    resident_dev = {n: 1 for n in resident}
+    complete, written = set(), []
+
+    def trail(n, wait):                      # trail_brick: gives up when its core has left `resident`
+        time.sleep(wait)
+        with lock:
+            if n not in resident:
+                return False
+            complete.add(n)
+            written.append(("trail", n))
+        return True
+
+    def write_brick(n, core):
+        with lock:
+            assert n not in complete
+            complete.add(n)
+            written.append(("evict", n))
+
+    pool = ThreadPoolExecutor(1)
+    futures = {1: pool.submit(trail, 1, 0.0)}
+    futures[1].result()                                      # block 1: its brick was written behind the workers
+    futures[2] = pool.submit(trail, 2, 0.3)                  # block 2: being looked at by the writer while the eviction pops it
+    futures[3] = pool.submit(trail, 3, 0.0)                  # block 3: queued behind it
+    futures[4] = pool.submit(trail, 4, 0.0)
+    assert futures[4].cancel()                               # block 4: never begun (the blocks phase ended)
+    assert decwrap.evict_cores(1, resident, resident_dev, futures, lock, evict_lock, lambda n: n in complete, write_brick) == 4
+    pool.shutdown()
+    assert not resident and sorted(complete) == [1, 2, 3, 4]
+    assert ("trail", 1) in written and ("evict", 4) in written and len(written) == 4   # every brick exactly once
