@@ -201,8 +201,10 @@ def autosplit(stack_xyz, psf_size_xyz, filt: Filter, block_size_max: int, numit:
     if best is None:
         raise RuntimeError("autosplit: No block shape fits in memory. Try increasing block_size_max or reducing min_block.")
     core, shape = best
+    # (the reference's grid of the full-size block travels with it: process_block places the PSF by ITS parity, block_fft_shape)
     blk = Block(core[0], core[1], core[2], math.ceil(sx / core[0]), math.ceil(sy / core[1]), math.ceil(sz / core[2]),
-                pad[0], pad[1], pad[2], tuple(shape) if filt.use_fft else None)
+                pad[0], pad[1], pad[2], tuple(shape) if filt.use_fft else None,
+                tuple(next_fast_len([c + 2 * p for c, p in zip(core, pad)])) if filt.use_fft else None)
     blk.p1, blk.p2 = split_stack(stack_xyz, blk)
     return blk
 
