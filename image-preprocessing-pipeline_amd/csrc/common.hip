@@ -1,5 +1,6 @@
 // Error sink, device queries and the element-wise / data-movement kernels of the RL path.
 // All of these are pure HBM streaming kernels: 16 B per lane, grid-stride, >= 4 waves per SIMD.
+#include <algorithm>
 #include <map>
 #include <mutex>
 
@@ -300,22 +301,37 @@ namespace {
 // load_block (LsDeconv.m:817-904) on the device: dst (the padded block) <- the sub-box read from the volume, converted like
 // im2single (integer types: value / max of the type, a float32 division) and extended by padarray(..., 'symmetric')
 // (edge-inclusive mirror, repeated when the pad exceeds the box) where the padded block reaches beyond the volume
+// One work-group row per (y, z) row of the padded block -- its source row is found once, by the scalar unit -- and four samples per
+// lane along x (the first form divided a 64-bit index twice per sample: 1.04 ms for a 512 x 512 x 959 block, 1.5 GB of traffic).
 template <typename T>
 __global__ __launch_bounds__(kThreads) void k_load_block(const T* __restrict__ src, int sx, int sy, int sz, float* __restrict__ dst, int nx,
                                                           int ny, int nz, int bx, int by, int bz, float maxv) {
-    const size_t total = (size_t)nx * ny * nz;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int x = (int)(i % nx);
-        const size_t r = i / nx;
-        const int y = (int)(r % ny), z = (int)(r / ny);
-        auto mirror = [](int j, int n) {
-            const int p = 2 * n;
-            j %= p;
-            if (j < 0) j += p;
-            return j < n ? j : p - 1 - j;
-        };
-        const float v = (float)src[((size_t)mirror(z - bz, sz) * sy + mirror(y - by, sy)) * sx + mirror(x - bx, sx)];
-        dst[i] = maxv > 0.0f ? v / maxv : v;
+    auto mirror = [](int j, int n) {
+        const int p = 2 * n;
+        j %= p;
+        if (j < 0) j += p;
+        return j < n ? j : p - 1 - j;
+    };
+    const int y = blockIdx.y, z = blockIdx.z;
+    const T* srow = src + ((size_t)mirror(z - bz, sz) * sy + mirror(y - by, sy)) * sx;
+    float* drow = dst + ((size_t)z * ny + y) * nx;
+    const bool vec = (nx & 3) == 0 && ((uintptr_t)dst & 15) == 0;   // (every row of the padded block then starts on a 16-byte boundary)
+    for (int x0 = 4 * (blockIdx.x * kThreads + threadIdx.x); x0 < nx; x0 += 4 * kThreads * gridDim.x) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int x = min(x0 + e, nx - 1), j = x - bx;
+            // (inside the box -- nearly every sample -- the mirror is the identity: no division)
+            const float s = (float)srow[(unsigned)j < (unsigned)sx ? j : mirror(j, sx)];
+            v[e] = maxv > 0.0f ? s / maxv : s;
+        }
+        if (vec) {
+            *reinterpret_cast<float4*>(drow + x0) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (x0 + e < nx) drow[x0 + e] = v[e];
+        }
     }
 }
 }  // namespace
@@ -327,7 +343,8 @@ extern "C" int mi_load_block(int dev, void* stream, const void* src, int dtype, 
     MI_REQUIRE(sx > 0 && sy > 0 && sz > 0 && nx > 0 && ny > 0 && nz > 0, "load_block: empty box");
     MI_REQUIRE(bx >= 0 && by >= 0 && bz >= 0 && bx + sx <= nx && by + sy <= ny && bz + sz <= nz,
                "load_block: the box read from the volume must lie inside the padded block");
-    const dim3 grid(stream_grid((size_t)nx * ny * nz)), block(kThreads);
+    MI_REQUIRE(ny <= 65535 && nz <= 65535, "load_block: block of %d x %d rows (at most 65535 per axis)", ny, nz);
+    const dim3 grid((unsigned)std::min(64, (nx + 4 * kThreads - 1) / (4 * kThreads)), (unsigned)ny, (unsigned)nz), block(kThreads);
     hipStream_t s = as_stream(stream);
     switch (dtype) {
         case 1: hipLaunchKernelGGL(k_load_block<uint8_t>, grid, block, 0, s, (const uint8_t*)src, sx, sy, sz, dst, nx, ny, nz, bx, by, bz, 255.0f); break;
