@@ -212,32 +212,53 @@ __global__ __launch_bounds__(kThreads) void k_sumsq(const float* __restrict__ x,
 }
 
 // dst (fx,fy,fz) = zero-pad-centre(src (nx,ny,nz)) or the crop back; one thread per 1 dst element
+// (pad / crop: a work-group row per (y, z) row of the LARGER grid, four samples per lane; 16-byte accesses where both rows allow --
+//  the first forms divided a 64-bit index twice per sample)
 __global__ __launch_bounds__(kThreads) void k_pad_center(const float* __restrict__ src, int nx, int ny, int nz,
                                                           float* __restrict__ dst, int fx, int fy, int fz, int px, int py,
                                                           int pz) {
-    size_t total = (size_t)fx * fy * fz;
-    size_t tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = tid; i < total; i += stride) {
-        int x = (int)(i % fx);
-        size_t r = i / fx;
-        int y = (int)(r % fy), z = (int)(r / fy);
-        int sx = x - px, sy = y - py, sz = z - pz;
-        float v = 0.0f;
-        if (sx >= 0 && sx < nx && sy >= 0 && sy < ny && sz >= 0 && sz < nz) v = src[((size_t)sz * ny + sy) * nx + sx];
-        dst[i] = v;
+    const int y = blockIdx.y, z = blockIdx.z, sy = y - py, sz = z - pz;
+    const bool live = sy >= 0 && sy < ny && sz >= 0 && sz < nz;   // (scalar: a row of zeros otherwise)
+    const float* srow = src + ((size_t)(live ? sz : 0) * ny + (live ? sy : 0)) * nx;
+    float* drow = dst + ((size_t)z * fy + y) * fx;
+    const bool vec = (fx & 3) == 0 && ((uintptr_t)dst & 15) == 0;
+    for (int x0 = 4 * (blockIdx.x * kThreads + threadIdx.x); x0 < fx; x0 += 4 * kThreads * gridDim.x) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int sx = x0 + e - px;
+            const bool on = live && sx >= 0 && sx < nx;
+            const float s = srow[on ? sx : 0];
+            v[e] = on ? s : 0.0f;
+        }
+        if (vec) {
+            *reinterpret_cast<float4*>(drow + x0) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (x0 + e < fx) drow[x0 + e] = v[e];
+        }
     }
 }
 
 __global__ __launch_bounds__(kThreads) void k_crop_center(const float* __restrict__ src, int fx, int fy, int fz,
                                                            float* __restrict__ dst, int nx, int ny, int nz, int px, int py,
                                                            int pz) {
-    size_t total = (size_t)nx * ny * nz;
-    size_t tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = tid; i < total; i += stride) {
-        int x = (int)(i % nx);
-        size_t r = i / nx;
-        int y = (int)(r % ny), z = (int)(r / ny);
-        dst[i] = src[((size_t)(z + pz) * fy + (y + py)) * fx + (x + px)];
+    const int y = blockIdx.y, z = blockIdx.z;
+    const float* srow = src + ((size_t)(z + pz) * fy + (y + py)) * fx + px;
+    float* drow = dst + ((size_t)z * ny + y) * nx;
+    const bool vec = (nx & 3) == 0 && ((uintptr_t)dst & 15) == 0;
+    for (int x0 = 4 * (blockIdx.x * kThreads + threadIdx.x); x0 < nx; x0 += 4 * kThreads * gridDim.x) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = srow[min(x0 + e, nx - 1)];
+        if (vec) {
+            *reinterpret_cast<float4*>(drow + x0) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (x0 + e < nx) drow[x0 + e] = v[e];
+        }
     }
 }
 
@@ -395,8 +416,9 @@ extern "C" int mi_pad_center(int dev, void* stream, const float* src, int nx, in
     MI_REQUIRE(src && dst, "mi_pad_center: null pointer");
     MI_REQUIRE(nx > 0 && ny > 0 && nz > 0 && fx >= nx && fy >= ny && fz >= nz,
                "pad_block_to_fft_shape: bl [%d %d %d] is larger than FFT shape [%d %d %d], cannot pad", nx, ny, nz, fx, fy, fz);
-    hipLaunchKernelGGL(k_pad_center, dim3(stream_grid((size_t)fx * fy * fz)), dim3(kThreads), 0, as_stream(stream), src, nx, ny,
-                       nz, dst, fx, fy, fz, (fx - nx) / 2, (fy - ny) / 2, (fz - nz) / 2);
+    MI_REQUIRE(fy <= 65535 && fz <= 65535, "pad_block_to_fft_shape: FFT shape of %d x %d rows (at most 65535 per axis)", fy, fz);
+    hipLaunchKernelGGL(k_pad_center, dim3((unsigned)std::min(64, (fx + 4 * kThreads - 1) / (4 * kThreads)), (unsigned)fy, (unsigned)fz), dim3(kThreads), 0,
+                       as_stream(stream), src, nx, ny, nz, dst, fx, fy, fz, (fx - nx) / 2, (fy - ny) / 2, (fz - nz) / 2);
     return launch_check("k_pad_center");
 }
 
@@ -405,8 +427,9 @@ extern "C" int mi_crop_center(int dev, void* stream, const float* src, int fx, i
     MI_TRY(use_device(dev));
     MI_REQUIRE(src && dst, "mi_crop_center: null pointer");
     MI_REQUIRE(nx > 0 && ny > 0 && nz > 0 && fx >= nx && fy >= ny && fz >= nz, "unpad_block: invalid sizes");
-    hipLaunchKernelGGL(k_crop_center, dim3(stream_grid((size_t)nx * ny * nz)), dim3(kThreads), 0, as_stream(stream), src, fx, fy,
-                       fz, dst, nx, ny, nz, (fx - nx) / 2, (fy - ny) / 2, (fz - nz) / 2);
+    MI_REQUIRE(ny <= 65535 && nz <= 65535, "unpad_block: block of %d x %d rows (at most 65535 per axis)", ny, nz);
+    hipLaunchKernelGGL(k_crop_center, dim3((unsigned)std::min(64, (nx + 4 * kThreads - 1) / (4 * kThreads)), (unsigned)ny, (unsigned)nz), dim3(kThreads), 0,
+                       as_stream(stream), src, fx, fy, fz, dst, nx, ny, nz, (fx - nx) / 2, (fy - ny) / 2, (fz - nz) / 2);
     return launch_check("k_crop_center");
 }
 
