@@ -288,6 +288,28 @@ def test_decon_fft_psf_placed_by_a_named_grid(dev, engine, rocfft, monkeypatch):
         decon.decon(_t(vol, dev), psf, 1, 0.0, 0.0, 0, 1, False, None, False, psf_grid=big)
 
 
+@pytest.mark.parametrize("kshape", [(6, 5, 4), (4, 4, 6), (7, 6, 5)], ids=["even_z_x", "all_even", "even_y"])
+def test_decon_fft_named_grid_with_even_psf_extents(dev, kshape, monkeypatch):
+    """psf_grid with PSFs of even extents (no centre sample: ifftshift(zero-pad-centre) lands sample k / 2 at index 0 whatever the
+    parity of the grid, and the parity decides where the zero padding goes): device = oracle on the enlarged grid, for the
+    hand-written pipeline, rocFFT and the direct engine."""
+    from ipp_amd import decon
+    monkeypatch.setenv("MI_FFT_NATIVE_INFLATE", "100")
+    rng = np.random.default_rng(8)
+    psf = rng.random(kshape, dtype=np.float32)
+    psf /= psf.sum()
+    vol = R.bead_volume((24, 26, 28), seed=9, psf=R.gaussian_psf((5, 5, 5), (1.0, 1.0, 1.0)))
+    ref_grid, big = (29, 27, 25), (32, 32, 32)
+    want = R.decon_fft(vol, psf, big[::-1], 3, psf_grid_zyx=ref_grid[::-1])
+    for engine, rocfft in ((2, False), (2, True), (1, False)):
+        if rocfft:
+            monkeypatch.setenv("MI_FFT_ROCFFT", "1")
+        else:
+            monkeypatch.delenv("MI_FFT_ROCFFT", raising=False)
+        got = decon.decon(_t(vol, dev), psf, 3, 0.0, 0.0, 0, 1, True, big, False, engine=engine, psf_grid=ref_grid).cpu().numpy()
+        assert_close(got, want)
+
+
 def test_decon_plan_is_keyed_by_the_psf_grid(dev, monkeypatch):
     from ipp_amd import decon
     monkeypatch.setenv("MI_FFT_NATIVE_INFLATE", "100")
