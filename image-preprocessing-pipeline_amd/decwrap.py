@@ -916,6 +916,7 @@ def main(argv=None):
     # LsDeconv.m:286-296 removes the block cache once the output is complete.  Tens of gigabytes of bricks take seconds to unlink
     # (2.8 s of a 13-s run on the 17-GB probe): the folder is renamed -- from then on a rerun starts afresh, like after the
     # reference's rmdir -- and removed by a detached child; MI_DECWRAP_SYNC_CLEANUP=1 waits for it instead.
+    t_clean0 = time.perf_counter()
     doomed = cache.with_name(cache.name + f".removing.{os.getpid()}")
     try:
         os.replace(cache, doomed)
@@ -927,6 +928,8 @@ def main(argv=None):
                              start_new_session=True)
     except OSError:
         shutil.rmtree(cache, ignore_errors=True)
+    main.last_timing["cleanup_s"] = time.perf_counter() - t_clean0
+    main.last_timing["main_s"] = time.perf_counter() - t_main0
     log.info(f"wrote {out_dir} (scale {scal:g}, clip [{lo:.4g}, {hi:.4g}])")
     return 0
 

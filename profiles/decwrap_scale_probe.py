@@ -115,7 +115,9 @@ tm = getattr(decwrap.main, "last_timing", {})
 if tm:
     print(f"  blocks phase {tm['blocks_wall_s']:.1f} s (device work {tm['device_ms'] / 1e3:.1f} s = {tm['device_ms'] / 10 / max(tm['blocks_wall_s'], 1e-9):.0f} % "
           f"device-busy; box reads {tm['box_read_s']:.1f} s, D2H {tm['d2h_s']:.1f} s, waiting for a core buffer {tm['wait_buffer_s']:.1f} s, summed over "
-          f"the workers), assembly phase {tm.get('assembly_wall_s', 0.0):.1f} s; host time between the device events {tm.get('host_in_device_s', 0.0):.1f} s", flush=True)
+          f"the workers), assembly phase {tm.get('assembly_wall_s', 0.0):.1f} s; host time between the device events {tm.get('host_in_device_s', 0.0):.1f} s; "
+          f"cache folder handed to its remover in {tm.get('cleanup_s', 0.0):.2f} s, main() {tm.get('main_s', 0.0):.2f} s of the {dt:.2f} s the call took "
+          f"(the rest: its buffers being freed on return)", flush=True)
 nvox = float(np.prod(shape))
 print(f"{nworkers} workers per GPU; volume {shape[2]} x {shape[1]} x {shape[0]} uint16 = {nvox * 2 / 1e9:.1f} GB (generated in {t_gen:.0f} s), block-size-max {bmax}: rc {rc}, "
       f"{dt:.1f} s wall = {nvox / dt / 1e6:.0f} Mvoxel/s end to end (6 RL iterations, default filters), peak resident set {rss:.1f} GB "
