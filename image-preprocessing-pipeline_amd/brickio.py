@@ -188,12 +188,62 @@ def list_tiff_series(folder):
     return files
 
 
+_TIFF_DTYPES = {1: np.uint8, 2: np.uint16, 4: np.float32}   # include/mi_tiffio.h
+_TIFF_CODES = {np.dtype(v): k for k, v in _TIFF_DTYPES.items()}
+
+
+def _native():
+    """The library's TIFF reader / writer (include/mi_tiffio.h: strips of raw or deflate samples on all cores, no interpreter lock),
+    or None -- MI_TIFF_PILLOW=1, or the library is not built: Pillow then does everything, as it does for the files the native
+    reader does not take (tiles, LZW, BigTIFF, big-endian)."""
+    if os.environ.get("MI_TIFF_PILLOW"):
+        return None
+    try:
+        from . import capi
+        return capi.lib()
+    except (ImportError, OSError, AttributeError):
+        return None
+
+
+def tiff_info(path):
+    """(ny, nx), dtype (or None) and whether the native reader decodes the file; None when there is no native reader."""
+    lib = _native()
+    if lib is None:
+        return None
+    nx, ny, dt, fast = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    if lib.mi_tiff_info(os.fsencode(str(path)), C.byref(nx), C.byref(ny), C.byref(dt), C.byref(fast)) != 0:
+        return None
+    return (ny.value, nx.value), _TIFF_DTYPES.get(dt.value), bool(fast.value)
+
+
+def read_tiff_box(files, shape_yx, dtype, y0, y1, x0, x1, out=None, threads=0):
+    """``out[k] = slice files[k][y0:y1, x0:x1]`` through the native reader (every file must be one it decodes: ``tiff_info``)."""
+    from . import capi
+    lib = capi.lib()
+    n = len(files)
+    if out is None:
+        out = np.empty((n, y1 - y0, x1 - x0), dtype)
+    assert out.flags.c_contiguous and out.dtype == np.dtype(dtype) and out.shape == (n, y1 - y0, x1 - x0)
+    paths = (C.c_char_p * n)(*[os.fsencode(str(f)) for f in files])
+    capi.check(lib.mi_tiff_read_box(paths, n, int(shape_yx[1]), int(shape_yx[0]), _TIFF_CODES[np.dtype(dtype)], int(y0), int(y1), int(x0),
+                                    int(x1), out.ctypes.data, int(threads)))
+    return out
+
+
 def load_tiff_series(folder, z0=0, z1=None):
     """Slices ``[z0, z1)`` of a folder of 2-D grayscale TIFFs as one (Z, Y, X) array (uint8 / uint16 / float32)."""
-    Image = _pil()
     files = list_tiff_series(folder)[z0:z1]
     if not files:
         raise RuntimeError(f"no *.tif slices in {folder}")
+    info = tiff_info(files[0])
+    if info is not None and info[2]:
+        (ny, nx), dt, _ = info
+        try:
+            return read_tiff_box(files, (ny, nx), dt, 0, ny, 0, nx)
+        except Exception as e:          # a later file of another kind: the general reader decides what is wrong with the folder
+            if "differs from the first slice" in str(e):
+                raise ValueError(str(e)) from e
+    Image = _pil()
     first = np.asarray(Image.open(files[0]))
     if first.ndim != 2 or first.dtype not in (np.uint8, np.uint16, np.float32):
         raise TypeError(f"{files[0]}: 16-bit or 32bit float grayscale images supported (LsDeconv.m:1231), got {first.dtype} {first.shape}")
@@ -210,12 +260,23 @@ def load_tiff_series(folder, z0=0, z1=None):
 def save_tiff_series(folder, vol, first_index=1, compression="tiff_adobe_deflate"):
     """``img_%06d.tif`` per z slice, deflate-compressed; slices that already exist are left alone (LsDeconv.m:1120-1145).
     Returns the number of slices written."""
-    Image = _pil()
     folder = Path(folder)
     folder.mkdir(parents=True, exist_ok=True)
     vol = np.asarray(vol)
     if vol.ndim != 3 or vol.dtype not in (np.uint8, np.uint16, np.float32):
         raise TypeError("save_tiff_series: a 3-D uint8 / uint16 / float32 volume is expected")
+    lib = _native()
+    if lib is not None and compression in ("tiff_adobe_deflate", None):
+        # one slice per task on all cores, Adobe deflate at level 1 like save_bl_tif.cpp:343-346 (Pillow: 29 MB/s under the lock)
+        from . import capi
+        v = np.ascontiguousarray(vol)
+        n = v.shape[0]
+        paths = (C.c_char_p * n)(*[os.fsencode(str(folder / f"img_{first_index + k:06d}.tif")) for k in range(n)])
+        made = C.c_int(0)
+        capi.check(lib.mi_tiff_write_series(paths, n, v.ctypes.data, _TIFF_CODES[v.dtype], v.shape[2], v.shape[1],
+                                            0 if compression is None else 1, 1, 0, C.byref(made)))
+        return int(made.value)
+    Image = _pil()
     written = 0
     for k in range(vol.shape[0]):
         path = folder / f"img_{first_index + k:06d}.tif"

@@ -128,6 +128,11 @@ class LazyTiffVolume:
         self._folder, self._np, self._brickio = folder, np, brickio
         self._cache, self._lock = OrderedDict(), threading.Lock()
         self._budget = max(1, int(cache_bytes) // max(1, first[0].nbytes))
+        # slices the library's reader decodes (strips of raw / deflate samples: include/mi_tiffio.h) arrive sixteen at a time on all
+        # cores; one bulk read at a time -- the workers of a z slab ask for the same slices at the same moment
+        info = brickio.tiff_info(self.files[0])
+        self._fast = bool(info is not None and info[2] and info[0] == first.shape[1:] and info[1] == first.dtype)
+        self._bulk = threading.Lock()
 
     def _slice(self, z):
         with self._lock:
@@ -144,10 +149,30 @@ class LazyTiffVolume:
                 self._cache.popitem(last=False)
         return a
 
+    def _ensure(self, zs):
+        """the slices `zs` into the cache, decoded sixteen at a time by the library's reader"""
+        with self._bulk:
+            with self._lock:
+                missing = [z for z in zs if z not in self._cache]
+            for i in range(0, len(missing), 16):
+                part = missing[i:i + 16]
+                try:
+                    arr = self._brickio.read_tiff_box([self.files[z] for z in part], self.shape[1:], self.dtype, 0, self.shape[1], 0, self.shape[2])
+                except Exception:
+                    self._fast = False          # (a file of another kind further down the folder: slice by slice from here on)
+                    return
+                with self._lock:
+                    for j, z in enumerate(part):
+                        self._cache[z] = arr[j].copy() if len(part) > 1 and self._budget < 64 else arr[j]
+                    while len(self._cache) > self._budget:
+                        self._cache.popitem(last=False)
+
     def __getitem__(self, key):
         np = self._np
         kz, ky, kx = key
         zs = range(*kz.indices(self.shape[0]))
+        if self._fast and len(zs) > 1:
+            self._ensure(zs)
         out = None
         for i, z in enumerate(zs):
             a = self._slice(z)[ky, kx]

@@ -119,3 +119,85 @@ def test_parallel_chunks_round_trip_and_out_buffer(tmp_path):
     import pytest
     with pytest.raises(ValueError, match="too small"):
         brickio.load_lz4(tmp_path / "par.lz4", out=np.empty(16, np.uint8))
+
+
+# ------------------------------------------------------------------------------------------------ the library's TIFF reader / writer
+# (include/mi_tiffio.h, csrc/tiffio.hip: host code -- strips of raw or deflate samples, one slice per task on all cores; the checker
+#  is Pillow's libtiff, which reads what the library writes and writes what the library reads)
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.float32])
+@pytest.mark.parametrize("compression", ["tiff_adobe_deflate", None])
+def test_native_tiff_writer_is_read_by_libtiff(tmp_path, dtype, compression):
+    from PIL import Image
+    rng = np.random.default_rng(3)
+    vol = (rng.random((4, 301, 517)) * 200).astype(dtype)           # odd extents; 301 rows of 517 samples: one strip (uint8) or several
+    big = (rng.random((2, 1500, 1111)) * 60000).astype(dtype)       # several strips of ~1 MiB
+    for k, v in enumerate((vol, big)):
+        d = tmp_path / f"s{k}"
+        assert brickio.save_tiff_series(d, v, first_index=7, compression=compression) == v.shape[0]
+        files = brickio.list_tiff_series(d)
+        assert [f.name for f in files][:2] == ["img_000007.tif", "img_000008.tif"] and not list(d.glob("*.tmp"))
+        back = np.stack([np.asarray(Image.open(f)) for f in files])
+        assert back.dtype == np.dtype(dtype) and np.array_equal(back, v)
+        im = Image.open(files[0])
+        assert im.tag_v2[259] == (8 if compression else 1) and im.tag_v2[277] == 1 and im.tag_v2[262] == 1
+        assert brickio.save_tiff_series(d, v * 0, first_index=7, compression=compression) == 0     # existing slices are kept (LsDeconv.m:1120-1132)
+        assert np.array_equal(brickio.load_tiff_series(d), v)
+
+
+@pytest.mark.parametrize("compression,kwargs,fast", [("tiff_adobe_deflate", {}, True), ("tiff_deflate", {}, True), (None, {}, True),
+                                                     ("tiff_adobe_deflate", {"tiffinfo": {317: 2}}, True), ("tiff_lzw", {}, False)],
+                         ids=["adobe_deflate", "deflate_32946", "raw", "horizontal_predictor", "lzw_goes_to_pillow"])
+def test_native_tiff_reader_on_files_libtiff_wrote(tmp_path, compression, kwargs, fast):
+    from PIL import Image
+    rng = np.random.default_rng(4)
+    vol = (np.cumsum(rng.standard_normal((3, 700, 640)), axis=2) * 40 + 30000).clip(0, 65535).astype(np.uint16)
+    for k in range(3):
+        Image.fromarray(vol[k]).save(tmp_path / f"s{k:03d}.tif", format="TIFF", compression=compression, **kwargs)
+    files = brickio.list_tiff_series(tmp_path)
+    shape, dt, is_fast = brickio.tiff_info(files[0])
+    assert shape == (700, 640) and is_fast == fast and (dt == np.uint16 or not fast)
+    assert np.array_equal(brickio.load_tiff_series(tmp_path), vol)                 # (the LZW folder through Pillow)
+    assert np.array_equal(brickio.load_tiff_series(tmp_path, 1, 3), vol[1:3])
+    if fast:
+        for box in ((0, 700, 0, 640), (13, 14, 5, 6), (100, 650, 33, 600), (699, 700, 639, 640)):
+            got = brickio.read_tiff_box(files, (700, 640), np.uint16, *box, threads=3)
+            assert np.array_equal(got, vol[:, box[0]:box[1], box[2]:box[3]])
+        from ipp_amd import capi
+        with pytest.raises(capi.MiError, match="outside"):
+            brickio.read_tiff_box(files, (700, 640), np.uint16, 0, 701, 0, 640)
+        with pytest.raises(capi.MiError, match="differs from the first slice"):
+            brickio.read_tiff_box(files, (700, 641), np.uint16, 0, 700, 0, 640)
+
+
+def test_native_tiff_errors_and_the_zlib_route(tmp_path):
+    import os
+    import sys
+    (tmp_path / "junk.tif").write_bytes(b"not a tiff at all")
+    assert brickio.tiff_info(tmp_path / "junk.tif") is None and brickio.tiff_info(tmp_path / "missing.tif") is None
+    # a truncated file: the reader says which, the folder loader raises
+    d = tmp_path / "t"
+    vol = (np.arange(2 * 64 * 64).reshape(2, 64, 64) % 251).astype(np.uint8)
+    brickio.save_tiff_series(d, vol)
+    f = brickio.list_tiff_series(d)[1]
+    f.write_bytes(f.read_bytes()[:100])
+    with pytest.raises(Exception):
+        brickio.load_tiff_series(d)
+    # libdeflate is loaded at run time when the host has it; without it (MI_TIFF_ZLIB=1: a fresh process) zlib writes the same format
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); from ipp_amd import brickio, capi; "
+            "v = (np.arange(3 * 200 * 300).reshape(3, 200, 300) %% 1000).astype(np.uint16); "
+            "assert capi.lib().mi_tiff_codec() == b'zlib'; assert brickio.save_tiff_series(%r, v) == 3; "
+            "assert np.array_equal(brickio.load_tiff_series(%r), v)" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(tmp_path / "z"),
+                                                                        str(tmp_path / "z")))
+    subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, MI_TIFF_ZLIB="1"))
+    from PIL import Image
+    v = (np.arange(3 * 200 * 300).reshape(3, 200, 300) % 1000).astype(np.uint16)
+    assert np.array_equal(np.stack([np.asarray(Image.open(p)) for p in brickio.list_tiff_series(tmp_path / "z")]), v)
+    assert np.array_equal(brickio.load_tiff_series(tmp_path / "z"), v)              # ... and this process' codec reads it
+
+
+def test_pillow_route_still_works(tmp_path, monkeypatch):
+    monkeypatch.setenv("MI_TIFF_PILLOW", "1")
+    vol = (np.arange(2 * 40 * 50).reshape(2, 40, 50) % 777).astype(np.uint16)
+    assert brickio.tiff_info(tmp_path / "x.tif") is None
+    assert brickio.save_tiff_series(tmp_path / "p", vol) == 2
+    assert np.array_equal(brickio.load_tiff_series(tmp_path / "p"), vol)
