@@ -840,7 +840,9 @@ def main(argv=None):
     bits = 8 if scal <= 255 else 16
     tiff_out = not args.input.is_file() and bool(brickio.list_tiff_series(args.input))
     # whole-volume *.npy copies (float32 result, integer stack): always for *.npy inputs, for TIFF inputs only while they are small
-    want_npy = os.environ.get("MI_DECWRAP_NPY", "1" if (not tiff_out or sz * sy * sx <= (1 << 31)) else "0") == "1"
+    # (a TIFF folder of more than 512^3 voxels gets its slices and nothing else, like the reference: the float32 copy of a 4-GB stack
+    #  is 8.6 GB through the page cache)
+    want_npy = os.environ.get("MI_DECWRAP_NPY", "1" if (not tiff_out or sz * sy * sx <= (1 << 27)) else "0") == "1"
     npy_f = np.lib.format.open_memmap(out_dir / "deconvolved.npy", mode="w+", dtype=np.float32, shape=(sz, sy, sx)) if want_npy else None
     npy_i = (np.lib.format.open_memmap(out_dir / f"deconvolved_{bits}bit.npy", mode="w+", dtype=np.uint8 if bits == 8 else np.uint16,
                                        shape=(sz, sy, sx)) if want_npy else None)
