@@ -148,7 +148,7 @@ struct TiffInfo {
     }
     bool fast() const {
         return dtype() != 0 && !tiled && planar == 1 && (comp == 1 || comp == 8 || comp == 32946) &&
-               (predictor == 1 || (predictor == 2 && fmt == 1)) && photometric <= 1 && !off.empty() && off.size() == cnt.size() && rps > 0 &&
+               (predictor == 1 || (predictor == 2 && fmt == 1)) && photometric == 1 && !off.empty() && off.size() == cnt.size() && rps > 0 &&
                off.size() == (size_t)((ny + rps - 1) / rps);
     }
 };
