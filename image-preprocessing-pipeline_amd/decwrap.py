@@ -149,30 +149,48 @@ class LazyTiffVolume:
                 self._cache.popitem(last=False)
         return a
 
-    def _ensure(self, zs):
-        """the slices `zs` into the cache, decoded sixteen at a time by the library's reader"""
+    def _chunk(self, part):
+        """up to sixteen slices as arrays: from the cache, the others decoded together by the library's reader (and cached); None when
+        the reader does not take one of the files (slice by slice through Pillow from then on)"""
         with self._bulk:
             with self._lock:
-                missing = [z for z in zs if z not in self._cache]
-            for i in range(0, len(missing), 16):
-                part = missing[i:i + 16]
+                got = {z: self._cache.get(z) for z in part}
+            missing = [z for z in part if got[z] is None]
+            if missing:
                 try:
-                    arr = self._brickio.read_tiff_box([self.files[z] for z in part], self.shape[1:], self.dtype, 0, self.shape[1], 0, self.shape[2])
+                    arr = self._brickio.read_tiff_box([self.files[z] for z in missing], self.shape[1:], self.dtype, 0, self.shape[1], 0, self.shape[2])
                 except Exception:
-                    self._fast = False          # (a file of another kind further down the folder: slice by slice from here on)
-                    return
+                    self._fast = False
+                    return None
                 with self._lock:
-                    for j, z in enumerate(part):
-                        self._cache[z] = arr[j].copy() if len(part) > 1 and self._budget < 64 else arr[j]
+                    for j, z in enumerate(missing):
+                        got[z] = self._cache[z] = arr[j]
                     while len(self._cache) > self._budget:
                         self._cache.popitem(last=False)
+            else:
+                with self._lock:
+                    for z in part:
+                        self._cache.move_to_end(z)
+        return [got[z] for z in part]
 
     def __getitem__(self, key):
         np = self._np
         kz, ky, kx = key
-        zs = range(*kz.indices(self.shape[0]))
+        zs = list(range(*kz.indices(self.shape[0])))
         if self._fast and len(zs) > 1:
-            self._ensure(zs)
+            out, i = None, 0
+            while i < len(zs) and self._fast:
+                got = self._chunk(zs[i:i + 16])
+                if got is None:
+                    break
+                for j, a in enumerate(got):
+                    b = a[ky, kx]
+                    if out is None:
+                        out = np.empty((len(zs),) + b.shape, self.dtype)
+                    out[i + j] = b
+                i += len(got)
+            if out is not None and i == len(zs):
+                return out
         out = None
         for i, z in enumerate(zs):
             a = self._slice(z)[ky, kx]

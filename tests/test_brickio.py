@@ -93,6 +93,25 @@ def test_lazy_tiff_volume_reads_boxes(tmp_path):
     for box in [(slice(0, 9), slice(0, 20), slice(0, 23)), (slice(2, 5), slice(3, 17), slice(1, 8)), (slice(8, 9), slice(19, 20), slice(0, 23))]:
         assert np.array_equal(lazy[box], vol[box])
     assert len(lazy._cache) <= 3
+    # more slices than one bulk read of the library's reader takes (sixteen), a cache that holds a few of them, several threads at once
+    from concurrent.futures import ThreadPoolExecutor
+    big = (rng.random((45, 33, 40)) * 60000).astype(np.uint16)
+    brickio.save_tiff_series(tmp_path / "b", big)
+    for budget in (5, 100):
+        lazy = decwrap.LazyTiffVolume(tmp_path / "b", cache_bytes=budget * big[0].nbytes)
+        boxes = [(slice(0, 45), slice(0, 33), slice(0, 40)), (slice(3, 40), slice(5, 30), slice(7, 33)), (slice(17, 18), slice(0, 33), slice(0, 40)),
+                 (slice(10, 45), slice(32, 33), slice(39, 40))]
+        with ThreadPoolExecutor(4) as ex:
+            for box, got in zip(boxes, ex.map(lambda b: lazy[b], boxes)):
+                assert np.array_equal(got, big[box])
+        assert len(lazy._cache) <= budget and lazy._fast
+    # a folder the library's reader does not take (LZW): the same answers through Pillow
+    from PIL import Image
+    (tmp_path / "l").mkdir()
+    for k in range(20):
+        Image.fromarray(big[k]).save(tmp_path / "l" / f"s{k:03d}.tif", format="TIFF", compression="tiff_lzw")
+    lazy = decwrap.LazyTiffVolume(tmp_path / "l", cache_bytes=4 * big[0].nbytes)
+    assert not lazy._fast and np.array_equal(lazy[2:19, 1:30, 2:39], big[2:19, 1:30, 2:39])
 
 
 def test_parallel_chunks_round_trip_and_out_buffer(tmp_path):
