@@ -97,12 +97,30 @@ struct Unzip {
     }
 };
 
-int thread_count(int asked, int jobs) {
-    int n = asked > 0 ? asked : (int)std::thread::hardware_concurrency();
+// the cores this process may keep busy: its affinity mask capped by the cgroup CPU quota (a 16-CPU container on a 256-core host has
+// 256 cores in its mask; threads beyond the quota only get every thread of the group stopped until the next period)
+int host_cores() {
+    int n = (int)std::thread::hardware_concurrency();
     cpu_set_t set;
-    if (asked <= 0 && sched_getaffinity(0, sizeof set, &set) == 0) n = std::max(1, CPU_COUNT(&set));  // (a container's share, not the host's cores)
-    return std::max(1, std::min(n, jobs));
+    if (sched_getaffinity(0, sizeof set, &set) == 0) n = CPU_COUNT(&set);
+    n = std::max(1, n);
+    long long quota = -1, period = 0;
+    if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[32] = {0};
+        if (std::fscanf(f, "%31s %lld", q, &period) == 2 && std::strcmp(q, "max") != 0) quota = std::atoll(q);
+        std::fclose(f);
+    } else if (FILE* g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+        if (std::fscanf(g, "%lld", &quota) != 1) quota = -1;
+        std::fclose(g);
+        if (FILE* h = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+            if (std::fscanf(h, "%lld", &period) != 1) period = 0;
+            std::fclose(h);
+        }
+    }
+    if (quota > 0 && period > 0) n = (int)std::max<long long>(1, std::min<long long>(n, (quota + period - 1) / period));
+    return n;
 }
+int thread_count(int asked, int jobs) { return std::max(1, std::min(asked > 0 ? asked : host_cores(), jobs)); }
 
 // runs job(k, thread) for k < jobs on nt threads; the first error message wins
 template <class F>

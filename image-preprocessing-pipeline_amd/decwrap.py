@@ -221,6 +221,27 @@ def open_volume(path: Path):
     raise RuntimeError(f"no *.npy / *.tif slices in {path}")
 
 
+def host_cores():
+    """Host cores this process may keep busy: the affinity mask capped by the cgroup CPU quota (a container of 16 CPUs on a 256-core
+    host shows 256 in its mask; threads beyond the quota only make the kernel stop EVERY thread of the group -- the GPU workers too --
+    until the next period)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 4
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: t.split()),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", lambda t: (t.strip(), open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().strip()))):
+        try:
+            with open(path) as f:
+                quota, period = parse(f.read())
+            if quota not in ("max", "-1") and int(period) > 0:
+                n = max(1, min(n, -(-int(quota) // int(period))))
+            break
+        except (OSError, ValueError):
+            continue
+    return n
+
+
 def evict_cores(g, resident, resident_dev, brick_future, lock, evict_lock, brick_complete, write_brick):
     """The cores of device ``g`` leave ``resident`` (block -> core); a core whose brick is not complete is written first
     (``write_brick(n, core)``).  Safe with several workers per device that run out of memory together: evictions of one device take
@@ -357,10 +378,7 @@ def main(argv=None):
     # LZ4 runs as chunk jobs on one pool for the whole run (bricks are written -- and later read -- as 32-MiB chunks, which the
     # brick format allows: every chunk's sizes are in the header, save_lz4_mex.c:56-67): a single core compresses side by side
     # on every host core instead of on one, and the few writer threads only put the chunks into their file in order
-    try:
-        n_cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        n_cores = os.cpu_count() or 4
+    n_cores = host_cores()
     n_writers = max(2, min(4, n_cores // 4))
     # (the GPU workers, which launch the kernels, and the brick writers need cores of their own: with every core compressing, the
     # device sat idle half of the time)
