@@ -257,6 +257,26 @@ def load_tiff_series(folder, z0=0, z1=None):
     return vol
 
 
+def save_tiff_series_device(folder, vol, first_index=1):
+    """``save_tiff_series`` for a volume that lies in device memory (a contiguous uint8 / uint16 / float32 CUDA tensor (Z, Y, X)): the
+    slices are deflated on the device (``mi_tiff_write_series_device``), the host frames and writes them.  Existing slices are kept."""
+    import torch
+    from . import capi
+    if not (isinstance(vol, torch.Tensor) and vol.is_cuda and vol.dim() == 3 and vol.is_contiguous()):
+        raise ValueError("save_tiff_series_device: a contiguous 3-D device tensor is expected")
+    code = {torch.uint8: 1, torch.uint16: 2, torch.float32: 4}.get(vol.dtype)
+    if code is None:
+        raise TypeError("save_tiff_series_device: uint8 / uint16 / float32 samples")
+    folder = Path(folder)
+    folder.mkdir(parents=True, exist_ok=True)
+    n = int(vol.shape[0])
+    paths = (C.c_char_p * n)(*[os.fsencode(str(folder / f"img_{first_index + k:06d}.tif")) for k in range(n)])
+    made = C.c_int(0)
+    capi.check(capi.lib().mi_tiff_write_series_device(vol.device.index, capi.current_stream_ptr(vol.device), paths, n, vol.data_ptr(), code,
+                                                      int(vol.shape[2]), int(vol.shape[1]), 0, C.byref(made)))
+    return int(made.value)
+
+
 def save_tiff_series(folder, vol, first_index=1, compression="tiff_adobe_deflate"):
     """``img_%06d.tif`` per z slice, deflate-compressed; slices that already exist are left alone (LsDeconv.m:1120-1145).
     Returns the number of slices written."""

@@ -122,6 +122,7 @@ SIGNATURES = {
     "mi_tiff_info": (_i, [C.c_char_p, _ip, _ip, _ip, _ip]),
     "mi_tiff_read_box": (_i, [C.POINTER(C.c_char_p), _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i]),
     "mi_tiff_write_series": (_i, [C.POINTER(C.c_char_p), _i, _vp, _i, _i, _i, _i, _i, _i, _ip]),
+    "mi_tiff_write_series_device": (_i, [_i, _vp, C.POINTER(C.c_char_p), _i, _vp, _i, _i, _i, _i, _ip]),
     "mi_peer_link_create": (_i, [_i, _sz, C.POINTER(_vp), C.c_char_p, C.c_char_p]),
     "mi_peer_link_connect": (_i, [_vp, _i, C.c_char_p, C.c_char_p, _i]),
     "mi_peer_link_begin": (_i, [_vp, _vp, C.c_uint, _i]),

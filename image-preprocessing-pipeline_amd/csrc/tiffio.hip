@@ -313,35 +313,11 @@ bool write_all(int fd, const void* buf, size_t n) {
     return true;
 }
 
-// header | strips | directory.  Strips of ~1 MiB of rows: a reader that wants a few rows inflates a few strips.
-std::string write_slice(const char* path, const char* data, int nx, int ny, int dtype, int compression, Zip& zp, std::vector<unsigned char>& file) {
-    const size_t bps = (size_t)(dtype == 4 ? 4 : dtype), rowb = (size_t)nx * bps;
-    const uint32_t rps = (uint32_t)std::max<size_t>(1, std::min<size_t>((size_t)ny, ((size_t)1 << 20) / std::max<size_t>(1, rowb)));
-    const uint32_t ns = ((uint32_t)ny + rps - 1) / rps;
-    std::vector<uint32_t> off(ns), cnt(ns);
-    file.clear();
-    file.reserve((size_t)ny * rowb / (compression ? 2 : 1) + 4096);
-    file.resize(8);
-    for (uint32_t s = 0; s < ns; ++s) {
-        const uint32_t r0 = s * rps, r1 = std::min<uint32_t>((uint32_t)ny, r0 + rps);
-        const size_t n = (size_t)(r1 - r0) * rowb, at = file.size();
-        if (compression) {
-            const size_t cap = zp.bound(n);
-            file.resize(at + cap);
-            const size_t got = zp.pack(data + (size_t)r0 * rowb, n, file.data() + at, cap);
-            if (!got) return std::string(path) + ": deflate failed";
-            file.resize(at + got);
-            cnt[s] = (uint32_t)got;
-        } else {
-            file.insert(file.end(), reinterpret_cast<const unsigned char*>(data) + (size_t)r0 * rowb,
-                        reinterpret_cast<const unsigned char*>(data) + (size_t)r0 * rowb + n);
-            cnt[s] = (uint32_t)n;
-        }
-        off[s] = (uint32_t)at;
-        if (file.size() & 1) file.push_back(0);  // (word alignment of what follows)
-        if (file.size() > 0xfff00000ull) return std::string(path) + ": a slice of more than 4 GB needs BigTIFF";
-    }
-    // strip tables (when there is more than one strip), then the directory
+// strip tables (when there is more than one strip), directory, header; written under a temporary name and renamed
+std::string finish_file(const char* path, std::vector<unsigned char>& file, const std::vector<uint32_t>& off, const std::vector<uint32_t>& cnt, int nx,
+                        int ny, int dtype, int compression, uint32_t rps) {
+    const size_t bps = (size_t)(dtype == 4 ? 4 : dtype);
+    const uint32_t ns = (uint32_t)off.size();
     uint32_t off_tab = 0, cnt_tab = 0;
     if (ns > 1) {
         off_tab = (uint32_t)file.size();
@@ -370,6 +346,332 @@ std::string write_slice(const char* path, const char* data, int nx, int ny, int 
     if (rename(tmp.c_str(), path) != 0) { unlink(tmp.c_str()); return std::string(path) + ": " + std::strerror(errno); }
     return "";
 }
+
+// header | strips | directory.  Strips of ~1 MiB of rows: a reader that wants a few rows inflates a few strips.
+std::string write_slice(const char* path, const char* data, int nx, int ny, int dtype, int compression, Zip& zp, std::vector<unsigned char>& file) {
+    const size_t bps = (size_t)(dtype == 4 ? 4 : dtype), rowb = (size_t)nx * bps;
+    const uint32_t rps = (uint32_t)std::max<size_t>(1, std::min<size_t>((size_t)ny, ((size_t)1 << 20) / std::max<size_t>(1, rowb)));
+    const uint32_t ns = ((uint32_t)ny + rps - 1) / rps;
+    std::vector<uint32_t> off(ns), cnt(ns);
+    file.clear();
+    file.reserve((size_t)ny * rowb / (compression ? 2 : 1) + 4096);
+    file.resize(8);
+    for (uint32_t s = 0; s < ns; ++s) {
+        const uint32_t r0 = s * rps, r1 = std::min<uint32_t>((uint32_t)ny, r0 + rps);
+        const size_t n = (size_t)(r1 - r0) * rowb, at = file.size();
+        if (compression) {
+            const size_t cap = zp.bound(n);
+            file.resize(at + cap);
+            const size_t got = zp.pack(data + (size_t)r0 * rowb, n, file.data() + at, cap);
+            if (!got) return std::string(path) + ": deflate failed";
+            file.resize(at + got);
+            cnt[s] = (uint32_t)got;
+        } else {
+            file.insert(file.end(), reinterpret_cast<const unsigned char*>(data) + (size_t)r0 * rowb,
+                        reinterpret_cast<const unsigned char*>(data) + (size_t)r0 * rowb + n);
+            cnt[s] = (uint32_t)n;
+        }
+        off[s] = (uint32_t)at;
+        if (file.size() & 1) file.push_back(0);  // (word alignment of what follows)
+        if (file.size() > 0xfff00000ull) return std::string(path) + ": a slice of more than 4 GB needs BigTIFF";
+    }
+    return finish_file(path, file, off, cnt, nx, ny, dtype, compression, rps);
+}
+
+// ------------------------------------------------------------------------------------------------ deflate on the device
+// The writer above spends the host's cores on deflate: 2.7 GB/s on the 16 CPUs of a one-GPU container, while the slab it writes was
+// computed on the device in a fraction of that time.  mi_tiff_write_series_device compresses where the samples are: every strip
+// becomes ONE dynamic-Huffman deflate block without string matching -- microscope samples are noise on a smooth field: what deflate
+// saves on them at level 1 is the entropy coding, matches are rare -- in three steps:
+//   k_strip_hist    per strip: histogram of its bytes and the two sums of its Adler-32;
+//   host            per strip: length-limited Huffman code (15 bits) of the 256 literals + end-of-block, the block header
+//                   (RFC 1951 3.2.7: every code length sent plainly through the code-length code, no run symbols);
+//   k_strip_encode  per strip: a work-group walks over tiles of 8 KB; a lane takes 32 bytes, the lanes' bit counts are scanned, every
+//                   lane ORs its codes into the tile's bit image in LDS, the image goes out as whole words.
+// The host then only frames the streams (zlib header, header bits, Adler-32) and writes the files.  Any inflater reads the result;
+// a strip whose bytes are all equally likely costs 130 bytes more than stored.
+struct HuffCode {
+    uint8_t len[288];
+    uint16_t code[288];  // bit-reversed: emitted least significant bit first
+};
+
+// code lengths of at most `maxlen` bits for the symbols with f[i] > 0 (n <= 288, at least two of them used)
+void huff_lengths(const uint32_t* f, int n, int maxlen, uint8_t* len) {
+    struct Node { uint64_t w; int l, r; };
+    std::vector<Node> nodes;
+    std::vector<int> used;
+    for (int i = 0; i < n; ++i) {
+        len[i] = 0;
+        if (f[i]) used.push_back(i);
+    }
+    if (used.size() == 1) { len[used[0]] = 1; return; }
+    std::sort(used.begin(), used.end(), [&](int a, int b) { return f[a] != f[b] ? f[a] < f[b] : a < b; });
+    const int m = (int)used.size();
+    nodes.reserve(2 * (size_t)m);
+    for (int i = 0; i < m; ++i) nodes.push_back({f[used[(size_t)i]], -1, -1});
+    // two queues: leaves in ascending order, internal nodes in creation order (ascending too)
+    int a = 0, b = m;
+    auto take = [&]() {
+        int pick;
+        if (a < m && (b >= (int)nodes.size() || nodes[(size_t)a].w <= nodes[(size_t)b].w)) pick = a++;
+        else pick = b++;
+        return pick;
+    };
+    for (int k = 0; k < m - 1; ++k) {
+        const int x = take(), y = take();
+        nodes.push_back({nodes[(size_t)x].w + nodes[(size_t)y].w, x, y});
+    }
+    std::vector<int> depth(nodes.size(), 0);
+    for (int i = (int)nodes.size() - 1; i >= m; --i) {
+        depth[(size_t)nodes[(size_t)i].l] = depth[(size_t)i] + 1;
+        depth[(size_t)nodes[(size_t)i].r] = depth[(size_t)i] + 1;
+    }
+    // the number of codes of every length, limited to maxlen (the usual Kraft repair: a code moves down from the deepest occupied
+    // level above, its two children take the place), then handed out by frequency: the rarest symbols get the longest codes
+    int cnt[64] = {0};
+    for (int i = 0; i < m; ++i) cnt[std::min(depth[(size_t)i], 63)]++;
+    for (int i = maxlen + 1; i < 64; ++i) { cnt[maxlen] += cnt[i]; cnt[i] = 0; }
+    uint64_t total = 0;
+    for (int i = maxlen; i > 0; --i) total += (uint64_t)cnt[i] << (maxlen - i);
+    while (total != (1ull << maxlen)) {
+        cnt[maxlen]--;
+        for (int i = maxlen - 1; i > 0; --i)
+            if (cnt[i]) { cnt[i]--; cnt[i + 1] += 2; break; }
+        total--;
+    }
+    int at = 0;
+    for (int l = maxlen; l > 0; --l)
+        for (int c = 0; c < cnt[l]; ++c) len[used[(size_t)at++]] = (uint8_t)l;
+}
+
+// canonical codes of RFC 1951 3.2.2, each reversed over its own length
+void huff_codes(const uint8_t* len, int n, uint16_t* code) {
+    int bl[16] = {0}, next[16] = {0};
+    for (int i = 0; i < n; ++i) bl[len[i]]++;
+    bl[0] = 0;
+    int c = 0;
+    for (int b = 1; b <= 15; ++b) { c = (c + bl[b - 1]) << 1; next[b] = c; }
+    for (int i = 0; i < n; ++i) {
+        code[i] = 0;
+        if (!len[i]) continue;
+        const int v = next[len[i]]++;
+        int r = 0;
+        for (int k = 0; k < len[i]; ++k) r |= ((v >> k) & 1) << (len[i] - 1 - k);
+        code[i] = (uint16_t)r;
+    }
+}
+
+struct BitWriter {
+    std::vector<unsigned char> b;
+    uint64_t n = 0;
+    void put(uint32_t v, int bits) {
+        for (int k = 0; k < bits; ++k, ++n) {
+            if ((n & 7) == 0) b.push_back(0);
+            b.back() |= (unsigned char)(((v >> k) & 1u) << (n & 7));
+        }
+    }
+};
+
+// the block header of one strip (bits before the first literal) and the table the encode kernel takes: [s] = len << 16 | code
+void strip_code(const uint32_t* hist, BitWriter& hdr, uint32_t* table /* 257 */, uint64_t* payload_bits) {
+    uint32_t f[257];
+    for (int i = 0; i < 256; ++i) f[i] = hist[i];
+    f[256] = 1;  // end of block
+    HuffCode lit;
+    huff_lengths(f, 257, 15, lit.len);
+    huff_codes(lit.len, 257, lit.code);
+    // 257 literal / length code lengths + two distance codes of one bit each (none is ever used; two, because some inflaters want a
+    // complete distance code) sent one by one through the code-length code
+    uint8_t all[259];
+    for (int i = 0; i < 257; ++i) all[i] = lit.len[i];
+    all[257] = all[258] = 1;
+    uint32_t cf[19] = {0};
+    for (uint8_t v : all) cf[v]++;
+    uint8_t cl[19];
+    uint16_t cc[19];
+    huff_lengths(cf, 19, 7, cl);
+    huff_codes(cl, 19, cc);
+    hdr.put(1, 1);   // BFINAL
+    hdr.put(2, 2);   // BTYPE: dynamic Huffman
+    hdr.put(0, 5);   // HLIT: 257 codes
+    hdr.put(1, 5);   // HDIST: 2 codes
+    hdr.put(15, 4);  // HCLEN: all 19 code-length code lengths
+    static const int order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+    for (int i = 0; i < 19; ++i) hdr.put(cl[order[i]], 3);
+    for (uint8_t v : all) hdr.put(cc[v], cl[v]);
+    uint64_t bits = lit.len[256];
+    for (int i = 0; i < 256; ++i) bits += (uint64_t)hist[i] * lit.len[i];
+    *payload_bits = bits;
+    for (int i = 0; i < 257; ++i) table[i] = (uint32_t)lit.len[i] << 16 | lit.code[i];
+}
+
+constexpr int kEncThreads = 256, kEncBytes = 32, kTileBytes = kEncThreads * kEncBytes;   // 8 KB of samples per tile
+constexpr int kTileWords = kTileBytes * 15 / 8 / 4 + 4;                                     // its bit image at 15 bits per byte
+
+struct StripGeom {
+    size_t slice_bytes, rowb;
+    uint32_t rps, ns, ny;
+    __host__ __device__ size_t start(uint32_t strip) const { return (size_t)(strip / ns) * slice_bytes + (size_t)(strip % ns) * rps * rowb; }
+    __host__ __device__ uint32_t bytes(uint32_t strip) const {
+        const uint32_t r0 = (strip % ns) * rps, r1 = r0 + rps < ny ? r0 + rps : ny;
+        return (uint32_t)((r1 - r0) * rowb);
+    }
+};
+
+__global__ __launch_bounds__(256) void k_strip_hist(const unsigned char* __restrict__ base, StripGeom g, uint32_t* __restrict__ hist,
+                                                     unsigned long long* __restrict__ sums) {
+    __shared__ uint32_t h[4][256];
+    __shared__ unsigned long long ssum[2];
+    const uint32_t strip = blockIdx.x, n = g.bytes(strip), tid = threadIdx.x;
+    const unsigned char* p = base + g.start(strip);
+    for (int i = tid; i < 1024; i += 256) (&h[0][0])[i] = 0;
+    if (tid < 2) ssum[tid] = 0;
+    __syncthreads();
+    unsigned long long s1 = 0, s2 = 0;
+    uint32_t* mine = h[tid & 3];
+    const bool aligned = (reinterpret_cast<uintptr_t>(p) & 15) == 0;
+    for (uint32_t i = tid * 16; i < n; i += 256 * 16) {
+        unsigned char b[16];
+        const uint32_t m = n - i < 16 ? n - i : 16;
+        if (aligned && m == 16) {
+            *reinterpret_cast<uint4*>(b) = *reinterpret_cast<const uint4*>(p + i);
+        } else {
+#pragma unroll
+            for (uint32_t k = 0; k < 16; ++k) b[k] = k < m ? p[i + k] : 0;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < 16; ++k) {
+            if (k < m) {
+                atomicAdd(&mine[b[k]], 1u);
+                s1 += b[k];
+                s2 += (unsigned long long)(n - (i + k)) * b[k];
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        s1 += __shfl_down(s1, o, 64);
+        s2 += __shfl_down(s2, o, 64);
+    }
+    if ((tid & 63) == 0) {
+        atomicAdd(&ssum[0], s1);
+        atomicAdd(&ssum[1], s2);
+    }
+    __syncthreads();
+    hist[(size_t)strip * 256 + tid] = h[0][tid] + h[1][tid] + h[2][tid] + h[3][tid];
+    if (tid < 2) sums[(size_t)strip * 2 + tid] = ssum[tid];
+}
+
+// the literals of a strip as bits, from bit hbits[strip] of its output slot on (the host puts the block header in front)
+__global__ __launch_bounds__(kEncThreads) void k_strip_encode(const unsigned char* __restrict__ base, StripGeom g, const uint32_t* __restrict__ tables,
+                                                              const uint32_t* __restrict__ hbits, unsigned char* __restrict__ out, size_t cap) {
+    __shared__ uint32_t tab[257];
+    __shared__ uint32_t img[kTileWords];
+    __shared__ uint32_t wsum[kEncThreads / 64];
+    const uint32_t strip = blockIdx.x, n = g.bytes(strip), tid = threadIdx.x;
+    const unsigned char* p = base + g.start(strip);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(out + (size_t)strip * cap);
+    for (int i = tid; i < 257; i += kEncThreads) tab[i] = tables[(size_t)strip * 257 + i];
+    for (int i = tid; i < kTileWords; i += kEncThreads) img[i] = 0;
+    __syncthreads();
+    unsigned long long bitpos = hbits[strip];   // where the next tile's first bit goes in the strip's stream
+    const bool aligned = (reinterpret_cast<uintptr_t>(p) & 15) == 0;
+    for (uint32_t t0 = 0; t0 < n; t0 += kTileBytes) {
+        const uint32_t j0 = t0 + tid * kEncBytes;
+        const uint32_t cnt = j0 < n ? (n - j0 < (uint32_t)kEncBytes ? n - j0 : (uint32_t)kEncBytes) : 0;
+        unsigned char b[kEncBytes];
+        if (aligned && cnt == (uint32_t)kEncBytes) {
+            *reinterpret_cast<uint4*>(b) = *reinterpret_cast<const uint4*>(p + j0);
+            *reinterpret_cast<uint4*>(b + 16) = *reinterpret_cast<const uint4*>(p + j0 + 16);
+        } else {
+#pragma unroll
+            for (uint32_t k = 0; k < (uint32_t)kEncBytes; ++k) b[k] = k < cnt ? p[j0 + k] : 0;
+        }
+        const bool last = cnt > 0 && j0 + cnt == n;   // this lane appends the end-of-block symbol
+        uint32_t mybits = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < (uint32_t)kEncBytes; ++k) mybits += k < cnt ? tab[b[k]] >> 16 : 0;
+        if (last) mybits += tab[256] >> 16;
+        // exclusive scan of the lanes' bit counts over the work-group
+        uint32_t incl = mybits;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t v = __shfl_up(incl, o, 64);
+            if ((int)(tid & 63) >= o) incl += v;
+        }
+        if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+        __syncthreads();
+        uint32_t before = 0, tile_bits = 0;
+        for (int w = 0; w < kEncThreads / 64; ++w) {
+            if (w < (int)(tid >> 6)) before += wsum[w];
+            tile_bits += wsum[w];
+        }
+        const uint32_t rel = (uint32_t)(bitpos & 31);   // the image's word 0 is the stream's word bitpos / 32
+        uint32_t pos = rel + before + incl - mybits;
+        uint32_t w = pos >> 5;
+        unsigned long long acc = 0;
+        uint32_t nb = pos & 31;
+#pragma unroll
+        for (uint32_t k = 0; k < (uint32_t)kEncBytes; ++k) {
+            if (k < cnt) {
+                const uint32_t c = tab[b[k]];
+                acc |= (unsigned long long)(c & 0xffffu) << nb;
+                nb += c >> 16;
+                if (nb >= 32) {
+                    atomicOr(&img[w++], (uint32_t)acc);
+                    acc >>= 32;
+                    nb -= 32;
+                }
+            }
+        }
+        if (last) {
+            const uint32_t c = tab[256];
+            acc |= (unsigned long long)(c & 0xffffu) << nb;
+            nb += c >> 16;
+            if (nb >= 32) {
+                atomicOr(&img[w++], (uint32_t)acc);
+                acc >>= 32;
+                nb -= 32;
+            }
+        }
+        if (nb > 0) atomicOr(&img[w], (uint32_t)acc);
+        __syncthreads();
+        // whole words out; the last, partial one stays behind as word 0 of the next tile's image
+        const uint32_t end = rel + tile_bits, full = end >> 5;
+        uint32_t* d = dst + (bitpos >> 5);
+        for (uint32_t i = tid; i < full; i += kEncThreads) d[i] = img[i];
+        const uint32_t carry = img[full];
+        __syncthreads();
+        for (uint32_t i = tid; i <= full; i += kEncThreads) img[i] = 0;
+        __syncthreads();
+        if (tid == 0) img[0] = carry;
+        bitpos += tile_bits;
+        __syncthreads();
+    }
+    if (tid == 0) dst[bitpos >> 5] = img[0];
+}
+
+// frames the device's streams into files: per strip zlib header | block header bits OR literals | Adler-32
+struct PackedStrip {
+    std::vector<unsigned char> hdr;  // the block header, its last byte partly filled
+    uint64_t hbits = 0, payload_bits = 0;
+    uint32_t adler = 1;
+};
+
+struct DevMem {
+    void* p = nullptr;
+    ~DevMem() { if (p) (void)hipFree(p); }
+    int alloc(size_t n) {
+        if (hipMalloc(&p, n) != hipSuccess) { p = nullptr; (void)hipGetLastError(); return fail(MI_ERR_NOMEM, "mi_tiff_write_series_device: hipMalloc(%zu bytes) failed", n); }
+        return MI_OK;
+    }
+};
+struct PinMem {
+    void* p = nullptr;
+    ~PinMem() { if (p) (void)hipHostFree(p); }
+    int alloc(size_t n) {
+        if (hipHostMalloc(&p, n, hipHostMallocDefault) != hipSuccess) { p = nullptr; (void)hipGetLastError(); return fail(MI_ERR_NOMEM, "mi_tiff_write_series_device: %zu bytes of pinned memory", n); }
+        return MI_OK;
+    }
+};
 
 }  // namespace
 
@@ -431,4 +733,112 @@ extern "C" int mi_tiff_write_series(const char* const* paths, int nz, const void
     for (Zip* z : zp) delete z;
     if (written) *written = made.load();
     return rc;
+}
+
+extern "C" int mi_tiff_write_series_device(int dev, void* stream, const char* const* paths, int nz, const void* vol, int dtype, int nx, int ny,
+                                           int n_threads, int* written) {
+    MI_TRY(mi::use_device(dev));
+    MI_REQUIRE(paths && vol, "mi_tiff_write_series_device: null pointer");
+    MI_REQUIRE(nz >= 0 && nx > 0 && ny > 0 && (dtype == 1 || dtype == 2 || dtype == 4), "mi_tiff_write_series_device: invalid extents or sample type");
+    if (written) *written = 0;
+    if (nz == 0) return MI_OK;
+    hipStream_t s = mi::as_stream(stream);
+    StripGeom g;
+    const size_t bps = (size_t)(dtype == 4 ? 4 : dtype);
+    g.rowb = (size_t)nx * bps;
+    g.slice_bytes = g.rowb * (size_t)ny;
+    g.ny = (uint32_t)ny;
+    g.rps = (uint32_t)std::max<size_t>(1, std::min<size_t>((size_t)ny, ((size_t)1 << 20) / std::max<size_t>(1, g.rowb)));
+    g.ns = ((uint32_t)ny + g.rps - 1) / g.rps;
+    MI_REQUIRE(g.slice_bytes < 0xfff00000ull, "mi_tiff_write_series_device: a slice of more than 4 GB needs BigTIFF");
+    const size_t strip_max = (size_t)g.rps * g.rowb;
+    const size_t cap = ((strip_max + strip_max / 32 + 4096) + 15) & ~(size_t)15;   // a strip's stream: at most ~8.01 bits per byte + header
+    // slices per batch: ~512 MB of samples at a time
+    const int per_batch = (int)std::max<size_t>(1, std::min<size_t>((size_t)nz, ((size_t)512 << 20) / std::max<size_t>(1, g.slice_bytes)));
+    const size_t bs = (size_t)per_batch * g.ns;   // strips per batch
+    DevMem d_hist, d_sums, d_tab, d_hbits, d_out;
+    PinMem h_hist, h_sums, h_tab, h_hbits, h_out;
+    MI_TRY(d_hist.alloc(bs * 256 * 4));
+    MI_TRY(d_sums.alloc(bs * 16));
+    MI_TRY(d_tab.alloc(bs * 257 * 4));
+    MI_TRY(d_hbits.alloc(bs * 4));
+    MI_TRY(d_out.alloc(bs * cap));
+    MI_TRY(h_hist.alloc(bs * 256 * 4));
+    MI_TRY(h_sums.alloc(bs * 16));
+    MI_TRY(h_tab.alloc(bs * 257 * 4));
+    MI_TRY(h_hbits.alloc(bs * 4));
+    MI_TRY(h_out.alloc(bs * cap));
+    const int nt = thread_count(n_threads, std::max(1, (int)bs));
+    std::atomic<int> made{0};
+    std::vector<PackedStrip> ps(bs);
+    std::vector<std::vector<unsigned char>> filebuf((size_t)nt);
+    for (int z0 = 0; z0 < nz; z0 += per_batch) {
+        const int nb = std::min(per_batch, nz - z0);
+        const uint32_t nstrip = (uint32_t)nb * g.ns;
+        const unsigned char* base = static_cast<const unsigned char*>(vol) + (size_t)z0 * g.slice_bytes;
+        hipLaunchKernelGGL(k_strip_hist, dim3(nstrip), dim3(256), 0, s, base, g, static_cast<uint32_t*>(d_hist.p), static_cast<unsigned long long*>(d_sums.p));
+        MI_TRY(mi::launch_check("k_strip_hist"));
+        MI_HIP(hipMemcpyAsync(h_hist.p, d_hist.p, (size_t)nstrip * 256 * 4, hipMemcpyDeviceToHost, s));
+        MI_HIP(hipMemcpyAsync(h_sums.p, d_sums.p, (size_t)nstrip * 16, hipMemcpyDeviceToHost, s));
+        MI_HIP(hipStreamSynchronize(s));
+        // codes and block headers, a strip per task
+        MI_TRY(run_jobs((int)nstrip, nt, [&](int k, int) -> std::string {
+            PackedStrip& q = ps[(size_t)k];
+            BitWriter bw;
+            strip_code(static_cast<const uint32_t*>(h_hist.p) + (size_t)k * 256, bw, static_cast<uint32_t*>(h_tab.p) + (size_t)k * 257, &q.payload_bits);
+            q.hbits = bw.n;
+            q.hdr.swap(bw.b);
+            static_cast<uint32_t*>(h_hbits.p)[k] = (uint32_t)q.hbits;
+            const unsigned long long* sm = static_cast<const unsigned long long*>(h_sums.p) + (size_t)k * 2;
+            const uint64_t n = g.bytes((uint32_t)k);
+            q.adler = (uint32_t)(((n + sm[1]) % 65521ull) << 16 | ((1ull + sm[0]) % 65521ull));
+            if ((q.hbits + q.payload_bits + 7) / 8 + 8 > cap) return "a strip's deflate stream does not fit its slot";
+            return "";
+        }));
+        MI_HIP(hipMemcpyAsync(d_tab.p, h_tab.p, (size_t)nstrip * 257 * 4, hipMemcpyHostToDevice, s));
+        MI_HIP(hipMemcpyAsync(d_hbits.p, h_hbits.p, (size_t)nstrip * 4, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_strip_encode, dim3(nstrip), dim3(kEncThreads), 0, s, base, g, static_cast<const uint32_t*>(d_tab.p),
+                           static_cast<const uint32_t*>(d_hbits.p), static_cast<unsigned char*>(d_out.p), cap);
+        MI_TRY(mi::launch_check("k_strip_encode"));
+        MI_HIP(hipMemcpyAsync(h_out.p, d_out.p, (size_t)nstrip * cap, hipMemcpyDeviceToHost, s));
+        MI_HIP(hipStreamSynchronize(s));
+        // files, a slice per task
+        MI_TRY(run_jobs(nb, std::min(nt, nb), [&](int k, int t) -> std::string {
+            const char* path = paths[z0 + k];
+            struct stat st;
+            if (stat(path, &st) == 0) return "";   // LsDeconv.m:1120-1132: slices that exist are kept
+            std::vector<unsigned char>& file = filebuf[(size_t)t];
+            file.clear();
+            file.resize(8);
+            std::vector<uint32_t> off(g.ns), cnt(g.ns);
+            for (uint32_t si = 0; si < g.ns; ++si) {
+                const size_t strip = (size_t)k * g.ns + si;
+                const PackedStrip& q = ps[strip];
+                const size_t nbytes = (size_t)((q.hbits + q.payload_bits + 7) / 8), at = file.size();
+                file.resize(at + 2 + nbytes + 4);
+                unsigned char* w = file.data() + at;
+                w[0] = 0x78;
+                w[1] = 0x01;
+                std::memcpy(w + 2, static_cast<const unsigned char*>(h_out.p) + strip * cap, nbytes);
+                // (the kernel wrote from the word of its first bit on, zeros below that bit; the header's whole bytes are assigned, its
+                //  last, partly filled byte is OR-ed onto the first literals)
+                for (size_t i = 0; i < q.hdr.size(); ++i) {
+                    if (i < q.hbits / 8) w[2 + i] = q.hdr[i];
+                    else w[2 + i] |= q.hdr[i];
+                }
+                w[2 + nbytes + 0] = (unsigned char)(q.adler >> 24);
+                w[2 + nbytes + 1] = (unsigned char)(q.adler >> 16);
+                w[2 + nbytes + 2] = (unsigned char)(q.adler >> 8);
+                w[2 + nbytes + 3] = (unsigned char)q.adler;
+                off[si] = (uint32_t)at;
+                cnt[si] = (uint32_t)(2 + nbytes + 4);
+                if (file.size() & 1) file.push_back(0);
+            }
+            std::string e = finish_file(path, file, off, cnt, nx, ny, dtype, 1, g.rps);
+            if (e.empty()) made.fetch_add(1);
+            return e;
+        }));
+    }
+    if (written) *written = made.load();
+    return MI_OK;
 }

@@ -37,6 +37,13 @@ int mi_tiff_read_box(const char* const* paths, int n, int nx, int ny, int dtype,
 int mi_tiff_write_series(const char* const* paths, int nz, const void* vol, int dtype, int nx, int ny, int compression, int level,
                          int n_threads, int* written);
 
+/* The same files from a volume that lies in DEVICE memory (vol [nz][ny][nx] on device `dev`), deflated there: every strip is one
+ * dynamic-Huffman block without string matching (csrc/tiffio.hip: histogram kernel, codes built on the host, encode kernel), the host
+ * only frames the streams and writes the files.  Adobe deflate always; readable by any inflater.  Enqueues on `stream` and
+ * synchronises it.  No counterpart in the reference (save_bl_tif.cpp compresses on the host's cores). */
+int mi_tiff_write_series_device(int dev, void* stream, const char* const* paths, int nz, const void* vol, int dtype, int nx, int ny,
+                                int n_threads, int* written);
+
 /* Name of the deflate implementation in use: "libdeflate" when libdeflate.so.0 could be loaded, else "zlib". */
 const char* mi_tiff_codec(void);
 
