@@ -315,7 +315,7 @@ bool write_all(int fd, const void* buf, size_t n) {
 
 // strip tables (when there is more than one strip), directory, header; written under a temporary name and renamed
 std::string finish_file(const char* path, std::vector<unsigned char>& file, const std::vector<uint32_t>& off, const std::vector<uint32_t>& cnt, int nx,
-                        int ny, int dtype, int compression, uint32_t rps) {
+                        int ny, int dtype, int compression, uint32_t rps, int predictor = 1) {
     const size_t bps = (size_t)(dtype == 4 ? 4 : dtype);
     const uint32_t ns = (uint32_t)off.size();
     uint32_t off_tab = 0, cnt_tab = 0;
@@ -330,10 +330,14 @@ std::string finish_file(const char* path, std::vector<unsigned char>& file, cons
     const Ent ents[] = {
         {256, 4, 1, (uint32_t)nx}, {257, 4, 1, (uint32_t)ny}, {258, 3, 1, (uint32_t)(8 * bps)}, {259, 3, 1, compression ? 8u : 1u},
         {262, 3, 1, 1u}, {273, 4, ns, ns > 1 ? off_tab : off[0]}, {277, 3, 1, 1u}, {278, 4, 1, rps}, {279, 4, ns, ns > 1 ? cnt_tab : cnt[0]},
-        {284, 3, 1, 1u}, {339, 3, 1, dtype == 4 ? 3u : 1u},
+        {284, 3, 1, 1u}, {317, 3, 1, (uint32_t)predictor}, {339, 3, 1, dtype == 4 ? 3u : 1u},
     };
-    put16(file, (uint32_t)(sizeof ents / sizeof ents[0]));
-    for (const Ent& e : ents) { put16(file, e.tag); put16(file, e.type); put32(file, e.count); put32(file, e.value); }
+    const int n_ent = (int)(sizeof ents / sizeof ents[0]) - (predictor == 1 ? 1 : 0);   // (the tag is left out when nothing is predicted)
+    put16(file, (uint32_t)n_ent);
+    for (const Ent& e : ents) {
+        if (e.tag == 317 && predictor == 1) continue;
+        put16(file, e.tag); put16(file, e.type); put32(file, e.count); put32(file, e.value);
+    }
     put32(file, 0);  // no further directory
     file[0] = 'I'; file[1] = 'I'; file[2] = 42; file[3] = 0;
     file[4] = (unsigned char)(ifd & 255); file[5] = (unsigned char)(ifd >> 8 & 255); file[6] = (unsigned char)(ifd >> 16 & 255); file[7] = (unsigned char)(ifd >> 24);
@@ -510,7 +514,7 @@ constexpr int kTileWords = kTileBytes * 15 / 8 / 4 + 4;                         
 
 struct StripGeom {
     size_t slice_bytes, rowb;
-    uint32_t rps, ns, ny;
+    uint32_t rps, ns, ny, bps;
     __host__ __device__ size_t start(uint32_t strip) const { return (size_t)(strip / ns) * slice_bytes + (size_t)(strip % ns) * rps * rowb; }
     __host__ __device__ uint32_t bytes(uint32_t strip) const {
         const uint32_t r0 = (strip % ns) * rps, r1 = r0 + rps < ny ? r0 + rps : ny;
@@ -518,47 +522,85 @@ struct StripGeom {
     }
 };
 
-__global__ __launch_bounds__(256) void k_strip_hist(const unsigned char* __restrict__ base, StripGeom g, uint32_t* __restrict__ hist,
+// NB bytes of a strip from byte j0 on (cnt of them exist), as stored: plain, or -- pred -- every 8 / 16-bit sample minus its left
+// neighbour in the row (TIFF 6.0 section 14, horizontal differencing; the first sample of a row stays).  j0 is a multiple of NB.
+template <int NB>
+__device__ __forceinline__ void strip_bytes(const unsigned char* __restrict__ p, uint32_t j0, uint32_t cnt, bool aligned, uint32_t bps, uint32_t rowb,
+                                            bool pred, unsigned char (&b)[NB]) {
+    if (aligned && cnt == (uint32_t)NB) {
+#pragma unroll
+        for (int q = 0; q < NB / 16; ++q) *reinterpret_cast<uint4*>(b + 16 * q) = *reinterpret_cast<const uint4*>(p + j0 + 16 * q);
+    } else {
+#pragma unroll
+        for (uint32_t k = 0; k < (uint32_t)NB; ++k) b[k] = k < cnt ? p[j0 + k] : 0;
+    }
+    if (!pred || cnt == 0) return;
+    uint32_t col = j0 % rowb;   // byte column of the chunk's first byte
+    if (bps == 2) {
+        uint32_t prev = col ? (uint32_t)p[j0 - 2] | (uint32_t)p[j0 - 1] << 8 : 0;
+#pragma unroll
+        for (uint32_t k = 0; k < (uint32_t)NB / 2; ++k) {
+            const uint32_t v = (uint32_t)b[2 * k] | (uint32_t)b[2 * k + 1] << 8;
+            const uint32_t d = (v - (col ? prev : 0u)) & 0xffffu;
+            b[2 * k] = (unsigned char)(d & 255);
+            b[2 * k + 1] = (unsigned char)(d >> 8);
+            prev = v;
+            col += 2;
+            if (col >= rowb) col -= rowb;
+        }
+    } else {
+        uint32_t prev = col ? (uint32_t)p[j0 - 1] : 0;
+#pragma unroll
+        for (uint32_t k = 0; k < (uint32_t)NB; ++k) {
+            const uint32_t v = b[k];
+            b[k] = (unsigned char)((v - (col ? prev : 0u)) & 255);
+            prev = v;
+            col += 1;
+            if (col >= rowb) col -= rowb;
+        }
+    }
+}
+
+// per strip: hist[strip][v][256] and sums[strip][v][2] for v = 0 (the bytes as they are) and -- `both` -- v = 1 (horizontally differenced)
+__global__ __launch_bounds__(256) void k_strip_hist(const unsigned char* __restrict__ base, StripGeom g, int both, uint32_t* __restrict__ hist,
                                                      unsigned long long* __restrict__ sums) {
-    __shared__ uint32_t h[4][256];
-    __shared__ unsigned long long ssum[2];
+    __shared__ uint32_t h[2][2][256];
+    __shared__ unsigned long long ssum[4];
     const uint32_t strip = blockIdx.x, n = g.bytes(strip), tid = threadIdx.x;
     const unsigned char* p = base + g.start(strip);
-    for (int i = tid; i < 1024; i += 256) (&h[0][0])[i] = 0;
-    if (tid < 2) ssum[tid] = 0;
+    for (int i = tid; i < 1024; i += 256) (&h[0][0][0])[i] = 0;
+    if (tid < 4) ssum[tid] = 0;
     __syncthreads();
-    unsigned long long s1 = 0, s2 = 0;
-    uint32_t* mine = h[tid & 3];
     const bool aligned = (reinterpret_cast<uintptr_t>(p) & 15) == 0;
-    for (uint32_t i = tid * 16; i < n; i += 256 * 16) {
-        unsigned char b[16];
-        const uint32_t m = n - i < 16 ? n - i : 16;
-        if (aligned && m == 16) {
-            *reinterpret_cast<uint4*>(b) = *reinterpret_cast<const uint4*>(p + i);
-        } else {
+    for (int v = 0; v < (both ? 2 : 1); ++v) {
+        unsigned long long s1 = 0, s2 = 0;
+        uint32_t* mine = h[v][tid & 1];
+        for (uint32_t i = tid * 16; i < n; i += 256 * 16) {
+            unsigned char b[16];
+            const uint32_t m = n - i < 16 ? n - i : 16;
+            strip_bytes<16>(p, i, m, aligned, g.bps, (uint32_t)g.rowb, v == 1, b);
 #pragma unroll
-            for (uint32_t k = 0; k < 16; ++k) b[k] = k < m ? p[i + k] : 0;
-        }
-#pragma unroll
-        for (uint32_t k = 0; k < 16; ++k) {
-            if (k < m) {
-                atomicAdd(&mine[b[k]], 1u);
-                s1 += b[k];
-                s2 += (unsigned long long)(n - (i + k)) * b[k];
+            for (uint32_t k = 0; k < 16; ++k) {
+                if (k < m) {
+                    atomicAdd(&mine[b[k]], 1u);
+                    s1 += b[k];
+                    s2 += (unsigned long long)(n - (i + k)) * b[k];
+                }
             }
         }
-    }
-    for (int o = 32; o > 0; o >>= 1) {
-        s1 += __shfl_down(s1, o, 64);
-        s2 += __shfl_down(s2, o, 64);
-    }
-    if ((tid & 63) == 0) {
-        atomicAdd(&ssum[0], s1);
-        atomicAdd(&ssum[1], s2);
+        for (int o = 32; o > 0; o >>= 1) {
+            s1 += __shfl_down(s1, o, 64);
+            s2 += __shfl_down(s2, o, 64);
+        }
+        if ((tid & 63) == 0) {
+            atomicAdd(&ssum[2 * v], s1);
+            atomicAdd(&ssum[2 * v + 1], s2);
+        }
     }
     __syncthreads();
-    hist[(size_t)strip * 256 + tid] = h[0][tid] + h[1][tid] + h[2][tid] + h[3][tid];
-    if (tid < 2) sums[(size_t)strip * 2 + tid] = ssum[tid];
+    hist[(size_t)strip * 512 + tid] = h[0][0][tid] + h[0][1][tid];
+    hist[(size_t)strip * 512 + 256 + tid] = h[1][0][tid] + h[1][1][tid];
+    if (tid < 4) sums[(size_t)strip * 4 + tid] = ssum[tid];
 }
 
 // the literals of a strip as bits, from bit hbits[strip] of its output slot on (the host puts the block header in front)
@@ -573,19 +615,14 @@ __global__ __launch_bounds__(kEncThreads) void k_strip_encode(const unsigned cha
     for (int i = tid; i < 257; i += kEncThreads) tab[i] = tables[(size_t)strip * 257 + i];
     for (int i = tid; i < kTileWords; i += kEncThreads) img[i] = 0;
     __syncthreads();
-    unsigned long long bitpos = hbits[strip];   // where the next tile's first bit goes in the strip's stream
+    const bool pred = (hbits[strip] >> 31) != 0;                    // (top bit: the strip is stored horizontally differenced)
+    unsigned long long bitpos = hbits[strip] & 0x7fffffffu;          // where the next tile's first bit goes in the strip's stream
     const bool aligned = (reinterpret_cast<uintptr_t>(p) & 15) == 0;
     for (uint32_t t0 = 0; t0 < n; t0 += kTileBytes) {
         const uint32_t j0 = t0 + tid * kEncBytes;
         const uint32_t cnt = j0 < n ? (n - j0 < (uint32_t)kEncBytes ? n - j0 : (uint32_t)kEncBytes) : 0;
         unsigned char b[kEncBytes];
-        if (aligned && cnt == (uint32_t)kEncBytes) {
-            *reinterpret_cast<uint4*>(b) = *reinterpret_cast<const uint4*>(p + j0);
-            *reinterpret_cast<uint4*>(b + 16) = *reinterpret_cast<const uint4*>(p + j0 + 16);
-        } else {
-#pragma unroll
-            for (uint32_t k = 0; k < (uint32_t)kEncBytes; ++k) b[k] = k < cnt ? p[j0 + k] : 0;
-        }
+        strip_bytes<kEncBytes>(p, j0 < n ? j0 : 0, cnt, aligned, g.bps, (uint32_t)g.rowb, pred, b);
         const bool last = cnt > 0 && j0 + cnt == n;   // this lane appends the end-of-block symbol
         uint32_t mybits = 0;
 #pragma unroll
@@ -748,6 +785,7 @@ extern "C" int mi_tiff_write_series_device(int dev, void* stream, const char* co
     g.rowb = (size_t)nx * bps;
     g.slice_bytes = g.rowb * (size_t)ny;
     g.ny = (uint32_t)ny;
+    g.bps = (uint32_t)bps;
     g.rps = (uint32_t)std::max<size_t>(1, std::min<size_t>((size_t)ny, ((size_t)1 << 20) / std::max<size_t>(1, g.rowb)));
     g.ns = ((uint32_t)ny + g.rps - 1) / g.rps;
     MI_REQUIRE(g.slice_bytes < 0xfff00000ull, "mi_tiff_write_series_device: a slice of more than 4 GB needs BigTIFF");
@@ -758,41 +796,67 @@ extern "C" int mi_tiff_write_series_device(int dev, void* stream, const char* co
     const size_t bs = (size_t)per_batch * g.ns;   // strips per batch
     DevMem d_hist, d_sums, d_tab, d_hbits, d_out;
     PinMem h_hist, h_sums, h_tab, h_hbits, h_out;
-    MI_TRY(d_hist.alloc(bs * 256 * 4));
-    MI_TRY(d_sums.alloc(bs * 16));
+    MI_TRY(d_hist.alloc(bs * 512 * 4));
+    MI_TRY(d_sums.alloc(bs * 32));
     MI_TRY(d_tab.alloc(bs * 257 * 4));
     MI_TRY(d_hbits.alloc(bs * 4));
     MI_TRY(d_out.alloc(bs * cap));
-    MI_TRY(h_hist.alloc(bs * 256 * 4));
-    MI_TRY(h_sums.alloc(bs * 16));
+    MI_TRY(h_hist.alloc(bs * 512 * 4));
+    MI_TRY(h_sums.alloc(bs * 32));
     MI_TRY(h_tab.alloc(bs * 257 * 4));
     MI_TRY(h_hbits.alloc(bs * 4));
     MI_TRY(h_out.alloc(bs * cap));
     const int nt = thread_count(n_threads, std::max(1, (int)bs));
     std::atomic<int> made{0};
     std::vector<PackedStrip> ps(bs);
+    std::vector<int> pred_of;
     std::vector<std::vector<unsigned char>> filebuf((size_t)nt);
     for (int z0 = 0; z0 < nz; z0 += per_batch) {
         const int nb = std::min(per_batch, nz - z0);
         const uint32_t nstrip = (uint32_t)nb * g.ns;
         const unsigned char* base = static_cast<const unsigned char*>(vol) + (size_t)z0 * g.slice_bytes;
-        hipLaunchKernelGGL(k_strip_hist, dim3(nstrip), dim3(256), 0, s, base, g, static_cast<uint32_t*>(d_hist.p), static_cast<unsigned long long*>(d_sums.p));
+        // integer samples: the strips are also counted horizontally differenced (TIFF predictor 2); a slice is stored that way when
+        // that makes it smaller -- smooth content: entropy coding without string matching then beats deflate level 1, noise: never
+        const int both = dtype != 4 ? 1 : 0;
+        hipLaunchKernelGGL(k_strip_hist, dim3(nstrip), dim3(256), 0, s, base, g, both, static_cast<uint32_t*>(d_hist.p),
+                           static_cast<unsigned long long*>(d_sums.p));
         MI_TRY(mi::launch_check("k_strip_hist"));
-        MI_HIP(hipMemcpyAsync(h_hist.p, d_hist.p, (size_t)nstrip * 256 * 4, hipMemcpyDeviceToHost, s));
-        MI_HIP(hipMemcpyAsync(h_sums.p, d_sums.p, (size_t)nstrip * 16, hipMemcpyDeviceToHost, s));
+        MI_HIP(hipMemcpyAsync(h_hist.p, d_hist.p, (size_t)nstrip * 512 * 4, hipMemcpyDeviceToHost, s));
+        MI_HIP(hipMemcpyAsync(h_sums.p, d_sums.p, (size_t)nstrip * 32, hipMemcpyDeviceToHost, s));
         MI_HIP(hipStreamSynchronize(s));
-        // codes and block headers, a strip per task
-        MI_TRY(run_jobs((int)nstrip, nt, [&](int k, int) -> std::string {
-            PackedStrip& q = ps[(size_t)k];
-            BitWriter bw;
-            strip_code(static_cast<const uint32_t*>(h_hist.p) + (size_t)k * 256, bw, static_cast<uint32_t*>(h_tab.p) + (size_t)k * 257, &q.payload_bits);
-            q.hbits = bw.n;
-            q.hdr.swap(bw.b);
-            static_cast<uint32_t*>(h_hbits.p)[k] = (uint32_t)q.hbits;
-            const unsigned long long* sm = static_cast<const unsigned long long*>(h_sums.p) + (size_t)k * 2;
-            const uint64_t n = g.bytes((uint32_t)k);
-            q.adler = (uint32_t)(((n + sm[1]) % 65521ull) << 16 | ((1ull + sm[0]) % 65521ull));
-            if ((q.hbits + q.payload_bits + 7) / 8 + 8 > cap) return "a strip's deflate stream does not fit its slot";
+        // codes and block headers, a slice per task (its strips share the choice of the predictor)
+        pred_of.assign((size_t)nb, 0);
+        MI_TRY(run_jobs(nb, std::min(nt, nb), [&](int k, int) -> std::string {
+            std::vector<uint32_t> tab2((size_t)g.ns * 257);
+            std::vector<PackedStrip> alt(g.ns);
+            uint64_t bits[2] = {0, 0};
+            for (int v = 0; v < (both ? 2 : 1); ++v) {
+                for (uint32_t si = 0; si < g.ns; ++si) {
+                    const size_t strip = (size_t)k * g.ns + si;
+                    PackedStrip& q = v ? alt[si] : ps[strip];
+                    BitWriter bw;
+                    strip_code(static_cast<const uint32_t*>(h_hist.p) + strip * 512 + (size_t)v * 256, bw,
+                               v ? tab2.data() + (size_t)si * 257 : static_cast<uint32_t*>(h_tab.p) + strip * 257, &q.payload_bits);
+                    q.hbits = bw.n;
+                    q.hdr.swap(bw.b);
+                    const unsigned long long* sm = static_cast<const unsigned long long*>(h_sums.p) + strip * 4 + (size_t)v * 2;
+                    const uint64_t n = g.bytes((uint32_t)strip);
+                    q.adler = (uint32_t)(((n + sm[1]) % 65521ull) << 16 | ((1ull + sm[0]) % 65521ull));
+                    bits[v] += q.hbits + q.payload_bits;
+                }
+            }
+            const bool use_pred = both && bits[1] < bits[0];
+            pred_of[(size_t)k] = use_pred ? 1 : 0;
+            for (uint32_t si = 0; si < g.ns; ++si) {
+                const size_t strip = (size_t)k * g.ns + si;
+                if (use_pred) {
+                    ps[strip] = std::move(alt[si]);
+                    std::memcpy(static_cast<uint32_t*>(h_tab.p) + strip * 257, tab2.data() + (size_t)si * 257, 257 * 4);
+                }
+                const PackedStrip& q = ps[strip];
+                static_cast<uint32_t*>(h_hbits.p)[strip] = (uint32_t)q.hbits | (use_pred ? 0x80000000u : 0u);
+                if ((q.hbits + q.payload_bits + 7) / 8 + 8 > cap) return "a strip's deflate stream does not fit its slot";
+            }
             return "";
         }));
         MI_HIP(hipMemcpyAsync(d_tab.p, h_tab.p, (size_t)nstrip * 257 * 4, hipMemcpyHostToDevice, s));
@@ -834,7 +898,7 @@ extern "C" int mi_tiff_write_series_device(int dev, void* stream, const char* co
                 cnt[si] = (uint32_t)(2 + nbytes + 4);
                 if (file.size() & 1) file.push_back(0);
             }
-            std::string e = finish_file(path, file, off, cnt, nx, ny, dtype, 1, g.rps);
+            std::string e = finish_file(path, file, off, cnt, nx, ny, dtype, 1, g.rps, pred_of[(size_t)k] ? 2 : 1);
             if (e.empty()) made.fetch_add(1);
             return e;
         }));
