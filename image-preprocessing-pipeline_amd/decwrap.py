@@ -607,7 +607,11 @@ def main(argv=None):
             log.debug(f"assembly buffers not prepared ahead: {e}")
 
     prep_thread = None
-    if int_input and int(args.start_block) == 1:
+    # (not for a TIFF folder whose slices are going to be deflated on the device: that slab lives there)
+    tiff_in = not args.input.is_file() and bool(brickio.list_tiff_series(args.input))
+    slab_on_device = (tiff_in and os.environ.get("MI_DECWRAP_TIFF_DEVICE", "1") != "0" and
+                      os.environ.get("MI_DECWRAP_NPY", "1" if sz * sy * sx <= (1 << 27) else "0") != "1")
+    if int_input and int(args.start_block) == 1 and not slab_on_device:
         prep_thread = threading.Thread(target=prepare_assembly, daemon=True)
         prep_thread.start()
 
@@ -914,9 +918,20 @@ def main(argv=None):
         z1, z2 = int(block.p1[ids[0] - 1][2]), int(block.p2[ids[0] - 1][2])
         if tiff_out and all((out_dir / f"img_{z:06d}.tif").exists() for z in range(z1, z2 + 1)) and not want_npy:
             continue                                                                       # resume: this slab's slices exist (:1037-1054)
-        if slab_buf is None:
+        # TIFF slices and nothing else to write: the integer slab is put together ON THE DEVICE and its slices are deflated there
+        # (brickio.save_tiff_series_device: 14-18 GB/s from device memory to files where the host's cores deflate 2.2 GB/s,
+        # profiles/r05_tiff_device.txt); MI_DECWRAP_TIFF_DEVICE=0, or no room for the slab: through the host as before
+        d_slab = None
+        if tiff_out and npy_i is None and npy_f is None and os.environ.get("MI_DECWRAP_TIFF_DEVICE", "1") != "0":
+            need = (z2 - z1 + 1) * sy * sx * (1 if bits == 8 else 2)
+            if torch.cuda.mem_get_info(dev)[0] > need + (4 << 30):
+                try:
+                    d_slab = torch.empty((z2 - z1 + 1, sy, sx), dtype=torch.uint8 if bits == 8 else torch.uint16, device=dev)
+                except torch.cuda.OutOfMemoryError:
+                    d_slab = None
+        if d_slab is None and slab_buf is None:
             slab_buf = np.empty((int(block.z), sy, sx), out_dtype)
-        slab = slab_buf[:z2 - z1 + 1]
+        slab = slab_buf[:z2 - z1 + 1] if d_slab is None else None
         with ThreadPoolExecutor(max_workers=2) as readers, ThreadPoolExecutor(max_workers=2) as copiers:
             # bricks are read ahead of the device; the integer cores are copied into the slab behind it
             placed = [None, None]
@@ -949,17 +964,30 @@ def main(argv=None):
                     if host is not None:
                         d_core = host[:size].view(shape).to(dev, non_blocking=True)          # (the pinned tensor itself: a true async copy)
                     q = D.rescale_block(d_core, scal, args.signal_amp, lo, hi)
-                    qh.copy_(q, non_blocking=True)
+                    if d_slab is None:
+                        qh.copy_(q, non_blocking=True)
                     ev = torch.cuda.Event()
                     ev.record()
                 ev.synchronize()
                 del d_core
                 if host is not None:
                     stage_free.put(host)
+                if d_slab is not None:
+                    with torch.cuda.device(dev):
+                        d_slab[box] = q.to(dev)                                                # (the integer core into its box of the device slab)
+                    del q
+                    continue
                 placed[k & 1] = copiers.submit(slab.__setitem__, box, qh.numpy())
             for fu in placed:
                 if fu is not None:
                     fu.result()
+        if d_slab is not None:
+            with torch.cuda.device(dev):
+                if args.flip:
+                    d_slab = d_slab.flip(1).contiguous()                                   # R = flip(R, 2): the y axis (LsDeconv.m:1097-1099)
+                n_tif += brickio.save_tiff_series_device(out_dir, d_slab, first_index=z1)  # img_%06d.tif, existing slices kept
+            del d_slab
+            continue
         if args.flip:
             slab = np.ascontiguousarray(slab[:, ::-1])                                     # R = flip(R, 2): the y axis (LsDeconv.m:1097-1099)
         if npy_i is not None:

@@ -290,6 +290,34 @@ def test_decwrap_tiff_folder_cache_and_resume(dev, tmp_path):
     assert np.array_equal(np.load(out / "deconvolved.npy"), ref)
 
 
+def test_decwrap_tiff_slices_from_the_device_slab(dev, tmp_path, monkeypatch):
+    """A TIFF folder that gets its slices and nothing else (MI_DECWRAP_NPY=0: what every stack of more than 512^3 voxels gets): the
+    integer slab is assembled on the device and its slices are deflated there (mi_tiff_write_series_device) -- the same stack as
+    through the host (MI_DECWRAP_TIFF_DEVICE=0), with and without --flip, read back by libtiff."""
+    from PIL import Image
+    from ipp_amd import brickio, decwrap
+    rng = np.random.default_rng(21)
+    vol16 = (rng.random((20, 70, 90)) * 3000 + 200).astype(np.uint16)
+    monkeypatch.setenv("MI_DECWRAP_NPY", "0")
+    stacks = {}
+    for name, env, extra in (("device", {}, []), ("host", {"MI_DECWRAP_TIFF_DEVICE": "0"}, []), ("device_flip", {}, ["--flip"]),
+                             ("host_flip", {"MI_DECWRAP_TIFF_DEVICE": "0"}, ["--flip"])):
+        monkeypatch.delenv("MI_DECWRAP_TIFF_DEVICE", raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        src = tmp_path / name
+        brickio.save_tiff_series(src, vol16)
+        assert decwrap.main(["-i", str(src), "-dxy", "0.422", "-dz", "1.0", "-ex", "488", "-em", "525", "-it", "2", "--gaussian-sigma", "0", "0", "0",
+                             "--block-size-max", "60000", "--gpu-indices", "1", "--use-fft"] + extra) == 0
+        out = src / ("deconvolved_flipped_upside_down" if extra else "deconvolved")
+        files = brickio.list_tiff_series(out)
+        assert len(files) == 20 and not (out / "deconvolved.npy").exists() and not (out / "cache").exists()
+        stacks[name] = np.stack([np.asarray(Image.open(f)) for f in files])
+        assert stacks[name].dtype == np.uint16 and np.array_equal(brickio.load_tiff_series(out), stacks[name])
+    assert np.array_equal(stacks["device"], stacks["host"]) and np.array_equal(stacks["device_flip"], stacks["host_flip"])
+    assert np.array_equal(stacks["device_flip"], stacks["device"][:, ::-1]) and int(stacks["device"].max()) > 0
+
+
 def test_decwrap_flip_and_destripe_options(dev, tmp_path):
     """--flip writes into deconvolved_flipped_upside_down with every slice mirrored along y (LsDeconv.m:91-94, 1097-1099);
     --destripe-sigma runs filter_subband_3d_z after the deconvolution of a block (LsDeconv.m:934-936)."""
