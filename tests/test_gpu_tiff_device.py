@@ -88,3 +88,31 @@ def test_device_writer_against_the_host_writer_sizes(dev, tmp_path):
     brickio.save_tiff_series_device(tmp_path / "r8", torch.from_numpy(ramp8).to(dev))
     assert np.array_equal(np.stack([np.asarray(Image.open(f)) for f in brickio.list_tiff_series(tmp_path / "r8")]), ramp8)
     assert np.array_equal(brickio.load_tiff_series(tmp_path / "r8"), ramp8)
+
+
+def test_device_writer_on_many_small_shapes(dev, tmp_path):
+    """Forty random volumes -- extents from one sample to a few hundred, 8 / 16-bit and float samples, contents from constant to noise,
+    ramps that pick the predictor -- through the device writer and back through libtiff and the library's reader."""
+    from PIL import Image
+    rng = np.random.default_rng(77)
+    for case in range(40):
+        nz, ny, nx = int(rng.integers(1, 4)), int(rng.integers(1, 200)), int(rng.integers(1, 300))
+        dt = (np.uint8, np.uint16, np.float32)[case % 3]
+        kind = case % 5
+        if kind == 0:
+            v = np.full((nz, ny, nx), 7, dt)
+        elif kind == 1:
+            v = (rng.random((nz, ny, nx)) * 250).astype(dt)
+        elif kind == 2:
+            v = (np.arange(nz * ny * nx).reshape(nz, ny, nx) % 251).astype(dt)
+        elif kind == 3:
+            v = (np.cumsum(rng.standard_normal((nz, ny, nx)), axis=2) * 3 + 120).clip(0, 255).astype(dt)
+        else:
+            v = (rng.random((nz, ny, nx)) > 0.97).astype(dt) * (200 if dt != np.float32 else 0.5)
+        v = np.ascontiguousarray(v.astype(dt))
+        d = tmp_path / f"c{case}"
+        assert brickio.save_tiff_series_device(d, torch.from_numpy(v).to(dev)) == nz
+        files = brickio.list_tiff_series(d)
+        back = np.stack([np.asarray(Image.open(f)).reshape(ny, nx) for f in files])
+        assert back.dtype == v.dtype and np.array_equal(back, v), (case, v.shape, dt)
+        assert np.array_equal(brickio.load_tiff_series(d), v), (case, v.shape, dt)
