@@ -79,36 +79,77 @@ def save_lz4(filename, array, chunk_size=CHUNK_SIZE, pool=None):
     h["dims"][:a.ndim] = a.shape[::-1]                                   # MATLAB order: fastest axis first
     h["total_uncompressed"], h["chunk_size"], h["num_chunks"] = total, chunk_size, n_chunks
     lib = _lib()
-    bound = lib.LZ4_compressBound(int(min(chunk_size, max(total, 1))))
 
-    def compress(i, dst):
+    # Every chunk is either deflated by liblz4, or -- when a 256-KB sample from its middle does not shrink by 3 % (float32 cores: LZ4
+    # finds nothing in mantissa noise), or the whole does not shrink -- left as it is: one literal run is a valid LZ4 block (token
+    # 0xF0, the length in bytes of 255, the bytes; LZ4_decompress_safe of both loaders reads it), 0.4 % longer than the samples.
+    probe_n = 256 << 10
+
+    def literal_header(n):
+        if n < 15:
+            return bytes([n << 4])
+        q, r = divmod(n - 15, 255)
+        return b"\xf0" + b"\xff" * q + bytes([r])
+
+    def prepare(i):
         src = raw[i * chunk_size:(i + 1) * chunk_size]
+        if src.size >= 4 * probe_n:
+            mid = (src.size // 2) & ~4095
+            tmp = np.empty(lib.LZ4_compressBound(probe_n), np.uint8)
+            k = lib.LZ4_compress_default(src[mid:].ctypes.data, tmp.ctypes.data, probe_n, int(tmp.size))
+            if k > 0.97 * probe_n:
+                return i, literal_header(int(src.size)), None
+        dst = np.empty(lib.LZ4_compressBound(int(src.size)), np.uint8)
         n = lib.LZ4_compress_default(src.ctypes.data, dst.ctypes.data, int(src.size), int(dst.size))
         if n <= 0:
             raise RuntimeError(f"save_lz4_mex:CompressionFailed: chunk {i}")
-        return int(src.size), n
+        if n >= src.size:                                     # (shrank in the sample, not as a whole)
+            return i, literal_header(int(src.size)), None
+        return i, None, dst[:n]
 
     with open(filename, "wb") as f:
         f.write(h.tobytes())
         if pool is None or n_chunks <= 1:
-            dst = np.empty(bound, np.uint8)
             for i in range(n_chunks):
-                usize, n = compress(i, dst)
-                f.write(memoryview(dst)[:n])
-                h["chunk_uncomp"][i], h["chunk_comp"][i] = usize, n
+                _, head, comp = prepare(i)
+                src = raw[i * chunk_size:(i + 1) * chunk_size]
+                if comp is None:
+                    f.write(head)
+                    f.write(memoryview(src))
+                else:
+                    f.write(memoryview(comp))
+                h["chunk_uncomp"][i], h["chunk_comp"][i] = int(src.size), (len(head) + int(src.size)) if comp is None else int(comp.size)
         else:
-            # a window of chunks in flight: compressed side by side, written in order
-            window = max(2, min(n_chunks, getattr(pool, "_max_workers", 4) + 1))
-            bufs = [np.empty(bound, np.uint8) for _ in range(window)]
-            futs = {}
-            nxt = 0
-            for i in range(n_chunks):
-                while nxt < n_chunks and nxt < i + window:
-                    futs[nxt] = pool.submit(compress, nxt, bufs[nxt % window])
-                    nxt += 1
-                usize, n = futs.pop(i).result()
-                f.write(memoryview(bufs[i % window])[:n])
-                h["chunk_uncomp"][i], h["chunk_comp"][i] = usize, n
+            # Chunks side by side, in two steps: (1) prepared on the pool; (2) the sizes are known, so every chunk has its place in the
+            # file: the pool writes them with pwrite, the unshrinkable ones straight from the caller's buffer.  (Before: chunks written
+            # one after the other by the calling thread -- 0.3 s per 860-MB core, which was what decwrap's writers did all day.)
+            f.flush()
+            fd = f.fileno()
+
+            def pwrite_all(buf, at):
+                mv = memoryview(buf).cast("B")
+                while len(mv):
+                    k = os.pwrite(fd, mv, at)
+                    mv, at = mv[k:], at + k
+
+            parts = [fu.result() for fu in [pool.submit(prepare, i) for i in range(n_chunks)]]
+            offs, at = [], HEADER_SIZE
+            for i, head, comp in parts:
+                usize = int(min(chunk_size, total - i * chunk_size))
+                csize = len(head) + usize if comp is None else int(comp.size)
+                h["chunk_uncomp"][i], h["chunk_comp"][i] = usize, csize
+                offs.append(at)
+                at += csize
+
+            def put(i, head, comp):
+                if comp is not None:
+                    pwrite_all(comp, offs[i])
+                else:
+                    pwrite_all(head, offs[i])
+                    pwrite_all(raw[i * chunk_size:(i + 1) * chunk_size], offs[i] + len(head))
+
+            for fu in [pool.submit(put, *part) for part in parts]:
+                fu.result()
         f.seek(0)
         f.write(h.tobytes())
 

@@ -140,6 +140,33 @@ def test_parallel_chunks_round_trip_and_out_buffer(tmp_path):
         brickio.load_lz4(tmp_path / "par.lz4", out=np.empty(16, np.uint8))
 
 
+def test_unshrinkable_chunks_are_stored_as_literal_runs(tmp_path):
+    """float32 cores are mantissa noise to LZ4: a chunk whose sample does not shrink is written as ONE literal run -- a valid LZ4 block
+    (token 0xF0, length bytes, the samples) that LZ4_decompress_safe, the call of both reference loaders (load_lz4_mex.c:150,
+    load_slab_lz4.cpp:118), reads back -- straight from the caller's buffer, the chunks of a brick side by side with pwrite."""
+    from concurrent.futures import ThreadPoolExecutor
+    rng = np.random.default_rng(9)
+    a = rng.random((3, 512, 600)).astype(np.float32)              # 3.7 MB of noise ...
+    a[1, :300] = 0.0                                               # ... with 0.6 MB of zeros in the second chunk
+    chunk = 1 << 20
+    with ThreadPoolExecutor(4) as pool:
+        brickio.save_lz4(tmp_path / "par.lz4", a, chunk_size=chunk, pool=pool)
+        brickio.save_lz4(tmp_path / "ser.lz4", a, chunk_size=chunk)
+        assert (tmp_path / "par.lz4").read_bytes() == (tmp_path / "ser.lz4").read_bytes()
+        with open(tmp_path / "par.lz4", "rb") as f:
+            h = brickio.read_header(f)
+        n = int(h["num_chunks"])
+        usz, csz = [int(v) for v in h["chunk_uncomp"][:n]], [int(v) for v in h["chunk_comp"][:n]]
+        assert n == 4 and sum(usz) == a.nbytes
+        head = 1 + (chunk - 15) // 255 + 1
+        assert csz[0] == chunk + head and csz[2] == chunk + head          # literal runs
+        assert csz[1] < 0.6 * chunk                                        # the chunk with the zeros went through LZ4
+        raw = (tmp_path / "par.lz4").read_bytes()
+        at = brickio.HEADER_SIZE
+        assert raw[at] == 0xF0 and raw[at + 1] == 0xFF and raw[at + head:at + head + 64] == a.tobytes()[:64]
+        assert np.array_equal(brickio.load_lz4(tmp_path / "par.lz4", pool=pool), a) and np.array_equal(brickio.load_lz4(tmp_path / "ser.lz4"), a)
+
+
 # ------------------------------------------------------------------------------------------------ the library's TIFF reader / writer
 # (include/mi_tiffio.h, csrc/tiffio.hip: host code -- strips of raw or deflate samples, one slice per task on all cores; the checker
 #  is Pillow's libtiff, which reads what the library writes and writes what the library reads)
