@@ -133,6 +133,24 @@ class LazyTiffVolume:
         info = brickio.tiff_info(self.files[0])
         self._fast = bool(info is not None and info[2] and info[0] == first.shape[1:] and info[1] == first.dtype)
         self._bulk = threading.Lock()
+        # ... and ahead of the workers: a thread walks through the folder in z order for as long as the cache has room (it never pushes a
+        # slice out), so that inflating the input -- 4 GB/s on 16 CPUs, as long as the deconvolution itself -- runs beside the blocks
+        # instead of in front of every z slab of them (17-GB stack: blocks phase 5.3 -> 5.1 s: inflating IS the blocks phase of such a
+        # run, 3.4 GB/s); MI_DECWRAP_TIFF_PREFETCH=0: on demand only
+        if self._fast and os.environ.get("MI_DECWRAP_TIFF_PREFETCH", "1") != "0":
+            threading.Thread(target=self._prefetch, daemon=True).start()
+
+    def _prefetch(self):
+        z = 0
+        while z < len(self.files) and self._fast:
+            with self._lock:
+                room = len(self._cache) + 16 <= self._budget
+            if not room:
+                return
+            part = list(range(z, min(z + 16, len(self.files))))
+            if self._chunk(part) is None:
+                return
+            z += len(part)
 
     def _slice(self, z):
         with self._lock:
