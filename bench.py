@@ -268,7 +268,7 @@ def c4_single(dev, steps=3):
     return out
 
 
-def decwrap_e2e(shape=(1024, 2048, 2048)):
+def decwrap_e2e(shape=(1024, 2048, 2048), tiff=False):
     """The application around the hot path, end to end: decwrap.py (the reference's command line, decwrap.py:294-305 defaults: 6
     iterations, Gaussian pre-filter 13 x 13 x 25, regularisation every 3rd iteration, deconFFT flavour) on a synthetic uint16 volume
     in a memory-mapped *.npy under /tmp -- block grid, box reads, uploads, per-block deconvolution, percentiles, bricks behind the
@@ -279,20 +279,30 @@ def decwrap_e2e(shape=(1024, 2048, 2048)):
     from ipp_amd import decwrap
     root = tempfile.mkdtemp(prefix="bench_decwrap_", dir="/tmp")
     try:
-        vol = np.lib.format.open_memmap(os.path.join(root, "vol.npy"), mode="w+", dtype=np.uint16, shape=shape)
         rng = np.random.default_rng(1)
-        for z in range(shape[0]):                      # sparse beads on a noisy background, slice by slice
-            sl = rng.integers(600, 700, size=shape[1:], dtype=np.uint16)
+
+        def scene(n):                                  # sparse beads on a noisy background
+            sl = rng.integers(600, 700, size=(n,) + tuple(shape[1:]), dtype=np.uint16)
             idx = rng.integers(0, sl.size, size=sl.size // 2000)
             sl.reshape(-1)[idx] = rng.integers(5000, 60000, size=idx.size, dtype=np.uint16)
-            vol[z] = sl
-        vol.flush()
-        del vol
+            return sl
+        if tiff:                                       # the reference's own input form: a folder of 2-D TIFF slices (deflate)
+            from ipp_amd import brickio
+            src = os.path.join(root, "stack")
+            for z0 in range(0, shape[0], 64):
+                brickio.save_tiff_series(src, scene(min(64, shape[0] - z0)), first_index=z0 + 1)
+        else:
+            src = os.path.join(root, "vol.npy")
+            vol = np.lib.format.open_memmap(src, mode="w+", dtype=np.uint16, shape=shape)
+            for z in range(shape[0]):
+                vol[z] = scene(1)[0]
+            vol.flush()
+            del vol
         keep = os.environ.get("MI_DECWRAP_NPY")
         os.environ["MI_DECWRAP_NPY"] = "0"             # (no whole-volume *.npy copies of the result: the streaming pipeline is what is timed)
         try:
             t0 = time.perf_counter()
-            rc = decwrap.main(["-i", os.path.join(root, "vol.npy"), "-dxy", "0.422", "-dz", "1.0", "-ex", "488", "-em", "525", "--use-fft",
+            rc = decwrap.main(["-i", src, "-dxy", "0.422", "-dz", "1.0", "-ex", "488", "-em", "525", "--use-fft",
                                "-it", "6", "--block-size-max", "300000000", "--gpu-indices", "1", "--gpu-workers-per-gpu", "5"])
             dt = time.perf_counter() - t0
         finally:
@@ -306,8 +316,9 @@ def decwrap_e2e(shape=(1024, 2048, 2048)):
                 "blocks": tm.get("blocks"), "blocks_phase_s": round(tm.get("blocks_wall_s", 0.0), 3),
                 "assembly_phase_s": round(tm.get("assembly_wall_s", 0.0), 3), "bricks_written_behind_the_workers": tm.get("bricks_trailed"),
                 "bricks_not_begun": tm.get("bricks_not_written"),
-                "config": f"decwrap.py on a {shape[2]}x{shape[1]}x{shape[0]} uint16 volume ({n * 2 / 1e9:.1f} GB, memory-mapped .npy), --use-fft, 6 iterations, "
-                          "default filters, --block-size-max 3e8, 5 workers on one GPU, MI_DECWRAP_BRICKS=trail (default)"}
+                "config": f"decwrap.py on a {shape[2]}x{shape[1]}x{shape[0]} uint16 volume ({n * 2 / 1e9:.1f} GB, " +
+                          ("a folder of deflate TIFF slices in, deflate TIFF slices out (deflated on the device)" if tiff else "memory-mapped .npy") +
+                          "), --use-fft, 6 iterations, default filters, --block-size-max 3e8, 5 workers on one GPU, MI_DECWRAP_BRICKS=trail (default)"}
     finally:
         shutil.rmtree(root, ignore_errors=True)
 
@@ -543,6 +554,10 @@ def main():
                     out["decwrap"] = decwrap_e2e()
                 except Exception as e:
                     out["decwrap"] = {"error": repr(e)}
+                try:
+                    out["decwrap_tiff"] = decwrap_e2e(shape=(512, 2048, 2048), tiff=True)
+                except Exception as e:
+                    out["decwrap_tiff"] = {"error": repr(e)}
                 torch.cuda.empty_cache()
                 capi.release_cached_memory()
         if not args.no_cpu_baseline and world == 1:
