@@ -1003,7 +1003,11 @@ def main(argv=None):
             with torch.cuda.device(dev):
                 if args.flip:
                     d_slab = d_slab.flip(1).contiguous()                                   # R = flip(R, 2): the y axis (LsDeconv.m:1097-1099)
-                n_tif += brickio.save_tiff_series_device(out_dir, d_slab, first_index=z1)  # img_%06d.tif, existing slices kept
+                try:
+                    n_tif += brickio.save_tiff_series_device(out_dir, d_slab, first_index=z1)   # img_%06d.tif, existing slices kept
+                except Exception as e:             # (no pinned memory left, say: the slab is complete -- its slices through the host)
+                    log.warning(f"slices {z1}..{z2} could not be deflated on the device ({e}); writing them from the host")
+                    n_tif += brickio.save_tiff_series(out_dir, d_slab.cpu().numpy(), first_index=z1)
             del d_slab
             continue
         if args.flip:
