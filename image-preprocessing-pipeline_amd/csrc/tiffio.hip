@@ -263,7 +263,10 @@ std::string read_slice(const char* path, int nx, int ny, int dtype, int y0, int 
     if (!ti.fast()) return std::string(path) + ": not a file this reader decodes (strips of raw or deflate samples, one sample per pixel)";
     if ((int)ti.nx != nx || (int)ti.ny != ny || ti.dtype() != dtype) return std::string(path) + ": slice shape / type differs from the first slice";
     const size_t bps = (size_t)(dtype == 4 ? 4 : dtype), rowb = (size_t)nx * bps, outb = (size_t)(x1 - x0) * bps;
+    struct stat st;
+    if (fstat(f.fd, &st) != 0) return std::string(path) + ": " + std::strerror(errno);
     for (uint32_t s = (uint32_t)y0 / ti.rps; s <= (uint32_t)(y1 - 1) / ti.rps; ++s) {
+        if (ti.off[s] > (uint64_t)st.st_size || ti.cnt[s] > (uint64_t)st.st_size - ti.off[s]) return std::string(path) + ": a strip lies outside the file";
         const uint32_t r0 = s * ti.rps, r1 = std::min<uint32_t>(ti.ny, r0 + ti.rps);
         const size_t want = (size_t)(r1 - r0) * rowb;
         const unsigned char* rows = nullptr;
