@@ -140,9 +140,15 @@ class LazyTiffVolume:
         if self._fast and os.environ.get("MI_DECWRAP_TIFF_PREFETCH", "1") != "0":
             threading.Thread(target=self._prefetch, daemon=True).start()
 
+    def close(self):
+        """ends the read-ahead and drops the cached slices"""
+        self._closed = True
+        with self._lock:
+            self._cache.clear()
+
     def _prefetch(self):
         z = 0
-        while z < len(self.files) and self._fast:
+        while z < len(self.files) and self._fast and not getattr(self, "_closed", False):
             with self._lock:
                 room = len(self._cache) + 16 <= self._budget
             if not room:
@@ -1041,6 +1047,8 @@ def main(argv=None):
                              start_new_session=True)
     except OSError:
         shutil.rmtree(cache, ignore_errors=True)
+    if hasattr(vol, "close"):
+        vol.close()
     main.last_timing["cleanup_s"] = time.perf_counter() - t_clean0
     main.last_timing["main_s"] = time.perf_counter() - t_main0
     log.info(f"wrote {out_dir} (scale {scal:g}, clip [{lo:.4g}, {hi:.4g}])")
