@@ -247,3 +247,44 @@ def test_pillow_route_still_works(tmp_path, monkeypatch):
     assert brickio.tiff_info(tmp_path / "x.tif") is None
     assert brickio.save_tiff_series(tmp_path / "p", vol) == 2
     assert np.array_equal(brickio.load_tiff_series(tmp_path / "p"), vol)
+
+
+def test_native_tiff_reader_survives_corrupted_files(tmp_path):
+    """Five hundred corruptions of a valid deflate TIFF -- random bytes anywhere, half of them in the directory, some files cut short --
+    are each either refused or decoded (the byte hit padding); run in a process of its own, which must end normally."""
+    import os
+    import sys
+    code = r'''
+import sys, os
+import numpy as np
+sys.path.insert(0, %r)
+from ipp_amd import brickio, capi
+rng = np.random.default_rng(5)
+d = %r
+vol = (rng.random((1, 120, 160)) * 60000).astype(np.uint16)
+brickio.save_tiff_series(d, vol)
+path = os.path.join(d, "img_000001.tif")
+good = open(path, "rb").read()
+decoded = refused = 0
+for it in range(500):
+    b = bytearray(good)
+    for _ in range(int(rng.integers(1, 6))):
+        pos = int(rng.integers(0, len(b))) if rng.random() < 0.5 else int(rng.integers(max(0, len(b) - 300), len(b)))
+        b[pos] = int(rng.integers(0, 256))
+    if rng.random() < 0.1:
+        b = b[:int(rng.integers(0, len(b)))]
+    open(path, "wb").write(bytes(b))
+    try:
+        info = brickio.tiff_info(path)
+        if info is not None and info[2] and info[0] == (120, 160) and info[1] == np.uint16:
+            brickio.read_tiff_box([path], (120, 160), np.uint16, 0, 120, 0, 160)
+            decoded += 1
+        else:
+            refused += 1
+    except capi.MiError:
+        refused += 1
+assert decoded + refused == 500 and refused > 300, (decoded, refused)
+print("ok", decoded, refused)
+''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(tmp_path / "f"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.startswith("ok"), (r.returncode, r.stdout[-300:], r.stderr[-600:])
